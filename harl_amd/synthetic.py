@@ -1,0 +1,135 @@
+"""Deterministic synthetic rollout data and parameters (SURVEY.md §8d recipe).
+
+Pure NumPy; shared by ``bench.py``, the tests and ``oracle/gen_golden.py`` so the
+reference, the oracle and the HIP path all see byte-identical inputs.  Nothing in
+here is part of the compute path.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+
+@dataclass
+class Shapes:
+    T: int                 # episode_length
+    N: int                 # n_rollout_threads
+    A: int                 # num_agents
+    obs_dim: int
+    share_obs_dim: int
+    act_dim: int           # Box: dimension; Discrete: number of actions
+    discrete: bool = False
+    hidden_sizes: Sequence[int] = (128, 128)
+
+    @property
+    def act_shape(self) -> int:  # width of the stored `actions` / `action_log_probs`
+        return 1 if self.discrete else self.act_dim
+
+
+def actor_param_shapes(sh: Shapes, use_feature_normalization: bool = True) -> List[Tuple[str, Tuple[int, ...]]]:
+    """Parameter names/shapes in the reference's ``StochasticPolicy.parameters()`` order
+    (harl/models/policy_models/stochastic_policy.py:11-54; probe in SURVEY.md §8a M1)."""
+    out: List[Tuple[str, Tuple[int, ...]]] = []
+    if use_feature_normalization:
+        out += [("base.feature_norm.weight", (sh.obs_dim,)), ("base.feature_norm.bias", (sh.obs_dim,))]
+    d = sh.obs_dim
+    for i, h in enumerate(sh.hidden_sizes):
+        out += [(f"base.mlp.fc.{3*i}.weight", (h, d)), (f"base.mlp.fc.{3*i}.bias", (h,)),
+                (f"base.mlp.fc.{3*i+2}.weight", (h,)), (f"base.mlp.fc.{3*i+2}.bias", (h,))]
+        d = h
+    if sh.discrete:
+        out += [("act.action_out.linear.weight", (sh.act_dim, d)), ("act.action_out.linear.bias", (sh.act_dim,))]
+    else:
+        out += [("act.action_out.log_std", (sh.act_dim,)),
+                ("act.action_out.fc_mean.weight", (sh.act_dim, d)), ("act.action_out.fc_mean.bias", (sh.act_dim,))]
+    return out
+
+
+def critic_param_shapes(sh: Shapes, use_feature_normalization: bool = True) -> List[Tuple[str, Tuple[int, ...]]]:
+    """``VNet.parameters()`` order (harl/models/value_function_models/v_net.py:10-46)."""
+    out: List[Tuple[str, Tuple[int, ...]]] = []
+    if use_feature_normalization:
+        out += [("base.feature_norm.weight", (sh.share_obs_dim,)), ("base.feature_norm.bias", (sh.share_obs_dim,))]
+    d = sh.share_obs_dim
+    for i, h in enumerate(sh.hidden_sizes):
+        out += [(f"base.mlp.fc.{3*i}.weight", (h, d)), (f"base.mlp.fc.{3*i}.bias", (h,)),
+                (f"base.mlp.fc.{3*i+2}.weight", (h,)), (f"base.mlp.fc.{3*i+2}.bias", (h,))]
+        d = h
+    out += [("v_out.weight", (1, d)), ("v_out.bias", (1,))]
+    return out
+
+
+def synthetic_state_dict(shapes: List[Tuple[str, Tuple[int, ...]]], seed: int, std_x_coef: float = 1.0) -> Dict[str, np.ndarray]:
+    """Seed-reproducible, deliberately *non-trivial* parameters: LayerNorm affine terms and
+    biases are perturbed so that every gradient path (incl. LN weight/bias, log_std) is exercised."""
+    rng = np.random.default_rng(seed)
+    sd: Dict[str, np.ndarray] = {}
+    for name, shp in shapes:
+        if name.endswith("log_std"):
+            v = std_x_coef + 0.1 * rng.standard_normal(shp)
+        elif len(shp) == 2:  # Linear weight [out, in]
+            scale = (0.3 if ("action_out" in name or name.startswith("v_out")) else 1.4) / np.sqrt(shp[1])
+            v = scale * rng.standard_normal(shp)
+        elif "feature_norm.weight" in name or (name.startswith("base.mlp.fc.") and int(name.split(".")[3]) % 3 == 2 and name.endswith("weight")):
+            v = 1.0 + 0.1 * rng.standard_normal(shp)
+        else:  # biases (Linear and LayerNorm)
+            v = 0.1 * rng.standard_normal(shp)
+        sd[name] = v.astype(np.float32)
+    return sd
+
+
+@dataclass
+class SyntheticBuffers:
+    """Host arrays in the reference buffer shapes (actor_buffer.py:31-76, critic_buffer_ep.py:27-71)."""
+    obs: List[np.ndarray]               # A x [T+1, N, D_o]
+    actions: List[np.ndarray]           # A x [T, N, act_shape]
+    action_log_probs: List[np.ndarray]  # A x [T, N, act_shape]
+    masks: List[np.ndarray]             # A x [T+1, N, 1]
+    active_masks: List[np.ndarray]      # A x [T+1, N, 1]
+    available_actions: List[Optional[np.ndarray]]  # A x ([T+1, N, n_act] | None)
+    share_obs: np.ndarray               # [T+1, N, D_s]
+    rewards: np.ndarray                 # [T, N, 1]
+    value_preds: np.ndarray             # [T+1, N, 1]
+    critic_masks: np.ndarray            # [T+1, N, 1]
+    bad_masks: np.ndarray               # [T+1, N, 1]
+
+
+def make_buffers(sh: Shapes, seed: int, inactive_p: float = 0.0, unavailable_p: float = 0.0) -> SyntheticBuffers:
+    """obs/share_obs/rewards/value_preds ~ N(0,1); Box actions ~ N(0,1) with stored
+    log-probs -1+0.1 N(0,1); Discrete actions ~ U{0..n-1} stored as fp32 with log-probs
+    log(1/n)+0.05 N(0,1); masks 0 w.p. 0.04 with bad_masks 0 at the same places; critic masks =
+    agent-0 masks.  ``inactive_p`` / ``unavailable_p`` > 0 add dead agents / masked actions for the
+    edge-case tests (the taken action always stays available)."""
+    rng = np.random.default_rng(seed)
+    T, N, A = sh.T, sh.N, sh.A
+    f32 = np.float32
+    obs, actions, logp, masks, active, avail = [], [], [], [], [], []
+    base_mask = (rng.random((T + 1, N, 1)) >= 0.04).astype(f32)
+    for _ in range(A):
+        obs.append(rng.standard_normal((T + 1, N, sh.obs_dim)).astype(f32))
+        if sh.discrete:
+            a = rng.integers(0, sh.act_dim, size=(T, N, 1))
+            actions.append(a.astype(f32))
+            logp.append((np.log(1.0 / sh.act_dim) + 0.05 * rng.standard_normal((T, N, 1))).astype(f32))
+            av = np.ones((T + 1, N, sh.act_dim), dtype=f32)
+            if unavailable_p > 0:
+                av = (rng.random((T + 1, N, sh.act_dim)) >= unavailable_p).astype(f32)
+                np.put_along_axis(av[:-1], a, 1.0, axis=-1)
+            avail.append(av)
+        else:
+            actions.append(rng.standard_normal((T, N, sh.act_dim)).astype(f32))
+            logp.append((-1.0 + 0.1 * rng.standard_normal((T, N, sh.act_dim))).astype(f32))
+            avail.append(None)
+        masks.append(base_mask.copy())
+        am = np.ones((T + 1, N, 1), dtype=f32)
+        if inactive_p > 0:
+            am = (rng.random((T + 1, N, 1)) >= inactive_p).astype(f32)
+        active.append(am)
+    share_obs = rng.standard_normal((T + 1, N, sh.share_obs_dim)).astype(f32)
+    rewards = rng.standard_normal((T, N, 1)).astype(f32)
+    value_preds = rng.standard_normal((T + 1, N, 1)).astype(f32)
+    bad = np.where(base_mask == 0.0, 0.0, 1.0).astype(f32)
+    return SyntheticBuffers(obs, actions, logp, masks, active, avail, share_obs, rewards, value_preds,
+                            base_mask.copy(), bad)

@@ -1,0 +1,304 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by running the REAL reference (imported from /root/reference).
+
+Run in the build container only (the GPU box has no /root/reference):
+
+    python oracle/gen_golden.py            # writes tests/golden/*.npz
+
+The reference is imported unmodified; two absent third-party modules it imports at
+module scope (``absl.flags`` via harl/envs/__init__.py:1, ``setproctitle`` via
+harl/runners/on_policy_base_runner.py:6) are stubbed, action/observation spaces are
+duck-typed (the reference dispatches on ``__class__.__name__`` only,
+harl/utils/envs_tools.py:22-46), and ``OnPolicyHARunner`` is built with ``__new__`` so no
+environment is created.  Inputs come from ``harl_amd.synthetic``
+(seeded), so the fixtures store outputs only.
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.environ.get("HARL_REFERENCE", "/root/reference")
+sys.path.insert(0, REPO)
+sys.path.insert(0, REF)
+
+absl = types.ModuleType("absl")
+flags = types.ModuleType("absl.flags")
+flags.FLAGS = lambda argv: argv
+absl.flags = flags
+sys.modules["absl"], sys.modules["absl.flags"] = absl, flags
+sp = types.ModuleType("setproctitle")
+sp.setproctitle = lambda s: None
+sys.modules["setproctitle"] = sp
+
+import yaml  # noqa: E402
+from harl.algorithms.actors import ALGO_REGISTRY  # noqa: E402
+from harl.algorithms.critics.v_critic import VCritic  # noqa: E402
+from harl.common.buffers.on_policy_actor_buffer import OnPolicyActorBuffer  # noqa: E402
+from harl.common.buffers.on_policy_critic_buffer_ep import OnPolicyCriticBufferEP  # noqa: E402
+from harl.common.valuenorm import ValueNorm  # noqa: E402
+from harl.runners.on_policy_ha_runner import OnPolicyHARunner  # noqa: E402
+
+from harl_amd.synthetic import (  # noqa: E402
+    Shapes, actor_param_shapes, critic_param_shapes, make_buffers, synthetic_state_dict,
+)
+
+
+class Box:  # duck-typed gym.spaces.Box
+    def __init__(self, shape):
+        self.shape = shape
+
+
+class Discrete:  # duck-typed gym.spaces.Discrete
+    def __init__(self, n):
+        self.n = n
+        self.shape = ()
+
+
+# ----------------------------------------------------------------------------------
+# golden cases: small enough for fixtures of a few hundred KB, wide enough to cover
+# Box / Discrete, prod / mean aggregation, 1 / 2 mini-batches, dead agents, masked
+# actions, random / fixed agent order, ValueNorm on / off, Huber / MSE.
+# ----------------------------------------------------------------------------------
+CASES = {
+    "mpe_box_h64": dict(shapes=dict(T=12, N=8, A=3, obs_dim=18, share_obs_dim=54, act_dim=5, discrete=False,
+                                    hidden_sizes=[64, 64]), seed=1, overrides={}),
+    "mpe_box_h128": dict(shapes=dict(T=10, N=16, A=3, obs_dim=18, share_obs_dim=54, act_dim=5, discrete=False,
+                                     hidden_sizes=[128, 128]), seed=7, overrides={}),
+    "mpe_disc_h64": dict(shapes=dict(T=12, N=8, A=3, obs_dim=18, share_obs_dim=54, act_dim=5, discrete=True,
+                                     hidden_sizes=[64, 64]), seed=2, overrides={}, unavailable_p=0.2),
+    "cheetah_h128x3_mb2": dict(shapes=dict(T=8, N=12, A=6, obs_dim=23, share_obs_dim=17, act_dim=1, discrete=False,
+                                           hidden_sizes=[128, 128, 128]), seed=3,
+                               overrides=dict(actor_num_mini_batch=2, critic_num_mini_batch=2, fixed_order=True)),
+    "box_mean_inactive_novn": dict(shapes=dict(T=9, N=8, A=2, obs_dim=10, share_obs_dim=20, act_dim=3, discrete=False,
+                                               hidden_sizes=[64, 64]), seed=4, inactive_p=0.3,
+                                   overrides=dict(action_aggregation="mean", use_valuenorm=False,
+                                                  use_huber_loss=False, ppo_epoch=3, critic_epoch=2)),
+    "wide_obs_h64": dict(shapes=dict(T=6, N=8, A=2, obs_dim=77, share_obs_dim=70, act_dim=2, discrete=False,
+                                     hidden_sizes=[64]), seed=5, onpolicy=False,
+                         overrides=dict(use_max_grad_norm=False, use_policy_active_masks=False,
+                                        use_clipped_value_loss=False, use_feature_normalization=False,
+                                        ppo_epoch=2, critic_epoch=2)),
+}
+
+
+def load_cfg(sh: Shapes, overrides: dict) -> dict:
+    cfg = yaml.safe_load(open(os.path.join(REF, "harl/configs/algos_cfgs/happo.yaml")))
+    cfg["train"].update(n_rollout_threads=sh.N, episode_length=sh.T)
+    cfg["model"]["hidden_sizes"] = list(sh.hidden_sizes)
+    for k, v in overrides.items():
+        for sec in ("train", "model", "algo"):
+            if k in cfg[sec]:
+                cfg[sec][k] = v
+    return cfg
+
+
+def run_case(name: str, spec: dict) -> dict:
+    sh = Shapes(**spec["shapes"])
+    seed = spec["seed"]
+    cfg = load_cfg(sh, spec.get("overrides", {}))
+    use_fn = cfg["model"]["use_feature_normalization"]
+    torch.set_num_threads(1)
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    dev = torch.device("cpu")
+    act_space = Discrete(sh.act_dim) if sh.discrete else Box((sh.act_dim,))
+    margs = {**cfg["model"], **cfg["algo"]}
+    actors = [ALGO_REGISTRY["happo"](margs, Box((sh.obs_dim,)), act_space, dev) for _ in range(sh.A)]
+    critic = VCritic(margs, Box((sh.share_obs_dim,)), dev)
+    for a, actor in enumerate(actors):
+        sd = synthetic_state_dict(actor_param_shapes(sh, use_fn), 1000 * seed + a, cfg["model"]["std_x_coef"])
+        assert list(sd.keys()) == list(actor.actor.state_dict().keys()), (list(sd.keys()), list(actor.actor.state_dict().keys()))
+        actor.actor.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    csd = synthetic_state_dict(critic_param_shapes(sh, use_fn), 1000 * seed + 999)
+    assert list(csd.keys()) == list(critic.critic.state_dict().keys())
+    critic.critic.load_state_dict({k: torch.from_numpy(v) for k, v in csd.items()})
+
+    data = make_buffers(sh, seed, spec.get("inactive_p", 0.0), spec.get("unavailable_p", 0.0))
+    abuf = [OnPolicyActorBuffer({**cfg["train"], **cfg["model"]}, Box((sh.obs_dim,)), act_space) for _ in range(sh.A)]
+    cbuf = OnPolicyCriticBufferEP({**cfg["train"], **cfg["model"], **cfg["algo"]}, Box((sh.share_obs_dim,)))
+    for a in range(sh.A):
+        abuf[a].obs[:] = data.obs[a]
+        abuf[a].actions[:] = data.actions[a]
+        abuf[a].action_log_probs[:] = data.action_log_probs[a]
+        abuf[a].masks[:] = data.masks[a]
+        abuf[a].active_masks[:] = data.active_masks[a]
+        if sh.discrete:
+            abuf[a].available_actions[:] = data.available_actions[a]
+    cbuf.share_obs[:] = data.share_obs
+    cbuf.rewards[:] = data.rewards
+    cbuf.value_preds[:] = data.value_preds
+    cbuf.masks[:] = data.critic_masks
+    cbuf.bad_masks[:] = data.bad_masks
+    onpolicy_inputs = {}
+    if spec.get("onpolicy", True):
+        # Policy-consistent actions / stored log-probs (importance ratios ~ 1, the regime PPO runs in):
+        # a ~ pi_theta(.|obs), stored logp = log pi_theta(a|obs) + 0.05 N(0,1).  They depend on a forward
+        # pass of the reference actor, so they are stored in the fixture as *inputs*.
+        for a in range(sh.A):
+            rng = np.random.default_rng(77000 + 100 * seed + a)
+            with torch.no_grad():
+                obs_flat = torch.from_numpy(abuf[a].obs[:-1].reshape(sh.T * sh.N, -1))
+                feat = actors[a].actor.base(obs_flat)
+                if sh.discrete:
+                    av = torch.from_numpy(abuf[a].available_actions[:-1].reshape(sh.T * sh.N, -1).copy())
+                    dist = actors[a].actor.act.action_out(feat, av)
+                    probs = dist.probs.numpy().astype(np.float64)
+                    probs /= probs.sum(-1, keepdims=True)
+                    acts = np.array([rng.choice(sh.act_dim, p=pr) for pr in probs], dtype=np.float32)[:, None]
+                else:
+                    dist = actors[a].actor.act.action_out(feat)
+                    acts = (dist.mean.numpy() + dist.stddev.numpy() * rng.standard_normal(dist.mean.shape)).astype(np.float32)
+                logp = dist.log_probs(torch.from_numpy(acts)).numpy()
+            logp = (logp + 0.05 * rng.standard_normal(logp.shape)).astype(np.float32)
+            abuf[a].actions[:] = acts.reshape(abuf[a].actions.shape)
+            abuf[a].action_log_probs[:] = logp.reshape(abuf[a].action_log_probs.shape)
+            onpolicy_inputs[f"in_actions_{a}"] = abuf[a].actions.copy()
+            onpolicy_inputs[f"in_logp_{a}"] = abuf[a].action_log_probs.copy()
+    vn = ValueNorm(1, device=dev) if cfg["train"]["use_valuenorm"] else None
+    if vn is not None:
+        # non-trivial running statistics so denormalize() is not the identity clamp
+        vn.running_mean.fill_(0.3 * 0.5)
+        vn.running_mean_sq.fill_(1.7 * 0.5)
+        vn.debiasing_term.fill_(0.5)
+
+    r = OnPolicyHARunner.__new__(OnPolicyHARunner)
+    r.algo_args, r.value_normalizer, r.critic_buffer, r.actor_buffer = cfg, vn, cbuf, abuf
+    r.actor, r.critic, r.num_agents, r.state_type = actors, critic, sh.A, "EP"
+    r.fixed_order = cfg["algo"]["fixed_order"]
+    r.action_aggregation, r.device = cfg["algo"]["action_aggregation"], dev
+
+    # ---- instrument: record per-update scalars, minibatch indices and the factor each agent saw
+    trace = {"actor": [], "critic": [], "perms": [], "factors": []}
+    real_randperm = torch.randperm
+
+    def rec_randperm(n, *a, **k):
+        p = real_randperm(n, *a, **k)
+        trace["perms"].append(p.numpy().copy())
+        return p
+
+    torch.randperm = rec_randperm
+    for a, actor in enumerate(actors):
+        orig = actor.update
+
+        def upd(sample, _orig=orig, _a=a, _actor=actor):
+            # capture the pre-clip flat gradient of the very first update only (fixture size)
+            out = _orig(sample)
+            trace["actor"].append(dict(agent=_a, policy_loss=float(out[0]), dist_entropy=float(out[1]),
+                                       grad_norm=float(out[2]), ratio=float(out[3].mean())))
+            return out
+
+        actor.update = upd
+        orig_uf = abuf[a].update_factor
+
+        def uf(f, _orig=orig_uf):
+            trace["factors"].append(f.copy())
+            return _orig(f)
+
+        abuf[a].update_factor = uf
+    corig = critic.update
+
+    def cupd(sample, value_normalizer=None):
+        out = corig(sample, value_normalizer=value_normalizer)
+        trace["critic"].append(dict(value_loss=float(out[0]), grad_norm=float(out[1])))
+        return out
+
+    critic.update = cupd
+
+    # model construction consumed the CPU generator; pin the state train() starts from
+    torch.manual_seed(seed + 12345)
+    next_value = cbuf.value_preds[-1].copy()
+    cbuf.compute_returns(next_value, vn)
+    returns = cbuf.returns.copy()
+    if vn is not None:
+        adv = returns[:-1] - vn.denormalize(cbuf.value_preds[:-1])
+    else:
+        adv = returns[:-1] - cbuf.value_preds[:-1]
+    r.prep_training()
+    infos, cinfo = r.train()
+    torch.randperm = real_randperm
+
+    def flat(mod):
+        return torch.cat([p.detach().reshape(-1) for p in mod.parameters()]).numpy()
+
+    out = dict(
+        returns=returns.astype(np.float32),
+        advantages=adv.astype(np.float32),
+        n_perms=np.int64(len(trace["perms"])),
+        factors=np.stack(trace["factors"]).astype(np.float32),
+        actor_trace=np.array([[t["agent"], t["policy_loss"], t["dist_entropy"], t["grad_norm"], t["ratio"]]
+                              for t in trace["actor"]], dtype=np.float64),
+        critic_trace=np.array([[t["value_loss"], t["grad_norm"]] for t in trace["critic"]], dtype=np.float64),
+        actor_infos=np.array([[float(i["policy_loss"]), float(i["dist_entropy"]), float(i["actor_grad_norm"]),
+                               float(i["ratio"])] for i in infos], dtype=np.float64),
+        critic_info=np.array([float(cinfo["value_loss"]), float(cinfo["critic_grad_norm"])], dtype=np.float64),
+        critic_final=flat(critic.critic).astype(np.float32),
+        meta=np.frombuffer(json.dumps(dict(
+            name=name, spec=spec, torch=torch.__version__, numpy=np.__version__, threads=torch.get_num_threads(),
+            algo=cfg["algo"], model=cfg["model"], train={k: cfg["train"][k] for k in
+                                                         ("use_valuenorm", "use_proper_time_limits", "episode_length",
+                                                          "n_rollout_threads")},
+        )).encode(), dtype=np.uint8),
+    )
+    out.update(onpolicy_inputs)
+    for i, p in enumerate(trace["perms"]):
+        out[f"perm_{i}"] = p.astype(np.int64)
+    for a, actor in enumerate(actors):
+        out[f"actor_final_{a}"] = flat(actor.actor).astype(np.float32)
+    if vn is not None:
+        out["vn_final"] = np.array([vn.running_mean.item(), vn.running_mean_sq.item(), vn.debiasing_term.item()],
+                                   dtype=np.float32)
+    return out
+
+
+def gae_branch_cases() -> dict:
+    """All 8 compute_returns branches of on_policy_critic_buffer_ep.py:97-200 on one seeded buffer."""
+    sh = Shapes(T=16, N=6, A=1, obs_dim=4, share_obs_dim=4, act_dim=1)
+    data = make_buffers(sh, 11)
+    out = {}
+    for use_gae in (True, False):
+        for ptl in (True, False):
+            for use_vn in (True, False):
+                cfg = load_cfg(sh, {})
+                cfg["algo"]["use_gae"] = use_gae
+                cfg["train"]["use_proper_time_limits"] = ptl
+                cbuf = OnPolicyCriticBufferEP({**cfg["train"], **cfg["model"], **cfg["algo"]}, Box((4,)))
+                cbuf.rewards[:] = data.rewards
+                cbuf.value_preds[:] = data.value_preds
+                cbuf.masks[:] = data.critic_masks
+                cbuf.bad_masks[:] = data.bad_masks
+                vn = None
+                if use_vn:
+                    vn = ValueNorm(1, device=torch.device("cpu"))
+                    vn.running_mean.fill_(-0.2 * 0.25)
+                    vn.running_mean_sq.fill_(2.3 * 0.25)
+                    vn.debiasing_term.fill_(0.25)
+                cbuf.compute_returns(data.value_preds[-1].copy() * 0.5, vn)
+                out[f"gae{int(use_gae)}_ptl{int(ptl)}_vn{int(use_vn)}"] = cbuf.returns.astype(np.float32).copy()
+    return out
+
+
+def main():
+    gdir = os.path.join(REPO, "tests", "golden")
+    os.makedirs(gdir, exist_ok=True)
+    only = sys.argv[1:]
+    for name, spec in CASES.items():
+        if only and name not in only:
+            continue
+        out = run_case(name, spec)
+        path = os.path.join(gdir, f"{name}.npz")
+        np.savez_compressed(path, **out)
+        print(f"{name}: {os.path.getsize(path)/1024:.0f} KiB  actor_infos={out['actor_infos'][:, 0]}  critic={out['critic_info']}")
+    if not only or "gae_branches" in only:
+        np.savez_compressed(os.path.join(gdir, "gae_branches.npz"), **gae_branch_cases())
+        print("gae_branches written")
+
+
+if __name__ == "__main__":
+    main()

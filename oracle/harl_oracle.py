@@ -1,0 +1,515 @@
+"""CPU oracle for HARL's on-policy sequential-update path.  TEST INFRASTRUCTURE ONLY.
+
+This file is the *checker*, never the product: only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import it.
+``harl_amd`` (the product) never imports anything under ``oracle/``.
+
+It is an independent restatement, in plain torch-CPU fp32 + NumPy, of the algorithm
+the reference implements in these files (paths relative to the reference root):
+
+* GAE / returns reverse scan   harl/common/buffers/on_policy_critic_buffer_ep.py:97-200
+* ValueNorm (PopArt-style)     harl/common/valuenorm.py:38-92
+* actor / critic MLP           harl/models/base/mlp.py:7-70,
+                               harl/models/policy_models/stochastic_policy.py:88-127,
+                               harl/models/value_function_models/v_net.py:48-67
+* action heads                 harl/models/base/act.py:104-157, harl/models/base/distributions.py:7-89
+* HAPPO update / train         harl/algorithms/actors/happo.py:28-158
+* V-critic update / train      harl/algorithms/critics/v_critic.py:75-200
+* sequential update + factor   harl/runners/on_policy_ha_runner.py:11-130
+* minibatch sampling           harl/common/buffers/on_policy_actor_buffer.py:114-178,
+                               harl/common/buffers/on_policy_critic_buffer_ep.py:202-250
+
+Third-party arithmetic on the path is PyTorch's (Linear / LayerNorm / autograd /
+Adam / clip_grad_norm_ / randperm) and NumPy's (GAE, nanmean/nanstd), exactly as in
+the reference; torch 2.10.0 / NumPy 2.2.6 are the versions
+the golden fixtures were generated with.
+
+Parity status: PINNED.  ``oracle/gen_golden.py`` imports the real reference from
+/root/reference, runs ``compute_returns`` + ``OnPolicyHARunner.train()`` on seeded
+synthetic buffers and commits the outputs under ``tests/golden/``;
+``tests/test_oracle_golden.py`` checks this restatement against those fixtures
+(returns and minibatch indices bit-exact, losses / grad-norms / params <= 1e-6 rel).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+LOG_SQRT_2PI = math.log(math.sqrt(2.0 * math.pi))
+
+
+# --------------------------------------------------------------------------------------
+# configuration (the subset of happo.yaml / hatrpo.yaml the path reads)
+# --------------------------------------------------------------------------------------
+@dataclass
+class PathConfig:
+    """Knobs read by the path; defaults = harl/configs/algos_cfgs/happo.yaml."""
+
+    hidden_sizes: Sequence[int] = (128, 128)
+    use_feature_normalization: bool = True
+    std_x_coef: float = 1.0
+    std_y_coef: float = 0.5
+    lr: float = 5e-4
+    critic_lr: float = 5e-4
+    opti_eps: float = 1e-5
+    weight_decay: float = 0.0
+    ppo_epoch: int = 5
+    critic_epoch: int = 5
+    use_clipped_value_loss: bool = True
+    clip_param: float = 0.2
+    actor_num_mini_batch: int = 1
+    critic_num_mini_batch: int = 1
+    entropy_coef: float = 0.01
+    value_loss_coef: float = 1.0
+    use_max_grad_norm: bool = True
+    max_grad_norm: float = 10.0
+    use_gae: bool = True
+    gamma: float = 0.99
+    gae_lambda: float = 0.95
+    use_huber_loss: bool = True
+    use_policy_active_masks: bool = True
+    huber_delta: float = 10.0
+    action_aggregation: str = "prod"
+    fixed_order: bool = False
+    use_proper_time_limits: bool = True
+    use_valuenorm: bool = True
+
+    @staticmethod
+    def from_reference_dicts(train: dict, model: dict, algo: dict) -> "PathConfig":
+        merged = {**train, **model, **algo}
+        kw = {k: merged[k] for k in PathConfig.__dataclass_fields__ if k in merged}
+        return PathConfig(**kw)
+
+
+# --------------------------------------------------------------------------------------
+# ValueNorm   (harl/common/valuenorm.py)
+# --------------------------------------------------------------------------------------
+class OracleValueNorm:
+    """State = (running_mean[1], running_mean_sq[1], debiasing_term[]), beta = 0.99999."""
+
+    def __init__(self, beta: float = 0.99999, epsilon: float = 1e-5):
+        self.beta = beta
+        self.epsilon = epsilon
+        self.running_mean = torch.zeros(1)
+        self.running_mean_sq = torch.zeros(1)
+        self.debiasing_term = torch.tensor(0.0)
+
+    def mean_var(self) -> Tuple[torch.Tensor, torch.Tensor]:  # valuenorm.py:38-45
+        d = self.debiasing_term.clamp(min=self.epsilon)
+        mean = self.running_mean / d
+        mean_sq = self.running_mean_sq / d
+        var = (mean_sq - mean**2).clamp(min=1e-2)
+        return mean, var
+
+    @torch.no_grad()
+    def update(self, x: torch.Tensor) -> None:  # valuenorm.py:47-64
+        x = _t(x)
+        bm = x.mean(dim=0)
+        bsq = (x**2).mean(dim=0)
+        w = self.beta
+        self.running_mean.mul_(w).add_(bm * (1.0 - w))
+        self.running_mean_sq.mul_(w).add_(bsq * (1.0 - w))
+        self.debiasing_term.mul_(w).add_(1.0 * (1.0 - w))
+
+    def normalize(self, x) -> torch.Tensor:  # valuenorm.py:66-76
+        x = _t(x)
+        mean, var = self.mean_var()
+        return (x - mean[None]) / torch.sqrt(var)[None]
+
+    def denormalize(self, x) -> np.ndarray:  # valuenorm.py:78-92 (returns NumPy)
+        x = _t(x)
+        mean, var = self.mean_var()
+        return (x * torch.sqrt(var)[None] + mean[None]).numpy()
+
+    def state(self) -> Dict[str, np.ndarray]:
+        return {
+            "running_mean": self.running_mean.numpy().copy(),
+            "running_mean_sq": self.running_mean_sq.numpy().copy(),
+            "debiasing_term": self.debiasing_term.numpy().copy(),
+        }
+
+    def load_state(self, s) -> None:
+        self.running_mean = torch.as_tensor(np.array(s["running_mean"], dtype=np.float32)).reshape(1).clone()
+        self.running_mean_sq = torch.as_tensor(np.array(s["running_mean_sq"], dtype=np.float32)).reshape(1).clone()
+        self.debiasing_term = torch.as_tensor(np.array(s["debiasing_term"], dtype=np.float32)).reshape(()).clone()
+
+
+def _t(x) -> torch.Tensor:
+    if isinstance(x, np.ndarray):
+        x = torch.from_numpy(x)
+    return x.to(torch.float32)
+
+
+# --------------------------------------------------------------------------------------
+# GAE / returns reverse scan   (on_policy_critic_buffer_ep.py:97-200, all 8 branches)
+# --------------------------------------------------------------------------------------
+def compute_returns(
+    rewards: np.ndarray,      # [T, N, 1]
+    value_preds: np.ndarray,  # [T+1, N, 1]   (slot T is overwritten with next_value in the GAE branches)
+    masks: np.ndarray,        # [T+1, N, 1]
+    bad_masks: np.ndarray,    # [T+1, N, 1]
+    next_value: np.ndarray,   # [N, 1]
+    gamma: float,
+    gae_lambda: float,
+    use_gae: bool = True,
+    use_proper_time_limits: bool = True,
+    value_normalizer: Optional[OracleValueNorm] = None,
+) -> Tuple[np.ndarray, np.ndarray]:
+    """Returns (returns[T+1,N,1], value_preds[T+1,N,1]) as fp32 NumPy, same op order as the reference."""
+    T = rewards.shape[0]
+    value_preds = value_preds.copy()
+    returns = np.zeros_like(value_preds)
+    den = (lambda v: value_normalizer.denormalize(v)) if value_normalizer is not None else (lambda v: v)
+    if use_gae:
+        value_preds[-1] = next_value
+        gae = 0
+        for step in reversed(range(T)):
+            delta = rewards[step] + gamma * den(value_preds[step + 1]) * masks[step + 1] - den(value_preds[step])
+            gae = delta + gamma * gae_lambda * masks[step + 1] * gae
+            if use_proper_time_limits:
+                gae = bad_masks[step + 1] * gae
+            returns[step] = gae + den(value_preds[step])
+    else:
+        returns[-1] = next_value
+        for step in reversed(range(T)):
+            if use_proper_time_limits:
+                returns[step] = (returns[step + 1] * gamma * masks[step + 1] + rewards[step]) * bad_masks[
+                    step + 1
+                ] + (1 - bad_masks[step + 1]) * den(value_preds[step])
+            else:
+                returns[step] = returns[step + 1] * gamma * masks[step + 1] + rewards[step]
+    return returns.astype(np.float32), value_preds
+
+
+def advantages_from_returns(returns, value_preds, value_normalizer: Optional[OracleValueNorm]):
+    """on_policy_ha_runner.py:26-33."""
+    if value_normalizer is not None:
+        return returns[:-1] - value_normalizer.denormalize(value_preds[:-1])
+    return returns[:-1] - value_preds[:-1]
+
+
+def normalize_advantages(adv: np.ndarray, active_masks_tm1: np.ndarray) -> np.ndarray:
+    """happo.py:122-127 (EP): masked mean / population std via the NaN trick."""
+    cp = adv.copy()
+    cp[active_masks_tm1 == 0.0] = np.nan
+    mean = np.nanmean(cp)
+    std = np.nanstd(cp)
+    return (adv - mean) / (std + 1e-5)
+
+
+# --------------------------------------------------------------------------------------
+# networks (functional; parameters keyed exactly like the reference state_dict)
+# --------------------------------------------------------------------------------------
+def _linear_keys(sd_keys: Sequence[str]) -> List[int]:
+    idx = sorted({int(k.split(".")[3]) for k in sd_keys if k.startswith("base.mlp.fc.") and k.endswith(".weight")})
+    return idx
+
+
+def mlp_base_forward(p: Dict[str, torch.Tensor], x: torch.Tensor) -> torch.Tensor:
+    """MLPBase: [LayerNorm(obs)] -> (Linear, ReLU, LayerNorm) x k   (mlp.py:25-38,64-70)."""
+    if "base.feature_norm.weight" in p:
+        x = F.layer_norm(x, (x.shape[-1],), p["base.feature_norm.weight"], p["base.feature_norm.bias"], 1e-5)
+    idx = _linear_keys(list(p.keys()))
+    # fc.{0,3,6,..} are Linear, fc.{2,5,8,..} LayerNorm (Sequential [Linear, act, LN] x k)
+    lin = [i for i in idx if i % 3 == 0]
+    for i in lin:
+        x = F.linear(x, p[f"base.mlp.fc.{i}.weight"], p[f"base.mlp.fc.{i}.bias"])
+        x = F.relu(x)
+        x = F.layer_norm(x, (x.shape[-1],), p[f"base.mlp.fc.{i+2}.weight"], p[f"base.mlp.fc.{i+2}.bias"], 1e-5)
+    return x
+
+
+def actor_evaluate_actions(
+    p: Dict[str, torch.Tensor],
+    cfg: PathConfig,
+    obs: torch.Tensor,
+    action: torch.Tensor,
+    available_actions: Optional[torch.Tensor],
+    active_masks: Optional[torch.Tensor],
+):
+    """StochasticPolicy.evaluate_actions for MLP policies (stochastic_policy.py:88-127, act.py:104-157).
+
+    Returns (action_log_probs [B, D_a | 1], dist_entropy scalar, dist-params dict).
+    """
+    feat = mlp_base_forward(p, obs)
+    am = active_masks if cfg.use_policy_active_masks else None
+    if "act.action_out.log_std" in p:  # Box -> DiagGaussian (distributions.py:58-89)
+        mean = F.linear(feat, p["act.action_out.fc_mean.weight"], p["act.action_out.fc_mean.bias"])
+        std = torch.sigmoid(p["act.action_out.log_std"] / cfg.std_x_coef) * cfg.std_y_coef
+        std = std.expand_as(mean)
+        var = std**2
+        logp = -((action - mean) ** 2) / (2 * var) - std.log() - LOG_SQRT_2PI
+        ent = (0.5 + 0.5 * math.log(2 * math.pi) + torch.log(std)).sum(-1)
+        dist = {"mean": mean, "std": std}
+    else:  # Discrete -> Categorical (distributions.py:37-55)
+        logits = F.linear(feat, p["act.action_out.linear.weight"], p["act.action_out.linear.bias"])
+        if available_actions is not None:
+            logits = torch.where(available_actions == 0, torch.full_like(logits, -1e10), logits)
+        logits = logits - logits.logsumexp(dim=-1, keepdim=True)
+        logp = logits.gather(-1, action.long())
+        probs = F.softmax(logits, dim=-1)
+        ent = -(torch.clamp(logits, min=torch.finfo(logits.dtype).min) * probs).sum(-1)
+        dist = {"logits": logits}
+    if am is not None:
+        dist_entropy = (ent * am.squeeze(-1)).sum() / am.sum()
+    else:
+        dist_entropy = ent.mean()
+    return logp, dist_entropy, dist
+
+
+def critic_forward(p: Dict[str, torch.Tensor], share_obs: torch.Tensor) -> torch.Tensor:
+    """VNet.forward for MLP critics (v_net.py:48-67)."""
+    feat = mlp_base_forward(p, share_obs)
+    return F.linear(feat, p["v_out.weight"], p["v_out.bias"])
+
+
+class _Net:
+    """Parameter dict + torch.optim.Adam, in the reference's parameters() order."""
+
+    def __init__(self, state_dict: Dict[str, torch.Tensor], lr: float, eps: float, weight_decay: float):
+        self.p = {k: v.detach().clone().to(torch.float32).requires_grad_(True) for k, v in state_dict.items()}
+        self.opt = torch.optim.Adam(list(self.p.values()), lr=lr, eps=eps, weight_decay=weight_decay)
+
+    def params(self) -> List[torch.Tensor]:
+        return list(self.p.values())
+
+    def flat(self) -> np.ndarray:
+        return torch.cat([v.detach().reshape(-1) for v in self.p.values()]).numpy().copy()
+
+    def flat_grad(self) -> np.ndarray:
+        return torch.cat([v.grad.reshape(-1) for v in self.p.values()]).numpy().copy()
+
+
+def _grad_norm_step(net: _Net, cfg: PathConfig) -> torch.Tensor:
+    """clip_grad_norm_ | get_grad_norm, then Adam.step (happo.py:93-100, v_critic.py:148-155)."""
+    if cfg.use_max_grad_norm:
+        gn = torch.nn.utils.clip_grad_norm_(net.params(), cfg.max_grad_norm)
+    else:
+        s = 0
+        for q in net.params():
+            if q.grad is not None:
+                s += q.grad.norm() ** 2
+        gn = torch.tensor(math.sqrt(s))
+    net.opt.step()
+    return gn
+
+
+# --------------------------------------------------------------------------------------
+# HAPPO   (happo.py)
+# --------------------------------------------------------------------------------------
+class OracleHAPPO:
+    def __init__(self, state_dict, cfg: PathConfig):
+        self.cfg = cfg
+        self.net = _Net(state_dict, cfg.lr, cfg.opti_eps, cfg.weight_decay)
+        self.trace: List[dict] = []  # one entry per update(): loss, entropy, grad norm, ratio mean, flat grad (pre-clip)
+
+    def evaluate_actions(self, obs, action, available_actions=None, active_masks=None):
+        return actor_evaluate_actions(
+            self.net.p, self.cfg, _t(obs), _t(action),
+            None if available_actions is None else _t(available_actions),
+            None if active_masks is None else _t(active_masks),
+        )
+
+    def update(self, sample, keep_grad: bool = False):  # happo.py:28-102
+        cfg = self.cfg
+        obs, actions, active, old_logp, adv, avail, factor = (None if s is None else _t(s) for s in sample)
+        logp, ent, _ = actor_evaluate_actions(self.net.p, cfg, obs, actions, avail, active)
+        agg = getattr(torch, cfg.action_aggregation)
+        imp = agg(torch.exp(logp - old_logp), dim=-1, keepdim=True)
+        surr1 = imp * adv
+        surr2 = torch.clamp(imp, 1.0 - cfg.clip_param, 1.0 + cfg.clip_param) * adv
+        if cfg.use_policy_active_masks:
+            pl = (-torch.sum(factor * torch.min(surr1, surr2), dim=-1, keepdim=True) * active).sum() / active.sum()
+        else:
+            pl = -torch.sum(factor * torch.min(surr1, surr2), dim=-1, keepdim=True).mean()
+        self.net.opt.zero_grad()
+        (pl - ent * cfg.entropy_coef).backward()
+        g = self.net.flat_grad() if keep_grad else None
+        gn = _grad_norm_step(self.net, cfg)
+        return pl.detach(), ent.detach(), gn.detach(), imp.detach(), g
+
+    def train(self, buf: "OracleActorBuffer", advantages: np.ndarray, keep_grad: bool = False) -> dict:  # happo.py:104-158
+        cfg = self.cfg
+        info = {"policy_loss": 0.0, "dist_entropy": 0.0, "actor_grad_norm": 0.0, "ratio": 0.0}
+        if np.all(buf.active_masks[:-1] == 0.0):
+            return info
+        advantages = normalize_advantages(advantages, buf.active_masks[:-1])
+        for _ in range(cfg.ppo_epoch):
+            for sample, idx in buf.feed_forward_generator(advantages, cfg.actor_num_mini_batch):
+                pl, ent, gn, imp, g = self.update(sample, keep_grad)
+                info["policy_loss"] += pl.item()
+                info["dist_entropy"] += ent.item()
+                info["actor_grad_norm"] += float(gn)
+                info["ratio"] += float(imp.mean())
+                self.trace.append(
+                    {"policy_loss": pl.item(), "dist_entropy": ent.item(), "grad_norm": float(gn),
+                     "ratio": float(imp.mean()), "indices": idx, "grad": g}
+                )
+        n = cfg.ppo_epoch * cfg.actor_num_mini_batch
+        return {k: v / n for k, v in info.items()}
+
+
+# --------------------------------------------------------------------------------------
+# V critic   (v_critic.py)
+# --------------------------------------------------------------------------------------
+def huber(e: torch.Tensor, d: float) -> torch.Tensor:  # models_tools.py:64-68
+    a = (abs(e) <= d).float()
+    b = (abs(e) > d).float()
+    return a * e**2 / 2 + b * d * (abs(e) - d / 2)
+
+
+class OracleVCritic:
+    def __init__(self, state_dict, cfg: PathConfig):
+        self.cfg = cfg
+        lr_cfg = cfg.critic_lr
+        self.net = _Net(state_dict, lr_cfg, cfg.opti_eps, cfg.weight_decay)
+        self.trace: List[dict] = []
+
+    def get_values(self, share_obs) -> torch.Tensor:
+        return critic_forward(self.net.p, _t(share_obs))
+
+    def value_loss(self, values, value_preds, returns, vn: Optional[OracleValueNorm]):  # v_critic.py:75-114
+        cfg = self.cfg
+        clipped = value_preds + (values - value_preds).clamp(-cfg.clip_param, cfg.clip_param)
+        if vn is not None:
+            vn.update(returns)
+            e_c = vn.normalize(returns) - clipped
+            e_o = vn.normalize(returns) - values
+        else:
+            e_c = returns - clipped
+            e_o = returns - values
+        if cfg.use_huber_loss:
+            l_c, l_o = huber(e_c, cfg.huber_delta), huber(e_o, cfg.huber_delta)
+        else:
+            l_c, l_o = e_c**2 / 2, e_o**2 / 2
+        loss = torch.max(l_o, l_c) if cfg.use_clipped_value_loss else l_o
+        return loss.mean()
+
+    def update(self, sample, vn, keep_grad: bool = False):  # v_critic.py:116-157
+        share_obs, value_preds, returns = (_t(s) for s in sample)
+        values = critic_forward(self.net.p, share_obs)
+        loss = self.value_loss(values, value_preds, returns, vn)
+        self.net.opt.zero_grad()
+        (loss * self.cfg.value_loss_coef).backward()
+        g = self.net.flat_grad() if keep_grad else None
+        gn = _grad_norm_step(self.net, self.cfg)
+        return loss.detach(), gn.detach(), g
+
+    def train(self, buf: "OracleCriticBufferEP", vn, keep_grad: bool = False) -> dict:  # v_critic.py:159-200
+        cfg = self.cfg
+        info = {"value_loss": 0.0, "critic_grad_norm": 0.0}
+        for _ in range(cfg.critic_epoch):
+            for sample, idx in buf.feed_forward_generator(cfg.critic_num_mini_batch):
+                loss, gn, g = self.update(sample, vn, keep_grad)
+                info["value_loss"] += loss.item()
+                info["critic_grad_norm"] += float(gn)
+                self.trace.append({"value_loss": loss.item(), "grad_norm": float(gn), "indices": idx, "grad": g})
+        n = cfg.critic_epoch * cfg.critic_num_mini_batch
+        return {k: v / n for k, v in info.items()}
+
+
+# --------------------------------------------------------------------------------------
+# buffers (host NumPy, reference shapes; only what train() reads)
+# --------------------------------------------------------------------------------------
+def minibatch_indices(batch_size: int, num_mini_batch: int) -> List[np.ndarray]:
+    """on_policy_actor_buffer.py:121-135: one torch.randperm draw on the global CPU generator,
+    remainder rows dropped."""
+    assert batch_size >= num_mini_batch
+    m = batch_size // num_mini_batch
+    rand = torch.randperm(batch_size).numpy()
+    return [rand[i * m:(i + 1) * m] for i in range(num_mini_batch)]
+
+
+@dataclass
+class OracleActorBuffer:
+    obs: np.ndarray               # [T+1, N, D_o]
+    actions: np.ndarray           # [T, N, D_a]
+    action_log_probs: np.ndarray  # [T, N, D_a]
+    masks: np.ndarray             # [T+1, N, 1]
+    active_masks: np.ndarray      # [T+1, N, 1]
+    available_actions: Optional[np.ndarray] = None  # [T+1, N, n_act] (Discrete only)
+    factor: Optional[np.ndarray] = None             # [T, N, 1]
+
+    def update_factor(self, factor):
+        self.factor = factor.copy()
+
+    def feed_forward_generator(self, advantages: np.ndarray, num_mini_batch: int):
+        T, N = self.actions.shape[:2]
+        sampler = minibatch_indices(T * N, num_mini_batch)
+        obs = self.obs[:-1].reshape(T * N, -1)
+        actions = self.actions.reshape(T * N, -1)
+        active = self.active_masks[:-1].reshape(-1, 1)
+        logp = self.action_log_probs.reshape(T * N, -1)
+        avail = None if self.available_actions is None else self.available_actions[:-1].reshape(T * N, -1)
+        factor = self.factor.reshape(-1, 1)
+        adv = advantages.reshape(-1, 1)
+        for idx in sampler:
+            yield (
+                obs[idx], actions[idx], active[idx], logp[idx], adv[idx],
+                None if avail is None else avail[idx], factor[idx],
+            ), idx
+
+
+@dataclass
+class OracleCriticBufferEP:
+    share_obs: np.ndarray    # [T+1, N, D_s]
+    rewards: np.ndarray      # [T, N, 1]
+    value_preds: np.ndarray  # [T+1, N, 1]
+    masks: np.ndarray        # [T+1, N, 1]
+    bad_masks: np.ndarray    # [T+1, N, 1]
+    returns: np.ndarray = field(default=None)
+
+    def compute_returns(self, next_value, vn, cfg: PathConfig):
+        self.returns, self.value_preds = compute_returns(
+            self.rewards, self.value_preds, self.masks, self.bad_masks, next_value,
+            cfg.gamma, cfg.gae_lambda, cfg.use_gae, cfg.use_proper_time_limits, vn,
+        )
+
+    def feed_forward_generator(self, num_mini_batch: int):
+        T, N = self.rewards.shape[:2]
+        sampler = minibatch_indices(T * N, num_mini_batch)
+        so = self.share_obs[:-1].reshape(T * N, -1)
+        vp = self.value_preds[:-1].reshape(-1, 1)
+        rt = self.returns[:-1].reshape(-1, 1)
+        for idx in sampler:
+            yield (so[idx], vp[idx], rt[idx]), idx
+
+
+# --------------------------------------------------------------------------------------
+# the sequential update   (on_policy_ha_runner.py:11-130)
+# --------------------------------------------------------------------------------------
+def ha_train(
+    actors: List[OracleHAPPO],
+    critic: OracleVCritic,
+    actor_buffers: List[OracleActorBuffer],
+    critic_buffer: OracleCriticBufferEP,
+    vn: Optional[OracleValueNorm],
+    cfg: PathConfig,
+    keep_grad: bool = False,
+):
+    """Returns (actor_train_infos in update order, critic_train_info, extras)."""
+    T, N = critic_buffer.rewards.shape[:2]
+    A = len(actors)
+    factor = np.ones((T, N, 1), dtype=np.float32)
+    advantages = advantages_from_returns(critic_buffer.returns, critic_buffer.value_preds, vn)
+    order = list(range(A)) if cfg.fixed_order else list(torch.randperm(A).numpy())
+    infos, factors = [], []
+    for a in order:
+        buf = actor_buffers[a]
+        buf.update_factor(factor)
+        flat = lambda v: v.reshape(T * N, -1)  # noqa: E731
+        avail = None if buf.available_actions is None else flat(buf.available_actions[:-1])
+        args = (flat(buf.obs[:-1]), flat(buf.actions), avail, flat(buf.active_masks[:-1]))
+        old_logp, _, _ = actors[a].evaluate_actions(*args)
+        infos.append(actors[a].train(buf, advantages.copy(), keep_grad))
+        new_logp, _, _ = actors[a].evaluate_actions(*args)
+        agg = getattr(torch, cfg.action_aggregation)
+        factor = factor * agg(torch.exp(new_logp - old_logp), dim=-1).reshape(T, N, 1).detach().numpy()
+        factors.append(factor.copy())
+    cinfo = critic.train(critic_buffer, vn, keep_grad)
+    return infos, cinfo, {"agent_order": [int(x) for x in order], "factors": factors, "advantages": advantages}

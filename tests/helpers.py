@@ -1,0 +1,63 @@
+"""Shared test helpers: load a golden case and rebuild its *inputs* deterministically."""
+from __future__ import annotations
+
+import json
+import os
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from harl_amd.synthetic import (
+    Shapes, SyntheticBuffers, actor_param_shapes, critic_param_shapes, make_buffers, synthetic_state_dict,
+)
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ALL_CASES = ["mpe_box_h64", "mpe_box_h128", "mpe_disc_h64", "cheetah_h128x3_mb2", "box_mean_inactive_novn",
+             "wide_obs_h64"]
+
+
+class GoldenCase:
+    def __init__(self, name: str):
+        self.name = name
+        self.z = np.load(os.path.join(GOLDEN_DIR, f"{name}.npz"))
+        self.meta = json.loads(bytes(self.z["meta"]).decode())
+        spec = self.meta["spec"]
+        self.shapes = Shapes(**spec["shapes"])
+        self.seed = spec["seed"]
+        self.algo, self.model, self.train = self.meta["algo"], self.meta["model"], self.meta["train"]
+        self.data: SyntheticBuffers = make_buffers(self.shapes, self.seed, spec.get("inactive_p", 0.0),
+                                                   spec.get("unavailable_p", 0.0))
+        for a in range(self.shapes.A):
+            if f"in_actions_{a}" in self.z:
+                self.data.actions[a] = self.z[f"in_actions_{a}"].copy()
+                self.data.action_log_probs[a] = self.z[f"in_logp_{a}"].copy()
+        use_fn = self.model["use_feature_normalization"]
+        self.actor_sd = [synthetic_state_dict(actor_param_shapes(self.shapes, use_fn), 1000 * self.seed + a,
+                                              self.model["std_x_coef"]) for a in range(self.shapes.A)]
+        self.critic_sd = synthetic_state_dict(critic_param_shapes(self.shapes, use_fn), 1000 * self.seed + 999)
+        self.use_valuenorm = self.train["use_valuenorm"]
+        # ValueNorm start state used by gen_golden.py
+        self.vn_init = dict(running_mean=0.3 * 0.5, running_mean_sq=1.7 * 0.5, debiasing_term=0.5)
+
+    def perms(self) -> List[np.ndarray]:
+        return [self.z[f"perm_{i}"] for i in range(int(self.z["n_perms"]))]
+
+    def reference_dicts(self) -> Tuple[dict, dict, dict]:
+        train = dict(self.train)
+        train.setdefault("episode_length", self.shapes.T)
+        train.setdefault("n_rollout_threads", self.shapes.N)
+        return train, dict(self.model), dict(self.algo)
+
+
+def rel_err(a, b) -> float:
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.max(np.abs(a - b) / (np.abs(b) + 1e-12))) if a.size else 0.0
+
+
+def vec_rel_err(a, b) -> float:
+    """|a-b|_inf / |b|_inf  (for parameter / gradient vectors with near-zero entries)."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.max(np.abs(a - b)) / (np.max(np.abs(b)) + 1e-30))

@@ -1,0 +1,105 @@
+"""Pin the CPU oracle against golden vectors produced by the REAL reference (oracle/gen_golden.py).
+
+These run without a GPU.  Bars: returns and minibatch permutations bit-exact; per-update losses,
+entropies, grad-norms, ratios <= 1e-6 rel; final parameters <= 1e-6 of the vector's inf-norm.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import harl_oracle as O
+from tests.helpers import ALL_CASES, GOLDEN_DIR, GoldenCase, rel_err, vec_rel_err
+
+
+def build_oracle(case: GoldenCase):
+    train, model, algo = case.reference_dicts()
+    cfg = O.PathConfig.from_reference_dicts(train, model, algo)
+    sh, d = case.shapes, case.data
+    actors = [O.OracleHAPPO({k: torch.from_numpy(v) for k, v in sd.items()}, cfg) for sd in case.actor_sd]
+    critic = O.OracleVCritic({k: torch.from_numpy(v) for k, v in case.critic_sd.items()}, cfg)
+    abufs = [O.OracleActorBuffer(d.obs[a].copy(), d.actions[a].copy(), d.action_log_probs[a].copy(), d.masks[a].copy(),
+                                 d.active_masks[a].copy(),
+                                 None if d.available_actions[a] is None else d.available_actions[a].copy())
+             for a in range(sh.A)]
+    cbuf = O.OracleCriticBufferEP(d.share_obs.copy(), d.rewards.copy(), d.value_preds.copy(), d.critic_masks.copy(),
+                                  d.bad_masks.copy())
+    vn = None
+    if case.use_valuenorm:
+        vn = O.OracleValueNorm()
+        vn.load_state(case.vn_init)
+    return cfg, actors, critic, abufs, cbuf, vn
+
+
+@pytest.mark.parametrize("name", ALL_CASES)
+def test_oracle_matches_reference_golden(name):
+    case = GoldenCase(name)
+    z = case.z
+    torch.set_num_threads(1)
+    torch.manual_seed(case.seed)
+    np.random.seed(case.seed)
+    cfg, actors, critic, abufs, cbuf, vn = build_oracle(case)
+    torch.manual_seed(case.seed + 12345)  # gen_golden.py re-seeds right before compute_returns/train
+
+    perms = []
+    real = torch.randperm
+
+    def rec(n, *a, **k):
+        p = real(n, *a, **k)
+        perms.append(p.numpy().copy())
+        return p
+
+    torch.randperm = rec
+    try:
+        cbuf.compute_returns(cbuf.value_preds[-1].copy(), vn, cfg)
+        assert np.array_equal(cbuf.returns, z["returns"]), "returns must be bit-exact"
+        adv = O.advantages_from_returns(cbuf.returns, cbuf.value_preds, vn)
+        assert np.array_equal(adv.astype(np.float32), z["advantages"])
+        infos, cinfo, extra = O.ha_train(actors, critic, abufs, cbuf, vn, cfg)
+    finally:
+        torch.randperm = real
+
+    # integer side: every randperm draw (agent order + minibatch permutations) bit-exact, same count
+    gold_perms = case.perms()
+    assert len(perms) == len(gold_perms)
+    for p, g in zip(perms, gold_perms):
+        assert p.dtype == np.int64 and np.array_equal(p, g)
+
+    # floating side
+    tr = np.array([[t["policy_loss"], t["dist_entropy"], t["grad_norm"], t["ratio"]]
+                   for a in extra["agent_order"] for t in actors[a].trace])
+    assert rel_err(tr, z["actor_trace"][:, 1:]) < 1e-6
+    ctr = np.array([[t["value_loss"], t["grad_norm"]] for t in critic.trace])
+    assert rel_err(ctr, z["critic_trace"]) < 1e-6
+    got_infos = np.array([[i["policy_loss"], i["dist_entropy"], i["actor_grad_norm"], i["ratio"]] for i in infos])
+    assert rel_err(got_infos, z["actor_infos"]) < 1e-6
+    assert rel_err([cinfo["value_loss"], cinfo["critic_grad_norm"]], z["critic_info"]) < 1e-6
+    assert vec_rel_err(np.stack([np.ones_like(extra["factors"][0])] + extra["factors"][:-1]), z["factors"]) < 1e-6
+    for a in range(case.shapes.A):
+        assert vec_rel_err(actors[a].net.flat(), z[f"actor_final_{a}"]) < 1e-6
+    assert vec_rel_err(critic.net.flat(), z["critic_final"]) < 1e-6
+    if vn is not None:
+        s = vn.state()
+        got = [s["running_mean"].item(), s["running_mean_sq"].item(), s["debiasing_term"].item()]
+        assert rel_err(got, z["vn_final"]) < 1e-6
+
+
+def test_oracle_gae_all_branches_bit_exact():
+    """All 8 branches of compute_returns (on_policy_critic_buffer_ep.py:97-200)."""
+    from harl_amd.synthetic import Shapes, make_buffers
+
+    z = np.load(os.path.join(GOLDEN_DIR, "gae_branches.npz"))
+    sh = Shapes(T=16, N=6, A=1, obs_dim=4, share_obs_dim=4, act_dim=1)
+    d = make_buffers(sh, 11)
+    for use_gae in (True, False):
+        for ptl in (True, False):
+            for use_vn in (True, False):
+                vn = None
+                if use_vn:
+                    vn = O.OracleValueNorm()
+                    vn.load_state(dict(running_mean=-0.2 * 0.25, running_mean_sq=2.3 * 0.25, debiasing_term=0.25))
+                ret, _ = O.compute_returns(d.rewards, d.value_preds, d.critic_masks, d.bad_masks,
+                                           d.value_preds[-1].copy() * 0.5, 0.99, 0.95, use_gae, ptl, vn)
+                key = f"gae{int(use_gae)}_ptl{int(ptl)}_vn{int(use_vn)}"
+                assert np.array_equal(ret, z[key]), key

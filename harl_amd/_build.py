@@ -1,0 +1,49 @@
+"""Build libharl_hip.so (gfx950) in-tree with hipcc.  No GPU needed: hipcc cross-compiles."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libharl_hip.so")
+SOURCES = ["elementwise.hip", "mlp.hip", "heads.hip"]
+HEADERS = ["common.h", os.path.join("..", "..", "include", "harl_hip.h")]
+
+
+def _stale() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile every HIP source into harl_amd/lib/libharl_hip.so for gfx950."""
+    if not force and not _stale():
+        return LIB
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    os.makedirs(LIBDIR, exist_ok=True)
+    objs = []
+    procs = []
+    for src in SOURCES:  # one hipcc per translation unit, in parallel
+        obj = os.path.join(LIBDIR, src.replace(".hip", ".o"))
+        objs.append(obj)
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", os.path.join(CSRC, src), "-o", obj]
+        procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for cmd, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError("hipcc failed: %s\n%s" % (" ".join(cmd), out.decode(errors="replace")))
+        if verbose and out:
+            print(out.decode(errors="replace"))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

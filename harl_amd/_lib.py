@@ -1,0 +1,104 @@
+"""ctypes binding of libharl_hip.so (the C ABI declared in include/harl_hip.h).
+
+The HIP library is the *only* compute backend of this package: if it is missing the import of
+any compute class fails loudly (there is no CPU / PyTorch fallback -- the oracle under oracle/ is
+test infrastructure and is never imported from here).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libharl_hip.so")
+
+PS_STRIDE = 48
+DHEAD_LD = 32
+SLAB = 32
+
+_vp, _i, _l, _f, _d = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_double
+
+# name -> argtypes (restype is int unless noted); mirrors include/harl_hip.h line by line
+SIGNATURES = {
+    "harl_gae_returns": [_vp] * 8 + [_i, _i, _f, _f, _i, _i, _i, _vp],
+    "harl_masked_moments": [_vp, _vp, _l, _vp, _vp],
+    "harl_adv_normalize": [_vp, _vp, _vp, _l, _vp],
+    "harl_factor_update": [_vp, _vp, _vp, _l, _i, _i, _vp],
+    "harl_sum_sumsq": [_vp, _vp, _l, _vp, _vp],
+    "harl_valuenorm_apply": [_vp, _vp, _d, _d, _vp],
+    "harl_gradnorm_clip_adam": [_vp, _vp, _vp, _vp, _l, _vp, _i, _f, _f, _f, _f, _f, _f, _d, _d, _vp, _vp],
+    "harl_fold_linear": [_vp] * 6 + [_i, _i, _vp],
+    "harl_unfold_linear_grads": [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
+    "harl_mlp_fwd_input": [_vp, _l, _vp, _l, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+    "harl_mlp_fwd_hidden": [_vp, _l, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+    "harl_mlp_bwd_dx": [_vp, _vp, _vp, _vp, _l, _i, _i, _vp, _vp, _vp],
+    "harl_mlp_dw_partials": [_vp, _i, _i, _i, _vp, _i, _l, _vp, _vp, _vp, _i, _l, _vp, _i, _vp],
+    "harl_reduce_partials": [_vp, _i, _l, _vp, _vp],
+    "harl_actor_head_logp": [_vp, _l, _i, _vp, _vp, _vp, _f, _f, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp],
+    "harl_actor_head_loss": [_vp, _vp, _vp, _l, _i, _vp, _vp, _vp, _f, _f, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,
+                             _vp, _vp, _f, _f, _i, _vp, _vp, _vp, _vp],
+    "harl_critic_head_values": [_vp, _l, _i, _vp, _vp, _vp, _vp],
+    "harl_critic_head_loss": [_vp, _vp, _vp, _l, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _f, _vp, _vp, _vp,
+                              _vp],
+    "harl_head_blocks": [_l],
+    "harl_reduce_scalars": [_vp, _i, _vp, _vp],
+    "harl_version": [],
+}
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """dlopen the in-tree library (built by ``__graft_entry__.build()`` / ``python -m harl_amd._build``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryMissing(
+            f"{LIB_PATH} not found: build it with `python -m harl_amd._build` (hipcc, gfx950). "
+            "harl_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    lib.harl_last_error.argtypes = []
+    lib.harl_last_error.restype = C.c_char_p
+    _lib = lib
+    return lib
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    """Device pointer of a (contiguous) tensor, None -> NULL."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "harl_amd kernels need contiguous tensors"
+    return t.data_ptr()
+
+
+def stream() -> int:
+    """Raw hipStream_t of torch's current stream (PyTorch-ROCm names the HIP device 'cuda')."""
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name: str, *args) -> None:
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise RuntimeError(f"{name} failed ({rc}): {lib.harl_last_error().decode()}")
+
+
+def require_gpu(device: torch.device) -> None:
+    if device.type != "cuda" or not torch.cuda.is_available():
+        raise RuntimeError(
+            "harl_amd runs on MI355X (PyTorch-ROCm device 'cuda') only; there is no CPU path. "
+            f"Got device={device}, torch.cuda.is_available()={torch.cuda.is_available()}")
+    load()

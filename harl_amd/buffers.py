@@ -1,0 +1,208 @@
+"""Device-resident on-policy rollout buffers with the reference's attribute names and shapes.
+
+Reference: harl/common/buffers/on_policy_actor_buffer.py:9-178, on_policy_critic_buffer_ep.py:8-250.
+Storage is ``[T(+1), N, D]`` row-major fp32 *device* tensors (time-major, thread-minor, feature-contiguous:
+flattening the first two axes gives row = t*N + n, the indexing the reference's generators use), so the update
+kernels read them in place: no per-minibatch gather copy, no host<->device traffic inside ``train()``.
+Minibatch sampling is bit-exact with the reference: the same ``torch.randperm`` draws on the global CPU generator
+in the same order; only the resulting int64 index arrays are uploaded.
+"""
+from __future__ import annotations
+
+from typing import Iterator, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import call, ptr, stream
+from .valuenorm import ValueNorm, _as_dev
+
+
+def _obs_shape(space) -> Tuple[int, ...]:
+    name = space.__class__.__name__
+    if name == "Box":
+        shp = tuple(space.shape)
+    elif name == "list":
+        shp = tuple(space)
+    else:
+        raise NotImplementedError(name)
+    if isinstance(shp[-1], list):
+        shp = shp[:1]
+    return shp
+
+
+def _act_shape(space) -> int:
+    name = space.__class__.__name__
+    if name == "Discrete":
+        return 1
+    return int(space.shape[0])
+
+
+def minibatch_indices(batch_size: int, num_mini_batch: int) -> List[torch.Tensor]:
+    """One ``torch.randperm(batch_size)`` draw on the global CPU generator, remainder rows dropped
+    (on_policy_actor_buffer.py:121-135).  Returns CPU int64 tensors."""
+    assert batch_size >= num_mini_batch, (
+        f"batch size ({batch_size}) must be >= the number of mini batches ({num_mini_batch})")
+    m = batch_size // num_mini_batch
+    rand = torch.randperm(batch_size)
+    return [rand[i * m:(i + 1) * m] for i in range(num_mini_batch)]
+
+
+class OnPolicyActorBuffer:
+    def __init__(self, args: dict, obs_space, act_space, device=torch.device("cuda:0")):
+        self.device = torch.device(device)
+        _lib.require_gpu(self.device)
+        self.episode_length = T = args["episode_length"]
+        self.n_rollout_threads = N = args["n_rollout_threads"]
+        self.hidden_sizes = args["hidden_sizes"]
+        self.rnn_hidden_size = self.hidden_sizes[-1]
+        self.recurrent_n = args["recurrent_n"]
+        obs_shape = _obs_shape(obs_space)
+        z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=self.device)  # noqa: E731
+        self.obs = z(T + 1, N, *obs_shape)
+        self.rnn_states = z(T + 1, N, self.recurrent_n, self.rnn_hidden_size)
+        if act_space.__class__.__name__ == "Discrete":
+            self.available_actions = torch.ones(T + 1, N, act_space.n, dtype=torch.float32, device=self.device)
+        else:
+            self.available_actions = None
+        a = _act_shape(act_space)
+        self.actions = z(T, N, a)
+        self.action_log_probs = z(T, N, a)
+        self.masks = torch.ones(T + 1, N, 1, dtype=torch.float32, device=self.device)
+        self.active_masks = torch.ones_like(self.masks)
+        self.factor = None
+        self.step = 0
+
+    def update_factor(self, factor):
+        """Save factor for this actor (actor_buffer.py:78-80); a device tensor is aliased, not copied --
+        the runner hands over a fresh tensor per agent."""
+        self.factor = _as_dev(factor, self.device).reshape(self.episode_length, self.n_rollout_threads, 1)
+
+    def insert(self, obs, rnn_states, actions, action_log_probs, masks, active_masks=None, available_actions=None):
+        s = self.step
+        self.obs[s + 1].copy_(_as_dev(obs, self.device))
+        self.rnn_states[s + 1].copy_(_as_dev(rnn_states, self.device))
+        self.actions[s].copy_(_as_dev(actions, self.device))
+        self.action_log_probs[s].copy_(_as_dev(action_log_probs, self.device))
+        self.masks[s + 1].copy_(_as_dev(masks, self.device))
+        if active_masks is not None:
+            self.active_masks[s + 1].copy_(_as_dev(active_masks, self.device))
+        if available_actions is not None:
+            self.available_actions[s + 1].copy_(_as_dev(available_actions, self.device))
+        self.step = (s + 1) % self.episode_length
+
+    def after_update(self):
+        self.obs[0].copy_(self.obs[-1])
+        self.rnn_states[0].copy_(self.rnn_states[-1])
+        self.masks[0].copy_(self.masks[-1])
+        self.active_masks[0].copy_(self.active_masks[-1])
+        if self.available_actions is not None:
+            self.available_actions[0].copy_(self.available_actions[-1])
+
+    # flat [T*N, .] views (row = t*N + n), zero-copy
+    def flat(self, name: str) -> torch.Tensor:
+        t = getattr(self, name)
+        if name in ("obs", "masks", "active_masks", "available_actions", "rnn_states"):
+            t = t[:-1]
+        return t.reshape(self.episode_length * self.n_rollout_threads, -1)
+
+    def feed_forward_generator_actor(self, advantages, actor_num_mini_batch=None, mini_batch_size=None):
+        """API-compatible generator (actor_buffer.py:114-178): yields gathered device tensors in the reference's
+        tuple order.  ``HAPPO.train`` does NOT go through this (it hands the index arrays to the kernels, which
+        gather in place); this exists for callers that iterate minibatches themselves."""
+        T, N = self.actions.shape[:2]
+        B = T * N
+        if mini_batch_size is None:
+            sampler = minibatch_indices(B, actor_num_mini_batch)
+        else:
+            rand = torch.randperm(B)
+            sampler = [rand[i * mini_batch_size:(i + 1) * mini_batch_size] for i in range(actor_num_mini_batch)]
+        adv = None if advantages is None else _as_dev(advantages, self.device).reshape(-1, 1)
+        for ind in sampler:
+            i = ind.to(self.device)
+            out = [self.flat("obs")[i], self.flat("rnn_states").reshape(B, self.recurrent_n, -1)[i], self.flat("actions")[i],
+                   self.flat("masks")[i], self.flat("active_masks")[i], self.flat("action_log_probs")[i],
+                   None if adv is None else adv[i],
+                   None if self.available_actions is None else self.flat("available_actions")[i]]
+            if self.factor is not None:
+                out.append(self.factor.reshape(B, -1)[i])
+            yield tuple(out)
+
+
+class OnPolicyCriticBufferEP:
+    def __init__(self, args: dict, share_obs_space, device=torch.device("cuda:0")):
+        self.device = torch.device(device)
+        _lib.require_gpu(self.device)
+        self.episode_length = T = args["episode_length"]
+        self.n_rollout_threads = N = args["n_rollout_threads"]
+        self.hidden_sizes = args["hidden_sizes"]
+        self.rnn_hidden_size = self.hidden_sizes[-1]
+        self.recurrent_n = args["recurrent_n"]
+        self.gamma = args["gamma"]
+        self.gae_lambda = args["gae_lambda"]
+        self.use_gae = args["use_gae"]
+        self.use_proper_time_limits = args["use_proper_time_limits"]
+        so = _obs_shape(share_obs_space)
+        z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=self.device)  # noqa: E731
+        self.share_obs = z(T + 1, N, *so)
+        self.rnn_states_critic = z(T + 1, N, self.recurrent_n, self.rnn_hidden_size)
+        self.value_preds = z(T + 1, N, 1)
+        self.returns = z(T + 1, N, 1)
+        self.rewards = z(T, N, 1)
+        self.masks = torch.ones(T + 1, N, 1, dtype=torch.float32, device=self.device)
+        self.bad_masks = torch.ones_like(self.masks)
+        self.advantages = z(T, N, 1)  # filled by compute_returns (fused on_policy_ha_runner.py:26-33)
+        self.step = 0
+
+    def insert(self, share_obs, rnn_states_critic, value_preds, rewards, masks, bad_masks):
+        s = self.step
+        self.share_obs[s + 1].copy_(_as_dev(share_obs, self.device))
+        self.rnn_states_critic[s + 1].copy_(_as_dev(rnn_states_critic, self.device))
+        self.value_preds[s].copy_(_as_dev(value_preds, self.device))
+        self.rewards[s].copy_(_as_dev(rewards, self.device))
+        self.masks[s + 1].copy_(_as_dev(masks, self.device))
+        self.bad_masks[s + 1].copy_(_as_dev(bad_masks, self.device))
+        self.step = (s + 1) % self.episode_length
+
+    def after_update(self):
+        self.share_obs[0].copy_(self.share_obs[-1])
+        self.rnn_states_critic[0].copy_(self.rnn_states_critic[-1])
+        self.masks[0].copy_(self.masks[-1])
+        self.bad_masks[0].copy_(self.bad_masks[-1])
+
+    def get_mean_rewards(self):
+        return float(self.rewards.mean().item())
+
+    def compute_returns(self, next_value, value_normalizer: Optional[ValueNorm] = None):
+        """GAE / discounted returns (critic_buffer_ep.py:97-200, all 8 branches) as ONE reverse-scan kernel,
+        bit-identical to the reference's NumPy loop; also writes ``self.advantages = returns[:-1] -
+        denormalize(value_preds[:-1])`` (on_policy_ha_runner.py:26-33) in the same pass."""
+        T, N = self.episode_length, self.n_rollout_threads
+        nv = _as_dev(next_value, self.device).reshape(N)
+        vn = None if value_normalizer is None else value_normalizer.stats
+        gamma32 = float(np.float32(self.gamma))
+        gl32 = float(np.float32(self.gamma * self.gae_lambda))  # python-double product, then cast
+        call("harl_gae_returns", ptr(self.rewards), ptr(self.value_preds), ptr(self.masks), ptr(self.bad_masks), ptr(nv),
+             ptr(vn), ptr(self.returns), ptr(self.advantages), T, N, gamma32, gl32, int(self.use_gae),
+             int(self.use_proper_time_limits), 0, stream())
+
+    def flat(self, name: str) -> torch.Tensor:
+        t = getattr(self, name)
+        if name in ("share_obs", "masks", "bad_masks", "value_preds", "returns", "rnn_states_critic"):
+            t = t[:-1]
+        return t.reshape(self.episode_length * self.n_rollout_threads, -1)
+
+    def feed_forward_generator_critic(self, critic_num_mini_batch=None, mini_batch_size=None):
+        """API-compatible generator (critic_buffer_ep.py:202-250); ``VCritic.train`` uses index arrays instead."""
+        T, N = self.rewards.shape[:2]
+        B = T * N
+        if mini_batch_size is None:
+            sampler = minibatch_indices(B, critic_num_mini_batch)
+        else:
+            rand = torch.randperm(B)
+            sampler = [rand[i * mini_batch_size:(i + 1) * mini_batch_size] for i in range(critic_num_mini_batch)]
+        for ind in sampler:
+            i = ind.to(self.device)
+            yield (self.flat("share_obs")[i], self.flat("rnn_states_critic").reshape(B, self.recurrent_n, -1)[i],
+                   self.flat("value_preds")[i], self.flat("returns")[i], self.flat("masks")[i])

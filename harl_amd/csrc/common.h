@@ -1,0 +1,128 @@
+// common.h -- shared device helpers for the gfx950 kernels (wave64, MFMA 32x32x2 f32 layouts).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace harl {
+
+constexpr int WAVE = 64;
+constexpr int SLAB = 32;          // samples per wave-slab (N dimension of v_mfma_f32_32x32x2_f32)
+constexpr int WG_THREADS = 256;   // 4 waves
+constexpr int WAVES_PER_WG = 4;
+constexpr int PS_STRIDE = 48;     // floats per partial-scalar row: [0..8) scalars, [8..40) per-dim sums
+constexpr int DHEAD_LD = 32;      // row stride of the head-gradient matrix (head width padded to 32)
+
+void set_error(const char *msg);
+int check_launch(const char *what);
+
+// ---------------------------------------------------------------------------------------------
+// Register <-> feature map of the "C layout" of v_mfma_f32_32x32x2_f32 (cdna_hip_programming.md §3):
+// a 32x32 tile D[row][col]: lane l holds col = l & 31 and, in register r (0..15),
+// row = (r & 3) + 8*(r >> 2) + 4*(l >> 5).
+// We compute Y^T = W * X^T, i.e. tile rows = output features, tile cols = samples, so lane
+// (s = l&31, h = l>>5) holds sample s and, for register index R = 16*t + r of a width-H
+// activation, feature  f(R, h) = 32*t + (r&3) + 8*(r>>2) + 4*h.   Each lane holds H/2 features.
+// Because a GEMM's k order is free, the same register file is directly the B operand of the
+// next layer's MFMA (k-step R: half h supplies feature f(R,h)) -- no transpose between layers.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ constexpr int feat_base(int R) {  // f(R, 0)
+  return 32 * (R >> 4) + (R & 3) + 8 * ((R & 15) >> 2);
+}
+
+__device__ __forceinline__ float wave_xor32(float v) {  // exchange with the partner half (lane ^ 32)
+  return __shfl_xor(v, 32, 64);
+}
+
+// sum over the 32 lanes of each half (lanes 0-31 and 32-63 separately); result in every lane of the half
+__device__ __forceinline__ float half_reduce_sum(float v) {
+#pragma unroll
+  for (int o = 16; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_reduce_sum(float v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_reduce_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// ATL (activation tile layout): slab g of a width-H activation = [H/8][64 lanes][4] floats.
+template <int H>
+__device__ __forceinline__ void atl_load(const float *__restrict__ base, long slab, int lane, float (&x)[H / 2]) {
+  const f32x4 *p = reinterpret_cast<const f32x4 *>(base + slab * (long)(H * SLAB)) + lane;
+#pragma unroll
+  for (int q = 0; q < H / 8; ++q) {
+    f32x4 v = p[q * WAVE];
+    x[4 * q + 0] = v[0];
+    x[4 * q + 1] = v[1];
+    x[4 * q + 2] = v[2];
+    x[4 * q + 3] = v[3];
+  }
+}
+template <int H>
+__device__ __forceinline__ void atl_store(float *__restrict__ base, long slab, int lane, const float (&x)[H / 2]) {
+  f32x4 *p = reinterpret_cast<f32x4 *>(base + slab * (long)(H * SLAB)) + lane;
+#pragma unroll
+  for (int q = 0; q < H / 8; ++q) {
+    f32x4 v;
+    v[0] = x[4 * q + 0];
+    v[1] = x[4 * q + 1];
+    v[2] = x[4 * q + 2];
+    v[3] = x[4 * q + 3];
+    p[q * WAVE] = v;
+  }
+}
+
+// backward of  x_hat = norm(relu(z))  for one sample per lane-pair:
+//   da = rstd (dx_hat - mean_f(dx_hat) - x_hat mean_f(dx_hat x_hat)) ;  dz = relu_mask ? da : 0 ; store ATL
+template <int H>
+__device__ __forceinline__ void ln_bwd_relu_store(const float (&dx)[H / 2], const float (&xh)[H / 2],
+                                                  const uint32_t *__restrict__ mask_in, float rstd, int lane, long slab,
+                                                  float *__restrict__ dz_out) {
+  constexpr int NR = H / 2;
+  constexpr int NW = (NR + 31) / 32;
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int R = 0; R < NR; ++R) {
+    s1 += dx[R];
+    s2 += dx[R] * xh[R];
+  }
+  s1 += wave_xor32(s1);
+  s2 += wave_xor32(s2);
+  s1 *= (1.0f / H);
+  s2 *= (1.0f / H);
+  uint32_t bits[NW];
+#pragma unroll
+  for (int w = 0; w < NW; ++w) bits[w] = mask_in[(slab * NW + w) * WAVE + lane];
+  float out[NR];
+#pragma unroll
+  for (int R = 0; R < NR; ++R) {
+    float da = rstd * (dx[R] - s1 - xh[R] * s2);
+    out[R] = ((bits[R >> 5] >> (R & 31)) & 1u) ? da : 0.f;
+  }
+  atl_store<H>(dz_out, slab, lane, out);
+}
+
+// dynamic LDS above 64 KiB needs an explicit opt-in per kernel
+template <typename F>
+inline void allow_big_lds(F kernel, size_t bytes) {
+  if (bytes > 48 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)bytes);
+}
+
+inline long n_slabs_of(long M) { return (M + SLAB - 1) / SLAB; }
+inline int persistent_grid(long n_slabs, int wg_per_cu) {
+  long wgs = (n_slabs + WAVES_PER_WG - 1) / WAVES_PER_WG;
+  long cap = 256L * wg_per_cu;
+  return (int)(wgs < cap ? (wgs < 1 ? 1 : wgs) : cap);
+}
+
+}  // namespace harl

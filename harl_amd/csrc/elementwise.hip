@@ -1,0 +1,451 @@
+// elementwise.hip -- HBM-bound scan / reduction / optimiser kernels of the HAPPO update path (gfx950).
+//
+//   harl_gae_returns        reverse scan over t, one lane per rollout column (coalesced across n)
+//   harl_masked_moments     advantage statistics (masked sum / sumsq / count, fp64)
+//   harl_adv_normalize      (adv - mean) / (std + 1e-5)
+//   harl_factor_update      factor *= agg_d exp(new - old)
+//   harl_sum_sumsq / harl_valuenorm_apply   PopArt-style running statistics
+//   harl_gradnorm_clip_adam fused ||g|| + clip + Adam over one flat arena
+//   harl_fold_linear / harl_unfold_linear_grads / harl_reduce_partials / harl_reduce_scalars
+#include "common.h"
+#include "../../include/harl_hip.h"
+
+#include <cstdio>
+#include <cstring>
+
+namespace harl {
+static thread_local char g_err[512] = "";
+void set_error(const char *msg) {
+  std::strncpy(g_err, msg, sizeof(g_err) - 1);
+  g_err[sizeof(g_err) - 1] = 0;
+}
+int check_launch(const char *what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    char buf[512];
+    std::snprintf(buf, sizeof(buf), "%s: %s", what, hipGetErrorString(e));
+    set_error(buf);
+    return -1;
+  }
+  return 0;
+}
+}  // namespace harl
+
+using namespace harl;
+
+extern "C" int harl_version(void) { return 100; }
+extern "C" const char *harl_last_error(void) { return g_err; }
+
+// =============================================================================================
+// GAE / returns.  20 algorithmic bytes per (t, column): 4 loads + 1 store (+4 for advantages).
+// One lane per column: every load/store of a wave is 256 contiguous bytes.  The carry chain is
+// sequential in t but the *inputs* do not depend on it, so the loop is unrolled by 8 and the
+// compiler hoists the 8 steps' loads ahead of the dependent arithmetic (loads in flight per lane:
+// 32) -- that, plus >=2 waves per SIMD at N >= 64K columns... at N = 4096 there are only 64 waves,
+// so latency, not bandwidth, bounds this kernel; it is 0.1 % of the update either way.
+// Arithmetic is the reference's, operation for operation, with FMA contraction disabled, so
+// `returns` is bit-identical to NumPy's.
+// =============================================================================================
+struct DenormStats {
+  float mean, sd;
+  int on;
+};
+
+__device__ __forceinline__ DenormStats load_denorm(const float *vn) {
+#pragma clang fp contract(off)
+  DenormStats s;
+  s.on = vn != nullptr;
+  s.mean = 0.f;
+  s.sd = 1.f;
+  if (s.on) {  // valuenorm.py:38-45
+    float d = fmaxf(vn[2], 1e-5f);
+    float mean = vn[0] / d;
+    float mean_sq = vn[1] / d;
+    float var = fmaxf(mean_sq - mean * mean, 1e-2f);
+    s.mean = mean;
+    s.sd = sqrtf(var);
+  }
+  return s;
+}
+__device__ __forceinline__ float denorm(const DenormStats &s, float v) {
+#pragma clang fp contract(off)
+  if (!s.on) return v;
+  float t = v * s.sd;
+  return t + s.mean;
+}
+
+template <bool GAE, bool PTL, bool FP_ORDER>
+__global__ __launch_bounds__(256) void k_gae(const float *__restrict__ rewards, float *__restrict__ value_preds,
+                                             const float *__restrict__ masks, const float *__restrict__ bad_masks,
+                                             const float *__restrict__ next_value, const float *__restrict__ vn,
+                                             float *__restrict__ returns, float *__restrict__ adv, int T, int ncols,
+                                             float gamma, float gl) {
+#pragma clang fp contract(off)
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ncols) return;
+  const DenormStats ds = load_denorm(vn);
+  const long N = ncols;
+  float nv = next_value[c];
+  if (GAE) {
+    value_preds[(long)T * N + c] = nv;  // critic_buffer_ep.py:107
+    float gae = 0.f;
+    float v1 = nv;  // value_preds[t+1]
+    float dv1 = denorm(ds, v1);
+#pragma unroll 8
+    for (int t = T - 1; t >= 0; --t) {
+      float r = rewards[t * N + c];
+      float v0 = value_preds[t * N + c];
+      float m1 = masks[(t + 1) * N + c];
+      float dv0 = denorm(ds, v0);
+      float delta = r + (gamma * dv1) * m1;
+      delta = delta - dv0;
+      float carry = FP_ORDER ? (gl * gae) * m1 : (gl * m1) * gae;
+      gae = delta + carry;
+      if (PTL) gae = bad_masks[(t + 1) * N + c] * gae;
+      float ret = gae + dv0;
+      returns[t * N + c] = ret;
+      if (adv) adv[t * N + c] = ret - dv0;
+      dv1 = dv0;
+    }
+  } else {
+    float ret1 = nv;
+    returns[(long)T * N + c] = nv;
+#pragma unroll 8
+    for (int t = T - 1; t >= 0; --t) {
+      float r = rewards[t * N + c];
+      float m1 = masks[(t + 1) * N + c];
+      float dv0 = denorm(ds, value_preds[t * N + c]);
+      float ret = (ret1 * gamma) * m1 + r;
+      if (PTL) {
+        float b1 = bad_masks[(t + 1) * N + c];
+        ret = ret * b1 + (1.f - b1) * dv0;
+      }
+      returns[t * N + c] = ret;
+      if (adv) adv[t * N + c] = ret - dv0;
+      ret1 = ret;
+    }
+  }
+}
+
+extern "C" int harl_gae_returns(const float *rewards, float *value_preds, const float *masks,
+                                const float *bad_masks, const float *next_value, const float *vn_stats,
+                                float *returns, float *advantages, int T, int ncols, float gamma,
+                                float gamma_lambda, int use_gae, int use_proper_time_limits, int fp_order,
+                                void *stream) {
+  if (T <= 0 || ncols <= 0) return 0;
+  dim3 block(256), grid((ncols + 255) / 256);
+  hipStream_t s = (hipStream_t)stream;
+#define LAUNCH(G, P, F)                                                                                     \
+  hipLaunchKernelGGL((k_gae<G, P, F>), grid, block, 0, s, rewards, value_preds, masks, bad_masks, next_value, \
+                     vn_stats, returns, advantages, T, ncols, gamma, gamma_lambda)
+  if (use_gae) {
+    if (use_proper_time_limits) {
+      if (fp_order) LAUNCH(true, true, true); else LAUNCH(true, true, false);
+    } else {
+      if (fp_order) LAUNCH(true, false, true); else LAUNCH(true, false, false);
+    }
+  } else {
+    if (use_proper_time_limits) LAUNCH(false, true, false); else LAUNCH(false, false, false);
+  }
+#undef LAUNCH
+  return check_launch("harl_gae_returns");
+}
+
+// =============================================================================================
+// masked moments (fp64 accumulation; one atomic triple per block)
+// =============================================================================================
+__global__ __launch_bounds__(256) void k_masked_moments(const float *__restrict__ x, const float *__restrict__ active,
+                                                        long n, double *__restrict__ out3) {
+  double s1 = 0, s2 = 0, cnt = 0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float a = active ? active[i] : 1.f;
+    if (a != 0.f) {
+      double v = x[i];
+      s1 += v;
+      s2 += v * v;
+      cnt += 1.0;
+    }
+  }
+  s1 = wave_reduce_sum_d(s1);
+  s2 = wave_reduce_sum_d(s2);
+  cnt = wave_reduce_sum_d(cnt);
+  __shared__ double sh[3][4];
+  int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  if (l == 0) {
+    sh[0][w] = s1;
+    sh[1][w] = s2;
+    sh[2][w] = cnt;
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    double t = sh[threadIdx.x][0] + sh[threadIdx.x][1] + sh[threadIdx.x][2] + sh[threadIdx.x][3];
+    atomicAdd(&out3[threadIdx.x], t);
+  }
+}
+
+extern "C" int harl_masked_moments(const float *x, const float *active, long n, double *out3, void *stream) {
+  if (n <= 0) return 0;
+  long nb = (n + 2047) / 2048;
+  if (nb > 1024) nb = 1024;
+  hipLaunchKernelGGL(k_masked_moments, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x, active, n, out3);
+  return check_launch("harl_masked_moments");
+}
+
+__global__ __launch_bounds__(256) void k_adv_normalize(const float *__restrict__ adv, const double *__restrict__ mom,
+                                                       float *__restrict__ out, long n) {
+  double cnt = mom[2];
+  double meand = mom[0] / cnt;
+  double vard = mom[1] / cnt - meand * meand;
+  float mean = (float)meand;
+  float denom = (float)sqrt(vard > 0 ? vard : 0.0) + 1e-5f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    out[i] = (adv[i] - mean) / denom;
+}
+
+extern "C" int harl_adv_normalize(const float *adv, const double *moments3, float *adv_out, long n, void *stream) {
+  if (n <= 0) return 0;
+  long nb = (n + 1023) / 1024;
+  if (nb > 2048) nb = 2048;
+  hipLaunchKernelGGL(k_adv_normalize, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, adv, moments3, adv_out, n);
+  return check_launch("harl_adv_normalize");
+}
+
+// =============================================================================================
+// factor *= agg_d exp(new - old)
+// =============================================================================================
+__global__ __launch_bounds__(256) void k_factor_update(float *__restrict__ factor, const float *__restrict__ nl,
+                                                       const float *__restrict__ ol, long n, int D, int agg_mean) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float acc = agg_mean ? 0.f : 1.f;
+    for (int d = 0; d < D; ++d) {
+      float r = expf(nl[i * D + d] - ol[i * D + d]);
+      acc = agg_mean ? acc + r : acc * r;
+    }
+    if (agg_mean) acc = acc / (float)D;
+    factor[i] = factor[i] * acc;
+  }
+}
+
+extern "C" int harl_factor_update(float *factor, const float *new_logp, const float *old_logp, long n, int act_dim,
+                                  int agg_mean, void *stream) {
+  if (n <= 0) return 0;
+  long nb = (n + 255) / 256;
+  if (nb > 2048) nb = 2048;
+  hipLaunchKernelGGL(k_factor_update, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, factor, new_logp, old_logp,
+                     n, act_dim, agg_mean);
+  return check_launch("harl_factor_update");
+}
+
+// =============================================================================================
+// ValueNorm
+// =============================================================================================
+__global__ __launch_bounds__(256) void k_sum_sumsq(const float *__restrict__ x, const int64_t *__restrict__ idx, long m,
+                                                   double *__restrict__ out2) {
+  double s1 = 0, s2 = 0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (long)gridDim.x * blockDim.x) {
+    double v = x[idx ? idx[i] : i];
+    s1 += v;
+    s2 += v * v;
+  }
+  s1 = wave_reduce_sum_d(s1);
+  s2 = wave_reduce_sum_d(s2);
+  __shared__ double sh[2][4];
+  int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  if (l == 0) {
+    sh[0][w] = s1;
+    sh[1][w] = s2;
+  }
+  __syncthreads();
+  if (threadIdx.x < 2) atomicAdd(&out2[threadIdx.x], sh[threadIdx.x][0] + sh[threadIdx.x][1] + sh[threadIdx.x][2] + sh[threadIdx.x][3]);
+}
+
+extern "C" int harl_sum_sumsq(const float *x, const int64_t *idx, long m, double *sums2, void *stream) {
+  if (m <= 0) return 0;
+  long nb = (m + 2047) / 2048;
+  if (nb > 1024) nb = 1024;
+  hipLaunchKernelGGL(k_sum_sumsq, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x, idx, m, sums2);
+  return check_launch("harl_sum_sumsq");
+}
+
+__global__ void k_valuenorm_apply(float *__restrict__ vn, const double *__restrict__ sums2, double count, float w,
+                                  float omw) {
+#pragma clang fp contract(off)
+  if (threadIdx.x == 0 && blockIdx.x == 0) {  // valuenorm.py:47-64
+    float bm = (float)(sums2[0] / count);
+    float bsq = (float)(sums2[1] / count);
+    float rm = vn[0] * w;
+    vn[0] = rm + bm * omw;
+    float rs = vn[1] * w;
+    vn[1] = rs + bsq * omw;
+    float db = vn[2] * w;
+    vn[2] = db + omw;
+  }
+}
+
+extern "C" int harl_valuenorm_apply(float *vn_stats, const double *sums2, double count, double beta, void *stream) {
+  float w = (float)beta;
+  float omw = (float)(1.0 - beta);
+  hipLaunchKernelGGL(k_valuenorm_apply, dim3(1), dim3(64), 0, (hipStream_t)stream, vn_stats, sums2, count, w, omw);
+  return check_launch("harl_valuenorm_apply");
+}
+
+// =============================================================================================
+// grad-norm + clip + Adam, one workgroup (P <= a few 100 k elements; launch-latency class)
+// =============================================================================================
+__global__ __launch_bounds__(1024) void k_gradnorm_clip_adam(float *__restrict__ p, const float *__restrict__ g,
+                                                             float *__restrict__ m, float *__restrict__ v, long n,
+                                                             const float *__restrict__ grad_scale, int use_clip,
+                                                             float max_norm, float lr_over_bc1, float beta1,
+                                                             float beta2, float eps, float wd, float bc2_sqrt,
+                                                             float *__restrict__ info_out) {
+  const float scale = grad_scale ? *grad_scale : 1.f;
+  double ss = 0;
+  for (long i = threadIdx.x; i < n; i += blockDim.x) {
+    float gi = g[i] * scale;
+    ss += (double)gi * gi;
+  }
+  ss = wave_reduce_sum_d(ss);
+  __shared__ double sh[16];
+  __shared__ float s_coef;
+  int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  if (l == 0) sh[w] = ss;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += sh[i];
+    float norm = (float)sqrt(t);
+    float coef = 1.f;
+    if (use_clip) {  // torch clip_grad_norm_: coef = clamp(max_norm / (total + 1e-6), max=1); grads always scaled
+      coef = max_norm / (norm + 1e-6f);
+      coef = coef > 1.f ? 1.f : coef;
+    }
+    s_coef = coef;
+    if (info_out) info_out[0] += norm;
+  }
+  __syncthreads();
+  const float coef = s_coef * scale;
+  const float omb1 = 1.f - beta1, omb2 = 1.f - beta2;
+  for (long i = threadIdx.x; i < n; i += blockDim.x) {
+    float gi = g[i] * coef;
+    float pi = p[i];
+    if (wd != 0.f) gi = gi + wd * pi;
+    float mi = m[i];
+    mi = mi + omb1 * (gi - mi);                 // exp_avg.lerp_(grad, 1 - beta1)
+    float vi = v[i] * beta2 + (omb2 * gi) * gi;  // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1-beta2)
+    m[i] = mi;
+    v[i] = vi;
+    float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = pi - lr_over_bc1 * (mi / denom);
+  }
+}
+
+extern "C" int harl_gradnorm_clip_adam(float *param, float *grad, float *exp_avg, float *exp_avg_sq, long n,
+                                       const float *grad_scale, int use_clip, float max_norm, float lr, float beta1,
+                                       float beta2, float eps, float weight_decay, double bias_correction1,
+                                       double bias_correction2, float *info_out, void *stream) {
+  if (n <= 0) return 0;
+  float step_size = (float)((double)lr / bias_correction1);
+  float bc2_sqrt = (float)sqrt(bias_correction2);
+  hipLaunchKernelGGL(k_gradnorm_clip_adam, dim3(1), dim3(1024), 0, (hipStream_t)stream, param, grad, exp_avg,
+                     exp_avg_sq, n, grad_scale, use_clip, max_norm, step_size, beta1, beta2, eps, weight_decay, bc2_sqrt,
+                     info_out);
+  return check_launch("harl_gradnorm_clip_adam");
+}
+
+// =============================================================================================
+// LayerNorm-affine folding and its adjoint
+// =============================================================================================
+__global__ __launch_bounds__(64) void k_fold_linear(const float *__restrict__ W, const float *__restrict__ b,
+                                                    const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                    float *__restrict__ Wp, float *__restrict__ bp, int in_dim) {
+  int o = blockIdx.x;
+  float acc = 0.f;
+  for (int k = threadIdx.x; k < in_dim; k += 64) {
+    float w = W[(long)o * in_dim + k];
+    Wp[(long)o * in_dim + k] = gamma ? w * gamma[k] : w;
+    if (beta) acc += w * beta[k];
+  }
+  acc = wave_reduce_sum(acc);
+  if (threadIdx.x == 0) bp[o] = b[o] + acc;
+}
+
+extern "C" int harl_fold_linear(const float *W, const float *b, const float *gamma, const float *beta, float *Wp,
+                                float *bp, int out_dim, int in_dim, void *stream) {
+  hipLaunchKernelGGL(k_fold_linear, dim3(out_dim), dim3(64), 0, (hipStream_t)stream, W, b, gamma, beta, Wp, bp, in_dim);
+  return check_launch("harl_fold_linear");
+}
+
+// one block per input column k (dgamma/dbeta need a reduction over o), plus row work spread over threads
+__global__ __launch_bounds__(64) void k_unfold(const float *__restrict__ dWp, const float *__restrict__ dbp, int ldp,
+                                               const float *__restrict__ W, const float *__restrict__ gamma,
+                                               const float *__restrict__ beta, float *__restrict__ dW,
+                                               float *__restrict__ db, float *__restrict__ dgamma,
+                                               float *__restrict__ dbeta, int out_dim, int in_dim) {
+  int k = blockIdx.x;
+  float g = gamma ? gamma[k] : 1.f;
+  float be = beta ? beta[k] : 0.f;
+  float sg = 0.f, sb = 0.f;
+  for (int o = threadIdx.x; o < out_dim; o += 64) {
+    float dwp = dWp[(long)o * ldp + k];
+    float dbo = dbp[o];
+    float w = W[(long)o * in_dim + k];
+    dW[(long)o * in_dim + k] = dwp * g + dbo * be;
+    sg += w * dwp;
+    sb += w * dbo;
+    if (k == 0) db[o] = dbo;
+  }
+  if (dgamma) {
+    sg = wave_reduce_sum(sg);
+    sb = wave_reduce_sum(sb);
+    if (threadIdx.x == 0) {
+      dgamma[k] = sg;
+      dbeta[k] = sb;
+    }
+  }
+}
+
+extern "C" int harl_unfold_linear_grads(const float *dWp, const float *dbp, int ldp, const float *W,
+                                        const float *gamma, const float *beta, float *dW, float *db, float *dgamma,
+                                        float *dbeta, int out_dim, int in_dim, void *stream) {
+  hipLaunchKernelGGL(k_unfold, dim3(in_dim), dim3(64), 0, (hipStream_t)stream, dWp, dbp, ldp, W, gamma, beta, dW, db,
+                     dgamma, dbeta, out_dim, in_dim);
+  return check_launch("harl_unfold_linear_grads");
+}
+
+// deterministic fixed-order reduction of per-workgroup partials
+__global__ __launch_bounds__(256) void k_reduce_partials(const float *__restrict__ part, int n_wg, long elems,
+                                                         float *__restrict__ out) {
+  long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= elems) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int w = 0;
+  for (; w + 3 < n_wg; w += 4) {
+    s0 += part[(long)(w + 0) * elems + e];
+    s1 += part[(long)(w + 1) * elems + e];
+    s2 += part[(long)(w + 2) * elems + e];
+    s3 += part[(long)(w + 3) * elems + e];
+  }
+  for (; w < n_wg; ++w) s0 += part[(long)w * elems + e];
+  out[e] = (s0 + s1) + (s2 + s3);
+}
+
+extern "C" int harl_reduce_partials(const float *part, int n_wg, long elems, float *out, void *stream) {
+  if (elems <= 0) return 0;
+  hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, (hipStream_t)stream, part,
+                     n_wg, elems, out);
+  return check_launch("harl_reduce_partials");
+}
+
+__global__ __launch_bounds__(64) void k_reduce_scalars(const float *__restrict__ ps, int n_blocks,
+                                                       double *__restrict__ out) {
+  int j = threadIdx.x;
+  if (j >= PS_STRIDE) return;
+  double s = 0;
+  for (int b = 0; b < n_blocks; ++b) s += (double)ps[(long)b * PS_STRIDE + j];
+  out[j] += s;
+}
+
+extern "C" int harl_reduce_scalars(const float *part_scalars, int n_blocks, double *scalars, void *stream) {
+  hipLaunchKernelGGL(k_reduce_scalars, dim3(1), dim3(64), 0, (hipStream_t)stream, part_scalars, n_blocks, scalars);
+  return check_launch("harl_reduce_scalars");
+}

@@ -1,0 +1,564 @@
+// heads.hip -- action / value heads with fused losses and their backward up to dz_L (gfx950).
+//
+//   actor : DiagGaussian / Categorical head  -> log-probs  (+ fused factor product)            [logp pass]
+//           ... -> importance ratio, clipped surrogate x factor, entropy, d(loss)/d(head),
+//           d(loss)/d(x_hat_L) -> LayerNorm/relu backward -> dz_L                                [train pass]
+//   critic: v_out head -> values ; clipped + ValueNorm'd + Huber loss and backward to dz_L
+//
+// Reference: harl/models/base/act.py:104-157, harl/models/base/distributions.py:7-89,
+// harl/algorithms/actors/happo.py:56-91, harl/algorithms/critics/v_critic.py:75-114,
+// harl/runners/on_policy_ha_runner.py:66-124.
+//
+// The head is narrow (act_dim <= 32, value = 1), so it runs on the VALU rather than padding an MFMA
+// tile: lane (s,h) holds 64 of the 128 features of sample s (ATL register image); the folded head
+// weights sit in LDS as whl[h][R][DAP] so that every lane of a half reads the same address
+// (LDS broadcast, ds_read_b128).  The two halves' partial dot products are combined with one
+// lane^32 exchange, after which both lanes of a sample redundantly evaluate the (tiny) loss.
+// These kernels are HBM-bound: they read x_hat_L once and write dz_L once (1 KiB per sample).
+#include "common.h"
+#include "../../include/harl_hip.h"
+
+using namespace harl;
+
+namespace {
+constexpr float LOG_SQRT_2PI = 0.918938533204672741780329736406f;
+constexpr float HALF_LOG_2PI_PLUS_HALF = 1.418938533204672741780329736406f;
+
+struct ActorArgs {
+  const float *xL;
+  const uint32_t *relu_mask;
+  const float *rstd;
+  long M;
+  const float *Whp, *bhp, *log_std;
+  float std_x_coef, std_y_coef;
+  int act_dim;
+  const int64_t *idx;
+  const float *actions, *avail, *old_logp, *adv;
+  const double *adv_moments;
+  const float *factor_in, *active;
+  float clip_param, entropy_coef;
+  int agg_mean;
+  float *dzL, *dhead, *part_scalars;
+  float *logp_out, *factor_out;
+  long n_slabs;
+};
+
+template <int H, int DAP>
+__device__ __forceinline__ void stage_head(float *whl, float *cst, const float *__restrict__ Whp,
+                                           const float *__restrict__ bhp, int act_dim) {
+  // whl[hh][R][d] = Whp[d][f(R,hh)] ; cst[0..DAP) = bias
+  for (int e = threadIdx.x; e < 2 * (H / 2) * DAP; e += WG_THREADS) {
+    const int d = e % DAP, R = (e / DAP) % (H / 2), hh = e / (DAP * (H / 2));
+    const int f = feat_base(R) + 4 * hh;
+    whl[e] = d < act_dim ? Whp[d * H + f] : 0.f;
+  }
+  for (int e = threadIdx.x; e < DAP; e += WG_THREADS) {
+    cst[e] = e < act_dim ? bhp[e] : 0.f;
+    float rs = 0.f;  // row sum of the folded head weights: mean_f(dx_hat) needs no per-feature pass (see head_bwd_stream)
+    if (e < act_dim)
+      for (int f = 0; f < H; ++f) rs += Whp[e * H + f];
+    cst[4 * DAP + e] = rs;
+  }
+}
+
+// z[d] = bias[d] + sum_f x_hat[f] * Whp[d][f].  x_hat is streamed from the ATL image one float4 per
+// lane at a time (prefetched one step ahead) in a *rolled* loop: nothing but the DAP accumulators
+// stays live, so these HBM-bound kernels keep a small register footprint / high occupancy.
+template <int H, int DAP>
+__device__ __forceinline__ void head_fwd_stream(const float *__restrict__ xL, long slab, int lane,
+                                                const float *whl_h, const float *cst, float (&z)[DAP]) {
+#pragma unroll
+  for (int d = 0; d < DAP; ++d) z[d] = 0.f;
+  const f32x4 *xp = reinterpret_cast<const f32x4 *>(xL + slab * (long)(H * SLAB)) + lane;
+  f32x4 xv = xp[0];
+#pragma unroll 1
+  for (int q = 0; q < H / 8; ++q) {
+    const f32x4 xn = xp[(q + 1 < H / 8 ? q + 1 : q) * WAVE];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+      for (int dq = 0; dq < DAP / 4; ++dq) {
+        const f32x4 w = *reinterpret_cast<const f32x4 *>(whl_h + (4 * q + c) * DAP + 4 * dq);
+        z[4 * dq + 0] += xv[c] * w[0];
+        z[4 * dq + 1] += xv[c] * w[1];
+        z[4 * dq + 2] += xv[c] * w[2];
+        z[4 * dq + 3] += xv[c] * w[3];
+      }
+    }
+    xv = xn;
+  }
+#pragma unroll
+  for (int d = 0; d < DAP; ++d) z[d] = z[d] + wave_xor32(z[d]) + cst[d];
+}
+
+// dz_L = relu_mask ? rstd (dx_hat - mean_f(dx_hat) - x_hat mean_f(dx_hat x_hat)) : 0  with
+// dx_hat[f] = sum_d dzh[d] Whp[d][f].  Both feature means are closed forms of head-level quantities:
+//   mean_f(dx_hat)       = sum_d dzh[d] * rowsum(Whp[d]) / H
+//   mean_f(dx_hat x_hat) = sum_d dzh[d] * (z[d] - bias[d]) / H        (z = head forward output)
+// so the backward is a single streaming pass over x_hat (second read; L2 / Infinity-Cache resident).
+template <int H, int DAP>
+__device__ __forceinline__ void head_bwd_stream(const float *__restrict__ xL, const uint32_t *__restrict__ mask_in,
+                                                float rstd, long slab, int lane, const float *whl_h,
+                                                const float (&dzh)[DAP], float s1, float s2,
+                                                float *__restrict__ dz_out) {
+  constexpr int NW = (H / 2 + 31) / 32;
+  uint32_t b0 = mask_in[(slab * NW + 0) * WAVE + lane];
+  uint32_t b1 = NW > 1 ? mask_in[(slab * NW + (NW - 1)) * WAVE + lane] : 0u;
+  s1 *= (1.0f / H);
+  s2 *= (1.0f / H);
+  const f32x4 *xp = reinterpret_cast<const f32x4 *>(xL + slab * (long)(H * SLAB)) + lane;
+  f32x4 *op = reinterpret_cast<f32x4 *>(dz_out + slab * (long)(H * SLAB)) + lane;
+  f32x4 xv = xp[0];
+#pragma unroll 1
+  for (int q = 0; q < H / 8; ++q) {
+    const f32x4 xn = xp[(q + 1 < H / 8 ? q + 1 : q) * WAVE];
+    const uint32_t bits = ((q >> 3) ? b1 : b0) >> ((4 * q) & 31);
+    f32x4 o;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float dx = 0.f;
+#pragma unroll
+      for (int dq = 0; dq < DAP / 4; ++dq) {
+        const f32x4 w = *reinterpret_cast<const f32x4 *>(whl_h + (4 * q + c) * DAP + 4 * dq);
+        dx += dzh[4 * dq + 0] * w[0] + dzh[4 * dq + 1] * w[1] + dzh[4 * dq + 2] * w[2] + dzh[4 * dq + 3] * w[3];
+      }
+      const float da = rstd * (dx - s1 - xv[c] * s2);
+      o[c] = ((bits >> c) & 1u) ? da : 0.f;
+    }
+    op[q * WAVE] = o;
+    xv = xn;
+  }
+}
+
+// block-level reduction of NV per-lane partial sums -> part_scalars[blockIdx.x][0..NV)
+template <int NV>
+__device__ __forceinline__ void block_reduce_store(float (&v)[NV], float *red /*[4][PS_STRIDE]*/, float *out_row) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    float t = wave_reduce_sum(v[k]);
+    if (lane == 0) red[wave * PS_STRIDE + k] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x < PS_STRIDE) {
+    float t = 0.f;
+    if (threadIdx.x < NV)
+      t = (red[0 * PS_STRIDE + threadIdx.x] + red[1 * PS_STRIDE + threadIdx.x]) +
+          (red[2 * PS_STRIDE + threadIdx.x] + red[3 * PS_STRIDE + threadIdx.x]);
+    out_row[threadIdx.x] = t;
+  }
+}
+
+// =============================================================================================
+// actor head
+// =============================================================================================
+template <int H, int DAP, bool DISCRETE, bool TRAIN>
+__global__ __launch_bounds__(WG_THREADS) void k_actor_head(ActorArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float *whl = lds;                    // [2][H/2][DAP]
+  float *cst = whl + 2 * (H / 2) * DAP;  // bias[DAP], sigma[DAP], logsigma[DAP], dsigma_dlogstd[DAP], rowsum[DAP]
+  float *red = cst + 5 * DAP;          // [4][PS_STRIDE]
+  stage_head<H, DAP>(whl, cst, A.Whp, A.bhp, A.act_dim);
+  if (!DISCRETE) {
+    for (int e = threadIdx.x; e < DAP; e += WG_THREADS) {
+      float sg = 0.5f, sig = 1.f, lsig = 0.f, dsd = 0.f;
+      if (e < A.act_dim) {  // distributions.py:86-89: std = sigmoid(log_std / x_coef) * y_coef
+        sg = 1.0f / (1.0f + expf(-A.log_std[e] / A.std_x_coef));
+        sig = sg * A.std_y_coef;
+        lsig = logf(sig);
+        dsd = A.std_y_coef * sg * (1.f - sg) / A.std_x_coef;
+      }
+      cst[DAP + e] = sig;
+      cst[2 * DAP + e] = lsig;
+      cst[3 * DAP + e] = dsd;
+    }
+  }
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  const float *whl_h = whl + h * (H / 2) * DAP;
+  const int D = A.act_dim;
+  const int act_w = DISCRETE ? 1 : D;
+
+  float adv_mean = 0.f, adv_den = 1.f;
+  if (TRAIN && A.adv_moments) {  // happo.py:122-127
+    const double cnt = A.adv_moments[2];
+    const double m = A.adv_moments[0] / cnt;
+    const double var = A.adv_moments[1] / cnt - m * m;
+    adv_mean = (float)m;
+    adv_den = (float)sqrt(var > 0 ? var : 0.0) + 1e-5f;
+  }
+
+  // per-lane partial sums: 0 loss*active, 1 active, 2 ent*active, 3 ratio, 4 count, [8..8+DAP) dlogstd
+  float sc[8 + DAP];
+#pragma unroll
+  for (int k = 0; k < 8 + DAP; ++k) sc[k] = 0.f;
+
+  for (long slab = (long)blockIdx.x * WAVES_PER_WG + wave; slab < A.n_slabs; slab += (long)gridDim.x * WAVES_PER_WG) {
+    float z[DAP];
+    head_fwd_stream<H, DAP>(A.xL, slab, lane, whl_h, cst, z);
+    float zlin[DAP];  // x_hat . Whp[d]  (= z - bias), needed by the closed-form LayerNorm backward
+#pragma unroll
+    for (int d = 0; d < DAP; ++d) zlin[d] = z[d] - cst[d];
+
+    const long j = slab * SLAB + i;
+    const bool valid = j < A.M;
+    const long jc = valid ? j : A.M - 1;
+    const long row = A.idx ? A.idx[jc] : jc;
+    const bool count_me = valid && h == 0;
+
+    float dzh[DAP];  // d(unscaled loss)/d(head output)
+#pragma unroll
+    for (int d = 0; d < DAP; ++d) dzh[d] = 0.f;
+
+    float imp = 1.f;      // aggregated importance weight
+    float ratio_d[DAP];   // per-dim ratios (Gaussian) / [0] only (Categorical)
+    float ent = 0.f;
+    float logp_d[DAP];
+
+    if (!DISCRETE) {
+      float prod = 1.f, sum = 0.f;
+#pragma unroll
+      for (int d = 0; d < DAP; ++d) {
+        ratio_d[d] = 1.f;
+        logp_d[d] = 0.f;
+        if (d < D) {
+          const float sig = cst[DAP + d], lsig = cst[2 * DAP + d];
+          const float a = A.actions[row * act_w + d];
+          const float diff = a - z[d];
+          const float var = sig * sig;
+          const float lp = -(diff * diff) / (2.f * var) - lsig - LOG_SQRT_2PI;  // torch Normal.log_prob
+          logp_d[d] = lp;
+          ent += HALF_LOG_2PI_PLUS_HALF + lsig;
+          if (TRAIN || A.old_logp) {
+            const float r = expf(lp - A.old_logp[(TRAIN ? row : jc) * act_w + d]);
+            ratio_d[d] = r;
+            prod *= r;
+            sum += r;
+          }
+        }
+      }
+      imp = A.agg_mean ? sum / (float)D : prod;
+    } else {
+      // Categorical: logits masked to -1e10 where unavailable, normalised by logsumexp (distributions.py:52-55)
+      float mx = -3.0e38f;
+#pragma unroll
+      for (int d = 0; d < DAP; ++d) {
+        if (d < D) {
+          if (A.avail && A.avail[row * D + d] == 0.f) z[d] = -1e10f;
+          mx = fmaxf(mx, z[d]);
+        }
+      }
+      float se = 0.f;
+#pragma unroll
+      for (int d = 0; d < DAP; ++d)
+        if (d < D) se += expf(z[d] - mx);
+      const float lse = mx + logf(se);
+      const int a = (int)A.actions[row];
+      float lpa = 0.f;
+#pragma unroll
+      for (int d = 0; d < DAP; ++d) {
+        logp_d[d] = 0.f;
+        ratio_d[d] = 0.f;  // reused as p_d below
+        if (d < D) {
+          const float lp = z[d] - lse;
+          logp_d[d] = lp;
+          const float p = expf(lp);
+          ratio_d[d] = p;
+          ent -= fmaxf(lp, -3.4028234663852886e38f) * p;
+          if (d == a) lpa = lp;
+        }
+      }
+      if (TRAIN || A.old_logp) imp = expf(lpa - A.old_logp[TRAIN ? row : jc]);
+      // stash log p(a) in z[0] for the logp output below
+      z[0] = lpa;
+    }
+
+    if (!TRAIN) {
+      if (valid && h == 0) {
+        if (A.logp_out) {
+          if (DISCRETE) A.logp_out[j] = z[0];
+          else {
+#pragma unroll
+            for (int d = 0; d < DAP; ++d)
+              if (d < D) A.logp_out[j * D + d] = logp_d[d];
+          }
+        }
+        if (A.factor_out) A.factor_out[j] = A.factor_out[j] * imp;  // on_policy_ha_runner.py:116-124
+      }
+      continue;
+    }
+
+    // ---------------- loss + backward (happo.py:66-91) ----------------
+    const float act = A.active ? A.active[row] : 1.f;
+    const float advn = (A.adv[row] - adv_mean) / adv_den;
+    const float fct = A.factor_in[row];
+    const float lo = 1.f - A.clip_param, hi = 1.f + A.clip_param;
+    const float surr1 = imp * advn;
+    const float impc = fminf(fmaxf(imp, lo), hi);
+    const float surr2 = impc * advn;
+    const float mn = fminf(surr1, surr2);
+    const float inrange = (imp >= lo && imp <= hi) ? 1.f : 0.f;
+    // torch.min(a, b) backward: ties split the gradient evenly between the two inputs
+    float gsel = surr1 < surr2 ? 1.f : (surr1 > surr2 ? inrange : 0.5f + 0.5f * inrange);
+    const float dimp = valid ? -fct * act * advn * gsel : 0.f;  // d(sum_s -f*min*active)/d(imp)
+    const float ecoef = valid ? -A.entropy_coef * act : 0.f;    // weight of d(ent_s)
+
+    if (count_me) {
+      sc[0] += -fct * mn * act;
+      sc[1] += act;
+      sc[2] += ent * act;
+      sc[3] += imp;
+      sc[4] += 1.f;
+    }
+
+    if (!DISCRETE) {
+#pragma unroll
+      for (int d = 0; d < DAP; ++d) {
+        if (d < D) {
+          const float sig = cst[DAP + d];
+          const float var = sig * sig;
+          const float a = A.actions[row * act_w + d];
+          const float diff = a - z[d];
+          // d imp / d logp_d : prod -> prod/r_d * r_d ; mean -> r_d / D
+          const float dlp = dimp * (A.agg_mean ? ratio_d[d] / (float)D : imp);
+          dzh[d] = dlp * diff / var;
+          const float dsig = dlp * (diff * diff / (var * sig) - 1.f / sig) + ecoef / sig;
+          if (h == 0) sc[8 + d] += dsig * cst[3 * DAP + d];
+        }
+      }
+    } else {
+      const int a = (int)A.actions[row];
+      const float dlp = dimp * imp;
+#pragma unroll
+      for (int d = 0; d < DAP; ++d) {
+        if (d < D) {
+          const float p = ratio_d[d];
+          const float onehot = d == a ? 1.f : 0.f;
+          // d logp_a/dz_d = onehot - p_d ;  d ent/dz_d = -p_d (log p_d + ent)
+          dzh[d] = dlp * (onehot - p) + ecoef * (-p * (logp_d[d] + ent));
+          if (p == 0.f) dzh[d] = dlp * onehot;  // masked logits receive no gradient
+        }
+      }
+    }
+    // head gradients for the dW kernel: row j, 32 columns (lane half h writes 16 of them)
+    {
+      float *dh = A.dhead + j * DHEAD_LD + 16 * h;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        const int d = 16 * h + c;
+        float v = 0.f;
+#pragma unroll
+        for (int dd = 0; dd < DAP; ++dd)
+          if (dd == d) v = dzh[dd];
+        dh[c] = v;
+      }
+    }
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int d = 0; d < DAP; ++d) {
+      s1 += dzh[d] * cst[4 * DAP + d];
+      s2 += dzh[d] * zlin[d];
+    }
+    head_bwd_stream<H, DAP>(A.xL, A.relu_mask, A.rstd[slab * SLAB + i], slab, lane, whl_h, dzh, s1, s2, A.dzL);
+  }
+
+  if (TRAIN) block_reduce_store<8 + DAP>(sc, red, A.part_scalars + (long)blockIdx.x * PS_STRIDE);
+}
+
+// =============================================================================================
+// critic head
+// =============================================================================================
+struct CriticArgs {
+  const float *xL;
+  const uint32_t *relu_mask;
+  const float *rstd;
+  long M;
+  const float *Whp, *bhp;
+  const int64_t *idx;
+  const float *value_preds, *returns, *vn_stats;
+  float clip_param, huber_delta;
+  int use_clipped, use_huber;
+  float *dzL, *dhead, *part_scalars, *values_out;
+  long n_slabs;
+};
+
+template <int H, bool TRAIN>
+__global__ __launch_bounds__(WG_THREADS) void k_critic_head(CriticArgs A) {
+  constexpr int DAP = 4;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float *whl = lds;
+  float *cst = whl + 2 * (H / 2) * DAP;
+  float *red = cst + 5 * DAP;
+  stage_head<H, DAP>(whl, cst, A.Whp, A.bhp, 1);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  const float *whl_h = whl + h * (H / 2) * DAP;
+
+  float vmean = 0.f, vsd = 1.f;
+  if (TRAIN && A.vn_stats) {  // valuenorm.py:38-45
+    const float d = fmaxf(A.vn_stats[2], 1e-5f);
+    vmean = A.vn_stats[0] / d;
+    const float msq = A.vn_stats[1] / d;
+    vsd = sqrtf(fmaxf(msq - vmean * vmean, 1e-2f));
+  }
+  float sc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) sc[k] = 0.f;
+
+  for (long slab = (long)blockIdx.x * WAVES_PER_WG + wave; slab < A.n_slabs; slab += (long)gridDim.x * WAVES_PER_WG) {
+    float z[DAP];
+    head_fwd_stream<H, DAP>(A.xL, slab, lane, whl_h, cst, z);
+    const float v = z[0];
+    const long j = slab * SLAB + i;
+    const bool valid = j < A.M;
+    if (!TRAIN) {
+      if (valid && h == 0) A.values_out[j] = v;
+      continue;
+    }
+    const long jc = valid ? j : A.M - 1;
+    const long row = A.idx ? A.idx[jc] : jc;
+    const float vold = A.value_preds[row];
+    const float ret = A.returns[row];
+    const float eps = A.clip_param, dl = A.huber_delta;
+    const float diff = v - vold;
+    const float vclip = vold + fminf(fmaxf(diff, -eps), eps);
+    const float tgt = A.vn_stats ? (ret - vmean) / vsd : ret;
+    const float ec = tgt - vclip, eo = tgt - v;
+    float lc, lo_, gc, go;  // losses and d(loss)/d(e)
+    if (A.use_huber) {      // models_tools.py:64-68
+      lc = fabsf(ec) <= dl ? ec * ec / 2.f : dl * (fabsf(ec) - dl / 2.f);
+      lo_ = fabsf(eo) <= dl ? eo * eo / 2.f : dl * (fabsf(eo) - dl / 2.f);
+      gc = fabsf(ec) <= dl ? ec : (ec > 0.f ? dl : -dl);
+      go = fabsf(eo) <= dl ? eo : (eo > 0.f ? dl : -dl);
+    } else {
+      lc = ec * ec / 2.f;
+      lo_ = eo * eo / 2.f;
+      gc = ec;
+      go = eo;
+    }
+    const float inr = (diff >= -eps && diff <= eps) ? 1.f : 0.f;
+    float loss = lo_, dv = -go;
+    if (A.use_clipped) {  // torch.max: ties split the gradient evenly
+      if (lc > lo_) {
+        loss = lc;
+        dv = -gc * inr;
+      } else if (lc == lo_) {
+        dv = 0.5f * (-go) + 0.5f * (-gc * inr);
+      }
+    }
+    if (!valid) dv = 0.f;
+    if (valid && h == 0) {
+      sc[0] += loss;
+      sc[1] += 1.f;
+    }
+    {
+      float *dh = A.dhead + j * DHEAD_LD + 16 * h;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) dh[c] = (h == 0 && c == 0) ? dv : 0.f;
+    }
+    const float dzh[DAP] = {dv, 0.f, 0.f, 0.f};
+    head_bwd_stream<H, DAP>(A.xL, A.relu_mask, A.rstd[slab * SLAB + i], slab, lane, whl_h, dzh, dv * cst[4 * DAP],
+                            dv * (v - cst[0]), A.dzL);
+  }
+  if (TRAIN) block_reduce_store<8>(sc, red, A.part_scalars + (long)blockIdx.x * PS_STRIDE);
+}
+
+int head_grid(long M) { return persistent_grid(n_slabs_of(M), 4); }
+
+template <int H, int DAP, bool DISC, bool TRAIN>
+void launch_actor(const ActorArgs &A, int grid, hipStream_t s) {
+  const size_t shm = ((size_t)2 * (H / 2) * DAP + 5 * DAP + 4 * PS_STRIDE) * sizeof(float);
+  hipLaunchKernelGGL((k_actor_head<H, DAP, DISC, TRAIN>), dim3(grid), dim3(WG_THREADS), shm, s, A);
+}
+
+template <bool TRAIN>
+int dispatch_actor(const ActorArgs &A, int H, int discrete, int grid, hipStream_t s) {
+  const int D = A.act_dim;
+  if (D < 1 || D > 32) {
+    set_error("actor head: act_dim must be in [1, 32]");
+    return -2;
+  }
+  const int dap = D <= 4 ? 4 : (D <= 8 ? 8 : (D <= 16 ? 16 : 32));
+#define CASE(Hv, DAPv)                                                    \
+  if (H == Hv && dap == DAPv) {                                           \
+    if (discrete) launch_actor<Hv, DAPv, true, TRAIN>(A, grid, s);        \
+    else launch_actor<Hv, DAPv, false, TRAIN>(A, grid, s);                \
+    return check_launch("harl_actor_head");                               \
+  }
+  CASE(128, 4) CASE(128, 8) CASE(128, 16) CASE(128, 32) CASE(64, 4) CASE(64, 8) CASE(64, 16) CASE(64, 32)
+#undef CASE
+  set_error("actor head: hidden width must be 64 or 128");
+  return -2;
+}
+}  // namespace
+
+extern "C" int harl_head_blocks(long M) { return head_grid(M); }
+
+extern "C" int harl_actor_head_logp(const float *xL, long M, int H, const float *Whp, const float *bhp,
+                                    const float *log_std, float std_x_coef, float std_y_coef, int discrete,
+                                    int act_dim, const float *actions, const float *avail, float *logp_out,
+                                    const float *old_logp, float *factor, int agg_mean, void *stream) {
+  if (M <= 0) return 0;
+  ActorArgs A{};
+  A.xL = xL; A.M = M; A.Whp = Whp; A.bhp = bhp; A.log_std = log_std;
+  A.std_x_coef = std_x_coef; A.std_y_coef = std_y_coef; A.act_dim = act_dim;
+  A.actions = actions; A.avail = avail; A.old_logp = old_logp; A.agg_mean = agg_mean;
+  A.logp_out = logp_out; A.factor_out = factor; A.n_slabs = n_slabs_of(M);
+  if (factor && !old_logp) {
+    set_error("harl_actor_head_logp: factor update needs old_logp");
+    return -2;
+  }
+  return dispatch_actor<false>(A, H, discrete, head_grid(M), (hipStream_t)stream);
+}
+
+extern "C" int harl_actor_head_loss(const float *xL, const uint32_t *relu_mask, const float *rstd, long M, int H,
+                                    const float *Whp, const float *bhp, const float *log_std, float std_x_coef,
+                                    float std_y_coef, int discrete, int act_dim, const int64_t *idx,
+                                    const float *actions, const float *avail, const float *old_logp, const float *adv,
+                                    const double *adv_moments, const float *factor, const float *active,
+                                    float clip_param, float entropy_coef, int agg_mean, float *dzL, float *dhead,
+                                    float *part_scalars, void *stream) {
+  if (M <= 0) return 0;
+  ActorArgs A{};
+  A.xL = xL; A.relu_mask = relu_mask; A.rstd = rstd; A.M = M; A.Whp = Whp; A.bhp = bhp; A.log_std = log_std;
+  A.std_x_coef = std_x_coef; A.std_y_coef = std_y_coef; A.act_dim = act_dim; A.idx = idx;
+  A.actions = actions; A.avail = avail; A.old_logp = old_logp; A.adv = adv; A.adv_moments = adv_moments;
+  A.factor_in = factor; A.active = active; A.clip_param = clip_param; A.entropy_coef = entropy_coef;
+  A.agg_mean = agg_mean; A.dzL = dzL; A.dhead = dhead; A.part_scalars = part_scalars; A.n_slabs = n_slabs_of(M);
+  return dispatch_actor<true>(A, H, discrete, head_grid(M), (hipStream_t)stream);
+}
+
+extern "C" int harl_critic_head_values(const float *xL, long M, int H, const float *Whp, const float *bhp,
+                                       float *values, void *stream) {
+  if (M <= 0) return 0;
+  CriticArgs A{};
+  A.xL = xL; A.M = M; A.Whp = Whp; A.bhp = bhp; A.values_out = values; A.n_slabs = n_slabs_of(M);
+  const int grid = head_grid(M);
+  const size_t shm = ((size_t)2 * (H / 2) * 4 + 20 + 4 * PS_STRIDE) * sizeof(float);
+  if (H == 128) hipLaunchKernelGGL((k_critic_head<128, false>), dim3(grid), dim3(WG_THREADS), shm, (hipStream_t)stream, A);
+  else if (H == 64) hipLaunchKernelGGL((k_critic_head<64, false>), dim3(grid), dim3(WG_THREADS), shm, (hipStream_t)stream, A);
+  else { set_error("critic head: hidden width must be 64 or 128"); return -2; }
+  return check_launch("harl_critic_head_values");
+}
+
+extern "C" int harl_critic_head_loss(const float *xL, const uint32_t *relu_mask, const float *rstd, long M, int H,
+                                     const float *Whp, const float *bhp, const int64_t *idx, const float *value_preds,
+                                     const float *returns, const float *vn_stats, float clip_param, int use_clipped,
+                                     int use_huber, float huber_delta, float *dzL, float *dhead, float *part_scalars,
+                                     void *stream) {
+  if (M <= 0) return 0;
+  CriticArgs A{};
+  A.xL = xL; A.relu_mask = relu_mask; A.rstd = rstd; A.M = M; A.Whp = Whp; A.bhp = bhp; A.idx = idx;
+  A.value_preds = value_preds; A.returns = returns; A.vn_stats = vn_stats; A.clip_param = clip_param;
+  A.huber_delta = huber_delta; A.use_clipped = use_clipped; A.use_huber = use_huber; A.dzL = dzL; A.dhead = dhead;
+  A.part_scalars = part_scalars; A.n_slabs = n_slabs_of(M);
+  const int grid = head_grid(M);
+  const size_t shm = ((size_t)2 * (H / 2) * 4 + 20 + 4 * PS_STRIDE) * sizeof(float);
+  if (H == 128) hipLaunchKernelGGL((k_critic_head<128, true>), dim3(grid), dim3(WG_THREADS), shm, (hipStream_t)stream, A);
+  else if (H == 64) hipLaunchKernelGGL((k_critic_head<64, true>), dim3(grid), dim3(WG_THREADS), shm, (hipStream_t)stream, A);
+  else { set_error("critic head: hidden width must be 64 or 128"); return -2; }
+  return check_launch("harl_critic_head_loss");
+}

@@ -1,0 +1,544 @@
+// mlp.hip -- actor / critic MLP forward and backward on fp32 MFMA (v_mfma_f32_32x32x2_f32), gfx950.
+//
+// Replaces MLPBase/MLPLayer forward + autograd backward of the reference
+// (harl/models/base/mlp.py:7-70) for the HAPPO / V-critic update.
+//
+// Formulation (see common.h): every GEMM is computed transposed, Y^T[feature, sample] =
+// W[feature, k] * X^T[k, sample], with a wave owning 32 samples (the MFMA N dimension).  The
+// accumulator ("C") layout then has lane <-> sample and registers <-> features, which is *also*
+// a valid B-operand layout of the next GEMM (the k order of a dot product is free), so
+// activations chain from layer to layer with no transpose, LayerNorm statistics are an in-lane
+// sum plus one exchange with lane^32, and the activation tensors stored to HBM between kernels
+// are register images ("ATL"), read and written with full 1 KiB wave transactions.
+// The only transposes are in the weight-gradient kernel (the reduction runs over samples, so
+// samples must become the MFMA k index); they go through LDS.
+//
+// Weights live in LDS for the lifetime of a persistent workgroup (<= 66 KiB -> 2 workgroups per CU).
+#include "common.h"
+#include "../../include/harl_hip.h"
+
+using namespace harl;
+
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+// ---------------------------------------------------------------------------------------------
+// epilogue shared by both forward kernels: relu, relu bit-mask, LayerNorm statistics over the
+// H features of each sample (in-lane + partner half), normalise, store ATL / mask / rstd.
+// ---------------------------------------------------------------------------------------------
+template <int HO>
+__device__ __forceinline__ void relu_norm_store(f32x16 (&acc)[HO / 32], int lane, long slab, float *__restrict__ xout,
+                                                uint32_t *__restrict__ mask_out, float *__restrict__ rstd_out) {
+  constexpr int NR = HO / 2;
+  float v[NR];
+  uint32_t bits[(NR + 31) / 32];
+#pragma unroll
+  for (int w = 0; w < (NR + 31) / 32; ++w) bits[w] = 0u;
+  float sum = 0.f;
+#pragma unroll
+  for (int R = 0; R < NR; ++R) {
+    float a = acc[R >> 4][R & 15];
+    bool pos = a > 0.f;
+    a = pos ? a : 0.f;
+    bits[R >> 5] |= pos ? (1u << (R & 31)) : 0u;
+    v[R] = a;
+    sum += a;
+  }
+  sum += wave_xor32(sum);
+  const float mean = sum * (1.0f / HO);
+  float vs = 0.f;
+#pragma unroll
+  for (int R = 0; R < NR; ++R) {
+    float d = v[R] - mean;
+    vs += d * d;
+  }
+  vs += wave_xor32(vs);
+  const float rstd = 1.0f / sqrtf(vs * (1.0f / HO) + 1e-5f);
+#pragma unroll
+  for (int R = 0; R < NR; ++R) v[R] = (v[R] - mean) * rstd;
+  atl_store<HO>(xout, slab, lane, v);
+#pragma unroll
+  for (int w = 0; w < (NR + 31) / 32; ++w) mask_out[(slab * ((NR + 31) / 32) + w) * WAVE + lane] = bits[w];
+  if (lane < 32) rstd_out[slab * SLAB + lane] = rstd;
+}
+
+// =============================================================================================
+// hidden layer forward:  xout = norm(relu(Wp * xin + bp))       (ATL(HI) -> ATL(HO))
+// LDS: Wl[HO][HI+1] (odd row stride: the A-operand read "lane i -> row 32t+i, fixed k" hits 32
+// distinct banks) + bias.  Per wave-slab: HO/32 * HI/2 MFMAs, one ds_read_b32 each.
+// =============================================================================================
+template <int HI, int HO>
+__global__ __launch_bounds__(WG_THREADS, 2) void k_fwd_hidden(const float *__restrict__ xin,
+                                                              const float *__restrict__ Wp,
+                                                              const float *__restrict__ bp, float *__restrict__ xout,
+                                                              uint32_t *__restrict__ mask_out,
+                                                              float *__restrict__ rstd_out, long n_slabs) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int LDW = HI + 1;
+  float *Wl = lds;
+  float *bl = lds + HO * LDW;
+  for (int e = threadIdx.x; e < HO * HI; e += WG_THREADS) {
+    int o = e / HI, k = e - o * HI;
+    Wl[o * LDW + k] = Wp[e];
+  }
+  for (int e = threadIdx.x; e < HO; e += WG_THREADS) bl[e] = bp[e];
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  const float *wl_lane = Wl + i * LDW + 4 * h;
+  for (long slab = (long)blockIdx.x * WAVES_PER_WG + wave; slab < n_slabs; slab += (long)gridDim.x * WAVES_PER_WG) {
+    f32x16 acc[HO / 32];
+#pragma unroll
+    for (int t = 0; t < HO / 32; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = bl[32 * t + (r & 3) + 8 * (r >> 2) + 4 * h];
+    // x_hat_in is streamed 4 registers (one float4 of the ATL image) at a time, one step ahead of
+    // its use: the q loop stays rolled so the scheduler cannot hoist all HI*HO/64 LDS reads.
+    const f32x4 *xp = reinterpret_cast<const f32x4 *>(xin + slab * (long)(HI * SLAB)) + lane;
+    f32x4 xv = xp[0];
+#pragma unroll 1
+    for (int q = 0; q < HI / 8; ++q) {
+      const f32x4 xn = xp[(q + 1 < HI / 8 ? q + 1 : q) * WAVE];
+      const float *wq = wl_lane + 32 * (q >> 2) + 8 * (q & 3);  // feat_base(4q)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+#pragma unroll
+        for (int t = 0; t < HO / 32; ++t) {
+          const float a = wq[32 * t * LDW + c];
+          acc[t] = MFMA(a, xv[c], acc[t]);
+        }
+      }
+      xv = xn;
+    }
+    relu_norm_store<HO>(acc, lane, slab, xout, mask_out, rstd_out);
+  }
+}
+
+// =============================================================================================
+// first layer forward: rows of X (optionally gathered by idx), optional feature LayerNorm on the
+// raw input, then the same epilogue.  k is processed in chunks of 32 input features; within chunk
+// c (Dc valid features, KS = ceil(Dc/2) MFMA steps) step j feeds feature 32c + h*KS + j from lane
+// half h.  The transposed weights W'^T[k][o] stay resident in LDS when they fit (D <= 128 for
+// H = 128), otherwise they are re-staged chunk by chunk (wide observations, e.g. Humanoid 393).
+// =============================================================================================
+template <int HO>
+__global__ __launch_bounds__(WG_THREADS, 2) void k_fwd_input(const float *__restrict__ X, long ldx,
+                                                             const int64_t *__restrict__ idx, long M, int D,
+                                                             const float *__restrict__ Wp,
+                                                             const float *__restrict__ bp, int use_ln0,
+                                                             float *__restrict__ xout,
+                                                             uint32_t *__restrict__ mask_out,
+                                                             float *__restrict__ rstd_out, float *__restrict__ mu0_out,
+                                                             float *__restrict__ rstd0_out, long n_slabs, int nch,
+                                                             int resident) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int krows = resident ? nch * 32 : 32;
+  float *Wt = lds;               // [krows][HO]
+  float *bl = lds + krows * HO;  // [HO]
+  for (int e = threadIdx.x; e < HO; e += WG_THREADS) bl[e] = bp[e];
+  if (resident) {
+    for (int e = threadIdx.x; e < HO * krows; e += WG_THREADS) {
+      int o = e / krows, k = e - o * krows;
+      Wt[k * HO + o] = k < D ? Wp[(long)o * D + k] : 0.f;
+    }
+  }
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  const long stride = (long)gridDim.x * WAVES_PER_WG;
+  const long iters = (n_slabs + stride - 1) / stride;
+  for (long it = 0; it < iters; ++it) {
+    const long slab = (it * gridDim.x + blockIdx.x) * WAVES_PER_WG + wave;
+    const bool active = slab < n_slabs;
+    long j = slab * SLAB + i;
+    if (j > M - 1) j = M - 1;
+    if (j < 0) j = 0;
+    const long row = idx ? idx[j] : j;
+    const float *xr = X + row * ldx;
+
+    float mean = 0.f, rstd = 1.f;
+    if (use_ln0) {
+      float s = 0.f;
+      for (int c = 0; c < nch; ++c) {
+        const int Dc = min(32, D - 32 * c), KS = (Dc + 1) >> 1;
+        for (int jj = 0; jj < KS; ++jj) {
+          const int kl = h * KS + jj;
+          if (kl < Dc) s += xr[32 * c + kl];
+        }
+      }
+      s += wave_xor32(s);
+      mean = s / (float)D;
+      float vs = 0.f;
+      for (int c = 0; c < nch; ++c) {
+        const int Dc = min(32, D - 32 * c), KS = (Dc + 1) >> 1;
+        for (int jj = 0; jj < KS; ++jj) {
+          const int kl = h * KS + jj;
+          if (kl < Dc) {
+            float d = xr[32 * c + kl] - mean;
+            vs += d * d;
+          }
+        }
+      }
+      vs += wave_xor32(vs);
+      rstd = 1.0f / sqrtf(vs / (float)D + 1e-5f);
+    }
+
+    f32x16 acc[HO / 32];
+#pragma unroll
+    for (int t = 0; t < HO / 32; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = bl[32 * t + (r & 3) + 8 * (r >> 2) + 4 * h];
+
+    for (int c = 0; c < nch; ++c) {
+      if (!resident) {
+        __syncthreads();  // previous chunk fully consumed
+        for (int e = threadIdx.x; e < HO * 32; e += WG_THREADS) {
+          int o = e >> 5, kl = e & 31;
+          int k = 32 * c + kl;
+          Wt[kl * HO + o] = k < D ? Wp[(long)o * D + k] : 0.f;
+        }
+        __syncthreads();
+      }
+      const int Dc = min(32, D - 32 * c), KS = (Dc + 1) >> 1;
+      float xv[16];
+#pragma unroll
+      for (int jj = 0; jj < 16; ++jj) {
+        const int kl = h * KS + jj;
+        xv[jj] = (jj < KS && kl < Dc) ? (xr[32 * c + kl] - mean) * rstd : 0.f;
+      }
+      const float *wt_lane = Wt + ((resident ? 32 * c : 0) + h * KS) * HO + i;
+#pragma unroll
+      for (int jj = 0; jj < 16; ++jj) {
+        if (jj < KS) {
+#pragma unroll
+          for (int t = 0; t < HO / 32; ++t) {
+            const float a = wt_lane[jj * HO + 32 * t];
+            acc[t] = MFMA(a, xv[jj], acc[t]);
+          }
+        }
+      }
+    }
+    if (active) {
+      relu_norm_store<HO>(acc, lane, slab, xout, mask_out, rstd_out);
+      if (lane < 32) {
+        mu0_out[slab * SLAB + lane] = mean;
+        rstd0_out[slab * SLAB + lane] = rstd;
+      }
+    }
+  }
+}
+
+// =============================================================================================
+// backward through Linear(HI->HO) and the relu+norm in front of it:
+//   dx_hat = Wp^T dz ;  da = rstd (dx_hat - mean_f(dx_hat) - x_hat mean_f(dx_hat x_hat)) ;  dz_prev = mask ? da : 0
+// A operand = Wp^T: lane i -> input feature 32t+i, step R -> output feature f(R,h); Wp row-major
+// in LDS is read with consecutive addresses by the 32 lanes of a half (conflict-free).
+// =============================================================================================
+template <int HO, int HI>
+__global__ __launch_bounds__(WG_THREADS, 2) void k_bwd_dx(const float *__restrict__ dz, const float *__restrict__ xprev,
+                                                          const uint32_t *__restrict__ mask_prev,
+                                                          const float *__restrict__ rstd_prev,
+                                                          const float *__restrict__ Wp, float *__restrict__ dz_prev,
+                                                          long n_slabs) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float *Wl = lds;  // [HO][HI] row-major
+  for (int e = threadIdx.x; e < HO * HI; e += WG_THREADS) Wl[e] = Wp[e];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  const float *wl_lane = Wl + 4 * h * HI + i;
+  for (long slab = (long)blockIdx.x * WAVES_PER_WG + wave; slab < n_slabs; slab += (long)gridDim.x * WAVES_PER_WG) {
+    f32x16 acc[HI / 32];
+#pragma unroll
+    for (int t = 0; t < HI / 32; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const f32x4 *gp = reinterpret_cast<const f32x4 *>(dz + slab * (long)(HO * SLAB)) + lane;
+    f32x4 gv = gp[0];
+#pragma unroll 1
+    for (int q = 0; q < HO / 8; ++q) {
+      const f32x4 gn = gp[(q + 1 < HO / 8 ? q + 1 : q) * WAVE];
+      const float *wq = wl_lane + (32 * (q >> 2) + 8 * (q & 3)) * HI;  // row feat_base(4q) (+4h in wl_lane)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+#pragma unroll
+        for (int t = 0; t < HI / 32; ++t) {
+          const float a = wq[c * HI + 32 * t];
+          acc[t] = MFMA(a, gv[c], acc[t]);
+        }
+      }
+      gv = gn;
+    }
+    float xh[HI / 2];
+    atl_load<HI>(xprev, slab, lane, xh);
+    const float rstd = rstd_prev[slab * SLAB + i];
+    float dx[HI / 2];
+#pragma unroll
+    for (int R = 0; R < HI / 2; ++R) dx[R] = acc[R >> 4][R & 15];
+    ln_bwd_relu_store<HI>(dx, xh, mask_prev, rstd, lane, slab, dz_prev);
+  }
+}
+
+// =============================================================================================
+// weight-gradient partials  dWp[o][k] = sum_s dz[s][o] * x_hat[s][k],  dbp[o] = sum_s dz[s][o].
+// The reduction index (samples) must be the MFMA k index, i.e. both operands are needed with
+// lane <-> feature: each iteration stages 64 samples of both operands into LDS as [sample][feature]
+// (ds_write_b128 from the ATL register image, row stride 32*tiles+4 floats: conflict-free for the
+// 8-lane write groups and for the 32-lane ds_read_b32 fragment reads), then the 4 waves split the
+// 32x32 output tiles and run 32 MFMA steps per tile.  Accumulators persist across the workgroup's
+// iterations; the per-workgroup partial is written once and reduced in fixed order afterwards.
+//   A_KIND 0: dz in ATL (HO = 32*MT)      1: row-major [M_pad][DHEAD_LD] head gradients (MT = 1)
+//   B_KIND 0: x_hat in ATL (K = 32*NT)    1: raw X rows (gather + input-LayerNorm on the fly),
+//                                            blockIdx.y selects a group of NT 32-wide k tiles
+// =============================================================================================
+constexpr int DW_S = 64;  // samples per staging round
+
+template <int MT, int NT>
+struct DwSplit {
+  static constexpr int WM = MT >= 4 ? 4 : (MT == 2 ? 2 : 1);
+  static constexpr int WN = 4 / WM;
+  static constexpr int TM = MT / WM;
+  static constexpr int TN = (NT + WN - 1) / WN;
+};
+
+template <int A_KIND, int B_KIND, int MT, int NT>
+__global__ __launch_bounds__(WG_THREADS, 2) void k_dw(const float *__restrict__ a_src, const float *__restrict__ b_src,
+                                                      long ldx, const int64_t *__restrict__ idx,
+                                                      const float *__restrict__ mu0, const float *__restrict__ rstd0,
+                                                      int K, long M, long n_slabs, float *__restrict__ part, int KP) {
+  using SP = DwSplit<MT, NT>;
+  constexpr int LDA = 32 * MT + 4, LDB = 32 * NT + 4;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float *As = lds;               // [DW_S][LDA]
+  float *Bs = lds + DW_S * LDA;  // [DW_S][LDB]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  const int wm = wave % SP::WM, wn = wave / SP::WM;
+  const int k0 = blockIdx.y * (32 * NT);  // first input feature handled by this workgroup (B_KIND 1)
+
+  f32x16 acc[SP::TM][SP::TN];
+  float dbsum[SP::TM];
+#pragma unroll
+  for (int a = 0; a < SP::TM; ++a) {
+    dbsum[a] = 0.f;
+#pragma unroll
+    for (int b = 0; b < SP::TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  }
+
+  const long n_iter = (n_slabs + 1) / 2;
+  for (long it = blockIdx.x; it < n_iter; it += gridDim.x) {
+    __syncthreads();  // previous round's fragments fully read
+    // ---- stage A (waves 0,1: slab 2it, 2it+1)  and  B (waves 2,3)
+    {
+      const int sl = wave & 1;
+      const long slab = 2 * it + sl;
+      const bool ok = slab < n_slabs;
+      if (wave < 2) {
+        if (A_KIND == 0) {
+          constexpr int H = 32 * MT;
+          const f32x4 *p = reinterpret_cast<const f32x4 *>(a_src + slab * (long)(H * SLAB)) + lane;
+#pragma unroll
+          for (int q = 0; q < H / 8; ++q) {
+            f32x4 v = ok ? p[q * WAVE] : f32x4{0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4 *>(&As[(sl * SLAB + i) * LDA + 32 * (q >> 2) + 8 * (q & 3) + 4 * h]) = v;
+          }
+        } else {  // [M_pad][32] row-major: lane -> 16 consecutive floats of one row
+          const float *p = a_src + (slab * SLAB + i) * (long)DHEAD_LD + 16 * h;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            f32x4 v = ok ? *reinterpret_cast<const f32x4 *>(p + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4 *>(&As[(sl * SLAB + i) * LDA + 16 * h + 4 * q]) = v;
+          }
+        }
+      } else {
+        if (B_KIND == 0) {
+          constexpr int H = 32 * NT;
+          const f32x4 *p = reinterpret_cast<const f32x4 *>(b_src + slab * (long)(H * SLAB)) + lane;
+#pragma unroll
+          for (int q = 0; q < H / 8; ++q) {
+            f32x4 v = ok ? p[q * WAVE] : f32x4{0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4 *>(&Bs[(sl * SLAB + i) * LDB + 32 * (q >> 2) + 8 * (q & 3) + 4 * h]) = v;
+          }
+        } else {  // raw rows: lanes sweep the row (coalesced), one sample after the other
+          for (int s = 0; s < SLAB; ++s) {
+            long j = slab * SLAB + s;
+            if (j > M - 1) j = M - 1;
+            if (j < 0) j = 0;
+            const long row = idx ? idx[j] : j;
+            const float mu = mu0 ? mu0[slab * SLAB + s] : 0.f;
+            const float rs = rstd0 ? rstd0[slab * SLAB + s] : 1.f;
+            for (int kk = lane; kk < 32 * NT; kk += WAVE) {
+              const int k = k0 + kk;
+              float v = (ok && k < K) ? (b_src[row * ldx + k] - mu) * rs : 0.f;
+              Bs[(sl * SLAB + s) * LDB + kk] = v;
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // ---- MFMA over the 64 staged samples (32 steps of 2)
+#pragma unroll 4
+    for (int kk = 0; kk < DW_S / 2; ++kk) {
+      const int srow = 2 * kk + h;
+      float av[SP::TM], bv[SP::TN];
+#pragma unroll
+      for (int a = 0; a < SP::TM; ++a) {
+        av[a] = As[srow * LDA + 32 * (wm * SP::TM + a) + i];
+        if (wn == 0) dbsum[a] += av[a];
+      }
+#pragma unroll
+      for (int b = 0; b < SP::TN; ++b) {
+        const int nt = wn * SP::TN + b;
+        bv[b] = nt < NT ? Bs[srow * LDB + 32 * nt + i] : 0.f;
+      }
+#pragma unroll
+      for (int a = 0; a < SP::TM; ++a)
+#pragma unroll
+        for (int b = 0; b < SP::TN; ++b) acc[a][b] = MFMA(av[a], bv[b], acc[a][b]);
+    }
+  }
+
+  // ---- write this workgroup's partial: dWp[32*MT][KP] then dbp[32*MT]
+  float *mypart = part + (long)blockIdx.x * ((long)32 * MT * KP + 32 * MT);
+#pragma unroll
+  for (int a = 0; a < SP::TM; ++a) {
+    const int mt = wm * SP::TM + a;
+#pragma unroll
+    for (int b = 0; b < SP::TN; ++b) {
+      const int nt = wn * SP::TN + b;
+      if (nt < NT) {
+        const int kcol = k0 + 32 * nt + i;
+        if (kcol < KP) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int o = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * h;
+            mypart[(long)o * KP + kcol] = acc[a][b][r];
+          }
+        }
+      }
+    }
+    if (wn == 0 && blockIdx.y == 0) {
+      float t = dbsum[a] + wave_xor32(dbsum[a]);
+      if (h == 0) mypart[(long)32 * MT * KP + 32 * mt + i] = t;
+    }
+  }
+}
+
+// =============================================================================================
+// host launchers
+// =============================================================================================
+static int bad(const char *m) {
+  set_error(m);
+  return -2;
+}
+
+extern "C" int harl_mlp_fwd_input(const float *X, long ldx, const int64_t *idx, long M, int D, const float *Wp,
+                                  const float *bp, int use_ln0, int H, float *xout, uint32_t *relu_mask, float *rstd,
+                                  float *mu0, float *rstd0, void *stream) {
+  if (M <= 0) return 0;
+  const long n_slabs = n_slabs_of(M);
+  const int nch = (D + 31) / 32;
+  const int resident = (long)nch * 32 * H * 4 <= 64 * 1024;
+  const size_t shm = ((size_t)(resident ? nch * 32 : 32) * H + H) * sizeof(float);
+  const int grid = persistent_grid(n_slabs, 2);
+  hipStream_t s = (hipStream_t)stream;
+  if (H == 128)
+    hipLaunchKernelGGL((k_fwd_input<128>), dim3(grid), dim3(WG_THREADS), shm, s, X, ldx, idx, M, D, Wp, bp, use_ln0,
+                       xout, relu_mask, rstd, mu0, rstd0, n_slabs, nch, resident);
+  else if (H == 64)
+    hipLaunchKernelGGL((k_fwd_input<64>), dim3(grid), dim3(WG_THREADS), shm, s, X, ldx, idx, M, D, Wp, bp, use_ln0,
+                       xout, relu_mask, rstd, mu0, rstd0, n_slabs, nch, resident);
+  else
+    return bad("harl_mlp_fwd_input: hidden width must be 64 or 128");
+  return check_launch("harl_mlp_fwd_input");
+}
+
+extern "C" int harl_mlp_fwd_hidden(const float *xin, long M, int HI, int HO, const float *Wp, const float *bp,
+                                   float *xout, uint32_t *relu_mask, float *rstd, void *stream) {
+  if (M <= 0) return 0;
+  const long n_slabs = n_slabs_of(M);
+  const size_t shm = ((size_t)HO * (HI + 1) + HO) * sizeof(float);
+  const int grid = persistent_grid(n_slabs, 2);
+  hipStream_t s = (hipStream_t)stream;
+#define L(a, b)                                                                                                  \
+  hipLaunchKernelGGL((k_fwd_hidden<a, b>), dim3(grid), dim3(WG_THREADS), shm, s, xin, Wp, bp, xout, relu_mask, rstd, \
+                     n_slabs)
+  if (HI == 128 && HO == 128) L(128, 128);
+  else if (HI == 64 && HO == 64) L(64, 64);
+  else if (HI == 128 && HO == 64) L(128, 64);
+  else if (HI == 64 && HO == 128) L(64, 128);
+  else return bad("harl_mlp_fwd_hidden: widths must be 64 or 128");
+#undef L
+  return check_launch("harl_mlp_fwd_hidden");
+}
+
+extern "C" int harl_mlp_bwd_dx(const float *dz, const float *xprev, const uint32_t *relu_mask_prev,
+                               const float *rstd_prev, long M, int HO, int HI, const float *Wp, float *dz_prev,
+                               void *stream) {
+  if (M <= 0) return 0;
+  const long n_slabs = n_slabs_of(M);
+  const size_t shm = (size_t)HO * HI * sizeof(float);
+  const int grid = persistent_grid(n_slabs, 2);
+  hipStream_t s = (hipStream_t)stream;
+#define L(a, b)                                                                                                    \
+  hipLaunchKernelGGL((k_bwd_dx<a, b>), dim3(grid), dim3(WG_THREADS), shm, s, dz, xprev, relu_mask_prev, rstd_prev, Wp, \
+                     dz_prev, n_slabs)
+  if (HO == 128 && HI == 128) L(128, 128);
+  else if (HO == 64 && HI == 64) L(64, 64);
+  else if (HO == 128 && HI == 64) L(128, 64);
+  else if (HO == 64 && HI == 128) L(64, 128);
+  else return bad("harl_mlp_bwd_dx: widths must be 64 or 128");
+#undef L
+  return check_launch("harl_mlp_bwd_dx");
+}
+
+template <int A_KIND, int B_KIND, int MT, int NT>
+static void launch_dw(const float *a, const float *b, long ldx, const int64_t *idx, const float *mu0,
+                      const float *rstd0, int K, long M, long n_slabs, float *part, int KP, int n_wg, int ny,
+                      hipStream_t s) {
+  const size_t shm = (size_t)DW_S * ((32 * MT + 4) + (32 * NT + 4)) * sizeof(float);
+  hipLaunchKernelGGL((k_dw<A_KIND, B_KIND, MT, NT>), dim3(n_wg, ny), dim3(WG_THREADS), shm, s, a, b, ldx, idx, mu0,
+                     rstd0, K, M, n_slabs, part, KP);
+}
+
+extern "C" int harl_mlp_dw_partials(const float *a, int a_kind, int lda, int HO, const float *b, int b_kind, long ldx,
+                                    const int64_t *idx, const float *mu0, const float *rstd0, int K, long M,
+                                    float *part, int n_wg, void *stream) {
+  if (M <= 0 || n_wg <= 0) return 0;
+  const long n_slabs = n_slabs_of(M);
+  const int KP = ((K + 31) / 32) * 32;
+  hipStream_t s = (hipStream_t)stream;
+  if (a_kind == 1 && lda != DHEAD_LD) return bad("harl_mlp_dw_partials: head gradient matrix must have row stride 32");
+  const int MT = a_kind == 1 ? 1 : HO / 32;
+  if (a_kind == 0 && HO != 64 && HO != 128) return bad("harl_mlp_dw_partials: HO must be 64 or 128");
+  if (a_kind == 1 && HO > 32) return bad("harl_mlp_dw_partials: head width must be <= 32");
+#define DW(AK, BK, MTv, NTv, ny) launch_dw<AK, BK, MTv, NTv>(a, b, ldx, idx, mu0, rstd0, K, M, n_slabs, part, KP, n_wg, ny, s)
+  if (b_kind == 0) {
+    const int NT = K / 32;
+    if (K != 64 && K != 128) return bad("harl_mlp_dw_partials: ATL input width must be 64 or 128");
+    if (MT == 4 && NT == 4) DW(0, 0, 4, 4, 1);
+    else if (MT == 4 && NT == 2) DW(0, 0, 4, 2, 1);
+    else if (MT == 2 && NT == 4) DW(0, 0, 2, 4, 1);
+    else if (MT == 2 && NT == 2) DW(0, 0, 2, 2, 1);
+    else if (MT == 1 && NT == 4) DW(1, 0, 1, 4, 1);
+    else if (MT == 1 && NT == 2) DW(1, 0, 1, 2, 1);
+    else return bad("harl_mlp_dw_partials: unsupported tile shape");
+  } else {
+    const int ktiles = KP / 32;
+    if (a_kind != 0) return bad("harl_mlp_dw_partials: raw-input B operand needs an ATL A operand");
+    if (ktiles == 1) {
+      if (MT == 4) DW(0, 1, 4, 1, 1); else DW(0, 1, 2, 1, 1);
+    } else if (ktiles == 2) {
+      if (MT == 4) DW(0, 1, 4, 2, 1); else DW(0, 1, 2, 2, 1);
+    } else {
+      const int ny = (ktiles + 3) / 4;
+      if (MT == 4) DW(0, 1, 4, 4, ny); else DW(0, 1, 2, 4, ny);
+    }
+  }
+#undef DW
+  return check_launch("harl_mlp_dw_partials");
+}

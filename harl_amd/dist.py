@@ -1,0 +1,73 @@
+"""Data-parallel plumbing: one process per GPU, ``torch.distributed`` (backend "nccl" = RCCL over xGMI).
+
+The update shards ``n_rollout_threads`` across ranks (columns are independent in GAE, in the forward/backward
+and in the factor product -- SURVEY.md §8e); parameters, Adam state and ValueNorm statistics are replicated.
+The only exchange steps are SUM all-reduces of (a) the flat gradient arena with the loss scalars packed behind
+it, (b) the advantage moments, (c) the ValueNorm batch sums.  With world_size == 1 everything is a no-op.
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+class Comm:
+    """Thin wrapper so the algorithm code is identical for 1 and N ranks (and for gloo in CPU tests)."""
+
+    def __init__(self, group=None):
+        self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.group = group
+        self.world_size = dist.get_world_size(group) if self.enabled else 1
+        self.rank = dist.get_rank(group) if self.enabled else 0
+
+    def all_reduce_sum(self, t: torch.Tensor) -> torch.Tensor:
+        if self.enabled:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t
+
+    def all_reduce_packed(self, flat_grad: torch.Tensor, scalars64: torch.Tensor, staging: torch.Tensor) -> None:
+        """One collective per optimiser step: [grad | hi(scalars) | lo(scalars)] in fp32.
+        The fp64 loss scalars are split into an fp32 head + fp32 residual so a single fp32 SUM all-reduce
+        carries them with ~48 bits; ``staging`` has flat_grad.numel() + 2*scalars64.numel() fp32 elements."""
+        if not self.enabled:
+            return
+        n, k = flat_grad.numel(), scalars64.numel()
+        staging[:n].copy_(flat_grad)
+        hi = scalars64.to(torch.float32)
+        staging[n:n + k].copy_(hi)
+        staging[n + k:n + 2 * k].copy_((scalars64 - hi.to(torch.float64)).to(torch.float32))
+        dist.all_reduce(staging, op=dist.ReduceOp.SUM, group=self.group)
+        flat_grad.copy_(staging[:n])
+        scalars64.copy_(staging[n:n + k].to(torch.float64) + staging[n + k:n + 2 * k].to(torch.float64))
+
+
+def shard_columns(n_rollout_threads: int, rank: int, world_size: int) -> Tuple[int, int]:
+    """Rank r owns rollout columns [lo, hi): contiguous, sizes differ by at most one."""
+    base, rem = divmod(n_rollout_threads, world_size)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def local_minibatch_rows(global_idx: torch.Tensor, n_global: int, lo: int, hi: int) -> torch.Tensor:
+    """Rows of a GLOBAL minibatch permutation (row = t*N + n over the unsharded buffer, identical on every rank
+    and bit-identical to the reference's draw) that fall into this rank's column range, re-indexed to the
+    local [T, hi-lo] buffer.  Order within the minibatch is preserved."""
+    t = torch.div(global_idx, n_global, rounding_mode="floor")
+    n = global_idx - t * n_global
+    keep = (n >= lo) & (n < hi)
+    return t[keep] * (hi - lo) + (n[keep] - lo)
+
+
+def init_from_env(backend: Optional[str] = None) -> Comm:
+    """torchrun-style rendezvous (RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT / LOCAL_RANK)."""
+    ws = int(os.environ.get("WORLD_SIZE", "1"))
+    if ws > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        dist.init_process_group(backend=backend)
+    return Comm()

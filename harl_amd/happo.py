@@ -1,0 +1,192 @@
+"""HAPPO on MI355X: same class surface as the reference (harl/algorithms/actors/on_policy_base.py:8-137,
+harl/algorithms/actors/happo.py:10-158), arithmetic in libharl_hip.so.
+
+One ``update`` = fold -> trunk forward (MFMA) -> fused head/loss/backward-to-dz_L -> weight-gradient partials
+(MFMA) -> deterministic reduce + unfold -> [data-parallel all-reduce] -> fused grad-norm/clip/Adam.  Nothing
+returns to the host inside ``train()`` except the int64 minibatch permutations going up and one small read-back
+of the accumulated training statistics at the end.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import PS_STRIDE, call, ptr, stream
+from .buffers import OnPolicyActorBuffer, minibatch_indices
+from .dist import Comm, local_minibatch_rows
+from .nets import FusedAdam, StochasticPolicy
+from .valuenorm import _as_dev
+
+
+class OnPolicyBase:
+    """Actor + optimiser (reference: actors/on_policy_base.py:8-137)."""
+
+    def __init__(self, args, obs_space, act_space, device=torch.device("cuda:0")):
+        self.args = args
+        self.device = torch.device(device)
+        _lib.require_gpu(self.device)
+        self.tpdv = dict(dtype=torch.float32, device=self.device)
+        self.data_chunk_length = args["data_chunk_length"]
+        self.use_recurrent_policy = args["use_recurrent_policy"]
+        self.use_naive_recurrent_policy = args["use_naive_recurrent_policy"]
+        self.use_policy_active_masks = args["use_policy_active_masks"]
+        self.action_aggregation = args["action_aggregation"]
+        self.lr = args["lr"]
+        self.opti_eps = args["opti_eps"]
+        self.weight_decay = args["weight_decay"]
+        self.obs_space = obs_space
+        self.act_space = act_space
+        self.actor = StochasticPolicy(args, obs_space, act_space, self.device)
+        self.actor_optimizer = FusedAdam(self.actor, self.lr, self.opti_eps, self.weight_decay)
+        self.comm = Comm()
+        self.shard = None  # (n_global, lo, hi) when n_rollout_threads is sharded across ranks
+        self._old_logp: Optional[torch.Tensor] = None
+
+    def lr_decay(self, episode, episodes):  # utils/models_tools.py:77-87
+        lr = self.lr - (self.lr * ((episode - 1) / float(episodes)))
+        for g in self.actor_optimizer.param_groups:
+            g["lr"] = lr
+
+    # ---- log-prob passes over a whole [T*N] batch (on_policy_ha_runner.py:66-83,96-113) --------------
+    def _logp_pass(self, obs, actions, avail, M, logp_out, old_logp=None, factor=None):
+        net = self.actor
+        net.forward_trunk(obs, None, M)
+        Wp, bp = net._packs[-1]
+        call("harl_actor_head_logp", ptr(net.xh[-1]), M, net.hidden_sizes[-1], ptr(Wp), ptr(bp), ptr(net.log_std()),
+             net.std_x_coef, net.std_y_coef, int(net.discrete), net.act_dim, ptr(actions), ptr(avail), ptr(logp_out),
+             ptr(old_logp), ptr(factor), int(self.action_aggregation == "mean"), stream())
+
+    def evaluate_actions(self, obs, rnn_states_actor, action, masks, available_actions=None, active_masks=None):
+        """Returns (action_log_probs [B, act_w] device tensor, None, None).  Entropy and the distribution object are
+        only consumed inside ``update`` in the reference's on-policy path; they are fused into the loss kernel."""
+        obs = _as_dev(obs, self.device)
+        obs = obs.reshape(obs.shape[0], -1)
+        action = _as_dev(action, self.device).reshape(obs.shape[0], -1)
+        avail = None if available_actions is None else _as_dev(available_actions, self.device).reshape(obs.shape[0], -1)
+        M = obs.shape[0]
+        out = torch.empty(M, self.actor.act_w, **self.tpdv)
+        self.actor.fold()
+        self._logp_pass(obs, action, avail, M, out)
+        return out, None, None
+
+    def get_actions(self, obs, rnn_states_actor, masks, available_actions=None, deterministic=False):
+        raise NotImplementedError("rollout-side action sampling is outside this round's hot path (SURVEY.md §8f.1)")
+
+    def act(self, obs, rnn_states_actor, masks, available_actions=None, deterministic=False):
+        raise NotImplementedError("rollout-side action sampling is outside this round's hot path (SURVEY.md §8f.1)")
+
+    def prep_training(self):
+        self.actor.train()
+
+    def prep_rollout(self):
+        self.actor.eval()
+
+
+class HAPPO(OnPolicyBase):
+    def __init__(self, args, obs_space, act_space, device=torch.device("cuda:0")):
+        super().__init__(args, obs_space, act_space, device)
+        self.clip_param = args["clip_param"]
+        self.ppo_epoch = args["ppo_epoch"]
+        self.actor_num_mini_batch = args["actor_num_mini_batch"]
+        self.entropy_coef = args["entropy_coef"]
+        self.use_max_grad_norm = args["use_max_grad_norm"]
+        self.max_grad_norm = args["max_grad_norm"]
+        self._info = torch.zeros(4, **self.tpdv)  # sums of policy_loss, dist_entropy, grad_norm, ratio
+        self._staging = None
+        self._grad_tap = None
+
+    # ---- one optimiser step on rows idx[0..m) of the flat [T*N, .] tensors (happo.py:28-102) ---------
+    def _update_core(self, obs, idx, m, actions, avail, old_logp, adv, adv_moments, factor, active):
+        net = self.actor
+        net.forward_trunk(obs, idx, m)
+        Wp, bp = net._packs[-1]
+        s = stream()
+        call("harl_actor_head_loss", ptr(net.xh[-1]), ptr(net.rmask[-1]), ptr(net.rstd[-1]), m, net.hidden_sizes[-1],
+             ptr(Wp), ptr(bp), ptr(net.log_std()), net.std_x_coef, net.std_y_coef, int(net.discrete), net.act_dim,
+             ptr(idx), ptr(actions), ptr(avail), ptr(old_logp), ptr(adv), ptr(adv_moments), ptr(factor), ptr(active),
+             float(self.clip_param), float(self.entropy_coef), int(self.action_aggregation == "mean"),
+             ptr(net.dz[0]), ptr(net.dhead), ptr(net.part_scalars), s)
+        net.scalars.zero_()
+        call("harl_reduce_scalars", ptr(net.part_scalars), _lib.load().harl_head_blocks(m), ptr(net.scalars), s)
+        net.backward_trunk(obs, idx, m)
+        sc = net.scalars
+        if not net.discrete:
+            net.gview("act.action_out.log_std").copy_(sc[8:8 + net.act_dim])
+        if self.comm.enabled:
+            if self._staging is None:
+                self._staging = torch.empty(net.n_params + 2 * PS_STRIDE, **self.tpdv)
+            self.comm.all_reduce_packed(net.flat_grad, sc, self._staging)
+        # loss = sum / sum(active) (happo.py:77-85); gradients are linear in 1/sum(active)
+        grad_scale = (1.0 / sc[1]).to(torch.float32).reshape(1)
+        if self._grad_tap is not None:  # test hook: scaled, pre-clip gradient of this update
+            self._grad_tap(net.flat_grad * grad_scale, sc.clone())
+        self.actor_optimizer.step(grad_scale, self.use_max_grad_norm, self.max_grad_norm, self._info[2:3])
+        self._info[0] += (sc[0] / sc[1]).to(torch.float32)
+        self._info[1] += (sc[2] / sc[1]).to(torch.float32)
+        self._info[3] += (sc[3] / sc[4]).to(torch.float32)
+        net.fold()
+
+    def update(self, sample):
+        """API-compatible single update on an already-gathered minibatch (tuple order of happo.py:37-48).
+        Returns (policy_loss, dist_entropy, actor_grad_norm, mean importance weight) as 0-d device tensors."""
+        (obs, _rnn, actions, _masks, active, old_logp, adv, avail, factor) = sample
+        dev = self.device
+        obs = _as_dev(obs, dev)
+        m = obs.shape[0]
+        before = self._info.clone()
+        self.actor.fold()
+        self._update_core(obs.reshape(m, -1), None, m, _as_dev(actions, dev).reshape(m, -1),
+                          None if avail is None else _as_dev(avail, dev).reshape(m, -1),
+                          _as_dev(old_logp, dev).reshape(m, -1), _as_dev(adv, dev).reshape(m), None,
+                          _as_dev(factor, dev).reshape(m),
+                          _as_dev(active, dev).reshape(m) if self.use_policy_active_masks else None)
+        d = self._info - before
+        return d[0], d[1], d[2], d[3]
+
+    def train(self, actor_buffer: OnPolicyActorBuffer, advantages, state_type):
+        """ppo_epoch x actor_num_mini_batch updates (happo.py:104-158).  ``advantages`` is the raw [T, N, 1]
+        advantage tensor; the per-agent masked normalisation (happo.py:122-127) is folded into the loss kernel
+        through the fp64 moments {sum, sumsq, count}."""
+        if state_type != "EP":
+            raise NotImplementedError("FP state type (per-agent advantages) is not implemented in this round")
+        dev = self.device
+        buf = actor_buffer
+        T, N = buf.actions.shape[:2]
+        B = T * N
+        train_info = {"policy_loss": 0.0, "dist_entropy": 0.0, "actor_grad_norm": 0.0, "ratio": 0.0}
+        adv = _as_dev(advantages, dev).reshape(B)
+        active = buf.flat("active_masks").reshape(B)
+        moments = torch.zeros(3, dtype=torch.float64, device=dev)
+        call("harl_masked_moments", ptr(adv), ptr(active), B, ptr(moments), stream())
+        self.comm.all_reduce_sum(moments)
+        if float(moments[2].item()) == 0.0:  # np.all(active_masks[:-1] == 0) early-out (happo.py:119-120)
+            return train_info
+        self._info.zero_()
+        self.actor.fold()
+        obs = buf.flat("obs")
+        actions = buf.flat("actions")
+        avail = None if buf.available_actions is None else buf.flat("available_actions")
+        old_logp = buf.flat("action_log_probs")
+        factor = buf.factor.reshape(B)
+        n_global = self.shard[0] * T if self.shard else B
+        for _ in range(self.ppo_epoch):
+            if self.use_recurrent_policy or self.use_naive_recurrent_policy:
+                raise NotImplementedError("recurrent generators are not implemented in this round")
+            sampler = minibatch_indices(n_global, self.actor_num_mini_batch)  # CPU RNG draw, bit-exact with the reference
+            for ind in sampler:
+                if self.shard:
+                    ind = local_minibatch_rows(ind, self.shard[0], self.shard[1], self.shard[2])
+                if self.actor_num_mini_batch == 1:
+                    idx, m = None, B  # a full-batch "minibatch" is the whole (local) buffer: order does not enter the sums
+                else:
+                    idx, m = ind.to(dev), ind.numel()
+                self._update_core(obs, idx, m, actions, avail, old_logp, adv, moments, factor,
+                                  active if self.use_policy_active_masks else None)
+        n_upd = self.ppo_epoch * self.actor_num_mini_batch
+        vals = (self._info / n_upd).cpu().tolist()  # the single read-back of this agent's update
+        for k, v in zip(("policy_loss", "dist_entropy", "actor_grad_norm", "ratio"), vals):
+            train_info[k] = v
+        return train_info

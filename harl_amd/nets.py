@@ -1,0 +1,334 @@
+"""Device-side actor / critic networks: parameter containers + kernel orchestration.
+
+``StochasticPolicy`` / ``VNet`` are ``nn.Module``s whose ``state_dict()`` has exactly the
+reference's keys, shapes and order (harl/models/policy_models/stochastic_policy.py:11-54,
+harl/models/value_function_models/v_net.py:10-46), so ``save()/restore()``
+checkpoints are interchangeable.  All parameters are views into ONE flat fp32 arena per
+network (so grad-norm/clip/Adam are a single fused launch and the data-parallel gradient
+all-reduce is a single RCCL call); gradients are views into a second arena of the same layout.
+
+The arithmetic is in libharl_hip.so (include/harl_hip.h); torch is used here only for device
+memory and the stream.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import DHEAD_LD, PS_STRIDE, SLAB, call, ptr, stream
+
+SUPPORTED_WIDTHS = (64, 128)
+
+
+def _space_shape(space) -> Tuple[int, ...]:
+    """Duck-typed like the reference (harl/utils/envs_tools.py:15-29)."""
+    name = space.__class__.__name__
+    if name == "Box":
+        return tuple(space.shape)
+    if name == "list":
+        return tuple(space)
+    raise NotImplementedError(f"observation space {name}")
+
+
+class _Node(nn.Module):
+    """Empty container used to reproduce the reference's dotted parameter names."""
+
+
+def _register(root: nn.Module, dotted: str, p: nn.Parameter) -> None:
+    parts = dotted.split(".")
+    mod = root
+    for name in parts[:-1]:
+        if name not in mod._modules:
+            mod.add_module(name, _Node())
+        mod = mod._modules[name]
+    mod.register_parameter(parts[-1], p)
+
+
+class _FlatNet(nn.Module):
+    """nn.Module whose parameters are views into one flat arena, plus the MLP trunk kernels."""
+
+    def __init__(self, args: dict, in_dim: int, device: torch.device):
+        super().__init__()
+        _lib.require_gpu(device)
+        self.device_ = device
+        self.hidden_sizes = list(args["hidden_sizes"])
+        self.use_feature_normalization = bool(args["use_feature_normalization"])
+        if args.get("activation_func", "relu") != "relu":
+            raise NotImplementedError("harl_amd kernels implement relu MLPs only (every tuned HARL config uses relu)")
+        if args.get("use_recurrent_policy", False) or args.get("use_naive_recurrent_policy", False):
+            raise NotImplementedError("recurrent (GRU) policies are not implemented in this round")
+        for h in self.hidden_sizes:
+            if h not in SUPPORTED_WIDTHS:
+                raise NotImplementedError(f"hidden width {h}: kernels are instantiated for {SUPPORTED_WIDTHS}")
+        self.in_dim = in_dim
+        self._cpu_params: List[Tuple[str, torch.Tensor]] = []
+        self._build_trunk_params(args)
+
+    # ---- parameter construction: same torch calls in the same order as the reference, so that the
+    # global RNG stream (and therefore the initial weights) match for a given seed.
+    def _build_trunk_params(self, args: dict) -> None:
+        init = getattr(nn.init, args["initialization_method"])
+        gain = nn.init.calculate_gain("relu")
+        d = self.in_dim
+        if self.use_feature_normalization:  # MLPBase.feature_norm (mlp.py:57-58)
+            self._cpu_params += [("base.feature_norm.weight", torch.ones(d)), ("base.feature_norm.bias", torch.zeros(d))]
+        for i, h in enumerate(self.hidden_sizes):  # MLPLayer (mlp.py:25-38): [Linear, act, LayerNorm] x k
+            lin = nn.Linear(d, h)
+            init(lin.weight.data, gain=gain)
+            nn.init.constant_(lin.bias.data, 0)
+            self._cpu_params += [(f"base.mlp.fc.{3*i}.weight", lin.weight.data), (f"base.mlp.fc.{3*i}.bias", lin.bias.data),
+                                 (f"base.mlp.fc.{3*i+2}.weight", torch.ones(h)), (f"base.mlp.fc.{3*i+2}.bias", torch.zeros(h))]
+            d = h
+
+    def _finalize_params(self) -> None:
+        """Move the collected CPU tensors into the flat device arena and register views as nn.Parameters."""
+        dev = self.device_
+        total = sum(t.numel() for _, t in self._cpu_params)
+        self.flat_param = torch.empty(total, dtype=torch.float32, device=dev)
+        self.flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.offsets: Dict[str, Tuple[int, Tuple[int, ...]]] = {}
+        off = 0
+        for name, t in self._cpu_params:
+            n = t.numel()
+            view = self.flat_param[off:off + n].view(t.shape)
+            view.copy_(t.to(dev))
+            p = nn.Parameter(view, requires_grad=True)
+            p.grad = self.flat_grad[off:off + n].view(t.shape)
+            _register(self, name, p)
+            self.offsets[name] = (off, tuple(t.shape))
+            off += n
+        self.n_params = total
+        del self._cpu_params
+        # folded weights (W' = W diag(gamma_prev), b' = b + W beta_prev), one pack per Linear incl. the head
+        self._packs: List[Tuple[torch.Tensor, torch.Tensor]] = []
+        self._max_rows = 0
+
+    def pview(self, name: str) -> torch.Tensor:
+        off, shape = self.offsets[name]
+        return self.flat_param[off:off + math.prod(shape)].view(shape)
+
+    def gview(self, name: str) -> torch.Tensor:
+        off, shape = self.offsets[name]
+        return self.flat_grad[off:off + math.prod(shape)].view(shape)
+
+    # ---- layer table: (W name, b name, gamma name | None, beta name | None, out, in)
+    def _layers(self) -> List[Tuple[str, str, Optional[str], Optional[str], int, int]]:
+        out = []
+        d = self.in_dim
+        g = ("base.feature_norm.weight", "base.feature_norm.bias") if self.use_feature_normalization else (None, None)
+        for i, h in enumerate(self.hidden_sizes):
+            out.append((f"base.mlp.fc.{3*i}.weight", f"base.mlp.fc.{3*i}.bias", g[0], g[1], h, d))
+            g = (f"base.mlp.fc.{3*i+2}.weight", f"base.mlp.fc.{3*i+2}.bias")
+            d = h
+        hw, hb, hdim = self._head_names()
+        out.append((hw, hb, g[0], g[1], hdim, d))
+        return out
+
+    def _head_names(self) -> Tuple[str, str, int]:
+        raise NotImplementedError
+
+    def fold(self) -> None:
+        """Recompute the folded weights from the current parameters (after init / load / every Adam step)."""
+        layers = self._layers()
+        if not self._packs:
+            for (_, _, _, _, o, k) in layers:
+                self._packs.append((torch.empty(o * k, dtype=torch.float32, device=self.device_),
+                                    torch.empty(o, dtype=torch.float32, device=self.device_)))
+        s = stream()
+        for (wn, bn, gn, ben, o, k), (Wp, bp) in zip(layers, self._packs):
+            call("harl_fold_linear", ptr(self.pview(wn)), ptr(self.pview(bn)),
+                 ptr(self.pview(gn)) if gn else None, ptr(self.pview(ben)) if ben else None, ptr(Wp), ptr(bp), o, k, s)
+
+    # ---- workspaces -------------------------------------------------------------------------
+    def _ensure_ws(self, M: int) -> None:
+        if M <= self._max_rows:
+            return
+        dev = self.device_
+        n_slabs = (M + SLAB - 1) // SLAB
+        mp = n_slabs * SLAB
+        f32, u32 = torch.float32, torch.int32
+        self.xh = [torch.empty(mp * h, dtype=f32, device=dev) for h in self.hidden_sizes]      # x_hat_l, ATL
+        self.rmask = [torch.empty(n_slabs * max(h // 64, 1) * 64, dtype=u32, device=dev) for h in self.hidden_sizes]
+        self.rstd = [torch.empty(mp, dtype=f32, device=dev) for _ in self.hidden_sizes]
+        self.mu0 = torch.empty(mp, dtype=f32, device=dev)
+        self.rstd0 = torch.empty(mp, dtype=f32, device=dev)
+        hmax = max(self.hidden_sizes)
+        self.dz = [torch.empty(mp * hmax, dtype=f32, device=dev) for _ in range(2)]            # ping-pong, ATL
+        self.dhead = torch.zeros(mp * DHEAD_LD, dtype=f32, device=dev)
+        n_iter = (n_slabs + 1) // 2
+        self.n_wg = max(1, min(512, n_iter))
+        kp_in = ((self.in_dim + 31) // 32) * 32
+        elems = max([hmax * hmax + hmax, hmax * kp_in + hmax, 32 * hmax + 32])
+        self.part = torch.empty(self.n_wg * elems, dtype=f32, device=dev)
+        self.dwp = torch.empty(elems, dtype=f32, device=dev)
+        self.n_head_blocks = _lib.load().harl_head_blocks(M)
+        self.part_scalars = torch.zeros(self.n_head_blocks * PS_STRIDE, dtype=f32, device=dev)
+        self.scalars = torch.zeros(PS_STRIDE, dtype=torch.float64, device=dev)
+        self._max_rows = M
+
+    # ---- trunk forward: X[rows, D] (gathered by idx) -> x_hat_L in self.xh[-1] ------------------
+    def forward_trunk(self, X: torch.Tensor, idx: Optional[torch.Tensor], M: int) -> None:
+        assert X.dim() == 2 and X.shape[1] == self.in_dim and X.is_contiguous()
+        self._ensure_ws(M)
+        s = stream()
+        Wp, bp = self._packs[0]
+        h0 = self.hidden_sizes[0]
+        call("harl_mlp_fwd_input", ptr(X), X.shape[1], ptr(idx), M, self.in_dim, ptr(Wp), ptr(bp),
+             int(self.use_feature_normalization), h0, ptr(self.xh[0]), ptr(self.rmask[0]), ptr(self.rstd[0]),
+             ptr(self.mu0), ptr(self.rstd0), s)
+        for l in range(1, len(self.hidden_sizes)):
+            Wp, bp = self._packs[l]
+            call("harl_mlp_fwd_hidden", ptr(self.xh[l - 1]), M, self.hidden_sizes[l - 1], self.hidden_sizes[l],
+                 ptr(Wp), ptr(bp), ptr(self.xh[l]), ptr(self.rmask[l]), ptr(self.rstd[l]), s)
+
+    # ---- backward: dz_L (in self.dz[0]) and dhead -> flat_grad (UNSCALED sums over samples) ------
+    def backward_trunk(self, X: torch.Tensor, idx: Optional[torch.Tensor], M: int) -> None:
+        s = stream()
+        layers = self._layers()
+        L = len(self.hidden_sizes)
+        nwg = self.n_wg
+
+        def finish(layer_i: int, o: int, k: int) -> None:
+            wn, bn, gn, ben, _, _ = layers[layer_i]
+            kp = ((k + 31) // 32) * 32
+            op = ((o + 31) // 32) * 32
+            elems = op * kp + op
+            call("harl_reduce_partials", ptr(self.part), nwg, elems, ptr(self.dwp), s)
+            dbp = self.dwp[op * kp:]
+            call("harl_unfold_linear_grads", ptr(self.dwp), ptr(dbp), kp, ptr(self.pview(wn)),
+                 ptr(self.pview(gn)) if gn else None, ptr(self.pview(ben)) if ben else None,
+                 ptr(self.gview(wn)), ptr(self.gview(bn)), ptr(self.gview(gn)) if gn else None,
+                 ptr(self.gview(ben)) if ben else None, o, k, s)
+
+        # head: dW_head' = dhead^T x_hat_L
+        hdim = layers[-1][4]
+        hL = self.hidden_sizes[-1]
+        call("harl_mlp_dw_partials", ptr(self.dhead), 1, DHEAD_LD, hdim, ptr(self.xh[-1]), 0, 0, None, None, None, hL, M,
+             ptr(self.part), nwg, s)
+        finish(L, hdim, hL)
+        cur = 0  # self.dz[cur] holds dz_l
+        for l in range(L - 1, 0, -1):
+            ho, hi = self.hidden_sizes[l], self.hidden_sizes[l - 1]
+            call("harl_mlp_dw_partials", ptr(self.dz[cur]), 0, 0, ho, ptr(self.xh[l - 1]), 0, 0, None, None, None, hi, M,
+                 ptr(self.part), nwg, s)
+            finish(l, ho, hi)
+            Wp, _ = self._packs[l]
+            call("harl_mlp_bwd_dx", ptr(self.dz[cur]), ptr(self.xh[l - 1]), ptr(self.rmask[l - 1]), ptr(self.rstd[l - 1]),
+                 M, ho, hi, ptr(Wp), ptr(self.dz[1 - cur]), s)
+            cur = 1 - cur
+        h0 = self.hidden_sizes[0]
+        use_ln = self.use_feature_normalization
+        call("harl_mlp_dw_partials", ptr(self.dz[cur]), 0, 0, h0, ptr(X), 1, X.shape[1], ptr(idx),
+             ptr(self.mu0) if use_ln else None, ptr(self.rstd0) if use_ln else None, self.in_dim, M,
+             ptr(self.part), nwg, s)
+        finish(0, h0, self.in_dim)
+
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):  # keep views, then refold
+        out = super().load_state_dict(state_dict, strict=strict, assign=False)
+        self.fold()
+        return out
+
+
+class StochasticPolicy(_FlatNet):
+    """Actor network container (reference: models/policy_models/stochastic_policy.py:11-54)."""
+
+    def __init__(self, args: dict, obs_space, action_space, device: torch.device):
+        obs_shape = _space_shape(obs_space)
+        if len(obs_shape) != 1:
+            raise NotImplementedError("image observations (CNNBase) are outside the accelerated path")
+        super().__init__(args, obs_shape[0], device)
+        self.action_type = action_space.__class__.__name__
+        self.std_x_coef = float(args["std_x_coef"])
+        self.std_y_coef = float(args["std_y_coef"])
+        init = getattr(nn.init, args["initialization_method"])
+        d = self.hidden_sizes[-1]
+        if self.action_type == "Discrete":  # Categorical (distributions.py:37-55)
+            self.discrete, self.act_dim, self.act_w = True, int(action_space.n), 1
+            lin = nn.Linear(d, self.act_dim)
+            init(lin.weight.data, gain=args["gain"])
+            nn.init.constant_(lin.bias.data, 0)
+            self._cpu_params += [("act.action_out.linear.weight", lin.weight.data), ("act.action_out.linear.bias", lin.bias.data)]
+        elif self.action_type == "Box":  # DiagGaussian (distributions.py:58-89); log_std precedes fc_mean in parameters()
+            self.discrete, self.act_dim = False, int(action_space.shape[0])
+            self.act_w = self.act_dim
+            lin = nn.Linear(d, self.act_dim)
+            init(lin.weight.data, gain=args["gain"])
+            nn.init.constant_(lin.bias.data, 0)
+            self._cpu_params += [("act.action_out.log_std", torch.ones(self.act_dim) * self.std_x_coef),
+                                 ("act.action_out.fc_mean.weight", lin.weight.data), ("act.action_out.fc_mean.bias", lin.bias.data)]
+        else:
+            raise NotImplementedError(f"action space {self.action_type} (MultiDiscrete is HAPPO-only in the reference)")
+        if self.act_dim > 32:
+            raise NotImplementedError("action heads wider than 32 are not instantiated")
+        self._finalize_params()
+        self.fold()
+
+    def _head_names(self):
+        if self.discrete:
+            return "act.action_out.linear.weight", "act.action_out.linear.bias", self.act_dim
+        return "act.action_out.fc_mean.weight", "act.action_out.fc_mean.bias", self.act_dim
+
+    def log_std(self) -> Optional[torch.Tensor]:
+        return None if self.discrete else self.pview("act.action_out.log_std")
+
+
+class VNet(_FlatNet):
+    """Critic network container (reference: models/value_function_models/v_net.py:10-46)."""
+
+    def __init__(self, args: dict, cent_obs_space, device: torch.device):
+        shape = _space_shape(cent_obs_space)
+        if len(shape) != 1:
+            raise NotImplementedError("image observations (CNNBase) are outside the accelerated path")
+        super().__init__(args, shape[0], device)
+        init = getattr(nn.init, args["initialization_method"])
+        lin = nn.Linear(self.hidden_sizes[-1], 1)
+        init(lin.weight.data, gain=1)
+        nn.init.constant_(lin.bias.data, 0)
+        self._cpu_params += [("v_out.weight", lin.weight.data), ("v_out.bias", lin.bias.data)]
+        self._finalize_params()
+        self.fold()
+
+    def _head_names(self):
+        return "v_out.weight", "v_out.bias", 1
+
+
+class FusedAdam:
+    """torch.optim.Adam semantics (defaults betas=(0.9,0.999), amsgrad=False) over one flat arena, fused with
+    the gradient-norm / clip step into a single launch (harl_gradnorm_clip_adam).  Exposes ``param_groups`` so the
+    reference's ``update_linear_schedule`` (utils/models_tools.py:77-87) works unchanged."""
+
+    def __init__(self, net: _FlatNet, lr: float, eps: float, weight_decay: float):
+        self.net = net
+        self.param_groups = [dict(lr=lr, betas=(0.9, 0.999), eps=eps, weight_decay=weight_decay)]
+        self.exp_avg = torch.zeros_like(net.flat_param)
+        self.exp_avg_sq = torch.zeros_like(net.flat_param)
+        self.step_count = 0
+
+    def zero_grad(self) -> None:  # gradients are overwritten, never accumulated
+        return None
+
+    def step(self, grad_scale: Optional[torch.Tensor], use_clip: bool, max_norm: float,
+             info_out: Optional[torch.Tensor]) -> None:
+        g = self.param_groups[0]
+        self.step_count += 1
+        b1, b2 = g["betas"]
+        bc1 = 1.0 - b1 ** self.step_count
+        bc2 = 1.0 - b2 ** self.step_count
+        n = self.net
+        call("harl_gradnorm_clip_adam", ptr(n.flat_param), ptr(n.flat_grad), ptr(self.exp_avg), ptr(self.exp_avg_sq),
+             n.n_params, ptr(grad_scale), int(use_clip), float(max_norm), float(g["lr"]), float(b1), float(b2),
+             float(g["eps"]), float(g["weight_decay"]), bc1, bc2, ptr(info_out), stream())
+
+    def state_dict(self) -> dict:
+        return dict(step=self.step_count, exp_avg=self.exp_avg.clone(), exp_avg_sq=self.exp_avg_sq.clone(),
+                    param_groups=[dict(g) for g in self.param_groups])
+
+    def load_state_dict(self, sd: dict) -> None:
+        self.step_count = int(sd["step"])
+        self.exp_avg.copy_(sd["exp_avg"])
+        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        self.param_groups = [dict(g) for g in sd["param_groups"]]

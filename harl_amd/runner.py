@@ -1,0 +1,141 @@
+"""OnPolicyHARunner: the sequential-update training step on MI355X.
+
+Reference: harl/runners/on_policy_ha_runner.py:11-130 (train), harl/runners/on_policy_base_runner.py:462-497
+(compute / after_update), :712-763 (prep_*, save / restore).  Environment stepping (collect/insert/eval/render) is
+the reference's host-side rollout loop and stays there; ``from_spaces`` builds the update-side
+objects directly from the spaces, which is also what ``bench.py`` and the tests use.
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Optional
+
+import torch
+
+from . import _lib
+from .buffers import OnPolicyActorBuffer, OnPolicyCriticBufferEP
+from .dist import Comm, shard_columns
+from .happo import HAPPO
+from .v_critic import VCritic
+from .valuenorm import ValueNorm
+
+ALGO_REGISTRY = {"happo": HAPPO}
+
+
+class OnPolicyHARunner:
+    def __init__(self, args: dict, algo_args: dict, env_args: Optional[dict] = None, *, obs_spaces=None,
+                 share_obs_space=None, act_spaces=None, device: Optional[torch.device] = None,
+                 comm: Optional[Comm] = None):
+        """``args``/``algo_args`` as in examples/train.py:87-91.  Spaces must be given explicitly (this class does
+        not create environments).  With an initialised process group, ``algo_args['train']['n_rollout_threads']`` is
+        the GLOBAL thread count and this rank keeps its contiguous column shard."""
+        if obs_spaces is None or share_obs_space is None or act_spaces is None:
+            raise ValueError("OnPolicyHARunner needs obs_spaces / share_obs_space / act_spaces (no env creation here)")
+        self.args = args
+        self.algo_args = algo_args
+        self.env_args = env_args
+        self.device = torch.device(device if device is not None else "cuda:0")
+        _lib.require_gpu(self.device)
+        self.comm = comm if comm is not None else Comm()
+        algo = args.get("algo", "happo")
+        if algo not in ALGO_REGISTRY:
+            raise NotImplementedError(f"algo {algo}: this round implements {sorted(ALGO_REGISTRY)}")
+        self.num_agents = len(obs_spaces)
+        self.state_type = (env_args or {}).get("state_type", "EP")
+        if self.state_type != "EP":
+            raise NotImplementedError("FP state type is not implemented in this round")
+        if algo_args["algo"].get("share_param", False):
+            raise NotImplementedError("share_param")
+        self.fixed_order = algo_args["algo"]["fixed_order"]
+        self.action_aggregation = algo_args["algo"]["action_aggregation"]
+        self.share_param = False
+
+        n_global = algo_args["train"]["n_rollout_threads"]
+        lo, hi = shard_columns(n_global, self.comm.rank, self.comm.world_size)
+        self.n_global, self.col_lo, self.col_hi = n_global, lo, hi
+        train_local = dict(algo_args["train"])
+        train_local["n_rollout_threads"] = hi - lo
+        margs = {**algo_args["model"], **algo_args["algo"]}
+        self.actor: List[HAPPO] = []
+        for a in range(self.num_agents):  # construction order = reference (actors 0..A-1, then critic) for RNG parity
+            self.actor.append(ALGO_REGISTRY[algo](margs, obs_spaces[a], act_spaces[a], device=self.device))
+        self.actor_buffer = [OnPolicyActorBuffer({**train_local, **algo_args["model"]}, obs_spaces[a], act_spaces[a],
+                                                 device=self.device) for a in range(self.num_agents)]
+        self.critic = VCritic(margs, share_obs_space, device=self.device)
+        self.critic_buffer = OnPolicyCriticBufferEP({**train_local, **algo_args["model"], **algo_args["algo"]},
+                                                    share_obs_space, device=self.device)
+        self.value_normalizer = ValueNorm(1, device=self.device) if algo_args["train"]["use_valuenorm"] else None
+        shard = (n_global, lo, hi) if self.comm.enabled else None
+        for x in self.actor + [self.critic]:
+            x.comm, x.shard = self.comm, shard
+        self._logp_old = None
+
+    # ---- on_policy_base_runner.py:462-484 -------------------------------------------------------
+    @torch.no_grad()
+    def compute(self):
+        cb = self.critic_buffer
+        next_value, _ = self.critic.get_values(cb.share_obs[-1], cb.rnn_states_critic[-1], cb.masks[-1])
+        cb.compute_returns(next_value, self.value_normalizer)
+
+    # ---- on_policy_ha_runner.py:11-130 ------------------------------------------------------------
+    @torch.no_grad()
+    def train(self):
+        T = self.algo_args["train"]["episode_length"]
+        N = self.col_hi - self.col_lo
+        B = T * N
+        dev = self.device
+        actor_train_infos = []
+        factor = torch.ones(T, N, 1, dtype=torch.float32, device=dev)
+        advantages = self.critic_buffer.advantages  # returns[:-1] - denormalize(value_preds[:-1]), fused into the GAE scan
+        if self.fixed_order:
+            agent_order = list(range(self.num_agents))
+        else:
+            agent_order = [int(a) for a in torch.randperm(self.num_agents).numpy()]  # first CPU-RNG draw of train()
+        for agent_id in agent_order:
+            buf, actor = self.actor_buffer[agent_id], self.actor[agent_id]
+            buf.update_factor(factor)
+            obs, actions = buf.flat("obs"), buf.flat("actions")
+            avail = None if buf.available_actions is None else buf.flat("available_actions")
+            if self._logp_old is None or self._logp_old.shape != (B, actor.actor.act_w):
+                self._logp_old = torch.empty(B, actor.actor.act_w, dtype=torch.float32, device=dev)
+            actor.actor.fold()
+            actor._logp_pass(obs, actions, avail, B, self._logp_old)            # pre-update log-probs (:66-83)
+            actor_train_infos.append(actor.train(buf, advantages, "EP"))      # :86-93
+            new_factor = factor.clone()
+            # post-update log-probs fused with factor *= agg(exp(new - old))   (:96-124)
+            actor._logp_pass(obs, actions, avail, B, None, old_logp=self._logp_old, factor=new_factor.reshape(B))
+            factor = new_factor
+        critic_train_info = self.critic.train(self.critic_buffer, self.value_normalizer)
+        return actor_train_infos, critic_train_info
+
+    def after_update(self):
+        for b in self.actor_buffer:
+            b.after_update()
+        self.critic_buffer.after_update()
+
+    def prep_rollout(self):
+        for a in self.actor:
+            a.prep_rollout()
+        self.critic.prep_rollout()
+
+    def prep_training(self):
+        for a in self.actor:
+            a.prep_training()
+        self.critic.prep_training()
+
+    # ---- on_policy_base_runner.py:724-763: same file names, same state_dict keys ---------------------
+    def save(self, save_dir: str):
+        os.makedirs(save_dir, exist_ok=True)
+        for a in range(self.num_agents):
+            torch.save(self.actor[a].actor.state_dict(), os.path.join(save_dir, f"actor_agent{a}.pt"))
+        torch.save(self.critic.critic.state_dict(), os.path.join(save_dir, "critic_agent.pt"))
+        if self.value_normalizer is not None:
+            torch.save(self.value_normalizer.state_dict(), os.path.join(save_dir, "value_normalizer.pt"))
+
+    def restore(self, model_dir: str):
+        for a in range(self.num_agents):
+            self.actor[a].actor.load_state_dict(torch.load(os.path.join(model_dir, f"actor_agent{a}.pt"), map_location=self.device))
+        self.critic.critic.load_state_dict(torch.load(os.path.join(model_dir, "critic_agent.pt"), map_location=self.device))
+        p = os.path.join(model_dir, "value_normalizer.pt")
+        if self.value_normalizer is not None and os.path.exists(p):
+            self.value_normalizer.load_state_dict(torch.load(p, map_location=self.device))

@@ -1,0 +1,139 @@
+"""V critic on MI355X (reference: harl/algorithms/critics/v_critic.py:14-208)."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import PS_STRIDE, call, ptr, stream
+from .buffers import OnPolicyCriticBufferEP, minibatch_indices
+from .dist import Comm, local_minibatch_rows
+from .nets import FusedAdam, VNet
+from .valuenorm import ValueNorm, _as_dev
+
+
+class VCritic:
+    def __init__(self, args, cent_obs_space, device=torch.device("cuda:0")):
+        self.args = args
+        self.device = torch.device(device)
+        _lib.require_gpu(self.device)
+        self.tpdv = dict(dtype=torch.float32, device=self.device)
+        self.clip_param = args["clip_param"]
+        self.critic_epoch = args["critic_epoch"]
+        self.critic_num_mini_batch = args["critic_num_mini_batch"]
+        self.data_chunk_length = args["data_chunk_length"]
+        self.value_loss_coef = args["value_loss_coef"]
+        self.max_grad_norm = args["max_grad_norm"]
+        self.huber_delta = args["huber_delta"]
+        self.use_recurrent_policy = args["use_recurrent_policy"]
+        self.use_naive_recurrent_policy = args["use_naive_recurrent_policy"]
+        self.use_max_grad_norm = args["use_max_grad_norm"]
+        self.use_clipped_value_loss = args["use_clipped_value_loss"]
+        self.use_huber_loss = args["use_huber_loss"]
+        self.use_policy_active_masks = args["use_policy_active_masks"]
+        self.critic_lr = args["critic_lr"]
+        self.opti_eps = args["opti_eps"]
+        self.weight_decay = args["weight_decay"]
+        self.share_obs_space = cent_obs_space
+        self.critic = VNet(args, cent_obs_space, self.device)
+        self.critic_optimizer = FusedAdam(self.critic, self.critic_lr, self.opti_eps, self.weight_decay)
+        self.comm = Comm()
+        self.shard = None
+        self._info = torch.zeros(2, **self.tpdv)  # sums of value_loss, critic_grad_norm
+        self._scale = torch.zeros(1, **self.tpdv)
+        self._staging = None
+        self._grad_tap = None
+
+    def lr_decay(self, episode, episodes):
+        lr = self.critic_lr - (self.critic_lr * ((episode - 1) / float(episodes)))
+        for g in self.critic_optimizer.param_groups:
+            g["lr"] = lr
+
+    def get_values(self, cent_obs, rnn_states_critic, masks):
+        """values [B, 1] (device) = VNet(cent_obs)  (v_critic.py:62-73, v_net.py:48-67)."""
+        x = _as_dev(cent_obs, self.device)
+        x = x.reshape(x.shape[0], -1)
+        M = x.shape[0]
+        net = self.critic
+        net.fold()
+        net.forward_trunk(x, None, M)
+        Wp, bp = net._packs[-1]
+        out = torch.empty(M, 1, **self.tpdv)
+        call("harl_critic_head_values", ptr(net.xh[-1]), M, net.hidden_sizes[-1], ptr(Wp), ptr(bp), ptr(out), stream())
+        return out, rnn_states_critic
+
+    def _update_core(self, share_obs, idx, m, m_global, value_preds, returns, vn: Optional[ValueNorm]):
+        net = self.critic
+        s = stream()
+        if vn is not None:  # ValueNorm.update runs on this minibatch's returns BEFORE the targets are normalised
+            vn.update(returns, idx, count=m_global, reduce_fn=self.comm.all_reduce_sum if self.comm.enabled else None)
+        net.forward_trunk(share_obs, idx, m)
+        Wp, bp = net._packs[-1]
+        call("harl_critic_head_loss", ptr(net.xh[-1]), ptr(net.rmask[-1]), ptr(net.rstd[-1]), m, net.hidden_sizes[-1],
+             ptr(Wp), ptr(bp), ptr(idx), ptr(value_preds), ptr(returns), ptr(vn.stats) if vn is not None else None,
+             float(self.clip_param), int(self.use_clipped_value_loss), int(self.use_huber_loss), float(self.huber_delta),
+             ptr(net.dz[0]), ptr(net.dhead), ptr(net.part_scalars), s)
+        net.scalars.zero_()
+        call("harl_reduce_scalars", ptr(net.part_scalars), _lib.load().harl_head_blocks(m), ptr(net.scalars), s)
+        net.backward_trunk(share_obs, idx, m)
+        sc = net.scalars
+        if self.comm.enabled:
+            if self._staging is None:
+                self._staging = torch.empty(net.n_params + 2 * PS_STRIDE, **self.tpdv)
+            self.comm.all_reduce_packed(net.flat_grad, sc, self._staging)
+        # loss = mean over the (global) minibatch, times value_loss_coef before backward (v_critic.py:112,146)
+        self._scale.fill_(float(self.value_loss_coef) / float(m_global))
+        if self._grad_tap is not None:
+            self._grad_tap(net.flat_grad * self._scale, sc.clone())
+        self.critic_optimizer.step(self._scale, self.use_max_grad_norm, self.max_grad_norm, self._info[1:2])
+        self._info[0] += (sc[0] / sc[1]).to(torch.float32)
+        net.fold()
+
+    def update(self, sample, value_normalizer=None):
+        """API-compatible single update on a gathered minibatch (v_critic.py:116-157)."""
+        share_obs, _rnn, value_preds, returns, _masks = sample
+        dev = self.device
+        x = _as_dev(share_obs, dev)
+        m = x.shape[0]
+        before = self._info.clone()
+        self.critic.fold()
+        self._update_core(x.reshape(m, -1), None, m, m, _as_dev(value_preds, dev).reshape(m),
+                          _as_dev(returns, dev).reshape(m), value_normalizer)
+        d = self._info - before
+        return d[0], d[1]
+
+    def train(self, critic_buffer: OnPolicyCriticBufferEP, value_normalizer: Optional[ValueNorm] = None):
+        """critic_epoch x critic_num_mini_batch updates (v_critic.py:159-200)."""
+        buf = critic_buffer
+        T, N = buf.rewards.shape[:2]
+        B = T * N
+        dev = self.device
+        self._info.zero_()
+        self.critic.fold()
+        share_obs = buf.flat("share_obs")
+        value_preds = buf.flat("value_preds").reshape(B)
+        returns = buf.flat("returns").reshape(B)
+        n_global = self.shard[0] * T if self.shard else B
+        for _ in range(self.critic_epoch):
+            if self.use_recurrent_policy or self.use_naive_recurrent_policy:
+                raise NotImplementedError("recurrent generators are not implemented in this round")
+            sampler = minibatch_indices(n_global, self.critic_num_mini_batch)
+            for ind in sampler:
+                m_global = ind.numel()
+                if self.shard:
+                    ind = local_minibatch_rows(ind, self.shard[0], self.shard[1], self.shard[2])
+                if self.critic_num_mini_batch == 1:
+                    idx, m = None, B
+                else:
+                    idx, m = ind.to(dev), ind.numel()
+                self._update_core(share_obs, idx, m, m_global, value_preds, returns, value_normalizer)
+        n_upd = self.critic_epoch * self.critic_num_mini_batch
+        vals = (self._info / n_upd).cpu().tolist()
+        return {"value_loss": vals[0], "critic_grad_norm": vals[1]}
+
+    def prep_training(self):
+        self.critic.train()
+
+    def prep_rollout(self):
+        self.critic.eval()

@@ -1,0 +1,170 @@
+/*
+ * harl_hip.h -- C ABI of libharl_hip.so: gfx950 (MI355X) kernels for HARL's on-policy
+ * sequential-update path (HAPPO / V-critic).
+ *
+ * The reference (PKU-MARL/HARL) is 100 % Python and has no FFI for this path; every entry
+ * point below replaces a Python/NumPy/ATen *op sequence* of the reference, cited per function
+ * (paths relative to the reference root).  The Python classes in harl_amd/ mirror the
+ * reference's Runner / Algorithm / Buffer API and are the only callers (ctypes, see
+ * INTEGRATION.md for the binding a HARL maintainer would add).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (memory owned by the caller, normally a torch tensor);
+ *   - no allocation, no host synchronisation inside; work is enqueued on `stream`
+ *     (a hipStream_t passed as void*), so calls are safe under hipGraph capture;
+ *   - return value: 0 on success, negative on error (harl_last_error() gives the text);
+ *   - all floating data is fp32; "ATL" = activation tile layout: for a width-H
+ *     activation, slab g (32 consecutive samples) is stored as [H/8][64 lanes][4] floats;
+ *   - `idx` arguments are optional int64 row-gather arrays (NULL = identity): sample j of the
+ *     minibatch is row idx[j] of the flattened [T*N, .] buffer -- exactly the arrays the
+ *     reference draws with torch.randperm (on_policy_actor_buffer.py:131-135).
+ */
+#ifndef HARL_HIP_H
+#define HARL_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HARL_PS_STRIDE 48 /* floats per row of the per-workgroup partial-scalar tables */
+#define HARL_DHEAD_LD 32  /* row stride of the head-gradient matrix */
+
+int harl_version(void);
+const char *harl_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * GAE / returns reverse scan + fused advantages.
+ * Replaces OnPolicyCriticBufferEP.compute_returns (common/buffers/on_policy_critic_buffer_ep.py:97-200,
+ * all 8 branches; FP twin on_policy_critic_buffer_fp.py:107-210) and the advantage subtraction of
+ * OnPolicyHARunner.train (runners/on_policy_ha_runner.py:26-33).
+ *   rewards[T,ncols] value_preds[T+1,ncols] masks/bad_masks[T+1,ncols] next_value[ncols]
+ *   vn_stats: {running_mean, running_mean_sq, debiasing_term} or NULL (no ValueNorm)
+ *   returns[T+1,ncols] (out)   advantages[T,ncols] (out, may be NULL)
+ * Same fp32 operation order as the reference (no FMA contraction): bit-identical results.
+ * fp_order=1 selects the FP buffer's `gamma*lambda*gae*mask` product order (_fp.py:130).
+ */
+int harl_gae_returns(const float *rewards, float *value_preds, const float *masks, const float *bad_masks,
+                     const float *next_value, const float *vn_stats, float *returns, float *advantages,
+                     int T, int ncols, float gamma, float gamma_lambda, int use_gae,
+                     int use_proper_time_limits, int fp_order, void *stream);
+
+/* Masked moments of the advantages: {sum x, sum x^2, count} over entries with active != 0, fp64.
+ * Replaces the NaN trick + np.nanmean/np.nanstd of HAPPO.train (algorithms/actors/happo.py:122-127).
+ * out3 (double[3]) is ACCUMULATED into (zero it first); all-reduce it across ranks when sharded. */
+int harl_masked_moments(const float *x, const float *active, long n, double *out3, void *stream);
+/* adv_out = (adv - mean) / (std + 1e-5) with mean/std from `moments3` (happo.py:127). */
+int harl_adv_normalize(const float *adv, const double *moments3, float *adv_out, long n, void *stream);
+
+/* factor[i] *= agg_d exp(new_logp[i,d] - old_logp[i,d]), agg = prod (0) | mean (1).
+ * Replaces runners/on_policy_ha_runner.py:116-124. */
+int harl_factor_update(float *factor, const float *new_logp, const float *old_logp, long n, int act_dim,
+                       int agg_mean, void *stream);
+
+/* ValueNorm (common/valuenorm.py:47-64): sums2 (double[2]) += {sum R, sum R^2} over the minibatch
+ * (rows idx[0..m) of `returns`, or 0..m); then harl_valuenorm_apply does the debiased EMA update of
+ * vn_stats = {running_mean, running_mean_sq, debiasing_term} with the (global) count. */
+int harl_sum_sumsq(const float *x, const int64_t *idx, long m, double *sums2, void *stream);
+int harl_valuenorm_apply(float *vn_stats, const double *sums2, double count, double beta, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused grad-norm + clip + Adam over one flat parameter arena.
+ * Replaces nn.utils.clip_grad_norm_ / get_grad_norm + torch.optim.Adam.step
+ * (algorithms/actors/happo.py:93-100, algorithms/critics/v_critic.py:148-155).
+ *   grad is first multiplied by *grad_scale (device scalar, e.g. 1/sum(active); NULL = 1);
+ *   norm = ||grad||_2 ; if use_clip: grad *= min(1, max_norm/(norm+1e-6));
+ *   m += (1-b1)(g-m); v = b2 v + (1-b2) g^2; p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
+ *   info_out[0] += norm (pre-clip) if info_out != NULL.
+ */
+int harl_gradnorm_clip_adam(float *param, float *grad, float *exp_avg, float *exp_avg_sq, long n,
+                            const float *grad_scale, int use_clip, float max_norm, float lr, float beta1,
+                            float beta2, float eps, float weight_decay, double bias_correction1,
+                            double bias_correction2, float *info_out, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * MLP (harl/models/base/mlp.py:7-70) on fp32 MFMA.  LayerNorm affine terms are folded into the
+ * following Linear (W' = W diag(gamma), b' = b + W beta); the kernels work on pure normalisations
+ * and harl_mlp_unfold_grads maps the folded gradients back to the reference parameters.
+ */
+/* Wp[out,in] = W[out,in]*gamma[in]; bp[out] = b[out] + sum_k W[out,k]*beta[k]  (gamma/beta NULL = identity) */
+int harl_fold_linear(const float *W, const float *b, const float *gamma, const float *beta, float *Wp,
+                     float *bp, int out_dim, int in_dim, void *stream);
+/* dW = dWp*gamma + dbp (x) beta ; db = dbp ; dgamma[k] = sum_o W[o,k] dWp[o,k] ; dbeta[k] = sum_o W[o,k] dbp[o]
+ * dWp has row stride ldp (>= in_dim).  dgamma/dbeta may be NULL. */
+int harl_unfold_linear_grads(const float *dWp, const float *dbp, int ldp, const float *W, const float *gamma,
+                             const float *beta, float *dW, float *db, float *dgamma, float *dbeta,
+                             int out_dim, int in_dim, void *stream);
+
+/* first layer: x_hat1 = norm(relu(Wp * norm0(X[idx]) + bp))
+ *   X[rows, ldx] row-major, D features; use_ln0: feature LayerNorm on the input (mlp.py:57-58,65-66)
+ *   outputs: xout ATL(H), relu_mask [n_slabs][H/64][64] u32, rstd[M_pad], mu0/rstd0[M_pad] (input LN stats) */
+int harl_mlp_fwd_input(const float *X, long ldx, const int64_t *idx, long M, int D, const float *Wp,
+                       const float *bp, int use_ln0, int H, float *xout, uint32_t *relu_mask, float *rstd,
+                       float *mu0, float *rstd0, void *stream);
+/* hidden layer: xout = norm(relu(Wp * xin + bp)), xin ATL(HI) -> xout ATL(HO) */
+int harl_mlp_fwd_hidden(const float *xin, long M, int HI, int HO, const float *Wp, const float *bp,
+                        float *xout, uint32_t *relu_mask, float *rstd, void *stream);
+/* backward through Linear(HI->HO) then the preceding relu+norm:
+ *   dz_prev = relu_mask_prev ? LNbwd(Wp^T dz ; xprev, rstd_prev) : 0     (dz ATL(HO) -> dz_prev ATL(HI)) */
+int harl_mlp_bwd_dx(const float *dz, const float *xprev, const uint32_t *relu_mask_prev, const float *rstd_prev,
+                    long M, int HO, int HI, const float *Wp, float *dz_prev, void *stream);
+/* weight-gradient partials: part[wg] = { dWp[HO_pad32, KP] , dbp[HO_pad32] } summed over the samples the
+ * workgroup processed; a_kind: 0 = ATL(HO) dz, 1 = row-major [M, lda] (head gradients, HO <= 32);
+ * b_kind: 0 = ATL(K) x_hat, 1 = raw X[idx] rows (ldx, D=K) normalised with mu0/rstd0 (NULL = no LN0).
+ * n_wg workgroups (= number of partial slabs) ; KP = K rounded up to 32. */
+int harl_mlp_dw_partials(const float *a, int a_kind, int lda, int HO, const float *b, int b_kind, long ldx,
+                         const int64_t *idx, const float *mu0, const float *rstd0, int K, long M, float *part,
+                         int n_wg, void *stream);
+/* out[e] = sum_w part[w][e] in fixed order (deterministic), e < elems */
+int harl_reduce_partials(const float *part, int n_wg, long elems, float *out, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Heads and losses.
+ * Gaussian head: DiagGaussian (models/base/distributions.py:58-89) + FixedNormal.log_probs/entropy,
+ * Categorical head: distributions.py:7-21,37-55; ACTLayer.evaluate_actions (models/base/act.py:104-157).
+ *   xL ATL(H); Whp[act_dim, H], bhp[act_dim] folded head weights; log_std[act_dim] (Gaussian only)
+ *   discrete: actions[rows,1] hold the action index as fp32, avail[rows, act_dim] or NULL.
+ */
+/* log-probs only (the old/new passes of on_policy_ha_runner.py:66-83,96-113):
+ *   logp_out[M, act_w] (act_w = act_dim for Box, 1 for Discrete), natural row order (no gather).
+ *   If factor != NULL: factor[i] *= agg_d exp(logp - old_logp[i,d]) (fused on_policy_ha_runner.py:116-124)
+ *   and logp_out may be NULL. */
+int harl_actor_head_logp(const float *xL, long M, int H, const float *Whp, const float *bhp,
+                         const float *log_std, float std_x_coef, float std_y_coef, int discrete, int act_dim,
+                         const float *actions, const float *avail, float *logp_out, const float *old_logp,
+                         float *factor, int agg_mean, void *stream);
+/* HAPPO.update loss forward + backward (algorithms/actors/happo.py:28-102), everything up to dz_L:
+ *   inputs gathered by idx: actions, old_logp[rows,act_w], adv[rows] (raw), adv_moments (double[3], NULL = adv
+ *   already normalised), factor[rows], active[rows] (NULL = ones / use_policy_active_masks False)
+ *   outputs: dzL ATL(H) (grad wrt last hidden pre-activation, UNSCALED by 1/sum(active)),
+ *            dhead[M_pad, 32] (grad wrt head outputs; dw input), part_scalars[harl_head_blocks(M)][HARL_PS_STRIDE]:
+ *            {0: sum loss*active, 1: sum active, 2: sum ent*active, 3: sum ratio, 4: count, 8..8+act_dim: dlogstd}
+ *   mask/rstd: relu mask and rstd of the last hidden layer.
+ */
+int harl_actor_head_loss(const float *xL, const uint32_t *relu_mask, const float *rstd, long M, int H,
+                         const float *Whp, const float *bhp, const float *log_std, float std_x_coef,
+                         float std_y_coef, int discrete, int act_dim, const int64_t *idx, const float *actions,
+                         const float *avail, const float *old_logp, const float *adv, const double *adv_moments,
+                         const float *factor, const float *active, float clip_param, float entropy_coef,
+                         int agg_mean, float *dzL, float *dhead, float *part_scalars, void *stream);
+/* V head forward: values[M] = Whp . xL + bhp   (v_net.py:64) */
+int harl_critic_head_values(const float *xL, long M, int H, const float *Whp, const float *bhp, float *values,
+                            void *stream);
+/* VCritic.cal_value_loss forward + backward (algorithms/critics/v_critic.py:75-114), up to dz_L (UNSCALED by
+ * value_loss_coef / m).  vn_stats NULL = no ValueNorm (it must already contain this step's update).
+ * part_scalars[harl_head_blocks(M)][HARL_PS_STRIDE]: {0: sum loss, 1: count} */
+int harl_critic_head_loss(const float *xL, const uint32_t *relu_mask, const float *rstd, long M, int H,
+                          const float *Whp, const float *bhp, const int64_t *idx, const float *value_preds,
+                          const float *returns, const float *vn_stats, float clip_param, int use_clipped,
+                          int use_huber, float huber_delta, float *dzL, float *dhead, float *part_scalars,
+                          void *stream);
+/* number of workgroups (= rows of part_scalars) the head-loss kernels use for M samples */
+int harl_head_blocks(long M);
+/* scalars[j] += sum_b part_scalars[b][j], j < HARL_PS_STRIDE (fixed order, fp64) */
+int harl_reduce_scalars(const float *part_scalars, int n_blocks, double *scalars, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HARL_HIP_H */

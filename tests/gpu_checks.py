@@ -1,0 +1,389 @@
+"""GPU parity checks: every HIP kernel (through the C ABI) against the CPU oracle on the same seeded inputs.
+
+Each ``check_*`` function returns a dict of named error figures; ``tests/test_gpu_parity.py`` asserts on them and
+``tests/gpu_diag.py`` prints them all in one run (one gpurun call = full picture, GPU minutes are scarce).
+Tolerances: integer / index data and the GAE scan bit-exact; fp32 losses, grad-norms, gradients 1e-5 relative
+(BASELINE.json north_star).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from harl_amd import _lib
+from harl_amd._lib import call, ptr, stream
+from harl_amd.synthetic import Shapes, actor_param_shapes, critic_param_shapes, make_buffers, synthetic_state_dict
+from oracle import harl_oracle as O
+from tests.helpers import GoldenCase, rel_err, vec_rel_err
+
+DEV = torch.device("cuda:0")
+
+
+class Box:
+    def __init__(self, shape):
+        self.shape = shape
+
+
+class Discrete:
+    def __init__(self, n):
+        self.n = n
+        self.shape = ()
+
+
+def dev(x, dtype=torch.float32):
+    return torch.as_tensor(np.ascontiguousarray(x), dtype=dtype).to(DEV).contiguous()
+
+
+def default_args(hidden, **over):
+    a = dict(hidden_sizes=list(hidden), activation_func="relu", use_feature_normalization=True,
+             initialization_method="orthogonal_", gain=0.01, use_naive_recurrent_policy=False,
+             use_recurrent_policy=False, recurrent_n=1, data_chunk_length=10, lr=5e-4, critic_lr=5e-4, opti_eps=1e-5,
+             weight_decay=0, std_x_coef=1, std_y_coef=0.5, ppo_epoch=5, critic_epoch=5, use_clipped_value_loss=True,
+             clip_param=0.2, actor_num_mini_batch=1, critic_num_mini_batch=1, entropy_coef=0.01, value_loss_coef=1,
+             use_max_grad_norm=True, max_grad_norm=10.0, use_gae=True, gamma=0.99, gae_lambda=0.95, use_huber_loss=True,
+             use_policy_active_masks=True, huber_delta=10.0, action_aggregation="prod", share_param=False,
+             fixed_order=False)
+    a.update(over)
+    return a
+
+
+# ------------------------------------------------------------------------------------------------
+def check_gae() -> Dict[str, float]:
+    """All 8 compute_returns branches, two shapes (incl. a ragged column count), vs the oracle: bit-exact."""
+    out = {}
+    for (T, N, seed) in [(16, 6, 11), (200, 333, 5)]:
+        sh = Shapes(T=T, N=N, A=1, obs_dim=4, share_obs_dim=4, act_dim=1)
+        d = make_buffers(sh, seed)
+        nv = (d.value_preds[-1] * 0.5).copy()
+        for use_gae in (True, False):
+            for ptl in (True, False):
+                for use_vn in (True, False):
+                    vn = None
+                    stats = None
+                    if use_vn:
+                        vn = O.OracleValueNorm()
+                        vn.load_state(dict(running_mean=-0.2 * 0.25, running_mean_sq=2.3 * 0.25, debiasing_term=0.25))
+                        stats = dev(np.array([-0.2 * 0.25, 2.3 * 0.25, 0.25], dtype=np.float32))
+                    ret, vp = O.compute_returns(d.rewards, d.value_preds, d.critic_masks, d.bad_masks, nv, 0.99, 0.95,
+                                                use_gae, ptl, vn)
+                    adv = O.advantages_from_returns(ret, vp, vn).astype(np.float32)
+                    r, v, m, b = dev(d.rewards), dev(d.value_preds), dev(d.critic_masks), dev(d.bad_masks)
+                    g_ret = torch.zeros(T + 1, N, 1, device=DEV)
+                    g_adv = torch.zeros(T, N, 1, device=DEV)
+                    call("harl_gae_returns", ptr(r), ptr(v), ptr(m), ptr(b), ptr(dev(nv)), ptr(stats), ptr(g_ret),
+                         ptr(g_adv), T, N, float(np.float32(0.99)), float(np.float32(0.99 * 0.95)), int(use_gae), int(ptl),
+                         0, stream())
+                    torch.cuda.synchronize()
+                    key = f"T{T}N{N}_gae{int(use_gae)}_ptl{int(ptl)}_vn{int(use_vn)}"
+                    got = g_ret.cpu().numpy()
+                    rows = slice(0, T) if use_gae else slice(0, T + 1)
+                    out[key + "_returns_mismatch"] = float(np.sum(got[rows] != ret[rows]))
+                    out[key + "_adv_mismatch"] = float(np.sum(g_adv.cpu().numpy() != adv))
+    return out
+
+
+def check_elementwise() -> Dict[str, float]:
+    out = {}
+    rng = np.random.default_rng(3)
+    n = 100003
+    adv = rng.standard_normal(n).astype(np.float32) * 2 + 0.3
+    act = (rng.random(n) > 0.2).astype(np.float32)
+    ref = O.normalize_advantages(adv.reshape(-1, 1, 1), act.reshape(-1, 1, 1)).reshape(-1)
+    mom = torch.zeros(3, dtype=torch.float64, device=DEV)
+    call("harl_masked_moments", ptr(dev(adv)), ptr(dev(act)), n, ptr(mom), stream())
+    g = torch.empty(n, device=DEV)
+    call("harl_adv_normalize", ptr(dev(adv)), ptr(mom), ptr(g), n, stream())
+    out["adv_normalize_vec_rel"] = vec_rel_err(g.cpu().numpy(), ref)
+    out["moments_count_err"] = abs(mom[2].item() - act.sum())
+    # factor
+    for agg in ("prod", "mean"):
+        D = 5
+        nl = (rng.standard_normal((n, D)) * 0.1).astype(np.float32)
+        ol = (rng.standard_normal((n, D)) * 0.1).astype(np.float32)
+        f0 = (1 + 0.1 * rng.standard_normal(n)).astype(np.float32)
+        ref = f0 * getattr(torch, agg)(torch.exp(torch.from_numpy(nl) - torch.from_numpy(ol)), dim=-1).numpy()
+        f = dev(f0)
+        call("harl_factor_update", ptr(f), ptr(dev(nl)), ptr(dev(ol)), n, D, int(agg == "mean"), stream())
+        out[f"factor_{agg}_rel"] = rel_err(f.cpu().numpy(), ref)
+    # valuenorm
+    x = (rng.standard_normal(5000) * 3 + 1).astype(np.float32)
+    vn = O.OracleValueNorm()
+    vn.load_state(dict(running_mean=0.15, running_mean_sq=0.85, debiasing_term=0.5))
+    from harl_amd.valuenorm import ValueNorm
+    gvn = ValueNorm(1, device=DEV)
+    gvn.stats.copy_(dev(np.array([0.15, 0.85, 0.5], dtype=np.float32)))
+    for _ in range(3):
+        vn.update(x.reshape(-1, 1))
+        gvn.update(dev(x))
+    s = vn.state()
+    ref = np.array([s["running_mean"].item(), s["running_mean_sq"].item(), s["debiasing_term"].item()])
+    out["valuenorm_rel"] = rel_err(gvn.stats.cpu().numpy(), ref)
+    idx = torch.from_numpy(rng.permutation(5000)[:1234].astype(np.int64))
+    vn.update(x[idx.numpy()].reshape(-1, 1))
+    gvn.update(dev(x), idx.to(DEV))
+    s = vn.state()
+    ref = np.array([s["running_mean"].item(), s["running_mean_sq"].item(), s["debiasing_term"].item()])
+    out["valuenorm_gather_rel"] = rel_err(gvn.stats.cpu().numpy(), ref)
+    return out
+
+
+def check_adam() -> Dict[str, float]:
+    out = {}
+    rng = np.random.default_rng(9)
+    for n, clip, scale in [(20142, True, 1.0), (70001, True, 37.0), (501, False, 0.5)]:
+        p0 = rng.standard_normal(n).astype(np.float32)
+        pt = torch.nn.Parameter(torch.from_numpy(p0.copy()))
+        opt = torch.optim.Adam([pt], lr=5e-4, eps=1e-5, weight_decay=0)
+        gp, gm, gv = dev(p0), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+        info = torch.zeros(1, device=DEV)
+        sc = dev(np.array([scale], dtype=np.float32))
+        norms = []
+        for step in range(1, 6):
+            g = (rng.standard_normal(n) * (3.0 if step % 2 else 0.01)).astype(np.float32)
+            pt.grad = torch.from_numpy(g.copy()) * scale
+            if clip:
+                norms.append(float(torch.nn.utils.clip_grad_norm_([pt], 10.0)))
+            else:
+                norms.append(float(pt.grad.norm()))
+            opt.step()
+            call("harl_gradnorm_clip_adam", ptr(gp), ptr(dev(g)), ptr(gm), ptr(gv), n, ptr(sc), int(clip), 10.0, 5e-4, 0.9,
+                 0.999, 1e-5, 0.0, 1.0 - 0.9 ** step, 1.0 - 0.999 ** step, ptr(info), stream())
+        out[f"adam_n{n}_param_vec_rel"] = vec_rel_err(gp.cpu().numpy(), pt.detach().numpy())
+        out[f"adam_n{n}_norm_rel"] = rel_err(info.item(), sum(norms))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+def _mk_actor(sh: Shapes, seed: int, **over):
+    from harl_amd.happo import HAPPO
+    args = default_args(sh.hidden_sizes, **over)
+    space = Discrete(sh.act_dim) if sh.discrete else Box((sh.act_dim,))
+    a = HAPPO(args, Box((sh.obs_dim,)), space, device=DEV)
+    sd = synthetic_state_dict(actor_param_shapes(sh, args["use_feature_normalization"]), seed, args["std_x_coef"])
+    assert list(sd.keys()) == list(a.actor.state_dict().keys()), (list(sd.keys()), list(a.actor.state_dict().keys()))
+    a.actor.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    return a, sd, args
+
+
+def _mk_critic(sh: Shapes, seed: int, **over):
+    from harl_amd.v_critic import VCritic
+    args = default_args(sh.hidden_sizes, **over)
+    c = VCritic(args, Box((sh.share_obs_dim,)), device=DEV)
+    sd = synthetic_state_dict(critic_param_shapes(sh, args["use_feature_normalization"]), seed)
+    assert list(sd.keys()) == list(c.critic.state_dict().keys())
+    c.critic.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    return c, sd, args
+
+
+FWD_SHAPES = [
+    dict(name="mpe_box", obs_dim=18, share_obs_dim=54, act_dim=5, discrete=False, hidden_sizes=[128, 128], M=1000),
+    dict(name="mpe_disc_h64", obs_dim=18, share_obs_dim=54, act_dim=5, discrete=True, hidden_sizes=[64, 64], M=77),
+    dict(name="cheetah_3x128", obs_dim=23, share_obs_dim=17, act_dim=1, discrete=False, hidden_sizes=[128, 128, 128], M=4100),
+    dict(name="wide_nofn_h64", obs_dim=77, share_obs_dim=70, act_dim=2, discrete=False, hidden_sizes=[64], M=257,
+         over=dict(use_feature_normalization=False)),
+    dict(name="humanoid_393", obs_dim=393, share_obs_dim=376, act_dim=1, discrete=False, hidden_sizes=[128, 128, 128], M=300),
+    dict(name="mixed_64_128_disc14", obs_dim=40, share_obs_dim=33, act_dim=14, discrete=True, hidden_sizes=[64, 128], M=513),
+    dict(name="mixed_128_64_box20", obs_dim=31, share_obs_dim=65, act_dim=20, discrete=False, hidden_sizes=[128, 64], M=640),
+]
+
+
+def check_forward(spec) -> Dict[str, float]:
+    """log-probs (actor) and values (critic) of the MFMA forward vs the oracle's torch forward."""
+    out = {}
+    over = spec.get("over", {})
+    M = spec["M"]
+    sh = Shapes(T=M, N=1, A=1, obs_dim=spec["obs_dim"], share_obs_dim=spec["share_obs_dim"], act_dim=spec["act_dim"],
+                discrete=spec["discrete"], hidden_sizes=spec["hidden_sizes"])
+    d = make_buffers(sh, 21, unavailable_p=0.25 if sh.discrete else 0.0)
+    actor, sd, args = _mk_actor(sh, 4242, **over)
+    cfg = O.PathConfig.from_reference_dicts({}, args, args)
+    obs = d.obs[0][:-1].reshape(M, -1)
+    act = d.actions[0].reshape(M, -1)
+    avail = None if not sh.discrete else d.available_actions[0][:-1].reshape(M, -1)
+    p = {k: torch.from_numpy(v) for k, v in sd.items()}
+    with torch.no_grad():
+        ref, _, _ = O.actor_evaluate_actions(p, cfg, torch.from_numpy(obs), torch.from_numpy(act),
+                                             None if avail is None else torch.from_numpy(avail), None)
+    got, _, _ = actor.evaluate_actions(obs, None, act, None, avail, None)
+    torch.cuda.synchronize()
+    out["logp_vec_rel"] = vec_rel_err(got.cpu().numpy(), ref.numpy())
+    critic, csd, _ = _mk_critic(sh, 777, **over)
+    so = d.share_obs[:-1].reshape(M, -1)
+    with torch.no_grad():
+        vref = O.critic_forward({k: torch.from_numpy(v) for k, v in csd.items()}, torch.from_numpy(so))
+    vgot, _ = critic.get_values(so, None, None)
+    torch.cuda.synchronize()
+    out["values_vec_rel"] = vec_rel_err(vgot.cpu().numpy(), vref.numpy())
+    return out
+
+
+def check_gradients(spec, mini_batches: int = 1, agg: str = "prod", inactive_p: float = 0.0) -> Dict[str, float]:
+    """ONE HAPPO.update and ONE VCritic.update: pre-clip gradient vector, loss scalars, grad-norm and the
+    post-Adam parameters vs the oracle (autograd + torch.optim.Adam)."""
+    out = {}
+    over = dict(spec.get("over", {}))
+    over.update(action_aggregation=agg)
+    M = spec["M"]
+    sh = Shapes(T=M, N=1, A=1, obs_dim=spec["obs_dim"], share_obs_dim=spec["share_obs_dim"], act_dim=spec["act_dim"],
+                discrete=spec["discrete"], hidden_sizes=spec["hidden_sizes"])
+    d = make_buffers(sh, 33, inactive_p=inactive_p, unavailable_p=0.25 if sh.discrete else 0.0)
+    actor, sd, args = _mk_actor(sh, 99, **over)
+    cfg = O.PathConfig.from_reference_dicts({}, args, args)
+    rng = np.random.default_rng(5)
+    obs = d.obs[0][:-1].reshape(M, -1)
+    avail = None if not sh.discrete else d.available_actions[0][:-1].reshape(M, -1)
+    oracle = O.OracleHAPPO({k: torch.from_numpy(v) for k, v in sd.items()}, cfg)
+    # policy-consistent actions / old log-probs so that ratios straddle the clip range
+    with torch.no_grad():
+        feat = O.mlp_base_forward(oracle.net.p, torch.from_numpy(obs))
+        if sh.discrete:
+            logits = torch.nn.functional.linear(feat, oracle.net.p["act.action_out.linear.weight"], oracle.net.p["act.action_out.linear.bias"])
+            logits = torch.where(torch.from_numpy(avail) == 0, torch.full_like(logits, -1e10), logits)
+            pr = torch.softmax(logits, -1).numpy().astype(np.float64)
+            pr /= pr.sum(-1, keepdims=True)
+            act = np.array([rng.choice(sh.act_dim, p=q) for q in pr], dtype=np.float32)[:, None]
+        else:
+            mean = torch.nn.functional.linear(feat, oracle.net.p["act.action_out.fc_mean.weight"], oracle.net.p["act.action_out.fc_mean.bias"]).numpy()
+            std = (torch.sigmoid(oracle.net.p["act.action_out.log_std"] / cfg.std_x_coef) * cfg.std_y_coef).detach().numpy()
+            act = (mean + std * rng.standard_normal(mean.shape)).astype(np.float32)
+        lp, _, _ = oracle.evaluate_actions(obs, act, avail, None)
+    old_logp = (lp.numpy() + 0.15 * rng.standard_normal(lp.shape)).astype(np.float32)
+    adv = rng.standard_normal((M, 1)).astype(np.float32)
+    factor = (1 + 0.2 * rng.standard_normal((M, 1))).astype(np.float32)
+    active = d.active_masks[0][:-1].reshape(M, 1)
+    sample_o = (obs, act, active, old_logp, adv, avail, factor)
+    pl, ent, gn, imp, g = oracle.update(sample_o, keep_grad=True)
+    taps = []
+    actor._grad_tap = lambda gr, sc: taps.append((gr.clone(), sc))
+    rnn = np.zeros((M, 1, 1), dtype=np.float32)
+    res = actor.update((obs, rnn, act, None, active, old_logp, adv, avail, factor))
+    torch.cuda.synchronize()
+    gg = taps[0][0].cpu().numpy()
+    out["actor_grad_vec_rel"] = vec_rel_err(gg, g)
+    # per-parameter-tensor breakdown (largest)
+    worst, off = ("", 0.0), 0
+    for name, shp in actor_param_shapes(sh, args["use_feature_normalization"]):
+        n = int(np.prod(shp))
+        e = vec_rel_err(gg[off:off + n], g[off:off + n]) if np.max(np.abs(g[off:off + n])) > 0 else 0.0
+        if e > worst[1]:
+            worst = (name, e)
+        off += n
+    out["actor_grad_worst_tensor_rel"] = worst[1]
+    out["_actor_grad_worst_tensor"] = worst[0]
+    out["actor_loss_rel"] = rel_err(res[0].item(), pl.item())
+    out["actor_entropy_rel"] = rel_err(res[1].item(), ent.item())
+    out["actor_gradnorm_rel"] = rel_err(res[2].item(), float(gn))
+    out["actor_ratio_rel"] = rel_err(res[3].item(), float(imp.mean()))
+    out["actor_param_after_vec_rel"] = vec_rel_err(actor.actor.flat_param.cpu().numpy(), oracle.net.flat())
+
+    # ---- critic
+    critic, csd, cargs = _mk_critic(sh, 55, **over)
+    oc = O.OracleVCritic({k: torch.from_numpy(v) for k, v in csd.items()}, cfg)
+    so = d.share_obs[:-1].reshape(M, -1)
+    with torch.no_grad():
+        v0 = O.critic_forward(oc.net.p, torch.from_numpy(so)).numpy()
+    vp = (v0 + 0.3 * rng.standard_normal(v0.shape)).astype(np.float32)  # straddles the value-clip range
+    ret = (3.0 * rng.standard_normal(v0.shape) + 1.0).astype(np.float32)
+    ret[::17] += 40.0  # push some errors past huber_delta
+    ovn = O.OracleValueNorm()
+    ovn.load_state(dict(running_mean=0.15, running_mean_sq=0.85, debiasing_term=0.5))
+    from harl_amd.valuenorm import ValueNorm
+    gvn = ValueNorm(1, device=DEV)
+    gvn.stats.copy_(dev(np.array([0.15, 0.85, 0.5], dtype=np.float32)))
+    loss, cgn, cg = oc.update((so, vp, ret), ovn, keep_grad=True)
+    ctaps = []
+    critic._grad_tap = lambda gr, sc: ctaps.append(gr.clone())
+    cres = critic.update((so, rnn, vp, ret, None), gvn)
+    torch.cuda.synchronize()
+    out["critic_grad_vec_rel"] = vec_rel_err(ctaps[0].cpu().numpy(), cg)
+    out["critic_loss_rel"] = rel_err(cres[0].item(), loss.item())
+    out["critic_gradnorm_rel"] = rel_err(cres[1].item(), float(cgn))
+    out["critic_param_after_vec_rel"] = vec_rel_err(critic.critic.flat_param.cpu().numpy(), oc.net.flat())
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+def build_runner(case: GoldenCase):
+    from harl_amd.runner import OnPolicyHARunner
+    train, model, algo = case.reference_dicts()
+    sh, d = case.shapes, case.data
+    space = Discrete(sh.act_dim) if sh.discrete else Box((sh.act_dim,))
+    algo_args = dict(train=train, model=model, algo=algo)
+    r = OnPolicyHARunner(dict(algo="happo"), algo_args, dict(state_type="EP"),
+                         obs_spaces=[Box((sh.obs_dim,))] * sh.A, share_obs_space=Box((sh.share_obs_dim,)),
+                         act_spaces=[space] * sh.A, device=DEV)
+    for a in range(sh.A):
+        r.actor[a].actor.load_state_dict({k: torch.from_numpy(v) for k, v in case.actor_sd[a].items()})
+        b = r.actor_buffer[a]
+        b.obs.copy_(dev(d.obs[a]))
+        b.actions.copy_(dev(d.actions[a]))
+        b.action_log_probs.copy_(dev(d.action_log_probs[a]))
+        b.masks.copy_(dev(d.masks[a]))
+        b.active_masks.copy_(dev(d.active_masks[a]))
+        if sh.discrete:
+            b.available_actions.copy_(dev(d.available_actions[a]))
+    r.critic.critic.load_state_dict({k: torch.from_numpy(v) for k, v in case.critic_sd.items()})
+    cb = r.critic_buffer
+    cb.share_obs.copy_(dev(d.share_obs))
+    cb.rewards.copy_(dev(d.rewards))
+    cb.value_preds.copy_(dev(d.value_preds))
+    cb.masks.copy_(dev(d.critic_masks))
+    cb.bad_masks.copy_(dev(d.bad_masks))
+    if r.value_normalizer is not None:
+        vi = case.vn_init
+        r.value_normalizer.stats.copy_(dev(np.array([vi["running_mean"], vi["running_mean_sq"], vi["debiasing_term"]],
+                                                    dtype=np.float32)))
+    return r
+
+
+def check_train_golden(name: str) -> Dict[str, float]:
+    """compute_returns + OnPolicyHARunner.train() against the golden vectors recorded from the REAL reference."""
+    case = GoldenCase(name)
+    z = case.z
+    out = {}
+    torch.manual_seed(case.seed)
+    np.random.seed(case.seed)
+    r = build_runner(case)
+    perms: List[np.ndarray] = []
+    real = torch.randperm
+
+    def rec(n, *a, **k):
+        p = real(n, *a, **k)
+        perms.append(p.numpy().copy())
+        return p
+
+    torch.manual_seed(case.seed + 12345)
+    torch.randperm = rec
+    try:
+        cb = r.critic_buffer
+        cb.compute_returns(cb.value_preds[-1].clone(), r.value_normalizer)
+        torch.cuda.synchronize()
+        use_gae = case.algo["use_gae"]
+        T = case.shapes.T
+        out["returns_mismatch"] = float(np.sum(cb.returns.cpu().numpy()[:T] != z["returns"][:T]))
+        out["advantages_mismatch"] = float(np.sum(cb.advantages.cpu().numpy() != z["advantages"]))
+        r.prep_training()
+        infos, cinfo = r.train()
+        torch.cuda.synchronize()
+    finally:
+        torch.randperm = real
+    gp = case.perms()
+    out["perm_count_diff"] = float(abs(len(perms) - len(gp)))
+    out["perm_mismatch"] = float(sum(int(not np.array_equal(a, b)) for a, b in zip(perms, gp)))
+    got = np.array([[i["policy_loss"], i["dist_entropy"], i["actor_grad_norm"], i["ratio"]] for i in infos])
+    gold = z["actor_infos"]
+    out["actor_policy_loss_rel"] = rel_err(got[:, 0], gold[:, 0])
+    out["actor_entropy_rel"] = rel_err(got[:, 1], gold[:, 1])
+    out["actor_gradnorm_rel"] = rel_err(got[:, 2], gold[:, 2])
+    out["actor_ratio_rel"] = rel_err(got[:, 3], gold[:, 3])
+    out["critic_value_loss_rel"] = rel_err(cinfo["value_loss"], z["critic_info"][0])
+    out["critic_gradnorm_rel"] = rel_err(cinfo["critic_grad_norm"], z["critic_info"][1])
+    for a in range(case.shapes.A):
+        out[f"actor{a}_final_param_vec_rel"] = vec_rel_err(r.actor[a].actor.flat_param.cpu().numpy(), z[f"actor_final_{a}"])
+    out["critic_final_param_vec_rel"] = vec_rel_err(r.critic.critic.flat_param.cpu().numpy(), z["critic_final"])
+    if r.value_normalizer is not None:
+        out["vn_final_rel"] = rel_err(r.value_normalizer.stats.cpu().numpy(), z["vn_final"])
+    return out

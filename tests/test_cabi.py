@@ -1,0 +1,59 @@
+"""C-ABI checks that run without a GPU: the in-tree library loads, exports every symbol that
+include/harl_hip.h declares, and the ctypes signatures in harl_amd/_lib.py agree with the header."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from harl_amd import _lib
+
+
+def _header_decls(repo_root):
+    src = open(os.path.join(repo_root, "include", "harl_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    decls = {}
+    for m in re.finditer(r"\b(int|const char \*)\s*(harl_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
+        args = m.group(3).strip()
+        arglist = [] if args in ("void", "") else [a.strip() for a in args.split(",")]
+        decls[m.group(2)] = arglist
+    return decls
+
+
+def _ctype_of(arg: str):
+    if "*" in arg:
+        return ctypes.c_void_p
+    t = arg.rsplit(" ", 1)[0].replace("const", "").strip()
+    return {"int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float, "double": ctypes.c_double}[t]
+
+
+def test_library_builds_and_exports_all_header_symbols(repo_root):
+    from harl_amd._build import build
+
+    path = build()
+    lib = ctypes.CDLL(path)
+    decls = _header_decls(repo_root)
+    assert len(decls) >= 20
+    for name in decls:
+        assert hasattr(lib, name), f"{name} declared in include/harl_hip.h but not exported"
+    lib.harl_version.restype = ctypes.c_int
+    assert lib.harl_version() >= 100  # host-only call, no GPU needed
+
+
+def test_ctypes_signatures_match_header(repo_root):
+    decls = _header_decls(repo_root)
+    for name, argtypes in _lib.SIGNATURES.items():
+        assert name in decls, name
+        want = [_ctype_of(a) for a in decls[name]]
+        assert want == argtypes, f"{name}: header {decls[name]} vs ctypes {argtypes}"
+    missing = set(decls) - set(_lib.SIGNATURES) - {"harl_last_error"}
+    assert not missing, missing
+
+
+def test_product_does_not_import_oracle(repo_root):
+    """The oracle is test infrastructure: nothing under harl_amd/ may import it."""
+    for dirpath, _, files in os.walk(os.path.join(repo_root, "harl_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), os.path.join(dirpath, f)

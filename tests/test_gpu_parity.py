@@ -1,0 +1,57 @@
+"""-m gpu: parity of the HIP path (through the C ABI) against the oracle and the reference's golden vectors."""
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5  # BASELINE.json: fp32 losses / grad-norms within 1e-5 relative
+
+
+def _G():
+    from tests import gpu_checks
+    return gpu_checks
+
+
+def _assert_all(res, tol=TOL, exact_keys=("mismatch", "perm_", "count")):
+    for k, v in res.items():
+        if k.startswith("_") or not isinstance(v, float):
+            continue
+        if any(e in k for e in exact_keys):
+            assert v == 0.0, (k, v)
+        else:
+            assert v < tol, (k, v)
+
+
+def test_gae_bit_exact_all_branches():
+    res = _G().check_gae()
+    assert all(v == 0.0 for v in res.values()), {k: v for k, v in res.items() if v}
+
+
+def test_elementwise_kernels():
+    _assert_all(_G().check_elementwise(), tol=2e-6)
+
+
+def test_fused_gradnorm_clip_adam():
+    _assert_all(_G().check_adam(), tol=2e-6)
+
+
+@pytest.mark.parametrize("i", range(7))
+def test_mlp_forward_logp_and_values(i):
+    G = _G()
+    _assert_all(G.check_forward(G.FWD_SHAPES[i]), tol=TOL)
+
+
+@pytest.mark.parametrize("i", range(7))
+def test_single_update_gradients(i):
+    G = _G()
+    _assert_all(G.check_gradients(G.FWD_SHAPES[i]), tol=TOL)
+
+
+def test_single_update_gradients_mean_aggregation_inactive_agents():
+    G = _G()
+    _assert_all(G.check_gradients(G.FWD_SHAPES[0], agg="mean", inactive_p=0.3), tol=TOL)
+
+
+@pytest.mark.parametrize("name", ["mpe_box_h64", "mpe_box_h128", "mpe_disc_h64", "cheetah_h128x3_mb2",
+                                  "box_mean_inactive_novn", "wide_obs_h64"])
+def test_train_matches_reference_golden(name):
+    _assert_all(_G().check_train_golden(name), tol=TOL)

@@ -89,9 +89,40 @@ def stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
-def call(name: str, *args) -> None:
+_timing_on = False
+_timing_events: dict = {}
+
+
+def enable_kernel_timing(on: bool) -> None:
+    """Bracket every tagged launch with HIP events on the launch stream (torch's current stream, which is the
+    stream handed to the kernels).  Used by bench.py for the per-kernel roofline figures."""
+    global _timing_on
+    _timing_on = bool(on)
+    if on:
+        _timing_events.clear()
+
+
+def collect_kernel_timing() -> dict:
+    """{tag: {n, avg_ms, total_ms}} for the launches recorded since enable_kernel_timing(True)."""
+    torch.cuda.synchronize()
+    out = {}
+    for tag, evs in _timing_events.items():
+        ms = [a.elapsed_time(b) for a, b in evs]
+        out[tag] = dict(n=len(ms), avg_ms=sum(ms) / max(len(ms), 1), total_ms=sum(ms))
+    return out
+
+
+def call(name: str, *args, tag: Optional[str] = None) -> None:
     lib = load()
-    rc = getattr(lib, name)(*args)
+    if _timing_on and tag is not None:
+        a = torch.cuda.Event(enable_timing=True)
+        b = torch.cuda.Event(enable_timing=True)
+        a.record()
+        rc = getattr(lib, name)(*args)
+        b.record()
+        _timing_events.setdefault(tag, []).append((a, b))
+    else:
+        rc = getattr(lib, name)(*args)
     if rc != 0:
         raise RuntimeError(f"{name} failed ({rc}): {lib.harl_last_error().decode()}")
 

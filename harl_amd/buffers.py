@@ -185,7 +185,7 @@ class OnPolicyCriticBufferEP:
         gl32 = float(np.float32(self.gamma * self.gae_lambda))  # python-double product, then cast
         call("harl_gae_returns", ptr(self.rewards), ptr(self.value_preds), ptr(self.masks), ptr(self.bad_masks), ptr(nv),
              ptr(vn), ptr(self.returns), ptr(self.advantages), T, N, gamma32, gl32, int(self.use_gae),
-             int(self.use_proper_time_limits), 0, stream())
+             int(self.use_proper_time_limits), 0, stream(), tag="gae_returns")
 
     def flat(self, name: str) -> torch.Tensor:
         t = getattr(self, name)

@@ -57,7 +57,7 @@ class OnPolicyBase:
         Wp, bp = net._packs[-1]
         call("harl_actor_head_logp", ptr(net.xh[-1]), M, net.hidden_sizes[-1], ptr(Wp), ptr(bp), ptr(net.log_std()),
              net.std_x_coef, net.std_y_coef, int(net.discrete), net.act_dim, ptr(actions), ptr(avail), ptr(logp_out),
-             ptr(old_logp), ptr(factor), int(self.action_aggregation == "mean"), stream())
+             ptr(old_logp), ptr(factor), int(self.action_aggregation == "mean"), stream(), tag="actor_head_logp")
 
     def evaluate_actions(self, obs, rnn_states_actor, action, masks, available_actions=None, active_masks=None):
         """Returns (action_log_probs [B, act_w] device tensor, None, None).  Entropy and the distribution object are
@@ -108,7 +108,7 @@ class HAPPO(OnPolicyBase):
              ptr(Wp), ptr(bp), ptr(net.log_std()), net.std_x_coef, net.std_y_coef, int(net.discrete), net.act_dim,
              ptr(idx), ptr(actions), ptr(avail), ptr(old_logp), ptr(adv), ptr(adv_moments), ptr(factor), ptr(active),
              float(self.clip_param), float(self.entropy_coef), int(self.action_aggregation == "mean"),
-             ptr(net.dz[0]), ptr(net.dhead), ptr(net.part_scalars), s)
+             ptr(net.dz[0]), ptr(net.dhead), ptr(net.part_scalars), s, tag="actor_head_loss")
         net.scalars.zero_()
         call("harl_reduce_scalars", ptr(net.part_scalars), _lib.load().harl_head_blocks(m), ptr(net.scalars), s)
         net.backward_trunk(obs, idx, m)

@@ -179,11 +179,11 @@ class _FlatNet(nn.Module):
         h0 = self.hidden_sizes[0]
         call("harl_mlp_fwd_input", ptr(X), X.shape[1], ptr(idx), M, self.in_dim, ptr(Wp), ptr(bp),
              int(self.use_feature_normalization), h0, ptr(self.xh[0]), ptr(self.rmask[0]), ptr(self.rstd[0]),
-             ptr(self.mu0), ptr(self.rstd0), s)
+             ptr(self.mu0), ptr(self.rstd0), s, tag="fwd_input")
         for l in range(1, len(self.hidden_sizes)):
             Wp, bp = self._packs[l]
             call("harl_mlp_fwd_hidden", ptr(self.xh[l - 1]), M, self.hidden_sizes[l - 1], self.hidden_sizes[l],
-                 ptr(Wp), ptr(bp), ptr(self.xh[l]), ptr(self.rmask[l]), ptr(self.rstd[l]), s)
+                 ptr(Wp), ptr(bp), ptr(self.xh[l]), ptr(self.rmask[l]), ptr(self.rstd[l]), s, tag="fwd_hidden")
 
     # ---- backward: dz_L (in self.dz[0]) and dhead -> flat_grad (UNSCALED sums over samples) ------
     def backward_trunk(self, X: torch.Tensor, idx: Optional[torch.Tensor], M: int) -> None:
@@ -197,7 +197,7 @@ class _FlatNet(nn.Module):
             kp = ((k + 31) // 32) * 32
             op = ((o + 31) // 32) * 32
             elems = op * kp + op
-            call("harl_reduce_partials", ptr(self.part), nwg, elems, ptr(self.dwp), s)
+            call("harl_reduce_partials", ptr(self.part), nwg, elems, ptr(self.dwp), s, tag="reduce_partials")
             dbp = self.dwp[op * kp:]
             call("harl_unfold_linear_grads", ptr(self.dwp), ptr(dbp), kp, ptr(self.pview(wn)),
                  ptr(self.pview(gn)) if gn else None, ptr(self.pview(ben)) if ben else None,
@@ -208,23 +208,23 @@ class _FlatNet(nn.Module):
         hdim = layers[-1][4]
         hL = self.hidden_sizes[-1]
         call("harl_mlp_dw_partials", ptr(self.dhead), 1, DHEAD_LD, hdim, ptr(self.xh[-1]), 0, 0, None, None, None, hL, M,
-             ptr(self.part), nwg, s)
+             ptr(self.part), nwg, s, tag="dw_head")
         finish(L, hdim, hL)
         cur = 0  # self.dz[cur] holds dz_l
         for l in range(L - 1, 0, -1):
             ho, hi = self.hidden_sizes[l], self.hidden_sizes[l - 1]
             call("harl_mlp_dw_partials", ptr(self.dz[cur]), 0, 0, ho, ptr(self.xh[l - 1]), 0, 0, None, None, None, hi, M,
-                 ptr(self.part), nwg, s)
+                 ptr(self.part), nwg, s, tag="dw_hidden")
             finish(l, ho, hi)
             Wp, _ = self._packs[l]
             call("harl_mlp_bwd_dx", ptr(self.dz[cur]), ptr(self.xh[l - 1]), ptr(self.rmask[l - 1]), ptr(self.rstd[l - 1]),
-                 M, ho, hi, ptr(Wp), ptr(self.dz[1 - cur]), s)
+                 M, ho, hi, ptr(Wp), ptr(self.dz[1 - cur]), s, tag="bwd_dx")
             cur = 1 - cur
         h0 = self.hidden_sizes[0]
         use_ln = self.use_feature_normalization
         call("harl_mlp_dw_partials", ptr(self.dz[cur]), 0, 0, h0, ptr(X), 1, X.shape[1], ptr(idx),
              ptr(self.mu0) if use_ln else None, ptr(self.rstd0) if use_ln else None, self.in_dim, M,
-             ptr(self.part), nwg, s)
+             ptr(self.part), nwg, s, tag="dw_input")
         finish(0, h0, self.in_dim)
 
     def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):  # keep views, then refold
@@ -321,7 +321,7 @@ class FusedAdam:
         n = self.net
         call("harl_gradnorm_clip_adam", ptr(n.flat_param), ptr(n.flat_grad), ptr(self.exp_avg), ptr(self.exp_avg_sq),
              n.n_params, ptr(grad_scale), int(use_clip), float(max_norm), float(g["lr"]), float(b1), float(b2),
-             float(g["eps"]), float(g["weight_decay"]), bc1, bc2, ptr(info_out), stream())
+             float(g["eps"]), float(g["weight_decay"]), bc1, bc2, ptr(info_out), stream(), tag="gradnorm_clip_adam")
 
     def state_dict(self) -> dict:
         return dict(step=self.step_count, exp_avg=self.exp_avg.clone(), exp_avg_sq=self.exp_avg_sq.clone(),

@@ -73,7 +73,7 @@ class VCritic:
         call("harl_critic_head_loss", ptr(net.xh[-1]), ptr(net.rmask[-1]), ptr(net.rstd[-1]), m, net.hidden_sizes[-1],
              ptr(Wp), ptr(bp), ptr(idx), ptr(value_preds), ptr(returns), ptr(vn.stats) if vn is not None else None,
              float(self.clip_param), int(self.use_clipped_value_loss), int(self.use_huber_loss), float(self.huber_delta),
-             ptr(net.dz[0]), ptr(net.dhead), ptr(net.part_scalars), s)
+             ptr(net.dz[0]), ptr(net.dhead), ptr(net.part_scalars), s, tag="critic_head_loss")
         net.scalars.zero_()
         call("harl_reduce_scalars", ptr(net.part_scalars), _lib.load().harl_head_blocks(m), ptr(net.scalars), s)
         net.backward_trunk(share_obs, idx, m)

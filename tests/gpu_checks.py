@@ -71,9 +71,10 @@ def check_gae() -> Dict[str, float]:
                                                 use_gae, ptl, vn)
                     adv = O.advantages_from_returns(ret, vp, vn).astype(np.float32)
                     r, v, m, b = dev(d.rewards), dev(d.value_preds), dev(d.critic_masks), dev(d.bad_masks)
+                    d_nv = dev(nv)
                     g_ret = torch.zeros(T + 1, N, 1, device=DEV)
                     g_adv = torch.zeros(T, N, 1, device=DEV)
-                    call("harl_gae_returns", ptr(r), ptr(v), ptr(m), ptr(b), ptr(dev(nv)), ptr(stats), ptr(g_ret),
+                    call("harl_gae_returns", ptr(r), ptr(v), ptr(m), ptr(b), ptr(d_nv), ptr(stats), ptr(g_ret),
                          ptr(g_adv), T, N, float(np.float32(0.99)), float(np.float32(0.99 * 0.95)), int(use_gae), int(ptl),
                          0, stream())
                     torch.cuda.synchronize()
@@ -93,9 +94,10 @@ def check_elementwise() -> Dict[str, float]:
     act = (rng.random(n) > 0.2).astype(np.float32)
     ref = O.normalize_advantages(adv.reshape(-1, 1, 1), act.reshape(-1, 1, 1)).reshape(-1)
     mom = torch.zeros(3, dtype=torch.float64, device=DEV)
-    call("harl_masked_moments", ptr(dev(adv)), ptr(dev(act)), n, ptr(mom), stream())
+    d_adv, d_act = dev(adv), dev(act)  # keep references: a temporary would be recycled by the caching allocator
+    call("harl_masked_moments", ptr(d_adv), ptr(d_act), n, ptr(mom), stream())
     g = torch.empty(n, device=DEV)
-    call("harl_adv_normalize", ptr(dev(adv)), ptr(mom), ptr(g), n, stream())
+    call("harl_adv_normalize", ptr(d_adv), ptr(mom), ptr(g), n, stream())
     out["adv_normalize_vec_rel"] = vec_rel_err(g.cpu().numpy(), ref)
     out["moments_count_err"] = abs(mom[2].item() - act.sum())
     # factor
@@ -105,8 +107,8 @@ def check_elementwise() -> Dict[str, float]:
         ol = (rng.standard_normal((n, D)) * 0.1).astype(np.float32)
         f0 = (1 + 0.1 * rng.standard_normal(n)).astype(np.float32)
         ref = f0 * getattr(torch, agg)(torch.exp(torch.from_numpy(nl) - torch.from_numpy(ol)), dim=-1).numpy()
-        f = dev(f0)
-        call("harl_factor_update", ptr(f), ptr(dev(nl)), ptr(dev(ol)), n, D, int(agg == "mean"), stream())
+        f, d_nl, d_ol = dev(f0), dev(nl), dev(ol)
+        call("harl_factor_update", ptr(f), ptr(d_nl), ptr(d_ol), n, D, int(agg == "mean"), stream())
         out[f"factor_{agg}_rel"] = rel_err(f.cpu().numpy(), ref)
     # valuenorm
     x = (rng.standard_normal(5000) * 3 + 1).astype(np.float32)
@@ -149,7 +151,8 @@ def check_adam() -> Dict[str, float]:
             else:
                 norms.append(float(pt.grad.norm()))
             opt.step()
-            call("harl_gradnorm_clip_adam", ptr(gp), ptr(dev(g)), ptr(gm), ptr(gv), n, ptr(sc), int(clip), 10.0, 5e-4, 0.9,
+            d_g = dev(g)
+            call("harl_gradnorm_clip_adam", ptr(gp), ptr(d_g), ptr(gm), ptr(gv), n, ptr(sc), int(clip), 10.0, 5e-4, 0.9,
                  0.999, 1e-5, 0.0, 1.0 - 0.9 ** step, 1.0 - 0.999 ** step, ptr(info), stream())
         out[f"adam_n{n}_param_vec_rel"] = vec_rel_err(gp.cpu().numpy(), pt.detach().numpy())
         out[f"adam_n{n}_norm_rel"] = rel_err(info.item(), sum(norms))

@@ -141,7 +141,9 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--threads-per-gpu", type=int, default=N_PER_GPU)
-    ap.add_argument("--cpu-cols", type=int, default=256, help="rollout threads of the bounded CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-cols", type=int, default=512, help="rollout threads of the bounded CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-threads", type=int, default=16,
+                    help="torch CPU threads for the baseline (these nets are small: more threads than ~16 is slower)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
 
@@ -211,7 +213,7 @@ def main():
             kernels={k: dict(n=v["n"], avg_ms=round(v["avg_ms"], 4), total_ms=round(v["total_ms"], 3)) for k, v in kern.items()},
         )
         if world == 1 and args.cpu_cols > 0:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_cols, os.cpu_count() or 1)
+            out["cpu_baseline"] = cpu_baseline(args.cpu_cols, min(args.cpu_threads, os.cpu_count() or 1))
         print(json.dumps(out), flush=True)
     if comm.enabled:
         torch.distributed.barrier()

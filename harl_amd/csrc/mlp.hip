@@ -309,13 +309,92 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_dw(const float *__restrict__ 
                                                       int K, long M, long n_slabs, float *__restrict__ part, int KP) {
   using SP = DwSplit<MT, NT>;
   constexpr int LDA = 32 * MT + 4, LDB = 32 * NT + 4;
+  constexpr bool A_ATL = A_KIND == 0, B_ATL = B_KIND == 0;
+  constexpr int HA = 32 * MT, HB = 32 * NT;
+  // Staging roles.  Both operands ATL: waves 0,1 fetch the two A tiles, waves 2,3 the two B tiles.  Only one ATL
+  // operand (first layer: B = raw rows; head: A = [M][32] rows): its two tiles are split in q-halves over all four
+  // waves and the light operand is fetched element-wise by all 256 threads.
+  constexpr int A_SPLIT = (A_ATL && !B_ATL) ? 2 : 1, B_SPLIT = (B_ATL && !A_ATL) ? 2 : 1;
+  constexpr int A_NQ = A_ATL ? HA / 8 / A_SPLIT : 0, B_NQ = B_ATL ? HB / 8 / B_SPLIT : 0;
+  constexpr int NQ = A_NQ > B_NQ ? A_NQ : B_NQ;       // float4 prefetch registers per lane for the ATL piece
+  constexpr int BRAW = B_ATL ? 0 : (DW_S * HB) / WG_THREADS;  // raw-B elements per thread (= 8 NT)
+  constexpr int BCOLS_LOG = NT == 1 ? 5 : (NT == 2 ? 6 : 7);
+
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float *As = lds;               // [DW_S][LDA]
   float *Bs = lds + DW_S * LDA;  // [DW_S][LDB]
+  float *mul = Bs + DW_S * LDB;  // [DW_S] input-LayerNorm mean  (raw-B only)
+  float *rsl = mul + DW_S;       // [DW_S] input-LayerNorm rstd
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 31, h = lane >> 5;
   const int wm = wave % SP::WM, wn = wave / SP::WM;
-  const int k0 = blockIdx.y * (32 * NT);  // first input feature handled by this workgroup (B_KIND 1)
+  const int k0 = blockIdx.y * (32 * NT);  // first input feature handled by this workgroup (raw B)
+  const bool norm_b = !B_ATL && mu0 != nullptr;
+
+  // which ATL piece this wave fetches
+  bool piece_is_a;
+  int piece_q0, piece_nq;
+  const int sl = wave & 1;
+  if (A_ATL && B_ATL) {
+    piece_is_a = wave < 2;
+    piece_q0 = 0;
+    piece_nq = piece_is_a ? A_NQ : B_NQ;
+  } else if (A_ATL) {
+    piece_is_a = true;
+    piece_q0 = (wave >> 1) * A_NQ;
+    piece_nq = A_NQ;
+  } else {
+    piece_is_a = false;
+    piece_q0 = (wave >> 1) * B_NQ;
+    piece_nq = B_NQ;
+  }
+  const float *piece_src = piece_is_a ? a_src : b_src;
+  const int piece_h = piece_is_a ? HA : HB;
+
+  f32x4 pr[NQ > 0 ? NQ : 1];
+  float xb[BRAW > 0 ? BRAW : 1];
+  f32x4 ha[2];
+  float pmu = 0.f, prs = 1.f;
+
+  auto prefetch = [&](long it) {
+    const long slab = 2 * it + sl;
+    const bool ok = slab < n_slabs;
+    if (NQ > 0) {
+      const f32x4 *p = reinterpret_cast<const f32x4 *>(piece_src + slab * (long)(piece_h * SLAB)) + lane;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+        pr[q] = (ok && q < piece_nq) ? p[(piece_q0 + q) * WAVE] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (!A_ATL) {  // head gradients [M_pad][32]: 64 rows x 8 float4, two per thread
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int f = threadIdx.x + WG_THREADS * u;
+        const int row = f >> 3, c4 = f & 7;
+        const long slab_r = 2 * it + (row >> 5);
+        ha[u] = slab_r < n_slabs ? *reinterpret_cast<const f32x4 *>(a_src + (2 * it * SLAB + row) * (long)DHEAD_LD + 4 * c4)
+                                 : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    if (!B_ATL) {  // raw input rows (gathered): thread -> fixed column, 8*NT/... samples
+#pragma unroll
+      for (int u = 0; u < BRAW; ++u) {
+        const int e = threadIdx.x + WG_THREADS * u;
+        const int s = e >> BCOLS_LOG, kk = e & (HB - 1);
+        long j = 2 * it * SLAB + s;
+        const bool okr = j < M;
+        if (j > M - 1) j = M - 1;
+        const long row = idx ? idx[j] : j;
+        const int k = k0 + kk;
+        xb[u] = (okr && k < K) ? b_src[row * ldx + k] : 0.f;
+      }
+      if (norm_b && threadIdx.x < DW_S) {
+        long j = 2 * it * SLAB + threadIdx.x;
+        if (j > M - 1) j = M - 1;
+        pmu = mu0[j];   // NB: mu0/rstd0 are indexed by minibatch position (as written by the forward pass)
+        prs = rstd0[j];
+      }
+    }
+  };
 
   f32x16 acc[SP::TM][SP::TN];
   float dbsum[SP::TM];
@@ -329,57 +408,40 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_dw(const float *__restrict__ 
   }
 
   const long n_iter = (n_slabs + 1) / 2;
+  if ((long)blockIdx.x < n_iter) prefetch(blockIdx.x);
   for (long it = blockIdx.x; it < n_iter; it += gridDim.x) {
     __syncthreads();  // previous round's fragments fully read
-    // ---- stage A (waves 0,1: slab 2it, 2it+1)  and  B (waves 2,3)
-    {
-      const int sl = wave & 1;
-      const long slab = 2 * it + sl;
-      const bool ok = slab < n_slabs;
-      if (wave < 2) {
-        if (A_KIND == 0) {
-          constexpr int H = 32 * MT;
-          const f32x4 *p = reinterpret_cast<const f32x4 *>(a_src + slab * (long)(H * SLAB)) + lane;
+    // ---- registers -> LDS as [sample][feature]
+    if (NQ > 0) {
+      float *dst = (piece_is_a ? As : Bs) + (sl * SLAB + i) * (piece_is_a ? LDA : LDB) + 4 * h;
 #pragma unroll
-          for (int q = 0; q < H / 8; ++q) {
-            f32x4 v = ok ? p[q * WAVE] : f32x4{0.f, 0.f, 0.f, 0.f};
-            *reinterpret_cast<f32x4 *>(&As[(sl * SLAB + i) * LDA + 32 * (q >> 2) + 8 * (q & 3) + 4 * h]) = v;
-          }
-        } else {  // [M_pad][32] row-major: lane -> 16 consecutive floats of one row
-          const float *p = a_src + (slab * SLAB + i) * (long)DHEAD_LD + 16 * h;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            f32x4 v = ok ? *reinterpret_cast<const f32x4 *>(p + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
-            *reinterpret_cast<f32x4 *>(&As[(sl * SLAB + i) * LDA + 16 * h + 4 * q]) = v;
-          }
-        }
-      } else {
-        if (B_KIND == 0) {
-          constexpr int H = 32 * NT;
-          const f32x4 *p = reinterpret_cast<const f32x4 *>(b_src + slab * (long)(H * SLAB)) + lane;
-#pragma unroll
-          for (int q = 0; q < H / 8; ++q) {
-            f32x4 v = ok ? p[q * WAVE] : f32x4{0.f, 0.f, 0.f, 0.f};
-            *reinterpret_cast<f32x4 *>(&Bs[(sl * SLAB + i) * LDB + 32 * (q >> 2) + 8 * (q & 3) + 4 * h]) = v;
-          }
-        } else {  // raw rows: lanes sweep the row (coalesced), one sample after the other
-          for (int s = 0; s < SLAB; ++s) {
-            long j = slab * SLAB + s;
-            if (j > M - 1) j = M - 1;
-            if (j < 0) j = 0;
-            const long row = idx ? idx[j] : j;
-            const float mu = mu0 ? mu0[slab * SLAB + s] : 0.f;
-            const float rs = rstd0 ? rstd0[slab * SLAB + s] : 1.f;
-            for (int kk = lane; kk < 32 * NT; kk += WAVE) {
-              const int k = k0 + kk;
-              float v = (ok && k < K) ? (b_src[row * ldx + k] - mu) * rs : 0.f;
-              Bs[(sl * SLAB + s) * LDB + kk] = v;
-            }
-          }
+      for (int q = 0; q < NQ; ++q) {
+        if (q < piece_nq) {
+          const int qq = piece_q0 + q;
+          *reinterpret_cast<f32x4 *>(dst + 32 * (qq >> 2) + 8 * (qq & 3)) = pr[q];
         }
       }
     }
+    if (!A_ATL) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int f = threadIdx.x + WG_THREADS * u;
+        *reinterpret_cast<f32x4 *>(&As[(f >> 3) * LDA + 4 * (f & 7)]) = ha[u];
+      }
+    }
+    if (!B_ATL) {
+#pragma unroll
+      for (int u = 0; u < BRAW; ++u) {
+        const int e = threadIdx.x + WG_THREADS * u;
+        Bs[(e >> BCOLS_LOG) * LDB + (e & (HB - 1))] = xb[u];
+      }
+      if (norm_b && threadIdx.x < DW_S) {
+        mul[threadIdx.x] = pmu;
+        rsl[threadIdx.x] = prs;
+      }
+    }
     __syncthreads();
+    if (it + gridDim.x < n_iter) prefetch(it + gridDim.x);  // next round's loads fly during the MFMA phase
     // ---- MFMA over the 64 staged samples (32 steps of 2)
 #pragma unroll 4
     for (int kk = 0; kk < DW_S / 2; ++kk) {
@@ -390,10 +452,18 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_dw(const float *__restrict__ 
         av[a] = As[srow * LDA + 32 * (wm * SP::TM + a) + i];
         if (wn == 0) dbsum[a] += av[a];
       }
+      float m_ = 0.f, r_ = 1.f;
+      if (norm_b) {
+        m_ = mul[srow];
+        r_ = rsl[srow];
+      }
 #pragma unroll
       for (int b = 0; b < SP::TN; ++b) {
         const int nt = wn * SP::TN + b;
-        bv[b] = nt < NT ? Bs[srow * LDB + 32 * nt + i] : 0.f;
+        float v = nt < NT ? Bs[srow * LDB + 32 * nt + i] : 0.f;
+        // input LayerNorm applied at fragment-read time; zero-padded columns (k >= K) become -mu*rstd, which only
+        // lands in dWp columns >= K that nobody reads
+        bv[b] = norm_b ? (v - m_) * r_ : v;
       }
 #pragma unroll
       for (int a = 0; a < SP::TM; ++a)
@@ -500,7 +570,7 @@ template <int A_KIND, int B_KIND, int MT, int NT>
 static void launch_dw(const float *a, const float *b, long ldx, const int64_t *idx, const float *mu0,
                       const float *rstd0, int K, long M, long n_slabs, float *part, int KP, int n_wg, int ny,
                       hipStream_t s) {
-  const size_t shm = (size_t)DW_S * ((32 * MT + 4) + (32 * NT + 4)) * sizeof(float);
+  const size_t shm = ((size_t)DW_S * ((32 * MT + 4) + (32 * NT + 4)) + 2 * DW_S) * sizeof(float);
   hipLaunchKernelGGL((k_dw<A_KIND, B_KIND, MT, NT>), dim3(n_wg, ny), dim3(WG_THREADS), shm, s, a, b, ldx, idx, mu0,
                      rstd0, K, M, n_slabs, part, KP);
 }

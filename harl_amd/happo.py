@@ -15,7 +15,7 @@ import torch
 
 from . import _lib
 from ._lib import PS_STRIDE, call, ptr, stream
-from .buffers import OnPolicyActorBuffer, minibatch_indices
+from .buffers import OnPolicyActorBuffer, consume_randperm, minibatch_indices
 from .dist import Comm, local_minibatch_rows
 from .nets import FusedAdam, StochasticPolicy
 from .valuenorm import _as_dev
@@ -175,15 +175,18 @@ class HAPPO(OnPolicyBase):
         for _ in range(self.ppo_epoch):
             if self.use_recurrent_policy or self.use_naive_recurrent_policy:
                 raise NotImplementedError("recurrent generators are not implemented in this round")
+            if self.actor_num_mini_batch == 1:
+                # the single "minibatch" is the whole (local) buffer: the sums do not depend on the order, so only the
+                # generator state is replayed (bit-exact RNG stream), not the 819200-element shuffle itself
+                consume_randperm(n_global)
+                self._update_core(obs, None, B, actions, avail, old_logp, adv, moments, factor,
+                                  active if self.use_policy_active_masks else None)
+                continue
             sampler = minibatch_indices(n_global, self.actor_num_mini_batch)  # CPU RNG draw, bit-exact with the reference
             for ind in sampler:
                 if self.shard:
                     ind = local_minibatch_rows(ind, self.shard[0], self.shard[1], self.shard[2])
-                if self.actor_num_mini_batch == 1:
-                    idx, m = None, B  # a full-batch "minibatch" is the whole (local) buffer: order does not enter the sums
-                else:
-                    idx, m = ind.to(dev), ind.numel()
-                self._update_core(obs, idx, m, actions, avail, old_logp, adv, moments, factor,
+                self._update_core(obs, ind.to(dev), ind.numel(), actions, avail, old_logp, adv, moments, factor,
                                   active if self.use_policy_active_masks else None)
         n_upd = self.ppo_epoch * self.actor_num_mini_batch
         vals = (self._info / n_upd).cpu().tolist()  # the single read-back of this agent's update

@@ -7,7 +7,7 @@ import torch
 
 from . import _lib
 from ._lib import PS_STRIDE, call, ptr, stream
-from .buffers import OnPolicyCriticBufferEP, minibatch_indices
+from .buffers import OnPolicyCriticBufferEP, consume_randperm, minibatch_indices
 from .dist import Comm, local_minibatch_rows
 from .nets import FusedAdam, VNet
 from .valuenorm import ValueNorm, _as_dev
@@ -118,16 +118,16 @@ class VCritic:
         for _ in range(self.critic_epoch):
             if self.use_recurrent_policy or self.use_naive_recurrent_policy:
                 raise NotImplementedError("recurrent generators are not implemented in this round")
+            if self.critic_num_mini_batch == 1:
+                consume_randperm(n_global)  # replay the generator state only (see HAPPO.train)
+                self._update_core(share_obs, None, B, n_global, value_preds, returns, value_normalizer)
+                continue
             sampler = minibatch_indices(n_global, self.critic_num_mini_batch)
             for ind in sampler:
                 m_global = ind.numel()
                 if self.shard:
                     ind = local_minibatch_rows(ind, self.shard[0], self.shard[1], self.shard[2])
-                if self.critic_num_mini_batch == 1:
-                    idx, m = None, B
-                else:
-                    idx, m = ind.to(dev), ind.numel()
-                self._update_core(share_obs, idx, m, m_global, value_preds, returns, value_normalizer)
+                self._update_core(share_obs, ind.to(dev), ind.numel(), m_global, value_preds, returns, value_normalizer)
         n_upd = self.critic_epoch * self.critic_num_mini_batch
         vals = (self._info / n_upd).cpu().tolist()
         return {"value_loss": vals[0], "critic_grad_norm": vals[1]}

@@ -373,9 +373,28 @@ def check_train_golden(name: str) -> Dict[str, float]:
         torch.cuda.synchronize()
     finally:
         torch.randperm = real
+    # Integer side.  (1) The CPU generator must end in exactly the state the reference's draws leave it in
+    # (replay the recorded reference permutations from the same seed).  (2) Every permutation this implementation
+    # materialised (agent order; minibatch permutations when num_mini_batch > 1 -- with a single minibatch only the
+    # generator state is replayed, see buffers.consume_randperm) must be bit-identical to the reference's draw at the
+    # same position of the stream.
     gp = case.perms()
-    out["perm_count_diff"] = float(abs(len(perms) - len(gp)))
-    out["perm_mismatch"] = float(sum(int(not np.array_equal(a, b)) for a, b in zip(perms, gp)))
+    state_after = torch.get_rng_state()
+    torch.manual_seed(case.seed + 12345)
+    replay_bad = 0
+    for g in gp:
+        replay_bad += int(not np.array_equal(torch.randperm(len(g)).numpy(), g))
+    out["golden_replay_mismatch"] = float(replay_bad)
+    out["rng_state_mismatch"] = float(not torch.equal(state_after, torch.get_rng_state()))
+    pos, bad = 0, 0
+    for pm in perms:
+        while pos < len(gp) and not (len(gp[pos]) == len(pm) and np.array_equal(gp[pos], pm)):
+            pos += 1
+        if pos == len(gp):
+            bad += 1
+        else:
+            pos += 1
+    out["perm_mismatch"] = float(bad)
     got = np.array([[i["policy_loss"], i["dist_entropy"], i["actor_grad_norm"], i["ratio"]] for i in infos])
     gold = z["actor_infos"]
     out["actor_policy_loss_rel"] = rel_err(got[:, 0], gold[:, 0])

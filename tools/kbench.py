@@ -1,0 +1,103 @@
+#!/usr/bin/env python3
+"""Per-kernel micro-benchmark through the C ABI at the bench shape (B = 200*4096 samples, H = 128).
+
+    python tools/kbench.py [--reps 20] [--lib path/to/libharl_hip.so] [filter ...]
+
+Prints ms per launch and the algorithmic TFLOP/s or TB/s of each kernel (HIP events on the launch stream)."""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--lib", default=None)
+    ap.add_argument("--B", type=int, default=200 * 4096)
+    ap.add_argument("filters", nargs="*")
+    args = ap.parse_args()
+    from harl_amd import _lib
+    if args.lib:
+        _lib.LIB_PATH = os.path.abspath(args.lib)
+    from harl_amd._lib import call, ptr, stream
+    dev = torch.device("cuda:0")
+    B, H = args.B, 128
+    ns = (B + 31) // 32
+    mp = ns * 32
+    g = torch.Generator(device=dev).manual_seed(0)
+    rn = lambda *s: torch.randn(*s, device=dev, generator=g)  # noqa: E731
+    obs, sobs = rn(B, 18), rn(B, 54)
+    xh1, xh2, dz, dz2 = rn(mp * H), rn(mp * H), rn(mp * H), torch.empty(mp * H, device=dev)
+    mask = torch.randint(-2**31, 2**31 - 1, (ns * 2 * 64,), device=dev, dtype=torch.int32, generator=g)
+    rstd = torch.rand(mp, device=dev, generator=g) + 0.5
+    mu0, rstd0 = torch.zeros(mp, device=dev), torch.ones(mp, device=dev)
+    W = rn(H * H) * 0.1
+    b = rn(H) * 0.1
+    W1, W1c = rn(H * 18) * 0.2, rn(H * 54) * 0.2
+    Wh, bh, ls = rn(5 * H) * 0.05, rn(5) * 0.1, torch.ones(5, device=dev)
+    Wv, bv = rn(H) * 0.05, rn(1)
+    actions, old_logp = rn(B, 5), rn(B, 5) * 0.1 - 1
+    adv, factor, active = rn(B), torch.ones(B, device=dev), torch.ones(B, device=dev)
+    dhead = rn(mp * 32) * 0.01
+    n_wg = 512
+    part = torch.empty(n_wg * (H * H + H), device=dev)
+    dwp = torch.empty(H * H + H, device=dev)
+    nb = _lib.load().harl_head_blocks(B)
+    ps = torch.zeros(nb * 48, device=dev)
+    logp_out = torch.empty(B, 5, device=dev)
+    vals = torch.empty(B, device=dev)
+    vp, ret = rn(B), rn(B)
+    vn = torch.tensor([0.1, 1.2, 0.9], device=dev)
+    T, N = 200, B // 200
+    rew, vpT, mk = rn(T, N), rn(T + 1, N), (torch.rand(T + 1, N, device=dev) > 0.04).float()
+    rets, advs = torch.empty(T + 1, N, device=dev), torch.empty(T, N, device=dev)
+    P = 20142
+    pp, gg, mm, vv = rn(P), rn(P), torch.zeros(P, device=dev), torch.zeros(P, device=dev)
+    s = stream()
+    GF = lambda f: ("TFLOP/s", f / 1e12)  # noqa: E731
+    GB = lambda f: ("TB/s", f / 1e12)  # noqa: E731
+    fl = 2.0 * B * H * H
+    jobs = [
+        ("fwd_input_D18", lambda: call("harl_mlp_fwd_input", ptr(obs), 18, None, B, 18, ptr(W1), ptr(b), 1, H, ptr(xh1), ptr(mask), ptr(rstd), ptr(mu0), ptr(rstd0), s), GB(B * (72 + 512 + 20))),
+        ("fwd_input_D54", lambda: call("harl_mlp_fwd_input", ptr(sobs), 54, None, B, 54, ptr(W1c), ptr(b), 1, H, ptr(xh1), ptr(mask), ptr(rstd), ptr(mu0), ptr(rstd0), s), GB(B * (216 + 512 + 20))),
+        ("fwd_hidden", lambda: call("harl_mlp_fwd_hidden", ptr(xh1), B, H, H, ptr(W), ptr(b), ptr(xh2), ptr(mask), ptr(rstd), s), GF(fl)),
+        ("bwd_dx", lambda: call("harl_mlp_bwd_dx", ptr(dz), ptr(xh1), ptr(mask), ptr(rstd), B, H, H, ptr(W), ptr(dz2), s), GF(fl)),
+        ("dw_hidden", lambda: call("harl_mlp_dw_partials", ptr(dz), 0, 0, H, ptr(xh1), 0, 0, None, None, None, H, B, ptr(part), n_wg, s), GF(fl)),
+        ("dw_head", lambda: call("harl_mlp_dw_partials", ptr(dhead), 1, 32, 5, ptr(xh2), 0, 0, None, None, None, H, B, ptr(part), n_wg, s), GB(B * (512 + 128))),
+        ("dw_input_D18", lambda: call("harl_mlp_dw_partials", ptr(dz), 0, 0, H, ptr(obs), 1, 18, None, ptr(mu0), ptr(rstd0), 18, B, ptr(part), n_wg, s), GB(B * (512 + 72 + 8))),
+        ("dw_input_D54", lambda: call("harl_mlp_dw_partials", ptr(dz), 0, 0, H, ptr(sobs), 1, 54, None, ptr(mu0), ptr(rstd0), 54, B, ptr(part), n_wg, s), GB(B * (512 + 216 + 8))),
+        ("reduce_partials", lambda: call("harl_reduce_partials", ptr(part), n_wg, H * H + H, ptr(dwp), s), GB(n_wg * (H * H + H) * 4)),
+        ("actor_head_logp", lambda: call("harl_actor_head_logp", ptr(xh2), B, H, ptr(Wh), ptr(bh), ptr(ls), 1.0, 0.5, 0, 5, ptr(actions), None, ptr(logp_out), None, None, 0, s), GB(B * (512 + 40))),
+        ("actor_head_loss", lambda: call("harl_actor_head_loss", ptr(xh2), ptr(mask), ptr(rstd), B, H, ptr(Wh), ptr(bh), ptr(ls), 1.0, 0.5, 0, 5, None, ptr(actions), None, ptr(old_logp), ptr(adv), None, ptr(factor), ptr(active), 0.2, 0.01, 0, ptr(dz2), ptr(dhead), ptr(ps), s), GB(B * (512 + 512 + 128 + 60))),
+        ("critic_head_loss", lambda: call("harl_critic_head_loss", ptr(xh2), ptr(mask), ptr(rstd), B, H, ptr(Wv), ptr(bv), None, ptr(vp), ptr(ret), ptr(vn), 0.2, 1, 1, 10.0, ptr(dz2), ptr(dhead), ptr(ps), s), GB(B * (512 + 512 + 128 + 8))),
+        ("critic_head_values", lambda: call("harl_critic_head_values", ptr(xh2), B, H, ptr(Wv), ptr(bv), ptr(vals), s), GB(B * 516)),
+        ("gae_returns", lambda: call("harl_gae_returns", ptr(rew), ptr(vpT), ptr(mk), ptr(mk), ptr(vpT[-1].contiguous()), ptr(vn), ptr(rets), ptr(advs), T, N, 0.99, 0.9405, 1, 1, 0, s), GB(B * 24)),
+        ("gradnorm_clip_adam", lambda: call("harl_gradnorm_clip_adam", ptr(pp), ptr(gg), ptr(mm), ptr(vv), P, None, 1, 10.0, 5e-4, 0.9, 0.999, 1e-5, 0.0, 0.1, 0.001, None, s), GB(P * 28)),
+    ]
+    print(f"B={B}  H={H}  reps={args.reps}  lib={_lib.LIB_PATH}")
+    for name, fn, (unit, work) in jobs:
+        if args.filters and not any(f in name for f in args.filters):
+            continue
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        evs = []
+        for _ in range(args.reps):
+            a, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            fn()
+            b_.record()
+            evs.append((a, b_))
+        torch.cuda.synchronize()
+        ms = sorted(a.elapsed_time(b_) for a, b_ in evs)
+        med, mn = ms[len(ms) // 2], ms[0]
+        print(f"{name:22s} median {med:8.4f} ms  min {mn:8.4f} ms   {work / (med * 1e-3):8.2f} {unit}")
+
+
+if __name__ == "__main__":
+    main()

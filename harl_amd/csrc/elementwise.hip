@@ -436,16 +436,210 @@ extern "C" int harl_reduce_partials(const float *part, int n_wg, long elems, flo
   return check_launch("harl_reduce_partials");
 }
 
-__global__ __launch_bounds__(64) void k_reduce_scalars(const float *__restrict__ ps, int n_blocks,
-                                                       double *__restrict__ out) {
-  int j = threadIdx.x;
-  if (j >= PS_STRIDE) return;
+__global__ __launch_bounds__(1024) void k_reduce_scalars(const float *__restrict__ ps, int n_blocks,
+                                                         double *__restrict__ out) {
+  // 16 row-groups x 64 columns; fixed summation order -> deterministic
+  __shared__ double sh[16][64];
+  const int j = threadIdx.x & 63, rg = threadIdx.x >> 6;
   double s = 0;
-  for (int b = 0; b < n_blocks; ++b) s += (double)ps[(long)b * PS_STRIDE + j];
-  out[j] += s;
+  if (j < PS_STRIDE)
+    for (int b = rg; b < n_blocks; b += 16) s += (double)ps[(long)b * PS_STRIDE + j];
+  sh[rg][j] = s;
+  __syncthreads();
+  if (threadIdx.x < PS_STRIDE) {
+    double t = 0;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) t += sh[g][threadIdx.x];
+    out[threadIdx.x] += t;
+  }
 }
 
 extern "C" int harl_reduce_scalars(const float *part_scalars, int n_blocks, double *scalars, void *stream) {
-  hipLaunchKernelGGL(k_reduce_scalars, dim3(1), dim3(64), 0, (hipStream_t)stream, part_scalars, n_blocks, scalars);
+  hipLaunchKernelGGL(k_reduce_scalars, dim3(1), dim3(1024), 0, (hipStream_t)stream, part_scalars, n_blocks, scalars);
   return check_launch("harl_reduce_scalars");
+}
+
+// =============================================================================================
+// Layer table (device int32[HARL_TABLE_STRIDE * n_layers]) shared by the fused kernels below.
+//   0 w_off  1 b_off  2 gamma_off (-1)  3 beta_off (-1)     offsets into the flat parameter / gradient arena
+//   4 out    5 in     6 pack_w_off      7 pack_b_off          offsets into the folded-weight arena
+//   8 dwp_off (dense folded gradient: dWp[op][kp] then dbp[op])  9 kp  10 op  11 part_off (per-WG partials arena)
+// =============================================================================================
+constexpr int TS = 12;
+
+// out[dwp_off_l + e] = sum_w part[part_off_l + w * elems_l + e]   for every layer segment, ONE launch
+__global__ __launch_bounds__(256) void k_reduce_partials_multi(const float *__restrict__ part, const int *__restrict__ tab,
+                                                               int n_layers, int n_wg, float *__restrict__ dwp) {
+  long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  for (int l = 0; l < n_layers; ++l) {
+    const int *t = tab + l * TS;
+    const long elems = (long)t[10] * t[9] + t[10];
+    if (e < elems) {
+      const float *p = part + (long)t[11] * 1 + e;  // part_off is in floats
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f, s5 = 0.f, s6 = 0.f, s7 = 0.f;
+      int w = 0;
+      for (; w + 7 < n_wg; w += 8) {
+        s0 += p[(long)(w + 0) * elems];
+        s1 += p[(long)(w + 1) * elems];
+        s2 += p[(long)(w + 2) * elems];
+        s3 += p[(long)(w + 3) * elems];
+        s4 += p[(long)(w + 4) * elems];
+        s5 += p[(long)(w + 5) * elems];
+        s6 += p[(long)(w + 6) * elems];
+        s7 += p[(long)(w + 7) * elems];
+      }
+      for (; w < n_wg; ++w) s0 += p[(long)w * elems];
+      dwp[t[8] + e] = ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
+      return;
+    }
+    e -= elems;
+  }
+}
+
+extern "C" int harl_reduce_partials_multi(const float *part, const int *table, int n_layers, int n_wg, long total_elems,
+                                          float *dwp, void *stream) {
+  if (total_elems <= 0) return 0;
+  hipLaunchKernelGGL(k_reduce_partials_multi, dim3((unsigned)((total_elems + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, part, table, n_layers, n_wg, dwp);
+  return check_launch("harl_reduce_partials_multi");
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused optimiser epilogue, ONE workgroup (P <= a few 100 k):
+//   loss scalars -> gradient scale + training statistics ; unfold folded gradients (all layers) ;
+//   ||g|| ; clip ; Adam ; re-fold the updated weights for the next forward.
+// Replaces (per update) ~25 tiny launches: unfold x L, reciprocal/cast/copy glue, grad-norm, Adam, fold x L.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_adam_fold(float *__restrict__ p, float *__restrict__ g, float *__restrict__ m,
+                                                    float *__restrict__ v, long n, const float *__restrict__ dwp,
+                                                    const int *__restrict__ tab, int n_layers, float *__restrict__ packs,
+                                                    const double *__restrict__ scalars, int mode, float const_scale,
+                                                    int logstd_off, int act_dim, float *__restrict__ info,
+                                                    int use_clip, float max_norm, float lr_over_bc1, float beta1,
+                                                    float beta2, float eps, float wd, float bc2_sqrt) {
+  __shared__ float s_scale, s_coef;
+  __shared__ double sh[16];
+  const int tid = threadIdx.x, nt = blockDim.x;
+  // ---- phase 0: scalars
+  if (tid == 0) {
+    float scale;
+    if (mode == 0) {  // actor: loss = sum / sum(active)   (happo.py:77-85)
+      const double sa = scalars[1];
+      scale = (float)(1.0 / sa);
+      if (info) {
+        info[0] += (float)(scalars[0] / sa);
+        info[1] += (float)(scalars[2] / sa);
+        info[3] += (float)(scalars[3] / scalars[4]);
+      }
+    } else {  // critic: mean over the (global) minibatch, times value_loss_coef (v_critic.py:112,146)
+      scale = const_scale;
+      if (info) info[0] += (float)(scalars[0] / scalars[1]);
+    }
+    s_scale = scale;
+  }
+  if (logstd_off >= 0 && tid < act_dim) g[logstd_off + tid] = (float)scalars[8 + tid];
+  // ---- phase 1: unfold  dW = dWp*gamma + dbp (x) beta ; db = dbp ; dgamma = sum_o W.dWp ; dbeta = sum_o W.dbp
+  for (int l = 0; l < n_layers; ++l) {
+    const int *t = tab + l * TS;
+    const int O = t[4], K = t[5], kp = t[9], op = t[10];
+    const float *dW_ = dwp + t[8];
+    const float *db_ = dW_ + (long)op * kp;
+    const float *gam = t[2] >= 0 ? p + t[2] : nullptr;
+    const float *bet = t[3] >= 0 ? p + t[3] : nullptr;
+    for (int e = tid; e < O * K; e += nt) {
+      const int o = e / K, k = e - o * K;
+      const float dwp_ = dW_[(long)o * kp + k];
+      g[t[0] + e] = gam ? dwp_ * gam[k] + db_[o] * bet[k] : dwp_;
+    }
+    for (int o = tid; o < O; o += nt) g[t[1] + o] = db_[o];
+    if (gam) {  // one wave per input column: lanes sweep the rows, wave-reduce (fixed order -> deterministic)
+      const int wv = tid >> 6, ln = tid & 63, nw = nt >> 6;
+      for (int k = wv; k < K; k += nw) {
+        float sg = 0.f, sb = 0.f;
+        for (int o = ln; o < O; o += 64) {
+          const float w = p[t[0] + o * K + k];
+          sg += w * dW_[(long)o * kp + k];
+          sb += w * db_[o];
+        }
+        sg = wave_reduce_sum(sg);
+        sb = wave_reduce_sum(sb);
+        if (ln == 0) {
+          g[t[2] + k] = sg;
+          g[t[3] + k] = sb;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- phase 2: ||g * scale||
+  const float scale = s_scale;
+  double ss = 0;
+  for (long i = tid; i < n; i += nt) {
+    const float gi = g[i] * scale;
+    ss += (double)gi * gi;
+  }
+  ss = wave_reduce_sum_d(ss);
+  if ((tid & 63) == 0) sh[tid >> 6] = ss;
+  __syncthreads();
+  if (tid == 0) {
+    double t = 0;
+    for (int i = 0; i < (nt >> 6); ++i) t += sh[i];
+    const float norm = (float)sqrt(t);
+    float coef = 1.f;
+    if (use_clip) {
+      coef = max_norm / (norm + 1e-6f);
+      coef = coef > 1.f ? 1.f : coef;
+    }
+    s_coef = coef;
+    if (info) info[2 - mode] += norm;  // actor: info[2] ; critic: info[1]
+  }
+  __syncthreads();
+  // ---- phase 3: Adam
+  const float coef = s_coef * scale;
+  const float omb1 = 1.f - beta1, omb2 = 1.f - beta2;
+  for (long i = tid; i < n; i += nt) {
+    float gi = g[i] * coef;
+    const float pi = p[i];
+    if (wd != 0.f) gi = gi + wd * pi;
+    float mi = m[i];
+    mi = mi + omb1 * (gi - mi);
+    const float vi = v[i] * beta2 + (omb2 * gi) * gi;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] = pi - lr_over_bc1 * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+  }
+  __syncthreads();
+  // ---- phase 4: re-fold   Wp = W*gamma ; bp = b + W.beta
+  for (int l = 0; l < n_layers; ++l) {
+    const int *t = tab + l * TS;
+    const int O = t[4], K = t[5];
+    const float *gam = t[2] >= 0 ? p + t[2] : nullptr;
+    const float *bet = t[3] >= 0 ? p + t[3] : nullptr;
+    for (int e = tid; e < O * K; e += nt) {
+      const int k = e % K;
+      const float w = p[t[0] + e];
+      packs[t[6] + e] = gam ? w * gam[k] : w;
+    }
+    const int wv = tid >> 6, ln = tid & 63;
+    for (int o = wv; o < O; o += (nt >> 6)) {
+      float acc = 0.f;
+      if (bet)
+        for (int k = ln; k < K; k += 64) acc += p[t[0] + o * K + k] * bet[k];
+      acc = wave_reduce_sum(acc);
+      if (ln == 0) packs[t[7] + o] = p[t[1] + o] + acc;
+    }
+  }
+}
+
+extern "C" int harl_adam_fold(float *param, float *grad, float *exp_avg, float *exp_avg_sq, long n, const float *dwp,
+                              const int *table, int n_layers, float *packs, const double *scalars, int mode,
+                              float const_scale, int logstd_off, int act_dim, float *info, int use_clip, float max_norm,
+                              float lr, float beta1, float beta2, float eps, float weight_decay,
+                              double bias_correction1, double bias_correction2, void *stream) {
+  const float step_size = (float)((double)lr / bias_correction1);
+  const float bc2_sqrt = (float)sqrt(bias_correction2);
+  hipLaunchKernelGGL(k_adam_fold, dim3(1), dim3(1024), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, dwp,
+                     table, n_layers, packs, scalars, mode, const_scale, logstd_off, act_dim, info, use_clip, max_norm,
+                     step_size, beta1, beta2, eps, weight_decay, bc2_sqrt);
+  return check_launch("harl_adam_fold");
 }

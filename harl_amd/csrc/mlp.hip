@@ -26,11 +26,9 @@ using namespace harl;
 // H features of each sample (in-lane + partner half), normalise, store ATL / mask / rstd.
 // ---------------------------------------------------------------------------------------------
 template <int HO>
-__device__ __forceinline__ void relu_norm_store(f32x16 (&acc)[HO / 32], int lane, long slab, float *__restrict__ xout,
-                                                uint32_t *__restrict__ mask_out, float *__restrict__ rstd_out) {
+__device__ __forceinline__ void relu_norm_regs(f32x16 (&acc)[HO / 32], float (&v)[HO / 2], uint32_t (&bits)[(HO / 2 + 31) / 32],
+                                               float &rstd_out) {
   constexpr int NR = HO / 2;
-  float v[NR];
-  uint32_t bits[(NR + 31) / 32];
 #pragma unroll
   for (int w = 0; w < (NR + 31) / 32; ++w) bits[w] = 0u;
   float sum = 0.f;
@@ -55,10 +53,28 @@ __device__ __forceinline__ void relu_norm_store(f32x16 (&acc)[HO / 32], int lane
   const float rstd = 1.0f / sqrtf(vs * (1.0f / HO) + 1e-5f);
 #pragma unroll
   for (int R = 0; R < NR; ++R) v[R] = (v[R] - mean) * rstd;
+  rstd_out = rstd;
+}
+
+template <int HO>
+__device__ __forceinline__ void act_store(const float (&v)[HO / 2], const uint32_t (&bits)[(HO / 2 + 31) / 32], float rstd,
+                                          int lane, long slab, float *__restrict__ xout,
+                                          uint32_t *__restrict__ mask_out, float *__restrict__ rstd_out) {
+  constexpr int NW = (HO / 2 + 31) / 32;
   atl_store<HO>(xout, slab, lane, v);
 #pragma unroll
-  for (int w = 0; w < (NR + 31) / 32; ++w) mask_out[(slab * ((NR + 31) / 32) + w) * WAVE + lane] = bits[w];
+  for (int w = 0; w < NW; ++w) mask_out[(slab * NW + w) * WAVE + lane] = bits[w];
   if (lane < 32) rstd_out[slab * SLAB + lane] = rstd;
+}
+
+template <int HO>
+__device__ __forceinline__ void relu_norm_store(f32x16 (&acc)[HO / 32], int lane, long slab, float *__restrict__ xout,
+                                                uint32_t *__restrict__ mask_out, float *__restrict__ rstd_out) {
+  float v[HO / 2];
+  uint32_t bits[(HO / 2 + 31) / 32];
+  float rstd;
+  relu_norm_regs<HO>(acc, v, bits, rstd);
+  act_store<HO>(v, bits, rstd, lane, slab, xout, mask_out, rstd_out);
 }
 
 // =============================================================================================
@@ -86,30 +102,65 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_fwd_hidden(const float *__res
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 31, h = lane >> 5;
   const float *wl_lane = Wl + i * LDW + 4 * h;
-  for (long slab = (long)blockIdx.x * WAVES_PER_WG + wave; slab < n_slabs; slab += (long)gridDim.x * WAVES_PER_WG) {
+  static_assert((HI / 8) % 8 == 0, "ping-pong ring prefetch consumes 8 float4 per outer step");
+  const long slab0 = (long)blockIdx.x * WAVES_PER_WG + wave, slab_stride = (long)gridDim.x * WAVES_PER_WG;
+  constexpr int NQ = HI / 8, NT_ = HO / 32;
+  f32x4 ringA[4], ringB[4];
+  float aX[4 * NT_], aY[4 * NT_];
+  {
+    const f32x4 *p0 = reinterpret_cast<const f32x4 *>(xin + (slab0 < n_slabs ? slab0 : 0) * (long)(HI * SLAB)) + lane;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) ringA[u] = p0[u * WAVE];
+  }
+  auto lds_frag = [&](int q, float (&a)[4 * NT_]) {  // weight fragments of q-step q: W'[32t+i][f(4q+c, h)]
+    const float *wq = wl_lane + 32 * (q >> 2) + 8 * (q & 3);
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int t = 0; t < NT_; ++t) a[c * NT_ + t] = wq[32 * t * LDW + c];
+  };
+  lds_frag(0, aX);
+  for (long slab = slab0; slab < n_slabs; slab += slab_stride) {
+    const f32x4 *xp = reinterpret_cast<const f32x4 *>(xin + slab * (long)(HI * SLAB)) + lane;
+    const long nslab = slab + slab_stride < n_slabs ? slab + slab_stride : slab;
+    const f32x4 *xp_next = reinterpret_cast<const f32x4 *>(xin + nslab * (long)(HI * SLAB)) + lane;
     f32x16 acc[HO / 32];
 #pragma unroll
     for (int t = 0; t < HO / 32; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[t][r] = bl[32 * t + (r & 3) + 8 * (r >> 2) + 4 * h];
-    // x_hat_in is streamed 4 registers (one float4 of the ATL image) at a time, one step ahead of
-    // its use: the q loop stays rolled so the scheduler cannot hoist all HI*HO/64 LDS reads.
-    const f32x4 *xp = reinterpret_cast<const f32x4 *>(xin + slab * (long)(HI * SLAB)) + lane;
-    f32x4 xv = xp[0];
+    auto mfma16 = [&](const f32x4 &xv, const float (&a)[4 * NT_]) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int t = 0; t < NT_; ++t) acc[t] = MFMA(a[c * NT_ + t], xv[c], acc[t]);
+    };
+    // Software pipeline, pinned with sched_barrier(0) so hipcc cannot undo it:
+    //  * x_hat_in streams through two 4-deep float4 register rings in ping-pong: while ring A is consumed, the
+    //    float4s for 4 q-steps later (>= 4096 MFMA cycles ~ 1.7 us) are loaded into ring B and vice versa, rolling
+    //    over into the next slab.  (Refilling the slot just consumed makes hipcc load into a temporary and copy at the
+    //    loop back-edge behind s_waitcnt vmcnt(0): full HBM latency exposed every 64 MFMAs -- measured MFMA pipe 60 %
+    //    busy, waves 46 % of their time in s_waitcnt.)
+    //  * the 16 weight fragments of q-step q+1 are read from LDS into a second register set while the 16 MFMAs of
+    //    q-step q run (the fragment stream wraps around, weights do not depend on the slab).
+    //  The outer loop stays rolled: a fully unrolled body lets the scheduler hoist all HI*HO/64 LDS reads and spill.
+#define FWD_SUBSTEP(u, q, CONS, PROD, ACUR, ANXT)                                                              \
+    PROD[u] = (q) + 4 < NQ ? xp[((q) + 4) * WAVE] : xp_next[((q) + 4 - NQ) * WAVE];                            \
+    lds_frag(((q) + 1) % NQ, ANXT);                                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
+    mfma16(CONS[u], ACUR);
 #pragma unroll 1
-    for (int q = 0; q < HI / 8; ++q) {
-      const f32x4 xn = xp[(q + 1 < HI / 8 ? q + 1 : q) * WAVE];
-      const float *wq = wl_lane + 32 * (q >> 2) + 8 * (q & 3);  // feat_base(4q)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-#pragma unroll
-        for (int t = 0; t < HO / 32; ++t) {
-          const float a = wq[32 * t * LDW + c];
-          acc[t] = MFMA(a, xv[c], acc[t]);
-        }
-      }
-      xv = xn;
+    for (int qo = 0; qo < NQ; qo += 8) {
+      FWD_SUBSTEP(0, qo + 0, ringA, ringB, aX, aY)
+      FWD_SUBSTEP(1, qo + 1, ringA, ringB, aY, aX)
+      FWD_SUBSTEP(2, qo + 2, ringA, ringB, aX, aY)
+      FWD_SUBSTEP(3, qo + 3, ringA, ringB, aY, aX)
+      FWD_SUBSTEP(0, qo + 4, ringB, ringA, aX, aY)
+      FWD_SUBSTEP(1, qo + 5, ringB, ringA, aY, aX)
+      FWD_SUBSTEP(2, qo + 6, ringB, ringA, aX, aY)
+      FWD_SUBSTEP(3, qo + 7, ringB, ringA, aY, aX)
     }
+#undef FWD_SUBSTEP
     relu_norm_store<HO>(acc, lane, slab, xout, mask_out, rstd_out);
   }
 }
@@ -230,6 +281,316 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_fwd_input(const float *__rest
 }
 
 // =============================================================================================
+// first layer, narrow inputs (D <= 64: MPE 18/54, MAMuJoCo 17/23): the 32 rows of a wave-slab are fetched
+// row-by-row with the lanes sweeping the row (each load instruction touches 1-2 cache lines instead of 64),
+// parked in LDS as xs[row][LDX] (LDX odd: the "lane = sample" reads below are conflict-free), and the input
+// LayerNorm statistics and the MFMA B operands are then taken from LDS.  Weights W'^T[k][o] resident in LDS.
+// =============================================================================================
+template <int HO>
+__global__ __launch_bounds__(WG_THREADS, 2) void k_fwd_input_staged(const float *__restrict__ X, long ldx,
+                                                                    const int64_t *__restrict__ idx, long M, int D,
+                                                                    const float *__restrict__ Wp,
+                                                                    const float *__restrict__ bp, int use_ln0,
+                                                                    float *__restrict__ xout,
+                                                                    uint32_t *__restrict__ mask_out,
+                                                                    float *__restrict__ rstd_out,
+                                                                    float *__restrict__ mu0_out,
+                                                                    float *__restrict__ rstd0_out, long n_slabs) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int nch = (D + 31) / 32;
+  const int krows = nch * 32;
+  const int LDX = D | 1;
+  float *Wt = lds;                     // [krows][HO]
+  float *bl = Wt + krows * HO;         // [HO]
+  float *xs = bl + HO;                 // [4 waves][32 rows][LDX]
+  for (int e = threadIdx.x; e < HO; e += WG_THREADS) bl[e] = bp[e];
+  for (int e = threadIdx.x; e < HO * krows; e += WG_THREADS) {
+    int o = e / krows, k = e - o * krows;
+    Wt[k * HO + o] = k < D ? Wp[(long)o * D + k] : 0.f;
+  }
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  float *xw = xs + wave * SLAB * LDX;  // this wave's 32 rows (private: no cross-wave hazards)
+  // rows per load instruction: 2 when a row fits half a wave
+  const int rpi = D <= 32 ? 2 : 1;
+  const int lane_row = rpi == 2 ? h : 0, lane_k = rpi == 2 ? i : lane;
+  for (long slab = (long)blockIdx.x * WAVES_PER_WG + wave; slab < n_slabs; slab += (long)gridDim.x * WAVES_PER_WG) {
+    // ---- fetch the slab's rows (gathered) into LDS
+    for (int r0 = 0; r0 < SLAB; r0 += rpi) {
+      const int r = r0 + lane_row;
+      long j = slab * SLAB + r;
+      if (j > M - 1) j = M - 1;
+      const long row = idx ? idx[j] : j;
+      if (lane_k < D) xw[r * LDX + lane_k] = X[row * ldx + lane_k];
+    }
+    // wave-private LDS hand-off between lanes: LDS executes a wave's accesses in order, so all that is needed is a
+    // compiler barrier + lgkmcnt(0).  (A workgroup-scope release fence would also wait for vmcnt(0), i.e. for the
+    // previous slab's 16 KiB of activation stores -- ~2 us per slab.)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    const float *xr = xw + i * LDX;  // my sample's row
+
+    float mean = 0.f, rstd = 1.f;
+    if (use_ln0) {
+      float s = 0.f;
+      for (int c = 0; c < nch; ++c) {
+        const int Dc = min(32, D - 32 * c), KS = (Dc + 1) >> 1;
+        for (int jj = 0; jj < KS; ++jj) {
+          const int kl = h * KS + jj;
+          if (kl < Dc) s += xr[32 * c + kl];
+        }
+      }
+      s += wave_xor32(s);
+      mean = s / (float)D;
+      float vs = 0.f;
+      for (int c = 0; c < nch; ++c) {
+        const int Dc = min(32, D - 32 * c), KS = (Dc + 1) >> 1;
+        for (int jj = 0; jj < KS; ++jj) {
+          const int kl = h * KS + jj;
+          if (kl < Dc) {
+            float d = xr[32 * c + kl] - mean;
+            vs += d * d;
+          }
+        }
+      }
+      vs += wave_xor32(vs);
+      rstd = 1.0f / sqrtf(vs / (float)D + 1e-5f);
+    }
+
+    f32x16 acc[HO / 32];
+#pragma unroll
+    for (int t = 0; t < HO / 32; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = bl[32 * t + (r & 3) + 8 * (r >> 2) + 4 * h];
+    for (int c = 0; c < nch; ++c) {
+      const int Dc = min(32, D - 32 * c), KS = (Dc + 1) >> 1;
+      float xv[16];
+#pragma unroll
+      for (int jj = 0; jj < 16; ++jj) {
+        const int kl = h * KS + jj;
+        xv[jj] = (jj < KS && kl < Dc) ? (xr[32 * c + kl] - mean) * rstd : 0.f;
+      }
+      const float *wt_lane = Wt + (32 * c + h * KS) * HO + i;
+#pragma unroll
+      for (int jj = 0; jj < 16; ++jj) {
+        if (jj < KS) {
+#pragma unroll
+          for (int t = 0; t < HO / 32; ++t) {
+            const float a = wt_lane[jj * HO + 32 * t];
+            acc[t] = MFMA(a, xv[jj], acc[t]);
+          }
+        }
+      }
+    }
+    relu_norm_store<HO>(acc, lane, slab, xout, mask_out, rstd_out);
+    if (lane < 32) {
+      mu0_out[slab * SLAB + lane] = mean;
+      rstd0_out[slab * SLAB + lane] = rstd;
+    }
+    __builtin_amdgcn_wave_barrier();  // all lanes done reading xw before the next slab overwrites it
+  }
+}
+
+// =============================================================================================
+// Fused two-layer forward for narrow inputs (D <= 64) and a 128 -> 128 (or 64 -> 64) second layer -- the bench
+// configuration.  x_hat_1 never leaves the registers between the layers: the accumulator image of layer 1 IS the B
+// operand of layer 2 (common.h), so the second GEMM runs straight out of the register file; x_hat_1 is written to
+// HBM only when a backward pass will need it (store1).  512-thread workgroups (8 waves) share ONE LDS copy of both
+// weight matrices (W1'^T + W2' + per-wave row staging <= 155 KiB), 1 workgroup per CU = 2 waves per SIMD.
+// Layer 2 is the pinned software pipeline of k_fwd_hidden with the global ring replaced by registers.
+// =============================================================================================
+constexpr int FUSED_WAVES = 8;
+
+template <int H, int RPI, int NCH>
+__global__ __launch_bounds__(64 * FUSED_WAVES, 2) void k_fwd_fused2(
+    const float *__restrict__ X, long ldx, const int64_t *__restrict__ idx, long M, int D, const float *__restrict__ W1p,
+    const float *__restrict__ b1p, int use_ln0, const float *__restrict__ W2p, const float *__restrict__ b2p, int store1,
+    float *__restrict__ x1out, uint32_t *__restrict__ mask1, float *__restrict__ rstd1, float *__restrict__ mu0_out,
+    float *__restrict__ rstd0_out, float *__restrict__ x2out, uint32_t *__restrict__ mask2, float *__restrict__ rstd2,
+    long n_slabs) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int NTHR = 64 * FUSED_WAVES;
+  constexpr int LDW = H + 1, NQ = H / 8, NT_ = H / 32, NPF = SLAB / RPI;
+  // compile-time row stride (odd) so every LDS address below is ONE per-lane base + an immediate offset; with a
+  // run-time stride hipcc keeps ~30 loop-invariant address VGPRs alive and spills them (measured: 46 % s_waitcnt)
+  constexpr int krows = NCH * 32, LDX = NCH * 32 + 1;
+  float *xs = lds;                              // [8 waves][32 rows][LDX]
+  float *b1l = xs + FUSED_WAVES * SLAB * LDX;   // [H]
+  float *b2l = b1l + H;                         // [H]
+  float *Wt = b2l + H;                          // [krows][H]   W1'^T
+  float *W2l = Wt + krows * H;                  // [H][H+1]
+  for (int e = threadIdx.x; e < H * H; e += NTHR) {
+    int o = e / H, k = e - o * H;
+    W2l[o * LDW + k] = W2p[e];
+  }
+  for (int e = threadIdx.x; e < H; e += NTHR) {
+    b2l[e] = b2p[e];
+    b1l[e] = b1p[e];
+  }
+  for (int e = threadIdx.x; e < H * krows; e += NTHR) {
+    int o = e / krows, k = e - o * krows;
+    Wt[k * H + o] = k < D ? W1p[(long)o * D + k] : 0.f;
+  }
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  float *xw = xs + wave * SLAB * LDX;
+  const int lane_row = RPI == 2 ? h : 0, lane_k = RPI == 2 ? i : lane;
+  const float *wl_lane = W2l + i * LDW + 4 * h;
+  const long slab0 = (long)blockIdx.x * FUSED_WAVES + wave, slab_stride = (long)gridDim.x * FUSED_WAVES;
+
+  float pf[NPF];  // next slab's rows, in flight while this slab computes
+  auto prefetch_rows = [&](long slab) {
+#pragma unroll
+    for (int u = 0; u < NPF; ++u) {
+      long j = slab * SLAB + u * RPI + lane_row;
+      if (j > M - 1) j = M - 1;
+      const long row = idx ? idx[j] : j;
+      pf[u] = lane_k < D ? X[row * ldx + lane_k] : 0.f;
+    }
+  };
+  auto lds_frag = [&](int q, float (&a)[4 * NT_]) {
+    const float *wq = wl_lane + 32 * (q >> 2) + 8 * (q & 3);
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int t = 0; t < NT_; ++t) a[c * NT_ + t] = wq[32 * t * LDW + c];
+  };
+  if (slab0 < n_slabs) prefetch_rows(slab0);
+
+  for (long slab = slab0; slab < n_slabs; slab += slab_stride) {
+    // ---- rows -> LDS (private to the wave), then prefetch the next slab's rows
+#pragma unroll
+    for (int u = 0; u < NPF; ++u)
+      if (lane_k < D) xw[(u * RPI + lane_row) * LDX + lane_k] = pf[u];
+    // wave-private LDS hand-off between lanes: LDS executes a wave's accesses in order, so all that is needed is a
+    // compiler barrier + lgkmcnt(0).  (A workgroup-scope release fence would also wait for vmcnt(0), i.e. for the
+    // previous slab's 16 KiB of activation stores -- ~2 us per slab.)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    const float *xr = xw + i * LDX;
+
+    // ---- my sample's features (<= 16 per 32-feature chunk and lane half) -> registers in ONE sweep of independent
+    // LDS reads; input-LayerNorm statistics (two-pass, from registers) and normalisation in place
+    float xv[NCH][16];
+    int ks[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int Dc = min(32, D - 32 * c);
+      ks[c] = Dc > 0 ? (Dc + 1) >> 1 : 0;
+#pragma unroll
+      for (int jj = 0; jj < 16; ++jj) {
+        const int kl = h * ks[c] + jj;
+        xv[c][jj] = (jj < ks[c] && kl < Dc) ? xr[32 * c + kl] : 0.f;
+      }
+    }
+    float mean = 0.f, rstd0 = 1.f;
+    if (use_ln0) {
+      float sm = 0.f;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) sm += xv[c][jj];  // invalid slots hold 0
+      sm += wave_xor32(sm);
+      mean = sm / (float)D;
+      float vs = 0.f;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int Dc = min(32, D - 32 * c);
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) {
+          const int kl = h * ks[c] + jj;
+          const float d = xv[c][jj] - mean;
+          vs += (jj < ks[c] && kl < Dc) ? d * d : 0.f;
+        }
+      }
+      vs += wave_xor32(vs);
+      rstd0 = 1.0f / sqrtf(vs / (float)D + 1e-5f);
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int Dc = min(32, D - 32 * c);
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) {
+          const int kl = h * ks[c] + jj;
+          xv[c][jj] = (jj < ks[c] && kl < Dc) ? (xv[c][jj] - mean) * rstd0 : 0.f;
+        }
+      }
+    }
+
+    // ---- layer 1: weight fragments of step jj+1 are read (unconditionally, from a clamped row) while the MFMAs of
+    // step jj run; steps beyond KS are skipped with a wave-uniform branch
+    float x1[H / 2];
+    uint32_t bits1[(H / 2 + 31) / 32];
+    float r1;
+    {
+      f32x16 acc[NT_];
+#pragma unroll
+      for (int t = 0; t < NT_; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = b1l[32 * t + (r & 3) + 8 * (r >> 2) + 4 * h];
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int KS = ks[c];
+        const float *wt_lane = Wt + (32 * c + h * KS) * H + i;
+        float a_cur[NT_], a_nxt[NT_];
+#pragma unroll
+        for (int t = 0; t < NT_; ++t) a_cur[t] = wt_lane[32 * t];
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) {
+          const int jn = jj + 1 < KS ? jj + 1 : jj;  // clamped: always a valid LDS row
+#pragma unroll
+          for (int t = 0; t < NT_; ++t) a_nxt[t] = wt_lane[jn * H + 32 * t];
+          if (jj < KS) {
+#pragma unroll
+            for (int t = 0; t < NT_; ++t) acc[t] = MFMA(a_cur[t], xv[c][jj], acc[t]);
+          }
+#pragma unroll
+          for (int t = 0; t < NT_; ++t) a_cur[t] = a_nxt[t];
+        }
+      }
+      relu_norm_regs<H>(acc, x1, bits1, r1);
+    }
+    if (store1) {
+      act_store<H>(x1, bits1, r1, lane, slab, x1out, mask1, rstd1);
+      if (lane < 32) {
+        mu0_out[slab * SLAB + lane] = mean;
+        rstd0_out[slab * SLAB + lane] = rstd0;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();  // all lanes done with xw before the next slab's rows overwrite it
+
+    // ---- layer 2 straight out of the register file
+    f32x16 acc[NT_];
+#pragma unroll
+    for (int t = 0; t < NT_; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = b2l[32 * t + (r & 3) + 8 * (r >> 2) + 4 * h];
+    // one fragment register set, each register refilled for q-step q+1 right after the MFMA that read it has issued
+    // (the WAR dependency pins the refill; its LDS latency hides under the following 15 MFMAs)
+    float aX[4 * NT_];
+    lds_frag(0, aX);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const float *wn = wl_lane + 32 * ((q + 1) >> 2) + 8 * ((q + 1) & 3);
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int t = 0; t < NT_; ++t) {
+          acc[t] = MFMA(aX[c * NT_ + t], x1[4 * q + c], acc[t]);
+          if (q + 1 < NQ) aX[c * NT_ + t] = wn[32 * t * LDW + c];
+        }
+    }
+    // next slab's rows: issued here (not earlier) so the 16-32 prefetch registers are not live across the layer-2
+    // loop; the epilogue below (~1.5k cycles) and the other wave's MFMAs cover most of the latency
+    if (slab + slab_stride < n_slabs) prefetch_rows(slab + slab_stride);
+    relu_norm_store<H>(acc, lane, slab, x2out, mask2, rstd2);
+  }
+}
+
+// =============================================================================================
 // backward through Linear(HI->HO) and the relu+norm in front of it:
 //   dx_hat = Wp^T dz ;  da = rstd (dx_hat - mean_f(dx_hat) - x_hat mean_f(dx_hat x_hat)) ;  dz_prev = mask ? da : 0
 // A operand = Wp^T: lane i -> input feature 32t+i, step R -> output feature f(R,h); Wp row-major
@@ -248,31 +609,61 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_bwd_dx(const float *__restric
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 31, h = lane >> 5;
   const float *wl_lane = Wl + 4 * h * HI + i;
-  for (long slab = (long)blockIdx.x * WAVES_PER_WG + wave; slab < n_slabs; slab += (long)gridDim.x * WAVES_PER_WG) {
+  static_assert((HO / 8) % 8 == 0, "ping-pong ring prefetch consumes 8 float4 per outer step");
+  const long slab0 = (long)blockIdx.x * WAVES_PER_WG + wave, slab_stride = (long)gridDim.x * WAVES_PER_WG;
+  constexpr int NQ = HO / 8, NT_ = HI / 32;
+  f32x4 ringA[4], ringB[4];
+  float aX[4 * NT_], aY[4 * NT_];
+  {
+    const f32x4 *p0 = reinterpret_cast<const f32x4 *>(dz + (slab0 < n_slabs ? slab0 : 0) * (long)(HO * SLAB)) + lane;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) ringA[u] = p0[u * WAVE];
+  }
+  auto lds_frag = [&](int q, float (&a)[4 * NT_]) {  // W'^T fragments: W'[f(4q+c, h)][32t+i]
+    const float *wq = wl_lane + (32 * (q >> 2) + 8 * (q & 3)) * HI;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int t = 0; t < NT_; ++t) a[c * NT_ + t] = wq[c * HI + 32 * t];
+  };
+  lds_frag(0, aX);
+  for (long slab = slab0; slab < n_slabs; slab += slab_stride) {
+    const f32x4 *gp = reinterpret_cast<const f32x4 *>(dz + slab * (long)(HO * SLAB)) + lane;
+    const long nslab = slab + slab_stride < n_slabs ? slab + slab_stride : slab;
+    const f32x4 *gp_next = reinterpret_cast<const f32x4 *>(dz + nslab * (long)(HO * SLAB)) + lane;
+    // operands of the LayerNorm backward: issued now, consumed after the MFMA loop (latency fully hidden)
+    float xh[HI / 2];
+    atl_load<HI>(xprev, slab, lane, xh);
+    const float rstd = rstd_prev[slab * SLAB + i];
     f32x16 acc[HI / 32];
 #pragma unroll
     for (int t = 0; t < HI / 32; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    const f32x4 *gp = reinterpret_cast<const f32x4 *>(dz + slab * (long)(HO * SLAB)) + lane;
-    f32x4 gv = gp[0];
+    auto mfma16 = [&](const f32x4 &gv, const float (&a)[4 * NT_]) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int t = 0; t < NT_; ++t) acc[t] = MFMA(a[c * NT_ + t], gv[c], acc[t]);
+    };
+    // same pinned software pipeline as k_fwd_hidden (ping-pong global rings + double-buffered LDS fragments)
+#define BWD_SUBSTEP(u, q, CONS, PROD, ACUR, ANXT)                                                              \
+    PROD[u] = (q) + 4 < NQ ? gp[((q) + 4) * WAVE] : gp_next[((q) + 4 - NQ) * WAVE];                            \
+    lds_frag(((q) + 1) % NQ, ANXT);                                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
+    mfma16(CONS[u], ACUR);
 #pragma unroll 1
-    for (int q = 0; q < HO / 8; ++q) {
-      const f32x4 gn = gp[(q + 1 < HO / 8 ? q + 1 : q) * WAVE];
-      const float *wq = wl_lane + (32 * (q >> 2) + 8 * (q & 3)) * HI;  // row feat_base(4q) (+4h in wl_lane)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-#pragma unroll
-        for (int t = 0; t < HI / 32; ++t) {
-          const float a = wq[c * HI + 32 * t];
-          acc[t] = MFMA(a, gv[c], acc[t]);
-        }
-      }
-      gv = gn;
+    for (int qo = 0; qo < NQ; qo += 8) {
+      BWD_SUBSTEP(0, qo + 0, ringA, ringB, aX, aY)
+      BWD_SUBSTEP(1, qo + 1, ringA, ringB, aY, aX)
+      BWD_SUBSTEP(2, qo + 2, ringA, ringB, aX, aY)
+      BWD_SUBSTEP(3, qo + 3, ringA, ringB, aY, aX)
+      BWD_SUBSTEP(0, qo + 4, ringB, ringA, aX, aY)
+      BWD_SUBSTEP(1, qo + 5, ringB, ringA, aY, aX)
+      BWD_SUBSTEP(2, qo + 6, ringB, ringA, aX, aY)
+      BWD_SUBSTEP(3, qo + 7, ringB, ringA, aY, aX)
     }
-    float xh[HI / 2];
-    atl_load<HI>(xprev, slab, lane, xh);
-    const float rstd = rstd_prev[slab * SLAB + i];
+#undef BWD_SUBSTEP
     float dx[HI / 2];
 #pragma unroll
     for (int R = 0; R < HI / 2; ++R) dx[R] = acc[R >> 4][R & 15];
@@ -512,19 +903,58 @@ extern "C" int harl_mlp_fwd_input(const float *X, long ldx, const int64_t *idx, 
   if (M <= 0) return 0;
   const long n_slabs = n_slabs_of(M);
   const int nch = (D + 31) / 32;
-  const int resident = (long)nch * 32 * H * 4 <= 64 * 1024;
-  const size_t shm = ((size_t)(resident ? nch * 32 : 32) * H + H) * sizeof(float);
   const int grid = persistent_grid(n_slabs, 2);
   hipStream_t s = (hipStream_t)stream;
-  if (H == 128)
+  if (H != 128 && H != 64) return bad("harl_mlp_fwd_input: hidden width must be 64 or 128");
+  if (D <= 64) {
+    const size_t shm = ((size_t)nch * 32 * H + H + (size_t)WG_THREADS / 2 * (D | 1)) * sizeof(float);
+    if (H == 128) {
+      allow_big_lds(k_fwd_input_staged<128>, shm);
+      hipLaunchKernelGGL((k_fwd_input_staged<128>), dim3(grid), dim3(WG_THREADS), shm, s, X, ldx, idx, M, D, Wp, bp,
+                         use_ln0, xout, relu_mask, rstd, mu0, rstd0, n_slabs);
+    } else {
+      allow_big_lds(k_fwd_input_staged<64>, shm);
+      hipLaunchKernelGGL((k_fwd_input_staged<64>), dim3(grid), dim3(WG_THREADS), shm, s, X, ldx, idx, M, D, Wp, bp,
+                         use_ln0, xout, relu_mask, rstd, mu0, rstd0, n_slabs);
+    }
+    return check_launch("harl_mlp_fwd_input");
+  }
+  const int resident = (long)nch * 32 * H * 4 <= 64 * 1024;
+  const size_t shm = ((size_t)(resident ? nch * 32 : 32) * H + H) * sizeof(float);
+  if (H == 128) {
+    allow_big_lds(k_fwd_input<128>, shm);
     hipLaunchKernelGGL((k_fwd_input<128>), dim3(grid), dim3(WG_THREADS), shm, s, X, ldx, idx, M, D, Wp, bp, use_ln0,
                        xout, relu_mask, rstd, mu0, rstd0, n_slabs, nch, resident);
-  else if (H == 64)
+  } else {
+    allow_big_lds(k_fwd_input<64>, shm);
     hipLaunchKernelGGL((k_fwd_input<64>), dim3(grid), dim3(WG_THREADS), shm, s, X, ldx, idx, M, D, Wp, bp, use_ln0,
                        xout, relu_mask, rstd, mu0, rstd0, n_slabs, nch, resident);
-  else
-    return bad("harl_mlp_fwd_input: hidden width must be 64 or 128");
+  }
   return check_launch("harl_mlp_fwd_input");
+}
+
+extern "C" int harl_mlp_fwd_fused2(const float *X, long ldx, const int64_t *idx, long M, int D, const float *W1p,
+                                   const float *b1p, int use_ln0, const float *W2p, const float *b2p, int H, int store1,
+                                   float *x1out, uint32_t *mask1, float *rstd1, float *mu0, float *rstd0, float *x2out,
+                                   uint32_t *mask2, float *rstd2, void *stream) {
+  if (M <= 0) return 0;
+  if (D > 32) return bad("harl_mlp_fwd_fused2: input width must be <= 32 (LDS budget)");
+  if (H != 128 && H != 64) return bad("harl_mlp_fwd_fused2: hidden width must be 64 or 128");
+  const long n_slabs = n_slabs_of(M);
+  const int nch = (D + 31) / 32;
+  const size_t shm = ((size_t)H * (H + 1) + 2 * H + (size_t)nch * 32 * H + (size_t)FUSED_WAVES * SLAB * (nch * 32 + 1)) * sizeof(float);
+  long wgs = (n_slabs + FUSED_WAVES - 1) / FUSED_WAVES;
+  const int grid = (int)(wgs < 256 ? (wgs < 1 ? 1 : wgs) : 256);
+  hipStream_t s = (hipStream_t)stream;
+#define LF(Hv, R, C)                                                                                                 \
+  {                                                                                                                  \
+    allow_big_lds(k_fwd_fused2<Hv, R, C>, shm);                                                                      \
+    hipLaunchKernelGGL((k_fwd_fused2<Hv, R, C>), dim3(grid), dim3(64 * FUSED_WAVES), shm, s, X, ldx, idx, M, D, W1p,  \
+                       b1p, use_ln0, W2p, b2p, store1, x1out, mask1, rstd1, mu0, rstd0, x2out, mask2, rstd2, n_slabs); \
+  }
+  if (H == 128) LF(128, 2, 1) else LF(64, 2, 1)
+#undef LF
+  return check_launch("harl_mlp_fwd_fused2");
 }
 
 extern "C" int harl_mlp_fwd_hidden(const float *xin, long M, int HI, int HO, const float *Wp, const float *bp,

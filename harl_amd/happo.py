@@ -53,7 +53,7 @@ class OnPolicyBase:
     # ---- log-prob passes over a whole [T*N] batch (on_policy_ha_runner.py:66-83,96-113) --------------
     def _logp_pass(self, obs, actions, avail, M, logp_out, old_logp=None, factor=None):
         net = self.actor
-        net.forward_trunk(obs, None, M)
+        net.forward_trunk(obs, None, M, for_backward=False)
         Wp, bp = net._packs[-1]
         call("harl_actor_head_logp", ptr(net.xh[-1]), M, net.hidden_sizes[-1], ptr(Wp), ptr(bp), ptr(net.log_std()),
              net.std_x_coef, net.std_y_coef, int(net.discrete), net.act_dim, ptr(actions), ptr(avail), ptr(logp_out),
@@ -113,21 +113,15 @@ class HAPPO(OnPolicyBase):
         call("harl_reduce_scalars", ptr(net.part_scalars), _lib.load().harl_head_blocks(m), ptr(net.scalars), s)
         net.backward_trunk(obs, idx, m)
         sc = net.scalars
-        if not net.discrete:
-            net.gview("act.action_out.log_std").copy_(sc[8:8 + net.act_dim])
-        if self.comm.enabled:
+        if self.comm.enabled:  # ONE collective per optimiser step: [folded gradients | loss scalars]
             if self._staging is None:
-                self._staging = torch.empty(net.n_params + 2 * PS_STRIDE, **self.tpdv)
-            self.comm.all_reduce_packed(net.flat_grad, sc, self._staging)
-        # loss = sum / sum(active) (happo.py:77-85); gradients are linear in 1/sum(active)
-        grad_scale = (1.0 / sc[1]).to(torch.float32).reshape(1)
-        if self._grad_tap is not None:  # test hook: scaled, pre-clip gradient of this update
-            self._grad_tap(net.flat_grad * grad_scale, sc.clone())
-        self.actor_optimizer.step(grad_scale, self.use_max_grad_norm, self.max_grad_norm, self._info[2:3])
-        self._info[0] += (sc[0] / sc[1]).to(torch.float32)
-        self._info[1] += (sc[2] / sc[1]).to(torch.float32)
-        self._info[3] += (sc[3] / sc[4]).to(torch.float32)
-        net.fold()
+                self._staging = torch.empty(net.total_dwp + 2 * PS_STRIDE, **self.tpdv)
+            self.comm.all_reduce_packed(net.dwp, sc, self._staging)
+        # loss = sum / sum(active) (happo.py:77-85): gradients are linear in 1/sum(active), applied inside the kernel
+        ls_off = -1 if net.discrete else net.offsets["act.action_out.log_std"][0]
+        self.actor_optimizer.step(0, 0.0, self.use_max_grad_norm, self.max_grad_norm, self._info, ls_off, net.act_dim)
+        if self._grad_tap is not None:  # test hook: scaled, pre-clip gradient of this update (host sync)
+            self._grad_tap(net.flat_grad * float(1.0 / sc[1].item()), sc.clone())
 
     def update(self, sample):
         """API-compatible single update on an already-gathered minibatch (tuple order of happo.py:37-48).

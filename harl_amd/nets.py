@@ -131,13 +131,37 @@ class _FlatNet(nn.Module):
     def _head_names(self) -> Tuple[str, str, int]:
         raise NotImplementedError
 
+    def _build_tables(self) -> None:
+        """Folded-weight arena, dense folded-gradient arena and the device layer table (include/harl_hip.h,
+        HARL_TABLE_STRIDE) used by harl_reduce_partials_multi / harl_adam_fold."""
+        layers = self._layers()
+        dev = self.device_
+        rows, pack_off, dwp_off = [], 0, 0
+        self._pack_offs, self._dwp_offs, self._elems = [], [], []
+        for (wn, bn, gn, ben, o, k) in layers:
+            kp, op = ((k + 31) // 32) * 32, ((o + 31) // 32) * 32
+            elems = op * kp + op
+            rows.append([self.offsets[wn][0], self.offsets[bn][0], self.offsets[gn][0] if gn else -1,
+                         self.offsets[ben][0] if ben else -1, o, k, pack_off, pack_off + o * k, dwp_off, kp, op, 0])
+            self._pack_offs.append((pack_off, pack_off + o * k))
+            self._dwp_offs.append(dwp_off)
+            self._elems.append(elems)
+            pack_off += o * k + o
+            dwp_off += elems
+        self._table_rows = rows
+        self.pack_arena = torch.empty(pack_off, dtype=torch.float32, device=dev)
+        self.dwp = torch.zeros(dwp_off, dtype=torch.float32, device=dev)
+        self.total_dwp = dwp_off
+        self._packs = [(self.pack_arena[a:b], self.pack_arena[b:b + o]) for (a, b), (_, _, _, _, o, _) in
+                       zip(self._pack_offs, layers)]
+        self.table = None  # device table is finalised in _ensure_ws (part offsets depend on n_wg)
+
     def fold(self) -> None:
-        """Recompute the folded weights from the current parameters (after init / load / every Adam step)."""
+        """Recompute the folded weights from the current parameters (after init / load_state_dict; the optimiser
+        step re-folds inside harl_adam_fold)."""
         layers = self._layers()
         if not self._packs:
-            for (_, _, _, _, o, k) in layers:
-                self._packs.append((torch.empty(o * k, dtype=torch.float32, device=self.device_),
-                                    torch.empty(o, dtype=torch.float32, device=self.device_)))
+            self._build_tables()
         s = stream()
         for (wn, bn, gn, ben, o, k), (Wp, bp) in zip(layers, self._packs):
             call("harl_fold_linear", ptr(self.pview(wn)), ptr(self.pview(bn)),
@@ -161,61 +185,60 @@ class _FlatNet(nn.Module):
         self.dhead = torch.zeros(mp * DHEAD_LD, dtype=f32, device=dev)
         n_iter = (n_slabs + 1) // 2
         self.n_wg = max(1, min(512, n_iter))
-        kp_in = ((self.in_dim + 31) // 32) * 32
-        elems = max([hmax * hmax + hmax, hmax * kp_in + hmax, 32 * hmax + 32])
-        self.part = torch.empty(self.n_wg * elems, dtype=f32, device=dev)
-        self.dwp = torch.empty(elems, dtype=f32, device=dev)
+        part_off, rows = 0, [list(r) for r in self._table_rows]
+        self._part_offs = []
+        for r, elems in zip(rows, self._elems):
+            r[11] = part_off
+            self._part_offs.append(part_off)
+            part_off += self.n_wg * elems
+        self.part = torch.empty(part_off, dtype=f32, device=dev)
+        self.table = torch.tensor(rows, dtype=torch.int32, device=dev).reshape(-1).contiguous()
         self.n_head_blocks = _lib.load().harl_head_blocks(M)
         self.part_scalars = torch.zeros(self.n_head_blocks * PS_STRIDE, dtype=f32, device=dev)
         self.scalars = torch.zeros(PS_STRIDE, dtype=torch.float64, device=dev)
         self._max_rows = M
 
     # ---- trunk forward: X[rows, D] (gathered by idx) -> x_hat_L in self.xh[-1] ------------------
-    def forward_trunk(self, X: torch.Tensor, idx: Optional[torch.Tensor], M: int) -> None:
+    def forward_trunk(self, X: torch.Tensor, idx: Optional[torch.Tensor], M: int, for_backward: bool = True) -> None:
         assert X.dim() == 2 and X.shape[1] == self.in_dim and X.is_contiguous()
         self._ensure_ws(M)
         s = stream()
-        Wp, bp = self._packs[0]
-        h0 = self.hidden_sizes[0]
-        call("harl_mlp_fwd_input", ptr(X), X.shape[1], ptr(idx), M, self.in_dim, ptr(Wp), ptr(bp),
-             int(self.use_feature_normalization), h0, ptr(self.xh[0]), ptr(self.rmask[0]), ptr(self.rstd[0]),
-             ptr(self.mu0), ptr(self.rstd0), s, tag="fwd_input")
-        for l in range(1, len(self.hidden_sizes)):
+        hs = self.hidden_sizes
+        first_hidden = 1
+        if len(hs) >= 2 and hs[0] == hs[1] and self.in_dim <= 32:
+            # layers 1+2 fused: x_hat_1 stays in registers; it is written out only if a backward pass follows
+            (W1, b1), (W2, b2) = self._packs[0], self._packs[1]
+            call("harl_mlp_fwd_fused2", ptr(X), X.shape[1], ptr(idx), M, self.in_dim, ptr(W1), ptr(b1),
+                 int(self.use_feature_normalization), ptr(W2), ptr(b2), hs[0], int(for_backward), ptr(self.xh[0]),
+                 ptr(self.rmask[0]), ptr(self.rstd[0]), ptr(self.mu0), ptr(self.rstd0), ptr(self.xh[1]),
+                 ptr(self.rmask[1]), ptr(self.rstd[1]), s, tag="fwd_fused2")
+            first_hidden = 2
+        else:
+            Wp, bp = self._packs[0]
+            call("harl_mlp_fwd_input", ptr(X), X.shape[1], ptr(idx), M, self.in_dim, ptr(Wp), ptr(bp),
+                 int(self.use_feature_normalization), hs[0], ptr(self.xh[0]), ptr(self.rmask[0]), ptr(self.rstd[0]),
+                 ptr(self.mu0), ptr(self.rstd0), s, tag="fwd_input")
+        for l in range(first_hidden, len(hs)):
             Wp, bp = self._packs[l]
-            call("harl_mlp_fwd_hidden", ptr(self.xh[l - 1]), M, self.hidden_sizes[l - 1], self.hidden_sizes[l],
+            call("harl_mlp_fwd_hidden", ptr(self.xh[l - 1]), M, hs[l - 1], hs[l],
                  ptr(Wp), ptr(bp), ptr(self.xh[l]), ptr(self.rmask[l]), ptr(self.rstd[l]), s, tag="fwd_hidden")
 
-    # ---- backward: dz_L (in self.dz[0]) and dhead -> flat_grad (UNSCALED sums over samples) ------
+    # ---- backward: dz_L (in self.dz[0]) and dhead -> dense folded gradients self.dwp (UNSCALED sums over samples)
     def backward_trunk(self, X: torch.Tensor, idx: Optional[torch.Tensor], M: int) -> None:
         s = stream()
-        layers = self._layers()
         L = len(self.hidden_sizes)
         nwg = self.n_wg
-
-        def finish(layer_i: int, o: int, k: int) -> None:
-            wn, bn, gn, ben, _, _ = layers[layer_i]
-            kp = ((k + 31) // 32) * 32
-            op = ((o + 31) // 32) * 32
-            elems = op * kp + op
-            call("harl_reduce_partials", ptr(self.part), nwg, elems, ptr(self.dwp), s, tag="reduce_partials")
-            dbp = self.dwp[op * kp:]
-            call("harl_unfold_linear_grads", ptr(self.dwp), ptr(dbp), kp, ptr(self.pview(wn)),
-                 ptr(self.pview(gn)) if gn else None, ptr(self.pview(ben)) if ben else None,
-                 ptr(self.gview(wn)), ptr(self.gview(bn)), ptr(self.gview(gn)) if gn else None,
-                 ptr(self.gview(ben)) if ben else None, o, k, s)
-
-        # head: dW_head' = dhead^T x_hat_L
-        hdim = layers[-1][4]
+        po = self._part_offs
+        hdim = self._layers()[-1][4]
         hL = self.hidden_sizes[-1]
+        # head: dW_head' = dhead^T x_hat_L
         call("harl_mlp_dw_partials", ptr(self.dhead), 1, DHEAD_LD, hdim, ptr(self.xh[-1]), 0, 0, None, None, None, hL, M,
-             ptr(self.part), nwg, s, tag="dw_head")
-        finish(L, hdim, hL)
+             ptr(self.part[po[L]:]), nwg, s, tag="dw_head")
         cur = 0  # self.dz[cur] holds dz_l
         for l in range(L - 1, 0, -1):
             ho, hi = self.hidden_sizes[l], self.hidden_sizes[l - 1]
             call("harl_mlp_dw_partials", ptr(self.dz[cur]), 0, 0, ho, ptr(self.xh[l - 1]), 0, 0, None, None, None, hi, M,
-                 ptr(self.part), nwg, s, tag="dw_hidden")
-            finish(l, ho, hi)
+                 ptr(self.part[po[l]:]), nwg, s, tag="dw_hidden")
             Wp, _ = self._packs[l]
             call("harl_mlp_bwd_dx", ptr(self.dz[cur]), ptr(self.xh[l - 1]), ptr(self.rmask[l - 1]), ptr(self.rstd[l - 1]),
                  M, ho, hi, ptr(Wp), ptr(self.dz[1 - cur]), s, tag="bwd_dx")
@@ -224,8 +247,10 @@ class _FlatNet(nn.Module):
         use_ln = self.use_feature_normalization
         call("harl_mlp_dw_partials", ptr(self.dz[cur]), 0, 0, h0, ptr(X), 1, X.shape[1], ptr(idx),
              ptr(self.mu0) if use_ln else None, ptr(self.rstd0) if use_ln else None, self.in_dim, M,
-             ptr(self.part), nwg, s, tag="dw_input")
-        finish(0, h0, self.in_dim)
+             ptr(self.part[po[0]:]), nwg, s, tag="dw_input")
+        # deterministic fixed-order combine of every layer's per-workgroup partials, one launch
+        call("harl_reduce_partials_multi", ptr(self.part), ptr(self.table), L + 1, nwg, self.total_dwp, ptr(self.dwp), s,
+             tag="reduce_partials")
 
     def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):  # keep views, then refold
         out = super().load_state_dict(state_dict, strict=strict, assign=False)
@@ -311,17 +336,20 @@ class FusedAdam:
     def zero_grad(self) -> None:  # gradients are overwritten, never accumulated
         return None
 
-    def step(self, grad_scale: Optional[torch.Tensor], use_clip: bool, max_norm: float,
-             info_out: Optional[torch.Tensor]) -> None:
+    def step(self, mode: int, const_scale: float, use_clip: bool, max_norm: float, info_out: Optional[torch.Tensor],
+             logstd_off: int = -1, act_dim: int = 0) -> None:
+        """One fused launch: loss scalars -> scale/statistics, unfold, ||g||, clip, Adam, re-fold (harl_adam_fold)."""
         g = self.param_groups[0]
         self.step_count += 1
         b1, b2 = g["betas"]
         bc1 = 1.0 - b1 ** self.step_count
         bc2 = 1.0 - b2 ** self.step_count
         n = self.net
-        call("harl_gradnorm_clip_adam", ptr(n.flat_param), ptr(n.flat_grad), ptr(self.exp_avg), ptr(self.exp_avg_sq),
-             n.n_params, ptr(grad_scale), int(use_clip), float(max_norm), float(g["lr"]), float(b1), float(b2),
-             float(g["eps"]), float(g["weight_decay"]), bc1, bc2, ptr(info_out), stream(), tag="gradnorm_clip_adam")
+        call("harl_adam_fold", ptr(n.flat_param), ptr(n.flat_grad), ptr(self.exp_avg), ptr(self.exp_avg_sq), n.n_params,
+             ptr(n.dwp), ptr(n.table), len(n.hidden_sizes) + 1, ptr(n.pack_arena), ptr(n.scalars), int(mode),
+             float(const_scale), int(logstd_off), int(act_dim), ptr(info_out), int(use_clip), float(max_norm),
+             float(g["lr"]), float(b1), float(b2), float(g["eps"]), float(g["weight_decay"]), bc1, bc2, stream(),
+             tag="adam_fold")
 
     def state_dict(self) -> dict:
         return dict(step=self.step_count, exp_avg=self.exp_avg.clone(), exp_avg_sq=self.exp_avg_sq.clone(),

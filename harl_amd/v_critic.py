@@ -41,7 +41,6 @@ class VCritic:
         self.comm = Comm()
         self.shard = None
         self._info = torch.zeros(2, **self.tpdv)  # sums of value_loss, critic_grad_norm
-        self._scale = torch.zeros(1, **self.tpdv)
         self._staging = None
         self._grad_tap = None
 
@@ -57,7 +56,7 @@ class VCritic:
         M = x.shape[0]
         net = self.critic
         net.fold()
-        net.forward_trunk(x, None, M)
+        net.forward_trunk(x, None, M, for_backward=False)
         Wp, bp = net._packs[-1]
         out = torch.empty(M, 1, **self.tpdv)
         call("harl_critic_head_values", ptr(net.xh[-1]), M, net.hidden_sizes[-1], ptr(Wp), ptr(bp), ptr(out), stream())
@@ -80,15 +79,13 @@ class VCritic:
         sc = net.scalars
         if self.comm.enabled:
             if self._staging is None:
-                self._staging = torch.empty(net.n_params + 2 * PS_STRIDE, **self.tpdv)
-            self.comm.all_reduce_packed(net.flat_grad, sc, self._staging)
+                self._staging = torch.empty(net.total_dwp + 2 * PS_STRIDE, **self.tpdv)
+            self.comm.all_reduce_packed(net.dwp, sc, self._staging)
         # loss = mean over the (global) minibatch, times value_loss_coef before backward (v_critic.py:112,146)
-        self._scale.fill_(float(self.value_loss_coef) / float(m_global))
+        scale = float(self.value_loss_coef) / float(m_global)
+        self.critic_optimizer.step(1, scale, self.use_max_grad_norm, self.max_grad_norm, self._info)
         if self._grad_tap is not None:
-            self._grad_tap(net.flat_grad * self._scale, sc.clone())
-        self.critic_optimizer.step(self._scale, self.use_max_grad_norm, self.max_grad_norm, self._info[1:2])
-        self._info[0] += (sc[0] / sc[1]).to(torch.float32)
-        net.fold()
+            self._grad_tap(net.flat_grad * scale, sc.clone())
 
     def update(self, sample, value_normalizer=None):
         """API-compatible single update on a gathered minibatch (v_critic.py:116-157)."""

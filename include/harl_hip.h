@@ -102,6 +102,12 @@ int harl_unfold_linear_grads(const float *dWp, const float *dbp, int ldp, const 
 int harl_mlp_fwd_input(const float *X, long ldx, const int64_t *idx, long M, int D, const float *Wp,
                        const float *bp, int use_ln0, int H, float *xout, uint32_t *relu_mask, float *rstd,
                        float *mu0, float *rstd0, void *stream);
+/* fused layers 1+2 for narrow inputs (D <= 32) and equal widths H: x_hat_1 stays in registers between the two GEMMs;
+ * store1 != 0 also writes x_hat_1 / mask1 / rstd1 / mu0 / rstd0 (needed only when a backward pass follows). */
+int harl_mlp_fwd_fused2(const float *X, long ldx, const int64_t *idx, long M, int D, const float *W1p,
+                        const float *b1p, int use_ln0, const float *W2p, const float *b2p, int H, int store1,
+                        float *x1out, uint32_t *mask1, float *rstd1, float *mu0, float *rstd0, float *x2out,
+                        uint32_t *mask2, float *rstd2, void *stream);
 /* hidden layer: xout = norm(relu(Wp * xin + bp)), xin ATL(HI) -> xout ATL(HO) */
 int harl_mlp_fwd_hidden(const float *xin, long M, int HI, int HO, const float *Wp, const float *bp,
                         float *xout, uint32_t *relu_mask, float *rstd, void *stream);
@@ -118,6 +124,28 @@ int harl_mlp_dw_partials(const float *a, int a_kind, int lda, int HO, const floa
                          int n_wg, void *stream);
 /* out[e] = sum_w part[w][e] in fixed order (deterministic), e < elems */
 int harl_reduce_partials(const float *part, int n_wg, long elems, float *out, void *stream);
+
+/* Layer table used by the two fused kernels below: int32[HARL_TABLE_STRIDE * n_layers] in device memory, per Linear
+ * (hidden layers in order, head last):
+ *   0 w_off 1 b_off 2 gamma_off(-1) 3 beta_off(-1)  -- offsets into the flat parameter/gradient arena (floats)
+ *   4 out   5 in    6 pack_w_off    7 pack_b_off     -- offsets into the folded-weight arena
+ *   8 dwp_off (dense folded gradient dWp[op][kp] then dbp[op])  9 kp  10 op  11 part_off (per-workgroup partials arena,
+ *   row stride op*kp+op floats per workgroup) */
+#define HARL_TABLE_STRIDE 12
+/* dwp[dwp_off_l + e] = sum_w part[part_off_l + w*elems_l + e] for all layers in ONE launch (fixed order, deterministic) */
+int harl_reduce_partials_multi(const float *part, const int *table, int n_layers, int n_wg, long total_elems,
+                               float *dwp, void *stream);
+/* Fused optimiser epilogue in one workgroup: loss scalars -> gradient scale + statistics (info), unfold the folded
+ * gradients of every layer into `grad` (reference parameter layout), ||grad||, clip, Adam, re-fold the updated weights
+ * into `packs`.  mode 0 (actor): scale = 1/scalars[1] (sum active), info += {loss, entropy, grad_norm, ratio};
+ * mode 1 (critic): scale = const_scale (= value_loss_coef / m), info += {value_loss, grad_norm}.
+ * logstd_off >= 0: grad[logstd_off + d] = scalars[8 + d].  Replaces clip_grad_norm_ + Adam.step + the LayerNorm-affine
+ * adjoint (algorithms/actors/happo.py:89-100, algorithms/critics/v_critic.py:144-155). */
+int harl_adam_fold(float *param, float *grad, float *exp_avg, float *exp_avg_sq, long n, const float *dwp,
+                   const int *table, int n_layers, float *packs, const double *scalars, int mode, float const_scale,
+                   int logstd_off, int act_dim, float *info, int use_clip, float max_norm, float lr, float beta1,
+                   float beta2, float eps, float weight_decay, double bias_correction1, double bias_correction2,
+                   void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Heads and losses.

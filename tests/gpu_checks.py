@@ -350,6 +350,8 @@ def check_train_golden(name: str) -> Dict[str, float]:
     torch.manual_seed(case.seed)
     np.random.seed(case.seed)
     r = build_runner(case)
+    from harl_amd.buffers import _advance_matches_randperm
+    assert _advance_matches_randperm()  # run the one-time RNG self-check outside the recording window
     perms: List[np.ndarray] = []
     real = torch.randperm
 

@@ -98,11 +98,15 @@ _timing_on = False
 _timing_events: dict = {}
 
 
-def enable_kernel_timing(on: bool) -> None:
-    """Bracket every tagged launch with HIP events on the launch stream (torch's current stream, which is the
-    stream handed to the kernels).  Used by bench.py for the per-kernel roofline figures."""
-    global _timing_on
+_timing_tags = None
+
+
+def enable_kernel_timing(on: bool, tags=None) -> None:
+    """Bracket tagged launches (all, or only those whose tag is in ``tags``) with HIP events on the launch stream
+    (torch's current stream, which is the stream handed to the kernels).  Used by bench.py for the roofline figures."""
+    global _timing_on, _timing_tags
     _timing_on = bool(on)
+    _timing_tags = set(tags) if tags else None
     if on:
         _timing_events.clear()
 
@@ -119,7 +123,7 @@ def collect_kernel_timing() -> dict:
 
 def call(name: str, *args, tag: Optional[str] = None) -> None:
     lib = load()
-    if _timing_on and tag is not None:
+    if _timing_on and tag is not None and (_timing_tags is None or tag in _timing_tags):
         a = torch.cuda.Event(enable_timing=True)
         b = torch.cuda.Event(enable_timing=True)
         a.record()

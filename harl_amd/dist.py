@@ -23,9 +23,19 @@ class Comm:
         self.world_size = dist.get_world_size(group) if self.enabled else 1
         self.rank = dist.get_rank(group) if self.enabled else 0
 
+    def _all_reduce(self, t: torch.Tensor) -> None:
+        # RCCL reduces device tensors in place; the gloo backend (CPU tests, and the 2-ranks-on-1-GPU parity test)
+        # is routed through host memory, which works for every build of gloo
+        if t.is_cuda and dist.get_backend(self.group) == "gloo":
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+
     def all_reduce_sum(self, t: torch.Tensor) -> torch.Tensor:
         if self.enabled:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            self._all_reduce(t)
         return t
 
     def all_reduce_packed(self, flat_grad: torch.Tensor, scalars64: torch.Tensor, staging: torch.Tensor) -> None:
@@ -39,7 +49,7 @@ class Comm:
         hi = scalars64.to(torch.float32)
         staging[n:n + k].copy_(hi)
         staging[n + k:n + 2 * k].copy_((scalars64 - hi.to(torch.float64)).to(torch.float32))
-        dist.all_reduce(staging, op=dist.ReduceOp.SUM, group=self.group)
+        self._all_reduce(staging)
         flat_grad.copy_(staging[:n])
         scalars64.copy_(staging[n:n + k].to(torch.float64) + staging[n + k:n + 2 * k].to(torch.float64))
 

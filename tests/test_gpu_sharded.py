@@ -1,0 +1,106 @@
+"""-m gpu: the data-parallel update path end to end.  Two ranks (gloo rendezvous, both on cuda:0 -- RCCL refuses two
+ranks on one device, the collective semantics are the same) each own half of the rollout threads of a golden case; the
+sharded train() must reproduce the reference's unsharded golden vectors: identical CPU-RNG stream, losses / grad-norms
+/ final parameters within the end-of-train tolerance, and bit-identical parameters on both ranks."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, name, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0")
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from harl_amd.dist import Comm, shard_columns
+        from harl_amd.runner import OnPolicyHARunner
+        from tests import gpu_checks as G
+        from tests.helpers import GoldenCase, rel_err, vec_rel_err
+
+        case = GoldenCase(name)
+        z, sh, d = case.z, case.shapes, case.data
+        train, model, algo = case.reference_dicts()
+        space = G.Discrete(sh.act_dim) if sh.discrete else G.Box((sh.act_dim,))
+        comm = Comm()
+        lo, hi = shard_columns(sh.N, rank, world)
+        torch.manual_seed(case.seed)
+        r = OnPolicyHARunner(dict(algo="happo"), dict(train=train, model=model, algo=algo), dict(state_type="EP"),
+                             obs_spaces=[G.Box((sh.obs_dim,))] * sh.A, share_obs_space=G.Box((sh.share_obs_dim,)),
+                             act_spaces=[space] * sh.A, device=G.DEV, comm=comm)
+        assert (r.col_lo, r.col_hi) == (lo, hi)
+        cut = lambda x: np.ascontiguousarray(x[:, lo:hi])  # noqa: E731
+        for a in range(sh.A):
+            r.actor[a].actor.load_state_dict({k: torch.from_numpy(v) for k, v in case.actor_sd[a].items()})
+            b = r.actor_buffer[a]
+            b.obs.copy_(G.dev(cut(d.obs[a])))
+            b.actions.copy_(G.dev(cut(d.actions[a])))
+            b.action_log_probs.copy_(G.dev(cut(d.action_log_probs[a])))
+            b.masks.copy_(G.dev(cut(d.masks[a])))
+            b.active_masks.copy_(G.dev(cut(d.active_masks[a])))
+            if sh.discrete:
+                b.available_actions.copy_(G.dev(cut(d.available_actions[a])))
+        r.critic.critic.load_state_dict({k: torch.from_numpy(v) for k, v in case.critic_sd.items()})
+        cb = r.critic_buffer
+        for nm, arr in (("share_obs", d.share_obs), ("rewards", d.rewards), ("value_preds", d.value_preds),
+                        ("masks", d.critic_masks), ("bad_masks", d.bad_masks)):
+            getattr(cb, nm).copy_(G.dev(cut(arr)))
+        if r.value_normalizer is not None:
+            vi = case.vn_init
+            r.value_normalizer.stats.copy_(G.dev(np.array([vi["running_mean"], vi["running_mean_sq"], vi["debiasing_term"]],
+                                                          dtype=np.float32)))
+        from harl_amd.buffers import _advance_matches_randperm
+        assert _advance_matches_randperm()
+        torch.manual_seed(case.seed + 12345)
+        cb.compute_returns(cb.value_preds[-1].clone(), r.value_normalizer)
+        ret_bad = float(np.sum(cb.returns.cpu().numpy()[:sh.T] != z["returns"][:sh.T, lo:hi]))
+        r.prep_training()
+        infos, cinfo = r.train()
+        torch.cuda.synchronize()
+        state_after = torch.get_rng_state()
+        torch.manual_seed(case.seed + 12345)
+        for g in case.perms():
+            torch.randperm(len(g))
+        res = dict(rank=rank, ret_bad=ret_bad, rng_bad=float(not torch.equal(state_after, torch.get_rng_state())))
+        got = np.array([[i["policy_loss"], i["dist_entropy"], i["actor_grad_norm"], i["ratio"]] for i in infos])
+        res["actor_rel"] = rel_err(got, z["actor_infos"])
+        res["critic_rel"] = rel_err([cinfo["value_loss"], cinfo["critic_grad_norm"]], z["critic_info"])
+        res["param_rel"] = max([vec_rel_err(r.actor[a].actor.flat_param.cpu().numpy(), z[f"actor_final_{a}"])
+                                for a in range(sh.A)] + [vec_rel_err(r.critic.critic.flat_param.cpu().numpy(), z["critic_final"])])
+        res["param_sum"] = float(sum(r.actor[a].actor.flat_param.double().sum().item() for a in range(sh.A)))
+        q.put(res)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name", ["mpe_box_h128", "cheetah_h128x3_mb2"])
+def test_two_rank_sharded_train_matches_unsharded_golden(name):
+    import torch.multiprocessing as mp
+
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, name, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in res:
+        assert r["ret_bad"] == 0.0 and r["rng_bad"] == 0.0, r
+        assert r["actor_rel"] < 1e-4 and r["critic_rel"] < 1e-4 and r["param_rel"] < 1e-4, r
+    assert res[0]["param_sum"] == res[1]["param_sum"], "replicated parameters diverged between ranks"

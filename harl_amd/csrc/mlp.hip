@@ -286,7 +286,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_fwd_input(const float *__rest
 // parked in LDS as xs[row][LDX] (LDX odd: the "lane = sample" reads below are conflict-free), and the input
 // LayerNorm statistics and the MFMA B operands are then taken from LDS.  Weights W'^T[k][o] resident in LDS.
 // =============================================================================================
-template <int HO>
+template <int HO, int RPI>
 __global__ __launch_bounds__(WG_THREADS, 2) void k_fwd_input_staged(const float *__restrict__ X, long ldx,
                                                                     const int64_t *__restrict__ idx, long M, int D,
                                                                     const float *__restrict__ Wp,
@@ -297,12 +297,10 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_fwd_input_staged(const float 
                                                                     float *__restrict__ mu0_out,
                                                                     float *__restrict__ rstd0_out, long n_slabs) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int nch = (D + 31) / 32;
-  const int krows = nch * 32;
-  const int LDX = D | 1;
-  float *Wt = lds;                     // [krows][HO]
-  float *bl = Wt + krows * HO;         // [HO]
-  float *xs = bl + HO;                 // [4 waves][32 rows][LDX]
+  constexpr int NCH = RPI == 2 ? 1 : 2, krows = NCH * 32, LDX = krows + 1, NPF = SLAB / RPI;
+  float *xs = lds;                              // [4 waves][32 rows][LDX]  (compile-time odd stride)
+  float *bl = xs + WAVES_PER_WG * SLAB * LDX;   // [HO]
+  float *Wt = bl + HO;                          // [krows][HO]
   for (int e = threadIdx.x; e < HO; e += WG_THREADS) bl[e] = bp[e];
   for (int e = threadIdx.x; e < HO * krows; e += WG_THREADS) {
     int o = e / krows, k = e - o * krows;
@@ -313,50 +311,73 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_fwd_input_staged(const float 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 31, h = lane >> 5;
   float *xw = xs + wave * SLAB * LDX;  // this wave's 32 rows (private: no cross-wave hazards)
-  // rows per load instruction: 2 when a row fits half a wave
-  const int rpi = D <= 32 ? 2 : 1;
-  const int lane_row = rpi == 2 ? h : 0, lane_k = rpi == 2 ? i : lane;
-  for (long slab = (long)blockIdx.x * WAVES_PER_WG + wave; slab < n_slabs; slab += (long)gridDim.x * WAVES_PER_WG) {
-    // ---- fetch the slab's rows (gathered) into LDS
-    for (int r0 = 0; r0 < SLAB; r0 += rpi) {
-      const int r = r0 + lane_row;
-      long j = slab * SLAB + r;
+  const int lane_row = RPI == 2 ? h : 0, lane_k = RPI == 2 ? i : lane;
+  const long slab0 = (long)blockIdx.x * WAVES_PER_WG + wave, slab_stride = (long)gridDim.x * WAVES_PER_WG;
+  float pf[NPF];  // next slab's rows, in flight while this slab computes
+  auto prefetch_rows = [&](long slab) {
+#pragma unroll
+    for (int u = 0; u < NPF; ++u) {
+      long j = slab * SLAB + u * RPI + lane_row;
       if (j > M - 1) j = M - 1;
       const long row = idx ? idx[j] : j;
-      if (lane_k < D) xw[r * LDX + lane_k] = X[row * ldx + lane_k];
+      pf[u] = lane_k < D ? X[row * ldx + lane_k] : 0.f;
     }
+  };
+  if (slab0 < n_slabs) prefetch_rows(slab0);
+  for (long slab = slab0; slab < n_slabs; slab += slab_stride) {
+#pragma unroll
+    for (int u = 0; u < NPF; ++u)
+      if (lane_k < D) xw[(u * RPI + lane_row) * LDX + lane_k] = pf[u];
     // wave-private LDS hand-off between lanes: LDS executes a wave's accesses in order, so all that is needed is a
-    // compiler barrier + lgkmcnt(0).  (A workgroup-scope release fence would also wait for vmcnt(0), i.e. for the
-    // previous slab's 16 KiB of activation stores -- ~2 us per slab.)
+    // compiler barrier + lgkmcnt(0) (a workgroup-scope release fence would also drain vmcnt, i.e. the stores)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
+    if (slab + slab_stride < n_slabs) prefetch_rows(slab + slab_stride);
     const float *xr = xw + i * LDX;  // my sample's row
 
+    float xv[NCH][16];
+    int ks[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int Dc = min(32, D - 32 * c);
+      ks[c] = Dc > 0 ? (Dc + 1) >> 1 : 0;
+#pragma unroll
+      for (int jj = 0; jj < 16; ++jj) {
+        const int kl = h * ks[c] + jj;
+        xv[c][jj] = (jj < ks[c] && kl < Dc) ? xr[32 * c + kl] : 0.f;
+      }
+    }
     float mean = 0.f, rstd = 1.f;
     if (use_ln0) {
-      float s = 0.f;
-      for (int c = 0; c < nch; ++c) {
-        const int Dc = min(32, D - 32 * c), KS = (Dc + 1) >> 1;
-        for (int jj = 0; jj < KS; ++jj) {
-          const int kl = h * KS + jj;
-          if (kl < Dc) s += xr[32 * c + kl];
-        }
-      }
-      s += wave_xor32(s);
-      mean = s / (float)D;
+      float sm = 0.f;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) sm += xv[c][jj];
+      sm += wave_xor32(sm);
+      mean = sm / (float)D;
       float vs = 0.f;
-      for (int c = 0; c < nch; ++c) {
-        const int Dc = min(32, D - 32 * c), KS = (Dc + 1) >> 1;
-        for (int jj = 0; jj < KS; ++jj) {
-          const int kl = h * KS + jj;
-          if (kl < Dc) {
-            float d = xr[32 * c + kl] - mean;
-            vs += d * d;
-          }
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int Dc = min(32, D - 32 * c);
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) {
+          const int kl = h * ks[c] + jj;
+          const float d = xv[c][jj] - mean;
+          vs += (jj < ks[c] && kl < Dc) ? d * d : 0.f;
         }
       }
       vs += wave_xor32(vs);
       rstd = 1.0f / sqrtf(vs / (float)D + 1e-5f);
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int Dc = min(32, D - 32 * c);
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) {
+          const int kl = h * ks[c] + jj;
+          xv[c][jj] = (jj < ks[c] && kl < Dc) ? (xv[c][jj] - mean) * rstd : 0.f;
+        }
+      }
     }
 
     f32x16 acc[HO / 32];
@@ -364,24 +385,24 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_fwd_input_staged(const float 
     for (int t = 0; t < HO / 32; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[t][r] = bl[32 * t + (r & 3) + 8 * (r >> 2) + 4 * h];
-    for (int c = 0; c < nch; ++c) {
-      const int Dc = min(32, D - 32 * c), KS = (Dc + 1) >> 1;
-      float xv[16];
 #pragma unroll
-      for (int jj = 0; jj < 16; ++jj) {
-        const int kl = h * KS + jj;
-        xv[jj] = (jj < KS && kl < Dc) ? (xr[32 * c + kl] - mean) * rstd : 0.f;
-      }
+    for (int c = 0; c < NCH; ++c) {
+      const int KS = ks[c];
       const float *wt_lane = Wt + (32 * c + h * KS) * HO + i;
+      float a_cur[HO / 32], a_nxt[HO / 32];
+#pragma unroll
+      for (int t = 0; t < HO / 32; ++t) a_cur[t] = wt_lane[32 * t];
 #pragma unroll
       for (int jj = 0; jj < 16; ++jj) {
+        const int jn = jj + 1 < KS ? jj + 1 : jj;
+#pragma unroll
+        for (int t = 0; t < HO / 32; ++t) a_nxt[t] = wt_lane[jn * HO + 32 * t];
         if (jj < KS) {
 #pragma unroll
-          for (int t = 0; t < HO / 32; ++t) {
-            const float a = wt_lane[jj * HO + 32 * t];
-            acc[t] = MFMA(a, xv[jj], acc[t]);
-          }
+          for (int t = 0; t < HO / 32; ++t) acc[t] = MFMA(a_cur[t], xv[c][jj], acc[t]);
         }
+#pragma unroll
+        for (int t = 0; t < HO / 32; ++t) a_cur[t] = a_nxt[t];
       }
     }
     relu_norm_store<HO>(acc, lane, slab, xout, mask_out, rstd_out);
@@ -833,6 +854,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_dw(const float *__restrict__ 
     }
     __syncthreads();
     if (it + gridDim.x < n_iter) prefetch(it + gridDim.x);  // next round's loads fly during the MFMA phase
+    __builtin_amdgcn_sched_barrier(0);  // pin the issue point: hipcc otherwise sinks the loads to their first use
     // ---- MFMA over the 64 staged samples (32 steps of 2)
 #pragma unroll 4
     for (int kk = 0; kk < DW_S / 2; ++kk) {
@@ -907,16 +929,20 @@ extern "C" int harl_mlp_fwd_input(const float *X, long ldx, const int64_t *idx, 
   hipStream_t s = (hipStream_t)stream;
   if (H != 128 && H != 64) return bad("harl_mlp_fwd_input: hidden width must be 64 or 128");
   if (D <= 64) {
-    const size_t shm = ((size_t)nch * 32 * H + H + (size_t)WG_THREADS / 2 * (D | 1)) * sizeof(float);
+    const int kr = D <= 32 ? 32 : 64;
+    const size_t shm = ((size_t)kr * H + H + (size_t)WAVES_PER_WG * SLAB * (kr + 1)) * sizeof(float);
+#define LS(Hv, R)                                                                                                 \
+  {                                                                                                               \
+    allow_big_lds(k_fwd_input_staged<Hv, R>, shm);                                                                \
+    hipLaunchKernelGGL((k_fwd_input_staged<Hv, R>), dim3(grid), dim3(WG_THREADS), shm, s, X, ldx, idx, M, D, Wp, bp, \
+                       use_ln0, xout, relu_mask, rstd, mu0, rstd0, n_slabs);                                       \
+  }
     if (H == 128) {
-      allow_big_lds(k_fwd_input_staged<128>, shm);
-      hipLaunchKernelGGL((k_fwd_input_staged<128>), dim3(grid), dim3(WG_THREADS), shm, s, X, ldx, idx, M, D, Wp, bp,
-                         use_ln0, xout, relu_mask, rstd, mu0, rstd0, n_slabs);
+      if (D <= 32) LS(128, 2) else LS(128, 1)
     } else {
-      allow_big_lds(k_fwd_input_staged<64>, shm);
-      hipLaunchKernelGGL((k_fwd_input_staged<64>), dim3(grid), dim3(WG_THREADS), shm, s, X, ldx, idx, M, D, Wp, bp,
-                         use_ln0, xout, relu_mask, rstd, mu0, rstd0, n_slabs);
+      if (D <= 32) LS(64, 2) else LS(64, 1)
     }
+#undef LS
     return check_launch("harl_mlp_fwd_input");
   }
   const int resident = (long)nch * 32 * H * 4 <= 64 * 1024;

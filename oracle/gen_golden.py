@@ -85,11 +85,19 @@ CASES = {
                          overrides=dict(use_max_grad_norm=False, use_policy_active_masks=False,
                                         use_clipped_value_loss=False, use_feature_normalization=False,
                                         ppo_epoch=2, critic_epoch=2)),
+    # ---- HATRPO (harl/algorithms/actors/hatrpo.py): CG + Fisher-vector products + backtracking line search
+    "trpo_box_h64": dict(algo="hatrpo", shapes=dict(T=10, N=8, A=2, obs_dim=11, share_obs_dim=9, act_dim=3, discrete=False,
+                                                    hidden_sizes=[64, 64]), seed=6, overrides={}),
+    "trpo_disc_h64": dict(algo="hatrpo", shapes=dict(T=10, N=8, A=2, obs_dim=11, share_obs_dim=9, act_dim=4, discrete=True,
+                                                     hidden_sizes=[64, 64]), seed=8, overrides={}, unavailable_p=0.2),
+    "trpo_wide_h128x3": dict(algo="hatrpo", shapes=dict(T=8, N=8, A=3, obs_dim=70, share_obs_dim=65, act_dim=1,
+                                                        discrete=False, hidden_sizes=[128, 128, 128]), seed=9,
+                             overrides=dict(fixed_order=True), inactive_p=0.15),
 }
 
 
-def load_cfg(sh: Shapes, overrides: dict) -> dict:
-    cfg = yaml.safe_load(open(os.path.join(REF, "harl/configs/algos_cfgs/happo.yaml")))
+def load_cfg(sh: Shapes, overrides: dict, algo: str = "happo") -> dict:
+    cfg = yaml.safe_load(open(os.path.join(REF, f"harl/configs/algos_cfgs/{algo}.yaml")))
     cfg["train"].update(n_rollout_threads=sh.N, episode_length=sh.T)
     cfg["model"]["hidden_sizes"] = list(sh.hidden_sizes)
     for k, v in overrides.items():
@@ -102,7 +110,8 @@ def load_cfg(sh: Shapes, overrides: dict) -> dict:
 def run_case(name: str, spec: dict) -> dict:
     sh = Shapes(**spec["shapes"])
     seed = spec["seed"]
-    cfg = load_cfg(sh, spec.get("overrides", {}))
+    algo_name = spec.get("algo", "happo")
+    cfg = load_cfg(sh, spec.get("overrides", {}), algo_name)
     use_fn = cfg["model"]["use_feature_normalization"]
     torch.set_num_threads(1)
     torch.manual_seed(seed)
@@ -110,7 +119,7 @@ def run_case(name: str, spec: dict) -> dict:
     dev = torch.device("cpu")
     act_space = Discrete(sh.act_dim) if sh.discrete else Box((sh.act_dim,))
     margs = {**cfg["model"], **cfg["algo"]}
-    actors = [ALGO_REGISTRY["happo"](margs, Box((sh.obs_dim,)), act_space, dev) for _ in range(sh.A)]
+    actors = [ALGO_REGISTRY[algo_name](margs, Box((sh.obs_dim,)), act_space, dev) for _ in range(sh.A)]
     critic = VCritic(margs, Box((sh.share_obs_dim,)), dev)
     for a, actor in enumerate(actors):
         sd = synthetic_state_dict(actor_param_shapes(sh, use_fn), 1000 * seed + a, cfg["model"]["std_x_coef"])
@@ -190,8 +199,13 @@ def run_case(name: str, spec: dict) -> dict:
         def upd(sample, _orig=orig, _a=a, _actor=actor):
             # capture the pre-clip flat gradient of the very first update only (fixture size)
             out = _orig(sample)
-            trace["actor"].append(dict(agent=_a, policy_loss=float(out[0]), dist_entropy=float(out[1]),
-                                       grad_norm=float(out[2]), ratio=float(out[3].mean())))
+            if algo_name == "hatrpo":  # (kl, loss_improve, expected_improve, dist_entropy, ratio)
+                trace["actor"].append(dict(agent=_a, policy_loss=float(out[0]), dist_entropy=float(out[1].item()),
+                                           grad_norm=float(np.asarray(out[2]).reshape(-1)[0]),
+                                           ratio=float(out[4].mean()), entropy=float(out[3])))
+            else:
+                trace["actor"].append(dict(agent=_a, policy_loss=float(out[0]), dist_entropy=float(out[1]),
+                                           grad_norm=float(out[2]), ratio=float(out[3].mean())))
             return out
 
         actor.update = upd
@@ -235,12 +249,15 @@ def run_case(name: str, spec: dict) -> dict:
         actor_trace=np.array([[t["agent"], t["policy_loss"], t["dist_entropy"], t["grad_norm"], t["ratio"]]
                               for t in trace["actor"]], dtype=np.float64),
         critic_trace=np.array([[t["value_loss"], t["grad_norm"]] for t in trace["critic"]], dtype=np.float64),
-        actor_infos=np.array([[float(i["policy_loss"]), float(i["dist_entropy"]), float(i["actor_grad_norm"]),
-                               float(i["ratio"])] for i in infos], dtype=np.float64),
+        actor_infos=(np.array([[float(i["kl"]), float(i["loss_improve"]), float(np.asarray(i["expected_improve"]).reshape(-1)[0]),
+                                float(i["dist_entropy"]), float(i["ratio"])] for i in infos], dtype=np.float64)
+                     if algo_name == "hatrpo" else
+                     np.array([[float(i["policy_loss"]), float(i["dist_entropy"]), float(i["actor_grad_norm"]),
+                                float(i["ratio"])] for i in infos], dtype=np.float64)),
         critic_info=np.array([float(cinfo["value_loss"]), float(cinfo["critic_grad_norm"])], dtype=np.float64),
         critic_final=flat(critic.critic).astype(np.float32),
         meta=np.frombuffer(json.dumps(dict(
-            name=name, spec=spec, torch=torch.__version__, numpy=np.__version__, threads=torch.get_num_threads(),
+            name=name, algo_name=algo_name, spec=spec, torch=torch.__version__, numpy=np.__version__, threads=torch.get_num_threads(),
             algo=cfg["algo"], model=cfg["model"], train={k: cfg["train"][k] for k in
                                                          ("use_valuenorm", "use_proper_time_limits", "episode_length",
                                                           "n_rollout_threads")},

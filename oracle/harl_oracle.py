@@ -513,3 +513,159 @@ def ha_train(
         factors.append(factor.copy())
     cinfo = critic.train(critic_buffer, vn, keep_grad)
     return infos, cinfo, {"agent_order": [int(x) for x in order], "factors": factors, "advantages": advantages}
+
+
+# --------------------------------------------------------------------------------------
+# HATRPO   (harl/algorithms/actors/hatrpo.py:37-247, harl/utils/trpo_util.py:5-158)
+# --------------------------------------------------------------------------------------
+@dataclass
+class TrpoConfig:
+    kl_threshold: float = 0.01
+    ls_step: int = 10
+    accept_ratio: float = 0.5
+    backtrack_coeff: float = 0.8
+
+
+def _dist_params(p, cfg: PathConfig, obs, avail):
+    """(kind, tensors) of the action distribution: Gaussian (mean, std) or Categorical normalised logits."""
+    feat = mlp_base_forward(p, obs)
+    if "act.action_out.log_std" in p:
+        mean = F.linear(feat, p["act.action_out.fc_mean.weight"], p["act.action_out.fc_mean.bias"])
+        std = (torch.sigmoid(p["act.action_out.log_std"] / cfg.std_x_coef) * cfg.std_y_coef).expand_as(mean)
+        return "normal", (mean, std)
+    logits = F.linear(feat, p["act.action_out.linear.weight"], p["act.action_out.linear.bias"])
+    if avail is not None:
+        logits = torch.where(avail == 0, torch.full_like(logits, -1e10), logits)
+    return "categorical", (logits - logits.logsumexp(dim=-1, keepdim=True),)
+
+
+def trpo_kl(p_new, p_old, cfg: PathConfig, obs, avail) -> torch.Tensor:
+    """kl_divergence (trpo_util.py:65-92): [B, 1]; Gaussian analytic KL(old || new) in float64 summed over dims,
+    Categorical `kl_approx` on the normalised logits (trpo_util.py:47-51)."""
+    kind, new = _dist_params(p_new, cfg, obs, avail)
+    with torch.no_grad():
+        _, old = _dist_params(p_old, cfg, obs, avail)
+    if kind == "categorical":
+        q, pp = new[0], old[0]
+        kl = torch.exp(q - pp) - 1 - q + pp
+    else:
+        (mq, sq), (mp, sp) = new, old
+        var_ratio = (sp.to(torch.float64) / sq.to(torch.float64)).pow(2)
+        t1 = ((mp.to(torch.float64) - mq.to(torch.float64)) / sq.to(torch.float64)).pow(2)
+        kl = 0.5 * (var_ratio + t1 - 1 - var_ratio.log())
+    return kl.sum(1, keepdim=True)
+
+
+def consume_policy_init_rng(shapes: Dict[str, Tuple[int, ...]], gain: float = 0.01) -> None:
+    """HATRPO.update builds a fresh ``StochasticPolicy`` as the "old actor" snapshot (hatrpo.py:127-130); its
+    construction draws from the GLOBAL CPU generator (nn.Linear's default init, then orthogonal_), so those draws
+    are part of the RNG stream of train() and must be replayed for the later permutations to match."""
+    relu_gain = torch.nn.init.calculate_gain("relu")
+    for name, shp in shapes.items():
+        if len(shp) == 2:  # every Linear, in parameters() order: hidden layers (relu gain), then the head (gain)
+            lin = torch.nn.Linear(shp[1], shp[0])
+            torch.nn.init.orthogonal_(lin.weight.data, gain=gain if ("action_out" in name) else relu_gain)
+
+
+class OracleHATRPO:
+    """update() = loss gradient -> CG(10) with Fisher-vector products (double backward) -> backtracking line search."""
+
+    def __init__(self, state_dict, cfg: PathConfig, tcfg: TrpoConfig):
+        self.cfg, self.tcfg = cfg, tcfg
+        self.p = {k: v.detach().clone().to(torch.float32).requires_grad_(True) for k, v in state_dict.items()}
+        self.trace: List[dict] = []
+
+    def params(self):
+        return list(self.p.values())
+
+    def flat(self) -> torch.Tensor:
+        return torch.cat([v.data.reshape(-1) for v in self.params()])
+
+    def set_flat(self, vec: torch.Tensor) -> None:
+        i = 0
+        for v in self.params():
+            n = v.numel()
+            v.data.copy_(vec[i:i + n].view(v.shape))
+            i += n
+
+    def evaluate_actions(self, obs, action, available_actions=None, active_masks=None):
+        return actor_evaluate_actions(self.p, self.cfg, _t(obs), _t(action),
+                                      None if available_actions is None else _t(available_actions),
+                                      None if active_masks is None else _t(active_masks))
+
+    def fvp(self, obs, avail, vec: torch.Tensor) -> torch.Tensor:  # trpo_util.py:132-158
+        old = {k: v.detach() for k, v in self.p.items()}
+        kl = trpo_kl(self.p, old, self.cfg, obs, avail).mean()
+        g = torch.autograd.grad(kl, self.params(), create_graph=True, allow_unused=True)
+        gflat = torch.cat([x.reshape(-1) for x in g if x is not None])
+        hv = torch.autograd.grad((gflat * vec).sum(), self.params(), allow_unused=True)
+        return torch.cat([x.contiguous().reshape(-1) for x in hv if x is not None]).data + 0.1 * vec
+
+    def surrogate(self, obs, actions, avail, active, old_logp, adv, factor):
+        logp, ent, _ = actor_evaluate_actions(self.p, self.cfg, obs, actions, avail, active)
+        ratio = getattr(torch, self.cfg.action_aggregation)(torch.exp(logp - old_logp), dim=-1, keepdim=True)
+        if self.cfg.use_policy_active_masks:
+            loss = (torch.sum(ratio * factor * adv, dim=-1, keepdim=True) * active).sum() / active.sum()
+        else:
+            loss = torch.sum(ratio * factor * adv, dim=-1, keepdim=True).mean()
+        return loss, ent, ratio
+
+    def update(self, sample):  # hatrpo.py:37-194
+        t = self.tcfg
+        obs, actions, active, old_logp, adv, avail, factor = (None if s is None else _t(s) for s in sample)
+        loss, ent, ratio = self.surrogate(obs, actions, avail, active, old_logp, adv, factor)
+        g = torch.autograd.grad(loss, self.params(), allow_unused=True)
+        g = torch.cat([x.reshape(-1) for x in g if x is not None]).data
+        # conjugate gradient, 10 steps, residual tolerance 1e-10 (trpo_util.py:96-129)
+        x = torch.zeros_like(g)
+        r, pvec = g.clone(), g.clone()
+        rdotr = torch.dot(r, r)
+        for _ in range(10):
+            avp = self.fvp(obs, avail, pvec)
+            alpha = rdotr / torch.dot(pvec, avp)
+            x += alpha * pvec
+            r -= alpha * avp
+            new_rdotr = torch.dot(r, r)
+            pvec = r + (new_rdotr / rdotr) * pvec
+            rdotr = new_rdotr
+            if rdotr < 1e-10:
+                break
+        loss0 = loss.data.numpy()
+        params = self.flat().clone()
+        fv = self.fvp(obs, avail, x)
+        shs = 0.5 * (x * fv).sum(0, keepdim=True)
+        step_size = 1 / torch.sqrt(shs / t.kl_threshold)[0]
+        full_step = step_size * x
+        old = {k: v.detach().clone() for k, v in self.p.items()}
+        consume_policy_init_rng({k: tuple(v.shape) for k, v in self.p.items()})
+        expected = (g * full_step).sum(0, keepdim=True).numpy()
+        flag, fraction = False, 1
+        info = dict(grad=g.numpy().copy(), step_dir=x.numpy().copy(), step_size=float(step_size), shs=float(shs))
+        for _ in range(t.ls_step):
+            self.set_flat(params + fraction * full_step)
+            new_loss, ent, ratio = self.surrogate(obs, actions, avail, active, old_logp, adv, factor)
+            improve = new_loss.data.numpy() - loss0
+            kl = trpo_kl(self.p, old, self.cfg, obs, avail).mean()
+            if kl < t.kl_threshold and (improve / expected) > t.accept_ratio and improve.item() > 0:
+                flag = True
+                break
+            expected = expected * t.backtrack_coeff
+            fraction *= t.backtrack_coeff
+        if not flag:
+            self.set_flat(params)
+        info.update(kl=float(kl), loss_improve=float(improve), expected_improve=float(expected[0]),
+                    dist_entropy=float(ent), ratio=float(ratio.mean()), accepted=flag, fraction=float(fraction),
+                    loss=float(loss0))
+        self.trace.append(info)
+        return info
+
+    def train(self, buf: "OracleActorBuffer", advantages: np.ndarray, keep_grad: bool = False) -> dict:  # hatrpo.py:196-247
+        out = {"kl": 0.0, "dist_entropy": 0.0, "loss_improve": 0.0, "expected_improve": 0.0, "ratio": 0.0}
+        if np.all(buf.active_masks[:-1] == 0.0):
+            return out
+        advantages = normalize_advantages(advantages, buf.active_masks[:-1])
+        for sample, _ in buf.feed_forward_generator(advantages, 1):
+            i = self.update(sample)
+            for k in out:
+                out[k] += i[k]
+        return out

@@ -15,6 +15,7 @@ from harl_amd.synthetic import (
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 ALL_CASES = ["mpe_box_h64", "mpe_box_h128", "mpe_disc_h64", "cheetah_h128x3_mb2", "box_mean_inactive_novn",
              "wide_obs_h64"]
+TRPO_CASES = ["trpo_box_h64", "trpo_disc_h64", "trpo_wide_h128x3"]
 
 
 class GoldenCase:
@@ -26,6 +27,7 @@ class GoldenCase:
         self.shapes = Shapes(**spec["shapes"])
         self.seed = spec["seed"]
         self.algo, self.model, self.train = self.meta["algo"], self.meta["model"], self.meta["train"]
+        self.algo_name = self.meta.get("algo_name", "happo")
         self.data: SyntheticBuffers = make_buffers(self.shapes, self.seed, spec.get("inactive_p", 0.0),
                                                    spec.get("unavailable_p", 0.0))
         for a in range(self.shapes.A):

@@ -10,14 +10,18 @@ import pytest
 import torch
 
 from oracle import harl_oracle as O
-from tests.helpers import ALL_CASES, GOLDEN_DIR, GoldenCase, rel_err, vec_rel_err
+from tests.helpers import ALL_CASES, GOLDEN_DIR, TRPO_CASES, GoldenCase, rel_err, vec_rel_err
 
 
 def build_oracle(case: GoldenCase):
     train, model, algo = case.reference_dicts()
     cfg = O.PathConfig.from_reference_dicts(train, model, algo)
     sh, d = case.shapes, case.data
-    actors = [O.OracleHAPPO({k: torch.from_numpy(v) for k, v in sd.items()}, cfg) for sd in case.actor_sd]
+    if case.algo_name == "hatrpo":
+        tc = O.TrpoConfig(**{k: algo[k] for k in ("kl_threshold", "ls_step", "accept_ratio", "backtrack_coeff")})
+        actors = [O.OracleHATRPO({k: torch.from_numpy(v) for k, v in sd.items()}, cfg, tc) for sd in case.actor_sd]
+    else:
+        actors = [O.OracleHAPPO({k: torch.from_numpy(v) for k, v in sd.items()}, cfg) for sd in case.actor_sd]
     critic = O.OracleVCritic({k: torch.from_numpy(v) for k, v in case.critic_sd.items()}, cfg)
     abufs = [O.OracleActorBuffer(d.obs[a].copy(), d.actions[a].copy(), d.action_log_probs[a].copy(), d.masks[a].copy(),
                                  d.active_masks[a].copy(),
@@ -32,7 +36,7 @@ def build_oracle(case: GoldenCase):
     return cfg, actors, critic, abufs, cbuf, vn
 
 
-@pytest.mark.parametrize("name", ALL_CASES)
+@pytest.mark.parametrize("name", ALL_CASES + TRPO_CASES)
 def test_oracle_matches_reference_golden(name):
     case = GoldenCase(name)
     z = case.z
@@ -67,17 +71,24 @@ def test_oracle_matches_reference_golden(name):
         assert p.dtype == np.int64 and np.array_equal(p, g)
 
     # floating side
-    tr = np.array([[t["policy_loss"], t["dist_entropy"], t["grad_norm"], t["ratio"]]
-                   for a in extra["agent_order"] for t in actors[a].trace])
+    if case.algo_name == "hatrpo":  # trace columns: kl, loss_improve, expected_improve, ratio
+        tr = np.array([[t["kl"], t["loss_improve"], t["expected_improve"], t["ratio"]]
+                       for a in extra["agent_order"] for t in actors[a].trace])
+        got_infos = np.array([[i["kl"], i["loss_improve"], i["expected_improve"], i["dist_entropy"], i["ratio"]]
+                              for i in infos])
+    else:
+        tr = np.array([[t["policy_loss"], t["dist_entropy"], t["grad_norm"], t["ratio"]]
+                       for a in extra["agent_order"] for t in actors[a].trace])
+        got_infos = np.array([[i["policy_loss"], i["dist_entropy"], i["actor_grad_norm"], i["ratio"]] for i in infos])
     assert rel_err(tr, z["actor_trace"][:, 1:]) < 1e-6
     ctr = np.array([[t["value_loss"], t["grad_norm"]] for t in critic.trace])
     assert rel_err(ctr, z["critic_trace"]) < 1e-6
-    got_infos = np.array([[i["policy_loss"], i["dist_entropy"], i["actor_grad_norm"], i["ratio"]] for i in infos])
     assert rel_err(got_infos, z["actor_infos"]) < 1e-6
     assert rel_err([cinfo["value_loss"], cinfo["critic_grad_norm"]], z["critic_info"]) < 1e-6
     assert vec_rel_err(np.stack([np.ones_like(extra["factors"][0])] + extra["factors"][:-1]), z["factors"]) < 1e-6
     for a in range(case.shapes.A):
-        assert vec_rel_err(actors[a].net.flat(), z[f"actor_final_{a}"]) < 1e-6
+        flat = actors[a].flat().numpy() if case.algo_name == "hatrpo" else actors[a].net.flat()
+        assert vec_rel_err(flat, z[f"actor_final_{a}"]) < 1e-6
     assert vec_rel_err(critic.net.flat(), z["critic_final"]) < 1e-6
     if vn is not None:
         s = vn.state()

@@ -6,7 +6,7 @@ class without an MI355X raises.
 """
 __version__ = "0.1.0"
 
-__all__ = ["OnPolicyHARunner", "HAPPO", "VCritic", "OnPolicyActorBuffer", "OnPolicyCriticBufferEP", "ValueNorm"]
+__all__ = ["OnPolicyHARunner", "HAPPO", "HATRPO", "VCritic", "OnPolicyActorBuffer", "OnPolicyCriticBufferEP", "ValueNorm"]
 
 
 def __getattr__(name):  # lazy: importing harl_amd.synthetic (pure NumPy) must not need torch/HIP
@@ -16,6 +16,9 @@ def __getattr__(name):  # lazy: importing harl_amd.synthetic (pure NumPy) must n
     if name == "HAPPO":
         from .happo import HAPPO
         return HAPPO
+    if name == "HATRPO":
+        from .hatrpo import HATRPO
+        return HATRPO
     if name == "VCritic":
         from .v_critic import VCritic
         return VCritic

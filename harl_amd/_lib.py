@@ -42,12 +42,17 @@ SIGNATURES = {
     "harl_reduce_partials_multi": [_vp, _vp, _i, _i, _l, _vp, _vp],
     "harl_adam_fold": [_vp, _vp, _vp, _vp, _l, _vp, _vp, _i, _vp, _vp, _i, _f, _i, _i, _vp, _i, _f, _f, _f, _f, _f, _f,
                        _d, _d, _vp],
-    "harl_actor_head_logp": [_vp, _l, _i, _vp, _vp, _vp, _f, _f, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp],
+    "harl_actor_head_logp": [_vp, _l, _i, _vp, _vp, _vp, _f, _f, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp],
     "harl_actor_head_loss": [_vp, _vp, _vp, _l, _i, _vp, _vp, _vp, _f, _f, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,
-                             _vp, _vp, _f, _f, _i, _vp, _vp, _vp, _vp],
+                             _vp, _vp, _f, _f, _i, _i, _vp, _vp, _vp, _vp],
     "harl_critic_head_values": [_vp, _l, _i, _vp, _vp, _vp, _vp],
     "harl_critic_head_loss": [_vp, _vp, _vp, _l, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _f, _vp, _vp, _vp,
                               _vp],
+    "harl_fold_linear_tangent": [_vp] * 9 + [_i, _i, _vp],
+    "harl_mlp_tangent_input": [_vp, _l, _vp, _l, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp],
+    "harl_mlp_tangent_hidden": [_vp, _vp, _l, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "harl_actor_head_fvp": [_vp, _vp, _vp, _vp, _l, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _i, _vp, _vp, _vp, _vp],
+    "harl_trpo_kl_sum": [_vp, _vp, _vp, _vp, _f, _f, _l, _i, _i, _vp, _vp],
     "harl_head_blocks": [_l],
     "harl_reduce_scalars": [_vp, _i, _vp, _vp],
     "harl_version": [],

@@ -40,6 +40,8 @@ struct ActorArgs {
   int agg_mean;
   float *dzL, *dhead, *part_scalars;
   float *logp_out, *factor_out;
+  float *head_out;  // [M, act_dim]: Gaussian mean / normalised Categorical logits (rollout sampling, HATRPO KL)
+  int trpo;         // 1: HATRPO surrogate  +ratio*f*adv*active  (no clip, no entropy term; hatrpo.py:82-90)
   long n_slabs;
 };
 
@@ -276,6 +278,11 @@ __global__ __launch_bounds__(WG_THREADS) void k_actor_head(ActorArgs A) {
     }
 
     if (!TRAIN) {
+      if (valid && h == 0 && A.head_out) {
+#pragma unroll
+        for (int d = 0; d < DAP; ++d)
+          if (d < D) A.head_out[j * D + d] = DISCRETE ? logp_d[d] : z[d];
+      }
       if (valid && h == 0) {
         if (A.logp_out) {
           if (DISCRETE) A.logp_out[j] = z[0];
@@ -302,11 +309,13 @@ __global__ __launch_bounds__(WG_THREADS) void k_actor_head(ActorArgs A) {
     const float inrange = (imp >= lo && imp <= hi) ? 1.f : 0.f;
     // torch.min(a, b) backward: ties split the gradient evenly between the two inputs
     float gsel = surr1 < surr2 ? 1.f : (surr1 > surr2 ? inrange : 0.5f + 0.5f * inrange);
-    const float dimp = valid ? -fct * act * advn * gsel : 0.f;  // d(sum_s -f*min*active)/d(imp)
-    const float ecoef = valid ? -A.entropy_coef * act : 0.f;    // weight of d(ent_s)
+    if (A.trpo) gsel = 1.f;
+    // HAPPO: d(sum_s -f*min*active)/d(imp) ; HATRPO: d(sum_s +imp*f*adv*active)/d(imp)
+    const float dimp = valid ? (A.trpo ? fct * act * advn : -fct * act * advn * gsel) : 0.f;
+    const float ecoef = (valid && !A.trpo) ? -A.entropy_coef * act : 0.f;  // weight of d(ent_s)
 
     if (count_me) {
-      sc[0] += -fct * mn * act;
+      sc[0] += A.trpo ? surr1 * fct * act : -fct * mn * act;
       sc[1] += act;
       sc[2] += ent * act;
       sc[3] += imp;
@@ -466,6 +475,202 @@ __global__ __launch_bounds__(WG_THREADS) void k_critic_head(CriticArgs A) {
   if (TRAIN) block_reduce_store<8>(sc, red, A.part_scalars + (long)blockIdx.x * PS_STRIDE);
 }
 
+// =============================================================================================
+// HATRPO Fisher-vector product, head part (harl/utils/trpo_util.py:132-158).  At theta_new == theta_old the
+// Hessian of KL(old || new) is the Gauss-Newton matrix J^T M J (the first-order terms vanish identically), so
+//   F v = J^T M (J v):   J v = forward-mode tangent of the head outputs (trunk tangent from harl_mlp_tangent_*),
+//   M = diag(1 / sigma^2) for the Gaussian mean  (the log_std block is diagonal and handled by the caller),
+//   M = identity on the normalised logits q = z - logsumexp(z) for `kl_approx` (trpo_util.py:47-51,83-86),
+//       over ALL action entries, masked ones included (q_masked = -1e10 - lse still depends on theta through lse),
+// followed by the ordinary backward pass.  This kernel: tangent of the head, M, backward through the head and the
+// last LayerNorm/ReLU -> dz_L (ATL) + dhead (for the head dW); the caller divides by the batch size (kl.mean()).
+// =============================================================================================
+struct FvpArgs {
+  const float *xL, *xLdot;
+  const uint32_t *relu_mask;
+  const float *rstd;
+  long M;
+  const float *Whp, *bhp, *Whdp, *bhdp, *log_std;
+  float std_x_coef, std_y_coef;
+  int act_dim;
+  const float *avail;
+  float *dzL, *dhead;
+  long n_slabs;
+};
+
+template <int H, int DAP, bool DISCRETE>
+__global__ __launch_bounds__(WG_THREADS) void k_actor_head_fvp(FvpArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float *whl = lds;                       // [2][H/2][DAP]  Wh'
+  float *cst = whl + 2 * (H / 2) * DAP;   // bias, sigma, logsigma, dsig, rowsum
+  float *wdl = cst + 5 * DAP;             // [2][H/2][DAP]  Wh'_dot
+  float *cdt = wdl + 2 * (H / 2) * DAP;   // bias_dot (+ unused slots)
+  stage_head<H, DAP>(whl, cst, A.Whp, A.bhp, A.act_dim);
+  stage_head<H, DAP>(wdl, cdt, A.Whdp, A.bhdp, A.act_dim);
+  if (!DISCRETE) {
+    for (int e = threadIdx.x; e < DAP; e += WG_THREADS) {
+      float sig = 1.f;
+      if (e < A.act_dim) sig = A.std_y_coef / (1.0f + expf(-A.log_std[e] / A.std_x_coef));
+      cst[DAP + e] = sig;
+    }
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  const float *whl_h = whl + h * (H / 2) * DAP;
+  const float *wdl_h = wdl + h * (H / 2) * DAP;
+  const int D = A.act_dim;
+  for (long slab = (long)blockIdx.x * WAVES_PER_WG + wave; slab < A.n_slabs; slab += (long)gridDim.x * WAVES_PER_WG) {
+    // z = Wh' x_hat + b ;  zd = Wh' x_hat_dot + Wh'_dot x_hat + b_dot   (one sweep over both ATL images)
+    float z[DAP], zd[DAP];
+#pragma unroll
+    for (int d = 0; d < DAP; ++d) z[d] = zd[d] = 0.f;
+    const f32x4 *xp = reinterpret_cast<const f32x4 *>(A.xL + slab * (long)(H * SLAB)) + lane;
+    const f32x4 *xdp = reinterpret_cast<const f32x4 *>(A.xLdot + slab * (long)(H * SLAB)) + lane;
+#pragma unroll 1
+    for (int q = 0; q < H / 8; ++q) {
+      const f32x4 xv = xp[q * WAVE], xd = xdp[q * WAVE];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+#pragma unroll
+        for (int dq = 0; dq < DAP / 4; ++dq) {
+          const f32x4 w = *reinterpret_cast<const f32x4 *>(whl_h + (4 * q + c) * DAP + 4 * dq);
+          const f32x4 wd = *reinterpret_cast<const f32x4 *>(wdl_h + (4 * q + c) * DAP + 4 * dq);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            z[4 * dq + k] += xv[c] * w[k];
+            zd[4 * dq + k] += xd[c] * w[k] + xv[c] * wd[k];
+          }
+        }
+      }
+    }
+    float zlin[DAP];
+#pragma unroll
+    for (int d = 0; d < DAP; ++d) {
+      zlin[d] = z[d] + wave_xor32(z[d]);
+      z[d] = zlin[d] + cst[d];
+      zd[d] = zd[d] + wave_xor32(zd[d]) + cdt[d];
+    }
+    const long j = slab * SLAB + i;
+    const bool valid = j < A.M;
+    float dzh[DAP];
+#pragma unroll
+    for (int d = 0; d < DAP; ++d) dzh[d] = 0.f;
+    if (!DISCRETE) {
+#pragma unroll
+      for (int d = 0; d < DAP; ++d)
+        if (d < D && valid) {
+          const float sig = cst[DAP + d];
+          dzh[d] = zd[d] / (sig * sig);
+        }
+    } else {
+      const long jc = valid ? j : A.M - 1;
+      float mx = -3.0e38f;
+      bool un[DAP];
+#pragma unroll
+      for (int d = 0; d < DAP; ++d) {
+        un[d] = d < D && !(A.avail && A.avail[jc * D + d] == 0.f);
+        if (d < D) {
+          if (!un[d]) z[d] = -1e10f;
+          mx = fmaxf(mx, z[d]);
+        }
+      }
+      float se = 0.f;
+#pragma unroll
+      for (int d = 0; d < DAP; ++d)
+        if (d < D) se += expf(z[d] - mx);
+      const float lse = mx + logf(se);
+      float pr[DAP], S = 0.f, sum_zd = 0.f;
+#pragma unroll
+      for (int d = 0; d < DAP; ++d) {
+        pr[d] = d < D ? expf(z[d] - lse) : 0.f;
+        if (un[d]) {
+          S += pr[d] * zd[d];
+          sum_zd += zd[d];
+        }
+      }
+      const float sum_dq = sum_zd - (float)D * S;  // sum over ALL D entries of q_dot_d = [unmasked] zd_d - S
+#pragma unroll
+      for (int d = 0; d < DAP; ++d)
+        if (un[d] && valid) dzh[d] = (zd[d] - S) - pr[d] * sum_dq;  // log-softmax backward of dq = q_dot
+    }
+    {
+      float *dh = A.dhead + j * DHEAD_LD + 16 * h;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        const int d = 16 * h + c;
+        float v = 0.f;
+#pragma unroll
+        for (int dd = 0; dd < DAP; ++dd)
+          if (dd == d) v = dzh[dd];
+        dh[c] = v;
+      }
+    }
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int d = 0; d < DAP; ++d) {
+      s1 += dzh[d] * cst[4 * DAP + d];
+      s2 += dzh[d] * zlin[d];
+    }
+    head_bwd_stream<H, DAP>(A.xL, A.relu_mask, A.rstd[slab * SLAB + i], slab, lane, whl_h, dzh, s1, s2, A.dzL);
+  }
+}
+
+// sum over samples of KL(old || new) per trpo_util.py:47-62,65-92 (Gaussian in fp64, Categorical kl_approx in fp32)
+__global__ __launch_bounds__(256) void k_trpo_kl(const float *__restrict__ ho, const float *__restrict__ hn,
+                                                 const float *__restrict__ ls_old, const float *__restrict__ ls_new,
+                                                 float xc, float yc, long M, int D, int discrete,
+                                                 double *__restrict__ out) {
+  double acc = 0;
+  for (long s = (long)blockIdx.x * blockDim.x + threadIdx.x; s < M; s += (long)gridDim.x * blockDim.x) {
+    if (discrete) {
+      float k = 0.f;
+      for (int d = 0; d < D; ++d) {
+        const float pp = ho[s * D + d], q = hn[s * D + d];
+        k += (expf(q - pp) - 1.f - q) + pp;
+      }
+      acc += (double)k;
+    } else {
+      double k = 0;
+      for (int d = 0; d < D; ++d) {
+        const float sp = yc / (1.0f + expf(-ls_old[d] / xc)), sq = yc / (1.0f + expf(-ls_new[d] / xc));
+        const double vr = ((double)sp / (double)sq) * ((double)sp / (double)sq);
+        const double t = ((double)ho[s * D + d] - (double)hn[s * D + d]) / (double)sq;
+        k += 0.5 * (vr + t * t - 1.0 - log(vr));
+      }
+      acc += k;
+    }
+  }
+  acc = wave_reduce_sum_d(acc);
+  __shared__ double sh[4];
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, sh[0] + sh[1] + sh[2] + sh[3]);
+}
+
+// tangent of the LayerNorm-affine fold:  Wp_dot = W_dot*g + W*g_dot ;  bp_dot = b_dot + W_dot.beta + W.beta_dot
+__global__ __launch_bounds__(64) void k_fold_tangent(const float *__restrict__ W, const float *__restrict__ g,
+                                                     const float *__restrict__ be, const float *__restrict__ Wd,
+                                                     const float *__restrict__ bd, const float *__restrict__ gd,
+                                                     const float *__restrict__ bed, float *__restrict__ Wpd,
+                                                     float *__restrict__ bpd, int in_dim) {
+  const int o = blockIdx.x;
+  float acc = 0.f;
+  for (int k = threadIdx.x; k < in_dim; k += 64) {
+    const float w = W[(long)o * in_dim + k], wd = Wd[(long)o * in_dim + k];
+    Wpd[(long)o * in_dim + k] = g ? wd * g[k] + w * gd[k] : wd;
+    if (be) acc += wd * be[k] + w * bed[k];
+  }
+  acc = wave_reduce_sum(acc);
+  if (threadIdx.x == 0) bpd[o] = bd[o] + acc;
+}
+
+template <int H, int DAP, bool DISC>
+void launch_fvp(const FvpArgs &A, int grid, hipStream_t s) {
+  const size_t shm = ((size_t)4 * (H / 2) * DAP + 10 * DAP) * sizeof(float);
+  hipLaunchKernelGGL((k_actor_head_fvp<H, DAP, DISC>), dim3(grid), dim3(WG_THREADS), shm, s, A);
+}
+
 int head_grid(long M) { return persistent_grid(n_slabs_of(M), 4); }
 
 template <int H, int DAP, bool DISC, bool TRAIN>
@@ -500,9 +705,10 @@ extern "C" int harl_head_blocks(long M) { return head_grid(M); }
 extern "C" int harl_actor_head_logp(const float *xL, long M, int H, const float *Whp, const float *bhp,
                                     const float *log_std, float std_x_coef, float std_y_coef, int discrete,
                                     int act_dim, const float *actions, const float *avail, float *logp_out,
-                                    const float *old_logp, float *factor, int agg_mean, void *stream) {
+                                    const float *old_logp, float *factor, int agg_mean, float *head_out, void *stream) {
   if (M <= 0) return 0;
   ActorArgs A{};
+  A.head_out = head_out;
   A.xL = xL; A.M = M; A.Whp = Whp; A.bhp = bhp; A.log_std = log_std;
   A.std_x_coef = std_x_coef; A.std_y_coef = std_y_coef; A.act_dim = act_dim;
   A.actions = actions; A.avail = avail; A.old_logp = old_logp; A.agg_mean = agg_mean;
@@ -519,10 +725,11 @@ extern "C" int harl_actor_head_loss(const float *xL, const uint32_t *relu_mask, 
                                     float std_y_coef, int discrete, int act_dim, const int64_t *idx,
                                     const float *actions, const float *avail, const float *old_logp, const float *adv,
                                     const double *adv_moments, const float *factor, const float *active,
-                                    float clip_param, float entropy_coef, int agg_mean, float *dzL, float *dhead,
-                                    float *part_scalars, void *stream) {
+                                    float clip_param, float entropy_coef, int agg_mean, int trpo, float *dzL,
+                                    float *dhead, float *part_scalars, void *stream) {
   if (M <= 0) return 0;
   ActorArgs A{};
+  A.trpo = trpo;
   A.xL = xL; A.relu_mask = relu_mask; A.rstd = rstd; A.M = M; A.Whp = Whp; A.bhp = bhp; A.log_std = log_std;
   A.std_x_coef = std_x_coef; A.std_y_coef = std_y_coef; A.act_dim = act_dim; A.idx = idx;
   A.actions = actions; A.avail = avail; A.old_logp = old_logp; A.adv = adv; A.adv_moments = adv_moments;
@@ -561,4 +768,48 @@ extern "C" int harl_critic_head_loss(const float *xL, const uint32_t *relu_mask,
   else if (H == 64) hipLaunchKernelGGL((k_critic_head<64, true>), dim3(grid), dim3(WG_THREADS), shm, (hipStream_t)stream, A);
   else { set_error("critic head: hidden width must be 64 or 128"); return -2; }
   return check_launch("harl_critic_head_loss");
+}
+
+extern "C" int harl_actor_head_fvp(const float *xL, const float *xLdot, const uint32_t *relu_mask, const float *rstd, long M,
+                                   int H, const float *Whp, const float *bhp, const float *Whdp, const float *bhdp,
+                                   const float *log_std, float std_x_coef, float std_y_coef, int discrete, int act_dim,
+                                   const float *avail, float *dzL, float *dhead, void *stream) {
+  if (M <= 0) return 0;
+  FvpArgs A{};
+  A.xL = xL; A.xLdot = xLdot; A.relu_mask = relu_mask; A.rstd = rstd; A.M = M; A.Whp = Whp; A.bhp = bhp; A.Whdp = Whdp;
+  A.bhdp = bhdp; A.log_std = log_std; A.std_x_coef = std_x_coef; A.std_y_coef = std_y_coef; A.act_dim = act_dim;
+  A.avail = avail; A.dzL = dzL; A.dhead = dhead; A.n_slabs = n_slabs_of(M);
+  const int grid = head_grid(M);
+  hipStream_t s = (hipStream_t)stream;
+  if (act_dim < 1 || act_dim > 32) { set_error("head fvp: act_dim must be in [1, 32]"); return -2; }
+  const int dap = act_dim <= 4 ? 4 : (act_dim <= 8 ? 8 : (act_dim <= 16 ? 16 : 32));
+#define CASE(Hv, DAPv)                                          \
+  if (H == Hv && dap == DAPv) {                                 \
+    if (discrete) launch_fvp<Hv, DAPv, true>(A, grid, s);       \
+    else launch_fvp<Hv, DAPv, false>(A, grid, s);               \
+    return check_launch("harl_actor_head_fvp");                 \
+  }
+  CASE(128, 4) CASE(128, 8) CASE(128, 16) CASE(128, 32) CASE(64, 4) CASE(64, 8) CASE(64, 16) CASE(64, 32)
+#undef CASE
+  set_error("head fvp: hidden width must be 64 or 128");
+  return -2;
+}
+
+extern "C" int harl_trpo_kl_sum(const float *head_old, const float *head_new, const float *log_std_old,
+                                const float *log_std_new, float std_x_coef, float std_y_coef, long M, int act_dim,
+                                int discrete, double *out_sum, void *stream) {
+  if (M <= 0) return 0;
+  long nb = (M + 255) / 256;
+  if (nb > 1024) nb = 1024;
+  hipLaunchKernelGGL(k_trpo_kl, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, head_old, head_new, log_std_old,
+                     log_std_new, std_x_coef, std_y_coef, M, act_dim, discrete, out_sum);
+  return check_launch("harl_trpo_kl_sum");
+}
+
+extern "C" int harl_fold_linear_tangent(const float *W, const float *gamma, const float *beta, const float *Wd,
+                                        const float *bd, const float *gammad, const float *betad, float *Wpd,
+                                        float *bpd, int out_dim, int in_dim, void *stream) {
+  hipLaunchKernelGGL(k_fold_tangent, dim3(out_dim), dim3(64), 0, (hipStream_t)stream, W, gamma, beta, Wd, bd, gammad,
+                     betad, Wpd, bpd, in_dim);
+  return check_launch("harl_fold_linear_tangent");
 }

@@ -77,6 +77,37 @@ __device__ __forceinline__ void relu_norm_store(f32x16 (&acc)[HO / 32], int lane
   act_store<HO>(v, bits, rstd, lane, slab, xout, mask_out, rstd_out);
 }
 
+// forward-mode (tangent) epilogue: given the tangent of the pre-activation in acc and the PRIMAL x_hat / relu mask /
+// rstd of this layer,  a_dot = mask ? z_dot : 0 ;  x_hat_dot = rstd (a_dot - mean_f(a_dot) - x_hat mean_f(a_dot x_hat))
+// (the LayerNorm Jacobian is symmetric, so this is the backward formula with the mask applied first).
+template <int HO>
+__device__ __forceinline__ void ln_jac_store(f32x16 (&acc)[HO / 32], const float *__restrict__ xprimal,
+                                             const uint32_t *__restrict__ mask_in, const float *__restrict__ rstd_in,
+                                             int lane, long slab, float *__restrict__ xdot_out) {
+  constexpr int NR = HO / 2, NW = (NR + 31) / 32;
+  float xh[NR];
+  atl_load<HO>(xprimal, slab, lane, xh);
+  uint32_t bits[NW];
+#pragma unroll
+  for (int w = 0; w < NW; ++w) bits[w] = mask_in[(slab * NW + w) * WAVE + lane];
+  const float rstd = rstd_in[slab * SLAB + (lane & 31)];
+  float ad[NR];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int R = 0; R < NR; ++R) {
+    ad[R] = ((bits[R >> 5] >> (R & 31)) & 1u) ? acc[R >> 4][R & 15] : 0.f;
+    s1 += ad[R];
+    s2 += ad[R] * xh[R];
+  }
+  s1 += wave_xor32(s1);
+  s2 += wave_xor32(s2);
+  s1 *= (1.0f / HO);
+  s2 *= (1.0f / HO);
+#pragma unroll
+  for (int R = 0; R < NR; ++R) ad[R] = rstd * (ad[R] - s1 - xh[R] * s2);
+  atl_store<HO>(xdot_out, slab, lane, ad);
+}
+
 // =============================================================================================
 // hidden layer forward:  xout = norm(relu(Wp * xin + bp))       (ATL(HI) -> ATL(HO))
 // LDS: Wl[HO][HI+1] (odd row stride: the A-operand read "lane i -> row 32t+i, fixed k" hits 32
@@ -172,7 +203,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_fwd_hidden(const float *__res
 // half h.  The transposed weights W'^T[k][o] stay resident in LDS when they fit (D <= 128 for
 // H = 128), otherwise they are re-staged chunk by chunk (wide observations, e.g. Humanoid 393).
 // =============================================================================================
-template <int HO>
+template <int HO, bool TANGENT>
 __global__ __launch_bounds__(WG_THREADS, 2) void k_fwd_input(const float *__restrict__ X, long ldx,
                                                              const int64_t *__restrict__ idx, long M, int D,
                                                              const float *__restrict__ Wp,
@@ -181,7 +212,9 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_fwd_input(const float *__rest
                                                              uint32_t *__restrict__ mask_out,
                                                              float *__restrict__ rstd_out, float *__restrict__ mu0_out,
                                                              float *__restrict__ rstd0_out, long n_slabs, int nch,
-                                                             int resident) {
+                                                             int resident, const float *__restrict__ xprimal,
+                                                             const uint32_t *__restrict__ mask_in,
+                                                             const float *__restrict__ rstd_in) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int krows = resident ? nch * 32 : 32;
   float *Wt = lds;               // [krows][HO]
@@ -271,10 +304,14 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_fwd_input(const float *__rest
       }
     }
     if (active) {
-      relu_norm_store<HO>(acc, lane, slab, xout, mask_out, rstd_out);
-      if (lane < 32) {
-        mu0_out[slab * SLAB + lane] = mean;
-        rstd0_out[slab * SLAB + lane] = rstd;
+      if (TANGENT) {  // acc = W1'_dot x_hat0 + b1'_dot  ->  x_hat1_dot
+        ln_jac_store<HO>(acc, xprimal, mask_in, rstd_in, lane, slab, xout);
+      } else {
+        relu_norm_store<HO>(acc, lane, slab, xout, mask_out, rstd_out);
+        if (lane < 32) {
+          mu0_out[slab * SLAB + lane] = mean;
+          rstd0_out[slab * SLAB + lane] = rstd;
+        }
       }
     }
   }
@@ -948,15 +985,118 @@ extern "C" int harl_mlp_fwd_input(const float *X, long ldx, const int64_t *idx, 
   const int resident = (long)nch * 32 * H * 4 <= 64 * 1024;
   const size_t shm = ((size_t)(resident ? nch * 32 : 32) * H + H) * sizeof(float);
   if (H == 128) {
-    allow_big_lds(k_fwd_input<128>, shm);
-    hipLaunchKernelGGL((k_fwd_input<128>), dim3(grid), dim3(WG_THREADS), shm, s, X, ldx, idx, M, D, Wp, bp, use_ln0,
-                       xout, relu_mask, rstd, mu0, rstd0, n_slabs, nch, resident);
+    allow_big_lds(k_fwd_input<128, false>, shm);
+    hipLaunchKernelGGL((k_fwd_input<128, false>), dim3(grid), dim3(WG_THREADS), shm, s, X, ldx, idx, M, D, Wp, bp,
+                       use_ln0, xout, relu_mask, rstd, mu0, rstd0, n_slabs, nch, resident, nullptr, nullptr, nullptr);
   } else {
-    allow_big_lds(k_fwd_input<64>, shm);
-    hipLaunchKernelGGL((k_fwd_input<64>), dim3(grid), dim3(WG_THREADS), shm, s, X, ldx, idx, M, D, Wp, bp, use_ln0,
-                       xout, relu_mask, rstd, mu0, rstd0, n_slabs, nch, resident);
+    allow_big_lds(k_fwd_input<64, false>, shm);
+    hipLaunchKernelGGL((k_fwd_input<64, false>), dim3(grid), dim3(WG_THREADS), shm, s, X, ldx, idx, M, D, Wp, bp,
+                       use_ln0, xout, relu_mask, rstd, mu0, rstd0, n_slabs, nch, resident, nullptr, nullptr, nullptr);
   }
   return check_launch("harl_mlp_fwd_input");
+}
+
+// ---- forward-mode (tangent) pass, first layer:  x_hat1_dot = LNjac(mask1 * (W1'_dot norm0(X) + b1'_dot))
+extern "C" int harl_mlp_tangent_input(const float *X, long ldx, const int64_t *idx, long M, int D, const float *Wdp,
+                                      const float *bdp, int use_ln0, int H, const float *x1, const uint32_t *mask1,
+                                      const float *rstd1, float *x1dot, void *stream) {
+  if (M <= 0) return 0;
+  const long n_slabs = n_slabs_of(M);
+  const int nch = (D + 31) / 32;
+  const int grid = persistent_grid(n_slabs, 2);
+  hipStream_t s = (hipStream_t)stream;
+  const int resident = (long)nch * 32 * H * 4 <= 64 * 1024;
+  const size_t shm = ((size_t)(resident ? nch * 32 : 32) * H + H) * sizeof(float);
+  if (H == 128) {
+    allow_big_lds(k_fwd_input<128, true>, shm);
+    hipLaunchKernelGGL((k_fwd_input<128, true>), dim3(grid), dim3(WG_THREADS), shm, s, X, ldx, idx, M, D, Wdp, bdp,
+                       use_ln0, x1dot, nullptr, nullptr, nullptr, nullptr, n_slabs, nch, resident, x1, mask1, rstd1);
+  } else if (H == 64) {
+    allow_big_lds(k_fwd_input<64, true>, shm);
+    hipLaunchKernelGGL((k_fwd_input<64, true>), dim3(grid), dim3(WG_THREADS), shm, s, X, ldx, idx, M, D, Wdp, bdp,
+                       use_ln0, x1dot, nullptr, nullptr, nullptr, nullptr, n_slabs, nch, resident, x1, mask1, rstd1);
+  } else {
+    return bad("harl_mlp_tangent_input: hidden width must be 64 or 128");
+  }
+  return check_launch("harl_mlp_tangent_input");
+}
+
+// ---- forward-mode pass, hidden layer:  z_dot = W' x_hat_in_dot + W'_dot x_hat_in + b'_dot ; x_hat_out_dot = LNjac(.)
+// Both weight matrices live in LDS (2 x [HO][HI+1]); one workgroup per CU.  Plain rolled streaming loop (this pass is
+// 1/3 of a Fisher-vector product and not on the HAPPO bench path; it is kept simple).
+template <int HI, int HO>
+__global__ __launch_bounds__(WG_THREADS, 1) void k_tangent_hidden(const float *__restrict__ xin_dot,
+                                                                  const float *__restrict__ xin,
+                                                                  const float *__restrict__ Wp,
+                                                                  const float *__restrict__ Wdp,
+                                                                  const float *__restrict__ bdp,
+                                                                  const float *__restrict__ xprimal,
+                                                                  const uint32_t *__restrict__ mask_in,
+                                                                  const float *__restrict__ rstd_in,
+                                                                  float *__restrict__ xout_dot, long n_slabs) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int LDW = HI + 1;
+  float *Wl = lds;
+  float *Wdl = lds + HO * LDW;
+  float *bl = Wdl + HO * LDW;
+  for (int e = threadIdx.x; e < HO * HI; e += WG_THREADS) {
+    int o = e / HI, k = e - o * HI;
+    Wl[o * LDW + k] = Wp[e];
+    Wdl[o * LDW + k] = Wdp[e];
+  }
+  for (int e = threadIdx.x; e < HO; e += WG_THREADS) bl[e] = bdp[e];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  const float *wl_lane = Wl + i * LDW + 4 * h;
+  const float *wdl_lane = Wdl + i * LDW + 4 * h;
+  for (long slab = (long)blockIdx.x * WAVES_PER_WG + wave; slab < n_slabs; slab += (long)gridDim.x * WAVES_PER_WG) {
+    f32x16 acc[HO / 32];
+#pragma unroll
+    for (int t = 0; t < HO / 32; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = bl[32 * t + (r & 3) + 8 * (r >> 2) + 4 * h];
+    const f32x4 *xdp = reinterpret_cast<const f32x4 *>(xin_dot + slab * (long)(HI * SLAB)) + lane;
+    const f32x4 *xp = reinterpret_cast<const f32x4 *>(xin + slab * (long)(HI * SLAB)) + lane;
+#pragma unroll 1
+    for (int q = 0; q < HI / 8; ++q) {
+      const f32x4 xd = xdp[q * WAVE];
+      const f32x4 xv = xp[q * WAVE];
+      const int off = 32 * (q >> 2) + 8 * (q & 3);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+#pragma unroll
+        for (int t = 0; t < HO / 32; ++t) {
+          acc[t] = MFMA(wl_lane[off + 32 * t * LDW + c], xd[c], acc[t]);
+          acc[t] = MFMA(wdl_lane[off + 32 * t * LDW + c], xv[c], acc[t]);
+        }
+      }
+    }
+    ln_jac_store<HO>(acc, xprimal, mask_in, rstd_in, lane, slab, xout_dot);
+  }
+}
+
+extern "C" int harl_mlp_tangent_hidden(const float *xin_dot, const float *xin, long M, int HI, int HO, const float *Wp,
+                                       const float *Wdp, const float *bdp, const float *xprimal,
+                                       const uint32_t *mask_in, const float *rstd_in, float *xout_dot, void *stream) {
+  if (M <= 0) return 0;
+  const long n_slabs = n_slabs_of(M);
+  const size_t shm = ((size_t)2 * HO * (HI + 1) + HO) * sizeof(float);
+  const int grid = persistent_grid(n_slabs, 1);
+  hipStream_t s = (hipStream_t)stream;
+#define L(a, b)                                                                                                \
+  {                                                                                                            \
+    allow_big_lds(k_tangent_hidden<a, b>, shm);                                                                \
+    hipLaunchKernelGGL((k_tangent_hidden<a, b>), dim3(grid), dim3(WG_THREADS), shm, s, xin_dot, xin, Wp, Wdp, bdp, \
+                       xprimal, mask_in, rstd_in, xout_dot, n_slabs);                                           \
+  }
+  if (HI == 128 && HO == 128) L(128, 128)
+  else if (HI == 64 && HO == 64) L(64, 64)
+  else if (HI == 128 && HO == 64) L(128, 64)
+  else if (HI == 64 && HO == 128) L(64, 128)
+  else return bad("harl_mlp_tangent_hidden: widths must be 64 or 128");
+#undef L
+  return check_launch("harl_mlp_tangent_hidden");
 }
 
 extern "C" int harl_mlp_fwd_fused2(const float *X, long ldx, const int64_t *idx, long M, int D, const float *W1p,

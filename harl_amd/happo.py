@@ -51,13 +51,14 @@ class OnPolicyBase:
             g["lr"] = lr
 
     # ---- log-prob passes over a whole [T*N] batch (on_policy_ha_runner.py:66-83,96-113) --------------
-    def _logp_pass(self, obs, actions, avail, M, logp_out, old_logp=None, factor=None):
+    def _logp_pass(self, obs, actions, avail, M, logp_out, old_logp=None, factor=None, head_out=None):
         net = self.actor
         net.forward_trunk(obs, None, M, for_backward=False)
         Wp, bp = net._packs[-1]
         call("harl_actor_head_logp", ptr(net.xh[-1]), M, net.hidden_sizes[-1], ptr(Wp), ptr(bp), ptr(net.log_std()),
              net.std_x_coef, net.std_y_coef, int(net.discrete), net.act_dim, ptr(actions), ptr(avail), ptr(logp_out),
-             ptr(old_logp), ptr(factor), int(self.action_aggregation == "mean"), stream(), tag="actor_head_logp")
+             ptr(old_logp), ptr(factor), int(self.action_aggregation == "mean"), ptr(head_out), stream(),
+             tag="actor_head_logp")
 
     def evaluate_actions(self, obs, rnn_states_actor, action, masks, available_actions=None, active_masks=None):
         """Returns (action_log_probs [B, act_w] device tensor, None, None).  Entropy and the distribution object are
@@ -107,7 +108,7 @@ class HAPPO(OnPolicyBase):
         call("harl_actor_head_loss", ptr(net.xh[-1]), ptr(net.rmask[-1]), ptr(net.rstd[-1]), m, net.hidden_sizes[-1],
              ptr(Wp), ptr(bp), ptr(net.log_std()), net.std_x_coef, net.std_y_coef, int(net.discrete), net.act_dim,
              ptr(idx), ptr(actions), ptr(avail), ptr(old_logp), ptr(adv), ptr(adv_moments), ptr(factor), ptr(active),
-             float(self.clip_param), float(self.entropy_coef), int(self.action_aggregation == "mean"),
+             float(self.clip_param), float(self.entropy_coef), int(self.action_aggregation == "mean"), 0,
              ptr(net.dz[0]), ptr(net.dhead), ptr(net.part_scalars), s, tag="actor_head_loss")
         net.scalars.zero_()
         call("harl_reduce_scalars", ptr(net.part_scalars), _lib.load().harl_head_blocks(m), ptr(net.scalars), s)

@@ -1,0 +1,226 @@
+"""HATRPO on MI355X (reference: harl/algorithms/actors/hatrpo.py:18-247, harl/utils/trpo_util.py:5-158).
+
+update() = surrogate gradient -> 10 conjugate-gradient steps on Fisher-vector products -> step size from the KL
+threshold -> backtracking line search on (KL, surrogate improvement).  The Fisher-vector product is evaluated as
+J^T M (J v): a forward-mode tangent pass through the MLP, the KL Hessian w.r.t. the distribution parameters, and the
+same backward kernels HAPPO uses -- exact at theta_new == theta_old, where the reference's double backward computes
+the same matrix.  Vectors of parameter size (P ~ 20-70 k) are combined with torch device ops; the control decisions
+of CG / line search are host-side like the reference's.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import call, ptr, stream
+from .buffers import OnPolicyActorBuffer, consume_randperm
+from .happo import OnPolicyBase
+from .nets import consume_policy_init_rng
+from .valuenorm import _as_dev
+
+
+class HATRPO(OnPolicyBase):
+    def __init__(self, args, obs_space, act_space, device=torch.device("cuda:0")):
+        assert act_space.__class__.__name__ != "MultiDiscrete", \
+            "only continuous and discrete action space is supported by HATRPO."
+        super().__init__(args, obs_space, act_space, device)
+        self.kl_threshold = args["kl_threshold"]
+        self.ls_step = args["ls_step"]
+        self.accept_ratio = args["accept_ratio"]
+        self.backtrack_coeff = args["backtrack_coeff"]
+        self._tangent_ws = None
+        self._grad_tap = None
+
+    # ---- surrogate  sum_s ratio*f*adv*active / sum(active)  (hatrpo.py:77-90), optionally with its gradient ---------
+    def _surrogate(self, obs, m, actions, avail, old_logp, adv, adv_moments, factor, active, want_grad: bool):
+        net = self.actor
+        net.forward_trunk(obs, None, m, for_backward=True)
+        Wp, bp = net._packs[-1]
+        s = stream()
+        call("harl_actor_head_loss", ptr(net.xh[-1]), ptr(net.rmask[-1]), ptr(net.rstd[-1]), m, net.hidden_sizes[-1],
+             ptr(Wp), ptr(bp), ptr(net.log_std()), net.std_x_coef, net.std_y_coef, int(net.discrete), net.act_dim,
+             None, ptr(actions), ptr(avail), ptr(old_logp), ptr(adv), ptr(adv_moments), ptr(factor), ptr(active),
+             0.0, 0.0, int(self.action_aggregation == "mean"), 1, ptr(net.dz[0]), ptr(net.dhead), ptr(net.part_scalars), s)
+        net.scalars.zero_()
+        call("harl_reduce_scalars", ptr(net.part_scalars), _lib.load().harl_head_blocks(m), ptr(net.scalars), s)
+        grad = None
+        if want_grad:
+            net.backward_trunk(obs, None, m)
+            net.unfold_grads()
+            if not net.discrete:
+                net.gview("act.action_out.log_std").copy_(net.scalars[8:8 + net.act_dim])
+            grad = net.flat_grad.clone()
+        sc = net.scalars.clone()
+        if self.comm.enabled:
+            self.comm.all_reduce_sum(sc)
+            if grad is not None:
+                self.comm.all_reduce_sum(grad)
+        if grad is not None:
+            grad = grad * (1.0 / sc[1]).to(torch.float32)
+        return sc, grad
+
+    # ---- Fisher-vector product (trpo_util.py:132-158):  F v + 0.1 v -----------------------------------------------
+    def _fvp(self, obs, m, m_global, avail, vec: torch.Tensor) -> torch.Tensor:
+        net = self.actor
+        s = stream()
+        layers = net._layers()
+        L = len(net.hidden_sizes)
+        if self._tangent_ws is None or self._tangent_ws["rows"] < m:
+            mp = ((m + 31) // 32) * 32
+            self._tangent_ws = dict(
+                rows=m, xd=[torch.empty(mp * h, **self.tpdv) for h in net.hidden_sizes],
+                packs=[(torch.empty(o * k, **self.tpdv), torch.empty(o, **self.tpdv)) for (_, _, _, _, o, k) in layers])
+        ws = self._tangent_ws
+        vec = vec.contiguous()
+
+        def vview(name):
+            off, shape = net.offsets[name]
+            return vec[off:off + int(np.prod(shape))]
+
+        for (wn, bn, gn, ben, o, k), (Wpd, bpd) in zip(layers, ws["packs"]):  # tangent of the folded weights
+            call("harl_fold_linear_tangent", ptr(net.pview(wn)), ptr(net.pview(gn)) if gn else None,
+                 ptr(net.pview(ben)) if ben else None, ptr(vview(wn)), ptr(vview(bn)), ptr(vview(gn)) if gn else None,
+                 ptr(vview(ben)) if ben else None, ptr(Wpd), ptr(bpd), o, k, s)
+        hs = net.hidden_sizes
+        Wpd, bpd = ws["packs"][0]
+        call("harl_mlp_tangent_input", ptr(obs), obs.shape[1], None, m, net.in_dim, ptr(Wpd), ptr(bpd),
+             int(net.use_feature_normalization), hs[0], ptr(net.xh[0]), ptr(net.rmask[0]), ptr(net.rstd[0]),
+             ptr(ws["xd"][0]), s)
+        for l in range(1, L):
+            Wp, _ = net._packs[l]
+            Wpd, bpd = ws["packs"][l]
+            call("harl_mlp_tangent_hidden", ptr(ws["xd"][l - 1]), ptr(net.xh[l - 1]), m, hs[l - 1], hs[l], ptr(Wp), ptr(Wpd),
+                 ptr(bpd), ptr(net.xh[l]), ptr(net.rmask[l]), ptr(net.rstd[l]), ptr(ws["xd"][l]), s)
+        Whp, bhp = net._packs[-1]
+        Whpd, bhpd = ws["packs"][-1]
+        call("harl_actor_head_fvp", ptr(net.xh[-1]), ptr(ws["xd"][-1]), ptr(net.rmask[-1]), ptr(net.rstd[-1]), m, hs[-1],
+             ptr(Whp), ptr(bhp), ptr(Whpd), ptr(bhpd), ptr(net.log_std()), net.std_x_coef, net.std_y_coef,
+             int(net.discrete), net.act_dim, ptr(avail), ptr(net.dz[0]), ptr(net.dhead), s)
+        net.backward_trunk(obs, None, m)
+        net.unfold_grads()
+        out = net.flat_grad.clone()
+        if not net.discrete:  # log_std block: d2 KL / d sigma^2 = 2 / sigma^2 per sample, sigma = sigmoid(ls/xc) yc
+            off, shape = net.offsets["act.action_out.log_std"]
+            out[off:off + net.act_dim] = 0.0
+        if self.comm.enabled:
+            self.comm.all_reduce_sum(out)
+        out = out / float(m_global)  # kl.mean() over the (global) batch
+        if not net.discrete:
+            ls = net.log_std()
+            sg = torch.sigmoid(ls / net.std_x_coef)
+            sigma = sg * net.std_y_coef
+            dsig = net.std_y_coef * sg * (1.0 - sg) / net.std_x_coef
+            out[off:off + net.act_dim] = (2.0 * dsig * dsig / (sigma * sigma)) * vview("act.action_out.log_std")
+        return out + 0.1 * vec
+
+    def _head_outputs(self, obs, m, actions, avail) -> torch.Tensor:
+        """Distribution parameters at the current weights: Gaussian mean / normalised logits, [m, act_dim]."""
+        out = torch.empty(m, self.actor.act_dim, **self.tpdv)
+        self._logp_pass(obs, actions, avail, m, None, head_out=out)
+        return out
+
+    def _kl_mean(self, head_old, ls_old, head_new, m, m_global) -> float:
+        net = self.actor
+        acc = torch.zeros(1, dtype=torch.float64, device=self.device)
+        call("harl_trpo_kl_sum", ptr(head_old), ptr(head_new), ptr(ls_old), ptr(net.log_std()), net.std_x_coef,
+             net.std_y_coef, m, net.act_dim, int(net.discrete), ptr(acc), stream())
+        if self.comm.enabled:
+            self.comm.all_reduce_sum(acc)
+        return float(acc.item()) / float(m_global)
+
+    def _update_core(self, obs, m, m_global, actions, avail, old_logp, adv, adv_moments, factor, active):
+        net = self.actor
+        net.fold()
+        sc, g = self._surrogate(obs, m, actions, avail, old_logp, adv, adv_moments, factor, active, want_grad=True)
+        loss = float((sc[0] / sc[1]).item())
+        # conjugate gradient, 10 steps, residual tolerance 1e-10 (trpo_util.py:96-129)
+        x = torch.zeros_like(g)
+        r, p = g.clone(), g.clone()
+        rdotr = torch.dot(r, r)
+        for _ in range(10):
+            avp = self._fvp(obs, m, m_global, avail, p)
+            alpha = rdotr / torch.dot(p, avp)
+            x += alpha * p
+            r -= alpha * avp
+            new_rdotr = torch.dot(r, r)
+            p = r + (new_rdotr / rdotr) * p
+            rdotr = new_rdotr
+            if float(rdotr.item()) < 1e-10:
+                break
+        params = net.flat_param.clone()
+        fv = self._fvp(obs, m, m_global, avail, x)
+        shs = 0.5 * torch.dot(x, fv)
+        step_size = 1.0 / torch.sqrt(shs / self.kl_threshold)
+        full_step = step_size * x
+        # "old actor" snapshot (hatrpo.py:127-130): distribution parameters at theta_old + the RNG draws its construction costs
+        head_old = self._head_outputs(obs, m, actions, avail)
+        ls_old = None if net.discrete else net.log_std().clone()
+        consume_policy_init_rng(self.args, self.obs_space, self.act_space)
+        expected_improve = float(torch.dot(g, full_step).item())
+        if self._grad_tap is not None:
+            self._grad_tap(g.clone(), x.clone(), float(step_size.item()))
+        flag, fraction = False, 1.0
+        kl = loss_improve = 0.0
+        sc_new = sc
+        for _ in range(self.ls_step):
+            net.flat_param.copy_(params + fraction * full_step)
+            net.fold()
+            sc_new, _ = self._surrogate(obs, m, actions, avail, old_logp, adv, adv_moments, factor, active, want_grad=False)
+            new_loss = float((sc_new[0] / sc_new[1]).item())
+            loss_improve = new_loss - loss
+            head_new = self._head_outputs(obs, m, actions, avail)
+            kl = self._kl_mean(head_old, ls_old, head_new, m, m_global)
+            if kl < self.kl_threshold and (loss_improve / expected_improve) > self.accept_ratio and loss_improve > 0:
+                flag = True
+                break
+            expected_improve *= self.backtrack_coeff
+            fraction *= self.backtrack_coeff
+        if not flag:
+            net.flat_param.copy_(params)
+            net.fold()
+            print("policy update does not impove the surrogate")
+        dist_entropy = float((sc_new[2] / sc_new[1]).item())
+        ratio = float((sc_new[3] / sc_new[4]).item())
+        return kl, loss_improve, expected_improve, dist_entropy, ratio
+
+    def update(self, sample):
+        """API-compatible update on an already-gathered sample (tuple order of hatrpo.py:50-60)."""
+        (obs, _rnn, actions, _masks, active, old_logp, adv, avail, factor) = sample
+        dev = self.device
+        obs = _as_dev(obs, dev)
+        m = obs.shape[0]
+        return self._update_core(obs.reshape(m, -1), m, m, _as_dev(actions, dev).reshape(m, -1),
+                                 None if avail is None else _as_dev(avail, dev).reshape(m, -1),
+                                 _as_dev(old_logp, dev).reshape(m, -1), _as_dev(adv, dev).reshape(m), None,
+                                 _as_dev(factor, dev).reshape(m),
+                                 _as_dev(active, dev).reshape(m) if self.use_policy_active_masks else None)
+
+    def train(self, actor_buffer: OnPolicyActorBuffer, advantages, state_type):
+        """One full-batch update (hatrpo.py:196-247)."""
+        if state_type != "EP":
+            raise NotImplementedError("FP state type (per-agent advantages) is not implemented in this round")
+        if self.use_recurrent_policy or self.use_naive_recurrent_policy:
+            raise NotImplementedError("recurrent generators are not implemented in this round")
+        dev = self.device
+        buf = actor_buffer
+        T, N = buf.actions.shape[:2]
+        B = T * N
+        info = {"kl": 0.0, "dist_entropy": 0.0, "loss_improve": 0.0, "expected_improve": 0.0, "ratio": 0.0}
+        adv = _as_dev(advantages, dev).reshape(B)
+        active = buf.flat("active_masks").reshape(B)
+        moments = torch.zeros(3, dtype=torch.float64, device=dev)
+        call("harl_masked_moments", ptr(adv), ptr(active), B, ptr(moments), stream())
+        self.comm.all_reduce_sum(moments)
+        if float(moments[2].item()) == 0.0:
+            return info
+        n_global = self.shard[0] * T if self.shard else B
+        consume_randperm(n_global)  # feed_forward_generator_actor(advantages, 1): one draw, whole buffer
+        kl, li, ei, ent, ratio = self._update_core(
+            buf.flat("obs"), B, n_global, buf.flat("actions"),
+            None if buf.available_actions is None else buf.flat("available_actions"), buf.flat("action_log_probs"), adv,
+            moments, buf.factor.reshape(B), active if self.use_policy_active_masks else None)
+        info.update(kl=kl, dist_entropy=ent, loss_improve=li, expected_improve=ei, ratio=ratio)
+        return info

@@ -252,6 +252,17 @@ class _FlatNet(nn.Module):
         call("harl_reduce_partials_multi", ptr(self.part), ptr(self.table), L + 1, nwg, self.total_dwp, ptr(self.dwp), s,
              tag="reduce_partials")
 
+    def unfold_grads(self) -> None:
+        """self.dwp (dense folded gradients) -> self.flat_grad in the reference parameter layout (UNSCALED)."""
+        s = stream()
+        for (wn, bn, gn, ben, o, k), off in zip(self._layers(), self._dwp_offs):
+            kp, op = ((k + 31) // 32) * 32, ((o + 31) // 32) * 32
+            dW = self.dwp[off:off + op * kp]
+            db = self.dwp[off + op * kp:off + op * kp + op]
+            call("harl_unfold_linear_grads", ptr(dW), ptr(db), kp, ptr(self.pview(wn)),
+                 ptr(self.pview(gn)) if gn else None, ptr(self.pview(ben)) if ben else None, ptr(self.gview(wn)),
+                 ptr(self.gview(bn)), ptr(self.gview(gn)) if gn else None, ptr(self.gview(ben)) if ben else None, o, k, s)
+
     def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):  # keep views, then refold
         out = super().load_state_dict(state_dict, strict=strict, assign=False)
         self.fold()
@@ -319,6 +330,23 @@ class VNet(_FlatNet):
 
     def _head_names(self):
         return "v_out.weight", "v_out.bias", 1
+
+
+def consume_policy_init_rng(args: dict, obs_space, action_space) -> None:
+    """Draw from the global CPU generator exactly what constructing a ``StochasticPolicy`` draws (same torch calls, same
+    order) without allocating anything on the device.  HATRPO.update builds a fresh policy object as its "old actor"
+    snapshot on every call (algorithms/actors/hatrpo.py:127-130); those draws are part of the RNG stream of train()
+    and must happen for the later minibatch permutations / agent orders to match the reference."""
+    init = getattr(nn.init, args["initialization_method"])
+    gain = nn.init.calculate_gain("relu")
+    d = _space_shape(obs_space)[0]
+    for h in args["hidden_sizes"]:
+        lin = nn.Linear(d, h)
+        init(lin.weight.data, gain=gain)
+        d = h
+    n_out = int(action_space.n) if action_space.__class__.__name__ == "Discrete" else int(action_space.shape[0])
+    lin = nn.Linear(d, n_out)
+    init(lin.weight.data, gain=args["gain"])
 
 
 class FusedAdam:

@@ -16,10 +16,11 @@ from . import _lib
 from .buffers import OnPolicyActorBuffer, OnPolicyCriticBufferEP
 from .dist import Comm, shard_columns
 from .happo import HAPPO
+from .hatrpo import HATRPO
 from .v_critic import VCritic
 from .valuenorm import ValueNorm
 
-ALGO_REGISTRY = {"happo": HAPPO}
+ALGO_REGISTRY = {"happo": HAPPO, "hatrpo": HATRPO}
 
 
 class OnPolicyHARunner:

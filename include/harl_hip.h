@@ -157,11 +157,12 @@ int harl_adam_fold(float *param, float *grad, float *exp_avg, float *exp_avg_sq,
 /* log-probs only (the old/new passes of on_policy_ha_runner.py:66-83,96-113):
  *   logp_out[M, act_w] (act_w = act_dim for Box, 1 for Discrete), natural row order (no gather).
  *   If factor != NULL: factor[i] *= agg_d exp(logp - old_logp[i,d]) (fused on_policy_ha_runner.py:116-124)
- *   and logp_out may be NULL. */
+ *   and logp_out may be NULL.  head_out (nullable) [M, act_dim] receives the head outputs themselves: the Gaussian
+ *   mean, or the normalised Categorical logits (used for rollout sampling and for HATRPO's KL). */
 int harl_actor_head_logp(const float *xL, long M, int H, const float *Whp, const float *bhp,
                          const float *log_std, float std_x_coef, float std_y_coef, int discrete, int act_dim,
                          const float *actions, const float *avail, float *logp_out, const float *old_logp,
-                         float *factor, int agg_mean, void *stream);
+                         float *factor, int agg_mean, float *head_out, void *stream);
 /* HAPPO.update loss forward + backward (algorithms/actors/happo.py:28-102), everything up to dz_L:
  *   inputs gathered by idx: actions, old_logp[rows,act_w], adv[rows] (raw), adv_moments (double[3], NULL = adv
  *   already normalised), factor[rows], active[rows] (NULL = ones / use_policy_active_masks False)
@@ -169,13 +170,15 @@ int harl_actor_head_logp(const float *xL, long M, int H, const float *Whp, const
  *            dhead[M_pad, 32] (grad wrt head outputs; dw input), part_scalars[harl_head_blocks(M)][HARL_PS_STRIDE]:
  *            {0: sum loss*active, 1: sum active, 2: sum ent*active, 3: sum ratio, 4: count, 8..8+act_dim: dlogstd}
  *   mask/rstd: relu mask and rstd of the last hidden layer.
+ *   trpo != 0: HATRPO surrogate  sum_s +ratio*f*adv*active  instead (no clip, no entropy term;
+ *   algorithms/actors/hatrpo.py:77-95); scalar 0 is then that sum.
  */
 int harl_actor_head_loss(const float *xL, const uint32_t *relu_mask, const float *rstd, long M, int H,
                          const float *Whp, const float *bhp, const float *log_std, float std_x_coef,
                          float std_y_coef, int discrete, int act_dim, const int64_t *idx, const float *actions,
                          const float *avail, const float *old_logp, const float *adv, const double *adv_moments,
                          const float *factor, const float *active, float clip_param, float entropy_coef,
-                         int agg_mean, float *dzL, float *dhead, float *part_scalars, void *stream);
+                         int agg_mean, int trpo, float *dzL, float *dhead, float *part_scalars, void *stream);
 /* V head forward: values[M] = Whp . xL + bhp   (v_net.py:64) */
 int harl_critic_head_values(const float *xL, long M, int H, const float *Whp, const float *bhp, float *values,
                             void *stream);
@@ -187,6 +190,36 @@ int harl_critic_head_loss(const float *xL, const uint32_t *relu_mask, const floa
                           const float *returns, const float *vn_stats, float clip_param, int use_clipped,
                           int use_huber, float huber_delta, float *dzL, float *dhead, float *part_scalars,
                           void *stream);
+/* ---------------------------------------------------------------------------------------------
+ * HATRPO (algorithms/actors/hatrpo.py:37-194, utils/trpo_util.py:47-158).  The Fisher-vector product
+ * F v = grad((grad KL) . v) is evaluated as J^T M (J v) (exact at theta_new == theta_old, where KL's first-order terms
+ * vanish): a forward-mode tangent pass (harl_fold_linear_tangent, harl_mlp_tangent_input/_hidden), M and the head
+ * backward (harl_actor_head_fvp), then the ordinary backward kernels above.
+ */
+/* Wpd = Wd*gamma + W*gammad ; bpd = bd + Wd.beta + W.betad   (gamma/beta NULL: Wpd = Wd, bpd = bd) */
+int harl_fold_linear_tangent(const float *W, const float *gamma, const float *beta, const float *Wd, const float *bd,
+                             const float *gammad, const float *betad, float *Wpd, float *bpd, int out_dim, int in_dim,
+                             void *stream);
+/* x1dot = LNjac(mask1 * (Wdp norm0(X[idx]) + bdp)) given the primal x1 / mask1 / rstd1 (ATL(H)) */
+int harl_mlp_tangent_input(const float *X, long ldx, const int64_t *idx, long M, int D, const float *Wdp,
+                           const float *bdp, int use_ln0, int H, const float *x1, const uint32_t *mask1,
+                           const float *rstd1, float *x1dot, void *stream);
+/* xout_dot = LNjac(mask * (Wp xin_dot + Wdp xin + bdp)) given the primal xprimal / mask / rstd of this layer */
+int harl_mlp_tangent_hidden(const float *xin_dot, const float *xin, long M, int HI, int HO, const float *Wp,
+                            const float *Wdp, const float *bdp, const float *xprimal, const uint32_t *mask_in,
+                            const float *rstd_in, float *xout_dot, void *stream);
+/* head tangent, M (Gaussian 1/sigma^2 on the mean; identity on the normalised logits incl. masked entries), head +
+ * LayerNorm/ReLU backward -> dzL ATL(H), dhead[M_pad,32]; NOT yet divided by the batch size */
+int harl_actor_head_fvp(const float *xL, const float *xLdot, const uint32_t *relu_mask, const float *rstd, long M, int H,
+                        const float *Whp, const float *bhp, const float *Whdp, const float *bhdp, const float *log_std,
+                        float std_x_coef, float std_y_coef, int discrete, int act_dim, const float *avail, float *dzL,
+                        float *dhead, void *stream);
+/* out_sum (double, accumulated) += sum_s KL(old || new)_s from the head outputs of harl_actor_head_logp:
+ * Gaussian analytic KL in fp64 (trpo_util.py:54-62), Categorical kl_approx on normalised logits (trpo_util.py:47-51) */
+int harl_trpo_kl_sum(const float *head_old, const float *head_new, const float *log_std_old, const float *log_std_new,
+                     float std_x_coef, float std_y_coef, long M, int act_dim, int discrete, double *out_sum,
+                     void *stream);
+
 /* number of workgroups (= rows of part_scalars) the head-loss kernels use for M samples */
 int harl_head_blocks(long M);
 /* scalars[j] += sum_b part_scalars[b][j], j < HARL_PS_STRIDE (fixed order, fp64) */

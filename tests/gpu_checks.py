@@ -308,6 +308,77 @@ def check_gradients(spec, mini_batches: int = 1, agg: str = "prod", inactive_p: 
     return out
 
 
+def check_trpo(spec, agg: str = "prod") -> Dict[str, float]:
+    """HATRPO: surrogate gradient, one Fisher-vector product on a random vector, and one full update (CG + line
+    search) vs the oracle (autograd double backward), from identical parameters and data."""
+    from harl_amd.hatrpo import HATRPO
+    out = {}
+    M = spec["M"]
+    sh = Shapes(T=M, N=1, A=1, obs_dim=spec["obs_dim"], share_obs_dim=spec["share_obs_dim"], act_dim=spec["act_dim"],
+                discrete=spec["discrete"], hidden_sizes=spec["hidden_sizes"])
+    over = dict(spec.get("over", {}))
+    args = default_args(sh.hidden_sizes, kl_threshold=0.01, ls_step=10, accept_ratio=0.5, backtrack_coeff=0.8,
+                        action_aggregation=agg, **over)
+    space = Discrete(sh.act_dim) if sh.discrete else Box((sh.act_dim,))
+    actor = HATRPO(args, Box((sh.obs_dim,)), space, device=DEV)
+    sd = synthetic_state_dict(actor_param_shapes(sh, args["use_feature_normalization"]), 17, args["std_x_coef"])
+    actor.actor.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    cfg = O.PathConfig.from_reference_dicts({}, args, args)
+    oracle = O.OracleHATRPO({k: torch.from_numpy(v) for k, v in sd.items()}, cfg, O.TrpoConfig())
+    d = make_buffers(sh, 44, inactive_p=0.1, unavailable_p=0.25 if sh.discrete else 0.0)
+    rng = np.random.default_rng(8)
+    obs = d.obs[0][:-1].reshape(M, -1)
+    avail = None if not sh.discrete else d.available_actions[0][:-1].reshape(M, -1)
+    with torch.no_grad():
+        kind, dp = O._dist_params(oracle.p, cfg, torch.from_numpy(obs), None if avail is None else torch.from_numpy(avail))
+    if sh.discrete:
+        pr = torch.exp(dp[0]).numpy().astype(np.float64)
+        pr /= pr.sum(-1, keepdims=True)
+        act = np.array([rng.choice(sh.act_dim, p=q) for q in pr], dtype=np.float32)[:, None]
+    else:
+        act = (dp[0].numpy() + dp[1].numpy() * rng.standard_normal(dp[0].shape)).astype(np.float32)
+    lp, _, _ = oracle.evaluate_actions(obs, act, avail, None)
+    old_logp = (lp.detach().numpy() + 0.05 * rng.standard_normal(lp.shape)).astype(np.float32)
+    adv = rng.standard_normal((M, 1)).astype(np.float32)
+    factor = (1 + 0.1 * rng.standard_normal((M, 1))).astype(np.float32)
+    active = d.active_masks[0][:-1].reshape(M, 1)
+
+    # ---- Fisher-vector product on a random direction (primal activations come from a surrogate evaluation)
+    d_obs, d_act, d_old = dev(obs), dev(act), dev(old_logp)
+    d_avail = None if avail is None else dev(avail)
+    d_adv, d_fac, d_actv = dev(adv.reshape(M)), dev(factor.reshape(M)), dev(active.reshape(M))
+    actor.actor.fold()
+    sc, g = actor._surrogate(d_obs, M, d_act, d_avail, d_old, d_adv, None, d_fac, d_actv, want_grad=True)
+    t = lambda x: None if x is None else torch.from_numpy(x)  # noqa: E731
+    loss, ent, ratio = oracle.surrogate(t(obs), t(act), t(avail), t(active), t(old_logp), t(adv), t(factor))
+    og = torch.autograd.grad(loss, oracle.params(), allow_unused=True)
+    og = torch.cat([x.reshape(-1) for x in og]).numpy()
+    out["surrogate_loss_rel"] = rel_err((sc[0] / sc[1]).item(), loss.item())
+    out["surrogate_grad_vec_rel"] = vec_rel_err(g.cpu().numpy(), og)
+    v = rng.standard_normal(og.shape).astype(np.float32)
+    ofv = oracle.fvp(t(obs), t(avail), torch.from_numpy(v)).numpy()
+    gfv = actor._fvp(d_obs, M, M, d_avail, dev(v))
+    torch.cuda.synchronize()
+    out["fvp_vec_rel"] = vec_rel_err(gfv.cpu().numpy(), ofv)
+
+    # ---- one full update
+    info = oracle.update((obs, act, active, old_logp, adv, avail, factor))
+    taps = []
+    actor._grad_tap = lambda g_, x_, ss: taps.append((g_.cpu().numpy(), x_.cpu().numpy(), ss))
+    rnn = np.zeros((M, 1, 1), dtype=np.float32)
+    kl, li, ei, ent_, ratio_ = actor.update((obs, rnn, act, None, active, old_logp, adv, avail, factor))
+    torch.cuda.synchronize()
+    out["cg_step_dir_vec_rel"] = vec_rel_err(taps[0][1], info["step_dir"])
+    out["step_size_rel"] = rel_err(taps[0][2], info["step_size"])
+    out["kl_rel"] = rel_err(kl, info["kl"])
+    out["loss_improve_rel"] = rel_err(li, info["loss_improve"])
+    out["expected_improve_rel"] = rel_err(ei, info["expected_improve"])
+    out["entropy_rel"] = rel_err(ent_, info["dist_entropy"])
+    out["ratio_rel"] = rel_err(ratio_, info["ratio"])
+    out["param_after_vec_rel"] = vec_rel_err(actor.actor.flat_param.cpu().numpy(), oracle.flat().numpy())
+    return out
+
+
 # ------------------------------------------------------------------------------------------------
 def build_runner(case: GoldenCase):
     from harl_amd.runner import OnPolicyHARunner
@@ -315,7 +386,7 @@ def build_runner(case: GoldenCase):
     sh, d = case.shapes, case.data
     space = Discrete(sh.act_dim) if sh.discrete else Box((sh.act_dim,))
     algo_args = dict(train=train, model=model, algo=algo)
-    r = OnPolicyHARunner(dict(algo="happo"), algo_args, dict(state_type="EP"),
+    r = OnPolicyHARunner(dict(algo=case.algo_name), algo_args, dict(state_type="EP"),
                          obs_spaces=[Box((sh.obs_dim,))] * sh.A, share_obs_space=Box((sh.share_obs_dim,)),
                          act_spaces=[space] * sh.A, device=DEV)
     for a in range(sh.A):
@@ -384,8 +455,18 @@ def check_train_golden(name: str) -> Dict[str, float]:
     state_after = torch.get_rng_state()
     torch.manual_seed(case.seed + 12345)
     replay_bad = 0
-    for g in gp:
+    n_actor_draws = 0
+    for gi, g in enumerate(gp):
         replay_bad += int(not np.array_equal(torch.randperm(len(g)).numpy(), g))
+        if case.algo_name == "hatrpo":
+            # HATRPO.update constructs a fresh policy ("old actor") per agent, which draws from the same generator
+            # (hatrpo.py:127-130): one such construction after each of the A per-agent minibatch permutations
+            is_order = (gi == 0 and not case.algo["fixed_order"])
+            if not is_order and n_actor_draws < case.shapes.A:
+                n_actor_draws += 1
+                from harl_amd.nets import consume_policy_init_rng
+                sp = Discrete(case.shapes.act_dim) if case.shapes.discrete else Box((case.shapes.act_dim,))
+                consume_policy_init_rng({**case.model, **case.algo}, Box((case.shapes.obs_dim,)), sp)
     out["golden_replay_mismatch"] = float(replay_bad)
     out["rng_state_mismatch"] = float(not torch.equal(state_after, torch.get_rng_state()))
     pos, bad = 0, 0
@@ -397,12 +478,17 @@ def check_train_golden(name: str) -> Dict[str, float]:
         else:
             pos += 1
     out["perm_mismatch"] = float(bad)
-    got = np.array([[i["policy_loss"], i["dist_entropy"], i["actor_grad_norm"], i["ratio"]] for i in infos])
     gold = z["actor_infos"]
-    out["actor_policy_loss_rel"] = rel_err(got[:, 0], gold[:, 0])
-    out["actor_entropy_rel"] = rel_err(got[:, 1], gold[:, 1])
-    out["actor_gradnorm_rel"] = rel_err(got[:, 2], gold[:, 2])
-    out["actor_ratio_rel"] = rel_err(got[:, 3], gold[:, 3])
+    if case.algo_name == "hatrpo":
+        got = np.array([[i["kl"], i["loss_improve"], i["expected_improve"], i["dist_entropy"], i["ratio"]] for i in infos])
+        for c, nm in enumerate(("kl", "loss_improve", "expected_improve", "entropy", "ratio")):
+            out[f"actor_{nm}_rel"] = rel_err(got[:, c], gold[:, c])
+    else:
+        got = np.array([[i["policy_loss"], i["dist_entropy"], i["actor_grad_norm"], i["ratio"]] for i in infos])
+        out["actor_policy_loss_rel"] = rel_err(got[:, 0], gold[:, 0])
+        out["actor_entropy_rel"] = rel_err(got[:, 1], gold[:, 1])
+        out["actor_gradnorm_rel"] = rel_err(got[:, 2], gold[:, 2])
+        out["actor_ratio_rel"] = rel_err(got[:, 3], gold[:, 3])
     out["critic_value_loss_rel"] = rel_err(cinfo["value_loss"], z["critic_info"][0])
     out["critic_gradnorm_rel"] = rel_err(cinfo["critic_grad_norm"], z["critic_info"][1])
     for a in range(case.shapes.A):

@@ -27,6 +27,11 @@ def main():
     jobs.append(("grad[mpe_box,mean,inactive]", lambda: G.check_gradients(G.FWD_SHAPES[0], agg="mean", inactive_p=0.3)))
     for name in ALL_CASES:
         jobs.append((f"train[{name}]", lambda n=name: G.check_train_golden(n)))
+    for i in (0, 1, 2, 4):
+        jobs.append((f"trpo[{G.FWD_SHAPES[i]['name']}]", lambda s=G.FWD_SHAPES[i]: G.check_trpo(s)))
+    from tests.helpers import TRPO_CASES
+    for name in TRPO_CASES:
+        jobs.append((f"train[{name}]", lambda n=name: G.check_train_golden(n)))
     print("device:", torch.cuda.get_device_name(0), flush=True)
     results = {}
     for name, fn in jobs:

@@ -60,3 +60,19 @@ def test_single_update_gradients_mean_aggregation_inactive_agents():
                                   "box_mean_inactive_novn", "wide_obs_h64"])
 def test_train_matches_reference_golden(name):
     _assert_all(_G().check_train_golden(name), tol=TOL_TRAIN)
+
+
+@pytest.mark.parametrize("i", [0, 1, 2, 4])
+def test_hatrpo_gradient_fvp_and_update(i):
+    """HATRPO: surrogate gradient, Fisher-vector product (tangent pass + backward) and one full update (CG + line search)
+    vs the oracle's autograd double backward.  CG amplifies rounding differences: step direction held to 1e-4."""
+    G = _G()
+    res = G.check_trpo(G.FWD_SHAPES[i])
+    cg = res.pop("cg_step_dir_vec_rel")
+    assert cg < 1e-4, cg
+    _assert_all(res, tol=TOL)
+
+
+@pytest.mark.parametrize("name", ["trpo_box_h64", "trpo_disc_h64", "trpo_wide_h128x3"])
+def test_hatrpo_train_matches_reference_golden(name):
+    _assert_all(_G().check_train_golden(name), tol=TOL_TRAIN)

@@ -6,7 +6,7 @@ class without an MI355X raises.
 """
 __version__ = "0.1.0"
 
-__all__ = ["OnPolicyHARunner", "HAPPO", "HATRPO", "VCritic", "OnPolicyActorBuffer", "OnPolicyCriticBufferEP", "ValueNorm"]
+__all__ = ["OnPolicyHARunner", "HAPPO", "HATRPO", "VCritic", "OnPolicyActorBuffer", "OnPolicyCriticBufferEP", "OnPolicyCriticBufferFP", "ValueNorm"]
 
 
 def __getattr__(name):  # lazy: importing harl_amd.synthetic (pure NumPy) must not need torch/HIP
@@ -22,7 +22,7 @@ def __getattr__(name):  # lazy: importing harl_amd.synthetic (pure NumPy) must n
     if name == "VCritic":
         from .v_critic import VCritic
         return VCritic
-    if name in ("OnPolicyActorBuffer", "OnPolicyCriticBufferEP"):
+    if name in ("OnPolicyActorBuffer", "OnPolicyCriticBufferEP", "OnPolicyCriticBufferFP"):
         from . import buffers
         return getattr(buffers, name)
     if name == "ValueNorm":

@@ -242,3 +242,64 @@ class OnPolicyCriticBufferEP:
             i = ind.to(self.device)
             yield (self.flat("share_obs")[i], self.flat("rnn_states_critic").reshape(B, self.recurrent_n, -1)[i],
                    self.flat("value_preds")[i], self.flat("returns")[i], self.flat("masks")[i])
+
+
+class OnPolicyCriticBufferFP(OnPolicyCriticBufferEP):
+    """Critic buffer for the Feature-Pruned (per-agent) state type: every array carries an agent axis
+    ``[T(+1), N, A, .]`` (reference: harl/common/buffers/on_policy_critic_buffer_fp.py:10-260).  The GAE scan runs over
+    N*A columns; the flattened batch is T*N*A rows with row = (t*N + n)*A + a, as in the reference generators."""
+
+    def __init__(self, args: dict, share_obs_space, num_agents: int, device=torch.device("cuda:0")):
+        self.device = torch.device(device)
+        _lib.require_gpu(self.device)
+        self.episode_length = T = args["episode_length"]
+        self.n_rollout_threads = N = args["n_rollout_threads"]
+        self.num_agents = A = num_agents
+        self.hidden_sizes = args["hidden_sizes"]
+        self.rnn_hidden_size = self.hidden_sizes[-1]
+        self.recurrent_n = args["recurrent_n"]
+        self.gamma = args["gamma"]
+        self.gae_lambda = args["gae_lambda"]
+        self.use_gae = args["use_gae"]
+        self.use_proper_time_limits = args["use_proper_time_limits"]
+        so = _obs_shape(share_obs_space)
+        z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=self.device)  # noqa: E731
+        self.share_obs = z(T + 1, N, A, *so)
+        self.rnn_states_critic = z(T + 1, N, A, self.recurrent_n, self.rnn_hidden_size)
+        self.value_preds = z(T + 1, N, A, 1)
+        self.returns = z(T + 1, N, A, 1)
+        self.rewards = z(T, N, A, 1)
+        self.masks = torch.ones(T + 1, N, A, 1, dtype=torch.float32, device=self.device)
+        self.bad_masks = torch.ones_like(self.masks)
+        self.advantages = z(T, N, A, 1)
+        self.step = 0
+
+    def compute_returns(self, next_value, value_normalizer: Optional[ValueNorm] = None):
+        """Same scan over N*A columns; the ValueNorm + proper-time-limits GAE branch multiplies in the FP buffer's
+        order ``gamma*lambda*gae*mask`` (on_policy_critic_buffer_fp.py:130)."""
+        T, cols = self.episode_length, self.n_rollout_threads * self.num_agents
+        nv = _as_dev(next_value, self.device).reshape(cols)
+        vn = None if value_normalizer is None else value_normalizer.stats
+        fp_order = int(self.use_gae and self.use_proper_time_limits and value_normalizer is not None)
+        call("harl_gae_returns", ptr(self.rewards), ptr(self.value_preds), ptr(self.masks), ptr(self.bad_masks), ptr(nv),
+             ptr(vn), ptr(self.returns), ptr(self.advantages), T, cols, float(np.float32(self.gamma)),
+             float(np.float32(self.gamma * self.gae_lambda)), int(self.use_gae), int(self.use_proper_time_limits), fp_order,
+             stream(), tag="gae_returns")
+
+    def flat(self, name: str) -> torch.Tensor:
+        t = getattr(self, name)
+        if name in ("share_obs", "masks", "bad_masks", "value_preds", "returns", "rnn_states_critic"):
+            t = t[:-1]
+        return t.reshape(self.episode_length * self.n_rollout_threads * self.num_agents, -1)
+
+    def feed_forward_generator_critic(self, critic_num_mini_batch=None, mini_batch_size=None):
+        B = self.episode_length * self.n_rollout_threads * self.num_agents
+        if mini_batch_size is None:
+            sampler = minibatch_indices(B, critic_num_mini_batch)
+        else:
+            rand = torch.randperm(B)
+            sampler = [rand[i * mini_batch_size:(i + 1) * mini_batch_size] for i in range(critic_num_mini_batch)]
+        for ind in sampler:
+            i = ind.to(self.device)
+            yield (self.flat("share_obs")[i], self.flat("rnn_states_critic").reshape(B, self.recurrent_n, -1)[i],
+                   self.flat("value_preds")[i], self.flat("returns")[i], self.flat("masks")[i])

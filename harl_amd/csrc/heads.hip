@@ -41,7 +41,8 @@ struct ActorArgs {
   float *dzL, *dhead, *part_scalars;
   float *logp_out, *factor_out;
   float *head_out;  // [M, act_dim]: Gaussian mean / normalised Categorical logits (rollout sampling, HATRPO KL)
-  int trpo;         // 1: HATRPO surrogate  +ratio*f*adv*active  (no clip, no entropy term; hatrpo.py:82-90)
+  int trpo;         // surrogate: 0 HAPPO (clipped, happo.py:71-85); 1 HATRPO +ratio*f*adv*active, no entropy term
+                    // (hatrpo.py:82-90); 2 HAA2C -ratio*f*adv*active, no clip (haa2c.py:70-80)
   long n_slabs;
 };
 
@@ -309,13 +310,13 @@ __global__ __launch_bounds__(WG_THREADS) void k_actor_head(ActorArgs A) {
     const float inrange = (imp >= lo && imp <= hi) ? 1.f : 0.f;
     // torch.min(a, b) backward: ties split the gradient evenly between the two inputs
     float gsel = surr1 < surr2 ? 1.f : (surr1 > surr2 ? inrange : 0.5f + 0.5f * inrange);
-    if (A.trpo) gsel = 1.f;
-    // HAPPO: d(sum_s -f*min*active)/d(imp) ; HATRPO: d(sum_s +imp*f*adv*active)/d(imp)
-    const float dimp = valid ? (A.trpo ? fct * act * advn : -fct * act * advn * gsel) : 0.f;
-    const float ecoef = (valid && !A.trpo) ? -A.entropy_coef * act : 0.f;  // weight of d(ent_s)
+    if (A.trpo != 0) gsel = 1.f;
+    // HAPPO/HAA2C: d(sum_s -f*min|surr*active)/d(imp) ; HATRPO: d(sum_s +imp*f*adv*active)/d(imp)
+    const float dimp = valid ? (A.trpo == 1 ? fct * act * advn : -fct * act * advn * gsel) : 0.f;
+    const float ecoef = (valid && A.trpo != 1) ? -A.entropy_coef * act : 0.f;  // weight of d(ent_s)
 
     if (count_me) {
-      sc[0] += A.trpo ? surr1 * fct * act : -fct * mn * act;
+      sc[0] += A.trpo == 1 ? surr1 * fct * act : -fct * (A.trpo == 2 ? surr1 : mn) * act;
       sc[1] += act;
       sc[2] += ent * act;
       sc[3] += imp;

@@ -95,6 +95,7 @@ class HAPPO(OnPolicyBase):
         self.entropy_coef = args["entropy_coef"]
         self.use_max_grad_norm = args["use_max_grad_norm"]
         self.max_grad_norm = args["max_grad_norm"]
+        self._surrogate_mode = 0  # harl_actor_head_loss `trpo` argument: 0 = clipped (HAPPO)
         self._info = torch.zeros(4, **self.tpdv)  # sums of policy_loss, dist_entropy, grad_norm, ratio
         self._staging = None
         self._grad_tap = None
@@ -108,7 +109,7 @@ class HAPPO(OnPolicyBase):
         call("harl_actor_head_loss", ptr(net.xh[-1]), ptr(net.rmask[-1]), ptr(net.rstd[-1]), m, net.hidden_sizes[-1],
              ptr(Wp), ptr(bp), ptr(net.log_std()), net.std_x_coef, net.std_y_coef, int(net.discrete), net.act_dim,
              ptr(idx), ptr(actions), ptr(avail), ptr(old_logp), ptr(adv), ptr(adv_moments), ptr(factor), ptr(active),
-             float(self.clip_param), float(self.entropy_coef), int(self.action_aggregation == "mean"), 0,
+             float(self.clip_param), float(self.entropy_coef), int(self.action_aggregation == "mean"), self._surrogate_mode,
              ptr(net.dz[0]), ptr(net.dhead), ptr(net.part_scalars), s, tag="actor_head_loss")
         net.scalars.zero_()
         call("harl_reduce_scalars", ptr(net.part_scalars), _lib.load().harl_head_blocks(m), ptr(net.scalars), s)
@@ -145,20 +146,20 @@ class HAPPO(OnPolicyBase):
         """ppo_epoch x actor_num_mini_batch updates (happo.py:104-158).  ``advantages`` is the raw [T, N, 1]
         advantage tensor; the per-agent masked normalisation (happo.py:122-127) is folded into the loss kernel
         through the fp64 moments {sum, sumsq, count}."""
-        if state_type != "EP":
-            raise NotImplementedError("FP state type (per-agent advantages) is not implemented in this round")
         dev = self.device
         buf = actor_buffer
         T, N = buf.actions.shape[:2]
         B = T * N
         train_info = {"policy_loss": 0.0, "dist_entropy": 0.0, "actor_grad_norm": 0.0, "ratio": 0.0}
-        adv = _as_dev(advantages, dev).reshape(B)
+        adv = _as_dev(advantages, dev).reshape(B).contiguous()
         active = buf.flat("active_masks").reshape(B)
         moments = torch.zeros(3, dtype=torch.float64, device=dev)
         call("harl_masked_moments", ptr(adv), ptr(active), B, ptr(moments), stream())
         self.comm.all_reduce_sum(moments)
         if float(moments[2].item()) == 0.0:  # np.all(active_masks[:-1] == 0) early-out (happo.py:119-120)
             return train_info
+        if state_type != "EP":  # FP: the runner already normalised over all agents (on_policy_ha_runner.py:36-45)
+            moments = None
         self._info.zero_()
         self.actor.fold()
         obs = buf.flat("obs")
@@ -188,3 +189,16 @@ class HAPPO(OnPolicyBase):
         for k, v in zip(("policy_loss", "dist_entropy", "actor_grad_norm", "ratio"), vals):
             train_info[k] = v
         return train_info
+
+
+class HAA2C(HAPPO):
+    """HAPPO without ratio clipping, ``a2c_epoch`` epochs (reference: harl/algorithms/actors/haa2c.py:10-153)."""
+
+    def __init__(self, args, obs_space, act_space, device=torch.device("cuda:0")):
+        a = dict(args)
+        a.setdefault("clip_param", 0.0)   # unused by the unclipped surrogate
+        a.setdefault("ppo_epoch", a["a2c_epoch"])
+        super().__init__(a, obs_space, act_space, device)
+        self.args = args
+        self.a2c_epoch = self.ppo_epoch = args["a2c_epoch"]
+        self._surrogate_mode = 2

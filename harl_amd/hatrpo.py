@@ -200,8 +200,6 @@ class HATRPO(OnPolicyBase):
 
     def train(self, actor_buffer: OnPolicyActorBuffer, advantages, state_type):
         """One full-batch update (hatrpo.py:196-247)."""
-        if state_type != "EP":
-            raise NotImplementedError("FP state type (per-agent advantages) is not implemented in this round")
         if self.use_recurrent_policy or self.use_naive_recurrent_policy:
             raise NotImplementedError("recurrent generators are not implemented in this round")
         dev = self.device
@@ -209,13 +207,15 @@ class HATRPO(OnPolicyBase):
         T, N = buf.actions.shape[:2]
         B = T * N
         info = {"kl": 0.0, "dist_entropy": 0.0, "loss_improve": 0.0, "expected_improve": 0.0, "ratio": 0.0}
-        adv = _as_dev(advantages, dev).reshape(B)
+        adv = _as_dev(advantages, dev).reshape(B).contiguous()
         active = buf.flat("active_masks").reshape(B)
         moments = torch.zeros(3, dtype=torch.float64, device=dev)
         call("harl_masked_moments", ptr(adv), ptr(active), B, ptr(moments), stream())
         self.comm.all_reduce_sum(moments)
         if float(moments[2].item()) == 0.0:
             return info
+        if state_type != "EP":  # FP: advantages arrive normalised over all agents (on_policy_ha_runner.py:36-45)
+            moments = None
         n_global = self.shard[0] * T if self.shard else B
         consume_randperm(n_global)  # feed_forward_generator_actor(advantages, 1): one draw, whole buffer
         kl, li, ei, ent, ratio = self._update_core(

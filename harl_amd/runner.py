@@ -13,14 +13,15 @@ from typing import List, Optional
 import torch
 
 from . import _lib
-from .buffers import OnPolicyActorBuffer, OnPolicyCriticBufferEP
+from .buffers import OnPolicyActorBuffer, OnPolicyCriticBufferEP, OnPolicyCriticBufferFP
+from ._lib import call, ptr, stream
 from .dist import Comm, shard_columns
-from .happo import HAPPO
+from .happo import HAA2C, HAPPO
 from .hatrpo import HATRPO
 from .v_critic import VCritic
 from .valuenorm import ValueNorm
 
-ALGO_REGISTRY = {"happo": HAPPO, "hatrpo": HATRPO}
+ALGO_REGISTRY = {"happo": HAPPO, "hatrpo": HATRPO, "haa2c": HAA2C}
 
 
 class OnPolicyHARunner:
@@ -43,8 +44,8 @@ class OnPolicyHARunner:
             raise NotImplementedError(f"algo {algo}: this round implements {sorted(ALGO_REGISTRY)}")
         self.num_agents = len(obs_spaces)
         self.state_type = (env_args or {}).get("state_type", "EP")
-        if self.state_type != "EP":
-            raise NotImplementedError("FP state type is not implemented in this round")
+        if self.state_type not in ("EP", "FP"):
+            raise ValueError(f"state_type {self.state_type}")
         if algo_args["algo"].get("share_param", False):
             raise NotImplementedError("share_param")
         self.fixed_order = algo_args["algo"]["fixed_order"]
@@ -63,8 +64,11 @@ class OnPolicyHARunner:
         self.actor_buffer = [OnPolicyActorBuffer({**train_local, **algo_args["model"]}, obs_spaces[a], act_spaces[a],
                                                  device=self.device) for a in range(self.num_agents)]
         self.critic = VCritic(margs, share_obs_space, device=self.device)
-        self.critic_buffer = OnPolicyCriticBufferEP({**train_local, **algo_args["model"], **algo_args["algo"]},
-                                                    share_obs_space, device=self.device)
+        cb_args = {**train_local, **algo_args["model"], **algo_args["algo"]}
+        if self.state_type == "EP":
+            self.critic_buffer = OnPolicyCriticBufferEP(cb_args, share_obs_space, device=self.device)
+        else:
+            self.critic_buffer = OnPolicyCriticBufferFP(cb_args, share_obs_space, self.num_agents, device=self.device)
         self.value_normalizer = ValueNorm(1, device=self.device) if algo_args["train"]["use_valuenorm"] else None
         shard = (n_global, lo, hi) if self.comm.enabled else None
         for x in self.actor + [self.critic]:
@@ -75,7 +79,11 @@ class OnPolicyHARunner:
     @torch.no_grad()
     def compute(self):
         cb = self.critic_buffer
-        next_value, _ = self.critic.get_values(cb.share_obs[-1], cb.rnn_states_critic[-1], cb.masks[-1])
+        if self.state_type == "EP":
+            next_value, _ = self.critic.get_values(cb.share_obs[-1], cb.rnn_states_critic[-1], cb.masks[-1])
+        else:  # FP: all (thread, agent) rows in one batch (np.concatenate over threads, base_runner.py:472-481)
+            so = cb.share_obs[-1]
+            next_value, _ = self.critic.get_values(so.reshape(-1, so.shape[-1]), None, None)
         cb.compute_returns(next_value, self.value_normalizer)
 
     # ---- on_policy_ha_runner.py:11-130 ------------------------------------------------------------
@@ -88,6 +96,16 @@ class OnPolicyHARunner:
         actor_train_infos = []
         factor = torch.ones(T, N, 1, dtype=torch.float32, device=dev)
         advantages = self.critic_buffer.advantages  # returns[:-1] - denormalize(value_preds[:-1]), fused into the GAE scan
+        if self.state_type == "FP":
+            # global masked normalisation over every agent's active entries (on_policy_ha_runner.py:36-45)
+            active = torch.stack([b.active_masks[:-1] for b in self.actor_buffer], dim=2).contiguous()  # [T,N,A,1]
+            mom = torch.zeros(3, dtype=torch.float64, device=dev)
+            n = advantages.numel()
+            call("harl_masked_moments", ptr(advantages), ptr(active), n, ptr(mom), stream())
+            self.comm.all_reduce_sum(mom)
+            adv_n = torch.empty_like(advantages)
+            call("harl_adv_normalize", ptr(advantages), ptr(mom), ptr(adv_n), n, stream())
+            advantages = adv_n
         if self.fixed_order:
             agent_order = list(range(self.num_agents))
         else:
@@ -101,7 +119,10 @@ class OnPolicyHARunner:
                 self._logp_old = torch.empty(B, actor.actor.act_w, dtype=torch.float32, device=dev)
             actor.actor.fold()
             actor._logp_pass(obs, actions, avail, B, self._logp_old)            # pre-update log-probs (:66-83)
-            actor_train_infos.append(actor.train(buf, advantages, "EP"))      # :86-93
+            if self.state_type == "EP":
+                actor_train_infos.append(actor.train(buf, advantages, "EP"))  # :86-93
+            else:
+                actor_train_infos.append(actor.train(buf, advantages[:, :, agent_id].contiguous(), "FP"))
             new_factor = factor.clone()
             # post-update log-probs fused with factor *= agg(exp(new - old))   (:96-124)
             actor._logp_pass(obs, actions, avail, B, None, old_logp=self._logp_old, factor=new_factor.reshape(B))

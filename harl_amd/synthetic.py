@@ -94,9 +94,11 @@ class SyntheticBuffers:
     value_preds: np.ndarray             # [T+1, N, 1]
     critic_masks: np.ndarray            # [T+1, N, 1]
     bad_masks: np.ndarray               # [T+1, N, 1]
+    fp: Optional[dict] = None           # FP state type: share_obs/value_preds/masks/bad_masks [T+1,N,A,.], rewards [T,N,A,1]
 
 
-def make_buffers(sh: Shapes, seed: int, inactive_p: float = 0.0, unavailable_p: float = 0.0) -> SyntheticBuffers:
+def make_buffers(sh: Shapes, seed: int, inactive_p: float = 0.0, unavailable_p: float = 0.0,
+                 fp: bool = False) -> SyntheticBuffers:
     """obs/share_obs/rewards/value_preds ~ N(0,1); Box actions ~ N(0,1) with stored
     log-probs -1+0.1 N(0,1); Discrete actions ~ U{0..n-1} stored as fp32 with log-probs
     log(1/n)+0.05 N(0,1); masks 0 w.p. 0.04 with bad_masks 0 at the same places; critic masks =
@@ -131,5 +133,12 @@ def make_buffers(sh: Shapes, seed: int, inactive_p: float = 0.0, unavailable_p: 
     rewards = rng.standard_normal((T, N, 1)).astype(f32)
     value_preds = rng.standard_normal((T + 1, N, 1)).astype(f32)
     bad = np.where(base_mask == 0.0, 0.0, 1.0).astype(f32)
-    return SyntheticBuffers(obs, actions, logp, masks, active, avail, share_obs, rewards, value_preds,
-                            base_mask.copy(), bad)
+    out = SyntheticBuffers(obs, actions, logp, masks, active, avail, share_obs, rewards, value_preds,
+                           base_mask.copy(), bad)
+    if fp:  # feature-pruned (per-agent) critic inputs (on_policy_critic_buffer_fp.py:13-83); drawn AFTER the EP arrays
+        m_fp = np.repeat(base_mask[:, :, None, :], A, axis=2)
+        out.fp = dict(share_obs=rng.standard_normal((T + 1, N, A, sh.share_obs_dim)).astype(f32),
+                      rewards=rng.standard_normal((T, N, A, 1)).astype(f32),
+                      value_preds=rng.standard_normal((T + 1, N, A, 1)).astype(f32),
+                      masks=m_fp.astype(f32), bad_masks=np.where(m_fp == 0.0, 0.0, 1.0).astype(f32))
+    return out

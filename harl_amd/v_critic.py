@@ -104,14 +104,15 @@ class VCritic:
         """critic_epoch x critic_num_mini_batch updates (v_critic.py:159-200)."""
         buf = critic_buffer
         T, N = buf.rewards.shape[:2]
-        B = T * N
+        A = getattr(buf, "num_agents", None)  # FP buffers carry an agent axis: rows = (t*N + n)*A + a
+        B = T * N * (A or 1)
         dev = self.device
         self._info.zero_()
         self.critic.fold()
         share_obs = buf.flat("share_obs")
         value_preds = buf.flat("value_preds").reshape(B)
         returns = buf.flat("returns").reshape(B)
-        n_global = self.shard[0] * T if self.shard else B
+        n_global = self.shard[0] * T * (A or 1) if self.shard else B
         for _ in range(self.critic_epoch):
             if self.use_recurrent_policy or self.use_naive_recurrent_policy:
                 raise NotImplementedError("recurrent generators are not implemented in this round")
@@ -123,6 +124,8 @@ class VCritic:
             for ind in sampler:
                 m_global = ind.numel()
                 if self.shard:
+                    if A:
+                        raise NotImplementedError("sharded FP critic with more than one mini-batch")
                     ind = local_minibatch_rows(ind, self.shard[0], self.shard[1], self.shard[2])
                 self._update_core(share_obs, ind.to(dev), ind.numel(), m_global, value_preds, returns, value_normalizer)
         n_upd = self.critic_epoch * self.critic_num_mini_batch

@@ -170,8 +170,9 @@ int harl_actor_head_logp(const float *xL, long M, int H, const float *Whp, const
  *            dhead[M_pad, 32] (grad wrt head outputs; dw input), part_scalars[harl_head_blocks(M)][HARL_PS_STRIDE]:
  *            {0: sum loss*active, 1: sum active, 2: sum ent*active, 3: sum ratio, 4: count, 8..8+act_dim: dlogstd}
  *   mask/rstd: relu mask and rstd of the last hidden layer.
- *   trpo != 0: HATRPO surrogate  sum_s +ratio*f*adv*active  instead (no clip, no entropy term;
- *   algorithms/actors/hatrpo.py:77-95); scalar 0 is then that sum.
+ *   trpo: 0 = HAPPO; 1 = HATRPO surrogate  sum_s +ratio*f*adv*active  (no clip, no entropy term;
+ *   algorithms/actors/hatrpo.py:77-95); 2 = HAA2C  sum_s -ratio*f*adv*active  (no clip; algorithms/actors/haa2c.py:70-80).
+ *   Scalar 0 is that sum.
  */
 int harl_actor_head_loss(const float *xL, const uint32_t *relu_mask, const float *rstd, long M, int H,
                          const float *Whp, const float *bhp, const float *log_std, float std_x_coef,

@@ -42,6 +42,7 @@ from harl.algorithms.actors import ALGO_REGISTRY  # noqa: E402
 from harl.algorithms.critics.v_critic import VCritic  # noqa: E402
 from harl.common.buffers.on_policy_actor_buffer import OnPolicyActorBuffer  # noqa: E402
 from harl.common.buffers.on_policy_critic_buffer_ep import OnPolicyCriticBufferEP  # noqa: E402
+from harl.common.buffers.on_policy_critic_buffer_fp import OnPolicyCriticBufferFP  # noqa: E402
 from harl.common.valuenorm import ValueNorm  # noqa: E402
 from harl.runners.on_policy_ha_runner import OnPolicyHARunner  # noqa: E402
 
@@ -85,6 +86,16 @@ CASES = {
                          overrides=dict(use_max_grad_norm=False, use_policy_active_masks=False,
                                         use_clipped_value_loss=False, use_feature_normalization=False,
                                         ppo_epoch=2, critic_epoch=2)),
+    # ---- FP state type (per-agent critic inputs, on_policy_critic_buffer_fp.py; global advantage normalisation,
+    #      on_policy_ha_runner.py:36-45)
+    "fp_box_h64": dict(state_type="FP", shapes=dict(T=10, N=6, A=3, obs_dim=14, share_obs_dim=21, act_dim=2, discrete=False,
+                                                    hidden_sizes=[64, 64]), seed=13, overrides={}, inactive_p=0.2),
+    "fp_disc_h128_mb2": dict(state_type="FP", shapes=dict(T=8, N=8, A=2, obs_dim=30, share_obs_dim=40, act_dim=6,
+                                                          discrete=True, hidden_sizes=[128, 128]), seed=14,
+                             overrides=dict(critic_num_mini_batch=2, actor_num_mini_batch=2), unavailable_p=0.2),
+    # ---- HAA2C (harl/algorithms/actors/haa2c.py): unclipped surrogate, a2c_epoch epochs
+    "a2c_box_h64": dict(algo="haa2c", shapes=dict(T=10, N=8, A=2, obs_dim=13, share_obs_dim=9, act_dim=2, discrete=False,
+                                                  hidden_sizes=[64, 64]), seed=12, overrides={}),
     # ---- HATRPO (harl/algorithms/actors/hatrpo.py): CG + Fisher-vector products + backtracking line search
     "trpo_box_h64": dict(algo="hatrpo", shapes=dict(T=10, N=8, A=2, obs_dim=11, share_obs_dim=9, act_dim=3, discrete=False,
                                                     hidden_sizes=[64, 64]), seed=6, overrides={}),
@@ -129,9 +140,13 @@ def run_case(name: str, spec: dict) -> dict:
     assert list(csd.keys()) == list(critic.critic.state_dict().keys())
     critic.critic.load_state_dict({k: torch.from_numpy(v) for k, v in csd.items()})
 
-    data = make_buffers(sh, seed, spec.get("inactive_p", 0.0), spec.get("unavailable_p", 0.0))
+    fp = spec.get("state_type", "EP") == "FP"
+    data = make_buffers(sh, seed, spec.get("inactive_p", 0.0), spec.get("unavailable_p", 0.0), fp=fp)
     abuf = [OnPolicyActorBuffer({**cfg["train"], **cfg["model"]}, Box((sh.obs_dim,)), act_space) for _ in range(sh.A)]
-    cbuf = OnPolicyCriticBufferEP({**cfg["train"], **cfg["model"], **cfg["algo"]}, Box((sh.share_obs_dim,)))
+    if fp:
+        cbuf = OnPolicyCriticBufferFP({**cfg["train"], **cfg["model"], **cfg["algo"]}, Box((sh.share_obs_dim,)), sh.A)
+    else:
+        cbuf = OnPolicyCriticBufferEP({**cfg["train"], **cfg["model"], **cfg["algo"]}, Box((sh.share_obs_dim,)))
     for a in range(sh.A):
         abuf[a].obs[:] = data.obs[a]
         abuf[a].actions[:] = data.actions[a]
@@ -140,11 +155,15 @@ def run_case(name: str, spec: dict) -> dict:
         abuf[a].active_masks[:] = data.active_masks[a]
         if sh.discrete:
             abuf[a].available_actions[:] = data.available_actions[a]
-    cbuf.share_obs[:] = data.share_obs
-    cbuf.rewards[:] = data.rewards
-    cbuf.value_preds[:] = data.value_preds
-    cbuf.masks[:] = data.critic_masks
-    cbuf.bad_masks[:] = data.bad_masks
+    if fp:
+        for k in ("share_obs", "rewards", "value_preds", "masks", "bad_masks"):
+            getattr(cbuf, k)[:] = data.fp[k]
+    else:
+        cbuf.share_obs[:] = data.share_obs
+        cbuf.rewards[:] = data.rewards
+        cbuf.value_preds[:] = data.value_preds
+        cbuf.masks[:] = data.critic_masks
+        cbuf.bad_masks[:] = data.bad_masks
     onpolicy_inputs = {}
     if spec.get("onpolicy", True):
         # Policy-consistent actions / stored log-probs (importance ratios ~ 1, the regime PPO runs in):
@@ -179,7 +198,7 @@ def run_case(name: str, spec: dict) -> dict:
 
     r = OnPolicyHARunner.__new__(OnPolicyHARunner)
     r.algo_args, r.value_normalizer, r.critic_buffer, r.actor_buffer = cfg, vn, cbuf, abuf
-    r.actor, r.critic, r.num_agents, r.state_type = actors, critic, sh.A, "EP"
+    r.actor, r.critic, r.num_agents, r.state_type = actors, critic, sh.A, ("FP" if fp else "EP")
     r.fixed_order = cfg["algo"]["fixed_order"]
     r.action_aggregation, r.device = cfg["algo"]["action_aggregation"], dev
 

@@ -159,6 +159,7 @@ def compute_returns(
     use_gae: bool = True,
     use_proper_time_limits: bool = True,
     value_normalizer: Optional[OracleValueNorm] = None,
+    fp_order: bool = False,
 ) -> Tuple[np.ndarray, np.ndarray]:
     """Returns (returns[T+1,N,1], value_preds[T+1,N,1]) as fp32 NumPy, same op order as the reference."""
     T = rewards.shape[0]
@@ -170,7 +171,10 @@ def compute_returns(
         gae = 0
         for step in reversed(range(T)):
             delta = rewards[step] + gamma * den(value_preds[step + 1]) * masks[step + 1] - den(value_preds[step])
-            gae = delta + gamma * gae_lambda * masks[step + 1] * gae
+            if fp_order and use_proper_time_limits and value_normalizer is not None:
+                gae = delta + gamma * gae_lambda * gae * masks[step + 1]  # on_policy_critic_buffer_fp.py:130
+            else:
+                gae = delta + gamma * gae_lambda * masks[step + 1] * gae
             if use_proper_time_limits:
                 gae = bad_masks[step + 1] * gae
             returns[step] = gae + den(value_preds[step])
@@ -303,6 +307,8 @@ def _grad_norm_step(net: _Net, cfg: PathConfig) -> torch.Tensor:
 # HAPPO   (happo.py)
 # --------------------------------------------------------------------------------------
 class OracleHAPPO:
+    clipped = True
+
     def __init__(self, state_dict, cfg: PathConfig):
         self.cfg = cfg
         self.net = _Net(state_dict, cfg.lr, cfg.opti_eps, cfg.weight_decay)
@@ -322,23 +328,29 @@ class OracleHAPPO:
         agg = getattr(torch, cfg.action_aggregation)
         imp = agg(torch.exp(logp - old_logp), dim=-1, keepdim=True)
         surr1 = imp * adv
-        surr2 = torch.clamp(imp, 1.0 - cfg.clip_param, 1.0 + cfg.clip_param) * adv
+        if self.clipped:
+            surr2 = torch.clamp(imp, 1.0 - cfg.clip_param, 1.0 + cfg.clip_param) * adv
+            surr = torch.min(surr1, surr2)
+        else:  # HAA2C (haa2c.py:70-80)
+            surr = surr1
         if cfg.use_policy_active_masks:
-            pl = (-torch.sum(factor * torch.min(surr1, surr2), dim=-1, keepdim=True) * active).sum() / active.sum()
+            pl = (-torch.sum(factor * surr, dim=-1, keepdim=True) * active).sum() / active.sum()
         else:
-            pl = -torch.sum(factor * torch.min(surr1, surr2), dim=-1, keepdim=True).mean()
+            pl = -torch.sum(factor * surr, dim=-1, keepdim=True).mean()
         self.net.opt.zero_grad()
         (pl - ent * cfg.entropy_coef).backward()
         g = self.net.flat_grad() if keep_grad else None
         gn = _grad_norm_step(self.net, cfg)
         return pl.detach(), ent.detach(), gn.detach(), imp.detach(), g
 
-    def train(self, buf: "OracleActorBuffer", advantages: np.ndarray, keep_grad: bool = False) -> dict:  # happo.py:104-158
+    def train(self, buf: "OracleActorBuffer", advantages: np.ndarray, keep_grad: bool = False,
+              state_type: str = "EP") -> dict:  # happo.py:104-158
         cfg = self.cfg
         info = {"policy_loss": 0.0, "dist_entropy": 0.0, "actor_grad_norm": 0.0, "ratio": 0.0}
         if np.all(buf.active_masks[:-1] == 0.0):
             return info
-        advantages = normalize_advantages(advantages, buf.active_masks[:-1])
+        if state_type == "EP":
+            advantages = normalize_advantages(advantages, buf.active_masks[:-1])
         for _ in range(cfg.ppo_epoch):
             for sample, idx in buf.feed_forward_generator(advantages, cfg.actor_num_mini_batch):
                 pl, ent, gn, imp, g = self.update(sample, keep_grad)
@@ -352,6 +364,11 @@ class OracleHAPPO:
                 )
         n = cfg.ppo_epoch * cfg.actor_num_mini_batch
         return {k: v / n for k, v in info.items()}
+
+
+class OracleHAA2C(OracleHAPPO):
+    """harl/algorithms/actors/haa2c.py: HAPPO with the unclipped surrogate; cfg.ppo_epoch carries a2c_epoch."""
+    clipped = False
 
 
 # --------------------------------------------------------------------------------------
@@ -464,20 +481,27 @@ class OracleCriticBufferEP:
     bad_masks: np.ndarray    # [T+1, N, 1]
     returns: np.ndarray = field(default=None)
 
+    fp = False  # OracleCriticBufferFP: arrays carry an agent axis [T(+1), N, A, .] (on_policy_critic_buffer_fp.py)
+
     def compute_returns(self, next_value, vn, cfg: PathConfig):
         self.returns, self.value_preds = compute_returns(
             self.rewards, self.value_preds, self.masks, self.bad_masks, next_value,
-            cfg.gamma, cfg.gae_lambda, cfg.use_gae, cfg.use_proper_time_limits, vn,
+            cfg.gamma, cfg.gae_lambda, cfg.use_gae, cfg.use_proper_time_limits, vn, fp_order=self.fp,
         )
 
     def feed_forward_generator(self, num_mini_batch: int):
-        T, N = self.rewards.shape[:2]
-        sampler = minibatch_indices(T * N, num_mini_batch)
+        B = int(np.prod(self.rewards.shape[:-1]))  # T*N (EP) or T*N*A (FP), row-major flattening
+        T, N = B, 1
+        sampler = minibatch_indices(B, num_mini_batch)
         so = self.share_obs[:-1].reshape(T * N, -1)
         vp = self.value_preds[:-1].reshape(-1, 1)
         rt = self.returns[:-1].reshape(-1, 1)
         for idx in sampler:
             yield (so[idx], vp[idx], rt[idx]), idx
+
+
+class OracleCriticBufferFP(OracleCriticBufferEP):
+    fp = True
 
 
 # --------------------------------------------------------------------------------------
@@ -493,10 +517,16 @@ def ha_train(
     keep_grad: bool = False,
 ):
     """Returns (actor_train_infos in update order, critic_train_info, extras)."""
-    T, N = critic_buffer.rewards.shape[:2]
+    T, N = actor_buffers[0].actions.shape[:2]
     A = len(actors)
     factor = np.ones((T, N, 1), dtype=np.float32)
     advantages = advantages_from_returns(critic_buffer.returns, critic_buffer.value_preds, vn)
+    fp = getattr(critic_buffer, "fp", False)
+    if fp:  # global advantage normalisation over all agents' active entries (on_policy_ha_runner.py:36-45)
+        am = np.stack([b.active_masks for b in actor_buffers], axis=2)
+        cp = advantages.copy()
+        cp[am[:-1] == 0.0] = np.nan
+        advantages = (advantages - np.nanmean(cp)) / (np.nanstd(cp) + 1e-5)
     order = list(range(A)) if cfg.fixed_order else list(torch.randperm(A).numpy())
     infos, factors = [], []
     for a in order:
@@ -506,7 +536,10 @@ def ha_train(
         avail = None if buf.available_actions is None else flat(buf.available_actions[:-1])
         args = (flat(buf.obs[:-1]), flat(buf.actions), avail, flat(buf.active_masks[:-1]))
         old_logp, _, _ = actors[a].evaluate_actions(*args)
-        infos.append(actors[a].train(buf, advantages.copy(), keep_grad))
+        if fp:
+            infos.append(actors[a].train(buf, advantages[:, :, a].copy(), keep_grad, state_type="FP"))
+        else:
+            infos.append(actors[a].train(buf, advantages.copy(), keep_grad))
         new_logp, _, _ = actors[a].evaluate_actions(*args)
         agg = getattr(torch, cfg.action_aggregation)
         factor = factor * agg(torch.exp(new_logp - old_logp), dim=-1).reshape(T, N, 1).detach().numpy()
@@ -659,11 +692,13 @@ class OracleHATRPO:
         self.trace.append(info)
         return info
 
-    def train(self, buf: "OracleActorBuffer", advantages: np.ndarray, keep_grad: bool = False) -> dict:  # hatrpo.py:196-247
+    def train(self, buf: "OracleActorBuffer", advantages: np.ndarray, keep_grad: bool = False,
+              state_type: str = "EP") -> dict:  # hatrpo.py:196-247
         out = {"kl": 0.0, "dist_entropy": 0.0, "loss_improve": 0.0, "expected_improve": 0.0, "ratio": 0.0}
         if np.all(buf.active_masks[:-1] == 0.0):
             return out
-        advantages = normalize_advantages(advantages, buf.active_masks[:-1])
+        if state_type == "EP":
+            advantages = normalize_advantages(advantages, buf.active_masks[:-1])
         for sample, _ in buf.feed_forward_generator(advantages, 1):
             i = self.update(sample)
             for k in out:

@@ -386,7 +386,7 @@ def build_runner(case: GoldenCase):
     sh, d = case.shapes, case.data
     space = Discrete(sh.act_dim) if sh.discrete else Box((sh.act_dim,))
     algo_args = dict(train=train, model=model, algo=algo)
-    r = OnPolicyHARunner(dict(algo=case.algo_name), algo_args, dict(state_type="EP"),
+    r = OnPolicyHARunner(dict(algo=case.algo_name), algo_args, dict(state_type=case.state_type),
                          obs_spaces=[Box((sh.obs_dim,))] * sh.A, share_obs_space=Box((sh.share_obs_dim,)),
                          act_spaces=[space] * sh.A, device=DEV)
     for a in range(sh.A):
@@ -401,11 +401,15 @@ def build_runner(case: GoldenCase):
             b.available_actions.copy_(dev(d.available_actions[a]))
     r.critic.critic.load_state_dict({k: torch.from_numpy(v) for k, v in case.critic_sd.items()})
     cb = r.critic_buffer
-    cb.share_obs.copy_(dev(d.share_obs))
-    cb.rewards.copy_(dev(d.rewards))
-    cb.value_preds.copy_(dev(d.value_preds))
-    cb.masks.copy_(dev(d.critic_masks))
-    cb.bad_masks.copy_(dev(d.bad_masks))
+    if case.state_type == "FP":
+        for k in ("share_obs", "rewards", "value_preds", "masks", "bad_masks"):
+            getattr(cb, k).copy_(dev(d.fp[k]))
+    else:
+        cb.share_obs.copy_(dev(d.share_obs))
+        cb.rewards.copy_(dev(d.rewards))
+        cb.value_preds.copy_(dev(d.value_preds))
+        cb.masks.copy_(dev(d.critic_masks))
+        cb.bad_masks.copy_(dev(d.bad_masks))
     if r.value_normalizer is not None:
         vi = case.vn_init
         r.value_normalizer.stats.copy_(dev(np.array([vi["running_mean"], vi["running_mean_sq"], vi["debiasing_term"]],

@@ -14,7 +14,7 @@ from harl_amd.synthetic import (
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 ALL_CASES = ["mpe_box_h64", "mpe_box_h128", "mpe_disc_h64", "cheetah_h128x3_mb2", "box_mean_inactive_novn",
-             "wide_obs_h64"]
+             "wide_obs_h64", "a2c_box_h64", "fp_box_h64", "fp_disc_h128_mb2"]
 TRPO_CASES = ["trpo_box_h64", "trpo_disc_h64", "trpo_wide_h128x3"]
 
 
@@ -28,8 +28,9 @@ class GoldenCase:
         self.seed = spec["seed"]
         self.algo, self.model, self.train = self.meta["algo"], self.meta["model"], self.meta["train"]
         self.algo_name = self.meta.get("algo_name", "happo")
+        self.state_type = spec.get("state_type", "EP")
         self.data: SyntheticBuffers = make_buffers(self.shapes, self.seed, spec.get("inactive_p", 0.0),
-                                                   spec.get("unavailable_p", 0.0))
+                                                   spec.get("unavailable_p", 0.0), fp=self.state_type == "FP")
         for a in range(self.shapes.A):
             if f"in_actions_{a}" in self.z:
                 self.data.actions[a] = self.z[f"in_actions_{a}"].copy()

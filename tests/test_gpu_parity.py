@@ -57,7 +57,8 @@ def test_single_update_gradients_mean_aggregation_inactive_agents():
 
 
 @pytest.mark.parametrize("name", ["mpe_box_h64", "mpe_box_h128", "mpe_disc_h64", "cheetah_h128x3_mb2",
-                                  "box_mean_inactive_novn", "wide_obs_h64"])
+                                  "box_mean_inactive_novn", "wide_obs_h64", "a2c_box_h64", "fp_box_h64",
+                                  "fp_disc_h128_mb2"])
 def test_train_matches_reference_golden(name):
     _assert_all(_G().check_train_golden(name), tol=TOL_TRAIN)
 

@@ -20,6 +20,9 @@ def build_oracle(case: GoldenCase):
     if case.algo_name == "hatrpo":
         tc = O.TrpoConfig(**{k: algo[k] for k in ("kl_threshold", "ls_step", "accept_ratio", "backtrack_coeff")})
         actors = [O.OracleHATRPO({k: torch.from_numpy(v) for k, v in sd.items()}, cfg, tc) for sd in case.actor_sd]
+    elif case.algo_name == "haa2c":
+        cfg.ppo_epoch = algo["a2c_epoch"]
+        actors = [O.OracleHAA2C({k: torch.from_numpy(v) for k, v in sd.items()}, cfg) for sd in case.actor_sd]
     else:
         actors = [O.OracleHAPPO({k: torch.from_numpy(v) for k, v in sd.items()}, cfg) for sd in case.actor_sd]
     critic = O.OracleVCritic({k: torch.from_numpy(v) for k, v in case.critic_sd.items()}, cfg)
@@ -27,8 +30,13 @@ def build_oracle(case: GoldenCase):
                                  d.active_masks[a].copy(),
                                  None if d.available_actions[a] is None else d.available_actions[a].copy())
              for a in range(sh.A)]
-    cbuf = O.OracleCriticBufferEP(d.share_obs.copy(), d.rewards.copy(), d.value_preds.copy(), d.critic_masks.copy(),
-                                  d.bad_masks.copy())
+    if case.state_type == "FP":
+        f = d.fp
+        cbuf = O.OracleCriticBufferFP(f["share_obs"].copy(), f["rewards"].copy(), f["value_preds"].copy(),
+                                      f["masks"].copy(), f["bad_masks"].copy())
+    else:
+        cbuf = O.OracleCriticBufferEP(d.share_obs.copy(), d.rewards.copy(), d.value_preds.copy(), d.critic_masks.copy(),
+                                      d.bad_masks.copy())
     vn = None
     if case.use_valuenorm:
         vn = O.OracleValueNorm()

@@ -228,7 +228,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_actor_head(ActorArgs A) {
         logp_d[d] = 0.f;
         if (d < D) {
           const float sig = cst[DAP + d], lsig = cst[2 * DAP + d];
-          const float a = A.actions[row * act_w + d];
+          const float a = A.actions ? A.actions[row * act_w + d] : z[d];  // actions == NULL: head outputs only
           const float diff = a - z[d];
           const float var = sig * sig;
           const float lp = -(diff * diff) / (2.f * var) - lsig - LOG_SQRT_2PI;  // torch Normal.log_prob
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_actor_head(ActorArgs A) {
       for (int d = 0; d < DAP; ++d)
         if (d < D) se += expf(z[d] - mx);
       const float lse = mx + logf(se);
-      const int a = (int)A.actions[row];
+      const int a = A.actions ? (int)A.actions[row] : 0;
       float lpa = 0.f;
 #pragma unroll
       for (int d = 0; d < DAP; ++d) {

@@ -73,11 +73,40 @@ class OnPolicyBase:
         self._logp_pass(obs, action, avail, M, out)
         return out, None, None
 
+    @torch.no_grad()
     def get_actions(self, obs, rnn_states_actor, masks, available_actions=None, deterministic=False):
-        raise NotImplementedError("rollout-side action sampling is outside this round's hot path (SURVEY.md §8f.1)")
+        """Rollout-side sampling (on_policy_base.py:52-69 -> StochasticPolicy.forward, act.py:45-86).  The trunk and head
+        run on the HIP kernels (head outputs via ``harl_actor_head_logp(head_out=...)``); the draw itself uses torch's
+        device generator, which is what the reference's ``Normal.sample()/Categorical.sample()`` use on a GPU.
+        Returns device tensors (actions [B, act_w], action_log_probs [B, act_w], rnn_states passthrough)."""
+        net = self.actor
+        x = _as_dev(obs, self.device)
+        x = x.reshape(x.shape[0], -1)
+        M = x.shape[0]
+        avail = None if available_actions is None else _as_dev(available_actions, self.device).reshape(M, -1)
+        net.fold()
+        head = torch.empty(M, net.act_dim, **self.tpdv)
+        self._logp_pass(x, None, avail, M, None, head_out=head)  # head_out only: no actions needed
+        if net.discrete:  # head = normalised logits (masked entries ~ -1e10)
+            if deterministic:
+                actions = head.argmax(dim=-1, keepdim=True).to(torch.float32)
+            else:
+                actions = torch.multinomial(torch.exp(head), 1).to(torch.float32)
+            logp = head.gather(-1, actions.long())
+        else:
+            sigma = torch.sigmoid(net.log_std() / net.std_x_coef) * net.std_y_coef
+            actions = head if deterministic else head + sigma * torch.randn_like(head)
+            logp = torch.empty(M, net.act_dim, **self.tpdv)
+            Wp, bp = net._packs[-1]  # x_hat_L of this batch is still resident: head-only second pass for log pi(a)
+            call("harl_actor_head_logp", ptr(net.xh[-1]), M, net.hidden_sizes[-1], ptr(Wp), ptr(bp), ptr(net.log_std()),
+                 net.std_x_coef, net.std_y_coef, 0, net.act_dim, ptr(actions.contiguous()), None, ptr(logp), None, None, 0,
+                 None, stream())
+        return actions, logp, rnn_states_actor
 
+    @torch.no_grad()
     def act(self, obs, rnn_states_actor, masks, available_actions=None, deterministic=False):
-        raise NotImplementedError("rollout-side action sampling is outside this round's hot path (SURVEY.md §8f.1)")
+        actions, _, rnn = self.get_actions(obs, rnn_states_actor, masks, available_actions, deterministic)
+        return actions, rnn
 
     def prep_training(self):
         self.actor.train()

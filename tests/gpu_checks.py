@@ -223,6 +223,42 @@ def check_forward(spec) -> Dict[str, float]:
     return out
 
 
+def check_get_actions(spec) -> Dict[str, float]:
+    """Rollout-side sampling: deterministic actions == distribution mode; returned log-probs == oracle log-probs of the
+    returned actions; stochastic samples have the right first/second moments (Gaussian) / respect availability."""
+    out = {}
+    M = 4096
+    sh = Shapes(T=M, N=1, A=1, obs_dim=spec["obs_dim"], share_obs_dim=spec["share_obs_dim"], act_dim=spec["act_dim"],
+                discrete=spec["discrete"], hidden_sizes=spec["hidden_sizes"])
+    d = make_buffers(sh, 5, unavailable_p=0.3 if sh.discrete else 0.0)
+    actor, sd, args = _mk_actor(sh, 31, **spec.get("over", {}))
+    cfg = O.PathConfig.from_reference_dicts({}, args, args)
+    obs = d.obs[0][:-1].reshape(M, -1)
+    avail = None if not sh.discrete else d.available_actions[0][:-1].reshape(M, -1)
+    p = {k: torch.from_numpy(v) for k, v in sd.items()}
+    with torch.no_grad():
+        kind, dp = O._dist_params(p, cfg, torch.from_numpy(obs), None if avail is None else torch.from_numpy(avail))
+    torch.manual_seed(0)
+    a_det, lp_det, _ = actor.get_actions(obs, None, None, avail, deterministic=True)
+    a_smp, lp_smp, _ = actor.get_actions(obs, None, None, avail, deterministic=False)
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        ref_lp, _, _ = O.actor_evaluate_actions(p, cfg, torch.from_numpy(obs), a_smp.cpu(),
+                                                None if avail is None else torch.from_numpy(avail), None)
+    out["sample_logp_vec_rel"] = vec_rel_err(lp_smp.cpu().numpy(), ref_lp.numpy())
+    if sh.discrete:
+        mode = dp[0].argmax(-1, keepdim=True).numpy()
+        out["mode_mismatch"] = float(np.sum(a_det.cpu().numpy() != mode))
+        taken = a_smp.cpu().numpy().astype(np.int64)
+        out["unavailable_action_sampled_count"] = float(np.sum(np.take_along_axis(avail, taken, axis=1) == 0))
+    else:
+        out["mode_vec_rel"] = vec_rel_err(a_det.cpu().numpy(), dp[0].numpy())
+        zs = (a_smp.cpu().numpy() - dp[0].numpy()) / dp[1].numpy()
+        out["sample_zscore_mean_abs"] = float(abs(zs.mean()))        # ~ N(0, 1/sqrt(M*D))
+        out["sample_zscore_std_err"] = float(abs(zs.std() - 1.0))
+    return out
+
+
 def check_gradients(spec, mini_batches: int = 1, agg: str = "prod", inactive_p: float = 0.0) -> Dict[str, float]:
     """ONE HAPPO.update and ONE VCritic.update: pre-clip gradient vector, loss scalars, grad-norm and the
     post-Adam parameters vs the oracle (autograd + torch.optim.Adam)."""

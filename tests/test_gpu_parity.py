@@ -77,3 +77,16 @@ def test_hatrpo_gradient_fvp_and_update(i):
 @pytest.mark.parametrize("name", ["trpo_box_h64", "trpo_disc_h64", "trpo_wide_h128x3"])
 def test_hatrpo_train_matches_reference_golden(name):
     _assert_all(_G().check_train_golden(name), tol=TOL_TRAIN)
+
+
+@pytest.mark.parametrize("i", [0, 1, 5])
+def test_rollout_get_actions(i):
+    G = _G()
+    res = G.check_get_actions(G.FWD_SHAPES[i])
+    for k, v in res.items():
+        if "count" in k or "mismatch" in k:
+            assert v == 0.0, (k, v)
+        elif "zscore" in k:
+            assert v < 0.05, (k, v)
+        else:
+            assert v < TOL, (k, v)

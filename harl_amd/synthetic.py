@@ -28,7 +28,14 @@ class Shapes:
         return 1 if self.discrete else self.act_dim
 
 
-def actor_param_shapes(sh: Shapes, use_feature_normalization: bool = True) -> List[Tuple[str, Tuple[int, ...]]]:
+def _rnn_shapes(h: int) -> List[Tuple[str, Tuple[int, ...]]]:
+    """RNNLayer (models/base/rnn.py:8-21): nn.GRU(h, h, 1) parameters in registration order, then the LayerNorm."""
+    return [("rnn.rnn.weight_ih_l0", (3 * h, h)), ("rnn.rnn.weight_hh_l0", (3 * h, h)), ("rnn.rnn.bias_ih_l0", (3 * h,)),
+            ("rnn.rnn.bias_hh_l0", (3 * h,)), ("rnn.norm.weight", (h,)), ("rnn.norm.bias", (h,))]
+
+
+def actor_param_shapes(sh: Shapes, use_feature_normalization: bool = True,
+                       recurrent: bool = False) -> List[Tuple[str, Tuple[int, ...]]]:
     """Parameter names/shapes in the reference's ``StochasticPolicy.parameters()`` order
     (harl/models/policy_models/stochastic_policy.py:11-54; probe in SURVEY.md §8a M1)."""
     out: List[Tuple[str, Tuple[int, ...]]] = []
@@ -39,6 +46,8 @@ def actor_param_shapes(sh: Shapes, use_feature_normalization: bool = True) -> Li
         out += [(f"base.mlp.fc.{3*i}.weight", (h, d)), (f"base.mlp.fc.{3*i}.bias", (h,)),
                 (f"base.mlp.fc.{3*i+2}.weight", (h,)), (f"base.mlp.fc.{3*i+2}.bias", (h,))]
         d = h
+    if recurrent:
+        out += _rnn_shapes(d)
     if sh.discrete:
         out += [("act.action_out.linear.weight", (sh.act_dim, d)), ("act.action_out.linear.bias", (sh.act_dim,))]
     else:
@@ -47,7 +56,8 @@ def actor_param_shapes(sh: Shapes, use_feature_normalization: bool = True) -> Li
     return out
 
 
-def critic_param_shapes(sh: Shapes, use_feature_normalization: bool = True) -> List[Tuple[str, Tuple[int, ...]]]:
+def critic_param_shapes(sh: Shapes, use_feature_normalization: bool = True,
+                        recurrent: bool = False) -> List[Tuple[str, Tuple[int, ...]]]:
     """``VNet.parameters()`` order (harl/models/value_function_models/v_net.py:10-46)."""
     out: List[Tuple[str, Tuple[int, ...]]] = []
     if use_feature_normalization:
@@ -57,6 +67,8 @@ def critic_param_shapes(sh: Shapes, use_feature_normalization: bool = True) -> L
         out += [(f"base.mlp.fc.{3*i}.weight", (h, d)), (f"base.mlp.fc.{3*i}.bias", (h,)),
                 (f"base.mlp.fc.{3*i+2}.weight", (h,)), (f"base.mlp.fc.{3*i+2}.bias", (h,))]
         d = h
+    if recurrent:
+        out += _rnn_shapes(d)
     out += [("v_out.weight", (1, d)), ("v_out.bias", (1,))]
     return out
 
@@ -72,6 +84,8 @@ def synthetic_state_dict(shapes: List[Tuple[str, Tuple[int, ...]]], seed: int, s
         elif len(shp) == 2:  # Linear weight [out, in]
             scale = (0.3 if ("action_out" in name or name.startswith("v_out")) else 1.4) / np.sqrt(shp[1])
             v = scale * rng.standard_normal(shp)
+        elif name == "rnn.norm.weight":
+            v = 1.0 + 0.1 * rng.standard_normal(shp)
         elif "feature_norm.weight" in name or (name.startswith("base.mlp.fc.") and int(name.split(".")[3]) % 3 == 2 and name.endswith("weight")):
             v = 1.0 + 0.1 * rng.standard_normal(shp)
         else:  # biases (Linear and LayerNorm)
@@ -95,10 +109,11 @@ class SyntheticBuffers:
     critic_masks: np.ndarray            # [T+1, N, 1]
     bad_masks: np.ndarray               # [T+1, N, 1]
     fp: Optional[dict] = None           # FP state type: share_obs/value_preds/masks/bad_masks [T+1,N,A,.], rewards [T,N,A,1]
+    rnn: Optional[dict] = None          # recurrent policies: actor = A x [T+1,N,1,H], critic = [T+1,N,1,H]
 
 
 def make_buffers(sh: Shapes, seed: int, inactive_p: float = 0.0, unavailable_p: float = 0.0,
-                 fp: bool = False) -> SyntheticBuffers:
+                 fp: bool = False, rnn: bool = False) -> SyntheticBuffers:
     """obs/share_obs/rewards/value_preds ~ N(0,1); Box actions ~ N(0,1) with stored
     log-probs -1+0.1 N(0,1); Discrete actions ~ U{0..n-1} stored as fp32 with log-probs
     log(1/n)+0.05 N(0,1); masks 0 w.p. 0.04 with bad_masks 0 at the same places; critic masks =
@@ -141,4 +156,8 @@ def make_buffers(sh: Shapes, seed: int, inactive_p: float = 0.0, unavailable_p: 
                       rewards=rng.standard_normal((T, N, A, 1)).astype(f32),
                       value_preds=rng.standard_normal((T + 1, N, A, 1)).astype(f32),
                       masks=m_fp.astype(f32), bad_masks=np.where(m_fp == 0.0, 0.0, 1.0).astype(f32))
+    if rnn:  # stored GRU hidden states (drawn last so the other arrays do not depend on the flag)
+        hh = sh.hidden_sizes[-1]
+        out.rnn = dict(actor=[(0.3 * rng.standard_normal((T + 1, N, 1, hh))).astype(f32) for _ in range(A)],
+                       critic=(0.3 * rng.standard_normal((T + 1, N, 1, hh))).astype(f32))
     return out

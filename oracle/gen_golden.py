@@ -93,6 +93,19 @@ CASES = {
     "fp_disc_h128_mb2": dict(state_type="FP", shapes=dict(T=8, N=8, A=2, obs_dim=30, share_obs_dim=40, act_dim=6,
                                                           discrete=True, hidden_sizes=[128, 128]), seed=14,
                              overrides=dict(critic_num_mini_batch=2, actor_num_mini_batch=2), unavailable_p=0.2),
+    # ---- recurrent (GRU) policies: chunked BPTT generator (on_policy_actor_buffer.py:223-326), naive generator (:180-221),
+    #      full-length unroll with mask resets in the runner's log-prob passes (models/base/rnn.py:33-78)
+    "rnn_box_h64": dict(shapes=dict(T=20, N=6, A=2, obs_dim=15, share_obs_dim=22, act_dim=3, discrete=False,
+                                    hidden_sizes=[64, 64]), seed=15, inactive_p=0.1,
+                        overrides=dict(use_recurrent_policy=True, data_chunk_length=10)),
+    "rnn_disc_h64_mb2": dict(shapes=dict(T=20, N=8, A=2, obs_dim=19, share_obs_dim=26, act_dim=7, discrete=True,
+                                         hidden_sizes=[64]), seed=16, unavailable_p=0.2,
+                             overrides=dict(use_recurrent_policy=True, data_chunk_length=5, actor_num_mini_batch=2,
+                                            critic_num_mini_batch=2, ppo_epoch=3, critic_epoch=3)),
+    "rnn_naive_h64": dict(shapes=dict(T=12, N=6, A=2, obs_dim=9, share_obs_dim=12, act_dim=2, discrete=False,
+                                      hidden_sizes=[64, 64, 64]), seed=17,
+                          overrides=dict(use_naive_recurrent_policy=True, actor_num_mini_batch=2, critic_num_mini_batch=2,
+                                         ppo_epoch=2, critic_epoch=2, fixed_order=True)),
     # ---- HAA2C (harl/algorithms/actors/haa2c.py): unclipped surrogate, a2c_epoch epochs
     "a2c_box_h64": dict(algo="haa2c", shapes=dict(T=10, N=8, A=2, obs_dim=13, share_obs_dim=9, act_dim=2, discrete=False,
                                                   hidden_sizes=[64, 64]), seed=12, overrides={}),
@@ -132,16 +145,17 @@ def run_case(name: str, spec: dict) -> dict:
     margs = {**cfg["model"], **cfg["algo"]}
     actors = [ALGO_REGISTRY[algo_name](margs, Box((sh.obs_dim,)), act_space, dev) for _ in range(sh.A)]
     critic = VCritic(margs, Box((sh.share_obs_dim,)), dev)
+    rec = bool(cfg["model"]["use_recurrent_policy"] or cfg["model"]["use_naive_recurrent_policy"])
     for a, actor in enumerate(actors):
-        sd = synthetic_state_dict(actor_param_shapes(sh, use_fn), 1000 * seed + a, cfg["model"]["std_x_coef"])
+        sd = synthetic_state_dict(actor_param_shapes(sh, use_fn, rec), 1000 * seed + a, cfg["model"]["std_x_coef"])
         assert list(sd.keys()) == list(actor.actor.state_dict().keys()), (list(sd.keys()), list(actor.actor.state_dict().keys()))
         actor.actor.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
-    csd = synthetic_state_dict(critic_param_shapes(sh, use_fn), 1000 * seed + 999)
+    csd = synthetic_state_dict(critic_param_shapes(sh, use_fn, rec), 1000 * seed + 999)
     assert list(csd.keys()) == list(critic.critic.state_dict().keys())
     critic.critic.load_state_dict({k: torch.from_numpy(v) for k, v in csd.items()})
 
     fp = spec.get("state_type", "EP") == "FP"
-    data = make_buffers(sh, seed, spec.get("inactive_p", 0.0), spec.get("unavailable_p", 0.0), fp=fp)
+    data = make_buffers(sh, seed, spec.get("inactive_p", 0.0), spec.get("unavailable_p", 0.0), fp=fp, rnn=rec)
     abuf = [OnPolicyActorBuffer({**cfg["train"], **cfg["model"]}, Box((sh.obs_dim,)), act_space) for _ in range(sh.A)]
     if fp:
         cbuf = OnPolicyCriticBufferFP({**cfg["train"], **cfg["model"], **cfg["algo"]}, Box((sh.share_obs_dim,)), sh.A)
@@ -155,6 +169,10 @@ def run_case(name: str, spec: dict) -> dict:
         abuf[a].active_masks[:] = data.active_masks[a]
         if sh.discrete:
             abuf[a].available_actions[:] = data.available_actions[a]
+        if rec:
+            abuf[a].rnn_states[:] = data.rnn["actor"][a]
+    if rec:
+        cbuf.rnn_states_critic[:] = data.rnn["critic"]
     if fp:
         for k in ("share_obs", "rewards", "value_preds", "masks", "bad_masks"):
             getattr(cbuf, k)[:] = data.fp[k]
@@ -174,6 +192,9 @@ def run_case(name: str, spec: dict) -> dict:
             with torch.no_grad():
                 obs_flat = torch.from_numpy(abuf[a].obs[:-1].reshape(sh.T * sh.N, -1))
                 feat = actors[a].actor.base(obs_flat)
+                if rec:
+                    feat, _ = actors[a].actor.rnn(feat, torch.from_numpy(abuf[a].rnn_states[0]),
+                                                  torch.from_numpy(abuf[a].masks[:-1].reshape(sh.T * sh.N, 1)))
                 if sh.discrete:
                     av = torch.from_numpy(abuf[a].available_actions[:-1].reshape(sh.T * sh.N, -1).copy())
                     dist = actors[a].actor.act.action_out(feat, av)

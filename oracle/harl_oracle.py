@@ -78,6 +78,14 @@ class PathConfig:
     fixed_order: bool = False
     use_proper_time_limits: bool = True
     use_valuenorm: bool = True
+    use_recurrent_policy: bool = False
+    use_naive_recurrent_policy: bool = False
+    data_chunk_length: int = 10
+    recurrent_n: int = 1
+
+    @property
+    def recurrent(self) -> bool:
+        return self.use_recurrent_policy or self.use_naive_recurrent_policy
 
     @staticmethod
     def from_reference_dicts(train: dict, model: dict, algo: dict) -> "PathConfig":
@@ -228,6 +236,33 @@ def mlp_base_forward(p: Dict[str, torch.Tensor], x: torch.Tensor) -> torch.Tenso
     return x
 
 
+def rnn_layer_forward(p: Dict[str, torch.Tensor], x: torch.Tensor, hxs: torch.Tensor, masks: torch.Tensor):
+    """RNNLayer.forward (models/base/rnn.py:23-81) for recurrent_n = 1: GRU (gate order r, z, n) with the hidden state
+    multiplied by the mask at every step (the reference multiplies at segment starts; elsewhere the mask is 1), then
+    LayerNorm.  x: [N, H] (one step) or [T*N, H] (t-major sequence); hxs: [N, 1, H]; masks: [N|T*N, 1]."""
+    Wih, Whh = p["rnn.rnn.weight_ih_l0"], p["rnn.rnn.weight_hh_l0"]
+    bih, bhh = p["rnn.rnn.bias_ih_l0"], p["rnn.rnn.bias_hh_l0"]
+    N = hxs.shape[0]
+    T = x.shape[0] // N
+    H = Whh.shape[1]
+    xs = x.view(T, N, -1)
+    ms = masks.view(T, N, 1)
+    h = hxs[:, 0, :]
+    outs = []
+    for t in range(T):
+        h = h * ms[t]
+        gi = F.linear(xs[t], Wih, bih)
+        gh = F.linear(h, Whh, bhh)
+        r = torch.sigmoid(gi[:, :H] + gh[:, :H])
+        z = torch.sigmoid(gi[:, H:2 * H] + gh[:, H:2 * H])
+        n = torch.tanh(gi[:, 2 * H:] + r * gh[:, 2 * H:])
+        h = (1 - z) * n + z * h
+        outs.append(h)
+    y = torch.stack(outs, 0).reshape(T * N, H)
+    y = F.layer_norm(y, (H,), p["rnn.norm.weight"], p["rnn.norm.bias"], 1e-5)
+    return y, h.unsqueeze(1)
+
+
 def actor_evaluate_actions(
     p: Dict[str, torch.Tensor],
     cfg: PathConfig,
@@ -235,12 +270,16 @@ def actor_evaluate_actions(
     action: torch.Tensor,
     available_actions: Optional[torch.Tensor],
     active_masks: Optional[torch.Tensor],
+    rnn_states: Optional[torch.Tensor] = None,
+    masks: Optional[torch.Tensor] = None,
 ):
     """StochasticPolicy.evaluate_actions for MLP policies (stochastic_policy.py:88-127, act.py:104-157).
 
     Returns (action_log_probs [B, D_a | 1], dist_entropy scalar, dist-params dict).
     """
     feat = mlp_base_forward(p, obs)
+    if "rnn.rnn.weight_ih_l0" in p:
+        feat, _ = rnn_layer_forward(p, feat, rnn_states, masks)
     am = active_masks if cfg.use_policy_active_masks else None
     if "act.action_out.log_std" in p:  # Box -> DiagGaussian (distributions.py:58-89)
         mean = F.linear(feat, p["act.action_out.fc_mean.weight"], p["act.action_out.fc_mean.bias"])
@@ -266,9 +305,11 @@ def actor_evaluate_actions(
     return logp, dist_entropy, dist
 
 
-def critic_forward(p: Dict[str, torch.Tensor], share_obs: torch.Tensor) -> torch.Tensor:
-    """VNet.forward for MLP critics (v_net.py:48-67)."""
+def critic_forward(p: Dict[str, torch.Tensor], share_obs: torch.Tensor, rnn_states=None, masks=None) -> torch.Tensor:
+    """VNet.forward (v_net.py:48-67)."""
     feat = mlp_base_forward(p, share_obs)
+    if "rnn.rnn.weight_ih_l0" in p:
+        feat, _ = rnn_layer_forward(p, feat, rnn_states, masks)
     return F.linear(feat, p["v_out.weight"], p["v_out.bias"])
 
 
@@ -314,17 +355,19 @@ class OracleHAPPO:
         self.net = _Net(state_dict, cfg.lr, cfg.opti_eps, cfg.weight_decay)
         self.trace: List[dict] = []  # one entry per update(): loss, entropy, grad norm, ratio mean, flat grad (pre-clip)
 
-    def evaluate_actions(self, obs, action, available_actions=None, active_masks=None):
+    def evaluate_actions(self, obs, action, available_actions=None, active_masks=None, rnn_states=None, masks=None):
         return actor_evaluate_actions(
             self.net.p, self.cfg, _t(obs), _t(action),
             None if available_actions is None else _t(available_actions),
             None if active_masks is None else _t(active_masks),
+            None if rnn_states is None else _t(rnn_states), None if masks is None else _t(masks),
         )
 
     def update(self, sample, keep_grad: bool = False):  # happo.py:28-102
         cfg = self.cfg
-        obs, actions, active, old_logp, adv, avail, factor = (None if s is None else _t(s) for s in sample)
-        logp, ent, _ = actor_evaluate_actions(self.net.p, cfg, obs, actions, avail, active)
+        obs, actions, active, old_logp, adv, avail, factor = (None if s is None else _t(s) for s in sample[:7])
+        rnn, msk = (_t(sample[7]), _t(sample[8])) if len(sample) > 7 else (None, None)
+        logp, ent, _ = actor_evaluate_actions(self.net.p, cfg, obs, actions, avail, active, rnn, msk)
         agg = getattr(torch, cfg.action_aggregation)
         imp = agg(torch.exp(logp - old_logp), dim=-1, keepdim=True)
         surr1 = imp * adv
@@ -352,7 +395,13 @@ class OracleHAPPO:
         if state_type == "EP":
             advantages = normalize_advantages(advantages, buf.active_masks[:-1])
         for _ in range(cfg.ppo_epoch):
-            for sample, idx in buf.feed_forward_generator(advantages, cfg.actor_num_mini_batch):
+            if cfg.use_recurrent_policy:
+                gen = buf.recurrent_generator(advantages, cfg.actor_num_mini_batch, cfg.data_chunk_length)
+            elif cfg.use_naive_recurrent_policy:
+                gen = buf.naive_recurrent_generator(advantages, cfg.actor_num_mini_batch)
+            else:
+                gen = buf.feed_forward_generator(advantages, cfg.actor_num_mini_batch)
+            for sample, idx in gen:
                 pl, ent, gn, imp, g = self.update(sample, keep_grad)
                 info["policy_loss"] += pl.item()
                 info["dist_entropy"] += ent.item()
@@ -387,8 +436,9 @@ class OracleVCritic:
         self.net = _Net(state_dict, lr_cfg, cfg.opti_eps, cfg.weight_decay)
         self.trace: List[dict] = []
 
-    def get_values(self, share_obs) -> torch.Tensor:
-        return critic_forward(self.net.p, _t(share_obs))
+    def get_values(self, share_obs, rnn_states=None, masks=None) -> torch.Tensor:
+        return critic_forward(self.net.p, _t(share_obs), None if rnn_states is None else _t(rnn_states),
+                              None if masks is None else _t(masks))
 
     def value_loss(self, values, value_preds, returns, vn: Optional[OracleValueNorm]):  # v_critic.py:75-114
         cfg = self.cfg
@@ -408,8 +458,9 @@ class OracleVCritic:
         return loss.mean()
 
     def update(self, sample, vn, keep_grad: bool = False):  # v_critic.py:116-157
-        share_obs, value_preds, returns = (_t(s) for s in sample)
-        values = critic_forward(self.net.p, share_obs)
+        share_obs, value_preds, returns = (_t(s) for s in sample[:3])
+        rnn, msk = (_t(sample[3]), _t(sample[4])) if len(sample) > 3 else (None, None)
+        values = critic_forward(self.net.p, share_obs, rnn, msk)
         loss = self.value_loss(values, value_preds, returns, vn)
         self.net.opt.zero_grad()
         (loss * self.cfg.value_loss_coef).backward()
@@ -421,7 +472,13 @@ class OracleVCritic:
         cfg = self.cfg
         info = {"value_loss": 0.0, "critic_grad_norm": 0.0}
         for _ in range(cfg.critic_epoch):
-            for sample, idx in buf.feed_forward_generator(cfg.critic_num_mini_batch):
+            if cfg.use_recurrent_policy:
+                gen = buf.recurrent_generator(cfg.critic_num_mini_batch, cfg.data_chunk_length)
+            elif cfg.use_naive_recurrent_policy:
+                gen = buf.naive_recurrent_generator(cfg.critic_num_mini_batch)
+            else:
+                gen = buf.feed_forward_generator(cfg.critic_num_mini_batch)
+            for sample, idx in gen:
                 loss, gn, g = self.update(sample, vn, keep_grad)
                 info["value_loss"] += loss.item()
                 info["critic_grad_norm"] += float(gn)
@@ -433,6 +490,16 @@ class OracleVCritic:
 # --------------------------------------------------------------------------------------
 # buffers (host NumPy, reference shapes; only what train() reads)
 # --------------------------------------------------------------------------------------
+def chunk_rows(chunk_ids: np.ndarray, T: int, N: int, L: int) -> Tuple[np.ndarray, np.ndarray]:
+    """Chunked recurrent sampling (on_policy_actor_buffer.py:255-322): arrays are cast thread-major [N*T] and chunk c is
+    rows [c*L, (c+1)*L) there, i.e. thread n = (c*L)//T, start time t0 = (c*L)%T.  Returns (rows [L*m] into the
+    t-major flattening row = t*N + n, ordered l-major like the reference's stack+flatten; first_rows [m] = rows of l=0)."""
+    start = chunk_ids * L
+    n, t0 = start // T, start % T
+    rows = ((t0[None, :] + np.arange(L)[:, None]) * N + n[None, :]).reshape(-1)
+    return rows, t0 * N + n
+
+
 def minibatch_indices(batch_size: int, num_mini_batch: int) -> List[np.ndarray]:
     """on_policy_actor_buffer.py:121-135: one torch.randperm draw on the global CPU generator,
     remainder rows dropped."""
@@ -451,9 +518,36 @@ class OracleActorBuffer:
     active_masks: np.ndarray      # [T+1, N, 1]
     available_actions: Optional[np.ndarray] = None  # [T+1, N, n_act] (Discrete only)
     factor: Optional[np.ndarray] = None             # [T, N, 1]
+    rnn_states: Optional[np.ndarray] = None         # [T+1, N, recurrent_n, H]
 
     def update_factor(self, factor):
         self.factor = factor.copy()
+
+    def _gather(self, rows, first_rows, advantages):
+        T, N = self.actions.shape[:2]
+        f = lambda a: a.reshape(T * N, -1)[rows]  # noqa: E731
+        rnn = self.rnn_states[:-1].reshape(T * N, *self.rnn_states.shape[2:])[first_rows]
+        return (f(self.obs[:-1]), f(self.actions), f(self.active_masks[:-1]), f(self.action_log_probs), f(advantages),
+                None if self.available_actions is None else f(self.available_actions[:-1]), f(self.factor), rnn,
+                f(self.masks[:-1]))
+
+    def recurrent_generator(self, advantages: np.ndarray, num_mini_batch: int, L: int):
+        """on_policy_actor_buffer.py:223-326."""
+        T, N = self.actions.shape[:2]
+        assert T % L == 0 and (T * N) // L >= 2
+        for chunks in minibatch_indices((T * N) // L, num_mini_batch):
+            rows, first = chunk_rows(chunks, T, N, L)
+            yield self._gather(rows, first, advantages), chunks
+
+    def naive_recurrent_generator(self, advantages: np.ndarray, num_mini_batch: int):
+        """on_policy_actor_buffer.py:180-221: whole columns, full-length sequences, rnn_states[0]."""
+        T, N = self.actions.shape[:2]
+        per = N // num_mini_batch
+        perm = torch.randperm(N).numpy()
+        for b in range(num_mini_batch):
+            ids = perm[b * per:(b + 1) * per]
+            rows = (np.arange(T)[:, None] * N + ids[None, :]).reshape(-1)
+            yield self._gather(rows, ids, advantages), ids
 
     def feed_forward_generator(self, advantages: np.ndarray, num_mini_batch: int):
         T, N = self.actions.shape[:2]
@@ -480,6 +574,30 @@ class OracleCriticBufferEP:
     masks: np.ndarray        # [T+1, N, 1]
     bad_masks: np.ndarray    # [T+1, N, 1]
     returns: np.ndarray = field(default=None)
+    rnn_states_critic: Optional[np.ndarray] = None  # [T+1, N, recurrent_n, H]
+
+    def _gather(self, rows, first_rows):
+        B = int(np.prod(self.rewards.shape[:-1]))
+        f = lambda a: a.reshape(B, -1)[rows]  # noqa: E731
+        rnn = self.rnn_states_critic[:-1].reshape(B, *self.rnn_states_critic.shape[-2:])[first_rows]
+        return f(self.share_obs[:-1]), f(self.value_preds[:-1]), f(self.returns[:-1]), rnn, f(self.masks[:-1])
+
+    def recurrent_generator(self, num_mini_batch: int, L: int):
+        """on_policy_critic_buffer_ep.py:285-369 (EP)."""
+        T, N = self.rewards.shape[:2]
+        for chunks in minibatch_indices((T * N) // L, num_mini_batch):
+            rows, first = chunk_rows(chunks, T, N, L)
+            yield self._gather(rows, first), chunks
+
+    def naive_recurrent_generator(self, num_mini_batch: int):
+        """on_policy_critic_buffer_ep.py:252-283."""
+        T, N = self.rewards.shape[:2]
+        per = N // num_mini_batch
+        perm = torch.randperm(N).numpy()
+        for b in range(num_mini_batch):
+            ids = perm[b * per:(b + 1) * per]
+            rows = (np.arange(T)[:, None] * N + ids[None, :]).reshape(-1)
+            yield self._gather(rows, ids), ids
 
     fp = False  # OracleCriticBufferFP: arrays carry an agent axis [T(+1), N, A, .] (on_policy_critic_buffer_fp.py)
 
@@ -535,6 +653,8 @@ def ha_train(
         flat = lambda v: v.reshape(T * N, -1)  # noqa: E731
         avail = None if buf.available_actions is None else flat(buf.available_actions[:-1])
         args = (flat(buf.obs[:-1]), flat(buf.actions), avail, flat(buf.active_masks[:-1]))
+        if cfg.recurrent:  # rnn_states[0:1] -> full-length unroll with mask resets (on_policy_ha_runner.py:70-72)
+            args = args + (buf.rnn_states[0], flat(buf.masks[:-1]))
         old_logp, _, _ = actors[a].evaluate_actions(*args)
         if fp:
             infos.append(actors[a].train(buf, advantages[:, :, a].copy(), keep_grad, state_type="FP"))

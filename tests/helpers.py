@@ -16,6 +16,7 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 ALL_CASES = ["mpe_box_h64", "mpe_box_h128", "mpe_disc_h64", "cheetah_h128x3_mb2", "box_mean_inactive_novn",
              "wide_obs_h64", "a2c_box_h64", "fp_box_h64", "fp_disc_h128_mb2"]
 TRPO_CASES = ["trpo_box_h64", "trpo_disc_h64", "trpo_wide_h128x3"]
+RNN_CASES = ["rnn_box_h64", "rnn_disc_h64_mb2", "rnn_naive_h64"]
 
 
 class GoldenCase:
@@ -28,17 +29,23 @@ class GoldenCase:
         self.seed = spec["seed"]
         self.algo, self.model, self.train = self.meta["algo"], self.meta["model"], self.meta["train"]
         self.algo_name = self.meta.get("algo_name", "happo")
+        self.model.setdefault("use_recurrent_policy", False)
+        self.model.setdefault("use_naive_recurrent_policy", False)
         self.state_type = spec.get("state_type", "EP")
+        self.recurrent = bool(self.model["use_recurrent_policy"] or self.model["use_naive_recurrent_policy"])
         self.data: SyntheticBuffers = make_buffers(self.shapes, self.seed, spec.get("inactive_p", 0.0),
-                                                   spec.get("unavailable_p", 0.0), fp=self.state_type == "FP")
+                                                   spec.get("unavailable_p", 0.0), fp=self.state_type == "FP",
+                                                   rnn=self.recurrent)
         for a in range(self.shapes.A):
             if f"in_actions_{a}" in self.z:
                 self.data.actions[a] = self.z[f"in_actions_{a}"].copy()
                 self.data.action_log_probs[a] = self.z[f"in_logp_{a}"].copy()
         use_fn = self.model["use_feature_normalization"]
-        self.actor_sd = [synthetic_state_dict(actor_param_shapes(self.shapes, use_fn), 1000 * self.seed + a,
-                                              self.model["std_x_coef"]) for a in range(self.shapes.A)]
-        self.critic_sd = synthetic_state_dict(critic_param_shapes(self.shapes, use_fn), 1000 * self.seed + 999)
+        self.actor_sd = [synthetic_state_dict(actor_param_shapes(self.shapes, use_fn, self.recurrent),
+                                              1000 * self.seed + a, self.model["std_x_coef"])
+                         for a in range(self.shapes.A)]
+        self.critic_sd = synthetic_state_dict(critic_param_shapes(self.shapes, use_fn, self.recurrent),
+                                              1000 * self.seed + 999)
         self.use_valuenorm = self.train["use_valuenorm"]
         # ValueNorm start state used by gen_golden.py
         self.vn_init = dict(running_mean=0.3 * 0.5, running_mean_sq=1.7 * 0.5, debiasing_term=0.5)

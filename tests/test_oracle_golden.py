@@ -10,7 +10,7 @@ import pytest
 import torch
 
 from oracle import harl_oracle as O
-from tests.helpers import ALL_CASES, GOLDEN_DIR, TRPO_CASES, GoldenCase, rel_err, vec_rel_err
+from tests.helpers import ALL_CASES, GOLDEN_DIR, RNN_CASES, TRPO_CASES, GoldenCase, rel_err, vec_rel_err
 
 
 def build_oracle(case: GoldenCase):
@@ -28,7 +28,8 @@ def build_oracle(case: GoldenCase):
     critic = O.OracleVCritic({k: torch.from_numpy(v) for k, v in case.critic_sd.items()}, cfg)
     abufs = [O.OracleActorBuffer(d.obs[a].copy(), d.actions[a].copy(), d.action_log_probs[a].copy(), d.masks[a].copy(),
                                  d.active_masks[a].copy(),
-                                 None if d.available_actions[a] is None else d.available_actions[a].copy())
+                                 None if d.available_actions[a] is None else d.available_actions[a].copy(),
+                                 rnn_states=None if d.rnn is None else d.rnn["actor"][a].copy())
              for a in range(sh.A)]
     if case.state_type == "FP":
         f = d.fp
@@ -37,6 +38,8 @@ def build_oracle(case: GoldenCase):
     else:
         cbuf = O.OracleCriticBufferEP(d.share_obs.copy(), d.rewards.copy(), d.value_preds.copy(), d.critic_masks.copy(),
                                       d.bad_masks.copy())
+    if d.rnn is not None:
+        cbuf.rnn_states_critic = d.rnn["critic"].copy()
     vn = None
     if case.use_valuenorm:
         vn = O.OracleValueNorm()
@@ -44,7 +47,7 @@ def build_oracle(case: GoldenCase):
     return cfg, actors, critic, abufs, cbuf, vn
 
 
-@pytest.mark.parametrize("name", ALL_CASES + TRPO_CASES)
+@pytest.mark.parametrize("name", ALL_CASES + TRPO_CASES + RNN_CASES)
 def test_oracle_matches_reference_golden(name):
     case = GoldenCase(name)
     z = case.z
@@ -52,6 +55,9 @@ def test_oracle_matches_reference_golden(name):
     torch.manual_seed(case.seed)
     np.random.seed(case.seed)
     cfg, actors, critic, abufs, cbuf, vn = build_oracle(case)
+    # recurrent cases: the reference runs ATen's fused GRU cell, the oracle the explicit gate formulas -> ~1e-6 apart
+    # per step, amplified over the update; every other case is the same ATen kernels -> essentially bit-identical
+    TOLF = 2e-5 if case.recurrent else 1e-6
     torch.manual_seed(case.seed + 12345)  # gen_golden.py re-seeds right before compute_returns/train
 
     perms = []
@@ -88,16 +94,16 @@ def test_oracle_matches_reference_golden(name):
         tr = np.array([[t["policy_loss"], t["dist_entropy"], t["grad_norm"], t["ratio"]]
                        for a in extra["agent_order"] for t in actors[a].trace])
         got_infos = np.array([[i["policy_loss"], i["dist_entropy"], i["actor_grad_norm"], i["ratio"]] for i in infos])
-    assert rel_err(tr, z["actor_trace"][:, 1:]) < 1e-6
+    assert rel_err(tr, z["actor_trace"][:, 1:]) < TOLF
     ctr = np.array([[t["value_loss"], t["grad_norm"]] for t in critic.trace])
-    assert rel_err(ctr, z["critic_trace"]) < 1e-6
-    assert rel_err(got_infos, z["actor_infos"]) < 1e-6
-    assert rel_err([cinfo["value_loss"], cinfo["critic_grad_norm"]], z["critic_info"]) < 1e-6
-    assert vec_rel_err(np.stack([np.ones_like(extra["factors"][0])] + extra["factors"][:-1]), z["factors"]) < 1e-6
+    assert rel_err(ctr, z["critic_trace"]) < TOLF
+    assert rel_err(got_infos, z["actor_infos"]) < TOLF
+    assert rel_err([cinfo["value_loss"], cinfo["critic_grad_norm"]], z["critic_info"]) < TOLF
+    assert vec_rel_err(np.stack([np.ones_like(extra["factors"][0])] + extra["factors"][:-1]), z["factors"]) < TOLF
     for a in range(case.shapes.A):
         flat = actors[a].flat().numpy() if case.algo_name == "hatrpo" else actors[a].net.flat()
-        assert vec_rel_err(flat, z[f"actor_final_{a}"]) < 1e-6
-    assert vec_rel_err(critic.net.flat(), z["critic_final"]) < 1e-6
+        assert vec_rel_err(flat, z[f"actor_final_{a}"]) < TOLF
+    assert vec_rel_err(critic.net.flat(), z["critic_final"]) < TOLF
     if vn is not None:
         s = vn.state()
         got = [s["running_mean"].item(), s["running_mean_sq"].item(), s["debiasing_term"].item()]

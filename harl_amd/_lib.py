@@ -31,7 +31,7 @@ SIGNATURES = {
     "harl_valuenorm_apply": [_vp, _vp, _d, _d, _vp],
     "harl_gradnorm_clip_adam": [_vp, _vp, _vp, _vp, _l, _vp, _i, _f, _f, _f, _f, _f, _f, _d, _d, _vp, _vp],
     "harl_fold_linear": [_vp] * 6 + [_i, _i, _vp],
-    "harl_unfold_linear_grads": [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
+    "harl_unfold_linear_grads": [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "harl_mlp_fwd_input": [_vp, _l, _vp, _l, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "harl_mlp_fwd_fused2": [_vp, _l, _vp, _l, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                             _vp],
@@ -42,12 +42,14 @@ SIGNATURES = {
     "harl_reduce_partials_multi": [_vp, _vp, _i, _i, _l, _vp, _vp],
     "harl_adam_fold": [_vp, _vp, _vp, _vp, _l, _vp, _vp, _i, _vp, _vp, _i, _f, _i, _i, _vp, _i, _f, _f, _f, _f, _f, _f,
                        _d, _d, _vp],
-    "harl_actor_head_logp": [_vp, _l, _i, _vp, _vp, _vp, _f, _f, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp],
+    "harl_actor_head_logp": [_vp, _l, _i, _vp, _vp, _vp, _f, _f, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _l, _l, _vp],
     "harl_actor_head_loss": [_vp, _vp, _vp, _l, _i, _vp, _vp, _vp, _f, _f, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,
-                             _vp, _vp, _f, _f, _i, _i, _vp, _vp, _vp, _vp],
+                             _vp, _vp, _f, _f, _i, _i, _l, _l, _vp, _vp, _vp, _vp],
     "harl_critic_head_values": [_vp, _l, _i, _vp, _vp, _vp, _vp],
-    "harl_critic_head_loss": [_vp, _vp, _vp, _l, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _f, _vp, _vp, _vp,
+    "harl_critic_head_loss": [_vp, _vp, _vp, _l, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _f, _l, _l, _vp, _vp, _vp,
                               _vp],
+    "harl_gru_fwd": [_vp] * 7 + [_i, _i, _l] + [_vp] * 8 + [_i, _vp],
+    "harl_gru_bwd": [_vp] * 9 + [_i, _i, _l] + [_vp] * 8 + [_vp],
     "harl_fold_linear_tangent": [_vp] * 9 + [_i, _i, _vp],
     "harl_mlp_tangent_input": [_vp, _l, _vp, _l, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "harl_mlp_tangent_hidden": [_vp, _vp, _l, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],

@@ -85,6 +85,25 @@ def minibatch_indices(batch_size: int, num_mini_batch: int) -> List[torch.Tensor
     return [rand[i * m:(i + 1) * m] for i in range(num_mini_batch)]
 
 
+def recurrent_first_rows(T: int, N: int, num_mini_batch: int, data_chunk_length: int, naive: bool):
+    """Sequence starts of the reference's recurrent samplers, as rows of the t-major flattening (row = t*N + n).
+    chunked (on_policy_actor_buffer.py:223-326): arrays are cast thread-major [N*T] and chunk c is rows [c*L, (c+1)*L)
+    there -> thread n = (c*L)//T, start time t0 = (c*L)%T; one randperm(T*N//L) on the global CPU generator.
+    naive (:180-221): whole columns, L = T, one randperm(N).  Yields (first_rows CPU int64 [m], L)."""
+    if naive:
+        assert N >= num_mini_batch, f"n_rollout_threads ({N}) must be >= num_mini_batch ({num_mini_batch})"
+        per = N // num_mini_batch
+        perm = torch.randperm(N)
+        for b in range(num_mini_batch):
+            yield perm[b * per:(b + 1) * per], T
+        return
+    L = data_chunk_length
+    assert T % L == 0, "episode_length must be a multiple of data_chunk_length"
+    for chunks in minibatch_indices((T * N) // L, num_mini_batch):
+        start = chunks * L
+        yield (start % T) * N + start // T, L
+
+
 class OnPolicyActorBuffer:
     def __init__(self, args: dict, obs_space, act_space, device=torch.device("cuda:0")):
         self.device = torch.device(device)
@@ -142,6 +161,18 @@ class OnPolicyActorBuffer:
         if name in ("obs", "masks", "active_masks", "available_actions", "rnn_states"):
             t = t[:-1]
         return t.reshape(self.episode_length * self.n_rollout_threads, -1)
+
+    def recurrent_batches(self, num_mini_batch: int, data_chunk_length: int, naive: bool = False, shard=None):
+        """GRU-layout minibatches (nets.build_seq) for the chunked / naive recurrent samplers: only the m sequence
+        starts travel to the device; the kernels gather rows first + l*N in place."""
+        from .nets import build_seq
+        if shard:
+            raise NotImplementedError("recurrent samplers with sharded n_rollout_threads")
+        T, N = self.actions.shape[:2]
+        H = self.rnn_hidden_size
+        for first, L in recurrent_first_rows(T, N, num_mini_batch, data_chunk_length, naive):
+            yield build_seq(self.device, L, first.numel(), H, first_rows=first, stride=N,
+                            h0_src=self.rnn_states.reshape((T + 1) * N, -1), masks_src=self.masks.reshape(-1))
 
     def feed_forward_generator_actor(self, advantages, actor_num_mini_batch=None, mini_batch_size=None):
         """API-compatible generator (actor_buffer.py:114-178): yields gathered device tensors in the reference's
@@ -228,6 +259,17 @@ class OnPolicyCriticBufferEP:
         if name in ("share_obs", "masks", "bad_masks", "value_preds", "returns", "rnn_states_critic"):
             t = t[:-1]
         return t.reshape(self.episode_length * self.n_rollout_threads, -1)
+
+    def recurrent_batches(self, num_mini_batch: int, data_chunk_length: int, naive: bool = False, shard=None):
+        """See OnPolicyActorBuffer.recurrent_batches (critic_buffer_ep.py:252-369)."""
+        from .nets import build_seq
+        if shard or getattr(self, "num_agents", None):
+            raise NotImplementedError("recurrent samplers: EP state type, unsharded")
+        T, N = self.rewards.shape[:2]
+        H = self.rnn_hidden_size
+        for first, L in recurrent_first_rows(T, N, num_mini_batch, data_chunk_length, naive):
+            yield build_seq(self.device, L, first.numel(), H, first_rows=first, stride=N,
+                            h0_src=self.rnn_states_critic.reshape((T + 1) * N, -1), masks_src=self.masks.reshape(-1))
 
     def feed_forward_generator_critic(self, critic_num_mini_batch=None, mini_batch_size=None):
         """API-compatible generator (critic_buffer_ep.py:202-250); ``VCritic.train`` uses index arrays instead."""

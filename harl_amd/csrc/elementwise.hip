@@ -380,7 +380,7 @@ __global__ __launch_bounds__(64) void k_unfold(const float *__restrict__ dWp, co
                                                const float *__restrict__ W, const float *__restrict__ gamma,
                                                const float *__restrict__ beta, float *__restrict__ dW,
                                                float *__restrict__ db, float *__restrict__ dgamma,
-                                               float *__restrict__ dbeta, int out_dim, int in_dim) {
+                                               float *__restrict__ dbeta, int out_dim, int in_dim, int accumulate) {
   int k = blockIdx.x;
   float g = gamma ? gamma[k] : 1.f;
   float be = beta ? beta[k] : 0.f;
@@ -397,18 +397,18 @@ __global__ __launch_bounds__(64) void k_unfold(const float *__restrict__ dWp, co
   if (dgamma) {
     sg = wave_reduce_sum(sg);
     sb = wave_reduce_sum(sb);
-    if (threadIdx.x == 0) {
-      dgamma[k] = sg;
-      dbeta[k] = sb;
+    if (threadIdx.x == 0) {  // several Linears may share one LayerNorm (the three GRU gate blocks): accumulate
+      dgamma[k] = accumulate ? dgamma[k] + sg : sg;
+      dbeta[k] = accumulate ? dbeta[k] + sb : sb;
     }
   }
 }
 
 extern "C" int harl_unfold_linear_grads(const float *dWp, const float *dbp, int ldp, const float *W,
                                         const float *gamma, const float *beta, float *dW, float *db, float *dgamma,
-                                        float *dbeta, int out_dim, int in_dim, void *stream) {
+                                        float *dbeta, int out_dim, int in_dim, int accumulate, void *stream) {
   hipLaunchKernelGGL(k_unfold, dim3(in_dim), dim3(64), 0, (hipStream_t)stream, dWp, dbp, ldp, W, gamma, beta, dW, db,
-                     dgamma, dbeta, out_dim, in_dim);
+                     dgamma, dbeta, out_dim, in_dim, accumulate);
   return check_launch("harl_unfold_linear_grads");
 }
 
@@ -538,7 +538,17 @@ __global__ __launch_bounds__(1024) void k_adam_fold(float *__restrict__ p, float
     s_scale = scale;
   }
   if (logstd_off >= 0 && tid < act_dim) g[logstd_off + tid] = (float)scalars[8 + tid];
-  // ---- phase 1: unfold  dW = dWp*gamma + dbp (x) beta ; db = dbp ; dgamma = sum_o W.dWp ; dbeta = sum_o W.dbp
+  // ---- phase 1: unfold  dW = dWp*gamma + dbp (x) beta ; db = dbp ; dgamma += sum_o W.dWp ; dbeta += sum_o W.dbp
+  // (several Linears may share one LayerNorm -- the three GRU gate blocks -- so gamma/beta gradients accumulate)
+  for (int l = 0; l < n_layers; ++l) {
+    const int *t = tab + l * TS;
+    if (t[2] >= 0)
+      for (int k = tid; k < t[5]; k += nt) {
+        g[t[2] + k] = 0.f;
+        g[t[3] + k] = 0.f;
+      }
+  }
+  __syncthreads();
   for (int l = 0; l < n_layers; ++l) {
     const int *t = tab + l * TS;
     const int O = t[4], K = t[5], kp = t[9], op = t[10];
@@ -564,10 +574,11 @@ __global__ __launch_bounds__(1024) void k_adam_fold(float *__restrict__ p, float
         sg = wave_reduce_sum(sg);
         sb = wave_reduce_sum(sb);
         if (ln == 0) {
-          g[t[2] + k] = sg;
-          g[t[3] + k] = sb;
+          g[t[2] + k] += sg;
+          g[t[3] + k] += sb;
         }
       }
+      __syncthreads();  // the next table entry may accumulate into the same gamma/beta slots from other waves
     }
   }
   __syncthreads();

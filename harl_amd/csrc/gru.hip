@@ -1,0 +1,300 @@
+// gru.hip -- GRU recurrent layer (harl/models/base/rnn.py:8-81, recurrent_n = 1) forward and BPTT on fp32 MFMA, gfx950.
+//
+// A recurrent batch is L time steps x m sequences, row (l, j) at index l*m_pad + j (m_pad = m rounded up to 32, so a
+// wave-slab never straddles two time steps).  A wave owns 32 sequences for the whole chunk: the hidden state lives in
+// its registers in the accumulator layout (common.h), which is also a valid MFMA B operand, so h_{l-1} feeds the
+// W_hh GEMM of step l straight from the register file -- no LDS staging, no transposes along the recurrence.
+//   per step:  h~ = h_{l-1} * mask_l
+//              r = sigma(W_ir x + b_ir + W_hr h~ + b_hr)     z = sigma(W_iz x + b_iz + W_hz h~ + b_hz)
+//              n = tanh(W_in x + b_in + r * (W_hn h~ + b_hn))   h_l = (1 - z) * n + z * h~        (torch.nn.GRU, gates r,z,n)
+//              y_l = (h_l - mean) * rstd        (rnn.norm; its affine part is folded into the head weights)
+// Both weight matrices stay in LDS ([3H][H+1] each, 100 KiB for H = 64 -> one workgroup per CU).
+// H = 64 only (every recurrent tuned HARL config: SMAC / SMACv2 / football use hidden 64).
+#include "common.h"
+#include "../../include/harl_hip.h"
+
+using namespace harl;
+
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+namespace {
+constexpr int GH = 64;         // hidden width
+constexpr int GR = GH / 2;     // registers per lane per width-64 activation
+constexpr int GT = GH / 32;    // 32-row tiles per gate
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__device__ __forceinline__ void load_act(const float *__restrict__ base, long slab, int lane, float (&x)[GR]) {
+  atl_load<GH>(base, slab, lane, x);
+}
+__device__ __forceinline__ void store_act(float *__restrict__ base, long slab, int lane, const float (&x)[GR]) {
+  atl_store<GH>(base, slab, lane, x);
+}
+// row-major [rows][64] <-> accumulator layout for the 32 sequences of a wave (initial / final hidden state)
+__device__ __forceinline__ void load_rows(const float *__restrict__ base, long row, int h, float (&x)[GR]) {
+#pragma unroll
+  for (int q = 0; q < GR / 4; ++q) {
+    const f32x4 v = *reinterpret_cast<const f32x4 *>(base + row * GH + 32 * (q >> 2) + 8 * (q & 3) + 4 * h);
+    x[4 * q + 0] = v[0];
+    x[4 * q + 1] = v[1];
+    x[4 * q + 2] = v[2];
+    x[4 * q + 3] = v[3];
+  }
+}
+__device__ __forceinline__ void store_rows(float *__restrict__ base, long row, int h, const float (&x)[GR]) {
+#pragma unroll
+  for (int q = 0; q < GR / 4; ++q) {
+    f32x4 v{x[4 * q + 0], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]};
+    *reinterpret_cast<f32x4 *>(base + row * GH + 32 * (q >> 2) + 8 * (q & 3) + 4 * h) = v;
+  }
+}
+
+// acc[g][t] += W[(g*64 + 32t + i)][f(R,h)] * b[R]   over R = 0..31, for the gates listed in GATES (bit mask)
+template <int GATES>
+__device__ __forceinline__ void gemm_gates(f32x16 (&acc)[3][GT], const float *wl_lane, const float (&b)[GR]) {
+  constexpr int LDW = GH + 1;
+#pragma unroll
+  for (int R = 0; R < GR; ++R) {
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+      if (!((GATES >> g) & 1)) continue;
+#pragma unroll
+      for (int t = 0; t < GT; ++t) {
+        const float a = wl_lane[(g * GH + 32 * t) * LDW + feat_base(R)];
+        acc[g][t] = MFMA(a, b[R], acc[g][t]);
+      }
+    }
+    if ((R & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // keep the LDS reads from being hoisted en bloc
+  }
+}
+
+// =============================================================================================
+// forward
+// =============================================================================================
+__global__ __launch_bounds__(WG_THREADS, 1) void k_gru_fwd(
+    const float *__restrict__ xin, const float *__restrict__ mrow, const float *__restrict__ h0,
+    const float *__restrict__ Wih, const float *__restrict__ bih, const float *__restrict__ Whh,
+    const float *__restrict__ bhh, int L, long m_pad, float *__restrict__ y, float *__restrict__ rstd_y,
+    float *__restrict__ hpm_s, float *__restrict__ r_s, float *__restrict__ z_s, float *__restrict__ n_s,
+    float *__restrict__ hn_s, float *__restrict__ h_last, int save) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int LDW = GH + 1;
+  float *Wil = lds;                     // [192][65]
+  float *Whl = Wil + 3 * GH * LDW;      // [192][65]
+  float *bil = Whl + 3 * GH * LDW;      // [192]
+  float *bhl = bil + 3 * GH;            // [192]
+  for (int e = threadIdx.x; e < 3 * GH * GH; e += WG_THREADS) {
+    const int o = e / GH, k = e - o * GH;
+    Wil[o * LDW + k] = Wih[e];
+    Whl[o * LDW + k] = Whh[e];
+  }
+  for (int e = threadIdx.x; e < 3 * GH; e += WG_THREADS) {
+    bil[e] = bih[e];
+    bhl[e] = bhh[e];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  const long groups = m_pad / SLAB;
+  const float *wi_lane = Wil + i * LDW + 4 * h;
+  const float *wh_lane = Whl + i * LDW + 4 * h;
+  for (long G = (long)blockIdx.x * WAVES_PER_WG + wave; G < groups; G += (long)gridDim.x * WAVES_PER_WG) {
+    float hs[GR];
+    load_rows(h0, G * SLAB + i, h, hs);
+    for (int l = 0; l < L; ++l) {
+      const long slab = (long)l * groups + G;
+      float x[GR];
+      load_act(xin, slab, lane, x);
+      const float mk = mrow[slab * SLAB + i];
+#pragma unroll
+      for (int R = 0; R < GR; ++R) hs[R] *= mk;  // h~ = h_{l-1} * mask_l
+      if (save) store_act(hpm_s, slab, lane, hs);
+      // accumulators: [0] r, [1] z share the x- and h- GEMMs; n keeps W_in x (acc[2]) and W_hn h~ (acch) apart
+      f32x16 acc[3][GT], acch[3][GT];
+#pragma unroll
+      for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int t = 0; t < GT; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int o = g * GH + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
+            acc[g][t][r] = g < 2 ? bil[o] + bhl[o] : bil[o];
+            acch[g][t][r] = bhl[o];
+          }
+      gemm_gates<7>(acc, wi_lane, x);
+      gemm_gates<3>(acc, wh_lane, hs);   // r, z: same accumulators
+      gemm_gates<4>(acch, wh_lane, hs);  // n: W_hn h~ + b_hn on its own
+      float rg[GR], zg[GR], ng[GR], hn[GR];
+      float sum = 0.f;
+#pragma unroll
+      for (int R = 0; R < GR; ++R) {
+        rg[R] = sigmoidf_(acc[0][R >> 4][R & 15]);
+        zg[R] = sigmoidf_(acc[1][R >> 4][R & 15]);
+        hn[R] = acch[2][R >> 4][R & 15];
+        ng[R] = tanhf(acc[2][R >> 4][R & 15] + rg[R] * hn[R]);
+        hs[R] = (1.f - zg[R]) * ng[R] + zg[R] * hs[R];
+        sum += hs[R];
+      }
+      if (save) {
+        store_act(r_s, slab, lane, rg);
+        store_act(z_s, slab, lane, zg);
+        store_act(n_s, slab, lane, ng);
+        store_act(hn_s, slab, lane, hn);
+      }
+      // rnn.norm (pure normalisation; affine folded into the head)
+      sum += wave_xor32(sum);
+      const float mean = sum * (1.0f / GH);
+      float vs = 0.f;
+#pragma unroll
+      for (int R = 0; R < GR; ++R) {
+        const float d = hs[R] - mean;
+        vs += d * d;
+      }
+      vs += wave_xor32(vs);
+      const float rstd = 1.0f / sqrtf(vs * (1.0f / GH) + 1e-5f);
+      float yo[GR];
+#pragma unroll
+      for (int R = 0; R < GR; ++R) yo[R] = (hs[R] - mean) * rstd;
+      store_act(y, slab, lane, yo);
+      if (lane < 32) rstd_y[slab * SLAB + lane] = rstd;
+    }
+    if (h_last) store_rows(h_last, G * SLAB + i, h, hs);
+  }
+}
+
+// =============================================================================================
+// backward (BPTT over the chunk, reverse in l).  Input: dh_out = d(loss)/d(h_l) through the output path (the head
+// kernels already applied the rnn.norm backward); output: the four gate-gradient tensors (for the weight-gradient
+// kernel) and dz of the last MLP layer (LayerNorm/ReLU backward of d(loss)/d(x_hat_mlp) applied here).
+//   A operands are W^T: lane i -> input feature, step -> gate output f(R,h); row-major W in LDS reads conflict-free.
+// =============================================================================================
+template <int NG>
+__device__ __forceinline__ void gemm_T(f32x16 (&acc)[GT], const float *wl_lane, const float (&b0)[GR],
+                                       const float (&b1)[GR], const float (&b2)[GR]) {
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+#pragma unroll
+    for (int R = 0; R < GR; ++R) {
+      const float bv = g == 0 ? b0[R] : (g == 1 ? b1[R] : b2[R]);
+#pragma unroll
+      for (int t = 0; t < GT; ++t) {
+        const float a = wl_lane[(g * GH + feat_base(R)) * GH + 32 * t];
+        acc[t] = MFMA(a, bv, acc[t]);
+      }
+      if ((R & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
+__global__ __launch_bounds__(WG_THREADS, 1) void k_gru_bwd(
+    const float *__restrict__ dhout, const float *__restrict__ mrow, const float *__restrict__ Wih,
+    const float *__restrict__ Whh, const float *__restrict__ hpm_s, const float *__restrict__ r_s,
+    const float *__restrict__ z_s, const float *__restrict__ n_s, const float *__restrict__ hn_s, int L, long m_pad,
+    const float *__restrict__ xmlp, const uint32_t *__restrict__ mask_mlp, const float *__restrict__ rstd_mlp,
+    float *__restrict__ dr_s, float *__restrict__ dz_s, float *__restrict__ dn_s, float *__restrict__ dhn_s,
+    float *__restrict__ dz_mlp) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float *Wil = lds;                 // [192][64] row-major
+  float *Whl = Wil + 3 * GH * GH;   // [192][64]
+  for (int e = threadIdx.x; e < 3 * GH * GH; e += WG_THREADS) {
+    Wil[e] = Wih[e];
+    Whl[e] = Whh[e];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  const long groups = m_pad / SLAB;
+  const float *wi_lane = Wil + 4 * h * GH + i;
+  const float *wh_lane = Whl + 4 * h * GH + i;
+  for (long G = (long)blockIdx.x * WAVES_PER_WG + wave; G < groups; G += (long)gridDim.x * WAVES_PER_WG) {
+    float dcarry[GR];
+#pragma unroll
+    for (int R = 0; R < GR; ++R) dcarry[R] = 0.f;
+    for (int l = L - 1; l >= 0; --l) {
+      const long slab = (long)l * groups + G;
+      float dh[GR], rg[GR], zg[GR], ng[GR], hn[GR], hp[GR];
+      load_act(dhout, slab, lane, dh);
+      load_act(r_s, slab, lane, rg);
+      load_act(z_s, slab, lane, zg);
+      load_act(n_s, slab, lane, ng);
+      load_act(hn_s, slab, lane, hn);
+      load_act(hpm_s, slab, lane, hp);
+      float drp[GR], dzp[GR], dnp[GR], dhnv[GR], dhp[GR];
+#pragma unroll
+      for (int R = 0; R < GR; ++R) {
+        const float d = dh[R] + dcarry[R];
+        const float dz_ = d * (hp[R] - ng[R]);
+        const float dn_ = d * (1.f - zg[R]);
+        dhp[R] = d * zg[R];
+        dnp[R] = dn_ * (1.f - ng[R] * ng[R]);
+        dhnv[R] = dnp[R] * rg[R];
+        drp[R] = (dnp[R] * hn[R]) * rg[R] * (1.f - rg[R]);
+        dzp[R] = dz_ * zg[R] * (1.f - zg[R]);
+      }
+      store_act(dr_s, slab, lane, drp);
+      store_act(dz_s, slab, lane, dzp);
+      store_act(dn_s, slab, lane, dnp);
+      store_act(dhn_s, slab, lane, dhnv);
+      // d h~ += W_hh^T [dr, dz, dhn] ;  carry = d h~ * mask_l
+      {
+        f32x16 acc[GT];
+#pragma unroll
+        for (int t = 0; t < GT; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        gemm_T<3>(acc, wh_lane, drp, dzp, dhnv);
+        const float mk = mrow[slab * SLAB + i];
+#pragma unroll
+        for (int R = 0; R < GR; ++R) dcarry[R] = (dhp[R] + acc[R >> 4][R & 15]) * mk;
+      }
+      // d x_hat_mlp = W_ih'^T [dr, dz, dn]  ->  LayerNorm/ReLU backward of the last MLP layer -> dz_mlp
+      {
+        f32x16 acc[GT];
+#pragma unroll
+        for (int t = 0; t < GT; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        gemm_T<3>(acc, wi_lane, drp, dzp, dnp);
+        float dx[GR], xh[GR];
+#pragma unroll
+        for (int R = 0; R < GR; ++R) dx[R] = acc[R >> 4][R & 15];
+        load_act(xmlp, slab, lane, xh);
+        ln_bwd_relu_store<GH>(dx, xh, mask_mlp, rstd_mlp[slab * SLAB + i], lane, slab, dz_mlp);
+      }
+    }
+  }
+}
+}  // namespace
+
+extern "C" int harl_gru_fwd(const float *xin, const float *mask_rows, const float *h0, const float *Wih,
+                            const float *bih, const float *Whh, const float *bhh, int H, int L, long m_pad, float *y,
+                            float *rstd_y, float *hpm, float *r, float *z, float *n, float *hn, float *h_last, int save,
+                            void *stream) {
+  if (L <= 0 || m_pad <= 0) return 0;
+  if (H != GH) { set_error("harl_gru_fwd: hidden width must be 64"); return -2; }
+  if (m_pad % SLAB) { set_error("harl_gru_fwd: m_pad must be a multiple of 32"); return -2; }
+  const size_t shm = ((size_t)2 * 3 * GH * (GH + 1) + 2 * 3 * GH) * sizeof(float);
+  const long groups = m_pad / SLAB;
+  long wgs = (groups + WAVES_PER_WG - 1) / WAVES_PER_WG;
+  const int grid = (int)(wgs < 256 ? wgs : 256);
+  allow_big_lds(k_gru_fwd, shm);
+  hipLaunchKernelGGL(k_gru_fwd, dim3(grid), dim3(WG_THREADS), shm, (hipStream_t)stream, xin, mask_rows, h0, Wih, bih, Whh,
+                     bhh, L, m_pad, y, rstd_y, hpm, r, z, n, hn, h_last, save);
+  return check_launch("harl_gru_fwd");
+}
+
+extern "C" int harl_gru_bwd(const float *dhout, const float *mask_rows, const float *Wih, const float *Whh,
+                            const float *hpm, const float *r, const float *z, const float *n, const float *hn, int H,
+                            int L, long m_pad, const float *xmlp, const uint32_t *mask_mlp, const float *rstd_mlp,
+                            float *dr, float *dz, float *dn, float *dhn, float *dz_mlp, void *stream) {
+  if (L <= 0 || m_pad <= 0) return 0;
+  if (H != GH) { set_error("harl_gru_bwd: hidden width must be 64"); return -2; }
+  const size_t shm = ((size_t)2 * 3 * GH * GH) * sizeof(float);
+  const long groups = m_pad / SLAB;
+  long wgs = (groups + WAVES_PER_WG - 1) / WAVES_PER_WG;
+  const int grid = (int)(wgs < 256 ? wgs : 256);
+  allow_big_lds(k_gru_bwd, shm);
+  hipLaunchKernelGGL(k_gru_bwd, dim3(grid), dim3(WG_THREADS), shm, (hipStream_t)stream, dhout, mask_rows, Wih, Whh, hpm, r,
+                     z, n, hn, L, m_pad, xmlp, mask_mlp, rstd_mlp, dr, dz, dn, dhn, dz_mlp);
+  return check_launch("harl_gru_bwd");
+}

@@ -41,6 +41,7 @@ struct ActorArgs {
   float *dzL, *dhead, *part_scalars;
   float *logp_out, *factor_out;
   float *head_out;  // [M, act_dim]: Gaussian mean / normalised Categorical logits (rollout sampling, HATRPO KL)
+  long m_valid, m_pad;  // recurrent batches: row j counts only if (j % m_pad) < m_valid   (m_pad = 0: every j < M)
   int trpo;         // surrogate: 0 HAPPO (clipped, happo.py:71-85); 1 HATRPO +ratio*f*adv*active, no entropy term
                     // (hatrpo.py:82-90); 2 HAA2C -ratio*f*adv*active, no clip (haa2c.py:70-80)
   long n_slabs;
@@ -206,8 +207,8 @@ __global__ __launch_bounds__(WG_THREADS) void k_actor_head(ActorArgs A) {
     for (int d = 0; d < DAP; ++d) zlin[d] = z[d] - cst[d];
 
     const long j = slab * SLAB + i;
-    const bool valid = j < A.M;
-    const long jc = valid ? j : A.M - 1;
+    const bool valid = j < A.M && (A.m_pad == 0 || (j % A.m_pad) < A.m_valid);
+    const long jc = j < A.M ? j : A.M - 1;
     const long row = A.idx ? A.idx[jc] : jc;
     const bool count_me = valid && h == 0;
 
@@ -389,6 +390,7 @@ struct CriticArgs {
   const int64_t *idx;
   const float *value_preds, *returns, *vn_stats;
   float clip_param, huber_delta;
+  long m_valid, m_pad;
   int use_clipped, use_huber;
   float *dzL, *dhead, *part_scalars, *values_out;
   long n_slabs;
@@ -423,12 +425,12 @@ __global__ __launch_bounds__(WG_THREADS) void k_critic_head(CriticArgs A) {
     head_fwd_stream<H, DAP>(A.xL, slab, lane, whl_h, cst, z);
     const float v = z[0];
     const long j = slab * SLAB + i;
-    const bool valid = j < A.M;
+    const bool valid = j < A.M && (A.m_pad == 0 || (j % A.m_pad) < A.m_valid);
     if (!TRAIN) {
-      if (valid && h == 0) A.values_out[j] = v;
+      if (j < A.M && h == 0) A.values_out[j] = v;
       continue;
     }
-    const long jc = valid ? j : A.M - 1;
+    const long jc = j < A.M ? j : A.M - 1;
     const long row = A.idx ? A.idx[jc] : jc;
     const float vold = A.value_preds[row];
     const float ret = A.returns[row];
@@ -706,10 +708,12 @@ extern "C" int harl_head_blocks(long M) { return head_grid(M); }
 extern "C" int harl_actor_head_logp(const float *xL, long M, int H, const float *Whp, const float *bhp,
                                     const float *log_std, float std_x_coef, float std_y_coef, int discrete,
                                     int act_dim, const float *actions, const float *avail, float *logp_out,
-                                    const float *old_logp, float *factor, int agg_mean, float *head_out, void *stream) {
+                                    const float *old_logp, float *factor, int agg_mean, float *head_out, long m_valid,
+                                    long m_pad, void *stream) {
   if (M <= 0) return 0;
   ActorArgs A{};
   A.head_out = head_out;
+  A.m_valid = m_valid; A.m_pad = m_pad;
   A.xL = xL; A.M = M; A.Whp = Whp; A.bhp = bhp; A.log_std = log_std;
   A.std_x_coef = std_x_coef; A.std_y_coef = std_y_coef; A.act_dim = act_dim;
   A.actions = actions; A.avail = avail; A.old_logp = old_logp; A.agg_mean = agg_mean;
@@ -726,11 +730,12 @@ extern "C" int harl_actor_head_loss(const float *xL, const uint32_t *relu_mask, 
                                     float std_y_coef, int discrete, int act_dim, const int64_t *idx,
                                     const float *actions, const float *avail, const float *old_logp, const float *adv,
                                     const double *adv_moments, const float *factor, const float *active,
-                                    float clip_param, float entropy_coef, int agg_mean, int trpo, float *dzL,
-                                    float *dhead, float *part_scalars, void *stream) {
+                                    float clip_param, float entropy_coef, int agg_mean, int trpo, long m_valid,
+                                    long m_pad, float *dzL, float *dhead, float *part_scalars, void *stream) {
   if (M <= 0) return 0;
   ActorArgs A{};
   A.trpo = trpo;
+  A.m_valid = m_valid; A.m_pad = m_pad;
   A.xL = xL; A.relu_mask = relu_mask; A.rstd = rstd; A.M = M; A.Whp = Whp; A.bhp = bhp; A.log_std = log_std;
   A.std_x_coef = std_x_coef; A.std_y_coef = std_y_coef; A.act_dim = act_dim; A.idx = idx;
   A.actions = actions; A.avail = avail; A.old_logp = old_logp; A.adv = adv; A.adv_moments = adv_moments;
@@ -755,10 +760,11 @@ extern "C" int harl_critic_head_values(const float *xL, long M, int H, const flo
 extern "C" int harl_critic_head_loss(const float *xL, const uint32_t *relu_mask, const float *rstd, long M, int H,
                                      const float *Whp, const float *bhp, const int64_t *idx, const float *value_preds,
                                      const float *returns, const float *vn_stats, float clip_param, int use_clipped,
-                                     int use_huber, float huber_delta, float *dzL, float *dhead, float *part_scalars,
-                                     void *stream) {
+                                     int use_huber, float huber_delta, long m_valid, long m_pad, float *dzL, float *dhead,
+                                     float *part_scalars, void *stream) {
   if (M <= 0) return 0;
   CriticArgs A{};
+  A.m_valid = m_valid; A.m_pad = m_pad;
   A.xL = xL; A.relu_mask = relu_mask; A.rstd = rstd; A.M = M; A.Whp = Whp; A.bhp = bhp; A.idx = idx;
   A.value_preds = value_preds; A.returns = returns; A.vn_stats = vn_stats; A.clip_param = clip_param;
   A.huber_delta = huber_delta; A.use_clipped = use_clipped; A.use_huber = use_huber; A.dzL = dzL; A.dhead = dhead;

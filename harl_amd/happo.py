@@ -17,7 +17,7 @@ from . import _lib
 from ._lib import PS_STRIDE, call, ptr, stream
 from .buffers import OnPolicyActorBuffer, consume_randperm, minibatch_indices
 from .dist import Comm, local_minibatch_rows
-from .nets import FusedAdam, StochasticPolicy
+from .nets import FusedAdam, StochasticPolicy, build_seq, seq_compact
 from .valuenorm import _as_dev
 
 
@@ -51,14 +51,42 @@ class OnPolicyBase:
             g["lr"] = lr
 
     # ---- log-prob passes over a whole [T*N] batch (on_policy_ha_runner.py:66-83,96-113) --------------
-    def _logp_pass(self, obs, actions, avail, M, logp_out, old_logp=None, factor=None, head_out=None):
+    def _logp_pass(self, obs, actions, avail, M, logp_out, old_logp=None, factor=None, head_out=None,
+                   rnn_states=None, masks=None, h_last=False):
+        """Forward + head over rows 0..M-1.  Recurrent nets follow the reference's convention (rnn.py:24-42): with
+        rnn_states [m, 1, H], M = L*m rows are L steps of m sequences (l-major) unrolled from rnn_states with mask
+        resets.  Returns the final hidden state [m, H] when ``h_last`` is set."""
         net = self.actor
-        net.forward_trunk(obs, None, M, for_backward=False)
+        agg = int(self.action_aggregation == "mean")
+        if not net.recurrent:
+            net.forward_trunk(obs, None, M, for_backward=False)
+            Wp, bp = net._packs[-1]
+            call("harl_actor_head_logp", ptr(net.xh[-1]), M, net.hidden_sizes[-1], ptr(Wp), ptr(bp), ptr(net.log_std()),
+                 net.std_x_coef, net.std_y_coef, int(net.discrete), net.act_dim, ptr(actions), ptr(avail), ptr(logp_out),
+                 ptr(old_logp), ptr(factor), agg, ptr(head_out), 0, 0, stream(), tag="actor_head_logp")
+            return None
+        H = net.hidden_sizes[-1]
+        m = rnn_states.shape[0]
+        L = M // m
+        seq = build_seq(self.device, L, m, H, h0=_as_dev(rnn_states, self.device).reshape(m, H),
+                        masks_src=_as_dev(masks, self.device), want_h_last=h_last)
+        idx, Mp = seq["idx"], L * seq["m_pad"]
+        padded = idx is not None
+        g = (lambda t: None if t is None else t[idx].contiguous()) if padded else (lambda t: t)  # noqa: E731
+        tmp = (lambda t: None if t is None else torch.empty(Mp, *t.shape[1:], **self.tpdv)) if padded else (lambda t: t)  # noqa: E731
+        a_p, av_p, old_p, f_p = g(actions), g(avail), g(old_logp), g(factor)
+        lo_p, ho_p = tmp(logp_out), tmp(head_out)
+        net.forward_trunk(obs, idx, Mp, for_backward=False, seq=seq)
+        fx, _, _, fh = net.feat()
         Wp, bp = net._packs[-1]
-        call("harl_actor_head_logp", ptr(net.xh[-1]), M, net.hidden_sizes[-1], ptr(Wp), ptr(bp), ptr(net.log_std()),
-             net.std_x_coef, net.std_y_coef, int(net.discrete), net.act_dim, ptr(actions), ptr(avail), ptr(logp_out),
-             ptr(old_logp), ptr(factor), int(self.action_aggregation == "mean"), ptr(head_out), stream(),
-             tag="actor_head_logp")
+        call("harl_actor_head_logp", ptr(fx), Mp, fh, ptr(Wp), ptr(bp), ptr(net.log_std()), net.std_x_coef,
+             net.std_y_coef, int(net.discrete), net.act_dim, ptr(a_p), ptr(av_p), ptr(lo_p), ptr(old_p), ptr(f_p), agg,
+             ptr(ho_p), m, seq["m_pad"], stream(), tag="actor_head_logp")
+        if padded:
+            for dst, src in ((logp_out, lo_p), (head_out, ho_p), (factor, f_p)):
+                if dst is not None:
+                    dst.copy_(seq_compact(src, seq))
+        return None if not h_last else seq["h_last"][:m]
 
     def evaluate_actions(self, obs, rnn_states_actor, action, masks, available_actions=None, active_masks=None):
         """Returns (action_log_probs [B, act_w] device tensor, None, None).  Entropy and the distribution object are
@@ -70,15 +98,15 @@ class OnPolicyBase:
         M = obs.shape[0]
         out = torch.empty(M, self.actor.act_w, **self.tpdv)
         self.actor.fold()
-        self._logp_pass(obs, action, avail, M, out)
+        self._logp_pass(obs, action, avail, M, out, rnn_states=rnn_states_actor, masks=masks)
         return out, None, None
 
     @torch.no_grad()
     def get_actions(self, obs, rnn_states_actor, masks, available_actions=None, deterministic=False):
-        """Rollout-side sampling (on_policy_base.py:52-69 -> StochasticPolicy.forward, act.py:45-86).  The trunk and head
-        run on the HIP kernels (head outputs via ``harl_actor_head_logp(head_out=...)``); the draw itself uses torch's
-        device generator, which is what the reference's ``Normal.sample()/Categorical.sample()`` use on a GPU.
-        Returns device tensors (actions [B, act_w], action_log_probs [B, act_w], rnn_states passthrough)."""
+        """Rollout-side sampling (on_policy_base.py:52-69 -> StochasticPolicy.forward, act.py:45-86).  The trunk, GRU
+        step and head run on the HIP kernels (head outputs via ``harl_actor_head_logp(head_out=...)``); the draw itself
+        uses torch's device generator, which is what the reference's ``Normal.sample()/Categorical.sample()`` use on a
+        GPU.  Returns device tensors (actions [B, act_w], action_log_probs [B, act_w], rnn_states [B, 1, H])."""
         net = self.actor
         x = _as_dev(obs, self.device)
         x = x.reshape(x.shape[0], -1)
@@ -86,22 +114,22 @@ class OnPolicyBase:
         avail = None if available_actions is None else _as_dev(available_actions, self.device).reshape(M, -1)
         net.fold()
         head = torch.empty(M, net.act_dim, **self.tpdv)
-        self._logp_pass(x, None, avail, M, None, head_out=head)  # head_out only: no actions needed
+        rnn_out = rnn_states_actor
+        h = self._logp_pass(x, None, avail, M, None, head_out=head, rnn_states=rnn_states_actor, masks=masks,
+                            h_last=True)  # head_out only: no actions needed
+        if net.recurrent:
+            rnn_out = h.reshape(M, 1, -1).clone()
         if net.discrete:  # head = normalised logits (masked entries ~ -1e10)
             if deterministic:
                 actions = head.argmax(dim=-1, keepdim=True).to(torch.float32)
             else:
                 actions = torch.multinomial(torch.exp(head), 1).to(torch.float32)
             logp = head.gather(-1, actions.long())
-        else:
+        else:  # log N(a; mean, sigma) by the same formula the loss kernel uses (elementwise, plumbing-sized)
             sigma = torch.sigmoid(net.log_std() / net.std_x_coef) * net.std_y_coef
             actions = head if deterministic else head + sigma * torch.randn_like(head)
-            logp = torch.empty(M, net.act_dim, **self.tpdv)
-            Wp, bp = net._packs[-1]  # x_hat_L of this batch is still resident: head-only second pass for log pi(a)
-            call("harl_actor_head_logp", ptr(net.xh[-1]), M, net.hidden_sizes[-1], ptr(Wp), ptr(bp), ptr(net.log_std()),
-                 net.std_x_coef, net.std_y_coef, 0, net.act_dim, ptr(actions.contiguous()), None, ptr(logp), None, None, 0,
-                 None, stream())
-        return actions, logp, rnn_states_actor
+            logp = -((actions - head) ** 2) / (2 * sigma * sigma) - torch.log(sigma) - 0.9189385332046727
+        return actions, logp, rnn_out
 
     @torch.no_grad()
     def act(self, obs, rnn_states_actor, masks, available_actions=None, deterministic=False):
@@ -130,19 +158,22 @@ class HAPPO(OnPolicyBase):
         self._grad_tap = None
 
     # ---- one optimiser step on rows idx[0..m) of the flat [T*N, .] tensors (happo.py:28-102) ---------
-    def _update_core(self, obs, idx, m, actions, avail, old_logp, adv, adv_moments, factor, active):
+    def _update_core(self, obs, idx, m, actions, avail, old_logp, adv, adv_moments, factor, active, seq=None):
+        """``seq`` (recurrent nets): the batch is L x m_pad rows in the GRU layout (nets.build_seq), idx = seq['idx']."""
         net = self.actor
-        net.forward_trunk(obs, idx, m)
+        net.forward_trunk(obs, idx, m, seq=seq)
         Wp, bp = net._packs[-1]
         s = stream()
-        call("harl_actor_head_loss", ptr(net.xh[-1]), ptr(net.rmask[-1]), ptr(net.rstd[-1]), m, net.hidden_sizes[-1],
+        fx, fmask, frstd, fh = net.feat()
+        mv, mp = (seq["m"], seq["m_pad"]) if seq is not None else (0, 0)
+        call("harl_actor_head_loss", ptr(fx), ptr(fmask), ptr(frstd), m, fh,
              ptr(Wp), ptr(bp), ptr(net.log_std()), net.std_x_coef, net.std_y_coef, int(net.discrete), net.act_dim,
              ptr(idx), ptr(actions), ptr(avail), ptr(old_logp), ptr(adv), ptr(adv_moments), ptr(factor), ptr(active),
              float(self.clip_param), float(self.entropy_coef), int(self.action_aggregation == "mean"), self._surrogate_mode,
-             ptr(net.dz[0]), ptr(net.dhead), ptr(net.part_scalars), s, tag="actor_head_loss")
+             mv, mp, ptr(net.dz[0]), ptr(net.dhead), ptr(net.part_scalars), s, tag="actor_head_loss")
         net.scalars.zero_()
         call("harl_reduce_scalars", ptr(net.part_scalars), _lib.load().harl_head_blocks(m), ptr(net.scalars), s)
-        net.backward_trunk(obs, idx, m)
+        net.backward_trunk(obs, idx, m, seq=seq)
         sc = net.scalars
         if self.comm.enabled:  # ONE collective per optimiser step: [folded gradients | loss scalars]
             if self._staging is None:
@@ -163,6 +194,18 @@ class HAPPO(OnPolicyBase):
         m = obs.shape[0]
         before = self._info.clone()
         self.actor.fold()
+        if self.actor.recurrent:  # gathered [L*m, .] l-major minibatch + rnn_states [m, 1, H] (recurrent generators)
+            H = self.actor.hidden_sizes[-1]
+            nseq = _as_dev(_rnn, dev).shape[0]
+            seq = build_seq(dev, m // nseq, nseq, H, h0=_as_dev(_rnn, dev).reshape(nseq, H), masks_src=_as_dev(_masks, dev))
+            idx = seq["idx"]
+            self._update_core(obs.reshape(m, -1), idx, seq["L"] * seq["m_pad"], _as_dev(actions, dev).reshape(m, -1),
+                              None if avail is None else _as_dev(avail, dev).reshape(m, -1),
+                              _as_dev(old_logp, dev).reshape(m, -1), _as_dev(adv, dev).reshape(m), None,
+                              _as_dev(factor, dev).reshape(m),
+                              _as_dev(active, dev).reshape(m) if self.use_policy_active_masks else None, seq=seq)
+            d = self._info - before
+            return d[0], d[1], d[2], d[3]
         self._update_core(obs.reshape(m, -1), None, m, _as_dev(actions, dev).reshape(m, -1),
                           None if avail is None else _as_dev(avail, dev).reshape(m, -1),
                           _as_dev(old_logp, dev).reshape(m, -1), _as_dev(adv, dev).reshape(m), None,
@@ -199,7 +242,11 @@ class HAPPO(OnPolicyBase):
         n_global = self.shard[0] * T if self.shard else B
         for _ in range(self.ppo_epoch):
             if self.use_recurrent_policy or self.use_naive_recurrent_policy:
-                raise NotImplementedError("recurrent generators are not implemented in this round")
+                for seq in buf.recurrent_batches(self.actor_num_mini_batch, self.data_chunk_length,
+                                                 naive=not self.use_recurrent_policy, shard=self.shard):
+                    self._update_core(obs, seq["idx"], seq["L"] * seq["m_pad"], actions, avail, old_logp, adv, moments,
+                                      factor, active if self.use_policy_active_masks else None, seq=seq)
+                continue
             if self.actor_num_mini_batch == 1:
                 # the single "minibatch" is the whole (local) buffer: the sums do not depend on the order, so only the
                 # generator state is replayed (bit-exact RNG stream), not the 819200-element shuffle itself

@@ -59,8 +59,10 @@ class _FlatNet(nn.Module):
         self.use_feature_normalization = bool(args["use_feature_normalization"])
         if args.get("activation_func", "relu") != "relu":
             raise NotImplementedError("harl_amd kernels implement relu MLPs only (every tuned HARL config uses relu)")
-        if args.get("use_recurrent_policy", False) or args.get("use_naive_recurrent_policy", False):
-            raise NotImplementedError("recurrent (GRU) policies are not implemented in this round")
+        self.recurrent = bool(args.get("use_recurrent_policy", False) or args.get("use_naive_recurrent_policy", False))
+        self.recurrent_n = int(args.get("recurrent_n", 1))
+        if self.recurrent and (self.hidden_sizes[-1] != 64 or self.recurrent_n != 1):
+            raise NotImplementedError("GRU kernels: hidden width 64 and recurrent_n = 1 (every recurrent tuned HARL config)")
         for h in self.hidden_sizes:
             if h not in SUPPORTED_WIDTHS:
                 raise NotImplementedError(f"hidden width {h}: kernels are instantiated for {SUPPORTED_WIDTHS}")
@@ -83,6 +85,17 @@ class _FlatNet(nn.Module):
             self._cpu_params += [(f"base.mlp.fc.{3*i}.weight", lin.weight.data), (f"base.mlp.fc.{3*i}.bias", lin.bias.data),
                                  (f"base.mlp.fc.{3*i+2}.weight", torch.ones(h)), (f"base.mlp.fc.{3*i+2}.bias", torch.zeros(h))]
             d = h
+        if self.recurrent:  # RNNLayer (rnn.py:8-21): nn.GRU default init, then bias = 0 / weight = init_method, then LayerNorm
+            gru = nn.GRU(d, d, num_layers=self.recurrent_n)
+            for name, param in gru.named_parameters():
+                if "bias" in name:
+                    nn.init.constant_(param, 0)
+                elif "weight" in name:
+                    init(param)
+            sd = dict(gru.named_parameters())
+            self._cpu_params += [(f"rnn.rnn.{k}", sd[k].data) for k in
+                                 ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0")]
+            self._cpu_params += [("rnn.norm.weight", torch.ones(d)), ("rnn.norm.bias", torch.zeros(d))]
 
     def _finalize_params(self) -> None:
         """Move the collected CPU tensors into the flat device arena and register views as nn.Parameters."""
@@ -125,8 +138,28 @@ class _FlatNet(nn.Module):
             g = (f"base.mlp.fc.{3*i+2}.weight", f"base.mlp.fc.{3*i+2}.bias")
             d = h
         hw, hb, hdim = self._head_names()
+        if self.recurrent:
+            g = ("rnn.norm.weight", "rnn.norm.bias")
         out.append((hw, hb, g[0], g[1], hdim, d))
         return out
+
+    def _entries(self) -> List[Tuple[int, int, int, int, int, int]]:
+        """Every Linear-like block in TABLE order as (w_off, b_off, gamma_off, beta_off, out, in) offsets into the flat
+        arena: MLP layers, [GRU W_ih gate blocks r,z,n (folded with the last MLP LayerNorm), GRU W_hh gate blocks], head."""
+        off = lambda n: self.offsets[n][0] if n else -1  # noqa: E731
+        layers = self._layers()
+        ents = [(off(w), off(b), off(g), off(be), o, k) for (w, b, g, be, o, k) in layers[:-1]]
+        if self.recurrent:
+            H = self.hidden_sizes[-1]
+            i = len(self.hidden_sizes) - 1
+            g, be = off(f"base.mlp.fc.{3*i+2}.weight"), off(f"base.mlp.fc.{3*i+2}.bias")
+            for gate in range(3):
+                ents.append((off("rnn.rnn.weight_ih_l0") + gate * H * H, off("rnn.rnn.bias_ih_l0") + gate * H, g, be, H, H))
+            for gate in range(3):
+                ents.append((off("rnn.rnn.weight_hh_l0") + gate * H * H, off("rnn.rnn.bias_hh_l0") + gate * H, -1, -1, H, H))
+        (w, b, g, be, o, k) = layers[-1]
+        ents.append((off(w), off(b), off(g), off(be), o, k))
+        return ents
 
     def _head_names(self) -> Tuple[str, str, int]:
         raise NotImplementedError
@@ -134,38 +167,61 @@ class _FlatNet(nn.Module):
     def _build_tables(self) -> None:
         """Folded-weight arena, dense folded-gradient arena and the device layer table (include/harl_hip.h,
         HARL_TABLE_STRIDE) used by harl_reduce_partials_multi / harl_adam_fold."""
-        layers = self._layers()
+        ents = self._entries()
         dev = self.device_
+        L = len(self.hidden_sizes)
         rows, pack_off, dwp_off = [], 0, 0
-        self._pack_offs, self._dwp_offs, self._elems = [], [], []
-        for (wn, bn, gn, ben, o, k) in layers:
+        pack_slots = []
+        self._dwp_offs, self._elems = [], []
+        if self.recurrent:  # GRU: the three gate blocks of each matrix must be contiguous ([3H][H], then [3H] biases)
+            H = self.hidden_sizes[-1]
+        for ei, (wo, bo, go, beo, o, k) in enumerate(ents):
+            gru_i = ei - L if (self.recurrent and L <= ei < L + 6) else -1
+            if gru_i >= 0:
+                mat, gate = divmod(gru_i, 3)
+                base = self._gru_pack_base + mat * (3 * H * H + 3 * H)
+                pw, pb = base + gate * H * H, base + 3 * H * H + gate * H
+            else:
+                if self.recurrent and ei == L:
+                    pass
+                pw, pb = pack_off, pack_off + o * k
+                pack_off += o * k + o
+                if self.recurrent and ei == L - 1:  # reserve the GRU block right after the last MLP layer
+                    self._gru_pack_base = pack_off
+                    pack_off += 2 * (3 * H * H + 3 * H)
             kp, op = ((k + 31) // 32) * 32, ((o + 31) // 32) * 32
             elems = op * kp + op
-            rows.append([self.offsets[wn][0], self.offsets[bn][0], self.offsets[gn][0] if gn else -1,
-                         self.offsets[ben][0] if ben else -1, o, k, pack_off, pack_off + o * k, dwp_off, kp, op, 0])
-            self._pack_offs.append((pack_off, pack_off + o * k))
+            rows.append([wo, bo, go, beo, o, k, pw, pb, dwp_off, kp, op, 0])
+            pack_slots.append((pw, pb, o, k))
             self._dwp_offs.append(dwp_off)
             self._elems.append(elems)
-            pack_off += o * k + o
             dwp_off += elems
         self._table_rows = rows
+        self.n_entries = len(rows)
         self.pack_arena = torch.empty(pack_off, dtype=torch.float32, device=dev)
         self.dwp = torch.zeros(dwp_off, dtype=torch.float32, device=dev)
         self.total_dwp = dwp_off
-        self._packs = [(self.pack_arena[a:b], self.pack_arena[b:b + o]) for (a, b), (_, _, _, _, o, _) in
-                       zip(self._pack_offs, layers)]
+        self._pack_slots = pack_slots
+        views = [(self.pack_arena[pw:pw + o * k], self.pack_arena[pb:pb + o]) for (pw, pb, o, k) in pack_slots]
+        self._packs = views[:L] + [views[-1]]  # MLP layers by index, head last (callers use [l] and [-1])
+        if self.recurrent:
+            b0 = self._gru_pack_base
+            n = 3 * H * H
+            self.gru_pack = dict(Wih=self.pack_arena[b0:b0 + n], bih=self.pack_arena[b0 + n:b0 + n + 3 * H],
+                                 Whh=self.pack_arena[b0 + n + 3 * H:b0 + 2 * n + 3 * H],
+                                 bhh=self.pack_arena[b0 + 2 * n + 3 * H:b0 + 2 * n + 6 * H])
         self.table = None  # device table is finalised in _ensure_ws (part offsets depend on n_wg)
 
     def fold(self) -> None:
         """Recompute the folded weights from the current parameters (after init / load_state_dict; the optimiser
         step re-folds inside harl_adam_fold)."""
-        layers = self._layers()
         if not self._packs:
             self._build_tables()
         s = stream()
-        for (wn, bn, gn, ben, o, k), (Wp, bp) in zip(layers, self._packs):
-            call("harl_fold_linear", ptr(self.pview(wn)), ptr(self.pview(bn)),
-                 ptr(self.pview(gn)) if gn else None, ptr(self.pview(ben)) if ben else None, ptr(Wp), ptr(bp), o, k, s)
+        fp, pa = self.flat_param, self.pack_arena
+        for (wo, bo, go, beo, o, k), (pw, pb, _, _) in zip(self._entries(), self._pack_slots):
+            call("harl_fold_linear", ptr(fp[wo:]), ptr(fp[bo:]), ptr(fp[go:]) if go >= 0 else None,
+                 ptr(fp[beo:]) if beo >= 0 else None, ptr(pa[pw:]), ptr(pa[pb:]), o, k, s)
 
     # ---- workspaces -------------------------------------------------------------------------
     def _ensure_ws(self, M: int) -> None:
@@ -193,14 +249,40 @@ class _FlatNet(nn.Module):
             part_off += self.n_wg * elems
         self.part = torch.empty(part_off, dtype=f32, device=dev)
         self.table = torch.tensor(rows, dtype=torch.int32, device=dev).reshape(-1).contiguous()
+        if self.recurrent:
+            H = self.hidden_sizes[-1]
+            a = lambda: torch.empty(mp * H, dtype=f32, device=dev)  # noqa: E731
+            self.rnn_y, self.rnn_rstd = a(), torch.empty(mp, dtype=f32, device=dev)
+            self.rnn_saved = [a() for _ in range(5)]   # h~ (= h*mask), r, z, n, hn
+            self.rnn_dgate = [a() for _ in range(4)]   # dr, dz, dn, dhn
+            self.rnn_ones = torch.full((n_slabs * 64,), -1, dtype=u32, device=dev)  # all-ones "relu mask" for rnn.norm
         self.n_head_blocks = _lib.load().harl_head_blocks(M)
         self.part_scalars = torch.zeros(self.n_head_blocks * PS_STRIDE, dtype=f32, device=dev)
         self.scalars = torch.zeros(PS_STRIDE, dtype=torch.float64, device=dev)
         self._max_rows = M
 
     # ---- trunk forward: X[rows, D] (gathered by idx) -> x_hat_L in self.xh[-1] ------------------
-    def forward_trunk(self, X: torch.Tensor, idx: Optional[torch.Tensor], M: int, for_backward: bool = True) -> None:
+    # head input: (ATL activation, relu mask, rstd, width) -- the last MLP layer, or the GRU's normalised output
+    def feat(self):
+        if self.recurrent:
+            return self.rnn_y, self.rnn_ones, self.rnn_rstd, self.hidden_sizes[-1]
+        return self.xh[-1], self.rmask[-1], self.rstd[-1], self.hidden_sizes[-1]
+
+    def forward_rnn(self, seq: dict, save: bool) -> None:
+        """GRU over a recurrent batch (seq: L, m_pad, h0 [m_pad, H], mask_rows [L*m_pad], optional h_last out)."""
+        gp = self.gru_pack
+        sv = self.rnn_saved
+        call("harl_gru_fwd", ptr(self.xh[-1]), ptr(seq["mask_rows"]), ptr(seq["h0"]), ptr(gp["Wih"]), ptr(gp["bih"]),
+             ptr(gp["Whh"]), ptr(gp["bhh"]), self.hidden_sizes[-1], seq["L"], seq["m_pad"], ptr(self.rnn_y),
+             ptr(self.rnn_rstd), ptr(sv[0]), ptr(sv[1]), ptr(sv[2]), ptr(sv[3]), ptr(sv[4]), ptr(seq.get("h_last")),
+             int(save), stream(), tag="gru_fwd")
+
+    def forward_trunk(self, X: torch.Tensor, idx: Optional[torch.Tensor], M: int, for_backward: bool = True,
+                      seq: Optional[dict] = None) -> None:
         assert X.dim() == 2 and X.shape[1] == self.in_dim and X.is_contiguous()
+        if self.recurrent:
+            assert seq is not None and seq["L"] * seq["m_pad"] == M, "recurrent nets need the sequence layout"
+            for_backward = True  # the fused 2-layer path may skip x_hat_1; keep it simple for recurrent nets
         self._ensure_ws(M)
         s = stream()
         hs = self.hidden_sizes
@@ -222,19 +304,35 @@ class _FlatNet(nn.Module):
             Wp, bp = self._packs[l]
             call("harl_mlp_fwd_hidden", ptr(self.xh[l - 1]), M, hs[l - 1], hs[l],
                  ptr(Wp), ptr(bp), ptr(self.xh[l]), ptr(self.rmask[l]), ptr(self.rstd[l]), s, tag="fwd_hidden")
+        if self.recurrent:
+            self.forward_rnn(seq, save=True)
 
     # ---- backward: dz_L (in self.dz[0]) and dhead -> dense folded gradients self.dwp (UNSCALED sums over samples)
-    def backward_trunk(self, X: torch.Tensor, idx: Optional[torch.Tensor], M: int) -> None:
+    def backward_trunk(self, X: torch.Tensor, idx: Optional[torch.Tensor], M: int, seq: Optional[dict] = None) -> None:
         s = stream()
         L = len(self.hidden_sizes)
         nwg = self.n_wg
         po = self._part_offs
         hdim = self._layers()[-1][4]
-        hL = self.hidden_sizes[-1]
-        # head: dW_head' = dhead^T x_hat_L
-        call("harl_mlp_dw_partials", ptr(self.dhead), 1, DHEAD_LD, hdim, ptr(self.xh[-1]), 0, 0, None, None, None, hL, M,
-             ptr(self.part[po[L]:]), nwg, s, tag="dw_head")
-        cur = 0  # self.dz[cur] holds dz_l
+        fx, _, _, fh = self.feat()
+        # head: dW_head' = dhead^T x_hat_L   (x_hat_L = GRU output for recurrent nets)
+        call("harl_mlp_dw_partials", ptr(self.dhead), 1, DHEAD_LD, hdim, ptr(fx), 0, 0, None, None, None, fh, M,
+             ptr(self.part[po[-1]:]), nwg, s, tag="dw_head")
+        cur = 0  # self.dz[cur] holds dz of the last MLP layer (non-recurrent) / d(loss)/d(h) (recurrent)
+        if self.recurrent:
+            gp, sv, dg = self.gru_pack, self.rnn_saved, self.rnn_dgate
+            H = self.hidden_sizes[-1]
+            call("harl_gru_bwd", ptr(self.dz[0]), ptr(seq["mask_rows"]), ptr(gp["Wih"]), ptr(gp["Whh"]), ptr(sv[0]),
+                 ptr(sv[1]), ptr(sv[2]), ptr(sv[3]), ptr(sv[4]), H, seq["L"], seq["m_pad"], ptr(self.xh[-1]),
+                 ptr(self.rmask[-1]), ptr(self.rstd[-1]), ptr(dg[0]), ptr(dg[1]), ptr(dg[2]), ptr(dg[3]), ptr(self.dz[1]), s,
+                 tag="gru_bwd")
+            for gate, a in enumerate((dg[0], dg[1], dg[2])):      # W_ih' gate blocks: d gi^T x_hat_mlp
+                call("harl_mlp_dw_partials", ptr(a), 0, 0, H, ptr(self.xh[-1]), 0, 0, None, None, None, H, M,
+                     ptr(self.part[po[L + gate]:]), nwg, s, tag="dw_gru")
+            for gate, a in enumerate((dg[0], dg[1], dg[3])):      # W_hh gate blocks: d gh^T h~
+                call("harl_mlp_dw_partials", ptr(a), 0, 0, H, ptr(sv[0]), 0, 0, None, None, None, H, M,
+                     ptr(self.part[po[L + 3 + gate]:]), nwg, s, tag="dw_gru")
+            cur = 1
         for l in range(L - 1, 0, -1):
             ho, hi = self.hidden_sizes[l], self.hidden_sizes[l - 1]
             call("harl_mlp_dw_partials", ptr(self.dz[cur]), 0, 0, ho, ptr(self.xh[l - 1]), 0, 0, None, None, None, hi, M,
@@ -248,20 +346,25 @@ class _FlatNet(nn.Module):
         call("harl_mlp_dw_partials", ptr(self.dz[cur]), 0, 0, h0, ptr(X), 1, X.shape[1], ptr(idx),
              ptr(self.mu0) if use_ln else None, ptr(self.rstd0) if use_ln else None, self.in_dim, M,
              ptr(self.part[po[0]:]), nwg, s, tag="dw_input")
-        # deterministic fixed-order combine of every layer's per-workgroup partials, one launch
-        call("harl_reduce_partials_multi", ptr(self.part), ptr(self.table), L + 1, nwg, self.total_dwp, ptr(self.dwp), s,
-             tag="reduce_partials")
+        # deterministic fixed-order combine of every entry's per-workgroup partials, one launch
+        call("harl_reduce_partials_multi", ptr(self.part), ptr(self.table), self.n_entries, nwg, self.total_dwp,
+             ptr(self.dwp), s, tag="reduce_partials")
 
     def unfold_grads(self) -> None:
         """self.dwp (dense folded gradients) -> self.flat_grad in the reference parameter layout (UNSCALED)."""
         s = stream()
-        for (wn, bn, gn, ben, o, k), off in zip(self._layers(), self._dwp_offs):
+        fp, fg = self.flat_param, self.flat_grad
+        seen = set()
+        for (wo, bo, go, beo, o, k), off in zip(self._entries(), self._dwp_offs):
             kp, op = ((k + 31) // 32) * 32, ((o + 31) // 32) * 32
             dW = self.dwp[off:off + op * kp]
             db = self.dwp[off + op * kp:off + op * kp + op]
-            call("harl_unfold_linear_grads", ptr(dW), ptr(db), kp, ptr(self.pview(wn)),
-                 ptr(self.pview(gn)) if gn else None, ptr(self.pview(ben)) if ben else None, ptr(self.gview(wn)),
-                 ptr(self.gview(bn)), ptr(self.gview(gn)) if gn else None, ptr(self.gview(ben)) if ben else None, o, k, s)
+            acc = int(go in seen)  # Linears sharing one LayerNorm (GRU gate blocks) accumulate its gradients
+            if go >= 0:
+                seen.add(go)
+            call("harl_unfold_linear_grads", ptr(dW), ptr(db), kp, ptr(fp[wo:]), ptr(fp[go:]) if go >= 0 else None,
+                 ptr(fp[beo:]) if beo >= 0 else None, ptr(fg[wo:]), ptr(fg[bo:]), ptr(fg[go:]) if go >= 0 else None,
+                 ptr(fg[beo:]) if beo >= 0 else None, o, k, acc, s)
 
     def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):  # keep views, then refold
         out = super().load_state_dict(state_dict, strict=strict, assign=False)
@@ -349,6 +452,51 @@ def consume_policy_init_rng(args: dict, obs_space, action_space) -> None:
     init(lin.weight.data, gain=args["gain"])
 
 
+def build_seq(dev, L: int, m: int, H: int, *, first_rows: Optional[torch.Tensor] = None, stride: Optional[int] = None,
+              h0: Optional[torch.Tensor] = None, h0_src: Optional[torch.Tensor] = None,
+              masks_src: Optional[torch.Tensor] = None, want_h_last: bool = False) -> dict:
+    """Layout of a recurrent batch for the GRU kernels (csrc/gru.hip): L time steps x m sequences, row (l, j) at
+    l*m_pad + j with m_pad = m rounded up to the 32-sample slab (padding sequences replay sequence 0 and are ignored by
+    the loss kernels through m_valid/m_pad).
+
+    buffer mode  (first_rows [m] CPU/device int64, stride = N): sequence j covers source rows first_rows[j] + l*stride
+                 of the t-major flattened buffers -- the reference's chunk slicing (on_policy_actor_buffer.py:255-322)
+                 and naive whole-column sampling (:180-221); h0 = h0_src[first_rows], masks = masks_src[rows].
+    direct mode  (first_rows None): the caller's arrays are already [L*m, .] l-major (evaluate_actions / get_actions,
+                 rnn.py:36-42 convention); h0 [m, H] and masks_src [L*m] are given explicitly.
+    Returns dict(L, m, m_pad, idx (None = identity), valid_idx, h0, mask_rows, h_last)."""
+    m_pad = (m + 31) // 32 * 32
+    direct = first_rows is None
+    if direct:
+        first, stride = torch.arange(m, device=dev), m
+    else:
+        first = first_rows.to(dev)
+    if m_pad != m:
+        first = torch.cat([first, first[:1].expand(m_pad - m)])
+    if direct and m_pad == m:
+        idx = valid_idx = None
+        mask_rows = masks_src.reshape(-1).contiguous()
+    else:
+        rows = first[None, :] + torch.arange(L, device=dev)[:, None] * stride
+        idx = rows.reshape(-1).contiguous()
+        valid_idx = idx if m_pad == m else rows[:, :m].reshape(-1).contiguous()
+        mask_rows = masks_src.reshape(-1)[idx].contiguous()
+    if h0 is None:
+        h0 = h0_src.reshape(-1, H)[first]
+    elif m_pad != m:
+        h0 = torch.cat([h0.reshape(m, H), torch.zeros(m_pad - m, H, dtype=h0.dtype, device=dev)])
+    return dict(L=L, m=m, m_pad=m_pad, idx=idx, valid_idx=valid_idx, h0=h0.reshape(m_pad, H).contiguous(),
+                mask_rows=mask_rows, h_last=torch.empty(m_pad, H, dtype=torch.float32, device=dev) if want_h_last else None)
+
+
+def seq_compact(t: torch.Tensor, seq: dict) -> torch.Tensor:
+    """[L*m_pad, w] padded rows -> [L*m, w] (drop the padding sequences)."""
+    if seq["m_pad"] == seq["m"]:
+        return t
+    w = t.shape[1:] if t.dim() > 1 else ()
+    return t.reshape(seq["L"], seq["m_pad"], *w)[:, :seq["m"]].reshape(seq["L"] * seq["m"], *w)
+
+
 class FusedAdam:
     """torch.optim.Adam semantics (defaults betas=(0.9,0.999), amsgrad=False) over one flat arena, fused with
     the gradient-norm / clip step into a single launch (harl_gradnorm_clip_adam).  Exposes ``param_groups`` so the
@@ -374,7 +522,7 @@ class FusedAdam:
         bc2 = 1.0 - b2 ** self.step_count
         n = self.net
         call("harl_adam_fold", ptr(n.flat_param), ptr(n.flat_grad), ptr(self.exp_avg), ptr(self.exp_avg_sq), n.n_params,
-             ptr(n.dwp), ptr(n.table), len(n.hidden_sizes) + 1, ptr(n.pack_arena), ptr(n.scalars), int(mode),
+             ptr(n.dwp), ptr(n.table), n.n_entries, ptr(n.pack_arena), ptr(n.scalars), int(mode),
              float(const_scale), int(logstd_off), int(act_dim), ptr(info_out), int(use_clip), float(max_norm),
              float(g["lr"]), float(b1), float(b2), float(g["eps"]), float(g["weight_decay"]), bc1, bc2, stream(),
              tag="adam_fold")

@@ -118,14 +118,15 @@ class OnPolicyHARunner:
             if self._logp_old is None or self._logp_old.shape != (B, actor.actor.act_w):
                 self._logp_old = torch.empty(B, actor.actor.act_w, dtype=torch.float32, device=dev)
             actor.actor.fold()
-            actor._logp_pass(obs, actions, avail, B, self._logp_old)            # pre-update log-probs (:66-83)
+            rnn_kw = dict(rnn_states=buf.rnn_states[0], masks=buf.flat("masks")) if actor.actor.recurrent else {}
+            actor._logp_pass(obs, actions, avail, B, self._logp_old, **rnn_kw)  # pre-update log-probs (:66-83)
             if self.state_type == "EP":
                 actor_train_infos.append(actor.train(buf, advantages, "EP"))  # :86-93
             else:
                 actor_train_infos.append(actor.train(buf, advantages[:, :, agent_id].contiguous(), "FP"))
             new_factor = factor.clone()
             # post-update log-probs fused with factor *= agg(exp(new - old))   (:96-124)
-            actor._logp_pass(obs, actions, avail, B, None, old_logp=self._logp_old, factor=new_factor.reshape(B))
+            actor._logp_pass(obs, actions, avail, B, None, old_logp=self._logp_old, factor=new_factor.reshape(B), **rnn_kw)
             factor = new_factor
         critic_train_info = self.critic.train(self.critic_buffer, self.value_normalizer)
         return actor_train_infos, critic_train_info

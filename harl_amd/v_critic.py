@@ -9,7 +9,7 @@ from . import _lib
 from ._lib import PS_STRIDE, call, ptr, stream
 from .buffers import OnPolicyCriticBufferEP, consume_randperm, minibatch_indices
 from .dist import Comm, local_minibatch_rows
-from .nets import FusedAdam, VNet
+from .nets import FusedAdam, VNet, build_seq
 from .valuenorm import ValueNorm, _as_dev
 
 
@@ -50,32 +50,50 @@ class VCritic:
             g["lr"] = lr
 
     def get_values(self, cent_obs, rnn_states_critic, masks):
-        """values [B, 1] (device) = VNet(cent_obs)  (v_critic.py:62-73, v_net.py:48-67)."""
+        """values [B, 1] (device) = VNet(cent_obs)  (v_critic.py:62-73, v_net.py:48-67); recurrent nets also return the
+        next hidden state [B, 1, H] (single GRU step when B == rnn_states.shape[0], rnn.py:24-33)."""
         x = _as_dev(cent_obs, self.device)
         x = x.reshape(x.shape[0], -1)
         M = x.shape[0]
         net = self.critic
         net.fold()
-        net.forward_trunk(x, None, M, for_backward=False)
         Wp, bp = net._packs[-1]
         out = torch.empty(M, 1, **self.tpdv)
-        call("harl_critic_head_values", ptr(net.xh[-1]), M, net.hidden_sizes[-1], ptr(Wp), ptr(bp), ptr(out), stream())
-        return out, rnn_states_critic
+        if not net.recurrent:
+            net.forward_trunk(x, None, M, for_backward=False)
+            call("harl_critic_head_values", ptr(net.xh[-1]), M, net.hidden_sizes[-1], ptr(Wp), ptr(bp), ptr(out), stream())
+            return out, rnn_states_critic
+        H = net.hidden_sizes[-1]
+        h0 = _as_dev(rnn_states_critic, self.device)
+        m = h0.shape[0]
+        seq = build_seq(self.device, M // m, m, H, h0=h0.reshape(m, H), masks_src=_as_dev(masks, self.device),
+                        want_h_last=True)
+        Mp = seq["L"] * seq["m_pad"]
+        net.forward_trunk(x, seq["idx"], Mp, for_backward=False, seq=seq)
+        fx, _, _, fh = net.feat()
+        outp = out if seq["idx"] is None else torch.empty(Mp, 1, **self.tpdv)
+        call("harl_critic_head_values", ptr(fx), Mp, fh, ptr(Wp), ptr(bp), ptr(outp), stream())
+        if seq["idx"] is not None:
+            out.copy_(outp.reshape(seq["L"], seq["m_pad"], 1)[:, :m].reshape(M, 1))
+        return out, seq["h_last"][:m].reshape(m, 1, H).clone()
 
-    def _update_core(self, share_obs, idx, m, m_global, value_preds, returns, vn: Optional[ValueNorm]):
+    def _update_core(self, share_obs, idx, m, m_global, value_preds, returns, vn: Optional[ValueNorm], seq=None):
         net = self.critic
         s = stream()
         if vn is not None:  # ValueNorm.update runs on this minibatch's returns BEFORE the targets are normalised
-            vn.update(returns, idx, count=m_global, reduce_fn=self.comm.all_reduce_sum if self.comm.enabled else None)
-        net.forward_trunk(share_obs, idx, m)
+            vidx = seq["valid_idx"] if seq is not None else idx
+            vn.update(returns, vidx, count=m_global, reduce_fn=self.comm.all_reduce_sum if self.comm.enabled else None)
+        net.forward_trunk(share_obs, idx, m, seq=seq)
         Wp, bp = net._packs[-1]
-        call("harl_critic_head_loss", ptr(net.xh[-1]), ptr(net.rmask[-1]), ptr(net.rstd[-1]), m, net.hidden_sizes[-1],
+        fx, fmask, frstd, fh = net.feat()
+        mv, mp = (seq["m"], seq["m_pad"]) if seq is not None else (0, 0)
+        call("harl_critic_head_loss", ptr(fx), ptr(fmask), ptr(frstd), m, fh,
              ptr(Wp), ptr(bp), ptr(idx), ptr(value_preds), ptr(returns), ptr(vn.stats) if vn is not None else None,
              float(self.clip_param), int(self.use_clipped_value_loss), int(self.use_huber_loss), float(self.huber_delta),
-             ptr(net.dz[0]), ptr(net.dhead), ptr(net.part_scalars), s, tag="critic_head_loss")
+             mv, mp, ptr(net.dz[0]), ptr(net.dhead), ptr(net.part_scalars), s, tag="critic_head_loss")
         net.scalars.zero_()
         call("harl_reduce_scalars", ptr(net.part_scalars), _lib.load().harl_head_blocks(m), ptr(net.scalars), s)
-        net.backward_trunk(share_obs, idx, m)
+        net.backward_trunk(share_obs, idx, m, seq=seq)
         sc = net.scalars
         if self.comm.enabled:
             if self._staging is None:
@@ -95,6 +113,14 @@ class VCritic:
         m = x.shape[0]
         before = self._info.clone()
         self.critic.fold()
+        if self.critic.recurrent:
+            H = self.critic.hidden_sizes[-1]
+            h0 = _as_dev(_rnn, dev)
+            seq = build_seq(dev, m // h0.shape[0], h0.shape[0], H, h0=h0.reshape(-1, H), masks_src=_as_dev(_masks, dev))
+            self._update_core(x.reshape(m, -1), seq["idx"], seq["L"] * seq["m_pad"], m, _as_dev(value_preds, dev).reshape(m),
+                              _as_dev(returns, dev).reshape(m), value_normalizer, seq=seq)
+            d = self._info - before
+            return d[0], d[1]
         self._update_core(x.reshape(m, -1), None, m, m, _as_dev(value_preds, dev).reshape(m),
                           _as_dev(returns, dev).reshape(m), value_normalizer)
         d = self._info - before
@@ -115,7 +141,11 @@ class VCritic:
         n_global = self.shard[0] * T * (A or 1) if self.shard else B
         for _ in range(self.critic_epoch):
             if self.use_recurrent_policy or self.use_naive_recurrent_policy:
-                raise NotImplementedError("recurrent generators are not implemented in this round")
+                for seq in buf.recurrent_batches(self.critic_num_mini_batch, self.data_chunk_length,
+                                                 naive=not self.use_recurrent_policy, shard=self.shard):
+                    self._update_core(share_obs, seq["idx"], seq["L"] * seq["m_pad"], seq["L"] * seq["m"], value_preds,
+                                      returns, value_normalizer, seq=seq)
+                continue
             if self.critic_num_mini_batch == 1:
                 consume_randperm(n_global)  # replay the generator state only (see HAPPO.train)
                 self._update_core(share_obs, None, B, n_global, value_preds, returns, value_normalizer)

@@ -91,10 +91,11 @@ int harl_gradnorm_clip_adam(float *param, float *grad, float *exp_avg, float *ex
 int harl_fold_linear(const float *W, const float *b, const float *gamma, const float *beta, float *Wp,
                      float *bp, int out_dim, int in_dim, void *stream);
 /* dW = dWp*gamma + dbp (x) beta ; db = dbp ; dgamma[k] = sum_o W[o,k] dWp[o,k] ; dbeta[k] = sum_o W[o,k] dbp[o]
- * dWp has row stride ldp (>= in_dim).  dgamma/dbeta may be NULL. */
+ * dWp has row stride ldp (>= in_dim).  dgamma/dbeta may be NULL; accumulate != 0 adds into them (Linears sharing one
+ * LayerNorm, e.g. the three GRU gate blocks). */
 int harl_unfold_linear_grads(const float *dWp, const float *dbp, int ldp, const float *W, const float *gamma,
                              const float *beta, float *dW, float *db, float *dgamma, float *dbeta,
-                             int out_dim, int in_dim, void *stream);
+                             int out_dim, int in_dim, int accumulate, void *stream);
 
 /* first layer: x_hat1 = norm(relu(Wp * norm0(X[idx]) + bp))
  *   X[rows, ldx] row-major, D features; use_ln0: feature LayerNorm on the input (mlp.py:57-58,65-66)
@@ -162,7 +163,7 @@ int harl_adam_fold(float *param, float *grad, float *exp_avg, float *exp_avg_sq,
 int harl_actor_head_logp(const float *xL, long M, int H, const float *Whp, const float *bhp,
                          const float *log_std, float std_x_coef, float std_y_coef, int discrete, int act_dim,
                          const float *actions, const float *avail, float *logp_out, const float *old_logp,
-                         float *factor, int agg_mean, float *head_out, void *stream);
+                         float *factor, int agg_mean, float *head_out, long m_valid, long m_pad, void *stream);
 /* HAPPO.update loss forward + backward (algorithms/actors/happo.py:28-102), everything up to dz_L:
  *   inputs gathered by idx: actions, old_logp[rows,act_w], adv[rows] (raw), adv_moments (double[3], NULL = adv
  *   already normalised), factor[rows], active[rows] (NULL = ones / use_policy_active_masks False)
@@ -179,18 +180,21 @@ int harl_actor_head_loss(const float *xL, const uint32_t *relu_mask, const float
                          float std_y_coef, int discrete, int act_dim, const int64_t *idx, const float *actions,
                          const float *avail, const float *old_logp, const float *adv, const double *adv_moments,
                          const float *factor, const float *active, float clip_param, float entropy_coef,
-                         int agg_mean, int trpo, float *dzL, float *dhead, float *part_scalars, void *stream);
+                         int agg_mean, int trpo, long m_valid, long m_pad, float *dzL, float *dhead, float *part_scalars,
+                         void *stream);
 /* V head forward: values[M] = Whp . xL + bhp   (v_net.py:64) */
 int harl_critic_head_values(const float *xL, long M, int H, const float *Whp, const float *bhp, float *values,
                             void *stream);
+/* Row validity for recurrent batches (all head kernels): with m_pad > 0, row j counts only if (j % m_pad) < m_valid
+ * (padding sequences inside every time step); m_pad = 0 means plain j < M. */
 /* VCritic.cal_value_loss forward + backward (algorithms/critics/v_critic.py:75-114), up to dz_L (UNSCALED by
  * value_loss_coef / m).  vn_stats NULL = no ValueNorm (it must already contain this step's update).
  * part_scalars[harl_head_blocks(M)][HARL_PS_STRIDE]: {0: sum loss, 1: count} */
 int harl_critic_head_loss(const float *xL, const uint32_t *relu_mask, const float *rstd, long M, int H,
                           const float *Whp, const float *bhp, const int64_t *idx, const float *value_preds,
                           const float *returns, const float *vn_stats, float clip_param, int use_clipped,
-                          int use_huber, float huber_delta, float *dzL, float *dhead, float *part_scalars,
-                          void *stream);
+                          int use_huber, float huber_delta, long m_valid, long m_pad, float *dzL, float *dhead,
+                          float *part_scalars, void *stream);
 /* ---------------------------------------------------------------------------------------------
  * HATRPO (algorithms/actors/hatrpo.py:37-194, utils/trpo_util.py:47-158).  The Fisher-vector product
  * F v = grad((grad KL) . v) is evaluated as J^T M (J v) (exact at theta_new == theta_old, where KL's first-order terms
@@ -220,6 +224,25 @@ int harl_actor_head_fvp(const float *xL, const float *xLdot, const uint32_t *rel
 int harl_trpo_kl_sum(const float *head_old, const float *head_new, const float *log_std_old, const float *log_std_new,
                      float std_x_coef, float std_y_coef, long M, int act_dim, int discrete, double *out_sum,
                      void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * GRU recurrent layer (models/base/rnn.py:8-81, recurrent_n = 1, H = 64), forward and BPTT.  A recurrent batch is L steps x m
+ * sequences with row (l, j) at index l*m_pad + j (m_pad = m rounded up to 32); a wave owns 32 sequences for the whole chunk and
+ * keeps the hidden state in registers.  xin / y / saved tensors are ATL(H) over L*m_pad rows; mask_rows[L*m_pad] are the
+ * reset masks in that row order; h0 / h_last are row-major [m_pad, H].  Wih is the FOLDED input matrix (LayerNorm affine of the
+ * last MLP layer folded in), gate order r, z, n.  y = normalised h (rnn.norm's affine part is folded into the head).
+ * save != 0 stores h~ = h*mask, r, z, n, hn for the backward pass.
+ */
+int harl_gru_fwd(const float *xin, const float *mask_rows, const float *h0, const float *Wih, const float *bih,
+                 const float *Whh, const float *bhh, int H, int L, long m_pad, float *y, float *rstd_y, float *hpm, float *r,
+                 float *z, float *n, float *hn, float *h_last, int save, void *stream);
+/* dhout = d(loss)/d(h_l) through the output path (after the rnn.norm backward, done by the head kernels with an all-ones relu
+ * mask).  Outputs the gate gradients dr, dz, dn (d gi = [dr,dz,dn]) and dhn (d gh = [dr,dz,dhn]) as ATL(H) for
+ * harl_mlp_dw_partials, and dz_mlp = LayerNorm/ReLU backward of W_ih'^T dgi for the last MLP layer (xmlp / mask_mlp / rstd_mlp). */
+int harl_gru_bwd(const float *dhout, const float *mask_rows, const float *Wih, const float *Whh, const float *hpm,
+                 const float *r, const float *z, const float *n, const float *hn, int H, int L, long m_pad,
+                 const float *xmlp, const uint32_t *mask_mlp, const float *rstd_mlp, float *dr, float *dz, float *dn,
+                 float *dhn, float *dz_mlp, void *stream);
 
 /* number of workgroups (= rows of part_scalars) the head-loss kernels use for M samples */
 int harl_head_blocks(long M);

@@ -160,12 +160,16 @@ def check_adam() -> Dict[str, float]:
 
 
 # ------------------------------------------------------------------------------------------------
+def _is_rnn(args) -> bool:
+    return bool(args["use_recurrent_policy"] or args["use_naive_recurrent_policy"])
+
+
 def _mk_actor(sh: Shapes, seed: int, **over):
     from harl_amd.happo import HAPPO
     args = default_args(sh.hidden_sizes, **over)
     space = Discrete(sh.act_dim) if sh.discrete else Box((sh.act_dim,))
     a = HAPPO(args, Box((sh.obs_dim,)), space, device=DEV)
-    sd = synthetic_state_dict(actor_param_shapes(sh, args["use_feature_normalization"]), seed, args["std_x_coef"])
+    sd = synthetic_state_dict(actor_param_shapes(sh, args["use_feature_normalization"], _is_rnn(args)), seed, args["std_x_coef"])
     assert list(sd.keys()) == list(a.actor.state_dict().keys()), (list(sd.keys()), list(a.actor.state_dict().keys()))
     a.actor.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     return a, sd, args
@@ -175,7 +179,7 @@ def _mk_critic(sh: Shapes, seed: int, **over):
     from harl_amd.v_critic import VCritic
     args = default_args(sh.hidden_sizes, **over)
     c = VCritic(args, Box((sh.share_obs_dim,)), device=DEV)
-    sd = synthetic_state_dict(critic_param_shapes(sh, args["use_feature_normalization"]), seed)
+    sd = synthetic_state_dict(critic_param_shapes(sh, args["use_feature_normalization"], _is_rnn(args)), seed)
     assert list(sd.keys()) == list(c.critic.state_dict().keys())
     c.critic.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     return c, sd, args
@@ -344,6 +348,105 @@ def check_gradients(spec, mini_batches: int = 1, agg: str = "prod", inactive_p: 
     return out
 
 
+RNN_SHAPES = [  # (L, m): m = 40 pads to 64 sequences, m = 64 is the identity layout, m = 7 a single ragged slab
+    dict(name="rnn_box_L10_m40", obs_dim=18, share_obs_dim=54, act_dim=5, discrete=False, hidden_sizes=[64, 64], L=10, m=40),
+    dict(name="rnn_disc_L5_m64", obs_dim=30, share_obs_dim=20, act_dim=9, discrete=True, hidden_sizes=[64], L=5, m=64),
+    dict(name="rnn_box_L25_m7_h128_64", obs_dim=70, share_obs_dim=11, act_dim=2, discrete=False, hidden_sizes=[128, 64], L=25, m=7),
+    dict(name="rnn_step_m50", obs_dim=18, share_obs_dim=54, act_dim=5, discrete=False, hidden_sizes=[64, 64], L=1, m=50),
+]
+
+
+def check_rnn_update(spec) -> Dict[str, float]:
+    """GRU policies: evaluate_actions / get_values (L-step unroll with mask resets) and ONE HAPPO.update + ONE
+    VCritic.update on an [L*m] recurrent minibatch vs the oracle (autograd through the explicit GRU)."""
+    out = {}
+    L, m = spec["L"], spec["m"]
+    M = L * m
+    H = spec["hidden_sizes"][-1]
+    over = dict(use_recurrent_policy=True)
+    sh = Shapes(T=L, N=m, A=1, obs_dim=spec["obs_dim"], share_obs_dim=spec["share_obs_dim"], act_dim=spec["act_dim"],
+                discrete=spec["discrete"], hidden_sizes=spec["hidden_sizes"])
+    d = make_buffers(sh, 61, inactive_p=0.2, unavailable_p=0.25 if sh.discrete else 0.0, rnn=True)
+    actor, sd, args = _mk_actor(sh, 17, **over)
+    cfg = O.PathConfig.from_reference_dicts({}, args, args)
+    rng = np.random.default_rng(8)
+    obs = d.obs[0][:-1].reshape(M, -1)          # row = l*m + j, the recurrent minibatch order
+    masks = d.masks[0][:-1].reshape(M, 1)
+    h0 = d.rnn["actor"][0][0]                    # [m, 1, H]
+    act = d.actions[0].reshape(M, -1)
+    avail = None if not sh.discrete else d.available_actions[0][:-1].reshape(M, -1)
+    active = d.active_masks[0][:-1].reshape(M, 1)
+    oracle = O.OracleHAPPO({k: torch.from_numpy(v) for k, v in sd.items()}, cfg)
+    with torch.no_grad():
+        lp, _, _ = oracle.evaluate_actions(obs, act, avail, None, h0, masks)
+    got, _, _ = actor.evaluate_actions(obs, h0, act, masks, avail, None)
+    torch.cuda.synchronize()
+    out["logp_vec_rel"] = vec_rel_err(got.cpu().numpy(), lp.numpy())
+    old_logp = (lp.numpy() + 0.15 * rng.standard_normal(lp.shape)).astype(np.float32)
+    adv = rng.standard_normal((M, 1)).astype(np.float32)
+    factor = (1 + 0.2 * rng.standard_normal((M, 1))).astype(np.float32)
+    pl, ent, gn, imp, g = oracle.update((obs, act, active, old_logp, adv, avail, factor, h0, masks), keep_grad=True)
+    taps = []
+    actor._grad_tap = lambda gr, sc: taps.append((gr.clone(), sc))
+    res = actor.update((obs, h0, act, masks, active, old_logp, adv, avail, factor))
+    torch.cuda.synchronize()
+    gg = taps[0][0].cpu().numpy()
+    out["actor_grad_vec_rel"] = vec_rel_err(gg, g)
+    worst, off = ("", 0.0), 0
+    for name, shp in actor_param_shapes(sh, args["use_feature_normalization"], True):
+        n = int(np.prod(shp))
+        e = vec_rel_err(gg[off:off + n], g[off:off + n]) if np.max(np.abs(g[off:off + n])) > 0 else 0.0
+        if e > worst[1]:
+            worst = (name, e)
+        off += n
+    out["actor_grad_worst_tensor_rel"] = worst[1]
+    out["_actor_grad_worst_tensor"] = worst[0]
+    out["actor_loss_rel"] = rel_err(res[0].item(), pl.item())
+    out["actor_entropy_rel"] = rel_err(res[1].item(), ent.item())
+    out["actor_gradnorm_rel"] = rel_err(res[2].item(), float(gn))
+    # Adam's first step is lr*g/(|g|+eps): elements whose gradient is ~eps-sized amplify fp32 rounding of g by lr/eps = 50
+    # (tools/rnn_diag.py), so the post-step comparison is restricted to |g| > 1e-4; the rest must stay within one lr.
+    pa, po = actor.actor.flat_param.cpu().numpy(), oracle.net.flat()
+    big = np.abs(g) > 1e-4
+    out["actor_param_after_vec_rel"] = vec_rel_err(pa[big], po[big])
+    out["actor_param_after_small_g_excess"] = float(max(0.0, np.max(np.abs(pa - po)) - 2 * args["lr"]))
+
+    critic, csd, cargs = _mk_critic(sh, 23, **over)
+    oc = O.OracleVCritic({k: torch.from_numpy(v) for k, v in csd.items()}, cfg)
+    so = d.share_obs[:-1].reshape(M, -1)
+    ch0 = d.rnn["critic"][0]
+    cmask = d.critic_masks[:-1].reshape(M, 1)
+    with torch.no_grad():
+        v0 = O.critic_forward(oc.net.p, torch.from_numpy(so), torch.from_numpy(ch0), torch.from_numpy(cmask)).numpy()
+    vgot, hnew = critic.get_values(so, ch0, cmask)
+    torch.cuda.synchronize()
+    out["values_vec_rel"] = vec_rel_err(vgot.cpu().numpy(), v0)
+    if L == 1:  # single step: the returned hidden state is the GRU output before rnn.norm
+        with torch.no_grad():
+            feat = O.mlp_base_forward(oc.net.p, torch.from_numpy(so))
+            _, href = O.rnn_layer_forward(oc.net.p, feat, torch.from_numpy(ch0), torch.from_numpy(cmask))
+        out["hidden_state_vec_rel"] = vec_rel_err(hnew.cpu().numpy(), href.numpy())
+    vp = (v0 + 0.3 * rng.standard_normal(v0.shape)).astype(np.float32)
+    ret = (3.0 * rng.standard_normal(v0.shape) + 1.0).astype(np.float32)
+    ovn = O.OracleValueNorm()
+    ovn.load_state(dict(running_mean=0.15, running_mean_sq=0.85, debiasing_term=0.5))
+    from harl_amd.valuenorm import ValueNorm
+    gvn = ValueNorm(1, device=DEV)
+    gvn.stats.copy_(dev(np.array([0.15, 0.85, 0.5], dtype=np.float32)))
+    loss, cgn, cg = oc.update((so, vp, ret, ch0, cmask), ovn, keep_grad=True)
+    ctaps = []
+    critic._grad_tap = lambda gr, sc: ctaps.append(gr.clone())
+    cres = critic.update((so, ch0, vp, ret, cmask), gvn)
+    torch.cuda.synchronize()
+    out["critic_grad_vec_rel"] = vec_rel_err(ctaps[0].cpu().numpy(), cg)
+    out["critic_loss_rel"] = rel_err(cres[0].item(), loss.item())
+    out["critic_gradnorm_rel"] = rel_err(cres[1].item(), float(cgn))
+    pa, po = critic.critic.flat_param.cpu().numpy(), oc.net.flat()
+    big = np.abs(cg) > 1e-4
+    out["critic_param_after_vec_rel"] = vec_rel_err(pa[big], po[big])
+    return out
+
+
 def check_trpo(spec, agg: str = "prod") -> Dict[str, float]:
     """HATRPO: surrogate gradient, one Fisher-vector product on a random vector, and one full update (CG + line
     search) vs the oracle (autograd double backward), from identical parameters and data."""
@@ -435,6 +538,10 @@ def build_runner(case: GoldenCase):
         b.active_masks.copy_(dev(d.active_masks[a]))
         if sh.discrete:
             b.available_actions.copy_(dev(d.available_actions[a]))
+        if d.rnn is not None:
+            b.rnn_states.copy_(dev(d.rnn["actor"][a]))
+    if d.rnn is not None:
+        r.critic_buffer.rnn_states_critic.copy_(dev(d.rnn["critic"]))
     r.critic.critic.load_state_dict({k: torch.from_numpy(v) for k, v in case.critic_sd.items()})
     cb = r.critic_buffer
     if case.state_type == "FP":

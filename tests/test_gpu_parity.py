@@ -90,3 +90,17 @@ def test_rollout_get_actions(i):
             assert v < 0.05, (k, v)
         else:
             assert v < TOL, (k, v)
+
+
+@pytest.mark.parametrize("i", range(4))
+def test_gru_policy_forward_and_update(i):
+    """GRU policies (rnn.py): L-step unroll with mask resets, BPTT, shared-LayerNorm unfold -- one actor and one critic
+    update vs the oracle; padded (m % 32 != 0) and identity sequence layouts, single-step rollout calls."""
+    G = _G()
+    _assert_all(G.check_rnn_update(G.RNN_SHAPES[i]), tol=2e-5)
+
+
+@pytest.mark.parametrize("name", ["rnn_box_h64", "rnn_disc_h64_mb2", "rnn_naive_h64"])
+def test_recurrent_train_matches_reference_golden(name):
+    """Chunked and naive recurrent samplers + GRU actor/critic through a whole OnPolicyHARunner.train() vs the reference."""
+    _assert_all(_G().check_train_golden(name), tol=TOL_TRAIN)

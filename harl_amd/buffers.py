@@ -9,6 +9,8 @@ in the same order; only the resulting int64 index arrays are uploaded.
 """
 from __future__ import annotations
 
+import queue
+import threading
 from typing import Iterator, List, Optional, Tuple
 
 import numpy as np
@@ -61,18 +63,62 @@ def _advance_matches_randperm() -> bool:
     return _ADVANCE_OK
 
 
-def consume_randperm(batch_size: int) -> None:
+class _RngWorker:
+    """FIFO background replay of generator advances.  ``Tensor.random_`` releases the GIL, so the ~0.6 ms per
+    819200-draw advance overlaps with the kernel launches of the update it belongs to instead of stalling the GPU
+    (20 advances per MPE train()).  Nothing else may touch the global CPU generator until ``rng_sync()`` returns;
+    every RNG consumer in this package calls it first and ``train()`` calls it before returning."""
+
+    def __init__(self):
+        self._q: "queue.Queue[int]" = queue.Queue()
+        self._t = threading.Thread(target=self._run, name="harl-rng-replay", daemon=True)
+        self._t.start()
+
+    def _run(self):
+        while True:
+            n = self._q.get()
+            try:
+                torch.empty(n, dtype=torch.int32).random_()
+            finally:
+                self._q.task_done()
+
+    def submit(self, n: int) -> None:
+        self._q.put(n)
+
+    def drain(self) -> None:
+        self._q.join()
+
+
+_RNG_WORKER: Optional[_RngWorker] = None
+
+
+def rng_sync() -> None:
+    """Wait until every deferred generator advance has been applied (call before ANY use of the global CPU RNG)."""
+    if _RNG_WORKER is not None:
+        _RNG_WORKER.drain()
+
+
+def consume_randperm(batch_size: int, deferred: bool = True) -> None:
     """Advance the global CPU generator exactly as ``torch.randperm(batch_size)`` would, without materialising
     the permutation.  Used when ``num_mini_batch == 1``: the single minibatch is the whole buffer, so the update
     does not depend on the order, but every later draw of the run (agent order, next epoch's permutation) must
     still see the same generator state as in the reference.  randperm(819200) costs ~30-70 ms of host time per
-    draw (20 draws per train()); this costs ~2 ms.  Falls back to a real randperm if the self-check fails."""
+    draw (20 draws per train()); the advance costs ~0.6 ms and runs on the replay thread (``_RngWorker``).
+    Falls back to a real randperm if the self-check fails."""
+    global _RNG_WORKER
     if batch_size <= 1:
         return
-    if _advance_matches_randperm():
-        torch.empty(batch_size - 1, dtype=torch.int32).random_()
-    else:
+    if not _advance_matches_randperm():
+        rng_sync()
         torch.randperm(batch_size)
+        return
+    if not deferred or batch_size < 65536:
+        rng_sync()
+        torch.empty(batch_size - 1, dtype=torch.int32).random_()
+        return
+    if _RNG_WORKER is None:
+        _RNG_WORKER = _RngWorker()
+    _RNG_WORKER.submit(batch_size - 1)
 
 
 def minibatch_indices(batch_size: int, num_mini_batch: int) -> List[torch.Tensor]:
@@ -81,6 +127,7 @@ def minibatch_indices(batch_size: int, num_mini_batch: int) -> List[torch.Tensor
     assert batch_size >= num_mini_batch, (
         f"batch size ({batch_size}) must be >= the number of mini batches ({num_mini_batch})")
     m = batch_size // num_mini_batch
+    rng_sync()
     rand = torch.randperm(batch_size)
     return [rand[i * m:(i + 1) * m] for i in range(num_mini_batch)]
 
@@ -93,6 +140,7 @@ def recurrent_first_rows(T: int, N: int, num_mini_batch: int, data_chunk_length:
     if naive:
         assert N >= num_mini_batch, f"n_rollout_threads ({N}) must be >= num_mini_batch ({num_mini_batch})"
         per = N // num_mini_batch
+        rng_sync()
         perm = torch.randperm(N)
         for b in range(num_mini_batch):
             yield perm[b * per:(b + 1) * per], T
@@ -183,6 +231,7 @@ class OnPolicyActorBuffer:
         if mini_batch_size is None:
             sampler = minibatch_indices(B, actor_num_mini_batch)
         else:
+            rng_sync()
             rand = torch.randperm(B)
             sampler = [rand[i * mini_batch_size:(i + 1) * mini_batch_size] for i in range(actor_num_mini_batch)]
         adv = None if advantages is None else _as_dev(advantages, self.device).reshape(-1, 1)
@@ -278,6 +327,7 @@ class OnPolicyCriticBufferEP:
         if mini_batch_size is None:
             sampler = minibatch_indices(B, critic_num_mini_batch)
         else:
+            rng_sync()
             rand = torch.randperm(B)
             sampler = [rand[i * mini_batch_size:(i + 1) * mini_batch_size] for i in range(critic_num_mini_batch)]
         for ind in sampler:
@@ -339,6 +389,7 @@ class OnPolicyCriticBufferFP(OnPolicyCriticBufferEP):
         if mini_batch_size is None:
             sampler = minibatch_indices(B, critic_num_mini_batch)
         else:
+            rng_sync()
             rand = torch.randperm(B)
             sampler = [rand[i * mini_batch_size:(i + 1) * mini_batch_size] for i in range(critic_num_mini_batch)]
         for ind in sampler:

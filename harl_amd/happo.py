@@ -15,7 +15,7 @@ import torch
 
 from . import _lib
 from ._lib import PS_STRIDE, call, ptr, stream
-from .buffers import OnPolicyActorBuffer, consume_randperm, minibatch_indices
+from .buffers import OnPolicyActorBuffer, consume_randperm, minibatch_indices, rng_sync
 from .dist import Comm, local_minibatch_rows
 from .nets import FusedAdam, StochasticPolicy, build_seq, seq_compact
 from .valuenorm import _as_dev
@@ -214,21 +214,36 @@ class HAPPO(OnPolicyBase):
         d = self._info - before
         return d[0], d[1], d[2], d[3]
 
-    def train(self, actor_buffer: OnPolicyActorBuffer, advantages, state_type):
+    _INFO_KEYS = ("policy_loss", "dist_entropy", "actor_grad_norm", "ratio")
+
+    def masked_moments(self, actor_buffer: OnPolicyActorBuffer, advantages, out: torch.Tensor) -> None:
+        """fp64 {sum, sumsq, count} of ``advantages`` over this agent's active entries (happo.py:119-127) -> out[3]."""
+        T, N = actor_buffer.actions.shape[:2]
+        adv = _as_dev(advantages, self.device).reshape(T * N)
+        call("harl_masked_moments", ptr(adv), ptr(actor_buffer.flat("active_masks")), T * N, ptr(out), stream())
+
+    def train(self, actor_buffer: OnPolicyActorBuffer, advantages, state_type, _pre=None, _defer=False):
         """ppo_epoch x actor_num_mini_batch updates (happo.py:104-158).  ``advantages`` is the raw [T, N, 1]
         advantage tensor; the per-agent masked normalisation (happo.py:122-127) is folded into the loss kernel
-        through the fp64 moments {sum, sumsq, count}."""
+        through the fp64 moments {sum, sumsq, count}.
+        Runner-internal: ``_pre = (moments[3] device fp64, count)`` when the runner already reduced the moments of all
+        agents with one read-back; ``_defer`` returns the averaged statistics as a device tensor (resolved by the
+        runner in one transfer at the end of train()) and leaves deferred RNG advances pending."""
         dev = self.device
         buf = actor_buffer
         T, N = buf.actions.shape[:2]
         B = T * N
-        train_info = {"policy_loss": 0.0, "dist_entropy": 0.0, "actor_grad_norm": 0.0, "ratio": 0.0}
+        train_info = {k: 0.0 for k in self._INFO_KEYS}
         adv = _as_dev(advantages, dev).reshape(B).contiguous()
         active = buf.flat("active_masks").reshape(B)
-        moments = torch.zeros(3, dtype=torch.float64, device=dev)
-        call("harl_masked_moments", ptr(adv), ptr(active), B, ptr(moments), stream())
-        self.comm.all_reduce_sum(moments)
-        if float(moments[2].item()) == 0.0:  # np.all(active_masks[:-1] == 0) early-out (happo.py:119-120)
+        if _pre is None:
+            moments = torch.zeros(3, dtype=torch.float64, device=dev)
+            self.masked_moments(buf, adv, moments)
+            self.comm.all_reduce_sum(moments)
+            count = float(moments[2].item())
+        else:
+            moments, count = _pre
+        if count == 0.0:  # np.all(active_masks[:-1] == 0) early-out (happo.py:119-120)
             return train_info
         if state_type != "EP":  # FP: the runner already normalised over all agents (on_policy_ha_runner.py:36-45)
             moments = None
@@ -261,8 +276,11 @@ class HAPPO(OnPolicyBase):
                 self._update_core(obs, ind.to(dev), ind.numel(), actions, avail, old_logp, adv, moments, factor,
                                   active if self.use_policy_active_masks else None)
         n_upd = self.ppo_epoch * self.actor_num_mini_batch
+        if _defer:
+            return self._info / n_upd
+        rng_sync()
         vals = (self._info / n_upd).cpu().tolist()  # the single read-back of this agent's update
-        for k, v in zip(("policy_loss", "dist_entropy", "actor_grad_norm", "ratio"), vals):
+        for k, v in zip(self._INFO_KEYS, vals):
             train_info[k] = v
         return train_info
 

@@ -16,7 +16,7 @@ import torch
 
 from . import _lib
 from ._lib import call, ptr, stream
-from .buffers import OnPolicyActorBuffer, consume_randperm
+from .buffers import OnPolicyActorBuffer, consume_randperm, rng_sync
 from .happo import OnPolicyBase
 from .nets import consume_policy_init_rng
 from .valuenorm import _as_dev
@@ -201,7 +201,7 @@ class HATRPO(OnPolicyBase):
     def train(self, actor_buffer: OnPolicyActorBuffer, advantages, state_type):
         """One full-batch update (hatrpo.py:196-247)."""
         if self.use_recurrent_policy or self.use_naive_recurrent_policy:
-            raise NotImplementedError("recurrent generators are not implemented in this round")
+            raise NotImplementedError("HATRPO with GRU policies (the FVP needs a recurrent tangent pass)")
         dev = self.device
         buf = actor_buffer
         T, N = buf.actions.shape[:2]
@@ -223,4 +223,5 @@ class HATRPO(OnPolicyBase):
             None if buf.available_actions is None else buf.flat("available_actions"), buf.flat("action_log_probs"), adv,
             moments, buf.factor.reshape(B), active if self.use_policy_active_masks else None)
         info.update(kl=kl, dist_entropy=ent, loss_improve=li, expected_improve=ei, ratio=ratio)
+        rng_sync()
         return info

@@ -440,6 +440,8 @@ def consume_policy_init_rng(args: dict, obs_space, action_space) -> None:
     order) without allocating anything on the device.  HATRPO.update builds a fresh policy object as its "old actor"
     snapshot on every call (algorithms/actors/hatrpo.py:127-130); those draws are part of the RNG stream of train()
     and must happen for the later minibatch permutations / agent orders to match the reference."""
+    from .buffers import rng_sync
+    rng_sync()
     init = getattr(nn.init, args["initialization_method"])
     gain = nn.init.calculate_gain("relu")
     d = _space_shape(obs_space)[0]

@@ -13,7 +13,7 @@ from typing import List, Optional
 import torch
 
 from . import _lib
-from .buffers import OnPolicyActorBuffer, OnPolicyCriticBufferEP, OnPolicyCriticBufferFP
+from .buffers import OnPolicyActorBuffer, OnPolicyCriticBufferEP, OnPolicyCriticBufferFP, rng_sync
 from ._lib import call, ptr, stream
 from .dist import Comm, shard_columns
 from .happo import HAA2C, HAPPO
@@ -109,7 +109,19 @@ class OnPolicyHARunner:
         if self.fixed_order:
             agent_order = list(range(self.num_agents))
         else:
+            rng_sync()
             agent_order = [int(a) for a in torch.randperm(self.num_agents).numpy()]  # first CPU-RNG draw of train()
+        # Host syncs per train(): ONE read-back of every agent's active-entry count up front (early-out test,
+        # happo.py:119-120) and ONE of all training statistics at the end; nothing in between waits for the GPU.
+        fast = [hasattr(a, "masked_moments") for a in self.actor]
+        mom_all = torch.zeros(self.num_agents, 3, dtype=torch.float64, device=dev)
+        for a in range(self.num_agents):
+            if fast[a]:
+                adv_a = advantages if self.state_type == "EP" else advantages[:, :, a].contiguous()
+                self.actor[a].masked_moments(self.actor_buffer[a], adv_a, mom_all[a])
+        self.comm.all_reduce_sum(mom_all)
+        counts = mom_all[:, 2].cpu().tolist()
+        pending = []
         for agent_id in agent_order:
             buf, actor = self.actor_buffer[agent_id], self.actor[agent_id]
             buf.update_factor(factor)
@@ -120,15 +132,26 @@ class OnPolicyHARunner:
             actor.actor.fold()
             rnn_kw = dict(rnn_states=buf.rnn_states[0], masks=buf.flat("masks")) if actor.actor.recurrent else {}
             actor._logp_pass(obs, actions, avail, B, self._logp_old, **rnn_kw)  # pre-update log-probs (:66-83)
-            if self.state_type == "EP":
-                actor_train_infos.append(actor.train(buf, advantages, "EP"))  # :86-93
-            else:
-                actor_train_infos.append(actor.train(buf, advantages[:, :, agent_id].contiguous(), "FP"))
+            adv_a = advantages if self.state_type == "EP" else advantages[:, :, agent_id].contiguous()
+            kw = dict(_pre=(mom_all[agent_id], counts[agent_id]), _defer=True) if fast[agent_id] else {}
+            info = actor.train(buf, adv_a, self.state_type, **kw)               # :86-93
+            pending.append((len(actor_train_infos), info, actor._INFO_KEYS) if torch.is_tensor(info) else None)
+            actor_train_infos.append(info)
             new_factor = factor.clone()
             # post-update log-probs fused with factor *= agg(exp(new - old))   (:96-124)
             actor._logp_pass(obs, actions, avail, B, None, old_logp=self._logp_old, factor=new_factor.reshape(B), **rnn_kw)
             factor = new_factor
-        critic_train_info = self.critic.train(self.critic_buffer, self.value_normalizer)
+        cinfo = self.critic.train(self.critic_buffer, self.value_normalizer, _defer=True)
+        rng_sync()  # the global CPU generator is exactly where the reference leaves it
+        dev_infos = [p[1] for p in pending if p is not None] + [cinfo]
+        flat = torch.cat([t.reshape(-1) for t in dev_infos]).cpu().tolist()  # the single end-of-train read-back
+        off = 0
+        for p in pending:
+            if p is not None:
+                i, _, keys = p
+                actor_train_infos[i] = dict(zip(keys, flat[off:off + len(keys)]))
+                off += len(keys)
+        critic_train_info = {"value_loss": flat[off], "critic_grad_norm": flat[off + 1]}
         return actor_train_infos, critic_train_info
 
     def after_update(self):

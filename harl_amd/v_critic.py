@@ -7,7 +7,7 @@ import torch
 
 from . import _lib
 from ._lib import PS_STRIDE, call, ptr, stream
-from .buffers import OnPolicyCriticBufferEP, consume_randperm, minibatch_indices
+from .buffers import OnPolicyCriticBufferEP, consume_randperm, minibatch_indices, rng_sync
 from .dist import Comm, local_minibatch_rows
 from .nets import FusedAdam, VNet, build_seq
 from .valuenorm import ValueNorm, _as_dev
@@ -126,8 +126,9 @@ class VCritic:
         d = self._info - before
         return d[0], d[1]
 
-    def train(self, critic_buffer: OnPolicyCriticBufferEP, value_normalizer: Optional[ValueNorm] = None):
-        """critic_epoch x critic_num_mini_batch updates (v_critic.py:159-200)."""
+    def train(self, critic_buffer: OnPolicyCriticBufferEP, value_normalizer: Optional[ValueNorm] = None, _defer=False):
+        """critic_epoch x critic_num_mini_batch updates (v_critic.py:159-200).  ``_defer`` (runner-internal): return the
+        averaged statistics as a device tensor and leave deferred RNG advances pending."""
         buf = critic_buffer
         T, N = buf.rewards.shape[:2]
         A = getattr(buf, "num_agents", None)  # FP buffers carry an agent axis: rows = (t*N + n)*A + a
@@ -159,6 +160,9 @@ class VCritic:
                     ind = local_minibatch_rows(ind, self.shard[0], self.shard[1], self.shard[2])
                 self._update_core(share_obs, ind.to(dev), ind.numel(), m_global, value_preds, returns, value_normalizer)
         n_upd = self.critic_epoch * self.critic_num_mini_batch
+        if _defer:
+            return self._info / n_upd
+        rng_sync()
         vals = (self._info / n_upd).cpu().tolist()
         return {"value_loss": vals[0], "critic_grad_norm": vals[1]}
 

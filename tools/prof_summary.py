@@ -46,5 +46,33 @@ def main():
               f"{a[3]/1e3:.1f} | {a[4]} | {a[5]} |")
 
 
+def gaps(path, last_ms=None):
+    """GPU idle analysis of the kernel timeline: busy time vs span, idle time attributed to the kernel that FOLLOWS
+    each gap (= the launch the host was late for)."""
+    db = sqlite3.connect(path)
+    ks = sorted(db.cursor().execute("select start, end, name from kernels").fetchall())
+    if last_ms is not None:  # only the tail of the run (the timed region)
+        t1 = ks[-1][1]
+        ks = [k for k in ks if k[0] >= t1 - last_ms * 1e6]
+    span = ks[-1][1] - ks[0][0]
+    busy, cur_end = 0, ks[0][0]
+    idle_by = defaultdict(lambda: [0, 0])
+    for st, en, name in ks:
+        if st > cur_end:
+            g = idle_by[name.replace("(anonymous namespace)::", "")[:60]]
+            g[0] += 1
+            g[1] += st - cur_end
+        busy += max(0, en - max(st, cur_end))
+        cur_end = max(cur_end, en)
+    print(f"\n## timeline: span {span/1e6:.2f} ms, GPU busy {busy/1e6:.2f} ms ({100*busy/span:.1f} %), "
+          f"idle {(span-busy)/1e6:.2f} ms over {len(ks)} launches\n")
+    print("| idle before kernel | gaps | total idle ms | avg gap us |")
+    print("|---|---|---|---|")
+    for name, (n, t) in sorted(idle_by.items(), key=lambda kv: -kv[1][1])[:14]:
+        print(f"| `{name}` | {n} | {t/1e6:.3f} | {t/n/1e3:.1f} |")
+
+
 if __name__ == "__main__":
     main()
+    if sys.argv[1].endswith(".db") and len(sys.argv) > 2 and sys.argv[2] == "--gaps":
+        gaps(sys.argv[1], float(sys.argv[3]) if len(sys.argv) > 3 else None)

@@ -32,9 +32,9 @@ SIGNATURES = {
     "harl_gradnorm_clip_adam": [_vp, _vp, _vp, _vp, _l, _vp, _i, _f, _f, _f, _f, _f, _f, _d, _d, _vp, _vp],
     "harl_fold_linear": [_vp] * 6 + [_i, _i, _vp],
     "harl_unfold_linear_grads": [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
-    "harl_mlp_fwd_input": [_vp, _l, _vp, _l, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+    "harl_mlp_fwd_input": [_vp, _l, _vp, _l, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "harl_mlp_fwd_fused2": [_vp, _l, _vp, _l, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
-                            _vp],
+                            _vp, _vp],
     "harl_mlp_fwd_hidden": [_vp, _l, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "harl_mlp_bwd_dx": [_vp, _vp, _vp, _vp, _l, _i, _i, _vp, _vp, _vp],
     "harl_mlp_dw_partials": [_vp, _i, _i, _i, _vp, _i, _l, _vp, _vp, _vp, _i, _l, _vp, _i, _vp],

@@ -317,6 +317,21 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_fwd_input(const float *__rest
   }
 }
 
+// normalised input rows of a wave-slab (parked in LDS as xr = my sample's row; columns >= D hold zeros from the
+// kernel prologue) -> ATL(32*NCH) image in HBM: the B operand of the first layer's weight-gradient kernel (saves it the
+// gather + re-normalisation of raw rows).  Pad columns come out as -mean*rstd and only reach dWp columns >= D, which
+// nobody reads (same convention as the raw-row path of k_dw).
+template <int NCH>
+__device__ __forceinline__ void x0n_store(const float *xr, float mean, float rstd, int lane, long slab,
+                                          float *__restrict__ out) {
+  constexpr int HW = 32 * NCH;
+  const float *xl = xr + 4 * (lane >> 5);
+  float v[HW / 2];
+#pragma unroll
+  for (int R = 0; R < HW / 2; ++R) v[R] = (xl[feat_base(R)] - mean) * rstd;  // mean = 0, rstd = 1 without input LN
+  atl_store<HW>(out, slab, lane, v);
+}
+
 // =============================================================================================
 // first layer, narrow inputs (D <= 64: MPE 18/54, MAMuJoCo 17/23): the 32 rows of a wave-slab are fetched
 // row-by-row with the lanes sweeping the row (each load instruction touches 1-2 cache lines instead of 64),
@@ -332,12 +347,14 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_fwd_input_staged(const float 
                                                                     uint32_t *__restrict__ mask_out,
                                                                     float *__restrict__ rstd_out,
                                                                     float *__restrict__ mu0_out,
-                                                                    float *__restrict__ rstd0_out, long n_slabs) {
+                                                                    float *__restrict__ rstd0_out,
+                                                                    float *__restrict__ x0n_out, long n_slabs) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int NCH = RPI == 2 ? 1 : 2, krows = NCH * 32, LDX = krows + 1, NPF = SLAB / RPI;
   float *xs = lds;                              // [4 waves][32 rows][LDX]  (compile-time odd stride)
   float *bl = xs + WAVES_PER_WG * SLAB * LDX;   // [HO]
   float *Wt = bl + HO;                          // [krows][HO]
+  for (int e = threadIdx.x; e < WAVES_PER_WG * SLAB * LDX; e += WG_THREADS) xs[e] = 0.f;  // pad columns stay zero
   for (int e = threadIdx.x; e < HO; e += WG_THREADS) bl[e] = bp[e];
   for (int e = threadIdx.x; e < HO * krows; e += WG_THREADS) {
     int o = e / krows, k = e - o * krows;
@@ -447,6 +464,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_fwd_input_staged(const float 
       mu0_out[slab * SLAB + lane] = mean;
       rstd0_out[slab * SLAB + lane] = rstd;
     }
+    if (x0n_out) x0n_store<NCH>(xr, mean, rstd, lane, slab, x0n_out);
     __builtin_amdgcn_wave_barrier();  // all lanes done reading xw before the next slab overwrites it
   }
 }
@@ -467,7 +485,7 @@ __global__ __launch_bounds__(64 * FUSED_WAVES, 2) void k_fwd_fused2(
     const float *__restrict__ b1p, int use_ln0, const float *__restrict__ W2p, const float *__restrict__ b2p, int store1,
     float *__restrict__ x1out, uint32_t *__restrict__ mask1, float *__restrict__ rstd1, float *__restrict__ mu0_out,
     float *__restrict__ rstd0_out, float *__restrict__ x2out, uint32_t *__restrict__ mask2, float *__restrict__ rstd2,
-    long n_slabs) {
+    float *__restrict__ x0n_out, long n_slabs) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int NTHR = 64 * FUSED_WAVES;
   constexpr int LDW = H + 1, NQ = H / 8, NT_ = H / 32, NPF = SLAB / RPI;
@@ -479,6 +497,7 @@ __global__ __launch_bounds__(64 * FUSED_WAVES, 2) void k_fwd_fused2(
   float *b2l = b1l + H;                         // [H]
   float *Wt = b2l + H;                          // [krows][H]   W1'^T
   float *W2l = Wt + krows * H;                  // [H][H+1]
+  for (int e = threadIdx.x; e < FUSED_WAVES * SLAB * LDX; e += NTHR) xs[e] = 0.f;  // pad columns stay zero
   for (int e = threadIdx.x; e < H * H; e += NTHR) {
     int o = e / H, k = e - o * H;
     W2l[o * LDW + k] = W2p[e];
@@ -617,6 +636,7 @@ __global__ __launch_bounds__(64 * FUSED_WAVES, 2) void k_fwd_fused2(
         mu0_out[slab * SLAB + lane] = mean;
         rstd0_out[slab * SLAB + lane] = rstd0;
       }
+      if (x0n_out) x0n_store<NCH>(xr, mean, rstd0, lane, slab, x0n_out);
     }
     __builtin_amdgcn_wave_barrier();  // all lanes done with xw before the next slab's rows overwrite it
 
@@ -958,7 +978,7 @@ static int bad(const char *m) {
 
 extern "C" int harl_mlp_fwd_input(const float *X, long ldx, const int64_t *idx, long M, int D, const float *Wp,
                                   const float *bp, int use_ln0, int H, float *xout, uint32_t *relu_mask, float *rstd,
-                                  float *mu0, float *rstd0, void *stream) {
+                                  float *mu0, float *rstd0, float *x0n, void *stream) {
   if (M <= 0) return 0;
   const long n_slabs = n_slabs_of(M);
   const int nch = (D + 31) / 32;
@@ -972,7 +992,7 @@ extern "C" int harl_mlp_fwd_input(const float *X, long ldx, const int64_t *idx, 
   {                                                                                                               \
     allow_big_lds(k_fwd_input_staged<Hv, R>, shm);                                                                \
     hipLaunchKernelGGL((k_fwd_input_staged<Hv, R>), dim3(grid), dim3(WG_THREADS), shm, s, X, ldx, idx, M, D, Wp, bp, \
-                       use_ln0, xout, relu_mask, rstd, mu0, rstd0, n_slabs);                                       \
+                       use_ln0, xout, relu_mask, rstd, mu0, rstd0, x0n, n_slabs);                                  \
   }
     if (H == 128) {
       if (D <= 32) LS(128, 2) else LS(128, 1)
@@ -1102,7 +1122,7 @@ extern "C" int harl_mlp_tangent_hidden(const float *xin_dot, const float *xin, l
 extern "C" int harl_mlp_fwd_fused2(const float *X, long ldx, const int64_t *idx, long M, int D, const float *W1p,
                                    const float *b1p, int use_ln0, const float *W2p, const float *b2p, int H, int store1,
                                    float *x1out, uint32_t *mask1, float *rstd1, float *mu0, float *rstd0, float *x2out,
-                                   uint32_t *mask2, float *rstd2, void *stream) {
+                                   uint32_t *mask2, float *rstd2, float *x0n, void *stream) {
   if (M <= 0) return 0;
   if (D > 32) return bad("harl_mlp_fwd_fused2: input width must be <= 32 (LDS budget)");
   if (H != 128 && H != 64) return bad("harl_mlp_fwd_fused2: hidden width must be 64 or 128");
@@ -1116,7 +1136,7 @@ extern "C" int harl_mlp_fwd_fused2(const float *X, long ldx, const int64_t *idx,
   {                                                                                                                  \
     allow_big_lds(k_fwd_fused2<Hv, R, C>, shm);                                                                      \
     hipLaunchKernelGGL((k_fwd_fused2<Hv, R, C>), dim3(grid), dim3(64 * FUSED_WAVES), shm, s, X, ldx, idx, M, D, W1p,  \
-                       b1p, use_ln0, W2p, b2p, store1, x1out, mask1, rstd1, mu0, rstd0, x2out, mask2, rstd2, n_slabs); \
+                       b1p, use_ln0, W2p, b2p, store1, x1out, mask1, rstd1, mu0, rstd0, x2out, mask2, rstd2, x0n, n_slabs); \
   }
   if (H == 128) LF(128, 2, 1) else LF(64, 2, 1)
 #undef LF
@@ -1185,8 +1205,10 @@ extern "C" int harl_mlp_dw_partials(const float *a, int a_kind, int lda, int HO,
 #define DW(AK, BK, MTv, NTv, ny) launch_dw<AK, BK, MTv, NTv>(a, b, ldx, idx, mu0, rstd0, K, M, n_slabs, part, KP, n_wg, ny, s)
   if (b_kind == 0) {
     const int NT = K / 32;
-    if (K != 64 && K != 128) return bad("harl_mlp_dw_partials: ATL input width must be 64 or 128");
-    if (MT == 4 && NT == 4) DW(0, 0, 4, 4, 1);
+    if (K != 32 && K != 64 && K != 128) return bad("harl_mlp_dw_partials: ATL input width must be 32, 64 or 128");
+    if (MT == 4 && NT == 1) DW(0, 0, 4, 1, 1);
+    else if (MT == 2 && NT == 1) DW(0, 0, 2, 1, 1);
+    else if (MT == 4 && NT == 4) DW(0, 0, 4, 4, 1);
     else if (MT == 4 && NT == 2) DW(0, 0, 4, 2, 1);
     else if (MT == 2 && NT == 4) DW(0, 0, 2, 4, 1);
     else if (MT == 2 && NT == 2) DW(0, 0, 2, 2, 1);

@@ -236,6 +236,9 @@ class _FlatNet(nn.Module):
         self.rstd = [torch.empty(mp, dtype=f32, device=dev) for _ in self.hidden_sizes]
         self.mu0 = torch.empty(mp, dtype=f32, device=dev)
         self.rstd0 = torch.empty(mp, dtype=f32, device=dev)
+        # narrow inputs: the forward pass leaves the normalised inputs behind as an ATL image for the dW_1 kernel
+        self.kp0 = ((self.in_dim + 31) // 32) * 32
+        self.x0n = torch.empty(mp * self.kp0, dtype=f32, device=dev) if self.in_dim <= 64 else None
         hmax = max(self.hidden_sizes)
         self.dz = [torch.empty(mp * hmax, dtype=f32, device=dev) for _ in range(2)]            # ping-pong, ATL
         self.dhead = torch.zeros(mp * DHEAD_LD, dtype=f32, device=dev)
@@ -293,13 +296,13 @@ class _FlatNet(nn.Module):
             call("harl_mlp_fwd_fused2", ptr(X), X.shape[1], ptr(idx), M, self.in_dim, ptr(W1), ptr(b1),
                  int(self.use_feature_normalization), ptr(W2), ptr(b2), hs[0], int(for_backward), ptr(self.xh[0]),
                  ptr(self.rmask[0]), ptr(self.rstd[0]), ptr(self.mu0), ptr(self.rstd0), ptr(self.xh[1]),
-                 ptr(self.rmask[1]), ptr(self.rstd[1]), s, tag="fwd_fused2")
+                 ptr(self.rmask[1]), ptr(self.rstd[1]), ptr(self.x0n) if for_backward else None, s, tag="fwd_fused2")
             first_hidden = 2
         else:
             Wp, bp = self._packs[0]
             call("harl_mlp_fwd_input", ptr(X), X.shape[1], ptr(idx), M, self.in_dim, ptr(Wp), ptr(bp),
                  int(self.use_feature_normalization), hs[0], ptr(self.xh[0]), ptr(self.rmask[0]), ptr(self.rstd[0]),
-                 ptr(self.mu0), ptr(self.rstd0), s, tag="fwd_input")
+                 ptr(self.mu0), ptr(self.rstd0), ptr(self.x0n) if for_backward else None, s, tag="fwd_input")
         for l in range(first_hidden, len(hs)):
             Wp, bp = self._packs[l]
             call("harl_mlp_fwd_hidden", ptr(self.xh[l - 1]), M, hs[l - 1], hs[l],
@@ -343,9 +346,13 @@ class _FlatNet(nn.Module):
             cur = 1 - cur
         h0 = self.hidden_sizes[0]
         use_ln = self.use_feature_normalization
-        call("harl_mlp_dw_partials", ptr(self.dz[cur]), 0, 0, h0, ptr(X), 1, X.shape[1], ptr(idx),
-             ptr(self.mu0) if use_ln else None, ptr(self.rstd0) if use_ln else None, self.in_dim, M,
-             ptr(self.part[po[0]:]), nwg, s, tag="dw_input")
+        if self.x0n is not None:  # B = normalised inputs as written by the forward pass (ATL, zero-padded to kp0)
+            call("harl_mlp_dw_partials", ptr(self.dz[cur]), 0, 0, h0, ptr(self.x0n), 0, 0, None, None, None, self.kp0, M,
+                 ptr(self.part[po[0]:]), nwg, s, tag="dw_input")
+        else:
+            call("harl_mlp_dw_partials", ptr(self.dz[cur]), 0, 0, h0, ptr(X), 1, X.shape[1], ptr(idx),
+                 ptr(self.mu0) if use_ln else None, ptr(self.rstd0) if use_ln else None, self.in_dim, M,
+                 ptr(self.part[po[0]:]), nwg, s, tag="dw_input")
         # deterministic fixed-order combine of every entry's per-workgroup partials, one launch
         call("harl_reduce_partials_multi", ptr(self.part), ptr(self.table), self.n_entries, nwg, self.total_dwp,
              ptr(self.dwp), s, tag="reduce_partials")

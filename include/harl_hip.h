@@ -99,16 +99,19 @@ int harl_unfold_linear_grads(const float *dWp, const float *dbp, int ldp, const 
 
 /* first layer: x_hat1 = norm(relu(Wp * norm0(X[idx]) + bp))
  *   X[rows, ldx] row-major, D features; use_ln0: feature LayerNorm on the input (mlp.py:57-58,65-66)
- *   outputs: xout ATL(H), relu_mask [n_slabs][H/64][64] u32, rstd[M_pad], mu0/rstd0[M_pad] (input LN stats) */
+ *   outputs: xout ATL(H), relu_mask [n_slabs][H/64][64] u32, rstd[M_pad], mu0/rstd0[M_pad] (input LN stats)
+ *   x0n (optional, honoured for D <= 64 only): ATL(32*ceil(D/32)) image of the normalised inputs, zero-padded -- the
+ *   B operand of harl_mlp_dw_partials(b_kind = 0) for this layer's weight gradient (no second gather of raw rows) */
 int harl_mlp_fwd_input(const float *X, long ldx, const int64_t *idx, long M, int D, const float *Wp,
                        const float *bp, int use_ln0, int H, float *xout, uint32_t *relu_mask, float *rstd,
-                       float *mu0, float *rstd0, void *stream);
+                       float *mu0, float *rstd0, float *x0n, void *stream);
 /* fused layers 1+2 for narrow inputs (D <= 32) and equal widths H: x_hat_1 stays in registers between the two GEMMs;
- * store1 != 0 also writes x_hat_1 / mask1 / rstd1 / mu0 / rstd0 (needed only when a backward pass follows). */
+ * store1 != 0 also writes x_hat_1 / mask1 / rstd1 / mu0 / rstd0 and (if non-NULL) x0n as in harl_mlp_fwd_input
+ * (needed only when a backward pass follows). */
 int harl_mlp_fwd_fused2(const float *X, long ldx, const int64_t *idx, long M, int D, const float *W1p,
                         const float *b1p, int use_ln0, const float *W2p, const float *b2p, int H, int store1,
                         float *x1out, uint32_t *mask1, float *rstd1, float *mu0, float *rstd0, float *x2out,
-                        uint32_t *mask2, float *rstd2, void *stream);
+                        uint32_t *mask2, float *rstd2, float *x0n, void *stream);
 /* hidden layer: xout = norm(relu(Wp * xin + bp)), xin ATL(HI) -> xout ATL(HO) */
 int harl_mlp_fwd_hidden(const float *xin, long M, int HI, int HO, const float *Wp, const float *bp,
                         float *xout, uint32_t *relu_mask, float *rstd, void *stream);

@@ -134,6 +134,72 @@ __device__ __forceinline__ void head_bwd_stream(const float *__restrict__ xL, co
   }
 }
 
+// ---- training kernels: x_hat_L is needed twice (head forward, then LayerNorm backward), so it is loaded ONCE, as a
+// burst of H/8 independent float4 loads per lane (64 VGPRs for H = 128), and stays in registers across the loss.
+// The loops are fully unrolled (static register indexing); sched_barrier(0) after every q-step keeps hipcc from hoisting
+// the broadcast LDS weight reads of later steps (which is what spilled the first unrolled version of this kernel).
+template <int H>
+__device__ __forceinline__ void head_load_regs(const float *__restrict__ xL, long slab, int lane, f32x4 (&xs)[H / 8]) {
+  const f32x4 *xp = reinterpret_cast<const f32x4 *>(xL + slab * (long)(H * SLAB)) + lane;
+#pragma unroll
+  for (int q = 0; q < H / 8; ++q) xs[q] = xp[q * WAVE];
+}
+
+template <int H, int DAP>
+__device__ __forceinline__ void head_fwd_regs(const f32x4 (&xs)[H / 8], const float *whl_h, const float *cst,
+                                              float (&z)[DAP]) {
+#pragma unroll
+  for (int d = 0; d < DAP; ++d) z[d] = 0.f;
+#pragma unroll
+  for (int q = 0; q < H / 8; ++q) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+      for (int dq = 0; dq < DAP / 4; ++dq) {
+        const f32x4 w = *reinterpret_cast<const f32x4 *>(whl_h + (4 * q + c) * DAP + 4 * dq);
+        z[4 * dq + 0] += xs[q][c] * w[0];
+        z[4 * dq + 1] += xs[q][c] * w[1];
+        z[4 * dq + 2] += xs[q][c] * w[2];
+        z[4 * dq + 3] += xs[q][c] * w[3];
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int d = 0; d < DAP; ++d) z[d] = z[d] + wave_xor32(z[d]) + cst[d];
+}
+
+template <int H, int DAP>
+__device__ __forceinline__ void head_bwd_regs(const f32x4 (&xs)[H / 8], const uint32_t *__restrict__ mask_in,
+                                              float rstd, long slab, int lane, const float *whl_h,
+                                              const float (&dzh)[DAP], float s1, float s2,
+                                              float *__restrict__ dz_out) {
+  constexpr int NW = (H / 2 + 31) / 32;
+  const uint32_t b0 = mask_in[(slab * NW + 0) * WAVE + lane];
+  const uint32_t b1 = NW > 1 ? mask_in[(slab * NW + (NW - 1)) * WAVE + lane] : 0u;
+  s1 *= (1.0f / H);
+  s2 *= (1.0f / H);
+  f32x4 *op = reinterpret_cast<f32x4 *>(dz_out + slab * (long)(H * SLAB)) + lane;
+#pragma unroll
+  for (int q = 0; q < H / 8; ++q) {
+    const uint32_t bits = ((q >> 3) ? b1 : b0) >> ((4 * q) & 31);
+    f32x4 o;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float dx = 0.f;
+#pragma unroll
+      for (int dq = 0; dq < DAP / 4; ++dq) {
+        const f32x4 w = *reinterpret_cast<const f32x4 *>(whl_h + (4 * q + c) * DAP + 4 * dq);
+        dx += dzh[4 * dq + 0] * w[0] + dzh[4 * dq + 1] * w[1] + dzh[4 * dq + 2] * w[2] + dzh[4 * dq + 3] * w[3];
+      }
+      const float da = rstd * (dx - s1 - xs[q][c] * s2);
+      o[c] = ((bits >> c) & 1u) ? da : 0.f;
+    }
+    op[q * WAVE] = o;
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // block-level reduction of NV per-lane partial sums -> part_scalars[blockIdx.x][0..NV)
 template <int NV>
 __device__ __forceinline__ void block_reduce_store(float (&v)[NV], float *red /*[4][PS_STRIDE]*/, float *out_row) {
@@ -201,7 +267,13 @@ __global__ __launch_bounds__(WG_THREADS) void k_actor_head(ActorArgs A) {
 
   for (long slab = (long)blockIdx.x * WAVES_PER_WG + wave; slab < A.n_slabs; slab += (long)gridDim.x * WAVES_PER_WG) {
     float z[DAP];
-    head_fwd_stream<H, DAP>(A.xL, slab, lane, whl_h, cst, z);
+    f32x4 xs[TRAIN ? H / 8 : 1];
+    if constexpr (TRAIN) {
+      head_load_regs<H>(A.xL, slab, lane, xs);
+      head_fwd_regs<H, DAP>(xs, whl_h, cst, z);
+    } else {
+      head_fwd_stream<H, DAP>(A.xL, slab, lane, whl_h, cst, z);
+    }
     float zlin[DAP];  // x_hat . Whp[d]  (= z - bias), needed by the closed-form LayerNorm backward
 #pragma unroll
     for (int d = 0; d < DAP; ++d) zlin[d] = z[d] - cst[d];
@@ -372,7 +444,8 @@ __global__ __launch_bounds__(WG_THREADS) void k_actor_head(ActorArgs A) {
       s1 += dzh[d] * cst[4 * DAP + d];
       s2 += dzh[d] * zlin[d];
     }
-    head_bwd_stream<H, DAP>(A.xL, A.relu_mask, A.rstd[slab * SLAB + i], slab, lane, whl_h, dzh, s1, s2, A.dzL);
+    if constexpr (TRAIN)
+      head_bwd_regs<H, DAP>(xs, A.relu_mask, A.rstd[slab * SLAB + i], slab, lane, whl_h, dzh, s1, s2, A.dzL);
   }
 
   if (TRAIN) block_reduce_store<8 + DAP>(sc, red, A.part_scalars + (long)blockIdx.x * PS_STRIDE);
@@ -422,7 +495,13 @@ __global__ __launch_bounds__(WG_THREADS) void k_critic_head(CriticArgs A) {
 
   for (long slab = (long)blockIdx.x * WAVES_PER_WG + wave; slab < A.n_slabs; slab += (long)gridDim.x * WAVES_PER_WG) {
     float z[DAP];
-    head_fwd_stream<H, DAP>(A.xL, slab, lane, whl_h, cst, z);
+    f32x4 xs[TRAIN ? H / 8 : 1];
+    if constexpr (TRAIN) {
+      head_load_regs<H>(A.xL, slab, lane, xs);
+      head_fwd_regs<H, DAP>(xs, whl_h, cst, z);
+    } else {
+      head_fwd_stream<H, DAP>(A.xL, slab, lane, whl_h, cst, z);
+    }
     const float v = z[0];
     const long j = slab * SLAB + i;
     const bool valid = j < A.M && (A.m_pad == 0 || (j % A.m_pad) < A.m_valid);
@@ -472,7 +551,8 @@ __global__ __launch_bounds__(WG_THREADS) void k_critic_head(CriticArgs A) {
       for (int c = 0; c < 16; ++c) dh[c] = (h == 0 && c == 0) ? dv : 0.f;
     }
     const float dzh[DAP] = {dv, 0.f, 0.f, 0.f};
-    head_bwd_stream<H, DAP>(A.xL, A.relu_mask, A.rstd[slab * SLAB + i], slab, lane, whl_h, dzh, dv * cst[4 * DAP],
+    if constexpr (TRAIN)
+      head_bwd_regs<H, DAP>(xs, A.relu_mask, A.rstd[slab * SLAB + i], slab, lane, whl_h, dzh, dv * cst[4 * DAP],
                             dv * (v - cst[0]), A.dzL);
   }
   if (TRAIN) block_reduce_store<8>(sc, red, A.part_scalars + (long)blockIdx.x * PS_STRIDE);

@@ -136,12 +136,15 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_fwd_hidden(const float *__res
   static_assert((HI / 8) % 8 == 0, "ping-pong ring prefetch consumes 8 float4 per outer step");
   const long slab0 = (long)blockIdx.x * WAVES_PER_WG + wave, slab_stride = (long)gridDim.x * WAVES_PER_WG;
   constexpr int NQ = HI / 8, NT_ = HO / 32;
-  f32x4 ringA[4], ringB[4];
+  // prefetch distance of the activation stream in q-steps (float4 per lane): 8 for HI = 128.  With 4 the chip holds
+  // only 8 MB of loads in flight (2 waves/SIMD x 4 KB), which caps the stream at ~3.3 TB/s for ~2.5 us loaded latency.
+  constexpr int RD = NQ >= 16 ? 8 : 4;
+  f32x4 ringA[RD], ringB[RD];
   float aX[4 * NT_], aY[4 * NT_];
   {
     const f32x4 *p0 = reinterpret_cast<const f32x4 *>(xin + (slab0 < n_slabs ? slab0 : 0) * (long)(HI * SLAB)) + lane;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) ringA[u] = p0[u * WAVE];
+    for (int u = 0; u < RD; ++u) ringA[u] = p0[u * WAVE];
   }
   auto lds_frag = [&](int q, float (&a)[4 * NT_]) {  // weight fragments of q-step q: W'[32t+i][f(4q+c, h)]
     const float *wq = wl_lane + 32 * (q >> 2) + 8 * (q & 3);
@@ -176,21 +179,28 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_fwd_hidden(const float *__res
     //    q-step q run (the fragment stream wraps around, weights do not depend on the slab).
     //  The outer loop stays rolled: a fully unrolled body lets the scheduler hoist all HI*HO/64 LDS reads and spill.
 #define FWD_SUBSTEP(u, q, CONS, PROD, ACUR, ANXT)                                                              \
-    PROD[u] = (q) + 4 < NQ ? xp[((q) + 4) * WAVE] : xp_next[((q) + 4 - NQ) * WAVE];                            \
+    PROD[u] = (q) + RD < NQ ? xp[((q) + RD) * WAVE] : xp_next[((q) + RD - NQ) * WAVE];                         \
     lds_frag(((q) + 1) % NQ, ANXT);                                                                            \
     __builtin_amdgcn_sched_barrier(0);                                                                         \
     mfma16(CONS[u], ACUR);
+#define FWD_SUB4(u0, q0, CONS, PROD)                                                                           \
+    FWD_SUBSTEP((u0) + 0, (q0) + 0, CONS, PROD, aX, aY)                                                        \
+    FWD_SUBSTEP((u0) + 1, (q0) + 1, CONS, PROD, aY, aX)                                                        \
+    FWD_SUBSTEP((u0) + 2, (q0) + 2, CONS, PROD, aX, aY)                                                        \
+    FWD_SUBSTEP((u0) + 3, (q0) + 3, CONS, PROD, aY, aX)
 #pragma unroll 1
-    for (int qo = 0; qo < NQ; qo += 8) {
-      FWD_SUBSTEP(0, qo + 0, ringA, ringB, aX, aY)
-      FWD_SUBSTEP(1, qo + 1, ringA, ringB, aY, aX)
-      FWD_SUBSTEP(2, qo + 2, ringA, ringB, aX, aY)
-      FWD_SUBSTEP(3, qo + 3, ringA, ringB, aY, aX)
-      FWD_SUBSTEP(0, qo + 4, ringB, ringA, aX, aY)
-      FWD_SUBSTEP(1, qo + 5, ringB, ringA, aY, aX)
-      FWD_SUBSTEP(2, qo + 6, ringB, ringA, aX, aY)
-      FWD_SUBSTEP(3, qo + 7, ringB, ringA, aY, aX)
+    for (int qo = 0; qo < NQ; qo += 2 * RD) {
+      if constexpr (RD == 8) {
+        FWD_SUB4(0, qo + 0, ringA, ringB)
+        FWD_SUB4(4, qo + 4, ringA, ringB)
+        FWD_SUB4(0, qo + 8, ringB, ringA)
+        FWD_SUB4(4, qo + 12, ringB, ringA)
+      } else {
+        FWD_SUB4(0, qo + 0, ringA, ringB)
+        FWD_SUB4(0, qo + 4, ringB, ringA)
+      }
     }
+#undef FWD_SUB4
 #undef FWD_SUBSTEP
     relu_norm_store<HO>(acc, lane, slab, xout, mask_out, rstd_out);
   }
@@ -690,12 +700,13 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_bwd_dx(const float *__restric
   static_assert((HO / 8) % 8 == 0, "ping-pong ring prefetch consumes 8 float4 per outer step");
   const long slab0 = (long)blockIdx.x * WAVES_PER_WG + wave, slab_stride = (long)gridDim.x * WAVES_PER_WG;
   constexpr int NQ = HO / 8, NT_ = HI / 32;
-  f32x4 ringA[4], ringB[4];
+  constexpr int RD = NQ >= 16 ? 8 : 4;  // prefetch distance in q-steps (see k_fwd_hidden)
+  f32x4 ringA[RD], ringB[RD];
   float aX[4 * NT_], aY[4 * NT_];
   {
     const f32x4 *p0 = reinterpret_cast<const f32x4 *>(dz + (slab0 < n_slabs ? slab0 : 0) * (long)(HO * SLAB)) + lane;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) ringA[u] = p0[u * WAVE];
+    for (int u = 0; u < RD; ++u) ringA[u] = p0[u * WAVE];
   }
   auto lds_frag = [&](int q, float (&a)[4 * NT_]) {  // W'^T fragments: W'[f(4q+c, h)][32t+i]
     const float *wq = wl_lane + (32 * (q >> 2) + 8 * (q & 3)) * HI;
@@ -726,21 +737,28 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_bwd_dx(const float *__restric
     };
     // same pinned software pipeline as k_fwd_hidden (ping-pong global rings + double-buffered LDS fragments)
 #define BWD_SUBSTEP(u, q, CONS, PROD, ACUR, ANXT)                                                              \
-    PROD[u] = (q) + 4 < NQ ? gp[((q) + 4) * WAVE] : gp_next[((q) + 4 - NQ) * WAVE];                            \
+    PROD[u] = (q) + RD < NQ ? gp[((q) + RD) * WAVE] : gp_next[((q) + RD - NQ) * WAVE];                         \
     lds_frag(((q) + 1) % NQ, ANXT);                                                                            \
     __builtin_amdgcn_sched_barrier(0);                                                                         \
     mfma16(CONS[u], ACUR);
+#define BWD_SUB4(u0, q0, CONS, PROD)                                                                           \
+    BWD_SUBSTEP((u0) + 0, (q0) + 0, CONS, PROD, aX, aY)                                                        \
+    BWD_SUBSTEP((u0) + 1, (q0) + 1, CONS, PROD, aY, aX)                                                        \
+    BWD_SUBSTEP((u0) + 2, (q0) + 2, CONS, PROD, aX, aY)                                                        \
+    BWD_SUBSTEP((u0) + 3, (q0) + 3, CONS, PROD, aY, aX)
 #pragma unroll 1
-    for (int qo = 0; qo < NQ; qo += 8) {
-      BWD_SUBSTEP(0, qo + 0, ringA, ringB, aX, aY)
-      BWD_SUBSTEP(1, qo + 1, ringA, ringB, aY, aX)
-      BWD_SUBSTEP(2, qo + 2, ringA, ringB, aX, aY)
-      BWD_SUBSTEP(3, qo + 3, ringA, ringB, aY, aX)
-      BWD_SUBSTEP(0, qo + 4, ringB, ringA, aX, aY)
-      BWD_SUBSTEP(1, qo + 5, ringB, ringA, aY, aX)
-      BWD_SUBSTEP(2, qo + 6, ringB, ringA, aX, aY)
-      BWD_SUBSTEP(3, qo + 7, ringB, ringA, aY, aX)
+    for (int qo = 0; qo < NQ; qo += 2 * RD) {
+      if constexpr (RD == 8) {
+        BWD_SUB4(0, qo + 0, ringA, ringB)
+        BWD_SUB4(4, qo + 4, ringA, ringB)
+        BWD_SUB4(0, qo + 8, ringB, ringA)
+        BWD_SUB4(4, qo + 12, ringB, ringA)
+      } else {
+        BWD_SUB4(0, qo + 0, ringA, ringB)
+        BWD_SUB4(0, qo + 4, ringB, ringA)
+      }
     }
+#undef BWD_SUB4
 #undef BWD_SUBSTEP
     float dx[HI / 2];
 #pragma unroll

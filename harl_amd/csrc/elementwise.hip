@@ -505,50 +505,58 @@ extern "C" int harl_reduce_partials_multi(const float *part, const int *table, i
 }
 
 // ---------------------------------------------------------------------------------------------
-// Fused optimiser epilogue, ONE workgroup (P <= a few 100 k):
-//   loss scalars -> gradient scale + training statistics ; unfold folded gradients (all layers) ;
-//   ||g|| ; clip ; Adam ; re-fold the updated weights for the next forward.
-// Replaces (per update) ~25 tiny launches: unfold x L, reciprocal/cast/copy glue, grad-norm, Adam, fold x L.
+// Fused optimiser epilogue, ADAM_WGS co-resident workgroups with a software grid barrier between phases:
+//   A  loss scalars (optionally reduced here from the loss kernel's per-block partials) -> gradient scale + training
+//      statistics ; unfold the folded gradients of every table entry
+//   B  ||g||  (per-workgroup partial sums, combined in fixed order by every workgroup -> deterministic)
+//   C  clip + Adam
+//   D  re-fold the updated weights for the next forward
+// Replaces (per update) ~25 tiny launches: scalar reduce, unfold x L, reciprocal/cast/copy glue, grad-norm, Adam,
+// fold x L.  64 workgroups x 256 threads are always co-resident on 256 CUs (the stream is in-order, nothing else runs),
+// which is what makes the spin barrier safe; it costs ~2 us, a kernel boundary ~6-8 us.
+// ws: [0] arrivals, [1] finished, then doubles from byte 32: [w] per-workgroup sum of squares, [G + w*48 + j] scalar row sums
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_adam_fold(float *__restrict__ p, float *__restrict__ g, float *__restrict__ m,
-                                                    float *__restrict__ v, long n, const float *__restrict__ dwp,
-                                                    const int *__restrict__ tab, int n_layers, float *__restrict__ packs,
-                                                    const double *__restrict__ scalars, int mode, float const_scale,
-                                                    int logstd_off, int act_dim, float *__restrict__ info,
-                                                    int use_clip, float max_norm, float lr_over_bc1, float beta1,
-                                                    float beta2, float eps, float wd, float bc2_sqrt) {
-  __shared__ float s_scale, s_coef;
-  __shared__ double sh[16];
-  const int tid = threadIdx.x, nt = blockDim.x;
-  // ---- phase 0: scalars
-  if (tid == 0) {
-    float scale;
-    if (mode == 0) {  // actor: loss = sum / sum(active)   (happo.py:77-85)
-      const double sa = scalars[1];
-      scale = (float)(1.0 / sa);
-      if (info) {
-        info[0] += (float)(scalars[0] / sa);
-        info[1] += (float)(scalars[2] / sa);
-        info[3] += (float)(scalars[3] / scalars[4]);
-      }
-    } else {  // critic: mean over the (global) minibatch, times value_loss_coef (v_critic.py:112,146)
-      scale = const_scale;
-      if (info) info[0] += (float)(scalars[0] / scalars[1]);
-    }
-    s_scale = scale;
-  }
-  if (logstd_off >= 0 && tid < act_dim) g[logstd_off + tid] = (float)scalars[8 + tid];
-  // ---- phase 1: unfold  dW = dWp*gamma + dbp (x) beta ; db = dbp ; dgamma += sum_o W.dWp ; dbeta += sum_o W.dbp
-  // (several Linears may share one LayerNorm -- the three GRU gate blocks -- so gamma/beta gradients accumulate)
-  for (int l = 0; l < n_layers; ++l) {
-    const int *t = tab + l * TS;
-    if (t[2] >= 0)
-      for (int k = tid; k < t[5]; k += nt) {
-        g[t[2] + k] = 0.f;
-        g[t[3] + k] = 0.f;
-      }
+constexpr int ADAM_WGS = 64, ADAM_THREADS = 256;
+
+__device__ __forceinline__ void grid_barrier(unsigned *bar, unsigned target) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();  // release: this workgroup's global writes precede the arrival
+    __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    while (__hip_atomic_load(bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(2);
+    __threadfence();  // acquire: invalidates this CU's vector L1 for the whole workgroup
   }
   __syncthreads();
+}
+
+__global__ __launch_bounds__(ADAM_THREADS) void k_adam_fold(
+    float *__restrict__ p, float *__restrict__ g, float *__restrict__ m, float *__restrict__ v, long n,
+    const float *__restrict__ dwp, const int *__restrict__ tab, int n_layers, float *__restrict__ packs,
+    double *__restrict__ scalars, const float *__restrict__ part_scalars, int n_scalar_blocks, int mode,
+    float const_scale, int logstd_off, int act_dim, float *__restrict__ info, int use_clip, float max_norm,
+    float lr_over_bc1, float beta1, float beta2, float eps, float wd, float bc2_sqrt, unsigned *__restrict__ ws) {
+  __shared__ double sh[64];
+  const int tid = threadIdx.x, nt = ADAM_THREADS;
+  const int G = gridDim.x, blk = blockIdx.x;
+  const long gtid = (long)blk * nt + tid, gnt = (long)G * nt;
+  const int gw = (int)(gtid >> 6), ln = tid & 63, gnw = (int)(gnt >> 6);  // global wave id / lane / wave count
+  double *ws_part = reinterpret_cast<double *>(ws + 8);
+
+  // ---- phase A.0: loss-kernel partial rows -> 64 row sums (workgroup b takes rows b, b+G, ...; fixed order)
+  double *ws_rows = ws_part + ADAM_WGS;  // [G][PS_STRIDE]
+  if (part_scalars && tid < PS_STRIDE) {
+    double t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+    int b = blk;
+    for (; b + 3 * G < n_scalar_blocks; b += 4 * G) {
+      t0 += (double)part_scalars[(long)b * PS_STRIDE + tid];
+      t1 += (double)part_scalars[(long)(b + G) * PS_STRIDE + tid];
+      t2 += (double)part_scalars[(long)(b + 2 * G) * PS_STRIDE + tid];
+      t3 += (double)part_scalars[(long)(b + 3 * G) * PS_STRIDE + tid];
+    }
+    for (; b < n_scalar_blocks; b += G) t0 += (double)part_scalars[(long)b * PS_STRIDE + tid];
+    ws_rows[blk * PS_STRIDE + tid] = (t0 + t1) + (t2 + t3);
+  }
+  // ---- phase A.1: unfold  dW = dWp*gamma + dbp (x) beta ; db = dbp
   for (int l = 0; l < n_layers; ++l) {
     const int *t = tab + l * TS;
     const int O = t[4], K = t[5], kp = t[9], op = t[10];
@@ -556,59 +564,116 @@ __global__ __launch_bounds__(1024) void k_adam_fold(float *__restrict__ p, float
     const float *db_ = dW_ + (long)op * kp;
     const float *gam = t[2] >= 0 ? p + t[2] : nullptr;
     const float *bet = t[3] >= 0 ? p + t[3] : nullptr;
-    for (int e = tid; e < O * K; e += nt) {
-      const int o = e / K, k = e - o * K;
+    for (long e = gtid; e < (long)O * K; e += gnt) {
+      const int o = (int)(e / K), k = (int)(e - (long)o * K);
       const float dwp_ = dW_[(long)o * kp + k];
       g[t[0] + e] = gam ? dwp_ * gam[k] + db_[o] * bet[k] : dwp_;
     }
-    for (int o = tid; o < O; o += nt) g[t[1] + o] = db_[o];
-    if (gam) {  // one wave per input column: lanes sweep the rows, wave-reduce (fixed order -> deterministic)
-      const int wv = tid >> 6, ln = tid & 63, nw = nt >> 6;
-      for (int k = wv; k < K; k += nw) {
+    for (long o = gtid; o < O; o += gnt) g[t[1] + o] = db_[o];
+  }
+  // ---- phase A.2: dgamma[k] = sum_{entries sharing gamma} sum_o W[o][k] dWp[o][k] ; dbeta[k] likewise with dbp[o].
+  // One wave per (owner entry, column): lanes sweep the rows, then the entries that share the LayerNorm (the three
+  // GRU gate blocks) in table order -- fixed order, no atomics, no zero-fill.
+  {
+    int wslot = 0;
+    for (int l = 0; l < n_layers; ++l) {
+      const int *t = tab + l * TS;
+      const int go = t[2];
+      if (go < 0) continue;
+      bool owner = true;
+      for (int l2 = 0; l2 < l; ++l2) owner = owner && (tab[l2 * TS + 2] != go);
+      if (!owner) continue;
+      const int K = t[5];
+      for (int k = gw - wslot; k < K; k += gnw) {
+        if (k < 0) continue;
         float sg = 0.f, sb = 0.f;
-        for (int o = ln; o < O; o += 64) {
-          const float w = p[t[0] + o * K + k];
-          sg += w * dW_[(long)o * kp + k];
-          sb += w * db_[o];
+        for (int l2 = l; l2 < n_layers; ++l2) {
+          const int *t2 = tab + l2 * TS;
+          if (t2[2] != go) continue;
+          const int O = t2[4], kp = t2[9], op = t2[10];
+          const float *dW_ = dwp + t2[8];
+          const float *db_ = dW_ + (long)op * kp;
+          for (int o = ln; o < O; o += 64) {
+            const float w = p[t2[0] + o * K + k];
+            sg += w * dW_[(long)o * kp + k];
+            sb += w * db_[o];
+          }
         }
         sg = wave_reduce_sum(sg);
         sb = wave_reduce_sum(sb);
         if (ln == 0) {
-          g[t[2] + k] += sg;
-          g[t[3] + k] += sb;
+          g[go + k] = sg;
+          g[t[3] + k] = sb;
         }
       }
-      __syncthreads();  // the next table entry may accumulate into the same gamma/beta slots from other waves
+      wslot = (wslot + K) % gnw;  // spread the columns of successive LayerNorms over different waves
     }
   }
-  __syncthreads();
-  // ---- phase 2: ||g * scale||
-  const float scale = s_scale;
-  double ss = 0;
-  for (long i = tid; i < n; i += nt) {
-    const float gi = g[i] * scale;
-    ss += (double)gi * gi;
-  }
-  ss = wave_reduce_sum_d(ss);
-  if ((tid & 63) == 0) sh[tid >> 6] = ss;
-  __syncthreads();
-  if (tid == 0) {
+  grid_barrier(ws, (unsigned)G);
+  // ---- every workgroup: the scalar sums (same fixed order everywhere); workgroup 0 publishes them
+  if (tid < PS_STRIDE) {
     double t = 0;
-    for (int i = 0; i < (nt >> 6); ++i) t += sh[i];
+    if (part_scalars) {
+      double u0 = 0, u1 = 0, u2 = 0, u3 = 0;
+      for (int b = 0; b < G; b += 4) {
+        u0 += ws_rows[(b + 0) * PS_STRIDE + tid];
+        u1 += ws_rows[(b + 1) * PS_STRIDE + tid];
+        u2 += ws_rows[(b + 2) * PS_STRIDE + tid];
+        u3 += ws_rows[(b + 3) * PS_STRIDE + tid];
+      }
+      t = (u0 + u1) + (u2 + u3);
+      if (blk == 0) scalars[tid] = t;
+    } else {
+      t = scalars[tid];
+    }
+    sh[tid] = t;
+  }
+  __syncthreads();
+  float scale;
+  if (mode == 0) {  // actor: loss = sum / sum(active)   (happo.py:77-85)
+    scale = (float)(1.0 / sh[1]);
+    if (blk == 0 && tid == 0 && info) {
+      info[0] += (float)(sh[0] / sh[1]);
+      info[1] += (float)(sh[2] / sh[1]);
+      info[3] += (float)(sh[3] / sh[4]);
+    }
+  } else {  // critic: mean over the (global) minibatch, times value_loss_coef (v_critic.py:112,146)
+    scale = const_scale;
+    if (blk == 0 && tid == 0 && info) info[0] += (float)(sh[0] / sh[1]);
+  }
+  const bool has_ls = logstd_off >= 0;
+  if (has_ls && blk == 0 && tid < act_dim) g[logstd_off + tid] = (float)sh[8 + tid];  // read again in phase C
+  // ---- phase B: ||g * scale||   (log_std gradients come straight from the scalar sums)
+  {
+    double ss = 0;
+    for (long i = gtid; i < n; i += gnt) {
+      const bool is_ls = has_ls && i >= logstd_off && i < logstd_off + act_dim;
+      const float gi = (is_ls ? (float)sh[8 + (is_ls ? (int)(i - logstd_off) : 0)] : g[i]) * scale;
+      ss += (double)gi * gi;
+    }
+    __syncthreads();  // sh[0..48) fully read before it is reused for the wave partials
+    ss = wave_reduce_sum_d(ss);
+    if (ln == 0) sh[48 + (tid >> 6)] = ss;
+    __syncthreads();
+    if (tid == 0) ws_part[blk] = (sh[48] + sh[49]) + (sh[50] + sh[51]);
+  }
+  grid_barrier(ws, (unsigned)(2 * G));
+  float coef;
+  {
+    double t = 0;
+    for (int b = 0; b < G; ++b) t += ws_part[b];  // same order in every workgroup
     const float norm = (float)sqrt(t);
-    float coef = 1.f;
+    coef = 1.f;
     if (use_clip) {
       coef = max_norm / (norm + 1e-6f);
       coef = coef > 1.f ? 1.f : coef;
     }
-    s_coef = coef;
-    if (info) info[2 - mode] += norm;  // actor: info[2] ; critic: info[1]
+    if (blk == 0 && tid == 0 && info) info[2 - mode] += norm;  // actor: info[2] ; critic: info[1]
   }
-  __syncthreads();
-  // ---- phase 3: Adam
-  const float coef = s_coef * scale;
+  // ---- phase C: Adam
+  coef *= scale;
   const float omb1 = 1.f - beta1, omb2 = 1.f - beta2;
-  for (long i = tid; i < n; i += nt) {
+  for (long i = gtid; i < n; i += gnt) {
     float gi = g[i] * coef;
     const float pi = p[i];
     if (wd != 0.f) gi = gi + wd * pi;
@@ -619,20 +684,19 @@ __global__ __launch_bounds__(1024) void k_adam_fold(float *__restrict__ p, float
     v[i] = vi;
     p[i] = pi - lr_over_bc1 * (mi / (sqrtf(vi) / bc2_sqrt + eps));
   }
-  __syncthreads();
-  // ---- phase 4: re-fold   Wp = W*gamma ; bp = b + W.beta
+  grid_barrier(ws, (unsigned)(3 * G));
+  // ---- phase D: re-fold   Wp = W*gamma ; bp = b + W.beta
   for (int l = 0; l < n_layers; ++l) {
     const int *t = tab + l * TS;
     const int O = t[4], K = t[5];
     const float *gam = t[2] >= 0 ? p + t[2] : nullptr;
     const float *bet = t[3] >= 0 ? p + t[3] : nullptr;
-    for (int e = tid; e < O * K; e += nt) {
-      const int k = e % K;
+    for (long e = gtid; e < (long)O * K; e += gnt) {
+      const int k = (int)(e % K);
       const float w = p[t[0] + e];
       packs[t[6] + e] = gam ? w * gam[k] : w;
     }
-    const int wv = tid >> 6, ln = tid & 63;
-    for (int o = wv; o < O; o += (nt >> 6)) {
+    for (int o = gw; o < O; o += gnw) {
       float acc = 0.f;
       if (bet)
         for (int k = ln; k < K; k += 64) acc += p[t[0] + o * K + k] * bet[k];
@@ -640,17 +704,29 @@ __global__ __launch_bounds__(1024) void k_adam_fold(float *__restrict__ p, float
       if (ln == 0) packs[t[7] + o] = p[t[1] + o] + acc;
     }
   }
+  // ---- reset the barrier words for the next launch (last workgroup out)
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned done = __hip_atomic_fetch_add(ws + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (done == (unsigned)G - 1) {
+      __hip_atomic_store(ws, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(ws + 1, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 
 extern "C" int harl_adam_fold(float *param, float *grad, float *exp_avg, float *exp_avg_sq, long n, const float *dwp,
-                              const int *table, int n_layers, float *packs, const double *scalars, int mode,
-                              float const_scale, int logstd_off, int act_dim, float *info, int use_clip, float max_norm,
-                              float lr, float beta1, float beta2, float eps, float weight_decay,
-                              double bias_correction1, double bias_correction2, void *stream) {
+                              const int *table, int n_layers, float *packs, double *scalars, const float *part_scalars,
+                              int n_scalar_blocks, int mode, float const_scale, int logstd_off, int act_dim, float *info,
+                              int use_clip, float max_norm, float lr, float beta1, float beta2, float eps,
+                              float weight_decay, double bias_correction1, double bias_correction2, void *ws,
+                              void *stream) {
+  if (!ws) { set_error("harl_adam_fold: workspace (>= 32 KiB, zero-initialised once) is required"); return -2; }
   const float step_size = (float)((double)lr / bias_correction1);
   const float bc2_sqrt = (float)sqrt(bias_correction2);
-  hipLaunchKernelGGL(k_adam_fold, dim3(1), dim3(1024), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, dwp,
-                     table, n_layers, packs, scalars, mode, const_scale, logstd_off, act_dim, info, use_clip, max_norm,
-                     step_size, beta1, beta2, eps, weight_decay, bc2_sqrt);
+  hipLaunchKernelGGL(k_adam_fold, dim3(ADAM_WGS), dim3(ADAM_THREADS), 0, (hipStream_t)stream, param, grad, exp_avg,
+                     exp_avg_sq, n, dwp, table, n_layers, packs, scalars, part_scalars, n_scalar_blocks, mode,
+                     const_scale, logstd_off, act_dim, info, use_clip, max_norm, step_size, beta1, beta2, eps,
+                     weight_decay, bc2_sqrt, (unsigned *)ws);
   return check_launch("harl_adam_fold");
 }

@@ -171,17 +171,21 @@ class HAPPO(OnPolicyBase):
              ptr(idx), ptr(actions), ptr(avail), ptr(old_logp), ptr(adv), ptr(adv_moments), ptr(factor), ptr(active),
              float(self.clip_param), float(self.entropy_coef), int(self.action_aggregation == "mean"), self._surrogate_mode,
              mv, mp, ptr(net.dz[0]), ptr(net.dhead), ptr(net.part_scalars), s, tag="actor_head_loss")
-        net.scalars.zero_()
-        call("harl_reduce_scalars", ptr(net.part_scalars), _lib.load().harl_head_blocks(m), ptr(net.scalars), s)
         net.backward_trunk(obs, idx, m, seq=seq)
         sc = net.scalars
+        nblk = _lib.load().harl_head_blocks(m)
+        ps_kw = dict(part_scalars=net.part_scalars, n_scalar_blocks=nblk)  # reduced inside the optimiser launch
         if self.comm.enabled:  # ONE collective per optimiser step: [folded gradients | loss scalars]
+            sc.zero_()
+            call("harl_reduce_scalars", ptr(net.part_scalars), nblk, ptr(sc), s)
             if self._staging is None:
                 self._staging = torch.empty(net.total_dwp + 2 * PS_STRIDE, **self.tpdv)
             self.comm.all_reduce_packed(net.dwp, sc, self._staging)
+            ps_kw = {}
         # loss = sum / sum(active) (happo.py:77-85): gradients are linear in 1/sum(active), applied inside the kernel
         ls_off = -1 if net.discrete else net.offsets["act.action_out.log_std"][0]
-        self.actor_optimizer.step(0, 0.0, self.use_max_grad_norm, self.max_grad_norm, self._info, ls_off, net.act_dim)
+        self.actor_optimizer.step(0, 0.0, self.use_max_grad_norm, self.max_grad_norm, self._info, ls_off, net.act_dim,
+                                  **ps_kw)
         if self._grad_tap is not None:  # test hook: scaled, pre-clip gradient of this update (host sync)
             self._grad_tap(net.flat_grad * float(1.0 / sc[1].item()), sc.clone())
 

@@ -517,13 +517,17 @@ class FusedAdam:
         self.exp_avg = torch.zeros_like(net.flat_param)
         self.exp_avg_sq = torch.zeros_like(net.flat_param)
         self.step_count = 0
+        self._ws = torch.zeros(8192, dtype=torch.int32, device=net.flat_param.device)  # grid-barrier words + partials
 
     def zero_grad(self) -> None:  # gradients are overwritten, never accumulated
         return None
 
     def step(self, mode: int, const_scale: float, use_clip: bool, max_norm: float, info_out: Optional[torch.Tensor],
-             logstd_off: int = -1, act_dim: int = 0) -> None:
-        """One fused launch: loss scalars -> scale/statistics, unfold, ||g||, clip, Adam, re-fold (harl_adam_fold)."""
+             logstd_off: int = -1, act_dim: int = 0, part_scalars: Optional[torch.Tensor] = None,
+             n_scalar_blocks: int = 0) -> None:
+        """One fused launch: loss scalars -> scale/statistics, unfold, ||g||, clip, Adam, re-fold (harl_adam_fold).
+        ``part_scalars``: the loss kernel's per-block partial sums, reduced inside the launch into ``net.scalars``
+        (single-GPU path); None = ``net.scalars`` already holds the (all-reduced) sums."""
         g = self.param_groups[0]
         self.step_count += 1
         b1, b2 = g["betas"]
@@ -531,10 +535,10 @@ class FusedAdam:
         bc2 = 1.0 - b2 ** self.step_count
         n = self.net
         call("harl_adam_fold", ptr(n.flat_param), ptr(n.flat_grad), ptr(self.exp_avg), ptr(self.exp_avg_sq), n.n_params,
-             ptr(n.dwp), ptr(n.table), n.n_entries, ptr(n.pack_arena), ptr(n.scalars), int(mode),
-             float(const_scale), int(logstd_off), int(act_dim), ptr(info_out), int(use_clip), float(max_norm),
-             float(g["lr"]), float(b1), float(b2), float(g["eps"]), float(g["weight_decay"]), bc1, bc2, stream(),
-             tag="adam_fold")
+             ptr(n.dwp), ptr(n.table), n.n_entries, ptr(n.pack_arena), ptr(n.scalars), ptr(part_scalars),
+             int(n_scalar_blocks), int(mode), float(const_scale), int(logstd_off), int(act_dim), ptr(info_out),
+             int(use_clip), float(max_norm), float(g["lr"]), float(b1), float(b2), float(g["eps"]),
+             float(g["weight_decay"]), bc1, bc2, ptr(self._ws), stream(), tag="adam_fold")
 
     def state_dict(self) -> dict:
         return dict(step=self.step_count, exp_avg=self.exp_avg.clone(), exp_avg_sq=self.exp_avg_sq.clone(),

@@ -91,17 +91,20 @@ class VCritic:
              ptr(Wp), ptr(bp), ptr(idx), ptr(value_preds), ptr(returns), ptr(vn.stats) if vn is not None else None,
              float(self.clip_param), int(self.use_clipped_value_loss), int(self.use_huber_loss), float(self.huber_delta),
              mv, mp, ptr(net.dz[0]), ptr(net.dhead), ptr(net.part_scalars), s, tag="critic_head_loss")
-        net.scalars.zero_()
-        call("harl_reduce_scalars", ptr(net.part_scalars), _lib.load().harl_head_blocks(m), ptr(net.scalars), s)
         net.backward_trunk(share_obs, idx, m, seq=seq)
         sc = net.scalars
+        nblk = _lib.load().harl_head_blocks(m)
+        ps_kw = dict(part_scalars=net.part_scalars, n_scalar_blocks=nblk)  # reduced inside the optimiser launch
         if self.comm.enabled:
+            sc.zero_()
+            call("harl_reduce_scalars", ptr(net.part_scalars), nblk, ptr(sc), s)
             if self._staging is None:
                 self._staging = torch.empty(net.total_dwp + 2 * PS_STRIDE, **self.tpdv)
             self.comm.all_reduce_packed(net.dwp, sc, self._staging)
+            ps_kw = {}
         # loss = mean over the (global) minibatch, times value_loss_coef before backward (v_critic.py:112,146)
         scale = float(self.value_loss_coef) / float(m_global)
-        self.critic_optimizer.step(1, scale, self.use_max_grad_norm, self.max_grad_norm, self._info)
+        self.critic_optimizer.step(1, scale, self.use_max_grad_norm, self.max_grad_norm, self._info, **ps_kw)
         if self._grad_tap is not None:
             self._grad_tap(net.flat_grad * scale, sc.clone())
 

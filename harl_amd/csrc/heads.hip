@@ -372,6 +372,14 @@ __global__ __launch_bounds__(WG_THREADS) void k_actor_head(ActorArgs A) {
     }
 
     // ---------------- loss + backward (happo.py:66-91) ----------------
+    if (A.logp_out && valid && h == 0) {  // log pi(a|o) under the CURRENT parameters, by batch position
+      if (DISCRETE) A.logp_out[j] = z[0];
+      else {
+#pragma unroll
+        for (int d = 0; d < DAP; ++d)
+          if (d < D) A.logp_out[j * D + d] = logp_d[d];
+      }
+    }
     const float act = A.active ? A.active[row] : 1.f;
     const float advn = (A.adv[row] - adv_mean) / adv_den;
     const float fct = A.factor_in[row];
@@ -811,10 +819,12 @@ extern "C" int harl_actor_head_loss(const float *xL, const uint32_t *relu_mask, 
                                     const float *actions, const float *avail, const float *old_logp, const float *adv,
                                     const double *adv_moments, const float *factor, const float *active,
                                     float clip_param, float entropy_coef, int agg_mean, int trpo, long m_valid,
-                                    long m_pad, float *dzL, float *dhead, float *part_scalars, void *stream) {
+                                    long m_pad, float *logp_out, float *dzL, float *dhead, float *part_scalars,
+                                    void *stream) {
   if (M <= 0) return 0;
   ActorArgs A{};
   A.trpo = trpo;
+  A.logp_out = logp_out;
   A.m_valid = m_valid; A.m_pad = m_pad;
   A.xL = xL; A.relu_mask = relu_mask; A.rstd = rstd; A.M = M; A.Whp = Whp; A.bhp = bhp; A.log_std = log_std;
   A.std_x_coef = std_x_coef; A.std_y_coef = std_y_coef; A.act_dim = act_dim; A.idx = idx;

@@ -158,8 +158,10 @@ class HAPPO(OnPolicyBase):
         self._grad_tap = None
 
     # ---- one optimiser step on rows idx[0..m) of the flat [T*N, .] tensors (happo.py:28-102) ---------
-    def _update_core(self, obs, idx, m, actions, avail, old_logp, adv, adv_moments, factor, active, seq=None):
-        """``seq`` (recurrent nets): the batch is L x m_pad rows in the GRU layout (nets.build_seq), idx = seq['idx']."""
+    def _update_core(self, obs, idx, m, actions, avail, old_logp, adv, adv_moments, factor, active, seq=None,
+                     logp_out=None):
+        """``seq`` (recurrent nets): the batch is L x m_pad rows in the GRU layout (nets.build_seq), idx = seq['idx'].
+        ``logp_out`` [m, act_w]: also emit log pi(a|o) under the pre-step parameters (by batch position)."""
         net = self.actor
         net.forward_trunk(obs, idx, m, seq=seq)
         Wp, bp = net._packs[-1]
@@ -170,7 +172,7 @@ class HAPPO(OnPolicyBase):
              ptr(Wp), ptr(bp), ptr(net.log_std()), net.std_x_coef, net.std_y_coef, int(net.discrete), net.act_dim,
              ptr(idx), ptr(actions), ptr(avail), ptr(old_logp), ptr(adv), ptr(adv_moments), ptr(factor), ptr(active),
              float(self.clip_param), float(self.entropy_coef), int(self.action_aggregation == "mean"), self._surrogate_mode,
-             mv, mp, ptr(net.dz[0]), ptr(net.dhead), ptr(net.part_scalars), s, tag="actor_head_loss")
+             mv, mp, ptr(logp_out), ptr(net.dz[0]), ptr(net.dhead), ptr(net.part_scalars), s, tag="actor_head_loss")
         net.backward_trunk(obs, idx, m, seq=seq)
         sc = net.scalars
         nblk = _lib.load().harl_head_blocks(m)
@@ -226,13 +228,20 @@ class HAPPO(OnPolicyBase):
         adv = _as_dev(advantages, self.device).reshape(T * N)
         call("harl_masked_moments", ptr(adv), ptr(actor_buffer.flat("active_masks")), T * N, ptr(out), stream())
 
-    def train(self, actor_buffer: OnPolicyActorBuffer, advantages, state_type, _pre=None, _defer=False):
+    def fuses_old_logp(self) -> bool:
+        """True when train()'s first forward sees every buffer row, in order, under the pre-update parameters -- i.e. it
+        computes exactly what the runner's pre-update log-prob pass computes (on_policy_ha_runner.py:66-83)."""
+        return self.actor_num_mini_batch == 1 and not (self.use_recurrent_policy or self.use_naive_recurrent_policy)
+
+    def train(self, actor_buffer: OnPolicyActorBuffer, advantages, state_type, _pre=None, _defer=False,
+              _old_logp_out=None):
         """ppo_epoch x actor_num_mini_batch updates (happo.py:104-158).  ``advantages`` is the raw [T, N, 1]
         advantage tensor; the per-agent masked normalisation (happo.py:122-127) is folded into the loss kernel
         through the fp64 moments {sum, sumsq, count}.
         Runner-internal: ``_pre = (moments[3] device fp64, count)`` when the runner already reduced the moments of all
         agents with one read-back; ``_defer`` returns the averaged statistics as a device tensor (resolved by the
-        runner in one transfer at the end of train()) and leaves deferred RNG advances pending."""
+        runner in one transfer at the end of train()) and leaves deferred RNG advances pending; ``_old_logp_out``
+        [T*N, act_w] receives the pre-update log-probs from the first epoch's forward (only if ``fuses_old_logp()``)."""
         dev = self.device
         buf = actor_buffer
         T, N = buf.actions.shape[:2]
@@ -259,7 +268,7 @@ class HAPPO(OnPolicyBase):
         old_logp = buf.flat("action_log_probs")
         factor = buf.factor.reshape(B)
         n_global = self.shard[0] * T if self.shard else B
-        for _ in range(self.ppo_epoch):
+        for epoch in range(self.ppo_epoch):
             if self.use_recurrent_policy or self.use_naive_recurrent_policy:
                 for seq in buf.recurrent_batches(self.actor_num_mini_batch, self.data_chunk_length,
                                                  naive=not self.use_recurrent_policy, shard=self.shard):
@@ -271,7 +280,8 @@ class HAPPO(OnPolicyBase):
                 # generator state is replayed (bit-exact RNG stream), not the 819200-element shuffle itself
                 consume_randperm(n_global)
                 self._update_core(obs, None, B, actions, avail, old_logp, adv, moments, factor,
-                                  active if self.use_policy_active_masks else None)
+                                  active if self.use_policy_active_masks else None,
+                                  logp_out=_old_logp_out if epoch == 0 else None)
                 continue
             sampler = minibatch_indices(n_global, self.actor_num_mini_batch)  # CPU RNG draw, bit-exact with the reference
             for ind in sampler:

@@ -131,9 +131,15 @@ class OnPolicyHARunner:
                 self._logp_old = torch.empty(B, actor.actor.act_w, dtype=torch.float32, device=dev)
             actor.actor.fold()
             rnn_kw = dict(rnn_states=buf.rnn_states[0], masks=buf.flat("masks")) if actor.actor.recurrent else {}
-            actor._logp_pass(obs, actions, avail, B, self._logp_old, **rnn_kw)  # pre-update log-probs (:66-83)
             adv_a = advantages if self.state_type == "EP" else advantages[:, :, agent_id].contiguous()
             kw = dict(_pre=(mom_all[agent_id], counts[agent_id]), _defer=True) if fast[agent_id] else {}
+            # pre-update log-probs (:66-83).  With one full-buffer minibatch the first epoch's forward inside train()
+            # computes exactly these (same rows, same parameters), so they are taken from there.
+            fused_old = fast[agent_id] and actor.fuses_old_logp() and counts[agent_id] > 0.0
+            if fused_old:
+                kw["_old_logp_out"] = self._logp_old
+            else:
+                actor._logp_pass(obs, actions, avail, B, self._logp_old, **rnn_kw)
             info = actor.train(buf, adv_a, self.state_type, **kw)               # :86-93
             pending.append((len(actor_train_infos), info, actor._INFO_KEYS) if torch.is_tensor(info) else None)
             actor_train_infos.append(info)

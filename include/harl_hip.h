@@ -181,14 +181,17 @@ int harl_actor_head_logp(const float *xL, long M, int H, const float *Whp, const
  *   trpo: 0 = HAPPO; 1 = HATRPO surrogate  sum_s +ratio*f*adv*active  (no clip, no entropy term;
  *   algorithms/actors/hatrpo.py:77-95); 2 = HAA2C  sum_s -ratio*f*adv*active  (no clip; algorithms/actors/haa2c.py:70-80).
  *   Scalar 0 is that sum.
+ *   logp_out (optional): log pi(a|o) of every row under the current parameters, [M, act_w] by batch position -- with a
+ *   single full-buffer minibatch the first epoch's forward IS the runner's pre-update log-prob pass
+ *   (on_policy_ha_runner.py:66-83), so the runner takes it from here instead of running that pass separately.
  */
 int harl_actor_head_loss(const float *xL, const uint32_t *relu_mask, const float *rstd, long M, int H,
                          const float *Whp, const float *bhp, const float *log_std, float std_x_coef,
                          float std_y_coef, int discrete, int act_dim, const int64_t *idx, const float *actions,
                          const float *avail, const float *old_logp, const float *adv, const double *adv_moments,
                          const float *factor, const float *active, float clip_param, float entropy_coef,
-                         int agg_mean, int trpo, long m_valid, long m_pad, float *dzL, float *dhead, float *part_scalars,
-                         void *stream);
+                         int agg_mean, int trpo, long m_valid, long m_pad, float *logp_out, float *dzL, float *dhead,
+                         float *part_scalars, void *stream);
 /* V head forward: values[M] = Whp . xL + bhp   (v_net.py:64) */
 int harl_critic_head_values(const float *xL, long M, int H, const float *Whp, const float *bhp, float *values,
                             void *stream);

@@ -378,14 +378,29 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_fwd_input_staged(const float 
   const int lane_row = RPI == 2 ? h : 0, lane_k = RPI == 2 ? i : lane;
   const long slab0 = (long)blockIdx.x * WAVES_PER_WG + wave, slab_stride = (long)gridDim.x * WAVES_PER_WG;
   float pf[NPF];  // next slab's rows, in flight while this slab computes
+  // Branch-free on purpose: with `idx ? idx[j] : j` and a predicated load inside the unrolled loop, hipcc emitted a
+  // uniform branch + exec-masked load per row and closed each with s_waitcnt vmcnt(0) -- the 16-32 row loads of a slab
+  // were fully serialised (rocprofv3: waves 40 % of their time in s_waitcnt, MFMA pipe 49 % busy in the fused kernel).
+  const int lane_kc = lane_k < D ? lane_k : 0;
   auto prefetch_rows = [&](long slab) {
+    int rows[NPF];
+    if (idx) {
 #pragma unroll
-    for (int u = 0; u < NPF; ++u) {
-      long j = slab * SLAB + u * RPI + lane_row;
-      if (j > M - 1) j = M - 1;
-      const long row = idx ? idx[j] : j;
-      pf[u] = lane_k < D ? X[row * ldx + lane_k] : 0.f;
+      for (int u = 0; u < NPF; ++u) {
+        long j = slab * SLAB + u * RPI + lane_row;
+        rows[u] = (int)idx[j < M ? j : M - 1];
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < NPF; ++u) {
+        long j = slab * SLAB + u * RPI + lane_row;
+        rows[u] = (int)(j < M ? j : M - 1);
+      }
     }
+    // no select on the loaded value (lanes >= D fetch column 0 and simply never store it to LDS): a dependent VALU op
+    // right behind each load made hipcc wait for every load individually (s_waitcnt vmcnt(0) x NPF per slab)
+#pragma unroll
+    for (int u = 0; u < NPF; ++u) pf[u] = X[(long)rows[u] * ldx + lane_kc];
   };
   if (slab0 < n_slabs) prefetch_rows(slab0);
   for (long slab = slab0; slab < n_slabs; slab += slab_stride) {
@@ -530,14 +545,29 @@ __global__ __launch_bounds__(64 * FUSED_WAVES, 2) void k_fwd_fused2(
   const long slab0 = (long)blockIdx.x * FUSED_WAVES + wave, slab_stride = (long)gridDim.x * FUSED_WAVES;
 
   float pf[NPF];  // next slab's rows, in flight while this slab computes
+  // Branch-free on purpose: with `idx ? idx[j] : j` and a predicated load inside the unrolled loop, hipcc emitted a
+  // uniform branch + exec-masked load per row and closed each with s_waitcnt vmcnt(0) -- the 16-32 row loads of a slab
+  // were fully serialised (rocprofv3: waves 40 % of their time in s_waitcnt, MFMA pipe 49 % busy in the fused kernel).
+  const int lane_kc = lane_k < D ? lane_k : 0;
   auto prefetch_rows = [&](long slab) {
+    int rows[NPF];
+    if (idx) {
 #pragma unroll
-    for (int u = 0; u < NPF; ++u) {
-      long j = slab * SLAB + u * RPI + lane_row;
-      if (j > M - 1) j = M - 1;
-      const long row = idx ? idx[j] : j;
-      pf[u] = lane_k < D ? X[row * ldx + lane_k] : 0.f;
+      for (int u = 0; u < NPF; ++u) {
+        long j = slab * SLAB + u * RPI + lane_row;
+        rows[u] = (int)idx[j < M ? j : M - 1];
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < NPF; ++u) {
+        long j = slab * SLAB + u * RPI + lane_row;
+        rows[u] = (int)(j < M ? j : M - 1);
+      }
     }
+    // no select on the loaded value (lanes >= D fetch column 0 and simply never store it to LDS): a dependent VALU op
+    // right behind each load made hipcc wait for every load individually (s_waitcnt vmcnt(0) x NPF per slab)
+#pragma unroll
+    for (int u = 0; u < NPF; ++u) pf[u] = X[(long)rows[u] * ldx + lane_kc];
   };
   auto lds_frag = [&](int q, float (&a)[4 * NT_]) {
     const float *wq = wl_lane + 32 * (q >> 2) + 8 * (q & 3);
@@ -649,6 +679,11 @@ __global__ __launch_bounds__(64 * FUSED_WAVES, 2) void k_fwd_fused2(
       if (x0n_out) x0n_store<NCH>(xr, mean, rstd0, lane, slab, x0n_out);
     }
     __builtin_amdgcn_wave_barrier();  // all lanes done with xw before the next slab's rows overwrite it
+    // next slab's rows: issued BEFORE the layer-2 GEMM (16 more live VGPRs) so that ~16k MFMA cycles cover the HBM
+    // latency.  Issued after it, only the ~1.5k-cycle epilogue did, and rocprofv3 showed the waves 40 % of their time in
+    // s_waitcnt with the MFMA pipe 49 % busy.
+    if (slab + slab_stride < n_slabs) prefetch_rows(slab + slab_stride);
+    __builtin_amdgcn_sched_barrier(0);
 
     // ---- layer 2 straight out of the register file
     f32x16 acc[NT_];
@@ -671,9 +706,6 @@ __global__ __launch_bounds__(64 * FUSED_WAVES, 2) void k_fwd_fused2(
           if (q + 1 < NQ) aX[c * NT_ + t] = wn[32 * t * LDW + c];
         }
     }
-    // next slab's rows: issued here (not earlier) so the 16-32 prefetch registers are not live across the layer-2
-    // loop; the epilogue below (~1.5k cycles) and the other wave's MFMAs cover most of the latency
-    if (slab + slab_stride < n_slabs) prefetch_rows(slab + slab_stride);
     relu_norm_store<H>(acc, lane, slab, x2out, mask2, rstd2);
   }
 }

@@ -80,34 +80,101 @@ __device__ __forceinline__ void atl_store(float *__restrict__ base, long slab, i
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// ReLU masks.  One bit per (sample, feature): lane (s, h) keeps H/2 bits in (H/2+31)/32 words, feature register R in
+// word R>>5, pushed MSB-first (R = 0 ends up in bit 31) and consumed in the same order by shifting the top bit out
+// into VCC.  On gfx950 VALU instructions are NOT overlapped with another wave's MFMAs on the same SIMD (measured:
+// tools/mfma_lds.hip, time = 64 cycles x MFMAs + 4 cycles x VALU ops), so the epilogues of the MFMA kernels are written
+// for instruction count: 3 ops per element for relu + mask here (compare, select, add-with-carry), 2 to apply a mask.
+// ---------------------------------------------------------------------------------------------
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float relu_push(float a, uint32_t &bits) {  // returns a > 0 ? a : 0 ; bits = bits<<1 | (a>0)
+  float v;
+  asm volatile("v_cmp_lt_f32 vcc, 0, %2\n\tv_cndmask_b32 %0, 0, %2, vcc\n\tv_addc_co_u32 %1, vcc, %1, %1, vcc"
+               : "=&v"(v), "+v"(bits)
+               : "v"(a)
+               : "vcc");
+  return v;
+}
+__device__ __forceinline__ float mask_pop(float x, uint32_t &bits) {  // returns top bit ? x : 0 ; bits <<= 1
+  float o;
+  asm volatile("v_add_co_u32 %1, vcc, %1, %1\n\tv_cndmask_b32 %0, 0, %2, vcc" : "=&v"(o), "+v"(bits) : "v"(x) : "vcc");
+  return o;
+}
+
 // backward of  x_hat = norm(relu(z))  for one sample per lane-pair:
 //   da = rstd (dx_hat - mean_f(dx_hat) - x_hat mean_f(dx_hat x_hat)) ;  dz = relu_mask ? da : 0 ; store ATL
+// evaluated as  da = fma(x_hat, -s2 rstd, fma(dx_hat, rstd, -s1 rstd))  on register pairs (v_pk_fma_f32).
 template <int H>
 __device__ __forceinline__ void ln_bwd_relu_store(const float (&dx)[H / 2], const float (&xh)[H / 2],
                                                   const uint32_t *__restrict__ mask_in, float rstd, int lane, long slab,
                                                   float *__restrict__ dz_out) {
   constexpr int NR = H / 2;
   constexpr int NW = (NR + 31) / 32;
-  float s1 = 0.f, s2 = 0.f;
+  f32x2 a1 = {0.f, 0.f}, a2 = {0.f, 0.f};
 #pragma unroll
-  for (int R = 0; R < NR; ++R) {
-    s1 += dx[R];
-    s2 += dx[R] * xh[R];
+  for (int P = 0; P < NR / 2; ++P) {
+    const f32x2 d = {dx[2 * P], dx[2 * P + 1]}, x = {xh[2 * P], xh[2 * P + 1]};
+    a1 += d;
+    a2 += d * x;
   }
+  float s1 = a1[0] + a1[1], s2 = a2[0] + a2[1];
   s1 += wave_xor32(s1);
   s2 += wave_xor32(s2);
-  s1 *= (1.0f / H);
-  s2 *= (1.0f / H);
+  const float c1 = -(s1 * (1.0f / H)) * rstd, c2 = -(s2 * (1.0f / H)) * rstd;
+  const f32x2 c1v = {c1, c1}, c2v = {c2, c2}, rv = {rstd, rstd};
   uint32_t bits[NW];
 #pragma unroll
   for (int w = 0; w < NW; ++w) bits[w] = mask_in[(slab * NW + w) * WAVE + lane];
   float out[NR];
 #pragma unroll
-  for (int R = 0; R < NR; ++R) {
-    float da = rstd * (dx[R] - s1 - xh[R] * s2);
-    out[R] = ((bits[R >> 5] >> (R & 31)) & 1u) ? da : 0.f;
+  for (int P = 0; P < NR / 2; ++P) {
+    const f32x2 d = {dx[2 * P], dx[2 * P + 1]}, x = {xh[2 * P], xh[2 * P + 1]};
+    const f32x2 da = __builtin_elementwise_fma(x, c2v, __builtin_elementwise_fma(d, rv, c1v));
+    out[2 * P] = mask_pop(da[0], bits[(2 * P) >> 5]);
+    out[2 * P + 1] = mask_pop(da[1], bits[(2 * P + 1) >> 5]);
   }
   atl_store<H>(dz_out, slab, lane, out);
+}
+
+// Workgroup-cooperative copy of a row-major [ROWS][COLS] fp32 matrix from global memory into LDS with row stride LD.
+// All of a thread's float4 loads are issued before the first LDS write: the prologue of the persistent MFMA kernels
+// costs one L2 latency instead of ROWS*COLS/NTHR dependent-looking scalar round trips (it was ~20 us of a ~250 us
+// kernel, see tools/mfma_lds.hip).  Falls back to scalar loads when src is not 16-byte aligned.
+template <int ROWS, int COLS, int LD, int NTHR>
+__device__ __forceinline__ void stage_matrix(float *__restrict__ dst, const float *__restrict__ src) {
+  static_assert(COLS % 4 == 0, "rows are copied in float4 pieces");
+  constexpr int NV = ROWS * COLS / 4, PER = (NV + NTHR - 1) / NTHR;
+  if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+    f32x4 v[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int e4 = threadIdx.x + u * NTHR;
+      v[u] = e4 < NV ? reinterpret_cast<const f32x4 *>(src)[e4] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int e4 = threadIdx.x + u * NTHR;
+      if (e4 < NV) {
+        const int e = 4 * e4, o = e / COLS, k = e - o * COLS;
+        float *d = dst + o * LD + k;
+        if constexpr (LD % 4 == 0) {
+          *reinterpret_cast<f32x4 *>(d) = v[u];
+        } else {
+          d[0] = v[u][0];
+          d[1] = v[u][1];
+          d[2] = v[u][2];
+          d[3] = v[u][3];
+        }
+      }
+    }
+  } else {
+    for (int e = threadIdx.x; e < ROWS * COLS; e += NTHR) {
+      const int o = e / COLS, k = e - o * COLS;
+      dst[o * LD + k] = src[e];
+    }
+  }
 }
 
 // dynamic LDS above 64 KiB needs an explicit opt-in per kernel

@@ -83,11 +83,8 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_gru_fwd(
   float *Whl = Wil + 3 * GH * LDW;      // [192][65]
   float *bil = Whl + 3 * GH * LDW;      // [192]
   float *bhl = bil + 3 * GH;            // [192]
-  for (int e = threadIdx.x; e < 3 * GH * GH; e += WG_THREADS) {
-    const int o = e / GH, k = e - o * GH;
-    Wil[o * LDW + k] = Wih[e];
-    Whl[o * LDW + k] = Whh[e];
-  }
+  stage_matrix<3 * GH, GH, LDW, WG_THREADS>(Wil, Wih);
+  stage_matrix<3 * GH, GH, LDW, WG_THREADS>(Whl, Whh);
   for (int e = threadIdx.x; e < 3 * GH; e += WG_THREADS) {
     bil[e] = bih[e];
     bhl[e] = bhh[e];
@@ -196,10 +193,8 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_gru_bwd(
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float *Wil = lds;                 // [192][64] row-major
   float *Whl = Wil + 3 * GH * GH;   // [192][64]
-  for (int e = threadIdx.x; e < 3 * GH * GH; e += WG_THREADS) {
-    Wil[e] = Wih[e];
-    Whl[e] = Whh[e];
-  }
+  stage_matrix<3 * GH, GH, GH, WG_THREADS>(Wil, Wih);
+  stage_matrix<3 * GH, GH, GH, WG_THREADS>(Whl, Whh);
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 31, h = lane >> 5;

@@ -116,7 +116,7 @@ __device__ __forceinline__ void head_bwd_stream(const float *__restrict__ xL, co
 #pragma unroll 1
   for (int q = 0; q < H / 8; ++q) {
     const f32x4 xn = xp[(q + 1 < H / 8 ? q + 1 : q) * WAVE];
-    const uint32_t bits = ((q >> 3) ? b1 : b0) >> ((4 * q) & 31);
+    if (q == 8) b0 = b1;  // second mask word (features R = 32..63 of this lane); bits are consumed MSB-first
     f32x4 o;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -127,7 +127,8 @@ __device__ __forceinline__ void head_bwd_stream(const float *__restrict__ xL, co
         dx += dzh[4 * dq + 0] * w[0] + dzh[4 * dq + 1] * w[1] + dzh[4 * dq + 2] * w[2] + dzh[4 * dq + 3] * w[3];
       }
       const float da = rstd * (dx - s1 - xv[c] * s2);
-      o[c] = ((bits >> c) & 1u) ? da : 0.f;
+      o[c] = (int)b0 < 0 ? da : 0.f;  // MSB-first mask (common.h); plain C here: these kernels are HBM-bound and
+      b0 <<= 1;                        // the asm form of mask_pop only restricts the scheduler
     }
     op[q * WAVE] = o;
     xv = xn;
@@ -175,14 +176,14 @@ __device__ __forceinline__ void head_bwd_regs(const f32x4 (&xs)[H / 8], const ui
                                               const float (&dzh)[DAP], float s1, float s2,
                                               float *__restrict__ dz_out) {
   constexpr int NW = (H / 2 + 31) / 32;
-  const uint32_t b0 = mask_in[(slab * NW + 0) * WAVE + lane];
+  uint32_t b0 = mask_in[(slab * NW + 0) * WAVE + lane];
   const uint32_t b1 = NW > 1 ? mask_in[(slab * NW + (NW - 1)) * WAVE + lane] : 0u;
   s1 *= (1.0f / H);
   s2 *= (1.0f / H);
   f32x4 *op = reinterpret_cast<f32x4 *>(dz_out + slab * (long)(H * SLAB)) + lane;
 #pragma unroll
   for (int q = 0; q < H / 8; ++q) {
-    const uint32_t bits = ((q >> 3) ? b1 : b0) >> ((4 * q) & 31);
+    if (q == 8) b0 = b1;  // second mask word; bits are consumed MSB-first
     f32x4 o;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -193,7 +194,8 @@ __device__ __forceinline__ void head_bwd_regs(const f32x4 (&xs)[H / 8], const ui
         dx += dzh[4 * dq + 0] * w[0] + dzh[4 * dq + 1] * w[1] + dzh[4 * dq + 2] * w[2] + dzh[4 * dq + 3] * w[3];
       }
       const float da = rstd * (dx - s1 - xs[q][c] * s2);
-      o[c] = ((bits >> c) & 1u) ? da : 0.f;
+      o[c] = (int)b0 < 0 ? da : 0.f;  // MSB-first mask (common.h); plain C here: these kernels are HBM-bound and
+      b0 <<= 1;                        // the asm form of mask_pop only restricts the scheduler
     }
     op[q * WAVE] = o;
     __builtin_amdgcn_sched_barrier(0);

@@ -31,28 +31,34 @@ __device__ __forceinline__ void relu_norm_regs(f32x16 (&acc)[HO / 32], float (&v
   constexpr int NR = HO / 2;
 #pragma unroll
   for (int w = 0; w < (NR + 31) / 32; ++w) bits[w] = 0u;
-  float sum = 0.f;
 #pragma unroll
-  for (int R = 0; R < NR; ++R) {
-    float a = acc[R >> 4][R & 15];
-    bool pos = a > 0.f;
-    a = pos ? a : 0.f;
-    bits[R >> 5] |= pos ? (1u << (R & 31)) : 0u;
-    v[R] = a;
-    sum += a;
-  }
+  for (int R = 0; R < NR; ++R) v[R] = relu_push(acc[R >> 4][R & 15], bits[R >> 5]);
+  // statistics and normalisation on register pairs (v_pk_add_f32 / v_pk_fma_f32 / v_pk_mul_f32)
+  f32x2 s2v = {0.f, 0.f};
+#pragma unroll
+  for (int P = 0; P < NR / 2; ++P) s2v += f32x2{v[2 * P], v[2 * P + 1]};
+  float sum = s2v[0] + s2v[1];
   sum += wave_xor32(sum);
   const float mean = sum * (1.0f / HO);
-  float vs = 0.f;
+  const f32x2 mv = {mean, mean};
+  f32x2 vsv = {0.f, 0.f};
 #pragma unroll
-  for (int R = 0; R < NR; ++R) {
-    float d = v[R] - mean;
-    vs += d * d;
+  for (int P = 0; P < NR / 2; ++P) {
+    const f32x2 d = f32x2{v[2 * P], v[2 * P + 1]} - mv;
+    vsv = __builtin_elementwise_fma(d, d, vsv);
+    v[2 * P] = d[0];
+    v[2 * P + 1] = d[1];
   }
+  float vs = vsv[0] + vsv[1];
   vs += wave_xor32(vs);
   const float rstd = 1.0f / sqrtf(vs * (1.0f / HO) + 1e-5f);
+  const f32x2 rv = {rstd, rstd};
 #pragma unroll
-  for (int R = 0; R < NR; ++R) v[R] = (v[R] - mean) * rstd;
+  for (int P = 0; P < NR / 2; ++P) {
+    const f32x2 o = f32x2{v[2 * P], v[2 * P + 1]} * rv;
+    v[2 * P] = o[0];
+    v[2 * P + 1] = o[1];
+  }
   rstd_out = rstd;
 }
 
@@ -95,7 +101,7 @@ __device__ __forceinline__ void ln_jac_store(f32x16 (&acc)[HO / 32], const float
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
   for (int R = 0; R < NR; ++R) {
-    ad[R] = ((bits[R >> 5] >> (R & 31)) & 1u) ? acc[R >> 4][R & 15] : 0.f;
+    ad[R] = mask_pop(acc[R >> 4][R & 15], bits[R >> 5]);
     s1 += ad[R];
     s2 += ad[R] * xh[R];
   }
@@ -123,10 +129,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_fwd_hidden(const float *__res
   constexpr int LDW = HI + 1;
   float *Wl = lds;
   float *bl = lds + HO * LDW;
-  for (int e = threadIdx.x; e < HO * HI; e += WG_THREADS) {
-    int o = e / HI, k = e - o * HI;
-    Wl[o * LDW + k] = Wp[e];
-  }
+  stage_matrix<HO, HI, LDW, WG_THREADS>(Wl, Wp);
   for (int e = threadIdx.x; e < HO; e += WG_THREADS) bl[e] = bp[e];
   __syncthreads();
 
@@ -523,10 +526,7 @@ __global__ __launch_bounds__(64 * FUSED_WAVES, 2) void k_fwd_fused2(
   float *Wt = b2l + H;                          // [krows][H]   W1'^T
   float *W2l = Wt + krows * H;                  // [H][H+1]
   for (int e = threadIdx.x; e < FUSED_WAVES * SLAB * LDX; e += NTHR) xs[e] = 0.f;  // pad columns stay zero
-  for (int e = threadIdx.x; e < H * H; e += NTHR) {
-    int o = e / H, k = e - o * H;
-    W2l[o * LDW + k] = W2p[e];
-  }
+  stage_matrix<H, H, LDW, NTHR>(W2l, W2p);
   for (int e = threadIdx.x; e < H; e += NTHR) {
     b2l[e] = b2p[e];
     b1l[e] = b1p[e];
@@ -724,7 +724,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_bwd_dx(const float *__restric
                                                           long n_slabs) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float *Wl = lds;  // [HO][HI] row-major
-  for (int e = threadIdx.x; e < HO * HI; e += WG_THREADS) Wl[e] = Wp[e];
+  stage_matrix<HO, HI, HI, WG_THREADS>(Wl, Wp);
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 31, h = lane >> 5;
@@ -1109,11 +1109,8 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_tangent_hidden(const float *_
   float *Wl = lds;
   float *Wdl = lds + HO * LDW;
   float *bl = Wdl + HO * LDW;
-  for (int e = threadIdx.x; e < HO * HI; e += WG_THREADS) {
-    int o = e / HI, k = e - o * HI;
-    Wl[o * LDW + k] = Wp[e];
-    Wdl[o * LDW + k] = Wdp[e];
-  }
+  stage_matrix<HO, HI, LDW, WG_THREADS>(Wl, Wp);
+  stage_matrix<HO, HI, LDW, WG_THREADS>(Wdl, Wdp);
   for (int e = threadIdx.x; e < HO; e += WG_THREADS) bl[e] = bdp[e];
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

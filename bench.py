@@ -12,8 +12,9 @@ the timed region.  One transition = one (t, n) environment step for all agents. 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus 8 --steps 5 --warmup 2
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel family (HIP-event timing of every launch
-of that family inside the timed region); `cpu_baseline` is the oracle (a torch-CPU restatement of the reference,
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant MFMA kernel family (HIP-event timing of every launch
+of the four MFMA families inside the timed region; `traffic` from the committed PMC pass in profiles/); `kernels` is the
+full per-kernel breakdown from extra instrumented steps after the timed region; `cpu_baseline` is the oracle (a torch-CPU restatement of the reference,
 same ATen kernels) timed on this box's host cores on a bounded sample of the same workload.
 """
 from __future__ import annotations
@@ -169,20 +170,28 @@ def main():
     for _ in range(args.warmup):
         one_step(r)
     barrier()
+    # Roofline timing lives INSIDE the timed region: every launch of the four MFMA kernel families is bracketed by HIP
+    # events on the launch stream (64 event pairs per step, <1 % of wall time).
+    MFMA_TAGS = ("fwd_fused2", "fwd_hidden", "bwd_dx", "dw_hidden")
+    if not args.no_kernel_timing:
+        _lib.enable_kernel_timing(True, MFMA_TAGS)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step(r)
     barrier()
     dt = time.perf_counter() - t0
+    mfma_kern = {}
+    if not args.no_kernel_timing:
+        mfma_kern = _lib.collect_kernel_timing()
+        _lib.enable_kernel_timing(False)
     if comm.enabled:
         tt = torch.tensor([dt], dtype=torch.float64, device=device)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt.item())
-    # Per-kernel HIP-event timing: `instr_steps` further steps of the SAME workload right after the timed region, every
-    # tagged launch bracketed by two events on the launch stream.  It is kept out of the K timed steps because ~700
-    # event pairs per step cost ~10 % of wall time, which would understate `value`.
+    # Full per-kernel breakdown (every tagged launch, ~270 event pairs per step ~ 10 % of wall time): `instr_steps`
+    # further steps of the SAME workload after the timed region, so that it does not understate `value`.
     kern = {}
-    if not args.no_kernel_timing:
+    if not args.no_kernel_timing and args.instr_steps > 0:
         _lib.enable_kernel_timing(True)
         for _ in range(args.instr_steps):
             one_step(r)
@@ -199,15 +208,31 @@ def main():
         # its ALGORITHMIC flops per launch (Linear layers only) / its average HIP-event duration
         flops = dict(fwd_hidden=2.0 * B * 128 * 128, bwd_dx=2.0 * B * 128 * 128, dw_hidden=2.0 * B * 128 * 128,
                      fwd_fused2=2.0 * B * (128 * 128 + OBS * 128))
-        cand = {k: v for k, v in kern.items() if k in flops and v["n"] > 0}
+        cand = {k: v for k, v in mfma_kern.items() if k in flops and v["n"] > 0}
         roof = None
         if cand:
             dom = max(cand, key=lambda k: cand[k]["total_ms"])
             avg_s = cand[dom]["avg_ms"] * 1e-3
             ach = flops[dom] / avg_s
+            # ALGORITHMIC HBM bytes per launch of each family for THIS run's launch mix: the fused forward is
+            # launched 15x per step in training mode (writes x_hat_1, x_hat_2, the normalised inputs, masks, statistics)
+            # and 3x in log-prob mode (x_hat_2 only).
+            alg = dict(fwd_hidden=B * (512 + 512 + 16 + 4), bwd_dx=B * (512 + 512 + 16 + 4 + 512), dw_hidden=B * (512 + 512),
+                       fwd_fused2=B * (15 * (4 * OBS + 512 + 512 + 128 + 32 + 16) + 3 * (4 * OBS + 512 + 16 + 4)) / 18.0)
+            traffic, traffic_note = None, None
+            tp = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+            if os.path.exists(tp):  # PMC pass over the same kernels (tools/kbench.py); measured/algorithmic ratio per family
+                tj = json.load(open(tp))
+                if dom in tj["kernels"]:
+                    ratio = tj["kernels"][dom]["ratio"]
+                    traffic = ratio * alg[dom] / 1e9
+                    traffic_note = (f"GB per launch = {ratio:.3f} (HBM bytes measured by rocprofv3 --pmc FETCH_SIZE x2 [gfx950] + "
+                                    f"WRITE_SIZE, separate passes, / algorithmic bytes of the same kernel; "
+                                    f"profiles/r01_hbm_traffic.md) x {alg[dom] / 1e9:.3f} GB algorithmic for this launch mix")
             roof = dict(kernel=dom, bound="mfma", achieved=ach / 1e12, peak=MFMA_F32_PEAK / 1e12, unit="TFLOP/s",
-                        frac=ach / MFMA_F32_PEAK, traffic=None, launches=cand[dom]["n"], avg_ms=cand[dom]["avg_ms"],
-                        flops_per_launch=flops[dom],
+                        frac=ach / MFMA_F32_PEAK, traffic=traffic, traffic_note=traffic_note, launches=cand[dom]["n"],
+                        avg_ms=cand[dom]["avg_ms"], flops_per_launch=flops[dom],
+                        timing="HIP events around every launch of the MFMA kernel families inside the timed region",
                         others={k: round(flops[k] / (v["avg_ms"] * 1e-3) / MFMA_F32_PEAK, 4) for k, v in cand.items()})
         e2e = flops_per_transition() * value
         out = dict(
@@ -223,7 +248,7 @@ def main():
                             flops_per_transition=flops_per_transition()),
             kernels={k: dict(n=v["n"], avg_ms=round(v["avg_ms"], 4), total_ms=round(v["total_ms"], 3))
                      for k, v in breakdown.items()},
-            kernel_timing=f"HIP events around every tagged launch, {args.instr_steps} instrumented steps after the timed region",
+            kernel_timing=f"`kernels`: HIP events around every tagged launch, {args.instr_steps} instrumented steps after the timed region",
         )
         if world == 1 and args.cpu_cols > 0:
             out["cpu_baseline"] = cpu_baseline(args.cpu_cols, min(args.cpu_threads, os.cpu_count() or 1))

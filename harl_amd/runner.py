@@ -27,10 +27,16 @@ ALGO_REGISTRY = {"happo": HAPPO, "hatrpo": HATRPO, "haa2c": HAA2C}
 class OnPolicyHARunner:
     def __init__(self, args: dict, algo_args: dict, env_args: Optional[dict] = None, *, obs_spaces=None,
                  share_obs_space=None, act_spaces=None, device: Optional[torch.device] = None,
-                 comm: Optional[Comm] = None):
-        """``args``/``algo_args`` as in examples/train.py:87-91.  Spaces must be given explicitly (this class does
-        not create environments).  With an initialised process group, ``algo_args['train']['n_rollout_threads']`` is
+                 comm: Optional[Comm] = None, envs=None, logger=None):
+        """``args``/``algo_args`` as in examples/train.py:87-91.  Spaces must be given explicitly or through ``envs``
+        (a vectorised environment with the reference's ``ShareVecEnv`` surface: ``observation_space``,
+        ``share_observation_space``, ``action_space`` lists and ``reset()/step()``, envs/env_wrappers.py); this class
+        does not create environments.  With an initialised process group, ``algo_args['train']['n_rollout_threads']`` is
         the GLOBAL thread count and this rank keeps its contiguous column shard."""
+        self.envs, self.logger = envs, logger
+        if envs is not None and obs_spaces is None:
+            obs_spaces, act_spaces = list(envs.observation_space), list(envs.action_space)
+            share_obs_space = envs.share_observation_space[0]
         if obs_spaces is None or share_obs_space is None or act_spaces is None:
             raise ValueError("OnPolicyHARunner needs obs_spaces / share_obs_space / act_spaces (no env creation here)")
         self.args = args
@@ -164,6 +170,120 @@ class OnPolicyHARunner:
         for b in self.actor_buffer:
             b.after_update()
         self.critic_buffer.after_update()
+
+    # ---- rollout side (on_policy_base_runner.py:171-460): the loop is the reference's; what changes is where the data
+    # lives.  Observations go up once per step, actions come down once per step; log-probs, values, hidden states, masks
+    # and everything the update reads never leave the device.
+    def warmup(self):
+        """Reset the environments and fill slot 0 of the buffers (on_policy_base_runner.py:269-283)."""
+        obs, share_obs, available_actions = self.envs.reset()
+        obs = torch.as_tensor(obs, dtype=torch.float32).to(self.device)
+        for a in range(self.num_agents):
+            self.actor_buffer[a].obs[0].copy_(obs[:, a])
+            if self.actor_buffer[a].available_actions is not None:
+                av = torch.as_tensor(available_actions, dtype=torch.float32).to(self.device)
+                self.actor_buffer[a].available_actions[0].copy_(av[:, a])
+        so = torch.as_tensor(share_obs, dtype=torch.float32).to(self.device)
+        self.critic_buffer.share_obs[0].copy_(so[:, 0] if self.state_type == "EP" else so)
+
+    @torch.no_grad()
+    def collect(self, step: int):
+        """Sample actions from every actor and values from the critic at buffer slot ``step`` (:285-343).  Returns DEVICE
+        tensors (values [N,1] | [N,A,1], actions [N,A,act_w], action_log_probs, rnn_states [N,A,1,H],
+        rnn_states_critic [N,1,H] | [N,A,1,H])."""
+        acts, logps, rnns = [], [], []
+        for a in range(self.num_agents):
+            b = self.actor_buffer[a]
+            action, logp, rnn = self.actor[a].get_actions(
+                b.obs[step], b.rnn_states[step], b.masks[step],
+                b.available_actions[step] if b.available_actions is not None else None)
+            acts.append(action)
+            logps.append(logp)
+            rnns.append(rnn.reshape(rnn.shape[0], b.recurrent_n, -1))
+        actions, action_log_probs, rnn_states = torch.stack(acts, 1), torch.stack(logps, 1), torch.stack(rnns, 1)
+        cb = self.critic_buffer
+        if self.state_type == "EP":
+            values, rnn_c = self.critic.get_values(cb.share_obs[step], cb.rnn_states_critic[step], cb.masks[step])
+            rnn_c = rnn_c.reshape(values.shape[0], cb.recurrent_n, -1)
+        else:
+            so = cb.share_obs[step]
+            N, A = so.shape[:2]
+            values, rnn_c = self.critic.get_values(so.reshape(N * A, -1), cb.rnn_states_critic[step].reshape(N * A, 1, -1),
+                                                   cb.masks[step].reshape(N * A, 1))
+            values, rnn_c = values.reshape(N, A, 1), rnn_c.reshape(N, A, cb.recurrent_n, -1)
+        return values, actions, action_log_probs, rnn_states, rnn_c
+
+    @torch.no_grad()
+    def insert(self, data):
+        """Write one environment step into the buffers (:345-460): hidden states reset and masks 0 where the whole
+        environment is done, active_masks 0 for agents that died, bad_masks 0 on truncation (``bad_transition``)."""
+        (obs, share_obs, rewards, dones, infos, available_actions, values, actions, action_log_probs, rnn_states,
+         rnn_states_critic) = data
+        dev, A = self.device, self.num_agents
+        up = lambda x: torch.as_tensor(x, dtype=torch.float32).to(dev)  # noqa: E731
+        dones = torch.as_tensor(dones).to(dev).bool()
+        N = dones.shape[0]
+        dones_env = dones.all(dim=1)
+        keep = (~dones_env).to(torch.float32)
+        rnn_states = rnn_states * keep.view(N, 1, 1, 1)
+        rnn_states_critic = rnn_states_critic * (keep.view(N, 1, 1) if self.state_type == "EP" else keep.view(N, 1, 1, 1))
+        masks = keep.view(N, 1, 1).expand(N, A, 1)
+        active_masks = torch.where(dones & ~dones_env.view(N, 1), 0.0, 1.0).view(N, A, 1)
+        if self.state_type == "EP":
+            bad = [[0.0] if info[0].get("bad_transition", False) is True else [1.0] for info in infos]
+        else:
+            bad = [[[0.0] if info[a].get("bad_transition", False) is True else [1.0] for a in range(A)] for info in infos]
+        bad_masks = torch.tensor(bad, dtype=torch.float32, device=dev)
+        obs, rewards, share_obs = up(obs), up(rewards), up(share_obs)
+        avail = None if (available_actions is None or available_actions[0] is None) else up(available_actions)
+        for a in range(A):
+            self.actor_buffer[a].insert(obs[:, a], rnn_states[:, a], actions[:, a], action_log_probs[:, a], masks[:, a],
+                                        active_masks[:, a], None if avail is None else avail[:, a])
+        if self.state_type == "EP":
+            self.critic_buffer.insert(share_obs[:, 0], rnn_states_critic, values, rewards[:, 0], masks[:, 0], bad_masks)
+        else:
+            self.critic_buffer.insert(share_obs, rnn_states_critic, values, rewards, masks, bad_masks)
+
+    def run(self, num_episodes: Optional[int] = None):
+        """The reference's training loop (:171-267) over ``self.envs``: warmup, then per episode lr decay, T x
+        (collect -> envs.step -> insert), compute, train, after_update.  Returns the per-episode
+        (actor_train_infos, critic_train_info, mean step reward) list; ``logger`` callbacks are invoked if one was given."""
+        if self.envs is None:
+            raise RuntimeError("run() needs a vectorised environment (envs=...)")
+        tr = self.algo_args["train"]
+        T = tr["episode_length"]
+        episodes = num_episodes if num_episodes is not None else int(tr["num_env_steps"]) // T // tr["n_rollout_threads"]
+        self.warmup()
+        if self.logger is not None:
+            self.logger.init(episodes)
+        history = []
+        for episode in range(1, episodes + 1):
+            if tr.get("use_linear_lr_decay", False):
+                for a in self.actor:
+                    a.lr_decay(episode, episodes)
+                self.critic.lr_decay(episode, episodes)
+            if self.logger is not None:
+                self.logger.episode_init(episode)
+            self.prep_rollout()
+            for step in range(T):
+                values, actions, logp, rnn, rnn_c = self.collect(step)
+                obs, share_obs, rewards, dones, infos, avail = self.envs.step(actions.cpu().numpy())
+                data = (obs, share_obs, rewards, dones, infos, avail, values, actions, logp, rnn, rnn_c)
+                if self.logger is not None:
+                    self.logger.per_step(data)
+                self.insert(data)
+            self.compute()
+            self.prep_training()
+            infos_a, info_c = self.train()
+            history.append((infos_a, info_c, self.critic_buffer.get_mean_rewards()))
+            if self.logger is not None and episode % tr.get("log_interval", 1) == 0:
+                self.logger.episode_log(infos_a, info_c, self.actor_buffer, self.critic_buffer)
+            self.after_update()
+        return history
+
+    def close(self):
+        if self.envs is not None and hasattr(self.envs, "close"):
+            self.envs.close()
 
     def prep_rollout(self):
         for a in self.actor:

@@ -644,3 +644,38 @@ def check_train_golden(name: str) -> Dict[str, float]:
     if r.value_normalizer is not None:
         out["vn_final_rel"] = rel_err(r.value_normalizer.stats.cpu().numpy(), z["vn_final"])
     return out
+
+
+def check_rollout_learning(discrete: bool, recurrent: bool = False) -> Dict[str, float]:
+    """OnPolicyHARunner.run() end to end on a toy vectorised environment: collect (device-side sampling) -> env.step ->
+    insert -> compute -> train -> after_update.  The policy must actually learn (mean step reward improves), buffer
+    bookkeeping must follow the reference's insert() rules (masks / active_masks / bad_masks / hidden-state resets)."""
+    from harl_amd.runner import OnPolicyHARunner
+    from tests.fake_env import FakeVecEnv
+    torch.manual_seed(3)
+    np.random.seed(3)
+    N, T = 256, 50
+    env = FakeVecEnv(N, n_agents=3, state_dim=6, act_dim=4 if discrete else 2, discrete=discrete, horizon=25, seed=5)
+    a = default_args([64, 64], lr=3e-3, critic_lr=3e-3, use_recurrent_policy=recurrent, data_chunk_length=10,
+                     actor_num_mini_batch=1, critic_num_mini_batch=1)
+    train = dict(n_rollout_threads=N, episode_length=T, use_valuenorm=True, use_proper_time_limits=True,
+                 use_linear_lr_decay=False, num_env_steps=N * T * 14, log_interval=1)
+    model = {k: a[k] for k in ("hidden_sizes", "activation_func", "use_feature_normalization", "initialization_method",
+                                "gain", "use_naive_recurrent_policy", "use_recurrent_policy", "recurrent_n",
+                                "data_chunk_length", "lr", "critic_lr", "opti_eps", "weight_decay", "std_x_coef", "std_y_coef")}
+    algo = {k: v for k, v in a.items() if k not in model}
+    r = OnPolicyHARunner(dict(algo="happo"), dict(train=train, model=model, algo=algo), dict(state_type="EP"), envs=env,
+                         device=DEV)
+    hist = r.run()
+    torch.cuda.synchronize()
+    rew = [h[2] for h in hist]
+    out = {"reward_first": float(np.mean(rew[:2])), "reward_last": float(np.mean(rew[-2:]))}
+    out["_improvement"] = out["reward_last"] - out["reward_first"]
+    finite = all(np.isfinite(list(i.values())).all() for h in hist for i in h[0]) and all(np.isfinite(list(h[1].values())).all() for h in hist)
+    out["nonfinite_count"] = 0.0 if finite else 1.0
+    # bookkeeping of the last episode's buffers (before after_update rolled slot T into slot 0 they were checked in run)
+    b1, cb = r.actor_buffer[1], r.critic_buffer
+    out["mask_zero_frac"] = float((cb.masks[1:] == 0).float().mean().item())          # one reset per 25 steps
+    out["active_zero_frac_agent1"] = float((b1.active_masks[1:] == 0).float().mean().item())  # 3 dead steps per 25
+    out["bad_zero_frac"] = float((cb.bad_masks[1:] == 0).float().mean().item())
+    return out

@@ -104,3 +104,14 @@ def test_gru_policy_forward_and_update(i):
 def test_recurrent_train_matches_reference_golden(name):
     """Chunked and naive recurrent samplers + GRU actor/critic through a whole OnPolicyHARunner.train() vs the reference."""
     _assert_all(_G().check_train_golden(name), tol=TOL_TRAIN)
+
+
+@pytest.mark.parametrize("discrete,recurrent", [(False, False), (True, False), (False, True)])
+def test_rollout_loop_learns_on_toy_env(discrete, recurrent):
+    """run(): device-side collect/insert around a host environment, then the update; rewards must improve."""
+    res = _G().check_rollout_learning(discrete, recurrent)
+    assert res["nonfinite_count"] == 0.0
+    assert res["_improvement"] > (0.08 if discrete else 0.03), res
+    assert abs(res["mask_zero_frac"] - 0.04) < 1e-6, res           # every 25th step
+    assert abs(res["bad_zero_frac"] - 0.04) < 1e-6, res
+    assert abs(res["active_zero_frac_agent1"] - 0.12) < 1e-6, res  # agent 1 is dead 3 steps out of 25

@@ -384,7 +384,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_actor_head(ActorArgs A) {
     }
     const float act = A.active ? A.active[row] : 1.f;
     const float advn = (A.adv[row] - adv_mean) / adv_den;
-    const float fct = A.factor_in[row];
+    const float fct = A.factor_in ? A.factor_in[row] : 1.f;  // NULL: no sequential-update factor (MAPPO)
     const float lo = 1.f - A.clip_param, hi = 1.f + A.clip_param;
     const float surr1 = imp * advn;
     const float impc = fminf(fmaxf(imp, lo), hi);

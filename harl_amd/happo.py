@@ -158,10 +158,12 @@ class HAPPO(OnPolicyBase):
         self._grad_tap = None
 
     # ---- one optimiser step on rows idx[0..m) of the flat [T*N, .] tensors (happo.py:28-102) ---------
-    def _update_core(self, obs, idx, m, actions, avail, old_logp, adv, adv_moments, factor, active, seq=None,
-                     logp_out=None):
-        """``seq`` (recurrent nets): the batch is L x m_pad rows in the GRU layout (nets.build_seq), idx = seq['idx'].
-        ``logp_out`` [m, act_w]: also emit log pi(a|o) under the pre-step parameters (by batch position)."""
+    def _forward_backward(self, obs, idx, m, actions, avail, old_logp, adv, adv_moments, factor, active, seq=None,
+                          logp_out=None):
+        """Forward, loss and backward of one minibatch: leaves the UNSCALED folded gradients in ``net.dwp`` and the loss
+        kernel's per-block partial sums in ``net.part_scalars``.  ``seq`` (recurrent nets): the batch is L x m_pad rows in
+        the GRU layout (nets.build_seq), idx = seq['idx'].  ``logp_out`` [m, act_w]: also emit log pi(a|o) under the
+        pre-step parameters (by batch position).  ``factor`` None = 1 (MAPPO)."""
         net = self.actor
         net.forward_trunk(obs, idx, m, seq=seq)
         Wp, bp = net._packs[-1]
@@ -174,12 +176,18 @@ class HAPPO(OnPolicyBase):
              float(self.clip_param), float(self.entropy_coef), int(self.action_aggregation == "mean"), self._surrogate_mode,
              mv, mp, ptr(logp_out), ptr(net.dz[0]), ptr(net.dhead), ptr(net.part_scalars), s, tag="actor_head_loss")
         net.backward_trunk(obs, idx, m, seq=seq)
+        return _lib.load().harl_head_blocks(m)
+
+    def _optimizer_step(self, nblk: Optional[int]):
+        """[data-parallel all-reduce] + fused scalar reduce / unfold / grad-norm / clip / Adam / re-fold.  ``nblk`` None:
+        ``net.scalars`` already holds the summed loss scalars (several minibatch segments were accumulated)."""
+        net = self.actor
         sc = net.scalars
-        nblk = _lib.load().harl_head_blocks(m)
-        ps_kw = dict(part_scalars=net.part_scalars, n_scalar_blocks=nblk)  # reduced inside the optimiser launch
+        ps_kw = dict(part_scalars=net.part_scalars, n_scalar_blocks=nblk) if nblk is not None else {}
         if self.comm.enabled:  # ONE collective per optimiser step: [folded gradients | loss scalars]
-            sc.zero_()
-            call("harl_reduce_scalars", ptr(net.part_scalars), nblk, ptr(sc), s)
+            if nblk is not None:
+                sc.zero_()
+                call("harl_reduce_scalars", ptr(net.part_scalars), nblk, ptr(sc), stream())
             if self._staging is None:
                 self._staging = torch.empty(net.total_dwp + 2 * PS_STRIDE, **self.tpdv)
             self.comm.all_reduce_packed(net.dwp, sc, self._staging)
@@ -190,6 +198,12 @@ class HAPPO(OnPolicyBase):
                                   **ps_kw)
         if self._grad_tap is not None:  # test hook: scaled, pre-clip gradient of this update (host sync)
             self._grad_tap(net.flat_grad * float(1.0 / sc[1].item()), sc.clone())
+
+    def _update_core(self, obs, idx, m, actions, avail, old_logp, adv, adv_moments, factor, active, seq=None,
+                     logp_out=None):
+        nblk = self._forward_backward(obs, idx, m, actions, avail, old_logp, adv, adv_moments, factor, active, seq=seq,
+                                      logp_out=logp_out)
+        self._optimizer_step(nblk)
 
     def update(self, sample):
         """API-compatible single update on an already-gathered minibatch (tuple order of happo.py:37-48).
@@ -266,7 +280,7 @@ class HAPPO(OnPolicyBase):
         actions = buf.flat("actions")
         avail = None if buf.available_actions is None else buf.flat("available_actions")
         old_logp = buf.flat("action_log_probs")
-        factor = buf.factor.reshape(B)
+        factor = None if buf.factor is None else buf.factor.reshape(B)  # None: MAPPO (no sequential-update factor)
         n_global = self.shard[0] * T if self.shard else B
         for epoch in range(self.ppo_epoch):
             if self.use_recurrent_policy or self.use_naive_recurrent_policy:

@@ -1,0 +1,93 @@
+"""MAPPO on MI355X (reference: harl/algorithms/actors/mappo.py:10-234).
+
+``update``/``train`` are HAPPO's with the sequential-update factor fixed to 1 (the reference's two files differ only in
+that term), so they run on exactly the same kernels (``harl_actor_head_loss`` with ``factor = NULL``).  Parameter
+sharing (``share_param_train``, mappo.py:149-234) concatenates one minibatch per agent into a single update; here every
+agent's segment is pushed through forward / loss / backward in place (its own buffers, its own index array) and the
+UNSCALED folded gradients and loss sums are accumulated before ONE optimiser step -- the same sums the concatenated
+batch gives, without materialising it.
+"""
+from __future__ import annotations
+
+from typing import List
+
+import torch
+
+from . import _lib
+from ._lib import call, ptr, stream
+from .buffers import OnPolicyActorBuffer, consume_randperm, minibatch_indices, rng_sync
+from .dist import local_minibatch_rows
+from .happo import HAPPO
+from .valuenorm import _as_dev
+
+
+class MAPPO(HAPPO):
+    def update(self, sample):
+        """8-tuple of mappo.py:47-56 (no factor)."""
+        return super().update(tuple(sample) + (None,)) if len(sample) == 8 else super().update(sample)
+
+    def share_param_train(self, actor_buffer: List[OnPolicyActorBuffer], advantages, num_agents: int, state_type: str,
+                          _moments=None, _defer: bool = False):
+        """ppo_epoch x actor_num_mini_batch updates of the ONE shared actor on all agents' data (mappo.py:149-234).
+        EP: advantages [T, N, 1] are normalised with ONE mean/std over every agent's active entries (:165-183), passed to
+        the loss kernel as the summed fp64 moments; FP: per-agent slices of the runner-normalised [T, N, A, 1] tensor."""
+        if self.use_recurrent_policy or self.use_naive_recurrent_policy:
+            raise NotImplementedError("share_param with recurrent policies")
+        dev, net = self.device, self.actor
+        A = num_agents
+        T, N = actor_buffer[0].actions.shape[:2]
+        B = T * N
+        adv = _as_dev(advantages, dev)
+        moments = None
+        if state_type == "EP":
+            adv_a = [adv.reshape(B).contiguous()] * A
+            if _moments is None:
+                mom = torch.zeros(A, 3, dtype=torch.float64, device=dev)
+                for a in range(A):
+                    self.masked_moments(actor_buffer[a], adv_a[a], mom[a])
+                self.comm.all_reduce_sum(mom)
+                _moments = mom.sum(0)
+            moments = _moments
+        else:
+            adv_a = [adv[:, :, a].reshape(B).contiguous() for a in range(A)]
+        self._info.zero_()
+        net.fold()
+        acc = torch.zeros_like(net.dwp)
+        n_global = self.shard[0] * T if self.shard else B
+        k = self.actor_num_mini_batch
+        s = stream()
+        for _ in range(self.ppo_epoch):
+            # every agent's generator draws its own permutation, in agent order, when the first minibatch is requested
+            samplers = []
+            for a in range(A):
+                if k == 1:
+                    consume_randperm(n_global)
+                    samplers.append([None])
+                else:
+                    samplers.append(minibatch_indices(n_global, k))
+            for b in range(k):
+                acc.zero_()
+                net._ensure_ws(B)
+                net.scalars.zero_()
+                for a in range(A):
+                    buf = actor_buffer[a]
+                    ind = samplers[a][b]
+                    if ind is not None and self.shard:
+                        ind = local_minibatch_rows(ind, self.shard[0], self.shard[1], self.shard[2])
+                    idx = None if ind is None else ind.to(dev)
+                    m = B if ind is None else ind.numel()
+                    nblk = self._forward_backward(
+                        buf.flat("obs"), idx, m, buf.flat("actions"),
+                        None if buf.available_actions is None else buf.flat("available_actions"),
+                        buf.flat("action_log_probs"), adv_a[a], moments, None,
+                        buf.flat("active_masks").reshape(B) if self.use_policy_active_masks else None)
+                    acc.add_(net.dwp)
+                    call("harl_reduce_scalars", ptr(net.part_scalars), nblk, ptr(net.scalars), s)  # accumulates
+                net.dwp.copy_(acc)
+                self._optimizer_step(None)
+        n_upd = self.ppo_epoch * k
+        if _defer:
+            return self._info / n_upd
+        rng_sync()
+        vals = (self._info / n_upd).cpu().tolist()
+        return dict(zip(self._INFO_KEYS, vals))

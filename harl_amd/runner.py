@@ -18,10 +18,11 @@ from ._lib import call, ptr, stream
 from .dist import Comm, shard_columns
 from .happo import HAA2C, HAPPO
 from .hatrpo import HATRPO
+from .mappo import MAPPO
 from .v_critic import VCritic
 from .valuenorm import ValueNorm
 
-ALGO_REGISTRY = {"happo": HAPPO, "hatrpo": HATRPO, "haa2c": HAA2C}
+ALGO_REGISTRY = {"happo": HAPPO, "hatrpo": HATRPO, "haa2c": HAA2C, "mappo": MAPPO}
 
 
 class OnPolicyHARunner:
@@ -52,11 +53,11 @@ class OnPolicyHARunner:
         self.state_type = (env_args or {}).get("state_type", "EP")
         if self.state_type not in ("EP", "FP"):
             raise ValueError(f"state_type {self.state_type}")
-        if algo_args["algo"].get("share_param", False):
-            raise NotImplementedError("share_param")
-        self.fixed_order = algo_args["algo"]["fixed_order"]
+        self.share_param = bool(algo_args["algo"].get("share_param", False))
+        if self.share_param and algo != "mappo":
+            raise NotImplementedError("share_param is a MAPPO feature (HAPPO/HATRPO/HAA2C need per-agent actors)")
+        self.fixed_order = algo_args["algo"].get("fixed_order", True)
         self.action_aggregation = algo_args["algo"]["action_aggregation"]
-        self.share_param = False
 
         n_global = algo_args["train"]["n_rollout_threads"]
         lo, hi = shard_columns(n_global, self.comm.rank, self.comm.world_size)
@@ -66,7 +67,10 @@ class OnPolicyHARunner:
         margs = {**algo_args["model"], **algo_args["algo"]}
         self.actor: List[HAPPO] = []
         for a in range(self.num_agents):  # construction order = reference (actors 0..A-1, then critic) for RNG parity
-            self.actor.append(ALGO_REGISTRY[algo](margs, obs_spaces[a], act_spaces[a], device=self.device))
+            if self.share_param and a > 0:  # ONE actor object in every slot (on_policy_base_runner.py:96-113)
+                self.actor.append(self.actor[0])
+            else:
+                self.actor.append(ALGO_REGISTRY[algo](margs, obs_spaces[a], act_spaces[a], device=self.device))
         self.actor_buffer = [OnPolicyActorBuffer({**train_local, **algo_args["model"]}, obs_spaces[a], act_spaces[a],
                                                  device=self.device) for a in range(self.num_agents)]
         self.critic = VCritic(margs, share_obs_space, device=self.device)
@@ -103,15 +107,7 @@ class OnPolicyHARunner:
         factor = torch.ones(T, N, 1, dtype=torch.float32, device=dev)
         advantages = self.critic_buffer.advantages  # returns[:-1] - denormalize(value_preds[:-1]), fused into the GAE scan
         if self.state_type == "FP":
-            # global masked normalisation over every agent's active entries (on_policy_ha_runner.py:36-45)
-            active = torch.stack([b.active_masks[:-1] for b in self.actor_buffer], dim=2).contiguous()  # [T,N,A,1]
-            mom = torch.zeros(3, dtype=torch.float64, device=dev)
-            n = advantages.numel()
-            call("harl_masked_moments", ptr(advantages), ptr(active), n, ptr(mom), stream())
-            self.comm.all_reduce_sum(mom)
-            adv_n = torch.empty_like(advantages)
-            call("harl_adv_normalize", ptr(advantages), ptr(mom), ptr(adv_n), n, stream())
-            advantages = adv_n
+            advantages = self._fp_normalised_advantages(advantages)
         if self.fixed_order:
             agent_order = list(range(self.num_agents))
         else:
@@ -170,6 +166,19 @@ class OnPolicyHARunner:
         for b in self.actor_buffer:
             b.after_update()
         self.critic_buffer.after_update()
+
+    def _fp_normalised_advantages(self, advantages):
+        """Global masked normalisation over every agent's active entries (on_policy_ha_runner.py:36-45,
+        on_policy_ma_runner.py:25-36)."""
+        dev = self.device
+        active = torch.stack([b.active_masks[:-1] for b in self.actor_buffer], dim=2).contiguous()  # [T,N,A,1]
+        mom = torch.zeros(3, dtype=torch.float64, device=dev)
+        n = advantages.numel()
+        call("harl_masked_moments", ptr(advantages), ptr(active), n, ptr(mom), stream())
+        self.comm.all_reduce_sum(mom)
+        adv_n = torch.empty_like(advantages)
+        call("harl_adv_normalize", ptr(advantages), ptr(mom), ptr(adv_n), n, stream())
+        return adv_n
 
     # ---- rollout side (on_policy_base_runner.py:171-460): the loop is the reference's; what changes is where the data
     # lives.  Observations go up once per step, actions come down once per step; log-probs, values, hidden states, masks
@@ -311,3 +320,53 @@ class OnPolicyHARunner:
         p = os.path.join(model_dir, "value_normalizer.pt")
         if self.value_normalizer is not None and os.path.exists(p):
             self.value_normalizer.load_state_dict(torch.load(p, map_location=self.device))
+
+
+class OnPolicyMARunner(OnPolicyHARunner):
+    """MAPPO: simultaneous (not sequential) actor updates without the factor (runners/on_policy_ma_runner.py:10-64),
+    optionally with ONE parameter-shared actor."""
+
+    @torch.no_grad()
+    def train(self):
+        dev = self.device
+        A = self.num_agents
+        advantages = self.critic_buffer.advantages
+        if self.state_type == "FP":
+            advantages = self._fp_normalised_advantages(advantages)
+        mom_all = torch.zeros(A, 3, dtype=torch.float64, device=dev)
+        for a in range(A):
+            adv_a = advantages if self.state_type == "EP" else advantages[:, :, a].contiguous()
+            self.actor[a].masked_moments(self.actor_buffer[a], adv_a, mom_all[a])
+        self.comm.all_reduce_sum(mom_all)
+        dev_infos = []
+        if self.share_param:
+            info = self.actor[0].share_param_train(self.actor_buffer, advantages, A, self.state_type,
+                                                   _moments=mom_all.sum(0), _defer=True)
+            rng_sync()
+            torch.randperm(A)  # on_policy_ma_runner.py:42-43 iterates over a fresh permutation: one more CPU-RNG draw
+            dev_infos = [info]
+            slots = [0] * A
+        else:
+            counts = mom_all[:, 2].cpu().tolist()
+            slots = []
+            for a in range(A):
+                buf = self.actor_buffer[a]
+                buf.factor = None
+                adv_a = advantages if self.state_type == "EP" else advantages[:, :, a].contiguous()
+                info = self.actor[a].train(buf, adv_a, self.state_type, _pre=(mom_all[a], counts[a]), _defer=True)
+                if torch.is_tensor(info):
+                    slots.append(len(dev_infos))
+                    dev_infos.append(info)
+                else:
+                    slots.append(info)  # early-out dict (no active entries)
+        cinfo = self.critic.train(self.critic_buffer, self.value_normalizer, _defer=True)
+        rng_sync()
+        flat = torch.cat([t.reshape(-1) for t in dev_infos] + [cinfo.reshape(-1)]).cpu().tolist()
+        keys = self.actor[0]._INFO_KEYS
+        actor_train_infos = [s if isinstance(s, dict) else dict(zip(keys, flat[4 * s:4 * s + 4])) for s in slots]
+        off = 4 * len(dev_infos)
+        return actor_train_infos, {"value_loss": flat[off], "critic_grad_norm": flat[off + 1]}
+
+
+RUNNER_REGISTRY = {"happo": OnPolicyHARunner, "hatrpo": OnPolicyHARunner, "haa2c": OnPolicyHARunner,
+                   "mappo": OnPolicyMARunner}

@@ -45,6 +45,7 @@ from harl.common.buffers.on_policy_critic_buffer_ep import OnPolicyCriticBufferE
 from harl.common.buffers.on_policy_critic_buffer_fp import OnPolicyCriticBufferFP  # noqa: E402
 from harl.common.valuenorm import ValueNorm  # noqa: E402
 from harl.runners.on_policy_ha_runner import OnPolicyHARunner  # noqa: E402
+from harl.runners.on_policy_ma_runner import OnPolicyMARunner  # noqa: E402
 
 from harl_amd.synthetic import (  # noqa: E402
     Shapes, actor_param_shapes, critic_param_shapes, make_buffers, synthetic_state_dict,
@@ -114,6 +115,16 @@ CASES = {
                                                     hidden_sizes=[64, 64]), seed=6, overrides={}),
     "trpo_disc_h64": dict(algo="hatrpo", shapes=dict(T=10, N=8, A=2, obs_dim=11, share_obs_dim=9, act_dim=4, discrete=True,
                                                      hidden_sizes=[64, 64]), seed=8, overrides={}, unavailable_p=0.2),
+    # ---- MAPPO (harl/algorithms/actors/mappo.py, runners/on_policy_ma_runner.py): no factor; parameter sharing
+    "mappo_box_h64": dict(algo="mappo", shapes=dict(T=10, N=8, A=3, obs_dim=12, share_obs_dim=20, act_dim=2, discrete=False,
+                                                    hidden_sizes=[64, 64]), seed=21, overrides=dict(share_param=False), inactive_p=0.2),
+    "mappo_shared_disc_h64_mb2": dict(algo="mappo", shapes=dict(T=8, N=8, A=3, obs_dim=16, share_obs_dim=24, act_dim=5,
+                                                                discrete=True, hidden_sizes=[64, 64]), seed=22,
+                                      overrides=dict(share_param=True, actor_num_mini_batch=2, ppo_epoch=3),
+                                      unavailable_p=0.2, inactive_p=0.15),
+    "mappo_shared_fp_box_h128": dict(algo="mappo", state_type="FP",
+                                     shapes=dict(T=8, N=6, A=2, obs_dim=10, share_obs_dim=14, act_dim=3, discrete=False,
+                                                 hidden_sizes=[128, 128]), seed=23, overrides=dict(share_param=True)),
     "trpo_wide_h128x3": dict(algo="hatrpo", shapes=dict(T=8, N=8, A=3, obs_dim=70, share_obs_dim=65, act_dim=1,
                                                         discrete=False, hidden_sizes=[128, 128, 128]), seed=9,
                              overrides=dict(fixed_order=True), inactive_p=0.15),
@@ -143,10 +154,15 @@ def run_case(name: str, spec: dict) -> dict:
     dev = torch.device("cpu")
     act_space = Discrete(sh.act_dim) if sh.discrete else Box((sh.act_dim,))
     margs = {**cfg["model"], **cfg["algo"]}
-    actors = [ALGO_REGISTRY[algo_name](margs, Box((sh.obs_dim,)), act_space, dev) for _ in range(sh.A)]
+    share_param = bool(cfg["algo"].get("share_param", False))
+    if share_param:  # on_policy_base_runner.py:96-113: ONE actor object referenced by every agent slot
+        actors = [ALGO_REGISTRY[algo_name](margs, Box((sh.obs_dim,)), act_space, dev)]
+        actors += [actors[0]] * (sh.A - 1)
+    else:
+        actors = [ALGO_REGISTRY[algo_name](margs, Box((sh.obs_dim,)), act_space, dev) for _ in range(sh.A)]
     critic = VCritic(margs, Box((sh.share_obs_dim,)), dev)
     rec = bool(cfg["model"]["use_recurrent_policy"] or cfg["model"]["use_naive_recurrent_policy"])
-    for a, actor in enumerate(actors):
+    for a, actor in enumerate(actors[:1] if share_param else actors):
         sd = synthetic_state_dict(actor_param_shapes(sh, use_fn, rec), 1000 * seed + a, cfg["model"]["std_x_coef"])
         assert list(sd.keys()) == list(actor.actor.state_dict().keys()), (list(sd.keys()), list(actor.actor.state_dict().keys()))
         actor.actor.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
@@ -217,10 +233,12 @@ def run_case(name: str, spec: dict) -> dict:
         vn.running_mean_sq.fill_(1.7 * 0.5)
         vn.debiasing_term.fill_(0.5)
 
-    r = OnPolicyHARunner.__new__(OnPolicyHARunner)
+    RunnerCls = OnPolicyMARunner if algo_name == "mappo" else OnPolicyHARunner
+    r = RunnerCls.__new__(RunnerCls)
+    r.share_param = share_param
     r.algo_args, r.value_normalizer, r.critic_buffer, r.actor_buffer = cfg, vn, cbuf, abuf
     r.actor, r.critic, r.num_agents, r.state_type = actors, critic, sh.A, ("FP" if fp else "EP")
-    r.fixed_order = cfg["algo"]["fixed_order"]
+    r.fixed_order = cfg["algo"].get("fixed_order", True)
     r.action_aggregation, r.device = cfg["algo"]["action_aggregation"], dev
 
     # ---- instrument: record per-update scalars, minibatch indices and the factor each agent saw
@@ -233,7 +251,7 @@ def run_case(name: str, spec: dict) -> dict:
         return p
 
     torch.randperm = rec_randperm
-    for a, actor in enumerate(actors):
+    for a, actor in enumerate(actors[:1] if share_param else actors):
         orig = actor.update
 
         def upd(sample, _orig=orig, _a=a, _actor=actor):
@@ -285,7 +303,7 @@ def run_case(name: str, spec: dict) -> dict:
         returns=returns.astype(np.float32),
         advantages=adv.astype(np.float32),
         n_perms=np.int64(len(trace["perms"])),
-        factors=np.stack(trace["factors"]).astype(np.float32),
+        factors=(np.stack(trace["factors"]).astype(np.float32) if trace["factors"] else np.zeros((0,), np.float32)),
         actor_trace=np.array([[t["agent"], t["policy_loss"], t["dist_entropy"], t["grad_norm"], t["ratio"]]
                               for t in trace["actor"]], dtype=np.float64),
         critic_trace=np.array([[t["value_loss"], t["grad_norm"]] for t in trace["critic"]], dtype=np.float64),

@@ -366,6 +366,8 @@ class OracleHAPPO:
     def update(self, sample, keep_grad: bool = False):  # happo.py:28-102
         cfg = self.cfg
         obs, actions, active, old_logp, adv, avail, factor = (None if s is None else _t(s) for s in sample[:7])
+        if factor is None:  # MAPPO (mappo.py:36-95): no sequential-update factor
+            factor = torch.ones_like(adv)
         rnn, msk = (_t(sample[7]), _t(sample[8])) if len(sample) > 7 else (None, None)
         logp, ent, _ = actor_evaluate_actions(self.net.p, cfg, obs, actions, avail, active, rnn, msk)
         agg = getattr(torch, cfg.action_aggregation)
@@ -418,6 +420,49 @@ class OracleHAPPO:
 class OracleHAA2C(OracleHAPPO):
     """harl/algorithms/actors/haa2c.py: HAPPO with the unclipped surrogate; cfg.ppo_epoch carries a2c_epoch."""
     clipped = False
+
+
+class OracleMAPPO(OracleHAPPO):
+    """harl/algorithms/actors/mappo.py: the HAPPO update without the factor (update :36-95, train :97-147 are otherwise
+    the same code), plus parameter sharing (share_param_train :149-234): one actor, every agent's minibatch drawn from
+    its own buffer with its own randperm and concatenated into a single update."""
+
+    def share_param_train(self, bufs: List["OracleActorBuffer"], advantages: np.ndarray, state_type: str = "EP") -> dict:
+        cfg = self.cfg
+        A = len(bufs)
+        info = {"policy_loss": 0.0, "dist_entropy": 0.0, "actor_grad_norm": 0.0, "ratio": 0.0}
+        if state_type == "EP":  # ONE mean/std over all agents' active entries (mappo.py:165-183)
+            cp = np.stack([advantages.copy() for _ in range(A)])
+            for a in range(A):
+                cp[a][bufs[a].active_masks[:-1] == 0.0] = np.nan
+            mean, std = np.nanmean(cp), np.nanstd(cp)
+            adv_list = [(advantages - mean) / (std + 1e-5) for _ in range(A)]
+        else:
+            adv_list = [advantages[:, :, a] for a in range(A)]
+        for _ in range(cfg.ppo_epoch):
+            gens = []
+            for a in range(A):  # generators are created (and their permutations drawn) in agent order, lazily at first next()
+                if cfg.use_recurrent_policy:
+                    gens.append(bufs[a].recurrent_generator(adv_list[a], cfg.actor_num_mini_batch, cfg.data_chunk_length))
+                elif cfg.use_naive_recurrent_policy:
+                    gens.append(bufs[a].naive_recurrent_generator(adv_list[a], cfg.actor_num_mini_batch))
+                else:
+                    gens.append(bufs[a].feed_forward_generator(adv_list[a], cfg.actor_num_mini_batch))
+            for _mb in range(cfg.actor_num_mini_batch):
+                parts = [next(g)[0] for g in gens]
+                if len(parts[0]) > 7:  # recurrent rows are [L*m, .] l-major per agent; the reference concatenates agents on
+                    raise NotImplementedError("share_param with recurrent policies is not restated")  # axis 0 (mixes l and agent)
+                cat = [None if parts[0][i] is None else np.concatenate([p[i] for p in parts], axis=0)
+                       for i in range(len(parts[0]))]
+                pl, ent, gn, imp, g = self.update(tuple(cat))
+                info["policy_loss"] += pl.item()
+                info["dist_entropy"] += ent.item()
+                info["actor_grad_norm"] += float(gn)
+                info["ratio"] += float(imp.mean())
+                self.trace.append({"policy_loss": pl.item(), "dist_entropy": ent.item(), "grad_norm": float(gn),
+                                   "ratio": float(imp.mean()), "indices": None, "grad": g})
+        n = cfg.ppo_epoch * cfg.actor_num_mini_batch
+        return {k: v / n for k, v in info.items()}
 
 
 # --------------------------------------------------------------------------------------
@@ -528,8 +573,8 @@ class OracleActorBuffer:
         f = lambda a: a.reshape(T * N, -1)[rows]  # noqa: E731
         rnn = self.rnn_states[:-1].reshape(T * N, *self.rnn_states.shape[2:])[first_rows]
         return (f(self.obs[:-1]), f(self.actions), f(self.active_masks[:-1]), f(self.action_log_probs), f(advantages),
-                None if self.available_actions is None else f(self.available_actions[:-1]), f(self.factor), rnn,
-                f(self.masks[:-1]))
+                None if self.available_actions is None else f(self.available_actions[:-1]),
+                None if self.factor is None else f(self.factor), rnn, f(self.masks[:-1]))
 
     def recurrent_generator(self, advantages: np.ndarray, num_mini_batch: int, L: int):
         """on_policy_actor_buffer.py:223-326."""
@@ -557,12 +602,12 @@ class OracleActorBuffer:
         active = self.active_masks[:-1].reshape(-1, 1)
         logp = self.action_log_probs.reshape(T * N, -1)
         avail = None if self.available_actions is None else self.available_actions[:-1].reshape(T * N, -1)
-        factor = self.factor.reshape(-1, 1)
+        factor = None if self.factor is None else self.factor.reshape(-1, 1)
         adv = advantages.reshape(-1, 1)
         for idx in sampler:
             yield (
                 obs[idx], actions[idx], active[idx], logp[idx], adv[idx],
-                None if avail is None else avail[idx], factor[idx],
+                None if avail is None else avail[idx], None if factor is None else factor[idx],
             ), idx
 
 
@@ -666,6 +711,31 @@ def ha_train(
         factors.append(factor.copy())
     cinfo = critic.train(critic_buffer, vn, keep_grad)
     return infos, cinfo, {"agent_order": [int(x) for x in order], "factors": factors, "advantages": advantages}
+
+
+def ma_train(actors: List["OracleMAPPO"], critic: OracleVCritic, actor_buffers: List[OracleActorBuffer],
+             critic_buffer: OracleCriticBufferEP, vn: Optional[OracleValueNorm], cfg: PathConfig, share_param: bool = False):
+    """OnPolicyMARunner.train (runners/on_policy_ma_runner.py:10-64): no factor, agents in index order; with parameter
+    sharing one share_param_train call and a stray ``torch.randperm(num_agents)`` draw (:42-43)."""
+    A = len(actor_buffers)
+    advantages = advantages_from_returns(critic_buffer.returns, critic_buffer.value_preds, vn)
+    fp = getattr(critic_buffer, "fp", False)
+    if fp:
+        am = np.stack([b.active_masks for b in actor_buffers], axis=2)
+        cp = advantages.copy()
+        cp[am[:-1] == 0.0] = np.nan
+        advantages = (advantages - np.nanmean(cp)) / (np.nanstd(cp) + 1e-5)
+    infos = []
+    if share_param:
+        info = actors[0].share_param_train(actor_buffers, advantages.copy(), "FP" if fp else "EP")
+        for _ in torch.randperm(A):
+            infos.append(info)
+    else:
+        for a in range(A):
+            adv_a = advantages[:, :, a].copy() if fp else advantages.copy()
+            infos.append(actors[a].train(actor_buffers[a], adv_a, state_type="FP" if fp else "EP"))
+    cinfo = critic.train(critic_buffer, vn)
+    return infos, cinfo, {"agent_order": list(range(A)), "factors": [], "advantages": advantages}
 
 
 # --------------------------------------------------------------------------------------

@@ -520,7 +520,8 @@ def check_trpo(spec, agg: str = "prod") -> Dict[str, float]:
 
 # ------------------------------------------------------------------------------------------------
 def build_runner(case: GoldenCase):
-    from harl_amd.runner import OnPolicyHARunner
+    from harl_amd.runner import RUNNER_REGISTRY
+    OnPolicyHARunner = RUNNER_REGISTRY[case.algo_name]
     train, model, algo = case.reference_dicts()
     sh, d = case.shapes, case.data
     space = Discrete(sh.act_dim) if sh.discrete else Box((sh.act_dim,))
@@ -529,7 +530,8 @@ def build_runner(case: GoldenCase):
                          obs_spaces=[Box((sh.obs_dim,))] * sh.A, share_obs_space=Box((sh.share_obs_dim,)),
                          act_spaces=[space] * sh.A, device=DEV)
     for a in range(sh.A):
-        r.actor[a].actor.load_state_dict({k: torch.from_numpy(v) for k, v in case.actor_sd[a].items()})
+        if a == 0 or not getattr(case, "share_param", False):
+            r.actor[a].actor.load_state_dict({k: torch.from_numpy(v) for k, v in case.actor_sd[a].items()})
         b = r.actor_buffer[a]
         b.obs.copy_(dev(d.obs[a]))
         b.actions.copy_(dev(d.actions[a]))

@@ -17,6 +17,7 @@ ALL_CASES = ["mpe_box_h64", "mpe_box_h128", "mpe_disc_h64", "cheetah_h128x3_mb2"
              "wide_obs_h64", "a2c_box_h64", "fp_box_h64", "fp_disc_h128_mb2"]
 TRPO_CASES = ["trpo_box_h64", "trpo_disc_h64", "trpo_wide_h128x3"]
 RNN_CASES = ["rnn_box_h64", "rnn_disc_h64_mb2", "rnn_naive_h64"]
+MAPPO_CASES = ["mappo_box_h64", "mappo_shared_disc_h64_mb2", "mappo_shared_fp_box_h128"]
 
 
 class GoldenCase:
@@ -41,8 +42,9 @@ class GoldenCase:
                 self.data.actions[a] = self.z[f"in_actions_{a}"].copy()
                 self.data.action_log_probs[a] = self.z[f"in_logp_{a}"].copy()
         use_fn = self.model["use_feature_normalization"]
+        self.share_param = bool(self.algo.get("share_param", False)) and self.algo_name == "mappo"
         self.actor_sd = [synthetic_state_dict(actor_param_shapes(self.shapes, use_fn, self.recurrent),
-                                              1000 * self.seed + a, self.model["std_x_coef"])
+                                              1000 * self.seed + (0 if self.share_param else a), self.model["std_x_coef"])
                          for a in range(self.shapes.A)]
         self.critic_sd = synthetic_state_dict(critic_param_shapes(self.shapes, use_fn, self.recurrent),
                                               1000 * self.seed + 999)

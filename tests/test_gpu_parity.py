@@ -115,3 +115,10 @@ def test_rollout_loop_learns_on_toy_env(discrete, recurrent):
     assert abs(res["mask_zero_frac"] - 0.04) < 1e-6, res           # every 25th step
     assert abs(res["bad_zero_frac"] - 0.04) < 1e-6, res
     assert abs(res["active_zero_frac_agent1"] - 0.12) < 1e-6, res  # agent 1 is dead 3 steps out of 25
+
+
+@pytest.mark.parametrize("name", ["mappo_box_h64", "mappo_shared_disc_h64_mb2", "mappo_shared_fp_box_h128"])
+def test_mappo_train_matches_reference_golden(name):
+    """MAPPO through the same kernels (factor = NULL); parameter sharing accumulates every agent's segment before one
+    optimiser step; OnPolicyMARunner.train() vs the reference (incl. its stray randperm(num_agents) draw)."""
+    _assert_all(_G().check_train_golden(name), tol=TOL_TRAIN)

@@ -10,7 +10,7 @@ import pytest
 import torch
 
 from oracle import harl_oracle as O
-from tests.helpers import ALL_CASES, GOLDEN_DIR, RNN_CASES, TRPO_CASES, GoldenCase, rel_err, vec_rel_err
+from tests.helpers import ALL_CASES, GOLDEN_DIR, MAPPO_CASES, RNN_CASES, TRPO_CASES, GoldenCase, rel_err, vec_rel_err
 
 
 def build_oracle(case: GoldenCase):
@@ -23,6 +23,11 @@ def build_oracle(case: GoldenCase):
     elif case.algo_name == "haa2c":
         cfg.ppo_epoch = algo["a2c_epoch"]
         actors = [O.OracleHAA2C({k: torch.from_numpy(v) for k, v in sd.items()}, cfg) for sd in case.actor_sd]
+    elif case.algo_name == "mappo":
+        if case.share_param:  # one actor object in every agent slot (on_policy_base_runner.py:96-113)
+            actors = [O.OracleMAPPO({k: torch.from_numpy(v) for k, v in case.actor_sd[0].items()}, cfg)] * sh.A
+        else:
+            actors = [O.OracleMAPPO({k: torch.from_numpy(v) for k, v in sd.items()}, cfg) for sd in case.actor_sd]
     else:
         actors = [O.OracleHAPPO({k: torch.from_numpy(v) for k, v in sd.items()}, cfg) for sd in case.actor_sd]
     critic = O.OracleVCritic({k: torch.from_numpy(v) for k, v in case.critic_sd.items()}, cfg)
@@ -47,7 +52,7 @@ def build_oracle(case: GoldenCase):
     return cfg, actors, critic, abufs, cbuf, vn
 
 
-@pytest.mark.parametrize("name", ALL_CASES + TRPO_CASES + RNN_CASES)
+@pytest.mark.parametrize("name", ALL_CASES + TRPO_CASES + RNN_CASES + MAPPO_CASES)
 def test_oracle_matches_reference_golden(name):
     case = GoldenCase(name)
     z = case.z
@@ -74,7 +79,10 @@ def test_oracle_matches_reference_golden(name):
         assert np.array_equal(cbuf.returns, z["returns"]), "returns must be bit-exact"
         adv = O.advantages_from_returns(cbuf.returns, cbuf.value_preds, vn)
         assert np.array_equal(adv.astype(np.float32), z["advantages"])
-        infos, cinfo, extra = O.ha_train(actors, critic, abufs, cbuf, vn, cfg)
+        if case.algo_name == "mappo":
+            infos, cinfo, extra = O.ma_train(actors, critic, abufs, cbuf, vn, cfg, share_param=case.share_param)
+        else:
+            infos, cinfo, extra = O.ha_train(actors, critic, abufs, cbuf, vn, cfg)
     finally:
         torch.randperm = real
 
@@ -91,15 +99,17 @@ def test_oracle_matches_reference_golden(name):
         got_infos = np.array([[i["kl"], i["loss_improve"], i["expected_improve"], i["dist_entropy"], i["ratio"]]
                               for i in infos])
     else:
+        order = [0] if getattr(case, "share_param", False) else extra["agent_order"]
         tr = np.array([[t["policy_loss"], t["dist_entropy"], t["grad_norm"], t["ratio"]]
-                       for a in extra["agent_order"] for t in actors[a].trace])
+                       for a in order for t in actors[a].trace])
         got_infos = np.array([[i["policy_loss"], i["dist_entropy"], i["actor_grad_norm"], i["ratio"]] for i in infos])
     assert rel_err(tr, z["actor_trace"][:, 1:]) < TOLF
     ctr = np.array([[t["value_loss"], t["grad_norm"]] for t in critic.trace])
     assert rel_err(ctr, z["critic_trace"]) < TOLF
     assert rel_err(got_infos, z["actor_infos"]) < TOLF
     assert rel_err([cinfo["value_loss"], cinfo["critic_grad_norm"]], z["critic_info"]) < TOLF
-    assert vec_rel_err(np.stack([np.ones_like(extra["factors"][0])] + extra["factors"][:-1]), z["factors"]) < TOLF
+    if extra["factors"]:
+        assert vec_rel_err(np.stack([np.ones_like(extra["factors"][0])] + extra["factors"][:-1]), z["factors"]) < TOLF
     for a in range(case.shapes.A):
         flat = actors[a].flat().numpy() if case.algo_name == "hatrpo" else actors[a].net.flat()
         assert vec_rel_err(flat, z[f"actor_final_{a}"]) < TOLF

@@ -359,6 +359,34 @@ def gae_branch_cases() -> dict:
     return out
 
 
+def checkpoint_fixture(gdir: str) -> None:
+    """Reference-written checkpoint files (on_policy_base_runner.py:724-740, save()): a GRU Discrete actor, an MLP critic
+    input width, and the CPU ValueNorm's 3-key state_dict -- what ``restore()`` of the replacement must be able to load.
+    The parameter values are the synthetic state dicts, so the test knows what to expect without the reference."""
+    sh = Shapes(T=4, N=4, A=2, obs_dim=9, share_obs_dim=12, act_dim=4, discrete=True, hidden_sizes=[64, 64])
+    cfg = load_cfg(sh, dict(use_recurrent_policy=True))
+    dev = torch.device("cpu")
+    margs = {**cfg["model"], **cfg["algo"]}
+    torch.manual_seed(5)
+    actors = [ALGO_REGISTRY["happo"](margs, Box((sh.obs_dim,)), Discrete(sh.act_dim), dev) for _ in range(sh.A)]
+    critic = VCritic(margs, Box((sh.share_obs_dim,)), dev)
+    for a, actor in enumerate(actors):
+        sd = synthetic_state_dict(actor_param_shapes(sh, True, True), 500 + a, cfg["model"]["std_x_coef"])
+        actor.actor.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    csd = synthetic_state_dict(critic_param_shapes(sh, True, True), 599)
+    critic.critic.load_state_dict({k: torch.from_numpy(v) for k, v in csd.items()})
+    vn = ValueNorm(1, device=dev)
+    vn.running_mean.fill_(0.25)
+    vn.running_mean_sq.fill_(1.5)
+    vn.debiasing_term.fill_(0.75)
+    r = OnPolicyHARunner.__new__(OnPolicyHARunner)
+    r.num_agents, r.actor, r.critic, r.value_normalizer = sh.A, actors, critic, vn
+    r.save_dir = os.path.join(gdir, "ref_ckpt")
+    os.makedirs(r.save_dir, exist_ok=True)
+    r.save()
+    print("ref_ckpt:", sorted(os.listdir(r.save_dir)), {k: tuple(v.shape) for k, v in vn.state_dict().items()})
+
+
 def main():
     gdir = os.path.join(REPO, "tests", "golden")
     os.makedirs(gdir, exist_ok=True)
@@ -370,6 +398,8 @@ def main():
         path = os.path.join(gdir, f"{name}.npz")
         np.savez_compressed(path, **out)
         print(f"{name}: {os.path.getsize(path)/1024:.0f} KiB  actor_infos={out['actor_infos'][:, 0]}  critic={out['critic_info']}")
+    if not only or "ref_ckpt" in only:
+        checkpoint_fixture(gdir)
     if not only or "gae_branches" in only:
         np.savez_compressed(os.path.join(gdir, "gae_branches.npz"), **gae_branch_cases())
         print("gae_branches written")

@@ -57,3 +57,18 @@ def test_product_does_not_import_oracle(repo_root):
             if f.endswith(".py"):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), os.path.join(dirpath, f)
+
+
+def test_reference_checkpoint_fixture_keys_match_parameter_layout(repo_root):
+    """tests/golden/ref_ckpt/*.pt were written by the reference's save(): their key order and shapes are the parameter
+    layout harl_amd.synthetic / harl_amd.nets assume, for a GRU actor and critic."""
+    import torch
+    from harl_amd.synthetic import Shapes, actor_param_shapes, critic_param_shapes
+    sh = Shapes(T=4, N=4, A=2, obs_dim=9, share_obs_dim=12, act_dim=4, discrete=True, hidden_sizes=[64, 64])
+    d = os.path.join(repo_root, "tests", "golden", "ref_ckpt")
+    sd = torch.load(os.path.join(d, "actor_agent0.pt"), map_location="cpu")
+    assert [(k, tuple(v.shape)) for k, v in sd.items()] == actor_param_shapes(sh, True, True)
+    sd = torch.load(os.path.join(d, "critic_agent.pt"), map_location="cpu")
+    assert [(k, tuple(v.shape)) for k, v in sd.items()] == critic_param_shapes(sh, True, True)
+    sd = torch.load(os.path.join(d, "value_normalizer.pt"), map_location="cpu")
+    assert list(sd.keys()) == ["running_mean", "running_mean_sq", "debiasing_term"]

@@ -122,3 +122,15 @@ def test_mappo_train_matches_reference_golden(name):
     """MAPPO through the same kernels (factor = NULL); parameter sharing accumulates every agent's segment before one
     optimiser step; OnPolicyMARunner.train() vs the reference (incl. its stray randperm(num_agents) draw)."""
     _assert_all(_G().check_train_golden(name), tol=TOL_TRAIN)
+
+
+def test_checkpoint_compat_with_reference_files(tmp_path):
+    """restore() loads checkpoints written by the reference's save(); save() writes what the reference's restore() reads."""
+    res = _G().check_checkpoint_compat(str(tmp_path))
+    for k, v in res.items():
+        if "mismatch" in k:
+            assert v == 0.0, (k, v)
+        elif "max_abs" in k:
+            assert v == 0.0, (k, v)   # parameters are copied, not recomputed
+        else:
+            assert v < TOL, (k, v)

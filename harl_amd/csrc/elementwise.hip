@@ -459,6 +459,23 @@ extern "C" int harl_reduce_scalars(const float *part_scalars, int n_blocks, doub
   return check_launch("harl_reduce_scalars");
 }
 
+// fp64 loss scalars -> fp32 head + fp32 residual, written behind the folded gradients so that ONE fp32 SUM all-reduce
+// carries gradients and scalars (~48 bits for the latter)
+__global__ void k_pack_scalars_hilo(const double *__restrict__ scalars, float *__restrict__ hilo) {
+  const int t = threadIdx.x;
+  if (t < PS_STRIDE) {
+    const double v = scalars[t];
+    const float hi = (float)v;
+    hilo[t] = hi;
+    hilo[PS_STRIDE + t] = (float)(v - (double)hi);
+  }
+}
+
+extern "C" int harl_pack_scalars_hilo(const double *scalars, float *hilo, void *stream) {
+  hipLaunchKernelGGL(k_pack_scalars_hilo, dim3(1), dim3(64), 0, (hipStream_t)stream, scalars, hilo);
+  return check_launch("harl_pack_scalars_hilo");
+}
+
 // =============================================================================================
 // Layer table (device int32[HARL_TABLE_STRIDE * n_layers]) shared by the fused kernels below.
 //   0 w_off  1 b_off  2 gamma_off (-1)  3 beta_off (-1)     offsets into the flat parameter / gradient arena
@@ -532,8 +549,8 @@ __device__ __forceinline__ void grid_barrier(unsigned *bar, unsigned target) {
 __global__ __launch_bounds__(ADAM_THREADS) void k_adam_fold(
     float *__restrict__ p, float *__restrict__ g, float *__restrict__ m, float *__restrict__ v, long n,
     const float *__restrict__ dwp, const int *__restrict__ tab, int n_layers, float *__restrict__ packs,
-    double *__restrict__ scalars, const float *__restrict__ part_scalars, int n_scalar_blocks, int mode,
-    float const_scale, int logstd_off, int act_dim, float *__restrict__ info, int use_clip, float max_norm,
+    double *__restrict__ scalars, const float *__restrict__ part_scalars, int n_scalar_blocks,
+    const float *__restrict__ scalars_hilo, int mode, float const_scale, int logstd_off, int act_dim, float *__restrict__ info, int use_clip, float max_norm,
     float lr_over_bc1, float beta1, float beta2, float eps, float wd, float bc2_sqrt, unsigned *__restrict__ ws) {
   __shared__ double sh[64];
   const int tid = threadIdx.x, nt = ADAM_THREADS;
@@ -622,6 +639,9 @@ __global__ __launch_bounds__(ADAM_THREADS) void k_adam_fold(
         u3 += ws_rows[(b + 3) * PS_STRIDE + tid];
       }
       t = (u0 + u1) + (u2 + u3);
+      if (blk == 0) scalars[tid] = t;
+    } else if (scalars_hilo) {  // all-reduced fp32 head + residual (harl_pack_scalars_hilo)
+      t = (double)scalars_hilo[tid] + (double)scalars_hilo[PS_STRIDE + tid];
       if (blk == 0) scalars[tid] = t;
     } else {
       t = scalars[tid];
@@ -717,7 +737,8 @@ __global__ __launch_bounds__(ADAM_THREADS) void k_adam_fold(
 
 extern "C" int harl_adam_fold(float *param, float *grad, float *exp_avg, float *exp_avg_sq, long n, const float *dwp,
                               const int *table, int n_layers, float *packs, double *scalars, const float *part_scalars,
-                              int n_scalar_blocks, int mode, float const_scale, int logstd_off, int act_dim, float *info,
+                              int n_scalar_blocks, const float *scalars_hilo, int mode, float const_scale, int logstd_off,
+                              int act_dim, float *info,
                               int use_clip, float max_norm, float lr, float beta1, float beta2, float eps,
                               float weight_decay, double bias_correction1, double bias_correction2, void *ws,
                               void *stream) {
@@ -725,7 +746,7 @@ extern "C" int harl_adam_fold(float *param, float *grad, float *exp_avg, float *
   const float step_size = (float)((double)lr / bias_correction1);
   const float bc2_sqrt = (float)sqrt(bias_correction2);
   hipLaunchKernelGGL(k_adam_fold, dim3(ADAM_WGS), dim3(ADAM_THREADS), 0, (hipStream_t)stream, param, grad, exp_avg,
-                     exp_avg_sq, n, dwp, table, n_layers, packs, scalars, part_scalars, n_scalar_blocks, mode,
+                     exp_avg_sq, n, dwp, table, n_layers, packs, scalars, part_scalars, n_scalar_blocks, scalars_hilo, mode,
                      const_scale, logstd_off, act_dim, info, use_clip, max_norm, step_size, beta1, beta2, eps,
                      weight_decay, bc2_sqrt, (unsigned *)ws);
   return check_launch("harl_adam_fold");

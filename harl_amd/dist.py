@@ -38,20 +38,23 @@ class Comm:
             self._all_reduce(t)
         return t
 
-    def all_reduce_packed(self, flat_grad: torch.Tensor, scalars64: torch.Tensor, staging: torch.Tensor) -> None:
-        """One collective per optimiser step: [grad | hi(scalars) | lo(scalars)] in fp32.
-        The fp64 loss scalars are split into an fp32 head + fp32 residual so a single fp32 SUM all-reduce
-        carries them with ~48 bits; ``staging`` has flat_grad.numel() + 2*scalars64.numel() fp32 elements."""
-        if not self.enabled:
-            return
-        n, k = flat_grad.numel(), scalars64.numel()
-        staging[:n].copy_(flat_grad)
-        hi = scalars64.to(torch.float32)
-        staging[n:n + k].copy_(hi)
-        staging[n + k:n + 2 * k].copy_((scalars64 - hi.to(torch.float64)).to(torch.float32))
-        self._all_reduce(staging)
-        flat_grad.copy_(staging[:n])
-        scalars64.copy_(staging[n:n + k].to(torch.float64) + staging[n + k:n + 2 * k].to(torch.float64))
+    def all_reduce_message(self, msg: torch.Tensor) -> None:
+        """One collective per optimiser step over the contiguous fp32 message [folded gradients | hi(scalars) |
+        lo(scalars)] (nets.dwp_msg): the gradients are produced in place at its head, the fp64 loss scalars are split by
+        harl_pack_scalars_hilo into an fp32 head + residual (~48 bits through a single fp32 SUM), and harl_adam_fold reads
+        both straight from the reduced message -- no staging copies around the collective."""
+        if self.enabled:
+            self._all_reduce(msg)
+
+
+def pack_message_reference(flat_grad: torch.Tensor, scalars64: torch.Tensor) -> torch.Tensor:
+    """Host restatement of the message format (used by the CPU tests): [grad | (float)s | (float)(s - hi)]."""
+    hi = scalars64.to(torch.float32)
+    return torch.cat([flat_grad.to(torch.float32), hi, (scalars64 - hi.to(torch.float64)).to(torch.float32)])
+
+
+def unpack_message_reference(msg: torch.Tensor, n: int, k: int):
+    return msg[:n], msg[n:n + k].to(torch.float64) + msg[n + k:n + 2 * k].to(torch.float64)
 
 
 def shard_columns(n_rollout_threads: int, rank: int, world_size: int) -> Tuple[int, int]:

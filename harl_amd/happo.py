@@ -154,7 +154,6 @@ class HAPPO(OnPolicyBase):
         self.max_grad_norm = args["max_grad_norm"]
         self._surrogate_mode = 0  # harl_actor_head_loss `trpo` argument: 0 = clipped (HAPPO)
         self._info = torch.zeros(4, **self.tpdv)  # sums of policy_loss, dist_entropy, grad_norm, ratio
-        self._staging = None
         self._grad_tap = None
 
     # ---- one optimiser step on rows idx[0..m) of the flat [T*N, .] tensors (happo.py:28-102) ---------
@@ -184,14 +183,14 @@ class HAPPO(OnPolicyBase):
         net = self.actor
         sc = net.scalars
         ps_kw = dict(part_scalars=net.part_scalars, n_scalar_blocks=nblk) if nblk is not None else {}
-        if self.comm.enabled:  # ONE collective per optimiser step: [folded gradients | loss scalars]
+        if self.comm.enabled:  # ONE collective per optimiser step: [folded gradients | loss scalars] (dist.py)
             if nblk is not None:
                 sc.zero_()
                 call("harl_reduce_scalars", ptr(net.part_scalars), nblk, ptr(sc), stream())
-            if self._staging is None:
-                self._staging = torch.empty(net.total_dwp + 2 * PS_STRIDE, **self.tpdv)
-            self.comm.all_reduce_packed(net.dwp, sc, self._staging)
-            ps_kw = {}
+            hilo = net.dwp_msg[net.total_dwp:]
+            call("harl_pack_scalars_hilo", ptr(sc), ptr(hilo), stream())
+            self.comm.all_reduce_message(net.dwp_msg)
+            ps_kw = dict(scalars_hilo=hilo)
         # loss = sum / sum(active) (happo.py:77-85): gradients are linear in 1/sum(active), applied inside the kernel
         ls_off = -1 if net.discrete else net.offsets["act.action_out.log_std"][0]
         self.actor_optimizer.step(0, 0.0, self.use_max_grad_norm, self.max_grad_norm, self._info, ls_off, net.act_dim,

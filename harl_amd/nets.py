@@ -199,7 +199,9 @@ class _FlatNet(nn.Module):
         self._table_rows = rows
         self.n_entries = len(rows)
         self.pack_arena = torch.empty(pack_off, dtype=torch.float32, device=dev)
-        self.dwp = torch.zeros(dwp_off, dtype=torch.float32, device=dev)
+        # the dense folded gradients live at the head of the data-parallel all-reduce message: [dwp | hi | lo] (dist.py)
+        self.dwp_msg = torch.zeros(dwp_off + 2 * PS_STRIDE, dtype=torch.float32, device=dev)
+        self.dwp = self.dwp_msg[:dwp_off]
         self.total_dwp = dwp_off
         self._pack_slots = pack_slots
         views = [(self.pack_arena[pw:pw + o * k], self.pack_arena[pb:pb + o]) for (pw, pb, o, k) in pack_slots]
@@ -524,10 +526,11 @@ class FusedAdam:
 
     def step(self, mode: int, const_scale: float, use_clip: bool, max_norm: float, info_out: Optional[torch.Tensor],
              logstd_off: int = -1, act_dim: int = 0, part_scalars: Optional[torch.Tensor] = None,
-             n_scalar_blocks: int = 0) -> None:
+             n_scalar_blocks: int = 0, scalars_hilo: Optional[torch.Tensor] = None) -> None:
         """One fused launch: loss scalars -> scale/statistics, unfold, ||g||, clip, Adam, re-fold (harl_adam_fold).
         ``part_scalars``: the loss kernel's per-block partial sums, reduced inside the launch into ``net.scalars``
-        (single-GPU path); None = ``net.scalars`` already holds the (all-reduced) sums."""
+        (single-GPU path); ``scalars_hilo``: the all-reduced fp32 (hi, lo) pair behind the gradients in ``net.dwp_msg``
+        (data-parallel path); neither = ``net.scalars`` already holds the sums."""
         g = self.param_groups[0]
         self.step_count += 1
         b1, b2 = g["betas"]
@@ -536,7 +539,7 @@ class FusedAdam:
         n = self.net
         call("harl_adam_fold", ptr(n.flat_param), ptr(n.flat_grad), ptr(self.exp_avg), ptr(self.exp_avg_sq), n.n_params,
              ptr(n.dwp), ptr(n.table), n.n_entries, ptr(n.pack_arena), ptr(n.scalars), ptr(part_scalars),
-             int(n_scalar_blocks), int(mode), float(const_scale), int(logstd_off), int(act_dim), ptr(info_out),
+             int(n_scalar_blocks), ptr(scalars_hilo), int(mode), float(const_scale), int(logstd_off), int(act_dim), ptr(info_out),
              int(use_clip), float(max_norm), float(g["lr"]), float(b1), float(b2), float(g["eps"]),
              float(g["weight_decay"]), bc1, bc2, ptr(self._ws), stream(), tag="adam_fold")
 

@@ -41,7 +41,6 @@ class VCritic:
         self.comm = Comm()
         self.shard = None
         self._info = torch.zeros(2, **self.tpdv)  # sums of value_loss, critic_grad_norm
-        self._staging = None
         self._grad_tap = None
 
     def lr_decay(self, episode, episodes):
@@ -95,13 +94,13 @@ class VCritic:
         sc = net.scalars
         nblk = _lib.load().harl_head_blocks(m)
         ps_kw = dict(part_scalars=net.part_scalars, n_scalar_blocks=nblk)  # reduced inside the optimiser launch
-        if self.comm.enabled:
+        if self.comm.enabled:  # ONE collective per optimiser step: [folded gradients | loss scalars] (dist.py)
             sc.zero_()
             call("harl_reduce_scalars", ptr(net.part_scalars), nblk, ptr(sc), s)
-            if self._staging is None:
-                self._staging = torch.empty(net.total_dwp + 2 * PS_STRIDE, **self.tpdv)
-            self.comm.all_reduce_packed(net.dwp, sc, self._staging)
-            ps_kw = {}
+            hilo = net.dwp_msg[net.total_dwp:]
+            call("harl_pack_scalars_hilo", ptr(sc), ptr(hilo), s)
+            self.comm.all_reduce_message(net.dwp_msg)
+            ps_kw = dict(scalars_hilo=hilo)
         # loss = mean over the (global) minibatch, times value_loss_coef before backward (v_critic.py:112,146)
         scale = float(self.value_loss_coef) / float(m_global)
         self.critic_optimizer.step(1, scale, self.use_max_grad_norm, self.max_grad_norm, self._info, **ps_kw)

@@ -139,19 +139,24 @@ int harl_reduce_partials(const float *part, int n_wg, long elems, float *out, vo
 /* dwp[dwp_off_l + e] = sum_w part[part_off_l + w*elems_l + e] for all layers in ONE launch (fixed order, deterministic) */
 int harl_reduce_partials_multi(const float *part, const int *table, int n_layers, int n_wg, long total_elems,
                                float *dwp, void *stream);
+/* hilo[0..PS) = (float)scalars, hilo[PS..2PS) = (float)(scalars - hi): the loss scalars ride behind the folded gradients
+ * in the single fp32 SUM all-reduce of the data-parallel path. */
+int harl_pack_scalars_hilo(const double *scalars, float *hilo, void *stream);
 /* Fused optimiser epilogue (64 co-resident workgroups, software grid barrier between phases): loss scalars ->
  * gradient scale + statistics (info), unfold the folded gradients of every table entry into `grad` (reference parameter
  * layout; Linears sharing one LayerNorm accumulate its gradients), ||grad||, clip, Adam, re-fold the updated weights into
  * `packs`.  mode 0 (actor): scale = 1/scalars[1] (sum active), info += {loss, entropy, grad_norm, ratio};
  * mode 1 (critic): scale = const_scale (= value_loss_coef / m), info += {value_loss, grad_norm}.
  * part_scalars != NULL: `scalars` (double[HARL_PS_STRIDE]) is first computed here as the fixed-order sum of the loss
- * kernel's n_scalar_blocks partial rows (single-GPU path); NULL: `scalars` already holds the (all-reduced) sums.
+ * kernel's n_scalar_blocks partial rows (single-GPU path); else scalars_hilo != NULL: `scalars` = hi + lo of the
+ * all-reduced fp32 pair written by harl_pack_scalars_hilo (data-parallel path); else `scalars` already holds the sums.
  * logstd_off >= 0: grad[logstd_off + d] = scalars[8 + d].  ws: >= 32 KiB device workspace, zero-initialised ONCE by the
  * caller (barrier words are reset by the kernel).  Replaces clip_grad_norm_ + Adam.step + the LayerNorm-affine adjoint
  * (algorithms/actors/happo.py:89-100, algorithms/critics/v_critic.py:144-155). */
 int harl_adam_fold(float *param, float *grad, float *exp_avg, float *exp_avg_sq, long n, const float *dwp,
                    const int *table, int n_layers, float *packs, double *scalars, const float *part_scalars,
-                   int n_scalar_blocks, int mode, float const_scale, int logstd_off, int act_dim, float *info,
+                   int n_scalar_blocks, const float *scalars_hilo, int mode, float const_scale, int logstd_off,
+                   int act_dim, float *info,
                    int use_clip, float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay,
                    double bias_correction1, double bias_correction2, void *ws, void *stream);
 

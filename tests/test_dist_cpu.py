@@ -62,8 +62,10 @@ def _worker(rank, world, port, q):
         scal = torch.zeros(48, dtype=torch.float64)
         scal[1] = act_local
         scal[0] = 1e9 + rank + 0.123456789  # needs the hi/lo split to survive an fp32 all-reduce
-        staging = torch.empty(flat.numel() + 96, dtype=torch.float32)
-        comm.all_reduce_packed(flat, scal, staging)
+        from harl_amd.dist import pack_message_reference, unpack_message_reference
+        msg = pack_message_reference(flat, scal)  # the [grad | hi | lo] message the device path builds in place
+        comm.all_reduce_message(msg)
+        flat, scal = unpack_message_reference(msg, flat.numel(), scal.numel())
         got = flat.numpy() / scal[1].item()
         want = g_full / act_full
         err = float(np.max(np.abs(got - want)) / np.max(np.abs(want)))

@@ -43,6 +43,7 @@ SIGNATURES = {
     "harl_adam_fold": [_vp, _vp, _vp, _vp, _l, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _f, _i, _i, _vp, _i, _f, _f, _f,
                        _f, _f, _f, _d, _d, _vp, _vp],
     "harl_pack_scalars_hilo": [_vp, _vp, _vp],
+    "harl_randperm_replay": [_vp, _l, _l, _vp, _vp, _vp],
     "harl_actor_head_logp": [_vp, _l, _i, _vp, _vp, _vp, _f, _f, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _l, _l, _vp],
     "harl_actor_head_loss": [_vp, _vp, _vp, _l, _i, _vp, _vp, _vp, _f, _f, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,
                              _vp, _vp, _f, _f, _i, _i, _l, _l, _vp, _vp, _vp, _vp, _vp],

@@ -121,14 +121,78 @@ def consume_randperm(batch_size: int, deferred: bool = True) -> None:
     _RNG_WORKER.submit(batch_size - 1)
 
 
-def minibatch_indices(batch_size: int, num_mini_batch: int) -> List[torch.Tensor]:
+_REPLAY_OK: Optional[bool] = None
+_REPLAY_BUFS: dict = {}
+PERM_TAP = None  # test hook: called with every permutation this module materialises (CPU int64 copy)
+
+
+def _replay_raw(n: int, set_state: bool = True) -> torch.Tensor:
+    """ATen's randperm_cpu replayed by libharl_hip.so::harl_randperm_replay from the current generator state; advances
+    the generator exactly like torch.randperm(n).  Returns a reusable CPU int32 buffer (valid until the next call)."""
+    lib = _lib.load()
+    if n not in _REPLAY_BUFS:
+        pin = torch.cuda.is_available()
+        _REPLAY_BUFS[n] = (torch.empty(n, dtype=torch.int32, pin_memory=pin), torch.empty(n, dtype=torch.int32))
+    out, scratch = _REPLAY_BUFS[n]
+    st = torch.get_rng_state()
+    st2 = torch.empty_like(st)
+    rc = lib.harl_randperm_replay(st.data_ptr(), st.numel(), n, out.data_ptr(), scratch.data_ptr(), st2.data_ptr())
+    if rc != 0:
+        raise RuntimeError("harl_randperm_replay: unexpected CPU generator state layout")
+    if set_state:
+        torch.set_rng_state(st2)
+    return out
+
+
+def _replay_matches_randperm() -> bool:
+    """One-time self-check (global RNG state saved/restored): permutation AND final generator state of the replay are
+    those of torch.randperm, from a state that is mid-block and across several mt19937 block refills."""
+    global _REPLAY_OK
+    if _REPLAY_OK is None:
+        st = torch.get_rng_state()
+        try:
+            ok = True
+            for seed, n in ((987654321, 1031), (5, 70001)):
+                torch.manual_seed(seed)
+                torch.randperm(17)
+                mid = torch.get_rng_state()
+                a = _replay_raw(n).clone()
+                sa = torch.get_rng_state()
+                torch.set_rng_state(mid)
+                b = torch.randperm(n)
+                ok = ok and bool(torch.equal(a.long(), b)) and bool(torch.equal(sa, torch.get_rng_state()))
+            _REPLAY_OK = ok
+        except Exception:  # noqa: BLE001 -- any surprise (torch build with another state layout): use torch.randperm
+            _REPLAY_OK = False
+        finally:
+            torch.set_rng_state(st)
+    return _REPLAY_OK
+
+
+def draw_permutation(n: int, device=None) -> torch.Tensor:
+    """``torch.randperm(n)`` on the global CPU generator (bit-identical values and generator state), as an int64 tensor
+    on ``device`` (CPU if None).  Large n goes through the C replay: ATen fans the permutation's initialisation out to
+    its thread pool, whose wake-up made each 819200-element draw cost ~27 ms inside train() on the 256-thread GPU host;
+    the replay costs ~5 ms and uploads 4 bytes per index instead of 8."""
+    rng_sync()
+    if n >= 65536 and _replay_matches_randperm():
+        p32 = _replay_raw(n)
+        if PERM_TAP is not None:
+            PERM_TAP(p32.long())
+        return p32.long() if device is None else p32.to(device).long()
+    p = torch.randperm(n)
+    if PERM_TAP is not None:
+        PERM_TAP(p.clone())
+    return p if device is None else p.to(device)
+
+
+def minibatch_indices(batch_size: int, num_mini_batch: int, device=None) -> List[torch.Tensor]:
     """One ``torch.randperm(batch_size)`` draw on the global CPU generator, remainder rows dropped
-    (on_policy_actor_buffer.py:121-135).  Returns CPU int64 tensors."""
+    (on_policy_actor_buffer.py:121-135).  Returns int64 tensors (views of one permutation) on ``device`` (CPU if None)."""
     assert batch_size >= num_mini_batch, (
         f"batch size ({batch_size}) must be >= the number of mini batches ({num_mini_batch})")
     m = batch_size // num_mini_batch
-    rng_sync()
-    rand = torch.randperm(batch_size)
+    rand = draw_permutation(batch_size, device)
     return [rand[i * m:(i + 1) * m] for i in range(num_mini_batch)]
 
 
@@ -231,8 +295,7 @@ class OnPolicyActorBuffer:
         if mini_batch_size is None:
             sampler = minibatch_indices(B, actor_num_mini_batch)
         else:
-            rng_sync()
-            rand = torch.randperm(B)
+            rand = draw_permutation(B)
             sampler = [rand[i * mini_batch_size:(i + 1) * mini_batch_size] for i in range(actor_num_mini_batch)]
         adv = None if advantages is None else _as_dev(advantages, self.device).reshape(-1, 1)
         for ind in sampler:
@@ -327,8 +390,7 @@ class OnPolicyCriticBufferEP:
         if mini_batch_size is None:
             sampler = minibatch_indices(B, critic_num_mini_batch)
         else:
-            rng_sync()
-            rand = torch.randperm(B)
+            rand = draw_permutation(B)
             sampler = [rand[i * mini_batch_size:(i + 1) * mini_batch_size] for i in range(critic_num_mini_batch)]
         for ind in sampler:
             i = ind.to(self.device)
@@ -389,8 +451,7 @@ class OnPolicyCriticBufferFP(OnPolicyCriticBufferEP):
         if mini_batch_size is None:
             sampler = minibatch_indices(B, critic_num_mini_batch)
         else:
-            rng_sync()
-            rand = torch.randperm(B)
+            rand = draw_permutation(B)
             sampler = [rand[i * mini_batch_size:(i + 1) * mini_batch_size] for i in range(critic_num_mini_batch)]
         for ind in sampler:
             i = ind.to(self.device)

@@ -1,0 +1,101 @@
+// host_rng.hip -- host-side (no device code): a bit-exact, faster restatement of torch.randperm on the CPU generator.
+//
+// The reference draws every minibatch permutation with torch.randperm(B) on the global CPU generator
+// (on_policy_actor_buffer.py:131, on_policy_critic_buffer_ep.py:223); for B = 819200 ATen's serial Fisher-Yates costs
+// 35-95 ms of host time per draw, 20 draws per train() -- far more than the whole update on the GPU.  This file replays
+// exactly the same algorithm (ATen randperm_cpu, "small n" branch: for i in [0, n-1): z = random() % (n - i);
+// swap(r[i], r[i+z]), with random() = one tempered mt19937 output) from a COPY of the generator state, on 32-bit indices
+// with the random numbers generated in bulk.  torch's own generator is then advanced by the same n-1 draws
+// (harl_amd/buffers.py), so the RNG stream of the run is unchanged.  tests/test_cabi.py checks the permutations against
+// torch.randperm for many (seed, n).
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "../../include/harl_hip.h"
+
+namespace {
+constexpr int MT_N = 624, MT_M = 397;
+
+struct Mt {
+  uint32_t s[MT_N];
+  int left, next;
+  static inline uint32_t tw(uint32_t u, uint32_t v) {
+    return (((u & 0x80000000u) | (v & 0x7fffffffu)) >> 1) ^ ((v & 1u) ? 0x9908b0dfu : 0u);
+  }
+  void next_state() {  // at::mt19937::next_state
+    uint32_t *p = s;
+    left = MT_N;
+    next = 0;
+    for (int j = MT_N - MT_M + 1; --j; p++) *p = p[MT_M] ^ tw(p[0], p[1]);
+    for (int j = MT_M; --j; p++) *p = p[MT_M - MT_N] ^ tw(p[0], p[1]);
+    *p = p[MT_M - MT_N] ^ tw(p[0], s[0]);
+  }
+  inline uint32_t draw() {  // at::mt19937::operator()
+    if (--left == 0) next_state();
+    uint32_t y = s[next++];
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= (y >> 18);
+    return y;
+  }
+};
+}  // namespace
+
+// state_in/state_out: the bytes of torch.get_rng_state() (CPUGeneratorImplState: uint64 seed; int left; int seeded;
+// uint64 next; uint64 state[624]; ...); state_out = state_in advanced by the n-1 draws (pass it to torch.set_rng_state).
+// out: int32[n] (the permutation), scratch: uint32[n] -- both caller-owned and reusable (fresh allocations cost more in
+// page faults than the algorithm itself).  Returns 0, or -2 on an unexpected layout / n outside the 32-bit-draw branch.
+extern "C" int harl_randperm_replay(const uint8_t *state_in, long state_bytes, long n, int32_t *out, uint32_t *scratch,
+                                    uint8_t *state_out) {
+  if (state_bytes < 24 + 8 * MT_N || n < 0 || n >= (long)(0xffffffffu / 20)) return -2;
+  Mt g;
+  int32_t left, seeded;
+  uint64_t next;
+  std::memcpy(&left, state_in + 8, 4);
+  std::memcpy(&seeded, state_in + 12, 4);
+  std::memcpy(&next, state_in + 16, 8);
+  if (!seeded || left < 0 || left > MT_N || next > (uint64_t)MT_N) return -2;
+  for (int i = 0; i < MT_N; ++i) {
+    uint64_t v;
+    std::memcpy(&v, state_in + 24 + 8 * i, 8);
+    g.s[i] = (uint32_t)v;
+  }
+  g.left = left;
+  g.next = (int)next;
+  uint32_t *r = reinterpret_cast<uint32_t *>(out), *k = scratch;
+  for (long i = 0; i < n; ++i) r[i] = (uint32_t)i;
+  const long nd = n > 0 ? n - 1 : 0;
+  for (long i = 0; i < nd; ++i) k[i] = g.draw();
+  // k[i] = i + z % (n - i).  The quotient comes from a double division (exact to within one unit for 32-bit operands,
+  // fixed up below), which pipelines / vectorises; an integer `%` per element is 3x slower.
+  for (long i = 0; i < nd; ++i) {
+    const uint32_t z = k[i], m = (uint32_t)(n - i);
+    uint32_t q = (uint32_t)((double)z / (double)m);
+    uint32_t rem = z - q * m;
+    if ((int32_t)rem < 0) rem += m;   // q one too large
+    if (rem >= m) rem -= m;           // q one too small
+    k[i] = (uint32_t)i + rem;
+  }
+  constexpr long PF = 24;  // the swap partner is a random element of a 3 MB array: prefetch it a few iterations ahead
+  for (long i = 0; i < nd; ++i) {
+    if (i + PF < nd) __builtin_prefetch(r + k[i + PF], 1, 1);
+    const uint32_t kk = k[i];
+    const uint32_t sav = r[i];
+    r[i] = r[kk];
+    r[kk] = sav;
+  }
+  if (state_out) {
+    if (state_out != state_in) std::memcpy(state_out, state_in, (size_t)state_bytes);
+    left = g.left;
+    next = (uint64_t)g.next;
+    std::memcpy(state_out + 8, &left, 4);
+    std::memcpy(state_out + 16, &next, 8);
+    for (int i = 0; i < MT_N; ++i) {
+      const uint64_t v = g.s[i];
+      std::memcpy(state_out + 24 + 8 * i, &v, 8);
+    }
+  }
+  return 0;
+}

@@ -296,7 +296,7 @@ class HAPPO(OnPolicyBase):
                                   active if self.use_policy_active_masks else None,
                                   logp_out=_old_logp_out if epoch == 0 else None)
                 continue
-            sampler = minibatch_indices(n_global, self.actor_num_mini_batch)  # CPU RNG draw, bit-exact with the reference
+            sampler = minibatch_indices(n_global, self.actor_num_mini_batch, dev)  # CPU RNG draw, bit-exact with the reference
             for ind in sampler:
                 if self.shard:
                     ind = local_minibatch_rows(ind, self.shard[0], self.shard[1], self.shard[2])

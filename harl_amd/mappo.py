@@ -64,7 +64,7 @@ class MAPPO(HAPPO):
                     consume_randperm(n_global)
                     samplers.append([None])
                 else:
-                    samplers.append(minibatch_indices(n_global, k))
+                    samplers.append(minibatch_indices(n_global, k, dev))
             for b in range(k):
                 acc.zero_()
                 net._ensure_ws(B)

@@ -153,7 +153,7 @@ class VCritic:
                 consume_randperm(n_global)  # replay the generator state only (see HAPPO.train)
                 self._update_core(share_obs, None, B, n_global, value_preds, returns, value_normalizer)
                 continue
-            sampler = minibatch_indices(n_global, self.critic_num_mini_batch)
+            sampler = minibatch_indices(n_global, self.critic_num_mini_batch, dev)
             for ind in sampler:
                 m_global = ind.numel()
                 if self.shard:

@@ -264,6 +264,15 @@ int harl_head_blocks(long M);
 /* scalars[j] += sum_b part_scalars[b][j], j < HARL_PS_STRIDE (fixed order, fp64) */
 int harl_reduce_scalars(const float *part_scalars, int n_blocks, double *scalars, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Host helper (no GPU work): the permutation torch.randperm(n) WOULD return from the CPU generator whose state bytes
+ * (torch.get_rng_state()) are given, and the state it would leave behind -- ATen's randperm_cpu algorithm replayed from
+ * a copy of the mt19937 state without ATen's thread-pool fan-out (27 ms -> ~5 ms for n = 819200 on the GPU box's host).
+ * out: int32[n], scratch: uint32[n] (caller-owned, reusable), state_out: state_bytes bytes for torch.set_rng_state().
+ * Replaces the draw in on_policy_actor_buffer.py:131 / on_policy_critic_buffer_ep.py:223 bit for bit. */
+int harl_randperm_replay(const uint8_t *state_in, long state_bytes, long n, int32_t *out, uint32_t *scratch,
+                         uint8_t *state_out);
+
 #ifdef __cplusplus
 }
 #endif

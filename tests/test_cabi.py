@@ -72,3 +72,31 @@ def test_reference_checkpoint_fixture_keys_match_parameter_layout(repo_root):
     assert [(k, tuple(v.shape)) for k, v in sd.items()] == critic_param_shapes(sh, True, True)
     sd = torch.load(os.path.join(d, "value_normalizer.pt"), map_location="cpu")
     assert list(sd.keys()) == ["running_mean", "running_mean_sq", "debiasing_term"]
+
+
+def test_randperm_replay_is_bit_exact_with_torch():
+    """buffers.draw_permutation (C replay of ATen's randperm_cpu on a copy of the mt19937 state) returns exactly
+    torch.randperm's permutation and leaves the global CPU generator in exactly the same state -- the integer side of
+    the parity contract (minibatch sampling bit-exact) for the large-batch path that bypasses torch.randperm."""
+    import torch
+    from harl_amd import buffers
+    assert buffers._replay_matches_randperm()
+    for seed in (0, 1, 123456789):
+        for n in (65536, 70001, 204800, 819200):
+            torch.manual_seed(seed)
+            torch.randperm(5)  # off the freshly seeded state
+            st = torch.get_rng_state()
+            want = torch.randperm(n)
+            want_state = torch.get_rng_state()
+            torch.set_rng_state(st)
+            taps = []
+            buffers.PERM_TAP = taps.append
+            try:
+                got = buffers.draw_permutation(n)
+            finally:
+                buffers.PERM_TAP = None
+            assert got.dtype == torch.int64 and torch.equal(got, want), (seed, n)
+            assert torch.equal(torch.get_rng_state(), want_state), (seed, n)
+            assert len(taps) == 1 and torch.equal(taps[0], want)
+            # and the next draw of the stream is unaffected
+            assert torch.equal(torch.randperm(7), (torch.set_rng_state(want_state), torch.randperm(7))[1])

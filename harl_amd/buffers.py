@@ -373,15 +373,18 @@ class OnPolicyCriticBufferEP:
         return t.reshape(self.episode_length * self.n_rollout_threads, -1)
 
     def recurrent_batches(self, num_mini_batch: int, data_chunk_length: int, naive: bool = False, shard=None):
-        """See OnPolicyActorBuffer.recurrent_batches (critic_buffer_ep.py:252-369)."""
+        """See OnPolicyActorBuffer.recurrent_batches (critic_buffer_ep.py:252-369).  FP buffers
+        (critic_buffer_fp.py:262-390): the same samplers over N*A columns -- ``_ma_cast`` orders (thread, agent) pairs
+        as column c = n*A + a, which is exactly the row order of the [T, N, A, .] flattening used here."""
         from .nets import build_seq
-        if shard or getattr(self, "num_agents", None):
-            raise NotImplementedError("recurrent samplers: EP state type, unsharded")
+        if shard:
+            raise NotImplementedError("recurrent samplers with sharded n_rollout_threads")
         T, N = self.rewards.shape[:2]
+        ncol = N * (getattr(self, "num_agents", None) or 1)
         H = self.rnn_hidden_size
-        for first, L in recurrent_first_rows(T, N, num_mini_batch, data_chunk_length, naive):
-            yield build_seq(self.device, L, first.numel(), H, first_rows=first, stride=N,
-                            h0_src=self.rnn_states_critic.reshape((T + 1) * N, -1), masks_src=self.masks.reshape(-1))
+        for first, L in recurrent_first_rows(T, ncol, num_mini_batch, data_chunk_length, naive):
+            yield build_seq(self.device, L, first.numel(), H, first_rows=first, stride=ncol,
+                            h0_src=self.rnn_states_critic.reshape((T + 1) * ncol, -1), masks_src=self.masks.reshape(-1))
 
     def feed_forward_generator_critic(self, critic_num_mini_batch=None, mini_batch_size=None):
         """API-compatible generator (critic_buffer_ep.py:202-250); ``VCritic.train`` uses index arrays instead."""

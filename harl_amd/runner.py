@@ -93,7 +93,9 @@ class OnPolicyHARunner:
             next_value, _ = self.critic.get_values(cb.share_obs[-1], cb.rnn_states_critic[-1], cb.masks[-1])
         else:  # FP: all (thread, agent) rows in one batch (np.concatenate over threads, base_runner.py:472-481)
             so = cb.share_obs[-1]
-            next_value, _ = self.critic.get_values(so.reshape(-1, so.shape[-1]), None, None)
+            rows = so.shape[0] * so.shape[1]
+            next_value, _ = self.critic.get_values(so.reshape(rows, -1), cb.rnn_states_critic[-1].reshape(rows, 1, -1),
+                                                   cb.masks[-1].reshape(rows, 1))
         cb.compute_returns(next_value, self.value_normalizer)
 
     # ---- on_policy_ha_runner.py:11-130 ------------------------------------------------------------

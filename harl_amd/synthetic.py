@@ -109,7 +109,7 @@ class SyntheticBuffers:
     critic_masks: np.ndarray            # [T+1, N, 1]
     bad_masks: np.ndarray               # [T+1, N, 1]
     fp: Optional[dict] = None           # FP state type: share_obs/value_preds/masks/bad_masks [T+1,N,A,.], rewards [T,N,A,1]
-    rnn: Optional[dict] = None          # recurrent policies: actor = A x [T+1,N,1,H], critic = [T+1,N,1,H]
+    rnn: Optional[dict] = None          # recurrent policies: actor = A x [T+1,N,1,H], critic = [T+1,N,1,H], critic_fp = [T+1,N,A,1,H]
 
 
 def make_buffers(sh: Shapes, seed: int, inactive_p: float = 0.0, unavailable_p: float = 0.0,
@@ -160,4 +160,6 @@ def make_buffers(sh: Shapes, seed: int, inactive_p: float = 0.0, unavailable_p: 
         hh = sh.hidden_sizes[-1]
         out.rnn = dict(actor=[(0.3 * rng.standard_normal((T + 1, N, 1, hh))).astype(f32) for _ in range(A)],
                        critic=(0.3 * rng.standard_normal((T + 1, N, 1, hh))).astype(f32))
+        if fp:  # per-agent critic hidden states (on_policy_critic_buffer_fp.py:48-56)
+            out.rnn["critic_fp"] = (0.3 * rng.standard_normal((T + 1, N, A, 1, hh))).astype(f32)
     return out

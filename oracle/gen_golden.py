@@ -107,6 +107,16 @@ CASES = {
                                       hidden_sizes=[64, 64, 64]), seed=17,
                           overrides=dict(use_naive_recurrent_policy=True, actor_num_mini_batch=2, critic_num_mini_batch=2,
                                          ppo_epoch=2, critic_epoch=2, fixed_order=True)),
+    # ---- FP state type with recurrent critics: the samplers run over N*A (thread, agent) columns (critic_buffer_fp.py:262-390)
+    "rnn_fp_box_h64_mb2": dict(state_type="FP", shapes=dict(T=10, N=4, A=2, obs_dim=8, share_obs_dim=11, act_dim=2,
+                                                            discrete=False, hidden_sizes=[64]), seed=31, inactive_p=0.1,
+                               overrides=dict(use_recurrent_policy=True, data_chunk_length=5, actor_num_mini_batch=2,
+                                              critic_num_mini_batch=2, ppo_epoch=2, critic_epoch=3)),
+    "rnn_naive_fp_disc_h64": dict(state_type="FP", shapes=dict(T=8, N=4, A=3, obs_dim=10, share_obs_dim=9, act_dim=4,
+                                                               discrete=True, hidden_sizes=[64, 64]), seed=32,
+                                  unavailable_p=0.2,
+                                  overrides=dict(use_naive_recurrent_policy=True, critic_num_mini_batch=3, ppo_epoch=2,
+                                                 critic_epoch=2)),
     # ---- HAA2C (harl/algorithms/actors/haa2c.py): unclipped surrogate, a2c_epoch epochs
     "a2c_box_h64": dict(algo="haa2c", shapes=dict(T=10, N=8, A=2, obs_dim=13, share_obs_dim=9, act_dim=2, discrete=False,
                                                   hidden_sizes=[64, 64]), seed=12, overrides={}),
@@ -188,7 +198,7 @@ def run_case(name: str, spec: dict) -> dict:
         if rec:
             abuf[a].rnn_states[:] = data.rnn["actor"][a]
     if rec:
-        cbuf.rnn_states_critic[:] = data.rnn["critic"]
+        cbuf.rnn_states_critic[:] = data.rnn["critic_fp" if fp else "critic"]
     if fp:
         for k in ("share_obs", "rewards", "value_preds", "masks", "bad_masks"):
             getattr(cbuf, k)[:] = data.fp[k]

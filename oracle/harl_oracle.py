@@ -627,16 +627,21 @@ class OracleCriticBufferEP:
         rnn = self.rnn_states_critic[:-1].reshape(B, *self.rnn_states_critic.shape[-2:])[first_rows]
         return f(self.share_obs[:-1]), f(self.value_preds[:-1]), f(self.returns[:-1]), rnn, f(self.masks[:-1])
 
+    def _cols(self):
+        """(T, number of independent columns): N for EP, N*A for FP (critic_buffer_fp.py treats every (thread, agent)
+        pair as a column, ordered c = n*A + a by _ma_cast / the reshape in the naive generator)."""
+        return self.rewards.shape[0], int(np.prod(self.rewards.shape[1:-1]))
+
     def recurrent_generator(self, num_mini_batch: int, L: int):
-        """on_policy_critic_buffer_ep.py:285-369 (EP)."""
-        T, N = self.rewards.shape[:2]
+        """on_policy_critic_buffer_ep.py:285-369 (EP), on_policy_critic_buffer_fp.py:306-390 (FP)."""
+        T, N = self._cols()
         for chunks in minibatch_indices((T * N) // L, num_mini_batch):
             rows, first = chunk_rows(chunks, T, N, L)
             yield self._gather(rows, first), chunks
 
     def naive_recurrent_generator(self, num_mini_batch: int):
-        """on_policy_critic_buffer_ep.py:252-283."""
-        T, N = self.rewards.shape[:2]
+        """on_policy_critic_buffer_ep.py:252-283, on_policy_critic_buffer_fp.py:262-304."""
+        T, N = self._cols()
         per = N // num_mini_batch
         perm = torch.randperm(N).numpy()
         for b in range(num_mini_batch):

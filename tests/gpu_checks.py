@@ -543,7 +543,7 @@ def build_runner(case: GoldenCase):
         if d.rnn is not None:
             b.rnn_states.copy_(dev(d.rnn["actor"][a]))
     if d.rnn is not None:
-        r.critic_buffer.rnn_states_critic.copy_(dev(d.rnn["critic"]))
+        r.critic_buffer.rnn_states_critic.copy_(dev(d.rnn["critic_fp" if case.state_type == "FP" else "critic"]))
     r.critic.critic.load_state_dict({k: torch.from_numpy(v) for k, v in case.critic_sd.items()})
     cb = r.critic_buffer
     if case.state_type == "FP":

@@ -100,7 +100,8 @@ def test_gru_policy_forward_and_update(i):
     _assert_all(G.check_rnn_update(G.RNN_SHAPES[i]), tol=2e-5)
 
 
-@pytest.mark.parametrize("name", ["rnn_box_h64", "rnn_disc_h64_mb2", "rnn_naive_h64"])
+@pytest.mark.parametrize("name", ["rnn_box_h64", "rnn_disc_h64_mb2", "rnn_naive_h64", "rnn_fp_box_h64_mb2",
+                                  "rnn_naive_fp_disc_h64"])
 def test_recurrent_train_matches_reference_golden(name):
     """Chunked and naive recurrent samplers + GRU actor/critic through a whole OnPolicyHARunner.train() vs the reference."""
     _assert_all(_G().check_train_golden(name), tol=TOL_TRAIN)

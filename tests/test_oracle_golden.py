@@ -44,7 +44,7 @@ def build_oracle(case: GoldenCase):
         cbuf = O.OracleCriticBufferEP(d.share_obs.copy(), d.rewards.copy(), d.value_preds.copy(), d.critic_masks.copy(),
                                       d.bad_masks.copy())
     if d.rnn is not None:
-        cbuf.rnn_states_critic = d.rnn["critic"].copy()
+        cbuf.rnn_states_critic = d.rnn["critic_fp" if case.state_type == "FP" else "critic"].copy()
     vn = None
     if case.use_valuenorm:
         vn = O.OracleValueNorm()

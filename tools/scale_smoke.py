@@ -59,6 +59,13 @@ def run(name, c):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         r.compute(); infos, cinfo = r.train()
         torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+    if os.environ.get("HARL_KTIMING"):
+        from harl_amd import _lib
+        _lib.enable_kernel_timing(True)
+        r.compute(); r.train()
+        kt = _lib.collect_kernel_timing(); _lib.enable_kernel_timing(False)
+        for k, v in sorted(kt.items(), key=lambda kv: -kv[1]["total_ms"]):
+            print(f"    {k:20s} n={v['n']:5d} avg={v['avg_ms']*1e3:9.1f} us total={v['total_ms']:8.2f} ms")
     ok = all(np.isfinite(list(i.values())).all() for i in infos) and np.isfinite(list(cinfo.values())).all()
     tr = c["T"] * c["N"]
     print(f"{name:24s} T={c['T']} N={c['N']} A={c['A']} obs={c['obs']} hidden={c['hidden']}: {min(ts)*1e3:9.1f} ms/update "

@@ -69,21 +69,66 @@ __device__ __forceinline__ void gemm_gates(f32x16 (&acc)[3][GT], const float *wl
 }
 
 // =============================================================================================
+// input half of the gates for ALL time steps at once: gi_g = W_ig' x_hat + b_ig' (+ b_hg for r, z).  No recurrence here,
+// so every (step, sequence-group) slab is an independent wave-task; the sequential kernel below is left with the W_hh
+// products only (192 instead of 384 MFMAs per step), which matters when few sequences are unrolled over many steps
+// (the runner's full-length log-prob passes: 512 sequences x 160 steps in the SMAC-sized configuration).
+// =============================================================================================
+__global__ __launch_bounds__(WG_THREADS, 1) void k_gru_gates_x(const float *__restrict__ xin,
+                                                               const float *__restrict__ Wih,
+                                                               const float *__restrict__ bih,
+                                                               const float *__restrict__ bhh, long n_slabs,
+                                                               float *__restrict__ gi_r, float *__restrict__ gi_z,
+                                                               float *__restrict__ gi_n) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int LDW = GH + 1;
+  float *Wil = lds;                 // [192][65]
+  float *bl = Wil + 3 * GH * LDW;   // [192]  b_i (+ b_h for the r and z gates)
+  stage_matrix<3 * GH, GH, LDW, WG_THREADS>(Wil, Wih);
+  for (int e = threadIdx.x; e < 3 * GH; e += WG_THREADS) bl[e] = bih[e] + (e < 2 * GH ? bhh[e] : 0.f);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  const float *wi_lane = Wil + i * LDW + 4 * h;
+  for (long slab = (long)blockIdx.x * WAVES_PER_WG + wave; slab < n_slabs; slab += (long)gridDim.x * WAVES_PER_WG) {
+    float x[GR];
+    load_act(xin, slab, lane, x);
+    f32x16 acc[3][GT];
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+      for (int t = 0; t < GT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[g][t][r] = bl[g * GH + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h];
+    gemm_gates<7>(acc, wi_lane, x);
+    float o[GR];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+#pragma unroll
+      for (int R = 0; R < GR; ++R) o[R] = acc[g][R >> 4][R & 15];
+      store_act(g == 0 ? gi_r : (g == 1 ? gi_z : gi_n), slab, lane, o);
+    }
+  }
+}
+
+// =============================================================================================
 // forward
 // =============================================================================================
+template <bool PRE>
 __global__ __launch_bounds__(WG_THREADS, 1) void k_gru_fwd(
-    const float *__restrict__ xin, const float *__restrict__ mrow, const float *__restrict__ h0,
+    const float *__restrict__ xin, const float *__restrict__ gi_r, const float *__restrict__ gi_z,
+    const float *__restrict__ gi_n, const float *__restrict__ mrow, const float *__restrict__ h0,
     const float *__restrict__ Wih, const float *__restrict__ bih, const float *__restrict__ Whh,
     const float *__restrict__ bhh, int L, long m_pad, float *__restrict__ y, float *__restrict__ rstd_y,
     float *__restrict__ hpm_s, float *__restrict__ r_s, float *__restrict__ z_s, float *__restrict__ n_s,
     float *__restrict__ hn_s, float *__restrict__ h_last, int save) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int LDW = GH + 1;
-  float *Wil = lds;                     // [192][65]
-  float *Whl = Wil + 3 * GH * LDW;      // [192][65]
-  float *bil = Whl + 3 * GH * LDW;      // [192]
-  float *bhl = bil + 3 * GH;            // [192]
-  stage_matrix<3 * GH, GH, LDW, WG_THREADS>(Wil, Wih);
+  float *Whl = lds;                               // [192][65]
+  float *Wil = Whl + 3 * GH * LDW;                // [192][65]   (absent when the x half is precomputed)
+  float *bil = Wil + (PRE ? 0 : 3 * GH * LDW);    // [192]
+  float *bhl = bil + 3 * GH;                      // [192]
+  if (!PRE) stage_matrix<3 * GH, GH, LDW, WG_THREADS>(Wil, Wih);
   stage_matrix<3 * GH, GH, LDW, WG_THREADS>(Whl, Whh);
   for (int e = threadIdx.x; e < 3 * GH; e += WG_THREADS) {
     bil[e] = bih[e];
@@ -100,25 +145,39 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_gru_fwd(
     load_rows(h0, G * SLAB + i, h, hs);
     for (int l = 0; l < L; ++l) {
       const long slab = (long)l * groups + G;
-      float x[GR];
-      load_act(xin, slab, lane, x);
       const float mk = mrow[slab * SLAB + i];
 #pragma unroll
       for (int R = 0; R < GR; ++R) hs[R] *= mk;  // h~ = h_{l-1} * mask_l
       if (save) store_act(hpm_s, slab, lane, hs);
       // accumulators: [0] r, [1] z share the x- and h- GEMMs; n keeps W_in x (acc[2]) and W_hn h~ (acch) apart
       f32x16 acc[3][GT], acch[3][GT];
+      if (PRE) {  // x half (with b_i, and b_h for r/z) comes from k_gru_gates_x
+        float gx[GR];
 #pragma unroll
-      for (int g = 0; g < 3; ++g)
+        for (int g = 0; g < 3; ++g) {
+          load_act(g == 0 ? gi_r : (g == 1 ? gi_z : gi_n), slab, lane, gx);
+#pragma unroll
+          for (int R = 0; R < GR; ++R) acc[g][R >> 4][R & 15] = gx[R];
+        }
 #pragma unroll
         for (int t = 0; t < GT; ++t)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int o = g * GH + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
-            acc[g][t][r] = g < 2 ? bil[o] + bhl[o] : bil[o];
-            acch[g][t][r] = bhl[o];
-          }
-      gemm_gates<7>(acc, wi_lane, x);
+          for (int r = 0; r < 16; ++r) acch[2][t][r] = bhl[2 * GH + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h];
+      } else {
+        float x[GR];
+        load_act(xin, slab, lane, x);
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+          for (int t = 0; t < GT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int o = g * GH + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
+              acc[g][t][r] = g < 2 ? bil[o] + bhl[o] : bil[o];
+              acch[g][t][r] = bhl[o];
+            }
+        gemm_gates<7>(acc, wi_lane, x);
+      }
       gemm_gates<3>(acc, wh_lane, hs);   // r, z: same accumulators
       gemm_gates<4>(acch, wh_lane, hs);  // n: W_hn h~ + b_hn on its own
       float rg[GR], zg[GR], ng[GR], hn[GR];
@@ -264,17 +323,31 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_gru_bwd(
 extern "C" int harl_gru_fwd(const float *xin, const float *mask_rows, const float *h0, const float *Wih,
                             const float *bih, const float *Whh, const float *bhh, int H, int L, long m_pad, float *y,
                             float *rstd_y, float *hpm, float *r, float *z, float *n, float *hn, float *h_last, int save,
-                            void *stream) {
+                            float *gi_ws, void *stream) {
   if (L <= 0 || m_pad <= 0) return 0;
   if (H != GH) { set_error("harl_gru_fwd: hidden width must be 64"); return -2; }
   if (m_pad % SLAB) { set_error("harl_gru_fwd: m_pad must be a multiple of 32"); return -2; }
-  const size_t shm = ((size_t)2 * 3 * GH * (GH + 1) + 2 * 3 * GH) * sizeof(float);
   const long groups = m_pad / SLAB;
   long wgs = (groups + WAVES_PER_WG - 1) / WAVES_PER_WG;
   const int grid = (int)(wgs < 256 ? wgs : 256);
-  allow_big_lds(k_gru_fwd, shm);
-  hipLaunchKernelGGL(k_gru_fwd, dim3(grid), dim3(WG_THREADS), shm, (hipStream_t)stream, xin, mask_rows, h0, Wih, bih, Whh,
-                     bhh, L, m_pad, y, rstd_y, hpm, r, z, n, hn, h_last, save);
+  hipStream_t s = (hipStream_t)stream;
+  if (gi_ws) {  // two phases: parallel x half over all L*groups slabs, then the recurrence with W_hh only
+    const long n_slabs = (long)L * groups, M = n_slabs * SLAB;
+    float *gr = gi_ws, *gz = gi_ws + M * GH, *gn = gi_ws + 2 * M * GH;
+    const size_t shm_x = ((size_t)3 * GH * (GH + 1) + 3 * GH) * sizeof(float);
+    allow_big_lds(k_gru_gates_x, shm_x);
+    hipLaunchKernelGGL(k_gru_gates_x, dim3(persistent_grid(n_slabs, 1)), dim3(WG_THREADS), shm_x, s, xin, Wih, bih, bhh,
+                       n_slabs, gr, gz, gn);
+    const size_t shm = ((size_t)3 * GH * (GH + 1) + 2 * 3 * GH) * sizeof(float);
+    allow_big_lds(k_gru_fwd<true>, shm);
+    hipLaunchKernelGGL(k_gru_fwd<true>, dim3(grid), dim3(WG_THREADS), shm, s, xin, gr, gz, gn, mask_rows, h0, Wih, bih,
+                       Whh, bhh, L, m_pad, y, rstd_y, hpm, r, z, n, hn, h_last, save);
+  } else {
+    const size_t shm = ((size_t)2 * 3 * GH * (GH + 1) + 2 * 3 * GH) * sizeof(float);
+    allow_big_lds(k_gru_fwd<false>, shm);
+    hipLaunchKernelGGL(k_gru_fwd<false>, dim3(grid), dim3(WG_THREADS), shm, s, xin, nullptr, nullptr, nullptr, mask_rows,
+                       h0, Wih, bih, Whh, bhh, L, m_pad, y, rstd_y, hpm, r, z, n, hn, h_last, save);
+  }
   return check_launch("harl_gru_fwd");
 }
 

@@ -261,6 +261,7 @@ class _FlatNet(nn.Module):
             self.rnn_saved = [a() for _ in range(5)]   # h~ (= h*mask), r, z, n, hn
             self.rnn_dgate = [a() for _ in range(4)]   # dr, dz, dn, dhn
             self.rnn_ones = torch.full((n_slabs * 64,), -1, dtype=u32, device=dev)  # all-ones "relu mask" for rnn.norm
+            self.rnn_gi = torch.empty(3 * mp * H, dtype=f32, device=dev)  # input half of the gates, all steps (gru.hip)
         self.n_head_blocks = _lib.load().harl_head_blocks(M)
         self.part_scalars = torch.zeros(self.n_head_blocks * PS_STRIDE, dtype=f32, device=dev)
         self.scalars = torch.zeros(PS_STRIDE, dtype=torch.float64, device=dev)
@@ -280,7 +281,7 @@ class _FlatNet(nn.Module):
         call("harl_gru_fwd", ptr(self.xh[-1]), ptr(seq["mask_rows"]), ptr(seq["h0"]), ptr(gp["Wih"]), ptr(gp["bih"]),
              ptr(gp["Whh"]), ptr(gp["bhh"]), self.hidden_sizes[-1], seq["L"], seq["m_pad"], ptr(self.rnn_y),
              ptr(self.rnn_rstd), ptr(sv[0]), ptr(sv[1]), ptr(sv[2]), ptr(sv[3]), ptr(sv[4]), ptr(seq.get("h_last")),
-             int(save), stream(), tag="gru_fwd")
+             int(save), ptr(self.rnn_gi), stream(), tag="gru_fwd")
 
     def forward_trunk(self, X: torch.Tensor, idx: Optional[torch.Tensor], M: int, for_backward: bool = True,
                       seq: Optional[dict] = None) -> None:

@@ -247,10 +247,12 @@ int harl_trpo_kl_sum(const float *head_old, const float *head_new, const float *
  * reset masks in that row order; h0 / h_last are row-major [m_pad, H].  Wih is the FOLDED input matrix (LayerNorm affine of the
  * last MLP layer folded in), gate order r, z, n.  y = normalised h (rnn.norm's affine part is folded into the head).
  * save != 0 stores h~ = h*mask, r, z, n, hn for the backward pass.
+ * gi_ws (optional, 3*L*m_pad*H floats): when given, the input half of the gates (W_i' x + b) of ALL steps is computed
+ * first by a fully parallel kernel and the recurrence only carries the W_hh products (bit-identical results).
  */
 int harl_gru_fwd(const float *xin, const float *mask_rows, const float *h0, const float *Wih, const float *bih,
                  const float *Whh, const float *bhh, int H, int L, long m_pad, float *y, float *rstd_y, float *hpm, float *r,
-                 float *z, float *n, float *hn, float *h_last, int save, void *stream);
+                 float *z, float *n, float *hn, float *h_last, int save, float *gi_ws, void *stream);
 /* dhout = d(loss)/d(h_l) through the output path (after the rnn.norm backward, done by the head kernels with an all-ones relu
  * mask).  Outputs the gate gradients dr, dz, dn (d gi = [dr,dz,dn]) and dhn (d gh = [dr,dz,dhn]) as ATL(H) for
  * harl_mlp_dw_partials, and dz_mlp = LayerNorm/ReLU backward of W_ih'^T dgi for the last MLP layer (xmlp / mask_mlp / rstd_mlp). */

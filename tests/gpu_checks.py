@@ -731,3 +731,94 @@ def check_checkpoint_compat(tmpdir: str) -> Dict[str, float]:
         out[f"{name}_shape_mismatch"] = float(any(tuple(mine[k].shape) != tuple(ref[k].shape) for k in ref))
         out[f"{name}_roundtrip_max_abs"] = float(max(float((mine[k].float() - ref[k].float()).abs().max()) for k in ref))
     return out
+
+
+def check_full_size_properties() -> Dict[str, float]:
+    """BASELINE.json configs[1] sizes (T=200, N=4096, 3 agents, obs 18 / share_obs 54 / Box 5, MLP [128,128]) -- too big for
+    the oracle as a whole (51 s per update on the CPU), so parity is checked through size-independent properties:
+      * column independence: GAE returns / advantages and per-row log-probs of randomly chosen columns / rows equal the
+        oracle run on just those columns / rows (bit-exact for the scan, 1e-5 for the fp32 MLP);
+      * linearity: the unscaled folded gradients and loss sums of the full batch equal the sum over two column halves;
+      * determinism: two full train() calls from identical state give bit-identical parameters and statistics."""
+    import copy
+    import bench
+    out = {}
+    T, N, A = bench.T, bench.N_PER_GPU, bench.A
+    r = bench.build_gpu_runner(N, 0, 1, DEV)
+    rng = np.random.default_rng(0)
+    # ---- 1. GAE scan: 48 random columns vs the oracle on those columns (bit-exact)
+    cb = r.critic_buffer
+    snap_vp = cb.value_preds.clone()
+    nv = cb.value_preds[-1].clone()
+    cb.compute_returns(nv, r.value_normalizer)
+    torch.cuda.synchronize()
+    cols = np.sort(rng.choice(N, 48, replace=False))
+    g = lambda t: t[:, cols].cpu().numpy()  # noqa: E731
+    ovn = O.OracleValueNorm()
+    st = r.value_normalizer.stats.cpu().numpy()
+    ovn.load_state(dict(running_mean=float(st[0]), running_mean_sq=float(st[1]), debiasing_term=float(st[2])))
+    ret, _ = O.compute_returns(g(cb.rewards), g(snap_vp), g(cb.masks), g(cb.bad_masks), nv[cols].cpu().numpy(), 0.99, 0.95, True,
+                               True, ovn)
+    out["gae_columns_mismatch"] = float(np.sum(ret[:T] != g(cb.returns)[:T]))
+    adv = O.advantages_from_returns(ret, g(cb.value_preds), ovn)
+    out["adv_columns_mismatch"] = float(np.sum(adv.astype(np.float32) != g(cb.advantages)))
+    # ---- 2. per-row log-probs of 4096 random rows vs the oracle on those rows
+    a0, b0 = r.actor[0], r.actor_buffer[0]
+    rows = np.sort(rng.choice(T * N, 4096, replace=False))
+    lp, _, _ = a0.evaluate_actions(b0.flat("obs"), None, b0.flat("actions"), None)
+    torch.cuda.synchronize()
+    sd = {k: v.detach().cpu() for k, v in a0.actor.state_dict().items()}
+    args = {**r.algo_args["model"], **r.algo_args["algo"]}
+    cfg = O.PathConfig.from_reference_dicts({}, args, args)
+    with torch.no_grad():
+        ref, _, _ = O.actor_evaluate_actions(sd, cfg, b0.flat("obs")[rows].cpu(), b0.flat("actions")[rows].cpu(), None, None)
+    out["logp_rows_vec_rel"] = vec_rel_err(lp[rows].cpu().numpy(), ref.numpy())
+    # ---- 3. linearity of the unscaled sums under a column split (what the data-parallel path relies on)
+    B = T * N
+    advf = cb.advantages.reshape(B).contiguous()
+    mom = torch.zeros(3, dtype=torch.float64, device=DEV)
+    a0.masked_moments(b0, advf, mom)
+    factor = torch.ones(B, device=DEV)
+    a0.actor.fold()
+    full_idx = None
+    def fb(idx, m):
+        nb = a0._forward_backward(b0.flat("obs"), idx, m, b0.flat("actions"), None, b0.flat("action_log_probs"), advf, mom,
+                                  factor, b0.flat("active_masks").reshape(B))
+        sc = torch.zeros(48, dtype=torch.float64, device=DEV)
+        from harl_amd._lib import call, ptr, stream
+        call("harl_reduce_scalars", ptr(a0.actor.part_scalars), nb, ptr(sc), stream())
+        return a0.actor.dwp.clone(), sc
+    gfull, sfull = fb(full_idx, B)
+    allrows = torch.arange(B, device=DEV)
+    left = allrows[(allrows % N) < N // 2].contiguous()
+    right = allrows[(allrows % N) >= N // 2].contiguous()
+    gl, sl = fb(left, left.numel())
+    gr, sr = fb(right, right.numel())
+    torch.cuda.synchronize()
+    out["grad_split_sum_vec_rel"] = vec_rel_err((gl + gr).cpu().numpy(), gfull.cpu().numpy())
+    out["scalars_split_sum_rel"] = rel_err((sl + sr)[:5].cpu().numpy(), sfull[:5].cpu().numpy())
+    # ---- 4. determinism of a whole train() at full size
+    def snapshot():
+        return ([a.actor.flat_param.clone() for a in r.actor], r.critic.critic.flat_param.clone(),
+                [(a.actor_optimizer.exp_avg.clone(), a.actor_optimizer.exp_avg_sq.clone(), a.actor_optimizer.step_count) for a in r.actor],
+                (r.critic.critic_optimizer.exp_avg.clone(), r.critic.critic_optimizer.exp_avg_sq.clone(), r.critic.critic_optimizer.step_count),
+                r.value_normalizer.stats.clone(), torch.get_rng_state())
+    def restore(s):
+        for a, p, o in zip(r.actor, s[0], s[2]):
+            a.actor.flat_param.copy_(p); a.actor_optimizer.exp_avg.copy_(o[0]); a.actor_optimizer.exp_avg_sq.copy_(o[1])
+            a.actor_optimizer.step_count = o[2]
+        r.critic.critic.flat_param.copy_(s[1])
+        r.critic.critic_optimizer.exp_avg.copy_(s[3][0]); r.critic.critic_optimizer.exp_avg_sq.copy_(s[3][1])
+        r.critic.critic_optimizer.step_count = s[3][2]
+        r.value_normalizer.stats.copy_(s[4]); torch.set_rng_state(s[5])
+    s0 = snapshot()
+    i1, c1 = r.train()
+    p1 = [a.actor.flat_param.clone() for a in r.actor] + [r.critic.critic.flat_param.clone()]
+    restore(s0)
+    i2, c2 = r.train()
+    p2 = [a.actor.flat_param.clone() for a in r.actor] + [r.critic.critic.flat_param.clone()]
+    torch.cuda.synchronize()
+    out["determinism_param_mismatch"] = float(sum(int((x != y).sum().item()) for x, y in zip(p1, p2)))
+    out["determinism_info_mismatch"] = float(i1 != i2 or c1 != c2)
+    out["train_nonfinite_count"] = float(not all(np.isfinite(list(i.values())).all() for i in i1))
+    return out

@@ -135,3 +135,14 @@ def test_checkpoint_compat_with_reference_files(tmp_path):
             assert v == 0.0, (k, v)   # parameters are copied, not recomputed
         else:
             assert v < TOL, (k, v)
+
+
+def test_full_size_properties_baseline_config():
+    """BASELINE configs[1] sizes (819 200 transitions x 3 agents): column independence vs the oracle, linearity of the
+    unscaled sums under a column split, bit-exact determinism of train()."""
+    res = _G().check_full_size_properties()
+    for k, v in res.items():
+        if "mismatch" in k or "count" in k:
+            assert v == 0.0, (k, v)
+        else:
+            assert v < TOL, (k, v)

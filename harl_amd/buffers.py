@@ -309,6 +309,30 @@ class OnPolicyActorBuffer:
             yield tuple(out)
 
 
+    def _recurrent_api_generator(self, advantages, num_mini_batch, data_chunk_length, naive):
+        T, N = self.actions.shape[:2]
+        B = T * N
+        adv = None if advantages is None else _as_dev(advantages, self.device).reshape(B, 1)
+        for first, L in recurrent_first_rows(T, N, num_mini_batch, data_chunk_length, naive):
+            first = first.to(self.device)
+            rows = (first[None, :] + torch.arange(L, device=self.device)[:, None] * N).reshape(-1)  # l-major, like _flatten
+            f = lambda name: self.flat(name)[rows]  # noqa: E731
+            out = [f("obs"), self.rnn_states.reshape((T + 1) * N, self.recurrent_n, -1)[first], f("actions"), f("masks"),
+                   f("active_masks"), f("action_log_probs"), None if adv is None else adv[rows],
+                   None if self.available_actions is None else f("available_actions")]
+            if self.factor is not None:
+                out.append(self.factor.reshape(B, -1)[rows])
+            yield tuple(out)
+
+    def naive_recurrent_generator_actor(self, advantages, actor_num_mini_batch):
+        """API-compatible generator (actor_buffer.py:180-221): whole columns, full-length sequences, rnn_states[0]."""
+        return self._recurrent_api_generator(advantages, actor_num_mini_batch, 0, True)
+
+    def recurrent_generator_actor(self, advantages, actor_num_mini_batch, data_chunk_length):
+        """API-compatible generator (actor_buffer.py:223-326): chunks of ``data_chunk_length`` steps, rows l-major."""
+        return self._recurrent_api_generator(advantages, actor_num_mini_batch, data_chunk_length, False)
+
+
 class OnPolicyCriticBufferEP:
     def __init__(self, args: dict, share_obs_space, device=torch.device("cuda:0")):
         self.device = torch.device(device)
@@ -385,6 +409,24 @@ class OnPolicyCriticBufferEP:
         for first, L in recurrent_first_rows(T, ncol, num_mini_batch, data_chunk_length, naive):
             yield build_seq(self.device, L, first.numel(), H, first_rows=first, stride=ncol,
                             h0_src=self.rnn_states_critic.reshape((T + 1) * ncol, -1), masks_src=self.masks.reshape(-1))
+
+    def _recurrent_api_generator(self, num_mini_batch, data_chunk_length, naive):
+        T, N = self.rewards.shape[:2]
+        ncol = N * (getattr(self, "num_agents", None) or 1)
+        for first, L in recurrent_first_rows(T, ncol, num_mini_batch, data_chunk_length, naive):
+            first = first.to(self.device)
+            rows = (first[None, :] + torch.arange(L, device=self.device)[:, None] * ncol).reshape(-1)
+            f = lambda name: self.flat(name)[rows]  # noqa: E731
+            yield (f("share_obs"), self.rnn_states_critic.reshape((T + 1) * ncol, self.recurrent_n, -1)[first],
+                   f("value_preds"), f("returns"), f("masks"))
+
+    def naive_recurrent_generator_critic(self, critic_num_mini_batch):
+        """API-compatible generator (critic_buffer_ep.py:252-283, critic_buffer_fp.py:262-304)."""
+        return self._recurrent_api_generator(critic_num_mini_batch, 0, True)
+
+    def recurrent_generator_critic(self, critic_num_mini_batch, data_chunk_length):
+        """API-compatible generator (critic_buffer_ep.py:285-369, critic_buffer_fp.py:306-390)."""
+        return self._recurrent_api_generator(critic_num_mini_batch, data_chunk_length, False)
 
     def feed_forward_generator_critic(self, critic_num_mini_batch=None, mini_batch_size=None):
         """API-compatible generator (critic_buffer_ep.py:202-250); ``VCritic.train`` uses index arrays instead."""

@@ -822,3 +822,69 @@ def check_full_size_properties() -> Dict[str, float]:
     out["determinism_info_mismatch"] = float(i1 != i2 or c1 != c2)
     out["train_nonfinite_count"] = float(not all(np.isfinite(list(i.values())).all() for i in i1))
     return out
+
+
+def check_generator_api(name: str) -> Dict[str, float]:
+    """The buffers' public generators (feed-forward / naive / chunked recurrent, actor and critic) yield, for the
+    reference's recorded permutations, exactly the rows the oracle's generators yield (bit-exact gathers)."""
+    case = GoldenCase(name)
+    out = {}
+    r = build_runner(case)
+    train, model, algo = case.reference_dicts()
+    T, N = case.shapes.T, case.shapes.N
+    d = case.data
+    ob = O.OracleActorBuffer(d.obs[0].copy(), d.actions[0].copy(), d.action_log_probs[0].copy(), d.masks[0].copy(),
+                             d.active_masks[0].copy(),
+                             None if d.available_actions[0] is None else d.available_actions[0].copy(),
+                             rnn_states=None if d.rnn is None else d.rnn["actor"][0].copy())
+    adv = np.random.default_rng(1).standard_normal((T, N, 1)).astype(np.float32)
+    fac = (1 + 0.1 * np.random.default_rng(2).standard_normal((T, N, 1))).astype(np.float32)
+    ob.update_factor(fac)
+    buf = r.actor_buffer[0]
+    buf.update_factor(fac)
+    k, L = 2, model["data_chunk_length"]
+    def run(gen_o, gen_p, order):
+        bad = 0
+        torch.manual_seed(77)
+        want = [s for s, _ in gen_o()]
+        torch.manual_seed(77)
+        got = list(gen_p())
+        bad += int(len(want) != len(got))
+        for w, g in zip(want, got):
+            for wi, gi in order:
+                a, b = w[wi], g[gi]
+                if a is None or b is None:
+                    bad += int((a is None) != (b is None))
+                else:
+                    bad += int(not np.array_equal(np.asarray(a).reshape(-1), b.cpu().numpy().reshape(-1)))
+        return float(bad)
+    # oracle tuple: (obs, actions, active, logp, adv, avail, factor[, rnn, masks]) ; product: reference order
+    ff = [(0, 0), (1, 2), (2, 4), (3, 5), (4, 6), (5, 7), (6, 8)]
+    out["ff_actor_mismatch"] = run(lambda: ob.feed_forward_generator(adv, k), lambda: buf.feed_forward_generator_actor(adv, k), ff)
+    if case.recurrent:
+        rec = ff + [(7, 1), (8, 3)]
+        out["chunk_actor_mismatch"] = run(lambda: ob.recurrent_generator(adv, k, L),
+                                          lambda: buf.recurrent_generator_actor(adv, k, L), rec)
+        out["naive_actor_mismatch"] = run(lambda: ob.naive_recurrent_generator(adv, k),
+                                          lambda: buf.naive_recurrent_generator_actor(adv, k), rec)
+    # critic
+    cb = r.critic_buffer
+    cb.compute_returns(cb.value_preds[-1].clone(), r.value_normalizer)
+    torch.cuda.synchronize()
+    if case.state_type == "FP":
+        f = d.fp
+        oc = O.OracleCriticBufferFP(f["share_obs"].copy(), f["rewards"].copy(), cb.value_preds.cpu().numpy(), f["masks"].copy(),
+                                    f["bad_masks"].copy())
+    else:
+        oc = O.OracleCriticBufferEP(d.share_obs.copy(), d.rewards.copy(), cb.value_preds.cpu().numpy(), d.critic_masks.copy(),
+                                    d.bad_masks.copy())
+    oc.returns = cb.returns.cpu().numpy()
+    if d.rnn is not None:
+        oc.rnn_states_critic = d.rnn["critic_fp" if case.state_type == "FP" else "critic"].copy()
+    cff = [(0, 0), (1, 2), (2, 3)]  # oracle (share_obs, value_preds, returns[, rnn, masks]); product reference order
+    out["ff_critic_mismatch"] = run(lambda: oc.feed_forward_generator(k), lambda: cb.feed_forward_generator_critic(k), cff)
+    if case.recurrent:
+        crec = cff + [(3, 1), (4, 4)]
+        out["chunk_critic_mismatch"] = run(lambda: oc.recurrent_generator(k, L), lambda: cb.recurrent_generator_critic(k, L), crec)
+        out["naive_critic_mismatch"] = run(lambda: oc.naive_recurrent_generator(k), lambda: cb.naive_recurrent_generator_critic(k), crec)
+    return out

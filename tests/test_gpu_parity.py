@@ -146,3 +146,10 @@ def test_full_size_properties_baseline_config():
             assert v == 0.0, (k, v)
         else:
             assert v < TOL, (k, v)
+
+
+@pytest.mark.parametrize("name", ["mpe_disc_h64", "rnn_box_h64", "rnn_fp_box_h64_mb2"])
+def test_buffer_generator_api_matches_reference_order(name):
+    """Public *_generator_* methods of the buffers: same permutation draws, same gathered rows, reference tuple order."""
+    for k, v in _G().check_generator_api(name).items():
+        assert v == 0.0, (k, v)

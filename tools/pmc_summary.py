@@ -2,9 +2,10 @@
 """Summarise `rocprofv3 --pmc ... --kernel-trace --output-format csv` counter_collection CSVs per kernel (markdown).
 
     python tools/pmc_summary.py gpurun_out/pmc/*_counter_collection.csv [name-filter ...]
-Derived columns (when the counters are present): clock = GRBM_GUI_ACTIVE / duration; MFMA pipe busy =
-SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 XCDs * 1024 SIMDs); wave-time split = SQ_WAIT_INST_ANY (s_waitcnt),
-SQ_ACTIVE_INST_ANY (issuing), rest of SQ_WAVE_CYCLES (issue stalls); avg waves/SIMD = SQ_WAVE_CYCLES / SQ_BUSY_CYCLES.
+Derived columns (when the counters are present): clock = GRBM_GUI_ACTIVE/8 XCDs / duration; MFMA pipe busy =
+SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 1024 SIMDs); wave-time split: SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES (wave has
+an instruction ready but cannot issue it: pipe busy or arbitration lost), SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES (issuing), the
+rest (waiting on s_waitcnt / barriers / nothing to issue); VALU+MFMA instructions per launch.
 """
 import csv
 import glob
@@ -26,8 +27,8 @@ def main():
             dur[k][r["Dispatch_Id"]] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
     names = sorted({c for k in per for c in per[k]})
     print("counters:", " ".join(names), "\n")
-    print("| kernel | n | avg us | clock GHz | MFMA busy | s_waitcnt | issue stall | issuing | waves/SIMD | VALU insts/wave-cycle |")
-    print("|---|---|---|---|---|---|---|---|---|---|")
+    print("| kernel | n | avg us | clock GHz | MFMA pipe busy | waves: blocked at issue | waves: waiting (waitcnt etc.) | waves: issuing | VALU+MFMA insts per launch |")
+    print("|---|---|---|---|---|---|---|---|---|")
     for k in sorted(per, key=lambda k: -sum(dur[k].values())):
         c = {n: sum(v) / len(v) for n, v in per[k].items()}
         n = len(dur[k])
@@ -43,12 +44,9 @@ def main():
         stall = None if (wait is None or act is None) else 1 - wait - act
         occ = wc / c["SQ_BUSY_CYCLES"] / 4 if (wc and c.get("SQ_BUSY_CYCLES")) else None
         valu = c.get("SQ_INSTS_VALU") / wc if (wc and "SQ_INSTS_VALU" in c) else None
+        iv = c.get("SQ_INSTS_VALU")
         print(f"| `{k[:48]}` | {n} | {us:.1f} | {'-' if clock is None else f'{clock:.2f}'} | {f(busy)} | {f(wait)} | "
-              f"{f(stall)} | {f(act)} | {'-' if occ is None else f'{occ:.2f}'} | {'-' if valu is None else f'{valu:.3f}'} |")
-        extra = {n_: v for n_, v in c.items() if n_ not in ("GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES", "SQ_VALU_MFMA_BUSY_CYCLES",
-                                                             "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_BUSY_CYCLES")}
-        if extra:
-            print("|   | | | | | | | | | " + ", ".join(f"{a}={b:.4g}" for a, b in sorted(extra.items())) + " |")
+              f"{f(stall)} | {f(act)} | {'-' if iv is None else f'{iv:.4g}'} |")
 
 
 if __name__ == "__main__":

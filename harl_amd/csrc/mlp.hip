@@ -149,12 +149,21 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_fwd_hidden(const float *__res
 #pragma unroll
     for (int u = 0; u < RD; ++u) ringA[u] = p0[u * WAVE];
   }
+  // one LDS base address per output tile, opaque to the compiler: every fragment read is then base_t + a small
+  // immediate (ds_read2_b32 offsets reach 1020 B).  With the tile offsets visible as constants hipcc keeps ONE base
+  // and re-adds 16-48 KiB literals in front of most reads (~150 v_add_u32 per slab, and VALU is not free here).
+  int toff[NT_];
+#pragma unroll
+  for (int t = 0; t < NT_; ++t) {
+    toff[t] = 32 * t * LDW;
+    asm volatile("" : "+v"(toff[t]));
+  }
   auto lds_frag = [&](int q, float (&a)[4 * NT_]) {  // weight fragments of q-step q: W'[32t+i][f(4q+c, h)]
-    const float *wq = wl_lane + 32 * (q >> 2) + 8 * (q & 3);
+    const int qo_ = 32 * (q >> 2) + 8 * (q & 3);
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
-      for (int t = 0; t < NT_; ++t) a[c * NT_ + t] = wq[32 * t * LDW + c];
+      for (int t = 0; t < NT_; ++t) a[c * NT_ + t] = wl_lane[toff[t] + qo_ + c];
   };
   lds_frag(0, aX);
   for (long slab = slab0; slab < n_slabs; slab += slab_stride) {
@@ -569,12 +578,18 @@ __global__ __launch_bounds__(64 * FUSED_WAVES, 2) void k_fwd_fused2(
 #pragma unroll
     for (int u = 0; u < NPF; ++u) pf[u] = X[(long)rows[u] * ldx + lane_kc];
   };
+  int toff[NT_];  // opaque per-tile LDS offsets: fragment reads become base_t + small immediate (see k_fwd_hidden)
+#pragma unroll
+  for (int t = 0; t < NT_; ++t) {
+    toff[t] = 32 * t * LDW;
+    asm volatile("" : "+v"(toff[t]));
+  }
   auto lds_frag = [&](int q, float (&a)[4 * NT_]) {
-    const float *wq = wl_lane + 32 * (q >> 2) + 8 * (q & 3);
+    const int qo_ = 32 * (q >> 2) + 8 * (q & 3);
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
-      for (int t = 0; t < NT_; ++t) a[c * NT_ + t] = wq[32 * t * LDW + c];
+      for (int t = 0; t < NT_; ++t) a[c * NT_ + t] = wl_lane[toff[t] + qo_ + c];
   };
   if (slab0 < n_slabs) prefetch_rows(slab0);
 
@@ -697,13 +712,13 @@ __global__ __launch_bounds__(64 * FUSED_WAVES, 2) void k_fwd_fused2(
     lds_frag(0, aX);
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-      const float *wn = wl_lane + 32 * ((q + 1) >> 2) + 8 * ((q + 1) & 3);
+      const int qn_ = 32 * ((q + 1) >> 2) + 8 * ((q + 1) & 3);
 #pragma unroll
       for (int c = 0; c < 4; ++c)
 #pragma unroll
         for (int t = 0; t < NT_; ++t) {
           acc[t] = MFMA(aX[c * NT_ + t], x1[4 * q + c], acc[t]);
-          if (q + 1 < NQ) aX[c * NT_ + t] = wn[32 * t * LDW + c];
+          if (q + 1 < NQ) aX[c * NT_ + t] = wl_lane[toff[t] + qn_ + c];
         }
     }
     relu_norm_store<H>(acc, lane, slab, x2out, mask2, rstd2);

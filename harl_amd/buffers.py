@@ -216,6 +216,31 @@ def recurrent_first_rows(T: int, N: int, num_mini_batch: int, data_chunk_length:
         yield (start % T) * N + start // T, L
 
 
+def _recurrent_seqs(device, T: int, n_local: int, agents: int, H: int, num_mini_batch: int, data_chunk_length: int,
+                    naive: bool, shard, h0_src: torch.Tensor, masks_src: torch.Tensor):
+    """Shared body of the buffers' ``recurrent_batches``: draws the reference's sequence starts over the GLOBAL column
+    count (identical on every rank), keeps the sequences whose rollout thread lives on this rank and re-indexes them to
+    the local buffers.  Yields nets.build_seq dicts with ``m_global`` (sequences in the global minibatch) added, or
+    ``dict(empty=True, ...)`` when none of them is local."""
+    from .nets import build_seq
+    n_global, lo, hi = shard if shard else (n_local, 0, n_local)
+    ncol_g, ncol_l = n_global * agents, n_local * agents
+    for first, L in recurrent_first_rows(T, ncol_g, num_mini_batch, data_chunk_length, naive):
+        m_global = first.numel()
+        if shard:
+            t0 = torch.div(first, ncol_g, rounding_mode="floor")
+            c = first - t0 * ncol_g
+            n = torch.div(c, agents, rounding_mode="floor")
+            keep = (n >= lo) & (n < hi)
+            first = t0[keep] * ncol_l + (n[keep] - lo) * agents + (c[keep] - n[keep] * agents)
+        if first.numel() == 0:
+            yield dict(empty=True, L=L, m=0, m_global=m_global)
+            continue
+        seq = build_seq(device, L, first.numel(), H, first_rows=first, stride=ncol_l, h0_src=h0_src, masks_src=masks_src)
+        seq["m_global"] = m_global
+        yield seq
+
+
 class OnPolicyActorBuffer:
     def __init__(self, args: dict, obs_space, act_space, device=torch.device("cuda:0")):
         self.device = torch.device(device)
@@ -276,15 +301,11 @@ class OnPolicyActorBuffer:
 
     def recurrent_batches(self, num_mini_batch: int, data_chunk_length: int, naive: bool = False, shard=None):
         """GRU-layout minibatches (nets.build_seq) for the chunked / naive recurrent samplers: only the m sequence
-        starts travel to the device; the kernels gather rows first + l*N in place."""
-        from .nets import build_seq
-        if shard:
-            raise NotImplementedError("recurrent samplers with sharded n_rollout_threads")
+        starts travel to the device; the kernels gather rows first + l*N in place.  ``shard`` = (n_global, lo, hi):
+        the GLOBAL sampler is drawn and filtered to this rank's rollout threads."""
         T, N = self.actions.shape[:2]
-        H = self.rnn_hidden_size
-        for first, L in recurrent_first_rows(T, N, num_mini_batch, data_chunk_length, naive):
-            yield build_seq(self.device, L, first.numel(), H, first_rows=first, stride=N,
-                            h0_src=self.rnn_states.reshape((T + 1) * N, -1), masks_src=self.masks.reshape(-1))
+        return _recurrent_seqs(self.device, T, N, 1, self.rnn_hidden_size, num_mini_batch, data_chunk_length, naive, shard,
+                               self.rnn_states.reshape((T + 1) * N, -1), self.masks.reshape(-1))
 
     def feed_forward_generator_actor(self, advantages, actor_num_mini_batch=None, mini_batch_size=None):
         """API-compatible generator (actor_buffer.py:114-178): yields gathered device tensors in the reference's
@@ -400,15 +421,10 @@ class OnPolicyCriticBufferEP:
         """See OnPolicyActorBuffer.recurrent_batches (critic_buffer_ep.py:252-369).  FP buffers
         (critic_buffer_fp.py:262-390): the same samplers over N*A columns -- ``_ma_cast`` orders (thread, agent) pairs
         as column c = n*A + a, which is exactly the row order of the [T, N, A, .] flattening used here."""
-        from .nets import build_seq
-        if shard:
-            raise NotImplementedError("recurrent samplers with sharded n_rollout_threads")
         T, N = self.rewards.shape[:2]
-        ncol = N * (getattr(self, "num_agents", None) or 1)
-        H = self.rnn_hidden_size
-        for first, L in recurrent_first_rows(T, ncol, num_mini_batch, data_chunk_length, naive):
-            yield build_seq(self.device, L, first.numel(), H, first_rows=first, stride=ncol,
-                            h0_src=self.rnn_states_critic.reshape((T + 1) * ncol, -1), masks_src=self.masks.reshape(-1))
+        agents = getattr(self, "num_agents", None) or 1
+        return _recurrent_seqs(self.device, T, N, agents, self.rnn_hidden_size, num_mini_batch, data_chunk_length, naive,
+                               shard, self.rnn_states_critic.reshape((T + 1) * N * agents, -1), self.masks.reshape(-1))
 
     def _recurrent_api_generator(self, num_mini_batch, data_chunk_length, naive):
         T, N = self.rewards.shape[:2]

@@ -64,14 +64,18 @@ def shard_columns(n_rollout_threads: int, rank: int, world_size: int) -> Tuple[i
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def local_minibatch_rows(global_idx: torch.Tensor, n_global: int, lo: int, hi: int) -> torch.Tensor:
+def local_minibatch_rows(global_idx: torch.Tensor, n_global: int, lo: int, hi: int, agents: int = 1) -> torch.Tensor:
     """Rows of a GLOBAL minibatch permutation (row = t*N + n over the unsharded buffer, identical on every rank
     and bit-identical to the reference's draw) that fall into this rank's column range, re-indexed to the
-    local [T, hi-lo] buffer.  Order within the minibatch is preserved."""
-    t = torch.div(global_idx, n_global, rounding_mode="floor")
-    n = global_idx - t * n_global
+    local [T, hi-lo] buffer.  Order within the minibatch is preserved.  ``agents`` > 1: FP critic buffers, whose rows
+    are (t*N + n)*A + a."""
+    ncol = n_global * agents
+    t = torch.div(global_idx, ncol, rounding_mode="floor")
+    c = global_idx - t * ncol
+    n = torch.div(c, agents, rounding_mode="floor") if agents > 1 else c
     keep = (n >= lo) & (n < hi)
-    return t[keep] * (hi - lo) + (n[keep] - lo)
+    a = c[keep] - n[keep] * agents if agents > 1 else 0
+    return (t[keep] * (hi - lo) + (n[keep] - lo)) * agents + a
 
 
 def init_from_env(backend: Optional[str] = None) -> Comm:

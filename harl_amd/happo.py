@@ -181,7 +181,12 @@ class HAPPO(OnPolicyBase):
         """[data-parallel all-reduce] + fused scalar reduce / unfold / grad-norm / clip / Adam / re-fold.  ``nblk`` None:
         ``net.scalars`` already holds the summed loss scalars (several minibatch segments were accumulated)."""
         net = self.actor
+        net._ensure_ws(1)
         sc = net.scalars
+        if nblk == 0:  # this rank holds no row of the (global) minibatch: contribute zeros to the all-reduce
+            net.dwp.zero_()
+            sc.zero_()
+            nblk = None
         ps_kw = dict(part_scalars=net.part_scalars, n_scalar_blocks=nblk) if nblk is not None else {}
         if self.comm.enabled:  # ONE collective per optimiser step: [folded gradients | loss scalars] (dist.py)
             if nblk is not None:
@@ -285,6 +290,9 @@ class HAPPO(OnPolicyBase):
             if self.use_recurrent_policy or self.use_naive_recurrent_policy:
                 for seq in buf.recurrent_batches(self.actor_num_mini_batch, self.data_chunk_length,
                                                  naive=not self.use_recurrent_policy, shard=self.shard):
+                    if seq.get("empty"):
+                        self._optimizer_step(0)
+                        continue
                     self._update_core(obs, seq["idx"], seq["L"] * seq["m_pad"], actions, avail, old_logp, adv, moments,
                                       factor, active if self.use_policy_active_masks else None, seq=seq)
                 continue
@@ -300,6 +308,9 @@ class HAPPO(OnPolicyBase):
             for ind in sampler:
                 if self.shard:
                     ind = local_minibatch_rows(ind, self.shard[0], self.shard[1], self.shard[2])
+                    if ind.numel() == 0:
+                        self._optimizer_step(0)
+                        continue
                 self._update_core(obs, ind.to(dev), ind.numel(), actions, avail, old_logp, adv, moments, factor,
                                   active if self.use_policy_active_masks else None)
         n_upd = self.ppo_epoch * self.actor_num_mini_batch

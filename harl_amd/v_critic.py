@@ -77,26 +77,34 @@ class VCritic:
         return out, seq["h_last"][:m].reshape(m, 1, H).clone()
 
     def _update_core(self, share_obs, idx, m, m_global, value_preds, returns, vn: Optional[ValueNorm], seq=None):
+        """One optimiser step on rows idx[0..m) (m = 0: this rank holds none of the global minibatch's m_global rows and
+        only takes part in the collectives)."""
         net = self.critic
         s = stream()
         if vn is not None:  # ValueNorm.update runs on this minibatch's returns BEFORE the targets are normalised
             vidx = seq["valid_idx"] if seq is not None else idx
-            vn.update(returns, vidx, count=m_global, reduce_fn=self.comm.all_reduce_sum if self.comm.enabled else None)
-        net.forward_trunk(share_obs, idx, m, seq=seq)
-        Wp, bp = net._packs[-1]
-        fx, fmask, frstd, fh = net.feat()
-        mv, mp = (seq["m"], seq["m_pad"]) if seq is not None else (0, 0)
-        call("harl_critic_head_loss", ptr(fx), ptr(fmask), ptr(frstd), m, fh,
-             ptr(Wp), ptr(bp), ptr(idx), ptr(value_preds), ptr(returns), ptr(vn.stats) if vn is not None else None,
-             float(self.clip_param), int(self.use_clipped_value_loss), int(self.use_huber_loss), float(self.huber_delta),
-             mv, mp, ptr(net.dz[0]), ptr(net.dhead), ptr(net.part_scalars), s, tag="critic_head_loss")
-        net.backward_trunk(share_obs, idx, m, seq=seq)
+            vn.update(returns, vidx, count=m_global, reduce_fn=self.comm.all_reduce_sum if self.comm.enabled else None,
+                      local_count=(seq["L"] * seq["m"] if seq is not None else m))
+        net._ensure_ws(max(m, 1))
         sc = net.scalars
-        nblk = _lib.load().harl_head_blocks(m)
+        if m > 0:
+            net.forward_trunk(share_obs, idx, m, seq=seq)
+            Wp, bp = net._packs[-1]
+            fx, fmask, frstd, fh = net.feat()
+            mv, mp = (seq["m"], seq["m_pad"]) if seq is not None else (0, 0)
+            call("harl_critic_head_loss", ptr(fx), ptr(fmask), ptr(frstd), m, fh,
+                 ptr(Wp), ptr(bp), ptr(idx), ptr(value_preds), ptr(returns), ptr(vn.stats) if vn is not None else None,
+                 float(self.clip_param), int(self.use_clipped_value_loss), int(self.use_huber_loss), float(self.huber_delta),
+                 mv, mp, ptr(net.dz[0]), ptr(net.dhead), ptr(net.part_scalars), s, tag="critic_head_loss")
+            net.backward_trunk(share_obs, idx, m, seq=seq)
+        nblk = _lib.load().harl_head_blocks(m) if m > 0 else 0
         ps_kw = dict(part_scalars=net.part_scalars, n_scalar_blocks=nblk)  # reduced inside the optimiser launch
         if self.comm.enabled:  # ONE collective per optimiser step: [folded gradients | loss scalars] (dist.py)
             sc.zero_()
-            call("harl_reduce_scalars", ptr(net.part_scalars), nblk, ptr(sc), s)
+            if m > 0:
+                call("harl_reduce_scalars", ptr(net.part_scalars), nblk, ptr(sc), s)
+            else:
+                net.dwp.zero_()
             hilo = net.dwp_msg[net.total_dwp:]
             call("harl_pack_scalars_hilo", ptr(sc), ptr(hilo), s)
             self.comm.all_reduce_message(net.dwp_msg)
@@ -146,8 +154,12 @@ class VCritic:
             if self.use_recurrent_policy or self.use_naive_recurrent_policy:
                 for seq in buf.recurrent_batches(self.critic_num_mini_batch, self.data_chunk_length,
                                                  naive=not self.use_recurrent_policy, shard=self.shard):
-                    self._update_core(share_obs, seq["idx"], seq["L"] * seq["m_pad"], seq["L"] * seq["m"], value_preds,
-                                      returns, value_normalizer, seq=seq)
+                    if seq.get("empty"):
+                        self._update_core(share_obs, None, 0, seq["L"] * seq["m_global"], value_preds, returns,
+                                          value_normalizer)
+                        continue
+                    self._update_core(share_obs, seq["idx"], seq["L"] * seq["m_pad"], seq["L"] * seq["m_global"],
+                                      value_preds, returns, value_normalizer, seq=seq)
                 continue
             if self.critic_num_mini_batch == 1:
                 consume_randperm(n_global)  # replay the generator state only (see HAPPO.train)
@@ -157,9 +169,7 @@ class VCritic:
             for ind in sampler:
                 m_global = ind.numel()
                 if self.shard:
-                    if A:
-                        raise NotImplementedError("sharded FP critic with more than one mini-batch")
-                    ind = local_minibatch_rows(ind, self.shard[0], self.shard[1], self.shard[2])
+                    ind = local_minibatch_rows(ind, self.shard[0], self.shard[1], self.shard[2], agents=A or 1)
                 self._update_core(share_obs, ind.to(dev), ind.numel(), m_global, value_preds, returns, value_normalizer)
         n_upd = self.critic_epoch * self.critic_num_mini_batch
         if _defer:

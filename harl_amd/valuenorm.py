@@ -47,13 +47,18 @@ class ValueNorm:
         return mean, var
 
     @torch.no_grad()
-    def update(self, input_vector, idx: Optional[torch.Tensor] = None, count: Optional[int] = None, reduce_fn=None):
+    def update(self, input_vector, idx: Optional[torch.Tensor] = None, count: Optional[int] = None, reduce_fn=None,
+               local_count: Optional[int] = None):
         """EMA update from a minibatch of returns (valuenorm.py:47-64).  ``reduce_fn`` (data-parallel
-        all-reduce of the fp64 {sum, sumsq}) and the global ``count`` are supplied by the sharded critic."""
+        all-reduce of the fp64 {sum, sumsq}) and the global ``count`` are supplied by the sharded critic;
+        ``local_count`` = number of local rows when it is not idx.numel() / x.numel() (0: this rank only reduces)."""
         x = _as_dev(input_vector, self.device).reshape(-1)
         m = x.numel() if idx is None else idx.numel()
+        if local_count is not None and idx is None:
+            m = local_count
         self._sums.zero_()
-        call("harl_sum_sumsq", ptr(x), ptr(idx), m, ptr(self._sums), stream())
+        if m > 0:
+            call("harl_sum_sumsq", ptr(x), ptr(idx), m, ptr(self._sums), stream())
         if reduce_fn is not None:
             reduce_fn(self._sums)
         call("harl_valuenorm_apply", ptr(self.stats), ptr(self._sums), float(count if count is not None else m),

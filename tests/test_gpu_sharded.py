@@ -53,6 +53,10 @@ def _worker(rank, world, port, name, q):
             b.active_masks.copy_(G.dev(cut(d.active_masks[a])))
             if sh.discrete:
                 b.available_actions.copy_(G.dev(cut(d.available_actions[a])))
+            if d.rnn is not None:
+                b.rnn_states.copy_(G.dev(cut(d.rnn["actor"][a])))
+        if d.rnn is not None:
+            r.critic_buffer.rnn_states_critic.copy_(G.dev(cut(d.rnn["critic"])))
         r.critic.critic.load_state_dict({k: torch.from_numpy(v) for k, v in case.critic_sd.items()})
         cb = r.critic_buffer
         for nm, arr in (("share_obs", d.share_obs), ("rewards", d.rewards), ("value_preds", d.value_preds),
@@ -86,7 +90,7 @@ def _worker(rank, world, port, name, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name", ["mpe_box_h128", "cheetah_h128x3_mb2"])
+@pytest.mark.parametrize("name", ["mpe_box_h128", "cheetah_h128x3_mb2", "rnn_disc_h64_mb2", "rnn_naive_h64"])
 def test_two_rank_sharded_train_matches_unsharded_golden(name):
     import torch.multiprocessing as mp
 
@@ -96,7 +100,7 @@ def test_two_rank_sharded_train_matches_unsharded_golden(name):
     procs = [ctx.Process(target=_worker, args=(r, world, port, name, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=300) for _ in range(world)]
+    res = [q.get(timeout=90) for _ in range(world)]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0

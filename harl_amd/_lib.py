@@ -46,10 +46,10 @@ SIGNATURES = {
     "harl_randperm_replay": [_vp, _l, _l, _vp, _vp, _vp],
     "harl_actor_head_logp": [_vp, _l, _i, _vp, _vp, _vp, _f, _f, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _l, _l, _vp],
     "harl_actor_head_loss": [_vp, _vp, _vp, _l, _i, _vp, _vp, _vp, _f, _f, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,
-                             _vp, _vp, _f, _f, _i, _i, _l, _l, _vp, _vp, _vp, _vp, _vp],
+                             _vp, _vp, _f, _f, _i, _i, _l, _l, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "harl_critic_head_values": [_vp, _l, _i, _vp, _vp, _vp, _vp],
     "harl_critic_head_loss": [_vp, _vp, _vp, _l, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _f, _l, _l, _vp, _vp, _vp,
-                              _vp],
+                              _vp, _i, _vp],
     "harl_gru_fwd": [_vp] * 7 + [_i, _i, _l] + [_vp] * 8 + [_i, _vp, _vp],
     "harl_gru_bwd": [_vp] * 9 + [_i, _i, _l] + [_vp] * 8 + [_vp],
     "harl_fold_linear_tangent": [_vp] * 9 + [_i, _i, _vp],

@@ -39,6 +39,7 @@ struct ActorArgs {
   float clip_param, entropy_coef;
   int agg_mean;
   float *dzL, *dhead, *part_scalars;
+  float *dw_part;   // fused head weight gradient: per-workgroup partials [gridDim.x][32*H + 32] (NULL: write dhead instead)
   float *logp_out, *factor_out;
   float *head_out;  // [M, act_dim]: Gaussian mean / normalised Categorical logits (rollout sampling, HATRPO KL)
   long m_valid, m_pad;  // recurrent batches: row j counts only if (j % m_pad) < m_valid   (m_pad = 0: every j < M)
@@ -202,6 +203,83 @@ __device__ __forceinline__ void head_bwd_regs(const f32x4 (&xs)[H / 8], const ui
   }
 }
 
+// ---- head weight gradient fused into the loss kernels:  dW_head'[d][f] += sum_s dhead[s][d] x_hat_L[s][f].
+// The loss kernel already holds x_hat_L (registers, lane = sample) and dhead; the reduction runs over samples, so both
+// operands go through a wave-private LDS transpose ([sample][feature], the staging layout of k_dw) and 64 (H = 128)
+// MFMAs per slab -- instead of a separate pass that re-reads x_hat_L (512 B/sample) and a [M][32] dhead matrix from HBM.
+template <int H>
+struct HeadDw {
+  static constexpr int HX = 64 + 4;                       // one 64-feature half of x_hat per pass (row stride, floats)
+  static constexpr int TD = 33;                           // dhead tile row stride
+  static constexpr int WAVE_FLOATS = SLAB * HX + SLAB * TD;
+  static constexpr int OUT_FLOATS = 32 * H + 32;          // per-workgroup partial: dWp[32][H] then dbp[32] (k_dw layout)
+};
+
+template <int H, int DAP>
+__device__ __forceinline__ void head_dw_step(const f32x4 (&xs)[H / 8], const float (&dzh)[DAP], float *tx, float *td,
+                                             int lane, f32x16 (&acc)[H / 32]) {
+  constexpr int HX = HeadDw<H>::HX, TD = HeadDw<H>::TD;
+  const int i = lane & 31, h = lane >> 5;
+  if (h == 0) {
+#pragma unroll
+    for (int d = 0; d < DAP; ++d) td[i * TD + d] = dzh[d];  // columns >= DAP stay zero (cleared once)
+  }
+#pragma unroll
+  for (int half = 0; half < H / 64; ++half) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      *reinterpret_cast<f32x4 *>(tx + i * HX + 32 * (q >> 2) + 8 * (q & 3) + 4 * h) = xs[8 * half + q];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private hand-off between lanes (see mlp.hip)
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int t = 0; t < SLAB / 2; ++t) {
+      const float a = td[(2 * t + h) * TD + i];
+#pragma unroll
+      for (int n = 0; n < 2; ++n) {
+        const float b = tx[(2 * t + h) * HX + 32 * n + i];
+        acc[2 * half + n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[2 * half + n], 0, 0, 0);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();  // every lane is done reading tx / td before the next pass overwrites them
+  }
+}
+
+// end of kernel: combine the four waves' accumulators through LDS (one wave at a time, fixed order -> deterministic)
+// and write this workgroup's partial in the layout harl_reduce_partials_multi expects.
+template <int H, int DAP>
+__device__ __forceinline__ void head_dw_finish(f32x16 (&acc)[H / 32], float (&dbacc)[DAP], float *buf /* >= 32*H+32 */,
+                                               float *__restrict__ out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  float dbs[DAP];
+#pragma unroll
+  for (int d = 0; d < DAP; ++d) dbs[d] = wave_reduce_sum(dbacc[d]);
+  __syncthreads();  // staging tiles no longer in use: buf aliases them
+  for (int w = 0; w < WAVES_PER_WG; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int n = 0; n < H / 32; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int o = (r & 3) + 8 * (r >> 2) + 4 * h;
+          float *p = buf + o * H + 32 * n + i;
+          *p = (w == 0 ? 0.f : *p) + acc[n][r];
+        }
+      if (lane < 32) {
+        float v = 0.f;
+#pragma unroll
+        for (int d = 0; d < DAP; ++d)
+          if (lane == d) v = dbs[d];
+        float *p = buf + 32 * H + lane;
+        *p = (w == 0 ? 0.f : *p) + v;
+      }
+    }
+    __syncthreads();
+  }
+  for (int e = threadIdx.x; e < HeadDw<H>::OUT_FLOATS; e += WG_THREADS) out[e] = buf[e];
+}
+
 // block-level reduction of NV per-lane partial sums -> part_scalars[blockIdx.x][0..NV)
 template <int NV>
 __device__ __forceinline__ void block_reduce_store(float (&v)[NV], float *red /*[4][PS_STRIDE]*/, float *out_row) {
@@ -224,12 +302,15 @@ __device__ __forceinline__ void block_reduce_store(float (&v)[NV], float *red /*
 // =============================================================================================
 // actor head
 // =============================================================================================
-template <int H, int DAP, bool DISCRETE, bool TRAIN>
-__global__ __launch_bounds__(WG_THREADS) void k_actor_head(ActorArgs A) {
+template <int H, int DAP, bool DISCRETE, bool TRAIN, bool FUSE = false>
+__global__ __launch_bounds__(WG_THREADS, FUSE ? 2 : 1) void k_actor_head(ActorArgs A) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float *whl = lds;                    // [2][H/2][DAP]
   float *cst = whl + 2 * (H / 2) * DAP;  // bias[DAP], sigma[DAP], logsigma[DAP], dsigma_dlogstd[DAP], rowsum[DAP]
   float *red = cst + 5 * DAP;          // [4][PS_STRIDE]
+  float *dwl = red + 4 * PS_STRIDE;    // FUSE: [4 waves][HeadDw::WAVE_FLOATS] staging tiles (16-byte aligned)
+  if (FUSE)
+    for (int e = threadIdx.x; e < WAVES_PER_WG * HeadDw<H>::WAVE_FLOATS; e += WG_THREADS) dwl[e] = 0.f;
   stage_head<H, DAP>(whl, cst, A.Whp, A.bhp, A.act_dim);
   if (!DISCRETE) {
     for (int e = threadIdx.x; e < DAP; e += WG_THREADS) {
@@ -266,6 +347,17 @@ __global__ __launch_bounds__(WG_THREADS) void k_actor_head(ActorArgs A) {
   float sc[8 + DAP];
 #pragma unroll
   for (int k = 0; k < 8 + DAP; ++k) sc[k] = 0.f;
+  f32x16 dwacc[FUSE ? H / 32 : 1];
+  float dbacc[FUSE ? DAP : 1];
+  float *tx = dwl + (threadIdx.x >> 6) * HeadDw<H>::WAVE_FLOATS, *td = tx + SLAB * HeadDw<H>::HX;
+  if (FUSE) {
+#pragma unroll
+    for (int n = 0; n < H / 32; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dwacc[n][r] = 0.f;
+#pragma unroll
+    for (int d = 0; d < DAP; ++d) dbacc[d] = 0.f;
+  }
 
   for (long slab = (long)blockIdx.x * WAVES_PER_WG + wave; slab < A.n_slabs; slab += (long)gridDim.x * WAVES_PER_WG) {
     float z[DAP];
@@ -435,8 +527,13 @@ __global__ __launch_bounds__(WG_THREADS) void k_actor_head(ActorArgs A) {
         }
       }
     }
-    // head gradients for the dW kernel: row j, 32 columns (lane half h writes 16 of them)
-    {
+    if constexpr (FUSE) {  // head weight gradient right here (x_hat_L and dhead are both in registers)
+      head_dw_step<H, DAP>(xs, dzh, tx, td, lane, dwacc);
+      if (h == 0) {
+#pragma unroll
+        for (int d = 0; d < DAP; ++d) dbacc[d] += dzh[d];
+      }
+    } else {  // head gradients for the dW kernel: row j, 32 columns (lane half h writes 16 of them)
       float *dh = A.dhead + j * DHEAD_LD + 16 * h;
 #pragma unroll
       for (int c = 0; c < 16; ++c) {
@@ -459,6 +556,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_actor_head(ActorArgs A) {
   }
 
   if (TRAIN) block_reduce_store<8 + DAP>(sc, red, A.part_scalars + (long)blockIdx.x * PS_STRIDE);
+  if constexpr (FUSE) head_dw_finish<H, DAP>(dwacc, dbacc, dwl, A.dw_part + (long)blockIdx.x * HeadDw<H>::OUT_FLOATS);
 }
 
 // =============================================================================================
@@ -476,16 +574,20 @@ struct CriticArgs {
   long m_valid, m_pad;
   int use_clipped, use_huber;
   float *dzL, *dhead, *part_scalars, *values_out;
+  float *dw_part;  // fused head weight gradient partials (see ActorArgs)
   long n_slabs;
 };
 
-template <int H, bool TRAIN>
-__global__ __launch_bounds__(WG_THREADS) void k_critic_head(CriticArgs A) {
+template <int H, bool TRAIN, bool FUSE = false>
+__global__ __launch_bounds__(WG_THREADS, FUSE ? 2 : 1) void k_critic_head(CriticArgs A) {
   constexpr int DAP = 4;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float *whl = lds;
   float *cst = whl + 2 * (H / 2) * DAP;
   float *red = cst + 5 * DAP;
+  float *dwl = red + 4 * PS_STRIDE;
+  if (FUSE)
+    for (int e = threadIdx.x; e < WAVES_PER_WG * HeadDw<H>::WAVE_FLOATS; e += WG_THREADS) dwl[e] = 0.f;
   stage_head<H, DAP>(whl, cst, A.Whp, A.bhp, 1);
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -502,6 +604,17 @@ __global__ __launch_bounds__(WG_THREADS) void k_critic_head(CriticArgs A) {
   float sc[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) sc[k] = 0.f;
+  f32x16 dwacc[FUSE ? H / 32 : 1];
+  float dbacc[FUSE ? DAP : 1];
+  float *tx = dwl + (threadIdx.x >> 6) * HeadDw<H>::WAVE_FLOATS, *td = tx + SLAB * HeadDw<H>::HX;
+  if (FUSE) {
+#pragma unroll
+    for (int n = 0; n < H / 32; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dwacc[n][r] = 0.f;
+#pragma unroll
+    for (int d = 0; d < DAP; ++d) dbacc[d] = 0.f;
+  }
 
   for (long slab = (long)blockIdx.x * WAVES_PER_WG + wave; slab < A.n_slabs; slab += (long)gridDim.x * WAVES_PER_WG) {
     float z[DAP];
@@ -555,17 +668,21 @@ __global__ __launch_bounds__(WG_THREADS) void k_critic_head(CriticArgs A) {
       sc[0] += loss;
       sc[1] += 1.f;
     }
-    {
+    const float dzh[DAP] = {dv, 0.f, 0.f, 0.f};
+    if constexpr (FUSE) {
+      head_dw_step<H, DAP>(xs, dzh, tx, td, lane, dwacc);
+      if (h == 0) dbacc[0] += dv;
+    } else {
       float *dh = A.dhead + j * DHEAD_LD + 16 * h;
 #pragma unroll
       for (int c = 0; c < 16; ++c) dh[c] = (h == 0 && c == 0) ? dv : 0.f;
     }
-    const float dzh[DAP] = {dv, 0.f, 0.f, 0.f};
     if constexpr (TRAIN)
       head_bwd_regs<H, DAP>(xs, A.relu_mask, A.rstd[slab * SLAB + i], slab, lane, whl_h, dzh, dv * cst[4 * DAP],
                             dv * (v - cst[0]), A.dzL);
   }
   if (TRAIN) block_reduce_store<8>(sc, red, A.part_scalars + (long)blockIdx.x * PS_STRIDE);
+  if constexpr (FUSE) head_dw_finish<H, DAP>(dwacc, dbacc, dwl, A.dw_part + (long)blockIdx.x * HeadDw<H>::OUT_FLOATS);
 }
 
 // =============================================================================================
@@ -768,8 +885,18 @@ int head_grid(long M) { return persistent_grid(n_slabs_of(M), 4); }
 
 template <int H, int DAP, bool DISC, bool TRAIN>
 void launch_actor(const ActorArgs &A, int grid, hipStream_t s) {
-  const size_t shm = ((size_t)2 * (H / 2) * DAP + 5 * DAP + 4 * PS_STRIDE) * sizeof(float);
-  hipLaunchKernelGGL((k_actor_head<H, DAP, DISC, TRAIN>), dim3(grid), dim3(WG_THREADS), shm, s, A);
+  const size_t base = ((size_t)2 * (H / 2) * DAP + 5 * DAP + 4 * PS_STRIDE) * sizeof(float);
+  if constexpr (TRAIN) {
+    if (A.dw_part) {
+      size_t fl = (size_t)WAVES_PER_WG * HeadDw<H>::WAVE_FLOATS;
+      if (fl < (size_t)HeadDw<H>::OUT_FLOATS) fl = HeadDw<H>::OUT_FLOATS;
+      const size_t shm = base + fl * sizeof(float);
+      allow_big_lds(k_actor_head<H, DAP, DISC, true, true>, shm);
+      hipLaunchKernelGGL((k_actor_head<H, DAP, DISC, true, true>), dim3(grid), dim3(WG_THREADS), shm, s, A);
+      return;
+    }
+  }
+  hipLaunchKernelGGL((k_actor_head<H, DAP, DISC, TRAIN>), dim3(grid), dim3(WG_THREADS), base, s, A);
 }
 
 template <bool TRAIN>
@@ -822,18 +949,20 @@ extern "C" int harl_actor_head_loss(const float *xL, const uint32_t *relu_mask, 
                                     const double *adv_moments, const float *factor, const float *active,
                                     float clip_param, float entropy_coef, int agg_mean, int trpo, long m_valid,
                                     long m_pad, float *logp_out, float *dzL, float *dhead, float *part_scalars,
-                                    void *stream) {
+                                    float *dw_part, int n_wg, void *stream) {
   if (M <= 0) return 0;
   ActorArgs A{};
   A.trpo = trpo;
   A.logp_out = logp_out;
+  A.dw_part = dw_part;
+  if (dw_part && n_wg <= 0) { set_error("harl_actor_head_loss: fused head gradient needs n_wg > 0"); return -2; }
   A.m_valid = m_valid; A.m_pad = m_pad;
   A.xL = xL; A.relu_mask = relu_mask; A.rstd = rstd; A.M = M; A.Whp = Whp; A.bhp = bhp; A.log_std = log_std;
   A.std_x_coef = std_x_coef; A.std_y_coef = std_y_coef; A.act_dim = act_dim; A.idx = idx;
   A.actions = actions; A.avail = avail; A.old_logp = old_logp; A.adv = adv; A.adv_moments = adv_moments;
   A.factor_in = factor; A.active = active; A.clip_param = clip_param; A.entropy_coef = entropy_coef;
   A.agg_mean = agg_mean; A.dzL = dzL; A.dhead = dhead; A.part_scalars = part_scalars; A.n_slabs = n_slabs_of(M);
-  return dispatch_actor<true>(A, H, discrete, head_grid(M), (hipStream_t)stream);
+  return dispatch_actor<true>(A, H, discrete, dw_part ? n_wg : head_grid(M), (hipStream_t)stream);
 }
 
 extern "C" int harl_critic_head_values(const float *xL, long M, int H, const float *Whp, const float *bhp,
@@ -853,7 +982,7 @@ extern "C" int harl_critic_head_loss(const float *xL, const uint32_t *relu_mask,
                                      const float *Whp, const float *bhp, const int64_t *idx, const float *value_preds,
                                      const float *returns, const float *vn_stats, float clip_param, int use_clipped,
                                      int use_huber, float huber_delta, long m_valid, long m_pad, float *dzL, float *dhead,
-                                     float *part_scalars, void *stream) {
+                                     float *part_scalars, float *dw_part, int n_wg, void *stream) {
   if (M <= 0) return 0;
   CriticArgs A{};
   A.m_valid = m_valid; A.m_pad = m_pad;
@@ -861,12 +990,28 @@ extern "C" int harl_critic_head_loss(const float *xL, const uint32_t *relu_mask,
   A.value_preds = value_preds; A.returns = returns; A.vn_stats = vn_stats; A.clip_param = clip_param;
   A.huber_delta = huber_delta; A.use_clipped = use_clipped; A.use_huber = use_huber; A.dzL = dzL; A.dhead = dhead;
   A.part_scalars = part_scalars; A.n_slabs = n_slabs_of(M);
-  const int grid = head_grid(M);
-  const size_t shm = ((size_t)2 * (H / 2) * 4 + 20 + 4 * PS_STRIDE) * sizeof(float);
-  if (H == 128) hipLaunchKernelGGL((k_critic_head<128, true>), dim3(grid), dim3(WG_THREADS), shm, (hipStream_t)stream, A);
-  else if (H == 64) hipLaunchKernelGGL((k_critic_head<64, true>), dim3(grid), dim3(WG_THREADS), shm, (hipStream_t)stream, A);
-  else { set_error("critic head: hidden width must be 64 or 128"); return -2; }
-  return check_launch("harl_critic_head_loss");
+  A.dw_part = dw_part;
+  if (dw_part && n_wg <= 0) { set_error("harl_critic_head_loss: fused head gradient needs n_wg > 0"); return -2; }
+  const int grid = dw_part ? n_wg : head_grid(M);
+  const size_t base = ((size_t)2 * (H / 2) * 4 + 20 + 4 * PS_STRIDE) * sizeof(float);
+  hipStream_t s = (hipStream_t)stream;
+#define CL(Hv)                                                                                                     \
+  if (H == Hv) {                                                                                                   \
+    if (dw_part) {                                                                                                 \
+      size_t fl = (size_t)WAVES_PER_WG * HeadDw<Hv>::WAVE_FLOATS;                                                  \
+      if (fl < (size_t)HeadDw<Hv>::OUT_FLOATS) fl = HeadDw<Hv>::OUT_FLOATS;                                        \
+      const size_t shm = base + fl * sizeof(float);                                                                \
+      allow_big_lds(k_critic_head<Hv, true, true>, shm);                                                           \
+      hipLaunchKernelGGL((k_critic_head<Hv, true, true>), dim3(grid), dim3(WG_THREADS), shm, s, A);                \
+    } else {                                                                                                       \
+      hipLaunchKernelGGL((k_critic_head<Hv, true>), dim3(grid), dim3(WG_THREADS), base, s, A);                     \
+    }                                                                                                              \
+    return check_launch("harl_critic_head_loss");                                                                  \
+  }
+  CL(128) CL(64)
+#undef CL
+  set_error("critic head: hidden width must be 64 or 128");
+  return -2;
 }
 
 extern "C" int harl_actor_head_fvp(const float *xL, const float *xLdot, const uint32_t *relu_mask, const float *rstd, long M,

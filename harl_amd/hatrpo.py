@@ -43,7 +43,7 @@ class HATRPO(OnPolicyBase):
         call("harl_actor_head_loss", ptr(net.xh[-1]), ptr(net.rmask[-1]), ptr(net.rstd[-1]), m, net.hidden_sizes[-1],
              ptr(Wp), ptr(bp), ptr(net.log_std()), net.std_x_coef, net.std_y_coef, int(net.discrete), net.act_dim,
              None, ptr(actions), ptr(avail), ptr(old_logp), ptr(adv), ptr(adv_moments), ptr(factor), ptr(active),
-             0.0, 0.0, int(self.action_aggregation == "mean"), 1, 0, 0, None, ptr(net.dz[0]), ptr(net.dhead), ptr(net.part_scalars), s)
+             0.0, 0.0, int(self.action_aggregation == "mean"), 1, 0, 0, None, ptr(net.dz[0]), ptr(net.dhead), ptr(net.part_scalars), None, 0, s)
         net.scalars.zero_()
         call("harl_reduce_scalars", ptr(net.part_scalars), _lib.load().harl_head_blocks(m), ptr(net.scalars), s)
         grad = None

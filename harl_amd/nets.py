@@ -262,7 +262,7 @@ class _FlatNet(nn.Module):
             self.rnn_dgate = [a() for _ in range(4)]   # dr, dz, dn, dhn
             self.rnn_ones = torch.full((n_slabs * 64,), -1, dtype=u32, device=dev)  # all-ones "relu mask" for rnn.norm
             self.rnn_gi = torch.empty(3 * mp * H, dtype=f32, device=dev)  # input half of the gates, all steps (gru.hip)
-        self.n_head_blocks = _lib.load().harl_head_blocks(M)
+        self.n_head_blocks = max(_lib.load().harl_head_blocks(M), self.n_wg)
         self.part_scalars = torch.zeros(self.n_head_blocks * PS_STRIDE, dtype=f32, device=dev)
         self.scalars = torch.zeros(PS_STRIDE, dtype=torch.float64, device=dev)
         self._max_rows = M
@@ -314,7 +314,9 @@ class _FlatNet(nn.Module):
             self.forward_rnn(seq, save=True)
 
     # ---- backward: dz_L (in self.dz[0]) and dhead -> dense folded gradients self.dwp (UNSCALED sums over samples)
-    def backward_trunk(self, X: torch.Tensor, idx: Optional[torch.Tensor], M: int, seq: Optional[dict] = None) -> None:
+    def backward_trunk(self, X: torch.Tensor, idx: Optional[torch.Tensor], M: int, seq: Optional[dict] = None,
+                       head_dw_done: bool = False) -> None:
+        """``head_dw_done``: the loss kernel already wrote the head's weight-gradient partials (fused path)."""
         s = stream()
         L = len(self.hidden_sizes)
         nwg = self.n_wg
@@ -322,8 +324,9 @@ class _FlatNet(nn.Module):
         hdim = self._layers()[-1][4]
         fx, _, _, fh = self.feat()
         # head: dW_head' = dhead^T x_hat_L   (x_hat_L = GRU output for recurrent nets)
-        call("harl_mlp_dw_partials", ptr(self.dhead), 1, DHEAD_LD, hdim, ptr(fx), 0, 0, None, None, None, fh, M,
-             ptr(self.part[po[-1]:]), nwg, s, tag="dw_head")
+        if not head_dw_done:
+            call("harl_mlp_dw_partials", ptr(self.dhead), 1, DHEAD_LD, hdim, ptr(fx), 0, 0, None, None, None, fh, M,
+                 ptr(self.part[po[-1]:]), nwg, s, tag="dw_head")
         cur = 0  # self.dz[cur] holds dz of the last MLP layer (non-recurrent) / d(loss)/d(h) (recurrent)
         if self.recurrent:
             gp, sv, dg = self.gru_pack, self.rnn_saved, self.rnn_dgate

@@ -95,9 +95,10 @@ class VCritic:
             call("harl_critic_head_loss", ptr(fx), ptr(fmask), ptr(frstd), m, fh,
                  ptr(Wp), ptr(bp), ptr(idx), ptr(value_preds), ptr(returns), ptr(vn.stats) if vn is not None else None,
                  float(self.clip_param), int(self.use_clipped_value_loss), int(self.use_huber_loss), float(self.huber_delta),
-                 mv, mp, ptr(net.dz[0]), ptr(net.dhead), ptr(net.part_scalars), s, tag="critic_head_loss")
-            net.backward_trunk(share_obs, idx, m, seq=seq)
-        nblk = _lib.load().harl_head_blocks(m) if m > 0 else 0
+                 mv, mp, ptr(net.dz[0]), ptr(net.dhead), ptr(net.part_scalars), ptr(net.part[net._part_offs[-1]:]),
+                 net.n_wg, s, tag="critic_head_loss")  # head weight gradient fused into this launch
+            net.backward_trunk(share_obs, idx, m, seq=seq, head_dw_done=True)
+        nblk = net.n_wg if m > 0 else 0  # rows of part_scalars
         ps_kw = dict(part_scalars=net.part_scalars, n_scalar_blocks=nblk)  # reduced inside the optimiser launch
         if self.comm.enabled:  # ONE collective per optimiser step: [folded gradients | loss scalars] (dist.py)
             sc.zero_()

@@ -186,6 +186,9 @@ int harl_actor_head_logp(const float *xL, long M, int H, const float *Whp, const
  *   trpo: 0 = HAPPO; 1 = HATRPO surrogate  sum_s +ratio*f*adv*active  (no clip, no entropy term;
  *   algorithms/actors/hatrpo.py:77-95); 2 = HAA2C  sum_s -ratio*f*adv*active  (no clip; algorithms/actors/haa2c.py:70-80).
  *   Scalar 0 is that sum.
+ *   dw_part (optional) + n_wg: fuse the head weight gradient dW_head' = dhead^T x_hat_L into this kernel: launched with
+ *   n_wg workgroups, each writing one partial [32*H + 32] in the layout of harl_mlp_dw_partials (a_kind = 1); dhead is
+ *   then not written and the separate harl_mlp_dw_partials launch for the head is not needed; part_scalars has n_wg rows.
  *   logp_out (optional): log pi(a|o) of every row under the current parameters, [M, act_w] by batch position -- with a
  *   single full-buffer minibatch the first epoch's forward IS the runner's pre-update log-prob pass
  *   (on_policy_ha_runner.py:66-83), so the runner takes it from here instead of running that pass separately.
@@ -196,7 +199,7 @@ int harl_actor_head_loss(const float *xL, const uint32_t *relu_mask, const float
                          const float *avail, const float *old_logp, const float *adv, const double *adv_moments,
                          const float *factor, const float *active, float clip_param, float entropy_coef,
                          int agg_mean, int trpo, long m_valid, long m_pad, float *logp_out, float *dzL, float *dhead,
-                         float *part_scalars, void *stream);
+                         float *part_scalars, float *dw_part, int n_wg, void *stream);
 /* V head forward: values[M] = Whp . xL + bhp   (v_net.py:64) */
 int harl_critic_head_values(const float *xL, long M, int H, const float *Whp, const float *bhp, float *values,
                             void *stream);
@@ -209,7 +212,7 @@ int harl_critic_head_loss(const float *xL, const uint32_t *relu_mask, const floa
                           const float *Whp, const float *bhp, const int64_t *idx, const float *value_preds,
                           const float *returns, const float *vn_stats, float clip_param, int use_clipped,
                           int use_huber, float huber_delta, long m_valid, long m_pad, float *dzL, float *dhead,
-                          float *part_scalars, void *stream);
+                          float *part_scalars, float *dw_part, int n_wg, void *stream);  /* dw_part/n_wg: see actor */
 /* ---------------------------------------------------------------------------------------------
  * HATRPO (algorithms/actors/hatrpo.py:37-194, utils/trpo_util.py:47-158).  The Fisher-vector product
  * F v = grad((grad KL) . v) is evaluated as J^T M (J v) (exact at theta_new == theta_old, where KL's first-order terms

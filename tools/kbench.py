@@ -77,8 +77,8 @@ def main():
         ("dw_input_D54", lambda: call("harl_mlp_dw_partials", ptr(dz), 0, 0, H, ptr(sobs), 1, 54, None, ptr(mu0), ptr(rstd0), 54, B, ptr(part), n_wg, s), GB(B * (512 + 216 + 8))),
         ("reduce_partials", lambda: call("harl_reduce_partials", ptr(part), n_wg, H * H + H, ptr(dwp), s), GB(n_wg * (H * H + H) * 4)),
         ("actor_head_logp", lambda: call("harl_actor_head_logp", ptr(xh2), B, H, ptr(Wh), ptr(bh), ptr(ls), 1.0, 0.5, 0, 5, ptr(actions), None, ptr(logp_out), None, None, 0, None, 0, 0, s), GB(B * (512 + 40))),
-        ("actor_head_loss", lambda: call("harl_actor_head_loss", ptr(xh2), ptr(mask), ptr(rstd), B, H, ptr(Wh), ptr(bh), ptr(ls), 1.0, 0.5, 0, 5, None, ptr(actions), None, ptr(old_logp), ptr(adv), None, ptr(factor), ptr(active), 0.2, 0.01, 0, 0, 0, 0, None, ptr(dz2), ptr(dhead), ptr(ps), s), GB(B * (512 + 512 + 128 + 60))),
-        ("critic_head_loss", lambda: call("harl_critic_head_loss", ptr(xh2), ptr(mask), ptr(rstd), B, H, ptr(Wv), ptr(bv), None, ptr(vp), ptr(ret), ptr(vn), 0.2, 1, 1, 10.0, 0, 0, ptr(dz2), ptr(dhead), ptr(ps), s), GB(B * (512 + 512 + 128 + 8))),
+        ("actor_head_loss", lambda: call("harl_actor_head_loss", ptr(xh2), ptr(mask), ptr(rstd), B, H, ptr(Wh), ptr(bh), ptr(ls), 1.0, 0.5, 0, 5, None, ptr(actions), None, ptr(old_logp), ptr(adv), None, ptr(factor), ptr(active), 0.2, 0.01, 0, 0, 0, 0, None, ptr(dz2), ptr(dhead), ptr(ps), None, 0, s), GB(B * (512 + 512 + 128 + 60))),
+        ("critic_head_loss", lambda: call("harl_critic_head_loss", ptr(xh2), ptr(mask), ptr(rstd), B, H, ptr(Wv), ptr(bv), None, ptr(vp), ptr(ret), ptr(vn), 0.2, 1, 1, 10.0, 0, 0, ptr(dz2), ptr(dhead), ptr(ps), None, 0, s), GB(B * (512 + 512 + 128 + 8))),
         ("critic_head_values", lambda: call("harl_critic_head_values", ptr(xh2), B, H, ptr(Wv), ptr(bv), ptr(vals), s), GB(B * 516)),
         ("gae_returns", lambda: call("harl_gae_returns", ptr(rew), ptr(vpT), ptr(mk), ptr(mk), ptr(vpT[-1].contiguous()), ptr(vn), ptr(rets), ptr(advs), T, N, 0.99, 0.9405, 1, 1, 0, s), GB(B * 24)),
         ("gradnorm_clip_adam", lambda: call("harl_gradnorm_clip_adam", ptr(pp), ptr(gg), ptr(mm), ptr(vv), P, None, 1, 10.0, 5e-4, 0.9, 0.999, 1e-5, 0.0, 0.1, 0.001, None, s), GB(P * 28)),

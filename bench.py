@@ -172,7 +172,7 @@ def main():
     barrier()
     # Roofline timing lives INSIDE the timed region: every launch of the four MFMA kernel families is bracketed by HIP
     # events on the launch stream (64 event pairs per step, <1 % of wall time).
-    MFMA_TAGS = ("fwd_fused2", "fwd_hidden", "bwd_dx", "dw_hidden")
+    MFMA_TAGS = ("fwd_fused2", "fwd_hidden", "bwd_dx", "bwd_dx_dw1", "dw_hidden")
     if not args.no_kernel_timing:
         _lib.enable_kernel_timing(True, MFMA_TAGS)
     t0 = time.perf_counter()
@@ -207,7 +207,9 @@ def main():
         # dominant kernel = the MFMA kernel family with the largest total time inside the timed region; `achieved` is
         # its ALGORITHMIC flops per launch (Linear layers only) / its average HIP-event duration
         flops = dict(fwd_hidden=2.0 * B * 128 * 128, bwd_dx=2.0 * B * 128 * 128, dw_hidden=2.0 * B * 128 * 128,
-                     fwd_fused2=2.0 * B * (128 * 128 + OBS * 128))
+                     fwd_fused2=2.0 * B * (128 * 128 + OBS * 128),
+                     # dX of layer 2 + the fused first-layer weight gradient (15 actor launches with D=18, 5 critic with 54)
+                     bwd_dx_dw1=2.0 * B * (128 * 128 + 128 * (15 * OBS + 5 * SOBS) / 20.0))
         cand = {k: v for k, v in mfma_kern.items() if k in flops and v["n"] > 0}
         roof = None
         if cand:
@@ -218,6 +220,7 @@ def main():
             # launched 15x per step in training mode (writes x_hat_1, x_hat_2, the normalised inputs, masks, statistics)
             # and 3x in log-prob mode (x_hat_2 only).
             alg = dict(fwd_hidden=B * (512 + 512 + 16 + 4), bwd_dx=B * (512 + 512 + 16 + 4 + 512), dw_hidden=B * (512 + 512),
+                       bwd_dx_dw1=B * (512 + 512 + 16 + 4 + (15 * 128 + 5 * 256) / 20.0),
                        fwd_fused2=B * (15 * (4 * OBS + 512 + 512 + 128 + 32 + 16) + 3 * (4 * OBS + 512 + 16 + 4)) / 18.0)
             traffic, traffic_note = None, None
             tp = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")

@@ -107,9 +107,9 @@ __device__ __forceinline__ float mask_pop(float x, uint32_t &bits) {  // returns
 //   da = rstd (dx_hat - mean_f(dx_hat) - x_hat mean_f(dx_hat x_hat)) ;  dz = relu_mask ? da : 0 ; store ATL
 // evaluated as  da = fma(x_hat, -s2 rstd, fma(dx_hat, rstd, -s1 rstd))  on register pairs (v_pk_fma_f32).
 template <int H>
-__device__ __forceinline__ void ln_bwd_relu_store(const float (&dx)[H / 2], const float (&xh)[H / 2],
-                                                  const uint32_t *__restrict__ mask_in, float rstd, int lane, long slab,
-                                                  float *__restrict__ dz_out) {
+__device__ __forceinline__ void ln_bwd_relu_regs(const float (&dx)[H / 2], const float (&xh)[H / 2],
+                                                 const uint32_t *__restrict__ mask_in, float rstd, int lane, long slab,
+                                                 float (&out)[H / 2]) {
   constexpr int NR = H / 2;
   constexpr int NW = (NR + 31) / 32;
   f32x2 a1 = {0.f, 0.f}, a2 = {0.f, 0.f};
@@ -127,7 +127,6 @@ __device__ __forceinline__ void ln_bwd_relu_store(const float (&dx)[H / 2], cons
   uint32_t bits[NW];
 #pragma unroll
   for (int w = 0; w < NW; ++w) bits[w] = mask_in[(slab * NW + w) * WAVE + lane];
-  float out[NR];
 #pragma unroll
   for (int P = 0; P < NR / 2; ++P) {
     const f32x2 d = {dx[2 * P], dx[2 * P + 1]}, x = {xh[2 * P], xh[2 * P + 1]};
@@ -135,6 +134,14 @@ __device__ __forceinline__ void ln_bwd_relu_store(const float (&dx)[H / 2], cons
     out[2 * P] = mask_pop(da[0], bits[(2 * P) >> 5]);
     out[2 * P + 1] = mask_pop(da[1], bits[(2 * P + 1) >> 5]);
   }
+}
+
+template <int H>
+__device__ __forceinline__ void ln_bwd_relu_store(const float (&dx)[H / 2], const float (&xh)[H / 2],
+                                                  const uint32_t *__restrict__ mask_in, float rstd, int lane, long slab,
+                                                  float *__restrict__ dz_out) {
+  float out[H / 2];
+  ln_bwd_relu_regs<H>(dx, xh, mask_in, rstd, lane, slab, out);
   atl_store<H>(dz_out, slab, lane, out);
 }
 

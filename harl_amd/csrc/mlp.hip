@@ -344,13 +344,16 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_fwd_input(const float *__rest
 // gather + re-normalisation of raw rows).  Pad columns come out as -mean*rstd and only reach dWp columns >= D, which
 // nobody reads (same convention as the raw-row path of k_dw).
 template <int NCH>
-__device__ __forceinline__ void x0n_store(const float *xr, float mean, float rstd, int lane, long slab,
+__device__ __forceinline__ void x0n_store(const float *xr, int D, float mean, float rstd, int lane, long slab,
                                           float *__restrict__ out) {
   constexpr int HW = 32 * NCH;
   const float *xl = xr + 4 * (lane >> 5);
   float v[HW / 2];
 #pragma unroll
   for (int R = 0; R < HW / 2; ++R) v[R] = (xl[feat_base(R)] - mean) * rstd;  // mean = 0, rstd = 1 without input LN
+  // the LAST pad column (feature HW-1 = register HW/2-1 of the upper lane half) is a column of ones when D < HW: the
+  // weight-gradient GEMM then yields db' = sum_s dz[s] in that column for free (used by the fused path of k_bwd_dx)
+  if (D < HW && (lane >> 5) == 1) v[HW / 2 - 1] = 1.0f;
   atl_store<HW>(out, slab, lane, v);
 }
 
@@ -501,7 +504,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_fwd_input_staged(const float 
       mu0_out[slab * SLAB + lane] = mean;
       rstd0_out[slab * SLAB + lane] = rstd;
     }
-    if (x0n_out) x0n_store<NCH>(xr, mean, rstd, lane, slab, x0n_out);
+    if (x0n_out) x0n_store<NCH>(xr, D, mean, rstd, lane, slab, x0n_out);
     __builtin_amdgcn_wave_barrier();  // all lanes done reading xw before the next slab overwrites it
   }
 }
@@ -691,7 +694,7 @@ __global__ __launch_bounds__(64 * FUSED_WAVES, 2) void k_fwd_fused2(
         mu0_out[slab * SLAB + lane] = mean;
         rstd0_out[slab * SLAB + lane] = rstd0;
       }
-      if (x0n_out) x0n_store<NCH>(xr, mean, rstd0, lane, slab, x0n_out);
+      if (x0n_out) x0n_store<NCH>(xr, D, mean, rstd0, lane, slab, x0n_out);
     }
     __builtin_amdgcn_wave_barrier();  // all lanes done with xw before the next slab's rows overwrite it
     // next slab's rows: issued BEFORE the layer-2 GEMM (16 more live VGPRs) so that ~16k MFMA cycles cover the HBM
@@ -731,14 +734,21 @@ __global__ __launch_bounds__(64 * FUSED_WAVES, 2) void k_fwd_fused2(
 // A operand = Wp^T: lane i -> input feature 32t+i, step R -> output feature f(R,h); Wp row-major
 // in LDS is read with consecutive addresses by the 32 lanes of a half (conflict-free).
 // =============================================================================================
-template <int HO, int HI>
-__global__ __launch_bounds__(WG_THREADS, 2) void k_bwd_dx(const float *__restrict__ dz, const float *__restrict__ xprev,
-                                                          const uint32_t *__restrict__ mask_prev,
-                                                          const float *__restrict__ rstd_prev,
-                                                          const float *__restrict__ Wp, float *__restrict__ dz_prev,
-                                                          long n_slabs) {
+// KT > 0: FIRST-layer variant.  dz_prev (= dz_1) is only ever consumed by the first layer's weight gradient
+// dW_1' = dz_1^T x0n, so that GEMM is done right here -- dz_1 (registers, lane = sample) and the normalised inputs x0n
+// (ATL(32*KT), last pad column = ones -> db_1' for free) go through a wave-private LDS transpose and 64*KT extra MFMAs per
+// slab; dz_1 is never written to HBM and the separate harl_mlp_dw_partials pass over it disappears.  One workgroup per
+// CU (LDS: weights + staging), per-workgroup partials in the layout of harl_mlp_dw_partials.
+template <int HO, int HI, int KT = 0>
+__global__ __launch_bounds__(WG_THREADS, KT > 0 ? 1 : 2) void k_bwd_dx(
+    const float *__restrict__ dz, const float *__restrict__ xprev, const uint32_t *__restrict__ mask_prev,
+    const float *__restrict__ rstd_prev, const float *__restrict__ Wp, float *__restrict__ dz_prev, long n_slabs,
+    const float *__restrict__ x0n = nullptr, float *__restrict__ dw_part = nullptr) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float *Wl = lds;  // [HO][HI] row-major
+  constexpr int HX = 64 + 4, KPF = 32 * (KT > 0 ? KT : 1), LDB = KPF + 4;
+  constexpr int STAGE_FLOATS = SLAB * HX + SLAB * LDB;  // per wave: a 64-feature half of dz_1, and the x0n tile
+  float *stg = Wl + HO * HI;
   stage_matrix<HO, HI, HI, WG_THREADS>(Wl, Wp);
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -763,6 +773,15 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_bwd_dx(const float *__restric
       for (int t = 0; t < NT_; ++t) a[c * NT_ + t] = wq[c * HI + 32 * t];
   };
   lds_frag(0, aX);
+  f32x16 acc1[KT > 0 ? HI / 32 : 1][KT > 0 ? KT : 1];  // fused first-layer weight gradient, persistent over the slabs
+  if constexpr (KT > 0) {
+#pragma unroll
+    for (int mt = 0; mt < HI / 32; ++mt)
+#pragma unroll
+      for (int n = 0; n < KT; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc1[mt][n][r] = 0.f;
+  }
   for (long slab = slab0; slab < n_slabs; slab += slab_stride) {
     const f32x4 *gp = reinterpret_cast<const f32x4 *>(dz + slab * (long)(HO * SLAB)) + lane;
     const long nslab = slab + slab_stride < n_slabs ? slab + slab_stride : slab;
@@ -810,7 +829,68 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_bwd_dx(const float *__restric
     float dx[HI / 2];
 #pragma unroll
     for (int R = 0; R < HI / 2; ++R) dx[R] = acc[R >> 4][R & 15];
-    ln_bwd_relu_store<HI>(dx, xh, mask_prev, rstd, lane, slab, dz_prev);
+    if constexpr (KT == 0) {
+      ln_bwd_relu_store<HI>(dx, xh, mask_prev, rstd, lane, slab, dz_prev);
+    } else {
+      float out[HI / 2];
+      ln_bwd_relu_regs<HI>(dx, xh, mask_prev, rstd, lane, slab, out);
+      if (dz_prev) atl_store<HI>(dz_prev, slab, lane, out);
+      float *tx = stg + wave * STAGE_FLOATS, *tb = tx + SLAB * HX;
+      {  // normalised-input tile -> tb[sample][column]
+        const f32x4 *bp = reinterpret_cast<const f32x4 *>(x0n + slab * (long)(KPF * SLAB)) + lane;
+#pragma unroll
+        for (int q = 0; q < KPF / 8; ++q)
+          *reinterpret_cast<f32x4 *>(tb + i * LDB + 32 * (q >> 2) + 8 * (q & 3) + 4 * h) = bp[q * WAVE];
+      }
+#pragma unroll
+      for (int half = 0; half < HI / 64; ++half) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int R0 = 4 * (8 * half + q);
+          *reinterpret_cast<f32x4 *>(tx + i * HX + 32 * (q >> 2) + 8 * (q & 3) + 4 * h) =
+              f32x4{out[R0], out[R0 + 1], out[R0 + 2], out[R0 + 3]};
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private hand-off between lanes
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int t = 0; t < SLAB / 2; ++t) {
+          float bv[KT];
+#pragma unroll
+          for (int n = 0; n < KT; ++n) bv[n] = tb[(2 * t + h) * LDB + 32 * n + i];
+#pragma unroll
+          for (int m = 0; m < 2; ++m) {
+            const float a = tx[(2 * t + h) * HX + 32 * m + i];
+#pragma unroll
+            for (int n = 0; n < KT; ++n) acc1[2 * half + m][n] = MFMA(a, bv[n], acc1[2 * half + m][n]);
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();  // all lanes done reading before the next pass overwrites tx / tb
+      }
+    }
+  }
+  if constexpr (KT > 0) {
+    // combine the four waves' accumulators (one wave at a time, fixed order) and write dWp[HI][KPF] | dbp[HI]
+    float *buf = stg;  // staging no longer in use
+    __syncthreads();
+    for (int w = 0; w < WAVES_PER_WG; ++w) {
+      if (wave == w) {
+#pragma unroll
+        for (int mt = 0; mt < HI / 32; ++mt)
+#pragma unroll
+          for (int n = 0; n < KT; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int o = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * h;
+              float *p = buf + o * KPF + 32 * n + i;
+              *p = (w == 0 ? 0.f : *p) + acc1[mt][n][r];
+            }
+      }
+      __syncthreads();
+    }
+    float *outp = dw_part + (long)blockIdx.x * ((long)HI * KPF + HI);
+    for (int e = threadIdx.x; e < HI * KPF; e += WG_THREADS) outp[e] = buf[e];
+    for (int o = threadIdx.x; o < HI; o += WG_THREADS) outp[HI * KPF + o] = buf[o * KPF + KPF - 1];  // ones column
   }
 }
 
@@ -1226,15 +1306,36 @@ extern "C" int harl_mlp_fwd_hidden(const float *xin, long M, int HI, int HO, con
 
 extern "C" int harl_mlp_bwd_dx(const float *dz, const float *xprev, const uint32_t *relu_mask_prev,
                                const float *rstd_prev, long M, int HO, int HI, const float *Wp, float *dz_prev,
-                               void *stream) {
+                               const float *x0n, int kp0, float *dw_part, int n_wg, void *stream) {
   if (M <= 0) return 0;
   const long n_slabs = n_slabs_of(M);
+  hipStream_t s = (hipStream_t)stream;
+  if (dw_part) {  // first-layer variant with the weight gradient fused in
+    if (!x0n || (kp0 != 32 && kp0 != 64) || n_wg <= 0)
+      return bad("harl_mlp_bwd_dx: fused first-layer gradient needs x0n, kp0 in {32, 64} and n_wg > 0");
+#define LF(a, b, kt)                                                                                              \
+  {                                                                                                               \
+    size_t fl = (size_t)WAVES_PER_WG * (SLAB * (64 + 4) + SLAB * (32 * kt + 4));                                  \
+    if (fl < (size_t)b * 32 * kt) fl = (size_t)b * 32 * kt;                                                       \
+    const size_t shm = ((size_t)a * b + fl) * sizeof(float);                                                      \
+    allow_big_lds(k_bwd_dx<a, b, kt>, shm);                                                                       \
+    hipLaunchKernelGGL((k_bwd_dx<a, b, kt>), dim3(n_wg), dim3(WG_THREADS), shm, s, dz, xprev, relu_mask_prev,      \
+                       rstd_prev, Wp, dz_prev, n_slabs, x0n, dw_part);                                            \
+  }
+    const int kt = kp0 / 32;
+    if (HO == 128 && HI == 128) { if (kt == 1) LF(128, 128, 1) else LF(128, 128, 2) }
+    else if (HO == 64 && HI == 64) { if (kt == 1) LF(64, 64, 1) else LF(64, 64, 2) }
+    else if (HO == 128 && HI == 64) { if (kt == 1) LF(128, 64, 1) else LF(128, 64, 2) }
+    else if (HO == 64 && HI == 128) { if (kt == 1) LF(64, 128, 1) else LF(64, 128, 2) }
+    else return bad("harl_mlp_bwd_dx: widths must be 64 or 128");
+#undef LF
+    return check_launch("harl_mlp_bwd_dx");
+  }
   const size_t shm = (size_t)HO * HI * sizeof(float);
   const int grid = persistent_grid(n_slabs, 2);
-  hipStream_t s = (hipStream_t)stream;
 #define L(a, b)                                                                                                    \
   hipLaunchKernelGGL((k_bwd_dx<a, b>), dim3(grid), dim3(WG_THREADS), shm, s, dz, xprev, relu_mask_prev, rstd_prev, Wp, \
-                     dz_prev, n_slabs)
+                     dz_prev, n_slabs, nullptr, nullptr)
   if (HO == 128 && HI == 128) L(128, 128);
   else if (HO == 64 && HI == 64) L(64, 64);
   else if (HO == 128 && HI == 64) L(128, 64);

@@ -342,17 +342,25 @@ class _FlatNet(nn.Module):
                 call("harl_mlp_dw_partials", ptr(a), 0, 0, H, ptr(sv[0]), 0, 0, None, None, None, H, M,
                      ptr(self.part[po[L + 3 + gate]:]), nwg, s, tag="dw_gru")
             cur = 1
+        # first-layer weight gradient fused into the last bwd_dx (needs the ones column of x0n: in_dim < kp0)
+        fuse_dw1 = L >= 2 and self.x0n is not None and self.in_dim < self.kp0
         for l in range(L - 1, 0, -1):
             ho, hi = self.hidden_sizes[l], self.hidden_sizes[l - 1]
             call("harl_mlp_dw_partials", ptr(self.dz[cur]), 0, 0, ho, ptr(self.xh[l - 1]), 0, 0, None, None, None, hi, M,
                  ptr(self.part[po[l]:]), nwg, s, tag="dw_hidden")
             Wp, _ = self._packs[l]
-            call("harl_mlp_bwd_dx", ptr(self.dz[cur]), ptr(self.xh[l - 1]), ptr(self.rmask[l - 1]), ptr(self.rstd[l - 1]),
-                 M, ho, hi, ptr(Wp), ptr(self.dz[1 - cur]), s, tag="bwd_dx")
+            if l == 1 and fuse_dw1:
+                call("harl_mlp_bwd_dx", ptr(self.dz[cur]), ptr(self.xh[0]), ptr(self.rmask[0]), ptr(self.rstd[0]), M, ho, hi,
+                     ptr(Wp), None, ptr(self.x0n), self.kp0, ptr(self.part[po[0]:]), nwg, s, tag="bwd_dx_dw1")
+            else:
+                call("harl_mlp_bwd_dx", ptr(self.dz[cur]), ptr(self.xh[l - 1]), ptr(self.rmask[l - 1]),
+                     ptr(self.rstd[l - 1]), M, ho, hi, ptr(Wp), ptr(self.dz[1 - cur]), None, 0, None, 0, s, tag="bwd_dx")
             cur = 1 - cur
         h0 = self.hidden_sizes[0]
         use_ln = self.use_feature_normalization
-        if self.x0n is not None:  # B = normalised inputs as written by the forward pass (ATL, zero-padded to kp0)
+        if fuse_dw1:
+            pass
+        elif self.x0n is not None:  # B = normalised inputs as written by the forward pass (ATL, zero-padded to kp0)
             call("harl_mlp_dw_partials", ptr(self.dz[cur]), 0, 0, h0, ptr(self.x0n), 0, 0, None, None, None, self.kp0, M,
                  ptr(self.part[po[0]:]), nwg, s, tag="dw_input")
         else:

@@ -116,9 +116,14 @@ int harl_mlp_fwd_fused2(const float *X, long ldx, const int64_t *idx, long M, in
 int harl_mlp_fwd_hidden(const float *xin, long M, int HI, int HO, const float *Wp, const float *bp,
                         float *xout, uint32_t *relu_mask, float *rstd, void *stream);
 /* backward through Linear(HI->HO) then the preceding relu+norm:
- *   dz_prev = relu_mask_prev ? LNbwd(Wp^T dz ; xprev, rstd_prev) : 0     (dz ATL(HO) -> dz_prev ATL(HI)) */
+ *   dz_prev = relu_mask_prev ? LNbwd(Wp^T dz ; xprev, rstd_prev) : 0     (dz ATL(HO) -> dz_prev ATL(HI))
+ * dw_part != NULL: FIRST-layer variant -- dz_prev is dz_1, whose only consumer is dW_1' = dz_1^T x0n; that GEMM is fused
+ * in (x0n = the ATL(kp0) image written by the forward pass, kp0 in {32, 64}, in_dim < kp0 so that its last pad column is
+ * the column of ones that yields db_1').  Launched with n_wg workgroups, each writing one partial [HI*kp0 + HI] in the
+ * layout of harl_mlp_dw_partials; dz_prev may then be NULL (dz_1 is not needed in HBM). */
 int harl_mlp_bwd_dx(const float *dz, const float *xprev, const uint32_t *relu_mask_prev, const float *rstd_prev,
-                    long M, int HO, int HI, const float *Wp, float *dz_prev, void *stream);
+                    long M, int HO, int HI, const float *Wp, float *dz_prev, const float *x0n, int kp0, float *dw_part,
+                    int n_wg, void *stream);
 /* weight-gradient partials: part[wg] = { dWp[HO_pad32, KP] , dbp[HO_pad32] } summed over the samples the
  * workgroup processed; a_kind: 0 = ATL(HO) dz, 1 = row-major [M, lda] (head gradients, HO <= 32);
  * b_kind: 0 = ATL(K) x_hat, 1 = raw X[idx] rows (ldx, D=K) normalised with mu0/rstd0 (NULL = no LN0).

@@ -68,7 +68,7 @@ def main():
         ("fwd_fused2_D18_train", lambda: call("harl_mlp_fwd_fused2", ptr(obs), 18, None, B, 18, ptr(W1), ptr(b), 1, ptr(W), ptr(b), H, 1, ptr(xh1), ptr(mask), ptr(rstd), ptr(mu0), ptr(rstd0), ptr(xh2), ptr(mask), ptr(rstd), None, s), GF(fl + 2.0 * B * 18 * H)),
         ("fwd_fused2_D18_logp", lambda: call("harl_mlp_fwd_fused2", ptr(obs), 18, None, B, 18, ptr(W1), ptr(b), 1, ptr(W), ptr(b), H, 0, ptr(xh1), ptr(mask), ptr(rstd), ptr(mu0), ptr(rstd0), ptr(xh2), ptr(mask), ptr(rstd), None, s), GF(fl + 2.0 * B * 18 * H)),
         ("fwd_hidden", lambda: call("harl_mlp_fwd_hidden", ptr(xh1), B, H, H, ptr(W), ptr(b), ptr(xh2), ptr(mask), ptr(rstd), s), GF(fl)),
-        ("bwd_dx", lambda: call("harl_mlp_bwd_dx", ptr(dz), ptr(xh1), ptr(mask), ptr(rstd), B, H, H, ptr(W), ptr(dz2), s), GF(fl)),
+        ("bwd_dx", lambda: call("harl_mlp_bwd_dx", ptr(dz), ptr(xh1), ptr(mask), ptr(rstd), B, H, H, ptr(W), ptr(dz2), None, 0, None, 0, s), GF(fl)),
         ("dw_hidden", lambda: call("harl_mlp_dw_partials", ptr(dz), 0, 0, H, ptr(xh1), 0, 0, None, None, None, H, B, ptr(part), n_wg, s), GF(fl)),
         ("dw_head", lambda: call("harl_mlp_dw_partials", ptr(dhead), 1, 32, 5, ptr(xh2), 0, 0, None, None, None, H, B, ptr(part), n_wg, s), GB(B * (512 + 128))),
         ("dw_input_D18", lambda: call("harl_mlp_dw_partials", ptr(dz), 0, 0, H, ptr(obs), 1, 18, None, ptr(mu0), ptr(rstd0), 18, B, ptr(part), n_wg, s), GB(B * (512 + 72 + 8))),

@@ -58,6 +58,10 @@ def main():
     rets, advs = torch.empty(T + 1, N, device=dev), torch.empty(T, N, device=dev)
     P = 20142
     pp, gg, mm, vv = rn(P), rn(P), torch.zeros(P, device=dev), torch.zeros(P, device=dev)
+    x0n32 = rn(mp * 32)
+    ps_f = torch.zeros(n_wg * 48, device=dev)
+    part_h = torch.empty(n_wg * (32 * H + 32), device=dev)
+    part_1 = torch.empty(n_wg * (H * 32 + H), device=dev)
     s = stream()
     GF = lambda f: ("TFLOP/s", f / 1e12)  # noqa: E731
     GB = lambda f: ("TB/s", f / 1e12)  # noqa: E731
@@ -69,6 +73,7 @@ def main():
         ("fwd_fused2_D18_logp", lambda: call("harl_mlp_fwd_fused2", ptr(obs), 18, None, B, 18, ptr(W1), ptr(b), 1, ptr(W), ptr(b), H, 0, ptr(xh1), ptr(mask), ptr(rstd), ptr(mu0), ptr(rstd0), ptr(xh2), ptr(mask), ptr(rstd), None, s), GF(fl + 2.0 * B * 18 * H)),
         ("fwd_hidden", lambda: call("harl_mlp_fwd_hidden", ptr(xh1), B, H, H, ptr(W), ptr(b), ptr(xh2), ptr(mask), ptr(rstd), s), GF(fl)),
         ("bwd_dx", lambda: call("harl_mlp_bwd_dx", ptr(dz), ptr(xh1), ptr(mask), ptr(rstd), B, H, H, ptr(W), ptr(dz2), None, 0, None, 0, s), GF(fl)),
+        ("bwd_dx_dw1_fused", lambda: call("harl_mlp_bwd_dx", ptr(dz), ptr(xh1), ptr(mask), ptr(rstd), B, H, H, ptr(W), None, ptr(x0n32), 32, ptr(part_1), n_wg, s), GF(fl + 2.0 * B * H * 18)),
         ("dw_hidden", lambda: call("harl_mlp_dw_partials", ptr(dz), 0, 0, H, ptr(xh1), 0, 0, None, None, None, H, B, ptr(part), n_wg, s), GF(fl)),
         ("dw_head", lambda: call("harl_mlp_dw_partials", ptr(dhead), 1, 32, 5, ptr(xh2), 0, 0, None, None, None, H, B, ptr(part), n_wg, s), GB(B * (512 + 128))),
         ("dw_input_D18", lambda: call("harl_mlp_dw_partials", ptr(dz), 0, 0, H, ptr(obs), 1, 18, None, ptr(mu0), ptr(rstd0), 18, B, ptr(part), n_wg, s), GB(B * (512 + 72 + 8))),
@@ -78,6 +83,8 @@ def main():
         ("reduce_partials", lambda: call("harl_reduce_partials", ptr(part), n_wg, H * H + H, ptr(dwp), s), GB(n_wg * (H * H + H) * 4)),
         ("actor_head_logp", lambda: call("harl_actor_head_logp", ptr(xh2), B, H, ptr(Wh), ptr(bh), ptr(ls), 1.0, 0.5, 0, 5, ptr(actions), None, ptr(logp_out), None, None, 0, None, 0, 0, s), GB(B * (512 + 40))),
         ("actor_head_loss", lambda: call("harl_actor_head_loss", ptr(xh2), ptr(mask), ptr(rstd), B, H, ptr(Wh), ptr(bh), ptr(ls), 1.0, 0.5, 0, 5, None, ptr(actions), None, ptr(old_logp), ptr(adv), None, ptr(factor), ptr(active), 0.2, 0.01, 0, 0, 0, 0, None, ptr(dz2), ptr(dhead), ptr(ps), None, 0, s), GB(B * (512 + 512 + 128 + 60))),
+        ("actor_head_loss_fused_dw", lambda: call("harl_actor_head_loss", ptr(xh2), ptr(mask), ptr(rstd), B, H, ptr(Wh), ptr(bh), ptr(ls), 1.0, 0.5, 0, 5, None, ptr(actions), None, ptr(old_logp), ptr(adv), None, ptr(factor), ptr(active), 0.2, 0.01, 0, 0, 0, 0, None, ptr(dz2), None, ptr(ps_f), ptr(part_h), n_wg, s), GB(B * (512 + 512 + 20 + 60))),
+        ("critic_head_loss_fused_dw", lambda: call("harl_critic_head_loss", ptr(xh2), ptr(mask), ptr(rstd), B, H, ptr(Wv), ptr(bv), None, ptr(vp), ptr(ret), ptr(vn), 0.2, 1, 1, 10.0, 0, 0, ptr(dz2), None, ptr(ps_f), ptr(part_h), n_wg, s), GB(B * (512 + 512 + 20 + 8))),
         ("critic_head_loss", lambda: call("harl_critic_head_loss", ptr(xh2), ptr(mask), ptr(rstd), B, H, ptr(Wv), ptr(bv), None, ptr(vp), ptr(ret), ptr(vn), 0.2, 1, 1, 10.0, 0, 0, ptr(dz2), ptr(dhead), ptr(ps), None, 0, s), GB(B * (512 + 512 + 128 + 8))),
         ("critic_head_values", lambda: call("harl_critic_head_values", ptr(xh2), B, H, ptr(Wv), ptr(bv), ptr(vals), s), GB(B * 516)),
         ("gae_returns", lambda: call("harl_gae_returns", ptr(rew), ptr(vpT), ptr(mk), ptr(mk), ptr(vpT[-1].contiguous()), ptr(vn), ptr(rets), ptr(advs), T, N, 0.99, 0.9405, 1, 1, 0, s), GB(B * 24)),

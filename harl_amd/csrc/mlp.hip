@@ -15,6 +15,7 @@
 //
 // Weights live in LDS for the lifetime of a persistent workgroup (<= 66 KiB -> 2 workgroups per CU).
 #include "common.h"
+#include "split_mfma.h"
 #include "../../include/harl_hip.h"
 
 using namespace harl;
@@ -116,104 +117,41 @@ __device__ __forceinline__ void ln_jac_store(f32x16 (&acc)[HO / 32], const float
 
 // =============================================================================================
 // hidden layer forward:  xout = norm(relu(Wp * xin + bp))       (ATL(HI) -> ATL(HO))
-// LDS: Wl[HO][HI+1] (odd row stride: the A-operand read "lane i -> row 32t+i, fixed k" hits 32
-// distinct banks) + bias.  Per wave-slab: HO/32 * HI/2 MFMAs, one ds_read_b32 each.
+// GEMM on the bf16 matrix pipe with the exact three-way operand split (split_mfma.h).  LDS: the three weight images
+// (3 * HO * HI * 2 B = 96 KiB for 128 x 128 -> one workgroup per CU, one wave per SIMD with the whole register file) +
+// bias.  Per wave-slab: the slab's activations arrive as 16 float4 per lane (issued one slab ahead), are split once
+// (~5 VALU ops per value), and feed HO/32 * HI/16 * 6 MFMAs; HBM-bound (profiles/r01_mfma_bf16x3.txt).
 // =============================================================================================
+constexpr bool split_one_wg(int ho, int hi, size_t extra = 0) { return 2 * (split_image_bytes(ho, hi) + ho * 4 + extra) > 160 * 1024; }
+
 template <int HI, int HO>
-__global__ __launch_bounds__(WG_THREADS, 2) void k_fwd_hidden(const float *__restrict__ xin,
-                                                              const float *__restrict__ Wp,
-                                                              const float *__restrict__ bp, float *__restrict__ xout,
-                                                              uint32_t *__restrict__ mask_out,
-                                                              float *__restrict__ rstd_out, long n_slabs) {
+__global__ __launch_bounds__(WG_THREADS, split_one_wg(HO, HI) ? 1 : 2) void k_fwd_hidden(
+    const float *__restrict__ xin, const float *__restrict__ Wp, const float *__restrict__ bp, float *__restrict__ xout,
+    uint32_t *__restrict__ mask_out, float *__restrict__ rstd_out, long n_slabs) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  constexpr int LDW = HI + 1;
-  float *Wl = lds;
-  float *bl = lds + HO * LDW;
-  stage_matrix<HO, HI, LDW, WG_THREADS>(Wl, Wp);
+  constexpr int MT = HO / 32, NJ = HI / 16, NR = HI / 2;
+  u32x4 *img = reinterpret_cast<u32x4 *>(lds);
+  float *bl = reinterpret_cast<float *>(img + 3 * MT * NJ * 64);
+  stage_split_matrix<HO, HI, false, WG_THREADS>(img, Wp);
   for (int e = threadIdx.x; e < HO; e += WG_THREADS) bl[e] = bp[e];
   __syncthreads();
 
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int i = lane & 31, h = lane >> 5;
-  const float *wl_lane = Wl + i * LDW + 4 * h;
-  static_assert((HI / 8) % 8 == 0, "ping-pong ring prefetch consumes 8 float4 per outer step");
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
   const long slab0 = (long)blockIdx.x * WAVES_PER_WG + wave, slab_stride = (long)gridDim.x * WAVES_PER_WG;
-  constexpr int NQ = HI / 8, NT_ = HO / 32;
-  // prefetch distance of the activation stream in q-steps (float4 per lane): 8 for HI = 128.  With 4 the chip holds
-  // only 8 MB of loads in flight (2 waves/SIMD x 4 KB), which caps the stream at ~3.3 TB/s for ~2.5 us loaded latency.
-  constexpr int RD = NQ >= 16 ? 8 : 4;
-  f32x4 ringA[RD], ringB[RD];
-  float aX[4 * NT_], aY[4 * NT_];
-  {
-    const f32x4 *p0 = reinterpret_cast<const f32x4 *>(xin + (slab0 < n_slabs ? slab0 : 0) * (long)(HI * SLAB)) + lane;
-#pragma unroll
-    for (int u = 0; u < RD; ++u) ringA[u] = p0[u * WAVE];
-  }
-  // one LDS base address per output tile, opaque to the compiler: every fragment read is then base_t + a small
-  // immediate (ds_read2_b32 offsets reach 1020 B).  With the tile offsets visible as constants hipcc keeps ONE base
-  // and re-adds 16-48 KiB literals in front of most reads (~150 v_add_u32 per slab, and VALU is not free here).
-  int toff[NT_];
-#pragma unroll
-  for (int t = 0; t < NT_; ++t) {
-    toff[t] = 32 * t * LDW;
-    asm volatile("" : "+v"(toff[t]));
-  }
-  auto lds_frag = [&](int q, float (&a)[4 * NT_]) {  // weight fragments of q-step q: W'[32t+i][f(4q+c, h)]
-    const int qo_ = 32 * (q >> 2) + 8 * (q & 3);
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-#pragma unroll
-      for (int t = 0; t < NT_; ++t) a[c * NT_ + t] = wl_lane[toff[t] + qo_ + c];
-  };
-  lds_frag(0, aX);
+  const u32x4 *wl = img + lane;
+  float raw[NR];
+  atl_load<HI>(xin, slab0 < n_slabs ? slab0 : 0, lane, raw);
   for (long slab = slab0; slab < n_slabs; slab += slab_stride) {
-    const f32x4 *xp = reinterpret_cast<const f32x4 *>(xin + slab * (long)(HI * SLAB)) + lane;
-    const long nslab = slab + slab_stride < n_slabs ? slab + slab_stride : slab;
-    const f32x4 *xp_next = reinterpret_cast<const f32x4 *>(xin + nslab * (long)(HI * SLAB)) + lane;
-    f32x16 acc[HO / 32];
+    u32x4 x1[NJ], x2[NJ], x3[NJ];
+    split_acts<NR>(raw, x1, x2, x3);
+    // the next slab's activations: a whole slab of MFMA time (> 6000 cycles) to land
+    atl_load<HI>(xin, slab + slab_stride < n_slabs ? slab + slab_stride : slab, lane, raw);
+    f32x16 acc[MT];
 #pragma unroll
-    for (int t = 0; t < HO / 32; ++t)
+    for (int t = 0; t < MT; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[t][r] = bl[32 * t + (r & 3) + 8 * (r >> 2) + 4 * h];
-    auto mfma16 = [&](const f32x4 &xv, const float (&a)[4 * NT_]) {
-#pragma unroll
-      for (int c = 0; c < 4; ++c)
-#pragma unroll
-        for (int t = 0; t < NT_; ++t) acc[t] = MFMA(a[c * NT_ + t], xv[c], acc[t]);
-    };
-    // Software pipeline, pinned with sched_barrier(0) so hipcc cannot undo it:
-    //  * x_hat_in streams through two 4-deep float4 register rings in ping-pong: while ring A is consumed, the
-    //    float4s for 4 q-steps later (>= 4096 MFMA cycles ~ 1.7 us) are loaded into ring B and vice versa, rolling
-    //    over into the next slab.  (Refilling the slot just consumed makes hipcc load into a temporary and copy at the
-    //    loop back-edge behind s_waitcnt vmcnt(0): full HBM latency exposed every 64 MFMAs -- measured MFMA pipe 60 %
-    //    busy, waves 46 % of their time in s_waitcnt.)
-    //  * the 16 weight fragments of q-step q+1 are read from LDS into a second register set while the 16 MFMAs of
-    //    q-step q run (the fragment stream wraps around, weights do not depend on the slab).
-    //  The outer loop stays rolled: a fully unrolled body lets the scheduler hoist all HI*HO/64 LDS reads and spill.
-#define FWD_SUBSTEP(u, q, CONS, PROD, ACUR, ANXT)                                                              \
-    PROD[u] = (q) + RD < NQ ? xp[((q) + RD) * WAVE] : xp_next[((q) + RD - NQ) * WAVE];                         \
-    lds_frag(((q) + 1) % NQ, ANXT);                                                                            \
-    __builtin_amdgcn_sched_barrier(0);                                                                         \
-    mfma16(CONS[u], ACUR);
-#define FWD_SUB4(u0, q0, CONS, PROD)                                                                           \
-    FWD_SUBSTEP((u0) + 0, (q0) + 0, CONS, PROD, aX, aY)                                                        \
-    FWD_SUBSTEP((u0) + 1, (q0) + 1, CONS, PROD, aY, aX)                                                        \
-    FWD_SUBSTEP((u0) + 2, (q0) + 2, CONS, PROD, aX, aY)                                                        \
-    FWD_SUBSTEP((u0) + 3, (q0) + 3, CONS, PROD, aY, aX)
-#pragma unroll 1
-    for (int qo = 0; qo < NQ; qo += 2 * RD) {
-      if constexpr (RD == 8) {
-        FWD_SUB4(0, qo + 0, ringA, ringB)
-        FWD_SUB4(4, qo + 4, ringA, ringB)
-        FWD_SUB4(0, qo + 8, ringB, ringA)
-        FWD_SUB4(4, qo + 12, ringB, ringA)
-      } else {
-        FWD_SUB4(0, qo + 0, ringA, ringB)
-        FWD_SUB4(0, qo + 4, ringB, ringA)
-      }
-    }
-#undef FWD_SUB4
-#undef FWD_SUBSTEP
+    split_gemm<MT, NJ>(wl, x1, x2, x3, acc, [](int) {});
     relu_norm_store<HO>(acc, lane, slab, xout, mask_out, rstd_out);
   }
 }
@@ -514,8 +452,8 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_fwd_input_staged(const float 
 // configuration.  x_hat_1 never leaves the registers between the layers: the accumulator image of layer 1 IS the B
 // operand of layer 2 (common.h), so the second GEMM runs straight out of the register file; x_hat_1 is written to
 // HBM only when a backward pass will need it (store1).  512-thread workgroups (8 waves) share ONE LDS copy of both
-// weight matrices (W1'^T + W2' + per-wave row staging <= 155 KiB), 1 workgroup per CU = 2 waves per SIMD.
-// Layer 2 is the pinned software pipeline of k_fwd_hidden with the global ring replaced by registers.
+// weight matrices (W1'^T fp32 + the three bf16 images of W2' + per-wave row staging = 147 KiB), 1 workgroup per CU =
+// 2 waves per SIMD.  Layer 1 (K <= 32) stays on the fp32 MFMA; layer 2 is split_gemm() fed from registers.
 // =============================================================================================
 constexpr int FUSED_WAVES = 8;
 
@@ -528,7 +466,7 @@ __global__ __launch_bounds__(64 * FUSED_WAVES, 2) void k_fwd_fused2(
     float *__restrict__ x0n_out, long n_slabs) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int NTHR = 64 * FUSED_WAVES;
-  constexpr int LDW = H + 1, NQ = H / 8, NT_ = H / 32, NPF = SLAB / RPI;
+  constexpr int NT_ = H / 32, NJ = H / 16, NPF = SLAB / RPI;
   // compile-time row stride (odd) so every LDS address below is ONE per-lane base + an immediate offset; with a
   // run-time stride hipcc keeps ~30 loop-invariant address VGPRs alive and spills them (measured: 46 % s_waitcnt)
   constexpr int krows = NCH * 32, LDX = NCH * 32 + 1;
@@ -536,9 +474,9 @@ __global__ __launch_bounds__(64 * FUSED_WAVES, 2) void k_fwd_fused2(
   float *b1l = xs + FUSED_WAVES * SLAB * LDX;   // [H]
   float *b2l = b1l + H;                         // [H]
   float *Wt = b2l + H;                          // [krows][H]   W1'^T
-  float *W2l = Wt + krows * H;                  // [H][H+1]
+  u32x4 *w2img = reinterpret_cast<u32x4 *>(Wt + krows * H);  // three bf16 images of W2' (split_mfma.h)
   for (int e = threadIdx.x; e < FUSED_WAVES * SLAB * LDX; e += NTHR) xs[e] = 0.f;  // pad columns stay zero
-  stage_matrix<H, H, LDW, NTHR>(W2l, W2p);
+  stage_split_matrix<H, H, false, NTHR>(w2img, W2p);
   for (int e = threadIdx.x; e < H; e += NTHR) {
     b2l[e] = b2p[e];
     b1l[e] = b1p[e];
@@ -553,7 +491,7 @@ __global__ __launch_bounds__(64 * FUSED_WAVES, 2) void k_fwd_fused2(
   const int i = lane & 31, h = lane >> 5;
   float *xw = xs + wave * SLAB * LDX;
   const int lane_row = RPI == 2 ? h : 0, lane_k = RPI == 2 ? i : lane;
-  const float *wl_lane = W2l + i * LDW + 4 * h;
+  const u32x4 *wl = w2img + lane;
   const long slab0 = (long)blockIdx.x * FUSED_WAVES + wave, slab_stride = (long)gridDim.x * FUSED_WAVES;
 
   float pf[NPF];  // next slab's rows, in flight while this slab computes
@@ -580,19 +518,6 @@ __global__ __launch_bounds__(64 * FUSED_WAVES, 2) void k_fwd_fused2(
     // right behind each load made hipcc wait for every load individually (s_waitcnt vmcnt(0) x NPF per slab)
 #pragma unroll
     for (int u = 0; u < NPF; ++u) pf[u] = X[(long)rows[u] * ldx + lane_kc];
-  };
-  int toff[NT_];  // opaque per-tile LDS offsets: fragment reads become base_t + small immediate (see k_fwd_hidden)
-#pragma unroll
-  for (int t = 0; t < NT_; ++t) {
-    toff[t] = 32 * t * LDW;
-    asm volatile("" : "+v"(toff[t]));
-  }
-  auto lds_frag = [&](int q, float (&a)[4 * NT_]) {
-    const int qo_ = 32 * (q >> 2) + 8 * (q & 3);
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-#pragma unroll
-      for (int t = 0; t < NT_; ++t) a[c * NT_ + t] = wl_lane[toff[t] + qo_ + c];
   };
   if (slab0 < n_slabs) prefetch_rows(slab0);
 
@@ -703,27 +628,16 @@ __global__ __launch_bounds__(64 * FUSED_WAVES, 2) void k_fwd_fused2(
     if (slab + slab_stride < n_slabs) prefetch_rows(slab + slab_stride);
     __builtin_amdgcn_sched_barrier(0);
 
-    // ---- layer 2 straight out of the register file
+    // ---- layer 2 straight out of the register file, on the bf16 pipe: x_hat_1 is split once (exactly) into three
+    // bf16 operands per k-step, the three weight images sit in LDS
+    u32x4 y1[NJ], y2[NJ], y3[NJ];
+    split_acts<H / 2>(x1, y1, y2, y3);
     f32x16 acc[NT_];
 #pragma unroll
     for (int t = 0; t < NT_; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[t][r] = b2l[32 * t + (r & 3) + 8 * (r >> 2) + 4 * h];
-    // one fragment register set, each register refilled for q-step q+1 right after the MFMA that read it has issued
-    // (the WAR dependency pins the refill; its LDS latency hides under the following 15 MFMAs)
-    float aX[4 * NT_];
-    lds_frag(0, aX);
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      const int qn_ = 32 * ((q + 1) >> 2) + 8 * ((q + 1) & 3);
-#pragma unroll
-      for (int c = 0; c < 4; ++c)
-#pragma unroll
-        for (int t = 0; t < NT_; ++t) {
-          acc[t] = MFMA(aX[c * NT_ + t], x1[4 * q + c], acc[t]);
-          if (q + 1 < NQ) aX[c * NT_ + t] = wl_lane[toff[t] + qn_ + c];
-        }
-    }
+    split_gemm<NT_, NJ>(wl, y1, y2, y3, acc, [](int) {});
     relu_norm_store<H>(acc, lane, slab, x2out, mask2, rstd2);
   }
 }
@@ -739,40 +653,29 @@ __global__ __launch_bounds__(64 * FUSED_WAVES, 2) void k_fwd_fused2(
 // (ATL(32*KT), last pad column = ones -> db_1' for free) go through a wave-private LDS transpose and 64*KT extra MFMAs per
 // slab; dz_1 is never written to HBM and the separate harl_mlp_dw_partials pass over it disappears.  One workgroup per
 // CU (LDS: weights + staging), per-workgroup partials in the layout of harl_mlp_dw_partials.
+constexpr int bwd_pass_width(int kt) { return kt == 1 ? 64 : 32; }  // dz_1 features staged per pass of the fused dW_1
+constexpr size_t bwd_stage_floats(int kt) { return (size_t)SLAB * (bwd_pass_width(kt) + 4) + (size_t)SLAB * (32 * kt + 4); }
+
 template <int HO, int HI, int KT = 0>
-__global__ __launch_bounds__(WG_THREADS, KT > 0 ? 1 : 2) void k_bwd_dx(
+__global__ __launch_bounds__(WG_THREADS, (KT > 0 || split_one_wg(HI, HO)) ? 1 : 2) void k_bwd_dx(
     const float *__restrict__ dz, const float *__restrict__ xprev, const uint32_t *__restrict__ mask_prev,
     const float *__restrict__ rstd_prev, const float *__restrict__ Wp, float *__restrict__ dz_prev, long n_slabs,
     const float *__restrict__ x0n = nullptr, float *__restrict__ dw_part = nullptr) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float *Wl = lds;  // [HO][HI] row-major
-  constexpr int HX = 64 + 4, KPF = 32 * (KT > 0 ? KT : 1), LDB = KPF + 4;
-  constexpr int STAGE_FLOATS = SLAB * HX + SLAB * LDB;  // per wave: a 64-feature half of dz_1, and the x0n tile
-  float *stg = Wl + HO * HI;
-  stage_matrix<HO, HI, HI, WG_THREADS>(Wl, Wp);
+  // dx_hat = Wp^T dz on the bf16 pipe (split_mfma.h): GEMM rows = input features, k = output features
+  constexpr int MT = HI / 32, NJ = HO / 16, NRO = HO / 2;
+  u32x4 *img = reinterpret_cast<u32x4 *>(lds);
+  constexpr int PW = bwd_pass_width(KT), HX = PW + 4, MP = PW / 32, KPF = 32 * (KT > 0 ? KT : 1), LDB = KPF + 4;
+  constexpr int STAGE_FLOATS = SLAB * HX + SLAB * LDB;  // per wave: a PW-feature slice of dz_1, and the x0n tile
+  float *stg = reinterpret_cast<float *>(img + 3 * MT * NJ * 64);
+  stage_split_matrix<HO, HI, true, WG_THREADS>(img, Wp);
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 31, h = lane >> 5;
-  const float *wl_lane = Wl + 4 * h * HI + i;
-  static_assert((HO / 8) % 8 == 0, "ping-pong ring prefetch consumes 8 float4 per outer step");
   const long slab0 = (long)blockIdx.x * WAVES_PER_WG + wave, slab_stride = (long)gridDim.x * WAVES_PER_WG;
-  constexpr int NQ = HO / 8, NT_ = HI / 32;
-  constexpr int RD = NQ >= 16 ? 8 : 4;  // prefetch distance in q-steps (see k_fwd_hidden)
-  f32x4 ringA[RD], ringB[RD];
-  float aX[4 * NT_], aY[4 * NT_];
-  {
-    const f32x4 *p0 = reinterpret_cast<const f32x4 *>(dz + (slab0 < n_slabs ? slab0 : 0) * (long)(HO * SLAB)) + lane;
-#pragma unroll
-    for (int u = 0; u < RD; ++u) ringA[u] = p0[u * WAVE];
-  }
-  auto lds_frag = [&](int q, float (&a)[4 * NT_]) {  // W'^T fragments: W'[f(4q+c, h)][32t+i]
-    const float *wq = wl_lane + (32 * (q >> 2) + 8 * (q & 3)) * HI;
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-#pragma unroll
-      for (int t = 0; t < NT_; ++t) a[c * NT_ + t] = wq[c * HI + 32 * t];
-  };
-  lds_frag(0, aX);
+  const u32x4 *wl = img + lane;
+  float raw[NRO];
+  atl_load<HO>(dz, slab0 < n_slabs ? slab0 : 0, lane, raw);
   f32x16 acc1[KT > 0 ? HI / 32 : 1][KT > 0 ? KT : 1];  // fused first-layer weight gradient, persistent over the slabs
   if constexpr (KT > 0) {
 #pragma unroll
@@ -783,49 +686,25 @@ __global__ __launch_bounds__(WG_THREADS, KT > 0 ? 1 : 2) void k_bwd_dx(
         for (int r = 0; r < 16; ++r) acc1[mt][n][r] = 0.f;
   }
   for (long slab = slab0; slab < n_slabs; slab += slab_stride) {
-    const f32x4 *gp = reinterpret_cast<const f32x4 *>(dz + slab * (long)(HO * SLAB)) + lane;
-    const long nslab = slab + slab_stride < n_slabs ? slab + slab_stride : slab;
-    const f32x4 *gp_next = reinterpret_cast<const f32x4 *>(dz + nslab * (long)(HO * SLAB)) + lane;
+    u32x4 g1[NJ], g2[NJ], g3[NJ];
+    split_acts<NRO>(raw, g1, g2, g3);
+    atl_load<HO>(dz, slab + slab_stride < n_slabs ? slab + slab_stride : slab, lane, raw);  // one slab ahead
     // operands of the LayerNorm backward: issued now, consumed after the MFMA loop (latency fully hidden)
     float xh[HI / 2];
     atl_load<HI>(xprev, slab, lane, xh);
     const float rstd = rstd_prev[slab * SLAB + i];
+    f32x4 x0r[KT > 0 ? KPF / 8 : 1];
+    if constexpr (KT > 0) {
+      const f32x4 *bp = reinterpret_cast<const f32x4 *>(x0n + slab * (long)(KPF * SLAB)) + lane;
+#pragma unroll
+      for (int q = 0; q < KPF / 8; ++q) x0r[q] = bp[q * WAVE];
+    }
     f32x16 acc[HI / 32];
 #pragma unroll
     for (int t = 0; t < HI / 32; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    auto mfma16 = [&](const f32x4 &gv, const float (&a)[4 * NT_]) {
-#pragma unroll
-      for (int c = 0; c < 4; ++c)
-#pragma unroll
-        for (int t = 0; t < NT_; ++t) acc[t] = MFMA(a[c * NT_ + t], gv[c], acc[t]);
-    };
-    // same pinned software pipeline as k_fwd_hidden (ping-pong global rings + double-buffered LDS fragments)
-#define BWD_SUBSTEP(u, q, CONS, PROD, ACUR, ANXT)                                                              \
-    PROD[u] = (q) + RD < NQ ? gp[((q) + RD) * WAVE] : gp_next[((q) + RD - NQ) * WAVE];                         \
-    lds_frag(((q) + 1) % NQ, ANXT);                                                                            \
-    __builtin_amdgcn_sched_barrier(0);                                                                         \
-    mfma16(CONS[u], ACUR);
-#define BWD_SUB4(u0, q0, CONS, PROD)                                                                           \
-    BWD_SUBSTEP((u0) + 0, (q0) + 0, CONS, PROD, aX, aY)                                                        \
-    BWD_SUBSTEP((u0) + 1, (q0) + 1, CONS, PROD, aY, aX)                                                        \
-    BWD_SUBSTEP((u0) + 2, (q0) + 2, CONS, PROD, aX, aY)                                                        \
-    BWD_SUBSTEP((u0) + 3, (q0) + 3, CONS, PROD, aY, aX)
-#pragma unroll 1
-    for (int qo = 0; qo < NQ; qo += 2 * RD) {
-      if constexpr (RD == 8) {
-        BWD_SUB4(0, qo + 0, ringA, ringB)
-        BWD_SUB4(4, qo + 4, ringA, ringB)
-        BWD_SUB4(0, qo + 8, ringB, ringA)
-        BWD_SUB4(4, qo + 12, ringB, ringA)
-      } else {
-        BWD_SUB4(0, qo + 0, ringA, ringB)
-        BWD_SUB4(0, qo + 4, ringB, ringA)
-      }
-    }
-#undef BWD_SUB4
-#undef BWD_SUBSTEP
+    split_gemm<MT, NJ>(wl, g1, g2, g3, acc, [](int) {});
     float dx[HI / 2];
 #pragma unroll
     for (int R = 0; R < HI / 2; ++R) dx[R] = acc[R >> 4][R & 15];
@@ -836,17 +715,14 @@ __global__ __launch_bounds__(WG_THREADS, KT > 0 ? 1 : 2) void k_bwd_dx(
       ln_bwd_relu_regs<HI>(dx, xh, mask_prev, rstd, lane, slab, out);
       if (dz_prev) atl_store<HI>(dz_prev, slab, lane, out);
       float *tx = stg + wave * STAGE_FLOATS, *tb = tx + SLAB * HX;
-      {  // normalised-input tile -> tb[sample][column]
-        const f32x4 *bp = reinterpret_cast<const f32x4 *>(x0n + slab * (long)(KPF * SLAB)) + lane;
 #pragma unroll
-        for (int q = 0; q < KPF / 8; ++q)
-          *reinterpret_cast<f32x4 *>(tb + i * LDB + 32 * (q >> 2) + 8 * (q & 3) + 4 * h) = bp[q * WAVE];
-      }
+      for (int q = 0; q < KPF / 8; ++q)  // normalised-input tile -> tb[sample][column]
+        *reinterpret_cast<f32x4 *>(tb + i * LDB + 32 * (q >> 2) + 8 * (q & 3) + 4 * h) = x0r[q];
 #pragma unroll
-      for (int half = 0; half < HI / 64; ++half) {
+      for (int pass = 0; pass < HI / PW; ++pass) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const int R0 = 4 * (8 * half + q);
+        for (int q = 0; q < PW / 8; ++q) {
+          const int R0 = (PW / 2) * pass + 4 * q;
           *reinterpret_cast<f32x4 *>(tx + i * HX + 32 * (q >> 2) + 8 * (q & 3) + 4 * h) =
               f32x4{out[R0], out[R0 + 1], out[R0 + 2], out[R0 + 3]};
         }
@@ -858,10 +734,10 @@ __global__ __launch_bounds__(WG_THREADS, KT > 0 ? 1 : 2) void k_bwd_dx(
 #pragma unroll
           for (int n = 0; n < KT; ++n) bv[n] = tb[(2 * t + h) * LDB + 32 * n + i];
 #pragma unroll
-          for (int m = 0; m < 2; ++m) {
+          for (int m = 0; m < MP; ++m) {
             const float a = tx[(2 * t + h) * HX + 32 * m + i];
 #pragma unroll
-            for (int n = 0; n < KT; ++n) acc1[2 * half + m][n] = MFMA(a, bv[n], acc1[2 * half + m][n]);
+            for (int n = 0; n < KT; ++n) acc1[MP * pass + m][n] = MFMA(a, bv[n], acc1[MP * pass + m][n]);
           }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1270,7 +1146,7 @@ extern "C" int harl_mlp_fwd_fused2(const float *X, long ldx, const int64_t *idx,
   if (H != 128 && H != 64) return bad("harl_mlp_fwd_fused2: hidden width must be 64 or 128");
   const long n_slabs = n_slabs_of(M);
   const int nch = (D + 31) / 32;
-  const size_t shm = ((size_t)H * (H + 1) + 2 * H + (size_t)nch * 32 * H + (size_t)FUSED_WAVES * SLAB * (nch * 32 + 1)) * sizeof(float);
+  const size_t shm = split_image_bytes(H, H) + (2 * H + (size_t)nch * 32 * H + (size_t)FUSED_WAVES * SLAB * (nch * 32 + 1)) * sizeof(float);
   long wgs = (n_slabs + FUSED_WAVES - 1) / FUSED_WAVES;
   const int grid = (int)(wgs < 256 ? (wgs < 1 ? 1 : wgs) : 256);
   hipStream_t s = (hipStream_t)stream;
@@ -1289,16 +1165,17 @@ extern "C" int harl_mlp_fwd_hidden(const float *xin, long M, int HI, int HO, con
                                    float *xout, uint32_t *relu_mask, float *rstd, void *stream) {
   if (M <= 0) return 0;
   const long n_slabs = n_slabs_of(M);
-  const size_t shm = ((size_t)HO * (HI + 1) + HO) * sizeof(float);
-  const int grid = persistent_grid(n_slabs, 2);
+  const size_t shm = split_image_bytes(HO, HI) + (size_t)HO * sizeof(float);
+  const int grid = persistent_grid(n_slabs, split_one_wg(HO, HI) ? 1 : 2);
   hipStream_t s = (hipStream_t)stream;
 #define L(a, b)                                                                                                  \
+  allow_big_lds(k_fwd_hidden<a, b>, shm);                                                                        \
   hipLaunchKernelGGL((k_fwd_hidden<a, b>), dim3(grid), dim3(WG_THREADS), shm, s, xin, Wp, bp, xout, relu_mask, rstd, \
                      n_slabs)
-  if (HI == 128 && HO == 128) L(128, 128);
-  else if (HI == 64 && HO == 64) L(64, 64);
-  else if (HI == 128 && HO == 64) L(128, 64);
-  else if (HI == 64 && HO == 128) L(64, 128);
+  if (HI == 128 && HO == 128) { L(128, 128); }
+  else if (HI == 64 && HO == 64) { L(64, 64); }
+  else if (HI == 128 && HO == 64) { L(128, 64); }
+  else if (HI == 64 && HO == 128) { L(64, 128); }
   else return bad("harl_mlp_fwd_hidden: widths must be 64 or 128");
 #undef L
   return check_launch("harl_mlp_fwd_hidden");
@@ -1315,9 +1192,9 @@ extern "C" int harl_mlp_bwd_dx(const float *dz, const float *xprev, const uint32
       return bad("harl_mlp_bwd_dx: fused first-layer gradient needs x0n, kp0 in {32, 64} and n_wg > 0");
 #define LF(a, b, kt)                                                                                              \
   {                                                                                                               \
-    size_t fl = (size_t)WAVES_PER_WG * (SLAB * (64 + 4) + SLAB * (32 * kt + 4));                                  \
+    size_t fl = (size_t)WAVES_PER_WG * bwd_stage_floats(kt);                                                      \
     if (fl < (size_t)b * 32 * kt) fl = (size_t)b * 32 * kt;                                                       \
-    const size_t shm = ((size_t)a * b + fl) * sizeof(float);                                                      \
+    const size_t shm = split_image_bytes(b, a) + fl * sizeof(float);                                              \
     allow_big_lds(k_bwd_dx<a, b, kt>, shm);                                                                       \
     hipLaunchKernelGGL((k_bwd_dx<a, b, kt>), dim3(n_wg), dim3(WG_THREADS), shm, s, dz, xprev, relu_mask_prev,      \
                        rstd_prev, Wp, dz_prev, n_slabs, x0n, dw_part);                                            \
@@ -1331,15 +1208,16 @@ extern "C" int harl_mlp_bwd_dx(const float *dz, const float *xprev, const uint32
 #undef LF
     return check_launch("harl_mlp_bwd_dx");
   }
-  const size_t shm = (size_t)HO * HI * sizeof(float);
-  const int grid = persistent_grid(n_slabs, 2);
+  const size_t shm = split_image_bytes(HI, HO);
+  const int grid = persistent_grid(n_slabs, split_one_wg(HI, HO) ? 1 : 2);
 #define L(a, b)                                                                                                    \
+  allow_big_lds(k_bwd_dx<a, b>, shm);                                                                              \
   hipLaunchKernelGGL((k_bwd_dx<a, b>), dim3(grid), dim3(WG_THREADS), shm, s, dz, xprev, relu_mask_prev, rstd_prev, Wp, \
                      dz_prev, n_slabs, nullptr, nullptr)
-  if (HO == 128 && HI == 128) L(128, 128);
-  else if (HO == 64 && HI == 64) L(64, 64);
-  else if (HO == 128 && HI == 64) L(128, 64);
-  else if (HO == 64 && HI == 128) L(64, 128);
+  if (HO == 128 && HI == 128) { L(128, 128); }
+  else if (HO == 64 && HI == 64) { L(64, 64); }
+  else if (HO == 128 && HI == 64) { L(128, 64); }
+  else if (HO == 64 && HI == 128) { L(64, 128); }
   else return bad("harl_mlp_bwd_dx: widths must be 64 or 128");
 #undef L
   return check_launch("harl_mlp_bwd_dx");

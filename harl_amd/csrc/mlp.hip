@@ -990,6 +990,146 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_dw(const float *__restrict__ 
 }
 
 // =============================================================================================
+// weight-gradient partials of the hidden layers on the bf16 pipe (both operands ATL, widths 64 / 128).
+// The reduction index is the sample, so both operands are needed as "lane = feature, 8 consecutive samples per lane":
+// per round (ONE 32-sample slab) the four waves split the slab's (HA + HB)/8 float4 pieces, split every value exactly
+// into three bf16 (split_mfma.h) and scatter them with ds_write_b16 into per-term images [feature][32 samples] (row
+// stride 80 B: the 64-B runs written by the 32 lanes of a half and the ds_read_b128 fragment reads are both
+// conflict-free).  Each wave then owns TM x TN output tiles: 2 k-steps x 6 cross products per tile and round.
+// db' is summed in fp32 by the waves that stage dz (lane = sample) and reduced across lanes once at the end.
+// LDS 60 KiB for 128 x 128 -> 2 workgroups per CU.
+// =============================================================================================
+constexpr int DWS_ROWB = 80;  // bytes per feature row of a term image (32 samples x 2 B + 16 B pad)
+
+template <int MT, int NT>
+__global__ __launch_bounds__(WG_THREADS, 2) void k_dw_split(const float *__restrict__ a_src, const float *__restrict__ b_src,
+                                                            long n_slabs, float *__restrict__ part) {
+  using SP = DwSplit<MT, NT>;
+  constexpr int HA = 32 * MT, HB = 32 * NT, KP = HB;
+  constexpr int NPA = HA / 8, NPB = HB / 8, PER = (NPA + NPB) / WAVES_PER_WG;  // float4 pieces per lane and wave
+  static_assert((NPA + NPB) % WAVES_PER_WG == 0, "pieces divide evenly over the waves");
+  constexpr int IMG_A = HA * DWS_ROWB, IMG_B = HB * DWS_ROWB;  // bytes per term image
+  extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
+  unsigned char *Ab = ldsb;               // [3 terms][HA][80 B]
+  unsigned char *Bb = ldsb + 3 * IMG_A;   // [3 terms][HB][80 B]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  const int wm = wave % SP::WM, wn = wave / SP::WM;
+
+  // this wave's pieces: global piece index gu = wave * PER + u; gu < NPA -> dz piece q = gu, else x_hat piece q = gu - NPA
+  f32x4 pr[PER];
+  float dbacc[PER][4];
+#pragma unroll
+  for (int u = 0; u < PER; ++u)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) dbacc[u][c] = 0.f;
+  auto prefetch = [&](long slab) {
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int gu = wave * PER + u;
+      const bool is_a = gu < NPA;
+      const float *src = is_a ? a_src + slab * (long)(HA * SLAB) : b_src + slab * (long)(HB * SLAB);
+      const int q = is_a ? gu : gu - NPA;
+      pr[u] = (reinterpret_cast<const f32x4 *>(src) + lane)[q * WAVE];
+    }
+  };
+
+  f32x16 acc[SP::TM][SP::TN];
+#pragma unroll
+  for (int a = 0; a < SP::TM; ++a)
+#pragma unroll
+    for (int b = 0; b < SP::TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  if ((long)blockIdx.x < n_slabs) prefetch(blockIdx.x);
+  for (long slab = blockIdx.x; slab < n_slabs; slab += gridDim.x) {
+    __syncthreads();  // previous round's fragments fully read
+    // ---- split + scatter: lane (sample i, half h) of piece q holds features 32 (q>>2) + 8 (q&3) + 4 h + c
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int gu = wave * PER + u;
+      const bool is_a = gu < NPA;
+      const int q = is_a ? gu : gu - NPA;
+      unsigned char *img = (is_a ? Ab : Bb) + (32 * (q >> 2) + 8 * (q & 3) + 4 * h) * DWS_ROWB + 2 * i;
+      const int tstride = is_a ? IMG_A : IMG_B;
+      if (is_a) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) dbacc[u][c] += pr[u][c];
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float f0 = pr[u][c];
+        const unsigned u0 = __float_as_uint(f0) & 0xffff0000u;
+        const float r0 = f0 - __uint_as_float(u0);
+        const unsigned w0 = __float_as_uint(r0) & 0xffff0000u;
+        const float q0 = r0 - __uint_as_float(w0);
+        unsigned short *d = reinterpret_cast<unsigned short *>(img + c * DWS_ROWB);
+        d[0] = (unsigned short)(u0 >> 16);
+        *reinterpret_cast<unsigned short *>(reinterpret_cast<unsigned char *>(d) + tstride) = (unsigned short)(w0 >> 16);
+        *reinterpret_cast<unsigned short *>(reinterpret_cast<unsigned char *>(d) + 2 * tstride) =
+            (unsigned short)(__float_as_uint(q0) >> 16);
+      }
+    }
+    __syncthreads();
+    if (slab + gridDim.x < n_slabs) prefetch(slab + gridDim.x);  // next round's loads fly during the MFMA phase
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- 2 k-steps of 16 samples: lane (feature i, g = h) reads samples 16 ks + 8 g .. + 7 of its feature row
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      u32x4 av[3][SP::TM], bv[3][SP::TN];
+#pragma unroll
+      for (int term = 0; term < 3; ++term) {
+#pragma unroll
+        for (int a = 0; a < SP::TM; ++a)
+          av[term][a] = *reinterpret_cast<const u32x4 *>(Ab + term * IMG_A + (32 * (wm * SP::TM + a) + i) * DWS_ROWB + 32 * ks + 16 * h);
+#pragma unroll
+        for (int b = 0; b < SP::TN; ++b)
+          bv[term][b] = *reinterpret_cast<const u32x4 *>(Bb + term * IMG_B + (32 * (wn * SP::TN + b) + i) * DWS_ROWB + 32 * ks + 16 * h);
+      }
+#pragma unroll
+      for (int a = 0; a < SP::TM; ++a)
+#pragma unroll
+        for (int b = 0; b < SP::TN; ++b) {
+          acc[a][b] = mfma_bf16(av[2][a], bv[0][b], acc[a][b]);
+          acc[a][b] = mfma_bf16(av[0][a], bv[2][b], acc[a][b]);
+          acc[a][b] = mfma_bf16(av[1][a], bv[1][b], acc[a][b]);
+          acc[a][b] = mfma_bf16(av[1][a], bv[0][b], acc[a][b]);
+          acc[a][b] = mfma_bf16(av[0][a], bv[1][b], acc[a][b]);
+          acc[a][b] = mfma_bf16(av[0][a], bv[0][b], acc[a][b]);
+        }
+    }
+  }
+
+  // ---- write this workgroup's partial: dWp[HA][KP] then dbp[HA]
+  float *mypart = part + (long)blockIdx.x * ((long)HA * KP + HA);
+#pragma unroll
+  for (int a = 0; a < SP::TM; ++a) {
+    const int mt = wm * SP::TM + a;
+#pragma unroll
+    for (int b = 0; b < SP::TN; ++b) {
+      const int kcol = 32 * (wn * SP::TN + b) + i;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int o = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * h;
+        mypart[(long)o * KP + kcol] = acc[a][b][r];
+      }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    const int gu = wave * PER + u;
+    if (gu < NPA) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float t = half_reduce_sum(dbacc[u][c]);
+        if (i == 0) mypart[(long)HA * KP + 32 * (gu >> 2) + 8 * (gu & 3) + 4 * h + c] = t;
+      }
+    }
+  }
+}
+
+// =============================================================================================
 // host launchers
 // =============================================================================================
 static int bad(const char *m) {
@@ -1247,12 +1387,19 @@ extern "C" int harl_mlp_dw_partials(const float *a, int a_kind, int lda, int HO,
   if (b_kind == 0) {
     const int NT = K / 32;
     if (K != 32 && K != 64 && K != 128) return bad("harl_mlp_dw_partials: ATL input width must be 32, 64 or 128");
+#define DWS(MTv, NTv)                                                                                            \
+  {                                                                                                              \
+    const size_t shm = (size_t)3 * 32 * (MTv + NTv) * DWS_ROWB;                                                  \
+    allow_big_lds(k_dw_split<MTv, NTv>, shm);                                                                    \
+    hipLaunchKernelGGL((k_dw_split<MTv, NTv>), dim3(n_wg), dim3(WG_THREADS), shm, s, a, b, n_slabs, part);        \
+  }
     if (MT == 4 && NT == 1) DW(0, 0, 4, 1, 1);
     else if (MT == 2 && NT == 1) DW(0, 0, 2, 1, 1);
-    else if (MT == 4 && NT == 4) DW(0, 0, 4, 4, 1);
-    else if (MT == 4 && NT == 2) DW(0, 0, 4, 2, 1);
-    else if (MT == 2 && NT == 4) DW(0, 0, 2, 4, 1);
-    else if (MT == 2 && NT == 2) DW(0, 0, 2, 2, 1);
+    else if (MT == 4 && NT == 4) DWS(4, 4)
+    else if (MT == 4 && NT == 2) DWS(4, 2)
+    else if (MT == 2 && NT == 4) DWS(2, 4)
+    else if (MT == 2 && NT == 2) DWS(2, 2)
+#undef DWS
     else if (MT == 1 && NT == 4) DW(1, 0, 1, 4, 1);
     else if (MT == 1 && NT == 2) DW(1, 0, 1, 2, 1);
     else return bad("harl_mlp_dw_partials: unsupported tile shape");

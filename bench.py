@@ -12,8 +12,9 @@ the timed region.  One transition = one (t, n) environment step for all agents. 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus 8 --steps 5 --warmup 2
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant MFMA kernel family (HIP-event timing of every launch
-of the four MFMA families inside the timed region; `traffic` from the committed PMC pass in profiles/); `kernels` is the
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant GEMM kernel family (HIP-event timing of every launch
+of the GEMM families inside the timed region; HBM-bound since the GEMMs moved to the bf16 matrix pipe with an exact
+fp32 operand split; `traffic` from the committed PMC pass in profiles/); `kernels` is the
 full per-kernel breakdown from extra instrumented steps after the timed region; `cpu_baseline` is the oracle (a torch-CPU restatement of the reference,
 same ATen kernels) timed on this box's host cores on a bounded sample of the same workload.
 """
@@ -32,6 +33,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 MFMA_F32_PEAK = 157.3e12  # MI355X_MICROARCH.md: fp32-input MFMA, dense
+MFMA_BF16_PEAK = 2516.6e12  # 16 x the fp32 rate (dense bf16 MFMA, 1024 FLOP/clk/SIMD at 2.4 GHz)
 HBM_PEAK = 8.0e12
 
 T, N_PER_GPU, A = 200, 4096, 3
@@ -204,24 +206,28 @@ def main():
         trans_per_step = T * n_local * world
         value = trans_per_step * args.steps / dt
         B = T * n_local
-        # dominant kernel = the MFMA kernel family with the largest total time inside the timed region; `achieved` is
-        # its ALGORITHMIC flops per launch (Linear layers only) / its average HIP-event duration
+        # dominant kernel = the GEMM kernel family with the largest total time inside the timed region.  Since the GEMMs
+        # run on the bf16 matrix pipe (exact three-way fp32 split, 6 products: csrc/split_mfma.h) these kernels are
+        # HBM-bound: `achieved` = ALGORITHMIC bytes per launch / average HIP-event duration.  Reported
+        # next to it: the fp32-equivalent FLOP rate (Linear layers only) against the fp32 MFMA peak it no longer runs on,
+        # and the matrix-pipe time actually issued (6 x bf16 GEMM FLOPs + 16 x the FLOPs left on the fp32 MFMA).
         flops = dict(fwd_hidden=2.0 * B * 128 * 128, bwd_dx=2.0 * B * 128 * 128, dw_hidden=2.0 * B * 128 * 128,
                      fwd_fused2=2.0 * B * (128 * 128 + OBS * 128),
                      # dX of layer 2 + the fused first-layer weight gradient (15 actor launches with D=18, 5 critic with 54)
                      bwd_dx_dw1=2.0 * B * (128 * 128 + 128 * (15 * OBS + 5 * SOBS) / 20.0))
+        gemm_bf16 = 2.0 * B * 128 * 128  # the 128 x 128 GEMM of every family runs as 6 bf16 products
+        pipe = {k: 6.0 * gemm_bf16 + 16.0 * (v - gemm_bf16) for k, v in flops.items()}  # bf16-pipe-equivalent FLOPs issued
+        # ALGORITHMIC HBM bytes per launch of each family for THIS run's launch mix: the fused forward is
+        # launched 15x per step in training mode (writes x_hat_1, x_hat_2, the normalised inputs, masks, statistics)
+        # and 3x in log-prob mode (x_hat_2 only).
+        alg = dict(fwd_hidden=B * (512 + 512 + 16 + 4), bwd_dx=B * (512 + 512 + 16 + 4 + 512), dw_hidden=B * (512 + 512),
+                   bwd_dx_dw1=B * (512 + 512 + 16 + 4 + (15 * 128 + 5 * 256) / 20.0),
+                   fwd_fused2=B * (15 * (4 * OBS + 512 + 512 + 128 + 32 + 16) + 3 * (4 * OBS + 512 + 16 + 4)) / 18.0)
         cand = {k: v for k, v in mfma_kern.items() if k in flops and v["n"] > 0}
         roof = None
         if cand:
             dom = max(cand, key=lambda k: cand[k]["total_ms"])
             avg_s = cand[dom]["avg_ms"] * 1e-3
-            ach = flops[dom] / avg_s
-            # ALGORITHMIC HBM bytes per launch of each family for THIS run's launch mix: the fused forward is
-            # launched 15x per step in training mode (writes x_hat_1, x_hat_2, the normalised inputs, masks, statistics)
-            # and 3x in log-prob mode (x_hat_2 only).
-            alg = dict(fwd_hidden=B * (512 + 512 + 16 + 4), bwd_dx=B * (512 + 512 + 16 + 4 + 512), dw_hidden=B * (512 + 512),
-                       bwd_dx_dw1=B * (512 + 512 + 16 + 4 + (15 * 128 + 5 * 256) / 20.0),
-                       fwd_fused2=B * (15 * (4 * OBS + 512 + 512 + 128 + 32 + 16) + 3 * (4 * OBS + 512 + 16 + 4)) / 18.0)
             traffic, traffic_note = None, None
             tp = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
             if os.path.exists(tp):  # PMC pass over the same kernels (tools/kbench.py); measured/algorithmic ratio per family
@@ -232,16 +238,26 @@ def main():
                     traffic_note = (f"GB per launch = {ratio:.3f} (HBM bytes measured by rocprofv3 --pmc FETCH_SIZE x2 [gfx950] + "
                                     f"WRITE_SIZE, separate passes, / algorithmic bytes of the same kernel; "
                                     f"profiles/r01_hbm_traffic.md) x {alg[dom] / 1e9:.3f} GB algorithmic for this launch mix")
-            roof = dict(kernel=dom, bound="mfma", achieved=ach / 1e12, peak=MFMA_F32_PEAK / 1e12, unit="TFLOP/s",
-                        frac=ach / MFMA_F32_PEAK, traffic=traffic, traffic_note=traffic_note, launches=cand[dom]["n"],
-                        avg_ms=cand[dom]["avg_ms"], flops_per_launch=flops[dom],
-                        timing="HIP events around every launch of the MFMA kernel families inside the timed region",
-                        others={k: round(flops[k] / (v["avg_ms"] * 1e-3) / MFMA_F32_PEAK, 4) for k, v in cand.items()})
+            ach = alg[dom] / avg_s
+            roof = dict(kernel=dom, bound="hbm", achieved=ach / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s",
+                        frac=ach / HBM_PEAK, traffic=traffic, traffic_note=traffic_note, launches=cand[dom]["n"],
+                        avg_ms=cand[dom]["avg_ms"], bytes_per_launch=alg[dom], flops_per_launch=flops[dom],
+                        fp32_equiv_tflops=flops[dom] / avg_s / 1e12,
+                        frac_of_fp32_mfma_peak=flops[dom] / avg_s / MFMA_F32_PEAK,
+                        matrix_pipe_frac=pipe[dom] / avg_s / MFMA_BF16_PEAK,
+                        timing="HIP events around every launch of the GEMM kernel families inside the timed region",
+                        others={k: dict(hbm_frac=round(alg[k] / (v["avg_ms"] * 1e-3) / HBM_PEAK, 4),
+                                        fp32_equiv_frac=round(flops[k] / (v["avg_ms"] * 1e-3) / MFMA_F32_PEAK, 4),
+                                        matrix_pipe_frac=round(pipe[k] / (v["avg_ms"] * 1e-3) / MFMA_BF16_PEAK, 4))
+                                for k, v in cand.items()})
         e2e = flops_per_transition() * value
         out = dict(
             metric="transitions/sec through HAPPO update (MPE spread, 3 agents)", value=value, unit="transitions/s",
             n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=dt / args.steps * 1e3,
             higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32",
+            dtype_note="fp32 data, statistics and accumulators; the 128x128 GEMM operands are split EXACTLY into three bf16 "
+                       "each and multiplied as six cross products on v_mfma_f32_32x32x16_bf16 (error <= the fp32 MFMA's fmaf "
+                       "chain: profiles/r01_mfma_bf16x3.txt)",
             data="synthetic (SURVEY.md 8d recipe; stored log-probs set on-policy so ratios ~ 1)",
             config=dict(workload="MPE simple_spread_v2 3-agent HAPPO update: compute_returns + train(), T=200, "
                                  f"n_rollout_threads={n_local}/GPU, obs18/share54/Box5, MLP[128,128], ppo_epoch=5, critic_epoch=5",

@@ -33,6 +33,9 @@ SIGNATURES = {
     "harl_fold_linear": [_vp] * 6 + [_i, _i, _vp],
     "harl_unfold_linear_grads": [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "harl_mlp_fwd_input": [_vp, _l, _vp, _l, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "harl_mlp_x0n_wide": [_vp, _l, _vp, _l, _i, _i, _vp, _vp, _vp, _vp],
+    "harl_mlp_fwd_wide": [_vp, _l, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp],
+    "harl_mlp_tangent_wide": [_vp, _l, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "harl_mlp_fwd_fused2": [_vp, _l, _vp, _l, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                             _vp, _vp],
     "harl_mlp_fwd_hidden": [_vp, _l, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],

@@ -1001,11 +1001,15 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_dw(const float *__restrict__ 
 // =============================================================================================
 constexpr int DWS_ROWB = 80;  // bytes per feature row of a term image (32 samples x 2 B + 16 B pad)
 
+// Wide first layers (x0n ATL(KP), KP up to 512): launched once per group of NT <= 4 column tiles; `b_slab_floats` = KP * 32
+// is the slab stride of the B image, `tile0` the group's first 32-column tile, KP the row stride of dWp in the partial;
+// db' is written by the tile0 == 0 launch only.
 template <int MT, int NT>
 __global__ __launch_bounds__(WG_THREADS, 2) void k_dw_split(const float *__restrict__ a_src, const float *__restrict__ b_src,
-                                                            long n_slabs, float *__restrict__ part) {
+                                                            long n_slabs, float *__restrict__ part, long b_slab_floats,
+                                                            int tile0, int KP) {
   using SP = DwSplit<MT, NT>;
-  constexpr int HA = 32 * MT, HB = 32 * NT, KP = HB;
+  constexpr int HA = 32 * MT, HB = 32 * NT;
   constexpr int NPA = HA / 8, NPB = HB / 8, PER = (NPA + NPB) / WAVES_PER_WG;  // float4 pieces per lane and wave
   static_assert((NPA + NPB) % WAVES_PER_WG == 0, "pieces divide evenly over the waves");
   constexpr int IMG_A = HA * DWS_ROWB, IMG_B = HB * DWS_ROWB;  // bytes per term image
@@ -1028,8 +1032,8 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_dw_split(const float *__restr
     for (int u = 0; u < PER; ++u) {
       const int gu = wave * PER + u;
       const bool is_a = gu < NPA;
-      const float *src = is_a ? a_src + slab * (long)(HA * SLAB) : b_src + slab * (long)(HB * SLAB);
-      const int q = is_a ? gu : gu - NPA;
+      const float *src = is_a ? a_src + slab * (long)(HA * SLAB) : b_src + slab * b_slab_floats;
+      const int q = is_a ? gu : gu - NPA + 4 * tile0;
       pr[u] = (reinterpret_cast<const f32x4 *>(src) + lane)[q * WAVE];
     }
   };
@@ -1084,8 +1088,10 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_dw_split(const float *__restr
         for (int a = 0; a < SP::TM; ++a)
           av[term][a] = *reinterpret_cast<const u32x4 *>(Ab + term * IMG_A + (32 * (wm * SP::TM + a) + i) * DWS_ROWB + 32 * ks + 16 * h);
 #pragma unroll
-        for (int b = 0; b < SP::TN; ++b)
-          bv[term][b] = *reinterpret_cast<const u32x4 *>(Bb + term * IMG_B + (32 * (wn * SP::TN + b) + i) * DWS_ROWB + 32 * ks + 16 * h);
+        for (int b = 0; b < SP::TN; ++b) {
+          const int nt = wn * SP::TN + b < NT ? wn * SP::TN + b : NT - 1;  // surplus tile slots (NT = 1, 3) recompute the last tile
+          bv[term][b] = *reinterpret_cast<const u32x4 *>(Bb + term * IMG_B + (32 * nt + i) * DWS_ROWB + 32 * ks + 16 * h);
+        }
       }
 #pragma unroll
       for (int a = 0; a < SP::TM; ++a)
@@ -1108,18 +1114,20 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_dw_split(const float *__restr
     const int mt = wm * SP::TM + a;
 #pragma unroll
     for (int b = 0; b < SP::TN; ++b) {
-      const int kcol = 32 * (wn * SP::TN + b) + i;
+      if (wn * SP::TN + b < NT) {
+        const int kcol = 32 * (tile0 + wn * SP::TN + b) + i;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int o = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * h;
-        mypart[(long)o * KP + kcol] = acc[a][b][r];
+        for (int r = 0; r < 16; ++r) {
+          const int o = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * h;
+          mypart[(long)o * KP + kcol] = acc[a][b][r];
+        }
       }
     }
   }
 #pragma unroll
   for (int u = 0; u < PER; ++u) {
     const int gu = wave * PER + u;
-    if (gu < NPA) {
+    if (gu < NPA && tile0 == 0) {
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const float t = half_reduce_sum(dbacc[u][c]);
@@ -1386,13 +1394,27 @@ extern "C" int harl_mlp_dw_partials(const float *a, int a_kind, int lda, int HO,
 #define DW(AK, BK, MTv, NTv, ny) launch_dw<AK, BK, MTv, NTv>(a, b, ldx, idx, mu0, rstd0, K, M, n_slabs, part, KP, n_wg, ny, s)
   if (b_kind == 0) {
     const int NT = K / 32;
-    if (K != 32 && K != 64 && K != 128) return bad("harl_mlp_dw_partials: ATL input width must be 32, 64 or 128");
+    if (K % 32 != 0 || K < 32) return bad("harl_mlp_dw_partials: ATL input width must be a multiple of 32");
 #define DWS(MTv, NTv)                                                                                            \
   {                                                                                                              \
     const size_t shm = (size_t)3 * 32 * (MTv + NTv) * DWS_ROWB;                                                  \
     allow_big_lds(k_dw_split<MTv, NTv>, shm);                                                                    \
-    hipLaunchKernelGGL((k_dw_split<MTv, NTv>), dim3(n_wg), dim3(WG_THREADS), shm, s, a, b, n_slabs, part);        \
+    hipLaunchKernelGGL((k_dw_split<MTv, NTv>), dim3(n_wg), dim3(WG_THREADS), shm, s, a, b, n_slabs, part,         \
+                       (long)K * SLAB, tile0, K);                                                                \
   }
+    if (K > 128 || K == 96) {  // wide first layer: x0n ATL(K), K a multiple of 32 up to 512, in groups of <= 4 column tiles
+      if (K % 32 != 0 || K > 512 || (MT != 4 && MT != 2)) return bad("harl_mlp_dw_partials: wide ATL input must be a multiple of 32, <= 512");
+      for (int tile0 = 0; tile0 < K / 32; tile0 += 4) {
+        const int nt = K / 32 - tile0 < 4 ? K / 32 - tile0 : 4;
+        if (MT == 4) {
+          if (nt == 4) DWS(4, 4) else if (nt == 3) DWS(4, 3) else if (nt == 2) DWS(4, 2) else DWS(4, 1)
+        } else {
+          if (nt == 4) DWS(2, 4) else if (nt == 3) DWS(2, 3) else if (nt == 2) DWS(2, 2) else DWS(2, 1)
+        }
+      }
+      return check_launch("harl_mlp_dw_partials");
+    }
+    const int tile0 = 0;
     if (MT == 4 && NT == 1) DW(0, 0, 4, 1, 1);
     else if (MT == 2 && NT == 1) DW(0, 0, 2, 1, 1);
     else if (MT == 4 && NT == 4) DWS(4, 4)

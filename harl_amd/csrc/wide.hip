@@ -1,0 +1,380 @@
+// wide.hip -- first layer for WIDE observations (64 < D <= 512: MAMuJoCo Humanoid 393 / 376, SMAC 128+), gfx950.
+//
+// The narrow kernels of mlp.hip park a slab's rows in LDS next to the whole first-layer matrix; neither fits for wide
+// rows.  Here the layer is split in two streaming kernels:
+//   1. harl_mlp_x0n_wide: rows X[idx] -> input LayerNorm statistics (exact two-pass, in registers) -> the normalised
+//      inputs as an ATL(KP) image (KP = D rounded up to 32, zero padded).  Rows are read ONCE, coalesced (lane = column);
+//      the transposition to "lane = sample" goes through two 32x32 LDS tiles per 64 columns.  x0n depends on the inputs
+//      only, not on the weights: every later consumer (first-layer GEMM of each epoch / line-search step, its tangent in
+//      HATRPO's Fisher-vector products, the first-layer weight gradient) streams this image instead of gathering rows.
+//   2. harl_mlp_fwd_wide / harl_mlp_tangent_wide: x0n ATL(KP) -> H on the bf16 matrix pipe with the exact three-way
+//      operand split (split_mfma.h).  3 * H * KP bf16 (320 KiB for 128 x 416) do not fit the LDS, so the three weight
+//      images are built in a global scratch buffer by a small kernel (they stay L2 resident) and every wave streams its
+//      A fragments from there, amortised over TWO slabs per wave.
+// The first-layer weight gradient of wide inputs is k_dw_split (mlp.hip) over column groups of the same x0n image.
+#include <type_traits>
+#include "common.h"
+#include "split_mfma.h"
+#include "../../include/harl_hip.h"
+
+using namespace harl;
+
+namespace {
+
+int bad(const char *m) {
+  set_error(m);
+  return -2;
+}
+
+// ---------------------------------------------------------------------------------------------
+// rows -> x0n ATL(KP).  One wave per slab; NC = ceil(D / 64) column chunks of 64 (lane = column).
+// ---------------------------------------------------------------------------------------------
+// sum over the 64 lanes on the VALU only (4 DPP adds inside each row of 16, then the 4 row sums through SGPRs); the
+// result is wave-uniform.  __shfl_xor lowers to ds_bpermute here: 6 dependent LDS round trips per reduction.
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  auto dpp = [](float x, auto ctrl) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xf, 0xf, true));
+  };
+  v += dpp(v, std::integral_constant<int, 0xB1>{});   // quad_perm:[1,0,3,2]
+  v += dpp(v, std::integral_constant<int, 0x4E>{});   // quad_perm:[2,3,0,1]
+  v += dpp(v, std::integral_constant<int, 0x141>{});  // row_half_mirror
+  v += dpp(v, std::integral_constant<int, 0x140>{});  // row_mirror: every lane of a row holds the row's sum
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+  const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+  const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+  return (r0 + r1) + (r2 + r3);
+}
+
+constexpr int XT_LD = 36;  // floats per feature row of a transposition tile [32 features][32 samples + 4]
+
+template <int NC>
+__global__ __launch_bounds__(WG_THREADS, NC <= 3 ? 2 : 1) void k_x0n_wide(const float *__restrict__ X, long ldx,
+                                                                           const int64_t *__restrict__ idx, long M, int D,
+                                                                           int use_ln0, float *__restrict__ x0n,
+                                                                           float *__restrict__ mu0_out,
+                                                                           float *__restrict__ rstd0_out, long n_slabs, int KP) {
+  __shared__ __attribute__((aligned(16))) float tiles[WAVES_PER_WG][2][32 * XT_LD];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  float *tw = &tiles[wave][0][0];
+  for (long slab = (long)blockIdx.x * WAVES_PER_WG + wave; slab < n_slabs; slab += (long)gridDim.x * WAVES_PER_WG) {
+    // ---- the slab's 32 rows, lane = column (coalesced 256-byte runs), all loads in flight at once
+    // (row indices first and branch-free: with `idx ? idx[j] : j` inside the load loop hipcc closes every row's loads
+    // with s_waitcnt vmcnt(0) -- 32 serialised HBM round trips per slab)
+    long rows[32];
+    if (idx) {
+#pragma unroll
+      for (int r = 0; r < 32; ++r) {
+        const long j = slab * SLAB + r;
+        rows[r] = idx[j < M ? j : M - 1];
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 32; ++r) {
+        const long j = slab * SLAB + r;
+        rows[r] = j < M ? j : M - 1;
+      }
+    }
+    int kc[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) kc[c] = 64 * c + lane < D ? 64 * c + lane : 0;
+    float v[32][NC];
+#pragma unroll
+    for (int r = 0; r < 32; ++r) {
+      const float *xr = X + rows[r] * ldx;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) v[r][c] = xr[kc[c]];
+    }
+    // ---- input LayerNorm statistics per row: exact two-pass on the register image
+    const float invD = 1.0f / (float)D;
+    float my_mean = 0.f, my_rstd = 1.f;  // lane n < 32 keeps the statistics of sample n
+#pragma unroll
+    for (int r = 0; r < 32; ++r) {
+      float mean = 0.f, rstd = 1.f;
+      if (use_ln0) {
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) s += (64 * c + lane < D) ? v[r][c] : 0.f;
+        mean = wave_sum_dpp(s) * invD;
+        float q = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          const float d = v[r][c] - mean;
+          q += (64 * c + lane < D) ? d * d : 0.f;
+        }
+        rstd = 1.0f / sqrtf(wave_sum_dpp(q) * invD + 1e-5f);
+      }
+#pragma unroll
+      for (int c = 0; c < NC; ++c) v[r][c] = (64 * c + lane < D) ? (v[r][c] - mean) * rstd : 0.f;
+      if (lane == r) {
+        my_mean = mean;
+        my_rstd = rstd;
+      }
+    }
+    if (lane < 32) {
+      mu0_out[slab * SLAB + lane] = my_mean;
+      rstd0_out[slab * SLAB + lane] = my_rstd;
+    }
+    // ---- transposition, 64 columns (two 32-feature tiles) at a time: lane (tile h, feature i) writes its 32 samples,
+    // lane (sample i, half h) reads the 16 features of each tile it owns in the ATL image
+    f32x4 *op = reinterpret_cast<f32x4 *>(x0n + slab * (long)KP * SLAB) + lane;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      if (64 * c < KP) {
+        float *tl = tw + h * (32 * XT_LD) + i * XT_LD;
+#pragma unroll
+        for (int r4 = 0; r4 < 8; ++r4)
+          *reinterpret_cast<f32x4 *>(tl + 4 * r4) = f32x4{v[4 * r4][c], v[4 * r4 + 1][c], v[4 * r4 + 2][c], v[4 * r4 + 3][c]};
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private hand-off between lanes
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) {
+          if (64 * c + 32 * t2 < KP) {
+            const float *ts = tw + t2 * (32 * XT_LD);
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {  // piece q = 4 (2c + t2) + qq: features 8 qq + 4 h + e of this tile
+              f32x4 o;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) o[e] = ts[(8 * qq + 4 * h + e) * XT_LD + i];
+              op[(4 * (2 * c + t2) + qq) * WAVE] = o;
+            }
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();  // all lanes done reading before the next chunk overwrites the tiles
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// fp32 Wp[H][D] -> three bf16 images [term][tile][k-step][64 lanes] x 16 B in global memory, K zero-padded to KP
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_split_image(const float *__restrict__ Wp, int H, int D, int KP,
+                                                     u32x4 *__restrict__ img) {
+  const int MT = H / 32, NJ = KP / 16, total = MT * NJ * 64;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    const int ln = e & 63, j = (e >> 6) % NJ, t = (e >> 6) / NJ, m = 32 * t + (ln & 31), g = ln >> 5;
+    unsigned p[3][4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int k0 = 16 * j + 8 * g + 2 * c;  // B operand of k-step j, lane half g: x0n registers 8 j .. 8 j + 7
+      // register R of the ATL(KP) image <-> feature feat_base(R) + 4 g
+      const int f0 = feat_base(8 * j + 2 * c) + 4 * g, f1 = feat_base(8 * j + 2 * c + 1) + 4 * g;
+      (void)k0;
+      const float w0 = f0 < D ? Wp[(long)m * D + f0] : 0.f;
+      const float w1 = f1 < D ? Wp[(long)m * D + f1] : 0.f;
+      split3_rne(w0, w1, p[0][c], p[1][c], p[2][c]);
+    }
+#pragma unroll
+    for (int term = 0; term < 3; ++term) img[(long)term * total + e] = u32x4{p[term][0], p[term][1], p[term][2], p[term][3]};
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// x0n ATL(KP) -> H.  Each wave owns two slabs at a time (every A fragment read from L2 feeds 12 MFMAs); the fragments
+// and activations of k-step j+1 are in flight while the MFMAs of k-step j run.
+// TANGENT: the epilogue is the LayerNorm Jacobian (forward mode), otherwise ReLU + LayerNorm + mask.
+// ---------------------------------------------------------------------------------------------
+template <int HO, bool TANGENT>
+__global__ __launch_bounds__(WG_THREADS, 1) void k_fwd_wide(const float *__restrict__ x0n, const u32x4 *__restrict__ img,
+                                                            const float *__restrict__ bp, float *__restrict__ xout,
+                                                            uint32_t *__restrict__ mask_out, float *__restrict__ rstd_out,
+                                                            const float *__restrict__ xprimal,
+                                                            const uint32_t *__restrict__ mask_in,
+                                                            const float *__restrict__ rstd_in, long n_slabs, int KP) {
+  constexpr int MT = HO / 32;
+  const int NJ = KP / 16, TS = MT * NJ * 64;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
+  const long n_pairs = (n_slabs + 1) / 2;
+  const u32x4 *wl = img + lane;
+  for (long pair = (long)blockIdx.x * WAVES_PER_WG + wave; pair < n_pairs; pair += (long)gridDim.x * WAVES_PER_WG) {
+    const long s0 = 2 * pair, s1 = s0 + 1 < n_slabs ? s0 + 1 : s0;
+    const f32x4 *xp0 = reinterpret_cast<const f32x4 *>(x0n + s0 * (long)KP * SLAB) + lane;
+    const f32x4 *xp1 = reinterpret_cast<const f32x4 *>(x0n + s1 * (long)KP * SLAB) + lane;
+    f32x16 acc0[MT], acc1[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc0[t][r] = acc1[t][r] = bp[32 * t + (r & 3) + 8 * (r >> 2) + 4 * h];
+    u32x4 an[3][MT];
+    f32x4 bn[2][2];
+    auto fetch = [&](int j) {
+#pragma unroll
+      for (int term = 0; term < 3; ++term)
+#pragma unroll
+        for (int t = 0; t < MT; ++t) an[term][t] = wl[(long)term * TS + (t * NJ + j) * 64];
+      bn[0][0] = xp0[(2 * j) * WAVE];
+      bn[0][1] = xp0[(2 * j + 1) * WAVE];
+      bn[1][0] = xp1[(2 * j) * WAVE];
+      bn[1][1] = xp1[(2 * j + 1) * WAVE];
+    };
+    fetch(0);
+    for (int j = 0; j < NJ; ++j) {
+      u32x4 a[3][MT];
+#pragma unroll
+      for (int term = 0; term < 3; ++term)
+#pragma unroll
+        for (int t = 0; t < MT; ++t) a[term][t] = an[term][t];
+      u32x4 b[2][3];
+#pragma unroll
+      for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const f32x4 &src = bn[sl][c >> 1];
+          unsigned p1, p2, p3;
+          split3(src[2 * (c & 1)], src[2 * (c & 1) + 1], p1, p2, p3);
+          b[sl][0][c] = p1;
+          b[sl][1][c] = p2;
+          b[sl][2][c] = p3;
+        }
+      if (j + 1 < NJ) fetch(j + 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        acc0[t] = mfma_bf16(a[2][t], b[0][0], acc0[t]);
+        acc1[t] = mfma_bf16(a[2][t], b[1][0], acc1[t]);
+        acc0[t] = mfma_bf16(a[0][t], b[0][2], acc0[t]);
+        acc1[t] = mfma_bf16(a[0][t], b[1][2], acc1[t]);
+        acc0[t] = mfma_bf16(a[1][t], b[0][1], acc0[t]);
+        acc1[t] = mfma_bf16(a[1][t], b[1][1], acc1[t]);
+        acc0[t] = mfma_bf16(a[1][t], b[0][0], acc0[t]);
+        acc1[t] = mfma_bf16(a[1][t], b[1][0], acc1[t]);
+        acc0[t] = mfma_bf16(a[0][t], b[0][1], acc0[t]);
+        acc1[t] = mfma_bf16(a[0][t], b[1][1], acc1[t]);
+        acc0[t] = mfma_bf16(a[0][t], b[0][0], acc0[t]);
+        acc1[t] = mfma_bf16(a[0][t], b[1][0], acc1[t]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (TANGENT) {
+      // (the bias slot carries bdp)  x1dot = LNjac(mask1 * (Wdp x0n + bdp))
+      {
+        constexpr int NR = HO / 2, NW = (NR + 31) / 32;
+        auto epi = [&](f32x16(&acc)[MT], long slab) {
+          float xh[NR];
+          atl_load<HO>(xprimal, slab, lane, xh);
+          uint32_t bits[NW];
+#pragma unroll
+          for (int w = 0; w < NW; ++w) bits[w] = mask_in[(slab * NW + w) * WAVE + lane];
+          const float rstd = rstd_in[slab * SLAB + (lane & 31)];
+          float ad[NR];
+          float q1 = 0.f, q2 = 0.f;
+#pragma unroll
+          for (int R = 0; R < NR; ++R) {
+            ad[R] = mask_pop(acc[R >> 4][R & 15], bits[R >> 5]);
+            q1 += ad[R];
+            q2 += ad[R] * xh[R];
+          }
+          q1 += wave_xor32(q1);
+          q2 += wave_xor32(q2);
+          q1 *= (1.0f / HO);
+          q2 *= (1.0f / HO);
+#pragma unroll
+          for (int R = 0; R < NR; ++R) ad[R] = rstd * (ad[R] - q1 - xh[R] * q2);
+          atl_store<HO>(xout, slab, lane, ad);
+        };
+        epi(acc0, s0);
+        if (s1 != s0) epi(acc1, s1);
+      }
+    } else {
+      constexpr int NR = HO / 2, NW = (NR + 31) / 32;
+      auto epi = [&](f32x16(&acc)[MT], long slab) {
+        uint32_t bits[NW];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) bits[w] = 0u;
+        float v[NR];
+        float sum = 0.f;
+#pragma unroll
+        for (int R = 0; R < NR; ++R) {
+          v[R] = relu_push(acc[R >> 4][R & 15], bits[R >> 5]);
+          sum += v[R];
+        }
+        sum += wave_xor32(sum);
+        const float mean = sum * (1.0f / HO);
+        float vs = 0.f;
+#pragma unroll
+        for (int R = 0; R < NR; ++R) {
+          v[R] -= mean;
+          vs += v[R] * v[R];
+        }
+        vs += wave_xor32(vs);
+        const float rstd = 1.0f / sqrtf(vs * (1.0f / HO) + 1e-5f);
+#pragma unroll
+        for (int R = 0; R < NR; ++R) v[R] *= rstd;
+        atl_store<HO>(xout, slab, lane, v);
+#pragma unroll
+        for (int w = 0; w < NW; ++w) mask_out[(slab * NW + w) * WAVE + lane] = bits[w];
+        if (lane < 32) rstd_out[slab * SLAB + lane] = rstd;
+      };
+      epi(acc0, s0);
+      if (s1 != s0) epi(acc1, s1);
+    }
+  }
+}
+
+template <bool TANGENT>
+int launch_wide(const float *x0n, long M, int KP, const float *Wp, int D, const float *bp, int H, void *w_img, float *xout,
+                uint32_t *mask_out, float *rstd_out, const float *xprimal, const uint32_t *mask_in, const float *rstd_in,
+                hipStream_t s, const char *what) {
+  if (M <= 0) return 0;
+  if (H != 128 && H != 64) return bad("harl_mlp_*_wide: hidden width must be 64 or 128");
+  if (KP % 32 != 0 || KP < D || KP > 512) return bad("harl_mlp_*_wide: KP must be a multiple of 32, >= D and <= 512");
+  if (!w_img || !x0n) return bad("harl_mlp_*_wide: x0n and the weight-image scratch are required");
+  const long n_slabs = n_slabs_of(M);
+  const int total = (H / 32) * (KP / 16) * 64;
+  hipLaunchKernelGGL(k_split_image, dim3((total + 255) / 256), dim3(256), 0, s, Wp, H, D, KP, reinterpret_cast<u32x4 *>(w_img));
+  const long pairs = (n_slabs + 1) / 2, wgs = (pairs + WAVES_PER_WG - 1) / WAVES_PER_WG;
+  const int grid = (int)(wgs < 256 ? (wgs < 1 ? 1 : wgs) : 256);
+  if (H == 128)
+    hipLaunchKernelGGL((k_fwd_wide<128, TANGENT>), dim3(grid), dim3(WG_THREADS), 0, s, x0n, reinterpret_cast<const u32x4 *>(w_img),
+                       bp, xout, mask_out, rstd_out, xprimal, mask_in, rstd_in, n_slabs, KP);
+  else
+    hipLaunchKernelGGL((k_fwd_wide<64, TANGENT>), dim3(grid), dim3(WG_THREADS), 0, s, x0n, reinterpret_cast<const u32x4 *>(w_img),
+                       bp, xout, mask_out, rstd_out, xprimal, mask_in, rstd_in, n_slabs, KP);
+  return check_launch(what);
+}
+
+}  // namespace
+
+extern "C" int harl_mlp_x0n_wide(const float *X, long ldx, const int64_t *idx, long M, int D, int use_ln0, float *x0n,
+                                 float *mu0, float *rstd0, void *stream) {
+  if (M <= 0) return 0;
+  if (D <= 64 || D > 512) return bad("harl_mlp_x0n_wide: 64 < D <= 512");
+  const long n_slabs = n_slabs_of(M);
+  const int KP = ((D + 31) / 32) * 32, NC = (D + 63) / 64;
+  const long wgs = (n_slabs + WAVES_PER_WG - 1) / WAVES_PER_WG;
+  hipStream_t s = (hipStream_t)stream;
+#define LX(NCv)                                                                                                         \
+  {                                                                                                                     \
+    const long cap = 256L * (NCv <= 3 ? 2 : 1);                                                                         \
+    const int grid = (int)(wgs < cap ? (wgs < 1 ? 1 : wgs) : cap);                                                      \
+    hipLaunchKernelGGL((k_x0n_wide<NCv>), dim3(grid), dim3(WG_THREADS), 0, s, X, ldx, idx, M, D, use_ln0, x0n, mu0, rstd0, \
+                       n_slabs, KP);                                                                                    \
+  }
+  switch (NC) {
+    case 2: LX(2) break;
+    case 3: LX(3) break;
+    case 4: LX(4) break;
+    case 5: LX(5) break;
+    case 6: LX(6) break;
+    case 7: LX(7) break;
+    default: LX(8) break;
+  }
+#undef LX
+  return check_launch("harl_mlp_x0n_wide");
+}
+
+extern "C" int harl_mlp_fwd_wide(const float *x0n, long M, int KP, const float *Wp, int D, const float *bp, int H,
+                                 void *w_img, float *xout, uint32_t *relu_mask, float *rstd, void *stream) {
+  return launch_wide<false>(x0n, M, KP, Wp, D, bp, H, w_img, xout, relu_mask, rstd, nullptr, nullptr, nullptr,
+                            (hipStream_t)stream, "harl_mlp_fwd_wide");
+}
+
+extern "C" int harl_mlp_tangent_wide(const float *x0n, long M, int KP, const float *Wdp, int D, const float *bdp, int H,
+                                     void *w_img, const float *x1, const uint32_t *mask1, const float *rstd1, float *x1dot,
+                                     void *stream) {
+  return launch_wide<true>(x0n, M, KP, Wdp, D, bdp, H, w_img, x1dot, nullptr, nullptr, x1, mask1, rstd1,
+                           (hipStream_t)stream, "harl_mlp_tangent_wide");
+}

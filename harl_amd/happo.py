@@ -52,14 +52,15 @@ class OnPolicyBase:
 
     # ---- log-prob passes over a whole [T*N] batch (on_policy_ha_runner.py:66-83,96-113) --------------
     def _logp_pass(self, obs, actions, avail, M, logp_out, old_logp=None, factor=None, head_out=None,
-                   rnn_states=None, masks=None, h_last=False):
+                   rnn_states=None, masks=None, h_last=False, reuse_trunk=False):
         """Forward + head over rows 0..M-1.  Recurrent nets follow the reference's convention (rnn.py:24-42): with
         rnn_states [m, 1, H], M = L*m rows are L steps of m sequences (l-major) unrolled from rnn_states with mask
         resets.  Returns the final hidden state [m, H] when ``h_last`` is set."""
         net = self.actor
         agg = int(self.action_aggregation == "mean")
         if not net.recurrent:
-            net.forward_trunk(obs, None, M, for_backward=False)
+            if not reuse_trunk:  # reuse_trunk: x_hat_L of these rows under the current weights is still in the workspace
+                net.forward_trunk(obs, None, M, for_backward=False)
             Wp, bp = net._packs[-1]
             call("harl_actor_head_logp", ptr(net.xh[-1]), M, net.hidden_sizes[-1], ptr(Wp), ptr(bp), ptr(net.log_std()),
                  net.std_x_coef, net.std_y_coef, int(net.discrete), net.act_dim, ptr(actions), ptr(avail), ptr(logp_out),

@@ -86,9 +86,13 @@ class HATRPO(OnPolicyBase):
                  ptr(vview(ben)) if ben else None, ptr(Wpd), ptr(bpd), o, k, s)
         hs = net.hidden_sizes
         Wpd, bpd = ws["packs"][0]
-        call("harl_mlp_tangent_input", ptr(obs), obs.shape[1], None, m, net.in_dim, ptr(Wpd), ptr(bpd),
-             int(net.use_feature_normalization), hs[0], ptr(net.xh[0]), ptr(net.rmask[0]), ptr(net.rstd[0]),
-             ptr(ws["xd"][0]), s)
+        if net.wide:  # x0n of the same rows is still there from the forward pass of _surrogate()
+            call("harl_mlp_tangent_wide", ptr(net.x0n), m, net.kp0, ptr(Wpd), net.in_dim, ptr(bpd), hs[0], ptr(net.w1img),
+                 ptr(net.xh[0]), ptr(net.rmask[0]), ptr(net.rstd[0]), ptr(ws["xd"][0]), s, tag="tangent_wide")
+        else:
+            call("harl_mlp_tangent_input", ptr(obs), obs.shape[1], None, m, net.in_dim, ptr(Wpd), ptr(bpd),
+                 int(net.use_feature_normalization), hs[0], ptr(net.xh[0]), ptr(net.rmask[0]), ptr(net.rstd[0]),
+                 ptr(ws["xd"][0]), s)
         for l in range(1, L):
             Wp, _ = net._packs[l]
             Wpd, bpd = ws["packs"][l]
@@ -116,20 +120,25 @@ class HATRPO(OnPolicyBase):
             out[off:off + net.act_dim] = (2.0 * dsig * dsig / (sigma * sigma)) * vview("act.action_out.log_std")
         return out + 0.1 * vec
 
-    def _head_outputs(self, obs, m, actions, avail) -> torch.Tensor:
-        """Distribution parameters at the current weights: Gaussian mean / normalised logits, [m, act_dim]."""
+    def _head_outputs(self, obs, m, actions, avail, reuse_trunk=False) -> torch.Tensor:
+        """Distribution parameters at the current weights: Gaussian mean / normalised logits, [m, act_dim].
+        ``reuse_trunk``: a _surrogate() call under the same weights has just left x_hat_L in the workspace."""
         out = torch.empty(m, self.actor.act_dim, **self.tpdv)
-        self._logp_pass(obs, actions, avail, m, None, head_out=out)
+        self._logp_pass(obs, actions, avail, m, None, head_out=out, reuse_trunk=reuse_trunk)
         return out
 
-    def _kl_mean(self, head_old, ls_old, head_new, m, m_global) -> float:
+    def _kl_sum(self, head_old, ls_old, head_new, m) -> torch.Tensor:
+        """Sum over the (global) batch of KL(old || new), fp64 device scalar [1]."""
         net = self.actor
         acc = torch.zeros(1, dtype=torch.float64, device=self.device)
         call("harl_trpo_kl_sum", ptr(head_old), ptr(head_new), ptr(ls_old), ptr(net.log_std()), net.std_x_coef,
              net.std_y_coef, m, net.act_dim, int(net.discrete), ptr(acc), stream())
         if self.comm.enabled:
             self.comm.all_reduce_sum(acc)
-        return float(acc.item()) / float(m_global)
+        return acc
+
+    def _kl_mean(self, head_old, ls_old, head_new, m, m_global) -> float:
+        return float(self._kl_sum(head_old, ls_old, head_new, m).item()) / float(m_global)
 
     def _update_core(self, obs, m, m_global, actions, avail, old_logp, adv, adv_moments, factor, active):
         net = self.actor
@@ -137,26 +146,29 @@ class HATRPO(OnPolicyBase):
         sc, g = self._surrogate(obs, m, actions, avail, old_logp, adv, adv_moments, factor, active, want_grad=True)
         loss = float((sc[0] / sc[1]).item())
         # conjugate gradient, 10 steps, residual tolerance 1e-10 (trpo_util.py:96-129)
+        # The reference leaves the loop once rdotr < 1e-10; here that test stays on the device (a `done` flag freezes x, r
+        # and p from then on -- the same iterates, no host round trip per iteration, at the price of idle FVPs after a break).
         x = torch.zeros_like(g)
         r, p = g.clone(), g.clone()
         rdotr = torch.dot(r, r)
+        done = torch.zeros((), dtype=torch.bool, device=g.device)
+        zero = torch.zeros((), dtype=g.dtype, device=g.device)
         for _ in range(10):
             avp = self._fvp(obs, m, m_global, avail, p)
-            alpha = rdotr / torch.dot(p, avp)
+            alpha = torch.where(done, zero, rdotr / torch.dot(p, avp))
             x += alpha * p
             r -= alpha * avp
             new_rdotr = torch.dot(r, r)
-            p = r + (new_rdotr / rdotr) * p
+            p = torch.where(done, p, r + (new_rdotr / rdotr) * p)
             rdotr = new_rdotr
-            if float(rdotr.item()) < 1e-10:
-                break
+            done = done | (rdotr < 1e-10)
         params = net.flat_param.clone()
         fv = self._fvp(obs, m, m_global, avail, x)
         shs = 0.5 * torch.dot(x, fv)
         step_size = 1.0 / torch.sqrt(shs / self.kl_threshold)
         full_step = step_size * x
         # "old actor" snapshot (hatrpo.py:127-130): distribution parameters at theta_old + the RNG draws its construction costs
-        head_old = self._head_outputs(obs, m, actions, avail)
+        head_old = self._head_outputs(obs, m, actions, avail, reuse_trunk=True)  # FVPs do not touch x_hat_l
         ls_old = None if net.discrete else net.log_std().clone()
         consume_policy_init_rng(self.args, self.obs_space, self.act_space)
         expected_improve = float(torch.dot(g, full_step).item())
@@ -169,10 +181,11 @@ class HATRPO(OnPolicyBase):
             net.flat_param.copy_(params + fraction * full_step)
             net.fold()
             sc_new, _ = self._surrogate(obs, m, actions, avail, old_logp, adv, adv_moments, factor, active, want_grad=False)
-            new_loss = float((sc_new[0] / sc_new[1]).item())
+            head_new = self._head_outputs(obs, m, actions, avail, reuse_trunk=True)
+            kl_sum = self._kl_sum(head_old, ls_old, head_new, m)
+            # ONE read-back per line-search step (the accept test needs both numbers on the host)
+            new_loss, kl = torch.stack([(sc_new[0] / sc_new[1]).to(torch.float64), kl_sum[0] / float(m_global)]).tolist()
             loss_improve = new_loss - loss
-            head_new = self._head_outputs(obs, m, actions, avail)
-            kl = self._kl_mean(head_old, ls_old, head_new, m, m_global)
             if kl < self.kl_threshold and (loss_improve / expected_improve) > self.accept_ratio and loss_improve > 0:
                 flag = True
                 break

@@ -67,6 +67,8 @@ class _FlatNet(nn.Module):
             if h not in SUPPORTED_WIDTHS:
                 raise NotImplementedError(f"hidden width {h}: kernels are instantiated for {SUPPORTED_WIDTHS}")
         self.in_dim = in_dim
+        self.wide = 64 < in_dim <= 512  # first layer through the x0n image (csrc/wide.hip)
+        self._x0n_key = None
         self._cpu_params: List[Tuple[str, torch.Tensor]] = []
         self._build_trunk_params(args)
 
@@ -240,7 +242,11 @@ class _FlatNet(nn.Module):
         self.rstd0 = torch.empty(mp, dtype=f32, device=dev)
         # narrow inputs: the forward pass leaves the normalised inputs behind as an ATL image for the dW_1 kernel
         self.kp0 = ((self.in_dim + 31) // 32) * 32
-        self.x0n = torch.empty(mp * self.kp0, dtype=f32, device=dev) if self.in_dim <= 64 else None
+        # wide inputs (64 < D <= 512, csrc/wide.hip): x0n is the operand of the first-layer GEMM itself
+        self.wide = 64 < self.in_dim <= 512
+        self._x0n_key = None
+        self.x0n = torch.empty(mp * self.kp0, dtype=f32, device=dev) if (self.in_dim <= 64 or self.wide) else None
+        self.w1img = torch.empty(3 * self.hidden_sizes[0] * self.kp0 // 2, dtype=f32, device=dev) if self.wide else None
         hmax = max(self.hidden_sizes)
         self.dz = [torch.empty(mp * hmax, dtype=f32, device=dev) for _ in range(2)]            # ping-pong, ATL
         self.dhead = torch.zeros(mp * DHEAD_LD, dtype=f32, device=dev)
@@ -301,6 +307,19 @@ class _FlatNet(nn.Module):
                  ptr(self.rmask[0]), ptr(self.rstd[0]), ptr(self.mu0), ptr(self.rstd0), ptr(self.xh[1]),
                  ptr(self.rmask[1]), ptr(self.rstd[1]), ptr(self.x0n) if for_backward else None, s, tag="fwd_fused2")
             first_hidden = 2
+        elif self.wide:
+            Wp, bp = self._packs[0]
+            # x0n depends on the rows only: every epoch / line-search step / log-prob pass over the same (unmodified)
+            # tensor reuses the image (torch's version counter catches in-place writes to the buffer)
+            # (identity row order only; the cache keeps a reference to the source tensor, so its storage cannot have been
+            # recycled for different data at the same address)
+            key = (X.data_ptr(), X._version, tuple(X.shape), M) if idx is None else None
+            if key is None or key != self._x0n_key:
+                call("harl_mlp_x0n_wide", ptr(X), X.shape[1], ptr(idx), M, self.in_dim, int(self.use_feature_normalization),
+                     ptr(self.x0n), ptr(self.mu0), ptr(self.rstd0), s, tag="x0n_wide")
+                self._x0n_key, self._x0n_src = key, (X if key is not None else None)
+            call("harl_mlp_fwd_wide", ptr(self.x0n), M, self.kp0, ptr(Wp), self.in_dim, ptr(bp), hs[0], ptr(self.w1img),
+                 ptr(self.xh[0]), ptr(self.rmask[0]), ptr(self.rstd[0]), s, tag="fwd_wide")
         else:
             Wp, bp = self._packs[0]
             call("harl_mlp_fwd_input", ptr(X), X.shape[1], ptr(idx), M, self.in_dim, ptr(Wp), ptr(bp),
@@ -343,7 +362,7 @@ class _FlatNet(nn.Module):
                      ptr(self.part[po[L + 3 + gate]:]), nwg, s, tag="dw_gru")
             cur = 1
         # first-layer weight gradient fused into the last bwd_dx (needs the ones column of x0n: in_dim < kp0)
-        fuse_dw1 = L >= 2 and self.x0n is not None and self.in_dim < self.kp0
+        fuse_dw1 = L >= 2 and self.x0n is not None and self.in_dim < self.kp0 and not self.wide
         for l in range(L - 1, 0, -1):
             ho, hi = self.hidden_sizes[l], self.hidden_sizes[l - 1]
             call("harl_mlp_dw_partials", ptr(self.dz[cur]), 0, 0, ho, ptr(self.xh[l - 1]), 0, 0, None, None, None, hi, M,
@@ -465,14 +484,22 @@ def consume_policy_init_rng(args: dict, obs_space, action_space) -> None:
     rng_sync()
     init = getattr(nn.init, args["initialization_method"])
     gain = nn.init.calculate_gain("relu")
+
+    def draw(lin, g):
+        if args["initialization_method"] == "orthogonal_":
+            # nn.init.orthogonal_ = normal_(0, 1) on a [rows, cols] tensor + a QR (no further draws): only the normal_
+            # touches the generator, and the QR of a 393 x 128 matrix costs ~8 ms of host time per call
+            w = lin.weight.data
+            w.new_empty((w.size(0), w.numel() // w.size(0))).normal_(0, 1)
+        else:
+            init(lin.weight.data, gain=g)
+
     d = _space_shape(obs_space)[0]
     for h in args["hidden_sizes"]:
-        lin = nn.Linear(d, h)
-        init(lin.weight.data, gain=gain)
+        draw(nn.Linear(d, h), gain)
         d = h
     n_out = int(action_space.n) if action_space.__class__.__name__ == "Discrete" else int(action_space.shape[0])
-    lin = nn.Linear(d, n_out)
-    init(lin.weight.data, gain=args["gain"])
+    draw(nn.Linear(d, n_out), args["gain"])
 
 
 def build_seq(dev, L: int, m: int, H: int, *, first_rows: Optional[torch.Tensor] = None, stride: Optional[int] = None,

@@ -105,6 +105,16 @@ int harl_unfold_linear_grads(const float *dWp, const float *dbp, int ldp, const 
 int harl_mlp_fwd_input(const float *X, long ldx, const int64_t *idx, long M, int D, const float *Wp,
                        const float *bp, int use_ln0, int H, float *xout, uint32_t *relu_mask, float *rstd,
                        float *mu0, float *rstd0, float *x0n, void *stream);
+/* WIDE observations (64 < D <= 512; harl_amd/csrc/wide.hip).  The first layer is split in two streaming kernels:
+ *   harl_mlp_x0n_wide: x0n = ATL(KP) image of norm0(X[idx]) (KP = D rounded up to 32, zero padded; use_ln0 = 0: the raw
+ *     rows), mu0 / rstd0 by minibatch position.  x0n depends on the inputs only: it is also the operand of
+ *     harl_mlp_tangent_wide and of harl_mlp_dw_partials(b_kind = 0, K = KP) for this layer.
+ *   harl_mlp_fwd_wide: xout = norm(relu(Wp x0n + bp)) with Wp [H][D]; w_img = scratch of 3 * H * KP * 2 bytes (the three
+ *     bf16 images of Wp, rebuilt on every call). */
+int harl_mlp_x0n_wide(const float *X, long ldx, const int64_t *idx, long M, int D, int use_ln0, float *x0n, float *mu0,
+                      float *rstd0, void *stream);
+int harl_mlp_fwd_wide(const float *x0n, long M, int KP, const float *Wp, int D, const float *bp, int H, void *w_img,
+                      float *xout, uint32_t *relu_mask, float *rstd, void *stream);
 /* fused layers 1+2 for narrow inputs (D <= 32) and equal widths H: x_hat_1 stays in registers between the two GEMMs;
  * store1 != 0 also writes x_hat_1 / mask1 / rstd1 / mu0 / rstd0 and (if non-NULL) x0n as in harl_mlp_fwd_input
  * (needed only when a backward pass follows). */
@@ -126,7 +136,8 @@ int harl_mlp_bwd_dx(const float *dz, const float *xprev, const uint32_t *relu_ma
                     int n_wg, void *stream);
 /* weight-gradient partials: part[wg] = { dWp[HO_pad32, KP] , dbp[HO_pad32] } summed over the samples the
  * workgroup processed; a_kind: 0 = ATL(HO) dz, 1 = row-major [M, lda] (head gradients, HO <= 32);
- * b_kind: 0 = ATL(K) x_hat, 1 = raw X[idx] rows (ldx, D=K) normalised with mu0/rstd0 (NULL = no LN0).
+ * b_kind: 0 = ATL(K) x_hat (K = 32, 64, 128, or a wide x0n image: any multiple of 32 up to 512), 1 = raw X[idx] rows
+ * (ldx, D=K) normalised with mu0/rstd0 (NULL = no LN0).
  * n_wg workgroups (= number of partial slabs) ; KP = K rounded up to 32. */
 int harl_mlp_dw_partials(const float *a, int a_kind, int lda, int HO, const float *b, int b_kind, long ldx,
                          const int64_t *idx, const float *mu0, const float *rstd0, int K, long M, float *part,
@@ -232,6 +243,9 @@ int harl_fold_linear_tangent(const float *W, const float *gamma, const float *be
 int harl_mlp_tangent_input(const float *X, long ldx, const int64_t *idx, long M, int D, const float *Wdp,
                            const float *bdp, int use_ln0, int H, const float *x1, const uint32_t *mask1,
                            const float *rstd1, float *x1dot, void *stream);
+/* the same for wide inputs, from the x0n image of harl_mlp_x0n_wide (w_img: scratch as in harl_mlp_fwd_wide) */
+int harl_mlp_tangent_wide(const float *x0n, long M, int KP, const float *Wdp, int D, const float *bdp, int H, void *w_img,
+                          const float *x1, const uint32_t *mask1, const float *rstd1, float *x1dot, void *stream);
 /* xout_dot = LNjac(mask * (Wp xin_dot + Wdp xin + bdp)) given the primal xprimal / mask / rstd of this layer */
 int harl_mlp_tangent_hidden(const float *xin_dot, const float *xin, long M, int HI, int HO, const float *Wp,
                             const float *Wdp, const float *bdp, const float *xprimal, const uint32_t *mask_in,

@@ -100,3 +100,32 @@ def test_randperm_replay_is_bit_exact_with_torch():
             assert len(taps) == 1 and torch.equal(taps[0], want)
             # and the next draw of the stream is unaffected
             assert torch.equal(torch.randperm(7), (torch.set_rng_state(want_state), torch.randperm(7))[1])
+
+
+def test_policy_init_rng_replay_matches_real_construction():
+    """HATRPO's old-actor snapshot draws (hatrpo.py:127-130) are replayed without the QR of orthogonal_: the global CPU
+    generator must end exactly where constructing the layers for real leaves it."""
+    import torch
+    import torch.nn as nn
+    from harl_amd.nets import consume_policy_init_rng
+
+    class Box:
+        def __init__(self, shape):
+            self.shape = shape
+
+    def real(d, hs, n):
+        g = nn.init.calculate_gain("relu")
+        for h in hs:
+            lin = nn.Linear(d, h)
+            nn.init.orthogonal_(lin.weight.data, gain=g)
+            d = h
+        lin = nn.Linear(d, n)
+        nn.init.orthogonal_(lin.weight.data, gain=0.01)
+
+    for d, hs, n in [(393, [128, 128, 128], 1), (18, [64], 5), (70, [128, 64], 3)]:
+        torch.manual_seed(5)
+        real(d, hs, n)
+        a = torch.get_rng_state()
+        torch.manual_seed(5)
+        consume_policy_init_rng(dict(initialization_method="orthogonal_", hidden_sizes=hs, gain=0.01), Box((d,)), Box((n,)))
+        assert bool((a == torch.get_rng_state()).all())

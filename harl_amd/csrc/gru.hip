@@ -8,9 +8,10 @@
 //              r = sigma(W_ir x + b_ir + W_hr h~ + b_hr)     z = sigma(W_iz x + b_iz + W_hz h~ + b_hz)
 //              n = tanh(W_in x + b_in + r * (W_hn h~ + b_hn))   h_l = (1 - z) * n + z * h~        (torch.nn.GRU, gates r,z,n)
 //              y_l = (h_l - mean) * rstd        (rnn.norm; its affine part is folded into the head weights)
-// Both weight matrices stay in LDS ([3H][H+1] each, 100 KiB for H = 64 -> one workgroup per CU).
+// Both weight matrices stay in LDS (W_ih fp32 [3H][H+1], W_hh as three bf16 images: 122 KiB for H = 64 -> one workgroup per CU).
 // H = 64 only (every recurrent tuned HARL config: SMAC / SMACv2 / football use hidden 64).
 #include "common.h"
+#include "split_mfma.h"
 #include "../../include/harl_hip.h"
 
 using namespace harl;
@@ -22,7 +23,23 @@ constexpr int GH = 64;         // hidden width
 constexpr int GR = GH / 2;     // registers per lane per width-64 activation
 constexpr int GT = GH / 32;    // 32-row tiles per gate
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// Gate nonlinearities on the hardware exp2 / rcp (1 ulp each): 4-5 VALU ops per value.  With libm's expf / tanhf and IEEE
+// division the 96 transcendental values of a step cost ~2500 VALU instructions -- more than the step's 144 MFMAs, and on
+// the recurrence's critical path (one wave, L dependent steps).  Per-tensor gradient error of a 10-25 step BPTT update
+// against the oracle stays <= 1e-5 of the tensor's inf-norm (tools/rnn_diag.py), as with libm.
+__device__ __forceinline__ float rcp_nr(float d) {  // v_rcp_f32 + one Newton step: <= 0.5 ulp
+  const float r = __builtin_amdgcn_rcpf(d);
+  return fmaf(fmaf(-d, r, 1.0f), r, r);
+}
+__device__ __forceinline__ float exp_scaled(float x, float c_hi, float c_lo) {  // 2^{x (c_hi + c_lo)}: constant in two pieces
+  return __builtin_amdgcn_exp2f(fminf(fmaf(x, c_hi, x * c_lo), 126.0f));  // clamped: 1 + 2^126 is finite, so rcp_nr never sees inf * 0
+}
+__device__ __forceinline__ float sigmoidf_(float x) {
+  return rcp_nr(1.0f + exp_scaled(x, -1.44269502162933349609f, -1.92596303029868504e-8f));
+}
+__device__ __forceinline__ float tanhf_(float x) {  // 1 - 2 / (1 + e^{2x});  saturates cleanly for |x| large
+  return fmaf(-2.0f, rcp_nr(1.0f + exp_scaled(x, 2.88539004325866699219f, 3.85192606059737008e-8f)), 1.0f);
+}
 
 __device__ __forceinline__ void load_act(const float *__restrict__ base, long slab, int lane, float (&x)[GR]) {
   atl_load<GH>(base, slab, lane, x);
@@ -124,12 +141,15 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_gru_fwd(
     float *__restrict__ hn_s, float *__restrict__ h_last, int save) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int LDW = GH + 1;
-  float *Whl = lds;                               // [192][65]
-  float *Wil = Whl + 3 * GH * LDW;                // [192][65]   (absent when the x half is precomputed)
+  // W_hh: the recurrence's critical path (one wave, L dependent steps) runs on the bf16 pipe with the exact three-way
+  // operand split (split_mfma.h): 6 tiles x 4 k-steps x 6 products = 144 MFMAs of 32 cycles per step instead of 192 of 64
+  constexpr int MTH = 3 * GT, NJH = GH / 16;
+  u32x4 *Whimg = reinterpret_cast<u32x4 *>(lds);  // [3 terms][6 tiles][4 k-steps][64 lanes] x 16 B = 72 KiB
+  float *Wil = reinterpret_cast<float *>(Whimg + 3 * MTH * NJH * 64);  // [192][65]  (absent when the x half is precomputed)
   float *bil = Wil + (PRE ? 0 : 3 * GH * LDW);    // [192]
   float *bhl = bil + 3 * GH;                      // [192]
   if (!PRE) stage_matrix<3 * GH, GH, LDW, WG_THREADS>(Wil, Wih);
-  stage_matrix<3 * GH, GH, LDW, WG_THREADS>(Whl, Whh);
+  stage_split_matrix<3 * GH, GH, false, WG_THREADS>(Whimg, Whh);
   for (int e = threadIdx.x; e < 3 * GH; e += WG_THREADS) {
     bil[e] = bih[e];
     bhl[e] = bhh[e];
@@ -139,7 +159,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_gru_fwd(
   const int i = lane & 31, h = lane >> 5;
   const long groups = m_pad / SLAB;
   const float *wi_lane = Wil + i * LDW + 4 * h;
-  const float *wh_lane = Whl + i * LDW + 4 * h;
+  const u32x4 *wh_img = Whimg + lane;
   for (long G = (long)blockIdx.x * WAVES_PER_WG + wave; G < groups; G += (long)gridDim.x * WAVES_PER_WG) {
     float hs[GR];
     load_rows(h0, G * SLAB + i, h, hs);
@@ -178,8 +198,24 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_gru_fwd(
             }
         gemm_gates<7>(acc, wi_lane, x);
       }
-      gemm_gates<3>(acc, wh_lane, hs);   // r, z: same accumulators
-      gemm_gates<4>(acch, wh_lane, hs);  // n: W_hn h~ + b_hn on its own
+      {  // W_hh h~:  r, z onto the x-half accumulators, n (W_hn h~ + b_hn) on its own
+        u32x4 h1[NJH], h2[NJH], h3[NJH];
+        split_acts<GR>(hs, h1, h2, h3);
+        f32x16 a6[MTH];
+#pragma unroll
+        for (int t = 0; t < GT; ++t) {
+          a6[0 * GT + t] = acc[0][t];
+          a6[1 * GT + t] = acc[1][t];
+          a6[2 * GT + t] = acch[2][t];
+        }
+        split_gemm<MTH, NJH>(wh_img, h1, h2, h3, a6, [](int) {});
+#pragma unroll
+        for (int t = 0; t < GT; ++t) {
+          acc[0][t] = a6[0 * GT + t];
+          acc[1][t] = a6[1 * GT + t];
+          acch[2][t] = a6[2 * GT + t];
+        }
+      }
       float rg[GR], zg[GR], ng[GR], hn[GR];
       float sum = 0.f;
 #pragma unroll
@@ -187,7 +223,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_gru_fwd(
         rg[R] = sigmoidf_(acc[0][R >> 4][R & 15]);
         zg[R] = sigmoidf_(acc[1][R >> 4][R & 15]);
         hn[R] = acch[2][R >> 4][R & 15];
-        ng[R] = tanhf(acc[2][R >> 4][R & 15] + rg[R] * hn[R]);
+        ng[R] = tanhf_(acc[2][R >> 4][R & 15] + rg[R] * hn[R]);
         hs[R] = (1.f - zg[R]) * ng[R] + zg[R] * hs[R];
         sum += hs[R];
       }
@@ -338,12 +374,12 @@ extern "C" int harl_gru_fwd(const float *xin, const float *mask_rows, const floa
     allow_big_lds(k_gru_gates_x, shm_x);
     hipLaunchKernelGGL(k_gru_gates_x, dim3(persistent_grid(n_slabs, 1)), dim3(WG_THREADS), shm_x, s, xin, Wih, bih, bhh,
                        n_slabs, gr, gz, gn);
-    const size_t shm = ((size_t)3 * GH * (GH + 1) + 2 * 3 * GH) * sizeof(float);
+    const size_t shm = split_image_bytes(3 * GH, GH) + ((size_t)2 * 3 * GH) * sizeof(float);
     allow_big_lds(k_gru_fwd<true>, shm);
     hipLaunchKernelGGL(k_gru_fwd<true>, dim3(grid), dim3(WG_THREADS), shm, s, xin, gr, gz, gn, mask_rows, h0, Wih, bih,
                        Whh, bhh, L, m_pad, y, rstd_y, hpm, r, z, n, hn, h_last, save);
   } else {
-    const size_t shm = ((size_t)2 * 3 * GH * (GH + 1) + 2 * 3 * GH) * sizeof(float);
+    const size_t shm = split_image_bytes(3 * GH, GH) + ((size_t)3 * GH * (GH + 1) + 2 * 3 * GH) * sizeof(float);
     allow_big_lds(k_gru_fwd<false>, shm);
     hipLaunchKernelGGL(k_gru_fwd<false>, dim3(grid), dim3(WG_THREADS), shm, s, xin, nullptr, nullptr, nullptr, mask_rows,
                        h0, Wih, bih, Whh, bhh, L, m_pad, y, rstd_y, hpm, r, z, n, hn, h_last, save);

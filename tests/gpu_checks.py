@@ -86,6 +86,57 @@ def check_gae() -> Dict[str, float]:
     return out
 
 
+def check_wide_input() -> Dict[str, float]:
+    """Wide-observation first layer (csrc/wide.hip): the x0n ATL image + input-LayerNorm statistics against torch, and the
+    split-bf16 GEMM + ReLU/LayerNorm against a float64 evaluation, for widths around every tile / chunk boundary."""
+    out = {}
+    rng = np.random.default_rng(11)
+    H = 128
+    for D, M, use_ln, gather in ((65, 97, 1, False), (100, 257, 1, True), (128, 64, 0, False), (200, 1000, 1, False),
+                                 (393, 300, 1, True), (449, 33, 1, False), (512, 130, 1, False)):
+        KP, ns = (D + 31) // 32 * 32, (M + 31) // 32
+        rows = M + 40
+        X = (rng.standard_normal((rows, D)) * rng.uniform(0.2, 3.0, size=(1, D)) + rng.uniform(-2, 2, size=(1, D))).astype(np.float32)
+        idx = rng.permutation(rows)[:M].astype(np.int64) if gather else None
+        dX, didx = dev(X), (None if idx is None else torch.from_numpy(idx).to(DEV))
+        x0n = torch.full((ns * 32 * KP,), float("nan"), device=DEV)
+        mu0, rstd0 = torch.empty(ns * 32, device=DEV), torch.empty(ns * 32, device=DEV)
+        call("harl_mlp_x0n_wide", ptr(dX), D, ptr(didx), M, D, use_ln, ptr(x0n), ptr(mu0), ptr(rstd0), stream())
+        Xg = torch.from_numpy(X[:M] if idx is None else X[idx]).double()
+        ref = torch.nn.functional.layer_norm(Xg, (D,), eps=1e-5) if use_ln else Xg
+        img = x0n.cpu().reshape(ns, KP // 8, 2, 32, 4)  # [slab][piece q][half h][sample][c] -> feature 32(q>>2)+8(q&3)+4h+c
+        dec = torch.empty(ns * 32, KP, dtype=torch.float32)
+        for q in range(KP // 8):
+            for hh in range(2):
+                f0 = 32 * (q >> 2) + 8 * (q & 3) + 4 * hh
+                dec[:, f0:f0 + 4] = img[:, q, hh].reshape(ns * 32, 4)
+        tag = f"D{D}"
+        out[f"x0n_{tag}_abs"] = float((dec[:M, :D].double() - ref).abs().max())
+        out[f"x0n_{tag}_pad_abs"] = float(dec[:M, D:].abs().max()) if KP > D else 0.0
+        if use_ln:
+            out[f"mu0_{tag}_abs"] = float((mu0.cpu()[:M].double() - Xg.mean(1)).abs().max())
+            out[f"rstd0_{tag}_rel"] = float(((rstd0.cpu()[:M].double() * torch.sqrt(Xg.var(1, unbiased=False) + 1e-5)) - 1).abs().max())
+        # GEMM + epilogue
+        W = (rng.standard_normal((H, D)) / np.sqrt(D)).astype(np.float32)
+        b = (rng.standard_normal(H) * 0.1).astype(np.float32)
+        dW, db = dev(W), dev(b)
+        wimg = torch.empty(3 * H * KP // 2, device=DEV)
+        xo = torch.empty(ns * 32 * H, device=DEV)
+        msk = torch.empty(ns * 2 * 64, dtype=torch.int32, device=DEV)
+        rs = torch.empty(ns * 32, device=DEV)
+        call("harl_mlp_fwd_wide", ptr(x0n), M, KP, ptr(dW), D, ptr(db), H, ptr(wimg), ptr(xo), ptr(msk), ptr(rs), stream())
+        z = torch.relu(dec[:M, :D].double() @ torch.from_numpy(W).double().T + torch.from_numpy(b).double())
+        refy = torch.nn.functional.layer_norm(z, (H,), eps=1e-5)
+        yi = xo.cpu().reshape(ns, H // 8, 2, 32, 4)
+        y = torch.empty(ns * 32, H)
+        for q in range(H // 8):
+            for hh in range(2):
+                f0 = 32 * (q >> 2) + 8 * (q & 3) + 4 * hh
+                y[:, f0:f0 + 4] = yi[:, q, hh].reshape(ns * 32, 4)
+        out[f"fwd_wide_{tag}_abs"] = float((y[:M].double() - refy).abs().max())
+    return out
+
+
 def check_elementwise() -> Dict[str, float]:
     out = {}
     rng = np.random.default_rng(3)

@@ -35,6 +35,11 @@ def test_elementwise_kernels():
     _assert_all(_G().check_elementwise(), tol=2e-6)
 
 
+def test_wide_input_first_layer():
+    """x0n image / LayerNorm statistics / split-bf16 GEMM of the wide-observation path at widths 65..512."""
+    _assert_all(_G().check_wide_input(), tol=5e-6)
+
+
 def test_fused_gradnorm_clip_adam():
     _assert_all(_G().check_adam(), tol=2e-6)
 

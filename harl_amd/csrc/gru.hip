@@ -1,4 +1,4 @@
-// gru.hip -- GRU recurrent layer (harl/models/base/rnn.py:8-81, recurrent_n = 1) forward and BPTT on fp32 MFMA, gfx950.
+// gru.hip -- GRU recurrent layer (harl/models/base/rnn.py:8-81, recurrent_n = 1) forward and BPTT on the MFMA pipes, gfx950.
 //
 // A recurrent batch is L time steps x m sequences, row (l, j) at index l*m_pad + j (m_pad = m rounded up to 32, so a
 // wave-slab never straddles two time steps).  A wave owns 32 sequences for the whole chunk: the hidden state lives in

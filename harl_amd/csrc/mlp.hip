@@ -1,4 +1,6 @@
-// mlp.hip -- actor / critic MLP forward and backward on fp32 MFMA (v_mfma_f32_32x32x2_f32), gfx950.
+// mlp.hip -- actor / critic MLP forward and backward on the gfx950 matrix pipes: the H x H GEMMs on
+// v_mfma_f32_32x32x16_bf16 with an exact three-way fp32 operand split (split_mfma.h), the narrow ones (first layer,
+// fused first-layer weight gradient) on v_mfma_f32_32x32x2_f32.
 //
 // Replaces MLPBase/MLPLayer forward + autograd backward of the reference
 // (harl/models/base/mlp.py:7-70) for the HAPPO / V-critic update.
@@ -13,7 +15,7 @@
 // The only transposes are in the weight-gradient kernel (the reduction runs over samples, so
 // samples must become the MFMA k index); they go through LDS.
 //
-// Weights live in LDS for the lifetime of a persistent workgroup (<= 66 KiB -> 2 workgroups per CU).
+// Weights live in LDS for the lifetime of a persistent workgroup (three bf16 images, 96 KiB for 128 x 128).
 #include "common.h"
 #include "split_mfma.h"
 #include "../../include/harl_hip.h"

@@ -83,7 +83,8 @@ int harl_gradnorm_clip_adam(float *param, float *grad, float *exp_avg, float *ex
                             double bias_correction2, float *info_out, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
- * MLP (harl/models/base/mlp.py:7-70) on fp32 MFMA.  LayerNorm affine terms are folded into the
+ * MLP (harl/models/base/mlp.py:7-70) on the matrix pipes (H x H GEMMs: bf16 MFMA with an exact three-way fp32 operand
+ * split, fp32 accumulation -- csrc/split_mfma.h; narrow GEMMs: fp32 MFMA).  LayerNorm affine terms are folded into the
  * following Linear (W' = W diag(gamma), b' = b + W beta); the kernels work on pure normalisations
  * and harl_mlp_unfold_grads maps the folded gradients back to the reference parameters.
  */

@@ -662,7 +662,7 @@ template <int HO, int HI, int KT = 0>
 __global__ __launch_bounds__(WG_THREADS, (KT > 0 || split_one_wg(HI, HO)) ? 1 : 2) void k_bwd_dx(
     const float *__restrict__ dz, const float *__restrict__ xprev, const uint32_t *__restrict__ mask_prev,
     const float *__restrict__ rstd_prev, const float *__restrict__ Wp, float *__restrict__ dz_prev, long n_slabs,
-    const float *__restrict__ x0n = nullptr, float *__restrict__ dw_part = nullptr) {
+    const float *__restrict__ x0n = nullptr, float *__restrict__ dw_part = nullptr, int n_part_rows = 0) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   // dx_hat = Wp^T dz on the bf16 pipe (split_mfma.h): GEMM rows = input features, k = output features
   constexpr int MT = HI / 32, NJ = HO / 16, NRO = HO / 2;
@@ -769,6 +769,12 @@ __global__ __launch_bounds__(WG_THREADS, (KT > 0 || split_one_wg(HI, HO)) ? 1 : 
     float *outp = dw_part + (long)blockIdx.x * ((long)HI * KPF + HI);
     for (int e = threadIdx.x; e < HI * KPF; e += WG_THREADS) outp[e] = buf[e];
     for (int o = threadIdx.x; o < HI; o += WG_THREADS) outp[HI * KPF + o] = buf[o * KPF + KPF - 1];  // ones column
+    // the partial arena has n_part_rows rows per layer (shared with the other gradient kernels); this kernel runs one
+    // workgroup per CU (a second round of workgroups would pay the weight-image prologue twice), so it clears the rest
+    for (int row = blockIdx.x + gridDim.x; row < n_part_rows; row += gridDim.x) {
+      float *z = dw_part + (long)row * ((long)HI * KPF + HI);
+      for (int e = threadIdx.x; e < HI * KPF + HI; e += WG_THREADS) z[e] = 0.f;
+    }
   }
 }
 
@@ -1346,8 +1352,8 @@ extern "C" int harl_mlp_bwd_dx(const float *dz, const float *xprev, const uint32
     if (fl < (size_t)b * 32 * kt) fl = (size_t)b * 32 * kt;                                                       \
     const size_t shm = split_image_bytes(b, a) + fl * sizeof(float);                                              \
     allow_big_lds(k_bwd_dx<a, b, kt>, shm);                                                                       \
-    hipLaunchKernelGGL((k_bwd_dx<a, b, kt>), dim3(n_wg), dim3(WG_THREADS), shm, s, dz, xprev, relu_mask_prev,      \
-                       rstd_prev, Wp, dz_prev, n_slabs, x0n, dw_part);                                            \
+    hipLaunchKernelGGL((k_bwd_dx<a, b, kt>), dim3(n_wg < 256 ? n_wg : 256), dim3(WG_THREADS), shm, s, dz, xprev,   \
+                       relu_mask_prev, rstd_prev, Wp, dz_prev, n_slabs, x0n, dw_part, n_wg);                      \
   }
     const int kt = kp0 / 32;
     if (HO == 128 && HI == 128) { if (kt == 1) LF(128, 128, 1) else LF(128, 128, 2) }
@@ -1363,7 +1369,7 @@ extern "C" int harl_mlp_bwd_dx(const float *dz, const float *xprev, const uint32
 #define L(a, b)                                                                                                    \
   allow_big_lds(k_bwd_dx<a, b>, shm);                                                                              \
   hipLaunchKernelGGL((k_bwd_dx<a, b>), dim3(grid), dim3(WG_THREADS), shm, s, dz, xprev, relu_mask_prev, rstd_prev, Wp, \
-                     dz_prev, n_slabs, nullptr, nullptr)
+                     dz_prev, n_slabs, nullptr, nullptr, 0)
   if (HO == 128 && HI == 128) { L(128, 128); }
   else if (HO == 64 && HI == 64) { L(64, 64); }
   else if (HO == 128 && HI == 64) { L(128, 64); }

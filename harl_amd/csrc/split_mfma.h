@@ -77,18 +77,30 @@ constexpr size_t split_image_bytes(int rows, int k) { return (size_t)3 * rows * 
 template <int HO, int HI, bool TRANSPOSED, int NTHR>
 __device__ __forceinline__ void stage_split_matrix(u32x4 *__restrict__ img, const float *__restrict__ Wp) {
   constexpr int M = TRANSPOSED ? HI : HO, K = TRANSPOSED ? HO : HI, MT = M / 32, NJ = K / 16;
-  for (int e = threadIdx.x; e < MT * NJ * 64; e += NTHR) {
-    const int ln = e & 63, j = (e >> 6) % NJ, t = (e >> 6) / NJ, m = 32 * t + (ln & 31), g = ln >> 5;
-    unsigned p[3][4];
+  constexpr int TOTAL = MT * NJ * 64, PER = (TOTAL + NTHR - 1) / NTHR;
+  // all of a thread's weights are fetched before the first split: one L2 latency for the whole prologue instead of one
+  // per fragment (the prologue is paid by every workgroup of every launch)
+  float w[PER][8];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int k0 = feat_base(8 * j + 2 * c) + 4 * g, k1 = feat_base(8 * j + 2 * c + 1) + 4 * g;
-      const float w0 = TRANSPOSED ? Wp[(long)k0 * HI + m] : Wp[(long)m * HI + k0];
-      const float w1 = TRANSPOSED ? Wp[(long)k1 * HI + m] : Wp[(long)m * HI + k1];
-      split3_rne(w0, w1, p[0][c], p[1][c], p[2][c]);
+  for (int u = 0; u < PER; ++u) {
+    const int e = threadIdx.x + u * NTHR, ec = e < TOTAL ? e : 0;
+    const int ln = ec & 63, j = (ec >> 6) % NJ, t = (ec >> 6) / NJ, m = 32 * t + (ln & 31), g = ln >> 5;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const int k = feat_base(8 * j + c) + 4 * g;
+      w[u][c] = TRANSPOSED ? Wp[(long)k * HI + m] : Wp[(long)m * HI + k];
     }
+  }
 #pragma unroll
-    for (int term = 0; term < 3; ++term) img[term * (MT * NJ * 64) + e] = u32x4{p[term][0], p[term][1], p[term][2], p[term][3]};
+  for (int u = 0; u < PER; ++u) {
+    const int e = threadIdx.x + u * NTHR;
+    if (e < TOTAL) {
+      unsigned p[3][4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) split3_rne(w[u][2 * c], w[u][2 * c + 1], p[0][c], p[1][c], p[2][c]);
+#pragma unroll
+      for (int term = 0; term < 3; ++term) img[term * TOTAL + e] = u32x4{p[term][0], p[term][1], p[term][2], p[term][3]};
+    }
   }
 }
 

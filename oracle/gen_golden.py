@@ -135,6 +135,13 @@ CASES = {
     "mappo_shared_fp_box_h128": dict(algo="mappo", state_type="FP",
                                      shapes=dict(T=8, N=6, A=2, obs_dim=10, share_obs_dim=14, act_dim=3, discrete=False,
                                                  hidden_sizes=[128, 128]), seed=23, overrides=dict(share_param=True)),
+    # ---- HATRPO with GRU policies (tuned SMAC / SMACv2 configs): one sample of all chunks, FVP through the recurrence
+    "trpo_rnn_disc_h64": dict(algo="hatrpo", shapes=dict(T=10, N=8, A=2, obs_dim=14, share_obs_dim=12, act_dim=5, discrete=True,
+                                                         hidden_sizes=[64]), seed=41, unavailable_p=0.2, inactive_p=0.1,
+                              overrides=dict(use_recurrent_policy=True, data_chunk_length=5)),
+    "trpo_rnn_box_h64": dict(algo="hatrpo", shapes=dict(T=12, N=8, A=2, obs_dim=9, share_obs_dim=10, act_dim=2, discrete=False,
+                                                        hidden_sizes=[64, 64]), seed=42,
+                             overrides=dict(use_recurrent_policy=True, data_chunk_length=4, fixed_order=True)),
     "trpo_wide_h128x3": dict(algo="hatrpo", shapes=dict(T=8, N=8, A=3, obs_dim=70, share_obs_dim=65, act_dim=1,
                                                         discrete=False, hidden_sizes=[128, 128, 128]), seed=9,
                              overrides=dict(fixed_order=True), inactive_p=0.15),

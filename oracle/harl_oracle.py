@@ -754,9 +754,11 @@ class TrpoConfig:
     backtrack_coeff: float = 0.8
 
 
-def _dist_params(p, cfg: PathConfig, obs, avail):
+def _dist_params(p, cfg: PathConfig, obs, avail, rnn=None, masks=None):
     """(kind, tensors) of the action distribution: Gaussian (mean, std) or Categorical normalised logits."""
     feat = mlp_base_forward(p, obs)
+    if "rnn.rnn.weight_ih_l0" in p:
+        feat, _ = rnn_layer_forward(p, feat, rnn, masks)
     if "act.action_out.log_std" in p:
         mean = F.linear(feat, p["act.action_out.fc_mean.weight"], p["act.action_out.fc_mean.bias"])
         std = (torch.sigmoid(p["act.action_out.log_std"] / cfg.std_x_coef) * cfg.std_y_coef).expand_as(mean)
@@ -767,12 +769,12 @@ def _dist_params(p, cfg: PathConfig, obs, avail):
     return "categorical", (logits - logits.logsumexp(dim=-1, keepdim=True),)
 
 
-def trpo_kl(p_new, p_old, cfg: PathConfig, obs, avail) -> torch.Tensor:
+def trpo_kl(p_new, p_old, cfg: PathConfig, obs, avail, rnn=None, masks=None) -> torch.Tensor:
     """kl_divergence (trpo_util.py:65-92): [B, 1]; Gaussian analytic KL(old || new) in float64 summed over dims,
     Categorical `kl_approx` on the normalised logits (trpo_util.py:47-51)."""
-    kind, new = _dist_params(p_new, cfg, obs, avail)
+    kind, new = _dist_params(p_new, cfg, obs, avail, rnn, masks)
     with torch.no_grad():
-        _, old = _dist_params(p_old, cfg, obs, avail)
+        _, old = _dist_params(p_old, cfg, obs, avail, rnn, masks)
     if kind == "categorical":
         q, pp = new[0], old[0]
         kl = torch.exp(q - pp) - 1 - q + pp
@@ -790,7 +792,15 @@ def consume_policy_init_rng(shapes: Dict[str, Tuple[int, ...]], gain: float = 0.
     are part of the RNG stream of train() and must be replayed for the later permutations to match."""
     relu_gain = torch.nn.init.calculate_gain("relu")
     for name, shp in shapes.items():
-        if len(shp) == 2:  # every Linear, in parameters() order: hidden layers (relu gain), then the head (gain)
+        if name == "rnn.rnn.weight_ih_l0":  # RNNLayer (rnn.py:8-21): nn.GRU's own uniform init, then orthogonal_ on the weights
+            H = shp[1]
+            gru = torch.nn.GRU(H, H, num_layers=1)
+            for pn, prm in gru.named_parameters():
+                if "weight" in pn:
+                    torch.nn.init.orthogonal_(prm)
+        elif name.startswith("rnn."):
+            continue
+        elif len(shp) == 2:  # every Linear, in parameters() order: hidden layers (relu gain), then the head (gain)
             lin = torch.nn.Linear(shp[1], shp[0])
             torch.nn.init.orthogonal_(lin.weight.data, gain=gain if ("action_out" in name) else relu_gain)
 
@@ -816,21 +826,22 @@ class OracleHATRPO:
             v.data.copy_(vec[i:i + n].view(v.shape))
             i += n
 
-    def evaluate_actions(self, obs, action, available_actions=None, active_masks=None):
+    def evaluate_actions(self, obs, action, available_actions=None, active_masks=None, rnn_states=None, masks=None):
         return actor_evaluate_actions(self.p, self.cfg, _t(obs), _t(action),
                                       None if available_actions is None else _t(available_actions),
-                                      None if active_masks is None else _t(active_masks))
+                                      None if active_masks is None else _t(active_masks),
+                                      None if rnn_states is None else _t(rnn_states), None if masks is None else _t(masks))
 
-    def fvp(self, obs, avail, vec: torch.Tensor) -> torch.Tensor:  # trpo_util.py:132-158
+    def fvp(self, obs, avail, vec: torch.Tensor, rnn=None, masks=None) -> torch.Tensor:  # trpo_util.py:132-158
         old = {k: v.detach() for k, v in self.p.items()}
-        kl = trpo_kl(self.p, old, self.cfg, obs, avail).mean()
+        kl = trpo_kl(self.p, old, self.cfg, obs, avail, rnn, masks).mean()
         g = torch.autograd.grad(kl, self.params(), create_graph=True, allow_unused=True)
         gflat = torch.cat([x.reshape(-1) for x in g if x is not None])
         hv = torch.autograd.grad((gflat * vec).sum(), self.params(), allow_unused=True)
         return torch.cat([x.contiguous().reshape(-1) for x in hv if x is not None]).data + 0.1 * vec
 
-    def surrogate(self, obs, actions, avail, active, old_logp, adv, factor):
-        logp, ent, _ = actor_evaluate_actions(self.p, self.cfg, obs, actions, avail, active)
+    def surrogate(self, obs, actions, avail, active, old_logp, adv, factor, rnn=None, masks=None):
+        logp, ent, _ = actor_evaluate_actions(self.p, self.cfg, obs, actions, avail, active, rnn, masks)
         ratio = getattr(torch, self.cfg.action_aggregation)(torch.exp(logp - old_logp), dim=-1, keepdim=True)
         if self.cfg.use_policy_active_masks:
             loss = (torch.sum(ratio * factor * adv, dim=-1, keepdim=True) * active).sum() / active.sum()
@@ -840,8 +851,9 @@ class OracleHATRPO:
 
     def update(self, sample):  # hatrpo.py:37-194
         t = self.tcfg
-        obs, actions, active, old_logp, adv, avail, factor = (None if s is None else _t(s) for s in sample)
-        loss, ent, ratio = self.surrogate(obs, actions, avail, active, old_logp, adv, factor)
+        obs, actions, active, old_logp, adv, avail, factor = (None if s is None else _t(s) for s in sample[:7])
+        rnn, msk = (_t(sample[7]), _t(sample[8])) if len(sample) > 7 else (None, None)  # recurrent generators
+        loss, ent, ratio = self.surrogate(obs, actions, avail, active, old_logp, adv, factor, rnn, msk)
         g = torch.autograd.grad(loss, self.params(), allow_unused=True)
         g = torch.cat([x.reshape(-1) for x in g if x is not None]).data
         # conjugate gradient, 10 steps, residual tolerance 1e-10 (trpo_util.py:96-129)
@@ -849,7 +861,7 @@ class OracleHATRPO:
         r, pvec = g.clone(), g.clone()
         rdotr = torch.dot(r, r)
         for _ in range(10):
-            avp = self.fvp(obs, avail, pvec)
+            avp = self.fvp(obs, avail, pvec, rnn, msk)
             alpha = rdotr / torch.dot(pvec, avp)
             x += alpha * pvec
             r -= alpha * avp
@@ -860,7 +872,7 @@ class OracleHATRPO:
                 break
         loss0 = loss.data.numpy()
         params = self.flat().clone()
-        fv = self.fvp(obs, avail, x)
+        fv = self.fvp(obs, avail, x, rnn, msk)
         shs = 0.5 * (x * fv).sum(0, keepdim=True)
         step_size = 1 / torch.sqrt(shs / t.kl_threshold)[0]
         full_step = step_size * x
@@ -871,9 +883,9 @@ class OracleHATRPO:
         info = dict(grad=g.numpy().copy(), step_dir=x.numpy().copy(), step_size=float(step_size), shs=float(shs))
         for _ in range(t.ls_step):
             self.set_flat(params + fraction * full_step)
-            new_loss, ent, ratio = self.surrogate(obs, actions, avail, active, old_logp, adv, factor)
+            new_loss, ent, ratio = self.surrogate(obs, actions, avail, active, old_logp, adv, factor, rnn, msk)
             improve = new_loss.data.numpy() - loss0
-            kl = trpo_kl(self.p, old, self.cfg, obs, avail).mean()
+            kl = trpo_kl(self.p, old, self.cfg, obs, avail, rnn, msk).mean()
             if kl < t.kl_threshold and (improve / expected) > t.accept_ratio and improve.item() > 0:
                 flag = True
                 break
@@ -894,7 +906,14 @@ class OracleHATRPO:
             return out
         if state_type == "EP":
             advantages = normalize_advantages(advantages, buf.active_masks[:-1])
-        for sample, _ in buf.feed_forward_generator(advantages, 1):
+        cfg = self.cfg
+        if cfg.use_recurrent_policy:  # hatrpo.py:222-231: ONE sample holding every chunk
+            gen = buf.recurrent_generator(advantages, 1, cfg.data_chunk_length)
+        elif cfg.use_naive_recurrent_policy:
+            gen = buf.naive_recurrent_generator(advantages, 1)
+        else:
+            gen = buf.feed_forward_generator(advantages, 1)
+        for sample, _ in gen:
             i = self.update(sample)
             for k in out:
                 out[k] += i[k]

@@ -356,6 +356,168 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_gru_bwd(
 }
 }  // namespace
 
+// =============================================================================================
+// Forward-mode tangent through the recurrence (HATRPO's Fisher-vector product J v for GRU policies).
+//   a_r = W_ir x + W_hr h~ + b  ->  a_r' = [W_ir x' + W_ir' x + W_hr' h~] + W_hr h~' + b_ir' + b_hr' ;  r' = r (1 - r) a_r'
+//   hn  = W_hn h~ + b_hn        ->  hn'  = [W_hn' h~] + W_hn h~' + b_hn'
+//   a_n = W_in x + b_in + r hn  ->  a_n' = [W_in x' + W_in' x] + b_in' + r' hn + r hn' ;       n' = (1 - n^2) a_n'
+//   h   = (1 - z) n + z h~      ->  h'   = (1 - z) n' - z' n + z' h~ + z h~'
+//   y   = norm(h)               ->  y'   = rstd (h' - mean(h') - y mean(h' y))
+// The bracketed terms have no recurrence: harl_gru_gates computes them for all steps in parallel (g_r, g_z, g_nx, g_nh);
+// this kernel carries h' in registers and only multiplies W_hh h~' per step (the same bf16 images as the forward).
+// =============================================================================================
+__global__ __launch_bounds__(WG_THREADS, 1) void k_gru_gates_lin(const float *__restrict__ xin, const float *__restrict__ W,
+                                                                 long n_slabs, float *__restrict__ o_r,
+                                                                 float *__restrict__ o_z, float *__restrict__ o_n,
+                                                                 int acc_mask) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int LDW = GH + 1;
+  float *Wl = lds;  // [192][65]
+  stage_matrix<3 * GH, GH, LDW, WG_THREADS>(Wl, W);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  const float *w_lane = Wl + i * LDW + 4 * h;
+  for (long slab = (long)blockIdx.x * WAVES_PER_WG + wave; slab < n_slabs; slab += (long)gridDim.x * WAVES_PER_WG) {
+    float x[GR];
+    load_act(xin, slab, lane, x);
+    f32x16 acc[3][GT];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+      float *og = g == 0 ? o_r : (g == 1 ? o_z : o_n);
+      float prev[GR];
+      if ((acc_mask >> g) & 1) load_act(og, slab, lane, prev);
+#pragma unroll
+      for (int R = 0; R < GR; ++R) acc[g][R >> 4][R & 15] = ((acc_mask >> g) & 1) ? prev[R] : 0.f;
+    }
+    gemm_gates<7>(acc, w_lane, x);
+    float o[GR];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+#pragma unroll
+      for (int R = 0; R < GR; ++R) o[R] = acc[g][R >> 4][R & 15];
+      store_act(g == 0 ? o_r : (g == 1 ? o_z : o_n), slab, lane, o);
+    }
+  }
+}
+
+__global__ __launch_bounds__(WG_THREADS, 1) void k_gru_tangent(
+    const float *__restrict__ g_r, const float *__restrict__ g_z, const float *__restrict__ g_nx,
+    const float *__restrict__ g_nh, const float *__restrict__ mrow, const float *__restrict__ Whh,
+    const float *__restrict__ bihd, const float *__restrict__ bhhd, const float *__restrict__ hpm_s,
+    const float *__restrict__ r_s, const float *__restrict__ z_s, const float *__restrict__ n_s,
+    const float *__restrict__ hn_s, const float *__restrict__ y_s, const float *__restrict__ rstd_y, int L, long m_pad,
+    float *__restrict__ ydot) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int MTH = 3 * GT, NJH = GH / 16;
+  u32x4 *Whimg = reinterpret_cast<u32x4 *>(lds);
+  float *bl = reinterpret_cast<float *>(Whimg + 3 * MTH * NJH * 64);  // [192] b_i' + b_h' (r, z) / b_i' (n) ; [192..256) b_hn'
+  stage_split_matrix<3 * GH, GH, false, WG_THREADS>(Whimg, Whh);
+  for (int e = threadIdx.x; e < 3 * GH; e += WG_THREADS) bl[e] = bihd[e] + (e < 2 * GH ? bhhd[e] : 0.f);
+  for (int e = threadIdx.x; e < GH; e += WG_THREADS) bl[3 * GH + e] = bhhd[2 * GH + e];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, i = lane & 31;
+  const long groups = m_pad / SLAB;
+  const u32x4 *wh_img = Whimg + lane;
+  for (long G = (long)blockIdx.x * WAVES_PER_WG + wave; G < groups; G += (long)gridDim.x * WAVES_PER_WG) {
+    float hd[GR];
+#pragma unroll
+    for (int R = 0; R < GR; ++R) hd[R] = 0.f;  // the initial hidden state is data
+    for (int l = 0; l < L; ++l) {
+      const long slab = (long)l * groups + G;
+      const float mk = mrow[slab * SLAB + i];
+      // the 128 bias values a lane touches are loop invariant; hoisted into registers they push the kernel into spills,
+      // so the LDS offset is made opaque per step (re-reading them costs 128 ds_read_b32 against ~250 global loads)
+      int bo = 4 * h;
+      asm volatile("" : "+v"(bo));
+      const float *blh = bl + bo;
+#pragma unroll
+      for (int R = 0; R < GR; ++R) hd[R] *= mk;  // h~' = h' * mask
+      f32x16 a6[MTH];
+      {
+        float gx[GR];
+        load_act(g_r, slab, lane, gx);
+#pragma unroll
+        for (int R = 0; R < GR; ++R) a6[0 + (R >> 4)][R & 15] = gx[R] + blh[0 * GH + feat_base(R)];
+        load_act(g_z, slab, lane, gx);
+#pragma unroll
+        for (int R = 0; R < GR; ++R) a6[GT + (R >> 4)][R & 15] = gx[R] + blh[1 * GH + feat_base(R)];
+        load_act(g_nh, slab, lane, gx);
+#pragma unroll
+        for (int R = 0; R < GR; ++R) a6[2 * GT + (R >> 4)][R & 15] = gx[R] + blh[3 * GH + feat_base(R)];
+      }
+      __builtin_amdgcn_sched_barrier(0);  // keep the seven primal loads below from being hoisted over the GEMM (spills)
+      {
+        u32x4 h1[NJH], h2[NJH], h3[NJH];
+        split_acts<GR>(hd, h1, h2, h3);
+        split_gemm<MTH, NJH>(wh_img, h1, h2, h3, a6, [](int) {});
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // gate Jacobians piece by piece (one float4 of every saved tensor at a time: 28 live registers instead of 224)
+      auto piece = [&](const float *base, int q) { return (reinterpret_cast<const f32x4 *>(base + slab * (long)(GH * SLAB)) + lane)[q * WAVE]; };
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int q = 0; q < GR / 4; ++q) {
+        const f32x4 rg = piece(r_s, q), zg = piece(z_s, q), ng = piece(n_s, q), hn = piece(hn_s, q), hp = piece(hpm_s, q),
+                    gnx = piece(g_nx, q), yv = piece(y_s, q);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int R = 4 * q + c;
+          const float rd = rg[c] * (1.f - rg[c]) * a6[0 + (R >> 4)][R & 15];
+          const float zd = zg[c] * (1.f - zg[c]) * a6[GT + (R >> 4)][R & 15];
+          const float hnd = a6[2 * GT + (R >> 4)][R & 15];
+          const float and_ = gnx[c] + blh[2 * GH + feat_base(R)] + rd * hn[c] + rg[c] * hnd;
+          const float nd = (1.f - ng[c] * ng[c]) * and_;
+          hd[R] = (1.f - zg[c]) * nd - zd * ng[c] + zd * hp[c] + zg[c] * hd[R];
+          s1 += hd[R];
+          s2 += hd[R] * yv[c];
+        }
+      }
+      s1 += wave_xor32(s1);
+      s2 += wave_xor32(s2);
+      s1 *= (1.0f / GH);
+      s2 *= (1.0f / GH);
+      const float rstd = rstd_y[slab * SLAB + i];
+      float yo[GR];
+#pragma unroll
+      for (int q = 0; q < GR / 4; ++q) {
+        const f32x4 yv = piece(y_s, q);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) yo[4 * q + c] = rstd * (hd[4 * q + c] - s1 - yv[c] * s2);
+      }
+      store_act(ydot, slab, lane, yo);
+    }
+  }
+}
+
+extern "C" int harl_gru_gates(const float *xin, const float *W, int H, long n_slabs, float *out_r, float *out_z,
+                              float *out_n, int acc_mask, void *stream) {
+  if (n_slabs <= 0) return 0;
+  if (H != GH) { set_error("harl_gru_gates: hidden width must be 64"); return -2; }
+  const size_t shm = (size_t)3 * GH * (GH + 1) * sizeof(float);
+  allow_big_lds(k_gru_gates_lin, shm);
+  hipLaunchKernelGGL(k_gru_gates_lin, dim3(persistent_grid(n_slabs, 1)), dim3(WG_THREADS), shm, (hipStream_t)stream, xin, W,
+                     n_slabs, out_r, out_z, out_n, acc_mask);
+  return check_launch("harl_gru_gates");
+}
+
+extern "C" int harl_gru_tangent(const float *g_r, const float *g_z, const float *g_nx, const float *g_nh,
+                                const float *mask_rows, const float *Whh, const float *bihd, const float *bhhd,
+                                const float *hpm, const float *r, const float *z, const float *n, const float *hn,
+                                const float *y, const float *rstd_y, int H, int L, long m_pad, float *ydot, void *stream) {
+  if (L <= 0 || m_pad <= 0) return 0;
+  if (H != GH) { set_error("harl_gru_tangent: hidden width must be 64"); return -2; }
+  if (m_pad % SLAB) { set_error("harl_gru_tangent: m_pad must be a multiple of 32"); return -2; }
+  const long groups = m_pad / SLAB;
+  long wgs = (groups + WAVES_PER_WG - 1) / WAVES_PER_WG;
+  const int grid = (int)(wgs < 256 ? wgs : 256);
+  const size_t shm = split_image_bytes(3 * GH, GH) + (size_t)4 * GH * sizeof(float);
+  allow_big_lds(k_gru_tangent, shm);
+  hipLaunchKernelGGL(k_gru_tangent, dim3(grid), dim3(WG_THREADS), shm, (hipStream_t)stream, g_r, g_z, g_nx, g_nh, mask_rows,
+                     Whh, bihd, bhhd, hpm, r, z, n, hn, y, rstd_y, L, m_pad, ydot);
+  return check_launch("harl_gru_tangent");
+}
+
 extern "C" int harl_gru_fwd(const float *xin, const float *mask_rows, const float *h0, const float *Wih,
                             const float *bih, const float *Whh, const float *bhh, int H, int L, long m_pad, float *y,
                             float *rstd_y, float *hpm, float *r, float *z, float *n, float *hn, float *h_last, int save,

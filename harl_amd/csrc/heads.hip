@@ -706,6 +706,7 @@ struct FvpArgs {
   const float *avail;
   float *dzL, *dhead;
   long n_slabs;
+  long m_valid, m_pad;  // recurrent batches: rows j with (j % m_pad) >= m_valid are padding sequences
 };
 
 template <int H, int DAP, bool DISCRETE>
@@ -762,7 +763,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_actor_head_fvp(FvpArgs A) {
       zd[d] = zd[d] + wave_xor32(zd[d]) + cdt[d];
     }
     const long j = slab * SLAB + i;
-    const bool valid = j < A.M;
+    const bool valid = j < A.M && (A.m_pad == 0 || (j % A.m_pad) < A.m_valid);
     float dzh[DAP];
 #pragma unroll
     for (int d = 0; d < DAP; ++d) dzh[d] = 0.f;
@@ -1017,9 +1018,11 @@ extern "C" int harl_critic_head_loss(const float *xL, const uint32_t *relu_mask,
 extern "C" int harl_actor_head_fvp(const float *xL, const float *xLdot, const uint32_t *relu_mask, const float *rstd, long M,
                                    int H, const float *Whp, const float *bhp, const float *Whdp, const float *bhdp,
                                    const float *log_std, float std_x_coef, float std_y_coef, int discrete, int act_dim,
-                                   const float *avail, float *dzL, float *dhead, void *stream) {
+                                   const float *avail, long m_valid, long m_pad, float *dzL, float *dhead, void *stream) {
   if (M <= 0) return 0;
   FvpArgs A{};
+  A.m_valid = m_valid;
+  A.m_pad = m_pad;
   A.xL = xL; A.xLdot = xLdot; A.relu_mask = relu_mask; A.rstd = rstd; A.M = M; A.Whp = Whp; A.bhp = bhp; A.Whdp = Whdp;
   A.bhdp = bhdp; A.log_std = log_std; A.std_x_coef = std_x_coef; A.std_y_coef = std_y_coef; A.act_dim = act_dim;
   A.avail = avail; A.dzL = dzL; A.dhead = dhead; A.n_slabs = n_slabs_of(M);

@@ -18,7 +18,7 @@ from . import _lib
 from ._lib import call, ptr, stream
 from .buffers import OnPolicyActorBuffer, consume_randperm, rng_sync
 from .happo import OnPolicyBase
-from .nets import consume_policy_init_rng
+from .nets import build_seq, consume_policy_init_rng, seq_compact
 from .valuenorm import _as_dev
 
 
@@ -35,20 +35,25 @@ class HATRPO(OnPolicyBase):
         self._grad_tap = None
 
     # ---- surrogate  sum_s ratio*f*adv*active / sum(active)  (hatrpo.py:77-90), optionally with its gradient ---------
-    def _surrogate(self, obs, m, actions, avail, old_logp, adv, adv_moments, factor, active, want_grad: bool):
+    def _surrogate(self, obs, m, actions, avail, old_logp, adv, adv_moments, factor, active, want_grad: bool, seq=None):
+        """``seq`` (GRU policies): the batch is L x m_pad rows in the recurrent layout (nets.build_seq), m = L * m_pad and the
+        row arrays are the flat buffers gathered through seq['idx'] inside the kernels."""
         net = self.actor
-        net.forward_trunk(obs, None, m, for_backward=True)
+        idx = None if seq is None else seq["idx"]
+        net.forward_trunk(obs, idx, m, for_backward=True, seq=seq)
         Wp, bp = net._packs[-1]
         s = stream()
-        call("harl_actor_head_loss", ptr(net.xh[-1]), ptr(net.rmask[-1]), ptr(net.rstd[-1]), m, net.hidden_sizes[-1],
+        fx, fmask, frstd, fh = net.feat()
+        mv, mp = (seq["m"], seq["m_pad"]) if seq is not None else (0, 0)
+        call("harl_actor_head_loss", ptr(fx), ptr(fmask), ptr(frstd), m, fh,
              ptr(Wp), ptr(bp), ptr(net.log_std()), net.std_x_coef, net.std_y_coef, int(net.discrete), net.act_dim,
-             None, ptr(actions), ptr(avail), ptr(old_logp), ptr(adv), ptr(adv_moments), ptr(factor), ptr(active),
-             0.0, 0.0, int(self.action_aggregation == "mean"), 1, 0, 0, None, ptr(net.dz[0]), ptr(net.dhead), ptr(net.part_scalars), None, 0, s)
+             ptr(idx), ptr(actions), ptr(avail), ptr(old_logp), ptr(adv), ptr(adv_moments), ptr(factor), ptr(active),
+             0.0, 0.0, int(self.action_aggregation == "mean"), 1, mv, mp, None, ptr(net.dz[0]), ptr(net.dhead), ptr(net.part_scalars), None, 0, s)
         net.scalars.zero_()
         call("harl_reduce_scalars", ptr(net.part_scalars), _lib.load().harl_head_blocks(m), ptr(net.scalars), s)
         grad = None
         if want_grad:
-            net.backward_trunk(obs, None, m)
+            net.backward_trunk(obs, idx, m, seq=seq)
             net.unfold_grads()
             if not net.discrete:
                 net.gview("act.action_out.log_std").copy_(net.scalars[8:8 + net.act_dim])
@@ -63,47 +68,67 @@ class HATRPO(OnPolicyBase):
         return sc, grad
 
     # ---- Fisher-vector product (trpo_util.py:132-158):  F v + 0.1 v -----------------------------------------------
-    def _fvp(self, obs, m, m_global, avail, vec: torch.Tensor) -> torch.Tensor:
+    def _fvp(self, obs, m, m_global, avail, vec: torch.Tensor, seq=None) -> torch.Tensor:
+        """``avail`` is indexed by batch position (already gathered for recurrent batches)."""
         net = self.actor
         s = stream()
-        layers = net._layers()
         L = len(net.hidden_sizes)
+        hs = net.hidden_sizes
+        idx = None if seq is None else seq["idx"]
         if self._tangent_ws is None or self._tangent_ws["rows"] < m:
             mp = ((m + 31) // 32) * 32
-            self._tangent_ws = dict(
-                rows=m, xd=[torch.empty(mp * h, **self.tpdv) for h in net.hidden_sizes],
-                packs=[(torch.empty(o * k, **self.tpdv), torch.empty(o, **self.tpdv)) for (_, _, _, _, o, k) in layers])
+            self._tangent_ws = dict(rows=m, xd=[torch.empty(mp * h, **self.tpdv) for h in hs],
+                                    pack_d=torch.empty_like(net.pack_arena))
+            if net.recurrent:
+                H = hs[-1]
+                self._tangent_ws["gates"] = [torch.empty(mp * H, **self.tpdv) for _ in range(4)]  # g_r, g_z, g_nx, g_nh
+                self._tangent_ws["ydot"] = torch.empty(mp * H, **self.tpdv)
         ws = self._tangent_ws
         vec = vec.contiguous()
-
-        def vview(name):
-            off, shape = net.offsets[name]
-            return vec[off:off + int(np.prod(shape))]
-
-        for (wn, bn, gn, ben, o, k), (Wpd, bpd) in zip(layers, ws["packs"]):  # tangent of the folded weights
-            call("harl_fold_linear_tangent", ptr(net.pview(wn)), ptr(net.pview(gn)) if gn else None,
-                 ptr(net.pview(ben)) if ben else None, ptr(vview(wn)), ptr(vview(bn)), ptr(vview(gn)) if gn else None,
-                 ptr(vview(ben)) if ben else None, ptr(Wpd), ptr(bpd), o, k, s)
-        hs = net.hidden_sizes
-        Wpd, bpd = ws["packs"][0]
+        fp, pd = net.flat_param, ws["pack_d"]
+        # tangent of every folded block, in table order, into an arena laid out like net.pack_arena
+        for (wo, bo, go, beo, o, k), (pw, pb, _, _) in zip(net._entries(), net._pack_slots):
+            call("harl_fold_linear_tangent", ptr(fp[wo:]), ptr(fp[go:]) if go >= 0 else None,
+                 ptr(fp[beo:]) if beo >= 0 else None, ptr(vec[wo:]), ptr(vec[bo:]), ptr(vec[go:]) if go >= 0 else None,
+                 ptr(vec[beo:]) if beo >= 0 else None, ptr(pd[pw:]), ptr(pd[pb:]), o, k, s)
+        packs_d = [(pd[pw:pw + o * k], pd[pb:pb + o]) for (pw, pb, o, k) in net._pack_slots]
+        Wpd, bpd = packs_d[0]
         if net.wide:  # x0n of the same rows is still there from the forward pass of _surrogate()
             call("harl_mlp_tangent_wide", ptr(net.x0n), m, net.kp0, ptr(Wpd), net.in_dim, ptr(bpd), hs[0], ptr(net.w1img),
                  ptr(net.xh[0]), ptr(net.rmask[0]), ptr(net.rstd[0]), ptr(ws["xd"][0]), s, tag="tangent_wide")
         else:
-            call("harl_mlp_tangent_input", ptr(obs), obs.shape[1], None, m, net.in_dim, ptr(Wpd), ptr(bpd),
+            call("harl_mlp_tangent_input", ptr(obs), obs.shape[1], ptr(idx), m, net.in_dim, ptr(Wpd), ptr(bpd),
                  int(net.use_feature_normalization), hs[0], ptr(net.xh[0]), ptr(net.rmask[0]), ptr(net.rstd[0]),
                  ptr(ws["xd"][0]), s)
         for l in range(1, L):
             Wp, _ = net._packs[l]
-            Wpd, bpd = ws["packs"][l]
+            Wpd, bpd = packs_d[l]
             call("harl_mlp_tangent_hidden", ptr(ws["xd"][l - 1]), ptr(net.xh[l - 1]), m, hs[l - 1], hs[l], ptr(Wp), ptr(Wpd),
                  ptr(bpd), ptr(net.xh[l]), ptr(net.rmask[l]), ptr(net.rstd[l]), ptr(ws["xd"][l]), s)
+        fx, fmask, frstd, fh = net.feat()
+        xLdot = ws["xd"][-1]
+        mv, mp_ = 0, 0
+        if net.recurrent:  # tangent through the recurrence (csrc/gru.hip): parallel gate pre-pass + sequential kernel
+            H, gp, sv = hs[-1], net.gru_pack, net.rnn_saved
+            b0, n3 = net._gru_pack_base, 3 * H * H
+            Wihd, bihd = pd[b0:b0 + n3], pd[b0 + n3:b0 + n3 + 3 * H]
+            Whhd, bhhd = pd[b0 + n3 + 3 * H:b0 + 2 * n3 + 3 * H], pd[b0 + 2 * n3 + 3 * H:b0 + 2 * n3 + 6 * H]
+            g_r, g_z, g_nx, g_nh = ws["gates"]
+            n_slabs = m // 32
+            call("harl_gru_gates", ptr(ws["xd"][-1]), ptr(gp["Wih"]), H, n_slabs, ptr(g_r), ptr(g_z), ptr(g_nx), 0, s)
+            call("harl_gru_gates", ptr(net.xh[-1]), ptr(Wihd), H, n_slabs, ptr(g_r), ptr(g_z), ptr(g_nx), 7, s)
+            call("harl_gru_gates", ptr(sv[0]), ptr(Whhd), H, n_slabs, ptr(g_r), ptr(g_z), ptr(g_nh), 3, s)
+            call("harl_gru_tangent", ptr(g_r), ptr(g_z), ptr(g_nx), ptr(g_nh), ptr(seq["mask_rows"]), ptr(gp["Whh"]),
+                 ptr(bihd), ptr(bhhd), ptr(sv[0]), ptr(sv[1]), ptr(sv[2]), ptr(sv[3]), ptr(sv[4]), ptr(net.rnn_y),
+                 ptr(net.rnn_rstd), H, seq["L"], seq["m_pad"], ptr(ws["ydot"]), s, tag="gru_tangent")
+            xLdot = ws["ydot"]
+            mv, mp_ = seq["m"], seq["m_pad"]
         Whp, bhp = net._packs[-1]
-        Whpd, bhpd = ws["packs"][-1]
-        call("harl_actor_head_fvp", ptr(net.xh[-1]), ptr(ws["xd"][-1]), ptr(net.rmask[-1]), ptr(net.rstd[-1]), m, hs[-1],
+        Whpd, bhpd = packs_d[-1]
+        call("harl_actor_head_fvp", ptr(fx), ptr(xLdot), ptr(fmask), ptr(frstd), m, fh,
              ptr(Whp), ptr(bhp), ptr(Whpd), ptr(bhpd), ptr(net.log_std()), net.std_x_coef, net.std_y_coef,
-             int(net.discrete), net.act_dim, ptr(avail), ptr(net.dz[0]), ptr(net.dhead), s)
-        net.backward_trunk(obs, None, m)
+             int(net.discrete), net.act_dim, ptr(avail), mv, mp_, ptr(net.dz[0]), ptr(net.dhead), s)
+        net.backward_trunk(obs, idx, m, seq=seq)
         net.unfold_grads()
         out = net.flat_grad.clone()
         if not net.discrete:  # log_std block: d2 KL / d sigma^2 = 2 / sigma^2 per sample, sigma = sigmoid(ls/xc) yc
@@ -117,15 +142,26 @@ class HATRPO(OnPolicyBase):
             sg = torch.sigmoid(ls / net.std_x_coef)
             sigma = sg * net.std_y_coef
             dsig = net.std_y_coef * sg * (1.0 - sg) / net.std_x_coef
-            out[off:off + net.act_dim] = (2.0 * dsig * dsig / (sigma * sigma)) * vview("act.action_out.log_std")
+            out[off:off + net.act_dim] = (2.0 * dsig * dsig / (sigma * sigma)) * vec[off:off + net.act_dim]
         return out + 0.1 * vec
 
-    def _head_outputs(self, obs, m, actions, avail, reuse_trunk=False) -> torch.Tensor:
-        """Distribution parameters at the current weights: Gaussian mean / normalised logits, [m, act_dim].
-        ``reuse_trunk``: a _surrogate() call under the same weights has just left x_hat_L in the workspace."""
-        out = torch.empty(m, self.actor.act_dim, **self.tpdv)
-        self._logp_pass(obs, actions, avail, m, None, head_out=out, reuse_trunk=reuse_trunk)
-        return out
+    def _head_outputs(self, obs, m, actions, avail, reuse_trunk=False, seq=None, avail_rows=None) -> torch.Tensor:
+        """Distribution parameters at the current weights: Gaussian mean / normalised logits, [rows, act_dim].
+        ``reuse_trunk``: a _surrogate() call under the same weights has just left x_hat_L in the workspace.
+        Recurrent batches: always reuse (the caller has just run _surrogate on the same layout); ``avail_rows`` is the
+        availability mask by batch position; padding sequences are compacted away (rows = L * m)."""
+        net = self.actor
+        if seq is None:
+            out = torch.empty(m, net.act_dim, **self.tpdv)
+            self._logp_pass(obs, actions, avail, m, None, head_out=out, reuse_trunk=reuse_trunk)
+            return out
+        fx, _, _, fh = net.feat()
+        Wp, bp = net._packs[-1]
+        ho = torch.empty(m, net.act_dim, **self.tpdv)
+        call("harl_actor_head_logp", ptr(fx), m, fh, ptr(Wp), ptr(bp), ptr(net.log_std()), net.std_x_coef, net.std_y_coef,
+             int(net.discrete), net.act_dim, None, ptr(avail_rows), None, None, None, 0, ptr(ho), seq["m"], seq["m_pad"],
+             stream(), tag="actor_head_logp")
+        return seq_compact(ho, seq) if seq["m_pad"] != seq["m"] else ho
 
     def _kl_sum(self, head_old, ls_old, head_new, m) -> torch.Tensor:
         """Sum over the (global) batch of KL(old || new), fp64 device scalar [1]."""
@@ -140,10 +176,16 @@ class HATRPO(OnPolicyBase):
     def _kl_mean(self, head_old, ls_old, head_new, m, m_global) -> float:
         return float(self._kl_sum(head_old, ls_old, head_new, m).item()) / float(m_global)
 
-    def _update_core(self, obs, m, m_global, actions, avail, old_logp, adv, adv_moments, factor, active):
+    def _update_core(self, obs, m, m_global, actions, avail, old_logp, adv, adv_moments, factor, active, seq=None):
+        """``seq``: recurrent batch layout (m = L * m_pad rows, m_global = global number of real rows)."""
         net = self.actor
         net.fold()
-        sc, g = self._surrogate(obs, m, actions, avail, old_logp, adv, adv_moments, factor, active, want_grad=True)
+        avail_rows, kl_rows = avail, m
+        if seq is not None:
+            kl_rows = seq["L"] * seq["m"]
+            if avail is not None and seq["idx"] is not None:
+                avail_rows = avail[seq["idx"]].contiguous()  # by batch position, for the FVP / head-output kernels
+        sc, g = self._surrogate(obs, m, actions, avail, old_logp, adv, adv_moments, factor, active, want_grad=True, seq=seq)
         loss = float((sc[0] / sc[1]).item())
         # conjugate gradient, 10 steps, residual tolerance 1e-10 (trpo_util.py:96-129)
         # The reference leaves the loop once rdotr < 1e-10; here that test stays on the device (a `done` flag freezes x, r
@@ -154,7 +196,7 @@ class HATRPO(OnPolicyBase):
         done = torch.zeros((), dtype=torch.bool, device=g.device)
         zero = torch.zeros((), dtype=g.dtype, device=g.device)
         for _ in range(10):
-            avp = self._fvp(obs, m, m_global, avail, p)
+            avp = self._fvp(obs, m, m_global, avail_rows, p, seq=seq)
             alpha = torch.where(done, zero, rdotr / torch.dot(p, avp))
             x += alpha * p
             r -= alpha * avp
@@ -163,12 +205,12 @@ class HATRPO(OnPolicyBase):
             rdotr = new_rdotr
             done = done | (rdotr < 1e-10)
         params = net.flat_param.clone()
-        fv = self._fvp(obs, m, m_global, avail, x)
+        fv = self._fvp(obs, m, m_global, avail_rows, x, seq=seq)
         shs = 0.5 * torch.dot(x, fv)
         step_size = 1.0 / torch.sqrt(shs / self.kl_threshold)
         full_step = step_size * x
         # "old actor" snapshot (hatrpo.py:127-130): distribution parameters at theta_old + the RNG draws its construction costs
-        head_old = self._head_outputs(obs, m, actions, avail, reuse_trunk=True)  # FVPs do not touch x_hat_l
+        head_old = self._head_outputs(obs, m, actions, avail, reuse_trunk=True, seq=seq, avail_rows=avail_rows)  # FVPs do not touch x_hat_l / y
         ls_old = None if net.discrete else net.log_std().clone()
         consume_policy_init_rng(self.args, self.obs_space, self.act_space)
         expected_improve = float(torch.dot(g, full_step).item())
@@ -180,9 +222,10 @@ class HATRPO(OnPolicyBase):
         for _ in range(self.ls_step):
             net.flat_param.copy_(params + fraction * full_step)
             net.fold()
-            sc_new, _ = self._surrogate(obs, m, actions, avail, old_logp, adv, adv_moments, factor, active, want_grad=False)
-            head_new = self._head_outputs(obs, m, actions, avail, reuse_trunk=True)
-            kl_sum = self._kl_sum(head_old, ls_old, head_new, m)
+            sc_new, _ = self._surrogate(obs, m, actions, avail, old_logp, adv, adv_moments, factor, active, want_grad=False,
+                                        seq=seq)
+            head_new = self._head_outputs(obs, m, actions, avail, reuse_trunk=True, seq=seq, avail_rows=avail_rows)
+            kl_sum = self._kl_sum(head_old, ls_old, head_new, kl_rows)
             # ONE read-back per line-search step (the accept test needs both numbers on the host)
             new_loss, kl = torch.stack([(sc_new[0] / sc_new[1]).to(torch.float64), kl_sum[0] / float(m_global)]).tolist()
             loss_improve = new_loss - loss
@@ -205,6 +248,15 @@ class HATRPO(OnPolicyBase):
         dev = self.device
         obs = _as_dev(obs, dev)
         m = obs.shape[0]
+        if self.actor.recurrent:  # gathered [L*m, .] l-major sample + rnn_states [m, 1, H] (recurrent generators)
+            H = self.actor.hidden_sizes[-1]
+            nseq = _as_dev(_rnn, dev).shape[0]
+            seq = build_seq(dev, m // nseq, nseq, H, h0=_as_dev(_rnn, dev).reshape(nseq, H), masks_src=_as_dev(_masks, dev))
+            return self._update_core(obs.reshape(m, -1), seq["L"] * seq["m_pad"], m, _as_dev(actions, dev).reshape(m, -1),
+                                     None if avail is None else _as_dev(avail, dev).reshape(m, -1),
+                                     _as_dev(old_logp, dev).reshape(m, -1), _as_dev(adv, dev).reshape(m), None,
+                                     _as_dev(factor, dev).reshape(m),
+                                     _as_dev(active, dev).reshape(m) if self.use_policy_active_masks else None, seq=seq)
         return self._update_core(obs.reshape(m, -1), m, m, _as_dev(actions, dev).reshape(m, -1),
                                  None if avail is None else _as_dev(avail, dev).reshape(m, -1),
                                  _as_dev(old_logp, dev).reshape(m, -1), _as_dev(adv, dev).reshape(m), None,
@@ -213,8 +265,6 @@ class HATRPO(OnPolicyBase):
 
     def train(self, actor_buffer: OnPolicyActorBuffer, advantages, state_type):
         """One full-batch update (hatrpo.py:196-247)."""
-        if self.use_recurrent_policy or self.use_naive_recurrent_policy:
-            raise NotImplementedError("HATRPO with GRU policies (the FVP needs a recurrent tangent pass)")
         dev = self.device
         buf = actor_buffer
         T, N = buf.actions.shape[:2]
@@ -230,6 +280,19 @@ class HATRPO(OnPolicyBase):
         if state_type != "EP":  # FP: advantages arrive normalised over all agents (on_policy_ha_runner.py:36-45)
             moments = None
         n_global = self.shard[0] * T if self.shard else B
+        if self.use_recurrent_policy or self.use_naive_recurrent_policy:
+            # recurrent_generator_actor(advantages, 1, L) / naive_recurrent_generator_actor(advantages, 1): ONE sample that
+            # holds every chunk (hatrpo.py:222-231)
+            for seq in buf.recurrent_batches(1, self.data_chunk_length, naive=not self.use_recurrent_policy, shard=self.shard):
+                if seq.get("empty"):
+                    raise NotImplementedError("HATRPO: a rank without any sequence of the (single) batch")
+                kl, li, ei, ent, ratio = self._update_core(
+                    buf.flat("obs"), seq["L"] * seq["m_pad"], seq["L"] * seq["m_global"], buf.flat("actions"),
+                    None if buf.available_actions is None else buf.flat("available_actions"), buf.flat("action_log_probs"),
+                    adv, moments, buf.factor.reshape(B), active if self.use_policy_active_masks else None, seq=seq)
+                info.update(kl=kl, dist_entropy=ent, loss_improve=li, expected_improve=ei, ratio=ratio)
+            rng_sync()
+            return info
         consume_randperm(n_global)  # feed_forward_generator_actor(advantages, 1): one draw, whole buffer
         kl, li, ei, ent, ratio = self._update_core(
             buf.flat("obs"), B, n_global, buf.flat("actions"),

@@ -498,6 +498,15 @@ def consume_policy_init_rng(args: dict, obs_space, action_space) -> None:
     for h in args["hidden_sizes"]:
         draw(nn.Linear(d, h), gain)
         d = h
+    if args.get("use_recurrent_policy") or args.get("use_naive_recurrent_policy"):
+        # RNNLayer (rnn.py:8-21): nn.GRU's own uniform init of all four tensors, then init_method on the two weights
+        gru = nn.GRU(d, d, num_layers=args.get("recurrent_n", 1))
+        for pn, prm in gru.named_parameters():
+            if "weight" in pn:
+                if args["initialization_method"] == "orthogonal_":
+                    prm.data.new_empty((prm.size(0), prm.numel() // prm.size(0))).normal_(0, 1)
+                else:
+                    init(prm.data)
     n_out = int(action_space.n) if action_space.__class__.__name__ == "Discrete" else int(action_space.shape[0])
     draw(nn.Linear(d, n_out), args["gain"])
 

@@ -247,16 +247,29 @@ int harl_mlp_tangent_input(const float *X, long ldx, const int64_t *idx, long M,
 /* the same for wide inputs, from the x0n image of harl_mlp_x0n_wide (w_img: scratch as in harl_mlp_fwd_wide) */
 int harl_mlp_tangent_wide(const float *x0n, long M, int KP, const float *Wdp, int D, const float *bdp, int H, void *w_img,
                           const float *x1, const uint32_t *mask1, const float *rstd1, float *x1dot, void *stream);
+/* GRU policies: forward-mode tangent through the recurrence (csrc/gru.hip).
+ * harl_gru_gates: out_g (+)= W_g xin for the three gate blocks of W [3H][H] (xin ATL(H), n_slabs slabs; bit g of acc_mask:
+ *   accumulate into out_g instead of overwriting) -- the recurrence-free parts of the gate tangents, all steps at once.
+ * harl_gru_tangent: y' for L steps x m_pad sequences from  g_r = W_ir x' + W_ir' x + W_hr' h~ (same for g_z),
+ *   g_nx = W_in x' + W_in' x,  g_nh = W_hn' h~,  the primal tensors saved by harl_gru_fwd(save = 1) and its outputs
+ *   y / rstd_y, the primal W_hh and the bias tangents bihd / bhhd [3H]; the initial hidden state has no tangent. */
+int harl_gru_gates(const float *xin, const float *W, int H, long n_slabs, float *out_r, float *out_z, float *out_n,
+                   int acc_mask, void *stream);
+int harl_gru_tangent(const float *g_r, const float *g_z, const float *g_nx, const float *g_nh, const float *mask_rows,
+                     const float *Whh, const float *bihd, const float *bhhd, const float *hpm, const float *r,
+                     const float *z, const float *n, const float *hn, const float *y, const float *rstd_y, int H, int L,
+                     long m_pad, float *ydot, void *stream);
 /* xout_dot = LNjac(mask * (Wp xin_dot + Wdp xin + bdp)) given the primal xprimal / mask / rstd of this layer */
 int harl_mlp_tangent_hidden(const float *xin_dot, const float *xin, long M, int HI, int HO, const float *Wp,
                             const float *Wdp, const float *bdp, const float *xprimal, const uint32_t *mask_in,
                             const float *rstd_in, float *xout_dot, void *stream);
 /* head tangent, M (Gaussian 1/sigma^2 on the mean; identity on the normalised logits incl. masked entries), head +
- * LayerNorm/ReLU backward -> dzL ATL(H), dhead[M_pad,32]; NOT yet divided by the batch size */
+ * LayerNorm/ReLU backward -> dzL ATL(H), dhead[M_pad,32]; NOT yet divided by the batch size.  m_valid / m_pad as in
+ * harl_actor_head_loss (padding sequences of a recurrent batch get zero gradients; 0, 0 = no padding) */
 int harl_actor_head_fvp(const float *xL, const float *xLdot, const uint32_t *relu_mask, const float *rstd, long M, int H,
                         const float *Whp, const float *bhp, const float *Whdp, const float *bhdp, const float *log_std,
-                        float std_x_coef, float std_y_coef, int discrete, int act_dim, const float *avail, float *dzL,
-                        float *dhead, void *stream);
+                        float std_x_coef, float std_y_coef, int discrete, int act_dim, const float *avail, long m_valid,
+                        long m_pad, float *dzL, float *dhead, void *stream);
 /* out_sum (double, accumulated) += sum_s KL(old || new)_s from the head outputs of harl_actor_head_logp:
  * Gaussian analytic KL in fp64 (trpo_util.py:54-62), Categorical kl_approx on normalised logits (trpo_util.py:47-51) */
 int harl_trpo_kl_sum(const float *head_old, const float *head_new, const float *log_std_old, const float *log_std_new,

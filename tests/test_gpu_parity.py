@@ -79,7 +79,7 @@ def test_hatrpo_gradient_fvp_and_update(i):
     _assert_all(res, tol=TOL)
 
 
-@pytest.mark.parametrize("name", ["trpo_box_h64", "trpo_disc_h64", "trpo_wide_h128x3"])
+@pytest.mark.parametrize("name", ["trpo_box_h64", "trpo_disc_h64", "trpo_wide_h128x3", "trpo_rnn_disc_h64", "trpo_rnn_box_h64"])
 def test_hatrpo_train_matches_reference_golden(name):
     _assert_all(_G().check_train_golden(name), tol=TOL_TRAIN)
 

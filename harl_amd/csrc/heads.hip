@@ -173,7 +173,7 @@ __device__ __forceinline__ void head_fwd_regs(const f32x4 (&xs)[H / 8], const fl
 
 template <int H, int DAP>
 __device__ __forceinline__ void head_bwd_regs(const f32x4 (&xs)[H / 8], const uint32_t *__restrict__ mask_in,
-                                              float rstd, long slab, int lane, const float *whl_h,
+                                              float rstd, long slab, int lane, const float *whl /* base, both halves */,
                                               const float (&dzh)[DAP], float s1, float s2,
                                               float *__restrict__ dz_out) {
   constexpr int NW = (H / 2 + 31) / 32;
@@ -181,6 +181,24 @@ __device__ __forceinline__ void head_bwd_regs(const f32x4 (&xs)[H / 8], const ui
   const uint32_t b1 = NW > 1 ? mask_in[(slab * NW + (NW - 1)) * WAVE + lane] : 0u;
   s1 *= (1.0f / H);
   s2 *= (1.0f / H);
+  // dx_hat^T[f][n] = sum_d W'[d][f] dz[n][d] on the fp32 MFMA: k = d (DAP/2 steps of 2), 4 output tiles, and the result
+  // lands in the accumulator layout = the layout of xs.  Replaces 64 x DAP FMAs + 16 x DAP broadcast LDS reads per lane
+  // (LDS-latency bound: the loss kernels spent half their wave time in s_waitcnt) by DAP/2 x H/32 MFMAs and as many
+  // conflicted-but-few ds_read_b32 of the same weight image.
+  const int i = lane & 31, h = lane >> 5;
+  const float *wa = whl + (((i >> 2) & 1) * (H / 2) + (i & 3) + 4 * (i >> 3)) * DAP + h;  // W'[2s + h][32 t + i] at + 16 t DAP + 2 s
+  f32x16 acc[H / 32];
+#pragma unroll
+  for (int t = 0; t < H / 32; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+#pragma unroll
+  for (int st = 0; st < DAP / 2; ++st) {
+    const float bsel = h ? dzh[2 * st + 1] : dzh[2 * st];
+#pragma unroll
+    for (int t = 0; t < H / 32; ++t)
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[16 * t * DAP + 2 * st], bsel, acc[t], 0, 0, 0);
+  }
   f32x4 *op = reinterpret_cast<f32x4 *>(dz_out + slab * (long)(H * SLAB)) + lane;
 #pragma unroll
   for (int q = 0; q < H / 8; ++q) {
@@ -188,18 +206,12 @@ __device__ __forceinline__ void head_bwd_regs(const f32x4 (&xs)[H / 8], const ui
     f32x4 o;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      float dx = 0.f;
-#pragma unroll
-      for (int dq = 0; dq < DAP / 4; ++dq) {
-        const f32x4 w = *reinterpret_cast<const f32x4 *>(whl_h + (4 * q + c) * DAP + 4 * dq);
-        dx += dzh[4 * dq + 0] * w[0] + dzh[4 * dq + 1] * w[1] + dzh[4 * dq + 2] * w[2] + dzh[4 * dq + 3] * w[3];
-      }
+      const float dx = acc[(4 * q + c) >> 4][(4 * q + c) & 15];
       const float da = rstd * (dx - s1 - xs[q][c] * s2);
-      o[c] = (int)b0 < 0 ? da : 0.f;  // MSB-first mask (common.h); plain C here: these kernels are HBM-bound and
-      b0 <<= 1;                        // the asm form of mask_pop only restricts the scheduler
+      o[c] = (int)b0 < 0 ? da : 0.f;  // MSB-first mask (common.h)
+      b0 <<= 1;
     }
     op[q * WAVE] = o;
-    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -552,7 +564,7 @@ __global__ __launch_bounds__(WG_THREADS, FUSE ? 2 : 1) void k_actor_head(ActorAr
       s2 += dzh[d] * zlin[d];
     }
     if constexpr (TRAIN)
-      head_bwd_regs<H, DAP>(xs, A.relu_mask, A.rstd[slab * SLAB + i], slab, lane, whl_h, dzh, s1, s2, A.dzL);
+      head_bwd_regs<H, DAP>(xs, A.relu_mask, A.rstd[slab * SLAB + i], slab, lane, whl, dzh, s1, s2, A.dzL);
   }
 
   if (TRAIN) block_reduce_store<8 + DAP>(sc, red, A.part_scalars + (long)blockIdx.x * PS_STRIDE);
@@ -678,7 +690,7 @@ __global__ __launch_bounds__(WG_THREADS, FUSE ? 2 : 1) void k_critic_head(Critic
       for (int c = 0; c < 16; ++c) dh[c] = (h == 0 && c == 0) ? dv : 0.f;
     }
     if constexpr (TRAIN)
-      head_bwd_regs<H, DAP>(xs, A.relu_mask, A.rstd[slab * SLAB + i], slab, lane, whl_h, dzh, dv * cst[4 * DAP],
+      head_bwd_regs<H, DAP>(xs, A.relu_mask, A.rstd[slab * SLAB + i], slab, lane, whl, dzh, dv * cst[4 * DAP],
                             dv * (v - cst[0]), A.dzL);
   }
   if (TRAIN) block_reduce_store<8>(sc, red, A.part_scalars + (long)blockIdx.x * PS_STRIDE);

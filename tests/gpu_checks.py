@@ -399,6 +399,77 @@ def check_gradients(spec, mini_batches: int = 1, agg: str = "prod", inactive_p: 
     return out
 
 
+def check_trpo_rnn(spec, agg: str = "prod") -> Dict[str, float]:
+    """HATRPO with a GRU policy: surrogate gradient, one Fisher-vector product through the recurrence on a random vector and
+    one full update on an [L*m] recurrent sample vs the oracle (autograd double backward through the explicit GRU)."""
+    from harl_amd.hatrpo import HATRPO
+    from harl_amd.nets import build_seq
+    out = {}
+    L, m = spec["L"], spec["m"]
+    M = L * m
+    sh = Shapes(T=L, N=m, A=1, obs_dim=spec["obs_dim"], share_obs_dim=spec["share_obs_dim"], act_dim=spec["act_dim"],
+                discrete=spec["discrete"], hidden_sizes=spec["hidden_sizes"])
+    args = default_args(sh.hidden_sizes, kl_threshold=0.01, ls_step=10, accept_ratio=0.5, backtrack_coeff=0.8,
+                        action_aggregation=agg, use_recurrent_policy=True)
+    space = Discrete(sh.act_dim) if sh.discrete else Box((sh.act_dim,))
+    actor = HATRPO(args, Box((sh.obs_dim,)), space, device=DEV)
+    sd = synthetic_state_dict(actor_param_shapes(sh, args["use_feature_normalization"], True), 17, args["std_x_coef"])
+    assert list(sd.keys()) == list(actor.actor.state_dict().keys())
+    actor.actor.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    cfg = O.PathConfig.from_reference_dicts({}, args, args)
+    oracle = O.OracleHATRPO({k: torch.from_numpy(v) for k, v in sd.items()}, cfg, O.TrpoConfig())
+    d = make_buffers(sh, 61, inactive_p=0.2, unavailable_p=0.25 if sh.discrete else 0.0, rnn=True)
+    rng = np.random.default_rng(8)
+    obs = d.obs[0][:-1].reshape(M, -1)
+    masks = d.masks[0][:-1].reshape(M, 1)
+    h0 = d.rnn["actor"][0][0]  # [m, 1, H]
+    act = d.actions[0].reshape(M, -1)
+    avail = None if not sh.discrete else d.available_actions[0][:-1].reshape(M, -1)
+    active = d.active_masks[0][:-1].reshape(M, 1)
+    lp, _, _ = oracle.evaluate_actions(obs, act, avail, None, h0, masks)
+    old_logp = (lp.detach().numpy() + 0.05 * rng.standard_normal(lp.shape)).astype(np.float32)
+    adv = rng.standard_normal((M, 1)).astype(np.float32)
+    factor = (1 + 0.1 * rng.standard_normal((M, 1))).astype(np.float32)
+    t = lambda x: None if x is None else torch.from_numpy(x)  # noqa: E731
+
+    # ---- surrogate gradient + FVP on the recurrent layout
+    H = sh.hidden_sizes[-1]
+    seq = build_seq(DEV, L, m, H, h0=dev(h0).reshape(m, H), masks_src=dev(masks))
+    Mp = L * seq["m_pad"]
+    d_obs, d_act, d_old = dev(obs), dev(act), dev(old_logp)
+    d_avail = None if avail is None else dev(avail)
+    d_adv, d_fac, d_actv = dev(adv.reshape(M)), dev(factor.reshape(M)), dev(active.reshape(M))
+    actor.actor.fold()
+    sc, g = actor._surrogate(d_obs, Mp, d_act, d_avail, d_old, d_adv, None, d_fac, d_actv, want_grad=True, seq=seq)
+    loss, ent, ratio = oracle.surrogate(t(obs), t(act), t(avail), t(active), t(old_logp), t(adv), t(factor), t(h0), t(masks))
+    og = torch.autograd.grad(loss, oracle.params(), allow_unused=True)
+    og = torch.cat([x.reshape(-1) for x in og]).numpy()
+    out["surrogate_loss_rel"] = rel_err((sc[0] / sc[1]).item(), loss.item())
+    out["surrogate_grad_vec_rel"] = vec_rel_err(g.cpu().numpy(), og)
+    v = rng.standard_normal(og.shape).astype(np.float32)
+    ofv = oracle.fvp(t(obs), t(avail), torch.from_numpy(v), t(h0), t(masks)).numpy()
+    avail_rows = d_avail if (d_avail is None or seq["idx"] is None) else d_avail[seq["idx"]].contiguous()
+    gfv = actor._fvp(d_obs, Mp, M, avail_rows, dev(v), seq=seq)
+    torch.cuda.synchronize()
+    out["fvp_vec_rel"] = vec_rel_err(gfv.cpu().numpy(), ofv)
+
+    # ---- one full update through the API-compatible entry point
+    info = oracle.update((obs, act, active, old_logp, adv, avail, factor, h0, masks))
+    taps = []
+    actor._grad_tap = lambda g_, x_, ss: taps.append((g_.cpu().numpy(), x_.cpu().numpy(), ss))
+    kl, li, ei, ent_, ratio_ = actor.update((obs, h0, act, masks, active, old_logp, adv, avail, factor))
+    torch.cuda.synchronize()
+    out["cg_step_dir_vec_rel"] = vec_rel_err(taps[0][1], info["step_dir"])
+    out["step_size_rel"] = rel_err(taps[0][2], info["step_size"])
+    out["kl_rel"] = rel_err(kl, info["kl"])
+    out["loss_improve_rel"] = rel_err(li, info["loss_improve"])
+    out["expected_improve_rel"] = rel_err(ei, info["expected_improve"])
+    out["entropy_rel"] = rel_err(ent_, info["dist_entropy"])
+    out["ratio_rel"] = rel_err(ratio_, info["ratio"])
+    out["param_after_vec_rel"] = vec_rel_err(actor.actor.flat_param.cpu().numpy(), oracle.flat().numpy())
+    return out
+
+
 RNN_SHAPES = [  # (L, m): m = 40 pads to 64 sequences, m = 64 is the identity layout, m = 7 a single ragged slab
     dict(name="rnn_box_L10_m40", obs_dim=18, share_obs_dim=54, act_dim=5, discrete=False, hidden_sizes=[64, 64], L=10, m=40),
     dict(name="rnn_disc_L5_m64", obs_dim=30, share_obs_dim=20, act_dim=9, discrete=True, hidden_sizes=[64], L=5, m=64),

@@ -79,6 +79,17 @@ def test_hatrpo_gradient_fvp_and_update(i):
     _assert_all(res, tol=TOL)
 
 
+@pytest.mark.parametrize("i", [0, 1, 2])
+def test_hatrpo_gru_gradient_fvp_and_update(i):
+    """HATRPO with GRU policies: the Fisher-vector product through the recurrence (forward-mode tangent kernel + BPTT)
+    against the oracle's double backward, padded (m = 40), identity (m = 64) and ragged (m = 7, mixed widths) layouts."""
+    G = _G()
+    res = G.check_trpo_rnn(G.RNN_SHAPES[i])
+    cg = res.pop("cg_step_dir_vec_rel")
+    assert cg < 2e-4, cg
+    _assert_all(res, tol=2e-5)
+
+
 @pytest.mark.parametrize("name", ["trpo_box_h64", "trpo_disc_h64", "trpo_wide_h128x3", "trpo_rnn_disc_h64", "trpo_rnn_box_h64"])
 def test_hatrpo_train_matches_reference_golden(name):
     _assert_all(_G().check_train_golden(name), tol=TOL_TRAIN)

@@ -1,4 +1,4 @@
-// wide.hip -- first layer for WIDE observations (64 < D <= 512: MAMuJoCo Humanoid 393 / 376, SMAC 128+), gfx950.
+// wide.hip -- first layer for observations wider than 32 (32 < D <= 512: MPE share_obs 54, Humanoid 393 / 376, SMAC 128+), gfx950.
 //
 // The narrow kernels of mlp.hip park a slab's rows in LDS next to the whole first-layer matrix; neither fits for wide
 // rows.  Here the layer is split in two streaming kernels:
@@ -106,7 +106,12 @@ __global__ __launch_bounds__(WG_THREADS, NC <= 3 ? 2 : 1) void k_x0n_wide(const 
         rstd = 1.0f / sqrtf(wave_sum_dpp(q) * invD + 1e-5f);
       }
 #pragma unroll
-      for (int c = 0; c < NC; ++c) v[r][c] = (64 * c + lane < D) ? (v[r][c] - mean) * rstd : 0.f;
+      for (int c = 0; c < NC; ++c) {
+        const int k = 64 * c + lane;
+        // pad columns are zero except the LAST one (k = KP - 1 > D - 1), a column of ones: the weight images are zero
+        // there, and the fused first-layer weight gradient of k_bwd_dx reads db' out of it (mlp.hip, x0n_store)
+        v[r][c] = k < D ? (v[r][c] - mean) * rstd : ((k == KP - 1 && D < KP) ? 1.0f : 0.f);
+      }
       if (lane == r) {
         my_mean = mean;
         my_rstd = rstd;
@@ -341,7 +346,7 @@ int launch_wide(const float *x0n, long M, int KP, const float *Wp, int D, const 
 extern "C" int harl_mlp_x0n_wide(const float *X, long ldx, const int64_t *idx, long M, int D, int use_ln0, float *x0n,
                                  float *mu0, float *rstd0, void *stream) {
   if (M <= 0) return 0;
-  if (D <= 64 || D > 512) return bad("harl_mlp_x0n_wide: 64 < D <= 512");
+  if (D <= 32 || D > 512) return bad("harl_mlp_x0n_wide: 32 < D <= 512");
   const long n_slabs = n_slabs_of(M);
   const int KP = ((D + 31) / 32) * 32, NC = (D + 63) / 64;
   const long wgs = (n_slabs + WAVES_PER_WG - 1) / WAVES_PER_WG;
@@ -354,6 +359,7 @@ extern "C" int harl_mlp_x0n_wide(const float *X, long ldx, const int64_t *idx, l
                        n_slabs, KP);                                                                                    \
   }
   switch (NC) {
+    case 1: LX(1) break;
     case 2: LX(2) break;
     case 3: LX(3) break;
     case 4: LX(4) break;

@@ -67,7 +67,7 @@ class _FlatNet(nn.Module):
             if h not in SUPPORTED_WIDTHS:
                 raise NotImplementedError(f"hidden width {h}: kernels are instantiated for {SUPPORTED_WIDTHS}")
         self.in_dim = in_dim
-        self.wide = 64 < in_dim <= 512  # first layer through the x0n image (csrc/wide.hip)
+        self.wide = 32 < in_dim <= 512  # first layer through the cached x0n image (csrc/wide.hip); <= 32: fused 2-layer kernel
         self._x0n_key = None
         self._cpu_params: List[Tuple[str, torch.Tensor]] = []
         self._build_trunk_params(args)
@@ -242,8 +242,8 @@ class _FlatNet(nn.Module):
         self.rstd0 = torch.empty(mp, dtype=f32, device=dev)
         # narrow inputs: the forward pass leaves the normalised inputs behind as an ATL image for the dW_1 kernel
         self.kp0 = ((self.in_dim + 31) // 32) * 32
-        # wide inputs (64 < D <= 512, csrc/wide.hip): x0n is the operand of the first-layer GEMM itself
-        self.wide = 64 < self.in_dim <= 512
+        # inputs wider than 32 (csrc/wide.hip): x0n is the operand of the first-layer GEMM itself
+        self.wide = 32 < self.in_dim <= 512
         self._x0n_key = None
         self.x0n = torch.empty(mp * self.kp0, dtype=f32, device=dev) if (self.in_dim <= 64 or self.wide) else None
         self.w1img = torch.empty(3 * self.hidden_sizes[0] * self.kp0 // 2, dtype=f32, device=dev) if self.wide else None
@@ -362,7 +362,7 @@ class _FlatNet(nn.Module):
                      ptr(self.part[po[L + 3 + gate]:]), nwg, s, tag="dw_gru")
             cur = 1
         # first-layer weight gradient fused into the last bwd_dx (needs the ones column of x0n: in_dim < kp0)
-        fuse_dw1 = L >= 2 and self.x0n is not None and self.in_dim < self.kp0 and not self.wide
+        fuse_dw1 = L >= 2 and self.x0n is not None and self.in_dim < self.kp0 and self.kp0 <= 64
         for l in range(L - 1, 0, -1):
             ho, hi = self.hidden_sizes[l], self.hidden_sizes[l - 1]
             call("harl_mlp_dw_partials", ptr(self.dz[cur]), 0, 0, ho, ptr(self.xh[l - 1]), 0, 0, None, None, None, hi, M,

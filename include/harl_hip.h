@@ -106,7 +106,7 @@ int harl_unfold_linear_grads(const float *dWp, const float *dbp, int ldp, const 
 int harl_mlp_fwd_input(const float *X, long ldx, const int64_t *idx, long M, int D, const float *Wp,
                        const float *bp, int use_ln0, int H, float *xout, uint32_t *relu_mask, float *rstd,
                        float *mu0, float *rstd0, float *x0n, void *stream);
-/* WIDE observations (64 < D <= 512; harl_amd/csrc/wide.hip).  The first layer is split in two streaming kernels:
+/* observations wider than 32 (32 < D <= 512; harl_amd/csrc/wide.hip).  The first layer is split in two streaming kernels:
  *   harl_mlp_x0n_wide: x0n = ATL(KP) image of norm0(X[idx]) (KP = D rounded up to 32, zero padded; use_ln0 = 0: the raw
  *     rows), mu0 / rstd0 by minibatch position.  x0n depends on the inputs only: it is also the operand of
  *     harl_mlp_tangent_wide and of harl_mlp_dw_partials(b_kind = 0, K = KP) for this layer.

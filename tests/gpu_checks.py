@@ -92,7 +92,7 @@ def check_wide_input() -> Dict[str, float]:
     out = {}
     rng = np.random.default_rng(11)
     H = 128
-    for D, M, use_ln, gather in ((65, 97, 1, False), (100, 257, 1, True), (128, 64, 0, False), (200, 1000, 1, False),
+    for D, M, use_ln, gather in ((40, 70, 1, True), (54, 200, 1, False), (64, 33, 1, False), (65, 97, 1, False), (100, 257, 1, True), (128, 64, 0, False), (200, 1000, 1, False),
                                  (393, 300, 1, True), (449, 33, 1, False), (512, 130, 1, False)):
         KP, ns = (D + 31) // 32 * 32, (M + 31) // 32
         rows = M + 40
@@ -112,7 +112,9 @@ def check_wide_input() -> Dict[str, float]:
                 dec[:, f0:f0 + 4] = img[:, q, hh].reshape(ns * 32, 4)
         tag = f"D{D}"
         out[f"x0n_{tag}_abs"] = float((dec[:M, :D].double() - ref).abs().max())
-        out[f"x0n_{tag}_pad_abs"] = float(dec[:M, D:].abs().max()) if KP > D else 0.0
+        if KP > D:  # pad columns: zeros, except a column of ones in the last one (db' of the fused first-layer gradient)
+            out[f"x0n_{tag}_pad_abs"] = float(dec[:M, D:KP - 1].abs().max()) if KP - 1 > D else 0.0
+            out[f"x0n_{tag}_ones_abs"] = float((dec[:M, KP - 1] - 1.0).abs().max())
         if use_ln:
             out[f"mu0_{tag}_abs"] = float((mu0.cpu()[:M].double() - Xg.mean(1)).abs().max())
             out[f"rstd0_{tag}_rel"] = float(((rstd0.cpu()[:M].double() * torch.sqrt(Xg.var(1, unbiased=False) + 1e-5)) - 1).abs().max())

@@ -101,6 +101,11 @@ def build_gpu_runner(n_local: int, rank: int, world: int, device):
 
 
 def one_step(r) -> None:
+    # In training every step sees a freshly filled rollout buffer; the synthetic buffers here never change, so the
+    # per-buffer caches (the normalised-input images, nets._x0n_image) are dropped by hand to keep that work in the step.
+    for a in r.actor:
+        a.actor._x0n_key = None
+    r.critic.critic._x0n_key = None
     r.compute()
     r.train()
 

@@ -36,6 +36,7 @@ SIGNATURES = {
     "harl_mlp_x0n_wide": [_vp, _l, _vp, _l, _i, _i, _vp, _vp, _vp, _vp],
     "harl_mlp_fwd_wide": [_vp, _l, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp],
     "harl_mlp_tangent_wide": [_vp, _l, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+    "harl_mlp_fwd_fused2x": [_vp, _l, _vp, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "harl_mlp_fwd_fused2": [_vp, _l, _vp, _l, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                             _vp, _vp],
     "harl_mlp_fwd_hidden": [_vp, _l, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],

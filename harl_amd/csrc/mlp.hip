@@ -281,8 +281,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_fwd_input(const float *__rest
 
 // normalised input rows of a wave-slab (parked in LDS as xr = my sample's row; columns >= D hold zeros from the
 // kernel prologue) -> ATL(32*NCH) image in HBM: the B operand of the first layer's weight-gradient kernel (saves it the
-// gather + re-normalisation of raw rows).  Pad columns come out as -mean*rstd and only reach dWp columns >= D, which
-// nobody reads (same convention as the raw-row path of k_dw).
+// gather + re-normalisation of raw rows).  Pad columns are exact zeros (the same image k_x0n_wide writes).
 template <int NCH>
 __device__ __forceinline__ void x0n_store(const float *xr, int D, float mean, float rstd, int lane, long slab,
                                           float *__restrict__ out) {
@@ -290,7 +289,8 @@ __device__ __forceinline__ void x0n_store(const float *xr, int D, float mean, fl
   const float *xl = xr + 4 * (lane >> 5);
   float v[HW / 2];
 #pragma unroll
-  for (int R = 0; R < HW / 2; ++R) v[R] = (xl[feat_base(R)] - mean) * rstd;  // mean = 0, rstd = 1 without input LN
+  for (int R = 0; R < HW / 2; ++R)  // mean = 0, rstd = 1 without input LN; pad columns are exact zeros (as in k_x0n_wide)
+    v[R] = feat_base(R) + 4 * (lane >> 5) < D ? (xl[feat_base(R)] - mean) * rstd : 0.f;
   // the LAST pad column (feature HW-1 = register HW/2-1 of the upper lane half) is a column of ones when D < HW: the
   // weight-gradient GEMM then yields db' = sum_s dz[s] in that column for free (used by the fused path of k_bwd_dx)
   if (D < HW && (lane >> 5) == 1) v[HW / 2 - 1] = 1.0f;

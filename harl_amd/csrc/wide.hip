@@ -319,6 +319,129 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_fwd_wide(const float *__restr
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Fused layers 1 + 2 for narrow inputs (D <= 32, equal widths H) FROM the cached x0n ATL(32) image: the variant of
+// k_fwd_fused2 (mlp.hip) for identity row order.  No row gather, no LDS row staging, no input-LayerNorm statistics (all
+// done once per buffer by k_x0n_wide); both GEMMs are split_gemm() on the bf16 pipe (K = 32: 2 k-steps; K = H), x_hat_1
+// stays in registers and is written only when a backward pass follows.  8 waves share one LDS copy of the six weight images.
+// ---------------------------------------------------------------------------------------------
+constexpr int F2X_WAVES = 8;
+
+template <int H>
+__global__ __launch_bounds__(64 * F2X_WAVES, 2) void k_fwd_fused2x(
+    const float *__restrict__ x0n, const float *__restrict__ W1p, int D, const float *__restrict__ b1p,
+    const float *__restrict__ W2p, const float *__restrict__ b2p, int store1, float *__restrict__ x1out,
+    uint32_t *__restrict__ mask1, float *__restrict__ rstd1, float *__restrict__ x2out, uint32_t *__restrict__ mask2,
+    float *__restrict__ rstd2, long n_slabs) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int NTHR = 64 * F2X_WAVES, MT = H / 32, NJ1 = 2, NJ2 = H / 16, NR = H / 2, NW = (NR + 31) / 32;
+  u32x4 *w1img = reinterpret_cast<u32x4 *>(lds);          // [3][MT][2][64]
+  u32x4 *w2img = w1img + 3 * MT * NJ1 * 64;               // [3][MT][H/16][64]
+  float *b1l = reinterpret_cast<float *>(w2img + 3 * MT * NJ2 * 64);
+  float *b2l = b1l + H;
+  for (int e = threadIdx.x; e < MT * NJ1 * 64; e += NTHR) {  // W1' [H][D] (row stride D), K zero-padded to 32
+    const int ln = e & 63, j = (e >> 6) % NJ1, t = (e >> 6) / NJ1, m = 32 * t + (ln & 31), g = ln >> 5;
+    unsigned p[3][4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int f0 = feat_base(8 * j + 2 * c) + 4 * g, f1 = feat_base(8 * j + 2 * c + 1) + 4 * g;
+      split3_rne(f0 < D ? W1p[(long)m * D + f0] : 0.f, f1 < D ? W1p[(long)m * D + f1] : 0.f, p[0][c], p[1][c], p[2][c]);
+    }
+#pragma unroll
+    for (int term = 0; term < 3; ++term) w1img[term * (MT * NJ1 * 64) + e] = u32x4{p[term][0], p[term][1], p[term][2], p[term][3]};
+  }
+  stage_split_matrix<H, H, false, NTHR>(w2img, W2p);
+  for (int e = threadIdx.x; e < H; e += NTHR) {
+    b1l[e] = b1p[e];
+    b2l[e] = b2p[e];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
+  const long slab0 = (long)blockIdx.x * F2X_WAVES + wave, slab_stride = (long)gridDim.x * F2X_WAVES;
+  const u32x4 *wl1 = w1img + lane, *wl2 = w2img + lane;
+  float xr[16];
+  atl_load<32>(x0n, slab0 < n_slabs ? slab0 : 0, lane, xr);
+  for (long slab = slab0; slab < n_slabs; slab += slab_stride) {
+    u32x4 a1[NJ1], a2[NJ1], a3[NJ1];
+    split_acts<16>(xr, a1, a2, a3);
+    atl_load<32>(x0n, slab + slab_stride < n_slabs ? slab + slab_stride : slab, lane, xr);  // one slab ahead
+    float x1[NR];
+    uint32_t bits1[NW];
+    float r1;
+    {
+      f32x16 acc[MT];
+#pragma unroll
+      for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = b1l[32 * t + (r & 3) + 8 * (r >> 2) + 4 * h];
+      split_gemm<MT, NJ1>(wl1, a1, a2, a3, acc, [](int) {});
+      // ReLU + mask + LayerNorm of layer 1 (same arithmetic as relu_norm_regs in mlp.hip)
+#pragma unroll
+      for (int w = 0; w < NW; ++w) bits1[w] = 0u;
+      float sum = 0.f;
+#pragma unroll
+      for (int R = 0; R < NR; ++R) {
+        x1[R] = relu_push(acc[R >> 4][R & 15], bits1[R >> 5]);
+        sum += x1[R];
+      }
+      sum += wave_xor32(sum);
+      const float mean = sum * (1.0f / H);
+      float vs = 0.f;
+#pragma unroll
+      for (int R = 0; R < NR; ++R) {
+        x1[R] -= mean;
+        vs += x1[R] * x1[R];
+      }
+      vs += wave_xor32(vs);
+      r1 = 1.0f / sqrtf(vs * (1.0f / H) + 1e-5f);
+#pragma unroll
+      for (int R = 0; R < NR; ++R) x1[R] *= r1;
+    }
+    if (store1) {
+      atl_store<H>(x1out, slab, lane, x1);
+#pragma unroll
+      for (int w = 0; w < NW; ++w) mask1[(slab * NW + w) * WAVE + lane] = bits1[w];
+      if (lane < 32) rstd1[slab * SLAB + lane] = r1;
+    }
+    u32x4 y1[NJ2], y2[NJ2], y3[NJ2];
+    split_acts<NR>(x1, y1, y2, y3);
+    f32x16 acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = b2l[32 * t + (r & 3) + 8 * (r >> 2) + 4 * h];
+    split_gemm<MT, NJ2>(wl2, y1, y2, y3, acc, [](int) {});
+    {
+      uint32_t bits[NW];
+#pragma unroll
+      for (int w = 0; w < NW; ++w) bits[w] = 0u;
+      float v[NR];
+      float sum = 0.f;
+#pragma unroll
+      for (int R = 0; R < NR; ++R) {
+        v[R] = relu_push(acc[R >> 4][R & 15], bits[R >> 5]);
+        sum += v[R];
+      }
+      sum += wave_xor32(sum);
+      const float mean = sum * (1.0f / H);
+      float vs = 0.f;
+#pragma unroll
+      for (int R = 0; R < NR; ++R) {
+        v[R] -= mean;
+        vs += v[R] * v[R];
+      }
+      vs += wave_xor32(vs);
+      const float rstd = 1.0f / sqrtf(vs * (1.0f / H) + 1e-5f);
+#pragma unroll
+      for (int R = 0; R < NR; ++R) v[R] *= rstd;
+      atl_store<H>(x2out, slab, lane, v);
+#pragma unroll
+      for (int w = 0; w < NW; ++w) mask2[(slab * NW + w) * WAVE + lane] = bits[w];
+      if (lane < 32) rstd2[slab * SLAB + lane] = rstd;
+    }
+  }
+}
+
 template <bool TANGENT>
 int launch_wide(const float *x0n, long M, int KP, const float *Wp, int D, const float *bp, int H, void *w_img, float *xout,
                 uint32_t *mask_out, float *rstd_out, const float *xprimal, const uint32_t *mask_in, const float *rstd_in,
@@ -346,7 +469,7 @@ int launch_wide(const float *x0n, long M, int KP, const float *Wp, int D, const 
 extern "C" int harl_mlp_x0n_wide(const float *X, long ldx, const int64_t *idx, long M, int D, int use_ln0, float *x0n,
                                  float *mu0, float *rstd0, void *stream) {
   if (M <= 0) return 0;
-  if (D <= 32 || D > 512) return bad("harl_mlp_x0n_wide: 32 < D <= 512");
+  if (D < 1 || D > 512) return bad("harl_mlp_x0n_wide: 1 <= D <= 512");
   const long n_slabs = n_slabs_of(M);
   const int KP = ((D + 31) / 32) * 32, NC = (D + 63) / 64;
   const long wgs = (n_slabs + WAVES_PER_WG - 1) / WAVES_PER_WG;
@@ -383,4 +506,27 @@ extern "C" int harl_mlp_tangent_wide(const float *x0n, long M, int KP, const flo
                                      void *stream) {
   return launch_wide<true>(x0n, M, KP, Wdp, D, bdp, H, w_img, x1dot, nullptr, nullptr, x1, mask1, rstd1,
                            (hipStream_t)stream, "harl_mlp_tangent_wide");
+}
+
+extern "C" int harl_mlp_fwd_fused2x(const float *x0n, long M, const float *W1p, int D, const float *b1p, const float *W2p,
+                                    const float *b2p, int H, int store1, float *x1out, uint32_t *mask1, float *rstd1,
+                                    float *x2out, uint32_t *mask2, float *rstd2, void *stream) {
+  if (M <= 0) return 0;
+  if (D < 1 || D > 32) return bad("harl_mlp_fwd_fused2x: input width must be <= 32");
+  if (H != 128 && H != 64) return bad("harl_mlp_fwd_fused2x: hidden width must be 64 or 128");
+  const long n_slabs = n_slabs_of(M);
+  const size_t shm = split_image_bytes(H, 32) + split_image_bytes(H, H) + 2 * (size_t)H * sizeof(float);
+  const long wgs = (n_slabs + F2X_WAVES - 1) / F2X_WAVES;
+  const int grid = (int)(wgs < 256 ? (wgs < 1 ? 1 : wgs) : 256);
+  hipStream_t s = (hipStream_t)stream;
+  if (H == 128) {
+    allow_big_lds(k_fwd_fused2x<128>, shm);
+    hipLaunchKernelGGL((k_fwd_fused2x<128>), dim3(grid), dim3(64 * F2X_WAVES), shm, s, x0n, W1p, D, b1p, W2p, b2p, store1, x1out,
+                       mask1, rstd1, x2out, mask2, rstd2, n_slabs);
+  } else {
+    allow_big_lds(k_fwd_fused2x<64>, shm);
+    hipLaunchKernelGGL((k_fwd_fused2x<64>), dim3(grid), dim3(64 * F2X_WAVES), shm, s, x0n, W1p, D, b1p, W2p, b2p, store1, x1out,
+                       mask1, rstd1, x2out, mask2, rstd2, n_slabs);
+  }
+  return check_launch("harl_mlp_fwd_fused2x");
 }

@@ -289,6 +289,17 @@ class _FlatNet(nn.Module):
              ptr(self.rnn_rstd), ptr(sv[0]), ptr(sv[1]), ptr(sv[2]), ptr(sv[3]), ptr(sv[4]), ptr(seq.get("h_last")),
              int(save), ptr(self.rnn_gi), stream(), tag="gru_fwd")
 
+    def _x0n_image(self, X: torch.Tensor, M: int, s, idx: Optional[torch.Tensor] = None) -> None:
+        """Normalised inputs of rows X[idx] as the ATL(kp0) image self.x0n (csrc/wide.hip).  It depends on the rows only:
+        every epoch / line-search step / log-prob pass over the same (unmodified) tensor reuses it -- torch's version
+        counter catches in-place writes; identity row order only; the cache keeps a reference to the source tensor, so its
+        storage cannot have been recycled for different data at the same address."""
+        key = (X.data_ptr(), X._version, tuple(X.shape), M) if idx is None else None
+        if key is None or key != self._x0n_key:
+            call("harl_mlp_x0n_wide", ptr(X), X.shape[1], ptr(idx), M, self.in_dim, int(self.use_feature_normalization),
+                 ptr(self.x0n), ptr(self.mu0), ptr(self.rstd0), s, tag="x0n_wide")
+            self._x0n_key, self._x0n_src = key, (X if key is not None else None)
+
     def forward_trunk(self, X: torch.Tensor, idx: Optional[torch.Tensor], M: int, for_backward: bool = True,
                       seq: Optional[dict] = None) -> None:
         assert X.dim() == 2 and X.shape[1] == self.in_dim and X.is_contiguous()
@@ -299,9 +310,19 @@ class _FlatNet(nn.Module):
         s = stream()
         hs = self.hidden_sizes
         first_hidden = 1
-        if len(hs) >= 2 and hs[0] == hs[1] and self.in_dim <= 32:
+        if len(hs) >= 2 and hs[0] == hs[1] and self.in_dim <= 32 and idx is None:
+            # layers 1+2 fused, from the x0n image: the rows are gathered and normalised ONCE per buffer (every epoch, log-prob
+            # pass and line-search step over the same unmodified tensor reuses the image)
+            (W1, b1), (W2, b2) = self._packs[0], self._packs[1]
+            self._x0n_image(X, M, s)
+            call("harl_mlp_fwd_fused2x", ptr(self.x0n), M, ptr(W1), self.in_dim, ptr(b1), ptr(W2), ptr(b2), hs[0],
+                 int(for_backward), ptr(self.xh[0]), ptr(self.rmask[0]), ptr(self.rstd[0]), ptr(self.xh[1]),
+                 ptr(self.rmask[1]), ptr(self.rstd[1]), s, tag="fwd_fused2")
+            first_hidden = 2
+        elif len(hs) >= 2 and hs[0] == hs[1] and self.in_dim <= 32:
             # layers 1+2 fused: x_hat_1 stays in registers; it is written out only if a backward pass follows
             (W1, b1), (W2, b2) = self._packs[0], self._packs[1]
+            self._x0n_key = None  # this kernel writes the gathered minibatch's image into self.x0n
             call("harl_mlp_fwd_fused2", ptr(X), X.shape[1], ptr(idx), M, self.in_dim, ptr(W1), ptr(b1),
                  int(self.use_feature_normalization), ptr(W2), ptr(b2), hs[0], int(for_backward), ptr(self.xh[0]),
                  ptr(self.rmask[0]), ptr(self.rstd[0]), ptr(self.mu0), ptr(self.rstd0), ptr(self.xh[1]),
@@ -309,19 +330,12 @@ class _FlatNet(nn.Module):
             first_hidden = 2
         elif self.wide:
             Wp, bp = self._packs[0]
-            # x0n depends on the rows only: every epoch / line-search step / log-prob pass over the same (unmodified)
-            # tensor reuses the image (torch's version counter catches in-place writes to the buffer)
-            # (identity row order only; the cache keeps a reference to the source tensor, so its storage cannot have been
-            # recycled for different data at the same address)
-            key = (X.data_ptr(), X._version, tuple(X.shape), M) if idx is None else None
-            if key is None or key != self._x0n_key:
-                call("harl_mlp_x0n_wide", ptr(X), X.shape[1], ptr(idx), M, self.in_dim, int(self.use_feature_normalization),
-                     ptr(self.x0n), ptr(self.mu0), ptr(self.rstd0), s, tag="x0n_wide")
-                self._x0n_key, self._x0n_src = key, (X if key is not None else None)
+            self._x0n_image(X, M, s, idx)
             call("harl_mlp_fwd_wide", ptr(self.x0n), M, self.kp0, ptr(Wp), self.in_dim, ptr(bp), hs[0], ptr(self.w1img),
                  ptr(self.xh[0]), ptr(self.rmask[0]), ptr(self.rstd[0]), s, tag="fwd_wide")
         else:
             Wp, bp = self._packs[0]
+            self._x0n_key = None  # (may write self.x0n)
             call("harl_mlp_fwd_input", ptr(X), X.shape[1], ptr(idx), M, self.in_dim, ptr(Wp), ptr(bp),
                  int(self.use_feature_normalization), hs[0], ptr(self.xh[0]), ptr(self.rmask[0]), ptr(self.rstd[0]),
                  ptr(self.mu0), ptr(self.rstd0), ptr(self.x0n) if for_backward else None, s, tag="fwd_input")

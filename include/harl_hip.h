@@ -106,7 +106,8 @@ int harl_unfold_linear_grads(const float *dWp, const float *dbp, int ldp, const 
 int harl_mlp_fwd_input(const float *X, long ldx, const int64_t *idx, long M, int D, const float *Wp,
                        const float *bp, int use_ln0, int H, float *xout, uint32_t *relu_mask, float *rstd,
                        float *mu0, float *rstd0, float *x0n, void *stream);
-/* observations wider than 32 (32 < D <= 512; harl_amd/csrc/wide.hip).  The first layer is split in two streaming kernels:
+/* observations wider than 32 (32 < D <= 512; harl_amd/csrc/wide.hip; harl_mlp_x0n_wide itself accepts any D >= 1).  The
+ * first layer is split in two streaming kernels:
  *   harl_mlp_x0n_wide: x0n = ATL(KP) image of norm0(X[idx]) (KP = D rounded up to 32, zero padded; use_ln0 = 0: the raw
  *     rows), mu0 / rstd0 by minibatch position.  x0n depends on the inputs only: it is also the operand of
  *     harl_mlp_tangent_wide and of harl_mlp_dw_partials(b_kind = 0, K = KP) for this layer.
@@ -116,6 +117,11 @@ int harl_mlp_x0n_wide(const float *X, long ldx, const int64_t *idx, long M, int 
                       float *rstd0, void *stream);
 int harl_mlp_fwd_wide(const float *x0n, long M, int KP, const float *Wp, int D, const float *bp, int H, void *w_img,
                       float *xout, uint32_t *relu_mask, float *rstd, void *stream);
+/* the same two layers FROM the x0n ATL(32) image of harl_mlp_x0n_wide (identity row order; the image is built once per
+ * buffer): no gather, no input-LayerNorm work per call */
+int harl_mlp_fwd_fused2x(const float *x0n, long M, const float *W1p, int D, const float *b1p, const float *W2p,
+                         const float *b2p, int H, int store1, float *x1out, uint32_t *mask1, float *rstd1, float *x2out,
+                         uint32_t *mask2, float *rstd2, void *stream);
 /* fused layers 1+2 for narrow inputs (D <= 32) and equal widths H: x_hat_1 stays in registers between the two GEMMs;
  * store1 != 0 also writes x_hat_1 / mask1 / rstd1 / mu0 / rstd0 and (if non-NULL) x0n as in harl_mlp_fwd_input
  * (needed only when a backward pass follows). */

@@ -223,11 +223,12 @@ def main():
         gemm_bf16 = 2.0 * B * 128 * 128  # the 128 x 128 GEMM of every family runs as 6 bf16 products
         pipe = {k: 6.0 * gemm_bf16 + 16.0 * (v - gemm_bf16) for k, v in flops.items()}  # bf16-pipe-equivalent FLOPs issued
         # ALGORITHMIC HBM bytes per launch of each family for THIS run's launch mix: the fused forward is
-        # launched 15x per step in training mode (writes x_hat_1, x_hat_2, the normalised inputs, masks, statistics)
+        # launched 15x per step in training mode (reads the cached x0n image, writes x_hat_1, x_hat_2, masks, statistics)
         # and 3x in log-prob mode (x_hat_2 only).
         alg = dict(fwd_hidden=B * (512 + 512 + 16 + 4), bwd_dx=B * (512 + 512 + 16 + 4 + 512), dw_hidden=B * (512 + 512),
                    bwd_dx_dw1=B * (512 + 512 + 16 + 4 + (15 * 128 + 5 * 256) / 20.0),
-                   fwd_fused2=B * (15 * (4 * OBS + 512 + 512 + 128 + 32 + 16) + 3 * (4 * OBS + 512 + 16 + 4)) / 18.0)
+                   # fused forward from the cached x0n image: 128 B in; training mode writes x_hat_1, x_hat_2, masks, rstd
+                   fwd_fused2=B * (15 * (128 + 512 + 512 + 32 + 8) + 3 * (128 + 512 + 16 + 4)) / 18.0)
         cand = {k: v for k, v in mfma_kern.items() if k in flops and v["n"] > 0}
         roof = None
         if cand:

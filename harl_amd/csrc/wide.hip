@@ -153,6 +153,72 @@ __global__ __launch_bounds__(WG_THREADS, NC <= 3 ? 2 : 1) void k_x0n_wide(const 
   }
 }
 
+// narrow rows (D <= 32): two rows per load instruction (lane = (row parity, column)), statistics per half-wave
+__global__ __launch_bounds__(WG_THREADS, 2) void k_x0n_narrow(const float *__restrict__ X, long ldx,
+                                                              const int64_t *__restrict__ idx, long M, int D, int use_ln0,
+                                                              float *__restrict__ x0n, float *__restrict__ mu0_out,
+                                                              float *__restrict__ rstd0_out, long n_slabs) {
+  __shared__ __attribute__((aligned(16))) float tiles[WAVES_PER_WG][32 * XT_LD];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  float *tw = &tiles[wave][0];
+  const int kc = i < D ? i : 0;
+  for (long slab = (long)blockIdx.x * WAVES_PER_WG + wave; slab < n_slabs; slab += (long)gridDim.x * WAVES_PER_WG) {
+    long rows[16];
+    if (idx) {
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const long j = slab * SLAB + 2 * u + h;
+        rows[u] = idx[j < M ? j : M - 1];
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const long j = slab * SLAB + 2 * u + h;
+        rows[u] = j < M ? j : M - 1;
+      }
+    }
+    float v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = X[rows[u] * ldx + kc];
+    const float invD = 1.0f / (float)D;
+    float my_mean = 0.f, my_rstd = 1.f;  // lane (h, i) keeps the statistics of sample 2u + h for u = i >> 1 ... see below
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      float mean = 0.f, rstd = 1.f;
+      if (use_ln0) {
+        mean = half_reduce_sum(i < D ? v[u] : 0.f) * invD;
+        const float d = v[u] - mean;
+        rstd = 1.0f / sqrtf(half_reduce_sum(i < D ? d * d : 0.f) * invD + 1e-5f);
+      }
+      v[u] = i < D ? (v[u] - mean) * rstd : ((i == 31 && D < 32) ? 1.0f : 0.f);
+      if (i == u) {  // lane (h, i = u) ends up with the statistics of sample 2u + h
+        my_mean = mean;
+        my_rstd = rstd;
+      }
+    }
+    if (i < 16) {
+      mu0_out[slab * SLAB + 2 * i + h] = my_mean;
+      rstd0_out[slab * SLAB + 2 * i + h] = my_rstd;
+    }
+    // transposition: T[feature i][sample 2u + h], then lane (sample i, half h) reads its 16 features
+#pragma unroll
+    for (int u = 0; u < 16; ++u) tw[i * XT_LD + 2 * u + h] = v[u];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    f32x4 *op = reinterpret_cast<f32x4 *>(x0n + slab * (long)32 * SLAB) + lane;
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) {
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = tw[(8 * qq + 4 * h + e) * XT_LD + i];
+      op[qq * WAVE] = o;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // fp32 Wp[H][D] -> three bf16 images [term][tile][k-step][64 lanes] x 16 B in global memory, K zero-padded to KP
 // ---------------------------------------------------------------------------------------------
@@ -474,6 +540,11 @@ extern "C" int harl_mlp_x0n_wide(const float *X, long ldx, const int64_t *idx, l
   const int KP = ((D + 31) / 32) * 32, NC = (D + 63) / 64;
   const long wgs = (n_slabs + WAVES_PER_WG - 1) / WAVES_PER_WG;
   hipStream_t s = (hipStream_t)stream;
+  if (D <= 32) {
+    const int grid = (int)(wgs < 512 ? (wgs < 1 ? 1 : wgs) : 512);
+    hipLaunchKernelGGL(k_x0n_narrow, dim3(grid), dim3(WG_THREADS), 0, s, X, ldx, idx, M, D, use_ln0, x0n, mu0, rstd0, n_slabs);
+    return check_launch("harl_mlp_x0n_wide");
+  }
 #define LX(NCv)                                                                                                         \
   {                                                                                                                     \
     const long cap = 256L * (NCv <= 3 ? 2 : 1);                                                                         \

@@ -92,7 +92,7 @@ def check_wide_input() -> Dict[str, float]:
     out = {}
     rng = np.random.default_rng(11)
     H = 128
-    for D, M, use_ln, gather in ((40, 70, 1, True), (54, 200, 1, False), (64, 33, 1, False), (65, 97, 1, False), (100, 257, 1, True), (128, 64, 0, False), (200, 1000, 1, False),
+    for D, M, use_ln, gather in ((5, 45, 1, False), (18, 300, 1, True), (32, 64, 0, False), (40, 70, 1, True), (54, 200, 1, False), (64, 33, 1, False), (65, 97, 1, False), (100, 257, 1, True), (128, 64, 0, False), (200, 1000, 1, False),
                                  (393, 300, 1, True), (449, 33, 1, False), (512, 130, 1, False)):
         KP, ns = (D + 31) // 32 * 32, (M + 31) // 32
         rows = M + 40

@@ -26,9 +26,15 @@ FAMILIES = {
     "void k_dw_split<4, 4>": ("dw_hidden", B * (512 + 512), "dz_l + x_hat_{l-1} (+ 33 MB of per-workgroup partials)"),
     "void k_dw<0, 0, 4, 1>": ("dw_input (unfused path)", B * (512 + 128), "dz_1 + normalised inputs ATL(32)"),
     "void k_dw<1, 0, 1, 4>": ("dw_head (unfused path)", B * (128 + 512), "dhead rows + x_hat_L"),
-    "void k_fwd_fused2<128, 2, 1>": ("fwd_fused2", B * (72 + (512 + 512 + 32 + 8 + 8 + 512 + 16 + 4) / 2),
+    "void k_fwd_fused2x<128>": ("fwd_fused2", B * (128 + (512 + 512 + 32 + 8 + 512 + 16 + 4) / 2),
+                                "x0n ATL(32) + (train: x_hat_1, x_hat_2, masks, rstd | logp: x_hat_2, mask, rstd), mean of the two modes "
+                                "timed by kbench"),
+    "void k_fwd_fused2<128, 2, 1>": ("fwd_fused2 (minibatch gather path)", B * (72 + (512 + 512 + 32 + 8 + 8 + 512 + 16 + 4) / 2),
                                      "obs rows + (train: x_hat_1, x_hat_2, masks, rstd, LN0 stats | logp: x_hat_2, mask, rstd), "
                                      "mean of the two modes timed by kbench (x0n not written there)"),
+    "k_x0n_narrow": ("x0n_D18", B * (72 + 128 + 8), "obs rows + x0n ATL(32) + LN0 stats"),
+    "void k_x0n_wide<1>": ("x0n_D54", B * (216 + 256 + 8), "share_obs rows + x0n ATL(64) + LN0 stats"),
+    "void k_fwd_wide<128, false>": ("fwd_wide_K64", B * (256 + 512 + 16 + 4), "x0n ATL(64) + x_hat_1 + mask + rstd"),
     "void k_actor_head<128, 8, false, true, true>": ("actor_head_loss", B * (512 + 16 + 4 + 52 + 512),
                                                      "x_hat_L + mask + rstd + per-row loss inputs + dz_L (head dW fused: no dhead; + 8.6 MB partials)"),
     "void k_actor_head<128, 8, false, true, false>": ("actor_head_loss (unfused path)", B * (512 + 16 + 4 + 52 + 512 + 128), "... + dhead"),

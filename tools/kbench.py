@@ -59,6 +59,8 @@ def main():
     P = 20142
     pp, gg, mm, vv = rn(P), rn(P), torch.zeros(P, device=dev), torch.zeros(P, device=dev)
     x0n32 = rn(mp * 32)
+    x0n64 = rn(mp * 64)
+    wimg = torch.empty(3 * H * 64 // 2, device=dev)
     ps_f = torch.zeros(n_wg * 48, device=dev)
     part_h = torch.empty(n_wg * (32 * H + 32), device=dev)
     part_1 = torch.empty(n_wg * (H * 32 + H), device=dev)
@@ -71,6 +73,11 @@ def main():
         ("fwd_input_D54", lambda: call("harl_mlp_fwd_input", ptr(sobs), 54, None, B, 54, ptr(W1c), ptr(b), 1, H, ptr(xh1), ptr(mask), ptr(rstd), ptr(mu0), ptr(rstd0), None, s), GB(B * (216 + 512 + 20))),
         ("fwd_fused2_D18_train", lambda: call("harl_mlp_fwd_fused2", ptr(obs), 18, None, B, 18, ptr(W1), ptr(b), 1, ptr(W), ptr(b), H, 1, ptr(xh1), ptr(mask), ptr(rstd), ptr(mu0), ptr(rstd0), ptr(xh2), ptr(mask), ptr(rstd), None, s), GF(fl + 2.0 * B * 18 * H)),
         ("fwd_fused2_D18_logp", lambda: call("harl_mlp_fwd_fused2", ptr(obs), 18, None, B, 18, ptr(W1), ptr(b), 1, ptr(W), ptr(b), H, 0, ptr(xh1), ptr(mask), ptr(rstd), ptr(mu0), ptr(rstd0), ptr(xh2), ptr(mask), ptr(rstd), None, s), GF(fl + 2.0 * B * 18 * H)),
+        ("x0n_D18", lambda: call("harl_mlp_x0n_wide", ptr(obs), 18, None, B, 18, 1, ptr(x0n32), ptr(mu0), ptr(rstd0), s), GB(B * (72 + 128 + 8))),
+        ("x0n_D54", lambda: call("harl_mlp_x0n_wide", ptr(sobs), 54, None, B, 54, 1, ptr(x0n64), ptr(mu0), ptr(rstd0), s), GB(B * (216 + 256 + 8))),
+        ("fwd_fused2x_train", lambda: call("harl_mlp_fwd_fused2x", ptr(x0n32), B, ptr(W1), 18, ptr(b), ptr(W), ptr(b), H, 1, ptr(xh1), ptr(mask), ptr(rstd), ptr(xh2), ptr(mask), ptr(rstd), s), GF(fl + 2.0 * B * 18 * H)),
+        ("fwd_fused2x_logp", lambda: call("harl_mlp_fwd_fused2x", ptr(x0n32), B, ptr(W1), 18, ptr(b), ptr(W), ptr(b), H, 0, ptr(xh1), ptr(mask), ptr(rstd), ptr(xh2), ptr(mask), ptr(rstd), s), GF(fl + 2.0 * B * 18 * H)),
+        ("fwd_wide_K64", lambda: call("harl_mlp_fwd_wide", ptr(x0n64), B, 64, ptr(W1c), 54, ptr(b), H, ptr(wimg), ptr(xh1), ptr(mask), ptr(rstd), s), GB(B * (256 + 512 + 20))),
         ("fwd_hidden", lambda: call("harl_mlp_fwd_hidden", ptr(xh1), B, H, H, ptr(W), ptr(b), ptr(xh2), ptr(mask), ptr(rstd), s), GF(fl)),
         ("bwd_dx", lambda: call("harl_mlp_bwd_dx", ptr(dz), ptr(xh1), ptr(mask), ptr(rstd), B, H, H, ptr(W), ptr(dz2), None, 0, None, 0, s), GF(fl)),
         ("bwd_dx_dw1_fused", lambda: call("harl_mlp_bwd_dx", ptr(dz), ptr(xh1), ptr(mask), ptr(rstd), B, H, H, ptr(W), None, ptr(x0n32), 32, ptr(part_1), n_wg, s), GF(fl + 2.0 * B * H * 18)),

@@ -84,6 +84,7 @@ class OnPolicyHARunner:
         for x in self.actor + [self.critic]:
             x.comm, x.shard = self.comm, shard
         self._logp_old = None
+        self._counts_host = None
 
     # ---- on_policy_base_runner.py:462-484 -------------------------------------------------------
     @torch.no_grad()
@@ -124,7 +125,21 @@ class OnPolicyHARunner:
                 adv_a = advantages if self.state_type == "EP" else advantages[:, :, a].contiguous()
                 self.actor[a].masked_moments(self.actor_buffer[a], adv_a, mom_all[a])
         self.comm.all_reduce_sum(mom_all)
-        counts = mom_all[:, 2].cpu().tolist()
+        # The only mid-train host read: the active-entry counts (early-out test).  It is an asynchronous copy into pinned
+        # memory followed by an event; when the critic update may run first (it is independent of the actors, and with one
+        # full-buffer minibatch everywhere no permutation is ever materialised, so the CPU generator only advances by
+        # counts that do not depend on the order) its kernels are enqueued BEFORE the host waits on that event: the GPU
+        # works through them while the host queues the first actor's launches instead of idling behind a drained stream.
+        if self._counts_host is None or self._counts_host.numel() != self.num_agents:
+            self._counts_host = torch.empty(self.num_agents, dtype=torch.float64, pin_memory=True)
+        self._counts_host.copy_(mom_all[:, 2], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        cinfo = None
+        if self._critic_first_ok(fast):
+            cinfo = self.critic.train(self.critic_buffer, self.value_normalizer, _defer=True)
+        ev.synchronize()
+        counts = self._counts_host.tolist()
         pending = []
         for agent_id in agent_order:
             buf, actor = self.actor_buffer[agent_id], self.actor[agent_id]
@@ -151,7 +166,8 @@ class OnPolicyHARunner:
             # post-update log-probs fused with factor *= agg(exp(new - old))   (:96-124)
             actor._logp_pass(obs, actions, avail, B, None, old_logp=self._logp_old, factor=new_factor.reshape(B), **rnn_kw)
             factor = new_factor
-        cinfo = self.critic.train(self.critic_buffer, self.value_normalizer, _defer=True)
+        if cinfo is None:
+            cinfo = self.critic.train(self.critic_buffer, self.value_normalizer, _defer=True)
         rng_sync()  # the global CPU generator is exactly where the reference leaves it
         dev_infos = [p[1] for p in pending if p is not None] + [cinfo]
         flat = torch.cat([t.reshape(-1) for t in dev_infos]).cpu().tolist()  # the single end-of-train read-back
@@ -163,6 +179,18 @@ class OnPolicyHARunner:
                 off += len(keys)
         critic_train_info = {"value_loss": flat[off], "critic_grad_norm": flat[off + 1]}
         return actor_train_infos, critic_train_info
+
+    def _critic_first_ok(self, fast) -> bool:
+        """May the critic update be enqueued before the actors'?  Only when nothing in train() materialises a permutation
+        (one full-buffer minibatch everywhere, feed-forward nets, HAPPO-family actors): then every sampler merely advances
+        the CPU generator by a count, the final generator state does not depend on the order of those advances, and the
+        critic reads nothing the actors write."""
+        if not all(fast) or os.environ.get("HARL_CRITIC_FIRST", "1") == "0":
+            return False
+        c = self.critic
+        if c.critic_num_mini_batch != 1 or c.use_recurrent_policy or c.use_naive_recurrent_policy:
+            return False
+        return all(hasattr(a, "fuses_old_logp") and a.fuses_old_logp() for a in self.actor)
 
     def after_update(self):
         for b in self.actor_buffer:

@@ -284,10 +284,8 @@ __global__ __launch_bounds__(256) void k_split_image(const float *__restrict__ W
     unsigned p[3][4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      const int k0 = 16 * j + 8 * g + 2 * c;  // B operand of k-step j, lane half g: x0n registers 8 j .. 8 j + 7
-      // register R of the ATL(KP) image <-> feature feat_base(R) + 4 g
+      // B operand of k-step j, lane half g = x0n registers 8 j .. 8 j + 7; register R <-> feature feat_base(R) + 4 g
       const int f0 = feat_base(8 * j + 2 * c) + 4 * g, f1 = feat_base(8 * j + 2 * c + 1) + 4 * g;
-      (void)k0;
       const float w0 = f0 < D ? Wp[(long)m * D + f0] : 0.f;
       const float w1 = f1 < D ? Wp[(long)m * D + f1] : 0.f;
       split3_rne(w0, w1, p[0][c], p[1][c], p[2][c]);

@@ -438,26 +438,26 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_fwd_wide(const float *__restr
 }
 
 // ---------------------------------------------------------------------------------------------
-// Fused layers 1 + 2 for narrow inputs (D <= 32, equal widths H) FROM the cached x0n ATL(32) image: the variant of
+// Fused layers 1 + 2 for inputs up to 64 wide (equal widths H) FROM the cached x0n ATL(32 / 64) image: the variant of
 // k_fwd_fused2 (mlp.hip) for identity row order.  No row gather, no LDS row staging, no input-LayerNorm statistics (all
-// done once per buffer by k_x0n_wide); both GEMMs are split_gemm() on the bf16 pipe (K = 32: 2 k-steps; K = H), x_hat_1
+// done once per buffer by the x0n kernels); both GEMMs are split_gemm() on the bf16 pipe (K = 32 / 64; K = H), x_hat_1
 // stays in registers and is written only when a backward pass follows.  8 waves share one LDS copy of the six weight images.
 // ---------------------------------------------------------------------------------------------
 constexpr int F2X_WAVES = 8;
 
-template <int H>
+template <int H, int KP0>
 __global__ __launch_bounds__(64 * F2X_WAVES, 2) void k_fwd_fused2x(
     const float *__restrict__ x0n, const float *__restrict__ W1p, int D, const float *__restrict__ b1p,
     const float *__restrict__ W2p, const float *__restrict__ b2p, int store1, float *__restrict__ x1out,
     uint32_t *__restrict__ mask1, float *__restrict__ rstd1, float *__restrict__ x2out, uint32_t *__restrict__ mask2,
     float *__restrict__ rstd2, long n_slabs) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  constexpr int NTHR = 64 * F2X_WAVES, MT = H / 32, NJ1 = 2, NJ2 = H / 16, NR = H / 2, NW = (NR + 31) / 32;
-  u32x4 *w1img = reinterpret_cast<u32x4 *>(lds);          // [3][MT][2][64]
+  constexpr int NTHR = 64 * F2X_WAVES, MT = H / 32, NJ1 = KP0 / 16, NJ2 = H / 16, NR = H / 2, NW = (NR + 31) / 32;
+  u32x4 *w1img = reinterpret_cast<u32x4 *>(lds);          // [3][MT][KP0/16][64]
   u32x4 *w2img = w1img + 3 * MT * NJ1 * 64;               // [3][MT][H/16][64]
   float *b1l = reinterpret_cast<float *>(w2img + 3 * MT * NJ2 * 64);
   float *b2l = b1l + H;
-  for (int e = threadIdx.x; e < MT * NJ1 * 64; e += NTHR) {  // W1' [H][D] (row stride D), K zero-padded to 32
+  for (int e = threadIdx.x; e < MT * NJ1 * 64; e += NTHR) {  // W1' [H][D] (row stride D), K zero-padded to KP0
     const int ln = e & 63, j = (e >> 6) % NJ1, t = (e >> 6) / NJ1, m = 32 * t + (ln & 31), g = ln >> 5;
     unsigned p[3][4];
 #pragma unroll
@@ -477,12 +477,12 @@ __global__ __launch_bounds__(64 * F2X_WAVES, 2) void k_fwd_fused2x(
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
   const long slab0 = (long)blockIdx.x * F2X_WAVES + wave, slab_stride = (long)gridDim.x * F2X_WAVES;
   const u32x4 *wl1 = w1img + lane, *wl2 = w2img + lane;
-  float xr[16];
-  atl_load<32>(x0n, slab0 < n_slabs ? slab0 : 0, lane, xr);
+  float xr[KP0 / 2];
+  atl_load<KP0>(x0n, slab0 < n_slabs ? slab0 : 0, lane, xr);
   for (long slab = slab0; slab < n_slabs; slab += slab_stride) {
     u32x4 a1[NJ1], a2[NJ1], a3[NJ1];
-    split_acts<16>(xr, a1, a2, a3);
-    atl_load<32>(x0n, slab + slab_stride < n_slabs ? slab + slab_stride : slab, lane, xr);  // one slab ahead
+    split_acts<KP0 / 2>(xr, a1, a2, a3);
+    atl_load<KP0>(x0n, slab + slab_stride < n_slabs ? slab + slab_stride : slab, lane, xr);  // one slab ahead
     float x1[NR];
     uint32_t bits1[NW];
     float r1;
@@ -640,21 +640,25 @@ extern "C" int harl_mlp_fwd_fused2x(const float *x0n, long M, const float *W1p, 
                                     const float *b2p, int H, int store1, float *x1out, uint32_t *mask1, float *rstd1,
                                     float *x2out, uint32_t *mask2, float *rstd2, void *stream) {
   if (M <= 0) return 0;
-  if (D < 1 || D > 32) return bad("harl_mlp_fwd_fused2x: input width must be <= 32");
+  if (D < 1 || D > 64) return bad("harl_mlp_fwd_fused2x: input width must be <= 64");
   if (H != 128 && H != 64) return bad("harl_mlp_fwd_fused2x: hidden width must be 64 or 128");
   const long n_slabs = n_slabs_of(M);
-  const size_t shm = split_image_bytes(H, 32) + split_image_bytes(H, H) + 2 * (size_t)H * sizeof(float);
+  const int kp0 = D <= 32 ? 32 : 64;
+  const size_t shm = split_image_bytes(H, kp0) + split_image_bytes(H, H) + 2 * (size_t)H * sizeof(float);
   const long wgs = (n_slabs + F2X_WAVES - 1) / F2X_WAVES;
   const int grid = (int)(wgs < 256 ? (wgs < 1 ? 1 : wgs) : 256);
   hipStream_t s = (hipStream_t)stream;
-  if (H == 128) {
-    allow_big_lds(k_fwd_fused2x<128>, shm);
-    hipLaunchKernelGGL((k_fwd_fused2x<128>), dim3(grid), dim3(64 * F2X_WAVES), shm, s, x0n, W1p, D, b1p, W2p, b2p, store1, x1out,
-                       mask1, rstd1, x2out, mask2, rstd2, n_slabs);
-  } else {
-    allow_big_lds(k_fwd_fused2x<64>, shm);
-    hipLaunchKernelGGL((k_fwd_fused2x<64>), dim3(grid), dim3(64 * F2X_WAVES), shm, s, x0n, W1p, D, b1p, W2p, b2p, store1, x1out,
-                       mask1, rstd1, x2out, mask2, rstd2, n_slabs);
+#define LF(Hv, Kv)                                                                                                       \
+  {                                                                                                                      \
+    allow_big_lds(k_fwd_fused2x<Hv, Kv>, shm);                                                                           \
+    hipLaunchKernelGGL((k_fwd_fused2x<Hv, Kv>), dim3(grid), dim3(64 * F2X_WAVES), shm, s, x0n, W1p, D, b1p, W2p, b2p, store1, \
+                       x1out, mask1, rstd1, x2out, mask2, rstd2, n_slabs);                                                \
   }
+  if (H == 128) {
+    if (kp0 == 32) LF(128, 32) else LF(128, 64)
+  } else {
+    if (kp0 == 32) LF(64, 32) else LF(64, 64)
+  }
+#undef LF
   return check_launch("harl_mlp_fwd_fused2x");
 }

@@ -310,14 +310,14 @@ class _FlatNet(nn.Module):
         s = stream()
         hs = self.hidden_sizes
         first_hidden = 1
-        if len(hs) >= 2 and hs[0] == hs[1] and self.in_dim <= 32 and idx is None:
+        if len(hs) >= 2 and hs[0] == hs[1] and self.in_dim <= 64 and idx is None:
             # layers 1+2 fused, from the x0n image: the rows are gathered and normalised ONCE per buffer (every epoch, log-prob
             # pass and line-search step over the same unmodified tensor reuses the image)
             (W1, b1), (W2, b2) = self._packs[0], self._packs[1]
             self._x0n_image(X, M, s)
             call("harl_mlp_fwd_fused2x", ptr(self.x0n), M, ptr(W1), self.in_dim, ptr(b1), ptr(W2), ptr(b2), hs[0],
                  int(for_backward), ptr(self.xh[0]), ptr(self.rmask[0]), ptr(self.rstd[0]), ptr(self.xh[1]),
-                 ptr(self.rmask[1]), ptr(self.rstd[1]), s, tag="fwd_fused2")
+                 ptr(self.rmask[1]), ptr(self.rstd[1]), s, tag="fwd_fused2" if self.kp0 == 32 else "fwd_fused2_k64")
             first_hidden = 2
         elif len(hs) >= 2 and hs[0] == hs[1] and self.in_dim <= 32:
             # layers 1+2 fused: x_hat_1 stays in registers; it is written out only if a backward pass follows

@@ -117,8 +117,8 @@ int harl_mlp_x0n_wide(const float *X, long ldx, const int64_t *idx, long M, int 
                       float *rstd0, void *stream);
 int harl_mlp_fwd_wide(const float *x0n, long M, int KP, const float *Wp, int D, const float *bp, int H, void *w_img,
                       float *xout, uint32_t *relu_mask, float *rstd, void *stream);
-/* the same two layers FROM the x0n ATL(32) image of harl_mlp_x0n_wide (identity row order; the image is built once per
- * buffer): no gather, no input-LayerNorm work per call */
+/* the same two layers FROM the x0n ATL(32 | 64) image of harl_mlp_x0n_wide (D <= 64; identity row order; the image is
+ * built once per buffer): no gather, no input-LayerNorm work per call */
 int harl_mlp_fwd_fused2x(const float *x0n, long M, const float *W1p, int D, const float *b1p, const float *W2p,
                          const float *b2p, int H, int store1, float *x1out, uint32_t *mask1, float *rstd1, float *x2out,
                          uint32_t *mask2, float *rstd2, void *stream);

@@ -18,6 +18,21 @@ KEEP_ALGO = ("ppo_epoch", "a2c_epoch", "critic_epoch", "actor_num_mini_batch", "
 KEEP_TRAIN = ("n_rollout_threads", "episode_length", "use_valuenorm", "use_proper_time_limits")
 
 
+def n_actions(env: str, env_args: dict):
+    """Size of the action head where it follows from the configuration alone (None = small / environment defined)."""
+    if env == "smac":  # 6 + n_enemies (StarCraft2_Env.py:275-277), from the reference's map registry
+        import re
+        src = open(os.path.join(REF, "harl", "envs", "smac", "smac_maps.py")).read()
+        m = re.search(r'"%s":\s*\{\s*"n_agents":\s*\d+,\s*"n_enemies":\s*(\d+)' % re.escape(env_args["map_name"]), src)
+        return 6 + int(m.group(1)) if m else None
+    if env == "smacv2":  # <race>_<n>_vs_<m>: 6 + m
+        name = env_args.get("map_name", "")
+        return 6 + int(name.rsplit("_vs_", 1)[1]) if "_vs_" in name else None
+    if env == "football":
+        return 19  # gfootball default action set
+    return None
+
+
 def main():
     recs = []
     for p in sorted(glob.glob(os.path.join(REF, "tuned_configs", "**", "config.json"), recursive=True)):
@@ -27,7 +42,7 @@ def main():
             continue
         aa = c["algo_args"]
         recs.append(dict(path=os.path.relpath(p, os.path.join(REF, "tuned_configs")), algo=algo, env=c["main_args"]["env"],
-                         state_type=c["env_args"].get("state_type", "EP"),
+                         state_type=c["env_args"].get("state_type", "EP"), n_actions=n_actions(c["main_args"]["env"], c["env_args"]),
                          model={k: aa["model"][k] for k in KEEP_MODEL if k in aa["model"]},
                          algo_args={k: aa["algo"][k] for k in KEEP_ALGO if k in aa["algo"]},
                          train={k: aa["train"][k] for k in KEEP_TRAIN if k in aa["train"]}))

@@ -9,6 +9,7 @@ in the same order; only the resulting int64 index arrays are uploaded.
 """
 from __future__ import annotations
 
+import os
 import queue
 import threading
 from typing import Iterator, List, Optional, Tuple
@@ -63,6 +64,48 @@ def _advance_matches_randperm() -> bool:
     return _ADVANCE_OK
 
 
+_SKIP_OK: Optional[bool] = None
+
+
+def _skip_matches_random() -> bool:
+    """One-time self-check (global RNG state saved/restored): does libharl_hip.so::harl_rng_advance leave the generator
+    exactly where ``Tensor.random_`` over as many int32 elements does (mid-block start, several block refills)?"""
+    global _SKIP_OK
+    if _SKIP_OK is None:
+        st = torch.get_rng_state()
+        try:
+            ok = True
+            lib = _lib.load()
+            for seed, n in ((987654321, 1030), (5, 70000)):
+                torch.manual_seed(seed)
+                torch.randperm(17)
+                mid = torch.get_rng_state()
+                torch.empty(n, dtype=torch.int32).random_()
+                want = torch.get_rng_state()
+                out = torch.empty_like(mid)
+                rc = lib.harl_rng_advance(mid.data_ptr(), mid.numel(), n, out.data_ptr())
+                ok = ok and rc == 0 and bool(torch.equal(out, want))
+            _SKIP_OK = ok
+        except Exception:  # noqa: BLE001 -- library without the entry point / another state layout: use Tensor.random_
+            _SKIP_OK = False
+        finally:
+            torch.set_rng_state(st)
+    return _SKIP_OK
+
+
+def _advance_generator(n: int) -> None:
+    """Advance the global CPU generator by n 32-bit draws.  The C skip-ahead only refreshes the mt19937 state blocks
+    (~0.3 ms per 819200 draws); ``Tensor.random_`` tempers and stores every output (~1 ms) -- with 20 advances per train()
+    on the replay thread that was within a few ms of the whole update's GPU time, i.e. the thing train() ended up waiting for."""
+    if os.environ.get("HARL_RNG_SKIP", "1") != "0" and _skip_matches_random():
+        st = torch.get_rng_state()
+        out = torch.empty_like(st)
+        if _lib.load().harl_rng_advance(st.data_ptr(), st.numel(), n, out.data_ptr()) == 0:
+            torch.set_rng_state(out)
+            return
+    torch.empty(n, dtype=torch.int32).random_()
+
+
 class _RngWorker:
     """FIFO background replay of generator advances.  ``Tensor.random_`` releases the GIL, so the ~0.6 ms per
     819200-draw advance overlaps with the kernel launches of the update it belongs to instead of stalling the GPU
@@ -78,7 +121,7 @@ class _RngWorker:
         while True:
             n = self._q.get()
             try:
-                torch.empty(n, dtype=torch.int32).random_()
+                _advance_generator(n)
             finally:
                 self._q.task_done()
 
@@ -114,7 +157,7 @@ def consume_randperm(batch_size: int, deferred: bool = True) -> None:
         return
     if not deferred or batch_size < 65536:
         rng_sync()
-        torch.empty(batch_size - 1, dtype=torch.int32).random_()
+        _advance_generator(batch_size - 1)
         return
     if _RNG_WORKER is None:
         _RNG_WORKER = _RngWorker()

@@ -80,6 +80,52 @@ struct Mt {
 __attribute__((target("avx2"))) void draws_and_targets_avx2(Mt &g, uint32_t *k, long n, long nd) { HARL_DRAWS_BODY }
 void draws_and_targets_base(Mt &g, uint32_t *k, long n, long nd) { HARL_DRAWS_BODY }
 #undef HARL_DRAWS_BODY
+
+// discard nd draws: only the state refreshes remain (the outputs are never tempered)
+#define HARL_SKIP_BODY                 \
+  while (nd > 0) {                     \
+    if (g.left <= 1) {                 \
+      g.next_state();                  \
+      g.left = MT_N + 1;               \
+    }                                  \
+    const long avail = g.left - 1, take = nd < avail ? nd : avail; \
+    g.left -= (int)take;               \
+    g.next += (int)take;               \
+    nd -= take;                        \
+  }
+__attribute__((target("avx2"))) void skip_avx2(Mt &g, long nd) { HARL_SKIP_BODY }
+void skip_base(Mt &g, long nd) { HARL_SKIP_BODY }
+#undef HARL_SKIP_BODY
+
+bool load_state(Mt &g, const uint8_t *state_in, long state_bytes) {
+  if (state_bytes < 24 + 8 * MT_N) return false;
+  int32_t left, seeded;
+  uint64_t next;
+  std::memcpy(&left, state_in + 8, 4);
+  std::memcpy(&seeded, state_in + 12, 4);
+  std::memcpy(&next, state_in + 16, 8);
+  if (!seeded || left < 0 || left > MT_N || next > (uint64_t)MT_N) return false;
+  for (int i = 0; i < MT_N; ++i) {
+    uint64_t v;
+    std::memcpy(&v, state_in + 24 + 8 * i, 8);
+    g.s[i] = (uint32_t)v;
+  }
+  g.left = left;
+  g.next = (int)next;
+  return true;
+}
+
+void store_state(const Mt &g, const uint8_t *state_in, long state_bytes, uint8_t *state_out) {
+  if (state_out != state_in) std::memcpy(state_out, state_in, (size_t)state_bytes);
+  const int32_t left = g.left;
+  const uint64_t next = (uint64_t)g.next;
+  std::memcpy(state_out + 8, &left, 4);
+  std::memcpy(state_out + 16, &next, 8);
+  for (int i = 0; i < MT_N; ++i) {
+    const uint64_t v = g.s[i];
+    std::memcpy(state_out + 24 + 8 * i, &v, 8);
+  }
+}
 }  // namespace
 
 // state_in/state_out: the bytes of torch.get_rng_state() (CPUGeneratorImplState: uint64 seed; int left; int seeded;
@@ -127,5 +173,16 @@ extern "C" int harl_randperm_replay(const uint8_t *state_in, long state_bytes, l
       std::memcpy(state_out + 24 + 8 * i, &v, 8);
     }
   }
+  return 0;
+}
+
+// state_out = state_in advanced by n_draws 32-bit draws (what torch.randperm(n_draws + 1) consumes when the permutation
+// itself is not needed): ~0.3 ms per 819200 draws instead of ~1 ms for Tensor.random_ on the same generator.
+extern "C" int harl_rng_advance(const uint8_t *state_in, long state_bytes, long n_draws, uint8_t *state_out) {
+  Mt g;
+  if (n_draws < 0 || !state_out || !load_state(g, state_in, state_bytes)) return -2;
+  if (__builtin_cpu_supports("avx2")) skip_avx2(g, n_draws);
+  else skip_base(g, n_draws);
+  store_state(g, state_in, state_bytes, state_out);
   return 0;
 }

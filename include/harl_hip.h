@@ -316,6 +316,9 @@ int harl_reduce_scalars(const float *part_scalars, int n_blocks, double *scalars
  * Replaces the draw in on_policy_actor_buffer.py:131 / on_policy_critic_buffer_ep.py:223 bit for bit. */
 int harl_randperm_replay(const uint8_t *state_in, long state_bytes, long n, int32_t *out, uint32_t *scratch,
                          uint8_t *state_out);
+/* state_out = state_in advanced by n_draws 32-bit draws (host code; the generator advance of torch.randperm(n_draws + 1)
+ * without materialising the permutation).  Returns 0 or -2 on an unexpected state layout. */
+int harl_rng_advance(const uint8_t *state_in, long state_bytes, long n_draws, uint8_t *state_out);
 
 #ifdef __cplusplus
 }

@@ -129,3 +129,30 @@ def test_policy_init_rng_replay_matches_real_construction():
         torch.manual_seed(5)
         consume_policy_init_rng(dict(initialization_method="orthogonal_", hidden_sizes=hs, gain=0.01), Box((d,)), Box((n,)))
         assert bool((a == torch.get_rng_state()).all())
+
+
+def test_rng_advance_matches_tensor_random():
+    """harl_rng_advance (mt19937 skip-ahead, host code) leaves the CPU generator exactly where Tensor.random_ over as many
+    int32 elements does; consume_randperm (deferred replay thread) equals torch.randperm's generator advance."""
+    import torch
+    from harl_amd import _lib, buffers as B
+
+    lib = _lib.load()
+    for seed, n in ((1, 1), (2, 623), (3, 624), (4, 625), (5, 70000), (6, 819199)):
+        torch.manual_seed(seed)
+        torch.randperm(11)
+        mid = torch.get_rng_state()
+        torch.empty(n, dtype=torch.int32).random_()
+        want = torch.get_rng_state()
+        out = torch.empty_like(mid)
+        assert lib.harl_rng_advance(mid.data_ptr(), mid.numel(), n, out.data_ptr()) == 0
+        assert bool(torch.equal(out, want)), (seed, n)
+    torch.manual_seed(9)
+    for _ in range(3):
+        torch.randperm(819200)
+    a = torch.randperm(9)
+    torch.manual_seed(9)
+    for _ in range(3):
+        B.consume_randperm(819200)
+    B.rng_sync()
+    assert bool(torch.equal(a, torch.randperm(9)))

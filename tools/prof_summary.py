@@ -49,8 +49,11 @@ def main():
 def gaps(path, last_ms=None):
     """GPU idle analysis of the kernel timeline: busy time vs span, idle time attributed to the kernel that FOLLOWS
     each gap (= the launch the host was late for)."""
-    db = sqlite3.connect(path)
-    ks = sorted(db.cursor().execute("select start, end, name from kernels").fetchall())
+    if path.endswith(".db"):
+        db = sqlite3.connect(path)
+        ks = sorted(db.cursor().execute("select start, end, name from kernels").fetchall())
+    else:
+        ks = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(path)))
     if last_ms is not None:  # only the tail of the run (the timed region)
         t1 = ks[-1][1]
         ks = [k for k in ks if k[0] >= t1 - last_ms * 1e6]
@@ -74,5 +77,5 @@ def gaps(path, last_ms=None):
 
 if __name__ == "__main__":
     main()
-    if sys.argv[1].endswith(".db") and len(sys.argv) > 2 and sys.argv[2] == "--gaps":
+    if len(sys.argv) > 2 and sys.argv[2] == "--gaps":
         gaps(sys.argv[1], float(sys.argv[3]) if len(sys.argv) > 3 else None)

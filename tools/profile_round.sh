@@ -4,7 +4,7 @@ R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 python $R/bench.py > $R/gpurun_out/bench_r01.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python $R/bench.py --steps 3 --warmup 1 --cpu-cols 0 --instr-steps 0 > /dev/null 2>&1
-python $R/tools/prof_summary.py $(ls /tmp/kt/*/*kernel_trace.csv | head -1) --gaps > $R/gpurun_out/kt_summary.md 2>&1
+python $R/tools/prof_summary.py $(ls /tmp/kt/*/*kernel_trace.csv | head -1) --gaps 60 > $R/gpurun_out/kt_summary.md 2>&1
 python $R/tools/kbench.py --reps 20 > $R/gpurun_out/kb_r01.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pf -- python $R/tools/kbench.py --reps 3 > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pw -- python $R/tools/kbench.py --reps 3 > /dev/null 2>&1

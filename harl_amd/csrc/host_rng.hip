@@ -9,6 +9,7 @@
 // (harl_amd/buffers.py), so the RNG stream of the run is unchanged.  tests/test_cabi.py checks the permutations against
 // torch.randperm for many (seed, n).
 #include <cstdint>
+#include <immintrin.h>
 #include <cstring>
 #include <vector>
 
@@ -41,6 +42,33 @@ struct Mt {
     return y;
   }
 };
+// at::mt19937::next_state with 8 words per step (unaligned loads; the recurrence reaches back 227 / forward 397 words, so
+// 8-wide blocks never read a word written in the same block).  hipcc's host compiler does not vectorise the scalar loops.
+__attribute__((target("avx2"))) inline __m256i twist8(const uint32_t *pu, const uint32_t *pv, const uint32_t *pm) {
+  const __m256i upper = _mm256_set1_epi32((int)0x80000000u), lower = _mm256_set1_epi32(0x7fffffff),
+                matrix = _mm256_set1_epi32((int)0x9908b0dfu), one = _mm256_set1_epi32(1);
+  const __m256i u = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(pu));
+  const __m256i v = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(pv));
+  const __m256i m = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(pm));
+  const __m256i y = _mm256_or_si256(_mm256_and_si256(u, upper), _mm256_and_si256(v, lower));
+  const __m256i odd = _mm256_cmpeq_epi32(_mm256_and_si256(v, one), one);  // (v & 1) ? matrix : 0
+  return _mm256_xor_si256(_mm256_xor_si256(m, _mm256_srli_epi32(y, 1)), _mm256_and_si256(odd, matrix));
+}
+
+__attribute__((target("avx2"))) void next_state_avx2(Mt &g) {
+  uint32_t *s = g.s;
+  int i = 0;
+  for (; i + 8 <= MT_N - MT_M; i += 8)  // words 0 .. 226: partner s[i + 397]
+    _mm256_storeu_si256(reinterpret_cast<__m256i *>(s + i), twist8(s + i, s + i + 1, s + i + MT_M));
+  for (; i < MT_N - MT_M; ++i) s[i] = s[i + MT_M] ^ Mt::tw(s[i], s[i + 1]);
+  for (; i + 8 <= MT_N - 1; i += 8)     // words 227 .. 622: partner s[i - 227] (already refreshed)
+    _mm256_storeu_si256(reinterpret_cast<__m256i *>(s + i), twist8(s + i, s + i + 1, s + i + MT_M - MT_N));
+  for (; i < MT_N - 1; ++i) s[i] = s[i + MT_M - MT_N] ^ Mt::tw(s[i], s[i + 1]);
+  s[MT_N - 1] = s[MT_M - 1] ^ Mt::tw(s[MT_N - 1], s[0]);
+  g.left = MT_N;
+  g.next = 0;
+}
+
 // k[i] = i + random() % (n - i) for i < nd, in two vectorisable passes:
 //  1. the tempered mt19937 outputs in bulk, one 624-word state block at a time (the per-draw form -- refresh test, load,
 //     temper, store -- runs at ~3 ns per draw; the block form at ~0.5 ns, and the refresh loops vectorise too);
@@ -51,7 +79,7 @@ struct Mt {
   long i = 0;                                                                                                  \
   while (i < nd) {                                                                                             \
     if (g.left <= 1) { /* operator(): --left == 0 -> next_state() */                                           \
-      g.next_state();                                                                                          \
+      HARL_REFRESH(g);                                                                                         \
       g.left = MT_N + 1;                                                                                       \
     }                                                                                                          \
     const long avail = g.left - 1, take = nd - i < avail ? nd - i : avail;                                     \
@@ -77,15 +105,19 @@ struct Mt {
     k[e] = (uint32_t)e + rem;                                                                                  \
   }
 
+#define HARL_REFRESH(g) next_state_avx2(g)
 __attribute__((target("avx2"))) void draws_and_targets_avx2(Mt &g, uint32_t *k, long n, long nd) { HARL_DRAWS_BODY }
+#undef HARL_REFRESH
+#define HARL_REFRESH(g) (g).next_state()
 void draws_and_targets_base(Mt &g, uint32_t *k, long n, long nd) { HARL_DRAWS_BODY }
+#undef HARL_REFRESH
 #undef HARL_DRAWS_BODY
 
 // discard nd draws: only the state refreshes remain (the outputs are never tempered)
 #define HARL_SKIP_BODY                 \
   while (nd > 0) {                     \
     if (g.left <= 1) {                 \
-      g.next_state();                  \
+      HARL_REFRESH(g);                 \
       g.left = MT_N + 1;               \
     }                                  \
     const long avail = g.left - 1, take = nd < avail ? nd : avail; \
@@ -93,8 +125,12 @@ void draws_and_targets_base(Mt &g, uint32_t *k, long n, long nd) { HARL_DRAWS_BO
     g.next += (int)take;               \
     nd -= take;                        \
   }
+#define HARL_REFRESH(g) next_state_avx2(g)
 __attribute__((target("avx2"))) void skip_avx2(Mt &g, long nd) { HARL_SKIP_BODY }
+#undef HARL_REFRESH
+#define HARL_REFRESH(g) (g).next_state()
 void skip_base(Mt &g, long nd) { HARL_SKIP_BODY }
+#undef HARL_REFRESH
 #undef HARL_SKIP_BODY
 
 bool load_state(Mt &g, const uint8_t *state_in, long state_bytes) {

@@ -9,6 +9,7 @@
 // (harl_amd/buffers.py), so the RNG stream of the run is unchanged.  tests/test_cabi.py checks the permutations against
 // torch.randperm for many (seed, n).
 #include <cstdint>
+#include <cstdlib>
 #include <immintrin.h>
 #include <cstring>
 #include <vector>
@@ -69,6 +70,38 @@ __attribute__((target("avx2"))) void next_state_avx2(Mt &g) {
   g.next = 0;
 }
 
+__attribute__((target("avx512f"))) inline __m512i twist16(const uint32_t *pu, const uint32_t *pv, const uint32_t *pm) {
+  const __m512i upper = _mm512_set1_epi32((int)0x80000000u), lower = _mm512_set1_epi32(0x7fffffff),
+                matrix = _mm512_set1_epi32((int)0x9908b0dfu), one = _mm512_set1_epi32(1);
+  const __m512i u = _mm512_loadu_si512(pu), v = _mm512_loadu_si512(pv), m = _mm512_loadu_si512(pm);
+  const __m512i y = _mm512_or_si512(_mm512_and_si512(u, upper), _mm512_and_si512(v, lower));
+  const __mmask16 odd = _mm512_test_epi32_mask(v, one);
+  const __m512i r = _mm512_xor_si512(m, _mm512_srli_epi32(y, 1));
+  return _mm512_mask_xor_epi32(r, odd, r, matrix);
+}
+
+__attribute__((target("avx512f"))) void next_state_avx512(Mt &g) {
+  uint32_t *s = g.s;
+  int i = 0;
+  for (; i + 16 <= MT_N - MT_M; i += 16) _mm512_storeu_si512(s + i, twist16(s + i, s + i + 1, s + i + MT_M));
+  for (; i < MT_N - MT_M; ++i) s[i] = s[i + MT_M] ^ Mt::tw(s[i], s[i + 1]);
+  for (; i + 16 <= MT_N - 1; i += 16) _mm512_storeu_si512(s + i, twist16(s + i, s + i + 1, s + i + MT_M - MT_N));
+  for (; i < MT_N - 1; ++i) s[i] = s[i + MT_M - MT_N] ^ Mt::tw(s[i], s[i + 1]);
+  s[MT_N - 1] = s[MT_M - 1] ^ Mt::tw(s[MT_N - 1], s[0]);
+  g.left = MT_N;
+  g.next = 0;
+}
+
+// instruction set of the host loops: 2 = AVX-512, 1 = AVX2, 0 = baseline; HARL_RNG_ISA=avx2|base caps it (tests)
+int rng_isa() {
+  int isa = __builtin_cpu_supports("avx512f") ? 2 : (__builtin_cpu_supports("avx2") ? 1 : 0);
+  if (const char *e = std::getenv("HARL_RNG_ISA")) {
+    if (!std::strcmp(e, "base")) isa = 0;
+    else if (!std::strcmp(e, "avx2") && isa > 1) isa = 1;
+  }
+  return isa;
+}
+
 // k[i] = i + random() % (n - i) for i < nd, in two vectorisable passes:
 //  1. the tempered mt19937 outputs in bulk, one 624-word state block at a time (the per-draw form -- refresh test, load,
 //     temper, store -- runs at ~3 ns per draw; the block form at ~0.5 ns, and the refresh loops vectorise too);
@@ -105,6 +138,9 @@ __attribute__((target("avx2"))) void next_state_avx2(Mt &g) {
     k[e] = (uint32_t)e + rem;                                                                                  \
   }
 
+#define HARL_REFRESH(g) next_state_avx512(g)
+__attribute__((target("avx512f,avx2"))) void draws_and_targets_avx512(Mt &g, uint32_t *k, long n, long nd) { HARL_DRAWS_BODY }
+#undef HARL_REFRESH
 #define HARL_REFRESH(g) next_state_avx2(g)
 __attribute__((target("avx2"))) void draws_and_targets_avx2(Mt &g, uint32_t *k, long n, long nd) { HARL_DRAWS_BODY }
 #undef HARL_REFRESH
@@ -125,6 +161,9 @@ void draws_and_targets_base(Mt &g, uint32_t *k, long n, long nd) { HARL_DRAWS_BO
     g.next += (int)take;               \
     nd -= take;                        \
   }
+#define HARL_REFRESH(g) next_state_avx512(g)
+__attribute__((target("avx512f,avx2"))) void skip_avx512(Mt &g, long nd) { HARL_SKIP_BODY }
+#undef HARL_REFRESH
 #define HARL_REFRESH(g) next_state_avx2(g)
 __attribute__((target("avx2"))) void skip_avx2(Mt &g, long nd) { HARL_SKIP_BODY }
 #undef HARL_REFRESH
@@ -188,7 +227,9 @@ extern "C" int harl_randperm_replay(const uint8_t *state_in, long state_bytes, l
   uint32_t *r = reinterpret_cast<uint32_t *>(out), *k = scratch;
   for (long i = 0; i < n; ++i) r[i] = (uint32_t)i;
   const long nd = n > 0 ? n - 1 : 0;
-  if (__builtin_cpu_supports("avx2")) draws_and_targets_avx2(g, k, n, nd);
+  const int isa = rng_isa();
+  if (isa == 2) draws_and_targets_avx512(g, k, n, nd);
+  else if (isa == 1) draws_and_targets_avx2(g, k, n, nd);
   else draws_and_targets_base(g, k, n, nd);
   constexpr long PF = 24;  // the swap partner is a random element of a 3 MB array: prefetch it a few iterations ahead
   for (long i = 0; i < nd; ++i) {
@@ -217,7 +258,9 @@ extern "C" int harl_randperm_replay(const uint8_t *state_in, long state_bytes, l
 extern "C" int harl_rng_advance(const uint8_t *state_in, long state_bytes, long n_draws, uint8_t *state_out) {
   Mt g;
   if (n_draws < 0 || !state_out || !load_state(g, state_in, state_bytes)) return -2;
-  if (__builtin_cpu_supports("avx2")) skip_avx2(g, n_draws);
+  const int isa = rng_isa();
+  if (isa == 2) skip_avx512(g, n_draws);
+  else if (isa == 1) skip_avx2(g, n_draws);
   else skip_base(g, n_draws);
   store_state(g, state_in, state_bytes, state_out);
   return 0;

@@ -156,3 +156,28 @@ def test_rng_advance_matches_tensor_random():
         B.consume_randperm(819200)
     B.rng_sync()
     assert bool(torch.equal(a, torch.randperm(9)))
+
+
+def test_host_rng_instruction_set_paths_agree(monkeypatch):
+    """The AVX-512 / AVX2 / baseline variants of the mt19937 host loops (HARL_RNG_ISA caps the dispatch) give the same
+    permutation and generator state as torch for a block-crossing size."""
+    import torch
+    from harl_amd import _lib
+
+    lib = _lib.load()
+    n = 70001
+    torch.manual_seed(21)
+    torch.empty(33, dtype=torch.int32).random_()
+    mid = torch.get_rng_state()
+    want_perm = torch.randperm(n)
+    want_state = torch.get_rng_state()
+    for isa in ("", "avx2", "base"):
+        monkeypatch.setenv("HARL_RNG_ISA", isa)
+        out = torch.empty(n, dtype=torch.int32)
+        scratch = torch.empty(n, dtype=torch.int32)
+        st = torch.empty_like(mid)
+        assert lib.harl_randperm_replay(mid.data_ptr(), mid.numel(), n, out.data_ptr(), scratch.data_ptr(), st.data_ptr()) == 0
+        assert bool(torch.equal(out.long(), want_perm)) and bool(torch.equal(st, want_state)), isa
+        st2 = torch.empty_like(mid)
+        assert lib.harl_rng_advance(mid.data_ptr(), mid.numel(), n - 1, st2.data_ptr()) == 0
+        assert bool(torch.equal(st2, want_state)), isa

@@ -459,15 +459,24 @@ extern "C" int harl_reduce_scalars(const float *part_scalars, int n_blocks, doub
   return check_launch("harl_reduce_scalars");
 }
 
-// fp64 loss scalars -> fp32 head + fp32 residual, written behind the folded gradients so that ONE fp32 SUM all-reduce
-// carries gradients and scalars (~48 bits for the latter)
+// fp64 loss scalars -> FOUR fp32 pieces on a fixed exponent grid (quanta 2^24, 2^4, 2^-16, 2^-36; every piece is an
+// integer multiple n * q_k with |n| < 2^20), written behind the folded gradients so that ONE fp32 SUM all-reduce carries
+// gradients and scalars.  Because the grid does not depend on the rank's values, the fp32 sum of each piece over up to 16
+// ranks is EXACT (|sum n| < 2^24), so the reduced scalars equal the fp64 sum of the ranks' scalars up to 2^-36 absolute
+// per rank -- not merely a per-rank hi/lo pair, whose cross-rank fp32 rounding would be lost.  (|v| >= 2^44 degrades
+// gracefully to fp32 accuracy in the first piece.)
+constexpr int HILO_PIECES = 4;
+__device__ __constant__ double HILO_Q[HILO_PIECES] = {16777216.0, 16.0, 1.0 / 65536.0, 1.0 / 68719476736.0};
 __global__ void k_pack_scalars_hilo(const double *__restrict__ scalars, float *__restrict__ hilo) {
   const int t = threadIdx.x;
   if (t < PS_STRIDE) {
-    const double v = scalars[t];
-    const float hi = (float)v;
-    hilo[t] = hi;
-    hilo[PS_STRIDE + t] = (float)(v - (double)hi);
+    double r = scalars[t];
+#pragma unroll
+    for (int k = 0; k < HILO_PIECES; ++k) {
+      const double p = trunc(r / HILO_Q[k]) * HILO_Q[k];
+      hilo[k * PS_STRIDE + t] = (float)p;
+      r -= p;
+    }
   }
 }
 
@@ -645,8 +654,9 @@ __global__ __launch_bounds__(ADAM_THREADS) void k_adam_fold(
       }
       t = (u0 + u1) + (u2 + u3);
       if (blk == 0) scalars[tid] = t;
-    } else if (scalars_hilo) {  // all-reduced fp32 head + residual (harl_pack_scalars_hilo)
-      t = (double)scalars_hilo[tid] + (double)scalars_hilo[PS_STRIDE + tid];
+    } else if (scalars_hilo) {  // all-reduced fixed-grid fp32 pieces (harl_pack_scalars_hilo), smallest first
+      t = (((double)scalars_hilo[3 * PS_STRIDE + tid] + (double)scalars_hilo[2 * PS_STRIDE + tid]) +
+           (double)scalars_hilo[PS_STRIDE + tid]) + (double)scalars_hilo[tid];
       if (blk == 0) scalars[tid] = t;
     } else {
       t = scalars[tid];

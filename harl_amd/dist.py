@@ -39,22 +39,36 @@ class Comm:
         return t
 
     def all_reduce_message(self, msg: torch.Tensor) -> None:
-        """One collective per optimiser step over the contiguous fp32 message [folded gradients | hi(scalars) |
-        lo(scalars)] (nets.dwp_msg): the gradients are produced in place at its head, the fp64 loss scalars are split by
-        harl_pack_scalars_hilo into an fp32 head + residual (~48 bits through a single fp32 SUM), and harl_adam_fold reads
-        both straight from the reduced message -- no staging copies around the collective."""
+        """One collective per optimiser step over the contiguous fp32 message [folded gradients | 4 x scalar pieces]
+        (nets.dwp_msg): the gradients are produced in place at its head, the fp64 loss scalars are split by
+        harl_pack_scalars_hilo into four fp32 pieces on a FIXED exponent grid (each an integer multiple of its quantum
+        below 2^20, so the fp32 SUM over <= 16 ranks is exact: the reduced value is the fp64 sum of the ranks' scalars to
+        2^-36 absolute), and harl_adam_fold reads both straight from the reduced message -- no staging copies around the
+        collective."""
         if self.enabled:
             self._all_reduce(msg)
 
 
+SCALAR_QUANTA = (2.0 ** 24, 2.0 ** 4, 2.0 ** -16, 2.0 ** -36)
+
+
 def pack_message_reference(flat_grad: torch.Tensor, scalars64: torch.Tensor) -> torch.Tensor:
-    """Host restatement of the message format (used by the CPU tests): [grad | (float)s | (float)(s - hi)]."""
-    hi = scalars64.to(torch.float32)
-    return torch.cat([flat_grad.to(torch.float32), hi, (scalars64 - hi.to(torch.float64)).to(torch.float32)])
+    """Host restatement of the message format (used by the CPU tests): [grad | piece_0 | .. | piece_3] with
+    piece_k = trunc(r_k / q_k) * q_k, r_0 = s, r_{k+1} = r_k - piece_k  (k_pack_scalars_hilo, csrc/elementwise.hip)."""
+    r = scalars64.to(torch.float64).clone()
+    pieces = []
+    for q in SCALAR_QUANTA:
+        p = torch.trunc(r / q) * q
+        pieces.append(p.to(torch.float32))
+        r = r - p
+    return torch.cat([flat_grad.to(torch.float32)] + pieces)
 
 
 def unpack_message_reference(msg: torch.Tensor, n: int, k: int):
-    return msg[:n], msg[n:n + k].to(torch.float64) + msg[n + k:n + 2 * k].to(torch.float64)
+    s = torch.zeros(k, dtype=torch.float64)
+    for i in reversed(range(len(SCALAR_QUANTA))):  # smallest first
+        s = s + msg[n + i * k:n + (i + 1) * k].to(torch.float64)
+    return msg[:n], s
 
 
 def shard_columns(n_rollout_threads: int, rank: int, world_size: int) -> Tuple[int, int]:

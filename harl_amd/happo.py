@@ -266,6 +266,8 @@ class HAPPO(OnPolicyBase):
         buf = actor_buffer
         T, N = buf.actions.shape[:2]
         B = T * N
+        if _pre is None:  # called directly (the runner invalidates once, before its own pre-update log-prob pass)
+            self.actor.invalidate_caches()
         train_info = {k: 0.0 for k in self._INFO_KEYS}
         adv = _as_dev(advantages, dev).reshape(B).contiguous()
         active = buf.flat("active_masks").reshape(B)

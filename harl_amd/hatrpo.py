@@ -270,6 +270,7 @@ class HATRPO(OnPolicyBase):
         T, N = buf.actions.shape[:2]
         B = T * N
         info = {"kl": 0.0, "dist_entropy": 0.0, "loss_improve": 0.0, "expected_improve": 0.0, "ratio": 0.0}
+        self.actor.invalidate_caches()
         adv = _as_dev(advantages, dev).reshape(B).contiguous()
         active = buf.flat("active_masks").reshape(B)
         moments = torch.zeros(3, dtype=torch.float64, device=dev)

@@ -34,6 +34,7 @@ class MAPPO(HAPPO):
         if self.use_recurrent_policy or self.use_naive_recurrent_policy:
             raise NotImplementedError("share_param with recurrent policies")
         dev, net = self.device, self.actor
+        net.invalidate_caches()
         A = num_agents
         T, N = actor_buffer[0].actions.shape[:2]
         B = T * N

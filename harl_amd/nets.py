@@ -201,8 +201,8 @@ class _FlatNet(nn.Module):
         self._table_rows = rows
         self.n_entries = len(rows)
         self.pack_arena = torch.empty(pack_off, dtype=torch.float32, device=dev)
-        # the dense folded gradients live at the head of the data-parallel all-reduce message: [dwp | hi | lo] (dist.py)
-        self.dwp_msg = torch.zeros(dwp_off + 2 * PS_STRIDE, dtype=torch.float32, device=dev)
+        # the dense folded gradients live at the head of the data-parallel all-reduce message: [dwp | 4 fixed-grid scalar pieces] (dist.py)
+        self.dwp_msg = torch.zeros(dwp_off + 4 * PS_STRIDE, dtype=torch.float32, device=dev)
         self.dwp = self.dwp_msg[:dwp_off]
         self.total_dwp = dwp_off
         self._pack_slots = pack_slots
@@ -299,6 +299,15 @@ class _FlatNet(nn.Module):
             call("harl_mlp_x0n_wide", ptr(X), X.shape[1], ptr(idx), M, self.in_dim, int(self.use_feature_normalization),
                  ptr(self.x0n), ptr(self.mu0), ptr(self.rstd0), s, tag="x0n_wide")
             self._x0n_key, self._x0n_src = key, (X if key is not None else None)
+
+    def invalidate_caches(self) -> None:
+        """Drop the cached normalised-input image.  The cache key is (data_ptr, torch version counter, shape, rows): it
+        sees in-place torch writes but NOT writes through ``.data``, DLPack / NumPy-shared memory or raw-pointer kernels.
+        Contract: every ``train()`` entry point (runner, HAPPO/HATRPO/MAPPO, VCritic) calls this first, so an image never
+        outlives the update it was built for; callers that overwrite observations behind torch's back inside one update
+        (between log-prob passes over the same tensor) must call it themselves."""
+        self._x0n_key = None
+        self._x0n_src = None
 
     def forward_trunk(self, X: torch.Tensor, idx: Optional[torch.Tensor], M: int, for_backward: bool = True,
                       seq: Optional[dict] = None) -> None:
@@ -591,7 +600,7 @@ class FusedAdam:
              n_scalar_blocks: int = 0, scalars_hilo: Optional[torch.Tensor] = None) -> None:
         """One fused launch: loss scalars -> scale/statistics, unfold, ||g||, clip, Adam, re-fold (harl_adam_fold).
         ``part_scalars``: the loss kernel's per-block partial sums, reduced inside the launch into ``net.scalars``
-        (single-GPU path); ``scalars_hilo``: the all-reduced fp32 (hi, lo) pair behind the gradients in ``net.dwp_msg``
+        (single-GPU path); ``scalars_hilo``: the all-reduced fixed-grid fp32 pieces behind the gradients in ``net.dwp_msg``
         (data-parallel path); neither = ``net.scalars`` already holds the sums."""
         g = self.param_groups[0]
         self.step_count += 1

@@ -107,6 +107,8 @@ class OnPolicyHARunner:
         B = T * N
         dev = self.device
         actor_train_infos = []
+        for x in self.actor:  # cached normalised-input images never outlive one update (nets.invalidate_caches)
+            x.actor.invalidate_caches()
         factor = torch.ones(T, N, 1, dtype=torch.float32, device=dev)
         advantages = self.critic_buffer.advantages  # returns[:-1] - denormalize(value_preds[:-1]), fused into the GAE scan
         if self.state_type == "FP":
@@ -360,6 +362,8 @@ class OnPolicyMARunner(OnPolicyHARunner):
     def train(self):
         dev = self.device
         A = self.num_agents
+        for x in self.actor:
+            x.actor.invalidate_caches()
         advantages = self.critic_buffer.advantages
         if self.state_type == "FP":
             advantages = self._fp_normalised_advantages(advantages)

@@ -146,6 +146,7 @@ class VCritic:
         B = T * N * (A or 1)
         dev = self.device
         self._info.zero_()
+        self.critic.invalidate_caches()
         self.critic.fold()
         share_obs = buf.flat("share_obs")
         value_preds = buf.flat("value_preds").reshape(B)

@@ -162,8 +162,9 @@ int harl_reduce_partials(const float *part, int n_wg, long elems, float *out, vo
 /* dwp[dwp_off_l + e] = sum_w part[part_off_l + w*elems_l + e] for all layers in ONE launch (fixed order, deterministic) */
 int harl_reduce_partials_multi(const float *part, const int *table, int n_layers, int n_wg, long total_elems,
                                float *dwp, void *stream);
-/* hilo[0..PS) = (float)scalars, hilo[PS..2PS) = (float)(scalars - hi): the loss scalars ride behind the folded gradients
- * in the single fp32 SUM all-reduce of the data-parallel path. */
+/* hilo[k*PS + t], k = 0..3: the fp64 scalar t split into four fp32 pieces on a fixed exponent grid (quanta 2^24, 2^4,
+ * 2^-16, 2^-36, each piece an integer multiple of its quantum below 2^20): the loss scalars ride behind the folded
+ * gradients in the single fp32 SUM all-reduce of the data-parallel path and every piece sums EXACTLY over <= 16 ranks. */
 int harl_pack_scalars_hilo(const double *scalars, float *hilo, void *stream);
 /* Fused optimiser epilogue (64 co-resident workgroups, software grid barrier between phases): loss scalars ->
  * gradient scale + statistics (info), unfold the folded gradients of every table entry into `grad` (reference parameter
@@ -171,8 +172,8 @@ int harl_pack_scalars_hilo(const double *scalars, float *hilo, void *stream);
  * `packs`.  mode 0 (actor): scale = 1/scalars[1] (sum active), info += {loss, entropy, grad_norm, ratio};
  * mode 1 (critic): scale = const_scale (= value_loss_coef / m), info += {value_loss, grad_norm}.
  * part_scalars != NULL: `scalars` (double[HARL_PS_STRIDE]) is first computed here as the fixed-order sum of the loss
- * kernel's n_scalar_blocks partial rows (single-GPU path); else scalars_hilo != NULL: `scalars` = hi + lo of the
- * all-reduced fp32 pair written by harl_pack_scalars_hilo (data-parallel path); else `scalars` already holds the sums.
+ * kernel's n_scalar_blocks partial rows (single-GPU path); else scalars_hilo != NULL: `scalars` = sum of the four
+ * all-reduced fp32 pieces written by harl_pack_scalars_hilo (data-parallel path); else `scalars` already holds the sums.
  * logstd_off >= 0: grad[logstd_off + d] = scalars[8 + d].  ws: >= 32 KiB device workspace, zero-initialised ONCE by the
  * caller (barrier words are reset by the kernel).  Replaces clip_grad_norm_ + Adam.step + the LayerNorm-affine adjoint
  * (algorithms/actors/happo.py:89-100, algorithms/critics/v_critic.py:144-155). */

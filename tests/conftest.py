@@ -15,3 +15,16 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def repo_root():
     return ROOT
+
+
+def pytest_collection_modifyitems(config, items):
+    """Plain `pytest` on a host without an MI355X skips the `gpu` tests instead of failing them.  On a GPU box
+    nothing is skipped: a missing libharl_hip.so must fail loudly there, never hide behind a skip."""
+    import torch
+
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="needs an MI355X (torch.cuda.is_available() is False)")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)

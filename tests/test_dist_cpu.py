@@ -61,7 +61,10 @@ def _worker(rank, world, port, q):
         flat = torch.from_numpy(g_local.copy())
         scal = torch.zeros(48, dtype=torch.float64)
         scal[1] = act_local
-        scal[0] = 1e9 + rank + 0.123456789  # needs the hi/lo split to survive an fp32 all-reduce
+        # ranks with DIFFERENT magnitudes: a per-rank (float)v + residual pair loses the cross-rank fp32 rounding of the
+        # heads (1e9 + 3e7 is not an fp32 number); the fixed-grid pieces sum exactly
+        scal[0] = (1e9 if rank == 0 else 3.00000017e7) + rank + 0.123456789
+        scal[2] = 16777217.0 * (rank + 1)  # a count above 2^24
         from harl_amd.dist import pack_message_reference, unpack_message_reference
         msg = pack_message_reference(flat, scal)  # the [grad | hi | lo] message the device path builds in place
         comm.all_reduce_message(msg)
@@ -69,7 +72,8 @@ def _worker(rank, world, port, q):
         got = flat.numpy() / scal[1].item()
         want = g_full / act_full
         err = float(np.max(np.abs(got - want)) / np.max(np.abs(want)))
-        want0 = sum(1e9 + r + 0.123456789 for r in range(world))
+        want0 = sum((1e9 if r == 0 else 3.00000017e7) + r + 0.123456789 for r in range(world))
+        want2 = sum(16777217.0 * (r + 1) for r in range(world))
         # minibatch index mapping: union over ranks of local rows == the global minibatch, order preserved
         torch.manual_seed(11)
         perm = torch.randperm(T * N)[: (T * N) // 2]
@@ -77,7 +81,7 @@ def _worker(rank, world, port, q):
         t_, n_ = loc // (hi - lo), loc % (hi - lo) + lo
         back = (t_ * N + n_).tolist()
         keep = [int(x) for x in perm.tolist() if lo <= x % N < hi]
-        q.put((rank, err, abs(scal[1].item() - act_full), abs(scal[0].item() - want0) / want0, back == keep, (lo, hi)))
+        q.put((rank, err, abs(scal[1].item() - act_full), max(abs(scal[0].item() - want0) / want0, abs(scal[2].item() - want2)), back == keep, (lo, hi)))
     finally:
         dist.destroy_process_group()
 
@@ -108,5 +112,5 @@ def test_world2_gloo_packed_allreduce_and_sharded_gradient_identity():
     for rank, err, act_err, sc_err, idx_ok, _ in res:
         assert err < 2e-6, (rank, err)          # sharded sum / global sum(active) == unsharded gradient
         assert act_err == 0.0
-        assert sc_err < 1e-12, sc_err            # fp64 scalars survive the single fp32 all-reduce (hi + lo)
+        assert sc_err < 1e-15, sc_err            # fp64 scalars survive the single fp32 all-reduce (fixed-grid pieces, exact sums)
         assert idx_ok

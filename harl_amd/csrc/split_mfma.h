@@ -29,14 +29,27 @@ __device__ __forceinline__ f32x16 mfma_bf16(const u32x4 &a, const u32x4 &b, cons
 
 // exact split of two floats into three packed bf16 pairs (low half = first value).  Truncation at every level: the three
 // pieces are the three bytes-and-a-bit of the significand, all of the sign of x (3 VALU ops per value, 1.5 per pack).
+template <bool PACKED = true>
 __device__ __forceinline__ void split3(float f0, float f1, unsigned &p1, unsigned &p2, unsigned &p3) {
-  const unsigned u0 = __float_as_uint(f0) & 0xffff0000u, u1 = __float_as_uint(f1) & 0xffff0000u;
-  p1 = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
-  const float r0 = f0 - __uint_as_float(u0), r1 = f1 - __uint_as_float(u1);
-  const unsigned w0 = __float_as_uint(r0) & 0xffff0000u, w1 = __float_as_uint(r1) & 0xffff0000u;
-  p2 = __builtin_amdgcn_perm(w1, w0, 0x07060302u);
-  const float q0 = r0 - __uint_as_float(w0), q1 = r1 - __uint_as_float(w1);  // <= 8 significant bits: exact in bf16
-  p3 = __builtin_amdgcn_perm(__float_as_uint(q1), __float_as_uint(q0), 0x07060302u);
+  // v_perm takes the high halves directly (no masking needed for the packed terms)
+  const unsigned b0 = __float_as_uint(f0), b1 = __float_as_uint(f1);
+  p1 = __builtin_amdgcn_perm(b1, b0, 0x07060302u);
+  if constexpr (PACKED) {
+    // the two remainders of a pair are ONE packed subtraction (v_pk_add_f32 with neg modifiers): 9 VALU ops per pair, at
+    // the price of 64-bit-aligned register pairs (more pressure: the kernels that live at the register limit opt out)
+    const f32x2 r = f32x2{f0, f1} - f32x2{__uint_as_float(b0 & 0xffff0000u), __uint_as_float(b1 & 0xffff0000u)};
+    const unsigned c0 = __float_as_uint(r[0]), c1 = __float_as_uint(r[1]);
+    p2 = __builtin_amdgcn_perm(c1, c0, 0x07060302u);
+    // the last remainder has <= 8 significant bits: exact in bf16
+    const f32x2 q = r - f32x2{__uint_as_float(c0 & 0xffff0000u), __uint_as_float(c1 & 0xffff0000u)};
+    p3 = __builtin_amdgcn_perm(__float_as_uint(q[1]), __float_as_uint(q[0]), 0x07060302u);
+  } else {
+    const float r0 = f0 - __uint_as_float(b0 & 0xffff0000u), r1 = f1 - __uint_as_float(b1 & 0xffff0000u);
+    const unsigned c0 = __float_as_uint(r0), c1 = __float_as_uint(r1);
+    p2 = __builtin_amdgcn_perm(c1, c0, 0x07060302u);
+    const float q0 = r0 - __uint_as_float(c0 & 0xffff0000u), q1 = r1 - __uint_as_float(c1 & 0xffff0000u);
+    p3 = __builtin_amdgcn_perm(__float_as_uint(q1), __float_as_uint(q0), 0x07060302u);
+  }
 }
 
 // round-to-nearest variant for the weights (split once per workgroup; v_cvt_pk_bf16_f32 is slow but unbiased)
@@ -54,14 +67,14 @@ __device__ __forceinline__ void split3_rne(float f0, float f1, unsigned &p1, uns
 }
 
 // activations: NR = H/2 accumulator-layout registers of one lane -> NR/8 k-step operands per term
-template <int NR>
+template <int NR, bool PACKED = true>
 __device__ __forceinline__ void split_acts(const float (&v)[NR], u32x4 (&x1)[NR / 8], u32x4 (&x2)[NR / 8], u32x4 (&x3)[NR / 8]) {
 #pragma unroll
   for (int j = 0; j < NR / 8; ++j)
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       unsigned a, b, d;
-      split3(v[8 * j + 2 * c], v[8 * j + 2 * c + 1], a, b, d);
+      split3<PACKED>(v[8 * j + 2 * c], v[8 * j + 2 * c + 1], a, b, d);
       x1[j][c] = a;
       x2[j][c] = b;
       x3[j][c] = d;

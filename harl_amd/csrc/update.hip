@@ -1,0 +1,852 @@
+// update.hip -- the optimiser step of a two-hidden-layer MLP actor / critic with narrow inputs (D <= 64) as THREE launches
+// that keep every activation on chip (gfx950).
+//
+//   k_upd_fwd : x0n -> layer 1 -> layer 2 -> head -> loss -> head backward -> LayerNorm/ReLU backward -> dz_2   (+ head dW)
+//   k_upd_dw2 : x0n, dz_2 -> x_hat_1 (recomputed) -> dW_2' = dz_2^T x_hat_1, db_2'
+//   k_upd_dx  : x0n, dz_2 -> x_hat_1 (recomputed), dx_hat_1 = W_2'^T dz_2 -> dz_1 -> dW_1' = dz_1^T x0n, db_1'
+//
+// Replaces, for this network shape, harl_mlp_fwd_fused2x + harl_actor_head_loss / harl_critic_head_loss +
+// harl_mlp_dw_partials(hidden) + harl_mlp_bwd_dx (reference: autograd through MLPBase + ACTLayer / v_out,
+// harl/algorithms/actors/happo.py:28-102, harl/algorithms/critics/v_critic.py:116-157).  HBM traffic per sample and
+// optimiser step: x0n 3 x 128 B (256 B for D > 32) + the loss row inputs in, dz_2 512 B out and 2 x 512 B in -- about
+// 1.9 KB against 4.5 KB for the layer-by-layer kernels, which wrote x_hat_1, x_hat_2, both ReLU masks and dz_2 and read
+// them back.  x_hat_1 is recomputed from the 128-byte normalised-input image (48 MFMAs) instead of being stored.
+//
+// Transposes on the matrix pipe.  A weight gradient contracts over SAMPLES, but activations live as "lane = sample"
+// (common.h).  Multiplying a split operand (as the A operand, M = sample) by a permuted identity (B) yields the block in the
+// C layout: lane = feature, 16 samples per lane -- exactly, because every bf16 term times 1.0 is exact and each output
+// receives a single non-zero product.  Both operands of a weight-gradient GEMM are transposed the same way, so their
+// sample order (sigma(r, h) = (r & 3) + 8 (r >> 2) + 4 h) agrees and the k order of a dot product is free.  Per 32-feature
+// block: 6 MFMAs + 24 v_perm, no LDS, no barrier, and the weight-gradient accumulators stay wave-private (they are combined
+// once, in fixed order, at the end of the kernel).
+#include <type_traits>
+#include "common.h"
+#include "split_mfma.h"
+#include "heads_common.h"
+#include "../../include/harl_hip.h"
+
+using namespace harl;
+
+namespace {
+
+int bad(const char *m) {
+  set_error(m);
+  return -2;
+}
+
+// ---- ReLU (+ bit mask, MSB-first as in common.h) + LayerNorm over the H features of a sample, from the accumulators.
+// The SAME routine serves the forward pass and both recomputations, so the recomputed x_hat_1 / mask are bit-identical
+// to what the forward pass saw (same staging, same GEMM order, same epilogue).
+template <int H, bool MASK>
+__device__ __forceinline__ void relu_ln(const f32x16 (&acc)[H / 32], float (&v)[H / 2], uint32_t (&bits)[(H / 2 + 31) / 32],
+                                        float &rstd_out) {
+  constexpr int NR = H / 2;
+#pragma unroll
+  for (int w = 0; w < (NR + 31) / 32; ++w) bits[w] = 0u;
+#pragma unroll
+  for (int R = 0; R < NR; ++R) {
+    if constexpr (MASK) v[R] = relu_push(acc[R >> 4][R & 15], bits[R >> 5]);
+    else v[R] = fmaxf(acc[R >> 4][R & 15], 0.f);
+  }
+  f32x2 s2v = {0.f, 0.f};
+#pragma unroll
+  for (int P = 0; P < NR / 2; ++P) s2v += f32x2{v[2 * P], v[2 * P + 1]};
+  float sum = s2v[0] + s2v[1];
+  sum += wave_xor32(sum);
+  const float mean = sum * (1.0f / H);
+  const f32x2 mv = {mean, mean};
+  f32x2 vsv = {0.f, 0.f};
+#pragma unroll
+  for (int P = 0; P < NR / 2; ++P) {
+    const f32x2 d = f32x2{v[2 * P], v[2 * P + 1]} - mv;
+    vsv = __builtin_elementwise_fma(d, d, vsv);
+    v[2 * P] = d[0];
+    v[2 * P + 1] = d[1];
+  }
+  float vs = vsv[0] + vsv[1];
+  vs += wave_xor32(vs);
+  const float rstd = 1.0f / sqrtf(vs * (1.0f / H) + 1e-5f);
+  const f32x2 rv = {rstd, rstd};
+#pragma unroll
+  for (int P = 0; P < NR / 2; ++P) {
+    const f32x2 o = f32x2{v[2 * P], v[2 * P + 1]} * rv;
+    v[2 * P] = o[0];
+    v[2 * P + 1] = o[1];
+  }
+  rstd_out = rstd;
+}
+
+// backward of x_hat = norm(relu(z)) with the ReLU mask in registers (cf. ln_bwd_relu_regs in common.h)
+template <int H>
+__device__ __forceinline__ void ln_bwd_relu_bits(const float (&dx)[H / 2], const float (&xh)[H / 2],
+                                                 const uint32_t (&bits_in)[(H / 2 + 31) / 32], float rstd,
+                                                 float (&out)[H / 2]) {
+  constexpr int NR = H / 2, NW = (NR + 31) / 32;
+  f32x2 a1 = {0.f, 0.f}, a2 = {0.f, 0.f};
+#pragma unroll
+  for (int P = 0; P < NR / 2; ++P) {
+    const f32x2 d = {dx[2 * P], dx[2 * P + 1]}, x = {xh[2 * P], xh[2 * P + 1]};
+    a1 += d;
+    a2 += d * x;
+  }
+  float s1 = a1[0] + a1[1], s2 = a2[0] + a2[1];
+  s1 += wave_xor32(s1);
+  s2 += wave_xor32(s2);
+  const float c1 = -(s1 * (1.0f / H)) * rstd, c2 = -(s2 * (1.0f / H)) * rstd;
+  const f32x2 c1v = {c1, c1}, c2v = {c2, c2}, rv = {rstd, rstd};
+  uint32_t bits[NW];
+#pragma unroll
+  for (int w = 0; w < NW; ++w) bits[w] = bits_in[w];
+#pragma unroll
+  for (int P = 0; P < NR / 2; ++P) {
+    const f32x2 d = {dx[2 * P], dx[2 * P + 1]}, x = {xh[2 * P], xh[2 * P + 1]};
+    const f32x2 da = __builtin_elementwise_fma(x, c2v, __builtin_elementwise_fma(d, rv, c1v));
+    out[2 * P] = mask_pop(da[0], bits[(2 * P) >> 5]);
+    out[2 * P + 1] = mask_pop(da[1], bits[(2 * P + 1) >> 5]);
+  }
+}
+
+// three bf16 images of W1' [H][D] (row stride D), K zero-padded to KP0 (the staging of k_fwd_fused2x, wide.hip)
+template <int H, int KP0, int NTHR>
+__device__ __forceinline__ void stage_w1_images(u32x4 *__restrict__ w1img, const float *__restrict__ W1p, int D) {
+  constexpr int MT = H / 32, NJ1 = KP0 / 16;
+  for (int e = threadIdx.x; e < MT * NJ1 * 64; e += NTHR) {
+    const int ln = e & 63, j = (e >> 6) % NJ1, t = (e >> 6) / NJ1, m = 32 * t + (ln & 31), g = ln >> 5;
+    unsigned p[3][4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int f0 = feat_base(8 * j + 2 * c) + 4 * g, f1 = feat_base(8 * j + 2 * c + 1) + 4 * g;
+      split3_rne(f0 < D ? W1p[(long)m * D + f0] : 0.f, f1 < D ? W1p[(long)m * D + f1] : 0.f, p[0][c], p[1][c], p[2][c]);
+    }
+#pragma unroll
+    for (int term = 0; term < 3; ++term) w1img[term * (MT * NJ1 * 64) + e] = u32x4{p[term][0], p[term][1], p[term][2], p[term][3]};
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// MFMA transposes
+// ---------------------------------------------------------------------------------------------
+constexpr unsigned BF16_ONE_LO = 0x00003F80u, BF16_ONE_HI = 0x3F800000u;
+
+// Permuted identities for a 32-feature block of an accumulator-layout operand: k-step 2t supplies features
+// 32t + (i&3) + 8(i>>2) + 4g (element i of lane half g), k-step 2t+1 the same + 16 (common.h, feat_base).
+struct Ident {
+  u32x4 j0, j1;
+};
+__device__ __forceinline__ Ident make_ident(int lane) {
+  const int n = lane & 31, g = lane >> 5;
+  Ident I;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int f0 = ((2 * c) & 3) + 8 * ((2 * c) >> 2) + 4 * g, f1 = f0 + 1;
+    I.j0[c] = (n == f0 ? BF16_ONE_LO : 0u) | (n == f1 ? BF16_ONE_HI : 0u);
+    I.j1[c] = (n == 16 + f0 ? BF16_ONE_LO : 0u) | (n == 16 + f1 ? BF16_ONE_HI : 0u);
+  }
+  return I;
+}
+// identity for an operand whose lane half g holds entries 8g .. 8g+7 of a <= 16-entry vector (head gradients)
+__device__ __forceinline__ u32x4 make_ident16(int lane) {
+  const int n = lane & 31, g = lane >> 5;
+  u32x4 I;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) I[c] = (n == 8 * g + 2 * c ? BF16_ONE_LO : 0u) | (n == 8 * g + 2 * c + 1 ? BF16_ONE_HI : 0u);
+  return I;
+}
+
+__device__ __forceinline__ unsigned pack_hi16(float lo, float hi) {  // two exactly-bf16 floats -> packed pair (low = first)
+  return __builtin_amdgcn_perm(__float_as_uint(hi), __float_as_uint(lo), 0x07060302u);
+}
+
+// acc (lane = feature, 16 samples) -> the two k-step operands of a weight-gradient MFMA
+__device__ __forceinline__ void pack_transposed(const f32x16 &acc, u32x4 &o0, u32x4 &o1) {
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    o0[c] = pack_hi16(acc[2 * c], acc[2 * c + 1]);
+    o1[c] = pack_hi16(acc[8 + 2 * c], acc[8 + 2 * c + 1]);
+  }
+}
+
+// One 32-feature block (k-steps 2t, 2t+1 of the three split terms) -> transposed operands T[term][k-step].
+// SUM: also return sum_r (t1 + t2 + t3)[r] = the lane's feature summed over its 16 samples (bias gradients).
+template <bool SUM>
+__device__ __forceinline__ float transpose_block(const u32x4 &x1a, const u32x4 &x1b, const u32x4 &x2a, const u32x4 &x2b,
+                                                 const u32x4 &x3a, const u32x4 &x3b, const Ident &I, u32x4 (&T)[3][2]) {
+  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  f32x16 c1 = mfma_bf16(x1a, I.j0, zero), c2 = mfma_bf16(x2a, I.j0, zero), c3 = mfma_bf16(x3a, I.j0, zero);
+  c1 = mfma_bf16(x1b, I.j1, c1);
+  c2 = mfma_bf16(x2b, I.j1, c2);
+  c3 = mfma_bf16(x3b, I.j1, c3);
+  pack_transposed(c1, T[0][0], T[0][1]);
+  pack_transposed(c2, T[1][0], T[1][1]);
+  pack_transposed(c3, T[2][0], T[2][1]);
+  float s = 0.f;
+  if constexpr (SUM) {
+    f32x2 a = {0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      a += f32x2{c3[2 * r], c3[2 * r + 1]};
+      a += f32x2{c2[2 * r], c2[2 * r + 1]};
+      a += f32x2{c1[2 * r], c1[2 * r + 1]};
+    }
+    s = a[0] + a[1];
+  }
+  return s;
+}
+
+// 16 accumulator-layout registers (one 32-feature block) -> split + transposed
+template <bool SUM, bool PACKED = true>
+__device__ __forceinline__ float split_transpose_block(const float *v16, const Ident &I, u32x4 (&T)[3][2]) {
+  u32x4 y1[2], y2[2], y3[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      unsigned a, b, d;
+      split3<PACKED>(v16[8 * j + 2 * c], v16[8 * j + 2 * c + 1], a, b, d);
+      y1[j][c] = a;
+      y2[j][c] = b;
+      y3[j][c] = d;
+    }
+  return transpose_block<SUM>(y1[0], y1[1], y2[0], y2[1], y3[0], y3[1], I, T);
+}
+
+// acc += A^T-block x B^T-block over the slab's 32 samples: 2 k-steps x the six cross products (smallest first)
+__device__ __forceinline__ void dw_tile(f32x16 &acc, const u32x4 (&A)[3][2], const u32x4 (&B)[3][2]) {
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    acc = mfma_bf16(A[2][ks], B[0][ks], acc);
+    acc = mfma_bf16(A[0][ks], B[2][ks], acc);
+    acc = mfma_bf16(A[1][ks], B[1][ks], acc);
+    acc = mfma_bf16(A[1][ks], B[0][ks], acc);
+    acc = mfma_bf16(A[0][ks], B[1][ks], acc);
+    acc = mfma_bf16(A[0][ks], B[0][ks], acc);
+  }
+}
+
+// Combine the four waves' weight-gradient accumulators acc[MT_][NT_] (+ per-lane bias sums db[MT_]) through LDS in fixed
+// order and write ONE partial row  dWp[32 MT_][KP] | dbp[32 MT_]  (the layout harl_reduce_partials_multi expects);
+// rows gridDim.x .. n_part_rows-1 of the arena are cleared (this launch runs at most one workgroup per CU).
+template <int MT_, int NT_>
+__device__ __forceinline__ void finish_partials(f32x16 (&acc)[MT_][NT_], float (&db)[MT_], float *buf,
+                                                float *__restrict__ part, int n_part_rows) {
+  constexpr int HO = 32 * MT_, KP = 32 * NT_, ROW = HO * KP + HO;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, h = lane >> 5;
+  float dbt[MT_];
+#pragma unroll
+  for (int a = 0; a < MT_; ++a) dbt[a] = db[a] + wave_xor32(db[a]);
+  __syncthreads();  // buf may alias LDS that other waves were still reading
+  for (int w = 0; w < WAVES_PER_WG; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int a = 0; a < MT_; ++a) {
+#pragma unroll
+        for (int b = 0; b < NT_; ++b)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int o = 32 * a + (r & 3) + 8 * (r >> 2) + 4 * h;
+            float *p = buf + o * KP + 32 * b + i;
+            *p = (w == 0 ? 0.f : *p) + acc[a][b][r];
+          }
+        if (h == 0) {
+          float *p = buf + HO * KP + 32 * a + i;
+          *p = (w == 0 ? 0.f : *p) + dbt[a];
+        }
+      }
+    }
+    __syncthreads();
+  }
+  float *out = part + (long)blockIdx.x * ROW;
+  for (int e = threadIdx.x; e < ROW; e += WG_THREADS) out[e] = buf[e];
+  for (int row = blockIdx.x + gridDim.x; row < n_part_rows; row += gridDim.x) {
+    float *z = part + (long)row * ROW;
+    for (int e = threadIdx.x; e < ROW; e += WG_THREADS) z[e] = 0.f;
+  }
+}
+
+// =============================================================================================
+// k_upd_dw2:  dW_2'[o][k] = sum_s dz_2[s][o] x_hat_1[s][k],  db_2'[o] = sum_s dz_2[s][o],  x_hat_1 recomputed from x0n.
+// All 16 output tiles live in the wave's accumulators (256 registers: one wave per SIMD with the whole 512-entry file);
+// per slab 48 (layer-1 recompute) + 48 (transposes) + 192 (gradient) MFMAs.  The transposed x_hat_1 operands of the slab
+// (24 KiB per wave) are parked in a wave-private LDS area between their production and the gradient MFMAs -- every lane
+// reads back exactly what it wrote (lane-linear ds_write_b128 / ds_read_b128, no barrier) -- which keeps the rest of the
+// slab's state inside the 256 architectural VGPRs next to the 256 accumulator registers.
+// =============================================================================================
+template <int H, int KP0>
+__global__ __launch_bounds__(WG_THREADS, 1) void k_upd_dw2(const float *__restrict__ x0n, const float *__restrict__ dz2,
+                                                           const float *__restrict__ W1p, int D,
+                                                           const float *__restrict__ b1p, long n_slabs,
+                                                           float *__restrict__ part, int n_part_rows) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int MT = H / 32, NJ1 = KP0 / 16, NR = H / 2, NW = (NR + 31) / 32;
+  u32x4 *w1img = reinterpret_cast<u32x4 *>(lds);
+  float *b1l = reinterpret_cast<float *>(w1img + 3 * MT * NJ1 * 64);
+  u32x4 *park = reinterpret_cast<u32x4 *>(b1l + H);  // [4 waves][MT blocks][3 terms][2 k-steps][64 lanes]; combine buffer at the end
+  stage_w1_images<H, KP0, WG_THREADS>(w1img, W1p, D);
+  for (int e = threadIdx.x; e < H; e += WG_THREADS) b1l[e] = b1p[e];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
+  const long slab0 = (long)blockIdx.x * WAVES_PER_WG + wave, slab_stride = (long)gridDim.x * WAVES_PER_WG;
+  const u32x4 *wl1 = w1img + lane;
+  u32x4 *pk = park + (long)wave * (MT * 6 * 64) + lane;
+  const Ident I = make_ident(lane);
+  f32x16 acc2[MT][MT];
+  float dbs[MT];
+#pragma unroll
+  for (int a = 0; a < MT; ++a) {
+    dbs[a] = 0.f;
+#pragma unroll
+    for (int b = 0; b < MT; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc2[a][b][r] = 0.f;
+  }
+  float xr[KP0 / 2];
+  atl_load<KP0>(x0n, slab0 < n_slabs ? slab0 : 0, lane, xr);
+  for (long slab = slab0; slab < n_slabs; slab += slab_stride) {
+    float raw[NR];
+    {
+      u32x4 a1[NJ1], a2[NJ1], a3[NJ1];
+      split_acts<KP0 / 2, false>(xr, a1, a2, a3);
+      atl_load<H>(dz2, slab, lane, raw);  // consumed after the layer-1 recompute: > 2000 cycles to land
+      atl_load<KP0>(x0n, slab + slab_stride < n_slabs ? slab + slab_stride : slab, lane, xr);  // one slab ahead
+      float x1[NR];
+      f32x16 acc[MT];
+#pragma unroll
+      for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = b1l[32 * t + (r & 3) + 8 * (r >> 2) + 4 * h];
+      split_gemm<MT, NJ1>(wl1, a1, a2, a3, acc, [](int) {});
+      uint32_t bits[NW];
+      float r1;
+      relu_ln<H, false>(acc, x1, bits, r1);
+      // x_hat_1, block by block: split (exact), transposed, parked
+#pragma unroll
+      for (int b = 0; b < MT; ++b) {
+        u32x4 B[3][2];
+        split_transpose_block<false, false>(&x1[16 * b], I, B);
+#pragma unroll
+        for (int term = 0; term < 3; ++term)
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) pk[((b * 3 + term) * 2 + ks) * 64] = B[term][ks];
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // dz_2, block by block: split and transposed -> A operands, bias sums on the way
+    u32x4 A[MT][3][2];
+#pragma unroll
+    for (int a = 0; a < MT; ++a) dbs[a] += split_transpose_block<true, false>(&raw[16 * a], I, A[a]);
+#pragma unroll
+    for (int b = 0; b < MT; ++b) {
+      u32x4 B[3][2];
+#pragma unroll
+      for (int term = 0; term < 3; ++term)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) B[term][ks] = pk[((b * 3 + term) * 2 + ks) * 64];
+#pragma unroll
+      for (int a = 0; a < MT; ++a) dw_tile(acc2[a][b], A[a], B);
+    }
+  }
+  finish_partials<MT, MT>(acc2, dbs, reinterpret_cast<float *>(park), part, n_part_rows);
+}
+
+// =============================================================================================
+// k_upd_dx:  dx_hat_1 = W_2'^T dz_2 ; x_hat_1 / mask_1 / rstd_1 recomputed from x0n ; dz_1 = LayerNorm/ReLU backward ;
+// dW_1'[o][k] = sum_s dz_1[s][o] x0n[s][k], db_1'[o] = sum_s dz_1[s][o].  Nothing is written but the gradient partials.
+// LDS: the three images of W_2'^T (96 KiB at H = 128) + those of W_1'.
+// =============================================================================================
+template <int H, int KP0>
+__global__ __launch_bounds__(WG_THREADS, 1) void k_upd_dx(const float *__restrict__ x0n, const float *__restrict__ dz2,
+                                                          const float *__restrict__ W1p, int D,
+                                                          const float *__restrict__ b1p, const float *__restrict__ W2p,
+                                                          long n_slabs, float *__restrict__ part, int n_part_rows) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int MT = H / 32, KT = KP0 / 32, NJ1 = KP0 / 16, NJ2 = H / 16, NR = H / 2, NW = (NR + 31) / 32;
+  u32x4 *img2 = reinterpret_cast<u32x4 *>(lds);     // W2'^T images; reused as the combine buffer at the end
+  u32x4 *w1img = img2 + 3 * MT * NJ2 * 64;
+  float *b1l = reinterpret_cast<float *>(w1img + 3 * MT * NJ1 * 64);
+  stage_split_matrix<H, H, true, WG_THREADS>(img2, W2p);
+  stage_w1_images<H, KP0, WG_THREADS>(w1img, W1p, D);
+  for (int e = threadIdx.x; e < H; e += WG_THREADS) b1l[e] = b1p[e];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
+  const long slab0 = (long)blockIdx.x * WAVES_PER_WG + wave, slab_stride = (long)gridDim.x * WAVES_PER_WG;
+  const u32x4 *wl1 = w1img + lane, *wl2 = img2 + lane;
+  const Ident I = make_ident(lane);
+  f32x16 acc1[MT][KT];
+  float dbs[MT];
+#pragma unroll
+  for (int a = 0; a < MT; ++a) {
+    dbs[a] = 0.f;
+#pragma unroll
+    for (int n = 0; n < KT; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc1[a][n][r] = 0.f;
+  }
+  float raw[NR], xr[KP0 / 2];
+  atl_load<H>(dz2, slab0 < n_slabs ? slab0 : 0, lane, raw);
+  atl_load<KP0>(x0n, slab0 < n_slabs ? slab0 : 0, lane, xr);
+  for (long slab = slab0; slab < n_slabs; slab += slab_stride) {
+    u32x4 a1[NJ1], a2[NJ1], a3[NJ1];
+    split_acts<KP0 / 2>(xr, a1, a2, a3);
+    float dx[NR];
+    {
+      u32x4 g1[NJ2], g2[NJ2], g3[NJ2];
+      split_acts<NR>(raw, g1, g2, g3);
+      const long nxt = slab + slab_stride < n_slabs ? slab + slab_stride : slab;  // one slab ahead
+      atl_load<H>(dz2, nxt, lane, raw);
+      atl_load<KP0>(x0n, nxt, lane, xr);
+      f32x16 acc[MT];
+#pragma unroll
+      for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+      split_gemm<MT, NJ2>(wl2, g1, g2, g3, acc, [](int) {});
+#pragma unroll
+      for (int R = 0; R < NR; ++R) dx[R] = acc[R >> 4][R & 15];
+    }
+    float dz1[NR];
+    {
+      float x1[NR];
+      uint32_t bits1[NW];
+      float r1;
+      f32x16 acc[MT];
+#pragma unroll
+      for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = b1l[32 * t + (r & 3) + 8 * (r >> 2) + 4 * h];
+      split_gemm<MT, NJ1>(wl1, a1, a2, a3, acc, [](int) {});
+      relu_ln<H, true>(acc, x1, bits1, r1);
+      ln_bwd_relu_bits<H>(dx, x1, bits1, r1, dz1);
+    }
+    u32x4 B[KT][3][2];
+#pragma unroll
+    for (int n = 0; n < KT; ++n)
+      transpose_block<false>(a1[2 * n], a1[2 * n + 1], a2[2 * n], a2[2 * n + 1], a3[2 * n], a3[2 * n + 1], I, B[n]);
+#pragma unroll
+    for (int a = 0; a < MT; ++a) {
+      u32x4 A[3][2];
+      dbs[a] += split_transpose_block<true>(&dz1[16 * a], I, A);
+#pragma unroll
+      for (int n = 0; n < KT; ++n) dw_tile(acc1[a][n], A, B[n]);
+    }
+  }
+  finish_partials<MT, KT>(acc1, dbs, reinterpret_cast<float *>(img2), part, n_part_rows);
+}
+
+// =============================================================================================
+// k_upd_fwd:  the whole forward pass and the loss of one optimiser step (TRAIN), or a log-prob / value pass (!TRAIN).
+//   TRAIN : x0n -> x_hat_1 -> x_hat_2 -> head -> ratio / clipped surrogate x factor / entropy (actor) or clipped Huber value
+//           loss (critic) -> d loss / d head -> head weight gradient (transposes on the matrix pipe) -> LayerNorm / ReLU
+//           backward -> dz_2 (ATL).  x_hat_1, x_hat_2, their masks and statistics never leave the registers.
+//   !TRAIN: ... -> head -> log-probs (+ the sequential-update factor product) / values.
+// LDS: images of W_1' and W_2' (24-48 + 96 KiB), biases, the head weights as whl[h][R][DAP] (heads_common.h).
+// =============================================================================================
+struct UpdFwdArgs {
+  const float *x0n, *W1p, *b1p, *W2p, *b2p;
+  int D;
+  long n_slabs;
+  float *dz2;
+  int n_part_rows;
+};
+
+// EIGHT waves per workgroup = two per SIMD, 256 registers each: one wave's VALU / LDS / scalar work issues under the other's
+// MFMAs (a lone wave issues one instruction of ANY kind per four cycles -- measured: the four-wave version of this kernel
+// spent 42 % of its time issuing VALU, 31 % in s_waitcnt and 21 % blocked behind its own MFMAs, matrix pipe 28 % busy).
+// To fit, the head weight gradient is accumulated in a wave-private LDS tile (HROWS rows x H floats; ds_add_f32 from the
+// transient MFMA tile) instead of 64 persistent accumulator registers.
+constexpr int UF_WAVES = 8, UF_THREADS = 64 * UF_WAVES;
+
+template <int NV>
+__device__ __forceinline__ void block_reduce_store8(float (&v)[NV], float *red /*[8][PS_STRIDE]*/, float *out_row) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    float t = wave_reduce_sum(v[k]);
+    if (lane == 0) red[wave * PS_STRIDE + k] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x < PS_STRIDE) {
+    float t = 0.f;
+    if (threadIdx.x < NV) {
+#pragma unroll
+      for (int w = 0; w < UF_WAVES; ++w) t += red[w * PS_STRIDE + threadIdx.x];
+    }
+    out_row[threadIdx.x] = t;
+  }
+}
+
+template <int H, int KP0, int DAP, bool DISCRETE, bool TRAIN, typename ARGS>
+__global__ __launch_bounds__(UF_THREADS, 2) void k_upd_fwd(UpdFwdArgs U, ARGS A) {
+  constexpr bool CRITIC = std::is_same<ARGS, CriticArgs>::value;
+  static_assert(DAP <= 8, "the LDS head-gradient tile covers 8 head outputs");
+  constexpr int HROWS = CRITIC ? 1 : DAP;  // rows of the head weight gradient that can be non-zero
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int MT = H / 32, NJ1 = KP0 / 16, NJ2 = H / 16, NR = H / 2, NW = (NR + 31) / 32;
+  u32x4 *w2img = reinterpret_cast<u32x4 *>(lds);   // reused as the head-gradient combine buffer at the end
+  u32x4 *w1img = w2img + 3 * MT * NJ2 * 64;
+  float *b1l = reinterpret_cast<float *>(w1img + 3 * MT * NJ1 * 64);
+  float *b2l = b1l + H;
+  float *whl = b2l + H;                    // [2][H/2][DAP]
+  float *cst = whl + 2 * (H / 2) * DAP;    // bias, sigma, logsigma, dsigma_dlogstd, rowsum, 1/sigma, 1/sigma^2
+  float *red = cst + 7 * DAP;              // [8][PS_STRIDE]
+  float *hacc = red + UF_WAVES * PS_STRIDE;  // [8 waves][HROWS][H] head weight gradient, wave-private
+  stage_split_matrix<H, H, false, UF_THREADS>(w2img, U.W2p);
+  stage_w1_images<H, KP0, UF_THREADS>(w1img, U.W1p, U.D);
+  for (int e = threadIdx.x; e < H; e += UF_THREADS) {
+    b1l[e] = U.b1p[e];
+    b2l[e] = U.b2p[e];
+  }
+  if (TRAIN)
+    for (int e = threadIdx.x; e < UF_WAVES * HROWS * H; e += UF_THREADS) hacc[e] = 0.f;
+  if (threadIdx.x < WG_THREADS) {  // (the staging helpers of heads_common.h stride by WG_THREADS)
+    if constexpr (CRITIC) {
+      stage_head<H, DAP>(whl, cst, A.Whp, A.bhp, 1);
+    } else {
+      stage_head<H, DAP>(whl, cst, A.Whp, A.bhp, A.act_dim);
+      if (!DISCRETE) {
+        for (int e = threadIdx.x; e < DAP; e += WG_THREADS) {
+          float sg = 0.5f, sig = 1.f, lsig = 0.f, dsd = 0.f;
+          if (e < A.act_dim) {  // distributions.py:86-89: std = sigmoid(log_std / x_coef) * y_coef
+            sg = 1.0f / (1.0f + expf(-A.log_std[e] / A.std_x_coef));
+            sig = sg * A.std_y_coef;
+            lsig = logf(sig);
+            dsd = A.std_y_coef * sg * (1.f - sg) / A.std_x_coef;
+          }
+          cst[DAP + e] = sig;
+          cst[2 * DAP + e] = lsig;
+          cst[3 * DAP + e] = dsd;
+          cst[5 * DAP + e] = 1.0f / sig;
+          cst[6 * DAP + e] = 1.0f / (sig * sig);
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, h = lane >> 5;
+  const long slab0 = (long)blockIdx.x * UF_WAVES + wave, slab_stride = (long)gridDim.x * UF_WAVES;
+  const u32x4 *wl1 = w1img + lane, *wl2 = w2img + lane;
+  const float *whl_h = whl + h * (H / 2) * DAP;
+  float *hw = hacc + wave * (HROWS * H);
+  const Ident I = make_ident(lane);
+  const u32x4 I16 = make_ident16(lane);
+
+  float adv_mean = 0.f, adv_den = 1.f, vmean = 0.f, vsd = 1.f;
+  if constexpr (CRITIC) {
+    if (TRAIN && A.vn_stats) {  // valuenorm.py:38-45
+      const float d = fmaxf(A.vn_stats[2], 1e-5f);
+      vmean = A.vn_stats[0] / d;
+      const float msq = A.vn_stats[1] / d;
+      vsd = sqrtf(fmaxf(msq - vmean * vmean, 1e-2f));
+    }
+  } else {
+    if (TRAIN && A.adv_moments) {  // happo.py:122-127
+      const double cnt = A.adv_moments[2];
+      const double m = A.adv_moments[0] / cnt;
+      const double var = A.adv_moments[1] / cnt - m * m;
+      adv_mean = (float)m;
+      adv_den = 1.0f / ((float)sqrt(var > 0 ? var : 0.0) + 1e-5f);  // reciprocal (actor_sample multiplies)
+    }
+  }
+  constexpr int NSC = CRITIC ? 8 : 8 + DAP;
+  float sc[NSC];
+#pragma unroll
+  for (int k = 0; k < NSC; ++k) sc[k] = 0.f;
+  float dbacc[DAP];
+#pragma unroll
+  for (int d = 0; d < DAP; ++d) dbacc[d] = 0.f;
+
+  float xr[KP0 / 2];
+  atl_load<KP0>(U.x0n, slab0 < U.n_slabs ? slab0 : 0, lane, xr);
+  for (long slab = slab0; slab < U.n_slabs; slab += slab_stride) {
+    float v[NR];        // x_hat_2
+    uint32_t bits2[NW];
+    float r2;
+    {
+      float x1[NR];
+      {
+        u32x4 a1[NJ1], a2[NJ1], a3[NJ1];
+        split_acts<KP0 / 2>(xr, a1, a2, a3);
+        atl_load<KP0>(U.x0n, slab + slab_stride < U.n_slabs ? slab + slab_stride : slab, lane, xr);  // one slab ahead
+        f32x16 acc[MT];
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[t][r] = b1l[32 * t + (r & 3) + 8 * (r >> 2) + 4 * h];
+        split_gemm<MT, NJ1>(wl1, a1, a2, a3, acc, [](int) {});
+        uint32_t bits1[NW];
+        float r1;
+        relu_ln<H, false>(acc, x1, bits1, r1);
+      }
+      u32x4 y1[NJ2], y2[NJ2], y3[NJ2];
+      split_acts<NR>(x1, y1, y2, y3);
+      f32x16 acc[MT];
+#pragma unroll
+      for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = b2l[32 * t + (r & 3) + 8 * (r >> 2) + 4 * h];
+      split_gemm<MT, NJ2>(wl2, y1, y2, y3, acc, [](int) {});
+      relu_ln<H, TRAIN>(acc, v, bits2, r2);
+    }
+    f32x4 xs[H / 8];
+#pragma unroll
+    for (int q = 0; q < H / 8; ++q) xs[q] = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+    float z[DAP];
+    head_fwd_regs<H, DAP>(xs, whl_h, cst, z);
+    float dzh[DAP];
+    float s1, s2;
+    if constexpr (CRITIC) {
+      float dv;
+      if (!critic_sample<TRAIN>(A, z[0], slab, lane, vmean, vsd, sc, dv)) continue;
+#pragma unroll
+      for (int d = 0; d < DAP; ++d) dzh[d] = d == 0 ? dv : 0.f;
+      s1 = dv * cst[4 * DAP];
+      s2 = dv * (z[0] - cst[0]);
+    } else {
+      if (!actor_sample<DAP, DISCRETE, TRAIN>(A, cst, z, slab, lane, adv_mean, adv_den, sc, dzh, s1, s2)) continue;
+    }
+    if constexpr (TRAIN) {
+      // ---- head weight gradient dW_head'[d][f] += sum_s dzh[s][d] x_hat_2[s][f]: both operands transposed on the matrix
+      // pipe, one 32-feature tile at a time; rows d < HROWS of the tile are added to the wave's LDS accumulator
+      u32x4 Ah[3][2];
+      {
+        float e8[8];  // lane half 0 carries head-gradient entries 0..7 (entries >= DAP are zero), half 1 zeros
+#pragma unroll
+        for (int c = 0; c < 8; ++c) e8[c] = (c < DAP && h == 0) ? dzh[c < DAP ? c : 0] : 0.f;
+        u32x4 t1, t2, t3;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          unsigned a, b, d;
+          split3(e8[2 * c], e8[2 * c + 1], a, b, d);
+          t1[c] = a;
+          t2[c] = b;
+          t3[c] = d;
+        }
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const f32x16 c1 = mfma_bf16(t1, I16, zero), c2 = mfma_bf16(t2, I16, zero), c3 = mfma_bf16(t3, I16, zero);
+        pack_transposed(c1, Ah[0][0], Ah[0][1]);
+        pack_transposed(c2, Ah[1][0], Ah[1][1]);
+        pack_transposed(c3, Ah[2][0], Ah[2][1]);
+      }
+#pragma unroll
+      for (int n = 0; n < MT; ++n) {
+        u32x4 B[3][2];
+        split_transpose_block<false>(&v[16 * n], I, B);
+        f32x16 tile = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        dw_tile(tile, Ah, B);
+        // tile[r] of lane (i, h) = row d = (r & 3) + 8 (r >> 2) + 4 h, column 32 n + i
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (r < HROWS && h == 0) atomicAdd(hw + r * H + 32 * n + i, tile[r]);
+          if (4 + r < HROWS && h == 1) atomicAdd(hw + (4 + r) * H + 32 * n + i, tile[r]);
+        }
+      }
+      if (h == 0) {
+#pragma unroll
+        for (int d = 0; d < DAP; ++d) dbacc[d] += dzh[d];
+      }
+      // ---- head backward (W_head'^T dzh on the fp32 MFMA) + LayerNorm / ReLU backward -> dz_2
+      head_bwd_regs_bits<H, DAP>(xs, bits2[0], bits2[NW - 1], r2, slab, lane, whl, dzh, s1, s2, U.dz2);
+    }
+  }
+  if constexpr (TRAIN) {
+    block_reduce_store8<NSC>(sc, red, A.part_scalars + (long)blockIdx.x * PS_STRIDE);
+    for (int row = blockIdx.x + gridDim.x; row < U.n_part_rows; row += gridDim.x)
+      if (threadIdx.x < PS_STRIDE) A.part_scalars[(long)row * PS_STRIDE + threadIdx.x] = 0.f;
+    // ---- head weight gradient: bias sums across lanes, then the eight waves' tiles in fixed order -> ONE partial row
+    // dWp[32][H] | dbp[32] (rows >= HROWS are zero)
+    float dbs[DAP];
+#pragma unroll
+    for (int d = 0; d < DAP; ++d) dbs[d] = wave_reduce_sum(dbacc[d]);
+    float *dbl = red;  // [8][PS_STRIDE] reused (block_reduce_store8 is done with it after the barrier below)
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+      for (int d = 0; d < DAP; ++d) dbl[wave * PS_STRIDE + d] = dbs[d];
+    }
+    __syncthreads();
+    float *out = A.dw_part + (long)blockIdx.x * HeadDw<H>::OUT_FLOATS;
+    for (int e = threadIdx.x; e < HeadDw<H>::OUT_FLOATS; e += UF_THREADS) {
+      float t = 0.f;
+      if (e < 32 * H) {
+        const int row = e / H;
+        if (row < HROWS) {
+#pragma unroll
+          for (int w = 0; w < UF_WAVES; ++w) t += hacc[(w * HROWS + row) * H + (e - row * H)];
+        }
+      } else {
+        const int d = e - 32 * H;
+        if (d < DAP) {
+#pragma unroll
+          for (int w = 0; w < UF_WAVES; ++w) t += dbl[w * PS_STRIDE + d];
+        }
+      }
+      out[e] = t;
+    }
+    for (int row = blockIdx.x + gridDim.x; row < U.n_part_rows; row += gridDim.x) {
+      float *zr = A.dw_part + (long)row * HeadDw<H>::OUT_FLOATS;
+      for (int e = threadIdx.x; e < HeadDw<H>::OUT_FLOATS; e += UF_THREADS) zr[e] = 0.f;
+    }
+  }
+}
+
+int fwd_grid(long n_slabs) {
+  const long wgs = (n_slabs + UF_WAVES - 1) / UF_WAVES;
+  return (int)(wgs < 256 ? (wgs < 1 ? 1 : wgs) : 256);
+}
+
+int upd_grid(long n_slabs) {
+  const long wgs = (n_slabs + WAVES_PER_WG - 1) / WAVES_PER_WG;
+  return (int)(wgs < 256 ? (wgs < 1 ? 1 : wgs) : 256);
+}
+
+size_t fwd_lds_bytes(int H, int kp0, int dap, int hrows) {
+  return split_image_bytes(H, H) + split_image_bytes(H, kp0) +
+         ((size_t)2 * H + (size_t)2 * (H / 2) * dap + 7 * dap + UF_WAVES * PS_STRIDE + (size_t)UF_WAVES * hrows * H) * sizeof(float);
+}
+
+template <int H, int KP0, int DAP, bool DISC, bool TRAIN, typename ARGS>
+void launch_fwd(const UpdFwdArgs &U, const ARGS &A, hipStream_t s) {
+  const size_t shm = fwd_lds_bytes(H, KP0, DAP, std::is_same<ARGS, CriticArgs>::value ? 1 : DAP);
+  allow_big_lds(k_upd_fwd<H, KP0, DAP, DISC, TRAIN, ARGS>, shm);
+  hipLaunchKernelGGL((k_upd_fwd<H, KP0, DAP, DISC, TRAIN, ARGS>), dim3(fwd_grid(U.n_slabs)), dim3(UF_THREADS), shm, s, U, A);
+}
+
+template <bool TRAIN>
+int dispatch_fwd_actor(const UpdFwdArgs &U, const ActorArgs &A, int H, int discrete, hipStream_t s) {
+  const int D = A.act_dim;
+  if (D < 1 || D > 8) return bad("harl_update_fwd: act_dim must be in [1, 8]");
+  const int dap = D <= 4 ? 4 : 8;
+  const int kp0 = U.D <= 32 ? 32 : 64;
+#define CASE(Hv, Kv, DAPv)                                                             \
+  if (H == Hv && kp0 == Kv && dap == DAPv) {                                            \
+    if (discrete) launch_fwd<Hv, Kv, DAPv, true, TRAIN, ActorArgs>(U, A, s);           \
+    else launch_fwd<Hv, Kv, DAPv, false, TRAIN, ActorArgs>(U, A, s);                   \
+    return check_launch("harl_update_fwd");                                            \
+  }
+  CASE(128, 32, 4) CASE(128, 32, 8) CASE(128, 64, 4) CASE(128, 64, 8)
+  CASE(64, 32, 4) CASE(64, 32, 8) CASE(64, 64, 4) CASE(64, 64, 8)
+#undef CASE
+  return bad("harl_update_fwd: hidden width must be 64 or 128");
+}
+
+template <bool TRAIN>
+int dispatch_fwd_critic(const UpdFwdArgs &U, const CriticArgs &A, int H, hipStream_t s) {
+  const int kp0 = U.D <= 32 ? 32 : 64;
+#define CASE(Hv, Kv)                                                     \
+  if (H == Hv && kp0 == Kv) {                                            \
+    launch_fwd<Hv, Kv, 4, false, TRAIN, CriticArgs>(U, A, s);            \
+    return check_launch("harl_update_fwd");                              \
+  }
+  CASE(128, 32) CASE(128, 64) CASE(64, 32) CASE(64, 64)
+#undef CASE
+  return bad("harl_update_fwd: hidden width must be 64 or 128");
+}
+
+}  // namespace
+
+extern "C" int harl_update_supported(int D, int H, int act_dim) {
+  return (D >= 1 && D <= 64 && (H == 64 || H == 128) && act_dim >= 1 && act_dim <= 8) ? 1 : 0;
+}
+
+extern "C" int harl_update_fwd_actor(const float *x0n, long M, int D, int H, const float *W1p, const float *b1p,
+                                     const float *W2p, const float *b2p, const float *Whp, const float *bhp,
+                                     const float *log_std, float std_x_coef, float std_y_coef, int discrete, int act_dim,
+                                     const float *actions, const float *avail, const float *old_logp, const float *adv,
+                                     const double *adv_moments, const float *factor, const float *active,
+                                     float clip_param, float entropy_coef, int agg_mean, int trpo, float *logp_out,
+                                     float *dz2, float *part_scalars, float *dw_part_head, int n_part_rows, void *stream) {
+  if (M <= 0) return 0;
+  if (D < 1 || D > 64) return bad("harl_update_fwd_actor: input width must be <= 64");
+  if (!dz2 || !part_scalars || !dw_part_head || n_part_rows <= 0) return bad("harl_update_fwd_actor: missing outputs");
+  UpdFwdArgs U{x0n, W1p, b1p, W2p, b2p, D, n_slabs_of(M), dz2, n_part_rows};
+  if (fwd_grid(U.n_slabs) > n_part_rows) return bad("harl_update_fwd_actor: n_part_rows smaller than the launch grid");
+  ActorArgs A{};
+  A.trpo = trpo;
+  A.logp_out = logp_out;
+  A.dw_part = dw_part_head;
+  A.M = M; A.Whp = Whp; A.bhp = bhp; A.log_std = log_std;
+  A.std_x_coef = std_x_coef; A.std_y_coef = std_y_coef; A.act_dim = act_dim;
+  A.actions = actions; A.avail = avail; A.old_logp = old_logp; A.adv = adv; A.adv_moments = adv_moments;
+  A.factor_in = factor; A.active = active; A.clip_param = clip_param; A.entropy_coef = entropy_coef;
+  A.agg_mean = agg_mean; A.part_scalars = part_scalars; A.n_slabs = U.n_slabs;
+  return dispatch_fwd_actor<true>(U, A, H, discrete, (hipStream_t)stream);
+}
+
+extern "C" int harl_update_logp(const float *x0n, long M, int D, int H, const float *W1p, const float *b1p,
+                                const float *W2p, const float *b2p, const float *Whp, const float *bhp,
+                                const float *log_std, float std_x_coef, float std_y_coef, int discrete, int act_dim,
+                                const float *actions, const float *avail, float *logp_out, const float *old_logp,
+                                float *factor, int agg_mean, float *head_out, void *stream) {
+  if (M <= 0) return 0;
+  if (D < 1 || D > 64) return bad("harl_update_logp: input width must be <= 64");
+  if (factor && !old_logp) return bad("harl_update_logp: factor update needs old_logp");
+  UpdFwdArgs U{x0n, W1p, b1p, W2p, b2p, D, n_slabs_of(M), nullptr, 0};
+  ActorArgs A{};
+  A.head_out = head_out;
+  A.M = M; A.Whp = Whp; A.bhp = bhp; A.log_std = log_std;
+  A.std_x_coef = std_x_coef; A.std_y_coef = std_y_coef; A.act_dim = act_dim;
+  A.actions = actions; A.avail = avail; A.old_logp = old_logp; A.agg_mean = agg_mean;
+  A.logp_out = logp_out; A.factor_out = factor; A.n_slabs = U.n_slabs;
+  return dispatch_fwd_actor<false>(U, A, H, discrete, (hipStream_t)stream);
+}
+
+extern "C" int harl_update_fwd_critic(const float *x0n, long M, int D, int H, const float *W1p, const float *b1p,
+                                      const float *W2p, const float *b2p, const float *Whp, const float *bhp,
+                                      const float *value_preds, const float *returns, const float *vn_stats,
+                                      float clip_param, int use_clipped, int use_huber, float huber_delta, float *dz2,
+                                      float *part_scalars, float *dw_part_head, int n_part_rows, void *stream) {
+  if (M <= 0) return 0;
+  if (D < 1 || D > 64) return bad("harl_update_fwd_critic: input width must be <= 64");
+  if (!dz2 || !part_scalars || !dw_part_head || n_part_rows <= 0) return bad("harl_update_fwd_critic: missing outputs");
+  UpdFwdArgs U{x0n, W1p, b1p, W2p, b2p, D, n_slabs_of(M), dz2, n_part_rows};
+  if (fwd_grid(U.n_slabs) > n_part_rows) return bad("harl_update_fwd_critic: n_part_rows smaller than the launch grid");
+  CriticArgs A{};
+  A.M = M; A.Whp = Whp; A.bhp = bhp;
+  A.value_preds = value_preds; A.returns = returns; A.vn_stats = vn_stats; A.clip_param = clip_param;
+  A.huber_delta = huber_delta; A.use_clipped = use_clipped; A.use_huber = use_huber;
+  A.part_scalars = part_scalars; A.n_slabs = U.n_slabs;
+  A.dw_part = dw_part_head;
+  return dispatch_fwd_critic<true>(U, A, H, (hipStream_t)stream);
+}
+
+extern "C" int harl_update_values(const float *x0n, long M, int D, int H, const float *W1p, const float *b1p,
+                                  const float *W2p, const float *b2p, const float *Whp, const float *bhp, float *values,
+                                  void *stream) {
+  if (M <= 0) return 0;
+  if (D < 1 || D > 64) return bad("harl_update_values: input width must be <= 64");
+  UpdFwdArgs U{x0n, W1p, b1p, W2p, b2p, D, n_slabs_of(M), nullptr, 0};
+  CriticArgs A{};
+  A.M = M; A.Whp = Whp; A.bhp = bhp; A.values_out = values; A.n_slabs = U.n_slabs;
+  return dispatch_fwd_critic<false>(U, A, H, (hipStream_t)stream);
+}
+
+extern "C" int harl_update_bwd(const float *x0n, const float *dz2, long M, int D, int H, const float *W1p,
+                               const float *b1p, const float *W2p, float *dw_part1, float *dw_part2, int n_part_rows,
+                               void *stream) {
+  if (M <= 0) return 0;
+  if (D < 1 || D > 64) return bad("harl_update_bwd: input width must be <= 64");
+  if (!dw_part1 || !dw_part2 || n_part_rows <= 0) return bad("harl_update_bwd: missing outputs");
+  const long n_slabs = n_slabs_of(M);
+  const int grid = upd_grid(n_slabs), kp0 = D <= 32 ? 32 : 64;
+  if (grid > n_part_rows) return bad("harl_update_bwd: n_part_rows smaller than the launch grid");
+  hipStream_t s = (hipStream_t)stream;
+#define CASE(Hv, Kv)                                                                                                    \
+  if (H == Hv && kp0 == Kv) {                                                                                           \
+    size_t shm2 = (size_t)WAVES_PER_WG * (Hv / 32) * 6 * 64 * 16;              /* parked operands */                    \
+    if (shm2 < ((size_t)Hv * Hv + Hv) * sizeof(float)) shm2 = ((size_t)Hv * Hv + Hv) * sizeof(float);                  \
+    shm2 += split_image_bytes(Hv, Kv) + (size_t)Hv * sizeof(float);                                                     \
+    allow_big_lds(k_upd_dw2<Hv, Kv>, shm2);                                                                             \
+    hipLaunchKernelGGL((k_upd_dw2<Hv, Kv>), dim3(grid), dim3(WG_THREADS), shm2, s, x0n, dz2, W1p, D, b1p, n_slabs,      \
+                       dw_part2, n_part_rows);                                                                          \
+    size_t shm1 = split_image_bytes(Hv, Hv) + split_image_bytes(Hv, Kv) + (size_t)Hv * sizeof(float);                   \
+    const size_t need = ((size_t)Hv * Kv + Hv) * sizeof(float);                                                         \
+    if (shm1 < need) shm1 = need;                                                                                       \
+    allow_big_lds(k_upd_dx<Hv, Kv>, shm1);                                                                              \
+    hipLaunchKernelGGL((k_upd_dx<Hv, Kv>), dim3(grid), dim3(WG_THREADS), shm1, s, x0n, dz2, W1p, D, b1p, W2p, n_slabs,  \
+                       dw_part1, n_part_rows);                                                                          \
+    return check_launch("harl_update_bwd");                                                                             \
+  }
+  CASE(128, 32) CASE(128, 64) CASE(64, 32) CASE(64, 64)
+#undef CASE
+  return bad("harl_update_bwd: hidden width must be 64 or 128");
+}

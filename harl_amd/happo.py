@@ -58,6 +58,11 @@ class OnPolicyBase:
         resets.  Returns the final hidden state [m, H] when ``h_last`` is set."""
         net = self.actor
         agg = int(self.action_aggregation == "mean")
+        if not reuse_trunk and net.fused_update_ok(None, train=False):  # forward + head in one launch, x_hat_2 never leaves the chip
+            call("harl_update_logp", *net.fused_args(obs, M), ptr(net.log_std()), net.std_x_coef, net.std_y_coef,
+                 int(net.discrete), net.act_dim, ptr(actions), ptr(avail), ptr(logp_out), ptr(old_logp), ptr(factor), agg,
+                 ptr(head_out), stream(), tag="update_logp")
+            return None
         if not net.recurrent:
             if not reuse_trunk:  # reuse_trunk: x_hat_L of these rows under the current weights is still in the workspace
                 net.forward_trunk(obs, None, M, for_backward=False)
@@ -165,9 +170,18 @@ class HAPPO(OnPolicyBase):
         the GRU layout (nets.build_seq), idx = seq['idx'].  ``logp_out`` [m, act_w]: also emit log pi(a|o) under the
         pre-step parameters (by batch position).  ``factor`` None = 1 (MAPPO)."""
         net = self.actor
+        s = stream()
+        if net.fused_update_ok(idx, seq):  # three launches, every activation on chip (csrc/update.hip)
+            fa = net.fused_args(obs, m)
+            call("harl_update_fwd_actor", *fa, ptr(net.log_std()), net.std_x_coef, net.std_y_coef, int(net.discrete),
+                 net.act_dim, ptr(actions), ptr(avail), ptr(old_logp), ptr(adv), ptr(adv_moments), ptr(factor),
+                 ptr(active), float(self.clip_param), float(self.entropy_coef), int(self.action_aggregation == "mean"),
+                 self._surrogate_mode, ptr(logp_out), ptr(net.dz[0]), ptr(net.part_scalars),
+                 ptr(net.part[net._part_offs[-1]:]), net.n_wg, s, tag="update_fwd")
+            net.backward_fused(m)
+            return net.n_wg
         net.forward_trunk(obs, idx, m, seq=seq)
         Wp, bp = net._packs[-1]
-        s = stream()
         fx, fmask, frstd, fh = net.feat()
         mv, mp = (seq["m"], seq["m_pad"]) if seq is not None else (0, 0)
         call("harl_actor_head_loss", ptr(fx), ptr(fmask), ptr(frstd), m, fh,

@@ -13,6 +13,7 @@ memory and the stream.
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -354,6 +355,39 @@ class _FlatNet(nn.Module):
                  ptr(Wp), ptr(bp), ptr(self.xh[l]), ptr(self.rmask[l]), ptr(self.rstd[l]), s, tag="fwd_hidden")
         if self.recurrent:
             self.forward_rnn(seq, save=True)
+
+    # ---- fused optimiser-step path (csrc/update.hip): two equal hidden layers, inputs <= 64 wide, identity row order
+    def fused_update_ok(self, idx: Optional[torch.Tensor], seq: Optional[dict] = None, train: bool = True) -> bool:
+        """Route this pass through csrc/update.hip?  ``HARL_FUSED_UPDATE``: "logp" (default) = forward-only passes
+        (log-probs, factor product, values: one launch instead of two, x_hat_2 never written); "1" = optimiser steps too
+        (three launches, ~1.9 KB of HBM traffic per sample instead of ~4.5 KB -- fewer bytes but, on MI355X today, more
+        VALU work than the layer-by-layer kernels and a few % slower end to end: DESIGN.md §3); "actor" = "1" for actors
+        only; "0" = never."""
+        hs = self.hidden_sizes
+        mode = os.environ.get("HARL_FUSED_UPDATE", "logp")
+        if mode == "0" or (train and mode == "logp") or (train and mode == "actor" and isinstance(self, VNet)):
+            return False
+        return (not self.recurrent and idx is None and seq is None
+                and len(hs) == 2 and hs[0] == hs[1] and self.in_dim <= 64 and self._layers()[-1][4] <= 8)
+
+    def fused_args(self, X: torch.Tensor, M: int):
+        """(x0n, M, D, H, W1', b1', W2', b2', Wh', bh') -- the leading arguments of every harl_update_* entry point.
+        Builds / reuses the normalised-input image of X."""
+        self._ensure_ws(M)
+        self._x0n_image(X, M, stream())
+        (W1, b1), (W2, b2), (Wh, bh) = self._packs[0], self._packs[1], self._packs[-1]
+        return (ptr(self.x0n), M, self.in_dim, self.hidden_sizes[0], ptr(W1), ptr(b1), ptr(W2), ptr(b2), ptr(Wh), ptr(bh))
+
+    def backward_fused(self, M: int) -> None:
+        """dz_2 (self.dz[0], written by harl_update_fwd_*) + x0n -> dense folded gradients self.dwp (UNSCALED sums);
+        the head's partial rows were written by the forward launch."""
+        s = stream()
+        (W1, b1), (W2, _) = self._packs[0], self._packs[1]
+        po = self._part_offs
+        call("harl_update_bwd", ptr(self.x0n), ptr(self.dz[0]), M, self.in_dim, self.hidden_sizes[0], ptr(W1), ptr(b1),
+             ptr(W2), ptr(self.part[po[0]:]), ptr(self.part[po[1]:]), self.n_wg, s, tag="update_bwd")
+        call("harl_reduce_partials_multi", ptr(self.part), ptr(self.table), self.n_entries, self.n_wg, self.total_dwp,
+             ptr(self.dwp), s, tag="reduce_partials")
 
     # ---- backward: dz_L (in self.dz[0]) and dhead -> dense folded gradients self.dwp (UNSCALED sums over samples)
     def backward_trunk(self, X: torch.Tensor, idx: Optional[torch.Tensor], M: int, seq: Optional[dict] = None,

@@ -58,6 +58,9 @@ class VCritic:
         net.fold()
         Wp, bp = net._packs[-1]
         out = torch.empty(M, 1, **self.tpdv)
+        if net.fused_update_ok(None, train=False):
+            call("harl_update_values", *net.fused_args(x, M), ptr(out), stream(), tag="update_values")
+            return out, rnn_states_critic
         if not net.recurrent:
             net.forward_trunk(x, None, M, for_backward=False)
             call("harl_critic_head_values", ptr(net.xh[-1]), M, net.hidden_sizes[-1], ptr(Wp), ptr(bp), ptr(out), stream())
@@ -87,7 +90,13 @@ class VCritic:
                       local_count=(seq["L"] * seq["m"] if seq is not None else m))
         net._ensure_ws(max(m, 1))
         sc = net.scalars
-        if m > 0:
+        if m > 0 and net.fused_update_ok(idx, seq):  # three launches, every activation on chip (csrc/update.hip)
+            call("harl_update_fwd_critic", *net.fused_args(share_obs, m), ptr(value_preds), ptr(returns),
+                 ptr(vn.stats) if vn is not None else None, float(self.clip_param), int(self.use_clipped_value_loss),
+                 int(self.use_huber_loss), float(self.huber_delta), ptr(net.dz[0]), ptr(net.part_scalars),
+                 ptr(net.part[net._part_offs[-1]:]), net.n_wg, s, tag="update_fwd_critic")
+            net.backward_fused(m)
+        elif m > 0:
             net.forward_trunk(share_obs, idx, m, seq=seq)
             Wp, bp = net._packs[-1]
             fx, fmask, frstd, fh = net.feat()

@@ -284,6 +284,45 @@ int harl_trpo_kl_sum(const float *head_old, const float *head_new, const float *
                      void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Fused optimiser-step kernels for two equal-width hidden layers (H in {64, 128}) and inputs up to 64 wide, identity
+ * row order (csrc/update.hip).  They take the cached normalised-input image x0n (harl_mlp_x0n_wide) and keep every
+ * activation on chip: x_hat_1, x_hat_2, the ReLU masks and LayerNorm statistics are never written; x_hat_1 is recomputed
+ * from x0n in the backward launches.  Together they replace harl_mlp_fwd_fused2x + harl_actor_head_loss |
+ * harl_critic_head_loss + harl_mlp_dw_partials(hidden) + harl_mlp_bwd_dx, i.e. autograd through MLPBase + ACTLayer | v_out
+ * for one minibatch (algorithms/actors/happo.py:28-102, algorithms/critics/v_critic.py:116-157), and move ~1.9 KB per
+ * sample instead of ~4.5 KB.  Loss arguments as in harl_actor_head_loss / harl_critic_head_loss (idx = NULL, no padding).
+ *   harl_update_fwd_*  : forward, head, loss, head weight gradient, backward to dz2 (ATL(H), the only activation written);
+ *                        part_scalars rows [n_part_rows][HARL_PS_STRIDE], dw_part_head rows [n_part_rows][32*H + 32]
+ *                        (rows beyond the launch grid are cleared), logp_out as in harl_actor_head_loss.
+ *   harl_update_bwd    : dW_2' | db_2' partial rows into dw_part2 ([n_part_rows][H*H + H]) and dW_1' | db_1' into dw_part1
+ *                        ([n_part_rows][H*KP0 + H], KP0 = 32 or 64) from x0n and dz2.
+ *   harl_update_logp   : forward + log-probs (+ factor *= agg(exp(new - old)), head_out) -- harl_mlp_fwd_fused2x +
+ *                        harl_actor_head_logp without the x_hat_2 round trip (on_policy_ha_runner.py:66-124).
+ *   harl_update_values : forward + values (v_critic.py:54-73).
+ * harl_update_supported returns 1 when (D, H, act_dim) is inside the instantiated range (D <= 64, H in {64,128}, act_dim <= 8). */
+int harl_update_supported(int D, int H, int act_dim);
+int harl_update_fwd_actor(const float *x0n, long M, int D, int H, const float *W1p, const float *b1p, const float *W2p,
+                          const float *b2p, const float *Whp, const float *bhp, const float *log_std, float std_x_coef,
+                          float std_y_coef, int discrete, int act_dim, const float *actions, const float *avail,
+                          const float *old_logp, const float *adv, const double *adv_moments, const float *factor,
+                          const float *active, float clip_param, float entropy_coef, int agg_mean, int trpo,
+                          float *logp_out, float *dz2, float *part_scalars, float *dw_part_head, int n_part_rows,
+                          void *stream);
+int harl_update_logp(const float *x0n, long M, int D, int H, const float *W1p, const float *b1p, const float *W2p,
+                     const float *b2p, const float *Whp, const float *bhp, const float *log_std, float std_x_coef,
+                     float std_y_coef, int discrete, int act_dim, const float *actions, const float *avail,
+                     float *logp_out, const float *old_logp, float *factor, int agg_mean, float *head_out, void *stream);
+int harl_update_fwd_critic(const float *x0n, long M, int D, int H, const float *W1p, const float *b1p, const float *W2p,
+                           const float *b2p, const float *Whp, const float *bhp, const float *value_preds,
+                           const float *returns, const float *vn_stats, float clip_param, int use_clipped, int use_huber,
+                           float huber_delta, float *dz2, float *part_scalars, float *dw_part_head, int n_part_rows,
+                           void *stream);
+int harl_update_values(const float *x0n, long M, int D, int H, const float *W1p, const float *b1p, const float *W2p,
+                       const float *b2p, const float *Whp, const float *bhp, float *values, void *stream);
+int harl_update_bwd(const float *x0n, const float *dz2, long M, int D, int H, const float *W1p, const float *b1p,
+                    const float *W2p, float *dw_part1, float *dw_part2, int n_part_rows, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * GRU recurrent layer (models/base/rnn.py:8-81, recurrent_n = 1, H = 64), forward and BPTT.  A recurrent batch is L steps x m
  * sequences with row (l, j) at index l*m_pad + j (m_pad = m rounded up to 32); a wave owns 32 sequences for the whole chunk and
  * keeps the hidden state in registers.  xin / y / saved tensors are ATL(H) over L*m_pad rows; mask_rows[L*m_pad] are the

@@ -1012,3 +1012,72 @@ def check_generator_api(name: str) -> Dict[str, float]:
         out["chunk_critic_mismatch"] = run(lambda: oc.recurrent_generator(k, L), lambda: cb.recurrent_generator_critic(k, L), crec)
         out["naive_critic_mismatch"] = run(lambda: oc.naive_recurrent_generator(k), lambda: cb.naive_recurrent_generator_critic(k), crec)
     return out
+
+
+def check_fused_vs_layered(rows: int) -> Dict[str, float]:
+    """csrc/update.hip (HARL_FUSED_UPDATE=1) against the layer-by-layer kernels (=0) on the same data: unscaled folded
+    gradients, loss sums, first-epoch log-probs, log-prob pass + factor product; second fused run bit-identical."""
+    import os
+    sh = Shapes(T=rows, N=1, A=1, obs_dim=18, share_obs_dim=54, act_dim=5, discrete=False, hidden_sizes=[128, 128])
+    d = make_buffers(sh, 3)
+    actor, _, _ = _mk_actor(sh, 1)
+    critic, _, _ = _mk_critic(sh, 2)
+    obs = dev(d.obs[0][:-1].reshape(rows, -1))
+    act = dev(d.actions[0].reshape(rows, -1))
+    rng = np.random.default_rng(0)
+    adv = dev(rng.standard_normal(rows).astype(np.float32))
+    factor = dev((1 + 0.1 * rng.standard_normal(rows)).astype(np.float32))
+    active = dev((rng.random(rows) > 0.1).astype(np.float32))
+    so = dev(d.share_obs[:-1].reshape(rows, -1))
+    vp = dev(rng.standard_normal(rows).astype(np.float32))
+    ret = dev((vp.cpu().numpy() + rng.standard_normal(rows)).astype(np.float32))
+    prev = os.environ.get("HARL_FUSED_UPDATE")
+    got = {}
+    try:
+        os.environ["HARL_FUSED_UPDATE"] = "0"
+        actor.actor.fold()
+        lp0 = torch.empty(rows, actor.actor.act_w, device=DEV)
+        actor._logp_pass(obs, act, None, rows, lp0)
+        old_logp = (lp0 + dev(0.1 * rng.standard_normal((rows, actor.actor.act_w)).astype(np.float32))).contiguous()
+        for tag, mode in (("old", "0"), ("new", "1"), ("again", "1")):
+            os.environ["HARL_FUSED_UPDATE"] = mode
+            actor.actor.invalidate_caches()
+            critic.critic.invalidate_caches()
+            lp = torch.zeros(rows, actor.actor.act_w, device=DEV)
+            nblk = actor._forward_backward(obs, None, rows, act, None, old_logp, adv, None, factor, active, logp_out=lp)
+            sc = torch.zeros(_lib.PS_STRIDE, dtype=torch.float64, device=DEV)
+            call("harl_reduce_scalars", ptr(actor.actor.part_scalars), nblk, ptr(sc), stream())
+            lp2 = torch.empty(rows, actor.actor.act_w, device=DEV)
+            fac = factor.clone()
+            actor._logp_pass(obs, act, None, rows, lp2, old_logp=old_logp, factor=fac)
+            from harl_amd.valuenorm import ValueNorm
+            gvn = ValueNorm(1, device=DEV)
+            gvn.stats.copy_(dev(np.array([0.15, 0.85, 0.5], dtype=np.float32)))
+            taps = []
+            critic._grad_tap = lambda gr, s_: taps.append((gr.clone(), s_.clone()))
+            critic.critic.fold()
+            critic._update_core(so, None, rows, rows, vp, ret, None)
+            vals, _ = critic.get_values(so, None, None)
+            got[tag] = dict(dwp=actor.actor.dwp.clone(), sc=sc, lp=lp, lp2=lp2, fac=fac, cg=taps[0][0], csc=taps[0][1],
+                            vals=vals.clone())
+            # undo the critic's optimiser step so that every mode starts from the same weights
+            critic, _, _ = _mk_critic(sh, 2)
+    finally:
+        if prev is None:
+            os.environ.pop("HARL_FUSED_UPDATE", None)
+        else:
+            os.environ["HARL_FUSED_UPDATE"] = prev
+    torch.cuda.synchronize()
+
+    def vrel(a, b):
+        return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+    o, n, a = got["old"], got["new"], got["again"]
+    out = dict(actor_dwp_vec_rel=vrel(n["dwp"], o["dwp"]), actor_logp_epoch0_vec_rel=vrel(n["lp"], o["lp"]),
+               actor_logp_pass_vec_rel=vrel(n["lp2"], o["lp2"]), actor_factor_vec_rel=vrel(n["fac"], o["fac"]),
+               actor_loss_sums_rel=float(((n["sc"][:5] - o["sc"][:5]).abs() / o["sc"][:5].abs().clamp_min(1e-30)).max()),
+               critic_grad_vec_rel=vrel(n["cg"], o["cg"]), critic_values_vec_rel=vrel(n["vals"], o["vals"]),
+               critic_loss_sums_rel=float(((n["csc"][:2] - o["csc"][:2]).abs() / o["csc"][:2].abs().clamp_min(1e-30)).max()),
+               actor_rerun_bitwise_equal=float(torch.equal(n["dwp"], a["dwp"]) and torch.equal(n["sc"], a["sc"])),
+               critic_rerun_bitwise_equal=float(torch.equal(n["cg"], a["cg"])))
+    return out

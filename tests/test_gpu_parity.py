@@ -169,3 +169,33 @@ def test_buffer_generator_api_matches_reference_order(name):
     """Public *_generator_* methods of the buffers: same permutation draws, same gathered rows, reference tuple order."""
     for k, v in _G().check_generator_api(name).items():
         assert v == 0.0, (k, v)
+
+
+@pytest.mark.parametrize("i", [0, 1])
+def test_fused_update_kernels_single_update(i, monkeypatch):
+    """csrc/update.hip (HARL_FUSED_UPDATE=1): forward + loss + head gradient in one launch, weight gradients from the
+    recomputed x_hat_1 with transposes on the matrix pipe -- one actor and one critic update vs the oracle."""
+    monkeypatch.setenv("HARL_FUSED_UPDATE", "1")
+    G = _G()
+    _assert_all(G.check_gradients(G.FWD_SHAPES[i]), tol=TOL)
+    _assert_all(G.check_forward(G.FWD_SHAPES[i]), tol=TOL)
+
+
+@pytest.mark.parametrize("name", ["mpe_box_h64", "mpe_box_h128", "mpe_disc_h64", "box_mean_inactive_novn", "a2c_box_h64",
+                                  "mappo_box_h64"])
+def test_fused_update_kernels_train_golden(name, monkeypatch):
+    """Whole train() through the fused optimiser-step kernels vs the reference's golden vectors."""
+    monkeypatch.setenv("HARL_FUSED_UPDATE", "1")
+    _assert_all(_G().check_train_golden(name), tol=TOL_TRAIN)
+
+
+def test_fused_update_kernels_many_slabs_per_wave():
+    """The fused kernels against the layer-by-layer kernels at a size where every wave walks several slabs (the golden
+    cases are a slab or two per wave): folded gradients, loss sums, log-probs and the factor product, plus bit-exact
+    run-to-run determinism."""
+    res = _G().check_fused_vs_layered(32 * 8 * 256 * 2 + 7 * 32 + 3)
+    for k, v in res.items():
+        if "bitwise" in k:
+            assert v == 1.0, (k, v)
+        else:
+            assert v < 2e-5, (k, v)

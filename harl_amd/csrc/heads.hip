@@ -28,14 +28,23 @@ namespace {
 // actor head
 // =============================================================================================
 template <int H, int DAP, bool DISCRETE, bool TRAIN, bool FUSE = false>
-__global__ __launch_bounds__(WG_THREADS, FUSE ? 2 : 1) void k_actor_head(ActorArgs A) {
+// (min waves per SIMD: 2 for the fused kernels with <= 8 head outputs; wider heads need more than 256 registers -- at
+// 256 hipcc spills hundreds of them -- and run one wave per SIMD)
+__global__ __launch_bounds__(WG_THREADS, (FUSE && DAP <= 8) ? 2 : 1) void k_actor_head(ActorArgs A) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float *whl = lds;                    // [2][H/2][DAP]
   float *cst = whl + 2 * (H / 2) * DAP;  // bias, sigma, logsigma, dsigma_dlogstd, rowsum, 1/sigma, 1/sigma^2  [DAP each]
   float *red = cst + 7 * DAP;          // [4][PS_STRIDE]
   float *dwl = red + 4 * PS_STRIDE;    // FUSE: [4 waves][HeadDw::WAVE_FLOATS] staging tiles (16-byte aligned)
+  // FUSE with <= 8 head outputs: the head weight gradient accumulates in a wave-private LDS tile (head_dw_step_lds), and
+  // the registers that frees hold the NEXT slab's x_hat_L while this slab is being worked on
+  constexpr bool LDSACC = FUSE && DAP <= 8;
+  constexpr int HROWS = DAP <= 8 ? DAP : 8;
+  float *hacc = dwl + WAVES_PER_WG * HeadDw<H>::WAVE_FLOATS;  // LDSACC: [4 waves][HROWS][H]
   if (FUSE)
     for (int e = threadIdx.x; e < WAVES_PER_WG * HeadDw<H>::WAVE_FLOATS; e += WG_THREADS) dwl[e] = 0.f;
+  if (LDSACC)
+    for (int e = threadIdx.x; e < WAVES_PER_WG * HROWS * H; e += WG_THREADS) hacc[e] = 0.f;
   stage_head<H, DAP>(whl, cst, A.Whp, A.bhp, A.act_dim);
   if (!DISCRETE) {
     for (int e = threadIdx.x; e < DAP; e += WG_THREADS) {
@@ -74,23 +83,41 @@ __global__ __launch_bounds__(WG_THREADS, FUSE ? 2 : 1) void k_actor_head(ActorAr
   float sc[8 + DAP];
 #pragma unroll
   for (int k = 0; k < 8 + DAP; ++k) sc[k] = 0.f;
-  f32x16 dwacc[FUSE ? H / 32 : 1];
+  f32x16 dwacc[(FUSE && !LDSACC) ? H / 32 : 1];
   float dbacc[FUSE ? DAP : 1];
   float *tx = dwl + (threadIdx.x >> 6) * HeadDw<H>::WAVE_FLOATS, *td = tx + SLAB * HeadDw<H>::HX;
+  float *hw = hacc + (threadIdx.x >> 6) * (HROWS * H);
   if (FUSE) {
+    if constexpr (!LDSACC) {
 #pragma unroll
-    for (int n = 0; n < H / 32; ++n)
+      for (int n = 0; n < H / 32; ++n)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) dwacc[n][r] = 0.f;
+        for (int r = 0; r < 16; ++r) dwacc[n][r] = 0.f;
+    }
 #pragma unroll
     for (int d = 0; d < DAP; ++d) dbacc[d] = 0.f;
   }
 
-  for (long slab = (long)blockIdx.x * WAVES_PER_WG + wave; slab < A.n_slabs; slab += (long)gridDim.x * WAVES_PER_WG) {
+  // PREF: the NEXT slab's x_hat_L (16 float4 per lane) in flight while this slab's head / loss / backward math runs.
+  // Measured on MI355X: with the 64 extra registers the Gaussian / Categorical kernels spill 37-56 registers at the
+  // 256-register budget of two waves per SIMD and run SLOWER (0.40 vs 0.31 ms at 819 200 samples), so the actor kernels
+  // only take the LDS accumulators (no spills at all); the critic kernel (one head output) has room and prefetches.
+  constexpr bool PREF = false;
+  const long slab_first = (long)blockIdx.x * WAVES_PER_WG + wave, slab_step = (long)gridDim.x * WAVES_PER_WG;
+  f32x4 xnext[PREF ? H / 8 : 1];
+  if constexpr (PREF)
+    if (slab_first < A.n_slabs) head_load_regs<H>(A.xL, slab_first, lane, xnext);
+  for (long slab = slab_first; slab < A.n_slabs; slab += slab_step) {
     float z[DAP];
     f32x4 xs[TRAIN ? H / 8 : 1];
     if constexpr (TRAIN) {
-      head_load_regs<H>(A.xL, slab, lane, xs);
+      if constexpr (PREF) {
+#pragma unroll
+        for (int q = 0; q < H / 8; ++q) xs[q] = xnext[q];
+        head_load_regs<H>(A.xL, slab + slab_step < A.n_slabs ? slab + slab_step : slab, lane, xnext);
+      } else {
+        head_load_regs<H>(A.xL, slab, lane, xs);
+      }
       head_fwd_regs<H, DAP>(xs, whl_h, cst, z);
     } else {
       head_fwd_stream<H, DAP>(A.xL, slab, lane, whl_h, cst, z);
@@ -100,7 +127,8 @@ __global__ __launch_bounds__(WG_THREADS, FUSE ? 2 : 1) void k_actor_head(ActorAr
     if (!actor_sample<DAP, DISCRETE, TRAIN>(A, cst, z, slab, lane, adv_mean, adv_den, sc, dzh, s1, s2)) continue;
     const long j = slab * SLAB + i;
     if constexpr (FUSE) {  // head weight gradient right here (x_hat_L and dhead are both in registers)
-      head_dw_step<H, DAP>(xs, dzh, tx, td, lane, dwacc);
+      if constexpr (LDSACC) head_dw_step_lds<H, DAP, HROWS>(xs, dzh, tx, td, lane, hw);
+      else head_dw_step<H, DAP>(xs, dzh, tx, td, lane, dwacc);
       if (h == 0) {
 #pragma unroll
         for (int d = 0; d < DAP; ++d) dbacc[d] += dzh[d];
@@ -122,7 +150,11 @@ __global__ __launch_bounds__(WG_THREADS, FUSE ? 2 : 1) void k_actor_head(ActorAr
   }
 
   if (TRAIN) block_reduce_store<8 + DAP>(sc, red, A.part_scalars + (long)blockIdx.x * PS_STRIDE);
-  if constexpr (FUSE) head_dw_finish<H, DAP>(dwacc, dbacc, dwl, A.dw_part + (long)blockIdx.x * HeadDw<H>::OUT_FLOATS);
+  if constexpr (FUSE) {
+    float *outp = A.dw_part + (long)blockIdx.x * HeadDw<H>::OUT_FLOATS;
+    if constexpr (LDSACC) head_dw_finish_lds<H, DAP, HROWS, WAVES_PER_WG>(hacc, dbacc, dwl, outp);
+    else head_dw_finish<H, DAP>(dwacc, dbacc, dwl, outp);
+  }
 }
 
 // =============================================================================================
@@ -137,8 +169,13 @@ __global__ __launch_bounds__(WG_THREADS, FUSE ? 2 : 1) void k_critic_head(Critic
   float *cst = whl + 2 * (H / 2) * DAP;
   float *red = cst + 5 * DAP;
   float *dwl = red + 4 * PS_STRIDE;
-  if (FUSE)
+  constexpr bool LDSACC = FUSE;  // one head output: the weight gradient is ONE row, accumulated in wave-private LDS
+  constexpr int HROWS = 1;
+  float *hacc = dwl + WAVES_PER_WG * HeadDw<H>::WAVE_FLOATS;  // [4 waves][1][H]
+  if (FUSE) {
     for (int e = threadIdx.x; e < WAVES_PER_WG * HeadDw<H>::WAVE_FLOATS; e += WG_THREADS) dwl[e] = 0.f;
+    for (int e = threadIdx.x; e < WAVES_PER_WG * HROWS * H; e += WG_THREADS) hacc[e] = 0.f;
+  }
   stage_head<H, DAP>(whl, cst, A.Whp, A.bhp, 1);
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -155,23 +192,29 @@ __global__ __launch_bounds__(WG_THREADS, FUSE ? 2 : 1) void k_critic_head(Critic
   float sc[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) sc[k] = 0.f;
-  f32x16 dwacc[FUSE ? H / 32 : 1];
   float dbacc[FUSE ? DAP : 1];
   float *tx = dwl + (threadIdx.x >> 6) * HeadDw<H>::WAVE_FLOATS, *td = tx + SLAB * HeadDw<H>::HX;
+  float *hw = hacc + (threadIdx.x >> 6) * (HROWS * H);
   if (FUSE) {
-#pragma unroll
-    for (int n = 0; n < H / 32; ++n)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) dwacc[n][r] = 0.f;
 #pragma unroll
     for (int d = 0; d < DAP; ++d) dbacc[d] = 0.f;
   }
 
-  for (long slab = (long)blockIdx.x * WAVES_PER_WG + wave; slab < A.n_slabs; slab += (long)gridDim.x * WAVES_PER_WG) {
+  const long slab_first = (long)blockIdx.x * WAVES_PER_WG + wave, slab_step = (long)gridDim.x * WAVES_PER_WG;
+  f32x4 xnext[LDSACC ? H / 8 : 1];  // next slab's x_hat_L, in flight during this slab's math (see k_actor_head)
+  if constexpr (LDSACC)
+    if (slab_first < A.n_slabs) head_load_regs<H>(A.xL, slab_first, lane, xnext);
+  for (long slab = slab_first; slab < A.n_slabs; slab += slab_step) {
     float z[DAP];
     f32x4 xs[TRAIN ? H / 8 : 1];
     if constexpr (TRAIN) {
-      head_load_regs<H>(A.xL, slab, lane, xs);
+      if constexpr (LDSACC) {
+#pragma unroll
+        for (int q = 0; q < H / 8; ++q) xs[q] = xnext[q];
+        head_load_regs<H>(A.xL, slab + slab_step < A.n_slabs ? slab + slab_step : slab, lane, xnext);
+      } else {
+        head_load_regs<H>(A.xL, slab, lane, xs);
+      }
       head_fwd_regs<H, DAP>(xs, whl_h, cst, z);
     } else {
       head_fwd_stream<H, DAP>(A.xL, slab, lane, whl_h, cst, z);
@@ -182,7 +225,7 @@ __global__ __launch_bounds__(WG_THREADS, FUSE ? 2 : 1) void k_critic_head(Critic
     const long j = slab * SLAB + i;
     const float dzh[DAP] = {dv, 0.f, 0.f, 0.f};
     if constexpr (FUSE) {
-      head_dw_step<H, DAP>(xs, dzh, tx, td, lane, dwacc);
+      head_dw_step_lds<H, DAP, HROWS>(xs, dzh, tx, td, lane, hw);
       if (h == 0) dbacc[0] += dv;
     } else {
       float *dh = A.dhead + j * DHEAD_LD + 16 * h;
@@ -194,7 +237,8 @@ __global__ __launch_bounds__(WG_THREADS, FUSE ? 2 : 1) void k_critic_head(Critic
                             dv * (v - cst[0]), A.dzL);
   }
   if (TRAIN) block_reduce_store<8>(sc, red, A.part_scalars + (long)blockIdx.x * PS_STRIDE);
-  if constexpr (FUSE) head_dw_finish<H, DAP>(dwacc, dbacc, dwl, A.dw_part + (long)blockIdx.x * HeadDw<H>::OUT_FLOATS);
+  if constexpr (FUSE)
+    head_dw_finish_lds<H, DAP, HROWS, WAVES_PER_WG>(hacc, dbacc, dwl, A.dw_part + (long)blockIdx.x * HeadDw<H>::OUT_FLOATS);
 }
 
 // =============================================================================================
@@ -403,6 +447,7 @@ void launch_actor(const ActorArgs &A, int grid, hipStream_t s) {
     if (A.dw_part) {
       size_t fl = (size_t)WAVES_PER_WG * HeadDw<H>::WAVE_FLOATS;
       if (fl < (size_t)HeadDw<H>::OUT_FLOATS) fl = HeadDw<H>::OUT_FLOATS;
+      if (DAP <= 8) fl = (size_t)WAVES_PER_WG * HeadDw<H>::WAVE_FLOATS + (size_t)WAVES_PER_WG * DAP * H;  // + LDS accumulators
       const size_t shm = base + fl * sizeof(float);
       allow_big_lds(k_actor_head<H, DAP, DISC, true, true>, shm);
       hipLaunchKernelGGL((k_actor_head<H, DAP, DISC, true, true>), dim3(grid), dim3(WG_THREADS), shm, s, A);
@@ -511,8 +556,7 @@ extern "C" int harl_critic_head_loss(const float *xL, const uint32_t *relu_mask,
 #define CL(Hv)                                                                                                     \
   if (H == Hv) {                                                                                                   \
     if (dw_part) {                                                                                                 \
-      size_t fl = (size_t)WAVES_PER_WG * HeadDw<Hv>::WAVE_FLOATS;                                                  \
-      if (fl < (size_t)HeadDw<Hv>::OUT_FLOATS) fl = HeadDw<Hv>::OUT_FLOATS;                                        \
+      const size_t fl = (size_t)WAVES_PER_WG * HeadDw<Hv>::WAVE_FLOATS + (size_t)WAVES_PER_WG * Hv;  /* + LDS acc */  \
       const size_t shm = base + fl * sizeof(float);                                                                \
       allow_big_lds(k_critic_head<Hv, true, true>, shm);                                                           \
       hipLaunchKernelGGL((k_critic_head<Hv, true, true>), dim3(grid), dim3(WG_THREADS), shm, s, A);                \

@@ -254,6 +254,89 @@ __device__ __forceinline__ void head_dw_step(const f32x4 (&xs)[H / 8], const flo
   }
 }
 
+// Variant with the accumulators in a wave-private LDS tile hw[HROWS][H] (HROWS = number of head outputs that can be non-zero,
+// <= 8): the 64 persistent accumulator registers of head_dw_step become 32 transient ones per 64-feature pass, which is what
+// lets the loss kernels keep the NEXT slab's x_hat_L in flight (they are latency-bound otherwise).  Row d of a 32x32 tile
+// sits in register r = d & 3 of lane half h = d >> 2 (d < 8).
+template <int H, int DAP, int HROWS>
+__device__ __forceinline__ void head_dw_step_lds(const f32x4 (&xs)[H / 8], const float (&dzh)[DAP], float *tx, float *td,
+                                                 int lane, float *hw) {
+  constexpr int HX = HeadDw<H>::HX, TD = HeadDw<H>::TD;
+  static_assert(HROWS <= 8, "rows 0..7 of a tile live in registers 0..3 of both lane halves");
+  const int i = lane & 31, h = lane >> 5;
+  if (h == 0) {
+#pragma unroll
+    for (int d = 0; d < DAP; ++d) td[i * TD + d] = dzh[d];  // columns >= DAP stay zero (cleared once)
+  }
+#pragma unroll
+  for (int half = 0; half < H / 64; ++half) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      *reinterpret_cast<f32x4 *>(tx + i * HX + 32 * (q >> 2) + 8 * (q & 3) + 4 * h) = xs[8 * half + q];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private hand-off between lanes (see mlp.hip)
+    __builtin_amdgcn_wave_barrier();
+    f32x16 acc[2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+#pragma unroll
+    for (int t = 0; t < SLAB / 2; ++t) {
+      const float a = td[(2 * t + h) * TD + i];
+#pragma unroll
+      for (int n = 0; n < 2; ++n) {
+        const float b = tx[(2 * t + h) * HX + 32 * n + i];
+        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[n], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        // plain read-modify-write: every (row, column) of the wave's tile belongs to exactly one lane, and a wave's LDS
+        // accesses execute in order (ds_add_f32 measured slower here: LDS atomics run at a fraction of the ds_write rate)
+        if (r < HROWS && h == 0) hw[r * H + 64 * half + 32 * n + i] += acc[n][r];
+        if (4 + r < HROWS && h == 1) hw[(4 + r) * H + 64 * half + 32 * n + i] += acc[n][r];
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();  // every lane is done reading tx / td before the next pass overwrites them
+  }
+}
+
+// end of kernel, LDS-accumulator variant: the waves' tiles hacc[NWAVES][HROWS][H] and bias sums in fixed order -> ONE partial
+// row dWp[32][H] | dbp[32] (rows >= HROWS are zero).  `dbl` = NWAVES * PS_STRIDE floats of scratch LDS.
+template <int H, int DAP, int HROWS, int NWAVES>
+__device__ __forceinline__ void head_dw_finish_lds(const float *hacc, float (&dbacc)[DAP], float *dbl,
+                                                   float *__restrict__ out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float dbs[DAP];
+#pragma unroll
+  for (int d = 0; d < DAP; ++d) dbs[d] = wave_reduce_sum(dbacc[d]);
+  __syncthreads();  // every wave's LDS accumulation is complete; dbl is free
+  if (lane == 0) {
+#pragma unroll
+    for (int d = 0; d < DAP; ++d) dbl[wave * PS_STRIDE + d] = dbs[d];
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < HeadDw<H>::OUT_FLOATS; e += 64 * NWAVES) {
+    float t = 0.f;
+    if (e < 32 * H) {
+      const int row = e / H;
+      if (row < HROWS) {
+#pragma unroll
+        for (int w = 0; w < NWAVES; ++w) t += hacc[(w * HROWS + row) * H + (e - row * H)];
+      }
+    } else {
+      const int d = e - 32 * H;
+      if (d < DAP) {
+#pragma unroll
+        for (int w = 0; w < NWAVES; ++w) t += dbl[w * PS_STRIDE + d];
+      }
+    }
+    out[e] = t;
+  }
+}
+
 // end of kernel: combine the four waves' accumulators through LDS (one wave at a time, fixed order -> deterministic)
 // and write this workgroup's partial in the layout harl_reduce_partials_multi expects.
 template <int H, int DAP>

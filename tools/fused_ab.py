@@ -130,6 +130,7 @@ if __name__ == "__main__":
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--skip-oracle", action="store_true")
     ap.add_argument("--only-full", action="store_true")
+    ap.add_argument("--no-mid", action="store_true")
     a = ap.parse_args()
     out = {}
     if not a.skip_oracle:
@@ -137,6 +138,7 @@ if __name__ == "__main__":
     if not a.only_full:
         out["ab_small_ragged"] = ab(32 * 37 + 5, 2)
         out["ab_disc_small"] = ab(4099, 2, discrete=True)
-    out["ab_mid"] = ab(32 * 8 * 256 * 2 + 7 * 32 + 3, 2)
+    if not a.no_mid:
+        out["ab_mid"] = ab(32 * 8 * 256 * 2 + 7 * 32 + 3, 2)
     out["ab_full"] = ab(a.rows, a.reps)
     print(json.dumps(out, indent=1))

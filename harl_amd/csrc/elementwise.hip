@@ -384,22 +384,22 @@ __global__ __launch_bounds__(64) void k_unfold(const float *__restrict__ dWp, co
   int k = blockIdx.x;
   float g = gamma ? gamma[k] : 1.f;
   float be = beta ? beta[k] : 0.f;
-  float sg = 0.f, sb = 0.f;
+  double sg = 0.0, sb = 0.0;  // double: heavy cancellation over o (see k_reduce_partials_multi)
   for (int o = threadIdx.x; o < out_dim; o += 64) {
     float dwp = dWp[(long)o * ldp + k];
     float dbo = dbp[o];
     float w = W[(long)o * in_dim + k];
     dW[(long)o * in_dim + k] = dwp * g + dbo * be;
-    sg += w * dwp;
-    sb += w * dbo;
+    sg += (double)w * (double)dwp;
+    sb += (double)w * (double)dbo;
     if (k == 0) db[o] = dbo;
   }
   if (dgamma) {
-    sg = wave_reduce_sum(sg);
-    sb = wave_reduce_sum(sb);
+    sg = wave_reduce_sum_d(sg);
+    sb = wave_reduce_sum_d(sb);
     if (threadIdx.x == 0) {  // several Linears may share one LayerNorm (the three GRU gate blocks): accumulate
-      dgamma[k] = accumulate ? dgamma[k] + sg : sg;
-      dbeta[k] = accumulate ? dbeta[k] + sb : sb;
+      dgamma[k] = accumulate ? (float)((double)dgamma[k] + sg) : (float)sg;
+      dbeta[k] = accumulate ? (float)((double)dbeta[k] + sb) : (float)sb;
     }
   }
 }
@@ -499,23 +499,26 @@ constexpr int TS = 12;
 // dependent-latency-bound strided loads, so it is n_wg / 32 loads deep instead of n_wg / 8 (37 -> ~15 us at 512 rows).
 __global__ __launch_bounds__(256) void k_reduce_partials_multi(const float *__restrict__ part, const int *__restrict__ tab,
                                                                int n_layers, int n_wg, float *__restrict__ dwp) {
-  __shared__ float sh[4][64];
+  // The per-workgroup partials are summed in DOUBLE (fixed order): the LayerNorm-affine gradients are later formed as
+  // sum_o W[o][k] dWp[o][k] -- a dot product with heavy cancellation -- so rounding of dWp is amplified ~sqrt(H) times in
+  // them; the rows are fp32 sums over a few thousand samples each, the cross-row sum adds nothing to that.
+  __shared__ double sh[4][64];
   const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
   long e = (long)blockIdx.x * 64 + lane;
-  float total = 0.f;
+  double total = 0.0;
   long out_idx = -1;
   for (int l = 0; l < n_layers; ++l) {
     const int *t = tab + l * TS;
     const long elems = (long)t[10] * t[9] + t[10];
     if (e < elems) {
       const float *p = part + (long)t[11] + e;  // part_off is in floats
-      float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      double acc[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
       int w = rg;
       for (; w + 28 < n_wg; w += 32) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) acc[u] += p[(long)(w + 4 * u) * elems];
+        for (int u = 0; u < 8; ++u) acc[u] += (double)p[(long)(w + 4 * u) * elems];
       }
-      for (; w < n_wg; w += 4) acc[0] += p[(long)w * elems];
+      for (; w < n_wg; w += 4) acc[0] += (double)p[(long)w * elems];
       total = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
       out_idx = t[8] + e;
       break;
@@ -524,7 +527,7 @@ __global__ __launch_bounds__(256) void k_reduce_partials_multi(const float *__re
   }
   sh[rg][lane] = total;
   __syncthreads();
-  if (rg == 0 && out_idx >= 0) dwp[out_idx] = (sh[0][lane] + sh[1][lane]) + (sh[2][lane] + sh[3][lane]);
+  if (rg == 0 && out_idx >= 0) dwp[out_idx] = (float)((sh[0][lane] + sh[1][lane]) + (sh[2][lane] + sh[3][lane]));
 }
 
 extern "C" int harl_reduce_partials_multi(const float *part, const int *table, int n_layers, int n_wg, long total_elems,
@@ -617,7 +620,7 @@ __global__ __launch_bounds__(ADAM_THREADS) void k_adam_fold(
       const int K = t[5];
       for (int k = gw - wslot; k < K; k += gnw) {
         if (k < 0) continue;
-        float sg = 0.f, sb = 0.f;
+        double sg = 0.0, sb = 0.0;  // double: these dot products cancel heavily (see k_reduce_partials_multi)
         for (int l2 = l; l2 < n_layers; ++l2) {
           const int *t2 = tab + l2 * TS;
           if (t2[2] != go) continue;
@@ -625,16 +628,16 @@ __global__ __launch_bounds__(ADAM_THREADS) void k_adam_fold(
           const float *dW_ = dwp + t2[8];
           const float *db_ = dW_ + (long)op * kp;
           for (int o = ln; o < O; o += 64) {
-            const float w = p[t2[0] + o * K + k];
-            sg += w * dW_[(long)o * kp + k];
-            sb += w * db_[o];
+            const double w = p[t2[0] + o * K + k];
+            sg += w * (double)dW_[(long)o * kp + k];
+            sb += w * (double)db_[o];
           }
         }
-        sg = wave_reduce_sum(sg);
-        sb = wave_reduce_sum(sb);
+        sg = wave_reduce_sum_d(sg);
+        sb = wave_reduce_sum_d(sb);
         if (ln == 0) {
-          g[go + k] = sg;
-          g[t[3] + k] = sb;
+          g[go + k] = (float)sg;
+          g[t[3] + k] = (float)sb;
         }
       }
       wslot = (wslot + K) % gnw;  // spread the columns of successive LayerNorms over different waves

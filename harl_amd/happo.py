@@ -161,6 +161,7 @@ class HAPPO(OnPolicyBase):
         self._surrogate_mode = 0  # harl_actor_head_loss `trpo` argument: 0 = clipped (HAPPO)
         self._info = torch.zeros(4, **self.tpdv)  # sums of policy_loss, dist_entropy, grad_norm, ratio
         self._grad_tap = None
+        self._trace = None  # test hook: list receiving a clone of the running statistics after every optimiser step
 
     # ---- one optimiser step on rows idx[0..m) of the flat [T*N, .] tensors (happo.py:28-102) ---------
     def _forward_backward(self, obs, idx, m, actions, avail, old_logp, adv, adv_moments, factor, active, seq=None,
@@ -216,6 +217,8 @@ class HAPPO(OnPolicyBase):
         ls_off = -1 if net.discrete else net.offsets["act.action_out.log_std"][0]
         self.actor_optimizer.step(0, 0.0, self.use_max_grad_norm, self.max_grad_norm, self._info, ls_off, net.act_dim,
                                   **ps_kw)
+        if self._trace is not None:  # test hook: per-update statistics = differences of these snapshots (no host sync)
+            self._trace.append(self._info.clone())
         if self._grad_tap is not None:  # test hook: scaled, pre-clip gradient of this update (host sync)
             self._grad_tap(net.flat_grad * float(1.0 / sc[1].item()), sc.clone())
 

@@ -42,6 +42,7 @@ class VCritic:
         self.shard = None
         self._info = torch.zeros(2, **self.tpdv)  # sums of value_loss, critic_grad_norm
         self._grad_tap = None
+        self._trace = None  # test hook: snapshots of the running statistics after every optimiser step
 
     def lr_decay(self, episode, episodes):
         lr = self.critic_lr - (self.critic_lr * ((episode - 1) / float(episodes)))
@@ -122,6 +123,8 @@ class VCritic:
         # loss = mean over the (global) minibatch, times value_loss_coef before backward (v_critic.py:112,146)
         scale = float(self.value_loss_coef) / float(m_global)
         self.critic_optimizer.step(1, scale, self.use_max_grad_norm, self.max_grad_norm, self._info, **ps_kw)
+        if self._trace is not None:
+            self._trace.append(self._info.clone())
         if self._grad_tap is not None:
             self._grad_tap(net.flat_grad * scale, sc.clone())
 

@@ -142,15 +142,35 @@ class OracleValueNorm:
         }
 
     def load_state(self, s) -> None:
-        self.running_mean = torch.as_tensor(np.array(s["running_mean"], dtype=np.float32)).reshape(1).clone()
-        self.running_mean_sq = torch.as_tensor(np.array(s["running_mean_sq"], dtype=np.float32)).reshape(1).clone()
-        self.debiasing_term = torch.as_tensor(np.array(s["debiasing_term"], dtype=np.float32)).reshape(()).clone()
+        # (the reference's state is float32; the values are rounded to float32 first in every working precision)
+        f = lambda k: torch.as_tensor(np.array(s[k], dtype=np.float32)).to(WORK_DTYPE)  # noqa: E731
+        self.running_mean = f("running_mean").reshape(1).clone()
+        self.running_mean_sq = f("running_mean_sq").reshape(1).clone()
+        self.debiasing_term = f("debiasing_term").reshape(()).clone()
+
+
+# Working precision.  float32 = the reference's arithmetic (what the goldens pin).  oracle/gen_noise_floor.py re-runs the
+# same update in float64 to measure how far the reference's OWN fp32 results sit from exact arithmetic, case by case
+# (tests/golden/noise/*.npz): the yardstick for the GPU path's tolerances on ill-conditioned quantities.
+WORK_DTYPE = torch.float32
+
+
+STEP_HOOK = None  # callable(net) invoked after every Adam step (sensitivity measurements only)
+
+
+def set_work_dtype(dt) -> None:
+    global WORK_DTYPE
+    WORK_DTYPE = dt
+
+
+def _np_work():
+    return np.float64 if WORK_DTYPE == torch.float64 else np.float32
 
 
 def _t(x) -> torch.Tensor:
     if isinstance(x, np.ndarray):
         x = torch.from_numpy(x)
-    return x.to(torch.float32)
+    return x.to(WORK_DTYPE)
 
 
 # --------------------------------------------------------------------------------------
@@ -317,7 +337,7 @@ class _Net:
     """Parameter dict + torch.optim.Adam, in the reference's parameters() order."""
 
     def __init__(self, state_dict: Dict[str, torch.Tensor], lr: float, eps: float, weight_decay: float):
-        self.p = {k: v.detach().clone().to(torch.float32).requires_grad_(True) for k, v in state_dict.items()}
+        self.p = {k: v.detach().clone().to(WORK_DTYPE).requires_grad_(True) for k, v in state_dict.items()}
         self.opt = torch.optim.Adam(list(self.p.values()), lr=lr, eps=eps, weight_decay=weight_decay)
 
     def params(self) -> List[torch.Tensor]:
@@ -341,6 +361,8 @@ def _grad_norm_step(net: _Net, cfg: PathConfig) -> torch.Tensor:
                 s += q.grad.norm() ** 2
         gn = torch.tensor(math.sqrt(s))
     net.opt.step()
+    if STEP_HOOK is not None:  # oracle/gen_noise_floor.py: rounding-level noise injected after every optimiser step
+        STEP_HOOK(net)
     return gn
 
 
@@ -469,8 +491,8 @@ class OracleMAPPO(OracleHAPPO):
 # V critic   (v_critic.py)
 # --------------------------------------------------------------------------------------
 def huber(e: torch.Tensor, d: float) -> torch.Tensor:  # models_tools.py:64-68
-    a = (abs(e) <= d).float()
-    b = (abs(e) > d).float()
+    a = (abs(e) <= d).to(e.dtype)
+    b = (abs(e) > d).to(e.dtype)
     return a * e**2 / 2 + b * d * (abs(e) - d / 2)
 
 
@@ -687,7 +709,7 @@ def ha_train(
     """Returns (actor_train_infos in update order, critic_train_info, extras)."""
     T, N = actor_buffers[0].actions.shape[:2]
     A = len(actors)
-    factor = np.ones((T, N, 1), dtype=np.float32)
+    factor = np.ones((T, N, 1), dtype=_np_work())
     advantages = advantages_from_returns(critic_buffer.returns, critic_buffer.value_preds, vn)
     fp = getattr(critic_buffer, "fp", False)
     if fp:  # global advantage normalisation over all agents' active entries (on_policy_ha_runner.py:36-45)
@@ -810,7 +832,7 @@ class OracleHATRPO:
 
     def __init__(self, state_dict, cfg: PathConfig, tcfg: TrpoConfig):
         self.cfg, self.tcfg = cfg, tcfg
-        self.p = {k: v.detach().clone().to(torch.float32).requires_grad_(True) for k, v in state_dict.items()}
+        self.p = {k: v.detach().clone().to(WORK_DTYPE).requires_grad_(True) for k, v in state_dict.items()}
         self.trace: List[dict] = []
 
     def params(self):

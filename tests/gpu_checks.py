@@ -17,7 +17,7 @@ from harl_amd import _lib
 from harl_amd._lib import call, ptr, stream
 from harl_amd.synthetic import Shapes, actor_param_shapes, critic_param_shapes, make_buffers, synthetic_state_dict
 from oracle import harl_oracle as O
-from tests.helpers import GoldenCase, rel_err, vec_rel_err
+from tests.helpers import GoldenCase, excess, load_noise, rel_err, vec_excess, vec_rel_err
 
 DEV = torch.device("cuda:0")
 
@@ -715,6 +715,14 @@ def check_train_golden(name: str) -> Dict[str, float]:
         out["returns_mismatch"] = float(np.sum(cb.returns.cpu().numpy()[:T] != z["returns"][:T]))
         out["advantages_mismatch"] = float(np.sum(cb.advantages.cpu().numpy() != z["advantages"]))
         r.prep_training()
+        traced = case.algo_name != "hatrpo"
+        if traced:  # per-update statistics (the goldens carry the reference's actor_trace / critic_trace)
+            uniq = []
+            for a_ in r.actor:
+                if not any(a_ is u for u in uniq):
+                    uniq.append(a_)
+                    a_._trace = []
+            r.critic._trace = []
         infos, cinfo = r.train()
         torch.cuda.synchronize()
     finally:
@@ -752,21 +760,60 @@ def check_train_golden(name: str) -> Dict[str, float]:
             pos += 1
     out["perm_mismatch"] = float(bad)
     gold = z["actor_infos"]
+    nz = load_noise(name)  # the same update in float64 (oracle/gen_noise_floor.py): how exact the reference's own figures are
+    assert nz is not None, f"tests/golden/noise/{name}.npz missing: run oracle/gen_noise_floor.py"
     if case.algo_name == "hatrpo":
         got = np.array([[i["kl"], i["loss_improve"], i["expected_improve"], i["dist_entropy"], i["ratio"]] for i in infos])
         for c, nm in enumerate(("kl", "loss_improve", "expected_improve", "entropy", "ratio")):
-            out[f"actor_{nm}_rel"] = rel_err(got[:, c], gold[:, c])
+            out[f"_actor_{nm}_rel"] = rel_err(got[:, c], gold[:, c])
+            out[f"actor_{nm}_excess"] = excess(got[:, c], gold[:, c], nz["actor_infos"][:, c], nz["sens_actor_infos"][:, c])
     else:
         got = np.array([[i["policy_loss"], i["dist_entropy"], i["actor_grad_norm"], i["ratio"]] for i in infos])
-        out["actor_policy_loss_rel"] = rel_err(got[:, 0], gold[:, 0])
-        out["actor_entropy_rel"] = rel_err(got[:, 1], gold[:, 1])
-        out["actor_gradnorm_rel"] = rel_err(got[:, 2], gold[:, 2])
-        out["actor_ratio_rel"] = rel_err(got[:, 3], gold[:, 3])
-    out["critic_value_loss_rel"] = rel_err(cinfo["value_loss"], z["critic_info"][0])
-    out["critic_gradnorm_rel"] = rel_err(cinfo["critic_grad_norm"], z["critic_info"][1])
+        for c, nm in enumerate(("policy_loss", "entropy", "gradnorm", "ratio")):
+            out[f"_actor_{nm}_rel"] = rel_err(got[:, c], gold[:, c])
+            out[f"actor_{nm}_excess"] = excess(got[:, c], gold[:, c], nz["actor_infos"][:, c], nz["sens_actor_infos"][:, c])
+    if traced and "actor_trace" in z.files and not getattr(case, "share_param", False):
+        # per-update parity: the k-th optimiser step of every agent against the reference's k-th step of that agent
+        # (policy_loss, dist_entropy, grad_norm, ratio), and the critic's steps (value_loss, grad_norm)
+        gt, nt, st = z["actor_trace"], nz["actor_trace"], nz["sens_actor_trace"]
+        first, worst, wkey, exc = 0.0, 0.0, "", 0.0
+        for a in range(case.shapes.A):
+            ga, na, sa = gt[gt[:, 0] == a][:, 1:], nt[nt[:, 0] == a][:, 1:], st[nt[:, 0] == a][:, 1:]
+            tr = r.actor[a]._trace
+            if not tr or len(ga) == 0:
+                continue
+            cum = torch.stack(tr).double().cpu().numpy()
+            per = np.diff(np.concatenate([np.zeros((1, cum.shape[1])), cum]), axis=0)[:, :4]
+            n = min(len(per), len(ga))
+            e = np.abs(per[:n] - ga[:n]) / (np.abs(ga[:n]) + 1e-12)
+            first = max(first, float(e[0].max()))
+            exc = max(exc, excess(per[:n], ga[:n], na[:n], sa[:n]))
+            if float(e.max()) > worst:
+                k, c = np.unravel_index(np.argmax(e), e.shape)
+                worst, wkey = float(e.max()), f"agent{a}/update{k}/{('policy_loss', 'entropy', 'grad_norm', 'ratio')[c]}"
+        out["_actor_trace_first_update_rel"] = first
+        out["_actor_trace_max_rel"] = worst
+        out["_actor_trace_worst"] = wkey
+        out["actor_trace_excess"] = exc
+        gc = z["critic_trace"]
+        cum = torch.stack(r.critic._trace).double().cpu().numpy()
+        per = np.diff(np.concatenate([np.zeros((1, cum.shape[1])), cum]), axis=0)[:, :2]
+        n = min(len(per), len(gc))
+        e = np.abs(per[:n] - gc[:n]) / (np.abs(gc[:n]) + 1e-12)
+        out["_critic_trace_first_update_rel"] = float(e[0].max())
+        out["_critic_trace_max_rel"] = float(e.max())
+        out["critic_trace_excess"] = excess(per[:n], gc[:n], nz["critic_trace"][:n], nz["sens_critic_trace"][:n])
+    cg = [cinfo["value_loss"], cinfo["critic_grad_norm"]]
+    out["_critic_value_loss_rel"] = rel_err(cg[0], z["critic_info"][0])
+    out["_critic_gradnorm_rel"] = rel_err(cg[1], z["critic_info"][1])
+    out["critic_info_excess"] = excess(cg, z["critic_info"], nz["critic_info"], nz["sens_critic_info"])
     for a in range(case.shapes.A):
-        out[f"actor{a}_final_param_vec_rel"] = vec_rel_err(r.actor[a].actor.flat_param.cpu().numpy(), z[f"actor_final_{a}"])
-    out["critic_final_param_vec_rel"] = vec_rel_err(r.critic.critic.flat_param.cpu().numpy(), z["critic_final"])
+        fp = r.actor[a].actor.flat_param.cpu().numpy()
+        out[f"_actor{a}_final_param_vec_rel"] = vec_rel_err(fp, z[f"actor_final_{a}"])
+        out[f"actor{a}_final_param_excess"] = vec_excess(fp, z[f"actor_final_{a}"], nz[f"actor_final_{a}"], nz[f"sens_actor_final_{a}"])
+    fp = r.critic.critic.flat_param.cpu().numpy()
+    out["_critic_final_param_vec_rel"] = vec_rel_err(fp, z["critic_final"])
+    out["critic_final_param_excess"] = vec_excess(fp, z["critic_final"], nz["critic_final"], nz["sens_critic_final"])
     if r.value_normalizer is not None:
         out["vn_final_rel"] = rel_err(r.value_normalizer.stats.cpu().numpy(), z["vn_final"])
     return out
@@ -1080,4 +1127,61 @@ def check_fused_vs_layered(rows: int) -> Dict[str, float]:
                critic_loss_sums_rel=float(((n["csc"][:2] - o["csc"][:2]).abs() / o["csc"][:2].abs().clamp_min(1e-30)).max()),
                actor_rerun_bitwise_equal=float(torch.equal(n["dwp"], a["dwp"]) and torch.equal(n["sc"], a["sc"])),
                critic_rerun_bitwise_equal=float(torch.equal(n["cg"], a["cg"])))
+    return out
+
+
+def check_gradient_noise(spec, agg: str = "prod") -> Dict[str, float]:
+    """Where does ONE update of the HIP path sit relative to exact arithmetic, compared with the reference's fp32 arithmetic?
+    Pre-clip gradient of the same HAPPO.update computed three ways -- HIP kernels, oracle in float32 (= the reference's
+    arithmetic), oracle in float64 -- and reported per parameter tensor as |g - g64|_inf / |g64|_inf for the first two
+    (diagnostic: `_t32/<tensor>` and `_gpu/<tensor>`; `gpu_over_ref32_worst` = the largest ratio of the two)."""
+    out = {}
+    over = dict(spec.get("over", {}))
+    over.update(action_aggregation=agg)
+    M = spec["M"]
+    sh = Shapes(T=M, N=1, A=1, obs_dim=spec["obs_dim"], share_obs_dim=spec["share_obs_dim"], act_dim=spec["act_dim"],
+                discrete=spec["discrete"], hidden_sizes=spec["hidden_sizes"])
+    d = make_buffers(sh, 33, unavailable_p=0.25 if sh.discrete else 0.0)
+    actor, sd, args = _mk_actor(sh, 99, **over)
+    cfg = O.PathConfig.from_reference_dicts({}, args, args)
+    rng = np.random.default_rng(5)
+    obs = d.obs[0][:-1].reshape(M, -1)
+    avail = None if not sh.discrete else d.available_actions[0][:-1].reshape(M, -1)
+    act = d.actions[0].reshape(M, -1)
+    o32 = O.OracleHAPPO({k: torch.from_numpy(v) for k, v in sd.items()}, cfg)
+    with torch.no_grad():
+        lp, _, _ = o32.evaluate_actions(obs, act, avail, None)
+    old_logp = (lp.numpy() + 0.15 * rng.standard_normal(lp.shape)).astype(np.float32)
+    adv = rng.standard_normal((M, 1)).astype(np.float32)
+    factor = (1 + 0.2 * rng.standard_normal((M, 1))).astype(np.float32)
+    active = d.active_masks[0][:-1].reshape(M, 1)
+    sample_o = (obs, act, active, old_logp, adv, avail, factor)
+    pl32, _, gn32, _, g32 = o32.update(sample_o, keep_grad=True)
+    O.set_work_dtype(torch.float64)
+    try:
+        o64 = O.OracleHAPPO({k: torch.from_numpy(v) for k, v in sd.items()}, cfg)
+        pl64, _, gn64, _, g64 = o64.update(sample_o, keep_grad=True)
+    finally:
+        O.set_work_dtype(torch.float32)
+    taps = []
+    actor._grad_tap = lambda gr, sc: taps.append((gr.clone(), sc))
+    rnn = np.zeros((M, 1, 1), dtype=np.float32)
+    res = actor.update((obs, rnn, act, None, active, old_logp, adv, avail, factor))
+    torch.cuda.synchronize()
+    gg = taps[0][0].double().cpu().numpy()
+    worst, off = 0.0, 0
+    for name, shp in actor_param_shapes(sh, args["use_feature_normalization"]):
+        n = int(np.prod(shp))
+        ref = np.max(np.abs(g64[off:off + n])) + 1e-30
+        e32 = float(np.max(np.abs(g32[off:off + n] - g64[off:off + n])) / ref)
+        eg = float(np.max(np.abs(gg[off:off + n] - g64[off:off + n])) / ref)
+        out[f"_t32/{name}"] = e32
+        out[f"_gpu/{name}"] = eg
+        worst = max(worst, eg / max(e32, 1e-9))
+        off += n
+    out["gpu_over_ref32_worst"] = worst
+    out["_loss_t32_vs_64"] = rel_err(pl32.item(), pl64.item())
+    out["_loss_gpu_vs_64"] = rel_err(res[0].item(), pl64.item())
+    out["_gradnorm_t32_vs_64"] = rel_err(float(gn32), float(gn64))
+    out["_gradnorm_gpu_vs_64"] = rel_err(res[2].item(), float(gn64))
     return out

@@ -24,13 +24,15 @@ def main():
         jobs.append((f"forward[{spec['name']}]", lambda s=spec: G.check_forward(s)))
     for spec in G.FWD_SHAPES:
         jobs.append((f"grad[{spec['name']}]", lambda s=spec: G.check_gradients(s)))
+    for spec in G.FWD_SHAPES[:3]:
+        jobs.append((f"noise[{spec['name']}]", lambda s=spec: G.check_gradient_noise(s)))
     jobs.append(("grad[mpe_box,mean,inactive]", lambda: G.check_gradients(G.FWD_SHAPES[0], agg="mean", inactive_p=0.3)))
     for name in ALL_CASES:
         jobs.append((f"train[{name}]", lambda n=name: G.check_train_golden(n)))
     for i in (0, 1, 2, 4):
         jobs.append((f"trpo[{G.FWD_SHAPES[i]['name']}]", lambda s=G.FWD_SHAPES[i]: G.check_trpo(s)))
-    from tests.helpers import TRPO_CASES
-    for name in TRPO_CASES:
+    from tests.helpers import MAPPO_CASES, RNN_CASES, TRPO_CASES, TRPO_RNN_CASES
+    for name in TRPO_CASES + TRPO_RNN_CASES + RNN_CASES + MAPPO_CASES:
         jobs.append((f"train[{name}]", lambda n=name: G.check_train_golden(n)))
     print("device:", torch.cuda.get_device_name(0), flush=True)
     results = {}
@@ -44,7 +46,7 @@ def main():
             worst = max([v for k, v in res.items() if not k.startswith("_") and isinstance(v, float)] or [0.0])
             print(f"== {name}  ({time.time()-t0:.1f}s)  worst={worst:.3e}")
             for k, v in res.items():
-                if isinstance(v, float) and (v > 1e-6 or len(res) < 14):
+                if isinstance(v, float) and (v > 1e-6 or len(res) < 14 or name.startswith("noise")):
                     print(f"     {k:48s} {v:.3e}")
                 elif not isinstance(v, float):
                     print(f"     {k:48s} {v}")

@@ -4,11 +4,13 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-5  # BASELINE.json: fp32 losses / grad-norms within 1e-5 relative for identical buffer contents
-# Whole-train() comparisons chain 10-35 dependent optimiser steps; the reference itself moves by up to ~3e-6 under a
-# 1-ulp perturbation of its initial weights (measured, DESIGN.md "Numerics"), i.e. per-step rounding differences are
-# amplified ~6x by the end of train().  Per-update parity (same params, same buffers) is held to 1e-5 above; the
-# end-of-train() figures are held to 1e-4 (measured: <= 1e-5 on 5 of 6 golden cases, 5.6e-5 on the 6-agent case).
-TOL_TRAIN = 1e-4
+# Whole-train() comparisons against the reference's golden vectors use the SAME 1e-5 bar, entry by entry (every optimiser
+# step's loss / entropy / grad-norm / ratio, the averaged infos, the final parameters), except where the reference's own
+# fp32 figure is further than that from exact arithmetic: oracle/gen_noise_floor.py re-runs each golden case in float64
+# (tests/golden/noise/*.npz), and an entry may differ from the reference by at most
+#     max(1e-5, 8 x max(|reference_fp32 - fp64| / |fp64|, reference's movement under 1 ulp of parameter noise per step))
+# -- e.g. the first policy loss of `a2c_box_h64` is a near-zero masked mean of advantage-normalised surrogates and the
+# reference itself is 1.0e-4 away from its exact value.  check_train_golden reports that ratio as `*_excess` (<= 1 passes).
 
 
 def _G():
@@ -22,6 +24,8 @@ def _assert_all(res, tol=TOL, exact_keys=("mismatch", "perm_", "count")):
             continue
         if any(e in k for e in exact_keys):
             assert v == 0.0, (k, v)
+        elif k.endswith("_excess"):
+            assert v <= 1.0, (k, v)   # within max(1e-5, 8 x the reference's own measured uncertainty) on every entry
         else:
             assert v < tol, (k, v)
 
@@ -65,7 +69,7 @@ def test_single_update_gradients_mean_aggregation_inactive_agents():
                                   "box_mean_inactive_novn", "wide_obs_h64", "a2c_box_h64", "fp_box_h64",
                                   "fp_disc_h128_mb2"])
 def test_train_matches_reference_golden(name):
-    _assert_all(_G().check_train_golden(name), tol=TOL_TRAIN)
+    _assert_all(_G().check_train_golden(name), tol=TOL)
 
 
 @pytest.mark.parametrize("i", [0, 1, 2, 4])
@@ -92,7 +96,7 @@ def test_hatrpo_gru_gradient_fvp_and_update(i):
 
 @pytest.mark.parametrize("name", ["trpo_box_h64", "trpo_disc_h64", "trpo_wide_h128x3", "trpo_rnn_disc_h64", "trpo_rnn_box_h64"])
 def test_hatrpo_train_matches_reference_golden(name):
-    _assert_all(_G().check_train_golden(name), tol=TOL_TRAIN)
+    _assert_all(_G().check_train_golden(name), tol=TOL)
 
 
 @pytest.mark.parametrize("i", [0, 1, 5])
@@ -120,7 +124,7 @@ def test_gru_policy_forward_and_update(i):
                                   "rnn_naive_fp_disc_h64"])
 def test_recurrent_train_matches_reference_golden(name):
     """Chunked and naive recurrent samplers + GRU actor/critic through a whole OnPolicyHARunner.train() vs the reference."""
-    _assert_all(_G().check_train_golden(name), tol=TOL_TRAIN)
+    _assert_all(_G().check_train_golden(name), tol=TOL)
 
 
 @pytest.mark.parametrize("discrete,recurrent", [(False, False), (True, False), (False, True)])
@@ -138,7 +142,7 @@ def test_rollout_loop_learns_on_toy_env(discrete, recurrent):
 def test_mappo_train_matches_reference_golden(name):
     """MAPPO through the same kernels (factor = NULL); parameter sharing accumulates every agent's segment before one
     optimiser step; OnPolicyMARunner.train() vs the reference (incl. its stray randperm(num_agents) draw)."""
-    _assert_all(_G().check_train_golden(name), tol=TOL_TRAIN)
+    _assert_all(_G().check_train_golden(name), tol=TOL)
 
 
 def test_checkpoint_compat_with_reference_files(tmp_path):
@@ -186,7 +190,7 @@ def test_fused_update_kernels_single_update(i, monkeypatch):
 def test_fused_update_kernels_train_golden(name, monkeypatch):
     """Whole train() through the fused optimiser-step kernels vs the reference's golden vectors."""
     monkeypatch.setenv("HARL_FUSED_UPDATE", "1")
-    _assert_all(_G().check_train_golden(name), tol=TOL_TRAIN)
+    _assert_all(_G().check_train_golden(name), tol=TOL)
 
 
 def test_fused_update_kernels_many_slabs_per_wave():

@@ -8,6 +8,7 @@ Tolerances: integer / index data and the GAE scan bit-exact; fp32 losses, grad-n
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional
 
 import numpy as np
@@ -1184,4 +1185,141 @@ def check_gradient_noise(spec, agg: str = "prod") -> Dict[str, float]:
     out["_loss_gpu_vs_64"] = rel_err(res[0].item(), pl64.item())
     out["_gradnorm_t32_vs_64"] = rel_err(float(gn32), float(gn64))
     out["_gradnorm_gpu_vs_64"] = rel_err(res[2].item(), float(gn64))
+    return out
+
+
+# BASELINE.json configurations at their real network / agent shapes with the thread count cut so that the oracle (one CPU
+# socket) finishes each in well under a minute: rows = T * N <= 32 000, FULL agent count, one optimiser epoch per network.
+BASELINE_SHAPES = {
+    # configs[1]: MPE simple_spread, 3 agents, obs 18 / share 54, Box(5), hidden [128, 128]
+    "mpe3": dict(shapes=dict(T=200, N=160, A=3, obs_dim=18, share_obs_dim=54, act_dim=5, discrete=False,
+                             hidden_sizes=[128, 128]), seed=3, overrides=dict(ppo_epoch=1, critic_epoch=1)),
+    # configs[2]: MAMuJoCo HalfCheetah-6x1, 6 agents, obs 23 / share 17, Box(1), hidden [128, 128, 128]
+    "cheetah6": dict(shapes=dict(T=200, N=160, A=6, obs_dim=23, share_obs_dim=17, act_dim=1, discrete=False,
+                                 hidden_sizes=[128, 128, 128]), seed=4, overrides=dict(ppo_epoch=1, critic_epoch=1)),
+    # configs[3]: SMAC 3s5z, 8 agents, obs 128 / state 216, Discrete(14) with unavailable actions, GRU policy, T = 160,
+    # chunks of 10 (tuned_configs/smac/3s5z/happo)
+    "smac3s5z": dict(shapes=dict(T=160, N=96, A=8, obs_dim=128, share_obs_dim=216, act_dim=14, discrete=True,
+                                 hidden_sizes=[64, 64, 64]), seed=5, unavailable_p=0.3,
+                     overrides=dict(ppo_epoch=1, critic_epoch=1, use_recurrent_policy=True, data_chunk_length=10)),
+    # configs[4]: MAMuJoCo Humanoid-17x1, 17 agents, obs 393 / share 376, Box(1), HATRPO (CG + FVP + line search)
+    "humanoid17": dict(shapes=dict(T=200, N=40, A=17, obs_dim=393, share_obs_dim=376, act_dim=1, discrete=False,
+                                   hidden_sizes=[128, 128, 128]), seed=6, algo="hatrpo",
+                       overrides=dict(critic_epoch=1, fixed_order=True)),
+}
+
+
+def _mask_relu_kinks(case, margin: float = 2e-5) -> int:
+    """The update has two kinds of kinks: ReLU (derivative 0 / 1 at z = 0) and the PPO clip (gradient on / off where the
+    importance ratio crosses 1 +- clip_param).  A sample sitting within rounding distance of one gets the derivative switched
+    on in one fp32 implementation and off in another.  Measured at T = 200, N = 160: ONE sample out of 32 000 with a
+    pre-activation of ~1e-8 moved the lower layers' weight gradients by up to 1.3 % of their inf-norm, another one whose
+    ratio was 4e-7 from 0.8 moved EVERY gradient tensor by 0.5-3 %, and Adam's first step amplified either into 1e-3
+    differences in the following agents' losses -- while the same figures agree to 1e-6 once those samples are left out.
+    With ~8 million pre-activations per update a few always are that close, so they are taken out of the comparison: every
+    (t, n) whose actor pre-activations (float64 forward of the initial weights) come within ``margin`` of zero in any MLP
+    layer, or whose ratio comes within ``margin`` (relative) of a clip boundary, gets active_mask = 0, which removes it from
+    the loss and the gradient in the reference and here alike (happo.py:77-81).  Returns the number of masked samples."""
+    T, N = case.shapes.T, case.shapes.N
+    train, model, algo = case.reference_dicts()
+    cfg = O.PathConfig.from_reference_dicts(train, model, algo)
+    n_masked = 0
+    for a in range(case.shapes.A):
+        p = {k: torch.from_numpy(v).double() for k, v in case.actor_sd[a].items()}
+        obs = torch.from_numpy(case.data.obs[a][:-1].reshape(T * N, -1)).double()
+        x = obs
+        near = torch.zeros(T * N, dtype=torch.bool)
+        with torch.no_grad():
+            if "base.feature_norm.weight" in p:
+                x = torch.nn.functional.layer_norm(x, (x.shape[-1],), p["base.feature_norm.weight"], p["base.feature_norm.bias"], 1e-5)
+            i = 0
+            while f"base.mlp.fc.{i}.weight" in p:
+                z = torch.nn.functional.linear(x, p[f"base.mlp.fc.{i}.weight"], p[f"base.mlp.fc.{i}.bias"])
+                near |= (z.abs().min(dim=-1).values < margin)
+                x = torch.nn.functional.layer_norm(torch.relu(z), (z.shape[-1],), p[f"base.mlp.fc.{i+2}.weight"],
+                                                   p[f"base.mlp.fc.{i+2}.bias"], 1e-5)
+                i += 3
+            if case.algo_name != "hatrpo":  # clipped surrogate: ratio near 1 +- clip_param
+                d = case.data
+                avail = None if d.available_actions[a] is None else torch.from_numpy(d.available_actions[a][:-1].reshape(T * N, -1)).double()
+                rnn = masks = None
+                if case.recurrent:
+                    rnn = torch.from_numpy(d.rnn["actor"][a][0]).double()
+                    masks = torch.from_numpy(d.masks[a][:-1].reshape(T * N, 1)).double()
+                kind, dp = O._dist_params(p, cfg, obs, avail, rnn, masks)
+                act = torch.from_numpy(d.actions[a].reshape(T * N, -1)).double()
+                if kind == "categorical":
+                    lp = dp[0].gather(-1, act.long())
+                else:
+                    lp = -((act - dp[0]) ** 2) / (2 * dp[1] * dp[1]) - torch.log(dp[1]) - 0.9189385332046727
+                r_ = torch.exp(lp - torch.from_numpy(d.action_log_probs[a].reshape(T * N, -1)).double())
+                imp = r_.prod(-1) if cfg.action_aggregation == "prod" else r_.mean(-1)
+                for edge in (1.0 - cfg.clip_param, 1.0 + cfg.clip_param):
+                    near |= ((imp - edge).abs() < margin * edge)
+        am = case.data.active_masks[a]
+        am[:-1].reshape(T * N, 1)[near.numpy()] = 0.0
+        n_masked += int(near.sum())
+    return n_masked
+
+
+def check_baseline_shape(name: str) -> Dict[str, float]:
+    """One whole train() (one epoch per network) at a BASELINE.json configuration's real shapes and agent count against the
+    oracle on the same seeded buffers: every agent's first update (policy loss / entropy / grad-norm / ratio, or HATRPO's
+    kl / improvement figures), the sequential factor chain across all agents, the critic's update, final parameters.
+    Bar per entry: max(1e-5, NOISE_FACTOR x the oracle's own fp32-vs-fp64 distance) (tests/helpers.excess)."""
+    from tests.helpers import SyntheticCase
+    from tests.test_oracle_golden import build_oracle
+    spec = BASELINE_SHAPES[name]
+    case = SyntheticCase(name, Shapes(**spec["shapes"]), spec["seed"], algo_name=spec.get("algo", "happo"),
+                         overrides=spec.get("overrides"), unavailable_p=spec.get("unavailable_p", 0.0))
+    out = {}
+    out["_kink_adjacent_samples_masked"] = float(_mask_relu_kinks(case))
+    # ---- oracle, fp32 (= the reference's arithmetic) and fp64 (the yardstick)
+    runs = {}
+    torch.set_num_threads(max(1, min(32, (os.cpu_count() or 2) // 2)))
+    for tag, dt in (("f32", torch.float32), ("f64", torch.float64)):
+        O.set_work_dtype(dt)
+        try:
+            torch.manual_seed(case.seed)
+            np.random.seed(case.seed)
+            cfg, actors, critic, abufs, cbuf, vn = build_oracle(case)
+            torch.manual_seed(case.seed + 12345)
+            cbuf.compute_returns(cbuf.value_preds[-1].copy(), vn, cfg)
+            infos, cinfo, extra = O.ha_train(actors, critic, abufs, cbuf, vn, cfg)
+        finally:
+            O.set_work_dtype(torch.float32)
+        fin = [np.asarray(a_.flat().numpy() if case.algo_name == "hatrpo" else a_.net.flat(), dtype=np.float64) for a_ in actors]
+        runs[tag] = dict(infos=infos, cinfo=cinfo, fin=fin, cfin=np.asarray(critic.net.flat(), dtype=np.float64),
+                         returns=cbuf.returns.copy())
+    # ---- HIP path
+    torch.manual_seed(case.seed)
+    np.random.seed(case.seed)
+    r = build_runner(case)
+    torch.manual_seed(case.seed + 12345)
+    cb = r.critic_buffer
+    cb.compute_returns(cb.value_preds[-1].clone(), r.value_normalizer)
+    r.prep_training()
+    ginfos, gcinfo = r.train()
+    torch.cuda.synchronize()
+    T = case.shapes.T
+    out["returns_mismatch"] = float(np.sum(cb.returns.cpu().numpy()[:T] != runs["f32"]["returns"][:T]))
+    keys = (("kl", "loss_improve", "expected_improve", "dist_entropy", "ratio") if case.algo_name == "hatrpo"
+            else ("policy_loss", "dist_entropy", "actor_grad_norm", "ratio"))
+    tab = lambda infos_: np.array([[float(np.asarray(i[k]).reshape(-1)[0]) for k in keys] for i in infos_], dtype=np.float64)  # noqa: E731
+    g, o32, o64 = tab(ginfos), tab(runs["f32"]["infos"]), tab(runs["f64"]["infos"])
+    for c, k in enumerate(keys):
+        out[f"_actor_{k}_rel"] = rel_err(g[:, c], o32[:, c])
+        out[f"actor_{k}_excess"] = excess(g[:, c], o32[:, c], o64[:, c])
+    gc = [gcinfo["value_loss"], gcinfo["critic_grad_norm"]]
+    c32 = [runs["f32"]["cinfo"]["value_loss"], runs["f32"]["cinfo"]["critic_grad_norm"]]
+    c64 = [runs["f64"]["cinfo"]["value_loss"], runs["f64"]["cinfo"]["critic_grad_norm"]]
+    out["_critic_rel"] = rel_err(gc, c32)
+    out["critic_info_excess"] = excess(gc, c32, c64)
+    worst = 0.0
+    for a in range(case.shapes.A):
+        fp = r.actor[a].actor.flat_param.cpu().numpy()
+        worst = max(worst, vec_excess(fp, runs["f32"]["fin"][a], runs["f64"]["fin"][a]))
+        out["_actor_final_param_vec_rel_max"] = max(out.get("_actor_final_param_vec_rel_max", 0.0), vec_rel_err(fp, runs["f32"]["fin"][a]))
+    out["actor_final_param_excess"] = worst
+    out["critic_final_param_excess"] = vec_excess(r.critic.critic.flat_param.cpu().numpy(), runs["f32"]["cfin"], runs["f64"]["cfin"])
     return out

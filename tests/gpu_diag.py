@@ -26,6 +26,8 @@ def main():
         jobs.append((f"grad[{spec['name']}]", lambda s=spec: G.check_gradients(s)))
     for spec in G.FWD_SHAPES[:3]:
         jobs.append((f"noise[{spec['name']}]", lambda s=spec: G.check_gradient_noise(s)))
+    for nm in G.BASELINE_SHAPES:
+        jobs.append((f"baseline[{nm}]", lambda n=nm: G.check_baseline_shape(n)))
     jobs.append(("grad[mpe_box,mean,inactive]", lambda: G.check_gradients(G.FWD_SHAPES[0], agg="mean", inactive_p=0.3)))
     for name in ALL_CASES:
         jobs.append((f"train[{name}]", lambda n=name: G.check_train_golden(n)))

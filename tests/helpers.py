@@ -115,3 +115,70 @@ def vec_excess(got, gold, exact, sens=None, tol: float = 1e-5) -> float:
     if sens is not None:
         floor = max(floor, float(sens))
     return vec_rel_err(got, gold) / max(tol, NOISE_FACTOR * floor)
+
+
+class SyntheticCase(GoldenCase):
+    """A GoldenCase-shaped object WITHOUT a recorded reference run: same synthetic buffers / weights recipe, configuration
+    dictionaries cloned from a golden fixture's metadata (so it needs nothing outside tests/golden), policy-consistent
+    actions and stored log-probs drawn with the oracle's forward pass (what oracle/gen_golden.py does with the reference's).
+    Used for parity checks at BASELINE.json shapes, where the checker is the oracle itself (fp32, and fp64 for the bar)."""
+
+    def __init__(self, name: str, shapes: Shapes, seed: int, algo_name: str = "happo", overrides: Optional[dict] = None,
+                 inactive_p: float = 0.0, unavailable_p: float = 0.0, state_type: str = "EP", logp_noise: float = 0.05):
+        from oracle import harl_oracle as O
+        self.name, self.z = name, None
+        tmpl = GoldenCase("trpo_wide_h128x3" if algo_name == "hatrpo" else "mpe_box_h128")
+        self.algo, self.model, self.train = dict(tmpl.algo), dict(tmpl.model), dict(tmpl.train)
+        self.model["hidden_sizes"] = list(shapes.hidden_sizes)
+        self.train.update(episode_length=shapes.T, n_rollout_threads=shapes.N)
+        for k, v in (overrides or {}).items():
+            for sec in (self.train, self.model, self.algo):
+                if k in sec:
+                    sec[k] = v
+        self.meta = dict(spec=dict(seed=seed), algo=self.algo, model=self.model, train=self.train, algo_name=algo_name)
+        self.shapes, self.seed, self.algo_name, self.state_type = shapes, seed, algo_name, state_type
+        self.model.setdefault("use_recurrent_policy", False)
+        self.model.setdefault("use_naive_recurrent_policy", False)
+        self.recurrent = bool(self.model["use_recurrent_policy"] or self.model["use_naive_recurrent_policy"])
+        self.data = make_buffers(shapes, seed, inactive_p, unavailable_p, fp=state_type == "FP", rnn=self.recurrent)
+        use_fn = self.model["use_feature_normalization"]
+        self.share_param = False
+        self.actor_sd = [synthetic_state_dict(actor_param_shapes(shapes, use_fn, self.recurrent), 1000 * seed + a,
+                                              self.model["std_x_coef"]) for a in range(shapes.A)]
+        self.critic_sd = synthetic_state_dict(critic_param_shapes(shapes, use_fn, self.recurrent), 1000 * seed + 999)
+        self.use_valuenorm = self.train["use_valuenorm"]
+        self.vn_init = dict(running_mean=0.3 * 0.5, running_mean_sq=1.7 * 0.5, debiasing_term=0.5)
+        # a ~ pi_theta(.|obs), stored logp = log pi_theta(a|obs) + noise: importance ratios ~ 1, the regime PPO runs in
+        train, model, algo = self.reference_dicts()
+        cfg = O.PathConfig.from_reference_dicts(train, model, algo)
+        T, N = shapes.T, shapes.N
+        torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+        for a in range(shapes.A):
+            rng = np.random.default_rng(77000 + 100 * seed + a)
+            pp = {k: torch.from_numpy(v) for k, v in self.actor_sd[a].items()}
+            d = self.data
+            obs = torch.from_numpy(d.obs[a][:-1].reshape(T * N, -1))
+            avail = None if d.available_actions[a] is None else torch.from_numpy(d.available_actions[a][:-1].reshape(T * N, -1).copy())
+            rnn = masks = None
+            if self.recurrent:
+                rnn = torch.from_numpy(d.rnn["actor"][a][0])
+                masks = torch.from_numpy(d.masks[a][:-1].reshape(T * N, 1))
+            with torch.no_grad():
+                kind, dp = O._dist_params(pp, cfg, obs, avail, rnn, masks)
+            if kind == "categorical":
+                pr = torch.exp(dp[0]).numpy().astype(np.float64)
+                pr /= pr.sum(-1, keepdims=True)
+                cdf = np.cumsum(pr, axis=-1)
+                u = rng.random((T * N, 1))
+                acts = np.minimum((u > cdf).sum(-1), shapes.act_dim - 1).astype(np.float32)[:, None]
+                logp = np.log(np.take_along_axis(pr, acts.astype(np.int64), axis=1))
+            else:
+                mean, std = dp[0].numpy(), dp[1].numpy()
+                acts = (mean + std * rng.standard_normal(mean.shape)).astype(np.float32)
+                logp = -((acts - mean) ** 2) / (2 * std * std) - np.log(std) - 0.9189385332046727
+            logp = (logp + logp_noise * rng.standard_normal(logp.shape)).astype(np.float32)
+            self.data.actions[a] = acts.reshape(self.data.actions[a].shape).astype(np.float32)
+            self.data.action_log_probs[a] = logp.reshape(self.data.action_log_probs[a].shape)
+
+    def perms(self):
+        return []

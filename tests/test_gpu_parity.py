@@ -203,3 +203,10 @@ def test_fused_update_kernels_many_slabs_per_wave():
             assert v == 1.0, (k, v)
         else:
             assert v < 2e-5, (k, v)
+
+
+@pytest.mark.parametrize("name", ["mpe3", "cheetah6", "smac3s5z", "humanoid17"])
+def test_parity_at_baseline_shapes(name):
+    """BASELINE.json configs 1-4 at their real network shapes, observation widths and FULL agent counts (thread count cut
+    to <= 32 000 rows so the CPU oracle finishes): whole train() with one epoch per network vs the oracle."""
+    _assert_all(_G().check_baseline_shape(name), tol=TOL)

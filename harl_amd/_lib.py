@@ -29,7 +29,7 @@ SIGNATURES = {
     "harl_factor_update": [_vp, _vp, _vp, _l, _i, _i, _vp],
     "harl_sum_sumsq": [_vp, _vp, _l, _vp, _vp],
     "harl_valuenorm_apply": [_vp, _vp, _d, _d, _vp],
-    "harl_gradnorm_clip_adam": [_vp, _vp, _vp, _vp, _l, _vp, _i, _f, _f, _f, _f, _f, _f, _d, _d, _vp, _vp],
+    "harl_gradnorm_clip_adam": [_vp, _vp, _vp, _vp, _l, _vp, _i, _f, _d, _d, _d, _f, _f, _d, _d, _vp, _vp],
     "harl_fold_linear": [_vp] * 6 + [_i, _i, _vp],
     "harl_unfold_linear_grads": [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "harl_mlp_fwd_input": [_vp, _l, _vp, _l, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
@@ -44,14 +44,14 @@ SIGNATURES = {
     "harl_mlp_dw_partials": [_vp, _i, _i, _i, _vp, _i, _l, _vp, _vp, _vp, _i, _l, _vp, _i, _vp],
     "harl_reduce_partials": [_vp, _i, _l, _vp, _vp],
     "harl_reduce_partials_multi": [_vp, _vp, _i, _i, _l, _vp, _vp],
-    "harl_adam_fold": [_vp, _vp, _vp, _vp, _l, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _f, _i, _i, _vp, _i, _f, _f, _f,
-                       _f, _f, _f, _d, _d, _vp, _vp],
+    "harl_adam_fold": [_vp, _vp, _vp, _vp, _l, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _f, _i, _i, _vp, _i, _f, _d, _d,
+                       _d, _f, _f, _d, _d, _vp, _vp],
     "harl_pack_scalars_hilo": [_vp, _vp, _vp],
     "harl_randperm_replay": [_vp, _l, _l, _vp, _vp, _vp],
     "harl_rng_advance": [_vp, _l, _l, _vp],
     "harl_actor_head_logp": [_vp, _l, _i, _vp, _vp, _vp, _f, _f, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _l, _l, _vp],
     "harl_actor_head_loss": [_vp, _vp, _vp, _l, _i, _vp, _vp, _vp, _f, _f, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,
-                             _vp, _vp, _f, _f, _i, _i, _l, _l, _vp, _vp, _vp, _vp, _vp, _i, _vp],
+                             _vp, _vp, _d, _f, _i, _i, _l, _l, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "harl_critic_head_values": [_vp, _l, _i, _vp, _vp, _vp, _vp],
     "harl_critic_head_loss": [_vp, _vp, _vp, _l, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _f, _l, _l, _vp, _vp, _vp,
                               _vp, _i, _vp],
@@ -65,7 +65,7 @@ SIGNATURES = {
     "harl_actor_head_fvp": [_vp, _vp, _vp, _vp, _l, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _i, _vp, _l, _l, _vp, _vp, _vp],
     "harl_trpo_kl_sum": [_vp, _vp, _vp, _vp, _f, _f, _l, _i, _i, _vp, _vp],
     "harl_update_supported": [_i, _i, _i],
-    "harl_update_fwd_actor": [_vp, _l, _i, _i] + [_vp] * 7 + [_f, _f, _i, _i] + [_vp] * 7 + [_f, _f, _i, _i] + [_vp] * 4 + [_i, _vp],
+    "harl_update_fwd_actor": [_vp, _l, _i, _i] + [_vp] * 7 + [_f, _f, _i, _i] + [_vp] * 7 + [_d, _f, _i, _i] + [_vp] * 4 + [_i, _vp],
     "harl_update_logp": [_vp, _l, _i, _i] + [_vp] * 7 + [_f, _f, _i, _i] + [_vp] * 5 + [_i, _vp, _vp],
     "harl_update_fwd_critic": [_vp, _l, _i, _i] + [_vp] * 9 + [_f, _i, _i, _f] + [_vp] * 3 + [_i, _vp],
     "harl_update_values": [_vp, _l, _i, _i] + [_vp] * 7 + [_vp],
@@ -156,6 +156,13 @@ def call(name: str, *args, tag: Optional[str] = None) -> None:
         rc = getattr(lib, name)(*args)
     if rc != 0:
         raise RuntimeError(f"{name} failed ({rc}): {lib.harl_last_error().decode()}")
+
+
+def default_device() -> torch.device:
+    """Device of objects constructed without an explicit ``device=`` (the reference builds its buffers that way,
+    on_policy_base_runner.py:129-156): ``HARL_DEVICE`` if set, else ``cuda:<LOCAL_RANK>`` -- one process per GPU under
+    torchrun, cuda:0 otherwise."""
+    return torch.device(os.environ.get("HARL_DEVICE") or f"cuda:{int(os.environ.get('LOCAL_RANK', '0'))}")
 
 
 def require_gpu(device: torch.device) -> None:

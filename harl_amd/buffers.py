@@ -285,8 +285,8 @@ def _recurrent_seqs(device, T: int, n_local: int, agents: int, H: int, num_mini_
 
 
 class OnPolicyActorBuffer:
-    def __init__(self, args: dict, obs_space, act_space, device=torch.device("cuda:0")):
-        self.device = torch.device(device)
+    def __init__(self, args: dict, obs_space, act_space, device=None):
+        self.device = torch.device(device) if device is not None else _lib.default_device()
         _lib.require_gpu(self.device)
         self.episode_length = T = args["episode_length"]
         self.n_rollout_threads = N = args["n_rollout_threads"]
@@ -398,8 +398,8 @@ class OnPolicyActorBuffer:
 
 
 class OnPolicyCriticBufferEP:
-    def __init__(self, args: dict, share_obs_space, device=torch.device("cuda:0")):
-        self.device = torch.device(device)
+    def __init__(self, args: dict, share_obs_space, device=None):
+        self.device = torch.device(device) if device is not None else _lib.default_device()
         _lib.require_gpu(self.device)
         self.episode_length = T = args["episode_length"]
         self.n_rollout_threads = N = args["n_rollout_threads"]
@@ -507,8 +507,8 @@ class OnPolicyCriticBufferFP(OnPolicyCriticBufferEP):
     ``[T(+1), N, A, .]`` (reference: harl/common/buffers/on_policy_critic_buffer_fp.py:10-260).  The GAE scan runs over
     N*A columns; the flattened batch is T*N*A rows with row = (t*N + n)*A + a, as in the reference generators."""
 
-    def __init__(self, args: dict, share_obs_space, num_agents: int, device=torch.device("cuda:0")):
-        self.device = torch.device(device)
+    def __init__(self, args: dict, share_obs_space, num_agents: int, device=None):
+        self.device = torch.device(device) if device is not None else _lib.default_device()
         _lib.require_gpu(self.device)
         self.episode_length = T = args["episode_length"]
         self.n_rollout_threads = N = args["n_rollout_threads"]

@@ -296,8 +296,8 @@ __global__ __launch_bounds__(1024) void k_gradnorm_clip_adam(float *__restrict__
                                                              float *__restrict__ m, float *__restrict__ v, long n,
                                                              const float *__restrict__ grad_scale, int use_clip,
                                                              float max_norm, float lr_over_bc1, float beta1,
-                                                             float beta2, float eps, float wd, float bc2_sqrt,
-                                                             float *__restrict__ info_out) {
+                                                             float beta2, float omb1, float omb2, float eps, float wd,
+                                                             float bc2_sqrt, double *__restrict__ info_out) {
   const float scale = grad_scale ? *grad_scale : 1.f;
   double ss = 0;
   for (long i = threadIdx.x; i < n; i += blockDim.x) {
@@ -324,7 +324,6 @@ __global__ __launch_bounds__(1024) void k_gradnorm_clip_adam(float *__restrict__
   }
   __syncthreads();
   const float coef = s_coef * scale;
-  const float omb1 = 1.f - beta1, omb2 = 1.f - beta2;
   for (long i = threadIdx.x; i < n; i += blockDim.x) {
     float gi = g[i] * coef;
     float pi = p[i];
@@ -340,15 +339,15 @@ __global__ __launch_bounds__(1024) void k_gradnorm_clip_adam(float *__restrict__
 }
 
 extern "C" int harl_gradnorm_clip_adam(float *param, float *grad, float *exp_avg, float *exp_avg_sq, long n,
-                                       const float *grad_scale, int use_clip, float max_norm, float lr, float beta1,
-                                       float beta2, float eps, float weight_decay, double bias_correction1,
-                                       double bias_correction2, float *info_out, void *stream) {
+                                       const float *grad_scale, int use_clip, float max_norm, double lr, double beta1,
+                                       double beta2, float eps, float weight_decay, double bias_correction1,
+                                       double bias_correction2, double *info_out, void *stream) {
   if (n <= 0) return 0;
-  float step_size = (float)((double)lr / bias_correction1);
+  float step_size = (float)(lr / bias_correction1);
   float bc2_sqrt = (float)sqrt(bias_correction2);
   hipLaunchKernelGGL(k_gradnorm_clip_adam, dim3(1), dim3(1024), 0, (hipStream_t)stream, param, grad, exp_avg,
-                     exp_avg_sq, n, grad_scale, use_clip, max_norm, step_size, beta1, beta2, eps, weight_decay, bc2_sqrt,
-                     info_out);
+                     exp_avg_sq, n, grad_scale, use_clip, max_norm, step_size, (float)beta1, (float)beta2,
+                     (float)(1.0 - beta1), (float)(1.0 - beta2), eps, weight_decay, bc2_sqrt, info_out);
   return check_launch("harl_gradnorm_clip_adam");
 }
 
@@ -567,8 +566,9 @@ __global__ __launch_bounds__(ADAM_THREADS) void k_adam_fold(
     float *__restrict__ p, float *__restrict__ g, float *__restrict__ m, float *__restrict__ v, long n,
     const float *__restrict__ dwp, const int *__restrict__ tab, int n_layers, float *__restrict__ packs,
     double *__restrict__ scalars, const float *__restrict__ part_scalars, int n_scalar_blocks,
-    const float *__restrict__ scalars_hilo, int mode, float const_scale, int logstd_off, int act_dim, float *__restrict__ info, int use_clip, float max_norm,
-    float lr_over_bc1, float beta1, float beta2, float eps, float wd, float bc2_sqrt, unsigned *__restrict__ ws) {
+    const float *__restrict__ scalars_hilo, int mode, float const_scale, int logstd_off, int act_dim, double *__restrict__ info, int use_clip, float max_norm,
+    float lr_over_bc1, float beta1, float beta2, float omb1, float omb2, float eps, float wd, float bc2_sqrt,
+    unsigned *__restrict__ ws) {
   __shared__ double sh[64];
   const int tid = threadIdx.x, nt = ADAM_THREADS;
   const int G = gridDim.x, blk = blockIdx.x;
@@ -710,7 +710,6 @@ __global__ __launch_bounds__(ADAM_THREADS) void k_adam_fold(
   }
   // ---- phase C: Adam
   coef *= scale;
-  const float omb1 = 1.f - beta1, omb2 = 1.f - beta2;
   for (long i = gtid; i < n; i += gnt) {
     float gi = g[i] * coef;
     const float pi = p[i];
@@ -756,16 +755,16 @@ __global__ __launch_bounds__(ADAM_THREADS) void k_adam_fold(
 extern "C" int harl_adam_fold(float *param, float *grad, float *exp_avg, float *exp_avg_sq, long n, const float *dwp,
                               const int *table, int n_layers, float *packs, double *scalars, const float *part_scalars,
                               int n_scalar_blocks, const float *scalars_hilo, int mode, float const_scale, int logstd_off,
-                              int act_dim, float *info,
-                              int use_clip, float max_norm, float lr, float beta1, float beta2, float eps,
+                              int act_dim, double *info,
+                              int use_clip, float max_norm, double lr, double beta1, double beta2, float eps,
                               float weight_decay, double bias_correction1, double bias_correction2, void *ws,
                               void *stream) {
   if (!ws) { set_error("harl_adam_fold: workspace (>= 32 KiB, zero-initialised once) is required"); return -2; }
-  const float step_size = (float)((double)lr / bias_correction1);
+  const float step_size = (float)(lr / bias_correction1);
   const float bc2_sqrt = (float)sqrt(bias_correction2);
   hipLaunchKernelGGL(k_adam_fold, dim3(ADAM_WGS), dim3(ADAM_THREADS), 0, (hipStream_t)stream, param, grad, exp_avg,
                      exp_avg_sq, n, dwp, table, n_layers, packs, scalars, part_scalars, n_scalar_blocks, scalars_hilo, mode,
-                     const_scale, logstd_off, act_dim, info, use_clip, max_norm, step_size, beta1, beta2, eps,
-                     weight_decay, bc2_sqrt, (unsigned *)ws);
+                     const_scale, logstd_off, act_dim, info, use_clip, max_norm, step_size, (float)beta1, (float)beta2,
+                     (float)(1.0 - beta1), (float)(1.0 - beta2), eps, weight_decay, bc2_sqrt, (unsigned *)ws);
   return check_launch("harl_adam_fold");
 }

@@ -505,7 +505,7 @@ extern "C" int harl_actor_head_loss(const float *xL, const uint32_t *relu_mask, 
                                     float std_y_coef, int discrete, int act_dim, const int64_t *idx,
                                     const float *actions, const float *avail, const float *old_logp, const float *adv,
                                     const double *adv_moments, const float *factor, const float *active,
-                                    float clip_param, float entropy_coef, int agg_mean, int trpo, long m_valid,
+                                    double clip_param, float entropy_coef, int agg_mean, int trpo, long m_valid,
                                     long m_pad, float *logp_out, float *dzL, float *dhead, float *part_scalars,
                                     float *dw_part, int n_wg, void *stream) {
   if (M <= 0) return 0;
@@ -518,7 +518,8 @@ extern "C" int harl_actor_head_loss(const float *xL, const uint32_t *relu_mask, 
   A.xL = xL; A.relu_mask = relu_mask; A.rstd = rstd; A.M = M; A.Whp = Whp; A.bhp = bhp; A.log_std = log_std;
   A.std_x_coef = std_x_coef; A.std_y_coef = std_y_coef; A.act_dim = act_dim; A.idx = idx;
   A.actions = actions; A.avail = avail; A.old_logp = old_logp; A.adv = adv; A.adv_moments = adv_moments;
-  A.factor_in = factor; A.active = active; A.clip_param = clip_param; A.entropy_coef = entropy_coef;
+  A.factor_in = factor; A.active = active; A.entropy_coef = entropy_coef;
+  A.clip_lo = (float)(1.0 - clip_param); A.clip_hi = (float)(1.0 + clip_param);  // torch.clamp(imp, 1 - c, 1 + c): Python doubles
   A.agg_mean = agg_mean; A.dzL = dzL; A.dhead = dhead; A.part_scalars = part_scalars; A.n_slabs = n_slabs_of(M);
   return dispatch_actor<true>(A, H, discrete, dw_part ? n_wg : head_grid(M), (hipStream_t)stream);
 }

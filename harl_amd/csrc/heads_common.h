@@ -24,7 +24,7 @@ struct ActorArgs {
   const float *actions, *avail, *old_logp, *adv;
   const double *adv_moments;
   const float *factor_in, *active;
-  float clip_param, entropy_coef;
+  float clip_lo, clip_hi, entropy_coef;  // clip bounds 1 -+ clip_param, formed in double by the launcher
   int agg_mean;
   float *dzL, *dhead, *part_scalars;
   float *dw_part;   // fused head weight gradient: per-workgroup partials [gridDim.x][32*H + 32] (NULL: write dhead instead)
@@ -513,7 +513,7 @@ __device__ __forceinline__ bool actor_sample(const ActorArgs &A, const float *cs
   const float act = A.active ? A.active[row] : 1.f;
   const float advn = (A.adv[row] - adv_mean) * adv_den;  // adv_den: RECIPROCAL of (std + 1e-5), formed once per kernel
   const float fct = A.factor_in ? A.factor_in[row] : 1.f;  // NULL: no sequential-update factor (MAPPO)
-  const float lo = 1.f - A.clip_param, hi = 1.f + A.clip_param;
+  const float lo = A.clip_lo, hi = A.clip_hi;
   const float surr1 = imp * advn;
   const float impc = fminf(fmaxf(imp, lo), hi);
   const float surr2 = impc * advn;

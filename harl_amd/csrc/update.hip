@@ -753,7 +753,7 @@ extern "C" int harl_update_fwd_actor(const float *x0n, long M, int D, int H, con
                                      const float *log_std, float std_x_coef, float std_y_coef, int discrete, int act_dim,
                                      const float *actions, const float *avail, const float *old_logp, const float *adv,
                                      const double *adv_moments, const float *factor, const float *active,
-                                     float clip_param, float entropy_coef, int agg_mean, int trpo, float *logp_out,
+                                     double clip_param, float entropy_coef, int agg_mean, int trpo, float *logp_out,
                                      float *dz2, float *part_scalars, float *dw_part_head, int n_part_rows, void *stream) {
   if (M <= 0) return 0;
   if (D < 1 || D > 64) return bad("harl_update_fwd_actor: input width must be <= 64");
@@ -767,7 +767,8 @@ extern "C" int harl_update_fwd_actor(const float *x0n, long M, int D, int H, con
   A.M = M; A.Whp = Whp; A.bhp = bhp; A.log_std = log_std;
   A.std_x_coef = std_x_coef; A.std_y_coef = std_y_coef; A.act_dim = act_dim;
   A.actions = actions; A.avail = avail; A.old_logp = old_logp; A.adv = adv; A.adv_moments = adv_moments;
-  A.factor_in = factor; A.active = active; A.clip_param = clip_param; A.entropy_coef = entropy_coef;
+  A.factor_in = factor; A.active = active; A.entropy_coef = entropy_coef;
+  A.clip_lo = (float)(1.0 - clip_param); A.clip_hi = (float)(1.0 + clip_param);  // torch.clamp(imp, 1 - c, 1 + c): Python doubles
   A.agg_mean = agg_mean; A.part_scalars = part_scalars; A.n_slabs = U.n_slabs;
   return dispatch_fwd_actor<true>(U, A, H, discrete, (hipStream_t)stream);
 }

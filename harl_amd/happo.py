@@ -95,17 +95,35 @@ class OnPolicyBase:
         return None if not h_last else seq["h_last"][:m]
 
     def evaluate_actions(self, obs, rnn_states_actor, action, masks, available_actions=None, active_masks=None):
-        """Returns (action_log_probs [B, act_w] device tensor, None, None).  Entropy and the distribution object are
-        only consumed inside ``update`` in the reference's on-policy path; they are fused into the loss kernel."""
+        """(action_log_probs [B, act_w], dist_entropy 0-d, action_distribution) as the reference returns them
+        (stochastic_policy.py:88-127, act.py:104-157): the entropy is the active-mask-weighted mean over rows when
+        ``use_policy_active_masks`` and masks are given, the plain mean otherwise; the distribution is a
+        ``torch.distributions`` object built from the head outputs (Gaussian mean / sigma, or normalised masked logits).
+        Device tensors, no autograd graph (the update path differentiates inside the kernels)."""
         obs = _as_dev(obs, self.device)
         obs = obs.reshape(obs.shape[0], -1)
         action = _as_dev(action, self.device).reshape(obs.shape[0], -1)
         avail = None if available_actions is None else _as_dev(available_actions, self.device).reshape(obs.shape[0], -1)
         M = obs.shape[0]
-        out = torch.empty(M, self.actor.act_w, **self.tpdv)
-        self.actor.fold()
-        self._logp_pass(obs, action, avail, M, out, rnn_states=rnn_states_actor, masks=masks)
-        return out, None, None
+        net = self.actor
+        out = torch.empty(M, net.act_w, **self.tpdv)
+        head = torch.empty(M, net.act_dim, **self.tpdv)
+        net.fold()
+        self._logp_pass(obs, action, avail, M, out, head_out=head, rnn_states=rnn_states_actor, masks=masks)
+        if net.discrete:  # head = normalised logits (masked entries ~ -1e10): Categorical(logits=...).entropy()
+            dist = torch.distributions.Categorical(logits=head)
+            p = torch.exp(head)
+            ent_rows = -(torch.clamp(head, min=torch.finfo(torch.float32).min) * p).sum(-1, keepdim=True)
+        else:
+            sigma = (torch.sigmoid(net.log_std() / net.std_x_coef) * net.std_y_coef).expand_as(head)
+            dist = torch.distributions.Normal(head, sigma)
+            ent_rows = (0.5 + 0.9189385332046727 + torch.log(sigma)).sum(-1, keepdim=True)
+        if active_masks is not None and self.use_policy_active_masks:
+            am = _as_dev(active_masks, self.device).reshape(M, 1)
+            entropy = (ent_rows * am).sum() / am.sum()
+        else:
+            entropy = ent_rows.mean()
+        return out, entropy, dist
 
     @torch.no_grad()
     def get_actions(self, obs, rnn_states_actor, masks, available_actions=None, deterministic=False):
@@ -120,7 +138,8 @@ class OnPolicyBase:
         avail = None if available_actions is None else _as_dev(available_actions, self.device).reshape(M, -1)
         net.fold()
         head = torch.empty(M, net.act_dim, **self.tpdv)
-        rnn_out = rnn_states_actor
+        # (always a device tensor: the reference's callers apply _t2n to it, on_policy_base_runner.py:310-312,533)
+        rnn_out = None if rnn_states_actor is None else _as_dev(rnn_states_actor, self.device)
         h = self._logp_pass(x, None, avail, M, None, head_out=head, rnn_states=rnn_states_actor, masks=masks,
                             h_last=True)  # head_out only: no actions needed
         if net.recurrent:
@@ -159,7 +178,7 @@ class HAPPO(OnPolicyBase):
         self.use_max_grad_norm = args["use_max_grad_norm"]
         self.max_grad_norm = args["max_grad_norm"]
         self._surrogate_mode = 0  # harl_actor_head_loss `trpo` argument: 0 = clipped (HAPPO)
-        self._info = torch.zeros(4, **self.tpdv)  # sums of policy_loss, dist_entropy, grad_norm, ratio
+        self._info = torch.zeros(4, dtype=torch.float64, device=self.device)  # fp64 sums of the per-update fp32 policy_loss, dist_entropy, grad_norm, ratio (the reference sums .item() values: happo.py:145-150)
         self._grad_tap = None
         self._trace = None  # test hook: list receiving a clone of the running statistics after every optimiser step
 

@@ -28,13 +28,13 @@ ALGO_REGISTRY = {"happo": HAPPO, "hatrpo": HATRPO, "haa2c": HAA2C, "mappo": MAPP
 class OnPolicyHARunner:
     def __init__(self, args: dict, algo_args: dict, env_args: Optional[dict] = None, *, obs_spaces=None,
                  share_obs_space=None, act_spaces=None, device: Optional[torch.device] = None,
-                 comm: Optional[Comm] = None, envs=None, logger=None):
+                 comm: Optional[Comm] = None, envs=None, logger=None, eval_envs=None, save_dir: Optional[str] = None):
         """``args``/``algo_args`` as in examples/train.py:87-91.  Spaces must be given explicitly or through ``envs``
         (a vectorised environment with the reference's ``ShareVecEnv`` surface: ``observation_space``,
         ``share_observation_space``, ``action_space`` lists and ``reset()/step()``, envs/env_wrappers.py); this class
         does not create environments.  With an initialised process group, ``algo_args['train']['n_rollout_threads']`` is
         the GLOBAL thread count and this rank keeps its contiguous column shard."""
-        self.envs, self.logger = envs, logger
+        self.envs, self.logger, self.eval_envs, self.save_dir = envs, logger, eval_envs, save_dir
         if envs is not None and obs_spaces is None:
             obs_spaces, act_spaces = list(envs.observation_space), list(envs.action_space)
             share_obs_space = envs.share_observation_space[0]
@@ -80,15 +80,36 @@ class OnPolicyHARunner:
         else:
             self.critic_buffer = OnPolicyCriticBufferFP(cb_args, share_obs_space, self.num_agents, device=self.device)
         self.value_normalizer = ValueNorm(1, device=self.device) if algo_args["train"]["use_valuenorm"] else None
-        shard = (n_global, lo, hi) if self.comm.enabled else None
-        for x in self.actor + [self.critic]:
+        self._init_update_state(n_global)
+        if algo_args["train"].get("model_dir") is not None:  # on_policy_base_runner.py:168-169
+            self.restore(algo_args["train"]["model_dir"])
+
+    def _init_update_state(self, n_global: Optional[int] = None, comm: Optional[Comm] = None) -> None:
+        """Everything train() / compute() need beyond the reference runner's own attributes (the drop-in subclasses of the
+        reference's OnPolicyBaseRunner get it lazily through ``_ensure_update_state``): the communicator, this rank's column
+        shard, and the pinned / device scratch of train()."""
+        if not hasattr(self, "comm") or self.comm is None:
+            self.comm = comm if comm is not None else Comm()
+        if n_global is None:
+            n_global = self.algo_args["train"]["n_rollout_threads"]
+        if not hasattr(self, "col_lo"):
+            self.n_global = n_global
+            self.col_lo, self.col_hi = shard_columns(n_global, self.comm.rank, self.comm.world_size)
+        shard = (self.n_global, self.col_lo, self.col_hi) if self.comm.enabled else None
+        for x in list(self.actor) + [self.critic]:
             x.comm, x.shard = self.comm, shard
         self._logp_old = None
         self._counts_host = None
+        self._update_state_ready = True
+
+    def _ensure_update_state(self) -> None:
+        if not getattr(self, "_update_state_ready", False):
+            self._init_update_state()
 
     # ---- on_policy_base_runner.py:462-484 -------------------------------------------------------
     @torch.no_grad()
     def compute(self):
+        self._ensure_update_state()
         cb = self.critic_buffer
         if self.state_type == "EP":
             next_value, _ = self.critic.get_values(cb.share_obs[-1], cb.rnn_states_critic[-1], cb.masks[-1])
@@ -102,6 +123,7 @@ class OnPolicyHARunner:
     # ---- on_policy_ha_runner.py:11-130 ------------------------------------------------------------
     @torch.no_grad()
     def train(self):
+        self._ensure_update_state()
         T = self.algo_args["train"]["episode_length"]
         N = self.col_hi - self.col_lo
         B = T * N
@@ -133,7 +155,7 @@ class OnPolicyHARunner:
         # counts that do not depend on the order) its kernels are enqueued BEFORE the host waits on that event: the GPU
         # works through them while the host queues the first actor's launches instead of idling behind a drained stream.
         if self._counts_host is None or self._counts_host.numel() != self.num_agents:
-            self._counts_host = torch.empty(self.num_agents, dtype=torch.float64, pin_memory=True)
+            self._counts_host = torch.empty(self.num_agents, dtype=torch.float64, pin_memory=torch.cuda.is_available())
         self._counts_host.copy_(mom_all[:, 2], non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
@@ -287,8 +309,9 @@ class OnPolicyHARunner:
 
     def run(self, num_episodes: Optional[int] = None):
         """The reference's training loop (:171-267) over ``self.envs``: warmup, then per episode lr decay, T x
-        (collect -> envs.step -> insert), compute, train, after_update.  Returns the per-episode
-        (actor_train_infos, critic_train_info, mean step reward) list; ``logger`` callbacks are invoked if one was given."""
+        (collect -> envs.step -> insert), compute, train, [log], every ``eval_interval`` episodes [eval +] save,
+        after_update.  Returns the per-episode (actor_train_infos, critic_train_info, mean step reward) list; ``logger``
+        callbacks are invoked if one was given; checkpoints go to ``self.save_dir`` when it is set."""
         if self.envs is None:
             raise RuntimeError("run() needs a vectorised environment (envs=...)")
         tr = self.algo_args["train"]
@@ -319,12 +342,66 @@ class OnPolicyHARunner:
             history.append((infos_a, info_c, self.critic_buffer.get_mean_rewards()))
             if self.logger is not None and episode % tr.get("log_interval", 1) == 0:
                 self.logger.episode_log(infos_a, info_c, self.actor_buffer, self.critic_buffer)
+            if episode % tr.get("eval_interval", 25) == 0:  # on_policy_base_runner.py:252-258
+                if self.algo_args.get("eval", {}).get("use_eval", False) and self.eval_envs is not None:
+                    self.prep_rollout()
+                    self.eval()
+                if getattr(self, "save_dir", None):
+                    self.save(self.save_dir)
             self.after_update()
         return history
 
+    @torch.no_grad()
+    def eval(self):
+        """Deterministic evaluation episodes on ``self.eval_envs`` (on_policy_base_runner.py:499-590): actions from
+        ``actor.act(..., deterministic=True)``, hidden states reset and masks 0 where an environment finished, logger
+        callbacks ``eval_init / eval_per_step / eval_thread_done / eval_log``; returns the mean episode reward."""
+        import numpy as np
+        ev = self.algo_args["eval"]
+        n_thr, A = ev["n_eval_rollout_threads"], self.num_agents
+        lg = self.logger
+        if lg is not None:
+            lg.eval_init()
+        obs, _share, avail = self.eval_envs.reset()
+        H = self.algo_args["model"]["hidden_sizes"][-1]
+        rn = self.algo_args["model"]["recurrent_n"]
+        rnn = torch.zeros(n_thr, A, rn, H, dtype=torch.float32, device=self.device)
+        masks = torch.ones(n_thr, A, 1, dtype=torch.float32, device=self.device)
+        done_eps, ep_rewards, cur = 0, [], np.zeros(n_thr)
+        while True:
+            acts = []
+            obs_d = torch.as_tensor(np.asarray(obs), dtype=torch.float32).to(self.device)
+            av_d = None if (avail is None or avail[0] is None) else torch.as_tensor(np.asarray(avail), dtype=torch.float32).to(self.device)
+            for a in range(A):
+                act, r_ = self.actor[a].act(obs_d[:, a], rnn[:, a], masks[:, a], None if av_d is None else av_d[:, a],
+                                            deterministic=True)
+                rnn[:, a] = r_.reshape(n_thr, rn, H)
+                acts.append(act)
+            actions = torch.stack(acts, 1).cpu().numpy()
+            obs, share, rewards, dones, infos, avail = self.eval_envs.step(actions)
+            if lg is not None:
+                lg.eval_per_step((obs, share, rewards, dones, infos, avail))
+            cur += np.mean(np.asarray(rewards), axis=1).reshape(n_thr)
+            dones_env = np.all(np.asarray(dones), axis=1)
+            keep = torch.as_tensor(~dones_env).to(self.device).float()
+            rnn = rnn * keep.view(n_thr, 1, 1, 1)
+            masks = keep.view(n_thr, 1, 1).expand(n_thr, A, 1).contiguous()
+            for i in range(n_thr):
+                if dones_env[i]:
+                    done_eps += 1
+                    ep_rewards.append(cur[i])
+                    cur[i] = 0.0
+                    if lg is not None:
+                        lg.eval_thread_done(i)
+            if done_eps >= ev["eval_episodes"]:
+                if lg is not None:
+                    lg.eval_log(done_eps)
+                return float(np.mean(ep_rewards))
+
     def close(self):
-        if self.envs is not None and hasattr(self.envs, "close"):
-            self.envs.close()
+        for e in (self.envs, getattr(self, "eval_envs", None)):
+            if e is not None and hasattr(e, "close"):
+                e.close()
 
     def prep_rollout(self):
         for a in self.actor:
@@ -337,7 +414,10 @@ class OnPolicyHARunner:
         self.critic.prep_training()
 
     # ---- on_policy_base_runner.py:724-763: same file names, same state_dict keys ---------------------
-    def save(self, save_dir: str):
+    def save(self, save_dir: Optional[str] = None):
+        if save_dir is None:
+            save_dir = self.save_dir
+        save_dir = str(save_dir)
         os.makedirs(save_dir, exist_ok=True)
         for a in range(self.num_agents):
             torch.save(self.actor[a].actor.state_dict(), os.path.join(save_dir, f"actor_agent{a}.pt"))
@@ -345,7 +425,9 @@ class OnPolicyHARunner:
         if self.value_normalizer is not None:
             torch.save(self.value_normalizer.state_dict(), os.path.join(save_dir, "value_normalizer.pt"))
 
-    def restore(self, model_dir: str):
+    def restore(self, model_dir: Optional[str] = None):
+        if model_dir is None:
+            model_dir = self.algo_args["train"]["model_dir"]
         for a in range(self.num_agents):
             self.actor[a].actor.load_state_dict(torch.load(os.path.join(model_dir, f"actor_agent{a}.pt"), map_location=self.device))
         self.critic.critic.load_state_dict(torch.load(os.path.join(model_dir, "critic_agent.pt"), map_location=self.device))
@@ -360,6 +442,7 @@ class OnPolicyMARunner(OnPolicyHARunner):
 
     @torch.no_grad()
     def train(self):
+        self._ensure_update_state()
         dev = self.device
         A = self.num_agents
         for x in self.actor:

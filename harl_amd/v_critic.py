@@ -40,7 +40,7 @@ class VCritic:
         self.critic_optimizer = FusedAdam(self.critic, self.critic_lr, self.opti_eps, self.weight_decay)
         self.comm = Comm()
         self.shard = None
-        self._info = torch.zeros(2, **self.tpdv)  # sums of value_loss, critic_grad_norm
+        self._info = torch.zeros(2, dtype=torch.float64, device=self.device)  # fp64 sums of the per-update fp32 value_loss, critic_grad_norm (v_critic.py:186-187)
         self._grad_tap = None
         self._trace = None  # test hook: snapshots of the running statistics after every optimiser step
 
@@ -61,11 +61,11 @@ class VCritic:
         out = torch.empty(M, 1, **self.tpdv)
         if net.fused_update_ok(None, train=False):
             call("harl_update_values", *net.fused_args(x, M), ptr(out), stream(), tag="update_values")
-            return out, rnn_states_critic
+            return out, (None if rnn_states_critic is None else _as_dev(rnn_states_critic, self.device))
         if not net.recurrent:
             net.forward_trunk(x, None, M, for_backward=False)
             call("harl_critic_head_values", ptr(net.xh[-1]), M, net.hidden_sizes[-1], ptr(Wp), ptr(bp), ptr(out), stream())
-            return out, rnn_states_critic
+            return out, (None if rnn_states_critic is None else _as_dev(rnn_states_critic, self.device))
         H = net.hidden_sizes[-1]
         h0 = _as_dev(rnn_states_critic, self.device)
         m = h0.shape[0]

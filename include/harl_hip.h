@@ -75,12 +75,14 @@ int harl_valuenorm_apply(float *vn_stats, const double *sums2, double count, dou
  *   grad is first multiplied by *grad_scale (device scalar, e.g. 1/sum(active); NULL = 1);
  *   norm = ||grad||_2 ; if use_clip: grad *= min(1, max_norm/(norm+1e-6));
  *   m += (1-b1)(g-m); v = b2 v + (1-b2) g^2; p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
- *   info_out[0] += norm (pre-clip) if info_out != NULL.
+ *   lr, beta1, beta2 are DOUBLES as in torch.optim.Adam: 1-beta and lr/bc1 are formed in double and then rounded
+ *   (1.f - 0.999f is 1.3e-5 away from float(0.001): enough to bias every step of the run).
+ *   info_out[0] += norm (pre-clip) if info_out != NULL (double accumulator: the reference sums Python floats).
  */
 int harl_gradnorm_clip_adam(float *param, float *grad, float *exp_avg, float *exp_avg_sq, long n,
-                            const float *grad_scale, int use_clip, float max_norm, float lr, float beta1,
-                            float beta2, float eps, float weight_decay, double bias_correction1,
-                            double bias_correction2, float *info_out, void *stream);
+                            const float *grad_scale, int use_clip, float max_norm, double lr, double beta1,
+                            double beta2, float eps, float weight_decay, double bias_correction1,
+                            double bias_correction2, double *info_out, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * MLP (harl/models/base/mlp.py:7-70) on the matrix pipes (H x H GEMMs: bf16 MFMA with an exact three-way fp32 operand
@@ -170,7 +172,8 @@ int harl_pack_scalars_hilo(const double *scalars, float *hilo, void *stream);
  * gradient scale + statistics (info), unfold the folded gradients of every table entry into `grad` (reference parameter
  * layout; Linears sharing one LayerNorm accumulate its gradients), ||grad||, clip, Adam, re-fold the updated weights into
  * `packs`.  mode 0 (actor): scale = 1/scalars[1] (sum active), info += {loss, entropy, grad_norm, ratio};
- * mode 1 (critic): scale = const_scale (= value_loss_coef / m), info += {value_loss, grad_norm}.
+ * mode 1 (critic): scale = const_scale (= value_loss_coef / m), info += {value_loss, grad_norm}.  `info` is double: every
+ * update's fp32 figure is added the way the reference adds `.item()` values to a Python float (happo.py:145-150).
  * part_scalars != NULL: `scalars` (double[HARL_PS_STRIDE]) is first computed here as the fixed-order sum of the loss
  * kernel's n_scalar_blocks partial rows (single-GPU path); else scalars_hilo != NULL: `scalars` = sum of the four
  * all-reduced fp32 pieces written by harl_pack_scalars_hilo (data-parallel path); else `scalars` already holds the sums.
@@ -180,8 +183,8 @@ int harl_pack_scalars_hilo(const double *scalars, float *hilo, void *stream);
 int harl_adam_fold(float *param, float *grad, float *exp_avg, float *exp_avg_sq, long n, const float *dwp,
                    const int *table, int n_layers, float *packs, double *scalars, const float *part_scalars,
                    int n_scalar_blocks, const float *scalars_hilo, int mode, float const_scale, int logstd_off,
-                   int act_dim, float *info,
-                   int use_clip, float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay,
+                   int act_dim, double *info,
+                   int use_clip, float max_norm, double lr, double beta1, double beta2, float eps, float weight_decay,
                    double bias_correction1, double bias_correction2, void *ws, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
@@ -221,7 +224,7 @@ int harl_actor_head_loss(const float *xL, const uint32_t *relu_mask, const float
                          const float *Whp, const float *bhp, const float *log_std, float std_x_coef,
                          float std_y_coef, int discrete, int act_dim, const int64_t *idx, const float *actions,
                          const float *avail, const float *old_logp, const float *adv, const double *adv_moments,
-                         const float *factor, const float *active, float clip_param, float entropy_coef,
+                         const float *factor, const float *active, double clip_param, float entropy_coef,
                          int agg_mean, int trpo, long m_valid, long m_pad, float *logp_out, float *dzL, float *dhead,
                          float *part_scalars, float *dw_part, int n_wg, void *stream);
 /* V head forward: values[M] = Whp . xL + bhp   (v_net.py:64) */
@@ -305,7 +308,7 @@ int harl_update_fwd_actor(const float *x0n, long M, int D, int H, const float *W
                           const float *b2p, const float *Whp, const float *bhp, const float *log_std, float std_x_coef,
                           float std_y_coef, int discrete, int act_dim, const float *actions, const float *avail,
                           const float *old_logp, const float *adv, const double *adv_moments, const float *factor,
-                          const float *active, float clip_param, float entropy_coef, int agg_mean, int trpo,
+                          const float *active, double clip_param, float entropy_coef, int agg_mean, int trpo,
                           float *logp_out, float *dz2, float *part_scalars, float *dw_part_head, int n_part_rows,
                           void *stream);
 int harl_update_logp(const float *x0n, long M, int D, int H, const float *W1p, const float *b1p, const float *W2p,

@@ -9,13 +9,14 @@ rounding error on each figure.  Some of the logged figures are ill-conditioned (
 advantage-normalised surrogates, i.e. a difference of nearly equal sums), so that error is far above 1e-5 for them
 in the reference itself; tests/gpu_checks.py holds the HIP path to  max(1e-5, C x that error)  entry by entry instead
 of one blanket tolerance.  A second yardstick is stored next to it: the same fp32 update with every parameter moved by ONE
-ulp (random direction) at the start and again after every optimiser step, 8 independent runs -- `sens_*` = how far the
+ulp (random direction) at the start and again after every optimiser step, 32 independent runs -- `sens_*` = how far the
 reference's own figures move under the smallest perturbation fp32 can express, injected at the rate at which two correct fp32
 implementations differ (once per step).  Sequential Adam steps amplify such rounding-level differences by one to two orders
 of magnitude by the end of train().
 
     python oracle/gen_noise_floor.py            # all cases (about a minute)
 """
+import copy
 import os
 import sys
 
@@ -42,6 +43,38 @@ def _perturb_one_ulp(nets, seed, gen=None) -> None:
                                     torch.nextafter(v, torch.full_like(v, float("-inf")))))
 
 
+def _make_grad_hook(gen):
+    """g_fp32 = g_exact + e  ->  g_exact + s * e  with a random sign per element (see the module docstring)."""
+    stash = {}
+
+    def hook(phase, obj, sample, vn):
+        if O.WORK_DTYPE != torch.float32:
+            return
+        if phase == "pre":  # the exact gradient at the current parameters: a float64 clone of this network, same minibatch
+            saved = (O.GRAD_HOOK, O.STEP_HOOK)
+            O.GRAD_HOOK = O.STEP_HOOK = None
+            O.set_work_dtype(torch.float64)
+            try:
+                clone = type(obj)({k: v.detach() for k, v in obj.net.p.items()}, obj.cfg)
+                if isinstance(obj, O.OracleVCritic):
+                    stash[id(obj)] = clone.update(sample, copy.deepcopy(vn), keep_grad=True)[-1]
+                else:
+                    stash[id(obj)] = clone.update(sample, keep_grad=True)[-1]
+            finally:
+                O.set_work_dtype(torch.float32)
+                O.GRAD_HOOK, O.STEP_HOOK = saved
+            return
+        g64, off = torch.from_numpy(np.asarray(stash.pop(id(obj)), dtype=np.float64)), 0
+        for p in obj.net.params():
+            n = p.numel()
+            e = p.grad.reshape(-1).double() - g64[off:off + n]
+            off += n
+            s = (torch.rand(n, generator=gen) < 0.5).double() * 2.0 - 1.0
+            p.grad.add_(((s - 1.0) * e).to(p.grad.dtype).reshape(p.shape))
+
+    return hook
+
+
 def run_case(name: str, dtype=torch.float64, perturb_seed=None) -> dict:
     case = GoldenCase(name)
     torch.set_num_threads(1)
@@ -60,6 +93,8 @@ def run_case(name: str, dtype=torch.float64, perturb_seed=None) -> dict:
             # reference by rounding in every operation of every step, not by one kick at the start
             hook_gen = torch.Generator().manual_seed(perturb_seed + 77)
             O.STEP_HOOK = lambda net: _perturb_one_ulp([net], None, hook_gen)
+            if case.algo_name != "hatrpo":  # (HATRPO's CG / line-search update has no single gradient step to perturb)
+                O.GRAD_HOOK = _make_grad_hook(torch.Generator().manual_seed(perturb_seed + 991))
         torch.manual_seed(case.seed + 12345)
         cbuf.compute_returns(cbuf.value_preds[-1].copy(), vn, cfg)
         if case.algo_name == "mappo":
@@ -69,6 +104,7 @@ def run_case(name: str, dtype=torch.float64, perturb_seed=None) -> dict:
     finally:
         O.set_work_dtype(torch.float32)
         O.STEP_HOOK = None
+        O.GRAD_HOOK = None
     out = {}
     if case.algo_name == "hatrpo":
         out["actor_infos"] = np.array([[float(i["kl"]), float(i["loss_improve"]), float(np.asarray(i["expected_improve"]).reshape(-1)[0]),
@@ -88,7 +124,7 @@ def run_case(name: str, dtype=torch.float64, perturb_seed=None) -> dict:
     return out
 
 
-N_PERT = 8
+N_PERT = 32
 
 
 def main():
@@ -119,7 +155,7 @@ def main():
         msg = f"{name:28s} infos {rel(z['actor_infos'], res['actor_infos']):.2e}  critic {rel(z['critic_info'], res['critic_info']):.2e}"
         if "actor_trace" in res and "actor_trace" in z.files:
             msg += f"  actor_trace {rel(z['actor_trace'][:, 1:], res['actor_trace'][:, 1:]):.2e}  critic_trace {rel(z['critic_trace'], res['critic_trace']):.2e}"
-            msg += f"  | 1-ulp sensitivity: actor_trace {float(sens['actor_trace'].max()):.2e} critic_trace {float(sens['critic_trace'].max()):.2e}"
+            msg += f"  | sensitivity: actor_trace {float(sens['actor_trace'].max()):.2e} critic_trace {float(sens['critic_trace'].max()):.2e}"
         msg += f" infos {float(sens['actor_infos'].max()):.2e} final {max(float(v) for k, v in sens.items() if 'final' in k):.2e}"
         print(msg, flush=True)
 

@@ -156,6 +156,9 @@ WORK_DTYPE = torch.float32
 
 
 STEP_HOOK = None  # callable(net) invoked after every Adam step (sensitivity measurements only)
+# callable(phase, obj, sample, vn): phase "pre" at the start of every update() (before ValueNorm moves), "post" after
+# backward() and before the clip / Adam step (sensitivity measurements only: oracle/gen_noise_floor.py)
+GRAD_HOOK = None
 
 
 def set_work_dtype(dt) -> None:
@@ -391,6 +394,8 @@ class OracleHAPPO:
         if factor is None:  # MAPPO (mappo.py:36-95): no sequential-update factor
             factor = torch.ones_like(adv)
         rnn, msk = (_t(sample[7]), _t(sample[8])) if len(sample) > 7 else (None, None)
+        if GRAD_HOOK is not None:
+            GRAD_HOOK("pre", self, sample, None)
         logp, ent, _ = actor_evaluate_actions(self.net.p, cfg, obs, actions, avail, active, rnn, msk)
         agg = getattr(torch, cfg.action_aggregation)
         imp = agg(torch.exp(logp - old_logp), dim=-1, keepdim=True)
@@ -406,6 +411,8 @@ class OracleHAPPO:
             pl = -torch.sum(factor * surr, dim=-1, keepdim=True).mean()
         self.net.opt.zero_grad()
         (pl - ent * cfg.entropy_coef).backward()
+        if GRAD_HOOK is not None:
+            GRAD_HOOK("post", self, sample, None)
         g = self.net.flat_grad() if keep_grad else None
         gn = _grad_norm_step(self.net, cfg)
         return pl.detach(), ent.detach(), gn.detach(), imp.detach(), g
@@ -527,10 +534,14 @@ class OracleVCritic:
     def update(self, sample, vn, keep_grad: bool = False):  # v_critic.py:116-157
         share_obs, value_preds, returns = (_t(s) for s in sample[:3])
         rnn, msk = (_t(sample[3]), _t(sample[4])) if len(sample) > 3 else (None, None)
+        if GRAD_HOOK is not None:
+            GRAD_HOOK("pre", self, sample, vn)
         values = critic_forward(self.net.p, share_obs, rnn, msk)
         loss = self.value_loss(values, value_preds, returns, vn)
         self.net.opt.zero_grad()
         (loss * self.cfg.value_loss_coef).backward()
+        if GRAD_HOOK is not None:
+            GRAD_HOOK("post", self, sample, vn)
         g = self.net.flat_grad() if keep_grad else None
         gn = _grad_norm_step(self.net, self.cfg)
         return loss.detach(), gn.detach(), g

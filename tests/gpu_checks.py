@@ -18,7 +18,7 @@ from harl_amd import _lib
 from harl_amd._lib import call, ptr, stream
 from harl_amd.synthetic import Shapes, actor_param_shapes, critic_param_shapes, make_buffers, synthetic_state_dict
 from oracle import harl_oracle as O
-from tests.helpers import GoldenCase, excess, load_noise, rel_err, vec_excess, vec_rel_err
+from tests.helpers import GoldenCase, excess, excess_at, load_noise, rel_err, vec_excess, vec_rel_err
 
 DEV = torch.device("cuda:0")
 
@@ -194,7 +194,7 @@ def check_adam() -> Dict[str, float]:
         pt = torch.nn.Parameter(torch.from_numpy(p0.copy()))
         opt = torch.optim.Adam([pt], lr=5e-4, eps=1e-5, weight_decay=0)
         gp, gm, gv = dev(p0), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
-        info = torch.zeros(1, device=DEV)
+        info = torch.zeros(1, dtype=torch.float64, device=DEV)
         sc = dev(np.array([scale], dtype=np.float32))
         norms = []
         for step in range(1, 6):
@@ -266,11 +266,19 @@ def check_forward(spec) -> Dict[str, float]:
     avail = None if not sh.discrete else d.available_actions[0][:-1].reshape(M, -1)
     p = {k: torch.from_numpy(v) for k, v in sd.items()}
     with torch.no_grad():
-        ref, _, _ = O.actor_evaluate_actions(p, cfg, torch.from_numpy(obs), torch.from_numpy(act),
-                                             None if avail is None else torch.from_numpy(avail), None)
-    got, _, _ = actor.evaluate_actions(obs, None, act, None, avail, None)
+        ref, ent_ref, _ = O.actor_evaluate_actions(p, cfg, torch.from_numpy(obs), torch.from_numpy(act),
+                                                   None if avail is None else torch.from_numpy(avail), None)
+        am = torch.from_numpy((np.random.default_rng(1).random((M, 1)) > 0.3).astype(np.float32))
+        _, ent_ref_m, _ = O.actor_evaluate_actions(p, cfg, torch.from_numpy(obs), torch.from_numpy(act),
+                                                   None if avail is None else torch.from_numpy(avail), am)
+    got, ent, dist = actor.evaluate_actions(obs, None, act, None, avail, None)
+    _, ent_m, _ = actor.evaluate_actions(obs, None, act, None, avail, am.numpy())
     torch.cuda.synchronize()
     out["logp_vec_rel"] = vec_rel_err(got.cpu().numpy(), ref.numpy())
+    out["entropy_rel"] = rel_err(ent.item(), float(ent_ref))            # stochastic_policy.py:88-127 returns all three
+    out["entropy_active_masked_rel"] = rel_err(ent_m.item(), float(ent_ref_m))
+    out["dist_logp_vec_rel"] = vec_rel_err((dist.log_prob(torch.as_tensor(act, device=DEV).squeeze(-1)).reshape(M, -1) if sh.discrete
+                                            else dist.log_prob(torch.as_tensor(act, device=DEV))).cpu().numpy(), ref.numpy())
     critic, csd, _ = _mk_critic(sh, 777, **over)
     so = d.share_obs[:-1].reshape(M, -1)
     with torch.no_grad():
@@ -777,7 +785,7 @@ def check_train_golden(name: str) -> Dict[str, float]:
         # per-update parity: the k-th optimiser step of every agent against the reference's k-th step of that agent
         # (policy_loss, dist_entropy, grad_norm, ratio), and the critic's steps (value_loss, grad_norm)
         gt, nt, st = z["actor_trace"], nz["actor_trace"], nz["sens_actor_trace"]
-        first, worst, wkey, exc = 0.0, 0.0, "", 0.0
+        first, worst, wkey, exc, exc_at = 0.0, 0.0, "", 0.0, ""
         for a in range(case.shapes.A):
             ga, na, sa = gt[gt[:, 0] == a][:, 1:], nt[nt[:, 0] == a][:, 1:], st[nt[:, 0] == a][:, 1:]
             tr = r.actor[a]._trace
@@ -788,7 +796,12 @@ def check_train_golden(name: str) -> Dict[str, float]:
             n = min(len(per), len(ga))
             e = np.abs(per[:n] - ga[:n]) / (np.abs(ga[:n]) + 1e-12)
             first = max(first, float(e[0].max()))
-            exc = max(exc, excess(per[:n], ga[:n], na[:n], sa[:n]))
+            out.setdefault("_trace_policy_loss_err", {})[a] = " ".join(f"{x:.1e}" for x in e[:, 0])
+            out.setdefault("_trace_gradnorm_err", {})[a] = " ".join(f"{x:.1e}" for x in e[:, 2])
+            out.setdefault("_trace_policy_loss_ref", {})[a] = " ".join(f"{x:.4g}" for x in ga[:n, 0])
+            ex_a = excess(per[:n], ga[:n], na[:n], sa[:n])
+            if ex_a > exc:
+                exc, exc_at = ex_a, f"agent{a} " + excess_at(per[:n], ga[:n], na[:n], sa[:n])
             if float(e.max()) > worst:
                 k, c = np.unravel_index(np.argmax(e), e.shape)
                 worst, wkey = float(e.max()), f"agent{a}/update{k}/{('policy_loss', 'entropy', 'grad_norm', 'ratio')[c]}"
@@ -796,6 +809,7 @@ def check_train_golden(name: str) -> Dict[str, float]:
         out["_actor_trace_max_rel"] = worst
         out["_actor_trace_worst"] = wkey
         out["actor_trace_excess"] = exc
+        out["_actor_trace_excess_at"] = exc_at
         gc = z["critic_trace"]
         cum = torch.stack(r.critic._trace).double().cpu().numpy()
         per = np.diff(np.concatenate([np.zeros((1, cum.shape[1])), cum]), axis=0)[:, :2]
@@ -1178,6 +1192,9 @@ def check_gradient_noise(spec, agg: str = "prod") -> Dict[str, float]:
         eg = float(np.max(np.abs(gg[off:off + n] - g64[off:off + n])) / ref)
         out[f"_t32/{name}"] = e32
         out[f"_gpu/{name}"] = eg
+        rms = lambda x: float(np.sqrt(np.mean(x * x)))  # noqa: E731
+        out[f"_t32rms/{name}"] = rms(g32[off:off + n] - g64[off:off + n]) / ref
+        out[f"_gpurms/{name}"] = rms(gg[off:off + n] - g64[off:off + n]) / ref
         worst = max(worst, eg / max(e32, 1e-9))
         off += n
     out["gpu_over_ref32_worst"] = worst
@@ -1322,4 +1339,60 @@ def check_baseline_shape(name: str) -> Dict[str, float]:
         out["_actor_final_param_vec_rel_max"] = max(out.get("_actor_final_param_vec_rel_max", 0.0), vec_rel_err(fp, runs["f32"]["fin"][a]))
     out["actor_final_param_excess"] = worst
     out["critic_final_param_excess"] = vec_excess(r.critic.critic.flat_param.cpu().numpy(), runs["f32"]["cfin"], runs["f64"]["cfin"])
+    return out
+
+
+def check_run_eval_save_restore(tmpdir: str) -> Dict[str, float]:
+    """run() with the reference's end-of-episode block (on_policy_base_runner.py:252-258): every ``eval_interval`` episodes
+    eval() on ``eval_envs`` (deterministic actions, logger callbacks) and save(); a second runner constructed with
+    ``train.model_dir`` pointing at the checkpoints restores them in its constructor (:168-169) -- parameters and ValueNorm
+    statistics bit-identical."""
+    from harl_amd.runner import OnPolicyHARunner
+    from tests.fake_env import FakeVecEnv
+    torch.manual_seed(4)
+    np.random.seed(4)
+    N, T = 64, 25
+    a = default_args([64, 64])
+    model = {k: a[k] for k in ("hidden_sizes", "activation_func", "use_feature_normalization", "initialization_method",
+                                "gain", "use_naive_recurrent_policy", "use_recurrent_policy", "recurrent_n",
+                                "data_chunk_length", "lr", "critic_lr", "opti_eps", "weight_decay", "std_x_coef", "std_y_coef")}
+    algo = {k: v for k, v in a.items() if k not in model}
+
+    class Log:  # the logger surface run() / eval() call (common/base_logger.py)
+        def __init__(self):
+            self.n = {}
+
+        def __getattr__(self, name):
+            def f(*args, **kw):
+                self.n[name] = self.n.get(name, 0) + 1
+            return f
+
+    def make(model_dir=None):
+        train = dict(n_rollout_threads=N, episode_length=T, use_valuenorm=True, use_proper_time_limits=True,
+                     use_linear_lr_decay=True, num_env_steps=N * T * 4, log_interval=1, eval_interval=2, model_dir=model_dir)
+        ev = dict(use_eval=True, n_eval_rollout_threads=8, eval_episodes=16)
+        lg = Log()
+        r = OnPolicyHARunner(dict(algo="happo"), dict(train=train, model=model, algo=algo, eval=ev), dict(state_type="EP"),
+                             envs=FakeVecEnv(N, n_agents=3, state_dim=6, act_dim=2, horizon=25, seed=5),
+                             eval_envs=FakeVecEnv(8, n_agents=3, state_dim=6, act_dim=2, horizon=25, seed=6),
+                             logger=lg, save_dir=os.path.join(tmpdir, "models"), device=DEV)
+        return r, lg
+
+    r, lg = make()
+    hist = r.run()
+    torch.cuda.synchronize()
+    out = {"episodes_mismatch": float(len(hist) != 4), "eval_calls_mismatch": float(lg.n.get("eval_log", 0) != 2),
+           "eval_steps_missing_count": float(lg.n.get("eval_per_step", 0) < 2 * 2 * 25 // 1 // 8)}
+    files = set(os.listdir(os.path.join(tmpdir, "models")))
+    want = {"actor_agent0.pt", "actor_agent1.pt", "actor_agent2.pt", "critic_agent.pt", "value_normalizer.pt"}
+    out["checkpoint_files_missing_count"] = float(len(want - files))
+    r2, _ = make(model_dir=os.path.join(tmpdir, "models"))
+    d = 0.0
+    for a1, a2 in zip(r.actor, r2.actor):
+        d = max(d, float((a1.actor.flat_param - a2.actor.flat_param).abs().max().item()))
+    d = max(d, float((r.critic.critic.flat_param - r2.critic.critic.flat_param).abs().max().item()))
+    d = max(d, float((r.value_normalizer.stats - r2.value_normalizer.stats).abs().max().item()))
+    out["restored_param_max_abs"] = d
+    r.close()
+    r2.close()
     return out

@@ -77,12 +77,13 @@ def vec_rel_err(a, b) -> float:
 
 
 NOISE_DIR = os.path.join(GOLDEN_DIR, "noise")
-# How far a figure may sit from the reference's, in units of the reference's OWN measured uncertainty (see excess()).
-# The uncertainty model injects ONE ulp of parameter noise per optimiser step; two independent, equally accurate fp32
-# implementations differ by more than that per step (measured on MI355X, gpu_checks.check_gradient_noise: torch-fp32 and the
-# HIP path both sit ~4e-6 of each gradient tensor's inf-norm from exact arithmetic and ~1e-6 from each other, i.e. a few
-# ulps of every parameter after Adam), hence the factor.
-NOISE_FACTOR = 8.0
+# How many times the reference's OWN measured uncertainty an entry may deviate where that uncertainty exceeds 1e-5.  The
+# uncertainty is measured per entry (oracle/gen_noise_floor.py): the distance of the reference's fp32 figure from the same
+# update in float64, and how far the figure moves when the reference's own gradient rounding errors get another sign
+# pattern / its parameters move by one ulp per step (max over 32 runs).  Two independent implementations are each that far
+# from exact, hence 2.  Round-2 measurements with the HIP path (tools/golden_excess.py): every entry of every golden case is
+# below 0.3x this bar; well-conditioned figures (|value| not tiny) agree to 1e-7 .. 1e-6.
+NOISE_FACTOR = 2.0
 
 
 def load_noise(name: str):
@@ -107,6 +108,20 @@ def excess(got, gold, exact, sens=None, tol: float = 1e-5) -> float:
     if sens is not None:
         floor = np.maximum(floor, np.asarray(sens, dtype=np.float64))
     return float(np.max(err / np.maximum(tol, NOISE_FACTOR * floor)))
+
+
+def excess_at(got, gold, exact, sens=None, tol: float = 1e-5) -> str:
+    """Diagnostic companion of ``excess``: where the worst entry is and what went into its bar."""
+    got, gold, exact = (np.asarray(x, dtype=np.float64) for x in (got, gold, exact))
+    if got.size == 0:
+        return ""
+    err = np.abs(got - gold) / (np.abs(gold) + 1e-12)
+    fl = np.abs(gold - exact) / (np.abs(exact) + 1e-12)
+    se = np.zeros_like(fl) if sens is None else np.broadcast_to(np.asarray(sens, dtype=np.float64), fl.shape)
+    ex = err / np.maximum(tol, NOISE_FACTOR * np.maximum(fl, se))
+    i = np.unravel_index(int(np.argmax(ex)), ex.shape)
+    return (f"{tuple(int(x) for x in i)}: got {got[i]:.9g} ref {gold[i]:.9g} f64 {exact[i]:.9g} err {err[i]:.2e} "
+            f"|ref-f64| {fl[i]:.2e} sens {se[i]:.2e} excess {ex[i]:.3f}")
 
 
 def vec_excess(got, gold, exact, sens=None, tol: float = 1e-5) -> float:

@@ -8,7 +8,8 @@ TOL = 1e-5  # BASELINE.json: fp32 losses / grad-norms within 1e-5 relative for i
 # step's loss / entropy / grad-norm / ratio, the averaged infos, the final parameters), except where the reference's own
 # fp32 figure is further than that from exact arithmetic: oracle/gen_noise_floor.py re-runs each golden case in float64
 # (tests/golden/noise/*.npz), and an entry may differ from the reference by at most
-#     max(1e-5, 8 x max(|reference_fp32 - fp64| / |fp64|, reference's movement under 1 ulp of parameter noise per step))
+#     max(1e-5, 2 x max(|reference_fp32 - fp64| / |fp64|, how far the reference's figure moves when its own gradient rounding
+#                       errors get another sign pattern and its parameters one ulp of noise per step))
 # -- e.g. the first policy loss of `a2c_box_h64` is a near-zero masked mean of advantage-normalised surrogates and the
 # reference itself is 1.0e-4 away from its exact value.  check_train_golden reports that ratio as `*_excess` (<= 1 passes).
 
@@ -25,7 +26,7 @@ def _assert_all(res, tol=TOL, exact_keys=("mismatch", "perm_", "count")):
         if any(e in k for e in exact_keys):
             assert v == 0.0, (k, v)
         elif k.endswith("_excess"):
-            assert v <= 1.0, (k, v)   # within max(1e-5, 8 x the reference's own measured uncertainty) on every entry
+            assert v <= 1.0, (k, v)   # within max(1e-5, 2 x the reference's own measured uncertainty) on every entry
         else:
             assert v < tol, (k, v)
 
@@ -210,3 +211,32 @@ def test_parity_at_baseline_shapes(name):
     """BASELINE.json configs 1-4 at their real network shapes, observation widths and FULL agent counts (thread count cut
     to <= 32 000 rows so the CPU oracle finishes): whole train() with one epoch per network vs the oracle."""
     _assert_all(_G().check_baseline_shape(name), tol=TOL)
+
+
+def test_run_with_eval_save_and_restore(tmp_path):
+    """run(): eval() + save() every eval_interval episodes, restore() from train.model_dir in the constructor."""
+    res = _G().check_run_eval_save_restore(str(tmp_path))
+    for k, v in res.items():
+        assert v == 0.0, (k, v)
+
+
+def test_dropin_under_reference_launcher_on_gpu(tmp_path):
+    """The unmodified examples/train.py with harl_amd installed under it, on the GPU (no stubs).  Needs a reference
+    checkout next to the GPU (``HARL_REFERENCE``); skipped otherwise -- the CPU test tests/test_dropin_cpu.py covers the
+    plumbing with recorded kernel calls where there is none."""
+    import json
+    import os
+    import subprocess
+    import sys
+    ref = os.environ.get("HARL_REFERENCE", "/root/reference")
+    if not os.path.exists(os.path.join(ref, "examples", "train.py")):
+        pytest.skip("no reference checkout on this box")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "tests", "dropin_driver.py"), "--reference", ref, "--mode", "dropin",
+           "--log-dir", str(tmp_path), "--algo", "happo", "--env", "pettingzoo_mpe", "--exp_name", "gpu", "--n_rollout_threads",
+           "8", "--episode_length", "50", "--num_env_steps", "1600", "--eval_interval", "2", "--n_eval_rollout_threads", "2",
+           "--eval_episodes", "2", "--log_interval", "1"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, PYTHONPATH=root), cwd=root)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    res = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("DROPIN_RESULT ")][-1][len("DROPIN_RESULT "):])
+    assert res["actor_class"] == "harl_amd.happo.HAPPO" and "critic_agent.pt" in res["saved"]

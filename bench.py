@@ -1,28 +1,39 @@
 #!/usr/bin/env python3
-"""bench.py -- transitions/sec through the HAPPO update (compute_returns + OnPolicyHARunner.train()).
+"""bench.py -- transitions/sec through the on-policy sequential update (compute_returns + OnPolicyHARunner.train()).
 
-Workload = BASELINE.json configs[1]: MPE simple_spread_v2, 3 agents, HAPPO, n_rollout_threads=4096 per GPU,
-episode_length=200, obs 18 / share_obs 54 / Box(5), MLP [128,128], happo.yaml defaults (ppo_epoch=5,
-critic_epoch=5, 1 mini-batch, ValueNorm + GAE + proper time limits, Huber, clip 0.2, max_grad_norm 10).
-A "step" = one compute() + train() over the synthetic rollout buffers, which are resident in HBM before
-the timed region.  One transition = one (t, n) environment step for all agents.  Weak scaling: every rank owns
-4096 rollout threads; gradients / loss scalars are all-reduced over RCCL each optimiser step.
+Default workload = BASELINE.json configs[1]: MPE simple_spread_v2, 3 agents, HAPPO, n_rollout_threads=4096 per GPU,
+episode_length=200, obs 18 / share_obs 54 / Box(5), MLP [128,128], happo.yaml defaults (ppo_epoch=5, critic_epoch=5,
+1 mini-batch, ValueNorm + GAE + proper time limits, Huber, clip 0.2, max_grad_norm 10).  `--config` selects the other
+BASELINE.json configurations at their real shapes (one JSON line each):
 
-    python bench.py --gpus 1 --steps 5 --warmup 2
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P \
+    mpe         configs[1]  MPE simple_spread, 3 agents, HAPPO                         T=200 N=4096/GPU
+    cheetah6    configs[2]  MAMuJoCo HalfCheetah-6x1, 6 agents, HAPPO, MLP [128]x3      T=200 N=4096/GPU (8192 global with --scaling strong)
+    smac3s5z    configs[3]  SMAC 3s5z, 8 agents, HAPPO, GRU policy, Discrete(14)        T=160 N=512/GPU, chunks of 10
+    humanoid17  configs[4]  MAMuJoCo Humanoid-17x1, 17 agents, HATRPO, obs 393          T=200 N=1024/GPU
+
+A "step" = one compute() + train() over synthetic rollout buffers (SURVEY.md 8d recipe) resident in HBM before the timed
+region.  One transition = one (t, n) environment step for all agents.  `--scaling weak` (default): every rank owns
+N rollout threads; `--scaling strong`: `--global-threads` (default 8192, BASELINE configs[2]) are split over the ranks.
+Gradients / loss scalars are all-reduced over RCCL each optimiser step (one message per step, harl_amd/dist.py);
+`--dist-single` initialises the nccl(=RCCL) process group even with one rank so that branch runs on a 1-GPU box.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2 [--config cheetah6]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P \\
         bench.py --gpus 8 --steps 5 --warmup 2
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant GEMM kernel family (HIP-event timing of every launch
-of the GEMM families inside the timed region; HBM-bound since the GEMMs moved to the bf16 matrix pipe with an exact
-fp32 operand split; `traffic` from the committed PMC pass in profiles/); `kernels` is the
-full per-kernel breakdown from extra instrumented steps after the timed region; `cpu_baseline` is the oracle (a torch-CPU restatement of the reference,
-same ATen kernels) timed on this box's host cores on a bounded sample of the same workload.
+Prints ONE JSON line (rank 0).  `roofline`: the streaming kernel family with the largest total time inside the timed
+region -- achieved = algorithmic HBM bytes of the launches that ran (harl_amd/traffic.py, from each launch's own
+arguments) / their HIP-event time; `traffic` = measured HBM bytes per launch from the committed PMC pass of that kernel
+(profiles/r02_hbm_traffic.json, stamped with the commit it was taken at).  `kernels`: full per-kernel breakdown from extra
+instrumented steps after the timed region.  `cpu_baseline`: the oracle (torch-CPU restatement of the reference, same ATen
+kernels) on this box's host cores on a bounded sample of the same workload, warm-up + best of 3.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -33,27 +44,46 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 MFMA_F32_PEAK = 157.3e12  # MI355X_MICROARCH.md: fp32-input MFMA, dense
-MFMA_BF16_PEAK = 2516.6e12  # 16 x the fp32 rate (dense bf16 MFMA, 1024 FLOP/clk/SIMD at 2.4 GHz)
+MFMA_BF16_PEAK = 2516.6e12  # dense bf16 MFMA (1024 FLOP/clk/SIMD at 2.4 GHz)
 HBM_PEAK = 8.0e12
 
+WORKLOADS = {
+    "mpe": dict(algo="happo", T=200, N=4096, A=3, obs=18, sobs=54, act=5, disc=False, hidden=[128, 128],
+                metric="transitions/sec through HAPPO update (MPE spread, 3 agents)",
+                name="MPE simple_spread_v2 3-agent HAPPO update"),
+    "cheetah6": dict(algo="happo", T=200, N=4096, A=6, obs=23, sobs=17, act=1, disc=False, hidden=[128, 128, 128],
+                     metric="transitions/sec through HAPPO update (MAMuJoCo HalfCheetah-6x1, 6 agents)",
+                     name="MAMuJoCo HalfCheetah-6x1 6-agent HAPPO update"),
+    "smac3s5z": dict(algo="happo", T=160, N=512, A=8, obs=128, sobs=216, act=14, disc=True, hidden=[64, 64, 64], rnn=True, L=10,
+                     unavailable_p=0.3, metric="transitions/sec through HAPPO update (SMAC 3s5z, 8 agents, GRU policy)",
+                     name="SMAC 3s5z 8-agent recurrent HAPPO update"),
+    "humanoid17": dict(algo="hatrpo", T=200, N=1024, A=17, obs=393, sobs=376, act=1, disc=False, hidden=[128, 128, 128],
+                       metric="transitions/sec through HATRPO update (MAMuJoCo Humanoid-17x1, 17 agents)",
+                       name="MAMuJoCo Humanoid-17x1 17-agent HATRPO update"),
+}
+# module-level aliases of the default workload (tools/ and older scripts import these)
 T, N_PER_GPU, A = 200, 4096, 3
 OBS, SOBS, ACT = 18, 54, 5
 HIDDEN = [128, 128]
 
 
-def algo_args(n_threads: int, T_: int = T) -> dict:
-    return dict(
+def algo_args(n_threads: int, T_: int = T, w: dict | None = None) -> dict:
+    w = w or WORKLOADS["mpe"]
+    args = dict(
         train=dict(n_rollout_threads=n_threads, episode_length=T_, use_valuenorm=True, use_proper_time_limits=True),
-        model=dict(hidden_sizes=HIDDEN, activation_func="relu", use_feature_normalization=True,
+        model=dict(hidden_sizes=list(w["hidden"]), activation_func="relu", use_feature_normalization=True,
                    initialization_method="orthogonal_", gain=0.01, use_naive_recurrent_policy=False,
-                   use_recurrent_policy=False, recurrent_n=1, data_chunk_length=10, lr=5e-4, critic_lr=5e-4,
-                   opti_eps=1e-5, weight_decay=0, std_x_coef=1, std_y_coef=0.5),
+                   use_recurrent_policy=bool(w.get("rnn")), recurrent_n=1, data_chunk_length=w.get("L", 10), lr=5e-4,
+                   critic_lr=5e-4, opti_eps=1e-5, weight_decay=0, std_x_coef=1, std_y_coef=0.5),
         algo=dict(ppo_epoch=5, critic_epoch=5, use_clipped_value_loss=True, clip_param=0.2, actor_num_mini_batch=1,
                   critic_num_mini_batch=1, entropy_coef=0.01, value_loss_coef=1, use_max_grad_norm=True,
                   max_grad_norm=10.0, use_gae=True, gamma=0.99, gae_lambda=0.95, use_huber_loss=True,
                   use_policy_active_masks=True, huber_delta=10.0, action_aggregation="prod", share_param=False,
                   fixed_order=True),
     )
+    if w["algo"] == "hatrpo":  # hatrpo.yaml defaults
+        args["algo"].update(kl_threshold=0.01, ls_step=10, accept_ratio=0.5, backtrack_coeff=0.8)
+    return args
 
 
 class Box:
@@ -61,41 +91,85 @@ class Box:
         self.shape = shape
 
 
-def flops_per_transition() -> float:
-    """Linear FLOPs only. (2 + 3*ppo_epoch) F_actor per agent + 3*critic_epoch F_critic."""
-    f_actor = 2 * (OBS * 128 + 128 * 128 + 128 * ACT)
-    f_critic = 2 * (SOBS * 128 + 128 * 128 + 128 * 1)
-    return A * (2 + 3 * 5) * f_actor + 3 * 5 * f_critic
+class Discrete:
+    def __init__(self, n):
+        self.n = n
 
 
-def build_gpu_runner(n_local: int, rank: int, world: int, device):
-    from harl_amd.runner import OnPolicyHARunner
-    from harl_amd.synthetic import Shapes, make_buffers
+def flops_per_transition(w: dict) -> float:
+    """Linear FLOPs only.  HAPPO: (2 + 3 ppo_epoch) F_actor per agent + 3 critic_epoch F_critic (forward = 1,
+    backward = 2; two log-prob passes per agent).  Not reported for HATRPO (CG iteration count is data dependent)."""
+    def mlp(d):
+        f, prev = 0, d
+        for h in w["hidden"]:
+            f += 2 * prev * h
+            prev = h
+        if w.get("rnn"):
+            f += 2 * 6 * prev * prev
+        return f, prev
+    fa, pa = mlp(w["obs"])
+    fc, pc = mlp(w["sobs"])
+    fa += 2 * pa * w["act"]
+    fc += 2 * pc
+    return w["A"] * (2 + 3 * 5) * fa + 3 * 5 * fc
 
-    args = algo_args(n_local * world)
+
+def fill_buffers(r, w: dict, n_local: int, rank: int, device, logp: str) -> None:
+    """SURVEY.md 8d recipe, generated on the device (the 17-agent configuration holds 7 GB of observations): obs /
+    share_obs / rewards / value_preds ~ N(0,1); Box actions ~ N(0,1) with stored log-probs -1 + 0.1 N(0,1); Discrete actions
+    uniform with log-probs log(1/n) + 0.05 N(0,1); masks 0 w.p. 0.04, bad_masks 0 at the same places; GRU states 0.3 N(0,1).
+    `logp = onpolicy` replaces the stored log-probs by log pi(a|o) + 0.05 N(0,1) under the initial weights (ratios ~ 1)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(100 + rank)
+    Tn = w["T"]
+    rn = lambda *s: torch.randn(*s, generator=g, device=device)  # noqa: E731
+    base_mask = (torch.rand(Tn + 1, n_local, 1, generator=g, device=device) >= 0.04).float()
+    for a in range(w["A"]):
+        b = r.actor_buffer[a]
+        b.obs.copy_(rn(*b.obs.shape))
+        if w["disc"]:
+            act = torch.randint(0, w["act"], (Tn, n_local, 1), generator=g, device=device)
+            b.actions.copy_(act.float())
+            b.action_log_probs.copy_(float(np.log(1.0 / w["act"])) + 0.05 * rn(Tn, n_local, 1))
+            av = (torch.rand(Tn + 1, n_local, w["act"], generator=g, device=device) >= w.get("unavailable_p", 0.0)).float()
+            av[:-1].scatter_(-1, act, 1.0)  # the taken action always stays available
+            b.available_actions.copy_(av)
+        else:
+            b.actions.copy_(rn(*b.actions.shape))
+            b.action_log_probs.copy_(-1.0 + 0.1 * rn(*b.action_log_probs.shape))
+        b.masks.copy_(base_mask)
+        b.active_masks.fill_(1.0)
+        if w.get("rnn"):
+            b.rnn_states.copy_(0.3 * rn(*b.rnn_states.shape))
+        if logp == "onpolicy":
+            act_ = r.actor[a]
+            B = Tn * n_local
+            lp = torch.empty(B, act_.actor.act_w, device=device)
+            act_.actor.fold()
+            kw = dict(rnn_states=b.rnn_states[0], masks=b.flat("masks")) if w.get("rnn") else {}
+            act_._logp_pass(b.flat("obs"), b.flat("actions"), None if b.available_actions is None else b.flat("available_actions"),
+                            B, lp, **kw)
+            b.action_log_probs.copy_((lp + 0.05 * rn(*lp.shape)).reshape(b.action_log_probs.shape))
+    cb = r.critic_buffer
+    cb.share_obs.copy_(rn(*cb.share_obs.shape))
+    cb.rewards.copy_(rn(*cb.rewards.shape))
+    cb.value_preds.copy_(rn(*cb.value_preds.shape))
+    cb.masks.copy_(base_mask)
+    cb.bad_masks.copy_(base_mask)
+    if w.get("rnn"):
+        cb.rnn_states_critic.copy_(0.3 * rn(*cb.rnn_states_critic.shape))
+
+
+def build_gpu_runner(w: dict, n_local: int, rank: int, world: int, device, logp: str = "recipe"):
+    from harl_amd.runner import RUNNER_REGISTRY
+
+    args = algo_args(n_local * world, w["T"], w)
     torch.manual_seed(1)
     np.random.seed(1)
-    r = OnPolicyHARunner(dict(algo="happo"), args, dict(state_type="EP"), obs_spaces=[Box((OBS,))] * A,
-                         share_obs_space=Box((SOBS,)), act_spaces=[Box((ACT,))] * A, device=device)
-    sh = Shapes(T=T, N=n_local, A=A, obs_dim=OBS, share_obs_dim=SOBS, act_dim=ACT, hidden_sizes=HIDDEN)
-    d = make_buffers(sh, seed=100 + rank)
-    up = lambda x: torch.from_numpy(x).to(device)  # noqa: E731
-    for a in range(A):
-        b = r.actor_buffer[a]
-        b.obs.copy_(up(d.obs[a]))
-        b.actions.copy_(up(d.actions[a]))
-        b.masks.copy_(up(d.masks[a]))
-        b.active_masks.copy_(up(d.active_masks[a]))
-        # stored log-probs on-policy (ratio ~ 1, the regime PPO operates in): log pi(a|o) + 0.05 N(0,1)
-        lp, _, _ = r.actor[a].evaluate_actions(b.flat("obs"), None, b.flat("actions"), None)
-        noise = torch.from_numpy((0.05 * np.random.default_rng(7 + a).standard_normal(lp.shape)).astype(np.float32)).to(device)
-        b.action_log_probs.copy_((lp + noise).reshape(b.action_log_probs.shape))
-    cb = r.critic_buffer
-    cb.share_obs.copy_(up(d.share_obs))
-    cb.rewards.copy_(up(d.rewards))
-    cb.value_preds.copy_(up(d.value_preds))
-    cb.masks.copy_(up(d.critic_masks))
-    cb.bad_masks.copy_(up(d.bad_masks))
+    space = Discrete(w["act"]) if w["disc"] else Box((w["act"],))
+    r = RUNNER_REGISTRY[w["algo"]](dict(algo=w["algo"]), args, dict(state_type="EP"), obs_spaces=[Box((w["obs"],))] * w["A"],
+                                   share_obs_space=Box((w["sobs"],)), act_spaces=[space] * w["A"], device=device)
+    fill_buffers(r, w, n_local, rank, device, logp)
     r.prep_training()
     return r
 
@@ -111,37 +185,60 @@ def one_step(r) -> None:
     r.train()
 
 
-def cpu_baseline(n_cols: int, threads: int) -> dict:
+def cpu_baseline(w: dict, n_cols: int, threads: int, reps: int = 3) -> dict:
     """The oracle (torch-CPU restatement of the reference path, same ATen kernels / autograd / Adam) on a bounded
-    sample of the same workload: same shapes with fewer rollout threads.  Reported, not a target."""
+    sample of the same workload: same shapes with fewer rollout threads.  One untimed warm-up update, then the best of
+    `reps` timed ones (each from freshly built networks / buffers).  Reported, not a target."""
     from harl_amd.synthetic import Shapes, actor_param_shapes, critic_param_shapes, make_buffers, synthetic_state_dict
     from oracle import harl_oracle as O
 
     torch.set_num_threads(threads)
-    args = algo_args(n_cols)
+    Tn = w["T"]
+    args = algo_args(n_cols, Tn, w)
     cfg = O.PathConfig.from_reference_dicts(args["train"], args["model"], args["algo"])
-    sh = Shapes(T=T, N=n_cols, A=A, obs_dim=OBS, share_obs_dim=SOBS, act_dim=ACT, hidden_sizes=HIDDEN)
-    d = make_buffers(sh, seed=100)
-    actors = [O.OracleHAPPO({k: torch.from_numpy(v) for k, v in synthetic_state_dict(actor_param_shapes(sh), 10 + a).items()}, cfg)
-              for a in range(A)]
-    critic = O.OracleVCritic({k: torch.from_numpy(v) for k, v in synthetic_state_dict(critic_param_shapes(sh), 99).items()}, cfg)
-    abufs = []
-    for a in range(A):
-        with torch.no_grad():
-            lp, _, _ = actors[a].evaluate_actions(d.obs[a][:-1].reshape(T * n_cols, -1), d.actions[a].reshape(T * n_cols, -1))
-        logp = (lp.numpy() + 0.05 * np.random.default_rng(7 + a).standard_normal(lp.shape)).astype(np.float32)
-        abufs.append(O.OracleActorBuffer(d.obs[a], d.actions[a], logp.reshape(d.actions[a].shape), d.masks[a], d.active_masks[a]))
-    cbuf = O.OracleCriticBufferEP(d.share_obs, d.rewards, d.value_preds, d.critic_masks, d.bad_masks)
-    vn = O.OracleValueNorm()
-    t0 = time.perf_counter()
-    with torch.no_grad():
-        nv = critic.get_values(cbuf.share_obs[-1]).numpy()
-    cbuf.compute_returns(nv, vn, cfg)
-    O.ha_train(actors, critic, abufs, cbuf, vn, cfg)
-    dt = time.perf_counter() - t0
-    return dict(value=T * n_cols / dt, unit="transitions/s", cores=threads, kind="port",
-                sample=f"1 update at T={T}, n_rollout_threads={n_cols} (same nets/epochs; oracle = torch-CPU restatement "
-                       f"of the reference, {dt:.1f} s)")
+    sh = Shapes(T=Tn, N=n_cols, A=w["A"], obs_dim=w["obs"], share_obs_dim=w["sobs"], act_dim=w["act"], discrete=w["disc"],
+                hidden_sizes=w["hidden"])
+    rnn = bool(w.get("rnn"))
+    d = make_buffers(sh, seed=100, unavailable_p=w.get("unavailable_p", 0.0), rnn=rnn)
+    tc = (O.TrpoConfig(**{k: args["algo"][k] for k in ("kl_threshold", "ls_step", "accept_ratio", "backtrack_coeff")})
+          if w["algo"] == "hatrpo" else None)
+
+    def once() -> float:
+        sds = [{k: torch.from_numpy(v) for k, v in synthetic_state_dict(actor_param_shapes(sh, True, rnn), 10 + a).items()}
+               for a in range(w["A"])]
+        actors = [O.OracleHATRPO(sd, cfg, tc) if tc is not None else O.OracleHAPPO(sd, cfg) for sd in sds]
+        critic = O.OracleVCritic({k: torch.from_numpy(v) for k, v in
+                                  synthetic_state_dict(critic_param_shapes(sh, True, rnn), 99).items()}, cfg)
+        abufs = [O.OracleActorBuffer(d.obs[a], d.actions[a], d.action_log_probs[a], d.masks[a], d.active_masks[a],
+                                     d.available_actions[a], rnn_states=None if not rnn else d.rnn["actor"][a])
+                 for a in range(w["A"])]
+        cbuf = O.OracleCriticBufferEP(d.share_obs, d.rewards, d.value_preds.copy(), d.critic_masks, d.bad_masks)
+        if rnn:
+            cbuf.rnn_states_critic = d.rnn["critic"]
+        vn = O.OracleValueNorm()
+        t0 = time.perf_counter()
+        cbuf.compute_returns(cbuf.value_preds[-1].copy(), vn, cfg)
+        O.ha_train(actors, critic, abufs, cbuf, vn, cfg)
+        return time.perf_counter() - t0
+
+    once()  # warm-up (thread pool, allocator, first-touch of the buffers)
+    ts = [once() for _ in range(reps)]
+    dt = min(ts)
+    return dict(value=Tn * n_cols / dt, unit="transitions/s", cores=threads, host_cpu_count=os.cpu_count(), kind="port",
+                runs_s=[round(t, 2) for t in ts],
+                sample=f"1 update at T={Tn}, n_rollout_threads={n_cols} (same nets/epochs; oracle = torch-CPU restatement of the "
+                       f"reference); 1 warm-up + best of {reps} ({dt:.2f} s); {threads} torch threads of {os.cpu_count()} host CPUs "
+                       "(these nets are small: more threads is slower)")
+
+
+def git_sha() -> str | None:
+    try:
+        sha = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True, timeout=5).stdout.strip()
+    except Exception:  # noqa: BLE001
+        sha = ""
+    if not sha and os.path.exists(os.path.join(ROOT, ".git_sha")):  # the GPU box receives a snapshot without .git
+        sha = open(os.path.join(ROOT, ".git_sha")).read().strip()
+    return sha or None
 
 
 def main():
@@ -149,25 +246,41 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--threads-per-gpu", type=int, default=N_PER_GPU)
-    ap.add_argument("--cpu-cols", type=int, default=512, help="rollout threads of the bounded CPU-baseline sample (0 = skip)")
+    ap.add_argument("--config", choices=sorted(WORKLOADS), default="mpe")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--global-threads", type=int, default=8192, help="n_rollout_threads of the whole job with --scaling strong")
+    ap.add_argument("--threads-per-gpu", type=int, default=0, help="n_rollout_threads per rank with --scaling weak (0 = the config's)")
+    ap.add_argument("--logp", choices=("recipe", "onpolicy"), default="recipe",
+                    help="stored log-probs: SURVEY 8d recipe (default) or on-policy (ratios ~ 1)")
+    ap.add_argument("--dist-single", action="store_true", help="initialise the nccl (RCCL) group even with one rank")
+    ap.add_argument("--cpu-cols", type=int, default=-1, help="rollout threads of the bounded CPU-baseline sample (0 = skip, -1 = auto)")
     ap.add_argument("--cpu-threads", type=int, default=16,
                     help="torch CPU threads for the baseline (these nets are small: more threads than ~16 is slower)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--instr-steps", type=int, default=2, help="instrumented (HIP-event) steps after the timed region")
     args = ap.parse_args()
+    w = WORKLOADS[args.config]
 
     from harl_amd import _lib
     from harl_amd.dist import init_from_env
 
+    if args.dist_single and "RANK" not in os.environ:  # a one-rank RCCL group: exercises the collective branch on a 1-GPU box
+        os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1",
+                          MASTER_PORT=os.environ.get("MASTER_PORT", "29533"), HARL_DIST_SINGLE="1")
     comm = init_from_env()
     rank, world = comm.rank, comm.world_size
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     device = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(device)
     assert world == args.gpus or (world == 1 and args.gpus == 1), f"launched {world} ranks for --gpus {args.gpus}"
+    if args.scaling == "strong":
+        assert args.global_threads % world == 0, "--global-threads must be divisible by the number of ranks"
+        n_local = args.global_threads // world
+    else:
+        n_local = args.threads_per_gpu or w["N"]
+    Tn = w["T"]
 
-    r = build_gpu_runner(args.threads_per_gpu, rank, world, device)
+    r = build_gpu_runner(w, n_local, rank, world, device, args.logp)
 
     def barrier():
         torch.cuda.synchronize()
@@ -178,26 +291,27 @@ def main():
     for _ in range(args.warmup):
         one_step(r)
     barrier()
-    # Roofline timing lives INSIDE the timed region: every launch of the four MFMA kernel families is bracketed by HIP
-    # events on the launch stream (64 event pairs per step, <1 % of wall time).
-    MFMA_TAGS = ("fwd_fused2", "fwd_hidden", "bwd_dx", "bwd_dx_dw1", "dw_hidden")
+    # Roofline timing lives INSIDE the timed region: every launch of the streaming GEMM / recurrence kernel families is
+    # bracketed by HIP events on the launch stream (<1 % of wall time for the default workload).
+    ROOF_TAGS = ("fwd_fused2", "fwd_fused2_k64", "fwd_hidden", "bwd_dx", "bwd_dx_dw1", "dw_hidden", "fwd_wide", "dw_input",
+                 "tangent_wide", "gru_fwd", "gru_bwd", "update_fwd", "update_bwd", "update_logp", "update_fwd_critic")
     if not args.no_kernel_timing:
-        _lib.enable_kernel_timing(True, MFMA_TAGS)
+        _lib.enable_kernel_timing(True, ROOF_TAGS)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step(r)
     barrier()
     dt = time.perf_counter() - t0
-    mfma_kern = {}
+    roof_kern = {}
     if not args.no_kernel_timing:
-        mfma_kern = _lib.collect_kernel_timing()
+        roof_kern = _lib.collect_kernel_timing()
         _lib.enable_kernel_timing(False)
     if comm.enabled:
         tt = torch.tensor([dt], dtype=torch.float64, device=device)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt.item())
-    # Full per-kernel breakdown (every tagged launch, ~270 event pairs per step ~ 10 % of wall time): `instr_steps`
-    # further steps of the SAME workload after the timed region, so that it does not understate `value`.
+    # Full per-kernel breakdown (every tagged launch, ~10 % of wall time): `instr_steps` further steps of the SAME
+    # workload after the timed region, so that it does not understate `value`.
     kern = {}
     if not args.no_kernel_timing and args.instr_steps > 0:
         _lib.enable_kernel_timing(True)
@@ -205,79 +319,69 @@ def main():
             one_step(r)
         kern = _lib.collect_kernel_timing()
         _lib.enable_kernel_timing(False)
-    breakdown = kern
 
     if rank == 0:
-        n_local = args.threads_per_gpu
-        trans_per_step = T * n_local * world
+        trans_per_step = Tn * n_local * world
         value = trans_per_step * args.steps / dt
-        B = T * n_local
-        # dominant kernel = the GEMM kernel family with the largest total time inside the timed region.  Since the GEMMs
-        # run on the bf16 matrix pipe (exact three-way fp32 split, 6 products: csrc/split_mfma.h) these kernels are
-        # HBM-bound: `achieved` = ALGORITHMIC bytes per launch / average HIP-event duration.  Reported
-        # next to it: the fp32-equivalent FLOP rate (Linear layers only) against the fp32 MFMA peak it no longer runs on,
-        # and the matrix-pipe time actually issued (6 x bf16 GEMM FLOPs + 16 x the FLOPs left on the fp32 MFMA).
-        flops = dict(fwd_hidden=2.0 * B * 128 * 128, bwd_dx=2.0 * B * 128 * 128, dw_hidden=2.0 * B * 128 * 128,
-                     fwd_fused2=2.0 * B * (128 * 128 + OBS * 128),
-                     # dX of layer 2 + the fused first-layer weight gradient (15 actor launches with D=18, 5 critic with 54)
-                     bwd_dx_dw1=2.0 * B * (128 * 128 + 128 * (15 * OBS + 5 * SOBS) / 20.0))
-        gemm_bf16 = 2.0 * B * 128 * 128  # the 128 x 128 GEMM of every family runs as 6 bf16 products
-        pipe = {k: 6.0 * gemm_bf16 + 16.0 * (v - gemm_bf16) for k, v in flops.items()}  # bf16-pipe-equivalent FLOPs issued
-        # ALGORITHMIC HBM bytes per launch of each family for THIS run's launch mix: the fused forward is
-        # launched 15x per step in training mode (reads the cached x0n image, writes x_hat_1, x_hat_2, masks, statistics)
-        # and 3x in log-prob mode (x_hat_2 only).
-        alg = dict(fwd_hidden=B * (512 + 512 + 16 + 4), bwd_dx=B * (512 + 512 + 16 + 4 + 512), dw_hidden=B * (512 + 512),
-                   bwd_dx_dw1=B * (512 + 512 + 16 + 4 + (15 * 128 + 5 * 256) / 20.0),
-                   # fused forward from the cached x0n image: 128 B in; training mode writes x_hat_1, x_hat_2, masks, rstd
-                   fwd_fused2=B * (15 * (128 + 512 + 512 + 32 + 8) + 3 * (128 + 512 + 16 + 4)) / 18.0)
-        cand = {k: v for k, v in mfma_kern.items() if k in flops and v["n"] > 0}
+        # dominant kernel = the streaming family with the largest total time inside the timed region; `achieved` =
+        # algorithmic bytes of the launches that ran (harl_amd/traffic.py) / their HIP-event time.  The GEMMs run on the
+        # bf16 matrix pipe (exact three-way fp32 split, 6 products: csrc/split_mfma.h) and are bound by instruction issue and
+        # HBM together: the fraction of the HBM roof is the contract's figure, `matrix_pipe_frac` of the
+        # dominant GEMM is reported next to it where a FLOP model exists.
+        cand = {k: v for k, v in roof_kern.items() if v["n"] > 0 and v.get("bytes")}
         roof = None
         if cand:
             dom = max(cand, key=lambda k: cand[k]["total_ms"])
-            avg_s = cand[dom]["avg_ms"] * 1e-3
+            tot_s = cand[dom]["total_ms"] * 1e-3
+            ach = cand[dom]["bytes"] / tot_s
+            per_launch = cand[dom]["bytes"] / cand[dom]["n"]
             traffic, traffic_note = None, None
-            tp = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-            if os.path.exists(tp):  # PMC pass over the same kernels (tools/kbench.py); measured/algorithmic ratio per family
+            tp = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
+            if os.path.exists(tp):  # PMC passes over the same kernels at this workload's shapes (tools/pmc_traffic.sh)
                 tj = json.load(open(tp))
-                if dom in tj["kernels"]:
-                    ratio = tj["kernels"][dom]["ratio"]
-                    traffic = ratio * alg[dom] / 1e9
-                    traffic_note = (f"GB per launch = {ratio:.3f} (HBM bytes measured by rocprofv3 --pmc FETCH_SIZE x2 [gfx950] + "
-                                    f"WRITE_SIZE, separate passes, / algorithmic bytes of the same kernel; "
-                                    f"profiles/r01_hbm_traffic.md) x {alg[dom] / 1e9:.3f} GB algorithmic for this launch mix")
-            ach = alg[dom] / avg_s
-            roof = dict(kernel=dom, bound="hbm", achieved=ach / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s",
-                        frac=ach / HBM_PEAK, traffic=traffic, traffic_note=traffic_note, launches=cand[dom]["n"],
-                        avg_ms=cand[dom]["avg_ms"], bytes_per_launch=alg[dom], flops_per_launch=flops[dom],
-                        fp32_equiv_tflops=flops[dom] / avg_s / 1e12,
-                        frac_of_fp32_mfma_peak=flops[dom] / avg_s / MFMA_F32_PEAK,
-                        matrix_pipe_frac=pipe[dom] / avg_s / MFMA_BF16_PEAK,
-                        timing="HIP events around every launch of the GEMM kernel families inside the timed region",
-                        others={k: dict(hbm_frac=round(alg[k] / (v["avg_ms"] * 1e-3) / HBM_PEAK, 4),
-                                        fp32_equiv_frac=round(flops[k] / (v["avg_ms"] * 1e-3) / MFMA_F32_PEAK, 4),
-                                        matrix_pipe_frac=round(pipe[k] / (v["avg_ms"] * 1e-3) / MFMA_BF16_PEAK, 4))
-                                for k, v in cand.items()})
-        e2e = flops_per_transition() * value
+                ent = tj.get("workloads", {}).get(args.config, {}).get(dom)
+                if ent:
+                    traffic = ent["ratio"] * per_launch / 1e9
+                    traffic_note = (f"GB per launch = {ent['ratio']:.3f} (HBM bytes measured by rocprofv3 --pmc, FETCH_SIZE and "
+                                    f"WRITE_SIZE in separate passes with the guide's gfx950 unit corrections, / algorithmic bytes "
+                                    f"of the same launches; taken at commit {tj.get('git_sha')}, profiles/r02_hbm_traffic.md) x "
+                                    f"{per_launch / 1e9:.4f} GB algorithmic per launch in this run")
+            roof = dict(kernel=dom, bound="hbm", achieved=ach / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s", frac=ach / HBM_PEAK,
+                        traffic=traffic, traffic_note=traffic_note, launches=cand[dom]["n"], avg_ms=cand[dom]["avg_ms"],
+                        bytes_per_launch=per_launch,
+                        timing="HIP events around every launch of the streaming kernel families inside the timed region; bytes "
+                               "from each launch's own arguments (harl_amd/traffic.py)",
+                        others={k: dict(hbm_frac=round(v["bytes"] / (v["total_ms"] * 1e-3) / HBM_PEAK, 4), n=v["n"],
+                                        avg_ms=round(v["avg_ms"], 4)) for k, v in cand.items()})
         out = dict(
-            metric="transitions/sec through HAPPO update (MPE spread, 3 agents)", value=value, unit="transitions/s",
-            n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=dt / args.steps * 1e3,
-            higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32",
-            dtype_note="fp32 data, statistics and accumulators; the 128x128 GEMM operands are split EXACTLY into three bf16 "
-                       "each and multiplied as six cross products on v_mfma_f32_32x32x16_bf16 (error <= the fp32 MFMA's fmaf "
-                       "chain: profiles/r01_mfma_bf16x3.txt)",
-            data="synthetic (SURVEY.md 8d recipe; stored log-probs set on-policy so ratios ~ 1)",
-            config=dict(workload="MPE simple_spread_v2 3-agent HAPPO update: compute_returns + train(), T=200, "
-                                 f"n_rollout_threads={n_local}/GPU, obs18/share54/Box5, MLP[128,128], ppo_epoch=5, critic_epoch=5",
-                        episode_length=T, n_rollout_threads_per_gpu=n_local, n_agents=A, parallelism=f"dp{world}"),
+            metric=w["metric"], value=value, unit="transitions/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
+            ms_per_step=dt / args.steps * 1e3, higher_is_better=True, scaling=args.scaling, vs_baseline=None, dtype="f32",
+            dtype_note="fp32 data, statistics and accumulators; GEMM operands are split EXACTLY into three bf16 each and "
+                       "multiplied as six cross products on v_mfma_f32_32x32x16_bf16 (error <= the fp32 MFMA's fmaf chain: "
+                       "profiles/r01_mfma_bf16x3.txt)",
+            data=f"synthetic (SURVEY.md 8d recipe, generated on the device; stored log-probs: {args.logp})",
+            config=dict(workload=f"{w['name']}: compute_returns + train(), T={Tn}, n_rollout_threads={n_local}/GPU "
+                                 f"({n_local * world} global, {args.scaling} scaling), obs{w['obs']}/share{w['sobs']}/"
+                                 f"{'Discrete' if w['disc'] else 'Box'}{w['act']}, MLP{w['hidden']}{' + GRU' if w.get('rnn') else ''}, "
+                                 f"{'ppo_epoch=5, ' if w['algo'] == 'happo' else 'CG 10 + line search, '}critic_epoch=5",
+                        baseline_config=args.config, episode_length=Tn, n_rollout_threads_per_gpu=n_local, n_agents=w["A"],
+                        parallelism=f"dp{world}", collective="rccl" if comm.enabled else "none", git_sha=git_sha()),
             roofline=roof,
-            end_to_end=dict(algorithmic_tflops=e2e / 1e12, frac_of_mfma_peak=e2e / (MFMA_F32_PEAK * world),
-                            flops_per_transition=flops_per_transition()),
-            kernels={k: dict(n=v["n"], avg_ms=round(v["avg_ms"], 4), total_ms=round(v["total_ms"], 3))
-                     for k, v in breakdown.items()},
+            kernels={k: dict(n=v["n"], avg_ms=round(v["avg_ms"], 4), total_ms=round(v["total_ms"], 3),
+                             **({"hbm_frac": round(v["bytes"] / (v["total_ms"] * 1e-3) / HBM_PEAK, 4), "alg_bytes": v["bytes"]}
+                                if v.get("bytes") else {}))
+                     for k, v in kern.items()},
             kernel_timing=f"`kernels`: HIP events around every tagged launch, {args.instr_steps} instrumented steps after the timed region",
         )
-        if world == 1 and args.cpu_cols > 0:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_cols, min(args.cpu_threads, os.cpu_count() or 1))
+        if w["algo"] == "happo":
+            e2e = flops_per_transition(w) * value
+            out["end_to_end"] = dict(algorithmic_tflops=e2e / 1e12, frac_of_fp32_mfma_peak=e2e / (MFMA_F32_PEAK * world),
+                                     flops_per_transition=flops_per_transition(w))
+        cols = args.cpu_cols
+        if cols < 0:  # ~10-30 s of CPU work per update for every configuration
+            cols = {"mpe": 512, "cheetah6": 512, "smac3s5z": 128, "humanoid17": 16}[args.config]
+        if world == 1 and cols > 0:
+            out["cpu_baseline"] = cpu_baseline(w, cols, min(args.cpu_threads, os.cpu_count() or 1))
         print(json.dumps(out), flush=True)
     if comm.enabled:
         torch.distributed.barrier()

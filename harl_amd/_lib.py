@@ -12,6 +12,8 @@ from typing import Optional
 
 import torch
 
+from .traffic import algorithmic_bytes
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libharl_hip.so")
 
@@ -134,12 +136,15 @@ def enable_kernel_timing(on: bool, tags=None) -> None:
 
 
 def collect_kernel_timing() -> dict:
-    """{tag: {n, avg_ms, total_ms}} for the launches recorded since enable_kernel_timing(True)."""
+    """{tag: {n, avg_ms, total_ms, bytes}} for the launches recorded since enable_kernel_timing(True)."""
     torch.cuda.synchronize()
     out = {}
     for tag, evs in _timing_events.items():
-        ms = [a.elapsed_time(b) for a, b in evs]
-        out[tag] = dict(n=len(ms), avg_ms=sum(ms) / max(len(ms), 1), total_ms=sum(ms))
+        ms = [a.elapsed_time(b) for a, b, _ in evs]
+        nb = [x for _, _, x in evs if x is not None]
+        out[tag] = dict(n=len(ms), avg_ms=sum(ms) / max(len(ms), 1), total_ms=sum(ms),
+                        # algorithmic HBM bytes of the launches that ran (harl_amd/traffic.py), None if no model
+                        bytes=sum(nb) if len(nb) == len(evs) and nb else None)
     return out
 
 
@@ -151,7 +156,7 @@ def call(name: str, *args, tag: Optional[str] = None) -> None:
         a.record()
         rc = getattr(lib, name)(*args)
         b.record()
-        _timing_events.setdefault(tag, []).append((a, b))
+        _timing_events.setdefault(tag, []).append((a, b, algorithmic_bytes(name, args)))
     else:
         rc = getattr(lib, name)(*args)
     if rc != 0:

@@ -18,7 +18,8 @@ class Comm:
     """Thin wrapper so the algorithm code is identical for 1 and N ranks (and for gloo in CPU tests)."""
 
     def __init__(self, group=None):
-        self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.enabled = (dist.is_available() and dist.is_initialized()
+                        and (dist.get_world_size(group) > 1 or os.environ.get("HARL_DIST_SINGLE") == "1"))
         self.group = group
         self.world_size = dist.get_world_size(group) if self.enabled else 1
         self.rank = dist.get_rank(group) if self.enabled else 0
@@ -95,7 +96,10 @@ def local_minibatch_rows(global_idx: torch.Tensor, n_global: int, lo: int, hi: i
 def init_from_env(backend: Optional[str] = None) -> Comm:
     """torchrun-style rendezvous (RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT / LOCAL_RANK)."""
     ws = int(os.environ.get("WORLD_SIZE", "1"))
-    if ws > 1 and not dist.is_initialized():
+    # HARL_DIST_SINGLE=1: build the group even for ONE rank, so that the RCCL branch of the update (message packing,
+    # all_reduce, hi/lo scalar pieces) runs on a one-GPU box exactly as it does on eight
+    single = ws == 1 and os.environ.get("HARL_DIST_SINGLE") == "1" and "RANK" in os.environ
+    if (ws > 1 or single) and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":

@@ -1,0 +1,172 @@
+"""Algorithmic HBM bytes of one launch of each streaming kernel, computed from the C-ABI arguments of that launch.
+
+Measurement support only (bench.py's `roofline`): `_lib.call` evaluates the entry of the function it is
+about to launch when kernel timing is enabled, so that  achieved GB/s = sum(bytes) / sum(HIP-event time)  per kernel family
+uses the bytes of the launches that actually ran (training-mode and log-prob-mode forwards, actor and critic input
+widths, ...).  "Algorithmic" = every operand the kernel must read once and every result it must write once, per
+minibatch row, in the layouts of DESIGN.md section 2; weights, LDS staging and re-reads are not counted (they are what
+`roofline.traffic`, the PMC figure, is compared against).
+
+Per row of an activation of width H: the ATL image is 4H bytes, the ReLU bit mask H/8 bytes, the LayerNorm statistic 4 bytes.
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, Optional, Sequence
+
+
+def _act(H: int) -> float:  # x_hat image + ReLU mask + rstd of one row
+    return 4.0 * H + H / 8.0 + 4.0
+
+
+def _kp(D: int) -> int:  # padded input width of the cached normalised-input image
+    return 32 * ((int(D) + 31) // 32)
+
+
+def _fwd_fused2x(a: Sequence) -> float:
+    # (x0n, M, W1p, D, b1p, W2p, b2p, H, store1, x1out, mask1, rstd1, x2out, mask2, rstd2, stream)
+    M, D, H, store1 = a[1], a[3], a[7], a[8]
+    return M * (4.0 * _kp(D) + (_act(H) if store1 else 0.0) + _act(H))
+
+
+def _fwd_fused2(a: Sequence) -> float:
+    # (X, ldx, idx, M, D, W1p, b1p, use_ln0, W2p, b2p, H, store1, x1out, mask1, rstd1, mu0, rstd0, x2out, mask2, rstd2, x0n, stream)
+    M, D, H, store1, x0n = a[3], a[4], a[10], a[11], a[20]
+    return M * (4.0 * D + (8.0 if a[2] else 0.0) + (_act(H) if store1 else 0.0) + _act(H) + 8.0 + (4.0 * _kp(D) if x0n else 0.0))
+
+
+def _fwd_hidden(a: Sequence) -> float:  # (xin, M, HI, HO, Wp, bp, xout, relu_mask, rstd, stream)
+    return a[1] * (4.0 * a[2] + _act(a[3]))
+
+
+def _fwd_wide(a: Sequence) -> float:  # (x0n, M, KP, Wp, D, bp, H, w_img, xout, relu_mask, rstd, stream)
+    return a[1] * (4.0 * a[2] + _act(a[6]))
+
+
+def _fwd_input(a: Sequence) -> float:
+    # (X, ldx, idx, M, D, Wp, bp, use_ln0, H, xout, relu_mask, rstd, mu0, rstd0, x0n, stream)
+    return a[3] * (4.0 * a[4] + (8.0 if a[2] else 0.0) + _act(a[8]) + 8.0 + (4.0 * _kp(a[4]) if a[14] else 0.0))
+
+
+def _x0n_wide(a: Sequence) -> float:  # (X, ldx, idx, M, D, use_ln0, x0n, mu0, rstd0, stream)
+    return a[3] * (4.0 * a[4] + (8.0 if a[2] else 0.0) + 4.0 * _kp(a[4]) + 8.0)
+
+
+def _tangent_wide(a: Sequence) -> float:  # (x0n, M, KP, Wdp, D, bdp, H, w_img, x1, mask1, rstd1, x1dot, stream)
+    return a[1] * (4.0 * a[2] + _act(a[6]) + 4.0 * a[6])
+
+
+def _bwd_dx(a: Sequence) -> float:
+    # (dz, xprev, relu_mask_prev, rstd_prev, M, HO, HI, Wp, dz_prev, x0n, kp0, dw_part, n_wg, stream)
+    M, HO, HI = a[4], a[5], a[6]
+    return M * (4.0 * HO + _act(HI) + (4.0 * HI if a[8] else 0.0) + (4.0 * a[10] if a[9] else 0.0))
+
+
+def _dw_partials(a: Sequence) -> float:
+    # (a, a_kind, lda, HO, b, b_kind, ldx, idx, mu0, rstd0, K, M, part, n_wg, stream): dz rows (a_kind 0: ATL(HO); 1: row-major
+    # head gradient of `lda` floats) and the layer's input rows (ATL(K), or raw rows gathered through idx)
+    lda, HO, K, M = a[2], a[3], a[10], a[11]
+    return M * (4.0 * (lda if a[1] else HO) + 4.0 * K)
+
+
+def _gru_fwd(a: Sequence) -> float:
+    # (xin, mask_rows, h0, Wih, bih, Whh, bhh, H, L, m_pad, y, rstd_y, hpm, r, z, n, hn, h_last, save, gi_ws, stream)
+    H, L, m_pad, save = a[7], a[8], a[9], a[18]
+    return L * m_pad * (4.0 * H + 4.0 + 4.0 * H + 4.0 + (5 * 4.0 * H if save else 0.0))
+
+
+def _gru_bwd(a: Sequence) -> float:
+    # reads dhout + the five saved images + the MLP output feeding the GRU (+mask, rstd); writes the four gate gradients
+    # and the gradient into the MLP
+    H, L, m_pad = a[9], a[10], a[11]
+    return L * m_pad * (6 * 4.0 * H + 4.0 + _act(H) + 4 * 4.0 * H + 4.0 * H)
+
+
+def _head_rows(discrete: int, act_dim: int, avail) -> float:  # actions + old log-probs (+ availability mask) of one row
+    w = 1 if discrete else act_dim
+    return 4.0 * w + 4.0 * w + (4.0 * act_dim if avail else 0.0)
+
+
+def _actor_head_loss(a: Sequence) -> float:
+    # (xL, relu_mask, rstd, M, H, Whp, bhp, log_std, sx, sy, discrete, act_dim, idx, actions, avail, old_logp, adv, adv_moments,
+    #  factor, active, clip, ent, agg_mean, trpo, m_valid, m_pad, logp_out, dzL, dhead, part_scalars, dw_part, n_wg, stream)
+    M, H, disc, ad = a[3], a[4], a[10], a[11]
+    w = 1 if disc else ad
+    return M * (_act(H) + _head_rows(disc, ad, a[14]) + 4.0 + (4.0 if a[18] else 0.0) + (4.0 if a[19] else 0.0)
+                + (4.0 * w if a[26] else 0.0) + 4.0 * H + (4.0 * 32 if a[28] else 0.0))
+
+
+def _actor_head_logp(a: Sequence) -> float:
+    # (xL, M, H, Whp, bhp, log_std, sx, sy, discrete, act_dim, actions, avail, logp_out, old_logp, factor, agg_mean, head_out,
+    #  m_valid, m_pad, stream)
+    M, H, disc, ad = a[1], a[2], a[8], a[9]
+    w = 1 if disc else ad
+    return M * (4.0 * H + 4.0 * w + (4.0 * ad if a[11] else 0.0) + (4.0 * w if a[12] else 0.0) + (4.0 * w if a[13] else 0.0)
+                + (8.0 if a[14] else 0.0) + (4.0 * ad if a[16] else 0.0))
+
+
+def _critic_head_loss(a: Sequence) -> float:
+    # (xL, relu_mask, rstd, M, H, Whp, bhp, idx, value_preds, returns, vn_stats, ...)
+    return a[3] * (_act(a[4]) + 8.0 + 4.0 * a[4])
+
+
+def _update_fwd_actor(a: Sequence) -> float:
+    # (x0n, M, D, H, 7 weight pointers, sx, sy, discrete, act_dim, actions, avail, old_logp, adv, adv_moments, factor, active,
+    #  clip, ent, agg_mean, trpo, logp_out, dz2, part_scalars, dw_part_head, n_part_rows, stream)
+    M, D, H, disc, ad = a[1], a[2], a[3], a[13], a[14]
+    w = 1 if disc else ad
+    return M * (4.0 * _kp(D) + _head_rows(disc, ad, a[16]) + 4.0 + (4.0 if a[20] else 0.0) + (4.0 if a[21] else 0.0)
+                + (4.0 * w if a[26] else 0.0) + 4.0 * H)
+
+
+def _update_logp(a: Sequence) -> float:
+    M, D, disc, ad = a[1], a[2], a[13], a[14]
+    w = 1 if disc else ad
+    return M * (4.0 * _kp(D) + 4.0 * w + (4.0 * ad if a[16] else 0.0) + (4.0 * w if a[17] else 0.0) + (4.0 * w if a[18] else 0.0)
+                + (8.0 if a[19] else 0.0) + (4.0 * ad if a[21] else 0.0))
+
+
+def _update_fwd_critic(a: Sequence) -> float:
+    return a[1] * (4.0 * _kp(a[2]) + 8.0 + 4.0 * a[3])
+
+
+def _update_values(a: Sequence) -> float:
+    return a[1] * (4.0 * _kp(a[2]) + 4.0)
+
+
+def _update_bwd(a: Sequence) -> float:  # (x0n, dz2, M, D, H, ...): the normalised inputs and dz2; everything else is recomputed
+    return a[2] * (4.0 * _kp(a[3]) + 4.0 * a[4])
+
+
+def _gae(a: Sequence) -> float:
+    # rewards, value_preds (T+1), masks (T+1), bad_masks (T+1) in; returns (T+1), advantages out
+    T, n = a[8], a[9]
+    return 4.0 * n * (T + 3 * (T + 1) + (T + 1) + T)
+
+
+ALGORITHMIC_BYTES: Dict[str, Callable[[Sequence], float]] = {
+    "harl_mlp_fwd_fused2x": _fwd_fused2x,
+    "harl_mlp_fwd_fused2": _fwd_fused2,
+    "harl_mlp_fwd_hidden": _fwd_hidden,
+    "harl_mlp_fwd_wide": _fwd_wide,
+    "harl_mlp_fwd_input": _fwd_input,
+    "harl_mlp_x0n_wide": _x0n_wide,
+    "harl_mlp_tangent_wide": _tangent_wide,
+    "harl_mlp_bwd_dx": _bwd_dx,
+    "harl_mlp_dw_partials": _dw_partials,
+    "harl_gru_fwd": _gru_fwd,
+    "harl_gru_bwd": _gru_bwd,
+    "harl_actor_head_loss": _actor_head_loss,
+    "harl_actor_head_logp": _actor_head_logp,
+    "harl_critic_head_loss": _critic_head_loss,
+    "harl_update_fwd_actor": _update_fwd_actor,
+    "harl_update_logp": _update_logp,
+    "harl_update_fwd_critic": _update_fwd_critic,
+    "harl_update_values": _update_values,
+    "harl_update_bwd": _update_bwd,
+    "harl_gae_returns": _gae,
+}
+
+
+def algorithmic_bytes(name: str, args: Sequence) -> Optional[float]:
+    f = ALGORITHMIC_BYTES.get(name)
+    return None if f is None else float(f(args))

@@ -258,6 +258,9 @@ def main():
                     help="torch CPU threads for the baseline (these nets are small: more threads than ~16 is slower)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--instr-steps", type=int, default=2, help="instrumented (HIP-event) steps after the timed region")
+    ap.add_argument("--time-all-tags", action="store_true",
+                    help="bracket EVERY tagged launch inside the timed region (used by tools/pmc_traffic.sh so that `kernels` "
+                         "describes exactly the step the PMC passes profile; costs ~10 %% of the step)")
     args = ap.parse_args()
     w = WORKLOADS[args.config]
 
@@ -296,7 +299,7 @@ def main():
     ROOF_TAGS = ("fwd_fused2", "fwd_fused2_k64", "fwd_hidden", "bwd_dx", "bwd_dx_dw1", "dw_hidden", "fwd_wide", "dw_input",
                  "tangent_wide", "gru_fwd", "gru_bwd", "update_fwd", "update_bwd", "update_logp", "update_fwd_critic")
     if not args.no_kernel_timing:
-        _lib.enable_kernel_timing(True, ROOF_TAGS)
+        _lib.enable_kernel_timing(True, None if args.time_all_tags else ROOF_TAGS)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step(r)
@@ -312,7 +315,7 @@ def main():
         dt = float(tt.item())
     # Full per-kernel breakdown (every tagged launch, ~10 % of wall time): `instr_steps` further steps of the SAME
     # workload after the timed region, so that it does not understate `value`.
-    kern = {}
+    kern = dict(roof_kern) if args.time_all_tags else {}
     if not args.no_kernel_timing and args.instr_steps > 0:
         _lib.enable_kernel_timing(True)
         for _ in range(args.instr_steps):

@@ -74,55 +74,61 @@ __device__ __forceinline__ float denorm(const DenormStats &s, float v) {
   return t + s.mean;
 }
 
+// One column (rollout thread, or thread x agent for FP) per lane, 64-lane workgroups (N = 4096 columns -> 64 workgroups on 64
+// CUs instead of 16).  The scan over t is sequential per column and kept in the reference's operation order (bit-exact,
+// contraction off); what is parallel is the MEMORY side: the inputs of GAE_TC time steps are fetched into registers before
+// the dependent arithmetic of those steps starts (4 * GAE_TC independent coalesced loads in flight per lane instead of one
+// load latency per step: the loop was latency-bound at ~550 ns / step).
+constexpr int GAE_TC = 8;
 template <bool GAE, bool PTL, bool FP_ORDER>
-__global__ __launch_bounds__(256) void k_gae(const float *__restrict__ rewards, float *__restrict__ value_preds,
-                                             const float *__restrict__ masks, const float *__restrict__ bad_masks,
-                                             const float *__restrict__ next_value, const float *__restrict__ vn,
-                                             float *__restrict__ returns, float *__restrict__ adv, int T, int ncols,
-                                             float gamma, float gl) {
+__global__ __launch_bounds__(64) void k_gae(const float *__restrict__ rewards, float *__restrict__ value_preds,
+                                            const float *__restrict__ masks, const float *__restrict__ bad_masks,
+                                            const float *__restrict__ next_value, const float *__restrict__ vn,
+                                            float *__restrict__ returns, float *__restrict__ adv, int T, int ncols,
+                                            float gamma, float gl) {
 #pragma clang fp contract(off)
   int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= ncols) return;
   const DenormStats ds = load_denorm(vn);
   const long N = ncols;
-  float nv = next_value[c];
-  if (GAE) {
-    value_preds[(long)T * N + c] = nv;  // critic_buffer_ep.py:107
-    float gae = 0.f;
-    float v1 = nv;  // value_preds[t+1]
-    float dv1 = denorm(ds, v1);
-#pragma unroll 8
-    for (int t = T - 1; t >= 0; --t) {
-      float r = rewards[t * N + c];
-      float v0 = value_preds[t * N + c];
-      float m1 = masks[(t + 1) * N + c];
-      float dv0 = denorm(ds, v0);
-      float delta = r + (gamma * dv1) * m1;
-      delta = delta - dv0;
-      float carry = FP_ORDER ? (gl * gae) * m1 : (gl * m1) * gae;
-      gae = delta + carry;
-      if (PTL) gae = bad_masks[(t + 1) * N + c] * gae;
-      float ret = gae + dv0;
-      returns[t * N + c] = ret;
-      if (adv) adv[t * N + c] = ret - dv0;
-      dv1 = dv0;
+  const float nv = next_value[c];
+  float gae = 0.f, ret1 = nv;
+  float dv1 = denorm(ds, nv);  // value_preds[t+1], denormalised
+  if (GAE) value_preds[(long)T * N + c] = nv;  // critic_buffer_ep.py:107
+  else returns[(long)T * N + c] = nv;
+  for (int t0 = T - 1; t0 >= 0; t0 -= GAE_TC) {
+    float r[GAE_TC], v0[GAE_TC], m1[GAE_TC], b1[GAE_TC];
+#pragma unroll
+    for (int k = 0; k < GAE_TC; ++k) {
+      const int t = t0 - k;
+      const bool ok = t >= 0;
+      const long o = (long)(ok ? t : 0) * N + c;
+      r[k] = rewards[o];
+      v0[k] = value_preds[o];
+      m1[k] = masks[o + N];
+      b1[k] = PTL ? bad_masks[o + N] : 1.f;
     }
-  } else {
-    float ret1 = nv;
-    returns[(long)T * N + c] = nv;
-#pragma unroll 8
-    for (int t = T - 1; t >= 0; --t) {
-      float r = rewards[t * N + c];
-      float m1 = masks[(t + 1) * N + c];
-      float dv0 = denorm(ds, value_preds[t * N + c]);
-      float ret = (ret1 * gamma) * m1 + r;
-      if (PTL) {
-        float b1 = bad_masks[(t + 1) * N + c];
-        ret = ret * b1 + (1.f - b1) * dv0;
+#pragma unroll
+    for (int k = 0; k < GAE_TC; ++k) {
+      const int t = t0 - k;
+      if (t < 0) break;
+      const float dv0 = denorm(ds, v0[k]);
+      float ret;
+      if (GAE) {
+        float delta = r[k] + (gamma * dv1) * m1[k];
+        delta = delta - dv0;
+        const float carry = FP_ORDER ? (gl * gae) * m1[k] : (gl * m1[k]) * gae;
+        gae = delta + carry;
+        if (PTL) gae = b1[k] * gae;
+        ret = gae + dv0;
+        dv1 = dv0;
+      } else {
+        ret = (ret1 * gamma) * m1[k] + r[k];
+        if (PTL) ret = ret * b1[k] + (1.f - b1[k]) * dv0;
+        ret1 = ret;
       }
-      returns[t * N + c] = ret;
-      if (adv) adv[t * N + c] = ret - dv0;
-      ret1 = ret;
+      returns[(long)t * N + c] = ret;
+      if (adv) adv[(long)t * N + c] = ret - dv0;
     }
   }
 }
@@ -133,7 +139,7 @@ extern "C" int harl_gae_returns(const float *rewards, float *value_preds, const 
                                 float gamma_lambda, int use_gae, int use_proper_time_limits, int fp_order,
                                 void *stream) {
   if (T <= 0 || ncols <= 0) return 0;
-  dim3 block(256), grid((ncols + 255) / 256);
+  dim3 block(64), grid((ncols + 63) / 64);
   hipStream_t s = (hipStream_t)stream;
 #define LAUNCH(G, P, F)                                                                                     \
   hipLaunchKernelGGL((k_gae<G, P, F>), grid, block, 0, s, rewards, value_preds, masks, bad_masks, next_value, \
@@ -152,8 +158,14 @@ extern "C" int harl_gae_returns(const float *rewards, float *value_preds, const 
 }
 
 // =============================================================================================
-// masked moments (fp64 accumulation; one atomic triple per block)
+// masked moments (fp64 accumulation, FIXED summation order: the same bits on every run)
 // =============================================================================================
+// Every block leaves its partial {sum, sumsq, count} in a device scratch row; the block that takes the last ticket adds
+// the rows in index order onto out3.  (Launches of this kernel are serialised on one stream by the callers.)
+constexpr int MM_MAX_BLOCKS = 1024;
+__device__ double g_mm_part[MM_MAX_BLOCKS][3];
+__device__ unsigned g_mm_ticket;
+
 __global__ __launch_bounds__(256) void k_masked_moments(const float *__restrict__ x, const float *__restrict__ active,
                                                         long n, double *__restrict__ out3) {
   double s1 = 0, s2 = 0, cnt = 0;
@@ -170,6 +182,7 @@ __global__ __launch_bounds__(256) void k_masked_moments(const float *__restrict_
   s2 = wave_reduce_sum_d(s2);
   cnt = wave_reduce_sum_d(cnt);
   __shared__ double sh[3][4];
+  __shared__ unsigned s_last;
   int w = threadIdx.x >> 6, l = threadIdx.x & 63;
   if (l == 0) {
     sh[0][w] = s1;
@@ -177,16 +190,38 @@ __global__ __launch_bounds__(256) void k_masked_moments(const float *__restrict_
     sh[2][w] = cnt;
   }
   __syncthreads();
-  if (threadIdx.x < 3) {
-    double t = sh[threadIdx.x][0] + sh[threadIdx.x][1] + sh[threadIdx.x][2] + sh[threadIdx.x][3];
-    atomicAdd(&out3[threadIdx.x], t);
+  if (threadIdx.x < 3)
+    __hip_atomic_store(&g_mm_part[blockIdx.x][threadIdx.x],
+                       sh[threadIdx.x][0] + sh[threadIdx.x][1] + sh[threadIdx.x][2] + sh[threadIdx.x][3], __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();  // release this block's row before taking the ticket
+    s_last = __hip_atomic_fetch_add(&g_mm_ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
   }
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();  // acquire the other blocks' rows
+  __shared__ double red[3][256];
+  for (int k = 0; k < 3; ++k) {  // rows tid, tid + 256, ... in that order; then the 256 lane sums in lane order
+    double t = 0;
+    for (unsigned b = threadIdx.x; b < gridDim.x; b += 256)
+      t += __hip_atomic_load(&g_mm_part[b][k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    red[k][threadIdx.x] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    double t = 0;
+    for (int i = 0; i < 256; ++i) t += red[threadIdx.x][i];
+    out3[threadIdx.x] += t;
+  }
+  if (threadIdx.x == 0) __hip_atomic_store(&g_mm_ticket, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 extern "C" int harl_masked_moments(const float *x, const float *active, long n, double *out3, void *stream) {
   if (n <= 0) return 0;
   long nb = (n + 2047) / 2048;
-  if (nb > 1024) nb = 1024;
+  if (nb > MM_MAX_BLOCKS) nb = MM_MAX_BLOCKS;
   hipLaunchKernelGGL(k_masked_moments, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x, active, n, out3);
   return check_launch("harl_masked_moments");
 }

@@ -107,9 +107,14 @@ __global__ __launch_bounds__(WG_THREADS, (FUSE && DAP <= 8) ? 2 : 1) void k_acto
   f32x4 xnext[PREF ? H / 8 : 1];
   if constexpr (PREF)
     if (slab_first < A.n_slabs) head_load_regs<H>(A.xL, slab_first, lane, xnext);
+  // the per-row loss inputs run ONE slab ahead of the arithmetic (a dozen registers; see ActorRow)
+  ActorRow<DAP> rnext;
+  if (slab_first < A.n_slabs) actor_row_load<DAP, DISCRETE, TRAIN>(A, slab_first, lane, rnext);
   for (long slab = slab_first; slab < A.n_slabs; slab += slab_step) {
     float z[DAP];
     f32x4 xs[TRAIN ? H / 8 : 1];
+    const ActorRow<DAP> rcur = rnext;
+    actor_row_load<DAP, DISCRETE, TRAIN>(A, slab + slab_step < A.n_slabs ? slab + slab_step : slab, lane, rnext);
     if constexpr (TRAIN) {
       if constexpr (PREF) {
 #pragma unroll
@@ -124,7 +129,7 @@ __global__ __launch_bounds__(WG_THREADS, (FUSE && DAP <= 8) ? 2 : 1) void k_acto
     }
     float dzh[DAP];
     float s1, s2;
-    if (!actor_sample<DAP, DISCRETE, TRAIN>(A, cst, z, slab, lane, adv_mean, adv_den, sc, dzh, s1, s2)) continue;
+    if (!actor_sample<DAP, DISCRETE, TRAIN>(A, cst, z, slab, lane, adv_mean, adv_den, sc, dzh, s1, s2, rcur)) continue;
     const long j = slab * SLAB + i;
     if constexpr (FUSE) {  // head weight gradient right here (x_hat_L and dhead are both in registers)
       if constexpr (LDSACC) head_dw_step_lds<H, DAP, HROWS>(xs, dzh, tx, td, lane, hw);

@@ -398,10 +398,48 @@ __device__ __forceinline__ void block_reduce_store(float (&v)[NV], float *red /*
 // two closed-form LayerNorm-backward means s1 = sum_d dzh[d] rowsum(W'_d), s2 = sum_d dzh[d] (z_d - b_d); returns true.
 // (happo.py:66-91, act.py:104-157, distributions.py:7-89, on_policy_ha_runner.py:116-124)
 // ---------------------------------------------------------------------------------------------
+// The per-row loss inputs of one lane's sample (a few dwords gathered through the minibatch index).  Loaded by
+// actor_row_load AHEAD of the head arithmetic that consumes them -- the kernels issue the next slab's rows while the current
+// slab is being worked on -- so that their latency is not paid in the middle of every slab (measured: the loss kernel spent
+// > 50 % of its wave cycles in s_waitcnt with these loads issued at their point of use).
+template <int DAP>
+struct ActorRow {
+  float a[DAP];    // actions (Categorical: a[0])
+  float olp[DAP];  // stored log-probs (Categorical: olp[0])
+  float av[DAP];   // availability mask (Categorical with avail only)
+  float act, adv, fct;
+};
+template <int DAP, bool DISCRETE, bool TRAIN>
+__device__ __forceinline__ void actor_row_load(const ActorArgs &A, long slab, int lane, ActorRow<DAP> &R) {
+  const int i = lane & 31;
+  const int D = A.act_dim;
+  const long j = slab * SLAB + i;
+  const long jc = j < A.M ? j : A.M - 1;
+  const long row = A.idx ? A.idx[jc] : jc;
+  const long orow = TRAIN ? row : jc;
+  if (!DISCRETE) {
+#pragma unroll
+    for (int d = 0; d < DAP; ++d) {
+      R.a[d] = (A.actions && d < D) ? A.actions[row * D + d] : 0.f;
+      R.olp[d] = ((TRAIN || A.old_logp) && d < D) ? A.old_logp[orow * D + d] : 0.f;
+    }
+  } else {
+    R.a[0] = A.actions ? A.actions[row] : 0.f;
+    R.olp[0] = (TRAIN || A.old_logp) ? A.old_logp[orow] : 0.f;
+#pragma unroll
+    for (int d = 0; d < DAP; ++d) R.av[d] = (A.avail && d < D) ? A.avail[row * D + d] : 1.f;
+  }
+  if (TRAIN) {
+    R.act = A.active ? A.active[row] : 1.f;
+    R.adv = A.adv[row];
+    R.fct = A.factor_in ? A.factor_in[row] : 1.f;
+  }
+}
+
 template <int DAP, bool DISCRETE, bool TRAIN>
 __device__ __forceinline__ bool actor_sample(const ActorArgs &A, const float *cst, float (&z)[DAP], long slab, int lane,
                                              float adv_mean, float adv_den, float (&sc)[8 + DAP], float (&dzh)[DAP],
-                                             float &s1_out, float &s2_out) {
+                                             float &s1_out, float &s2_out, const ActorRow<DAP> &R) {
   const int i = lane & 31, h = lane >> 5;
   const int D = A.act_dim;
   const int act_w = DISCRETE ? 1 : D;
@@ -431,14 +469,14 @@ __device__ __forceinline__ bool actor_sample(const ActorArgs &A, const float *cs
       logp_d[d] = 0.f;
       if (d < D) {
         const float sig = cst[DAP + d], lsig = cst[2 * DAP + d];
-        const float a = A.actions ? A.actions[row * act_w + d] : z[d];  // actions == NULL: head outputs only
+        const float a = A.actions ? R.a[d] : z[d];  // actions == NULL: head outputs only
         const float diff = a - z[d];
         const float var = sig * sig;
         const float lp = -(diff * diff) * (0.5f * cst[6 * DAP + d]) - lsig - LOG_SQRT_2PI;  // torch Normal.log_prob (1/var from the prologue)
         logp_d[d] = lp;
         ent += HALF_LOG_2PI_PLUS_HALF + lsig;
         if (TRAIN || A.old_logp) {
-          const float r = expf(lp - A.old_logp[(TRAIN ? row : jc) * act_w + d]);
+          const float r = expf(lp - R.olp[d]);
           ratio_d[d] = r;
           prod *= r;
           sum += r;
@@ -452,7 +490,7 @@ __device__ __forceinline__ bool actor_sample(const ActorArgs &A, const float *cs
 #pragma unroll
     for (int d = 0; d < DAP; ++d) {
       if (d < D) {
-        if (A.avail && A.avail[row * D + d] == 0.f) z[d] = -1e10f;
+        if (A.avail && R.av[d] == 0.f) z[d] = -1e10f;
         mx = fmaxf(mx, z[d]);
       }
     }
@@ -461,7 +499,7 @@ __device__ __forceinline__ bool actor_sample(const ActorArgs &A, const float *cs
     for (int d = 0; d < DAP; ++d)
       if (d < D) se += expf(z[d] - mx);
     const float lse = mx + logf(se);
-    const int a = A.actions ? (int)A.actions[row] : 0;
+    const int a = A.actions ? (int)R.a[0] : 0;
     float lpa = 0.f;
 #pragma unroll
     for (int d = 0; d < DAP; ++d) {
@@ -476,7 +514,7 @@ __device__ __forceinline__ bool actor_sample(const ActorArgs &A, const float *cs
         if (d == a) lpa = lp;
       }
     }
-    if (TRAIN || A.old_logp) imp = expf(lpa - A.old_logp[TRAIN ? row : jc]);
+    if (TRAIN || A.old_logp) imp = expf(lpa - R.olp[0]);
     // stash log p(a) in z[0] for the logp output below
     z[0] = lpa;
   }
@@ -510,9 +548,9 @@ __device__ __forceinline__ bool actor_sample(const ActorArgs &A, const float *cs
         if (d < D) A.logp_out[j * D + d] = logp_d[d];
     }
   }
-  const float act = A.active ? A.active[row] : 1.f;
-  const float advn = (A.adv[row] - adv_mean) * adv_den;  // adv_den: RECIPROCAL of (std + 1e-5), formed once per kernel
-  const float fct = A.factor_in ? A.factor_in[row] : 1.f;  // NULL: no sequential-update factor (MAPPO)
+  const float act = R.act;
+  const float advn = (R.adv - adv_mean) * adv_den;  // adv_den: RECIPROCAL of (std + 1e-5), formed once per kernel
+  const float fct = R.fct;  // 1 without a sequential-update factor (MAPPO)
   const float lo = A.clip_lo, hi = A.clip_hi;
   const float surr1 = imp * advn;
   const float impc = fminf(fmaxf(imp, lo), hi);
@@ -540,7 +578,7 @@ __device__ __forceinline__ bool actor_sample(const ActorArgs &A, const float *cs
       if (d < D) {
         const float sig = cst[DAP + d];
         const float var = sig * sig;
-        const float a = A.actions[row * act_w + d];
+        const float a = R.a[d];
         const float diff = a - z[d];
         // d imp / d logp_d : prod -> prod/r_d * r_d ; mean -> r_d / D
         const float dlp = dimp * (A.agg_mean ? ratio_d[d] * (1.0f / (float)D) : imp);
@@ -551,7 +589,7 @@ __device__ __forceinline__ bool actor_sample(const ActorArgs &A, const float *cs
       }
     }
   } else {
-    const int a = (int)A.actions[row];
+    const int a = (int)R.a[0];
     const float dlp = dimp * imp;
 #pragma unroll
     for (int d = 0; d < DAP; ++d) {

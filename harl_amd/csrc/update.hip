@@ -561,6 +561,8 @@ __global__ __launch_bounds__(UF_THREADS, 2) void k_upd_fwd(UpdFwdArgs U, ARGS A)
     float v[NR];        // x_hat_2
     uint32_t bits2[NW];
     float r2;
+    ActorRow<DAP> rcur;  // this slab's per-row loss inputs: issued before the two GEMMs that precede their use
+    if constexpr (!CRITIC) actor_row_load<DAP, DISCRETE, TRAIN>(A, slab, lane, rcur);
     {
       float x1[NR];
       {
@@ -602,7 +604,7 @@ __global__ __launch_bounds__(UF_THREADS, 2) void k_upd_fwd(UpdFwdArgs U, ARGS A)
       s1 = dv * cst[4 * DAP];
       s2 = dv * (z[0] - cst[0]);
     } else {
-      if (!actor_sample<DAP, DISCRETE, TRAIN>(A, cst, z, slab, lane, adv_mean, adv_den, sc, dzh, s1, s2)) continue;
+      if (!actor_sample<DAP, DISCRETE, TRAIN>(A, cst, z, slab, lane, adv_mean, adv_den, sc, dzh, s1, s2, rcur)) continue;
     }
     if constexpr (TRAIN) {
       // ---- head weight gradient dW_head'[d][f] += sum_s dzh[s][d] x_hat_2[s][f]: both operands transposed on the matrix

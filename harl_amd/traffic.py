@@ -92,7 +92,7 @@ def _actor_head_loss(a: Sequence) -> float:
     M, H, disc, ad = a[3], a[4], a[10], a[11]
     w = 1 if disc else ad
     return M * (_act(H) + _head_rows(disc, ad, a[14]) + 4.0 + (4.0 if a[18] else 0.0) + (4.0 if a[19] else 0.0)
-                + (4.0 * w if a[26] else 0.0) + 4.0 * H + (4.0 * 32 if a[28] else 0.0))
+                + (4.0 * w if a[26] else 0.0) + 4.0 * H + (4.0 * 32 if (a[28] and not a[30]) else 0.0))  # dhead only when the head dW is not fused
 
 
 def _actor_head_logp(a: Sequence) -> float:

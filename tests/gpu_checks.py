@@ -930,7 +930,7 @@ def check_full_size_properties() -> Dict[str, float]:
     import bench
     out = {}
     T, N, A = bench.T, bench.N_PER_GPU, bench.A
-    r = bench.build_gpu_runner(N, 0, 1, DEV)
+    r = bench.build_gpu_runner(bench.WORKLOADS["mpe"], N, 0, 1, torch.device(DEV), "onpolicy")
     rng = np.random.default_rng(0)
     # ---- 1. GAE scan: 48 random columns vs the oracle on those columns (bit-exact)
     cb = r.critic_buffer
@@ -1339,6 +1339,47 @@ def check_baseline_shape(name: str) -> Dict[str, float]:
         out["_actor_final_param_vec_rel_max"] = max(out.get("_actor_final_param_vec_rel_max", 0.0), vec_rel_err(fp, runs["f32"]["fin"][a]))
     out["actor_final_param_excess"] = worst
     out["critic_final_param_excess"] = vec_excess(r.critic.critic.flat_param.cpu().numpy(), runs["f32"]["cfin"], runs["f64"]["cfin"])
+    return out
+
+
+def check_buffer_slots(case: str) -> Dict[str, float]:
+    """Slot contents of the rollout buffers after T + 2 runner.insert() calls with after_update() in between, against the
+    arrays recorded from the REFERENCE's own insert()/after_update() on the same seeded inputs (oracle/gen_buffer_golden.py:
+    on_policy_base_runner.py:342-460, on_policy_actor_buffer.py:49-96, on_policy_critic_buffer_{ep,fp}.py).  Bit-exact."""
+    from oracle.gen_buffer_golden import ACTOR_KEYS, CASES, CRITIC_KEYS, snapshot, step_inputs
+    from harl_amd.buffers import OnPolicyActorBuffer, OnPolicyCriticBufferEP, OnPolicyCriticBufferFP
+    from harl_amd.runner import OnPolicyHARunner
+    st, disc, rn, T, N, A, D, S, act, H = CASES[case]
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "buffers", f"{case}.npz"))
+    args = dict(episode_length=T, n_rollout_threads=N, hidden_sizes=[H, H], recurrent_n=rn, gamma=0.99, gae_lambda=0.95,
+                use_gae=True, use_proper_time_limits=True)
+    space = Discrete(act) if disc else Box((act,))
+    r = OnPolicyHARunner.__new__(OnPolicyHARunner)  # the buffers and insert() only: no networks of width 8 exist
+    r.device, r.num_agents, r.state_type = torch.device(DEV), A, st
+    r.actor_buffer = [OnPolicyActorBuffer(args, Box((D,)), space, device=DEV) for _ in range(A)]
+    r.critic_buffer = (OnPolicyCriticBufferEP(args, Box((S,)), device=DEV) if st == "EP"
+                       else OnPolicyCriticBufferFP(args, Box((S,)), A, device=DEV))
+    out, bad = {}, []
+    get = lambda t: t.detach().cpu().numpy()  # noqa: E731
+
+    def compare(prefix):
+        snap = snapshot(r.actor_buffer, r.critic_buffer, get)
+        for k, v in snap.items():
+            g = z[f"{prefix}_{k}"]
+            if v.shape != g.shape or not np.array_equal(v, g.astype(v.dtype)):
+                bad.append(f"{prefix}_{k}")
+        missing = [k for k in z.files if k.startswith(prefix + "_") and k[len(prefix) + 1:] not in snap]
+        bad.extend(missing)
+
+    for step in range(T + 2):
+        obs, share, rewards, dones, infos, avail, values, actions, logp, rnn, rnn_c = step_inputs(case, step)
+        r.insert((obs, share, rewards, dones, infos, avail, dev(values), dev(actions), dev(logp), dev(rnn), dev(rnn_c)))
+        if step == T - 1:
+            compare("full")
+            r.after_update()
+    compare("end")
+    out["buffer_slot_mismatch"] = float(len(bad))
+    out["_mismatched"] = ",".join(bad)
     return out
 
 

@@ -240,3 +240,11 @@ def test_dropin_under_reference_launcher_on_gpu(tmp_path):
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
     res = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("DROPIN_RESULT ")][-1][len("DROPIN_RESULT "):])
     assert res["actor_class"] == "harl_amd.happo.HAPPO" and "critic_agent.pt" in res["saved"]
+
+
+@pytest.mark.parametrize("case", ["ep_box", "ep_disc_avail", "fp_box", "fp_disc_avail"])
+def test_buffer_slots_match_reference_insert_and_after_update(case):
+    """A2 / B5: every slot of both buffers after T + 2 insert() calls around an after_update(), against the arrays the
+    reference's own runner.insert() / buffer.after_update() produced from the same inputs (bit-exact)."""
+    res = _G().check_buffer_slots(case)
+    assert res["buffer_slot_mismatch"] == 0.0, res["_mismatched"]

@@ -24,8 +24,8 @@ GROUPS = [
     (r"void k_fwd_hidden<", ("fwd_hidden",)),
     (r"void k_bwd_dx<\d+, \d+, 0>", ("bwd_dx",)),
     (r"void k_bwd_dx<\d+, \d+, 1>", ("bwd_dx_dw1",)),
-    (r"void k_dw_split<", ("dw_hidden", "dw_gru")),
-    (r"void k_dw<", ("dw_input", "dw_head")),
+    (r"void k_dw(_split<|<0)", ("dw_hidden", "dw_gru", "dw_input")),
+    (r"void k_dw<1", ("dw_head",)),
     (r"void k_fwd_wide<", ("fwd_wide", "tangent_wide")),
     (r"(void )?k_x0n_", ("x0n_wide",)),
     (r"void k_actor_head<.*(true|false), true, (true|false)>", ("actor_head_loss",)),
@@ -69,7 +69,7 @@ def report(root, out_base):
         wr = load_counters(os.path.join(root, cfg, "write"))
         res = {}
         md.append(f"\n## {cfg}: {json.loads(line)['config']['workload']}\n")
-        md.append("| kernel (tags) | launches | fetch MB/launch | write MB/launch | algorithmic MB/launch | traffic / algorithmic |\n|---|---|---|---|---|---|")
+        md.append("| kernel (tags) | kernel launches / calls | fetch MB/call | write MB/call | algorithmic MB/call | traffic / algorithmic |\n|---|---|---|---|---|---|")
         for pat, tags in GROUPS:
             names = [k for k in fe if re.match(pat, k)]
             if not names:
@@ -80,13 +80,17 @@ def report(root, out_base):
             tg = [t for t in tags if t in kern and kern[t].get("alg_bytes")]
             if not tg or n == 0:
                 continue
-            alg_n = sum(kern[t]["n"] for t in tg)
-            alg = sum(kern[t]["alg_bytes"] for t in tg) / alg_n  # per launch
-            ratio = (fetch + write) / n / alg
+            # both runs execute exactly ONE update step, so totals are comparable even where one call of a tag issues several
+            # kernels (the first-layer weight gradient of a 416-wide input is four k_dw_split launches)
+            calls = sum(kern[t]["n"] for t in tg)
+            alg_total = sum(kern[t]["alg_bytes"] for t in tg)
+            ratio = (fetch + write) / alg_total
             for t in tg:
-                res[t] = dict(group=list(tg), launches_profiled=n, fetch_bytes_per_launch=fetch / n, write_bytes_per_launch=write / n,
-                              algorithmic_bytes_per_launch=alg, ratio=ratio)
-            md.append(f"| {names[0].split('(')[0][:60]} ({', '.join(tg)}) | {n} | {fetch / n / 1e6:.1f} | {write / n / 1e6:.1f} | {alg / 1e6:.1f} | {ratio:.3f} |")
+                res[t] = dict(group=list(tg), kernels=sorted(set(k.split("(")[0] for k in names)), kernel_launches=n, calls=calls,
+                              fetch_bytes_per_call=fetch / calls, write_bytes_per_call=write / calls,
+                              algorithmic_bytes_per_call=alg_total / calls, ratio=ratio)
+            md.append(f"| {names[0].split('(')[0][:60]}{' +%d more' % (len(names) - 1) if len(names) > 1 else ''} ({', '.join(tg)}) | {n} / {calls} | "
+                      f"{fetch / calls / 1e6:.1f} | {write / calls / 1e6:.1f} | {alg_total / calls / 1e6:.1f} | {ratio:.3f} |")
         out["workloads"][cfg] = res
     json.dump(out, open(out_base + ".json", "w"), indent=1)
     open(out_base + ".md", "w").write("\n".join(md) + "\n")

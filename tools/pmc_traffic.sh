@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 for c in $CFGS; do
   mkdir -p $OUT/$c
   ARGS="--config $c --steps 1 --warmup 0 --cpu-cols 0"
-  timeout 600 python $R/bench.py $ARGS --instr-steps 1 > $OUT/$c/plain.json 2> $OUT/$c/plain.err
+  timeout 600 python $R/bench.py $ARGS --instr-steps 0 --time-all-tags > $OUT/$c/plain.json 2> $OUT/$c/plain.err
   rm -rf /tmp/pf /tmp/pw
   timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pf -- python $R/bench.py $ARGS --instr-steps 0 --no-kernel-timing > /dev/null 2>&1
   timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pw -- python $R/bench.py $ARGS --instr-steps 0 --no-kernel-timing > /dev/null 2>&1

@@ -107,9 +107,10 @@ __device__ __forceinline__ float mask_pop(float x, uint32_t &bits) {  // returns
 //   da = rstd (dx_hat - mean_f(dx_hat) - x_hat mean_f(dx_hat x_hat)) ;  dz = relu_mask ? da : 0 ; store ATL
 // evaluated as  da = fma(x_hat, -s2 rstd, fma(dx_hat, rstd, -s1 rstd))  on register pairs (v_pk_fma_f32).
 template <int H>
-__device__ __forceinline__ void ln_bwd_relu_regs(const float (&dx)[H / 2], const float (&xh)[H / 2],
-                                                 const uint32_t *__restrict__ mask_in, float rstd, int lane, long slab,
-                                                 float (&out)[H / 2]) {
+__device__ __forceinline__ void ln_bwd_relu_bits(const float (&dx)[H / 2], const float (&xh)[H / 2],
+                                                 const uint32_t (&bits_in)[(H / 2 + 31) / 32], float rstd, float (&out)[H / 2]) {
+  // the ReLU-mask words come in registers: the callers load them BEFORE their GEMM (behind its sched_barriers a load at the
+  // point of use is issued after the last MFMA and its whole latency is exposed once per slab)
   constexpr int NR = H / 2;
   constexpr int NW = (NR + 31) / 32;
   f32x2 a1 = {0.f, 0.f}, a2 = {0.f, 0.f};
@@ -126,7 +127,7 @@ __device__ __forceinline__ void ln_bwd_relu_regs(const float (&dx)[H / 2], const
   const f32x2 c1v = {c1, c1}, c2v = {c2, c2}, rv = {rstd, rstd};
   uint32_t bits[NW];
 #pragma unroll
-  for (int w = 0; w < NW; ++w) bits[w] = mask_in[(slab * NW + w) * WAVE + lane];
+  for (int w = 0; w < NW; ++w) bits[w] = bits_in[w];
 #pragma unroll
   for (int P = 0; P < NR / 2; ++P) {
     const f32x2 d = {dx[2 * P], dx[2 * P + 1]}, x = {xh[2 * P], xh[2 * P + 1]};
@@ -134,6 +135,17 @@ __device__ __forceinline__ void ln_bwd_relu_regs(const float (&dx)[H / 2], const
     out[2 * P] = mask_pop(da[0], bits[(2 * P) >> 5]);
     out[2 * P + 1] = mask_pop(da[1], bits[(2 * P + 1) >> 5]);
   }
+}
+
+template <int H>
+__device__ __forceinline__ void ln_bwd_relu_regs(const float (&dx)[H / 2], const float (&xh)[H / 2],
+                                                 const uint32_t *__restrict__ mask_in, float rstd, int lane, long slab,
+                                                 float (&out)[H / 2]) {
+  constexpr int NW = (H / 2 + 31) / 32;
+  uint32_t bits[NW];
+#pragma unroll
+  for (int w = 0; w < NW; ++w) bits[w] = mask_in[(slab * NW + w) * WAVE + lane];
+  ln_bwd_relu_mbits<H>(dx, xh, bits, rstd, out);
 }
 
 template <int H>

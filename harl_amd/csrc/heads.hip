@@ -109,12 +109,32 @@ __global__ __launch_bounds__(WG_THREADS, (FUSE && DAP <= 8) ? 2 : 1) void k_acto
     if (slab_first < A.n_slabs) head_load_regs<H>(A.xL, slab_first, lane, xnext);
   // the per-row loss inputs run ONE slab ahead of the arithmetic (a dozen registers; see ActorRow)
   ActorRow<DAP> rnext;
-  if (slab_first < A.n_slabs) actor_row_load<DAP, DISCRETE, TRAIN>(A, slab_first, lane, rnext);
+  constexpr int NWM = (H / 2 + 31) / 32;
+  uint32_t mb0n = 0u, mb1n = 0u;  // ... and so do the ReLU-mask words and the LayerNorm statistic of the backward
+  float rstdn = 0.f;
+  if (slab_first < A.n_slabs) {
+    actor_row_load<DAP, DISCRETE, TRAIN>(A, slab_first, lane, rnext);
+    if constexpr (TRAIN) {
+      mb0n = A.relu_mask[(slab_first * NWM + 0) * WAVE + lane];
+      mb1n = NWM > 1 ? A.relu_mask[(slab_first * NWM + (NWM - 1)) * WAVE + lane] : 0u;
+      rstdn = A.rstd[slab_first * SLAB + i];
+    }
+  }
   for (long slab = slab_first; slab < A.n_slabs; slab += slab_step) {
     float z[DAP];
     f32x4 xs[TRAIN ? H / 8 : 1];
     const ActorRow<DAP> rcur = rnext;
-    actor_row_load<DAP, DISCRETE, TRAIN>(A, slab + slab_step < A.n_slabs ? slab + slab_step : slab, lane, rnext);
+    const uint32_t mb0 = mb0n, mb1 = mb1n;
+    const float rstd_cur = rstdn;
+    {
+      const long sn = slab + slab_step < A.n_slabs ? slab + slab_step : slab;
+      actor_row_load<DAP, DISCRETE, TRAIN>(A, sn, lane, rnext);
+      if constexpr (TRAIN) {
+        mb0n = A.relu_mask[(sn * NWM + 0) * WAVE + lane];
+        mb1n = NWM > 1 ? A.relu_mask[(sn * NWM + (NWM - 1)) * WAVE + lane] : 0u;
+        rstdn = A.rstd[sn * SLAB + i];
+      }
+    }
     if constexpr (TRAIN) {
       if constexpr (PREF) {
 #pragma unroll
@@ -151,7 +171,7 @@ __global__ __launch_bounds__(WG_THREADS, (FUSE && DAP <= 8) ? 2 : 1) void k_acto
       }
     }
     if constexpr (TRAIN)
-      head_bwd_regs<H, DAP>(xs, A.relu_mask, A.rstd[slab * SLAB + i], slab, lane, whl, dzh, s1, s2, A.dzL);
+      head_bwd_regs_bits<H, DAP>(xs, mb0, mb1, rstd_cur, slab, lane, whl, dzh, s1, s2, A.dzL);
   }
 
   if (TRAIN) block_reduce_store<8 + DAP>(sc, red, A.part_scalars + (long)blockIdx.x * PS_STRIDE);
@@ -209,9 +229,28 @@ __global__ __launch_bounds__(WG_THREADS, FUSE ? 2 : 1) void k_critic_head(Critic
   f32x4 xnext[LDSACC ? H / 8 : 1];  // next slab's x_hat_L, in flight during this slab's math (see k_actor_head)
   if constexpr (LDSACC)
     if (slab_first < A.n_slabs) head_load_regs<H>(A.xL, slab_first, lane, xnext);
+  // value_preds / returns, ReLU-mask words and the LayerNorm statistic run one slab ahead as well (see ActorRow)
+  constexpr int NWM = (H / 2 + 31) / 32;
+  float voldn = 0.f, retn = 0.f, rstdn = 0.f;
+  uint32_t mb0n = 0u, mb1n = 0u;
+  if (TRAIN && slab_first < A.n_slabs) {
+    critic_row_load(A, slab_first, lane, voldn, retn);
+    mb0n = A.relu_mask[(slab_first * NWM + 0) * WAVE + lane];
+    mb1n = NWM > 1 ? A.relu_mask[(slab_first * NWM + (NWM - 1)) * WAVE + lane] : 0u;
+    rstdn = A.rstd[slab_first * SLAB + i];
+  }
   for (long slab = slab_first; slab < A.n_slabs; slab += slab_step) {
     float z[DAP];
     f32x4 xs[TRAIN ? H / 8 : 1];
+    const float vold = voldn, ret = retn, rstd_cur = rstdn;
+    const uint32_t mb0 = mb0n, mb1 = mb1n;
+    if constexpr (TRAIN) {
+      const long sn = slab + slab_step < A.n_slabs ? slab + slab_step : slab;
+      critic_row_load(A, sn, lane, voldn, retn);
+      mb0n = A.relu_mask[(sn * NWM + 0) * WAVE + lane];
+      mb1n = NWM > 1 ? A.relu_mask[(sn * NWM + (NWM - 1)) * WAVE + lane] : 0u;
+      rstdn = A.rstd[sn * SLAB + i];
+    }
     if constexpr (TRAIN) {
       if constexpr (LDSACC) {
 #pragma unroll
@@ -225,7 +264,7 @@ __global__ __launch_bounds__(WG_THREADS, FUSE ? 2 : 1) void k_critic_head(Critic
       head_fwd_stream<H, DAP>(A.xL, slab, lane, whl_h, cst, z);
     }
     float dv;
-    if (!critic_sample<TRAIN>(A, z[0], slab, lane, vmean, vsd, sc, dv)) continue;
+    if (!critic_sample<TRAIN>(A, z[0], slab, lane, vmean, vsd, sc, dv, vold, ret)) continue;
     const float v = z[0];
     const long j = slab * SLAB + i;
     const float dzh[DAP] = {dv, 0.f, 0.f, 0.f};
@@ -238,8 +277,7 @@ __global__ __launch_bounds__(WG_THREADS, FUSE ? 2 : 1) void k_critic_head(Critic
       for (int c = 0; c < 16; ++c) dh[c] = (h == 0 && c == 0) ? dv : 0.f;
     }
     if constexpr (TRAIN)
-      head_bwd_regs<H, DAP>(xs, A.relu_mask, A.rstd[slab * SLAB + i], slab, lane, whl, dzh, dv * cst[4 * DAP],
-                            dv * (v - cst[0]), A.dzL);
+      head_bwd_regs_bits<H, DAP>(xs, mb0, mb1, rstd_cur, slab, lane, whl, dzh, dv * cst[4 * DAP], dv * (v - cst[0]), A.dzL);
   }
   if (TRAIN) block_reduce_store<8>(sc, red, A.part_scalars + (long)blockIdx.x * PS_STRIDE);
   if constexpr (FUSE)

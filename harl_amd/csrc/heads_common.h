@@ -632,9 +632,17 @@ struct CriticArgs {
 // Per-sample critic-head arithmetic (v_critic.py:75-114): clipped value loss with optional ValueNorm'd targets and
 // Huber loss; returns d(unscaled loss)/d(value) (0 for padding rows) and adds {loss, count} to `sc`.  !TRAIN: writes the
 // value and returns false.
+__device__ __forceinline__ void critic_row_load(const CriticArgs &A, long slab, int lane, float &vold, float &ret) {
+  const long j = slab * SLAB + (lane & 31);
+  const long jc = j < A.M ? j : A.M - 1;
+  const long row = A.idx ? A.idx[jc] : jc;
+  vold = A.value_preds[row];
+  ret = A.returns[row];
+}
+
 template <bool TRAIN>
 __device__ __forceinline__ bool critic_sample(const CriticArgs &A, float v, long slab, int lane, float vmean, float vsd,
-                                              float (&sc)[8], float &dv_out) {
+                                              float (&sc)[8], float &dv_out, float vold, float ret) {
   const int i = lane & 31, h = lane >> 5;
   const long j = slab * SLAB + i;
   const bool valid = j < A.M && (A.m_pad == 0 || (j % A.m_pad) < A.m_valid);
@@ -642,10 +650,6 @@ __device__ __forceinline__ bool critic_sample(const CriticArgs &A, float v, long
     if (j < A.M && h == 0) A.values_out[j] = v;
     return false;
   }
-  const long jc = j < A.M ? j : A.M - 1;
-  const long row = A.idx ? A.idx[jc] : jc;
-  const float vold = A.value_preds[row];
-  const float ret = A.returns[row];
   const float eps = A.clip_param, dl = A.huber_delta;
   const float diff = v - vold;
   const float vclip = vold + fminf(fmaxf(diff, -eps), eps);

@@ -695,6 +695,10 @@ __global__ __launch_bounds__(WG_THREADS, (KT > 0 || split_one_wg(HI, HO)) ? 1 : 
     float xh[HI / 2];
     atl_load<HI>(xprev, slab, lane, xh);
     const float rstd = rstd_prev[slab * SLAB + i];
+    constexpr int NWP = (HI / 2 + 31) / 32;
+    uint32_t mbits[NWP];
+#pragma unroll
+    for (int w = 0; w < NWP; ++w) mbits[w] = mask_prev[(slab * NWP + w) * WAVE + lane];
     f32x4 x0r[KT > 0 ? KPF / 8 : 1];
     if constexpr (KT > 0) {
       const f32x4 *bp = reinterpret_cast<const f32x4 *>(x0n + slab * (long)(KPF * SLAB)) + lane;
@@ -711,10 +715,12 @@ __global__ __launch_bounds__(WG_THREADS, (KT > 0 || split_one_wg(HI, HO)) ? 1 : 
 #pragma unroll
     for (int R = 0; R < HI / 2; ++R) dx[R] = acc[R >> 4][R & 15];
     if constexpr (KT == 0) {
-      ln_bwd_relu_store<HI>(dx, xh, mask_prev, rstd, lane, slab, dz_prev);
+      float out[HI / 2];
+      ln_bwd_relu_mbits<HI>(dx, xh, mbits, rstd, out);
+      atl_store<HI>(dz_prev, slab, lane, out);
     } else {
       float out[HI / 2];
-      ln_bwd_relu_regs<HI>(dx, xh, mask_prev, rstd, lane, slab, out);
+      ln_bwd_relu_mbits<HI>(dx, xh, mbits, rstd, out);
       if (dz_prev) atl_store<HI>(dz_prev, slab, lane, out);
       float *tx = stg + wave * STAGE_FLOATS, *tb = tx + SLAB * HX;
 #pragma unroll

@@ -562,7 +562,9 @@ __global__ __launch_bounds__(UF_THREADS, 2) void k_upd_fwd(UpdFwdArgs U, ARGS A)
     uint32_t bits2[NW];
     float r2;
     ActorRow<DAP> rcur;  // this slab's per-row loss inputs: issued before the two GEMMs that precede their use
+    float cvold = 0.f, cret = 0.f;
     if constexpr (!CRITIC) actor_row_load<DAP, DISCRETE, TRAIN>(A, slab, lane, rcur);
+    else if constexpr (TRAIN) critic_row_load(A, slab, lane, cvold, cret);
     {
       float x1[NR];
       {
@@ -598,7 +600,7 @@ __global__ __launch_bounds__(UF_THREADS, 2) void k_upd_fwd(UpdFwdArgs U, ARGS A)
     float s1, s2;
     if constexpr (CRITIC) {
       float dv;
-      if (!critic_sample<TRAIN>(A, z[0], slab, lane, vmean, vsd, sc, dv)) continue;
+      if (!critic_sample<TRAIN>(A, z[0], slab, lane, vmean, vsd, sc, dv, cvold, cret)) continue;
 #pragma unroll
       for (int d = 0; d < DAP; ++d) dzh[d] = d == 0 ? dv : 0.f;
       s1 = dv * cst[4 * DAP];

@@ -107,7 +107,7 @@ __device__ __forceinline__ float mask_pop(float x, uint32_t &bits) {  // returns
 //   da = rstd (dx_hat - mean_f(dx_hat) - x_hat mean_f(dx_hat x_hat)) ;  dz = relu_mask ? da : 0 ; store ATL
 // evaluated as  da = fma(x_hat, -s2 rstd, fma(dx_hat, rstd, -s1 rstd))  on register pairs (v_pk_fma_f32).
 template <int H>
-__device__ __forceinline__ void ln_bwd_relu_bits(const float (&dx)[H / 2], const float (&xh)[H / 2],
+__device__ __forceinline__ void ln_bwd_relu_mbits(const float (&dx)[H / 2], const float (&xh)[H / 2],
                                                  const uint32_t (&bits_in)[(H / 2 + 31) / 32], float rstd, float (&out)[H / 2]) {
   // the ReLU-mask words come in registers: the callers load them BEFORE their GEMM (behind its sched_barriers a load at the
   // point of use is issued after the last MFMA and its whole latency is exposed once per slab)

@@ -22,6 +22,7 @@ namespace {
 constexpr int GH = 64;         // hidden width
 constexpr int GR = GH / 2;     // registers per lane per width-64 activation
 constexpr int GT = GH / 32;    // 32-row tiles per gate
+constexpr long GRU_TP_MAX_GROUPS = 512;  // <= this many 32-sequence groups (one per SIMD at most): latency variant of the forward
 
 // Gate nonlinearities on the hardware exp2 / rcp (1 ulp each): 4-5 VALU ops per value.  With libm's expf / tanhf and IEEE
 // division the 96 transcendental values of a step cost ~2500 VALU instructions -- more than the step's 144 MFMAs, and on
@@ -255,61 +256,229 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_gru_fwd(
 }
 
 // =============================================================================================
+// forward, LATENCY variant for few sequences unrolled over many steps (the runner's full-length log-prob passes: N
+// sequences x T steps, one dependent chain per 32 sequences; at N = 512 the plain kernel keeps 16 waves busy for T x 6 us).
+// Two waves share one slab and split the FEATURES: wave w owns hidden features [32 w, 32 w + 32) of all three gates, i.e.
+// the accumulator-layout registers R = 16 w .. 16 w + 15 of every lane, the W_hh row tiles {g * 2 + w} (72 of the 144
+// MFMAs of a step) and half of the gate nonlinearities.  Per step ONE exchange through LDS: the owner's half of
+// h~_{l+1} = h_l * mask_{l+1}, already split into its three bf16 terms (= the partner's missing B-operand k-steps), and the
+// half-row LayerNorm partials (mean_w, M2_w), merged with the exact pairwise formula
+//     mean = (mean_0 + mean_1) / 2,   M2 = M2_0 + M2_1 + 16 (mean_0 - mean_1)^2      (32 + 32 features).
+// The input half of the gates comes from k_gru_gates_x and is fetched one step ahead.  Inference only (nothing saved).
+// =============================================================================================
+__global__ __launch_bounds__(WG_THREADS, 1) void k_gru_fwd_tp(
+    const float *__restrict__ gi_r, const float *__restrict__ gi_z, const float *__restrict__ gi_n,
+    const float *__restrict__ mrow, const float *__restrict__ h0, const float *__restrict__ Whh,
+    const float *__restrict__ bhh, int L, long m_pad, float *__restrict__ y, float *__restrict__ rstd_y,
+    float *__restrict__ h_last) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int MTH = 3 * GT, NJH = GH / 16, TS = MTH * NJH * 64, HR = GR / 2;  // HR = 16 registers per lane and wave
+  u32x4 *Whimg = reinterpret_cast<u32x4 *>(lds);                     // [3 terms][6 tiles][4 k-steps][64 lanes] x 16 B
+  u32x4 *xch = Whimg + 3 * TS;                                        // [2 buffers][2 pairs][2 waves][6 slots][64 lanes]
+  float *xst = reinterpret_cast<float *>(xch + 2 * 2 * 2 * 6 * 64);   // [2 buffers][2 pairs][2 waves][64 lanes][2]
+  float *bhl = xst + 2 * 2 * 2 * 64 * 2;                              // b_hn [64]
+  stage_split_matrix<3 * GH, GH, false, WG_THREADS>(Whimg, Whh);
+  for (int e = threadIdx.x; e < GH; e += WG_THREADS) bhl[e] = bhh[2 * GH + e];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, pair = wave >> 1, w = wave & 1;
+  const int i = lane & 31, h = lane >> 5;
+  const long groups = m_pad / SLAB;
+  const u32x4 *wl = Whimg + lane;
+  for (long G0 = (long)blockIdx.x * 2; G0 < groups; G0 += (long)gridDim.x * 2) {  // uniform trip count (barriers inside)
+    const bool live = G0 + pair < groups;
+    const long G = live ? G0 + pair : groups - 1;
+    float hs[HR], hm[HR];
+    {  // own half of h_0: pieces q = 4 w .. 4 w + 3 of the row-major [m][64] state
+#pragma unroll
+      for (int q = 0; q < HR / 4; ++q) {
+        const int qq = 4 * w + q;
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(h0 + (G * SLAB + i) * GH + 32 * (qq >> 2) + 8 * (qq & 3) + 4 * h);
+        hs[4 * q + 0] = v[0];
+        hs[4 * q + 1] = v[1];
+        hs[4 * q + 2] = v[2];
+        hs[4 * q + 3] = v[3];
+      }
+    }
+    auto own_pieces = [&](const float *base, long slab, f32x4 (&dst)[HR / 4]) {
+      const f32x4 *pp = reinterpret_cast<const f32x4 *>(base + slab * (long)(GH * SLAB)) + lane;
+#pragma unroll
+      for (int q = 0; q < HR / 4; ++q) dst[q] = pp[(4 * w + q) * WAVE];
+    };
+    f32x4 gr[HR / 4], gz[HR / 4], gn[HR / 4];
+    own_pieces(gi_r, G, gr);
+    own_pieces(gi_z, G, gz);
+    own_pieces(gi_n, G, gn);
+    float mk = mrow[G * SLAB + i];
+    int buf = 0;
+    // B operands by LOCAL k-step: [0], [1] = this wave's own features (global k-steps 2w, 2w+1), [2], [3] = the partner's
+    // (2(w^1), 2(w^1)+1).  The k order of a dot product is free as long as the weight fragments follow it -- and a register
+    // array indexed by the run-time `w` would be lowered to select chains (measured: 3x the VALU instructions).
+    u32x4 x1[NJH], x2[NJH], x3[NJH];
+    float mean_own = 0.f, m2_own = 0.f;
+    // l = -1 is the hand-off of h~_0 = h_0 * mask_0; l = 0 .. L-1 are the steps (their tail hands h~_{l+1} over and
+    // finishes y_l)
+    for (int l = -1; l < L; ++l) {
+      if (l >= 0) {
+        const long slab = (long)l * groups + G;
+        f32x16 ar, az, ah;
+        float gnx[HR];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          ar[r] = gr[r >> 2][r & 3];
+          az[r] = gz[r >> 2][r & 3];
+          gnx[r] = gn[r >> 2][r & 3];
+          ah[r] = bhl[32 * w + (r & 3) + 8 * (r >> 2) + 4 * h];
+        }
+        if (l + 1 < L) {  // next step's input halves and mask: a whole step of latency to land
+          own_pieces(gi_r, slab + groups, gr);
+          own_pieces(gi_z, slab + groups, gz);
+          own_pieces(gi_n, slab + groups, gn);
+          mk = mrow[(slab + groups) * SLAB + i];
+        } else {
+          mk = 1.f;
+        }
+        // W_hh h~ for this wave's row tiles: 4 k-steps x 3 gates x 6 products, three independent accumulators in turn
+        u32x4 wb[2][3];
+        const int jg0 = 2 * w, jg1 = 2 * (w ^ 1);  // global k-step of local k-steps 0 / 2
+#pragma unroll
+        for (int term = 0; term < 3; ++term) wb[0][term] = wl[term * TS + ((0 * GT + w) * NJH + jg0) * 64];
+#pragma unroll
+        for (int sidx = 0; sidx < 3 * NJH; ++sidx) {
+          const int j = sidx / 3, g = sidx % 3, cur = sidx & 1, nxt = cur ^ 1;
+          if (sidx + 1 < 3 * NJH) {
+            const int j1 = (sidx + 1) / 3, g1 = (sidx + 1) % 3;
+            const int jglob = (j1 < 2 ? jg0 : jg1) + (j1 & 1);
+#pragma unroll
+            for (int term = 0; term < 3; ++term) wb[nxt][term] = wl[term * TS + ((g1 * GT + w) * NJH + jglob) * 64];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          f32x16 &a = g == 0 ? ar : (g == 1 ? az : ah);
+          a = mfma_bf16(wb[cur][2], x1[j], a);
+          a = mfma_bf16(wb[cur][0], x3[j], a);
+          a = mfma_bf16(wb[cur][1], x2[j], a);
+          a = mfma_bf16(wb[cur][1], x1[j], a);
+          a = mfma_bf16(wb[cur][0], x2[j], a);
+          a = mfma_bf16(wb[cur][0], x1[j], a);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        float sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < HR; ++r) {
+          const float rg = sigmoidf_(ar[r]);
+          const float zg = sigmoidf_(az[r]);
+          const float ng = tanhf_(gnx[r] + rg * ah[r]);
+          hs[r] = (1.f - zg) * ng + zg * hm[r];
+          sum += hs[r];
+        }
+        sum += wave_xor32(sum);
+        mean_own = sum * (1.0f / 32.f);
+        float vs = 0.f;
+#pragma unroll
+        for (int r = 0; r < HR; ++r) {
+          const float d = hs[r] - mean_own;
+          vs += d * d;
+        }
+        m2_own = vs + wave_xor32(vs);
+      }
+      // ---- hand-off: h~ (own half) as split operands + LayerNorm partials
+#pragma unroll
+      for (int r = 0; r < HR; ++r) hm[r] = hs[r] * mk;
+      u32x4 o1[HR / 8], o2[HR / 8], o3[HR / 8];
+      split_acts<HR>(hm, o1, o2, o3);
+      u32x4 *xo = xch + (((buf * 2 + pair) * 2 + w) * 6) * 64 + lane;
+      const u32x4 *xp = xch + (((buf * 2 + pair) * 2 + (w ^ 1)) * 6) * 64 + lane;
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        xo[(0 * 2 + jj) * 64] = o1[jj];
+        xo[(1 * 2 + jj) * 64] = o2[jj];
+        xo[(2 * 2 + jj) * 64] = o3[jj];
+      }
+      float *so = xst + (((buf * 2 + pair) * 2 + w) * 64 + lane) * 2;
+      const float *sp = xst + (((buf * 2 + pair) * 2 + (w ^ 1)) * 64 + lane) * 2;
+      so[0] = mean_own;
+      so[1] = m2_own;
+      __syncthreads();
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        x1[jj] = o1[jj];
+        x2[jj] = o2[jj];
+        x3[jj] = o3[jj];
+        x1[2 + jj] = xp[(0 * 2 + jj) * 64];
+        x2[2 + jj] = xp[(1 * 2 + jj) * 64];
+        x3[2 + jj] = xp[(2 * 2 + jj) * 64];
+      }
+      if (l >= 0) {  // y_l = rnn.norm(h_l), own half
+        const float mean_p = sp[0], m2_p = sp[1];
+        const float dm = mean_own - mean_p;
+        const float mean = 0.5f * (mean_own + mean_p);
+        const float m2 = m2_own + m2_p + 16.f * dm * dm;
+        const float rstd = 1.0f / sqrtf(m2 * (1.0f / GH) + 1e-5f);
+        const long slab = (long)l * groups + G;
+        if (live) {
+          f32x4 *yp = reinterpret_cast<f32x4 *>(y + slab * (long)(GH * SLAB)) + lane;
+#pragma unroll
+          for (int q = 0; q < HR / 4; ++q)
+            yp[(4 * w + q) * WAVE] = f32x4{(hs[4 * q] - mean) * rstd, (hs[4 * q + 1] - mean) * rstd, (hs[4 * q + 2] - mean) * rstd,
+                                           (hs[4 * q + 3] - mean) * rstd};
+          if (w == 0 && lane < 32) rstd_y[slab * SLAB + lane] = rstd;
+        }
+      }
+      buf ^= 1;
+    }
+    if (h_last && live) {
+#pragma unroll
+      for (int q = 0; q < HR / 4; ++q) {
+        const int qq = 4 * w + q;
+        *reinterpret_cast<f32x4 *>(h_last + (G * SLAB + i) * GH + 32 * (qq >> 2) + 8 * (qq & 3) + 4 * h) =
+            f32x4{hs[4 * q], hs[4 * q + 1], hs[4 * q + 2], hs[4 * q + 3]};
+      }
+    }
+  }
+}
+
+// =============================================================================================
 // backward (BPTT over the chunk, reverse in l).  Input: dh_out = d(loss)/d(h_l) through the output path (the head
 // kernels already applied the rnn.norm backward); output: the four gate-gradient tensors (for the weight-gradient
 // kernel) and dz of the last MLP layer (LayerNorm/ReLU backward of d(loss)/d(x_hat_mlp) applied here).
 //   A operands are W^T: lane i -> input feature, step -> gate output f(R,h); row-major W in LDS reads conflict-free.
 // =============================================================================================
-template <int NG>
-__device__ __forceinline__ void gemm_T(f32x16 (&acc)[GT], const float *wl_lane, const float (&b0)[GR],
-                                       const float (&b1)[GR], const float (&b2)[GR]) {
-#pragma unroll
-  for (int g = 0; g < NG; ++g) {
-#pragma unroll
-    for (int R = 0; R < GR; ++R) {
-      const float bv = g == 0 ? b0[R] : (g == 1 ? b1[R] : b2[R]);
-#pragma unroll
-      for (int t = 0; t < GT; ++t) {
-        const float a = wl_lane[(g * GH + feat_base(R)) * GH + 32 * t];
-        acc[t] = MFMA(a, bv, acc[t]);
-      }
-      if ((R & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-}
 
+// The recurrence carries only d h~ = W_hh^T [dr, dz, dhn] (144 bf16 MFMAs per step on the split images of W_hh^T); the input
+// side, d x_hat_mlp = W_ih'^T [dr, dz, dn] followed by the LayerNorm/ReLU backward of the last MLP layer, has no recurrence
+// and runs afterwards over all L x groups slabs in parallel (k_gru_dx) from the gate gradients this kernel stores anyway.
+// (Before: both products on the fp32 MFMA with one LDS read per MFMA inside the chain, 17 us per step.)
 __global__ __launch_bounds__(WG_THREADS, 1) void k_gru_bwd(
-    const float *__restrict__ dhout, const float *__restrict__ mrow, const float *__restrict__ Wih,
-    const float *__restrict__ Whh, const float *__restrict__ hpm_s, const float *__restrict__ r_s,
-    const float *__restrict__ z_s, const float *__restrict__ n_s, const float *__restrict__ hn_s, int L, long m_pad,
-    const float *__restrict__ xmlp, const uint32_t *__restrict__ mask_mlp, const float *__restrict__ rstd_mlp,
-    float *__restrict__ dr_s, float *__restrict__ dz_s, float *__restrict__ dn_s, float *__restrict__ dhn_s,
-    float *__restrict__ dz_mlp) {
+    const float *__restrict__ dhout, const float *__restrict__ mrow, const float *__restrict__ Whh,
+    const float *__restrict__ hpm_s, const float *__restrict__ r_s, const float *__restrict__ z_s,
+    const float *__restrict__ n_s, const float *__restrict__ hn_s, int L, long m_pad, float *__restrict__ dr_s,
+    float *__restrict__ dz_s, float *__restrict__ dn_s, float *__restrict__ dhn_s) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float *Wil = lds;                 // [192][64] row-major
-  float *Whl = Wil + 3 * GH * GH;   // [192][64]
-  stage_matrix<3 * GH, GH, GH, WG_THREADS>(Wil, Wih);
-  stage_matrix<3 * GH, GH, GH, WG_THREADS>(Whl, Whh);
+  constexpr int MT = GT, NJ = 3 * GH / 16;  // out = 64 hidden features (2 tiles), k = 192 gate outputs (12 k-steps)
+  u32x4 *img = reinterpret_cast<u32x4 *>(lds);
+  stage_split_matrix<3 * GH, GH, true, WG_THREADS>(img, Whh);
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int i = lane & 31, h = lane >> 5;
+  const int i = lane & 31;
   const long groups = m_pad / SLAB;
-  const float *wi_lane = Wil + 4 * h * GH + i;
-  const float *wh_lane = Whl + 4 * h * GH + i;
+  const u32x4 *wl = img + lane;
   for (long G = (long)blockIdx.x * WAVES_PER_WG + wave; G < groups; G += (long)gridDim.x * WAVES_PER_WG) {
     float dcarry[GR];
 #pragma unroll
     for (int R = 0; R < GR; ++R) dcarry[R] = 0.f;
-    for (int l = L - 1; l >= 0; --l) {
-      const long slab = (long)l * groups + G;
-      float dh[GR], rg[GR], zg[GR], ng[GR], hn[GR], hp[GR];
+    float dh[GR], rg[GR], zg[GR], ng[GR], hn[GR], hp[GR];
+    {
+      const long slab = (long)(L - 1) * groups + G;
       load_act(dhout, slab, lane, dh);
       load_act(r_s, slab, lane, rg);
       load_act(z_s, slab, lane, zg);
       load_act(n_s, slab, lane, ng);
       load_act(hn_s, slab, lane, hn);
       load_act(hpm_s, slab, lane, hp);
-      float drp[GR], dzp[GR], dnp[GR], dhnv[GR], dhp[GR];
+    }
+    float mk = mrow[((long)(L - 1) * groups + G) * SLAB + i];
+    for (int l = L - 1; l >= 0; --l) {
+      const long slab = (long)l * groups + G;
+      float gates[3 * GR], dnp[GR], dhp[GR];  // gates = [dr | dz | dhn]: the 192-wide B operand of W_hh^T
 #pragma unroll
       for (int R = 0; R < GR; ++R) {
         const float d = dh[R] + dcarry[R];
@@ -317,41 +486,98 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_gru_bwd(
         const float dn_ = d * (1.f - zg[R]);
         dhp[R] = d * zg[R];
         dnp[R] = dn_ * (1.f - ng[R] * ng[R]);
-        dhnv[R] = dnp[R] * rg[R];
-        drp[R] = (dnp[R] * hn[R]) * rg[R] * (1.f - rg[R]);
-        dzp[R] = dz_ * zg[R] * (1.f - zg[R]);
+        gates[2 * GR + R] = dnp[R] * rg[R];
+        gates[R] = (dnp[R] * hn[R]) * rg[R] * (1.f - rg[R]);
+        gates[GR + R] = dz_ * zg[R] * (1.f - zg[R]);
       }
-      store_act(dr_s, slab, lane, drp);
-      store_act(dz_s, slab, lane, dzp);
-      store_act(dn_s, slab, lane, dnp);
-      store_act(dhn_s, slab, lane, dhnv);
+      const float mk_cur = mk;
+      {
+        float t[GR];
+#pragma unroll
+        for (int R = 0; R < GR; ++R) t[R] = gates[R];
+        store_act(dr_s, slab, lane, t);
+#pragma unroll
+        for (int R = 0; R < GR; ++R) t[R] = gates[GR + R];
+        store_act(dz_s, slab, lane, t);
+        store_act(dn_s, slab, lane, dnp);
+#pragma unroll
+        for (int R = 0; R < GR; ++R) t[R] = gates[2 * GR + R];
+        store_act(dhn_s, slab, lane, t);
+      }
       // d h~ += W_hh^T [dr, dz, dhn] ;  carry = d h~ * mask_l
-      {
-        f32x16 acc[GT];
-#pragma unroll
-        for (int t = 0; t < GT; ++t)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-        gemm_T<3>(acc, wh_lane, drp, dzp, dhnv);
-        const float mk = mrow[slab * SLAB + i];
-#pragma unroll
-        for (int R = 0; R < GR; ++R) dcarry[R] = (dhp[R] + acc[R >> 4][R & 15]) * mk;
+      u32x4 g1[NJ], g2[NJ], g3[NJ];
+      split_acts<3 * GR>(gates, g1, g2, g3);
+      __builtin_amdgcn_sched_barrier(0);
+      if (l > 0) {  // the previous step's operands (the gate registers are dead now): the GEMM's time to land
+        const long sp = slab - groups;
+        load_act(dhout, sp, lane, dh);
+        load_act(r_s, sp, lane, rg);
+        load_act(z_s, sp, lane, zg);
+        load_act(n_s, sp, lane, ng);
+        load_act(hn_s, sp, lane, hn);
+        load_act(hpm_s, sp, lane, hp);
+        mk = mrow[sp * SLAB + i];
       }
-      // d x_hat_mlp = W_ih'^T [dr, dz, dn]  ->  LayerNorm/ReLU backward of the last MLP layer -> dz_mlp
-      {
-        f32x16 acc[GT];
+      f32x16 acc[MT];
 #pragma unroll
-        for (int t = 0; t < GT; ++t)
+      for (int t = 0; t < MT; ++t)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-        gemm_T<3>(acc, wi_lane, drp, dzp, dnp);
-        float dx[GR], xh[GR];
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+      split_gemm<MT, NJ>(wl, g1, g2, g3, acc, [](int) {});
 #pragma unroll
-        for (int R = 0; R < GR; ++R) dx[R] = acc[R >> 4][R & 15];
-        load_act(xmlp, slab, lane, xh);
-        ln_bwd_relu_store<GH>(dx, xh, mask_mlp, rstd_mlp[slab * SLAB + i], lane, slab, dz_mlp);
-      }
+      for (int R = 0; R < GR; ++R) dcarry[R] = (dhp[R] + acc[R >> 4][R & 15]) * mk_cur;
     }
+  }
+}
+
+// d x_hat_mlp = W_ih'^T [dr, dz, dn]  ->  LayerNorm/ReLU backward of the last MLP layer -> dz_mlp, every slab independent
+__global__ __launch_bounds__(WG_THREADS, 2) void k_gru_dx(const float *__restrict__ Wih, const float *__restrict__ dr_s,
+                                                          const float *__restrict__ dz_s, const float *__restrict__ dn_s,
+                                                          const float *__restrict__ xmlp, const uint32_t *__restrict__ mask_mlp,
+                                                          const float *__restrict__ rstd_mlp, float *__restrict__ dz_mlp,
+                                                          long n_slabs) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int MT = GT, NJ = 3 * GH / 16;
+  u32x4 *img = reinterpret_cast<u32x4 *>(lds);
+  stage_split_matrix<3 * GH, GH, true, WG_THREADS>(img, Wih);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 31;
+  const u32x4 *wl = img + lane;
+  for (long slab = (long)blockIdx.x * WAVES_PER_WG + wave; slab < n_slabs; slab += (long)gridDim.x * WAVES_PER_WG) {
+    float gates[3 * GR];
+    {
+      float t[GR];
+      load_act(dr_s, slab, lane, t);
+#pragma unroll
+      for (int R = 0; R < GR; ++R) gates[R] = t[R];
+      load_act(dz_s, slab, lane, t);
+#pragma unroll
+      for (int R = 0; R < GR; ++R) gates[GR + R] = t[R];
+      load_act(dn_s, slab, lane, t);
+#pragma unroll
+      for (int R = 0; R < GR; ++R) gates[2 * GR + R] = t[R];
+    }
+    float xh[GR];
+    load_act(xmlp, slab, lane, xh);
+    const float rstd = rstd_mlp[slab * SLAB + i];
+    constexpr int NWM = (GH / 2 + 31) / 32;
+    uint32_t mb[NWM];
+#pragma unroll
+    for (int w = 0; w < NWM; ++w) mb[w] = mask_mlp[(slab * NWM + w) * WAVE + lane];
+    u32x4 g1[NJ], g2[NJ], g3[NJ];
+    split_acts<3 * GR>(gates, g1, g2, g3);
+    f32x16 acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    split_gemm<MT, NJ>(wl, g1, g2, g3, acc, [](int) {});
+    float dx[GR], out[GR];
+#pragma unroll
+    for (int R = 0; R < GR; ++R) dx[R] = acc[R >> 4][R & 15];
+    ln_bwd_relu_mbits<GH>(dx, xh, mb, rstd, out);
+    store_act(dz_mlp, slab, lane, out);
   }
 }
 }  // namespace
@@ -536,6 +762,14 @@ extern "C" int harl_gru_fwd(const float *xin, const float *mask_rows, const floa
     allow_big_lds(k_gru_gates_x, shm_x);
     hipLaunchKernelGGL(k_gru_gates_x, dim3(persistent_grid(n_slabs, 1)), dim3(WG_THREADS), shm_x, s, xin, Wih, bih, bhh,
                        n_slabs, gr, gz, gn);
+    if (!save && groups <= GRU_TP_MAX_GROUPS) {  // few dependent chains: two waves per slab (k_gru_fwd_tp)
+      const size_t shm_tp = split_image_bytes(3 * GH, GH) + (size_t)2 * 2 * 2 * 6 * 64 * 16 + ((size_t)2 * 2 * 2 * 64 * 2 + GH) * sizeof(float);
+      allow_big_lds(k_gru_fwd_tp, shm_tp);
+      const long wg2 = (groups + 1) / 2;
+      hipLaunchKernelGGL(k_gru_fwd_tp, dim3((unsigned)(wg2 < 256 ? wg2 : 256)), dim3(WG_THREADS), shm_tp, s, gr, gz, gn, mask_rows,
+                         h0, Whh, bhh, L, m_pad, y, rstd_y, h_last);
+      return check_launch("harl_gru_fwd");
+    }
     const size_t shm = split_image_bytes(3 * GH, GH) + ((size_t)2 * 3 * GH) * sizeof(float);
     allow_big_lds(k_gru_fwd<true>, shm);
     hipLaunchKernelGGL(k_gru_fwd<true>, dim3(grid), dim3(WG_THREADS), shm, s, xin, gr, gz, gn, mask_rows, h0, Wih, bih,
@@ -555,12 +789,16 @@ extern "C" int harl_gru_bwd(const float *dhout, const float *mask_rows, const fl
                             float *dr, float *dz, float *dn, float *dhn, float *dz_mlp, void *stream) {
   if (L <= 0 || m_pad <= 0) return 0;
   if (H != GH) { set_error("harl_gru_bwd: hidden width must be 64"); return -2; }
-  const size_t shm = ((size_t)2 * 3 * GH * GH) * sizeof(float);
+  const size_t shm = split_image_bytes(3 * GH, GH);
   const long groups = m_pad / SLAB;
   long wgs = (groups + WAVES_PER_WG - 1) / WAVES_PER_WG;
   const int grid = (int)(wgs < 256 ? wgs : 256);
   allow_big_lds(k_gru_bwd, shm);
-  hipLaunchKernelGGL(k_gru_bwd, dim3(grid), dim3(WG_THREADS), shm, (hipStream_t)stream, dhout, mask_rows, Wih, Whh, hpm, r,
-                     z, n, hn, L, m_pad, xmlp, mask_mlp, rstd_mlp, dr, dz, dn, dhn, dz_mlp);
+  hipLaunchKernelGGL(k_gru_bwd, dim3(grid), dim3(WG_THREADS), shm, (hipStream_t)stream, dhout, mask_rows, Whh, hpm, r, z, n, hn,
+                     L, m_pad, dr, dz, dn, dhn);
+  const long n_slabs = (long)L * groups;
+  allow_big_lds(k_gru_dx, shm);
+  hipLaunchKernelGGL(k_gru_dx, dim3(persistent_grid(n_slabs, 2)), dim3(WG_THREADS), shm, (hipStream_t)stream, Wih, dr, dz, dn,
+                     xmlp, mask_mlp, rstd_mlp, dz_mlp, n_slabs);
   return check_launch("harl_gru_bwd");
 }

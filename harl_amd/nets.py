@@ -313,6 +313,7 @@ class _FlatNet(nn.Module):
     def forward_trunk(self, X: torch.Tensor, idx: Optional[torch.Tensor], M: int, for_backward: bool = True,
                       seq: Optional[dict] = None) -> None:
         assert X.dim() == 2 and X.shape[1] == self.in_dim and X.is_contiguous()
+        rnn_save = for_backward  # inference passes save no GRU internals (and take the latency variant of the kernel)
         if self.recurrent:
             assert seq is not None and seq["L"] * seq["m_pad"] == M, "recurrent nets need the sequence layout"
             for_backward = True  # the fused 2-layer path may skip x_hat_1; keep it simple for recurrent nets
@@ -354,7 +355,7 @@ class _FlatNet(nn.Module):
             call("harl_mlp_fwd_hidden", ptr(self.xh[l - 1]), M, hs[l - 1], hs[l],
                  ptr(Wp), ptr(bp), ptr(self.xh[l]), ptr(self.rmask[l]), ptr(self.rstd[l]), s, tag="fwd_hidden")
         if self.recurrent:
-            self.forward_rnn(seq, save=True)
+            self.forward_rnn(seq, save=rnn_save)
 
     # ---- fused optimiser-step path (csrc/update.hip): two equal hidden layers, inputs <= 64 wide, identity row order
     def fused_update_ok(self, idx: Optional[torch.Tensor], seq: Optional[dict] = None, train: bool = True) -> bool:

@@ -164,9 +164,36 @@ class OnPolicyHARunner:
             cinfo = self.critic.train(self.critic_buffer, self.value_normalizer, _defer=True)
         ev.synchronize()
         counts = self._counts_host.tolist()
+        # Pre-update log-probs that cannot come out of the first epoch's forward (recurrent policies: full-length unroll from
+        # rnn_states[0]; several minibatches) depend only on the agent's OWN pre-update weights, not on the agents before it
+        # (on_policy_ha_runner.py:66-83) -- so all of them are enqueued up front on a side stream, where the long, narrow
+        # recurrences (N/32 dependent chains of T steps) run next to the update kernels of the agents in front instead of in
+        # series with them; agent k's update waits for event k.
+        old_all, old_ev = {}, {}
+        side_agents = [a for a in agent_order
+                       if not (fast[a] and self.actor[a].fuses_old_logp() and counts[a] > 0.0) and os.environ.get("HARL_SIDE_STREAM", "1") != "0"]
+        if side_agents:
+            if getattr(self, "_side_stream", None) is None:
+                self._side_stream = torch.cuda.Stream(device=dev)
+            main = torch.cuda.current_stream(dev)
+            self._side_stream.wait_stream(main)
+            for a in side_agents:
+                act_a, buf_a = self.actor[a], self.actor_buffer[a]
+                old_all[a] = torch.empty(B, act_a.actor.act_w, dtype=torch.float32, device=dev)
+            with torch.cuda.stream(self._side_stream):
+                for a in side_agents:
+                    act_a, buf_a = self.actor[a], self.actor_buffer[a]
+                    act_a.actor.fold()
+                    kw_a = dict(rnn_states=buf_a.rnn_states[0], masks=buf_a.flat("masks")) if act_a.actor.recurrent else {}
+                    act_a._logp_pass(buf_a.flat("obs"), buf_a.flat("actions"),
+                                     None if buf_a.available_actions is None else buf_a.flat("available_actions"), B, old_all[a], **kw_a)
+                    old_ev[a] = torch.cuda.Event()
+                    old_ev[a].record(self._side_stream)
         pending = []
         for agent_id in agent_order:
             buf, actor = self.actor_buffer[agent_id], self.actor[agent_id]
+            if agent_id in old_ev:  # this agent's networks / workspaces are in use on the side stream until then
+                torch.cuda.current_stream(dev).wait_event(old_ev[agent_id])
             buf.update_factor(factor)
             obs, actions = buf.flat("obs"), buf.flat("actions")
             avail = None if buf.available_actions is None else buf.flat("available_actions")
@@ -181,6 +208,8 @@ class OnPolicyHARunner:
             fused_old = fast[agent_id] and actor.fuses_old_logp() and counts[agent_id] > 0.0
             if fused_old:
                 kw["_old_logp_out"] = self._logp_old
+            elif agent_id in old_all:
+                self._logp_old = old_all.pop(agent_id)
             else:
                 actor._logp_pass(obs, actions, avail, B, self._logp_old, **rnn_kw)
             info = actor.train(buf, adv_a, self.state_type, **kw)               # :86-93

@@ -27,6 +27,22 @@ __device__ __forceinline__ void vector_block(float (&v)[16], float c) {
     for (int k = 0; k < 16; ++k) v[k] = __builtin_fmaf(v[k], c, 0.5f);
 }
 
+// I1: ONE wave interleaves the two blocks instruction by instruction: after every MFMA (dependent chain of 6 on one
+// accumulator, as in split_gemm) 8 independent v_fma_f32 -- does VALU work issue in the shadow of the wave's OWN MFMAs?
+__device__ __forceinline__ void interleaved_block(f32x16 (&acc)[4], const u32x4 &a, const u32x4 &b, float (&v)[16], float c) {
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      acc[s & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc[s & 3], 0, 0, 0);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[(8 * (k & 1) + q) & 15] = __builtin_fmaf(v[(8 * (k & 1) + q) & 15], c, 0.5f);
+      __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x2, 8, 0);
+    }
+  }
+}
+
 template <int MODE>
 __global__ __launch_bounds__(512, 1) void k(float *out, int iters, float c) {
   const int wave = threadIdx.x >> 6;
@@ -41,6 +57,7 @@ __global__ __launch_bounds__(512, 1) void k(float *out, int iters, float c) {
     if (MODE == 1) vector_block(v, c);
     if (MODE == 2) { matrix_block(acc, a, b); __builtin_amdgcn_sched_barrier(0); vector_block(v, c); __builtin_amdgcn_sched_barrier(0); }
     if (MODE == 3) { if (wave < 4) matrix_block(acc, a, b); else vector_block(v, c); }
+    if (MODE == 4) interleaved_block(acc, a, b, v, c);
   }
   float s = 0.f;
   for (int t = 0; t < 4; ++t)
@@ -70,7 +87,8 @@ int main() {
   hipMalloc(&out, 256 * 512 * 4);
   const int IT = 4000;
   const float m1 = run<0>(256, IT, out), v1 = run<1>(256, IT, out), a1 = run<2>(256, IT, out), a2 = run<2>(512, IT / 2, out),
-              s2 = run<3>(512, IT, out), m2 = run<0>(512, IT / 2, out), v2 = run<1>(512, IT / 2, out);
+              s2 = run<3>(512, IT, out), m2 = run<0>(512, IT / 2, out), v2 = run<1>(512, IT / 2, out), i1 = run<4>(256, IT, out),
+              i2 = run<4>(512, IT / 2, out);
   printf("M1 matrix only, 1 wave/SIMD            %.3f ms  (%.1f cycles/MFMA at 2.4 GHz)\n", m1, m1 * 1e-3 * 2.4e9 / (IT * 48.0));
   printf("V1 vector only, 1 wave/SIMD            %.3f ms  (%.2f cycles/VALU at 2.4 GHz)\n", v1, v1 * 1e-3 * 2.4e9 / (IT * 384.0));
   printf("M2 matrix only, 2 waves/SIMD           %.3f ms\n", m2);
@@ -78,5 +96,7 @@ int main() {
   printf("A1 matrix then vector, 1 wave/SIMD     %.3f ms  (M1 + V1 = %.3f)\n", a1, m1 + v1);
   printf("A2 same work on 2 waves/SIMD           %.3f ms\n", a2);
   printf("S2 matrix waves + vector waves         %.3f ms  (max(M1, V1) = %.3f)\n", s2, m1 > v1 ? m1 : v1);
+  printf("I1 MFMA + 8 VALU interleaved, 1 wave/SIMD %.3f ms  (same work as A1: 48 MFMA + 384 VALU per iteration)\n", i1);
+  printf("I2 same on 2 waves/SIMD                 %.3f ms\n", i2);
   return 0;
 }

@@ -23,16 +23,16 @@ GROUPS = [
     (r"void k_fwd_fused2<", ("fwd_fused2",)),
     (r"void k_fwd_hidden<", ("fwd_hidden",)),
     (r"void k_bwd_dx<\d+, \d+, 0>", ("bwd_dx",)),
-    (r"void k_bwd_dx<\d+, \d+, 1>", ("bwd_dx_dw1",)),
+    (r"void k_bwd_dx<\d+, \d+, [1-9]>", ("bwd_dx_dw1",)),
     (r"void k_dw(_split<|<0)", ("dw_hidden", "dw_gru", "dw_input")),
     (r"void k_dw<1", ("dw_head",)),
     (r"void k_fwd_wide<", ("fwd_wide", "tangent_wide")),
     (r"(void )?k_x0n_", ("x0n_wide",)),
     (r"void k_actor_head<.*(true|false), true, (true|false)>", ("actor_head_loss",)),
     (r"void k_actor_head<.*(true|false), false, (true|false)>", ("actor_head_logp",)),
-    (r"void k_critic_head<", ("critic_head_loss",)),
-    (r"void k_gru_fwd", ("gru_fwd",)),
-    (r"void k_gru_bwd", ("gru_bwd",)),
+    (r"void k_critic_head<\d+, true", ("critic_head_loss",)),
+    (r"(void )?k_gru_fwd", ("gru_fwd",)),
+    (r"(void )?k_gru_(bwd|dx)", ("gru_bwd",)),
     (r"(void )?k_gae", ("gae_returns",)),
     (r"void k_upd_fwd<", ("update_fwd", "update_logp", "update_fwd_critic", "update_values")),
     (r"void k_upd_d", ("update_bwd",)),

@@ -18,6 +18,7 @@
 // Weights live in LDS for the lifetime of a persistent workgroup (three bf16 images, 96 KiB for 128 x 128).
 #include "common.h"
 #include "split_mfma.h"
+#include "mfma_transpose.h"
 #include "../../include/harl_hip.h"
 
 using namespace harl;
@@ -652,9 +653,10 @@ __global__ __launch_bounds__(64 * FUSED_WAVES, 2) void k_fwd_fused2(
 // =============================================================================================
 // KT > 0: FIRST-layer variant.  dz_prev (= dz_1) is only ever consumed by the first layer's weight gradient
 // dW_1' = dz_1^T x0n, so that GEMM is done right here -- dz_1 (registers, lane = sample) and the normalised inputs x0n
-// (ATL(32*KT), last pad column = ones -> db_1' for free) go through a wave-private LDS transpose and 64*KT extra MFMAs per
-// slab; dz_1 is never written to HBM and the separate harl_mlp_dw_partials pass over it disappears.  One workgroup per
-// CU (LDS: weights + staging), per-workgroup partials in the layout of harl_mlp_dw_partials.
+// (ATL(32*KT)) are transposed on the matrix pipe (mfma_transpose.h) and multiplied with 78 (KT = 1) / 132 (KT = 2) bf16
+// MFMAs per slab; dz_1 is never written to HBM and the separate harl_mlp_dw_partials pass over it disappears.  One
+// workgroup per CU, per-workgroup partials in the layout of harl_mlp_dw_partials.  (Round 1 staged both operands through a
+// wave-private LDS transpose and used the fp32 MFMA with one LDS read per MFMA: the same speed, measured.)
 constexpr int bwd_pass_width(int kt) { return kt == 1 ? 64 : 32; }  // dz_1 features staged per pass of the fused dW_1
 constexpr size_t bwd_stage_floats(int kt) { return (size_t)SLAB * (bwd_pass_width(kt) + 4) + (size_t)SLAB * (32 * kt + 4); }
 
@@ -679,6 +681,10 @@ __global__ __launch_bounds__(WG_THREADS, (KT > 0 || split_one_wg(HI, HO)) ? 1 : 
   float raw[NRO];
   atl_load<HO>(dz, slab0 < n_slabs ? slab0 : 0, lane, raw);
   f32x16 acc1[KT > 0 ? HI / 32 : 1][KT > 0 ? KT : 1];  // fused first-layer weight gradient, persistent over the slabs
+  float dbs[KT > 0 ? HI / 32 : 1];                     // ... and its bias gradient (per-lane sums over the lane's samples)
+  const Ident ident = make_ident(lane);
+#pragma unroll
+  for (int a = 0; a < (KT > 0 ? HI / 32 : 1); ++a) dbs[a] = 0.f;
   if constexpr (KT > 0) {
 #pragma unroll
     for (int mt = 0; mt < HI / 32; ++mt)
@@ -722,65 +728,36 @@ __global__ __launch_bounds__(WG_THREADS, (KT > 0 || split_one_wg(HI, HO)) ? 1 : 
       float out[HI / 2];
       ln_bwd_relu_mbits<HI>(dx, xh, mbits, rstd, out);
       if (dz_prev) atl_store<HI>(dz_prev, slab, lane, out);
-      float *tx = stg + wave * STAGE_FLOATS, *tb = tx + SLAB * HX;
+      // dW_1'[f][k] += sum_s dz_1[s][f] x0n[s][k] with both operands transposed on the matrix pipe (mfma_transpose.h): no LDS
+      // round trip, bf16 MFMAs instead of the fp32 pipe with an LDS read per MFMA (same speed, measured; no staging area)
+      float xr0[KPF / 2];
 #pragma unroll
-      for (int q = 0; q < KPF / 8; ++q)  // normalised-input tile -> tb[sample][column]
-        *reinterpret_cast<f32x4 *>(tb + i * LDB + 32 * (q >> 2) + 8 * (q & 3) + 4 * h) = x0r[q];
+      for (int q = 0; q < KPF / 8; ++q) {
+        xr0[4 * q + 0] = x0r[q][0];
+        xr0[4 * q + 1] = x0r[q][1];
+        xr0[4 * q + 2] = x0r[q][2];
+        xr0[4 * q + 3] = x0r[q][3];
+      }
+      u32x4 a1[KPF / 16], a2[KPF / 16], a3[KPF / 16];
+      split_acts<KPF / 2>(xr0, a1, a2, a3);
+      u32x4 Bt[KT][3][2];
 #pragma unroll
-      for (int pass = 0; pass < HI / PW; ++pass) {
+      for (int n = 0; n < KT; ++n)
+        transpose_block<false>(a1[2 * n], a1[2 * n + 1], a2[2 * n], a2[2 * n + 1], a3[2 * n], a3[2 * n + 1], ident, Bt[n]);
 #pragma unroll
-        for (int q = 0; q < PW / 8; ++q) {
-          const int R0 = (PW / 2) * pass + 4 * q;
-          *reinterpret_cast<f32x4 *>(tx + i * HX + 32 * (q >> 2) + 8 * (q & 3) + 4 * h) =
-              f32x4{out[R0], out[R0 + 1], out[R0 + 2], out[R0 + 3]};
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private hand-off between lanes
-        __builtin_amdgcn_wave_barrier();
+      for (int a = 0; a < HI / 32; ++a) {
+        u32x4 At[3][2];
+        dbs[a] += split_transpose_block<true>(&out[16 * a], ident, At);
 #pragma unroll
-        for (int t = 0; t < SLAB / 2; ++t) {
-          float bv[KT];
-#pragma unroll
-          for (int n = 0; n < KT; ++n) bv[n] = tb[(2 * t + h) * LDB + 32 * n + i];
-#pragma unroll
-          for (int m = 0; m < MP; ++m) {
-            const float a = tx[(2 * t + h) * HX + 32 * m + i];
-#pragma unroll
-            for (int n = 0; n < KT; ++n) acc1[MP * pass + m][n] = MFMA(a, bv[n], acc1[MP * pass + m][n]);
-          }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_wave_barrier();  // all lanes done reading before the next pass overwrites tx / tb
+        for (int n = 0; n < KT; ++n) dw_tile(acc1[a][n], At, Bt[n]);
       }
     }
   }
   if constexpr (KT > 0) {
-    // combine the four waves' accumulators (one wave at a time, fixed order) and write dWp[HI][KPF] | dbp[HI]
-    float *buf = stg;  // staging no longer in use
-    __syncthreads();
-    for (int w = 0; w < WAVES_PER_WG; ++w) {
-      if (wave == w) {
-#pragma unroll
-        for (int mt = 0; mt < HI / 32; ++mt)
-#pragma unroll
-          for (int n = 0; n < KT; ++n)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const int o = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * h;
-              float *p = buf + o * KPF + 32 * n + i;
-              *p = (w == 0 ? 0.f : *p) + acc1[mt][n][r];
-            }
-      }
-      __syncthreads();
-    }
-    float *outp = dw_part + (long)blockIdx.x * ((long)HI * KPF + HI);
-    for (int e = threadIdx.x; e < HI * KPF; e += WG_THREADS) outp[e] = buf[e];
-    for (int o = threadIdx.x; o < HI; o += WG_THREADS) outp[HI * KPF + o] = buf[o * KPF + KPF - 1];  // ones column
-    // the partial arena has n_part_rows rows per layer (shared with the other gradient kernels); this kernel runs one
-    // workgroup per CU (a second round of workgroups would pay the weight-image prologue twice), so it clears the rest
-    for (int row = blockIdx.x + gridDim.x; row < n_part_rows; row += gridDim.x) {
-      float *z = dw_part + (long)row * ((long)HI * KPF + HI);
-      for (int e = threadIdx.x; e < HI * KPF + HI; e += WG_THREADS) z[e] = 0.f;
-    }
+    // the four waves' accumulators combined in fixed order -> ONE partial row dWp[HI][KPF] | dbp[HI]; the partial arena has
+    // n_part_rows rows per layer (shared with the other gradient kernels) and this kernel runs one workgroup per CU, so it
+    // clears the rest (mfma_transpose.h)
+    finish_partials<HI / 32, KT>(acc1, dbs, reinterpret_cast<float *>(img), dw_part, n_part_rows);
   }
 }
 

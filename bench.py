@@ -263,6 +263,11 @@ def main():
                          "describes exactly the step the PMC passes profile; costs ~10 %% of the step)")
     args = ap.parse_args()
     w = WORKLOADS[args.config]
+    # stdout carries exactly ONE line (the JSON): everything else that native libraries write to file descriptor 1 -- RCCL prints
+    # a version banner there when the process group goes away -- is sent to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     from harl_amd import _lib
     from harl_amd.dist import init_from_env
@@ -385,7 +390,7 @@ def main():
             cols = {"mpe": 512, "cheetah6": 512, "smac3s5z": 128, "humanoid17": 16}[args.config]
         if world == 1 and cols > 0:
             out["cpu_baseline"] = cpu_baseline(w, cols, min(args.cpu_threads, os.cpu_count() or 1))
-        print(json.dumps(out), flush=True)
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if comm.enabled:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

@@ -158,23 +158,23 @@ __global__ __launch_bounds__(WG_THREADS, (FUSE && DAP <= 8) ? 2 : 1) void k_acto
 #pragma unroll
         for (int d = 0; d < DAP; ++d) dbacc[d] += dzh[d];
       }
-    } else {  // head gradients for the dW kernel: row j, 32 columns (lane half h writes 16 of them)
-      float *dh = A.dhead + j * DHEAD_LD + 16 * h;
-#pragma unroll
-      for (int c = 0; c < 16; ++c) {
-        const int d = 16 * h + c;
-        float v = 0.f;
-#pragma unroll
-        for (int dd = 0; dd < DAP; ++dd)
-          if (dd == d) v = dzh[dd];
-        dh[c] = v;
-      }
+    } else {  // head gradients for the dW kernel
+      store_dhead<DAP>(A.dhead, slab, lane, dzh);
     }
     if constexpr (TRAIN)
       head_bwd_regs_bits<H, DAP>(xs, mb0, mb1, rstd_cur, slab, lane, whl, dzh, s1, s2, A.dzL);
   }
 
-  if (TRAIN) block_reduce_store<8 + DAP>(sc, red, A.part_scalars + (long)blockIdx.x * PS_STRIDE);
+  if (TRAIN) {
+    if constexpr (DISCRETE) {  // no per-dimension log_std sums: 8 scalars (a 64-wide Categorical head would overrun the row)
+      float sc8[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) sc8[k] = sc[k];
+      block_reduce_store<8>(sc8, red, A.part_scalars + (long)blockIdx.x * PS_STRIDE);
+    } else {
+      block_reduce_store<8 + DAP>(sc, red, A.part_scalars + (long)blockIdx.x * PS_STRIDE);
+    }
+  }
   if constexpr (FUSE) {
     float *outp = A.dw_part + (long)blockIdx.x * HeadDw<H>::OUT_FLOATS;
     if constexpr (LDSACC) head_dw_finish_lds<H, DAP, HROWS, WAVES_PER_WG>(hacc, dbacc, dwl, outp);
@@ -404,18 +404,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_actor_head_fvp(FvpArgs A) {
       for (int d = 0; d < DAP; ++d)
         if (un[d] && valid) dzh[d] = (zd[d] - S) - pr[d] * sum_dq;  // log-softmax backward of dq = q_dot
     }
-    {
-      float *dh = A.dhead + j * DHEAD_LD + 16 * h;
-#pragma unroll
-      for (int c = 0; c < 16; ++c) {
-        const int d = 16 * h + c;
-        float v = 0.f;
-#pragma unroll
-        for (int dd = 0; dd < DAP; ++dd)
-          if (dd == d) v = dzh[dd];
-        dh[c] = v;
-      }
-    }
+    store_dhead<DAP>(A.dhead, slab, lane, dzh);
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int d = 0; d < DAP; ++d) {
@@ -486,7 +475,7 @@ int head_grid(long M) { return persistent_grid(n_slabs_of(M), 4); }
 template <int H, int DAP, bool DISC, bool TRAIN>
 void launch_actor(const ActorArgs &A, int grid, hipStream_t s) {
   const size_t base = ((size_t)2 * (H / 2) * DAP + 7 * DAP + 4 * PS_STRIDE) * sizeof(float);
-  if constexpr (TRAIN) {
+  if constexpr (TRAIN && DAP <= 32) {  // (the fused head dW handles up to 32 outputs; wider heads write dhead)
     if (A.dw_part) {
       size_t fl = (size_t)WAVES_PER_WG * HeadDw<H>::WAVE_FLOATS;
       if (fl < (size_t)HeadDw<H>::OUT_FLOATS) fl = HeadDw<H>::OUT_FLOATS;
@@ -503,11 +492,15 @@ void launch_actor(const ActorArgs &A, int grid, hipStream_t s) {
 template <bool TRAIN>
 int dispatch_actor(const ActorArgs &A, int H, int discrete, int grid, hipStream_t s) {
   const int D = A.act_dim;
-  if (D < 1 || D > 32) {
-    set_error("actor head: act_dim must be in [1, 32]");
+  if (D < 1 || D > 64 || (D > 32 && !discrete)) {
+    set_error("actor head: act_dim must be in [1, 32] (Categorical heads: [1, 64])");
     return -2;
   }
-  const int dap = D <= 4 ? 4 : (D <= 8 ? 8 : (D <= 16 ? 16 : 32));
+  if (D > 32 && A.dw_part) {
+    set_error("actor head: the fused head weight gradient stops at 32 outputs (pass dw_part = NULL and run harl_mlp_dw_partials on the ATL(64) dhead image)");
+    return -2;
+  }
+  const int dap = D <= 4 ? 4 : (D <= 8 ? 8 : (D <= 16 ? 16 : (D <= 32 ? 32 : 64)));
 #define CASE(Hv, DAPv)                                                    \
   if (H == Hv && dap == DAPv) {                                           \
     if (discrete) launch_actor<Hv, DAPv, true, TRAIN>(A, grid, s);        \
@@ -516,6 +509,11 @@ int dispatch_actor(const ActorArgs &A, int H, int discrete, int grid, hipStream_
   }
   CASE(128, 4) CASE(128, 8) CASE(128, 16) CASE(128, 32) CASE(64, 4) CASE(64, 8) CASE(64, 16) CASE(64, 32)
 #undef CASE
+  if (dap == 64 && (H == 64 || H == 128)) {  // Categorical only (checked above)
+    if (H == 64) launch_actor<64, 64, true, TRAIN>(A, grid, s);
+    else launch_actor<128, 64, true, TRAIN>(A, grid, s);
+    return check_launch("harl_actor_head");
+  }
   set_error("actor head: hidden width must be 64 or 128");
   return -2;
 }
@@ -628,8 +626,16 @@ extern "C" int harl_actor_head_fvp(const float *xL, const float *xLdot, const ui
   A.avail = avail; A.dzL = dzL; A.dhead = dhead; A.n_slabs = n_slabs_of(M);
   const int grid = head_grid(M);
   hipStream_t s = (hipStream_t)stream;
-  if (act_dim < 1 || act_dim > 32) { set_error("head fvp: act_dim must be in [1, 32]"); return -2; }
-  const int dap = act_dim <= 4 ? 4 : (act_dim <= 8 ? 8 : (act_dim <= 16 ? 16 : 32));
+  if (act_dim < 1 || act_dim > 64 || (act_dim > 32 && !discrete)) {
+    set_error("head fvp: act_dim must be in [1, 32] (Categorical heads: [1, 64])");
+    return -2;
+  }
+  const int dap = act_dim <= 4 ? 4 : (act_dim <= 8 ? 8 : (act_dim <= 16 ? 16 : (act_dim <= 32 ? 32 : 64)));
+  if (dap == 64 && (H == 64 || H == 128)) {
+    if (H == 64) launch_fvp<64, 64, true>(A, grid, s);
+    else launch_fvp<128, 64, true>(A, grid, s);
+    return check_launch("harl_actor_head_fvp");
+  }
 #define CASE(Hv, DAPv)                                          \
   if (H == Hv && dap == DAPv) {                                 \
     if (discrete) launch_fvp<Hv, DAPv, true>(A, grid, s);       \

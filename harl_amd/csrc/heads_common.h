@@ -373,6 +373,33 @@ __device__ __forceinline__ void head_dw_finish(f32x16 (&acc)[H / 32], float (&db
 }
 
 // block-level reduction of NV per-lane partial sums -> part_scalars[blockIdx.x][0..NV)
+// Head gradients of a slab for the separate dW pass.  DAP <= 32: row-major [M_pad][32] (k_dw A_KIND 1; lane half h writes 16
+// columns).  DAP = 64 (Categorical heads with 33..64 actions): an ATL(64) image -- the layout of every other dz tensor --
+// so that the head's weight gradient is an ordinary harl_mlp_dw_partials(a_kind = 0, HO = 64) launch.
+template <int DAP>
+__device__ __forceinline__ void store_dhead(float *__restrict__ dhead, long slab, int lane, const float (&dzh)[DAP]) {
+  const int i = lane & 31, h = lane >> 5;
+  if constexpr (DAP <= 32) {
+    float *dh = dhead + (slab * SLAB + i) * DHEAD_LD + 16 * h;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      float v0 = 0.f, v1 = 0.f;
+      if (c < DAP) v0 = dzh[c < DAP ? c : 0];
+      if (16 + c < DAP) v1 = dzh[16 + c < DAP ? 16 + c : 0];
+      dh[c] = h ? v1 : v0;
+    }
+  } else {
+    static_assert(DAP == 64, "wide heads are padded to 64 outputs");
+    float v[32];
+#pragma unroll
+    for (int R = 0; R < 32; ++R) {
+      const int f0 = 32 * (R >> 4) + (R & 3) + 8 * ((R & 15) >> 2);  // feature of register R in lane half 0 (+4 in half 1)
+      v[R] = h ? dzh[f0 + 4] : dzh[f0];
+    }
+    atl_store<64>(dhead, slab, lane, v);
+  }
+}
+
 template <int NV>
 __device__ __forceinline__ void block_reduce_store(float (&v)[NV], float *red /*[4][PS_STRIDE]*/, float *out_row) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

@@ -209,9 +209,10 @@ class HAPPO(OnPolicyBase):
              ptr(idx), ptr(actions), ptr(avail), ptr(old_logp), ptr(adv), ptr(adv_moments), ptr(factor), ptr(active),
              float(self.clip_param), float(self.entropy_coef), int(self.action_aggregation == "mean"), self._surrogate_mode,
              mv, mp, ptr(logp_out), ptr(net.dz[0]), ptr(net.dhead), ptr(net.part_scalars),
-             ptr(net.part[net._part_offs[-1]:]), net.n_wg, s, tag="actor_head_loss")  # head dW fused into this launch
-        net.backward_trunk(obs, idx, m, seq=seq, head_dw_done=True)
-        return net.n_wg  # rows of part_scalars
+             None if net.wide_head else ptr(net.part[net._part_offs[-1]:]), net.n_wg, s,
+             tag="actor_head_loss")  # head dW fused into this launch (heads of 33..64 actions: separate dW pass)
+        net.backward_trunk(obs, idx, m, seq=seq, head_dw_done=not net.wide_head)
+        return net.n_wg if not net.wide_head else _lib.load().harl_head_blocks(m)  # rows of part_scalars
 
     def _optimizer_step(self, nblk: Optional[int]):
         """[data-parallel all-reduce] + fused scalar reduce / unfold / grad-norm / clip / Adam / re-fold.  ``nblk`` None:

@@ -250,7 +250,9 @@ class _FlatNet(nn.Module):
         self.w1img = torch.empty(3 * self.hidden_sizes[0] * self.kp0 // 2, dtype=f32, device=dev) if self.wide else None
         hmax = max(self.hidden_sizes)
         self.dz = [torch.empty(mp * hmax, dtype=f32, device=dev) for _ in range(2)]            # ping-pong, ATL
-        self.dhead = torch.zeros(mp * DHEAD_LD, dtype=f32, device=dev)
+        # head gradients for the separate dW pass: row-major [mp][32], or the ATL(64) image of a 33..64-way Categorical head
+        self.wide_head = self._layers()[-1][4] > 32
+        self.dhead = torch.zeros(mp * (64 if self.wide_head else DHEAD_LD), dtype=f32, device=dev)
         n_iter = (n_slabs + 1) // 2
         self.n_wg = max(1, min(512, n_iter))
         part_off, rows = 0, [list(r) for r in self._table_rows]
@@ -402,8 +404,12 @@ class _FlatNet(nn.Module):
         fx, _, _, fh = self.feat()
         # head: dW_head' = dhead^T x_hat_L   (x_hat_L = GRU output for recurrent nets)
         if not head_dw_done:
-            call("harl_mlp_dw_partials", ptr(self.dhead), 1, DHEAD_LD, hdim, ptr(fx), 0, 0, None, None, None, fh, M,
-                 ptr(self.part[po[-1]:]), nwg, s, tag="dw_head")
+            if self.wide_head:  # ATL(64) image: an ordinary two-operand weight-gradient GEMM (partial layout dWp[64][fh] | dbp[64])
+                call("harl_mlp_dw_partials", ptr(self.dhead), 0, 0, 64, ptr(fx), 0, 0, None, None, None, fh, M,
+                     ptr(self.part[po[-1]:]), nwg, s, tag="dw_head")
+            else:
+                call("harl_mlp_dw_partials", ptr(self.dhead), 1, DHEAD_LD, hdim, ptr(fx), 0, 0, None, None, None, fh, M,
+                     ptr(self.part[po[-1]:]), nwg, s, tag="dw_head")
         cur = 0  # self.dz[cur] holds dz of the last MLP layer (non-recurrent) / d(loss)/d(h) (recurrent)
         if self.recurrent:
             gp, sv, dg = self.gru_pack, self.rnn_saved, self.rnn_dgate
@@ -499,8 +505,9 @@ class StochasticPolicy(_FlatNet):
                                  ("act.action_out.fc_mean.weight", lin.weight.data), ("act.action_out.fc_mean.bias", lin.bias.data)]
         else:
             raise NotImplementedError(f"action space {self.action_type} (MultiDiscrete is HAPPO-only in the reference)")
-        if self.act_dim > 32:
-            raise NotImplementedError("action heads wider than 32 are not instantiated")
+        if self.act_dim > 64 or (self.act_dim > 32 and not self.discrete):
+            raise NotImplementedError("action heads wider than 32 (Categorical: 64) are not instantiated")
+        self.wide_head = self.act_dim > 32
         self._finalize_params()
         self.fold()
 

@@ -142,6 +142,17 @@ CASES = {
     "trpo_rnn_box_h64": dict(algo="hatrpo", shapes=dict(T=12, N=8, A=2, obs_dim=9, share_obs_dim=10, act_dim=2, discrete=False,
                                                         hidden_sizes=[64, 64]), seed=42,
                              overrides=dict(use_recurrent_policy=True, data_chunk_length=4, fixed_order=True)),
+    # ---- Categorical heads of 33..64 actions (SMAC 27m_vs_30m: 36 actions, GRU policies, FP state)
+    "rnn_fp_disc36_h64": dict(state_type="FP", shapes=dict(T=10, N=6, A=3, obs_dim=40, share_obs_dim=30, act_dim=36,
+                                                           discrete=True, hidden_sizes=[64, 64, 64]), seed=51, unavailable_p=0.4,
+                              inactive_p=0.1, overrides=dict(use_recurrent_policy=True, data_chunk_length=5, ppo_epoch=2,
+                                                             critic_epoch=2)),
+    "trpo_rnn_fp_disc36_h64": dict(algo="hatrpo", state_type="FP",
+                                   shapes=dict(T=10, N=6, A=2, obs_dim=40, share_obs_dim=30, act_dim=36, discrete=True,
+                                               hidden_sizes=[64, 64, 64]), seed=52, unavailable_p=0.4, inactive_p=0.1,
+                                   overrides=dict(use_recurrent_policy=True, data_chunk_length=5)),
+    "disc50_h128": dict(shapes=dict(T=12, N=8, A=2, obs_dim=20, share_obs_dim=24, act_dim=50, discrete=True,
+                                    hidden_sizes=[128, 128]), seed=53, unavailable_p=0.3, overrides=dict(ppo_epoch=2, critic_epoch=2)),
     "trpo_wide_h128x3": dict(algo="hatrpo", shapes=dict(T=8, N=8, A=3, obs_dim=70, share_obs_dim=65, act_dim=1,
                                                         discrete=False, hidden_sizes=[128, 128, 128]), seed=9,
                              overrides=dict(fixed_order=True), inactive_p=0.15),

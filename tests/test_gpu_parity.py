@@ -68,7 +68,7 @@ def test_single_update_gradients_mean_aggregation_inactive_agents():
 
 @pytest.mark.parametrize("name", ["mpe_box_h64", "mpe_box_h128", "mpe_disc_h64", "cheetah_h128x3_mb2",
                                   "box_mean_inactive_novn", "wide_obs_h64", "a2c_box_h64", "fp_box_h64",
-                                  "fp_disc_h128_mb2"])
+                                  "fp_disc_h128_mb2", "disc50_h128"])
 def test_train_matches_reference_golden(name):
     _assert_all(_G().check_train_golden(name), tol=TOL)
 
@@ -95,7 +95,8 @@ def test_hatrpo_gru_gradient_fvp_and_update(i):
     _assert_all(res, tol=2e-5)
 
 
-@pytest.mark.parametrize("name", ["trpo_box_h64", "trpo_disc_h64", "trpo_wide_h128x3", "trpo_rnn_disc_h64", "trpo_rnn_box_h64"])
+@pytest.mark.parametrize("name", ["trpo_box_h64", "trpo_disc_h64", "trpo_wide_h128x3", "trpo_rnn_disc_h64", "trpo_rnn_box_h64",
+                                  "trpo_rnn_fp_disc36_h64"])
 def test_hatrpo_train_matches_reference_golden(name):
     _assert_all(_G().check_train_golden(name), tol=TOL)
 
@@ -122,7 +123,7 @@ def test_gru_policy_forward_and_update(i):
 
 
 @pytest.mark.parametrize("name", ["rnn_box_h64", "rnn_disc_h64_mb2", "rnn_naive_h64", "rnn_fp_box_h64_mb2",
-                                  "rnn_naive_fp_disc_h64"])
+                                  "rnn_naive_fp_disc_h64", "rnn_fp_disc36_h64"])
 def test_recurrent_train_matches_reference_golden(name):
     """Chunked and naive recurrent samplers + GRU actor/critic through a whole OnPolicyHARunner.train() vs the reference."""
     _assert_all(_G().check_train_golden(name), tol=TOL)

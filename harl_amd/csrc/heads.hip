@@ -110,13 +110,17 @@ __global__ __launch_bounds__(WG_THREADS, (FUSE && DAP <= 8) ? 2 : 1) void k_acto
   // the per-row loss inputs run ONE slab ahead of the arithmetic (a dozen registers; see ActorRow)
   ActorRow<DAP> rnext;
   constexpr int NWM = (H / 2 + 31) / 32;
-  uint32_t mb0n = 0u, mb1n = 0u;  // ... and so do the ReLU-mask words and the LayerNorm statistic of the backward
+  uint32_t mb0n = 0u, mb1n = 0u, mbm1n = 0u, mbm2n = 0u;  // ... and so do the ReLU-mask words and the LayerNorm statistic of the backward
   float rstdn = 0.f;
   if (slab_first < A.n_slabs) {
     actor_row_load<DAP, DISCRETE, TRAIN>(A, slab_first, lane, rnext);
     if constexpr (TRAIN) {
       mb0n = A.relu_mask[(slab_first * NWM + 0) * WAVE + lane];
       mb1n = NWM > 1 ? A.relu_mask[(slab_first * NWM + (NWM - 1)) * WAVE + lane] : 0u;
+      if constexpr (NWM == 4) {
+        mbm1n = A.relu_mask[(slab_first * NWM + 1) * WAVE + lane];
+        mbm2n = A.relu_mask[(slab_first * NWM + 2) * WAVE + lane];
+      }
       rstdn = A.rstd[slab_first * SLAB + i];
     }
   }
@@ -124,7 +128,7 @@ __global__ __launch_bounds__(WG_THREADS, (FUSE && DAP <= 8) ? 2 : 1) void k_acto
     float z[DAP];
     f32x4 xs[TRAIN ? H / 8 : 1];
     const ActorRow<DAP> rcur = rnext;
-    const uint32_t mb0 = mb0n, mb1 = mb1n;
+    const uint32_t mb0 = mb0n, mb1 = mb1n, mbm1 = mbm1n, mbm2 = mbm2n;
     const float rstd_cur = rstdn;
     {
       const long sn = slab + slab_step < A.n_slabs ? slab + slab_step : slab;
@@ -132,6 +136,10 @@ __global__ __launch_bounds__(WG_THREADS, (FUSE && DAP <= 8) ? 2 : 1) void k_acto
       if constexpr (TRAIN) {
         mb0n = A.relu_mask[(sn * NWM + 0) * WAVE + lane];
         mb1n = NWM > 1 ? A.relu_mask[(sn * NWM + (NWM - 1)) * WAVE + lane] : 0u;
+        if constexpr (NWM == 4) {
+          mbm1n = A.relu_mask[(sn * NWM + 1) * WAVE + lane];
+          mbm2n = A.relu_mask[(sn * NWM + 2) * WAVE + lane];
+        }
         rstdn = A.rstd[sn * SLAB + i];
       }
     }
@@ -162,7 +170,7 @@ __global__ __launch_bounds__(WG_THREADS, (FUSE && DAP <= 8) ? 2 : 1) void k_acto
       store_dhead<DAP>(A.dhead, slab, lane, dzh);
     }
     if constexpr (TRAIN)
-      head_bwd_regs_bits<H, DAP>(xs, mb0, mb1, rstd_cur, slab, lane, whl, dzh, s1, s2, A.dzL);
+      head_bwd_regs_bits<H, DAP>(xs, mb0, mb1, rstd_cur, slab, lane, whl, dzh, s1, s2, A.dzL, mbm1, mbm2);
   }
 
   if (TRAIN) {
@@ -232,23 +240,31 @@ __global__ __launch_bounds__(WG_THREADS, FUSE ? 2 : 1) void k_critic_head(Critic
   // value_preds / returns, ReLU-mask words and the LayerNorm statistic run one slab ahead as well (see ActorRow)
   constexpr int NWM = (H / 2 + 31) / 32;
   float voldn = 0.f, retn = 0.f, rstdn = 0.f;
-  uint32_t mb0n = 0u, mb1n = 0u;
+  uint32_t mb0n = 0u, mb1n = 0u, mbm1n = 0u, mbm2n = 0u;
   if (TRAIN && slab_first < A.n_slabs) {
     critic_row_load(A, slab_first, lane, voldn, retn);
     mb0n = A.relu_mask[(slab_first * NWM + 0) * WAVE + lane];
     mb1n = NWM > 1 ? A.relu_mask[(slab_first * NWM + (NWM - 1)) * WAVE + lane] : 0u;
+    if constexpr (NWM == 4) {
+      mbm1n = A.relu_mask[(slab_first * NWM + 1) * WAVE + lane];
+      mbm2n = A.relu_mask[(slab_first * NWM + 2) * WAVE + lane];
+    }
     rstdn = A.rstd[slab_first * SLAB + i];
   }
   for (long slab = slab_first; slab < A.n_slabs; slab += slab_step) {
     float z[DAP];
     f32x4 xs[TRAIN ? H / 8 : 1];
     const float vold = voldn, ret = retn, rstd_cur = rstdn;
-    const uint32_t mb0 = mb0n, mb1 = mb1n;
+    const uint32_t mb0 = mb0n, mb1 = mb1n, mbm1 = mbm1n, mbm2 = mbm2n;
     if constexpr (TRAIN) {
       const long sn = slab + slab_step < A.n_slabs ? slab + slab_step : slab;
       critic_row_load(A, sn, lane, voldn, retn);
       mb0n = A.relu_mask[(sn * NWM + 0) * WAVE + lane];
       mb1n = NWM > 1 ? A.relu_mask[(sn * NWM + (NWM - 1)) * WAVE + lane] : 0u;
+      if constexpr (NWM == 4) {
+        mbm1n = A.relu_mask[(sn * NWM + 1) * WAVE + lane];
+        mbm2n = A.relu_mask[(sn * NWM + 2) * WAVE + lane];
+      }
       rstdn = A.rstd[sn * SLAB + i];
     }
     if constexpr (TRAIN) {
@@ -277,7 +293,7 @@ __global__ __launch_bounds__(WG_THREADS, FUSE ? 2 : 1) void k_critic_head(Critic
       for (int c = 0; c < 16; ++c) dh[c] = (h == 0 && c == 0) ? dv : 0.f;
     }
     if constexpr (TRAIN)
-      head_bwd_regs_bits<H, DAP>(xs, mb0, mb1, rstd_cur, slab, lane, whl, dzh, dv * cst[4 * DAP], dv * (v - cst[0]), A.dzL);
+      head_bwd_regs_bits<H, DAP>(xs, mb0, mb1, rstd_cur, slab, lane, whl, dzh, dv * cst[4 * DAP], dv * (v - cst[0]), A.dzL, mbm1, mbm2);
   }
   if (TRAIN) block_reduce_store<8>(sc, red, A.part_scalars + (long)blockIdx.x * PS_STRIDE);
   if constexpr (FUSE)
@@ -508,6 +524,7 @@ int dispatch_actor(const ActorArgs &A, int H, int discrete, int grid, hipStream_
     return check_launch("harl_actor_head");                               \
   }
   CASE(128, 4) CASE(128, 8) CASE(128, 16) CASE(128, 32) CASE(64, 4) CASE(64, 8) CASE(64, 16) CASE(64, 32)
+  CASE(256, 4) CASE(256, 8) CASE(256, 16) CASE(256, 32)  // hidden width 256 (csrc/panel.hip)
 #undef CASE
   if (dap == 64 && (H == 64 || H == 128)) {  // Categorical only (checked above)
     if (H == 64) launch_actor<64, 64, true, TRAIN>(A, grid, s);
@@ -574,7 +591,8 @@ extern "C" int harl_critic_head_values(const float *xL, long M, int H, const flo
   const size_t shm = ((size_t)2 * (H / 2) * 4 + 20 + 4 * PS_STRIDE) * sizeof(float);
   if (H == 128) hipLaunchKernelGGL((k_critic_head<128, false>), dim3(grid), dim3(WG_THREADS), shm, (hipStream_t)stream, A);
   else if (H == 64) hipLaunchKernelGGL((k_critic_head<64, false>), dim3(grid), dim3(WG_THREADS), shm, (hipStream_t)stream, A);
-  else { set_error("critic head: hidden width must be 64 or 128"); return -2; }
+  else if (H == 256) hipLaunchKernelGGL((k_critic_head<256, false>), dim3(grid), dim3(WG_THREADS), shm, (hipStream_t)stream, A);
+  else { set_error("critic head: hidden width must be 64, 128 or 256"); return -2; }
   return check_launch("harl_critic_head_values");
 }
 
@@ -607,7 +625,7 @@ extern "C" int harl_critic_head_loss(const float *xL, const uint32_t *relu_mask,
     }                                                                                                              \
     return check_launch("harl_critic_head_loss");                                                                  \
   }
-  CL(128) CL(64)
+  CL(128) CL(64) CL(256)
 #undef CL
   set_error("critic head: hidden width must be 64 or 128");
   return -2;

@@ -105,7 +105,7 @@ __device__ __forceinline__ void head_bwd_stream(const float *__restrict__ xL, co
 #pragma unroll 1
   for (int q = 0; q < H / 8; ++q) {
     const f32x4 xn = xp[(q + 1 < H / 8 ? q + 1 : q) * WAVE];
-    if (q == 8) b0 = b1;  // second mask word (features R = 32..63 of this lane); bits are consumed MSB-first
+    if (q > 0 && (q & 7) == 0) b0 = q == 8 * (NW - 1) ? b1 : mask_in[(slab * NW + (q >> 3)) * WAVE + lane];  // next mask word; bits are consumed MSB-first
     f32x4 o;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -163,7 +163,9 @@ template <int H, int DAP>
 __device__ __forceinline__ void head_bwd_regs_bits(const f32x4 (&xs)[H / 8], uint32_t b0, const uint32_t b1, float rstd,
                                                    long slab, int lane, const float *whl /* base, both halves */,
                                                    const float (&dzh)[DAP], float s1, float s2,
-                                                   float *__restrict__ dz_out) {
+                                                   float *__restrict__ dz_out, const uint32_t bm1 = 0u,
+                                                   const uint32_t bm2 = 0u) {
+  // (H = 256 has four mask words per lane: b0, bm1, bm2, b1)
   // b0 / b1: the lane's first / last ReLU-mask word (the same word when H = 64), MSB-first (common.h)
   s1 *= (1.0f / H);
   s2 *= (1.0f / H);
@@ -188,7 +190,9 @@ __device__ __forceinline__ void head_bwd_regs_bits(const f32x4 (&xs)[H / 8], uin
   f32x4 *op = reinterpret_cast<f32x4 *>(dz_out + slab * (long)(H * SLAB)) + lane;
 #pragma unroll
   for (int q = 0; q < H / 8; ++q) {
-    if (q == 8) b0 = b1;  // second mask word; bits are consumed MSB-first
+    if (q == 8) b0 = H == 256 ? bm1 : b1;  // next mask word; bits are consumed MSB-first
+    if (H == 256 && q == 16) b0 = bm2;
+    if (H == 256 && q == 24) b0 = b1;
     f32x4 o;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -209,7 +213,8 @@ __device__ __forceinline__ void head_bwd_regs(const f32x4 (&xs)[H / 8], const ui
   constexpr int NW = (H / 2 + 31) / 32;
   const uint32_t b0 = mask_in[(slab * NW + 0) * WAVE + lane];
   const uint32_t b1 = NW > 1 ? mask_in[(slab * NW + (NW - 1)) * WAVE + lane] : 0u;
-  head_bwd_regs_bits<H, DAP>(xs, b0, b1, rstd, slab, lane, whl, dzh, s1, s2, dz_out);
+  const uint32_t bm1 = NW == 4 ? mask_in[(slab * NW + 1) * WAVE + lane] : 0u, bm2 = NW == 4 ? mask_in[(slab * NW + 2) * WAVE + lane] : 0u;
+  head_bwd_regs_bits<H, DAP>(xs, b0, b1, rstd, slab, lane, whl, dzh, s1, s2, dz_out, bm1, bm2);
 }
 
 // ---- head weight gradient fused into the loss kernels:  dW_head'[d][f] += sum_s dhead[s][d] x_hat_L[s][f].

@@ -1380,7 +1380,7 @@ extern "C" int harl_mlp_dw_partials(const float *a, int a_kind, int lda, int HO,
   hipStream_t s = (hipStream_t)stream;
   if (a_kind == 1 && lda != DHEAD_LD) return bad("harl_mlp_dw_partials: head gradient matrix must have row stride 32");
   const int MT = a_kind == 1 ? 1 : HO / 32;
-  if (a_kind == 0 && HO != 64 && HO != 128) return bad("harl_mlp_dw_partials: HO must be 64 or 128");
+  if (a_kind == 0 && HO != 64 && HO != 128 && HO != 256) return bad("harl_mlp_dw_partials: HO must be 64, 128 or 256");
   if (a_kind == 1 && HO > 32) return bad("harl_mlp_dw_partials: head width must be <= 32");
 #define DW(AK, BK, MTv, NTv, ny) launch_dw<AK, BK, MTv, NTv>(a, b, ldx, idx, mu0, rstd0, K, M, n_slabs, part, KP, n_wg, ny, s)
   if (b_kind == 0) {
@@ -1393,11 +1393,14 @@ extern "C" int harl_mlp_dw_partials(const float *a, int a_kind, int lda, int HO,
     hipLaunchKernelGGL((k_dw_split<MTv, NTv>), dim3(n_wg), dim3(WG_THREADS), shm, s, a, b, n_slabs, part,         \
                        (long)K * SLAB, tile0, K);                                                                \
   }
-    if (K > 128 || K == 96) {  // wide first layer: x0n ATL(K), K a multiple of 32 up to 512, in groups of <= 4 column tiles
-      if (K % 32 != 0 || K > 512 || (MT != 4 && MT != 2)) return bad("harl_mlp_dw_partials: wide ATL input must be a multiple of 32, <= 512");
-      for (int tile0 = 0; tile0 < K / 32; tile0 += 4) {
-        const int nt = K / 32 - tile0 < 4 ? K / 32 - tile0 : 4;
-        if (MT == 4) {
+    if (K > 128 || K == 96 || MT == 8) {  // wide first layer (and every 256-row operand): x0n ATL(K), K a multiple of 32 up to 512, in groups of <= 4 column tiles
+      if (K % 32 != 0 || K > 512 || (MT != 8 && MT != 4 && MT != 2)) return bad("harl_mlp_dw_partials: wide ATL input must be a multiple of 32, <= 512");
+      const int gstep = MT == 8 ? 2 : 4;  // 256-wide layers (csrc/panel.hip): 8 x 2 tiles per launch stay inside 256 registers
+      for (int tile0 = 0; tile0 < K / 32; tile0 += gstep) {
+        const int nt = K / 32 - tile0 < gstep ? K / 32 - tile0 : gstep;
+        if (MT == 8) {
+          if (nt == 2) DWS(8, 2) else DWS(8, 1)
+        } else if (MT == 4) {
           if (nt == 4) DWS(4, 4) else if (nt == 3) DWS(4, 3) else if (nt == 2) DWS(4, 2) else DWS(4, 1)
         } else {
           if (nt == 4) DWS(2, 4) else if (nt == 3) DWS(2, 3) else if (nt == 2) DWS(2, 2) else DWS(2, 1)

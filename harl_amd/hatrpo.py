@@ -27,6 +27,9 @@ class HATRPO(OnPolicyBase):
         assert act_space.__class__.__name__ != "MultiDiscrete", \
             "only continuous and discrete action space is supported by HATRPO."
         super().__init__(args, obs_space, act_space, device)
+        if self.actor.panel:
+            raise NotImplementedError("HATRPO with hidden width 256: the forward-mode tangent kernels are 64/128 wide "
+                                      "(no tuned HARL config needs it)")
         self.kl_threshold = args["kl_threshold"]
         self.ls_step = args["ls_step"]
         self.accept_ratio = args["accept_ratio"]

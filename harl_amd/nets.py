@@ -22,7 +22,7 @@ import torch.nn as nn
 from . import _lib
 from ._lib import DHEAD_LD, PS_STRIDE, SLAB, call, ptr, stream
 
-SUPPORTED_WIDTHS = (64, 128)
+SUPPORTED_WIDTHS = (64, 128, 256)
 
 
 def _space_shape(space) -> Tuple[int, ...]:
@@ -67,6 +67,10 @@ class _FlatNet(nn.Module):
         for h in self.hidden_sizes:
             if h not in SUPPORTED_WIDTHS:
                 raise NotImplementedError(f"hidden width {h}: kernels are instantiated for {SUPPORTED_WIDTHS}")
+        # width 256 runs on the panel kernels (csrc/panel.hip): every layer 256 wide, feed-forward, inputs up to 512
+        self.panel = 256 in self.hidden_sizes
+        if self.panel and (any(h != 256 for h in self.hidden_sizes) or self.recurrent or in_dim > 512):
+            raise NotImplementedError("hidden width 256: all layers must be 256 wide, feed-forward, inputs <= 512")
         self.in_dim = in_dim
         self.wide = 32 < in_dim <= 512  # first layer through the cached x0n image (csrc/wide.hip); <= 32: fused 2-layer kernel
         self._x0n_key = None
@@ -323,6 +327,14 @@ class _FlatNet(nn.Module):
         s = stream()
         hs = self.hidden_sizes
         first_hidden = 1
+        if self.panel:  # width 256: x0n image -> panel GEMMs (csrc/panel.hip)
+            self._x0n_image(X, M, s, idx)
+            for l in range(len(hs)):
+                Wp, bp = self._packs[l]
+                xin, kp, d = (self.x0n, self.kp0, self.in_dim) if l == 0 else (self.xh[l - 1], 256, 256)
+                call("harl_mlp_panel_fwd", ptr(xin), M, kp, ptr(Wp), d, ptr(bp), 256, ptr(self.xh[l]), ptr(self.rmask[l]),
+                     ptr(self.rstd[l]), s, tag="fwd_panel")
+            return
         if len(hs) >= 2 and hs[0] == hs[1] and self.in_dim <= 64 and idx is None:
             # layers 1+2 fused, from the x0n image: the rows are gathered and normalised ONCE per buffer (every epoch, log-prob
             # pass and line-search step over the same unmodified tensor reuses the image)
@@ -371,7 +383,7 @@ class _FlatNet(nn.Module):
         if mode == "0" or (train and mode == "logp") or (train and mode == "actor" and isinstance(self, VNet)):
             return False
         return (not self.recurrent and idx is None and seq is None
-                and len(hs) == 2 and hs[0] == hs[1] and self.in_dim <= 64 and self._layers()[-1][4] <= 8)
+                and len(hs) == 2 and hs[0] == hs[1] and hs[0] in (64, 128) and self.in_dim <= 64 and self._layers()[-1][4] <= 8)
 
     def fused_args(self, X: torch.Tensor, M: int):
         """(x0n, M, D, H, W1', b1', W2', b2', Wh', bh') -- the leading arguments of every harl_update_* entry point.
@@ -425,6 +437,19 @@ class _FlatNet(nn.Module):
                 call("harl_mlp_dw_partials", ptr(a), 0, 0, H, ptr(sv[0]), 0, 0, None, None, None, H, M,
                      ptr(self.part[po[L + 3 + gate]:]), nwg, s, tag="dw_gru")
             cur = 1
+        if self.panel:  # width 256 (csrc/panel.hip): per layer dW = dz^T x_hat_prev, then dz_prev through the panel GEMM
+            for l in range(L - 1, -1, -1):
+                b_in, k_in = (self.x0n, self.kp0) if l == 0 else (self.xh[l - 1], 256)
+                call("harl_mlp_dw_partials", ptr(self.dz[cur]), 0, 0, 256, ptr(b_in), 0, 0, None, None, None, k_in, M,
+                     ptr(self.part[po[l]:]), nwg, s, tag="dw_hidden" if l else "dw_input")
+                if l > 0:
+                    Wp, _ = self._packs[l]
+                    call("harl_mlp_panel_bwd", ptr(self.dz[cur]), ptr(self.xh[l - 1]), ptr(self.rmask[l - 1]),
+                         ptr(self.rstd[l - 1]), M, 256, 256, ptr(Wp), ptr(self.dz[1 - cur]), s, tag="bwd_panel")
+                    cur = 1 - cur
+            call("harl_reduce_partials_multi", ptr(self.part), ptr(self.table), self.n_entries, nwg, self.total_dwp,
+                 ptr(self.dwp), s, tag="reduce_partials")
+            return
         # first-layer weight gradient fused into the last bwd_dx (needs the ones column of x0n: in_dim < kp0)
         fuse_dw1 = L >= 2 and self.x0n is not None and self.in_dim < self.kp0 and self.kp0 <= 64
         for l in range(L - 1, 0, -1):

@@ -119,6 +119,17 @@ int harl_mlp_x0n_wide(const float *X, long ldx, const int64_t *idx, long M, int 
                       float *rstd0, void *stream);
 int harl_mlp_fwd_wide(const float *x0n, long M, int KP, const float *Wp, int D, const float *bp, int H, void *w_img,
                       float *xout, uint32_t *relu_mask, float *rstd, void *stream);
+/* Hidden width 256 (csrc/panel.hip; the reference's dexhands HAPPO configurations, mlp.py:7-70 with hidden_sizes
+ * [256, 256, 256]).  Three bf16 images of a 256-row matrix do not fit the LDS, so K is walked in 32-column panels that the
+ * workgroup restages from L2; everything else (ATL images, ReLU masks, LayerNorm statistics) is as in the 64/128-wide kernels.
+ *   harl_mlp_panel_fwd: xout = norm(relu(Wp xin + bp)), xin = ATL(KP) image (x0n of harl_mlp_x0n_wide, or x_hat of the layer
+ *     before with KP = D = 256), Wp [256][D] row-major.
+ *   harl_mlp_panel_bwd: dz_prev = relu' . LNbwd(Wp^T dz) for a 256 -> 256 layer (the role of harl_mlp_bwd_dx).
+ * Weight gradients: harl_mlp_dw_partials(a_kind = 0, HO = 256). */
+int harl_mlp_panel_fwd(const float *xin, long M, int KP, const float *Wp, int D, const float *bp, int HO, float *xout,
+                       uint32_t *relu_mask, float *rstd, void *stream);
+int harl_mlp_panel_bwd(const float *dz, const float *xprev, const uint32_t *relu_mask_prev, const float *rstd_prev, long M,
+                       int HO, int HI, const float *Wp, float *dz_prev, void *stream);
 /* the same two layers FROM the x0n ATL(32 | 64) image of harl_mlp_x0n_wide (D <= 64; identity row order; the image is
  * built once per buffer): no gather, no input-LayerNorm work per call */
 int harl_mlp_fwd_fused2x(const float *x0n, long M, const float *W1p, int D, const float *b1p, const float *W2p,

@@ -153,6 +153,12 @@ CASES = {
                                    overrides=dict(use_recurrent_policy=True, data_chunk_length=5)),
     "disc50_h128": dict(shapes=dict(T=12, N=8, A=2, obs_dim=20, share_obs_dim=24, act_dim=50, discrete=True,
                                     hidden_sizes=[128, 128]), seed=53, unavailable_p=0.3, overrides=dict(ppo_epoch=2, critic_epoch=2)),
+    # ---- hidden width 256 (the reference's dexhands HAPPO configurations: [256, 256, 256], wide observations, Box actions)
+    "hands_h256x3": dict(shapes=dict(T=10, N=8, A=2, obs_dim=211, share_obs_dim=200, act_dim=20, discrete=False,
+                                     hidden_sizes=[256, 256, 256]), seed=61, overrides=dict(ppo_epoch=2, critic_epoch=2)),
+    "hands_h256x3_mb2_fp": dict(state_type="FP", shapes=dict(T=12, N=8, A=2, obs_dim=40, share_obs_dim=60, act_dim=6, discrete=True,
+                                                             hidden_sizes=[256, 256, 256]), seed=62, unavailable_p=0.2, inactive_p=0.1,
+                                overrides=dict(ppo_epoch=2, critic_epoch=2, actor_num_mini_batch=2, critic_num_mini_batch=2)),
     "trpo_wide_h128x3": dict(algo="hatrpo", shapes=dict(T=8, N=8, A=3, obs_dim=70, share_obs_dim=65, act_dim=1,
                                                         discrete=False, hidden_sizes=[128, 128, 128]), seed=9,
                              overrides=dict(fixed_order=True), inactive_p=0.15),

@@ -248,6 +248,9 @@ FWD_SHAPES = [
     dict(name="humanoid_393", obs_dim=393, share_obs_dim=376, act_dim=1, discrete=False, hidden_sizes=[128, 128, 128], M=300),
     dict(name="mixed_64_128_disc14", obs_dim=40, share_obs_dim=33, act_dim=14, discrete=True, hidden_sizes=[64, 128], M=513),
     dict(name="mixed_128_64_box20", obs_dim=31, share_obs_dim=65, act_dim=20, discrete=False, hidden_sizes=[128, 64], M=640),
+    # hidden width 256 (csrc/panel.hip): the reference's dexhands shapes (obs 422 / 398, 20-26 Box actions, [256, 256, 256])
+    dict(name="hands_256x3_box20", obs_dim=211, share_obs_dim=200, act_dim=20, discrete=False, hidden_sizes=[256, 256, 256], M=700),
+    dict(name="narrow_256x2_disc6", obs_dim=24, share_obs_dim=40, act_dim=6, discrete=True, hidden_sizes=[256, 256], M=333),
 ]
 
 

@@ -49,13 +49,13 @@ def test_fused_gradnorm_clip_adam():
     _assert_all(_G().check_adam(), tol=2e-6)
 
 
-@pytest.mark.parametrize("i", range(7))
+@pytest.mark.parametrize("i", range(9))
 def test_mlp_forward_logp_and_values(i):
     G = _G()
     _assert_all(G.check_forward(G.FWD_SHAPES[i]), tol=TOL)
 
 
-@pytest.mark.parametrize("i", range(7))
+@pytest.mark.parametrize("i", range(9))
 def test_single_update_gradients(i):
     G = _G()
     _assert_all(G.check_gradients(G.FWD_SHAPES[i]), tol=TOL)
@@ -68,7 +68,7 @@ def test_single_update_gradients_mean_aggregation_inactive_agents():
 
 @pytest.mark.parametrize("name", ["mpe_box_h64", "mpe_box_h128", "mpe_disc_h64", "cheetah_h128x3_mb2",
                                   "box_mean_inactive_novn", "wide_obs_h64", "a2c_box_h64", "fp_box_h64",
-                                  "fp_disc_h128_mb2", "disc50_h128"])
+                                  "fp_disc_h128_mb2", "disc50_h128", "hands_h256x3", "hands_h256x3_mb2_fp"])
 def test_train_matches_reference_golden(name):
     _assert_all(_G().check_train_golden(name), tol=TOL)
 
@@ -101,7 +101,7 @@ def test_hatrpo_train_matches_reference_golden(name):
     _assert_all(_G().check_train_golden(name), tol=TOL)
 
 
-@pytest.mark.parametrize("i", [0, 1, 5])
+@pytest.mark.parametrize("i", [0, 1, 5, 7])
 def test_rollout_get_actions(i):
     G = _G()
     res = G.check_get_actions(G.FWD_SHAPES[i])

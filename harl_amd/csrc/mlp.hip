@@ -1395,12 +1395,16 @@ extern "C" int harl_mlp_dw_partials(const float *a, int a_kind, int lda, int HO,
   }
     if (K > 128 || K == 96 || MT == 8) {  // wide first layer (and every 256-row operand): x0n ATL(K), K a multiple of 32 up to 512, in groups of <= 4 column tiles
       if (K % 32 != 0 || K > 512 || (MT != 8 && MT != 4 && MT != 2)) return bad("harl_mlp_dw_partials: wide ATL input must be a multiple of 32, <= 512");
-      const int gstep = MT == 8 ? 2 : 4;  // 256-wide layers (csrc/panel.hip): 8 x 2 tiles per launch stay inside 256 registers
-      for (int tile0 = 0; tile0 < K / 32; tile0 += gstep) {
-        const int nt = K / 32 - tile0 < gstep ? K / 32 - tile0 : gstep;
+      // every launch re-reads and re-splits dz: as few column groups as the register file allows (8 x 2 tiles for 256-wide
+      // layers; up to 6 tiles next to 4 row tiles: a 416-wide first layer is 5 + 5 + 3 instead of 4 + 4 + 4 + 1)
+      const int ntiles = K / 32;
+      const int gstep = MT == 8 ? 2 : (MT == 4 && ntiles > 4 ? (ntiles + (ntiles + 5) / 6 - 1) / ((ntiles + 5) / 6) : 4);
+      for (int tile0 = 0; tile0 < ntiles; tile0 += gstep) {
+        const int nt = ntiles - tile0 < gstep ? ntiles - tile0 : gstep;
         if (MT == 8) {
           if (nt == 2) DWS(8, 2) else DWS(8, 1)
         } else if (MT == 4) {
+          if (nt == 6) DWS(4, 6) else if (nt == 5) DWS(4, 5) else
           if (nt == 4) DWS(4, 4) else if (nt == 3) DWS(4, 3) else if (nt == 2) DWS(4, 2) else DWS(4, 1)
         } else {
           if (nt == 4) DWS(2, 4) else if (nt == 3) DWS(2, 3) else if (nt == 2) DWS(2, 2) else DWS(2, 1)

@@ -127,16 +127,22 @@ __device__ __forceinline__ void ln_jac_store(f32x16 (&acc)[HO / 32], const float
 // =============================================================================================
 constexpr bool split_one_wg(int ho, int hi, size_t extra = 0) { return 2 * (split_image_bytes(ho, hi) + ho * 4 + extra) > 160 * 1024; }
 
-template <int HI, int HO>
+// MODE 0: x_hat_out = norm(relu(Wp x_in + bp)) (+ mask, rstd).   MODE 1: raw  z = Wp x_in + bp  stored as an ATL image.
+// MODE 2: z = xout (read) + Wp x_in, then the LayerNorm Jacobian with the PRIMAL x_hat / mask / rstd of this layer ->
+// xout.  (1 then 2 = the forward-mode tangent of a hidden layer, z_dot = Wp x_in_dot + Wp_dot x_hat_in + bp_dot, as two
+// split-bf16 GEMMs: both weight matrices do not fit the LDS at once.)
+template <int HI, int HO, int MODE = 0>
 __global__ __launch_bounds__(WG_THREADS, split_one_wg(HO, HI) ? 1 : 2) void k_fwd_hidden(
     const float *__restrict__ xin, const float *__restrict__ Wp, const float *__restrict__ bp, float *__restrict__ xout,
-    uint32_t *__restrict__ mask_out, float *__restrict__ rstd_out, long n_slabs) {
+    uint32_t *__restrict__ mask_out, float *__restrict__ rstd_out, long n_slabs, const float *__restrict__ xprimal = nullptr,
+    const uint32_t *__restrict__ mask_in = nullptr, const float *__restrict__ rstd_in = nullptr) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int MT = HO / 32, NJ = HI / 16, NR = HI / 2;
   u32x4 *img = reinterpret_cast<u32x4 *>(lds);
   float *bl = reinterpret_cast<float *>(img + 3 * MT * NJ * 64);
   stage_split_matrix<HO, HI, false, WG_THREADS>(img, Wp);
-  for (int e = threadIdx.x; e < HO; e += WG_THREADS) bl[e] = bp[e];
+  if (MODE != 2)
+    for (int e = threadIdx.x; e < HO; e += WG_THREADS) bl[e] = bp[e];
   __syncthreads();
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
@@ -150,12 +156,28 @@ __global__ __launch_bounds__(WG_THREADS, split_one_wg(HO, HI) ? 1 : 2) void k_fw
     // the next slab's activations: a whole slab of MFMA time (> 6000 cycles) to land
     atl_load<HI>(xin, slab + slab_stride < n_slabs ? slab + slab_stride : slab, lane, raw);
     f32x16 acc[MT];
+    if constexpr (MODE == 2) {
+      float z0[HO / 2];
+      atl_load<HO>(xout, slab, lane, z0);
 #pragma unroll
-    for (int t = 0; t < MT; ++t)
+      for (int R = 0; R < HO / 2; ++R) acc[R >> 4][R & 15] = z0[R];
+    } else {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[t][r] = bl[32 * t + (r & 3) + 8 * (r >> 2) + 4 * h];
+      for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = bl[32 * t + (r & 3) + 8 * (r >> 2) + 4 * h];
+    }
     split_gemm<MT, NJ>(wl, x1, x2, x3, acc, [](int) {});
-    relu_norm_store<HO>(acc, lane, slab, xout, mask_out, rstd_out);
+    if constexpr (MODE == 0) {
+      relu_norm_store<HO>(acc, lane, slab, xout, mask_out, rstd_out);
+    } else if constexpr (MODE == 1) {
+      float z[HO / 2];
+#pragma unroll
+      for (int R = 0; R < HO / 2; ++R) z[R] = acc[R >> 4][R & 15];
+      atl_store<HO>(xout, slab, lane, z);
+    } else {
+      ln_jac_store<HO>(acc, xprimal, mask_in, rstd_in, lane, slab, xout);
+    }
   }
 }
 
@@ -1202,70 +1224,26 @@ extern "C" int harl_mlp_tangent_input(const float *X, long ldx, const int64_t *i
 }
 
 // ---- forward-mode pass, hidden layer:  z_dot = W' x_hat_in_dot + W'_dot x_hat_in + b'_dot ; x_hat_out_dot = LNjac(.)
-// Both weight matrices live in LDS (2 x [HO][HI+1]); one workgroup per CU.  Plain rolled streaming loop (this pass is
-// 1/3 of a Fisher-vector product and not on the HAPPO bench path; it is kept simple).
-template <int HI, int HO>
-__global__ __launch_bounds__(WG_THREADS, 1) void k_tangent_hidden(const float *__restrict__ xin_dot,
-                                                                  const float *__restrict__ xin,
-                                                                  const float *__restrict__ Wp,
-                                                                  const float *__restrict__ Wdp,
-                                                                  const float *__restrict__ bdp,
-                                                                  const float *__restrict__ xprimal,
-                                                                  const uint32_t *__restrict__ mask_in,
-                                                                  const float *__restrict__ rstd_in,
-                                                                  float *__restrict__ xout_dot, long n_slabs) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  constexpr int LDW = HI + 1;
-  float *Wl = lds;
-  float *Wdl = lds + HO * LDW;
-  float *bl = Wdl + HO * LDW;
-  stage_matrix<HO, HI, LDW, WG_THREADS>(Wl, Wp);
-  stage_matrix<HO, HI, LDW, WG_THREADS>(Wdl, Wdp);
-  for (int e = threadIdx.x; e < HO; e += WG_THREADS) bl[e] = bdp[e];
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int i = lane & 31, h = lane >> 5;
-  const float *wl_lane = Wl + i * LDW + 4 * h;
-  const float *wdl_lane = Wdl + i * LDW + 4 * h;
-  for (long slab = (long)blockIdx.x * WAVES_PER_WG + wave; slab < n_slabs; slab += (long)gridDim.x * WAVES_PER_WG) {
-    f32x16 acc[HO / 32];
-#pragma unroll
-    for (int t = 0; t < HO / 32; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[t][r] = bl[32 * t + (r & 3) + 8 * (r >> 2) + 4 * h];
-    const f32x4 *xdp = reinterpret_cast<const f32x4 *>(xin_dot + slab * (long)(HI * SLAB)) + lane;
-    const f32x4 *xp = reinterpret_cast<const f32x4 *>(xin + slab * (long)(HI * SLAB)) + lane;
-#pragma unroll 1
-    for (int q = 0; q < HI / 8; ++q) {
-      const f32x4 xd = xdp[q * WAVE];
-      const f32x4 xv = xp[q * WAVE];
-      const int off = 32 * (q >> 2) + 8 * (q & 3);
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-#pragma unroll
-        for (int t = 0; t < HO / 32; ++t) {
-          acc[t] = MFMA(wl_lane[off + 32 * t * LDW + c], xd[c], acc[t]);
-          acc[t] = MFMA(wdl_lane[off + 32 * t * LDW + c], xv[c], acc[t]);
-        }
-      }
-    }
-    ln_jac_store<HO>(acc, xprimal, mask_in, rstd_in, lane, slab, xout_dot);
-  }
-}
-
+// (k_fwd_hidden MODE 1 then MODE 2)
 extern "C" int harl_mlp_tangent_hidden(const float *xin_dot, const float *xin, long M, int HI, int HO, const float *Wp,
                                        const float *Wdp, const float *bdp, const float *xprimal,
                                        const uint32_t *mask_in, const float *rstd_in, float *xout_dot, void *stream) {
   if (M <= 0) return 0;
   const long n_slabs = n_slabs_of(M);
-  const size_t shm = ((size_t)2 * HO * (HI + 1) + HO) * sizeof(float);
-  const int grid = persistent_grid(n_slabs, 1);
+  // two split-bf16 GEMMs through xout_dot:  z = Wdp x_hat_in + bdp (raw), then  z += Wp x_in_dot  and the LayerNorm Jacobian
+  // (round 1 ran both products on the fp32 MFMA from two fp32 weight copies in LDS: 0.19 ms at 204 800 rows, a quarter of
+  // the 17-agent HATRPO update)
+  const size_t shm = split_image_bytes(HO, HI) + (size_t)HO * sizeof(float);
+  const int grid = persistent_grid(n_slabs, split_one_wg(HO, HI) ? 1 : 2);
   hipStream_t s = (hipStream_t)stream;
-#define L(a, b)                                                                                                \
-  {                                                                                                            \
-    allow_big_lds(k_tangent_hidden<a, b>, shm);                                                                \
-    hipLaunchKernelGGL((k_tangent_hidden<a, b>), dim3(grid), dim3(WG_THREADS), shm, s, xin_dot, xin, Wp, Wdp, bdp, \
-                       xprimal, mask_in, rstd_in, xout_dot, n_slabs);                                           \
+#define L(a, b)                                                                                                      \
+  {                                                                                                                  \
+    allow_big_lds(k_fwd_hidden<a, b, 1>, shm);                                                                       \
+    hipLaunchKernelGGL((k_fwd_hidden<a, b, 1>), dim3(grid), dim3(WG_THREADS), shm, s, xin, Wdp, bdp, xout_dot, nullptr, \
+                       nullptr, n_slabs, nullptr, nullptr, nullptr);                                                 \
+    allow_big_lds(k_fwd_hidden<a, b, 2>, shm);                                                                       \
+    hipLaunchKernelGGL((k_fwd_hidden<a, b, 2>), dim3(grid), dim3(WG_THREADS), shm, s, xin_dot, Wp, nullptr, xout_dot,  \
+                       nullptr, nullptr, n_slabs, xprimal, mask_in, rstd_in);                                        \
   }
   if (HI == 128 && HO == 128) L(128, 128)
   else if (HI == 64 && HO == 64) L(64, 64)
@@ -1310,7 +1288,7 @@ extern "C" int harl_mlp_fwd_hidden(const float *xin, long M, int HI, int HO, con
 #define L(a, b)                                                                                                  \
   allow_big_lds(k_fwd_hidden<a, b>, shm);                                                                        \
   hipLaunchKernelGGL((k_fwd_hidden<a, b>), dim3(grid), dim3(WG_THREADS), shm, s, xin, Wp, bp, xout, relu_mask, rstd, \
-                     n_slabs)
+                     n_slabs, nullptr, nullptr, nullptr)
   if (HI == 128 && HO == 128) { L(128, 128); }
   else if (HI == 64 && HO == 64) { L(64, 64); }
   else if (HI == 128 && HO == 64) { L(128, 64); }

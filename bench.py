@@ -302,7 +302,8 @@ def main():
     # Roofline timing lives INSIDE the timed region: every launch of the streaming GEMM / recurrence kernel families is
     # bracketed by HIP events on the launch stream (<1 % of wall time for the default workload).
     ROOF_TAGS = ("fwd_fused2", "fwd_fused2_k64", "fwd_hidden", "bwd_dx", "bwd_dx_dw1", "dw_hidden", "fwd_wide", "dw_input",
-                 "tangent_wide", "gru_fwd", "gru_bwd", "update_fwd", "update_bwd", "update_logp", "update_fwd_critic")
+                 "tangent_wide", "tangent_hidden", "gru_fwd", "gru_bwd", "update_fwd", "update_bwd", "update_logp",
+                 "update_fwd_critic", "fwd_panel", "bwd_panel")
     if not args.no_kernel_timing:
         _lib.enable_kernel_timing(True, None if args.time_all_tags else ROOF_TAGS)
     t0 = time.perf_counter()

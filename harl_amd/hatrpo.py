@@ -107,7 +107,7 @@ class HATRPO(OnPolicyBase):
             Wp, _ = net._packs[l]
             Wpd, bpd = packs_d[l]
             call("harl_mlp_tangent_hidden", ptr(ws["xd"][l - 1]), ptr(net.xh[l - 1]), m, hs[l - 1], hs[l], ptr(Wp), ptr(Wpd),
-                 ptr(bpd), ptr(net.xh[l]), ptr(net.rmask[l]), ptr(net.rstd[l]), ptr(ws["xd"][l]), s)
+                 ptr(bpd), ptr(net.xh[l]), ptr(net.rmask[l]), ptr(net.rstd[l]), ptr(ws["xd"][l]), s, tag="tangent_hidden")
         fx, fmask, frstd, fh = net.feat()
         xLdot = ws["xd"][-1]
         mv, mp_ = 0, 0

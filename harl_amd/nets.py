@@ -226,11 +226,18 @@ class _FlatNet(nn.Module):
         step re-folds inside harl_adam_fold)."""
         if not self._packs:
             self._build_tables()
+        # nothing touched the parameters through torch since the packs were last made consistent with them (the optimiser
+        # kernel updates parameters AND packs together, without going through torch): the ten launches would rewrite the
+        # same values -- 200 such launches per update in the 8-agent recurrent configuration
+        ver = self.flat_param._version
+        if getattr(self, "_fold_version", None) == ver and os.environ.get("HARL_ALWAYS_FOLD", "0") != "1":
+            return
         s = stream()
         fp, pa = self.flat_param, self.pack_arena
         for (wo, bo, go, beo, o, k), (pw, pb, _, _) in zip(self._entries(), self._pack_slots):
             call("harl_fold_linear", ptr(fp[wo:]), ptr(fp[bo:]), ptr(fp[go:]) if go >= 0 else None,
                  ptr(fp[beo:]) if beo >= 0 else None, ptr(pa[pw:]), ptr(pa[pb:]), o, k, s)
+        self._fold_version = ver
 
     # ---- workspaces -------------------------------------------------------------------------
     def _ensure_ws(self, M: int) -> None:

@@ -137,6 +137,20 @@ def _update_bwd(a: Sequence) -> float:  # (x0n, dz2, M, D, H, ...): the normalis
     return a[2] * (4.0 * _kp(a[3]) + 4.0 * a[4])
 
 
+def _panel_fwd(a: Sequence) -> float:  # (xin, M, KP, Wp, D, bp, HO, xout, relu_mask, rstd, stream)
+    return a[1] * (4.0 * a[2] + _act(a[6]))
+
+
+def _panel_bwd(a: Sequence) -> float:  # (dz, xprev, relu_mask_prev, rstd_prev, M, HO, HI, Wp, dz_prev, stream)
+    return a[4] * (4.0 * a[5] + _act(a[6]) + 4.0 * a[6])
+
+
+def _tangent_hidden(a: Sequence) -> float:
+    # (xin_dot, xin, M, HI, HO, Wp, Wdp, bdp, xprimal, mask_in, rstd_in, xout_dot, stream): both inputs, the primal x_hat / mask /
+    # rstd of the layer, the tangent out (the raw intermediate of the two-GEMM formulation is traffic, not algorithm)
+    return a[2] * (2 * 4.0 * a[3] + _act(a[4]) + 4.0 * a[4])
+
+
 def _gae(a: Sequence) -> float:
     # rewards, value_preds (T+1), masks (T+1), bad_masks (T+1) in; returns (T+1), advantages out
     T, n = a[8], a[9]
@@ -164,6 +178,9 @@ ALGORITHMIC_BYTES: Dict[str, Callable[[Sequence], float]] = {
     "harl_update_values": _update_values,
     "harl_update_bwd": _update_bwd,
     "harl_gae_returns": _gae,
+    "harl_mlp_panel_fwd": _panel_fwd,
+    "harl_mlp_panel_bwd": _panel_bwd,
+    "harl_mlp_tangent_hidden": _tangent_hidden,
 }
 
 

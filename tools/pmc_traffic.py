@@ -21,7 +21,10 @@ import sys
 GROUPS = [
     (r"void k_fwd_fused2x<", ("fwd_fused2", "fwd_fused2_k64")),
     (r"void k_fwd_fused2<", ("fwd_fused2",)),
-    (r"void k_fwd_hidden<", ("fwd_hidden",)),
+    (r"void k_fwd_hidden<\d+, \d+, 0>", ("fwd_hidden",)),
+    (r"void k_fwd_hidden<\d+, \d+, [12]>", ("tangent_hidden",)),
+    (r"void k_panel<false>", ("fwd_panel",)),
+    (r"void k_panel<true>", ("bwd_panel",)),
     (r"void k_bwd_dx<\d+, \d+, 0>", ("bwd_dx",)),
     (r"void k_bwd_dx<\d+, \d+, [1-9]>", ("bwd_dx_dw1",)),
     (r"void k_dw(_split<|<0)", ("dw_hidden", "dw_gru", "dw_input")),

@@ -226,9 +226,10 @@ class _FlatNet(nn.Module):
         step re-folds inside harl_adam_fold)."""
         if not self._packs:
             self._build_tables()
-        # nothing touched the parameters through torch since the packs were last made consistent with them (the optimiser
-        # kernel updates parameters AND packs together, without going through torch): the ten launches would rewrite the
-        # same values -- 200 such launches per update in the 8-agent recurrent configuration
+        # nothing touched the parameters through torch since the packs were last made consistent with them INSIDE this update
+        # (the optimiser kernel updates parameters AND packs together, without going through torch): the ten launches would
+        # rewrite the same values -- 200 such launches per update in the 8-agent recurrent configuration.  Every train() entry
+        # point drops the marker (invalidate_caches), so writes behind torch's back between updates are still picked up.
         ver = self.flat_param._version
         if getattr(self, "_fold_version", None) == ver and os.environ.get("HARL_ALWAYS_FOLD", "0") != "1":
             return
@@ -322,6 +323,9 @@ class _FlatNet(nn.Module):
         (between log-prob passes over the same tensor) must call it themselves."""
         self._x0n_key = None
         self._x0n_src = None
+        # ... and the first fold() of every update re-folds unconditionally (see fold(): the version counter does not see
+        # parameter writes through ``.data`` either)
+        self._fold_version = None
 
     def forward_trunk(self, X: torch.Tensor, idx: Optional[torch.Tensor], M: int, for_backward: bool = True,
                       seq: Optional[dict] = None) -> None:
@@ -504,6 +508,7 @@ class _FlatNet(nn.Module):
 
     def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):  # keep views, then refold
         out = super().load_state_dict(state_dict, strict=strict, assign=False)
+        self._fold_version = None
         self.fold()
         return out
 

@@ -73,6 +73,8 @@ SIGNATURES = {
     "harl_update_values": [_vp, _l, _i, _i] + [_vp] * 7 + [_vp],
     "harl_update_bwd": [_vp, _vp, _l, _i, _i] + [_vp] * 5 + [_i, _vp],
     "harl_head_blocks": [_l],
+    "harl_trpo_fvp_finish": [_vp, _vp, _vp, _vp, _l, _f, _f, _l, _i, _f, _f, _vp],
+    "harl_trpo_cg_step": [_vp, _vp, _vp, _vp, _l, _vp, _vp],
     "harl_mlp_panel_fwd": [_vp, _l, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp],
     "harl_mlp_panel_bwd": [_vp, _vp, _vp, _vp, _l, _i, _i, _vp, _vp, _vp],
     "harl_reduce_scalars": [_vp, _i, _vp, _vp],

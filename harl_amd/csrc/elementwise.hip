@@ -803,3 +803,94 @@ extern "C" int harl_adam_fold(float *param, float *grad, float *exp_avg, float *
                      (float)(1.0 - beta1), (float)(1.0 - beta2), eps, weight_decay, bc2_sqrt, (unsigned *)ws);
   return check_launch("harl_adam_fold");
 }
+
+// =============================================================================================
+// HATRPO host-side vector algebra, fused (harl/utils/trpo_util.py:96-158).  The conjugate-gradient loop and the epilogue of
+// the Fisher-vector product are a dozen P-sized torch ops each: ~6 500 tiny launches per 17-agent update.  One launch each:
+//   harl_trpo_fvp_finish : out = grad / m  (log_std block: 2 (dsigma/dls)^2 / sigma^2 * vec)  + damping * vec
+//   harl_trpo_cg_step    : alpha = done ? 0 : rdotr / (p . avp);  x += alpha p;  r -= alpha avp;  new = r . r;
+//                          p = done ? p : r + (new / rdotr) p;  rdotr = new;  done |= rdotr < 1e-10
+// Element-wise arithmetic in the reference's fp32 operation order (contraction off); dot products accumulate in fp64.
+// =============================================================================================
+__global__ __launch_bounds__(256) void k_trpo_fvp_finish(const float *__restrict__ grad, const float *__restrict__ vec,
+                                                         const float *__restrict__ log_std, float *__restrict__ out, long n,
+                                                         float m_global, float damping, long ls_off, int act_dim,
+                                                         float xc, float yc) {
+#pragma clang fp contract(off)
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float o;
+    if (ls_off >= 0 && i >= ls_off && i < ls_off + act_dim) {
+      const float ls = log_std[i - ls_off];
+      const float sg = 1.0f / (1.0f + expf(-(ls / xc)));
+      const float sigma = sg * yc;
+      const float dsig = yc * sg * (1.0f - sg) / xc;
+      o = (2.0f * dsig * dsig / (sigma * sigma)) * vec[i];
+    } else {
+      o = grad[i] / m_global;
+    }
+    const float t = damping * vec[i];
+    out[i] = o + t;
+  }
+}
+
+extern "C" int harl_trpo_fvp_finish(const float *grad, const float *vec, const float *log_std, float *out, long n,
+                                    float m_global, float damping, long logstd_off, int act_dim, float std_x_coef,
+                                    float std_y_coef, void *stream) {
+  if (n <= 0) return 0;
+  long nb = (n + 255) / 256;
+  if (nb > 1024) nb = 1024;
+  hipLaunchKernelGGL(k_trpo_fvp_finish, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, grad, vec, log_std, out, n,
+                     m_global, damping, log_std ? logstd_off : -1, act_dim, std_x_coef, std_y_coef);
+  return check_launch("harl_trpo_fvp_finish");
+}
+
+__device__ __forceinline__ double block_sum_d(double v, double *sh) {  // 1024 threads -> every thread gets the sum
+  v = wave_reduce_sum_d(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();  // sh may still be read from the previous reduction
+  if (lane == 0) sh[wave] = v;
+  __syncthreads();
+  double t = 0.0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) t += sh[w];
+  return t;
+}
+
+__global__ __launch_bounds__(1024) void k_trpo_cg_step(float *__restrict__ x, float *__restrict__ r, float *__restrict__ p,
+                                                       const float *__restrict__ avp, long n, float *__restrict__ state) {
+#pragma clang fp contract(off)
+  __shared__ double sh[16];
+  const float rdotr = state[0];
+  const bool done = state[1] != 0.f;
+  double d = 0.0;
+  for (long i = threadIdx.x; i < n; i += 1024) d += (double)p[i] * (double)avp[i];
+  const float pavp = (float)block_sum_d(d, sh);
+  const float alpha = done ? 0.f : rdotr / pavp;
+  double rr = 0.0;
+  for (long i = threadIdx.x; i < n; i += 1024) {
+    const float ap = alpha * p[i];
+    x[i] = x[i] + ap;
+    const float aa = alpha * avp[i];
+    const float rn = r[i] - aa;
+    r[i] = rn;
+    rr += (double)rn * (double)rn;
+  }
+  const float new_rdotr = (float)block_sum_d(rr, sh);
+  if (!done) {
+    const float beta = new_rdotr / rdotr;
+    for (long i = threadIdx.x; i < n; i += 1024) {
+      const float bp = beta * p[i];
+      p[i] = r[i] + bp;
+    }
+  }
+  if (threadIdx.x == 0) {
+    state[0] = new_rdotr;
+    state[1] = (done || new_rdotr < 1e-10f) ? 1.f : 0.f;
+  }
+}
+
+extern "C" int harl_trpo_cg_step(float *x, float *r, float *p, const float *avp, long n, float *state, void *stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(k_trpo_cg_step, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, r, p, avp, n, state);
+  return check_launch("harl_trpo_cg_step");
+}

@@ -133,20 +133,20 @@ class HATRPO(OnPolicyBase):
              int(net.discrete), net.act_dim, ptr(avail), mv, mp_, ptr(net.dz[0]), ptr(net.dhead), s)
         net.backward_trunk(obs, idx, m, seq=seq)
         net.unfold_grads()
-        out = net.flat_grad.clone()
-        if not net.discrete:  # log_std block: d2 KL / d sigma^2 = 2 / sigma^2 per sample, sigma = sigmoid(ls/xc) yc
-            off, shape = net.offsets["act.action_out.log_std"]
-            out[off:off + net.act_dim] = 0.0
+        g = net.flat_grad
         if self.comm.enabled:
-            self.comm.all_reduce_sum(out)
-        out = out / float(m_global)  # kl.mean() over the (global) batch
-        if not net.discrete:
-            ls = net.log_std()
-            sg = torch.sigmoid(ls / net.std_x_coef)
-            sigma = sg * net.std_y_coef
-            dsig = net.std_y_coef * sg * (1.0 - sg) / net.std_x_coef
-            out[off:off + net.act_dim] = (2.0 * dsig * dsig / (sigma * sigma)) * vec[off:off + net.act_dim]
-        return out + 0.1 * vec
+            g = g.clone()
+            if not net.discrete:  # the log_std block is analytic (below), not part of the all-reduced sum
+                off0 = net.offsets["act.action_out.log_std"][0]
+                g[off0:off0 + net.act_dim] = 0.0
+            self.comm.all_reduce_sum(g)
+        # kl.mean() over the (global) batch, the analytic log_std block (d2 KL / d sigma^2 = 2 / sigma^2 per sample, sigma =
+        # sigmoid(ls / xc) yc) and the 0.1 damping in ONE launch (csrc/elementwise.hip)
+        out = torch.empty_like(vec)
+        ls_off = -1 if net.discrete else net.offsets["act.action_out.log_std"][0]
+        call("harl_trpo_fvp_finish", ptr(g), ptr(vec), ptr(net.log_std()), ptr(out), out.numel(), float(m_global), 0.1,
+             int(ls_off), net.act_dim, net.std_x_coef, net.std_y_coef, s)
+        return out
 
     def _head_outputs(self, obs, m, actions, avail, reuse_trunk=False, seq=None, avail_rows=None) -> torch.Tensor:
         """Distribution parameters at the current weights: Gaussian mean / normalised logits, [rows, act_dim].
@@ -195,18 +195,10 @@ class HATRPO(OnPolicyBase):
         # and p from then on -- the same iterates, no host round trip per iteration, at the price of idle FVPs after a break).
         x = torch.zeros_like(g)
         r, p = g.clone(), g.clone()
-        rdotr = torch.dot(r, r)
-        done = torch.zeros((), dtype=torch.bool, device=g.device)
-        zero = torch.zeros((), dtype=g.dtype, device=g.device)
+        state = torch.stack([torch.dot(r, r), torch.zeros((), dtype=g.dtype, device=g.device)])  # [r.r, done]
         for _ in range(10):
             avp = self._fvp(obs, m, m_global, avail_rows, p, seq=seq)
-            alpha = torch.where(done, zero, rdotr / torch.dot(p, avp))
-            x += alpha * p
-            r -= alpha * avp
-            new_rdotr = torch.dot(r, r)
-            p = torch.where(done, p, r + (new_rdotr / rdotr) * p)
-            rdotr = new_rdotr
-            done = done | (rdotr < 1e-10)
+            call("harl_trpo_cg_step", ptr(x), ptr(r), ptr(p), ptr(avp), x.numel(), ptr(state), stream())
         params = net.flat_param.clone()
         fv = self._fvp(obs, m, m_global, avail_rows, x, seq=seq)
         shs = 0.5 * torch.dot(x, fv)

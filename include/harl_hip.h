@@ -291,6 +291,14 @@ int harl_actor_head_fvp(const float *xL, const float *xLdot, const uint32_t *rel
                         const float *Whp, const float *bhp, const float *Whdp, const float *bhdp, const float *log_std,
                         float std_x_coef, float std_y_coef, int discrete, int act_dim, const float *avail, long m_valid,
                         long m_pad, float *dzL, float *dhead, void *stream);
+/* HATRPO's P-sized vector algebra, one launch each instead of a dozen torch ops (trpo_util.py:96-158):
+ *   harl_trpo_fvp_finish: out = grad / m_global + damping * vec, with the log_std block (offset logstd_off, act_dim entries;
+ *     log_std NULL for Categorical policies) replaced by 2 (dsigma/dlog_std)^2 / sigma^2 * vec  -- the epilogue of F v + 0.1 v.
+ *   harl_trpo_cg_step: one conjugate-gradient iteration on (x, r, p) given avp = F p; state[0] = r.r, state[1] = done flag
+ *     (the reference's `if rdotr < 1e-10: break`, kept on the device: a finished solve freezes x, r and p). */
+int harl_trpo_fvp_finish(const float *grad, const float *vec, const float *log_std, float *out, long n, float m_global,
+                         float damping, long logstd_off, int act_dim, float std_x_coef, float std_y_coef, void *stream);
+int harl_trpo_cg_step(float *x, float *r, float *p, const float *avp, long n, float *state, void *stream);
 /* out_sum (double, accumulated) += sum_s KL(old || new)_s from the head outputs of harl_actor_head_logp:
  * Gaussian analytic KL in fp64 (trpo_util.py:54-62), Categorical kl_approx on normalised logits (trpo_util.py:47-51) */
 int harl_trpo_kl_sum(const float *head_old, const float *head_new, const float *log_std_old, const float *log_std_new,

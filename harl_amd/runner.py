@@ -427,6 +427,49 @@ class OnPolicyHARunner:
                     lg.eval_log(done_eps)
                 return float(np.mean(ep_rewards))
 
+    @torch.no_grad()
+    def render(self, expand_dims: bool = False, manual_render: bool = False, delay: float = 0.0) -> List[float]:
+        """Roll the deterministic policy through ``algo_args['render']['render_episodes']`` episodes of ``self.envs``
+        (on_policy_base_runner.py:594-710).  ``expand_dims``: the environment is a single instance without the parallel-
+        environment axis (the reference's ``manual_expand_dims`` environments); ``manual_render`` calls ``envs.render()``
+        after every step, ``delay`` sleeps between steps.  Returns the episode returns (the reference prints them)."""
+        import time
+
+        import numpy as np
+        A = self.num_agents
+        H = self.algo_args["model"]["hidden_sizes"][-1]
+        rn = self.algo_args["model"]["recurrent_n"]
+        returns = []
+        for _ in range(self.algo_args["render"]["render_episodes"]):
+            obs, _share, avail = self.envs.reset()
+            n = 1 if expand_dims else len(obs)
+            rnn = torch.zeros(n, A, rn, H, dtype=torch.float32, device=self.device)
+            masks = torch.ones(n, A, 1, dtype=torch.float32, device=self.device)
+            total = 0.0
+            while True:
+                obs_d = torch.as_tensor(np.asarray(obs), dtype=torch.float32).to(self.device).reshape(n, A, -1)
+                no_av = avail is None or (not expand_dims and avail[0] is None)
+                av_d = None if no_av else torch.as_tensor(np.asarray(avail), dtype=torch.float32).to(self.device).reshape(n, A, -1)
+                acts = []
+                for a in range(A):
+                    act, r_ = self.actor[a].act(obs_d[:, a], rnn[:, a], masks[:, a], None if av_d is None else av_d[:, a],
+                                                deterministic=True)
+                    rnn[:, a] = r_.reshape(n, rn, H)
+                    acts.append(act)
+                actions = torch.stack(acts, 1).cpu().numpy()
+                obs, _share, rewards, dones, _infos, avail = self.envs.step(actions[0] if expand_dims else actions)
+                r0, d0 = np.asarray(rewards), np.asarray(dones)
+                total += float(r0.reshape(-1)[0])
+                if manual_render:
+                    self.envs.render()
+                if delay > 0.0:
+                    time.sleep(delay)
+                if bool(d0.reshape(-1)[0]):
+                    print(f"total reward of this episode: {total}")
+                    returns.append(total)
+                    break
+        return returns
+
     def close(self):
         for e in (self.envs, getattr(self, "eval_envs", None)):
             if e is not None and hasattr(e, "close"):

@@ -474,13 +474,9 @@ def check_trpo_rnn(spec, agg: str = "prod") -> Dict[str, float]:
     kl, li, ei, ent_, ratio_ = actor.update((obs, h0, act, masks, active, old_logp, adv, avail, factor))
     torch.cuda.synchronize()
     out["cg_step_dir_vec_rel"] = vec_rel_err(taps[0][1], info["step_dir"])
-    out["step_size_rel"] = rel_err(taps[0][2], info["step_size"])
-    out["kl_rel"] = rel_err(kl, info["kl"])
-    out["loss_improve_rel"] = rel_err(li, info["loss_improve"])
-    out["expected_improve_rel"] = rel_err(ei, info["expected_improve"])
-    out["entropy_rel"] = rel_err(ent_, info["dist_entropy"])
-    out["ratio_rel"] = rel_err(ratio_, info["ratio"])
-    out["param_after_vec_rel"] = vec_rel_err(actor.actor.flat_param.cpu().numpy(), oracle.flat().numpy())
+    _trpo_update_excess(out, sd, cfg, (obs, act, active, old_logp, adv, avail, factor, h0, masks), info,
+                        dict(step_size=taps[0][2], kl=kl, loss_improve=li, expected_improve=ei, entropy=ent_, ratio=ratio_),
+                        actor.actor.flat_param.cpu().numpy(), oracle.flat().numpy(), tol=2e-5)  # the GRU tests' flat bar
     return out
 
 
@@ -583,6 +579,56 @@ def check_rnn_update(spec) -> Dict[str, float]:
     return out
 
 
+def _perturb_one_ulp(nets, seed: int) -> None:
+    """Every parameter of the oracle networks moved to a neighbouring float32, up or down at random (the perturbation of
+    oracle/gen_noise_floor.py): how far the reference's fp32 figures move under the smallest change fp32 can express."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for net in nets:
+            for v in net.p.values():
+                up = torch.rand(v.shape, generator=g) < 0.5
+                v.copy_(torch.where(up, torch.nextafter(v, torch.full_like(v, float("inf"))),
+                                    torch.nextafter(v, torch.full_like(v, float("-inf")))))
+
+
+_TRPO_N_PERT = 8
+_TRPO_UPDATE_KEYS = (("step_size", "step_size"), ("kl", "kl"), ("loss_improve", "loss_improve"),
+                     ("expected_improve", "expected_improve"), ("entropy", "dist_entropy"), ("ratio", "ratio"))
+
+
+def _trpo_update_excess(out, sd, cfg, sample, info, got, param_after, oracle_after, tol: float = 1e-5) -> None:
+    """Everything HATRPO.update() reports after the conjugate-gradient solve (step size, KL, improvements, the parameters
+    after the line search) is a function of the CG solution, i.e. carries CG's amplification of rounding differences.
+    Those figures get the bar of the golden tests (tests/helpers.excess): max(1e-5, NOISE_FACTOR x the reference's OWN
+    uncertainty), the uncertainty measured here as its distance from the same update in fp64 and from the same fp32 update
+    with every initial parameter moved by one ulp (max over _TRPO_N_PERT draws)."""
+    t = lambda d_: {k: torch.from_numpy(v) for k, v in d_.items()}  # noqa: E731
+    O.set_work_dtype(torch.float64)
+    try:
+        o64 = O.OracleHATRPO(t(sd), cfg, O.TrpoConfig())
+        i64 = o64.update(sample)
+        p64 = o64.flat().numpy().astype(np.float64)
+    finally:
+        O.set_work_dtype(torch.float32)
+    f = lambda x: float(np.asarray(x).reshape(-1)[0])  # noqa: E731
+    pa = oracle_after.astype(np.float64)
+    sens = {name: 0.0 for name, _ in _TRPO_UPDATE_KEYS}
+    psens = 0.0
+    for k in range(_TRPO_N_PERT):  # the spread over a few independent one-ulp perturbations (a single draw can sit near 0)
+        op = O.OracleHATRPO(t(sd), cfg, O.TrpoConfig())
+        _perturb_one_ulp([op], 4242 + k)
+        ip = op.update(sample)
+        for name, key in _TRPO_UPDATE_KEYS:
+            sens[name] = max(sens[name], abs(f(ip[key]) - f(info[key])) / (abs(f(info[key])) + 1e-12))
+        psens = max(psens, vec_rel_err(op.flat().numpy(), pa))
+    for name, key in _TRPO_UPDATE_KEYS:
+        out[f"_{name}_rel"] = rel_err(got[name], f(info[key]))
+        out[f"_{name}_sens"] = sens[name]
+        out[f"{name}_excess"] = excess(got[name], f(info[key]), f(i64[key]), sens=sens[name], tol=tol)
+    out["_param_after_vec_rel"] = vec_rel_err(param_after, pa)
+    out["param_after_vec_excess"] = vec_excess(param_after, pa, p64, sens=psens, tol=tol)
+
+
 def check_trpo(spec, agg: str = "prod") -> Dict[str, float]:
     """HATRPO: surrogate gradient, one Fisher-vector product on a random vector, and one full update (CG + line
     search) vs the oracle (autograd double backward), from identical parameters and data."""
@@ -644,13 +690,9 @@ def check_trpo(spec, agg: str = "prod") -> Dict[str, float]:
     kl, li, ei, ent_, ratio_ = actor.update((obs, rnn, act, None, active, old_logp, adv, avail, factor))
     torch.cuda.synchronize()
     out["cg_step_dir_vec_rel"] = vec_rel_err(taps[0][1], info["step_dir"])
-    out["step_size_rel"] = rel_err(taps[0][2], info["step_size"])
-    out["kl_rel"] = rel_err(kl, info["kl"])
-    out["loss_improve_rel"] = rel_err(li, info["loss_improve"])
-    out["expected_improve_rel"] = rel_err(ei, info["expected_improve"])
-    out["entropy_rel"] = rel_err(ent_, info["dist_entropy"])
-    out["ratio_rel"] = rel_err(ratio_, info["ratio"])
-    out["param_after_vec_rel"] = vec_rel_err(actor.actor.flat_param.cpu().numpy(), oracle.flat().numpy())
+    _trpo_update_excess(out, sd, cfg, (obs, act, active, old_logp, adv, avail, factor), info,
+                        dict(step_size=taps[0][2], kl=kl, loss_improve=li, expected_improve=ei, entropy=ent_, ratio=ratio_),
+                        actor.actor.flat_param.cpu().numpy(), oracle.flat().numpy())
     return out
 
 
@@ -1282,6 +1324,9 @@ def _mask_relu_kinks(case, margin: float = 2e-5) -> int:
     return n_masked
 
 
+_BASELINE_N_PERT = 3
+
+
 def check_baseline_shape(name: str) -> Dict[str, float]:
     """One whole train() (one epoch per network) at a BASELINE.json configuration's real shapes and agent count against the
     oracle on the same seeded buffers: every agent's first update (policy loss / entropy / grad-norm / ratio, or HATRPO's
@@ -1311,6 +1356,20 @@ def check_baseline_shape(name: str) -> Dict[str, float]:
         fin = [np.asarray(a_.flat().numpy() if case.algo_name == "hatrpo" else a_.net.flat(), dtype=np.float64) for a_ in actors]
         runs[tag] = dict(infos=infos, cinfo=cinfo, fin=fin, cfin=np.asarray(critic.net.flat(), dtype=np.float64),
                          returns=cbuf.returns.copy())
+    # ---- HATRPO: the reported figures are functions of the CG solution, whose amplification of rounding differences a
+    # single fp32-vs-fp64 distance samples poorly (17 agents x 5 figures: some land near 0 by chance).  The bar also takes
+    # the reference's sensitivity: the same fp32 train() from initial parameters moved by one ulp (as for the goldens).
+    pert = []
+    if case.algo_name == "hatrpo":
+        for k in range(_BASELINE_N_PERT):
+            torch.manual_seed(case.seed)
+            np.random.seed(case.seed)
+            cfg, actors, critic, abufs, cbuf, vn = build_oracle(case)
+            _perturb_one_ulp(list(actors), 977 + k)
+            torch.manual_seed(case.seed + 12345)
+            cbuf.compute_returns(cbuf.value_preds[-1].copy(), vn, cfg)
+            infos, _, _ = O.ha_train(actors, critic, abufs, cbuf, vn, cfg)
+            pert.append(dict(infos=infos, fin=[np.asarray(a_.flat().numpy(), dtype=np.float64) for a_ in actors]))
     # ---- HIP path
     torch.manual_seed(case.seed)
     np.random.seed(case.seed)
@@ -1327,9 +1386,14 @@ def check_baseline_shape(name: str) -> Dict[str, float]:
             else ("policy_loss", "dist_entropy", "actor_grad_norm", "ratio"))
     tab = lambda infos_: np.array([[float(np.asarray(i[k]).reshape(-1)[0]) for k in keys] for i in infos_], dtype=np.float64)  # noqa: E731
     g, o32, o64 = tab(ginfos), tab(runs["f32"]["infos"]), tab(runs["f64"]["infos"])
+    sens = None
+    for pr in pert:
+        d_ = np.abs(tab(pr["infos"]) - o32) / (np.abs(o32) + 1e-12)
+        sens = d_ if sens is None else np.maximum(sens, d_)
     for c, k in enumerate(keys):
         out[f"_actor_{k}_rel"] = rel_err(g[:, c], o32[:, c])
-        out[f"actor_{k}_excess"] = excess(g[:, c], o32[:, c], o64[:, c])
+        out[f"actor_{k}_excess"] = excess(g[:, c], o32[:, c], o64[:, c], sens=None if sens is None else sens[:, c])
+        out[f"_actor_{k}_at"] = excess_at(g[:, c], o32[:, c], o64[:, c], sens=None if sens is None else sens[:, c])
     gc = [gcinfo["value_loss"], gcinfo["critic_grad_norm"]]
     c32 = [runs["f32"]["cinfo"]["value_loss"], runs["f32"]["cinfo"]["critic_grad_norm"]]
     c64 = [runs["f64"]["cinfo"]["value_loss"], runs["f64"]["cinfo"]["critic_grad_norm"]]
@@ -1338,7 +1402,8 @@ def check_baseline_shape(name: str) -> Dict[str, float]:
     worst = 0.0
     for a in range(case.shapes.A):
         fp = r.actor[a].actor.flat_param.cpu().numpy()
-        worst = max(worst, vec_excess(fp, runs["f32"]["fin"][a], runs["f64"]["fin"][a]))
+        ps = max([vec_rel_err(pr["fin"][a], runs["f32"]["fin"][a]) for pr in pert], default=None)
+        worst = max(worst, vec_excess(fp, runs["f32"]["fin"][a], runs["f64"]["fin"][a], sens=ps))
         out["_actor_final_param_vec_rel_max"] = max(out.get("_actor_final_param_vec_rel_max", 0.0), vec_rel_err(fp, runs["f32"]["fin"][a]))
     out["actor_final_param_excess"] = worst
     out["critic_final_param_excess"] = vec_excess(r.critic.critic.flat_param.cpu().numpy(), runs["f32"]["cfin"], runs["f64"]["cfin"])
@@ -1437,6 +1502,11 @@ def check_run_eval_save_restore(tmpdir: str) -> Dict[str, float]:
     d = max(d, float((r.critic.critic.flat_param - r2.critic.critic.flat_param).abs().max().item()))
     d = max(d, float((r.value_normalizer.stats - r2.value_normalizer.stats).abs().max().item()))
     out["restored_param_max_abs"] = d
+    # render(): deterministic episodes of the restored policy on a vectorised environment (on_policy_base_runner.py:594-710)
+    r2.algo_args["render"] = dict(render_episodes=2)
+    r2.envs = FakeVecEnv(4, n_agents=3, state_dim=6, act_dim=2, horizon=25, seed=9)
+    rets = r2.render()
+    out["render_episodes_mismatch"] = float(len(rets) != 2 or not all(np.isfinite(rets)))
     r.close()
     r2.close()
     return out

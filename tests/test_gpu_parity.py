@@ -92,9 +92,8 @@ def test_hatrpo_gru_gradient_fvp_and_update(i):
     res = G.check_trpo_rnn(G.RNN_SHAPES[i])
     cg = res.pop("cg_step_dir_vec_rel")
     assert cg < 2e-4, cg
-    # the step size 1 / sqrt(x.Fx / 2 delta) is a function of the CG solution x: same amplification, half the exponent
-    ss = res.pop("step_size_rel")
-    assert ss < 1e-4, ss
+    # everything update() reports after the CG solve (*_excess) is held to max(1e-5, 2 x the oracle's own measured
+    # uncertainty) -- gpu_checks._trpo_update_excess; gradient, FVP and surrogate loss to the flat tolerance
     _assert_all(res, tol=2e-5)
 
 

@@ -78,6 +78,10 @@ SIGNATURES = {
     "harl_mlp_panel_fwd": [_vp, _l, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp],
     "harl_mlp_panel_bwd": [_vp, _vp, _vp, _vp, _l, _i, _i, _vp, _vp, _vp],
     "harl_reduce_scalars": [_vp, _i, _vp, _vp],
+    "harl_mlp_linear": [_vp, _l, _i, _i, _vp, _vp, _vp, _vp],
+    "harl_md_head_logp": [_vp, _i, _vp, _i, _vp, _vp, _l, _vp, _vp, _vp, _i, _vp, _i, _vp, _l, _l, _vp],
+    "harl_md_head_loss": [_vp, _vp, _i, _vp, _i, _vp, _vp, _l, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _d, _f, _i, _i,
+                          _l, _l, _vp, _vp, _i, _vp],
     "harl_version": [],
 }
 

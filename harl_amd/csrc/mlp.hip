@@ -1254,6 +1254,30 @@ extern "C" int harl_mlp_tangent_hidden(const float *xin_dot, const float *xin, l
   return check_launch("harl_mlp_tangent_hidden");
 }
 
+// plain Linear, no epilogue: xout = Wp xin + bp as an ATL(HO) image (k_fwd_hidden MODE 1) -- the logits of the concatenated
+// MultiDiscrete heads (csrc/multihead.hip); Wp is [HO][HI] with zero rows past the last head
+extern "C" int harl_mlp_linear(const float *xin, long M, int HI, int HO, const float *Wp, const float *bp, float *xout,
+                               void *stream) {
+  if (M <= 0) return 0;
+  const long n_slabs = n_slabs_of(M);
+  const size_t shm = split_image_bytes(HO, HI) + (size_t)HO * sizeof(float);
+  const int grid = persistent_grid(n_slabs, split_one_wg(HO, HI) ? 1 : 2);
+  hipStream_t s = (hipStream_t)stream;
+#define L(a, b)                                                                                                      \
+  {                                                                                                                  \
+    allow_big_lds(k_fwd_hidden<a, b, 1>, shm);                                                                       \
+    hipLaunchKernelGGL((k_fwd_hidden<a, b, 1>), dim3(grid), dim3(WG_THREADS), shm, s, xin, Wp, bp, xout, nullptr, nullptr, \
+                       n_slabs, nullptr, nullptr, nullptr);                                                          \
+  }
+  if (HI == 128 && HO == 128) L(128, 128)
+  else if (HI == 64 && HO == 64) L(64, 64)
+  else if (HI == 128 && HO == 64) L(128, 64)
+  else if (HI == 64 && HO == 128) L(64, 128)
+  else return bad("harl_mlp_linear: widths must be 64 or 128");
+#undef L
+  return check_launch("harl_mlp_linear");
+}
+
 extern "C" int harl_mlp_fwd_fused2(const float *X, long ldx, const int64_t *idx, long M, int D, const float *W1p,
                                    const float *b1p, int use_ln0, const float *W2p, const float *b2p, int H, int store1,
                                    float *x1out, uint32_t *mask1, float *rstd1, float *mu0, float *rstd0, float *x2out,

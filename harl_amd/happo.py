@@ -58,6 +58,14 @@ class OnPolicyBase:
         resets.  Returns the final hidden state [m, H] when ``h_last`` is set."""
         net = self.actor
         agg = int(self.action_aggregation == "mean")
+        if net.md and not net.recurrent:  # MultiDiscrete: trunk -> logits of every group -> per-head log-softmax
+            if not reuse_trunk:
+                net.forward_trunk(obs, None, M, for_backward=False)
+            net.md_logits(M)
+            call("harl_md_head_logp", *net.md_layout(), M, ptr(actions), ptr(logp_out), ptr(old_logp),
+                 0 if old_logp is None else old_logp.shape[1], ptr(factor), agg, ptr(head_out), 0, 0, stream(),
+                 tag="md_head_logp")
+            return None
         if not reuse_trunk and net.fused_update_ok(None, train=False):  # forward + head in one launch, x_hat_2 never leaves the chip
             call("harl_update_logp", *net.fused_args(obs, M), ptr(net.log_std()), net.std_x_coef, net.std_y_coef,
                  int(net.discrete), net.act_dim, ptr(actions), ptr(avail), ptr(logp_out), ptr(old_logp), ptr(factor), agg,
@@ -85,9 +93,15 @@ class OnPolicyBase:
         net.forward_trunk(obs, idx, Mp, for_backward=False, seq=seq)
         fx, _, _, fh = net.feat()
         Wp, bp = net._packs[-1]
-        call("harl_actor_head_logp", ptr(fx), Mp, fh, ptr(Wp), ptr(bp), ptr(net.log_std()), net.std_x_coef,
-             net.std_y_coef, int(net.discrete), net.act_dim, ptr(a_p), ptr(av_p), ptr(lo_p), ptr(old_p), ptr(f_p), agg,
-             ptr(ho_p), m, seq["m_pad"], stream(), tag="actor_head_logp")
+        if net.md:
+            net.md_logits(Mp)
+            call("harl_md_head_logp", *net.md_layout(), Mp, ptr(a_p), ptr(lo_p), ptr(old_p),
+                 0 if old_p is None else old_p.shape[1], ptr(f_p), agg, ptr(ho_p), m, seq["m_pad"], stream(),
+                 tag="md_head_logp")
+        else:
+            call("harl_actor_head_logp", ptr(fx), Mp, fh, ptr(Wp), ptr(bp), ptr(net.log_std()), net.std_x_coef,
+                 net.std_y_coef, int(net.discrete), net.act_dim, ptr(a_p), ptr(av_p), ptr(lo_p), ptr(old_p), ptr(f_p), agg,
+                 ptr(ho_p), m, seq["m_pad"], stream(), tag="actor_head_logp")
         if padded:
             for dst, src in ((logp_out, lo_p), (head_out, ho_p), (factor, f_p)):
                 if dst is not None:
@@ -110,6 +124,9 @@ class OnPolicyBase:
         head = torch.empty(M, net.act_dim, **self.tpdv)
         net.fold()
         self._logp_pass(obs, action, avail, M, out, head_out=head, rnn_states=rnn_states_actor, masks=masks)
+        if net.md:  # act.py:117-141: no distribution object; entropy = (1/m) sum_rows sum_heads H (never mask-weighted)
+            ent_rows = -(torch.clamp(head, min=torch.finfo(torch.float32).min) * torch.exp(head)).sum(-1, keepdim=True)
+            return out, ent_rows.mean(), None
         if net.discrete:  # head = normalised logits (masked entries ~ -1e10): Categorical(logits=...).entropy()
             dist = torch.distributions.Categorical(logits=head)
             p = torch.exp(head)
@@ -144,6 +161,15 @@ class OnPolicyBase:
                             h_last=True)  # head_out only: no actions needed
         if net.recurrent:
             rnn_out = h.reshape(M, 1, -1).clone()
+        if net.md:  # act.py:56-73: one draw per head, log-probs summed to [B, 1]
+            acts, lps, lo = [], [], 0
+            for n in net.nvec:
+                hl = head[:, lo:lo + n]
+                a = hl.argmax(dim=-1, keepdim=True) if deterministic else torch.multinomial(torch.exp(hl), 1)
+                acts.append(a.to(torch.float32))
+                lps.append(hl.gather(-1, a))
+                lo += n
+            return torch.cat(acts, -1), torch.cat(lps, -1).sum(-1, keepdim=True), rnn_out
         if net.discrete:  # head = normalised logits (masked entries ~ -1e10)
             if deterministic:
                 actions = head.argmax(dim=-1, keepdim=True).to(torch.float32)
@@ -204,6 +230,16 @@ class HAPPO(OnPolicyBase):
         Wp, bp = net._packs[-1]
         fx, fmask, frstd, fh = net.feat()
         mv, mp = (seq["m"], seq["m_pad"]) if seq is not None else (0, 0)
+        if net.md:  # MultiDiscrete (csrc/multihead.hip): logits GEMM, per-sample loss -> d(logits) in place, layer-kernel backward
+            net.md_logits(m)
+            nblk = _lib.load().harl_head_blocks(m)
+            lay = net.md_layout()
+            call("harl_md_head_loss", lay[0], *lay, m, ptr(idx), ptr(actions), ptr(old_logp), old_logp.shape[1], ptr(adv),
+                 ptr(adv_moments), ptr(factor), ptr(active), ptr(self._md_ent_scale(idx, m, active, seq)),
+                 float(self.clip_param), float(self.entropy_coef), int(self.action_aggregation == "mean"),
+                 self._surrogate_mode, mv, mp, ptr(logp_out), ptr(net.part_scalars), nblk, s, tag="md_head_loss")
+            net.backward_trunk(obs, idx, m, seq=seq)
+            return nblk
         call("harl_actor_head_loss", ptr(fx), ptr(fmask), ptr(frstd), m, fh,
              ptr(Wp), ptr(bp), ptr(net.log_std()), net.std_x_coef, net.std_y_coef, int(net.discrete), net.act_dim,
              ptr(idx), ptr(actions), ptr(avail), ptr(old_logp), ptr(adv), ptr(adv_moments), ptr(factor), ptr(active),
@@ -213,6 +249,24 @@ class HAPPO(OnPolicyBase):
              tag="actor_head_loss")  # head dW fused into this launch (heads of 33..64 actions: separate dW pass)
         net.backward_trunk(obs, idx, m, seq=seq, head_dw_done=not net.wide_head)
         return net.n_wg if not net.wide_head else _lib.load().harl_head_blocks(m)  # rows of part_scalars
+
+    def _md_ent_scale(self, idx, m, active, seq) -> Optional[torch.Tensor]:
+        """MultiDiscrete: device scalar sum(active) / rows of the (global) minibatch.  The reference's entropy bonus there is
+        (1/rows) sum_rows sum_heads H while the surrogate is divided by sum(active) (act.py:126-139, happo.py:77-81); the
+        optimiser kernel applies ONE scale 1 / sum(active) to the whole gradient, so the entropy part carries this ratio.
+        None (= 1) without active masks."""
+        if active is None:
+            return None
+        if seq is not None:      # L x m_pad rows, padding rows addressed through idx but not counted
+            j = torch.arange(m, device=self.device)
+            live = (j % seq["m_pad"]) < seq["m"]
+            rows = idx[live] if idx is not None else j[live]
+            st = torch.stack([active[rows].sum(), torch.tensor(float(rows.numel()), device=self.device)])
+        else:
+            a = active if idx is None else active[idx]
+            st = torch.stack([a.sum(), torch.tensor(float(m), device=self.device)])
+        self.comm.all_reduce_sum(st)
+        return (st[0] / st[1]).reshape(1).contiguous()
 
     def _optimizer_step(self, nblk: Optional[int]):
         """[data-parallel all-reduce] + fused scalar reduce / unfold / grad-norm / clip / Adam / re-fold.  ``nblk`` None:

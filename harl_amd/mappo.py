@@ -33,6 +33,8 @@ class MAPPO(HAPPO):
         the loss kernel as the summed fp64 moments; FP: per-agent slices of the runner-normalised [T, N, A, 1] tensor."""
         if self.use_recurrent_policy or self.use_naive_recurrent_policy:
             raise NotImplementedError("share_param with recurrent policies")
+        if self.actor.md:
+            raise NotImplementedError("share_param with MultiDiscrete actions")
         dev, net = self.device, self.actor
         net.invalidate_caches()
         A = num_agents

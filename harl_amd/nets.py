@@ -74,6 +74,8 @@ class _FlatNet(nn.Module):
         self.in_dim = in_dim
         self.wide = 32 < in_dim <= 512  # first layer through the cached x0n image (csrc/wide.hip); <= 32: fused 2-layer kernel
         self._x0n_key = None
+        self.md = False  # MultiDiscrete heads (StochasticPolicy)
+        self._md_sp: List[int] = []
         self._cpu_params: List[Tuple[str, torch.Tensor]] = []
         self._build_trunk_params(args)
 
@@ -112,15 +114,28 @@ class _FlatNet(nn.Module):
         self.flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
         self.offsets: Dict[str, Tuple[int, Tuple[int, ...]]] = {}
         off = 0
+        hidden = getattr(self, "_hidden_blocks", ())
         for name, t in self._cpu_params:
             n = t.numel()
             view = self.flat_param[off:off + n].view(t.shape)
             view.copy_(t.to(dev))
-            p = nn.Parameter(view, requires_grad=True)
-            p.grad = self.flat_grad[off:off + n].view(t.shape)
-            _register(self, name, p)
+            if name not in hidden:
+                p = nn.Parameter(view, requires_grad=True)
+                p.grad = self.flat_grad[off:off + n].view(t.shape)
+                _register(self, name, p)
             self.offsets[name] = (off, tuple(t.shape))
             off += n
+        # parameters that are row ranges of a hidden block (the MultiDiscrete heads: one contiguous [sum n_k, H] matrix per
+        # group in the arena, registered under the reference's per-head names and in its order)
+        for name, base, lo, hi in getattr(self, "_alias_params", ()):
+            boff, bshape = self.offsets[base]
+            rowlen = math.prod(bshape[1:])
+            o, shape = boff + lo * rowlen, (hi - lo,) + tuple(bshape[1:])
+            n = math.prod(shape)
+            p = nn.Parameter(self.flat_param[o:o + n].view(shape), requires_grad=True)
+            p.grad = self.flat_grad[o:o + n].view(shape)
+            _register(self, name, p)
+            self.offsets[name] = (o, shape)
         self.n_params = total
         del self._cpu_params
         # folded weights (W' = W diag(gamma_prev), b' = b + W beta_prev), one pack per Linear incl. the head
@@ -144,18 +159,23 @@ class _FlatNet(nn.Module):
             out.append((f"base.mlp.fc.{3*i}.weight", f"base.mlp.fc.{3*i}.bias", g[0], g[1], h, d))
             g = (f"base.mlp.fc.{3*i+2}.weight", f"base.mlp.fc.{3*i+2}.bias")
             d = h
-        hw, hb, hdim = self._head_names()
         if self.recurrent:
             g = ("rnn.norm.weight", "rnn.norm.bias")
-        out.append((hw, hb, g[0], g[1], hdim, d))
+        for hw, hb, hdim in self._head_layers():
+            out.append((hw, hb, g[0], g[1], hdim, d))
         return out
+
+    def _head_layers(self) -> List[Tuple[str, str, int]]:
+        """The Linear(s) on top of the trunk: one head, or one per MultiDiscrete group (StochasticPolicy)."""
+        return [self._head_names()]
 
     def _entries(self) -> List[Tuple[int, int, int, int, int, int]]:
         """Every Linear-like block in TABLE order as (w_off, b_off, gamma_off, beta_off, out, in) offsets into the flat
         arena: MLP layers, [GRU W_ih gate blocks r,z,n (folded with the last MLP LayerNorm), GRU W_hh gate blocks], head."""
         off = lambda n: self.offsets[n][0] if n else -1  # noqa: E731
         layers = self._layers()
-        ents = [(off(w), off(b), off(g), off(be), o, k) for (w, b, g, be, o, k) in layers[:-1]]
+        nh = len(self._head_layers())
+        ents = [(off(w), off(b), off(g), off(be), o, k) for (w, b, g, be, o, k) in layers[:-nh]]
         if self.recurrent:
             H = self.hidden_sizes[-1]
             i = len(self.hidden_sizes) - 1
@@ -164,8 +184,8 @@ class _FlatNet(nn.Module):
                 ents.append((off("rnn.rnn.weight_ih_l0") + gate * H * H, off("rnn.rnn.bias_ih_l0") + gate * H, g, be, H, H))
             for gate in range(3):
                 ents.append((off("rnn.rnn.weight_hh_l0") + gate * H * H, off("rnn.rnn.bias_hh_l0") + gate * H, -1, -1, H, H))
-        (w, b, g, be, o, k) = layers[-1]
-        ents.append((off(w), off(b), off(g), off(be), o, k))
+        for (w, b, g, be, o, k) in layers[-nh:]:
+            ents.append((off(w), off(b), off(g), off(be), o, k))
         return ents
 
     def _head_names(self) -> Tuple[str, str, int]:
@@ -191,12 +211,16 @@ class _FlatNet(nn.Module):
             else:
                 if self.recurrent and ei == L:
                     pass
-                pw, pb = pack_off, pack_off + o * k
-                pack_off += o * k + o
+                # MultiDiscrete group: the GEMM kernels read a full [sp][k] matrix (zero rows past the last head)
+                orows = self._md_sp[ei - (len(ents) - len(self._md_sp))] if (self.md and ei >= len(ents) - len(self._md_sp)) else o
+                pw, pb = pack_off, pack_off + orows * k
+                pack_off += orows * k + orows
                 if self.recurrent and ei == L - 1:  # reserve the GRU block right after the last MLP layer
                     self._gru_pack_base = pack_off
                     pack_off += 2 * (3 * H * H + 3 * H)
             kp, op = ((k + 31) // 32) * 32, ((o + 31) // 32) * 32
+            if self.md and ei >= len(ents) - len(self._md_sp):
+                op = self._md_sp[ei - (len(ents) - len(self._md_sp))]  # partial layout of harl_mlp_dw_partials(HO = sp)
             elems = op * kp + op
             rows.append([wo, bo, go, beo, o, k, pw, pb, dwp_off, kp, op, 0])
             pack_slots.append((pw, pb, o, k))
@@ -205,7 +229,7 @@ class _FlatNet(nn.Module):
             dwp_off += elems
         self._table_rows = rows
         self.n_entries = len(rows)
-        self.pack_arena = torch.empty(pack_off, dtype=torch.float32, device=dev)
+        self.pack_arena = torch.zeros(pack_off, dtype=torch.float32, device=dev)
         # the dense folded gradients live at the head of the data-parallel all-reduce message: [dwp | 4 fixed-grid scalar pieces] (dist.py)
         self.dwp_msg = torch.zeros(dwp_off + 4 * PS_STRIDE, dtype=torch.float32, device=dev)
         self.dwp = self.dwp_msg[:dwp_off]
@@ -213,6 +237,8 @@ class _FlatNet(nn.Module):
         self._pack_slots = pack_slots
         views = [(self.pack_arena[pw:pw + o * k], self.pack_arena[pb:pb + o]) for (pw, pb, o, k) in pack_slots]
         self._packs = views[:L] + [views[-1]]  # MLP layers by index, head last (callers use [l] and [-1])
+        nh = len(self._head_layers())
+        self._head_packs = views[-nh:]          # every head entry (MultiDiscrete: one per group)
         if self.recurrent:
             b0 = self._gru_pack_base
             n = 3 * H * H
@@ -263,8 +289,10 @@ class _FlatNet(nn.Module):
         hmax = max(self.hidden_sizes)
         self.dz = [torch.empty(mp * hmax, dtype=f32, device=dev) for _ in range(2)]            # ping-pong, ATL
         # head gradients for the separate dW pass: row-major [mp][32], or the ATL(64) image of a 33..64-way Categorical head
-        self.wide_head = self._layers()[-1][4] > 32
+        self.wide_head = (not self.md) and self._layers()[-1][4] > 32
         self.dhead = torch.zeros(mp * (64 if self.wide_head else DHEAD_LD), dtype=f32, device=dev)
+        # MultiDiscrete: one logits image per group; the loss kernel overwrites it with d(loss)/d(logits)
+        self.md_z = [torch.zeros(mp * sp, dtype=f32, device=dev) for sp in self._md_sp]
         n_iter = (n_slabs + 1) // 2
         self.n_wg = max(1, min(512, n_iter))
         part_off, rows = 0, [list(r) for r in self._table_rows]
@@ -393,7 +421,7 @@ class _FlatNet(nn.Module):
         mode = os.environ.get("HARL_FUSED_UPDATE", "logp")
         if mode == "0" or (train and mode == "logp") or (train and mode == "actor" and isinstance(self, VNet)):
             return False
-        return (not self.recurrent and idx is None and seq is None
+        return (not self.recurrent and not self.md and idx is None and seq is None
                 and len(hs) == 2 and hs[0] == hs[1] and hs[0] in (64, 128) and self.in_dim <= 64 and self._layers()[-1][4] <= 8)
 
     def fused_args(self, X: torch.Tensor, M: int):
@@ -426,7 +454,9 @@ class _FlatNet(nn.Module):
         hdim = self._layers()[-1][4]
         fx, _, _, fh = self.feat()
         # head: dW_head' = dhead^T x_hat_L   (x_hat_L = GRU output for recurrent nets)
-        if not head_dw_done:
+        if self.md:
+            self.md_backward(M)
+        elif not head_dw_done:
             if self.wide_head:  # ATL(64) image: an ordinary two-operand weight-gradient GEMM (partial layout dWp[64][fh] | dbp[64])
                 call("harl_mlp_dw_partials", ptr(self.dhead), 0, 0, 64, ptr(fx), 0, 0, None, None, None, fh, M,
                      ptr(self.part[po[-1]:]), nwg, s, tag="dw_head")
@@ -490,13 +520,43 @@ class _FlatNet(nn.Module):
         call("harl_reduce_partials_multi", ptr(self.part), ptr(self.table), self.n_entries, nwg, self.total_dwp,
              ptr(self.dwp), s, tag="reduce_partials")
 
+    # ---- MultiDiscrete heads (csrc/multihead.hip): logits of every group from the head input; backward of the groups
+    def md_logits(self, M: int) -> None:
+        fx, _, _, fh = self.feat()
+        s = stream()
+        for (Wp, bp), z, sp in zip(self._head_packs, self.md_z, self._md_sp):
+            call("harl_mlp_linear", ptr(fx), M, fh, sp, ptr(Wp), ptr(bp), ptr(z), s, tag="md_linear")
+
+    def md_layout(self):
+        """(z pointer array, n_groups, sp[], n_heads, nvec[], head_group[]) -- the leading arguments of harl_md_head_*."""
+        import ctypes as C
+        G, K = len(self._md_sp), len(self.nvec)
+        zs = (C.c_void_p * G)(*[z.data_ptr() for z in self.md_z])
+        return (zs, G, (C.c_int * G)(*self._md_sp), K, (C.c_int * K)(*self.nvec), (C.c_int * K)(*self._md_head_group))
+
+    def md_backward(self, M: int) -> None:
+        """d(loss)/d(logits) images (self.md_z, written by harl_md_head_loss) -> the groups' weight-gradient partials and
+        d(loss)/d(head input) in self.dz[0]: the layer kernels of a hidden Linear (sum over the groups)."""
+        fx, fmask, frstd, fh = self.feat()
+        s = stream()
+        nh = len(self._md_sp)
+        po = self._part_offs[-nh:]
+        for g, ((Wp, _), dzg, sp) in enumerate(zip(self._head_packs, self.md_z, self._md_sp)):
+            call("harl_mlp_dw_partials", ptr(dzg), 0, 0, sp, ptr(fx), 0, 0, None, None, None, fh, M,
+                 ptr(self.part[po[g]:]), self.n_wg, s, tag="dw_head")
+            call("harl_mlp_bwd_dx", ptr(dzg), ptr(fx), ptr(fmask), ptr(frstd), M, sp, fh, ptr(Wp),
+                 ptr(self.dz[0 if g == 0 else 1]), None, 0, None, 0, s, tag="bwd_dx")
+            if g > 0:
+                n = ((M + SLAB - 1) // SLAB) * SLAB * fh
+                self.dz[0][:n].add_(self.dz[1][:n])
+
     def unfold_grads(self) -> None:
         """self.dwp (dense folded gradients) -> self.flat_grad in the reference parameter layout (UNSCALED)."""
         s = stream()
         fp, fg = self.flat_param, self.flat_grad
         seen = set()
-        for (wo, bo, go, beo, o, k), off in zip(self._entries(), self._dwp_offs):
-            kp, op = ((k + 31) // 32) * 32, ((o + 31) // 32) * 32
+        for (wo, bo, go, beo, o, k), off, trow in zip(self._entries(), self._dwp_offs, self._table_rows):
+            kp, op = trow[9], trow[10]
             dW = self.dwp[off:off + op * kp]
             db = self.dwp[off + op * kp:off + op * kp + op]
             acc = int(go in seen)  # Linears sharing one LayerNorm (GRU gate blocks) accumulate its gradients
@@ -540,13 +600,61 @@ class StochasticPolicy(_FlatNet):
             nn.init.constant_(lin.bias.data, 0)
             self._cpu_params += [("act.action_out.log_std", torch.ones(self.act_dim) * self.std_x_coef),
                                  ("act.action_out.fc_mean.weight", lin.weight.data), ("act.action_out.fc_mean.bias", lin.bias.data)]
+        elif self.action_type == "MultiDiscrete":  # one Categorical per entry of nvec (act.py:35-43)
+            self._init_multidiscrete(args, action_space, init, d)
         else:
-            raise NotImplementedError(f"action space {self.action_type} (MultiDiscrete is HAPPO-only in the reference)")
-        if self.act_dim > 64 or (self.act_dim > 32 and not self.discrete):
+            raise NotImplementedError(f"action space {self.action_type}")
+        if not self.md and (self.act_dim > 64 or (self.act_dim > 32 and not self.discrete)):
             raise NotImplementedError("action heads wider than 32 (Categorical: 64) are not instantiated")
-        self.wide_head = self.act_dim > 32
+        self.wide_head = (not self.md) and self.act_dim > 32
         self._finalize_params()
         self.fold()
+
+    def _init_multidiscrete(self, args: dict, action_space, init, d: int) -> None:
+        """Heads in the reference's order (same RNG draws), packed first-fit IN ORDER into groups of <= 128 logits; a group is
+        one contiguous [S_g, d] block of the arena so that fold / weight-gradient / Adam see it as a single Linear."""
+        nvec = [int(n) for n in action_space.nvec]
+        if self.panel:
+            raise NotImplementedError("MultiDiscrete heads on 256-wide layers")
+        if len(nvec) > 8 or max(nvec) > 128:
+            raise NotImplementedError("MultiDiscrete: at most 8 heads of at most 128 actions each")
+        self.md, self.discrete = True, True
+        self.nvec, self.n_heads = nvec, len(nvec)
+        self.act_dim = sum(nvec)   # width of the concatenated normalised logits (head_out)
+        self.act_w = 1             # log-probs are summed over the heads (act.py:124-137)
+        groups: List[List[int]] = [[]]
+        for k, n in enumerate(nvec):
+            if sum(nvec[j] for j in groups[-1]) + n > 128:
+                groups.append([])
+            groups[-1].append(k)
+        if len(groups) > 4:
+            raise NotImplementedError("MultiDiscrete: more than 4 groups of 128 logits")
+        self._md_groups = groups
+        self._md_head_group = [g for g, ks in enumerate(groups) for _ in ks]
+        self._md_sp = [64 if sum(nvec[k] for k in ks) <= 64 else 128 for ks in groups]
+        lins = []
+        for n in nvec:  # Categorical(inputs_dim, n): init_(nn.Linear) with gain (distributions.py:37-50)
+            lin = nn.Linear(d, n)
+            init(lin.weight.data, gain=args["gain"])
+            nn.init.constant_(lin.bias.data, 0)
+            lins.append(lin)
+        hidden, alias = [], []
+        for g, ks in enumerate(groups):
+            self._cpu_params += [(f"__md{g}.weight", torch.cat([lins[k].weight.data for k in ks], 0)),
+                                 (f"__md{g}.bias", torch.cat([lins[k].bias.data for k in ks], 0))]
+            hidden += [f"__md{g}.weight", f"__md{g}.bias"]
+        for g, ks in enumerate(groups):
+            lo = 0
+            for k in ks:
+                alias.append((f"act.action_outs.{k}.linear.weight", f"__md{g}.weight", lo, lo + nvec[k]))
+                alias.append((f"act.action_outs.{k}.linear.bias", f"__md{g}.bias", lo, lo + nvec[k]))
+                lo += nvec[k]
+        self._hidden_blocks, self._alias_params = tuple(hidden), alias
+
+    def _head_layers(self):
+        if self.md:
+            return [(f"__md{g}.weight", f"__md{g}.bias", sum(self.nvec[k] for k in ks)) for g, ks in enumerate(self._md_groups)]
+        return [self._head_names()]
 
     def _head_names(self):
         if self.discrete:
@@ -609,7 +717,12 @@ def consume_policy_init_rng(args: dict, obs_space, action_space) -> None:
                     prm.data.new_empty((prm.size(0), prm.numel() // prm.size(0))).normal_(0, 1)
                 else:
                     init(prm.data)
-    n_out = int(action_space.n) if action_space.__class__.__name__ == "Discrete" else int(action_space.shape[0])
+    kind = action_space.__class__.__name__
+    if kind == "MultiDiscrete":
+        for n in action_space.nvec:
+            draw(nn.Linear(d, int(n)), args["gain"])
+        return
+    n_out = int(action_space.n) if kind == "Discrete" else int(action_space.shape[0])
     draw(nn.Linear(d, n_out), args["gain"])
 
 

@@ -22,9 +22,12 @@ class Shapes:
     act_dim: int           # Box: dimension; Discrete: number of actions
     discrete: bool = False
     hidden_sizes: Sequence[int] = (128, 128)
+    nvec: Optional[Sequence[int]] = None   # MultiDiscrete: actions per head (act_dim = their sum, discrete = True)
 
     @property
     def act_shape(self) -> int:  # width of the stored `actions` / `action_log_probs`
+        if self.nvec is not None:
+            return len(self.nvec)
         return 1 if self.discrete else self.act_dim
 
 
@@ -48,7 +51,10 @@ def actor_param_shapes(sh: Shapes, use_feature_normalization: bool = True,
         d = h
     if recurrent:
         out += _rnn_shapes(d)
-    if sh.discrete:
+    if sh.nvec is not None:  # act.py:35-43: nn.ModuleList of Categoricals
+        for k, n in enumerate(sh.nvec):
+            out += [(f"act.action_outs.{k}.linear.weight", (int(n), d)), (f"act.action_outs.{k}.linear.bias", (int(n),))]
+    elif sh.discrete:
         out += [("act.action_out.linear.weight", (sh.act_dim, d)), ("act.action_out.linear.bias", (sh.act_dim,))]
     else:
         out += [("act.action_out.log_std", (sh.act_dim,)),
@@ -82,7 +88,7 @@ def synthetic_state_dict(shapes: List[Tuple[str, Tuple[int, ...]]], seed: int, s
         if name.endswith("log_std"):
             v = std_x_coef + 0.1 * rng.standard_normal(shp)
         elif len(shp) == 2:  # Linear weight [out, in]
-            scale = (0.3 if ("action_out" in name or name.startswith("v_out")) else 1.4) / np.sqrt(shp[1])
+            scale = (0.3 if ("action_out" in name or name.startswith("v_out")) else 1.4) / np.sqrt(shp[1])  # (incl. action_outs.k)
             v = scale * rng.standard_normal(shp)
         elif name == "rnn.norm.weight":
             v = 1.0 + 0.1 * rng.standard_normal(shp)
@@ -126,7 +132,17 @@ def make_buffers(sh: Shapes, seed: int, inactive_p: float = 0.0, unavailable_p: 
     base_mask = (rng.random((T + 1, N, 1)) >= 0.04).astype(f32)
     for _ in range(A):
         obs.append(rng.standard_normal((T + 1, N, sh.obs_dim)).astype(f32))
-        if sh.discrete:
+        if sh.nvec is not None:
+            # one index per head; the stored log-probs are the SUMMED log-prob broadcast over the heads' columns
+            # (actor_buffer.py:98 assigns the policy's [N, 1] output into the [N, n_heads] slot) -- plus a little per-column
+            # noise so that the kernels' per-column arithmetic is exercised
+            nh = len(sh.nvec)
+            a = np.stack([rng.integers(0, int(n), size=(T, N)) for n in sh.nvec], axis=-1)
+            actions.append(a.astype(f32))
+            base = sum(np.log(1.0 / int(n)) for n in sh.nvec) + 0.05 * rng.standard_normal((T, N, 1))
+            logp.append((base + 0.01 * rng.standard_normal((T, N, nh))).astype(f32))
+            avail.append(None)
+        elif sh.discrete:
             a = rng.integers(0, sh.act_dim, size=(T, N, 1))
             actions.append(a.astype(f32))
             logp.append((np.log(1.0 / sh.act_dim) + 0.05 * rng.standard_normal((T, N, 1))).astype(f32))

@@ -30,6 +30,8 @@ extern "C" {
 
 #define HARL_PS_STRIDE 48 /* floats per row of the per-workgroup partial-scalar tables */
 #define HARL_DHEAD_LD 32  /* row stride of the head-gradient matrix */
+#define HARL_MD_MAX_HEADS 8  /* MultiDiscrete: entries of nvec */
+#define HARL_MD_MAX_GROUPS 4 /* MultiDiscrete: logits images (<= 128 logits each) */
 
 int harl_version(void);
 const char *harl_last_error(void);
@@ -304,6 +306,36 @@ int harl_trpo_cg_step(float *x, float *r, float *p, const float *avp, long n, fl
 int harl_trpo_kl_sum(const float *head_old, const float *head_new, const float *log_std_old, const float *log_std_new,
                      float std_x_coef, float std_y_coef, long M, int act_dim, int discrete, double *out_sum,
                      void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * MultiDiscrete action spaces (harl/models/base/act.py:35-43,56-73,117-141: one Categorical per entry of nvec on the same
+ * trunk output; csrc/multihead.hip).  The concatenated heads are ordinary Linears packed into n_groups GROUPS of at most 128
+ * logits; group g is one weight matrix Wp_g [sp_g][H] (sp_g in {64, 128}, zero rows past its last head) with
+ *   logits        z_g = harl_mlp_linear(x_hat_L, Wp_g, bp_g)                      ATL(sp_g) image
+ *   weight grads  harl_mlp_dw_partials(dz_g, a_kind 0, HO = sp_g, x_hat_L)
+ *   trunk grad    dz_L = sum_g harl_mlp_bwd_dx(dz_g, x_hat_L, mask_L, rstd_L, HO = sp_g, HI = H, Wp_g)
+ * z / dz: HOST arrays of n_groups device pointers; nvec[n_heads] = logits per head, head_group[n_heads] = its image (heads
+ * fill an image in order).  actions [rows, n_heads] hold the indices as fp32.
+ * harl_mlp_linear: xout = Wp xin + bp, ATL(HI) -> ATL(HO), no epilogue (HI, HO in {64, 128}).
+ * harl_md_head_logp: logp_out[M] = sum_heads log p_k(a_k) (act.py:124-137); if factor != NULL:
+ *   factor[i] *= agg_c exp(logp - old_logp[i, c]), c < old_w (on_policy_ha_runner.py:116-124); head_out (nullable)
+ *   [M, sum(nvec)] = the normalised logits of every head, concatenated (rollout sampling).
+ * harl_md_head_loss: HAPPO / MAPPO (mode 0) or HAA2C (mode 2) loss and d(unscaled loss)/d(logits) -> dz_g (may alias
+ *   z_g).  The reference compares the summed log-prob [m, 1] with EVERY column of the buffer's [rows, old_w = n_heads]
+ *   log-prob array (happo.py:66-70), so `prod` raises the ratio to the old_w-th power; its entropy bonus is
+ *   (1/m) sum_rows sum_heads H (act.py:126-139: never active-mask weighted), while the surrogate is divided by
+ *   sum(active): ent_scale = device scalar sum(active) / m of the (global) minibatch (NULL = 1) folds that into the
+ *   unscaled sums.  part_scalars[n_blocks][HARL_PS_STRIDE] as harl_actor_head_loss
+ *   ({0: sum loss*active, 1: sum active, 2: ent_scale * sum ent, 3: sum ratio, 4: count}); launched with n_blocks workgroups. */
+int harl_mlp_linear(const float *xin, long M, int HI, int HO, const float *Wp, const float *bp, float *xout, void *stream);
+int harl_md_head_logp(const float *const *z, int n_groups, const int *sp, int n_heads, const int *nvec,
+                      const int *head_group, long M, const float *actions, float *logp_out, const float *old_logp,
+                      int old_w, float *factor, int agg_mean, float *head_out, long m_valid, long m_pad, void *stream);
+int harl_md_head_loss(const float *const *z, float *const *dz, int n_groups, const int *sp, int n_heads, const int *nvec,
+                      const int *head_group, long M, const int64_t *idx, const float *actions, const float *old_logp,
+                      int old_w, const float *adv, const double *adv_moments, const float *factor, const float *active,
+                      const float *ent_scale, double clip_param, float entropy_coef, int agg_mean, int mode, long m_valid,
+                      long m_pad, float *logp_out, float *part_scalars, int n_blocks, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused optimiser-step kernels for two equal-width hidden layers (H in {64, 128}) and inputs up to 64 wide, identity

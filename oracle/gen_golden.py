@@ -63,6 +63,18 @@ class Discrete:  # duck-typed gym.spaces.Discrete
         self.shape = ()
 
 
+class MultiDiscrete:  # duck-typed gym.spaces.MultiDiscrete (act.py:35-43 reads .nvec, envs_tools.py:40-41 reads .shape[0])
+    def __init__(self, nvec):
+        self.nvec = np.asarray(nvec, dtype=np.int64)
+        self.shape = (len(nvec),)
+
+
+def make_act_space(sh):
+    if sh.nvec is not None:
+        return MultiDiscrete(sh.nvec)
+    return Discrete(sh.act_dim) if sh.discrete else Box((sh.act_dim,))
+
+
 # ----------------------------------------------------------------------------------
 # golden cases: small enough for fixtures of a few hundred KB, wide enough to cover
 # Box / Discrete, prod / mean aggregation, 1 / 2 mini-batches, dead agents, masked
@@ -159,6 +171,18 @@ CASES = {
     "hands_h256x3_mb2_fp": dict(state_type="FP", shapes=dict(T=12, N=8, A=2, obs_dim=40, share_obs_dim=60, act_dim=6, discrete=True,
                                                              hidden_sizes=[256, 256, 256]), seed=62, unavailable_p=0.2, inactive_p=0.1,
                                 overrides=dict(ppo_epoch=2, critic_epoch=2, actor_num_mini_batch=2, critic_num_mini_batch=2)),
+    # ---- MultiDiscrete actions (act.py:35-43,117-141; the reference's LAG environments: MultiDiscrete([41, 41, 41, 30]))
+    "md_h64_mb2": dict(shapes=dict(T=12, N=8, A=2, obs_dim=18, share_obs_dim=30, act_dim=12, nvec=[5, 3, 4],
+                                   hidden_sizes=[64, 64]), seed=71, inactive_p=0.15,
+                       overrides=dict(ppo_epoch=2, critic_epoch=2, actor_num_mini_batch=2, critic_num_mini_batch=2)),
+    "md_lag_h128": dict(shapes=dict(T=10, N=8, A=2, obs_dim=22, share_obs_dim=30, act_dim=153, nvec=[41, 41, 41, 30],
+                                    hidden_sizes=[128, 128]), seed=72, inactive_p=0.1, overrides=dict(ppo_epoch=2, critic_epoch=2)),
+    "md_rnn_h64": dict(shapes=dict(T=10, N=6, A=2, obs_dim=20, share_obs_dim=24, act_dim=11, nvec=[6, 5],
+                                   hidden_sizes=[64]), seed=73, inactive_p=0.1,
+                       overrides=dict(ppo_epoch=2, critic_epoch=2, use_recurrent_policy=True, data_chunk_length=5)),
+    "md_mappo_mean_h64": dict(algo="mappo", shapes=dict(T=12, N=8, A=2, obs_dim=18, share_obs_dim=30, act_dim=70, nvec=[64, 6],
+                                                        hidden_sizes=[64, 64]), seed=74,
+                              overrides=dict(ppo_epoch=2, critic_epoch=2, action_aggregation="mean")),
     "trpo_wide_h128x3": dict(algo="hatrpo", shapes=dict(T=8, N=8, A=3, obs_dim=70, share_obs_dim=65, act_dim=1,
                                                         discrete=False, hidden_sizes=[128, 128, 128]), seed=9,
                              overrides=dict(fixed_order=True), inactive_p=0.15),
@@ -186,7 +210,7 @@ def run_case(name: str, spec: dict) -> dict:
     torch.manual_seed(seed)
     np.random.seed(seed)
     dev = torch.device("cpu")
-    act_space = Discrete(sh.act_dim) if sh.discrete else Box((sh.act_dim,))
+    act_space = make_act_space(sh)
     margs = {**cfg["model"], **cfg["algo"]}
     share_param = bool(cfg["algo"].get("share_param", False))
     if share_param:  # on_policy_base_runner.py:96-113: ONE actor object referenced by every agent slot
@@ -245,6 +269,23 @@ def run_case(name: str, spec: dict) -> dict:
                 if rec:
                     feat, _ = actors[a].actor.rnn(feat, torch.from_numpy(abuf[a].rnn_states[0]),
                                                   torch.from_numpy(abuf[a].masks[:-1].reshape(sh.T * sh.N, 1)))
+                if sh.nvec is not None:  # one draw per head; the stored log-prob is the SUM, broadcast over the columns
+                    cols, lps = [], []
+                    for k, n in enumerate(sh.nvec):
+                        dk = actors[a].actor.act.action_outs[k](feat)
+                        pk = dk.probs.numpy().astype(np.float64)
+                        pk /= pk.sum(-1, keepdims=True)
+                        ak = np.array([rng.choice(int(n), p=pr) for pr in pk], dtype=np.float32)[:, None]
+                        cols.append(ak)
+                        lps.append(dk.log_probs(torch.from_numpy(ak)).numpy())
+                    acts = np.concatenate(cols, -1)
+                    lsum = np.concatenate(lps, -1).sum(-1, keepdims=True) + 0.05 * rng.standard_normal((sh.T * sh.N, 1))
+                    logp = np.repeat(lsum, len(sh.nvec), axis=-1) + 0.01 * rng.standard_normal((sh.T * sh.N, len(sh.nvec)))
+                    abuf[a].actions[:] = acts.reshape(abuf[a].actions.shape)
+                    abuf[a].action_log_probs[:] = logp.astype(np.float32).reshape(abuf[a].action_log_probs.shape)
+                    onpolicy_inputs[f"in_actions_{a}"] = abuf[a].actions.copy()
+                    onpolicy_inputs[f"in_logp_{a}"] = abuf[a].action_log_probs.copy()
+                    continue
                 if sh.discrete:
                     av = torch.from_numpy(abuf[a].available_actions[:-1].reshape(sh.T * sh.N, -1).copy())
                     dist = actors[a].actor.act.action_out(feat, av)

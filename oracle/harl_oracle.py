@@ -304,6 +304,24 @@ def actor_evaluate_actions(
     if "rnn.rnn.weight_ih_l0" in p:
         feat, _ = rnn_layer_forward(p, feat, rnn_states, masks)
     am = active_masks if cfg.use_policy_active_masks else None
+    if "act.action_outs.0.linear.weight" in p:  # MultiDiscrete -> one Categorical per head (act.py:35-43,117-141)
+        lps, ents, all_logits = [], [], []
+        k = 0
+        while f"act.action_outs.{k}.linear.weight" in p:
+            logits = F.linear(feat, p[f"act.action_outs.{k}.linear.weight"], p[f"act.action_outs.{k}.linear.bias"])
+            logits = logits - logits.logsumexp(dim=-1, keepdim=True)  # torch Categorical(logits=...) normalisation
+            lps.append(logits.gather(-1, action[:, k].long().unsqueeze(-1)))
+            e = -(torch.clamp(logits, min=torch.finfo(logits.dtype).min) * F.softmax(logits, dim=-1)).sum(-1)  # [m]
+            # act.py:126-133: entropy() is [m] and active_masks [m, 1] -> the product BROADCASTS to [m, m]
+            ents.append((e * am) / am.sum() if am is not None else e / lps[-1].size(0))
+            all_logits.append(logits)
+            k += 1
+        logp = torch.cat(lps, dim=-1).sum(dim=-1, keepdim=True)                    # act.py:134-136
+        if am is not None:
+            dist_entropy = torch.cat(ents, dim=-1).sum(dim=-1, keepdim=True).mean()  # act.py:137-139
+        else:  # [m] pieces: cat -> [heads * m], sum(dim=-1, keepdim=True) -> [1], mean
+            dist_entropy = torch.cat(ents, dim=-1).sum(dim=-1, keepdim=True).mean()
+        return logp, dist_entropy, {"logits": torch.cat(all_logits, dim=-1)}
     if "act.action_out.log_std" in p:  # Box -> DiagGaussian (distributions.py:58-89)
         mean = F.linear(feat, p["act.action_out.fc_mean.weight"], p["act.action_out.fc_mean.bias"])
         std = torch.sigmoid(p["act.action_out.log_std"] / cfg.std_x_coef) * cfg.std_y_coef

@@ -34,6 +34,18 @@ class Discrete:
         self.shape = ()
 
 
+class MultiDiscrete:
+    def __init__(self, nvec):
+        self.nvec = np.asarray(nvec, dtype=np.int64)
+        self.shape = (len(nvec),)
+
+
+def act_space_of(sh):
+    if getattr(sh, "nvec", None) is not None:
+        return MultiDiscrete(sh.nvec)
+    return Discrete(sh.act_dim) if sh.discrete else Box((sh.act_dim,))
+
+
 def dev(x, dtype=torch.float32):
     return torch.as_tensor(np.ascontiguousarray(x), dtype=dtype).to(DEV).contiguous()
 
@@ -697,13 +709,62 @@ def check_trpo(spec, agg: str = "prod") -> Dict[str, float]:
     return out
 
 
+def check_multidiscrete_rollout(nvec, hidden) -> Dict[str, float]:
+    """MultiDiscrete rollout side: evaluate_actions (summed log-probs, entropy) and get_actions (deterministic = per-head
+    argmax; sampled actions in range with the log-probs of the drawn actions) against the oracle's heads."""
+    from harl_amd.happo import HAPPO
+    out = {}
+    M = 203
+    sh = Shapes(T=M, N=1, A=1, obs_dim=19, share_obs_dim=7, act_dim=sum(nvec), hidden_sizes=hidden, nvec=list(nvec))
+    args = default_args(sh.hidden_sizes)
+    actor = HAPPO(args, Box((sh.obs_dim,)), MultiDiscrete(nvec), device=DEV)
+    sd = synthetic_state_dict(actor_param_shapes(sh, args["use_feature_normalization"]), 23, args["std_x_coef"])
+    assert list(sd.keys()) == list(actor.actor.state_dict().keys())
+    actor.actor.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    cfg = O.PathConfig.from_reference_dicts({}, args, args)
+    d = make_buffers(sh, 9, inactive_p=0.2)
+    obs = d.obs[0][:-1].reshape(M, -1)
+    act = d.actions[0].reshape(M, -1)
+    active = d.active_masks[0][:-1].reshape(M, 1)
+    p = {k: torch.from_numpy(v) for k, v in sd.items()}
+    with torch.no_grad():
+        olp, oent, odist = O.actor_evaluate_actions(p, cfg, torch.from_numpy(obs), torch.from_numpy(act), None,
+                                                    torch.from_numpy(active))
+    lp, ent, dist = actor.evaluate_actions(obs, None, act, None, None, active)
+    out["logp_vec_rel"] = vec_rel_err(lp.cpu().numpy(), olp.numpy())
+    out["entropy_rel"] = rel_err(ent.item(), oent.item())
+    out["dist_is_none_mismatch"] = float(dist is not None)
+    ologits = odist["logits"].numpy()  # normalised logits of every head, concatenated
+    a_det, lp_det, _ = actor.get_actions(obs, None, None, None, deterministic=True)
+    lo, want, wlp = 0, [], 0.0
+    for n in nvec:
+        blk = ologits[:, lo:lo + n]
+        want.append(blk.argmax(-1))
+        wlp = wlp + blk.max(-1)
+        lo += n
+    # (ties between fp32 logits of two implementations are not expected on random weights)
+    out["deterministic_action_mismatch"] = float(np.sum(a_det.cpu().numpy() != np.stack(want, -1).astype(np.float32)))
+    out["deterministic_logp_vec_rel"] = vec_rel_err(lp_det.cpu().numpy().reshape(-1), wlp)
+    torch.manual_seed(5)
+    a_s, lp_s, _ = actor.get_actions(obs, None, None, None)
+    a_np = a_s.cpu().numpy()
+    out["sample_range_mismatch"] = float(np.sum((a_np < 0) | (a_np >= np.asarray(nvec)[None, :]) | (a_np != np.round(a_np))))
+    lo, wlp = 0, 0.0
+    for k, n in enumerate(nvec):
+        wlp = wlp + np.take_along_axis(ologits[:, lo:lo + n], a_np[:, k:k + 1].astype(np.int64), -1)[:, 0]
+        lo += n
+    out["sample_logp_vec_rel"] = vec_rel_err(lp_s.cpu().numpy().reshape(-1), wlp)
+    out["shape_mismatch"] = float(tuple(a_s.shape) != (M, len(nvec)) or tuple(lp_s.shape) != (M, 1))
+    return out
+
+
 # ------------------------------------------------------------------------------------------------
 def build_runner(case: GoldenCase):
     from harl_amd.runner import RUNNER_REGISTRY
     OnPolicyHARunner = RUNNER_REGISTRY[case.algo_name]
     train, model, algo = case.reference_dicts()
     sh, d = case.shapes, case.data
-    space = Discrete(sh.act_dim) if sh.discrete else Box((sh.act_dim,))
+    space = act_space_of(sh)
     algo_args = dict(train=train, model=model, algo=algo)
     r = OnPolicyHARunner(dict(algo=case.algo_name), algo_args, dict(state_type=case.state_type),
                          obs_spaces=[Box((sh.obs_dim,))] * sh.A, share_obs_space=Box((sh.share_obs_dim,)),

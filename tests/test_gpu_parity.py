@@ -142,6 +142,25 @@ def test_rollout_loop_learns_on_toy_env(discrete, recurrent):
     assert abs(res["active_zero_frac_agent1"] - 0.12) < 1e-6, res  # agent 1 is dead 3 steps out of 25
 
 
+@pytest.mark.parametrize("name", ["md_h64_mb2", "md_lag_h128", "md_rnn_h64", "md_mappo_mean_h64"])
+def test_multidiscrete_train_matches_reference_golden(name):
+    """MultiDiscrete action spaces (act.py:35-43,117-141; csrc/multihead.hip): whole train() vs the reference -- mini-batches,
+    the LAG layout [41, 41, 41, 30] (two logits images), a GRU policy, MAPPO with `mean` aggregation."""
+    _assert_all(_G().check_train_golden(name), tol=TOL)
+
+
+@pytest.mark.parametrize("nvec,hidden", [([5, 3, 4], [64, 64]), ([41, 41, 41, 30], [128, 128])])
+def test_multidiscrete_rollout_and_evaluate(nvec, hidden):
+    """get_actions / evaluate_actions for MultiDiscrete heads vs the oracle: per-head normalised logits, summed log-probs,
+    the reference's entropy figure, deterministic mode = per-head argmax, sampled actions inside their ranges."""
+    res = _G().check_multidiscrete_rollout(nvec, hidden)
+    for k, v in res.items():
+        if "mismatch" in k:
+            assert v == 0.0, (k, v)
+        else:
+            assert v < TOL, (k, v)
+
+
 @pytest.mark.parametrize("name", ["mappo_box_h64", "mappo_shared_disc_h64_mb2", "mappo_shared_fp_box_h128"])
 def test_mappo_train_matches_reference_golden(name):
     """MAPPO through the same kernels (factor = NULL); parameter sharing accumulates every agent's segment before one

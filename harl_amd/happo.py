@@ -257,6 +257,8 @@ class HAPPO(OnPolicyBase):
         None (= 1) without active masks."""
         if active is None:
             return None
+        if getattr(self, "_md_ent_override", None) is not None:  # parameter sharing: the ratio of the concatenated batch
+            return self._md_ent_override
         if seq is not None:      # L x m_pad rows, padding rows addressed through idx but not counted
             j = torch.arange(m, device=self.device)
             live = (j % seq["m_pad"]) < seq["m"]

@@ -33,8 +33,6 @@ class MAPPO(HAPPO):
         the loss kernel as the summed fp64 moments; FP: per-agent slices of the runner-normalised [T, N, A, 1] tensor."""
         if self.use_recurrent_policy or self.use_naive_recurrent_policy:
             raise NotImplementedError("share_param with recurrent policies")
-        if self.actor.md:
-            raise NotImplementedError("share_param with MultiDiscrete actions")
         dev, net = self.device, self.actor
         net.invalidate_caches()
         A = num_agents
@@ -72,13 +70,25 @@ class MAPPO(HAPPO):
                 acc.zero_()
                 net._ensure_ws(B)
                 net.scalars.zero_()
+                segs = []
                 for a in range(A):
-                    buf = actor_buffer[a]
                     ind = samplers[a][b]
                     if ind is not None and self.shard:
                         ind = local_minibatch_rows(ind, self.shard[0], self.shard[1], self.shard[2])
-                    idx = None if ind is None else ind.to(dev)
-                    m = B if ind is None else ind.numel()
+                    segs.append(None if ind is None else ind.to(dev))
+                if net.md and self.use_policy_active_masks:
+                    # MultiDiscrete: sum(active) / rows of the CONCATENATED minibatch (happo._md_ent_scale; mappo.py:185-234)
+                    st = torch.zeros(2, dtype=torch.float32, device=dev)
+                    for a in range(A):
+                        act_a = actor_buffer[a].flat("active_masks").reshape(B)
+                        st[0] += (act_a if segs[a] is None else act_a[segs[a]]).sum()
+                        st[1] += float(B if segs[a] is None else segs[a].numel())
+                    self.comm.all_reduce_sum(st)
+                    self._md_ent_override = (st[0] / st[1]).reshape(1).contiguous()
+                for a in range(A):
+                    buf = actor_buffer[a]
+                    idx = segs[a]
+                    m = B if idx is None else idx.numel()
                     nblk = self._forward_backward(
                         buf.flat("obs"), idx, m, buf.flat("actions"),
                         None if buf.available_actions is None else buf.flat("available_actions"),
@@ -86,6 +96,7 @@ class MAPPO(HAPPO):
                         buf.flat("active_masks").reshape(B) if self.use_policy_active_masks else None)
                     acc.add_(net.dwp)
                     call("harl_reduce_scalars", ptr(net.part_scalars), nblk, ptr(net.scalars), s)  # accumulates
+                self._md_ent_override = None
                 net.dwp.copy_(acc)
                 self._optimizer_step(None)
         n_upd = self.ppo_epoch * k

@@ -142,6 +142,11 @@ class _FlatNet(nn.Module):
         self._packs: List[Tuple[torch.Tensor, torch.Tensor]] = []
         self._max_rows = 0
 
+    def flat_reference(self) -> torch.Tensor:
+        """All parameters as one vector in the REFERENCE's ``parameters()`` order.  Equal to ``flat_param`` except for
+        MultiDiscrete policies, whose heads are stored group-contiguously ([W_0; W_1; ..][b_0; b_1; ..]) in the arena."""
+        return torch.cat([p.detach().reshape(-1) for p in self.parameters()])
+
     def pview(self, name: str) -> torch.Tensor:
         off, shape = self.offsets[name]
         return self.flat_param[off:off + math.prod(shape)].view(shape)

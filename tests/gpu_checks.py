@@ -930,7 +930,7 @@ def check_train_golden(name: str) -> Dict[str, float]:
     out["_critic_gradnorm_rel"] = rel_err(cg[1], z["critic_info"][1])
     out["critic_info_excess"] = excess(cg, z["critic_info"], nz["critic_info"], nz["sens_critic_info"])
     for a in range(case.shapes.A):
-        fp = r.actor[a].actor.flat_param.cpu().numpy()
+        fp = r.actor[a].actor.flat_reference().cpu().numpy()
         out[f"_actor{a}_final_param_vec_rel"] = vec_rel_err(fp, z[f"actor_final_{a}"])
         out[f"actor{a}_final_param_excess"] = vec_excess(fp, z[f"actor_final_{a}"], nz[f"actor_final_{a}"], nz[f"sens_actor_final_{a}"])
     fp = r.critic.critic.flat_param.cpu().numpy()

@@ -180,6 +180,8 @@ CASES = {
     "md_rnn_h64": dict(shapes=dict(T=10, N=6, A=2, obs_dim=20, share_obs_dim=24, act_dim=11, nvec=[6, 5],
                                    hidden_sizes=[64]), seed=73, inactive_p=0.1,
                        overrides=dict(ppo_epoch=2, critic_epoch=2, use_recurrent_policy=True, data_chunk_length=5)),
+    "md_a2c_h128_64": dict(algo="haa2c", shapes=dict(T=10, N=8, A=2, obs_dim=13, share_obs_dim=9, act_dim=9, nvec=[2, 7],
+                                                     hidden_sizes=[128, 64]), seed=75, inactive_p=0.1, overrides={}),
     "md_mappo_mean_h64": dict(algo="mappo", shapes=dict(T=12, N=8, A=2, obs_dim=18, share_obs_dim=30, act_dim=70, nvec=[64, 6],
                                                         hidden_sizes=[64, 64]), seed=74,
                               overrides=dict(ppo_epoch=2, critic_epoch=2, action_aggregation="mean")),

@@ -22,8 +22,8 @@ RNN_CASES = ["rnn_box_h64", "rnn_disc_h64_mb2", "rnn_naive_h64", "rnn_fp_box_h64
              "rnn_fp_disc36_h64"]
 MAPPO_CASES = ["mappo_box_h64", "mappo_shared_disc_h64_mb2", "mappo_shared_fp_box_h128"]
 # MultiDiscrete action spaces (act.py:35-43,117-141): MLP with mini-batches, the LAG layout [41, 41, 41, 30] (two logits
-# images), GRU policy, MAPPO with `mean` aggregation
-MD_CASES = ["md_h64_mb2", "md_lag_h128", "md_rnn_h64", "md_mappo_mean_h64"]
+# images), GRU policy, MAPPO (shared parameters) with `mean` aggregation, HAA2C on a mixed-width trunk
+MD_CASES = ["md_h64_mb2", "md_lag_h128", "md_rnn_h64", "md_mappo_mean_h64", "md_a2c_h128_64"]
 
 
 class GoldenCase:

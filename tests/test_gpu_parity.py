@@ -142,10 +142,10 @@ def test_rollout_loop_learns_on_toy_env(discrete, recurrent):
     assert abs(res["active_zero_frac_agent1"] - 0.12) < 1e-6, res  # agent 1 is dead 3 steps out of 25
 
 
-@pytest.mark.parametrize("name", ["md_h64_mb2", "md_lag_h128", "md_rnn_h64", "md_mappo_mean_h64"])
+@pytest.mark.parametrize("name", ["md_h64_mb2", "md_lag_h128", "md_rnn_h64", "md_mappo_mean_h64", "md_a2c_h128_64"])
 def test_multidiscrete_train_matches_reference_golden(name):
     """MultiDiscrete action spaces (act.py:35-43,117-141; csrc/multihead.hip): whole train() vs the reference -- mini-batches,
-    the LAG layout [41, 41, 41, 30] (two logits images), a GRU policy, MAPPO with `mean` aggregation."""
+    the LAG layout [41, 41, 41, 30] (two logits images), a GRU policy, MAPPO (shared parameters, `mean` aggregation), HAA2C."""
     _assert_all(_G().check_train_golden(name), tol=TOL)
 
 

@@ -34,7 +34,7 @@ def _worker(rank, world, port, name, q):
         case = GoldenCase(name)
         z, sh, d = case.z, case.shapes, case.data
         train, model, algo = case.reference_dicts()
-        space = G.Discrete(sh.act_dim) if sh.discrete else G.Box((sh.act_dim,))
+        space = G.act_space_of(sh)
         comm = Comm()
         lo, hi = shard_columns(sh.N, rank, world)
         torch.manual_seed(case.seed)
@@ -82,7 +82,7 @@ def _worker(rank, world, port, name, q):
         got = np.array([[i["policy_loss"], i["dist_entropy"], i["actor_grad_norm"], i["ratio"]] for i in infos])
         res["actor_rel"] = rel_err(got, z["actor_infos"])
         res["critic_rel"] = rel_err([cinfo["value_loss"], cinfo["critic_grad_norm"]], z["critic_info"])
-        res["param_rel"] = max([vec_rel_err(r.actor[a].actor.flat_param.cpu().numpy(), z[f"actor_final_{a}"])
+        res["param_rel"] = max([vec_rel_err(r.actor[a].actor.flat_reference().cpu().numpy(), z[f"actor_final_{a}"])
                                 for a in range(sh.A)] + [vec_rel_err(r.critic.critic.flat_param.cpu().numpy(), z["critic_final"])])
         res["param_sum"] = float(sum(r.actor[a].actor.flat_param.double().sum().item() for a in range(sh.A)))
         q.put(res)
@@ -90,7 +90,8 @@ def _worker(rank, world, port, name, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name", ["mpe_box_h128", "cheetah_h128x3_mb2", "rnn_disc_h64_mb2", "rnn_naive_h64"])
+@pytest.mark.parametrize("name", ["mpe_box_h128", "cheetah_h128x3_mb2", "rnn_disc_h64_mb2", "rnn_naive_h64", "md_h64_mb2",
+                                  "md_lag_h128"])
 def test_two_rank_sharded_train_matches_unsharded_golden(name):
     import torch.multiprocessing as mp
 

@@ -13,6 +13,19 @@ SOURCES = ["elementwise.hip", "mlp.hip", "wide.hip", "panel.hip", "heads.hip", "
 HEADERS = ["common.h", "split_mfma.h", "mfma_transpose.h", "heads_common.h", os.path.join("..", "..", "include", "harl_hip.h")]
 
 
+def _extra_flags() -> dict:
+    """Per-file extra hipcc flags for A/B builds: HARL_HIPCC_EXTRA="mlp.hip:-mllvm -amdgpu-mfma-vgpr-form;gru.hip:..." (the
+    in-tree library then has to be rebuilt with ``python -m harl_amd._build``).  Empty by default."""
+    out = {}
+    for item in filter(None, os.environ.get("HARL_HIPCC_EXTRA", "").split(";")):
+        name, _, flags = item.partition(":")
+        out[name.strip()] = flags.split()
+    return out
+
+
+EXTRA_FLAGS = _extra_flags()
+
+
 def _stale() -> bool:
     if not os.path.exists(LIB):
         return True
@@ -33,6 +46,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         obj = os.path.join(LIBDIR, src.replace(".hip", ".o"))
         objs.append(obj)
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd += EXTRA_FLAGS.get(src, [])
         procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     for cmd, p in procs:
         out, _ = p.communicate()

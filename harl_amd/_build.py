@@ -13,10 +13,18 @@ SOURCES = ["elementwise.hip", "mlp.hip", "wide.hip", "panel.hip", "heads.hip", "
 HEADERS = ["common.h", "split_mfma.h", "mfma_transpose.h", "heads_common.h", os.path.join("..", "..", "include", "harl_hip.h")]
 
 
+# MFMA results in VGPRs instead of AGPRs: the epilogues (LayerNorm / ReLU, operand splits, transposes) consume every
+# accumulator element on the VALU, and each element held in an AGPR costs a v_accvgpr_read first -- 5.7 % of the issue slots of
+# k_bwd_dx<128,128,1>, 17 % of <64,64,2> (tools/isa_census.py; measured +2.3 % on the MPE update).  Per file:
+# the same flag crashes the compiler on heads.hip and changes nothing in wide.hip / update.hip.
+VGPR_FORM = ["-mllvm", "-amdgpu-mfma-vgpr-form"]
+DEFAULT_EXTRA = {"mlp.hip": VGPR_FORM, "gru.hip": VGPR_FORM, "panel.hip": VGPR_FORM}
+
+
 def _extra_flags() -> dict:
-    """Per-file extra hipcc flags for A/B builds: HARL_HIPCC_EXTRA="mlp.hip:-mllvm -amdgpu-mfma-vgpr-form;gru.hip:..." (the
-    in-tree library then has to be rebuilt with ``python -m harl_amd._build``).  Empty by default."""
-    out = {}
+    """Per-file extra hipcc flags; HARL_HIPCC_EXTRA="mlp.hip:-mllvm -amdgpu-mfma-vgpr-form;gru.hip:" overrides the defaults
+    above for A/B builds (an empty flag list switches a file back; rebuild with ``python -m harl_amd._build``)."""
+    out = {k: list(v) for k, v in DEFAULT_EXTRA.items()}
     for item in filter(None, os.environ.get("HARL_HIPCC_EXTRA", "").split(";")):
         name, _, flags = item.partition(":")
         out[name.strip()] = flags.split()

@@ -17,8 +17,11 @@ HEADERS = ["common.h", "split_mfma.h", "mfma_transpose.h", "heads_common.h", os.
 # accumulator element on the VALU, and each element held in an AGPR costs a v_accvgpr_read first -- 5.7 % of the issue slots of
 # k_bwd_dx<128,128,1>, 17 % of <64,64,2> (tools/isa_census.py; measured +2.3 % on the MPE update).  Per file:
 # the same flag crashes the compiler on heads.hip and changes nothing in wide.hip / update.hip.
+# NOT switched on yet: the round's GPU budget ran out before the full parity suite could be run on the variant (smoke and the
+# bench were green on it); enable with HARL_HIPCC_EXTRA="mlp.hip:-mllvm -amdgpu-mfma-vgpr-form;gru.hip:...;panel.hip:..." or by
+# filling DEFAULT_EXTRA once `pytest -m gpu` has passed on such a build.
 VGPR_FORM = ["-mllvm", "-amdgpu-mfma-vgpr-form"]
-DEFAULT_EXTRA = {"mlp.hip": VGPR_FORM, "gru.hip": VGPR_FORM, "panel.hip": VGPR_FORM}
+DEFAULT_EXTRA: dict = {}
 
 
 def _extra_flags() -> dict:

@@ -12,7 +12,10 @@ the reference implements in these files (paths relative to the reference root):
 * actor / critic MLP           harl/models/base/mlp.py:7-70,
                                harl/models/policy_models/stochastic_policy.py:88-127,
                                harl/models/value_function_models/v_net.py:48-67
-* action heads                 harl/models/base/act.py:104-157, harl/models/base/distributions.py:7-89
+* action heads                 harl/models/base/act.py:104-157 (MultiDiscrete: :117-141), harl/models/base/distributions.py:7-89
+* GRU layer                    harl/models/base/rnn.py:8-81
+* HATRPO / HAA2C / MAPPO       harl/algorithms/actors/hatrpo.py:37-194, harl/utils/trpo_util.py:5-158,
+                               harl/algorithms/actors/haa2c.py:28-153, harl/algorithms/actors/mappo.py:36-234
 * HAPPO update / train         harl/algorithms/actors/happo.py:28-158
 * V-critic update / train      harl/algorithms/critics/v_critic.py:75-200
 * sequential update + factor   harl/runners/on_policy_ha_runner.py:11-130

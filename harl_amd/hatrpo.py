@@ -27,6 +27,8 @@ class HATRPO(OnPolicyBase):
         assert act_space.__class__.__name__ != "MultiDiscrete", \
             "only continuous and discrete action space is supported by HATRPO."
         super().__init__(args, obs_space, act_space, device)
+        if getattr(self.actor, "gru_wide", False):
+            raise NotImplementedError("HATRPO with a 128-wide GRU: the recurrent tangent kernels are 64 wide")
         if self.actor.panel:
             raise NotImplementedError("HATRPO with hidden width 256: the forward-mode tangent kernels are 64/128 wide "
                                       "(no tuned HARL config needs it)")

@@ -62,7 +62,15 @@ class _FlatNet(nn.Module):
             raise NotImplementedError("harl_amd kernels implement relu MLPs only (every tuned HARL config uses relu)")
         self.recurrent = bool(args.get("use_recurrent_policy", False) or args.get("use_naive_recurrent_policy", False))
         self.recurrent_n = int(args.get("recurrent_n", 1))
-        if self.recurrent and (self.hidden_sizes[-1] != 64 or self.recurrent_n != 1):
+        # a 128-wide GRU is composed from layer GEMMs + element-wise cell kernels (harl_amd/gru_wide.py); experimental until its
+        # GPU parity tests have run on hardware: opt in with HARL_GRU128=1
+        self.gru_wide = (self.recurrent and self.hidden_sizes[-1] == 128 and self.recurrent_n == 1
+                         and os.environ.get("HARL_GRU128", "0") == "1")
+        # HARL_GRU_COMPOSED=1 sends 64-wide GRUs through the same composition: a cross-check of gru_wide.py against the
+        # fused kernels and their goldens (tests only)
+        if self.recurrent and self.hidden_sizes[-1] == 64 and self.recurrent_n == 1 and os.environ.get("HARL_GRU_COMPOSED") == "1":
+            self.gru_wide = True
+        if self.recurrent and not self.gru_wide and (self.hidden_sizes[-1] != 64 or self.recurrent_n != 1):
             raise NotImplementedError("GRU kernels: hidden width 64 and recurrent_n = 1 (every recurrent tuned HARL config)")
         for h in self.hidden_sizes:
             if h not in SUPPORTED_WIDTHS:
@@ -316,6 +324,9 @@ class _FlatNet(nn.Module):
             self.rnn_dgate = [a() for _ in range(4)]   # dr, dz, dn, dhn
             self.rnn_ones = torch.full((n_slabs * 64,), -1, dtype=u32, device=dev)  # all-ones "relu mask" for rnn.norm
             self.rnn_gi = torch.empty(3 * mp * H, dtype=f32, device=dev)  # input half of the gates, all steps (gru.hip)
+            if self.gru_wide:
+                from . import gru_wide
+                gru_wide.ensure_ws(self, mp)
         self.n_head_blocks = max(_lib.load().harl_head_blocks(M), self.n_wg)
         self.part_scalars = torch.zeros(self.n_head_blocks * PS_STRIDE, dtype=f32, device=dev)
         self.scalars = torch.zeros(PS_STRIDE, dtype=torch.float64, device=dev)
@@ -330,6 +341,9 @@ class _FlatNet(nn.Module):
 
     def forward_rnn(self, seq: dict, save: bool) -> None:
         """GRU over a recurrent batch (seq: L, m_pad, h0 [m_pad, H], mask_rows [L*m_pad], optional h_last out)."""
+        if self.gru_wide:
+            from . import gru_wide
+            return gru_wide.forward(self, seq, save)
         gp = self.gru_pack
         sv = self.rnn_saved
         call("harl_gru_fwd", ptr(self.xh[-1]), ptr(seq["mask_rows"]), ptr(seq["h0"]), ptr(gp["Wih"]), ptr(gp["bih"]),
@@ -472,10 +486,14 @@ class _FlatNet(nn.Module):
         if self.recurrent:
             gp, sv, dg = self.gru_pack, self.rnn_saved, self.rnn_dgate
             H = self.hidden_sizes[-1]
-            call("harl_gru_bwd", ptr(self.dz[0]), ptr(seq["mask_rows"]), ptr(gp["Wih"]), ptr(gp["Whh"]), ptr(sv[0]),
-                 ptr(sv[1]), ptr(sv[2]), ptr(sv[3]), ptr(sv[4]), H, seq["L"], seq["m_pad"], ptr(self.xh[-1]),
-                 ptr(self.rmask[-1]), ptr(self.rstd[-1]), ptr(dg[0]), ptr(dg[1]), ptr(dg[2]), ptr(dg[3]), ptr(self.dz[1]), s,
-                 tag="gru_bwd")
+            if self.gru_wide:
+                from . import gru_wide
+                gru_wide.backward(self, seq)
+            else:
+                call("harl_gru_bwd", ptr(self.dz[0]), ptr(seq["mask_rows"]), ptr(gp["Wih"]), ptr(gp["Whh"]), ptr(sv[0]),
+                     ptr(sv[1]), ptr(sv[2]), ptr(sv[3]), ptr(sv[4]), H, seq["L"], seq["m_pad"], ptr(self.xh[-1]),
+                     ptr(self.rmask[-1]), ptr(self.rstd[-1]), ptr(dg[0]), ptr(dg[1]), ptr(dg[2]), ptr(dg[3]), ptr(self.dz[1]), s,
+                     tag="gru_bwd")
             for gate, a in enumerate((dg[0], dg[1], dg[2])):      # W_ih' gate blocks: d gi^T x_hat_mlp
                 call("harl_mlp_dw_partials", ptr(a), 0, 0, H, ptr(self.xh[-1]), 0, 0, None, None, None, H, M,
                      ptr(self.part[po[L + gate]:]), nwg, s, tag="dw_gru")

@@ -389,6 +389,24 @@ int harl_update_bwd(const float *x0n, const float *dz2, long M, int D, int H, co
 int harl_gru_fwd(const float *xin, const float *mask_rows, const float *h0, const float *Wih, const float *bih,
                  const float *Whh, const float *bhh, int H, int L, long m_pad, float *y, float *rstd_y, float *hpm, float *r,
                  float *z, float *n, float *hn, float *h_last, int save, float *gi_ws, void *stream);
+/* GRU steps composed from layer GEMMs, for hidden widths whose W_hh images do not fit the LDS of the fused kernels above
+ * (H = 128; csrc/gru_cell.hip, host composition in harl_amd/gru_wide.py; H = 64 is instantiated too, as a cross-check of the
+ * composition against harl_gru_fwd / harl_gru_bwd).  Per step l (m_pad rows, ATL(H) images):
+ *   gh_g = harl_mlp_linear(h~_l, W_hg, b_hg), g = r, z, n ; gi_g (all steps) = harl_mlp_linear(x_hat, W_ig', b_ig')
+ *   harl_gru_cell_init: hpm0 = h0 (row-major [m_pad, H]) * mask_0
+ *   harl_gru_cell_fwd : r, z, n, hn (= gh_n; all four NULL when nothing is saved), h_l, h~_{l+1} = h_l * mask_next (NULL at the
+ *     last step), h_last (row-major, nullable)
+ *   harl_gru_cell_bwd : G_l = dh_out_l + mask_next * (gz + t_r + t_z + t_n) with gz = G_{l+1} z_{l+1} (in place: leaves G_l z_l)
+ *     and t_g = W_hg^T dgh_{g,l+1} (all NULL at the last step); outputs dr, dz, dn (= d gi) and dhn (d gh = [dr, dz, dhn])
+ *   harl_rownorm      : y = (x - mean) rstd over M rows (rnn.norm without its affine part), rstd[M_pad] */
+int harl_gru_cell_init(const float *h0, const float *mask_rows, int H, long m_pad, float *hpm0, void *stream);
+int harl_gru_cell_fwd(const float *gi_r, const float *gi_z, const float *gi_n, const float *gh_r, const float *gh_z,
+                      const float *gh_n, const float *hpm, const float *mask_next, int H, long m_pad, float *r, float *z,
+                      float *n, float *hn, float *h, float *hpm_next, float *h_last, void *stream);
+int harl_gru_cell_bwd(const float *dh_out, const float *t_r, const float *t_z, const float *t_n, const float *mask_next,
+                      const float *r, const float *z, const float *n, const float *hn, const float *hpm, int H, long m_pad,
+                      float *gz, float *dr, float *dz, float *dn, float *dhn, void *stream);
+int harl_rownorm(const float *x, long M, int H, float *y, float *rstd, void *stream);
 /* dhout = d(loss)/d(h_l) through the output path (after the rnn.norm backward, done by the head kernels with an all-ones relu
  * mask).  Outputs the gate gradients dr, dz, dn (d gi = [dr,dz,dn]) and dhn (d gh = [dr,dz,dhn]) as ATL(H) for
  * harl_mlp_dw_partials, and dz_mlp = LayerNorm/ReLU backward of W_ih'^T dgi for the last MLP layer (xmlp / mask_mlp / rstd_mlp). */

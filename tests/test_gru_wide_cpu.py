@@ -72,3 +72,166 @@ def test_gru128_launch_sequence(stub_kernels, monkeypatch):  # noqa: F811
     # weight gradients of the six gate blocks run on the ordinary two-operand kernel at HO = K = 128
     gate_dw = [c for c in calls["harl_mlp_dw_partials"] if c[3] == H and c[10] == H]
     assert len(gate_dw) >= 6 * n_bwd_passes
+
+
+# ------------------------------------------------------------------------------------------------
+# Functional check of the COMPOSITION on the CPU: the entry points gru_wide.py calls are emulated with torch ops on
+# row-major [rows, H] arrays (the ATL layout is opaque to the host code: every emulated kernel uses the same one), and the
+# composed forward / BPTT is compared with autograd through a plain torch GRU.  What this cannot see is the kernels' own
+# indexing -- that is what the gated GPU tests are for.
+# ------------------------------------------------------------------------------------------------
+class _Arena:
+    """address -> tensor view, for the raw pointers the host code hands to the C ABI"""
+
+    def __init__(self):
+        self.regs = []
+
+    def add(self, t):
+        flat = t.reshape(-1)
+        self.regs.append((flat.data_ptr(), flat.data_ptr() + flat.numel() * flat.element_size(), flat))
+
+    def view(self, p, n):
+        for lo, hi, flat in self.regs:
+            if lo <= p < hi:
+                off = (p - lo) // flat.element_size()
+                assert off + n <= flat.numel(), "emulated kernel would run past the end of a buffer"
+                return flat[off:off + n]
+        raise AssertionError(f"pointer {p:#x} is not inside any registered buffer")
+
+
+def _emulate(arena, H):
+    def linear(xin, M, HI, HO, Wp, bp, xout, s):
+        x = arena.view(xin, M * HI).view(M, HI)
+        W = arena.view(Wp, HO * HI).view(HO, HI)
+        arena.view(xout, M * HO).view(M, HO).copy_(x @ W.t() + arena.view(bp, HO))
+
+    def cell_init(h0, mask_rows, H_, mp, hpm0, s):
+        arena.view(hpm0, mp * H).view(mp, H).copy_(arena.view(h0, mp * H).view(mp, H) * arena.view(mask_rows, mp).view(mp, 1))
+
+    def cell_fwd(gi_r, gi_z, gi_n, gh_r, gh_z, gh_n, hpm, mask_next, H_, mp, r, z, n, hn, h, hpm_next, h_last, s):
+        v = lambda p: arena.view(p, mp * H).view(mp, H)  # noqa: E731
+        rr = torch.sigmoid(v(gi_r) + v(gh_r))
+        zz = torch.sigmoid(v(gi_z) + v(gh_z))
+        nn_ = torch.tanh(v(gi_n) + rr * v(gh_n))
+        hh = (1 - zz) * nn_ + zz * v(hpm)
+        v(h).copy_(hh)
+        if r is not None:
+            v(r).copy_(rr); v(z).copy_(zz); v(n).copy_(nn_); v(hn).copy_(v(gh_n))
+        if hpm_next is not None:
+            v(hpm_next).copy_(hh * arena.view(mask_next, mp).view(mp, 1))
+        if h_last is not None:
+            v(h_last).copy_(hh)
+
+    def cell_bwd(dh_out, t_r, t_z, t_n, mask_next, r, z, n, hn, hpm, H_, mp, gz, dr, dz, dn, dhn, s):
+        v = lambda p: arena.view(p, mp * H).view(mp, H)  # noqa: E731
+        G = v(dh_out).clone()
+        if t_r is not None:
+            G += arena.view(mask_next, mp).view(mp, 1) * (v(gz) + v(t_r) + v(t_z) + v(t_n))
+        rr, zz, nn_, hn_, hp = v(r), v(z), v(n), v(hn), v(hpm)
+        dpre_n = G * (1 - zz) * (1 - nn_ * nn_)
+        v(dz).copy_(G * (hp - nn_) * zz * (1 - zz))
+        v(dn).copy_(dpre_n)
+        v(dr).copy_(dpre_n * hn_ * rr * (1 - rr))
+        v(dhn).copy_(dpre_n * rr)
+        v(gz).copy_(G * zz)
+
+    def rownorm(x, M, H_, y, rstd, s):
+        xx = arena.view(x, M * H).view(M, H)
+        mu = xx.mean(-1, keepdim=True)
+        rs = 1.0 / torch.sqrt(((xx - mu) ** 2).mean(-1, keepdim=True) + 1e-5)
+        arena.view(y, M * H).view(M, H).copy_((xx - mu) * rs)
+        arena.view(rstd, M).copy_(rs[:, 0])
+
+    def bwd_dx(dz, xprev, mask_prev, rstd_prev, M, HO, HI, Wp, dz_prev, x0n, kp0, dw_part, n_wg, s):
+        # emulated WITHOUT the LayerNorm / ReLU backward of the MLP layer (identity there): d x_hat = dz W
+        d = arena.view(dz, M * HO).view(M, HO)
+        arena.view(dz_prev, M * HI).view(M, HI).copy_(d @ arena.view(Wp, HO * HI).view(HO, HI))
+
+    return dict(harl_mlp_linear=linear, harl_gru_cell_init=cell_init, harl_gru_cell_fwd=cell_fwd, harl_gru_cell_bwd=cell_bwd,
+                harl_rownorm=rownorm, harl_mlp_bwd_dx=bwd_dx)
+
+
+@pytest.mark.parametrize("H,L,m", [(128, 7, 40), (64, 5, 32)])
+def test_composition_matches_autograd_gru(stub_kernels, monkeypatch, H, L, m):  # noqa: F811
+    from harl_amd import _lib, gru_wide
+    from harl_amd.nets import build_seq
+
+    torch.manual_seed(3)
+    mp = ((m + 31) // 32) * 32
+    M = L * mp
+    f = lambda *s_: torch.randn(*s_, dtype=torch.float64)  # noqa: E731  (fp64: the comparison is about logic, not rounding)
+
+    class Net:  # the attributes gru_wide.py reads from a _FlatNet
+        hidden_sizes = [H]
+        device_ = torch.device("cpu")
+    net = Net()
+    Wih, Whh, bih, bhh = 0.3 * f(3 * H * H), 0.3 * f(3 * H * H), 0.1 * f(3 * H), 0.1 * f(3 * H)
+    net.gru_pack = dict(Wih=Wih, bih=bih, Whh=Whh, bhh=bhh)
+    z = lambda n_: torch.zeros(n_, dtype=torch.float64)  # noqa: E731
+    net.xh, net.rmask, net.rstd = [f(M * H)], [torch.zeros(8, dtype=torch.int32)], [z(M)]
+    net.rnn_saved = [z(M * H) for _ in range(5)]
+    net.rnn_dgate = [z(M * H) for _ in range(4)]
+    net.rnn_gi, net.rnn_y, net.rnn_rstd = z(3 * M * H), z(M * H), z(M)
+    net.dz = [f(M * H), z(M * H)]
+    net.rnn_hraw, net.rnn_gh, net.rnn_gz, net.rnn_zero_bias = z(M * H), z(3 * M * H), z(M * H), z(H)
+    mask_rows = (torch.rand(M, dtype=torch.float64) > 0.2).to(torch.float64)
+    seq = dict(L=L, m_pad=mp, m=m, h0=0.5 * f(mp * H), mask_rows=mask_rows, h_last=z(mp * H))
+
+    arena = _Arena()
+    for t in (Wih, Whh, bih, bhh, net.xh[0], net.rstd[0], *net.rnn_saved, *net.rnn_dgate, net.rnn_gi, net.rnn_y, net.rnn_rstd,
+              *net.dz, net.rnn_hraw, net.rnn_gh, net.rnn_gz, net.rnn_zero_bias, mask_rows, seq["h0"], seq["h_last"]):
+        arena.add(t)
+    emu = _emulate(arena, H)
+    keep = []  # tensors created inside gru_wide (the transposed W_hh) must stay alive and be addressable
+
+    real_ptr = _lib.ptr
+
+    def ptr(t):
+        if t is None:
+            return None
+        if not any(lo <= t.data_ptr() < hi for lo, hi, _ in arena.regs):
+            keep.append(t)
+            arena.add(t if t.is_contiguous() else t.contiguous())
+        return real_ptr(t)
+
+    def call(name, *args, tag=None):
+        emu[name](*args)
+
+    monkeypatch.setattr(gru_wide, "call", call)
+    monkeypatch.setattr(gru_wide, "ptr", ptr)
+    monkeypatch.setattr(gru_wide, "stream", lambda: 0)
+
+    # ---- reference: plain torch GRU with autograd (torch.nn.GRU's equations, gate order r, z, n; masks reset the carried state)
+    x = net.xh[0].view(L, mp, H).clone().requires_grad_(True)
+    Wi, Wh = Wih.view(3, H, H).clone().requires_grad_(True), Whh.view(3, H, H).clone().requires_grad_(True)
+    h = seq["h0"].view(mp, H)
+    hs = []
+    for l in range(L):
+        ht = h * mask_rows[l * mp:(l + 1) * mp].view(mp, 1)
+        gi = [x[l] @ Wi[g].t() + bih[g * H:(g + 1) * H] for g in range(3)]
+        gh = [ht @ Wh[g].t() + bhh[g * H:(g + 1) * H] for g in range(3)]
+        r_ = torch.sigmoid(gi[0] + gh[0])
+        z_ = torch.sigmoid(gi[1] + gh[1])
+        n_ = torch.tanh(gi[2] + r_ * gh[2])
+        h = (1 - z_) * n_ + z_ * ht
+        hs.append(h)
+    hraw = torch.stack(hs)                                   # [L, mp, H]
+    mu = hraw.mean(-1, keepdim=True)
+    y_ref = (hraw - mu) / torch.sqrt(((hraw - mu) ** 2).mean(-1, keepdim=True) + 1e-5)
+
+    gru_wide.forward(net, seq, save=True)
+    assert torch.allclose(net.rnn_y.view(L, mp, H), y_ref.detach(), atol=1e-12)
+    assert torch.allclose(seq["h_last"].view(mp, H), hs[-1].detach(), atol=1e-12)
+
+    G = net.dz[0].view(L, mp, H).clone()                     # d(loss)/d(h_l)
+    (hraw * G).sum().backward()
+    gru_wide.backward(net, seq)
+    assert torch.allclose(net.dz[1].view(L, mp, H), x.grad, atol=1e-10)               # gradient into the MLP output
+    # weight gradients as backward_trunk forms them from the gate gradients: dW_ig = dgi_g^T x_hat, dW_hg = dgh_g^T h~
+    xh = net.xh[0].view(M, H)
+    hpm = net.rnn_saved[0].view(M, H)
+    for g, (gi_g, gh_g) in enumerate(zip((0, 1, 2), (0, 1, 3))):
+        dWi = net.rnn_dgate[gi_g].view(M, H).t() @ xh
+        dWh = net.rnn_dgate[gh_g].view(M, H).t() @ hpm
+        assert torch.allclose(dWi, Wi.grad[g], atol=1e-9), g
+        assert torch.allclose(dWh, Wh.grad[g], atol=1e-9), g

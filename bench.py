@@ -241,6 +241,24 @@ def git_sha() -> str | None:
     return sha or None
 
 
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: re-execute this command line under torch.distributed.run, one rank per
+    GPU of this node (rendezvous on 127.0.0.1, a free port unless MASTER_PORT is set).  Rank 0 of the child job prints the
+    JSON line on the inherited stdout; everything else the ranks write goes to stderr."""
+    import socket
+
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = str(sk.getsockname()[1])
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -261,7 +279,11 @@ def main():
     ap.add_argument("--time-all-tags", action="store_true",
                     help="bracket EVERY tagged launch inside the timed region (used by tools/pmc_traffic.sh so that `kernels` "
                          "describes exactly the step the PMC passes profile; costs ~10 %% of the step)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher check without a GPU: spawn / rendezvous (gloo) / one all-reduce, then print a line with value null")
     args = ap.parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
     w = WORKLOADS[args.config]
     # stdout carries exactly ONE line (the JSON): everything else that native libraries write to file descriptor 1 -- RCCL prints
     # a version banner there when the process group goes away -- is sent to stderr
@@ -277,6 +299,20 @@ def main():
                           MASTER_PORT=os.environ.get("MASTER_PORT", "29533"), HARL_DIST_SINGLE="1")
     comm = init_from_env()
     rank, world = comm.rank, comm.world_size
+    if args.dry_run:  # tests/test_bench_launcher_cpu.py: the command line the driver runs, minus the GPU work
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        comm.all_reduce_sum(t)
+        assert world == args.gpus and float(t.item()) == world * (world + 1) / 2, (world, args.gpus, t)
+        if rank == 0:
+            os.write(json_fd, (json.dumps(dict(metric=w["metric"], value=None, unit="transitions/s", n_gpus=world, steps=args.steps,
+                                               warmup=args.warmup, dry_run=True,
+                                               config=dict(parallelism=f"dp{world}",
+                                                           collective=torch.distributed.get_backend() if comm.enabled else "none")))
+                               + "\n").encode())
+        if comm.enabled:
+            torch.distributed.barrier()
+            torch.distributed.destroy_process_group()
+        return
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     device = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(device)
@@ -374,7 +410,8 @@ def main():
                                  f"{'Discrete' if w['disc'] else 'Box'}{w['act']}, MLP{w['hidden']}{' + GRU' if w.get('rnn') else ''}, "
                                  f"{'ppo_epoch=5, ' if w['algo'] == 'happo' else 'CG 10 + line search, '}critic_epoch=5",
                         baseline_config=args.config, episode_length=Tn, n_rollout_threads_per_gpu=n_local, n_agents=w["A"],
-                        parallelism=f"dp{world}", collective="rccl" if comm.enabled else "none", git_sha=git_sha()),
+                        parallelism=f"dp{world}", collective="rccl" if comm.enabled else "none",
+                        world_size=torch.distributed.get_world_size() if comm.enabled else 1, git_sha=git_sha()),
             roofline=roof,
             kernels={k: dict(n=v["n"], avg_ms=round(v["avg_ms"], 4), total_ms=round(v["total_ms"], 3),
                              **({"hbm_frac": round(v["bytes"] / (v["total_ms"] * 1e-3) / HBM_PEAK, 4), "alg_bytes": v["bytes"]}

@@ -37,27 +37,43 @@ def _extra_flags() -> dict:
 EXTRA_FLAGS = _extra_flags()
 
 
-def _stale() -> bool:
-    if not os.path.exists(LIB):
+def _flag_stamp(extra: dict) -> str:
+    """The effective per-file flag set as text; stored next to the library so that a build made with other flags counts as
+    stale (A/B measurements must not be attributed to the wrong variant)."""
+    return ";".join("%s:%s" % (k, " ".join(extra[k])) for k in sorted(extra) if extra[k])
+
+
+def _stale(lib: str, extra: dict) -> bool:
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
+    try:
+        with open(lib + ".flags") as f:
+            if f.read() != _flag_stamp(extra):
+                return True
+    except OSError:
+        return True
+    t = os.path.getmtime(lib)
     deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile every HIP source into harl_amd/lib/libharl_hip.so for gfx950."""
-    if not force and not _stale():
-        return LIB
+def build(force: bool = False, verbose: bool = False, variant: str = "", extra: dict = None) -> str:
+    """Compile every HIP source into harl_amd/lib/libharl_hip.so for gfx950 (``variant``: libharl_<variant>.so with its own
+    object directory, for A/B builds selected at run time with HARL_LIB)."""
+    extra = EXTRA_FLAGS if extra is None else extra
+    lib = LIB if not variant else os.path.join(LIBDIR, "libharl_%s.so" % variant)
+    if not force and not _stale(lib, extra):
+        return lib
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    os.makedirs(LIBDIR, exist_ok=True)
+    objdir = LIBDIR if not variant else os.path.join(LIBDIR, "obj_" + variant)
+    os.makedirs(objdir, exist_ok=True)
     objs = []
     procs = []
     for src in SOURCES:  # one hipcc per translation unit, in parallel
-        obj = os.path.join(LIBDIR, src.replace(".hip", ".o"))
+        obj = os.path.join(objdir, src.replace(".hip", ".o"))
         objs.append(obj)
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", os.path.join(CSRC, src), "-o", obj]
-        cmd += EXTRA_FLAGS.get(src, [])
+        cmd += extra.get(src, [])
         procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     for cmd, p in procs:
         out, _ = p.communicate()
@@ -65,9 +81,11 @@ def build(force: bool = False, verbose: bool = False) -> str:
             raise RuntimeError("hipcc failed: %s\n%s" % (" ".join(cmd), out.decode(errors="replace")))
         if verbose and out:
             print(out.decode(errors="replace"))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs
     subprocess.check_call(cmd)
-    return LIB
+    with open(lib + ".flags", "w") as f:
+        f.write(_flag_stamp(extra))
+    return lib
 
 
 if __name__ == "__main__":

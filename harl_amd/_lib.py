@@ -15,7 +15,8 @@ import torch
 from .traffic import algorithmic_bytes
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libharl_hip.so")
+# HARL_LIB=<variant> selects harl_amd/lib/libharl_<variant>.so (A/B builds of the same sources, harl_amd/_build.py)
+LIB_PATH = os.path.join(_HERE, "lib", "libharl_%s.so" % (os.environ.get("HARL_LIB") or "hip"))
 
 PS_STRIDE = 48
 DHEAD_LD = 32

@@ -15,13 +15,12 @@ HEADERS = ["common.h", "split_mfma.h", "mfma_transpose.h", "heads_common.h", os.
 
 # MFMA results in VGPRs instead of AGPRs: the epilogues (LayerNorm / ReLU, operand splits, transposes) consume every
 # accumulator element on the VALU, and each element held in an AGPR costs a v_accvgpr_read first -- 5.7 % of the issue slots of
-# k_bwd_dx<128,128,1>, 17 % of <64,64,2> (tools/isa_census.py; measured +2.3 % on the MPE update).  Per file:
-# the same flag crashes the compiler on heads.hip and changes nothing in wide.hip / update.hip.
-# NOT switched on yet: the round's GPU budget ran out before the full parity suite could be run on the variant (smoke and the
-# bench were green on it); enable with HARL_HIPCC_EXTRA="mlp.hip:-mllvm -amdgpu-mfma-vgpr-form;gru.hip:...;panel.hip:..." or by
-# filling DEFAULT_EXTRA once `pytest -m gpu` has passed on such a build.
+# k_bwd_dx<128,128,1>, 17 % of <64,64,2> (tools/isa_census.py).  Per file: the same flag crashes the compiler on heads.hip and
+# changes nothing in wide.hip / update.hip.  Adopted in round 3 after the full GPU parity suite passed on the variant
+# (gpurun_out/r3_vgpr_suite.log: 107 passed; A/B on one box 21.53 / 21.69 -> 20.93 / 21.18 ms per MPE update).
+# HARL_HIPCC_EXTRA="mlp.hip:;gru.hip:..." overrides per file for A/B builds.
 VGPR_FORM = ["-mllvm", "-amdgpu-mfma-vgpr-form"]
-DEFAULT_EXTRA: dict = {}
+DEFAULT_EXTRA: dict = {"mlp.hip": VGPR_FORM, "gru.hip": VGPR_FORM, "panel.hip": VGPR_FORM}
 
 
 def _extra_flags() -> dict:

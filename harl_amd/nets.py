@@ -322,7 +322,9 @@ class _FlatNet(nn.Module):
             self.rnn_y, self.rnn_rstd = a(), torch.empty(mp, dtype=f32, device=dev)
             self.rnn_saved = [a() for _ in range(5)]   # h~ (= h*mask), r, z, n, hn
             self.rnn_dgate = [a() for _ in range(4)]   # dr, dz, dn, dhn
-            self.rnn_ones = torch.full((n_slabs * 64,), -1, dtype=u32, device=dev)  # all-ones "relu mask" for rnn.norm
+            # all-ones "relu mask" for rnn.norm: (H/2 + 31) / 32 words per lane (two at H = 128 -- sized for one, the head kernels
+            # read the second word past the end: the first hardware run of the 128-wide GRU, round 3)
+            self.rnn_ones = torch.full((n_slabs * 64 * ((H // 2 + 31) // 32),), -1, dtype=u32, device=dev)
             self.rnn_gi = torch.empty(3 * mp * H, dtype=f32, device=dev)  # input half of the gates, all steps (gru.hip)
             if self.gru_wide:
                 from . import gru_wide

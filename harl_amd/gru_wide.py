@@ -9,8 +9,9 @@ it (cell backward + ``W_hg^T dgh_g`` GEMMs per step) and ends in the tensors the
 gradients ``net.rnn_dgate`` and the gradient into the last MLP layer ``net.dz[1]`` -- so that ``_FlatNet.backward_trunk``
 continues unchanged (weight gradients of the six gate blocks, MLP layers).
 
-Coverage path: launch-bound (4 L small launches per pass), not tuned.  EXPERIMENTAL until its GPU parity tests have run on
-hardware: ``_FlatNet`` only accepts a 128-wide GRU with ``HARL_GRU128=1`` in the environment.
+Coverage path: launch-bound (4 L small launches per pass), not tuned.  Parity-green on hardware since round 3 (the
+reference goldens ``rnn_box_h128`` / ``rnn_disc_h128_mb2``, and the same composition on 64-wide GRUs against the goldens of
+the fused kernels): the default for 128-wide GRUs; ``HARL_GRU128=0`` makes ``_FlatNet`` refuse them as before.
 """
 from __future__ import annotations
 

@@ -62,16 +62,16 @@ class _FlatNet(nn.Module):
             raise NotImplementedError("harl_amd kernels implement relu MLPs only (every tuned HARL config uses relu)")
         self.recurrent = bool(args.get("use_recurrent_policy", False) or args.get("use_naive_recurrent_policy", False))
         self.recurrent_n = int(args.get("recurrent_n", 1))
-        # a 128-wide GRU is composed from layer GEMMs + element-wise cell kernels (harl_amd/gru_wide.py); experimental until its
-        # GPU parity tests have run on hardware: opt in with HARL_GRU128=1
+        # a 128-wide GRU is composed from layer GEMMs + element-wise cell kernels (harl_amd/gru_wide.py; parity-green on
+        # hardware since round 3: goldens rnn_box_h128, rnn_disc_h128_mb2).  HARL_GRU128=0 restores the refusal.
         self.gru_wide = (self.recurrent and self.hidden_sizes[-1] == 128 and self.recurrent_n == 1
-                         and os.environ.get("HARL_GRU128", "0") == "1")
+                         and os.environ.get("HARL_GRU128", "1") != "0")
         # HARL_GRU_COMPOSED=1 sends 64-wide GRUs through the same composition: a cross-check of gru_wide.py against the
         # fused kernels and their goldens (tests only)
         if self.recurrent and self.hidden_sizes[-1] == 64 and self.recurrent_n == 1 and os.environ.get("HARL_GRU_COMPOSED") == "1":
             self.gru_wide = True
         if self.recurrent and not self.gru_wide and (self.hidden_sizes[-1] != 64 or self.recurrent_n != 1):
-            raise NotImplementedError("GRU kernels: hidden width 64 and recurrent_n = 1 (every recurrent tuned HARL config)")
+            raise NotImplementedError("GRU kernels: hidden width 64 (fused) or 128 (composed), recurrent_n = 1")
         for h in self.hidden_sizes:
             if h not in SUPPORTED_WIDTHS:
                 raise NotImplementedError(f"hidden width {h}: kernels are instantiated for {SUPPORTED_WIDTHS}")

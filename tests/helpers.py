@@ -20,7 +20,7 @@ TRPO_CASES = ["trpo_box_h64", "trpo_disc_h64", "trpo_wide_h128x3"]
 TRPO_RNN_CASES = ["trpo_rnn_disc_h64", "trpo_rnn_box_h64", "trpo_rnn_fp_disc36_h64"]
 RNN_CASES = ["rnn_box_h64", "rnn_disc_h64_mb2", "rnn_naive_h64", "rnn_fp_box_h64_mb2", "rnn_naive_fp_disc_h64",
              "rnn_fp_disc36_h64"]
-# GRU on 128-wide layers (harl_amd/gru_wide.py, opt-in): fixtures recorded, GPU tests behind HARL_TEST_EXPERIMENTAL=1
+# GRU on 128-wide layers (harl_amd/gru_wide.py: per-step composition of layer GEMMs + cell kernels)
 RNN128_CASES = ["rnn_box_h128", "rnn_disc_h128_mb2"]
 MAPPO_CASES = ["mappo_box_h64", "mappo_shared_disc_h64_mb2", "mappo_shared_fp_box_h128"]
 # MultiDiscrete action spaces (act.py:35-43,117-141): MLP with mini-batches, the LAG layout [41, 41, 41, 30] (two logits

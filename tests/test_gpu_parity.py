@@ -133,12 +133,6 @@ def test_recurrent_train_matches_reference_golden(name):
     _assert_all(_G().check_train_golden(name), tol=TOL)
 
 
-_EXPERIMENTAL = pytest.mark.skipif(os.environ.get("HARL_TEST_EXPERIMENTAL") != "1",
-                                   reason="composed GRU path (harl_amd/gru_wide.py): written and CPU-checked, first GPU run pending "
-                                          "-- set HARL_TEST_EXPERIMENTAL=1")
-
-
-@_EXPERIMENTAL
 @pytest.mark.parametrize("name", ["rnn_box_h64", "rnn_disc_h64_mb2", "rnn_naive_fp_disc_h64"])
 def test_composed_gru_matches_64_wide_goldens(name, monkeypatch):
     """The per-step composition (layer GEMMs + element-wise cell kernels) on 64-wide GRUs against the goldens the fused kernels
@@ -147,11 +141,9 @@ def test_composed_gru_matches_64_wide_goldens(name, monkeypatch):
     _assert_all(_G().check_train_golden(name), tol=TOL)
 
 
-@_EXPERIMENTAL
 @pytest.mark.parametrize("name", ["rnn_box_h128", "rnn_disc_h128_mb2"])
 def test_gru128_train_matches_reference_golden(name, monkeypatch):
     """GRU policies on 128-wide layers (the default hidden_sizes with use_recurrent_policy) vs the reference."""
-    monkeypatch.setenv("HARL_GRU128", "1")
     _assert_all(_G().check_train_golden(name), tol=TOL)
 
 

@@ -20,11 +20,11 @@ def _runner(hidden, T=10, N=6, A=2):
                                     device=torch.device("cpu"))
 
 
-def test_gru128_is_opt_in(stub_kernels, monkeypatch):  # noqa: F811
-    monkeypatch.delenv("HARL_GRU128", raising=False)
+def test_gru128_is_default_and_can_be_refused(stub_kernels, monkeypatch):  # noqa: F811
+    monkeypatch.setenv("HARL_GRU128", "0")
     with pytest.raises(NotImplementedError):
         _runner([128, 128])
-    monkeypatch.setenv("HARL_GRU128", "1")
+    monkeypatch.delenv("HARL_GRU128", raising=False)
     r = _runner([128, 128])
     assert r.actor[0].actor.gru_wide and r.critic.critic.gru_wide
     from harl_amd.hatrpo import HATRPO

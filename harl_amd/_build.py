@@ -10,7 +10,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libharl_hip.so")
 SOURCES = ["elementwise.hip", "mlp.hip", "wide.hip", "panel.hip", "heads.hip", "multihead.hip", "update.hip", "gru.hip", "gru_cell.hip", "host_rng.hip"]
-HEADERS = ["common.h", "split_mfma.h", "mfma_transpose.h", "heads_common.h", os.path.join("..", "..", "include", "harl_hip.h")]
+HEADERS = ["common.h", "split_mfma.h", "mfma_transpose.h", "heads_common.h", "dw_common.h", os.path.join("..", "..", "include", "harl_hip.h")]
 
 
 # MFMA results in VGPRs instead of AGPRs: the epilogues (LayerNorm / ReLU, operand splits, transposes) consume every

@@ -52,6 +52,7 @@ SIGNATURES = {
     "harl_pack_scalars_hilo": [_vp, _vp, _vp],
     "harl_randperm_replay": [_vp, _l, _l, _vp, _vp, _vp],
     "harl_rng_advance": [_vp, _l, _l, _vp],
+    "harl_rng_jump": [_vp, _l, _l, _vp],
     "harl_actor_head_logp": [_vp, _l, _i, _vp, _vp, _vp, _f, _f, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _l, _l, _vp],
     "harl_actor_head_loss": [_vp, _vp, _vp, _l, _i, _vp, _vp, _vp, _f, _f, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,
                              _vp, _vp, _d, _f, _i, _i, _l, _l, _vp, _vp, _vp, _vp, _vp, _i, _vp],

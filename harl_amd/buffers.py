@@ -10,8 +10,6 @@ in the same order; only the resulting int64 index arrays are uploaded.
 from __future__ import annotations
 
 import os
-import queue
-import threading
 from typing import Iterator, List, Optional, Tuple
 
 import numpy as np
@@ -76,7 +74,7 @@ def _skip_matches_random() -> bool:
         try:
             ok = True
             lib = _lib.load()
-            for seed, n in ((987654321, 1030), (5, 70000)):
+            for seed, n in ((987654321, 1030), (5, 70000), (7, 624 * 2600 + 11)):  # the last one takes the polynomial jump
                 torch.manual_seed(seed)
                 torch.empty(17, dtype=torch.int32).random_()  # start mid-block (no torch.randperm here: callers may tap it)
                 mid = torch.get_rng_state()
@@ -95,8 +93,8 @@ def _skip_matches_random() -> bool:
 
 def _advance_generator(n: int) -> None:
     """Advance the global CPU generator by n 32-bit draws.  The C skip-ahead only refreshes the mt19937 state blocks
-    (~0.3 ms per 819200 draws); ``Tensor.random_`` tempers and stores every output (~1 ms) -- with 20 advances per train()
-    on the replay thread that was within a few ms of the whole update's GPU time, i.e. the thing train() ended up waiting for."""
+    (~0.1 ms per 819200 draws) and jumps ahead polynomially beyond ~1.5 M draws; ``Tensor.random_`` tempers and stores every
+    output (~1 ms per 819200)."""
     if os.environ.get("HARL_RNG_SKIP", "1") != "0" and _skip_matches_random():
         st = torch.get_rng_state()
         out = torch.empty_like(st)
@@ -106,39 +104,22 @@ def _advance_generator(n: int) -> None:
     torch.empty(n, dtype=torch.int32).random_()
 
 
-class _RngWorker:
-    """FIFO background replay of generator advances.  ``Tensor.random_`` releases the GIL, so the ~0.6 ms per
-    819200-draw advance overlaps with the kernel launches of the update it belongs to instead of stalling the GPU
-    (20 advances per MPE train()).  Nothing else may touch the global CPU generator until ``rng_sync()`` returns;
-    every RNG consumer in this package calls it first and ``train()`` calls it before returning."""
-
-    def __init__(self):
-        self._q: "queue.Queue[int]" = queue.Queue()
-        self._t = threading.Thread(target=self._run, name="harl-rng-replay", daemon=True)
-        self._t.start()
-
-    def _run(self):
-        while True:
-            n = self._q.get()
-            try:
-                _advance_generator(n)
-            finally:
-                self._q.task_done()
-
-    def submit(self, n: int) -> None:
-        self._q.put(n)
-
-    def drain(self) -> None:
-        self._q.join()
-
-
-_RNG_WORKER: Optional[_RngWorker] = None
+# Deferred generator advances: with one full-buffer minibatch the permutation of a sampler call is never looked at, only the
+# generator has to end up where torch.randperm would leave it -- and the state after several such calls depends on the TOTAL
+# number of draws only.  consume_randperm() therefore just adds to this counter; rng_sync() -- called before ANY use of the
+# global CPU generator inside this package and at the end of every train() -- applies the total in ONE harl_rng_advance, which
+# jumps ahead in ~0.1-0.3 ms whatever the count is (GF(2) polynomial jump, csrc/host_rng.hip; the polynomial of a given total is
+# built once and cached, and the total of a train() is the same every time).  Round 2 advanced call by call on a background
+# thread: 0.8 ms per call for the 6.5 M draws of an 8-GPU run's global batch, 20 calls per update.
+_PENDING_DRAWS = 0
 
 
 def rng_sync() -> None:
-    """Wait until every deferred generator advance has been applied (call before ANY use of the global CPU RNG)."""
-    if _RNG_WORKER is not None:
-        _RNG_WORKER.drain()
+    """Apply every deferred generator advance (call before ANY use of the global CPU RNG)."""
+    global _PENDING_DRAWS
+    if _PENDING_DRAWS:
+        n, _PENDING_DRAWS = _PENDING_DRAWS, 0
+        _advance_generator(n)
 
 
 def consume_randperm(batch_size: int, deferred: bool = True) -> None:
@@ -146,22 +127,20 @@ def consume_randperm(batch_size: int, deferred: bool = True) -> None:
     the permutation.  Used when ``num_mini_batch == 1``: the single minibatch is the whole buffer, so the update
     does not depend on the order, but every later draw of the run (agent order, next epoch's permutation) must
     still see the same generator state as in the reference.  randperm(819200) costs ~30-70 ms of host time per
-    draw (20 draws per train()); the advance costs ~0.6 ms and runs on the replay thread (``_RngWorker``).
+    draw (20 draws per train()); deferred advances are summed and applied by the next ``rng_sync()`` in one jump.
     Falls back to a real randperm if the self-check fails."""
-    global _RNG_WORKER
+    global _PENDING_DRAWS
     if batch_size <= 1:
         return
     if not _advance_matches_randperm():
         rng_sync()
         torch.randperm(batch_size)
         return
-    if not deferred or batch_size < 65536:
+    if not deferred:
         rng_sync()
         _advance_generator(batch_size - 1)
         return
-    if _RNG_WORKER is None:
-        _RNG_WORKER = _RngWorker()
-    _RNG_WORKER.submit(batch_size - 1)
+    _PENDING_DRAWS += batch_size - 1
 
 
 _REPLAY_OK: Optional[bool] = None

@@ -6,6 +6,42 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// ---------------------------------------------------------------------------------------------
+// Phase timing (debug builds only: -DHARL_PHASE_TIMING, `python -m harl_amd._build` variant "phase", tools/phase_cycles.py).
+// s_memtime at phase boundaries of the persistent kernels' slab loops, summed per phase over the slabs of wave 0 of
+// workgroup 0 and left in a per-translation-unit device array that harl_phase_read_<tu>() copies out.  Compiled out otherwise.
+// ---------------------------------------------------------------------------------------------
+#ifdef HARL_PHASE_TIMING
+#define HARL_NPHASE 12
+static __device__ long long harl_phase_cyc[8][HARL_NPHASE];
+#define PHASE_BEGIN()                                    \
+  long long _pt_acc[HARL_NPHASE];                        \
+  for (int _k = 0; _k < HARL_NPHASE; ++_k) _pt_acc[_k] = 0; \
+  long long _pt_last = __builtin_readcyclecounter();
+#define PHASE(i)                                         \
+  do {                                                   \
+    __builtin_amdgcn_sched_barrier(0);                   \
+    const long long _t = __builtin_readcyclecounter();   \
+    _pt_acc[i] += _t - _pt_last;                         \
+    _pt_last = _t;                                       \
+    __builtin_amdgcn_sched_barrier(0);                   \
+  } while (0)
+#define PHASE_END(slot)                                  \
+  do {                                                   \
+    if (blockIdx.x == 0 && threadIdx.x == 0)             \
+      for (int _k = 0; _k < HARL_NPHASE; ++_k) harl_phase_cyc[slot][_k] = _pt_acc[_k]; \
+  } while (0)
+#define HARL_PHASE_ACCESSOR(tu)                                                                    \
+  extern "C" int harl_phase_read_##tu(long long *out) {                                            \
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(harl_phase_cyc), sizeof(long long) * 8 * HARL_NPHASE); \
+  }
+#else
+#define PHASE_BEGIN()
+#define PHASE(i)
+#define PHASE_END(slot)
+#define HARL_PHASE_ACCESSOR(tu)
+#endif
+
 namespace harl {
 
 constexpr int WAVE = 64;
@@ -34,6 +70,15 @@ __device__ __forceinline__ constexpr int feat_base(int R) {  // f(R, 0)
 
 __device__ __forceinline__ float wave_xor32(float v) {  // exchange with the partner half (lane ^ 32)
   return __shfl_xor(v, 32, 64);
+}
+// v + (the partner half's v), in every lane.  v_permlane32_swap exchanges lanes 32-63 of its first operand with lanes 0-31 of
+// its second; with both operands = v the two results are {own, partner} in one half and {partner, own} in the other, so
+// their sum is the same commutative fp32 addition everywhere.  9 + 5 cycles; __shfl_xor(v, 32) is a ds_bpermute_b32 whose LDS
+// round trip (~60 cycles, tools/valu_cost.hip) sits on the critical path of every LayerNorm statistic.
+__device__ __forceinline__ float wave_sum32(float v) {
+  const unsigned u = __float_as_uint(v);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
 // sum over the 32 lanes of each half (lanes 0-31 and 32-63 separately); result in every lane of the half
@@ -121,8 +166,8 @@ __device__ __forceinline__ void ln_bwd_relu_mbits(const float (&dx)[H / 2], cons
     a2 += d * x;
   }
   float s1 = a1[0] + a1[1], s2 = a2[0] + a2[1];
-  s1 += wave_xor32(s1);
-  s2 += wave_xor32(s2);
+  s1 = wave_sum32(s1);
+  s2 = wave_sum32(s2);
   const float c1 = -(s1 * (1.0f / H)) * rstd, c2 = -(s2 * (1.0f / H)) * rstd;
   const f32x2 c1v = {c1, c1}, c2v = {c2, c2}, rv = {rstd, rstd};
   uint32_t bits[NW];

@@ -235,7 +235,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_gru_fwd(
         store_act(hn_s, slab, lane, hn);
       }
       // rnn.norm (pure normalisation; affine folded into the head)
-      sum += wave_xor32(sum);
+      sum = wave_sum32(sum);
       const float mean = sum * (1.0f / GH);
       float vs = 0.f;
 #pragma unroll
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_gru_fwd(
         const float d = hs[R] - mean;
         vs += d * d;
       }
-      vs += wave_xor32(vs);
+      vs = wave_sum32(vs);
       const float rstd = 1.0f / sqrtf(vs * (1.0f / GH) + 1e-5f);
       float yo[GR];
 #pragma unroll
@@ -370,7 +370,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_gru_fwd_tp(
           hs[r] = (1.f - zg) * ng + zg * hm[r];
           sum += hs[r];
         }
-        sum += wave_xor32(sum);
+        sum = wave_sum32(sum);
         mean_own = sum * (1.0f / 32.f);
         float vs = 0.f;
 #pragma unroll
@@ -378,7 +378,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_gru_fwd_tp(
           const float d = hs[r] - mean_own;
           vs += d * d;
         }
-        m2_own = vs + wave_xor32(vs);
+        m2_own = wave_sum32(vs);
       }
       // ---- hand-off: h~ (own half) as split operands + LayerNorm partials
 #pragma unroll
@@ -699,8 +699,8 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_gru_tangent(
           s2 += hd[R] * yv[c];
         }
       }
-      s1 += wave_xor32(s1);
-      s2 += wave_xor32(s2);
+      s1 = wave_sum32(s1);
+      s2 = wave_sum32(s2);
       s1 *= (1.0f / GH);
       s2 *= (1.0f / GH);
       const float rstd = rstd_y[slab * SLAB + i];

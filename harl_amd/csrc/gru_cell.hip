@@ -146,7 +146,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_rownorm(const float *__restrict_
     float s = 0.f;
 #pragma unroll
     for (int R = 0; R < H / 2; ++R) s += v[R];
-    s += wave_xor32(s);
+    s = wave_sum32(s);
     const float mean = s * (1.0f / H);
     float q = 0.f;
 #pragma unroll
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_rownorm(const float *__restrict_
       v[R] -= mean;
       q += v[R] * v[R];
     }
-    q += wave_xor32(q);
+    q = wave_sum32(q);
     const float rstd = 1.0f / sqrtf(q * (1.0f / H) + 1e-5f);
 #pragma unroll
     for (int R = 0; R < H / 2; ++R) v[R] *= rstd;

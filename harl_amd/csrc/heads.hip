@@ -32,6 +32,7 @@ template <int H, int DAP, bool DISCRETE, bool TRAIN, bool FUSE = false>
 // 256 hipcc spills hundreds of them -- and run one wave per SIMD)
 __global__ __launch_bounds__(WG_THREADS, (FUSE && DAP <= 8) ? 2 : 1) void k_actor_head(ActorArgs A) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  PHASE_BEGIN();
   float *whl = lds;                    // [2][H/2][DAP]
   float *cst = whl + 2 * (H / 2) * DAP;  // bias, sigma, logsigma, dsigma_dlogstd, rowsum, 1/sigma, 1/sigma^2  [DAP each]
   float *red = cst + 7 * DAP;          // [4][PS_STRIDE]
@@ -124,6 +125,7 @@ __global__ __launch_bounds__(WG_THREADS, (FUSE && DAP <= 8) ? 2 : 1) void k_acto
       rstdn = A.rstd[slab_first * SLAB + i];
     }
   }
+  PHASE(10);
   for (long slab = slab_first; slab < A.n_slabs; slab += slab_step) {
     float z[DAP];
     f32x4 xs[TRAIN ? H / 8 : 1];
@@ -151,13 +153,16 @@ __global__ __launch_bounds__(WG_THREADS, (FUSE && DAP <= 8) ? 2 : 1) void k_acto
       } else {
         head_load_regs<H>(A.xL, slab, lane, xs);
       }
+      PHASE(0);
       head_fwd_regs<H, DAP>(xs, whl_h, cst, z);
     } else {
       head_fwd_stream<H, DAP>(A.xL, slab, lane, whl_h, cst, z);
     }
+    PHASE(1);
     float dzh[DAP];
     float s1, s2;
     if (!actor_sample<DAP, DISCRETE, TRAIN>(A, cst, z, slab, lane, adv_mean, adv_den, sc, dzh, s1, s2, rcur)) continue;
+    PHASE(2);
     const long j = slab * SLAB + i;
     if constexpr (FUSE) {  // head weight gradient right here (x_hat_L and dhead are both in registers)
       if constexpr (LDSACC) head_dw_step_lds<H, DAP, HROWS>(xs, dzh, tx, td, lane, hw);
@@ -169,8 +174,10 @@ __global__ __launch_bounds__(WG_THREADS, (FUSE && DAP <= 8) ? 2 : 1) void k_acto
     } else {  // head gradients for the dW kernel
       store_dhead<DAP>(A.dhead, slab, lane, dzh);
     }
+    PHASE(3);
     if constexpr (TRAIN)
       head_bwd_regs_bits<H, DAP>(xs, mb0, mb1, rstd_cur, slab, lane, whl, dzh, s1, s2, A.dzL, mbm1, mbm2);
+    PHASE(4);
   }
 
   if (TRAIN) {
@@ -188,6 +195,8 @@ __global__ __launch_bounds__(WG_THREADS, (FUSE && DAP <= 8) ? 2 : 1) void k_acto
     if constexpr (LDSACC) head_dw_finish_lds<H, DAP, HROWS, WAVES_PER_WG>(hacc, dbacc, dwl, outp);
     else head_dw_finish<H, DAP>(dwacc, dbacc, dwl, outp);
   }
+  PHASE(11);
+  PHASE_END((TRAIN && FUSE) ? 0 : 1);
 }
 
 // =============================================================================================
@@ -373,9 +382,9 @@ __global__ __launch_bounds__(WG_THREADS) void k_actor_head_fvp(FvpArgs A) {
     float zlin[DAP];
 #pragma unroll
     for (int d = 0; d < DAP; ++d) {
-      zlin[d] = z[d] + wave_xor32(z[d]);
+      zlin[d] = wave_sum32(z[d]);
       z[d] = zlin[d] + cst[d];
-      zd[d] = zd[d] + wave_xor32(zd[d]) + cdt[d];
+      zd[d] = wave_sum32(zd[d]) + cdt[d];
     }
     const long j = slab * SLAB + i;
     const bool valid = j < A.M && (A.m_pad == 0 || (j % A.m_pad) < A.m_valid);
@@ -535,6 +544,8 @@ int dispatch_actor(const ActorArgs &A, int H, int discrete, int grid, hipStream_
   return -2;
 }
 }  // namespace
+
+HARL_PHASE_ACCESSOR(heads)
 
 extern "C" int harl_head_blocks(long M) { return head_grid(M); }
 

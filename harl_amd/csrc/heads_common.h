@@ -81,7 +81,7 @@ __device__ __forceinline__ void head_fwd_stream(const float *__restrict__ xL, lo
     xv = xn;
   }
 #pragma unroll
-  for (int d = 0; d < DAP; ++d) z[d] = z[d] + wave_xor32(z[d]) + cst[d];
+  for (int d = 0; d < DAP; ++d) z[d] = wave_sum32(z[d]) + cst[d];
 }
 
 // dz_L = relu_mask ? rstd (dx_hat - mean_f(dx_hat) - x_hat mean_f(dx_hat x_hat)) : 0  with
@@ -156,7 +156,7 @@ __device__ __forceinline__ void head_fwd_regs(const f32x4 (&xs)[H / 8], const fl
     __builtin_amdgcn_sched_barrier(0);
   }
 #pragma unroll
-  for (int d = 0; d < DAP; ++d) z[d] = z[d] + wave_xor32(z[d]) + cst[d];
+  for (int d = 0; d < DAP; ++d) z[d] = wave_sum32(z[d]) + cst[d];
 }
 
 template <int H, int DAP>

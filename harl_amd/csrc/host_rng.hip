@@ -12,6 +12,8 @@
 #include <cstdlib>
 #include <immintrin.h>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <vector>
 
 #include "../../include/harl_hip.h"
@@ -172,6 +174,222 @@ void skip_base(Mt &g, long nd) { HARL_SKIP_BODY }
 #undef HARL_REFRESH
 #undef HARL_SKIP_BODY
 
+// ---------------------------------------------------------------------------------------------
+// Jump-ahead.  Advancing the generator by n draws only refreshes state blocks, floor(n / 624) of them; for the draw counts of
+// a data-parallel run (every rank replays the GLOBAL batch: 6.5 M draws per sampler call at 8 x 4096 threads) that is
+// 10 000 block refreshes = 0.8 ms per call, 20 calls per update.  The block refresh is a linear map over GF(2): with
+// T = one word step of the recurrence x[i+624] = x[i+397] ^ tw(x[i], x[i+1]) on the 19937-bit state, a jump by J steps is
+// g(T) with g(x) = x^J mod phi(x), phi = the characteristic polynomial of T (degree 19937), and
+//     (g(T) s)[j] = XOR over the set bits i of g of x[i + j],   x[0 ..] = the word sequence that starts at the current block,
+// i.e. 20 561 generated words and ~10 000 XORs of 624-word windows: ~0.1 ms independent of J (Haramoto, Matsumoto, Nishimura,
+// Panneton, L'Ecuyer: "Efficient jump ahead for F2-linear random number generators", 2008).  phi comes from Berlekamp-Massey
+// on 2 x 19937 output bits (once per process, ~15 ms); g from square-and-multiply (once per distinct block count, cached).
+// The low 31 bits of a block's word 0 are not part of the linear state, so the jump stops ONE block short and the last
+// refresh is the ordinary next_state(): every word of the final block is then exact, as the bit-identical-state test demands.
+// ---------------------------------------------------------------------------------------------
+constexpr int MT_DEG = 19937, PW = (MT_DEG + 1 + 63) / 64;  // polynomial words (bits 0 .. 19937)
+
+struct Poly {
+  uint64_t w[PW];
+};
+inline bool pbit(const uint64_t *w, int i) { return (w[i >> 6] >> (i & 63)) & 1u; }
+
+const Poly &mt_charpoly() {
+  static Poly phi;
+  static bool done = false;
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lk(mu);
+  if (done) return phi;
+  // output bit sequence b_t = bit 0 of the t-th generated word, from an arbitrary non-zero state
+  constexpr int NB = 2 * MT_DEG + 64;
+  std::vector<uint8_t> b(NB);
+  Mt g;
+  for (int i = 0; i < MT_N; ++i) g.s[i] = 0x9e3779b9u * (uint32_t)(i + 1) + 12345u;
+  for (int t = 0; t < NB;) {
+    g.next_state();
+    for (int i = 0; i < MT_N && t < NB; ++i, ++t) b[t] = g.s[i] & 1u;
+  }
+  // Berlekamp-Massey over GF(2) on bit sets; `win` holds b[n-1], b[n-2], ... at bits 1, 2, ... (bit 0 = b[n] pairs with c_0)
+  constexpr int W = (MT_DEG + 2 + 63) / 64 + 1;
+  std::vector<uint64_t> C(W, 0), B(W, 0), T(W, 0), win(W, 0);
+  C[0] = B[0] = 1;
+  int L = 0, m = 1;
+  for (int n = 0; n < NB; ++n) {
+    for (int k = W - 1; k > 0; --k) win[k] = (win[k] << 1) | (win[k - 1] >> 63);  // window <<= 1, insert b[n] at bit 0
+    win[0] = (win[0] << 1) | b[n];
+    uint64_t acc = 0;
+    const int lw = (L >> 6) + 1;
+    for (int k = 0; k < lw && k < W; ++k) acc ^= C[k] & win[k];
+    const bool d = __builtin_parityll(acc);
+    if (!d) {
+      ++m;
+      continue;
+    }
+    const bool grow = 2 * L <= n;
+    if (grow) T = C;
+    const int ws = m >> 6, bs = m & 63;  // C ^= B << m
+    for (int k = W - 1; k >= ws; --k) {
+      uint64_t v = B[k - ws] << bs;
+      if (bs && k - ws - 1 >= 0) v |= B[k - ws - 1] >> (64 - bs);
+      C[k] ^= v;
+    }
+    if (grow) {
+      L = n + 1 - L;
+      B = T;
+      m = 1;
+    } else {
+      ++m;
+    }
+  }
+  // connection polynomial C (c_0 = 1, degree L = 19937) -> characteristic polynomial phi(x) = x^L C(1/x)
+  for (int k = 0; k < PW; ++k) phi.w[k] = 0;
+  if (L == MT_DEG)
+    for (int i = 0; i <= L; ++i)
+      if (pbit(C.data(), i)) phi.w[(L - i) >> 6] |= 1ull << ((L - i) & 63);
+  done = true;
+  return phi;
+}
+
+// r = a * a mod phi   (a, r: degree < 19937)
+void poly_sqr_mod(const Poly &a, const Poly &phi, Poly &r) {
+  static const auto spread = [] {  // byte -> 16 bits with zeros interleaved
+    std::vector<uint16_t> t(256);
+    for (int v = 0; v < 256; ++v) {
+      uint16_t o = 0;
+      for (int k = 0; k < 8; ++k) o |= (uint16_t)((v >> k) & 1) << (2 * k);
+      t[v] = o;
+    }
+    return t;
+  }();
+  uint64_t sq[2 * PW + 1];
+  for (int k = 0; k < PW; ++k) {
+    uint64_t lo = 0, hi = 0;
+    for (int bt = 0; bt < 4; ++bt) {
+      lo |= (uint64_t)spread[(a.w[k] >> (8 * bt)) & 0xff] << (16 * bt);
+      hi |= (uint64_t)spread[(a.w[k] >> (32 + 8 * bt)) & 0xff] << (16 * bt);
+    }
+    sq[2 * k] = lo;
+    sq[2 * k + 1] = hi;
+  }
+  sq[2 * PW] = 0;
+  for (int dgr = 2 * (MT_DEG - 1); dgr >= MT_DEG; --dgr) {  // clear the high bits with shifted copies of phi
+    if (!pbit(sq, dgr)) continue;
+    const int sh = dgr - MT_DEG, ws = sh >> 6, bs = sh & 63;
+    for (int k = 0; k < PW; ++k) {
+      sq[k + ws] ^= phi.w[k] << bs;
+      if (bs) sq[k + ws + 1] ^= phi.w[k] >> (64 - bs);
+    }
+  }
+  for (int k = 0; k < PW; ++k) r.w[k] = sq[k];
+}
+
+// g = x^steps mod phi, cached per step count
+const Poly &jump_poly(long steps) {
+  static std::map<long, Poly> cache;
+  static std::mutex mu;
+  const Poly &phi = mt_charpoly();
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = cache.find(steps);
+  if (it != cache.end()) return it->second;
+  Poly g, t;
+  for (int k = 0; k < PW; ++k) g.w[k] = 0;
+  g.w[0] = 1;  // x^0
+  int top = 63;
+  while (top > 0 && !((steps >> top) & 1)) --top;
+  for (int bit = top; bit >= 0; --bit) {
+    poly_sqr_mod(g, phi, t);
+    g = t;
+    if ((steps >> bit) & 1) {  // g *= x
+      for (int k = PW - 1; k > 0; --k) g.w[k] = (g.w[k] << 1) | (g.w[k - 1] >> 63);
+      g.w[0] <<= 1;
+      if (pbit(g.w, MT_DEG))
+        for (int k = 0; k < PW; ++k) g.w[k] ^= phi.w[k];
+    }
+  }
+  if (cache.size() > 64) cache.clear();
+  return cache.emplace(steps, g).first->second;
+}
+
+#define HARL_XOR_WINDOW_BODY                                              \
+  for (int i = 0; i < MT_DEG; ++i) {                                      \
+    if (!pbit(gp.w, i)) continue;                                         \
+    const uint32_t *src = x + i;                                          \
+    HARL_XOR624(y, src)                                                   \
+  }
+#define HARL_XOR624(y, src) \
+  for (int j = 0; j < MT_N; j += 16) _mm512_storeu_si512(y + j, _mm512_xor_si512(_mm512_loadu_si512(y + j), _mm512_loadu_si512(src + j)));
+__attribute__((target("avx512f"))) void xor_windows_avx512(const Poly &gp, const uint32_t *x, uint32_t *y) { HARL_XOR_WINDOW_BODY }
+#undef HARL_XOR624
+#define HARL_XOR624(y, src)                                                                                             \
+  for (int j = 0; j < MT_N; j += 8)                                                                                     \
+    _mm256_storeu_si256(reinterpret_cast<__m256i *>(y + j), _mm256_xor_si256(_mm256_loadu_si256(reinterpret_cast<const __m256i *>(y + j)), \
+                                                                             _mm256_loadu_si256(reinterpret_cast<const __m256i *>(src + j))));
+__attribute__((target("avx2"))) void xor_windows_avx2(const Poly &gp, const uint32_t *x, uint32_t *y) { HARL_XOR_WINDOW_BODY }
+#undef HARL_XOR624
+#define HARL_XOR624(y, src) \
+  for (int j = 0; j < MT_N; ++j) y[j] ^= src[j];
+void xor_windows_base(const Poly &gp, const uint32_t *x, uint32_t *y) { HARL_XOR_WINDOW_BODY }
+#undef HARL_XOR624
+#undef HARL_XOR_WINDOW_BODY
+
+void refresh(Mt &g, int isa) {
+  if (isa == 2) next_state_avx512(g);
+  else if (isa == 1) next_state_avx2(g);
+  else g.next_state();
+}
+
+// the state block `blocks` refreshes ahead of g's current one (g.left / g.next untouched), blocks >= 2
+void jump_blocks(Mt &g, long blocks, int isa) {
+  const Poly &gp = jump_poly((blocks - 1) * (long)MT_N);
+  constexpr int NBLK = (MT_DEG + MT_N - 1) / MT_N + 1;  // word sequence x[0 .. 19937 + 623]
+  static thread_local std::vector<uint32_t> xs((NBLK + 1) * MT_N + 16);
+  alignas(64) uint32_t y[MT_N + 16];
+  uint32_t *x = xs.data();
+  Mt t = g;
+  std::memcpy(x, t.s, sizeof(t.s));
+  for (int bk = 1; bk <= NBLK; ++bk) {
+    refresh(t, isa);
+    std::memcpy(x + bk * MT_N, t.s, sizeof(t.s));
+  }
+  std::memset(y, 0, sizeof(y));
+  if (isa == 2) xor_windows_avx512(gp, x, y);
+  else if (isa == 1) xor_windows_avx2(gp, x, y);
+  else xor_windows_base(gp, x, y);
+  std::memcpy(g.s, y, sizeof(g.s));
+  refresh(g, isa);  // the last block refresh is the ordinary one: word 0's low bits are outside the linear state
+}
+
+thread_local long g_force_jump_min = -1;  // harl_rng_jump: threshold override for the calling thread
+long jump_min_blocks() {
+  if (g_force_jump_min >= 0) return g_force_jump_min;
+  static const long v = [] {
+    const char *e = std::getenv("HARL_RNG_JUMP_MIN_BLOCKS");
+    return e ? std::atol(e) : 2500L;  // ~0.2 ms of direct block refreshes (AVX-512); below that the direct skip is cheaper
+  }();
+  return v;
+}
+
+// discard nd draws with the jump for the bulk: same bookkeeping as HARL_SKIP_BODY
+void skip_with_jump(Mt &g, long nd, int isa) {
+  // refreshes the direct skip would perform: the first happens when g.left <= 1, i.e. after g.left - 1 further draws
+  const long avail0 = g.left >= 1 ? g.left - 1 : 0;
+  if (nd <= avail0) {
+    g.left -= (int)nd;
+    g.next += (int)nd;
+    return;
+  }
+  const long rest = nd - avail0;                 // draws after the first refresh point
+  const long k = (rest + MT_N - 1) / MT_N;       // number of refreshes (>= 1)
+  if (k >= jump_min_blocks()) {
+    jump_blocks(g, k, isa);
+  } else {
+    for (long r = 0; r < k; ++r) refresh(g, isa);
+  }
+  const long used = rest - (k - 1) * MT_N;       // draws taken from the last block (1 .. 624)
+  g.next = (int)used;
+  g.left = MT_N + 1 - (int)used;
+}
+
 bool load_state(Mt &g, const uint8_t *state_in, long state_bytes) {
   if (state_bytes < 24 + 8 * MT_N) return false;
   int32_t left, seeded;
@@ -259,9 +477,20 @@ extern "C" int harl_rng_advance(const uint8_t *state_in, long state_bytes, long 
   Mt g;
   if (n_draws < 0 || !state_out || !load_state(g, state_in, state_bytes)) return -2;
   const int isa = rng_isa();
-  if (isa == 2) skip_avx512(g, n_draws);
+  if (n_draws / MT_N >= jump_min_blocks()) skip_with_jump(g, n_draws, isa);
+  else if (isa == 2) skip_avx512(g, n_draws);
   else if (isa == 1) skip_avx2(g, n_draws);
   else skip_base(g, n_draws);
+  store_state(g, state_in, state_bytes, state_out);
+  return 0;
+}
+
+extern "C" int harl_rng_jump(const uint8_t *state_in, long state_bytes, long n_draws, uint8_t *state_out) {
+  Mt g;
+  if (n_draws < 0 || !state_out || !load_state(g, state_in, state_bytes)) return -2;
+  g_force_jump_min = 2;
+  skip_with_jump(g, n_draws, rng_isa());
+  g_force_jump_min = -1;
   store_state(g, state_in, state_bytes, state_out);
   return 0;
 }

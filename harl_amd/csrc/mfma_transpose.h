@@ -118,7 +118,7 @@ __device__ __forceinline__ void finish_partials(f32x16 (&acc)[MT_][NT_], float (
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, h = lane >> 5;
   float dbt[MT_];
 #pragma unroll
-  for (int a = 0; a < MT_; ++a) dbt[a] = db[a] + wave_xor32(db[a]);
+  for (int a = 0; a < MT_; ++a) dbt[a] = wave_sum32(db[a]);
   __syncthreads();  // buf may alias LDS that other waves were still reading
   for (int w = 0; w < WAVES_PER_WG; ++w) {
     if (wave == w) {

@@ -19,6 +19,7 @@
 #include "common.h"
 #include "split_mfma.h"
 #include "mfma_transpose.h"
+#include "dw_common.h"
 #include "../../include/harl_hip.h"
 
 using namespace harl;
@@ -42,7 +43,7 @@ __device__ __forceinline__ void relu_norm_regs(f32x16 (&acc)[HO / 32], float (&v
 #pragma unroll
   for (int P = 0; P < NR / 2; ++P) s2v += f32x2{v[2 * P], v[2 * P + 1]};
   float sum = s2v[0] + s2v[1];
-  sum += wave_xor32(sum);
+  sum = wave_sum32(sum);
   const float mean = sum * (1.0f / HO);
   const f32x2 mv = {mean, mean};
   f32x2 vsv = {0.f, 0.f};
@@ -54,7 +55,7 @@ __device__ __forceinline__ void relu_norm_regs(f32x16 (&acc)[HO / 32], float (&v
     v[2 * P + 1] = d[1];
   }
   float vs = vsv[0] + vsv[1];
-  vs += wave_xor32(vs);
+  vs = wave_sum32(vs);
   const float rstd = 1.0f / sqrtf(vs * (1.0f / HO) + 1e-5f);
   const f32x2 rv = {rstd, rstd};
 #pragma unroll
@@ -109,8 +110,8 @@ __device__ __forceinline__ void ln_jac_store(f32x16 (&acc)[HO / 32], const float
     s1 += ad[R];
     s2 += ad[R] * xh[R];
   }
-  s1 += wave_xor32(s1);
-  s2 += wave_xor32(s2);
+  s1 = wave_sum32(s1);
+  s2 = wave_sum32(s2);
   s1 *= (1.0f / HO);
   s2 *= (1.0f / HO);
 #pragma unroll
@@ -236,7 +237,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_fwd_input(const float *__rest
           if (kl < Dc) s += xr[32 * c + kl];
         }
       }
-      s += wave_xor32(s);
+      s = wave_sum32(s);
       mean = s / (float)D;
       float vs = 0.f;
       for (int c = 0; c < nch; ++c) {
@@ -249,7 +250,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_fwd_input(const float *__rest
           }
         }
       }
-      vs += wave_xor32(vs);
+      vs = wave_sum32(vs);
       rstd = 1.0f / sqrtf(vs / (float)D + 1e-5f);
     }
 
@@ -411,7 +412,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_fwd_input_staged(const float 
       for (int c = 0; c < NCH; ++c)
 #pragma unroll
         for (int jj = 0; jj < 16; ++jj) sm += xv[c][jj];
-      sm += wave_xor32(sm);
+      sm = wave_sum32(sm);
       mean = sm / (float)D;
       float vs = 0.f;
 #pragma unroll
@@ -424,7 +425,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_fwd_input_staged(const float 
           vs += (jj < ks[c] && kl < Dc) ? d * d : 0.f;
         }
       }
-      vs += wave_xor32(vs);
+      vs = wave_sum32(vs);
       rstd = 1.0f / sqrtf(vs / (float)D + 1e-5f);
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
@@ -579,7 +580,7 @@ __global__ __launch_bounds__(64 * FUSED_WAVES, 2) void k_fwd_fused2(
       for (int c = 0; c < NCH; ++c)
 #pragma unroll
         for (int jj = 0; jj < 16; ++jj) sm += xv[c][jj];  // invalid slots hold 0
-      sm += wave_xor32(sm);
+      sm = wave_sum32(sm);
       mean = sm / (float)D;
       float vs = 0.f;
 #pragma unroll
@@ -592,7 +593,7 @@ __global__ __launch_bounds__(64 * FUSED_WAVES, 2) void k_fwd_fused2(
           vs += (jj < ks[c] && kl < Dc) ? d * d : 0.f;
         }
       }
-      vs += wave_xor32(vs);
+      vs = wave_sum32(vs);
       rstd0 = 1.0f / sqrtf(vs / (float)D + 1e-5f);
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
@@ -688,6 +689,7 @@ __global__ __launch_bounds__(WG_THREADS, (KT > 0 || split_one_wg(HI, HO)) ? 1 : 
     const float *__restrict__ rstd_prev, const float *__restrict__ Wp, float *__restrict__ dz_prev, long n_slabs,
     const float *__restrict__ x0n = nullptr, float *__restrict__ dw_part = nullptr, int n_part_rows = 0) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  PHASE_BEGIN();
   // dx_hat = Wp^T dz on the bf16 pipe (split_mfma.h): GEMM rows = input features, k = output features
   constexpr int MT = HI / 32, NJ = HO / 16, NRO = HO / 2;
   u32x4 *img = reinterpret_cast<u32x4 *>(lds);
@@ -715,9 +717,11 @@ __global__ __launch_bounds__(WG_THREADS, (KT > 0 || split_one_wg(HI, HO)) ? 1 : 
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc1[mt][n][r] = 0.f;
   }
+  PHASE(10);
   for (long slab = slab0; slab < n_slabs; slab += slab_stride) {
     u32x4 g1[NJ], g2[NJ], g3[NJ];
     split_acts<NRO>(raw, g1, g2, g3);
+    PHASE(0);
     atl_load<HO>(dz, slab + slab_stride < n_slabs ? slab + slab_stride : slab, lane, raw);  // one slab ahead
     // operands of the LayerNorm backward: issued now, consumed after the MFMA loop (latency fully hidden)
     float xh[HI / 2];
@@ -738,7 +742,9 @@ __global__ __launch_bounds__(WG_THREADS, (KT > 0 || split_one_wg(HI, HO)) ? 1 : 
     for (int t = 0; t < HI / 32; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    PHASE(1);
     split_gemm<MT, NJ>(wl, g1, g2, g3, acc, [](int) {});
+    PHASE(2);
     float dx[HI / 2];
 #pragma unroll
     for (int R = 0; R < HI / 2; ++R) dx[R] = acc[R >> 4][R & 15];
@@ -746,10 +752,12 @@ __global__ __launch_bounds__(WG_THREADS, (KT > 0 || split_one_wg(HI, HO)) ? 1 : 
       float out[HI / 2];
       ln_bwd_relu_mbits<HI>(dx, xh, mbits, rstd, out);
       atl_store<HI>(dz_prev, slab, lane, out);
+      PHASE(3);
     } else {
       float out[HI / 2];
       ln_bwd_relu_mbits<HI>(dx, xh, mbits, rstd, out);
       if (dz_prev) atl_store<HI>(dz_prev, slab, lane, out);
+      PHASE(3);
       // dW_1'[f][k] += sum_s dz_1[s][f] x0n[s][k] with both operands transposed on the matrix pipe (mfma_transpose.h): no LDS
       // round trip, bf16 MFMAs instead of the fp32 pipe with an LDS read per MFMA (same speed, measured; no staging area)
       float xr0[KPF / 2];
@@ -773,6 +781,7 @@ __global__ __launch_bounds__(WG_THREADS, (KT > 0 || split_one_wg(HI, HO)) ? 1 : 
 #pragma unroll
         for (int n = 0; n < KT; ++n) dw_tile(acc1[a][n], At, Bt[n]);
       }
+      PHASE(4);
     }
   }
   if constexpr (KT > 0) {
@@ -781,6 +790,8 @@ __global__ __launch_bounds__(WG_THREADS, (KT > 0 || split_one_wg(HI, HO)) ? 1 : 
     // clears the rest (mfma_transpose.h)
     finish_partials<HI / 32, KT>(acc1, dbs, reinterpret_cast<float *>(img), dw_part, n_part_rows);
   }
+  PHASE(11);
+  PHASE_END(KT > 0 ? 0 : 1);
 }
 
 // =============================================================================================
@@ -797,13 +808,6 @@ __global__ __launch_bounds__(WG_THREADS, (KT > 0 || split_one_wg(HI, HO)) ? 1 : 
 // =============================================================================================
 constexpr int DW_S = 64;  // samples per staging round
 
-template <int MT, int NT>
-struct DwSplit {
-  static constexpr int WM = MT >= 4 ? 4 : (MT == 2 ? 2 : 1);
-  static constexpr int WN = 4 / WM;
-  static constexpr int TM = MT / WM;
-  static constexpr int TN = (NT + WN - 1) / WN;
-};
 
 template <int A_KIND, int B_KIND, int MT, int NT>
 __global__ __launch_bounds__(WG_THREADS, 2) void k_dw(const float *__restrict__ a_src, const float *__restrict__ b_src,
@@ -996,44 +1000,57 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_dw(const float *__restrict__ 
       }
     }
     if (wn == 0 && blockIdx.y == 0) {
-      float t = dbsum[a] + wave_xor32(dbsum[a]);
+      float t = wave_sum32(dbsum[a]);
       if (h == 0) mypart[(long)32 * MT * KP + 32 * mt + i] = t;
     }
   }
 }
 
 // =============================================================================================
-// weight-gradient partials of the hidden layers on the bf16 pipe (both operands ATL, widths 64 / 128).
-// The reduction index is the sample, so both operands are needed as "lane = feature, 8 consecutive samples per lane":
-// per round (ONE 32-sample slab) the four waves split the slab's (HA + HB)/8 float4 pieces, split every value exactly
-// into three bf16 (split_mfma.h) and scatter them with ds_write_b16 into per-term images [feature][32 samples] (row
-// stride 80 B: the 64-B runs written by the 32 lanes of a half and the ds_read_b128 fragment reads are both
-// conflict-free).  Each wave then owns TM x TN output tiles: 2 k-steps x 6 cross products per tile and round.
-// db' is summed in fp32 by the waves that stage dz (lane = sample) and reduced across lanes once at the end.
-// LDS 60 KiB for 128 x 128 -> 2 workgroups per CU.
-// =============================================================================================
-constexpr int DWS_ROWB = 80;  // bytes per feature row of a term image (32 samples x 2 B + 16 B pad)
-
-// Wide first layers (x0n ATL(KP), KP up to 512): launched once per group of NT <= 4 column tiles; `b_slab_floats` = KP * 32
+// k_dw_tr: weight-gradient partials of the hidden layers on the bf16 pipe (both operands ATL; widths 64 / 128 / 256 and the
+// wide first layers in column groups).  The reduction index is the sample, so both operands are needed as "lane = feature,
+// 8 consecutive samples per lane" while every producer holds "lane = sample".  The transposition is done by the LDS itself
+// (gfx950 ds_read_b64_tr_b16): per round (ONE 32-sample slab) the four waves split the slab's (HA + HB)/8 float4 pieces
+// exactly into three bf16 terms (split_mfma.h) and store them the way a lane holds them -- four consecutive features of its
+// sample as ONE ds_write_b64 per term -- into [4 samples][16 features] blocks; the transpose read then hands every lane of a
+// 16-lane group its feature column of a block: two ds_read_b64_tr_b16 per fragment.  Image per operand and term:
+// [8 sample quads][H/16 feature tiles][4][16] bf16 with 8 B of padding per sample quad (the 16 lanes of a store group hit 32
+// distinct banks; the 32 lanes of a read cycle take 256 contiguous bytes).  Each wave owns TM x TN output tiles: 2 k-steps x
+// the 6 cross products per tile and round.  db' is summed in fp32 by the waves that stage dz (lane = sample) and reduced
+// across lanes once at the end.  LDS 48 KiB for 128 x 128 -> 2 workgroups per CU.
+// Round 2 scattered every term with its own ds_write_b16 ([feature][32 samples] images, 384 two-byte stores per slab at 4
+// cycles each on the LDS store path): s_memtime showed 2.7k cycles per round in the scatter and 3.2k in a 48-MFMA phase that
+// needs 1.55k -- bound by the LDS store path (0.207 -> 0.189 ms at 819 200 x 128 x 128 with the 96 wide stores).
+//
+// Wide first layers (x0n ATL(KP), KP up to 512): launched once per group of NT <= 6 column tiles; `b_slab_floats` = KP * 32
 // is the slab stride of the B image, `tile0` the group's first 32-column tile, KP the row stride of dWp in the partial;
 // db' is written by the tile0 == 0 launch only.
+// =============================================================================================
+__device__ __forceinline__ u32x2_t tr_read(const unsigned char *p) {
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
+  const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (s16x4 __attribute__((address_space(3))) *)(const __attribute__((address_space(3))) unsigned char *)p);
+  return __builtin_bit_cast(u32x2_t, v);
+}
+
 template <int MT, int NT>
-__global__ __launch_bounds__(WG_THREADS, 2) void k_dw_split(const float *__restrict__ a_src, const float *__restrict__ b_src,
-                                                            long n_slabs, float *__restrict__ part, long b_slab_floats,
-                                                            int tile0, int KP) {
+__global__ __launch_bounds__(WG_THREADS, 2) void k_dw_tr(const float *__restrict__ a_src, const float *__restrict__ b_src,
+                                                         long n_slabs, float *__restrict__ part, long b_slab_floats,
+                                                         int tile0, int KP) {
   using SP = DwSplit<MT, NT>;
   constexpr int HA = 32 * MT, HB = 32 * NT;
   constexpr int NPA = HA / 8, NPB = HB / 8, PER = (NPA + NPB) / WAVES_PER_WG;  // float4 pieces per lane and wave
   static_assert((NPA + NPB) % WAVES_PER_WG == 0, "pieces divide evenly over the waves");
-  constexpr int IMG_A = HA * DWS_ROWB, IMG_B = HB * DWS_ROWB;  // bytes per term image
+  constexpr int SQA = (HA / 16) * 128 + 8, SQB = (HB / 16) * 128 + 8;  // bytes per sample quad (4 samples x H features + pad)
+  constexpr int IMG_A = 8 * SQA, IMG_B = 8 * SQB;                      // bytes per term image (32 samples)
   extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
-  unsigned char *Ab = ldsb;               // [3 terms][HA][80 B]
-  unsigned char *Bb = ldsb + 3 * IMG_A;   // [3 terms][HB][80 B]
+  PHASE_BEGIN();
+  unsigned char *Ab = ldsb;               // [3 terms][IMG_A]
+  unsigned char *Bb = ldsb + 3 * IMG_A;   // [3 terms][IMG_B]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 31, h = lane >> 5;
   const int wm = wave % SP::WM, wn = wave / SP::WM;
 
-  // this wave's pieces: global piece index gu = wave * PER + u; gu < NPA -> dz piece q = gu, else x_hat piece q = gu - NPA
   f32x4 pr[PER];
   float dbacc[PER][4];
 #pragma unroll
@@ -1059,51 +1076,59 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_dw_split(const float *__restr
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
+  // fragment address of this lane inside a term image: feature tile 2 t + ((lane >> 4) & 1), sample quads 4 ks + 2 h (+1),
+  // block row (lane & 15) >> 2, column segment 4 (lane & 3)
+  const int p16 = lane & 15, g1 = (lane >> 4) & 1;
+  const int frag_lane = g1 * 128 + (p16 >> 2) * 32 + (p16 & 3) * 8;
+
   if ((long)blockIdx.x < n_slabs) prefetch(blockIdx.x);
+  PHASE(10);
   for (long slab = blockIdx.x; slab < n_slabs; slab += gridDim.x) {
     __syncthreads();  // previous round's fragments fully read
-    // ---- split + scatter: lane (sample i, half h) of piece q holds features 32 (q>>2) + 8 (q&3) + 4 h + c
+    PHASE(0);
+    // ---- split + store: lane (sample i, half h) of piece q holds features 32 (q>>2) + 8 (q&3) + 4 h + c, c = 0..3
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
       const int gu = wave * PER + u;
       const bool is_a = gu < NPA;
       const int q = is_a ? gu : gu - NPA;
-      unsigned char *img = (is_a ? Ab : Bb) + (32 * (q >> 2) + 8 * (q & 3) + 4 * h) * DWS_ROWB + 2 * i;
-      const int tstride = is_a ? IMG_A : IMG_B;
+      const int sqb = is_a ? SQA : SQB, tstride = is_a ? IMG_A : IMG_B;
+      unsigned char *d = (is_a ? Ab : Bb) + (i >> 2) * sqb + (2 * (q >> 2) + ((q & 3) >> 1)) * 128 + (i & 3) * 32 +
+                         (8 * (q & 1) + 4 * h) * 2;
       if (is_a) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) dbacc[u][c] += pr[u][c];
       }
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const float f0 = pr[u][c];
-        const unsigned u0 = __float_as_uint(f0) & 0xffff0000u;
-        const float r0 = f0 - __uint_as_float(u0);
-        const unsigned w0 = __float_as_uint(r0) & 0xffff0000u;
-        const float q0 = r0 - __uint_as_float(w0);
-        unsigned short *d = reinterpret_cast<unsigned short *>(img + c * DWS_ROWB);
-        d[0] = (unsigned short)(u0 >> 16);
-        *reinterpret_cast<unsigned short *>(reinterpret_cast<unsigned char *>(d) + tstride) = (unsigned short)(w0 >> 16);
-        *reinterpret_cast<unsigned short *>(reinterpret_cast<unsigned char *>(d) + 2 * tstride) =
-            (unsigned short)(__float_as_uint(q0) >> 16);
-      }
+      unsigned t1a, t2a, t3a, t1b, t2b, t3b;
+      split3<false>(pr[u][0], pr[u][1], t1a, t2a, t3a);
+      split3<false>(pr[u][2], pr[u][3], t1b, t2b, t3b);
+      *reinterpret_cast<u32x2_t *>(d) = u32x2_t{t1a, t1b};
+      *reinterpret_cast<u32x2_t *>(d + tstride) = u32x2_t{t2a, t2b};
+      *reinterpret_cast<u32x2_t *>(d + 2 * tstride) = u32x2_t{t3a, t3b};
     }
+    PHASE(1);
     __syncthreads();
+    PHASE(2);
     if (slab + gridDim.x < n_slabs) prefetch(slab + gridDim.x);  // next round's loads fly during the MFMA phase
     __builtin_amdgcn_sched_barrier(0);
-    // ---- 2 k-steps of 16 samples: lane (feature i, g = h) reads samples 16 ks + 8 g .. + 7 of its feature row
+    // ---- 2 k-steps of 16 samples: lane (feature, g = h) takes samples 16 ks + 8 h .. + 7 of its feature column
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       u32x4 av[3][SP::TM], bv[3][SP::TN];
 #pragma unroll
       for (int term = 0; term < 3; ++term) {
 #pragma unroll
-        for (int a = 0; a < SP::TM; ++a)
-          av[term][a] = *reinterpret_cast<const u32x4 *>(Ab + term * IMG_A + (32 * (wm * SP::TM + a) + i) * DWS_ROWB + 32 * ks + 16 * h);
+        for (int a = 0; a < SP::TM; ++a) {
+          const unsigned char *fp = Ab + term * IMG_A + (4 * ks + 2 * h) * SQA + 2 * (wm * SP::TM + a) * 128 + frag_lane;
+          const u32x2_t lo = tr_read(fp), hi = tr_read(fp + SQA);
+          av[term][a] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+        }
 #pragma unroll
         for (int b = 0; b < SP::TN; ++b) {
           const int nt = wn * SP::TN + b < NT ? wn * SP::TN + b : NT - 1;  // surplus tile slots (NT = 1, 3) recompute the last tile
-          bv[term][b] = *reinterpret_cast<const u32x4 *>(Bb + term * IMG_B + (32 * nt + i) * DWS_ROWB + 32 * ks + 16 * h);
+          const unsigned char *fp = Bb + term * IMG_B + (4 * ks + 2 * h) * SQB + 2 * nt * 128 + frag_lane;
+          const u32x2_t lo = tr_read(fp), hi = tr_read(fp + SQB);
+          bv[term][b] = u32x4{lo[0], lo[1], hi[0], hi[1]};
         }
       }
 #pragma unroll
@@ -1118,6 +1143,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_dw_split(const float *__restr
           acc[a][b] = mfma_bf16(av[0][a], bv[0][b], acc[a][b]);
         }
     }
+    PHASE(3);
   }
 
   // ---- write this workgroup's partial: dWp[HA][KP] then dbp[HA]
@@ -1148,11 +1174,12 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_dw_split(const float *__restr
       }
     }
   }
+  PHASE(11);
+  PHASE_END(2);
 }
 
-// =============================================================================================
-// host launchers
-// =============================================================================================
+HARL_PHASE_ACCESSOR(mlp)
+
 static int bad(const char *m) {
   set_error(m);
   return -2;
@@ -1390,9 +1417,9 @@ extern "C" int harl_mlp_dw_partials(const float *a, int a_kind, int lda, int HO,
     if (K % 32 != 0 || K < 32) return bad("harl_mlp_dw_partials: ATL input width must be a multiple of 32");
 #define DWS(MTv, NTv)                                                                                            \
   {                                                                                                              \
-    const size_t shm = (size_t)3 * 32 * (MTv + NTv) * DWS_ROWB;                                                  \
-    allow_big_lds(k_dw_split<MTv, NTv>, shm);                                                                    \
-    hipLaunchKernelGGL((k_dw_split<MTv, NTv>), dim3(n_wg), dim3(WG_THREADS), shm, s, a, b, n_slabs, part,         \
+    const size_t shm = (size_t)3 * 8 * ((2 * MTv * 128 + 8) + (2 * NTv * 128 + 8));                              \
+    allow_big_lds(k_dw_tr<MTv, NTv>, shm);                                                                       \
+    hipLaunchKernelGGL((k_dw_tr<MTv, NTv>), dim3(n_wg), dim3(WG_THREADS), shm, s, a, b, n_slabs, part,            \
                        (long)K * SLAB, tile0, K);                                                                \
   }
     if (K > 128 || K == 96 || MT == 8) {  // wide first layer (and every 256-row operand): x0n ATL(K), K a multiple of 32 up to 512, in groups of <= 4 column tiles

@@ -80,7 +80,7 @@ __device__ __forceinline__ void head_stats(const float (&v)[64], int h, int lo, 
     const int f = feat_base(R) + 4 * h;
     if (f >= lo && f < hi) se += expf(v[R] - mx);
   }
-  se += wave_xor32(se);
+  se = wave_sum32(se);
   const float l = mx + logf(se);
   float e = 0.f, la = 0.f;
 #pragma unroll
@@ -93,8 +93,8 @@ __device__ __forceinline__ void head_stats(const float (&v)[64], int h, int lo, 
     }
   }
   lse = l;
-  ent = e + wave_xor32(e);
-  lpa = la + wave_xor32(la);
+  ent = wave_sum32(e);
+  lpa = wave_sum32(la);
 }
 
 // second pass over one head: d(loss)/d(logit) into out (TRAIN) or the normalised logits to head_out

@@ -9,7 +9,7 @@
 // samples; the dexhands batches are 19 200 - 32 000 rows per agent, i.e. this path is about coverage, not about the roof.
 //   forward  : x_hat_out = norm(relu(W' x_in + b'))            x_in  = ATL(KP) image (normalised inputs x0n, or x_hat of the layer before)
 //   backward : dz_in = relu' . LNbwd(W'^T dz_out)               (the layer kernels' harl_mlp_bwd_dx for 256-wide layers)
-// Weight gradients are harl_mlp_dw_partials (k_dw_split<8, NT>, mlp.hip) over the same ATL images.
+// Weight gradients are harl_mlp_dw_partials (k_dw_tr<8, NT>, mlp.hip) over the same ATL images.
 #include "common.h"
 #include "split_mfma.h"
 #include "../../include/harl_hip.h"
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_panel(const float *__restrict
         v[R] = relu_push(acc[R >> 4][R & 15], bits[R >> 5]);
         sum += v[R];
       }
-      sum += wave_xor32(sum);
+      sum = wave_sum32(sum);
       const float mean = sum * (1.0f / PH);
       float vs = 0.f;
 #pragma unroll
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_panel(const float *__restrict
         v[R] -= mean;
         vs += v[R] * v[R];
       }
-      vs += wave_xor32(vs);
+      vs = wave_sum32(vs);
       const float rstd = 1.0f / sqrtf(vs * (1.0f / PH) + 1e-5f);
 #pragma unroll
       for (int R = 0; R < NR; ++R) v[R] *= rstd;

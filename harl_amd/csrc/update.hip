@@ -53,7 +53,7 @@ __device__ __forceinline__ void relu_ln(const f32x16 (&acc)[H / 32], float (&v)[
 #pragma unroll
   for (int P = 0; P < NR / 2; ++P) s2v += f32x2{v[2 * P], v[2 * P + 1]};
   float sum = s2v[0] + s2v[1];
-  sum += wave_xor32(sum);
+  sum = wave_sum32(sum);
   const float mean = sum * (1.0f / H);
   const f32x2 mv = {mean, mean};
   f32x2 vsv = {0.f, 0.f};
@@ -65,7 +65,7 @@ __device__ __forceinline__ void relu_ln(const f32x16 (&acc)[H / 32], float (&v)[
     v[2 * P + 1] = d[1];
   }
   float vs = vsv[0] + vsv[1];
-  vs += wave_xor32(vs);
+  vs = wave_sum32(vs);
   const float rstd = 1.0f / sqrtf(vs * (1.0f / H) + 1e-5f);
   const f32x2 rv = {rstd, rstd};
 #pragma unroll
@@ -91,8 +91,8 @@ __device__ __forceinline__ void ln_bwd_relu_bits(const float (&dx)[H / 2], const
     a2 += d * x;
   }
   float s1 = a1[0] + a1[1], s2 = a2[0] + a2[1];
-  s1 += wave_xor32(s1);
-  s2 += wave_xor32(s2);
+  s1 = wave_sum32(s1);
+  s2 = wave_sum32(s2);
   const float c1 = -(s1 * (1.0f / H)) * rstd, c2 = -(s2 * (1.0f / H)) * rstd;
   const f32x2 c1v = {c1, c1}, c2v = {c2, c2}, rv = {rstd, rstd};
   uint32_t bits[NW];
@@ -418,6 +418,7 @@ __global__ __launch_bounds__(UF_THREADS, 2) void k_upd_fwd(UpdFwdArgs U, ARGS A)
 
   float xr[KP0 / 2];
   atl_load<KP0>(U.x0n, slab0 < U.n_slabs ? slab0 : 0, lane, xr);
+  PHASE_BEGIN();
   for (long slab = slab0; slab < U.n_slabs; slab += slab_stride) {
     float v[NR];        // x_hat_2
     uint32_t bits2[NW];
@@ -437,26 +438,32 @@ __global__ __launch_bounds__(UF_THREADS, 2) void k_upd_fwd(UpdFwdArgs U, ARGS A)
         for (int t = 0; t < MT; ++t)
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[t][r] = b1l[32 * t + (r & 3) + 8 * (r >> 2) + 4 * h];
+        PHASE(0);
         split_gemm<MT, NJ1>(wl1, a1, a2, a3, acc, [](int) {});
+        PHASE(1);
         uint32_t bits1[NW];
         float r1;
         relu_ln<H, false>(acc, x1, bits1, r1);
       }
       u32x4 y1[NJ2], y2[NJ2], y3[NJ2];
       split_acts<NR>(x1, y1, y2, y3);
+      PHASE(2);
       f32x16 acc[MT];
 #pragma unroll
       for (int t = 0; t < MT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = b2l[32 * t + (r & 3) + 8 * (r >> 2) + 4 * h];
       split_gemm<MT, NJ2>(wl2, y1, y2, y3, acc, [](int) {});
+      PHASE(3);
       relu_ln<H, TRAIN>(acc, v, bits2, r2);
     }
+    PHASE(4);
     f32x4 xs[H / 8];
 #pragma unroll
     for (int q = 0; q < H / 8; ++q) xs[q] = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
     float z[DAP];
     head_fwd_regs<H, DAP>(xs, whl_h, cst, z);
+    PHASE(5);
     float dzh[DAP];
     float s1, s2;
     if constexpr (CRITIC) {
@@ -469,6 +476,7 @@ __global__ __launch_bounds__(UF_THREADS, 2) void k_upd_fwd(UpdFwdArgs U, ARGS A)
     } else {
       if (!actor_sample<DAP, DISCRETE, TRAIN>(A, cst, z, slab, lane, adv_mean, adv_den, sc, dzh, s1, s2, rcur)) continue;
     }
+    PHASE(6);
     if constexpr (TRAIN) {
       // ---- head weight gradient dW_head'[d][f] += sum_s dzh[s][d] x_hat_2[s][f]: both operands transposed on the matrix
       // pipe, one 32-feature tile at a time; rows d < HROWS of the tile are added to the wave's LDS accumulator
@@ -509,10 +517,13 @@ __global__ __launch_bounds__(UF_THREADS, 2) void k_upd_fwd(UpdFwdArgs U, ARGS A)
 #pragma unroll
         for (int d = 0; d < DAP; ++d) dbacc[d] += dzh[d];
       }
+      PHASE(7);
       // ---- head backward (W_head'^T dzh on the fp32 MFMA) + LayerNorm / ReLU backward -> dz_2
       head_bwd_regs_bits<H, DAP>(xs, bits2[0], bits2[NW - 1], r2, slab, lane, whl, dzh, s1, s2, U.dz2);
+      PHASE(8);
     }
   }
+  PHASE_END((TRAIN ? 0 : 2) + (CRITIC ? 1 : 0));
   if constexpr (TRAIN) {
     block_reduce_store8<NSC>(sc, red, A.part_scalars + (long)blockIdx.x * PS_STRIDE);
     for (int row = blockIdx.x + gridDim.x; row < U.n_part_rows; row += gridDim.x)
@@ -608,6 +619,8 @@ int dispatch_fwd_critic(const UpdFwdArgs &U, const CriticArgs &A, int H, hipStre
 }
 
 }  // namespace
+
+HARL_PHASE_ACCESSOR(update)
 
 extern "C" int harl_update_supported(int D, int H, int act_dim) {
   return (D >= 1 && D <= 64 && (H == 64 || H == 128) && act_dim >= 1 && act_dim <= 8) ? 1 : 0;

@@ -11,7 +11,7 @@
 //      operand split (split_mfma.h).  3 * H * KP bf16 (320 KiB for 128 x 416) do not fit the LDS, so the three weight
 //      images are built in a global scratch buffer by a small kernel (they stay L2 resident) and every wave streams its
 //      A fragments from there, amortised over TWO slabs per wave.
-// The first-layer weight gradient of wide inputs is k_dw_split (mlp.hip) over column groups of the same x0n image.
+// The first-layer weight gradient of wide inputs is k_dw_tr (mlp.hip) over column groups of the same x0n image.
 #include <type_traits>
 #include "common.h"
 #include "split_mfma.h"
@@ -390,8 +390,8 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_fwd_wide(const float *__restr
             q1 += ad[R];
             q2 += ad[R] * xh[R];
           }
-          q1 += wave_xor32(q1);
-          q2 += wave_xor32(q2);
+          q1 = wave_sum32(q1);
+          q2 = wave_sum32(q2);
           q1 *= (1.0f / HO);
           q2 *= (1.0f / HO);
 #pragma unroll
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_fwd_wide(const float *__restr
           v[R] = relu_push(acc[R >> 4][R & 15], bits[R >> 5]);
           sum += v[R];
         }
-        sum += wave_xor32(sum);
+        sum = wave_sum32(sum);
         const float mean = sum * (1.0f / HO);
         float vs = 0.f;
 #pragma unroll
@@ -422,7 +422,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_fwd_wide(const float *__restr
           v[R] -= mean;
           vs += v[R] * v[R];
         }
-        vs += wave_xor32(vs);
+        vs = wave_sum32(vs);
         const float rstd = 1.0f / sqrtf(vs * (1.0f / HO) + 1e-5f);
 #pragma unroll
         for (int R = 0; R < NR; ++R) v[R] *= rstd;
@@ -453,6 +453,7 @@ __global__ __launch_bounds__(64 * F2X_WAVES, 2) void k_fwd_fused2x(
     float *__restrict__ rstd2, long n_slabs) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int NTHR = 64 * F2X_WAVES, MT = H / 32, NJ1 = KP0 / 16, NJ2 = H / 16, NR = H / 2, NW = (NR + 31) / 32;
+  PHASE_BEGIN();
   u32x4 *w1img = reinterpret_cast<u32x4 *>(lds);          // [3][MT][KP0/16][64]
   u32x4 *w2img = w1img + 3 * MT * NJ1 * 64;               // [3][MT][H/16][64]
   float *b1l = reinterpret_cast<float *>(w2img + 3 * MT * NJ2 * 64);
@@ -479,6 +480,7 @@ __global__ __launch_bounds__(64 * F2X_WAVES, 2) void k_fwd_fused2x(
   const u32x4 *wl1 = w1img + lane, *wl2 = w2img + lane;
   float xr[KP0 / 2];
   atl_load<KP0>(x0n, slab0 < n_slabs ? slab0 : 0, lane, xr);
+  PHASE(10);
   for (long slab = slab0; slab < n_slabs; slab += slab_stride) {
     u32x4 a1[NJ1], a2[NJ1], a3[NJ1];
     split_acts<KP0 / 2>(xr, a1, a2, a3);
@@ -486,6 +488,7 @@ __global__ __launch_bounds__(64 * F2X_WAVES, 2) void k_fwd_fused2x(
     float x1[NR];
     uint32_t bits1[NW];
     float r1;
+    PHASE(0);
     {
       f32x16 acc[MT];
 #pragma unroll
@@ -493,6 +496,7 @@ __global__ __launch_bounds__(64 * F2X_WAVES, 2) void k_fwd_fused2x(
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = b1l[32 * t + (r & 3) + 8 * (r >> 2) + 4 * h];
       split_gemm<MT, NJ1>(wl1, a1, a2, a3, acc, [](int) {});
+      PHASE(1);
       // ReLU + mask + LayerNorm of layer 1 (same arithmetic as relu_norm_regs in mlp.hip)
 #pragma unroll
       for (int w = 0; w < NW; ++w) bits1[w] = 0u;
@@ -502,7 +506,7 @@ __global__ __launch_bounds__(64 * F2X_WAVES, 2) void k_fwd_fused2x(
         x1[R] = relu_push(acc[R >> 4][R & 15], bits1[R >> 5]);
         sum += x1[R];
       }
-      sum += wave_xor32(sum);
+      sum = wave_sum32(sum);
       const float mean = sum * (1.0f / H);
       float vs = 0.f;
 #pragma unroll
@@ -510,7 +514,7 @@ __global__ __launch_bounds__(64 * F2X_WAVES, 2) void k_fwd_fused2x(
         x1[R] -= mean;
         vs += x1[R] * x1[R];
       }
-      vs += wave_xor32(vs);
+      vs = wave_sum32(vs);
       r1 = 1.0f / sqrtf(vs * (1.0f / H) + 1e-5f);
 #pragma unroll
       for (int R = 0; R < NR; ++R) x1[R] *= r1;
@@ -521,14 +525,17 @@ __global__ __launch_bounds__(64 * F2X_WAVES, 2) void k_fwd_fused2x(
       for (int w = 0; w < NW; ++w) mask1[(slab * NW + w) * WAVE + lane] = bits1[w];
       if (lane < 32) rstd1[slab * SLAB + lane] = r1;
     }
+    PHASE(2);
     u32x4 y1[NJ2], y2[NJ2], y3[NJ2];
     split_acts<NR>(x1, y1, y2, y3);
+    PHASE(3);
     f32x16 acc[MT];
 #pragma unroll
     for (int t = 0; t < MT; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[t][r] = b2l[32 * t + (r & 3) + 8 * (r >> 2) + 4 * h];
     split_gemm<MT, NJ2>(wl2, y1, y2, y3, acc, [](int) {});
+    PHASE(4);
     {
       uint32_t bits[NW];
 #pragma unroll
@@ -540,7 +547,7 @@ __global__ __launch_bounds__(64 * F2X_WAVES, 2) void k_fwd_fused2x(
         v[R] = relu_push(acc[R >> 4][R & 15], bits[R >> 5]);
         sum += v[R];
       }
-      sum += wave_xor32(sum);
+      sum = wave_sum32(sum);
       const float mean = sum * (1.0f / H);
       float vs = 0.f;
 #pragma unroll
@@ -548,7 +555,7 @@ __global__ __launch_bounds__(64 * F2X_WAVES, 2) void k_fwd_fused2x(
         v[R] -= mean;
         vs += v[R] * v[R];
       }
-      vs += wave_xor32(vs);
+      vs = wave_sum32(vs);
       const float rstd = 1.0f / sqrtf(vs * (1.0f / H) + 1e-5f);
 #pragma unroll
       for (int R = 0; R < NR; ++R) v[R] *= rstd;
@@ -557,7 +564,9 @@ __global__ __launch_bounds__(64 * F2X_WAVES, 2) void k_fwd_fused2x(
       for (int w = 0; w < NW; ++w) mask2[(slab * NW + w) * WAVE + lane] = bits[w];
       if (lane < 32) rstd2[slab * SLAB + lane] = rstd;
     }
+    PHASE(5);
   }
+  PHASE_END(0);
 }
 
 template <bool TANGENT>
@@ -583,6 +592,8 @@ int launch_wide(const float *x0n, long M, int KP, const float *Wp, int D, const 
 }
 
 }  // namespace
+
+HARL_PHASE_ACCESSOR(wide)
 
 extern "C" int harl_mlp_x0n_wide(const float *X, long ldx, const int64_t *idx, long M, int D, int use_ln0, float *x0n,
                                  float *mu0, float *rstd0, void *stream) {

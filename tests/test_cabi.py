@@ -133,7 +133,7 @@ def test_policy_init_rng_replay_matches_real_construction():
 
 def test_rng_advance_matches_tensor_random():
     """harl_rng_advance (mt19937 skip-ahead, host code) leaves the CPU generator exactly where Tensor.random_ over as many
-    int32 elements does; consume_randperm (deferred replay thread) equals torch.randperm's generator advance."""
+    int32 elements does; consume_randperm (deferred: summed, applied by rng_sync in one jump) equals torch.randperm's advance."""
     import torch
     from harl_amd import _lib, buffers as B
 
@@ -156,6 +156,53 @@ def test_rng_advance_matches_tensor_random():
         B.consume_randperm(819200)
     B.rng_sync()
     assert bool(torch.equal(a, torch.randperm(9)))
+
+
+def test_rng_jump_ahead_is_bit_identical_and_constant_time(monkeypatch):
+    """The GF(2) polynomial jump (harl_rng_jump; harl_rng_advance above ~1.5 M draws) leaves the generator exactly where drawing
+    does -- every word of the state block, from mid-block starts, on all three instruction-set paths -- and a whole train()'s
+    worth of deferred sampler advances at the 8-GPU global batch (20 x randperm(200 x 32768)) costs one jump: < 1 ms of host
+    time once the polynomial of that total is cached (round 2: 20 x 0.8 ms on a replay thread)."""
+    import time
+
+    import torch
+    from harl_amd import _lib, buffers as B
+
+    lib = _lib.load()
+    for isa in ("", "avx2", "base"):
+        monkeypatch.setenv("HARL_RNG_ISA", isa)
+        for seed, pre, n in ((1, 17, 624 * 3000 + 5), (5, 0, 1700000), (9, 623, 624 * 2600), (11, 624, 2000001)):
+            torch.manual_seed(seed)
+            if pre:
+                torch.empty(pre, dtype=torch.int32).random_()
+            mid = torch.get_rng_state()
+            torch.empty(n, dtype=torch.int32).random_()
+            want = torch.get_rng_state()
+            for fn in (lib.harl_rng_jump, lib.harl_rng_advance):
+                out = torch.empty_like(mid)
+                assert fn(mid.data_ptr(), mid.numel(), n, out.data_ptr()) == 0
+                assert bool(torch.equal(out, want)), (isa, seed, pre, n, fn.__name__)
+    monkeypatch.setenv("HARL_RNG_ISA", "")
+    n_global = 200 * 32768
+    torch.manual_seed(3)
+    torch.randperm(5)
+    start = torch.get_rng_state()
+    for _ in range(20):
+        torch.empty(n_global - 1, dtype=torch.int32).random_()
+    want = torch.get_rng_state()
+    best = 1e9
+    for rep in range(4):  # rep 0 builds the jump polynomial of this total (~20 ms, cached)
+        torch.set_rng_state(start)
+        t0 = time.perf_counter()
+        for _ in range(20):
+            B.consume_randperm(n_global)
+        B.rng_sync()
+        dt = time.perf_counter() - t0
+        assert bool(torch.equal(torch.get_rng_state(), want))
+        if rep:
+            best = min(best, dt)
+    print(f"20 deferred sampler advances of {n_global} draws + rng_sync: {best * 1e3:.3f} ms")
+    assert best < 1e-3, best
 
 
 def test_host_rng_instruction_set_paths_agree(monkeypatch):

@@ -23,7 +23,7 @@ FAMILIES = {
     "void k_bwd_dx<128, 128, 0>": ("bwd_dx", B * (512 + 512 + 16 + 4 + 512), "dz_l + x_hat_{l-1} + mask + rstd + dz_{l-1}"),
     "void k_bwd_dx<128, 128, 1>": ("bwd_dx_dw1", B * (512 + 512 + 16 + 4 + 128),
                                    "dz_2 + x_hat_1 + mask + rstd + x0n ATL(32); dz_1 stays on chip (+ 8.4 MB of per-workgroup partials)"),
-    "void k_dw_split<4, 4>": ("dw_hidden", B * (512 + 512), "dz_l + x_hat_{l-1} (+ 33 MB of per-workgroup partials)"),
+    "void k_dw_tr<4, 4>": ("dw_hidden", B * (512 + 512), "dz_l + x_hat_{l-1} (+ 33 MB of per-workgroup partials)"),
     "void k_dw<0, 0, 4, 1>": ("dw_input (unfused path)", B * (512 + 128), "dz_1 + normalised inputs ATL(32)"),
     "void k_dw<1, 0, 1, 4>": ("dw_head (unfused path)", B * (128 + 512), "dhead rows + x_hat_L"),
     "void k_fwd_fused2x<128>": ("fwd_fused2", B * (128 + (512 + 512 + 32 + 8 + 512 + 16 + 4) / 2),

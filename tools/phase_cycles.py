@@ -1,0 +1,74 @@
+"""Per-phase shader cycles of the persistent kernels' slab loops (debug library built with -DHARL_PHASE_TIMING):
+
+    python -c "from harl_amd import _build as B; ex=dict(B.DEFAULT_EXTRA); [ex.__setitem__(f, ex.get(f, [])+['-DHARL_PHASE_TIMING']) for f in ('mlp.hip','wide.hip','heads.hip','update.hip')]; B.build(variant='phase', extra=ex)"
+    HARL_LIB=phase python tools/phase_cycles.py            (on the MI355X box)
+
+Every instrumented kernel sums s_memtime deltas per phase over the slabs of wave 0 of workgroup 0 (csrc/common.h PHASE macros);
+this script runs one MPE update in the layer mode and one in the fused mode and prints the tables.
+"""
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+from harl_amd import _lib  # noqa: E402
+
+NPH = 12
+NAMES = {
+    ("mlp", 0): ("k_bwd_dx<KT>0> (bwd_dx_dw1)", ["split dz", "issue loads", "GEMM", "LN bwd + store", "dW1"]),
+    ("mlp", 1): ("k_bwd_dx<KT=0>", ["split dz", "issue loads", "GEMM", "LN bwd + store"]),
+    ("mlp", 2): ("k_dw_tr", ["barrier 1", "split + store", "barrier 2", "MFMA phase"]),
+    ("wide", 0): ("k_fwd_fused2x", ["split x0n + load", "GEMM 1", "relu/LN 1 + store", "split x1", "GEMM 2", "relu/LN 2 + store"]),
+    ("heads", 0): ("k_actor_head<TRAIN, FUSE>", ["row loads + x load issue", "head fwd", "sample / loss", "head dW", "head bwd + store"]),
+    ("heads", 1): ("k_actor_head<other>", ["load", "head fwd", "sample", "-", "-"]),
+    ("update", 0): ("k_upd_fwd actor TRAIN", ["rows + split x0n", "GEMM 1", "relu/LN 1 + split", "GEMM 2", "relu/LN 2", "head fwd",
+                                                "sample / loss", "head dW", "head bwd + store"]),
+    ("update", 1): ("k_upd_fwd critic TRAIN", ["rows + split x0n", "GEMM 1", "relu/LN 1 + split", "GEMM 2", "relu/LN 2", "head fwd",
+                                                 "sample / loss", "head dW", "head bwd + store"]),
+    ("update", 2): ("k_upd_fwd actor logp", ["rows + split x0n", "GEMM 1", "relu/LN 1 + split", "GEMM 2", "relu/LN 2", "head fwd", "sample"]),
+}
+
+
+def read(tu):
+    lib = _lib.load()
+    buf = (C.c_longlong * (8 * NPH))()
+    fn = getattr(lib, "harl_phase_read_" + tu)
+    fn.argtypes = [C.c_void_p]
+    fn.restype = C.c_int
+    assert fn(buf) == 0
+    return [[buf[s * NPH + k] for k in range(NPH)] for s in range(8)]
+
+
+def show(tus):
+    for tu in tus:
+        tab = read(tu)
+        for slot in range(8):
+            if (tu, slot) not in NAMES or sum(tab[slot]) == 0:
+                continue
+            name, ph = NAMES[(tu, slot)]
+            tot = sum(tab[slot])
+            print(f"## {name}: {tot} cycles, wave 0 / workgroup 0, kernel entry to exit")
+            for k, p in list(enumerate(ph)) + [(10, "PROLOGUE (before the loop)"), (11, "EPILOGUE (after the loop)")]:
+                if tab[slot][k]:
+                    print(f"   {p:28s} {tab[slot][k]:10d}  {100.0 * tab[slot][k] / tot:5.1f} %")
+
+
+def main():
+    assert os.environ.get("HARL_LIB") == "phase", "run with HARL_LIB=phase"
+    dev = torch.device("cuda:0")
+    w = bench.WORKLOADS["mpe"]
+    for mode in ("logp", "1"):
+        os.environ["HARL_FUSED_UPDATE"] = mode
+        r = bench.build_gpu_runner(w, w["N"], 0, 1, dev)
+        bench.one_step(r)
+        torch.cuda.synchronize()
+        print(f"# HARL_FUSED_UPDATE={mode}")
+        show(("mlp", "wide", "heads") if mode == "logp" else ("update",))
+        del r
+
+
+if __name__ == "__main__":
+    main()

@@ -84,7 +84,7 @@ def report(root, out_base):
             if not tg or n == 0:
                 continue
             # both runs execute exactly ONE update step, so totals are comparable even where one call of a tag issues several
-            # kernels (the first-layer weight gradient of a 416-wide input is four k_dw_split launches)
+            # kernels (the first-layer weight gradient of a 416-wide input is k_dw_tr launches)
             calls = sum(kern[t]["n"] for t in tg)
             alg_total = sum(kern[t]["alg_bytes"] for t in tg)
             ratio = (fetch + write) / alg_total

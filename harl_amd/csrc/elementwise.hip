@@ -7,6 +7,9 @@
 //   harl_sum_sumsq / harl_valuenorm_apply   PopArt-style running statistics
 //   harl_gradnorm_clip_adam fused ||g|| + clip + Adam over one flat arena
 //   harl_fold_linear / harl_unfold_linear_grads / harl_reduce_partials / harl_reduce_scalars
+#include <mutex>
+#include <unordered_map>
+
 #include "common.h"
 #include "../../include/harl_hip.h"
 
@@ -160,14 +163,20 @@ extern "C" int harl_gae_returns(const float *rewards, float *value_preds, const 
 // =============================================================================================
 // masked moments (fp64 accumulation, FIXED summation order: the same bits on every run)
 // =============================================================================================
-// Every block leaves its partial {sum, sumsq, count} in a device scratch row; the block that takes the last ticket adds
-// the rows in index order onto out3.  (Launches of this kernel are serialised on one stream by the callers.)
+// Every block leaves its partial {sum, sumsq, count} in a scratch row; the block that takes the last ticket adds the rows in
+// index order onto out3.  The scratch belongs to the launch STREAM (one allocation per stream, made on first use): launches
+// on one stream are serialised, launches on different streams (the runner's side streams) never share rows or the ticket,
+// and the ticket is cleared by a memset ahead of every launch, so an aborted launch cannot poison the next one.
 constexpr int MM_MAX_BLOCKS = 1024;
-__device__ double g_mm_part[MM_MAX_BLOCKS][3];
-__device__ unsigned g_mm_ticket;
+struct MmScratch {
+  double part[MM_MAX_BLOCKS][3];
+  unsigned ticket;
+};
 
 __global__ __launch_bounds__(256) void k_masked_moments(const float *__restrict__ x, const float *__restrict__ active,
-                                                        long n, double *__restrict__ out3) {
+                                                        long n, double *__restrict__ out3, MmScratch *__restrict__ ws) {
+  double(*g_mm_part)[3] = ws->part;
+  unsigned &g_mm_ticket = ws->ticket;
   double s1 = 0, s2 = 0, cnt = 0;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     float a = active ? active[i] : 1.f;
@@ -215,14 +224,32 @@ __global__ __launch_bounds__(256) void k_masked_moments(const float *__restrict_
     for (int i = 0; i < 256; ++i) t += red[threadIdx.x][i];
     out3[threadIdx.x] += t;
   }
-  if (threadIdx.x == 0) __hip_atomic_store(&g_mm_ticket, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+static MmScratch *mm_scratch_of(hipStream_t s) {
+  static std::mutex mu;
+  static std::unordered_map<hipStream_t, MmScratch *> pool;
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = pool.find(s);
+  if (it != pool.end()) return it->second;
+  MmScratch *p = nullptr;
+  if (hipMalloc(reinterpret_cast<void **>(&p), sizeof(MmScratch)) != hipSuccess) return nullptr;
+  pool.emplace(s, p);
+  return p;
 }
 
 extern "C" int harl_masked_moments(const float *x, const float *active, long n, double *out3, void *stream) {
   if (n <= 0) return 0;
   long nb = (n + 2047) / 2048;
   if (nb > MM_MAX_BLOCKS) nb = MM_MAX_BLOCKS;
-  hipLaunchKernelGGL(k_masked_moments, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x, active, n, out3);
+  hipStream_t s = (hipStream_t)stream;
+  MmScratch *ws = mm_scratch_of(s);
+  if (!ws) {
+    set_error("harl_masked_moments: scratch allocation failed");
+    return -2;
+  }
+  (void)hipMemsetAsync(&ws->ticket, 0, sizeof(unsigned), s);
+  hipLaunchKernelGGL(k_masked_moments, dim3((unsigned)nb), dim3(256), 0, s, x, active, n, out3, ws);
   return check_launch("harl_masked_moments");
 }
 
@@ -861,11 +888,13 @@ __global__ __launch_bounds__(1024) void k_trpo_cg_step(float *__restrict__ x, fl
 #pragma clang fp contract(off)
   __shared__ double sh[16];
   const float rdotr = state[0];
-  const bool done = state[1] != 0.f;
+  // the reference leaves its loop once rdotr < 1e-10 (trpo_util.py:127-128): later launches are true no-ops (block-uniform
+  // exit; multiplying the idle Fisher-vector product by alpha = 0 instead would turn a non-finite entry of it into NaN)
+  if (state[1] != 0.f) return;
   double d = 0.0;
   for (long i = threadIdx.x; i < n; i += 1024) d += (double)p[i] * (double)avp[i];
   const float pavp = (float)block_sum_d(d, sh);
-  const float alpha = done ? 0.f : rdotr / pavp;
+  const float alpha = rdotr / pavp;
   double rr = 0.0;
   for (long i = threadIdx.x; i < n; i += 1024) {
     const float ap = alpha * p[i];
@@ -876,16 +905,14 @@ __global__ __launch_bounds__(1024) void k_trpo_cg_step(float *__restrict__ x, fl
     rr += (double)rn * (double)rn;
   }
   const float new_rdotr = (float)block_sum_d(rr, sh);
-  if (!done) {
-    const float beta = new_rdotr / rdotr;
-    for (long i = threadIdx.x; i < n; i += 1024) {
-      const float bp = beta * p[i];
-      p[i] = r[i] + bp;
-    }
+  const float beta = new_rdotr / rdotr;
+  for (long i = threadIdx.x; i < n; i += 1024) {
+    const float bp = beta * p[i];
+    p[i] = r[i] + bp;
   }
   if (threadIdx.x == 0) {
     state[0] = new_rdotr;
-    state[1] = (done || new_rdotr < 1e-10f) ? 1.f : 0.f;
+    state[1] = new_rdotr < 1e-10f ? 1.f : 0.f;
   }
 }
 

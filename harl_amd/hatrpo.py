@@ -38,6 +38,7 @@ class HATRPO(OnPolicyBase):
         self.backtrack_coeff = args["backtrack_coeff"]
         self._tangent_ws = None
         self._grad_tap = None
+        self._cg_tap = None  # test hook: called with (k, x_k) after CG steps 1, 5 and 10
 
     # ---- surrogate  sum_s ratio*f*adv*active / sum(active)  (hatrpo.py:77-90), optionally with its gradient ---------
     def _surrogate(self, obs, m, actions, avail, old_logp, adv, adv_moments, factor, active, want_grad: bool, seq=None):
@@ -198,9 +199,11 @@ class HATRPO(OnPolicyBase):
         x = torch.zeros_like(g)
         r, p = g.clone(), g.clone()
         state = torch.stack([torch.dot(r, r), torch.zeros((), dtype=g.dtype, device=g.device)])  # [r.r, done]
-        for _ in range(10):
+        for it in range(10):
             avp = self._fvp(obs, m, m_global, avail_rows, p, seq=seq)
             call("harl_trpo_cg_step", ptr(x), ptr(r), ptr(p), ptr(avp), x.numel(), ptr(state), stream())
+            if self._cg_tap is not None and it + 1 in (1, 5, 10):
+                self._cg_tap(it + 1, x.clone())
         params = net.flat_param.clone()
         fv = self._fvp(obs, m, m_global, avail_rows, x, seq=seq)
         shs = 0.5 * torch.dot(x, fv)

@@ -159,9 +159,23 @@ class OnPolicyHARunner:
         self._counts_host.copy_(mom_all[:, 2], non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
-        cinfo = None
+        cinfo, critic_done = None, None
         if self._critic_first_ok(fast):
-            cinfo = self.critic.train(self.critic_buffer, self.value_normalizer, _defer=True)
+            # ... and on a stream of its own (single-GPU runs): the critic's twenty-odd launches are independent of the actors',
+            # and every one of these persistent kernels ends with a tail in which most CUs have run out of slabs (kernel time
+            # 0.19-0.26 ms against 0.14-0.20 ms for a wave's own slab loop, tools/phase_cycles.py) -- the other chain's next
+            # kernel fills it.  HARL_CRITIC_STREAM=0 keeps one stream.
+            if not self.comm.enabled and os.environ.get("HARL_CRITIC_STREAM", "1") != "0":
+                if getattr(self, "_critic_stream", None) is None:
+                    self._critic_stream = torch.cuda.Stream(device=dev)
+                main_s = torch.cuda.current_stream(dev)
+                self._critic_stream.wait_stream(main_s)
+                with torch.cuda.stream(self._critic_stream):
+                    cinfo = self.critic.train(self.critic_buffer, self.value_normalizer, _defer=True)
+                    critic_done = torch.cuda.Event()
+                    critic_done.record(self._critic_stream)
+            else:
+                cinfo = self.critic.train(self.critic_buffer, self.value_normalizer, _defer=True)
         ev.synchronize()
         counts = self._counts_host.tolist()
         # Pre-update log-probs that cannot come out of the first epoch's forward (recurrent policies: full-length unroll from
@@ -221,6 +235,8 @@ class OnPolicyHARunner:
             factor = new_factor
         if cinfo is None:
             cinfo = self.critic.train(self.critic_buffer, self.value_normalizer, _defer=True)
+        if critic_done is not None:
+            torch.cuda.current_stream(dev).wait_event(critic_done)
         rng_sync()  # the global CPU generator is exactly where the reference leaves it
         dev_infos = [p[1] for p in pending if p is not None] + [cinfo]
         flat = torch.cat([t.reshape(-1) for t in dev_infos]).cpu().tolist()  # the single end-of-train read-back

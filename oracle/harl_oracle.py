@@ -914,7 +914,8 @@ class OracleHATRPO:
         x = torch.zeros_like(g)
         r, pvec = g.clone(), g.clone()
         rdotr = torch.dot(r, r)
-        for _ in range(10):
+        cg_x = {}  # iterates after 1, 5, 10 steps (tests: evidence upstream of the solve's end)
+        for it in range(10):
             avp = self.fvp(obs, avail, pvec, rnn, msk)
             alpha = rdotr / torch.dot(pvec, avp)
             x += alpha * pvec
@@ -922,6 +923,8 @@ class OracleHATRPO:
             new_rdotr = torch.dot(r, r)
             pvec = r + (new_rdotr / rdotr) * pvec
             rdotr = new_rdotr
+            if it + 1 in (1, 5, 10):
+                cg_x[it + 1] = x.numpy().copy()
             if rdotr < 1e-10:
                 break
         loss0 = loss.data.numpy()
@@ -934,7 +937,7 @@ class OracleHATRPO:
         consume_policy_init_rng({k: tuple(v.shape) for k, v in self.p.items()})
         expected = (g * full_step).sum(0, keepdim=True).numpy()
         flag, fraction = False, 1
-        info = dict(grad=g.numpy().copy(), step_dir=x.numpy().copy(), step_size=float(step_size), shs=float(shs))
+        info = dict(grad=g.numpy().copy(), step_dir=x.numpy().copy(), step_size=float(step_size), shs=float(shs), cg_x=cg_x)
         for _ in range(t.ls_step):
             self.set_flat(params + fraction * full_step)
             new_loss, ent, ratio = self.surrogate(obs, actions, avail, active, old_logp, adv, factor, rnn, msk)

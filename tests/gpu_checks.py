@@ -1333,7 +1333,7 @@ BASELINE_SHAPES = {
 }
 
 
-def _mask_relu_kinks(case, margin: float = 2e-5) -> int:
+def _mask_relu_kinks(case, margin: float = 2e-5, replace=None) -> int:
     """The update has two kinds of kinks: ReLU (derivative 0 / 1 at z = 0) and the PPO clip (gradient on / off where the
     importance ratio crosses 1 +- clip_param).  A sample sitting within rounding distance of one gets the derivative switched
     on in one fp32 implementation and off in another.  Measured at T = 200, N = 160: ONE sample out of 32 000 with a
@@ -1343,7 +1343,14 @@ def _mask_relu_kinks(case, margin: float = 2e-5) -> int:
     With ~8 million pre-activations per update a few always are that close, so they are taken out of the comparison: every
     (t, n) whose actor pre-activations (float64 forward of the initial weights) come within ``margin`` of zero in any MLP
     layer, or whose ratio comes within ``margin`` (relative) of a clip boundary, gets active_mask = 0, which removes it from
-    the loss and the gradient in the reference and here alike (happo.py:77-81).  Returns the number of masked samples."""
+    the loss and the gradient in the reference and here alike (happo.py:77-81).  Returns the number of masked samples.
+    HATRPO (``replace`` defaults to True there): the Fisher-vector product differentiates kl.mean() over EVERY row of the batch,
+    active or not (trpo_util.py:132-158), so an inactive kink-adjacent row still flips a ReLU derivative inside F -- one such
+    row moves F v by 1/M of its norm (measured at M = 8000: 1.2e-4 in the lower layers' blocks, while the same product agrees
+    with float64 to 2e-7 at M = 4000 and 6000 where no row flips; tools/diag_fvp.py).  Those rows are therefore REPLACED by
+    copies of a kink-free row's observation instead of masked."""
+    if replace is None:
+        replace = case.algo_name == "hatrpo"
     T, N = case.shapes.T, case.shapes.N
     train, model, algo = case.reference_dicts()
     cfg = O.PathConfig.from_reference_dicts(train, model, algo)
@@ -1380,8 +1387,16 @@ def _mask_relu_kinks(case, margin: float = 2e-5) -> int:
                 imp = r_.prod(-1) if cfg.action_aggregation == "prod" else r_.mean(-1)
                 for edge in (1.0 - cfg.clip_param, 1.0 + cfg.clip_param):
                     near |= ((imp - edge).abs() < margin * edge)
-        am = case.data.active_masks[a]
-        am[:-1].reshape(T * N, 1)[near.numpy()] = 0.0
+        nn_ = near.numpy()
+        if replace and nn_.any():
+            safe = np.flatnonzero(~nn_)
+            ob = case.data.obs[a][:-1].reshape(T * N, -1)   # a view of the buffer: rows are overwritten in place
+            assert np.shares_memory(ob, case.data.obs[a])
+            bad = np.flatnonzero(nn_)
+            ob[bad] = ob[safe[np.arange(len(bad)) % len(safe)]]
+        else:
+            am = case.data.active_masks[a]
+            am[:-1].reshape(T * N, 1)[nn_] = 0.0
         n_masked += int(near.sum())
     return n_masked
 
@@ -1469,6 +1484,98 @@ def check_baseline_shape(name: str) -> Dict[str, float]:
         out["_actor_final_param_vec_rel_max"] = max(out.get("_actor_final_param_vec_rel_max", 0.0), vec_rel_err(fp, runs["f32"]["fin"][a]))
     out["actor_final_param_excess"] = worst
     out["critic_final_param_excess"] = vec_excess(r.critic.critic.flat_param.cpu().numpy(), runs["f32"]["cfin"], runs["f64"]["cfin"])
+    return out
+
+
+def check_trpo_upstream(name: str = "humanoid17", agents=(0, 8, 16)) -> Dict[str, float]:
+    """HATRPO at a BASELINE shape, UPSTREAM of the end of the conjugate-gradient solve: for a few agents, from
+    identical parameters and buffer contents, the surrogate gradient vector, the Fisher-vector product on three random vectors
+    and the CG iterate after 1, 5 and 10 steps -- each as the HIP path's distance from the oracle in float64 next to the fp32
+    oracle's own distance from it (symmetric yardstick: no perturbation bars).  Asserted (keys without "_"): gradient and
+    F.v within 1e-5 of the vector's inf-norm of the fp64 value; the CG iterates within 4 x the fp32 oracle's own distance
+    (they amplify rounding by the condition number of F; the distances are reported).  The samples an fp64 forward puts within
+    2e-5 of a ReLU kink are masked as in check_baseline_shape; the same figures WITHOUT the masking are reported under
+    `_unmasked_*` (not asserted: one such sample moves a gradient tensor by up to a few % in any fp32 implementation)."""
+    from tests.helpers import SyntheticCase
+    from tests.test_oracle_golden import build_oracle
+    spec = BASELINE_SHAPES[name]
+    out: Dict[str, float] = {}
+    rng = np.random.default_rng(123)
+    for masked in (True, False):
+        case = SyntheticCase(name, Shapes(**spec["shapes"]), spec["seed"], algo_name=spec.get("algo", "happo"),
+                             overrides=spec.get("overrides"), unavailable_p=spec.get("unavailable_p", 0.0))
+        if masked:
+            out["_kink_adjacent_samples_masked"] = float(_mask_relu_kinks(case))
+        sh = case.shapes
+        M = sh.T * sh.N
+        torch.manual_seed(case.seed)
+        np.random.seed(case.seed)
+        r = build_runner(case)
+        r.prep_training()
+        pre = "" if masked else "_unmasked_"
+        worst = dict(grad=0.0, fvp=0.0, cg1=0.0, cg5=0.0, cg10=0.0)
+        ref32 = dict(worst)
+        for a in agents:
+            d = case.data
+            obs = d.obs[a][:-1].reshape(M, -1)
+            act = d.actions[a].reshape(M, -1)
+            old_logp = d.action_log_probs[a].reshape(M, -1)
+            active = d.active_masks[a][:-1].reshape(M, 1)
+            adv = rng.standard_normal((M, 1)).astype(np.float32)
+            factor = (1 + 0.1 * rng.standard_normal((M, 1))).astype(np.float32)
+            vs = [rng.standard_normal(sum(int(np.prod(v.shape)) for v in case.actor_sd[a].values())).astype(np.float32)
+                  for _ in range(3)]
+            sample = (obs, act, active, old_logp, adv, None, factor)
+            ora = {}
+            for tag, dt in (("f32", torch.float32), ("f64", torch.float64)):
+                O.set_work_dtype(dt)
+                try:
+                    cfg, actors, _, _, _, _ = build_oracle(case)
+                    o = actors[a]
+                    t = lambda x: None if x is None else torch.from_numpy(x).to(dt)  # noqa: E731
+                    fv = [o.fvp(t(obs), None, torch.from_numpy(v).to(dt)).numpy().astype(np.float64) for v in vs]
+                    torch.manual_seed(1)
+                    info = o.update(tuple(None if x is None else x.astype(np.float64 if dt == torch.float64 else np.float32)
+                                          for x in sample))
+                    ora[tag] = dict(grad=info["grad"].astype(np.float64), fvp=fv,
+                                    cg={k: v.astype(np.float64) for k, v in info["cg_x"].items()})
+                finally:
+                    O.set_work_dtype(torch.float32)
+            actor = r.actor[a]
+            actor.actor.fold()
+            d_obs = dev(obs)
+            gfv = []
+            sc, g = actor._surrogate(d_obs, M, dev(act), None, dev(old_logp), dev(adv.reshape(M)), None, dev(factor.reshape(M)),
+                                     dev(active.reshape(M)), want_grad=True)
+            g = g.cpu().numpy().astype(np.float64)
+            for v in vs:
+                gfv.append(actor._fvp(d_obs, M, M, None, dev(v)).cpu().numpy().astype(np.float64))
+            taps = {}
+            actor._cg_tap = lambda k, x: taps.__setitem__(k, x.cpu().numpy().astype(np.float64))
+            torch.manual_seed(1)
+            actor.update((obs, np.zeros((M, 1, 1), dtype=np.float32), act, None, active, old_logp, adv, None, factor))
+            torch.cuda.synchronize()
+            actor._cg_tap = None
+            nrm = lambda x: float(np.max(np.abs(x)))  # noqa: E731
+            e = lambda x, y: nrm(x - y) / (nrm(y) + 1e-300)  # noqa: E731
+            worst["grad"] = max(worst["grad"], e(g, ora["f64"]["grad"]))
+            ref32["grad"] = max(ref32["grad"], e(ora["f32"]["grad"], ora["f64"]["grad"]))
+            for k in range(3):
+                worst["fvp"] = max(worst["fvp"], e(gfv[k], ora["f64"]["fvp"][k]))
+                ref32["fvp"] = max(ref32["fvp"], e(ora["f32"]["fvp"][k], ora["f64"]["fvp"][k]))
+            for k in (1, 5, 10):
+                if k in taps and k in ora["f64"]["cg"] and k in ora["f32"]["cg"]:
+                    worst[f"cg{k}"] = max(worst[f"cg{k}"], e(taps[k], ora["f64"]["cg"][k]))
+                    ref32[f"cg{k}"] = max(ref32[f"cg{k}"], e(ora["f32"]["cg"][k], ora["f64"]["cg"][k]))
+        for k in worst:
+            out[f"_{pre.strip('_')}_{k}_hip_vs_f64".replace("__", "_")] = worst[k]
+            out[f"_{pre.strip('_')}_{k}_ref32_vs_f64".replace("__", "_")] = ref32[k]
+        if masked:
+            out["grad_vs_f64"] = worst["grad"]      # asserted < 1e-5 of the inf-norm
+            out["fvp_vs_f64"] = worst["fvp"]
+            for k in (1, 5, 10):                    # asserted <= 1: within 4 x the fp32 oracle's own distance (floor 1e-5)
+                out[f"cg{k}_excess"] = worst[f"cg{k}"] / max(4.0 * ref32[f"cg{k}"], 1e-5)
+        del r
     return out
 
 

@@ -251,6 +251,18 @@ def test_parity_at_baseline_shapes(name):
     _assert_all(_G().check_baseline_shape(name), tol=TOL)
 
 
+def test_hatrpo_upstream_of_cg_at_humanoid_shape():
+    """Humanoid-17x1 shape (obs 393, [128]x3, 17 agents), agents 0 / 8 / 16: surrogate gradient vector, F.v on three random
+    vectors and the CG iterates after 1, 5, 10 steps, each against the oracle in float64 with the fp32 oracle's own distance
+    next to it (printed).  Gradient and F.v are held to 1e-5 of the inf-norm, the CG iterates to 4 x the fp32 oracle's
+    own distance from fp64; the figures without kink masking are reported, not asserted."""
+    res = _G().check_trpo_upstream("humanoid17", (0, 8, 16))
+    print({k: f"{v:.2e}" for k, v in res.items()})
+    assert res["grad_vs_f64"] < 1e-5 and res["fvp_vs_f64"] < 1e-5, res
+    for k in (1, 5, 10):
+        assert res[f"cg{k}_excess"] <= 1.0, res
+
+
 def test_run_with_eval_save_and_restore(tmp_path):
     """run(): eval() + save() every eval_interval episodes, restore() from train.model_dir in the constructor."""
     res = _G().check_run_eval_save_restore(str(tmp_path))

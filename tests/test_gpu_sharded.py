@@ -84,6 +84,18 @@ def _worker(rank, world, port, name, q):
         res["critic_rel"] = rel_err([cinfo["value_loss"], cinfo["critic_grad_norm"]], z["critic_info"])
         res["param_rel"] = max([vec_rel_err(r.actor[a].actor.flat_reference().cpu().numpy(), z[f"actor_final_{a}"])
                                 for a in range(sh.A)] + [vec_rel_err(r.critic.critic.flat_param.cpu().numpy(), z["critic_final"])])
+        # the bar of the unsharded golden tests (tests/helpers.excess): every entry within max(1e-5, 2 x the reference's own
+        # measured fp32 uncertainty) of the reference's figure -- the sharded sums are another correct fp32 summation order
+        from tests.helpers import excess, load_noise, vec_excess
+        nz = load_noise(name)
+        res["actor_excess"] = max(excess(got[:, c], z["actor_infos"][:, c], nz["actor_infos"][:, c], nz["sens_actor_infos"][:, c])
+                                  for c in range(4))
+        res["critic_excess"] = excess([cinfo["value_loss"], cinfo["critic_grad_norm"]], z["critic_info"], nz["critic_info"],
+                                      nz["sens_critic_info"])
+        res["param_excess"] = max([vec_excess(r.actor[a].actor.flat_reference().cpu().numpy(), z[f"actor_final_{a}"],
+                                              nz[f"actor_final_{a}"], nz[f"sens_actor_final_{a}"]) for a in range(sh.A)]
+                                  + [vec_excess(r.critic.critic.flat_param.cpu().numpy(), z["critic_final"], nz["critic_final"],
+                                                nz["sens_critic_final"])])
         res["param_sum"] = float(sum(r.actor[a].actor.flat_param.double().sum().item() for a in range(sh.A)))
         q.put(res)
     finally:
@@ -107,5 +119,5 @@ def test_two_rank_sharded_train_matches_unsharded_golden(name):
         assert p.exitcode == 0
     for r in res:
         assert r["ret_bad"] == 0.0 and r["rng_bad"] == 0.0, r
-        assert r["actor_rel"] < 1e-4 and r["critic_rel"] < 1e-4 and r["param_rel"] < 1e-4, r
+        assert r["actor_excess"] <= 1.0 and r["critic_excess"] <= 1.0 and r["param_excess"] <= 1.0, r
     assert res[0]["param_sum"] == res[1]["param_sum"], "replicated parameters diverged between ranks"

@@ -165,7 +165,7 @@ class OnPolicyHARunner:
             # and every one of these persistent kernels ends with a tail in which most CUs have run out of slabs (kernel time
             # 0.19-0.26 ms against 0.14-0.20 ms for a wave's own slab loop, tools/phase_cycles.py) -- the other chain's next
             # kernel fills it.  HARL_CRITIC_STREAM=0 keeps one stream.
-            if not self.comm.enabled and os.environ.get("HARL_CRITIC_STREAM", "1") != "0":
+            if dev.type == "cuda" and not self.comm.enabled and os.environ.get("HARL_CRITIC_STREAM", "1") != "0":
                 if getattr(self, "_critic_stream", None) is None:
                     self._critic_stream = torch.cuda.Stream(device=dev)
                 main_s = torch.cuda.current_stream(dev)

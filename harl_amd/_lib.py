@@ -45,6 +45,7 @@ SIGNATURES = {
     "harl_mlp_fwd_hidden": [_vp, _l, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "harl_mlp_bwd_dx": [_vp, _vp, _vp, _vp, _l, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _vp],
     "harl_mlp_dw_partials": [_vp, _i, _i, _i, _vp, _i, _l, _vp, _vp, _vp, _i, _l, _vp, _i, _vp],
+    "harl_mlp_dw_partials_multi": [_i, _vp, _vp, _vp, _i, _i, _l, _i, _vp],
     "harl_reduce_partials": [_vp, _i, _l, _vp, _vp],
     "harl_reduce_partials_multi": [_vp, _vp, _i, _i, _l, _vp, _vp],
     "harl_adam_fold": [_vp, _vp, _vp, _vp, _l, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _f, _i, _i, _vp, _i, _f, _d, _d,

@@ -241,10 +241,13 @@ __device__ __forceinline__ void stage_matrix(float *__restrict__ dst, const floa
   }
 }
 
-// dynamic LDS above 64 KiB needs an explicit opt-in per kernel
+// dynamic LDS above 64 KiB needs an explicit opt-in per kernel; done once per (kernel, size): the call is not a stream
+// operation and must not run while a stream is being captured into a hipGraph (the first, eager call of a sequence has
+// raised the limit by then)
+bool lds_opt_in_needed(const void *kernel, size_t bytes);  // elementwise.hip
 template <typename F>
 inline void allow_big_lds(F kernel, size_t bytes) {
-  if (bytes > 48 * 1024)
+  if (bytes > 48 * 1024 && lds_opt_in_needed(reinterpret_cast<const void *>(kernel), bytes))
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)bytes);
 }

@@ -17,6 +17,16 @@
 #include <cstring>
 
 namespace harl {
+bool lds_opt_in_needed(const void *kernel, size_t bytes) {
+  static std::mutex mu;
+  static std::unordered_map<const void *, size_t> done;
+  std::lock_guard<std::mutex> lk(mu);
+  size_t &have = done[kernel];
+  if (have >= bytes) return false;
+  have = bytes;
+  return true;
+}
+
 static thread_local char g_err[512] = "";
 void set_error(const char *msg) {
   std::strncpy(g_err, msg, sizeof(g_err) - 1);

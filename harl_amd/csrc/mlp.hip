@@ -1034,9 +1034,8 @@ __device__ __forceinline__ u32x2_t tr_read(const unsigned char *p) {
 }
 
 template <int MT, int NT>
-__global__ __launch_bounds__(WG_THREADS, 2) void k_dw_tr(const float *__restrict__ a_src, const float *__restrict__ b_src,
-                                                         long n_slabs, float *__restrict__ part, long b_slab_floats,
-                                                         int tile0, int KP) {
+__device__ __forceinline__ void dw_tr_body(const float *__restrict__ a_src, const float *__restrict__ b_src, long n_slabs,
+                                           float *__restrict__ part, long b_slab_floats, int tile0, int KP) {
   using SP = DwSplit<MT, NT>;
   constexpr int HA = 32 * MT, HB = 32 * NT;
   constexpr int NPA = HA / 8, NPB = HB / 8, PER = (NPA + NPB) / WAVES_PER_WG;  // float4 pieces per lane and wave
@@ -1176,6 +1175,27 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_dw_tr(const float *__restrict
   }
   PHASE(11);
   PHASE_END(2);
+}
+
+template <int MT, int NT>
+__global__ __launch_bounds__(WG_THREADS, 2) void k_dw_tr(const float *__restrict__ a_src, const float *__restrict__ b_src,
+                                                         long n_slabs, float *__restrict__ part, long b_slab_floats,
+                                                         int tile0, int KP) {
+  dw_tr_body<MT, NT>(a_src, b_src, n_slabs, part, b_slab_floats, tile0, KP);
+}
+
+// several independent weight-gradient problems of one shape in ONE launch (blockIdx.y = problem): the six gate blocks of a
+// GRU (d gi_g^T x_hat, d gh_g^T h~) were six launches of ~17 us each per optimiser step at the SMAC sizes, most of it launch
+// latency and ramp-up (270 of them per 8-agent update)
+constexpr int DW_MULTI_MAX = 8;
+struct DwMulti {
+  const float *a[DW_MULTI_MAX];
+  const float *b[DW_MULTI_MAX];
+  float *part[DW_MULTI_MAX];
+};
+template <int MT, int NT>
+__global__ __launch_bounds__(WG_THREADS, 2) void k_dw_tr_multi(DwMulti P, long n_slabs, int KP) {
+  dw_tr_body<MT, NT>(P.a[blockIdx.y], P.b[blockIdx.y], n_slabs, P.part[blockIdx.y], (long)KP * SLAB, 0, KP);
 }
 
 HARL_PHASE_ACCESSOR(mlp)
@@ -1466,4 +1486,29 @@ extern "C" int harl_mlp_dw_partials(const float *a, int a_kind, int lda, int HO,
   }
 #undef DW
   return check_launch("harl_mlp_dw_partials");
+}
+
+extern "C" int harl_mlp_dw_partials_multi(int n, const float *const *a, const float *const *b, float *const *part, int HO,
+                                          int K, long M, int n_wg, void *stream) {
+  if (M <= 0 || n_wg <= 0 || n <= 0) return 0;
+  if (n > DW_MULTI_MAX) return bad("harl_mlp_dw_partials_multi: at most 8 problems per launch");
+  const long n_slabs = n_slabs_of(M);
+  DwMulti P;
+  for (int k = 0; k < DW_MULTI_MAX; ++k) {
+    P.a[k] = a[k < n ? k : 0];
+    P.b[k] = b[k < n ? k : 0];
+    P.part[k] = part[k < n ? k : 0];
+  }
+  hipStream_t s = (hipStream_t)stream;
+#define DWM(MTv, NTv)                                                                                      \
+  {                                                                                                        \
+    const size_t shm = (size_t)3 * 8 * ((2 * MTv * 128 + 8) + (2 * NTv * 128 + 8));                        \
+    allow_big_lds(k_dw_tr_multi<MTv, NTv>, shm);                                                           \
+    hipLaunchKernelGGL((k_dw_tr_multi<MTv, NTv>), dim3(n_wg, n), dim3(WG_THREADS), shm, s, P, n_slabs, K);  \
+  }
+  if (HO == 64 && K == 64) DWM(2, 2)
+  else if (HO == 128 && K == 128) DWM(4, 4)
+  else return bad("harl_mlp_dw_partials_multi: square 64 / 128 blocks only");
+#undef DWM
+  return check_launch("harl_mlp_dw_partials_multi");
 }

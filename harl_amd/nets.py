@@ -496,12 +496,12 @@ class _FlatNet(nn.Module):
                      ptr(sv[1]), ptr(sv[2]), ptr(sv[3]), ptr(sv[4]), H, seq["L"], seq["m_pad"], ptr(self.xh[-1]),
                      ptr(self.rmask[-1]), ptr(self.rstd[-1]), ptr(dg[0]), ptr(dg[1]), ptr(dg[2]), ptr(dg[3]), ptr(self.dz[1]), s,
                      tag="gru_bwd")
-            for gate, a in enumerate((dg[0], dg[1], dg[2])):      # W_ih' gate blocks: d gi^T x_hat_mlp
-                call("harl_mlp_dw_partials", ptr(a), 0, 0, H, ptr(self.xh[-1]), 0, 0, None, None, None, H, M,
-                     ptr(self.part[po[L + gate]:]), nwg, s, tag="dw_gru")
-            for gate, a in enumerate((dg[0], dg[1], dg[3])):      # W_hh gate blocks: d gh^T h~
-                call("harl_mlp_dw_partials", ptr(a), 0, 0, H, ptr(sv[0]), 0, 0, None, None, None, H, M,
-                     ptr(self.part[po[L + 3 + gate]:]), nwg, s, tag="dw_gru")
+            # the six gate blocks in ONE launch: W_ih' blocks d gi_g^T x_hat_mlp (g = r, z, n), W_hh blocks d gh_g^T h~ (dhn for n)
+            import ctypes as C
+            a6 = (C.c_void_p * 6)(*[ptr(t) for t in (dg[0], dg[1], dg[2], dg[0], dg[1], dg[3])])
+            b6 = (C.c_void_p * 6)(*([ptr(self.xh[-1])] * 3 + [ptr(sv[0])] * 3))
+            p6 = (C.c_void_p * 6)(*[ptr(self.part[po[L + k]:]) for k in range(6)])
+            call("harl_mlp_dw_partials_multi", 6, a6, b6, p6, H, H, M, nwg, s, tag="dw_gru")
             cur = 1
         if self.panel:  # width 256 (csrc/panel.hip): per layer dW = dz^T x_hat_prev, then dz_prev through the panel GEMM
             for l in range(L - 1, -1, -1):

@@ -68,6 +68,12 @@ def _dw_partials(a: Sequence) -> float:
     return M * (4.0 * (lda if a[1] else HO) + 4.0 * K)
 
 
+def _dw_partials_multi(a: Sequence) -> float:
+    # (n, a_ptrs, b_ptrs, part_ptrs, HO, K, M, n_wg, stream): n problems, each reads its dz rows (ATL(HO)) and input rows (ATL(K))
+    n, HO, K, M = a[0], a[4], a[5], a[6]
+    return n * M * (4.0 * HO + 4.0 * K)
+
+
 def _gru_fwd(a: Sequence) -> float:
     # (xin, mask_rows, h0, Wih, bih, Whh, bhh, H, L, m_pad, y, rstd_y, hpm, r, z, n, hn, h_last, save, gi_ws, stream)
     H, L, m_pad, save = a[7], a[8], a[9], a[18]
@@ -167,6 +173,7 @@ ALGORITHMIC_BYTES: Dict[str, Callable[[Sequence], float]] = {
     "harl_mlp_tangent_wide": _tangent_wide,
     "harl_mlp_bwd_dx": _bwd_dx,
     "harl_mlp_dw_partials": _dw_partials,
+    "harl_mlp_dw_partials_multi": _dw_partials_multi,
     "harl_gru_fwd": _gru_fwd,
     "harl_gru_bwd": _gru_bwd,
     "harl_actor_head_loss": _actor_head_loss,

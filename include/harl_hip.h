@@ -164,6 +164,12 @@ int harl_mlp_bwd_dx(const float *dz, const float *xprev, const uint32_t *relu_ma
 int harl_mlp_dw_partials(const float *a, int a_kind, int lda, int HO, const float *b, int b_kind, long ldx,
                          const int64_t *idx, const float *mu0, const float *rstd0, int K, long M, float *part,
                          int n_wg, void *stream);
+/* n <= 8 independent weight-gradient problems of ONE shape (square 64 / 128 blocks, both operands ATL images of M rows) in a
+ * single launch: a[k], b[k], part[k] are HOST arrays of device pointers; problem k writes n_wg partial rows of
+ * dWp[HO][K] | dbp[HO] at part[k] exactly as harl_mlp_dw_partials would.  Used for the six gate blocks of a GRU
+ * (autograd of nn.GRU's weight_ih / weight_hh, harl/models/base/rnn.py:14-27). */
+int harl_mlp_dw_partials_multi(int n, const float *const *a, const float *const *b, float *const *part, int HO, int K,
+                               long M, int n_wg, void *stream);
 /* out[e] = sum_w part[w][e] in fixed order (deterministic), e < elems */
 int harl_reduce_partials(const float *part, int n_wg, long elems, float *out, void *stream);
 

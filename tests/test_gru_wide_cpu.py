@@ -69,9 +69,9 @@ def test_gru128_launch_sequence(stub_kernels, monkeypatch):  # noqa: F811
     # the last step of a pass has no successor: no next-step h~ / masks
     assert sum(1 for c in calls["harl_gru_cell_fwd"] if c[15] is None) == n_passes_fwd
     assert sum(1 for c in calls["harl_gru_cell_bwd"] if c[1] is None) == n_bwd_passes
-    # weight gradients of the six gate blocks run on the ordinary two-operand kernel at HO = K = 128
-    gate_dw = [c for c in calls["harl_mlp_dw_partials"] if c[3] == H and c[10] == H]
-    assert len(gate_dw) >= 6 * n_bwd_passes
+    # weight gradients of the six gate blocks: ONE multi-problem launch of the two-operand kernel per backward pass (HO = K = 128)
+    gate_dw = calls["harl_mlp_dw_partials_multi"]
+    assert len(gate_dw) == n_bwd_passes and all(c[0] == 6 and c[4] == H and c[5] == H for c in gate_dw)
 
 
 # ------------------------------------------------------------------------------------------------

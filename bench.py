@@ -279,9 +279,27 @@ def main():
     ap.add_argument("--time-all-tags", action="store_true",
                     help="bracket EVERY tagged launch inside the timed region (used by tools/pmc_traffic.sh so that `kernels` "
                          "describes exactly the step the PMC passes profile; costs ~10 %% of the step)")
+    ap.add_argument("--with-strong-cheetah6", action="store_true",
+                    help="after the line of this invocation print a SECOND JSON line: BASELINE configs[2] as quoted (HalfCheetah-6x1, "
+                         "--scaling strong, --global-threads 8192 split over the same ranks)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher check without a GPU: spawn / rendezvous (gloo) / one all-reduce, then print a line with value null")
     args = ap.parse_args()
+    if args.with_strong_cheetah6 and "RANK" not in os.environ:  # two runs of this script, one line each
+        base = [a for a in sys.argv[1:] if a != "--with-strong-cheetah6"]
+        rc = subprocess.call([sys.executable, os.path.abspath(__file__)] + base)
+        keep = []
+        skip = False
+        for a in base:  # drop the first run's workload selection
+            if skip:
+                skip = False
+            elif a in ("--config", "--scaling", "--global-threads", "--threads-per-gpu"):
+                skip = True
+            elif not a.startswith(("--config=", "--scaling=", "--global-threads=", "--threads-per-gpu=")):
+                keep.append(a)
+        rc2 = subprocess.call([sys.executable, os.path.abspath(__file__)] + keep +
+                              ["--config", "cheetah6", "--scaling", "strong", "--global-threads", "8192"])
+        sys.exit(rc or rc2)
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
     w = WORKLOADS[args.config]
@@ -381,7 +399,8 @@ def main():
             ach = cand[dom]["bytes"] / tot_s
             per_launch = cand[dom]["bytes"] / cand[dom]["n"]
             traffic, traffic_note = None, None
-            tp = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
+            tp = next((q for q in (os.path.join(ROOT, "profiles", f"r0{k}_hbm_traffic.json") for k in (3, 2)) if os.path.exists(q)),
+                      os.path.join(ROOT, "profiles", "r03_hbm_traffic.json"))
             if os.path.exists(tp):  # PMC passes over the same kernels at this workload's shapes (tools/pmc_traffic.sh)
                 tj = json.load(open(tp))
                 ent = tj.get("workloads", {}).get(args.config, {}).get(dom)
@@ -389,9 +408,22 @@ def main():
                     traffic = ent["ratio"] * per_launch / 1e9
                     traffic_note = (f"GB per launch = {ent['ratio']:.3f} (HBM bytes measured by rocprofv3 --pmc, FETCH_SIZE and "
                                     f"WRITE_SIZE in separate passes with the guide's gfx950 unit corrections, / algorithmic bytes "
-                                    f"of the same launches; taken at commit {tj.get('git_sha')}, profiles/r02_hbm_traffic.md) x "
+                                    f"of the same launches; taken at commit {tj.get('git_sha')}, profiles/{os.path.basename(tp)[:-5]}.md) x "
                                     f"{per_launch / 1e9:.4f} GB algorithmic per launch in this run")
+            # the same launches on the matrix pipe: bf16 MFMAs per 32-sample slab (static census of the compiled kernels,
+            # profiles/r03_isa_census.md) x 32.3 cycles each (profiles/r03_mfma_valu_overlap.md) over 1024 SIMDs at 2.4 GHz
+            mfma_slab = {"bwd_dx_dw1": 270, "bwd_dx": 192, "fwd_fused2": 240, "fwd_fused2_k64": 288, "fwd_hidden": 192,
+                         "dw_hidden": 192, "tangent_hidden": 384, "update_fwd": 315, "update_logp": 240}.get(dom)
+            pipe = None
+            if mfma_slab and not w.get("rnn"):
+                slabs = Tn * n_local / 32.0
+                pipe = slabs * mfma_slab * 32.3 / (1024 * 2.4e9) / (cand[dom]["avg_ms"] * 1e-3)
             roof = dict(kernel=dom, bound="hbm", achieved=ach / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s", frac=ach / HBM_PEAK,
+                        hbm_frac=ach / HBM_PEAK, matrix_pipe_frac=pipe,
+                        bound_note="streaming GEMM kernels between two roofs: `frac` = algorithmic bytes / time against the 8 TB/s "
+                                   "HBM peak (the contract's figure); `matrix_pipe_frac` = the launch's bf16 MFMAs x 32.3 cycles "
+                                   "against the time all 1024 SIMDs have at 2.4 GHz.  Neither is saturated: VALU work of the "
+                                   "exact bf16 split / LayerNorm / ReLU sits in separate phases of the same waves (DESIGN.md 3)",
                         traffic=traffic, traffic_note=traffic_note, launches=cand[dom]["n"], avg_ms=cand[dom]["avg_ms"],
                         bytes_per_launch=per_launch,
                         timing="HIP events around every launch of the streaming kernel families inside the timed region; bytes "

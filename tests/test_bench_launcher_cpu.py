@@ -32,6 +32,17 @@ def test_bench_under_explicit_torchrun():
     assert out["n_gpus"] == 2
 
 
+def test_bench_second_line_flag():
+    """--with-strong-cheetah6: the invocation's own line, then BASELINE configs[2] (strong scaling, 8192 global threads)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    p = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--dry-run", "--with-strong-cheetah6"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [json.loads(ln) for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 2 and "MPE" in lines[0]["metric"] and "HalfCheetah" in lines[1]["metric"], p.stdout
+    assert all(ln["n_gpus"] == 2 for ln in lines)
+
+
 def test_bench_single_rank_dry():
     out = _run([sys.executable, "bench.py", "--dry-run"])
     assert out["n_gpus"] == 1 and out["config"]["collective"] == "none"

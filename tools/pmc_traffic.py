@@ -3,7 +3,7 @@
 
     tools/pmc_traffic.sh            # on the GPU box: for every --config one plain run (per-tag algorithmic bytes) and two
                                     # PMC passes (FETCH_SIZE, WRITE_SIZE; --kernel-trace only), CSVs under gpurun_out/pmc_traffic/
-    python tools/pmc_traffic.py report gpurun_out/pmc_traffic profiles/r02_hbm_traffic   # -> .json + .md
+    python tools/pmc_traffic.py report gpurun_out/pmc_traffic profiles/r03_hbm_traffic   # -> .json + .md
 
 FETCH_SIZE is doubled (gfx950 tallies the 128-B requests of wide coalesced reads at 64 B: MI355X_MICROARCH.md / HBM);
 WRITE_SIZE is taken as reported (calibrated 1:1 on fwd_hidden, which writes exactly x_hat + mask + rstd); counter unit
@@ -27,7 +27,7 @@ GROUPS = [
     (r"void k_panel<true>", ("bwd_panel",)),
     (r"void k_bwd_dx<\d+, \d+, 0>", ("bwd_dx",)),
     (r"void k_bwd_dx<\d+, \d+, [1-9]>", ("bwd_dx_dw1",)),
-    (r"void k_dw(_split<|<0)", ("dw_hidden", "dw_gru", "dw_input")),
+    (r"void k_dw(_tr<|_tr_multi<|<0)", ("dw_hidden", "dw_gru", "dw_input")),
     (r"void k_dw<1", ("dw_head",)),
     (r"void k_fwd_wide<", ("fwd_wide", "tangent_wide")),
     (r"(void )?k_x0n_", ("x0n_wide",)),

@@ -21,5 +21,5 @@ for c in $CFGS; do
     done
   done
 done
-python $R/tools/pmc_traffic.py report $OUT $OUT/r02_hbm_traffic > $OUT/report.txt 2>&1
+python $R/tools/pmc_traffic.py report $OUT $OUT/${HARL_TRAFFIC_TAG:-r03}_hbm_traffic > $OUT/report.txt 2>&1
 tail -40 $OUT/report.txt

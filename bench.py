@@ -377,11 +377,20 @@ def main():
     # workload after the timed region, so that it does not understate `value`.
     kern = dict(roof_kern) if args.time_all_tags else {}
     if not args.no_kernel_timing and args.instr_steps > 0:
+        # (ONE stream here: in the timed region the critic's update runs on a stream of its own next to the actors' chain,
+        # so two kernels share the chip and every per-launch duration contains its neighbour's slices; the per-kernel table
+        # and `roofline.single_stream` are taken with the critic chain back on the main stream)
+        prev_cs = os.environ.get("HARL_CRITIC_STREAM")
+        os.environ["HARL_CRITIC_STREAM"] = "0"
         _lib.enable_kernel_timing(True)
         for _ in range(args.instr_steps):
             one_step(r)
         kern = _lib.collect_kernel_timing()
         _lib.enable_kernel_timing(False)
+        if prev_cs is None:
+            os.environ.pop("HARL_CRITIC_STREAM", None)
+        else:
+            os.environ["HARL_CRITIC_STREAM"] = prev_cs
 
     if rank == 0:
         trans_per_step = Tn * n_local * world
@@ -430,6 +439,14 @@ def main():
                                "from each launch's own arguments (harl_amd/traffic.py)",
                         others={k: dict(hbm_frac=round(v["bytes"] / (v["total_ms"] * 1e-3) / HBM_PEAK, 4), n=v["n"],
                                         avg_ms=round(v["avg_ms"], 4)) for k, v in cand.items()})
+            ks = kern.get(dom)
+            if ks and ks.get("bytes") and not args.time_all_tags:
+                a1 = ks["bytes"] / (ks["total_ms"] * 1e-3)
+                roof["single_stream"] = dict(
+                    achieved=a1 / 1e9, frac=a1 / HBM_PEAK, avg_ms=ks["avg_ms"], launches=ks["n"],
+                    matrix_pipe_frac=(pipe * cand[dom]["avg_ms"] / ks["avg_ms"]) if pipe else None,
+                    note=f"the same kernel family in the {args.instr_steps} instrumented steps after the timed region, critic chain on the "
+                         "main stream (HARL_CRITIC_STREAM=0): per-launch durations without a second kernel sharing the chip")
         out = dict(
             metric=w["metric"], value=value, unit="transitions/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
             ms_per_step=dt / args.steps * 1e3, higher_is_better=True, scaling=args.scaling, vs_baseline=None, dtype="f32",
@@ -449,7 +466,7 @@ def main():
                              **({"hbm_frac": round(v["bytes"] / (v["total_ms"] * 1e-3) / HBM_PEAK, 4), "alg_bytes": v["bytes"]}
                                 if v.get("bytes") else {}))
                      for k, v in kern.items()},
-            kernel_timing=f"`kernels`: HIP events around every tagged launch, {args.instr_steps} instrumented steps after the timed region",
+            kernel_timing=f"`kernels`: HIP events around every tagged launch, {args.instr_steps} instrumented single-stream steps after the timed region",
         )
         if w["algo"] == "happo":
             e2e = flops_per_transition(w) * value

@@ -233,8 +233,7 @@ def _is_rnn(args) -> bool:
 def _mk_actor(sh: Shapes, seed: int, **over):
     from harl_amd.happo import HAPPO
     args = default_args(sh.hidden_sizes, **over)
-    space = Discrete(sh.act_dim) if sh.discrete else Box((sh.act_dim,))
-    a = HAPPO(args, Box((sh.obs_dim,)), space, device=DEV)
+    a = HAPPO(args, Box((sh.obs_dim,)), act_space_of(sh), device=DEV)
     sd = synthetic_state_dict(actor_param_shapes(sh, args["use_feature_normalization"], _is_rnn(args)), seed, args["std_x_coef"])
     assert list(sd.keys()) == list(a.actor.state_dict().keys()), (list(sd.keys()), list(a.actor.state_dict().keys()))
     a.actor.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
@@ -347,19 +346,27 @@ def check_gradients(spec, mini_batches: int = 1, agg: str = "prod", inactive_p: 
     over = dict(spec.get("over", {}))
     over.update(action_aggregation=agg)
     M = spec["M"]
+    nvec = spec.get("nvec")  # MultiDiscrete heads (act_dim = sum(nvec))
     sh = Shapes(T=M, N=1, A=1, obs_dim=spec["obs_dim"], share_obs_dim=spec["share_obs_dim"], act_dim=spec["act_dim"],
-                discrete=spec["discrete"], hidden_sizes=spec["hidden_sizes"])
+                discrete=spec["discrete"], hidden_sizes=spec["hidden_sizes"], **({"nvec": list(nvec)} if nvec else {}))
     d = make_buffers(sh, 33, inactive_p=inactive_p, unavailable_p=0.25 if sh.discrete else 0.0)
     actor, sd, args = _mk_actor(sh, 99, **over)
     cfg = O.PathConfig.from_reference_dicts({}, args, args)
     rng = np.random.default_rng(5)
     obs = d.obs[0][:-1].reshape(M, -1)
-    avail = None if not sh.discrete else d.available_actions[0][:-1].reshape(M, -1)
+    avail = None if (not sh.discrete or nvec) else d.available_actions[0][:-1].reshape(M, -1)
     oracle = O.OracleHAPPO({k: torch.from_numpy(v) for k, v in sd.items()}, cfg)
     # policy-consistent actions / old log-probs so that ratios straddle the clip range
     with torch.no_grad():
         feat = O.mlp_base_forward(oracle.net.p, torch.from_numpy(obs))
-        if sh.discrete:
+        if nvec:
+            act = np.stack([rng.integers(0, n, size=M) for n in nvec], -1).astype(np.float32)
+        elif sh.discrete and M > 20000:  # (a per-row rng.choice loop is too slow at many-slab sizes: inverse-CDF draw)
+            logits = torch.nn.functional.linear(feat, oracle.net.p["act.action_out.linear.weight"], oracle.net.p["act.action_out.linear.bias"])
+            logits = torch.where(torch.from_numpy(avail) == 0, torch.full_like(logits, -1e10), logits)
+            cdf = np.cumsum(torch.softmax(logits, -1).numpy().astype(np.float64), -1)
+            act = (rng.random((M, 1)) * cdf[:, -1:] > cdf).sum(-1).clip(0, sh.act_dim - 1).astype(np.float32)[:, None]
+        elif sh.discrete:
             logits = torch.nn.functional.linear(feat, oracle.net.p["act.action_out.linear.weight"], oracle.net.p["act.action_out.linear.bias"])
             logits = torch.where(torch.from_numpy(avail) == 0, torch.full_like(logits, -1e10), logits)
             pr = torch.softmax(logits, -1).numpy().astype(np.float64)
@@ -382,6 +389,9 @@ def check_gradients(spec, mini_batches: int = 1, agg: str = "prod", inactive_p: 
     res = actor.update((obs, rnn, act, None, active, old_logp, adv, avail, factor))
     torch.cuda.synchronize()
     gg = taps[0][0].cpu().numpy()
+    if nvec:  # the arena keeps the heads of a group contiguous: compare in the reference's parameter order
+        net_ = actor.actor
+        gg = torch.cat([taps[0][0][net_.offsets[nm][0]:net_.offsets[nm][0] + p_.numel()] for nm, p_ in net_.named_parameters()]).cpu().numpy()
     out["actor_grad_vec_rel"] = vec_rel_err(gg, g)
     # per-parameter-tensor breakdown (largest)
     worst, off = ("", 0.0), 0
@@ -397,7 +407,8 @@ def check_gradients(spec, mini_batches: int = 1, agg: str = "prod", inactive_p: 
     out["actor_entropy_rel"] = rel_err(res[1].item(), ent.item())
     out["actor_gradnorm_rel"] = rel_err(res[2].item(), float(gn))
     out["actor_ratio_rel"] = rel_err(res[3].item(), float(imp.mean()))
-    out["actor_param_after_vec_rel"] = vec_rel_err(actor.actor.flat_param.cpu().numpy(), oracle.net.flat())
+    out["actor_param_after_vec_rel"] = vec_rel_err((actor.actor.flat_reference() if nvec else actor.actor.flat_param).cpu().numpy(),
+                                                   oracle.net.flat())
 
     # ---- critic
     critic, csd, cargs = _mk_critic(sh, 55, **over)

@@ -5,13 +5,15 @@
 Compiles harl_amd/csrc/<name>.hip to gfx950 assembly with the library's own flags (`hipcc -S --cuda-device-only`) and, per
 kernel, finds its STEADY-STATE LOOP -- the outermost backward branch that contains matrix instructions (the per-slab loop of
 the persistent kernels; for kernels without MFMAs: the largest loop) -- and counts what one trip of it issues: MFMAs, VALU,
-LDS, global memory, scalar, waits.  With the cost model measured in tools/mfma_valu_overlap.hip (a 32x32x16 bf16 MFMA holds
-the SIMD for 8 issue slots of 4 cycles, a 32x32x2 f32 MFMA for 16, and nothing else issues in their shadow; a VALU / LDS
-instruction takes one slot) that gives the ISSUE FLOOR of one slab per wave:
+LDS, global memory, scalar, waits.  Cost model (round 3, s_memtime: tools/mfma_valu_overlap2.hip, tools/valu_cost.hip): a
+32x32x16 bf16 MFMA holds the matrix pipe for 32.3 cycles (fp32 32x32x2: 64) but costs its wave ~12.5 cycles of issue, a plain
+VALU / LDS instruction ~4.9 cycles (transcendentals ~9), and up to five of them issue for free in the shadow of an MFMA of the
+same wave when they are INTERLEAVED with it.  Two floors per slab and wave:
 
-    slots = 8 * n_mfma_bf16 + 16 * n_mfma_f32 + n_valu + n_lds (+ transcendental VALU ops counted 4x)
+    serial      = 32.3 n_bf16 + 64 n_f32 + 4.9 (n_valu + n_lds) + 9 n_transc      (phases one after the other: today's kernels)
+    interleaved = max(32.3 n_bf16 + 64 n_f32,  12.5 (n_bf16 + n_f32) + 4.9 (n_valu + n_lds) + 9 n_transc)
 
-which DESIGN.md section 3 compares with the measured time per slab.  Inner loops (weight staging, k-panels) are counted once
+which DESIGN.md section 3 compares with the measured cycles per slab (tools/phase_cycles.py).  Inner loops (weight staging, k-panels) are counted once
 per textual occurrence, i.e. the floor is a LOWER bound for kernels with data-dependent inner trip counts; the report marks
 them.
 """
@@ -120,15 +122,18 @@ def issue_slots(c):
 
 def main():
     names = sys.argv[1:] or ["mlp", "heads", "gru", "wide", "panel", "update", "multihead", "elementwise"]
-    print("# Static instruction census of the gfx950 kernels (`tools/isa_census.py`, hipcc -O3, no GPU)\n")
-    print("One trip of each kernel's steady-state loop (one 32-sample slab per wave unless noted).  `slots` = issue slots of 4 "
-          "cycles: 8 per bf16 MFMA (32x32x16), 16 per fp32 MFMA, 1 per VALU / LDS instruction, 4 per transcendental; "
-          "`mfma share` = the part of them that is matrix work.  `inner` = loops nested inside (counted once: lower bound).\n")
+    print("# Static instruction census of the gfx950 kernels (`tools/isa_census.py`, hipcc -O3 + the library's per-file flags, no GPU)\n")
+    print("One trip of each kernel's steady-state loop (one 32-sample slab per wave unless noted).  `serial` / `interleaved` = "
+          "cycles per trip under the round-3 cost model (module docstring: MFMA 32.3 / 64 cycles of pipe and 12.5 of issue, VALU / "
+          "LDS 4.9, transcendentals 9; up to five VALU free per MFMA when interleaved).  `inner` = loops nested inside (counted "
+          "once: lower bound).\n")
+    sys.path.insert(0, REPO)
+    from harl_amd._build import EXTRA_FLAGS
     with tempfile.TemporaryDirectory() as td:
         for n in names:
             src, asm = os.path.join(CSRC, n + ".hip"), os.path.join(td, n + ".s")
             r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S",
-                                src, "-o", asm], capture_output=True, text=True)
+                                src, "-o", asm] + EXTRA_FLAGS.get(n + ".hip", []), capture_output=True, text=True)
             if r.returncode != 0:
                 print(f"## {n}.hip: hipcc failed\n```\n{r.stderr[-400:]}\n```")
                 continue
@@ -136,7 +141,7 @@ def main():
             syms = sorted(funcs)
             pretty = dict(zip(syms, demangle(syms)))
             print(f"## {n}.hip\n")
-            print("| kernel | mfma bf16 | mfma f32 | valu | transc. | lds | vmem ld / st | waits | inner | slots | mfma share | us @2.4 GHz |")
+            print("| kernel | mfma bf16 | mfma f32 | valu | transc. | lds | vmem ld / st | waits | inner | serial cycles | interleaved cycles | matrix share of serial |")
             print("|---|---|---|---|---|---|---|---|---|---|---|---|")
             rows = []
             for sym in syms:
@@ -150,12 +155,15 @@ def main():
                 nm = re.sub(r"\(anonymous namespace\)::", "", pretty[sym])
                 nm = re.sub(r"^void ", "", nm)
                 nm = nm.split("(")[0][:70]
-                share = (8 * g("mfma_bf16") + 16 * g("mfma_f32")) / sl
+                pipe = 32.3 * g("mfma_bf16") + 64.0 * g("mfma_f32")
+                other = 4.9 * (g("valu") + g("lds")) + 9.0 * g("valu_t")
+                serial = pipe + other
+                inter = max(pipe, 12.5 * (g("mfma_bf16") + g("mfma_f32")) + other)
                 rows.append((nm, g("mfma_bf16"), g("mfma_f32"), g("valu"), g("valu_t"), g("lds"), f"{g('vmem_ld')} / {g('vmem_st')}",
-                             g("wait"), inner, sl, share, sl * 4 / 2400.0))
+                             g("wait"), inner, serial, inter, pipe / max(serial, 1.0)))
             for r_ in sorted(rows, key=lambda x: (-x[9])):
-                print("| `%s` | %d | %d | %d | %d | %d | %s | %d | %d | %d | %.0f %% | %.2f |" % (
-                    r_[0], r_[1], r_[2], r_[3], r_[4], r_[5], r_[6], r_[7], r_[8], r_[9], 100 * r_[10], r_[11]))
+                print("| `%s` | %d | %d | %d | %d | %d | %s | %d | %d | %.0f | %.0f | %.0f %% |" % (
+                    r_[0], r_[1], r_[2], r_[3], r_[4], r_[5], r_[6], r_[7], r_[8], r_[9], r_[10], 100 * r_[11]))
             print()
 
 

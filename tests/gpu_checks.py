@@ -1263,6 +1263,62 @@ def check_fused_vs_layered(rows: int) -> Dict[str, float]:
     return out
 
 
+def check_many_slabs_linearity(spec, rows: int, chunk: int = 8192) -> Dict[str, float]:
+    """Size-independent property instead of a CPU oracle at a size the oracle cannot hold (a float64 autograd pass over
+    5e5 rows exhausts the GPU box's host memory; torch-fp32 itself is only good to ~1e-3 of a gradient tensor's inf-norm
+    there: sums with cancellation ~ sqrt(M)): the UNSCALED folded gradients and loss sums of one forward + loss + backward
+    over `rows` rows -- where every wave of the persistent kernels walks eight or more slabs -- must equal the float64 sum of
+    the same quantities over disjoint chunks of `chunk` rows, each of which is a size the oracle-checked tests cover (a
+    slab or two per wave).  A slab-indexing mistake that only shows when a wave iterates breaks this identity."""
+    nvec = spec.get("nvec")
+    sh = Shapes(T=rows, N=1, A=1, obs_dim=spec["obs_dim"], share_obs_dim=spec["share_obs_dim"], act_dim=spec["act_dim"],
+                discrete=spec["discrete"], hidden_sizes=spec["hidden_sizes"], **({"nvec": list(nvec)} if nvec else {}))
+    actor, _, _ = _mk_actor(sh, 31)
+    net = actor.actor
+    g = torch.Generator(device=DEV)
+    g.manual_seed(7)
+    obs = torch.randn(rows, sh.obs_dim, generator=g, device=DEV)
+    if nvec:
+        act = torch.stack([torch.randint(0, n, (rows,), generator=g, device=DEV) for n in nvec], -1).float()
+    elif sh.discrete:
+        act = torch.randint(0, sh.act_dim, (rows, 1), generator=g, device=DEV).float()
+    else:
+        act = torch.randn(rows, sh.act_dim, generator=g, device=DEV)
+    adv = torch.randn(rows, generator=g, device=DEV)
+    factor = (1 + 0.1 * torch.randn(rows, generator=g, device=DEV)).contiguous()
+    net.fold()
+    lp0 = torch.empty(rows, net.act_w, device=DEV)
+    actor._logp_pass(obs, act, None, rows, lp0)
+    old_logp = (lp0 + 0.1 * torch.randn(rows, net.act_w, generator=g, device=DEV)).contiguous()
+
+    def run(lo, hi):
+        m = hi - lo
+        net.invalidate_caches()
+        nblk = actor._forward_backward(obs[lo:hi].contiguous(), None, m, act[lo:hi].contiguous(), None,
+                                       old_logp[lo:hi].contiguous(), adv[lo:hi].contiguous(), None, factor[lo:hi].contiguous(), None)
+        sc = torch.zeros(_lib.PS_STRIDE, dtype=torch.float64, device=DEV)
+        call("harl_reduce_scalars", ptr(net.part_scalars), nblk, ptr(sc), stream())
+        return net.dwp.double().clone(), sc[:5].clone()
+
+    full_dwp, full_sc = run(0, rows)
+    acc_dwp, acc_sc = torch.zeros_like(full_dwp), torch.zeros_like(full_sc)
+    for lo in range(0, rows, chunk):
+        d_, s_ = run(lo, min(rows, lo + chunk))
+        acc_dwp += d_
+        acc_sc += s_
+    torch.cuda.synchronize()
+    out = {"loss_sums_rel": float(((full_sc - acc_sc).abs() / acc_sc.abs().clamp_min(1e-30)).max())}
+    # per layer block of the folded-gradient arena (the blocks differ by orders of magnitude)
+    worst = 0.0
+    offs = sorted(set([0, full_dwp.numel()] + [int(o) for o in net._dwp_offs]))
+    for a_, b_ in zip(offs[:-1], offs[1:]):
+        ref = acc_dwp[a_:b_]
+        if float(ref.abs().max()) > 0:
+            worst = max(worst, float((full_dwp[a_:b_] - ref).abs().max() / ref.abs().max()))
+    out["folded_grad_block_vec_rel"] = worst
+    return out
+
+
 def check_gradient_noise(spec, agg: str = "prod") -> Dict[str, float]:
     """Where does ONE update of the HIP path sit relative to exact arithmetic, compared with the reference's fp32 arithmetic?
     Pre-clip gradient of the same HAPPO.update computed three ways -- HIP kernels, oracle in float32 (= the reference's

@@ -246,16 +246,17 @@ def test_fused_update_kernels_many_slabs_per_wave():
 
 @pytest.mark.parametrize("kind", ["width256", "multidiscrete"])
 def test_many_slabs_per_wave_width256_and_multidiscrete(kind):
-    """One HAPPO.update + one VCritic.update against the oracle at sizes where every wave of the persistent kernels walks
-    EIGHT or more slabs -- the 256-wide panel kernels (dexhands shape) and the MultiDiscrete head kernels (LAG layout): their
-    golden fixtures are a slab or two per wave."""
+    """The 256-wide panel kernels (dexhands shape) and the MultiDiscrete head kernels (LAG layout) at sizes where every wave
+    of the persistent kernels walks EIGHT or more slabs (their golden fixtures are a slab or two per wave):
+    unscaled folded gradients and loss sums of the whole batch against the float64 sum over 8192-row chunks (linearity)."""
     G = _G()
     if kind == "width256":
-        spec = dict(G.FWD_SHAPES[7], M=32 * 8 * 1024 + 45)
+        res = G.check_many_slabs_linearity(G.FWD_SHAPES[7], 32 * 8 * 1024 + 45)
     else:
-        spec = dict(name="md_lag_many", obs_dim=19, share_obs_dim=7, act_dim=153, discrete=True, hidden_sizes=[128, 128],
-                    nvec=[41, 41, 41, 30], M=32 * 8 * 2048 + 77)
-    _assert_all(G.check_gradients(spec), tol=2e-5)
+        res = G.check_many_slabs_linearity(dict(name="md_lag_many", obs_dim=19, share_obs_dim=7, act_dim=153, discrete=True,
+                                                hidden_sizes=[128, 128], nvec=[41, 41, 41, 30]), 32 * 8 * 2048 + 77)
+    print(res)
+    _assert_all(res, tol=2e-5)
 
 
 @pytest.mark.parametrize("name", ["mpe3", "cheetah6", "smac3s5z", "humanoid17"])

@@ -500,6 +500,123 @@ __global__ __launch_bounds__(256) void k_reduce_partials(const float *__restrict
   out[e] = (s0 + s1) + (s2 + s3);
 }
 
+// =============================================================================================
+// Activation functions other than ReLU (harl/utils/models_tools.py:28-50: sigmoid, tanh, leaky_relu, selu -- the ones
+// nn.init.calculate_gain accepts, i.e. the ones the reference's MLPLayer can be built with, mlp.py:19-23).  A coverage path
+// composed from the verified GEMM kernels in raw mode (harl_mlp_linear / harl_mlp_linear_wide) and two element-wise launches
+// over ATL images, one wave per 32-sample slab:
+//   harl_act_ln_fwd :  a = act(z),  x_hat = LayerNorm(a)  -> x_hat, mean(a), rstd        (mlp.py:25-38: Linear, act, LayerNorm)
+//   harl_act_bwd    :  dz = da * act'(z), in place, with act' taken from the activation VALUE a = x_hat / rstd + mean
+//                      (tanh: 1 - a^2, sigmoid: a (1 - a), leaky_relu: a > 0 ? 1 : 0.01, selu: a > 0 ? scale : a + scale alpha)
+// where da is what the backward kernels produce when they are handed an all-ones ReLU mask (harl_mlp_bwd_dx, the loss
+// kernels' LayerNorm backward).  ACT ids: 1 leaky_relu, 2 tanh, 3 sigmoid, 4 selu.
+// =============================================================================================
+constexpr float SELU_SCALE = 1.0507009873554804934193349852946f, SELU_ALPHA = 1.6732632423543772848170429916717f;
+
+__device__ __forceinline__ float act_value(float z, int act) {
+  switch (act) {
+    case 1: return z > 0.f ? z : 0.01f * z;
+    case 2: return tanhf(z);
+    case 3: return 1.0f / (1.0f + expf(-z));
+    default: return z > 0.f ? SELU_SCALE * z : (SELU_SCALE * SELU_ALPHA) * (expf(z) - 1.0f);
+  }
+}
+__device__ __forceinline__ float act_slope_from_value(float a, int act) {
+  switch (act) {
+    case 1: return a > 0.f ? 1.0f : 0.01f;
+    case 2: return 1.0f - a * a;
+    case 3: return a * (1.0f - a);
+    default: return a > 0.f ? SELU_SCALE : a + SELU_SCALE * SELU_ALPHA;
+  }
+}
+
+template <int H>
+__global__ __launch_bounds__(WG_THREADS) void k_act_ln_fwd(const float *__restrict__ z, long n_slabs, int act,
+                                                           float *__restrict__ xhat, float *__restrict__ mean_out,
+                                                           float *__restrict__ rstd_out) {
+#pragma clang fp contract(off)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (long slab = (long)blockIdx.x * WAVES_PER_WG + wave; slab < n_slabs; slab += (long)gridDim.x * WAVES_PER_WG) {
+    float v[H / 2];
+    atl_load<H>(z, slab, lane, v);
+    float sum = 0.f;
+#pragma unroll
+    for (int R = 0; R < H / 2; ++R) {
+      v[R] = act_value(v[R], act);
+      sum += v[R];
+    }
+    sum = wave_sum32(sum);
+    const float mean = sum * (1.0f / H);
+    float vs = 0.f;
+#pragma unroll
+    for (int R = 0; R < H / 2; ++R) {
+      v[R] -= mean;
+      vs += v[R] * v[R];
+    }
+    vs = wave_sum32(vs);
+    const float rstd = 1.0f / sqrtf(vs * (1.0f / H) + 1e-5f);
+#pragma unroll
+    for (int R = 0; R < H / 2; ++R) v[R] *= rstd;
+    atl_store<H>(xhat, slab, lane, v);
+    if (lane < 32) {
+      mean_out[slab * SLAB + lane] = mean;
+      rstd_out[slab * SLAB + lane] = rstd;
+    }
+  }
+}
+
+template <int H>
+__global__ __launch_bounds__(WG_THREADS) void k_act_bwd(float *__restrict__ dz, const float *__restrict__ xhat,
+                                                        const float *__restrict__ mean_in, const float *__restrict__ rstd_in,
+                                                        long n_slabs, int act) {
+#pragma clang fp contract(off)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (long slab = (long)blockIdx.x * WAVES_PER_WG + wave; slab < n_slabs; slab += (long)gridDim.x * WAVES_PER_WG) {
+    float d[H / 2], x[H / 2];
+    atl_load<H>(dz, slab, lane, d);
+    atl_load<H>(xhat, slab, lane, x);
+    const float mean = mean_in[slab * SLAB + (lane & 31)], sd = 1.0f / rstd_in[slab * SLAB + (lane & 31)];
+#pragma unroll
+    for (int R = 0; R < H / 2; ++R) d[R] *= act_slope_from_value(x[R] * sd + mean, act);
+    atl_store<H>(dz, slab, lane, d);
+  }
+}
+
+extern "C" int harl_act_ln_fwd(const float *z, long M, int H, int act, float *xhat, float *mean, float *rstd, void *stream) {
+  if (M <= 0) return 0;
+  if (act < 1 || act > 4) {
+    set_error("harl_act_ln_fwd: activation id must be 1 (leaky_relu), 2 (tanh), 3 (sigmoid) or 4 (selu)");
+    return -2;
+  }
+  const long n_slabs = n_slabs_of(M);
+  const int grid = persistent_grid(n_slabs, 8);
+  if (H == 128) hipLaunchKernelGGL(k_act_ln_fwd<128>, dim3(grid), dim3(WG_THREADS), 0, (hipStream_t)stream, z, n_slabs, act, xhat, mean, rstd);
+  else if (H == 64) hipLaunchKernelGGL(k_act_ln_fwd<64>, dim3(grid), dim3(WG_THREADS), 0, (hipStream_t)stream, z, n_slabs, act, xhat, mean, rstd);
+  else {
+    set_error("harl_act_ln_fwd: width must be 64 or 128");
+    return -2;
+  }
+  return check_launch("harl_act_ln_fwd");
+}
+
+extern "C" int harl_act_bwd(float *dz, const float *xhat, const float *mean, const float *rstd, long M, int H, int act,
+                            void *stream) {
+  if (M <= 0) return 0;
+  if (act < 1 || act > 4) {
+    set_error("harl_act_bwd: activation id must be 1 (leaky_relu), 2 (tanh), 3 (sigmoid) or 4 (selu)");
+    return -2;
+  }
+  const long n_slabs = n_slabs_of(M);
+  const int grid = persistent_grid(n_slabs, 8);
+  if (H == 128) hipLaunchKernelGGL(k_act_bwd<128>, dim3(grid), dim3(WG_THREADS), 0, (hipStream_t)stream, dz, xhat, mean, rstd, n_slabs, act);
+  else if (H == 64) hipLaunchKernelGGL(k_act_bwd<64>, dim3(grid), dim3(WG_THREADS), 0, (hipStream_t)stream, dz, xhat, mean, rstd, n_slabs, act);
+  else {
+    set_error("harl_act_bwd: width must be 64 or 128");
+    return -2;
+  }
+  return check_launch("harl_act_bwd");
+}
+
 extern "C" int harl_reduce_partials(const float *part, int n_wg, long elems, float *out, void *stream) {
   if (elems <= 0) return 0;
   hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, (hipStream_t)stream, part,

@@ -298,9 +298,11 @@ __global__ __launch_bounds__(256) void k_split_image(const float *__restrict__ W
 // ---------------------------------------------------------------------------------------------
 // x0n ATL(KP) -> H.  Each wave owns two slabs at a time (every A fragment read from L2 feeds 12 MFMAs); the fragments
 // and activations of k-step j+1 are in flight while the MFMAs of k-step j run.
-// TANGENT: the epilogue is the LayerNorm Jacobian (forward mode), otherwise ReLU + LayerNorm + mask.
+// MODE 0: ReLU + LayerNorm + mask epilogue; MODE 1 (tangent): the LayerNorm Jacobian (forward mode); MODE 2 (raw): the
+// pre-activations z = W' x0n + b' as an ATL(HO) image (activation functions other than ReLU: csrc/elementwise.hip applies
+// the activation and the LayerNorm in a separate element-wise launch, harl_amd/nets.py).
 // ---------------------------------------------------------------------------------------------
-template <int HO, bool TANGENT>
+template <int HO, int MODE>
 __global__ __launch_bounds__(WG_THREADS, 1) void k_fwd_wide(const float *__restrict__ x0n, const u32x4 *__restrict__ img,
                                                             const float *__restrict__ bp, float *__restrict__ xout,
                                                             uint32_t *__restrict__ mask_out, float *__restrict__ rstd_out,
@@ -371,7 +373,16 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_fwd_wide(const float *__restr
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    if constexpr (TANGENT) {
+    if constexpr (MODE == 2) {
+      auto epi = [&](f32x16(&acc)[MT], long slab) {
+        float z[HO / 2];
+#pragma unroll
+        for (int R = 0; R < HO / 2; ++R) z[R] = acc[R >> 4][R & 15];
+        atl_store<HO>(xout, slab, lane, z);
+      };
+      epi(acc0, s0);
+      if (s1 != s0) epi(acc1, s1);
+    } else if constexpr (MODE == 1) {
       // (the bias slot carries bdp)  x1dot = LNjac(mask1 * (Wdp x0n + bdp))
       {
         constexpr int NR = HO / 2, NW = (NR + 31) / 32;
@@ -569,7 +580,7 @@ __global__ __launch_bounds__(64 * F2X_WAVES, 2) void k_fwd_fused2x(
   PHASE_END(0);
 }
 
-template <bool TANGENT>
+template <int MODE>
 int launch_wide(const float *x0n, long M, int KP, const float *Wp, int D, const float *bp, int H, void *w_img, float *xout,
                 uint32_t *mask_out, float *rstd_out, const float *xprimal, const uint32_t *mask_in, const float *rstd_in,
                 hipStream_t s, const char *what) {
@@ -583,10 +594,10 @@ int launch_wide(const float *x0n, long M, int KP, const float *Wp, int D, const 
   const long pairs = (n_slabs + 1) / 2, wgs = (pairs + WAVES_PER_WG - 1) / WAVES_PER_WG;
   const int grid = (int)(wgs < 256 ? (wgs < 1 ? 1 : wgs) : 256);
   if (H == 128)
-    hipLaunchKernelGGL((k_fwd_wide<128, TANGENT>), dim3(grid), dim3(WG_THREADS), 0, s, x0n, reinterpret_cast<const u32x4 *>(w_img),
+    hipLaunchKernelGGL((k_fwd_wide<128, MODE>), dim3(grid), dim3(WG_THREADS), 0, s, x0n, reinterpret_cast<const u32x4 *>(w_img),
                        bp, xout, mask_out, rstd_out, xprimal, mask_in, rstd_in, n_slabs, KP);
   else
-    hipLaunchKernelGGL((k_fwd_wide<64, TANGENT>), dim3(grid), dim3(WG_THREADS), 0, s, x0n, reinterpret_cast<const u32x4 *>(w_img),
+    hipLaunchKernelGGL((k_fwd_wide<64, MODE>), dim3(grid), dim3(WG_THREADS), 0, s, x0n, reinterpret_cast<const u32x4 *>(w_img),
                        bp, xout, mask_out, rstd_out, xprimal, mask_in, rstd_in, n_slabs, KP);
   return check_launch(what);
 }
@@ -636,15 +647,21 @@ extern "C" int harl_mlp_x0n_wide(const float *X, long ldx, const int64_t *idx, l
 
 extern "C" int harl_mlp_fwd_wide(const float *x0n, long M, int KP, const float *Wp, int D, const float *bp, int H,
                                  void *w_img, float *xout, uint32_t *relu_mask, float *rstd, void *stream) {
-  return launch_wide<false>(x0n, M, KP, Wp, D, bp, H, w_img, xout, relu_mask, rstd, nullptr, nullptr, nullptr,
-                            (hipStream_t)stream, "harl_mlp_fwd_wide");
+  return launch_wide<0>(x0n, M, KP, Wp, D, bp, H, w_img, xout, relu_mask, rstd, nullptr, nullptr, nullptr,
+                        (hipStream_t)stream, "harl_mlp_fwd_wide");
+}
+
+extern "C" int harl_mlp_linear_wide(const float *x0n, long M, int KP, const float *Wp, int D, const float *bp, int H,
+                                    void *w_img, float *zout, void *stream) {
+  return launch_wide<2>(x0n, M, KP, Wp, D, bp, H, w_img, zout, nullptr, nullptr, nullptr, nullptr, nullptr,
+                        (hipStream_t)stream, "harl_mlp_linear_wide");
 }
 
 extern "C" int harl_mlp_tangent_wide(const float *x0n, long M, int KP, const float *Wdp, int D, const float *bdp, int H,
                                      void *w_img, const float *x1, const uint32_t *mask1, const float *rstd1, float *x1dot,
                                      void *stream) {
-  return launch_wide<true>(x0n, M, KP, Wdp, D, bdp, H, w_img, x1dot, nullptr, nullptr, x1, mask1, rstd1,
-                           (hipStream_t)stream, "harl_mlp_tangent_wide");
+  return launch_wide<1>(x0n, M, KP, Wdp, D, bdp, H, w_img, x1dot, nullptr, nullptr, x1, mask1, rstd1,
+                        (hipStream_t)stream, "harl_mlp_tangent_wide");
 }
 
 extern "C" int harl_mlp_fwd_fused2x(const float *x0n, long M, const float *W1p, int D, const float *b1p, const float *W2p,

@@ -189,9 +189,14 @@ class OnPolicyBase:
 
     def prep_training(self):
         self.actor.train()
+        self.actor.invalidate_caches()
 
     def prep_rollout(self):
+        # phase boundary = cache boundary: the folded weights and the normalised-input image are re-derived on first use of
+        # every rollout / training phase, so a parameter write that torch's version counter cannot see (``p.data.copy_()``,
+        # a raw-pointer kernel, load through DLPack) is picked up at the next prep_rollout() / prep_training() / train()
         self.actor.eval()
+        self.actor.invalidate_caches()
 
 
 class HAPPO(OnPolicyBase):

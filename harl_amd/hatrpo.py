@@ -29,6 +29,8 @@ class HATRPO(OnPolicyBase):
         super().__init__(args, obs_space, act_space, device)
         if getattr(self.actor, "gru_wide", False):
             raise NotImplementedError("HATRPO with a 128-wide GRU: the recurrent tangent kernels are 64 wide")
+        if self.actor.act_id:
+            raise NotImplementedError("HATRPO with an activation other than relu: the forward-mode tangent kernels are ReLU only")
         if self.actor.panel:
             raise NotImplementedError("HATRPO with hidden width 256: the forward-mode tangent kernels are 64/128 wide "
                                       "(no tuned HARL config needs it)")

@@ -23,6 +23,8 @@ from . import _lib
 from ._lib import DHEAD_LD, PS_STRIDE, SLAB, call, ptr, stream
 
 SUPPORTED_WIDTHS = (64, 128, 256)
+# models_tools.py:28-50; ids of csrc/elementwise.hip (0 = the fused ReLU kernels)
+ACT_IDS = {"relu": 0, "leaky_relu": 1, "tanh": 2, "sigmoid": 3, "selu": 4}
 
 
 def _space_shape(space) -> Tuple[int, ...]:
@@ -58,8 +60,15 @@ class _FlatNet(nn.Module):
         self.device_ = device
         self.hidden_sizes = list(args["hidden_sizes"])
         self.use_feature_normalization = bool(args["use_feature_normalization"])
-        if args.get("activation_func", "relu") != "relu":
-            raise NotImplementedError("harl_amd kernels implement relu MLPs only (every tuned HARL config uses relu)")
+        # activation (models_tools.py:28-50).  ReLU runs on the fused kernels (one mask bit per element); leaky_relu / tanh /
+        # sigmoid / selu -- the other functions nn.init.calculate_gain accepts, i.e. the ones the reference's MLPLayer can be
+        # built with (mlp.py:19-23; "hardswish" and "identity" fail there) -- take a composed coverage path: the GEMM kernels in
+        # raw mode + element-wise activation / LayerNorm launches (harl_act_ln_fwd, harl_act_bwd; see forward_trunk)
+        self.activation_func = args.get("activation_func", "relu")
+        if self.activation_func not in ACT_IDS:
+            raise NotImplementedError(f"activation_func {self.activation_func!r}: supported are {sorted(ACT_IDS)} (the functions "
+                                      "torch.nn.init.calculate_gain knows, as in the reference's MLPLayer)")
+        self.act_id = ACT_IDS[self.activation_func]
         self.recurrent = bool(args.get("use_recurrent_policy", False) or args.get("use_naive_recurrent_policy", False))
         self.recurrent_n = int(args.get("recurrent_n", 1))
         # a 128-wide GRU is composed from layer GEMMs + element-wise cell kernels (harl_amd/gru_wide.py; parity-green on
@@ -79,6 +88,8 @@ class _FlatNet(nn.Module):
         self.panel = 256 in self.hidden_sizes
         if self.panel and (any(h != 256 for h in self.hidden_sizes) or self.recurrent or in_dim > 512):
             raise NotImplementedError("hidden width 256: all layers must be 256 wide, feed-forward, inputs <= 512")
+        if self.act_id and (self.recurrent or self.panel or in_dim > 512):
+            raise NotImplementedError("activation functions other than relu: feed-forward MLPs of width 64 / 128 with inputs <= 512")
         self.in_dim = in_dim
         self.wide = 32 < in_dim <= 512  # first layer through the cached x0n image (csrc/wide.hip); <= 32: fused 2-layer kernel
         self._x0n_key = None
@@ -91,7 +102,7 @@ class _FlatNet(nn.Module):
     # global RNG stream (and therefore the initial weights) match for a given seed.
     def _build_trunk_params(self, args: dict) -> None:
         init = getattr(nn.init, args["initialization_method"])
-        gain = nn.init.calculate_gain("relu")
+        gain = nn.init.calculate_gain(self.activation_func)  # mlp.py:21
         d = self.in_dim
         if self.use_feature_normalization:  # MLPBase.feature_norm (mlp.py:57-58)
             self._cpu_params += [("base.feature_norm.weight", torch.ones(d)), ("base.feature_norm.bias", torch.zeros(d))]
@@ -298,8 +309,13 @@ class _FlatNet(nn.Module):
         self.wide = 32 < self.in_dim <= 512
         self._x0n_key = None
         self.x0n = torch.empty(mp * self.kp0, dtype=f32, device=dev) if (self.in_dim <= 64 or self.wide) else None
-        self.w1img = torch.empty(3 * self.hidden_sizes[0] * self.kp0 // 2, dtype=f32, device=dev) if self.wide else None
+        self.w1img = (torch.empty(3 * self.hidden_sizes[0] * self.kp0 // 2, dtype=f32, device=dev)
+                      if (self.wide or self.act_id) else None)
         hmax = max(self.hidden_sizes)
+        if self.act_id:  # composed activation path: raw pre-activations, mean(act(z)) per layer, an all-ones "ReLU mask"
+            self.zraw = torch.empty(mp * hmax, dtype=f32, device=dev)
+            self.amean = [torch.empty(mp, dtype=f32, device=dev) for _ in self.hidden_sizes]
+            self.ones_mask = torch.full((n_slabs * 64 * 2,), -1, dtype=u32, device=dev)
         self.dz = [torch.empty(mp * hmax, dtype=f32, device=dev) for _ in range(2)]            # ping-pong, ATL
         # head gradients for the separate dW pass: row-major [mp][32], or the ATL(64) image of a 33..64-way Categorical head
         self.wide_head = (not self.md) and self._layers()[-1][4] > 32
@@ -339,6 +355,8 @@ class _FlatNet(nn.Module):
     def feat(self):
         if self.recurrent:
             return self.rnn_y, self.rnn_ones, self.rnn_rstd, self.hidden_sizes[-1]
+        if self.act_id:  # the loss kernels then leave the LayerNorm backward WITHOUT an activation derivative (backward_trunk)
+            return self.xh[-1], self.ones_mask, self.rstd[-1], self.hidden_sizes[-1]
         return self.xh[-1], self.rmask[-1], self.rstd[-1], self.hidden_sizes[-1]
 
     def forward_rnn(self, seq: dict, save: bool) -> None:
@@ -387,6 +405,19 @@ class _FlatNet(nn.Module):
         s = stream()
         hs = self.hidden_sizes
         first_hidden = 1
+        if self.act_id:
+            # activation other than ReLU: [Linear (raw GEMM) -> act + LayerNorm (element-wise)] per layer (mlp.py:25-38)
+            self._x0n_image(X, M, s, idx)
+            for l, h in enumerate(hs):
+                Wp, bp = self._packs[l]
+                if l == 0:
+                    call("harl_mlp_linear_wide", ptr(self.x0n), M, self.kp0, ptr(Wp), self.in_dim, ptr(bp), h, ptr(self.w1img),
+                         ptr(self.zraw), s, tag="linear_wide")
+                else:
+                    call("harl_mlp_linear", ptr(self.xh[l - 1]), M, hs[l - 1], h, ptr(Wp), ptr(bp), ptr(self.zraw), s, tag="linear")
+                call("harl_act_ln_fwd", ptr(self.zraw), M, h, self.act_id, ptr(self.xh[l]), ptr(self.amean[l]), ptr(self.rstd[l]),
+                     s, tag="act_ln_fwd")
+            return
         if self.panel:  # width 256: x0n image -> panel GEMMs (csrc/panel.hip)
             self._x0n_image(X, M, s, idx)
             for l in range(len(hs)):
@@ -440,6 +471,8 @@ class _FlatNet(nn.Module):
         only; "0" = never."""
         hs = self.hidden_sizes
         mode = os.environ.get("HARL_FUSED_UPDATE", "logp")
+        if self.act_id:
+            return False
         if mode == "0" or (train and mode == "logp") or (train and mode == "actor" and isinstance(self, VNet)):
             return False
         return (not self.recurrent and not self.md and idx is None and seq is None
@@ -513,6 +546,27 @@ class _FlatNet(nn.Module):
                     call("harl_mlp_panel_bwd", ptr(self.dz[cur]), ptr(self.xh[l - 1]), ptr(self.rmask[l - 1]),
                          ptr(self.rstd[l - 1]), M, 256, 256, ptr(Wp), ptr(self.dz[1 - cur]), s, tag="bwd_panel")
                     cur = 1 - cur
+            call("harl_reduce_partials_multi", ptr(self.part), ptr(self.table), self.n_entries, nwg, self.total_dwp,
+                 ptr(self.dwp), s, tag="reduce_partials")
+            return
+        if self.act_id:
+            # activation other than ReLU: the loss kernel / harl_mlp_bwd_dx were handed an all-ones mask, so self.dz holds the
+            # LayerNorm backward d(loss)/d(act(z)); harl_act_bwd multiplies by act'(z) in place (csrc/elementwise.hip)
+            hs = self.hidden_sizes
+            call("harl_act_bwd", ptr(self.dz[cur]), ptr(self.xh[L - 1]), ptr(self.amean[L - 1]), ptr(self.rstd[L - 1]), M, hs[L - 1],
+                 self.act_id, s, tag="act_bwd")
+            for l in range(L - 1, 0, -1):
+                ho, hi = hs[l], hs[l - 1]
+                call("harl_mlp_dw_partials", ptr(self.dz[cur]), 0, 0, ho, ptr(self.xh[l - 1]), 0, 0, None, None, None, hi, M,
+                     ptr(self.part[po[l]:]), nwg, s, tag="dw_hidden")
+                Wp, _ = self._packs[l]
+                call("harl_mlp_bwd_dx", ptr(self.dz[cur]), ptr(self.xh[l - 1]), ptr(self.ones_mask), ptr(self.rstd[l - 1]), M, ho,
+                     hi, ptr(Wp), ptr(self.dz[1 - cur]), None, 0, None, 0, s, tag="bwd_dx")
+                cur = 1 - cur
+                call("harl_act_bwd", ptr(self.dz[cur]), ptr(self.xh[l - 1]), ptr(self.amean[l - 1]), ptr(self.rstd[l - 1]), M, hi,
+                     self.act_id, s, tag="act_bwd")
+            call("harl_mlp_dw_partials", ptr(self.dz[cur]), 0, 0, hs[0], ptr(self.x0n), 0, 0, None, None, None, self.kp0, M,
+                 ptr(self.part[po[0]:]), nwg, s, tag="dw_input")
             call("harl_reduce_partials_multi", ptr(self.part), ptr(self.table), self.n_entries, nwg, self.total_dwp,
                  ptr(self.dwp), s, tag="reduce_partials")
             return
@@ -643,6 +697,8 @@ class StochasticPolicy(_FlatNet):
             raise NotImplementedError("MultiDiscrete heads on 256-wide layers")
         if len(nvec) > 8 or max(nvec) > 128:
             raise NotImplementedError("MultiDiscrete: at most 8 heads of at most 128 actions each")
+        if self.act_id:
+            raise NotImplementedError("MultiDiscrete heads with an activation other than relu are not implemented")
         self.md, self.discrete = True, True
         self.nvec, self.n_heads = nvec, len(nvec)
         self.act_dim = sum(nvec)   # width of the concatenated normalised logits (head_out)
@@ -718,7 +774,7 @@ def consume_policy_init_rng(args: dict, obs_space, action_space) -> None:
     from .buffers import rng_sync
     rng_sync()
     init = getattr(nn.init, args["initialization_method"])
-    gain = nn.init.calculate_gain("relu")
+    gain = nn.init.calculate_gain(args.get("activation_func", "relu"))
 
     def draw(lin, g):
         if args["initialization_method"] == "orthogonal_":

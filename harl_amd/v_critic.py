@@ -194,6 +194,11 @@ class VCritic:
 
     def prep_training(self):
         self.critic.train()
+        self.critic.invalidate_caches()
 
     def prep_rollout(self):
+        # phase boundary = cache boundary: the folded weights and the normalised-input image are re-derived on first use of
+        # every rollout / training phase, so a parameter write that torch's version counter cannot see (``p.data.copy_()``,
+        # a raw-pointer kernel, load through DLPack) is picked up at the next prep_rollout() / prep_training() / train()
         self.critic.eval()
+        self.critic.invalidate_caches()

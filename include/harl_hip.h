@@ -273,6 +273,16 @@ int harl_fold_linear_tangent(const float *W, const float *gamma, const float *be
 int harl_mlp_tangent_input(const float *X, long ldx, const int64_t *idx, long M, int D, const float *Wdp,
                            const float *bdp, int use_ln0, int H, const float *x1, const uint32_t *mask1,
                            const float *rstd1, float *x1dot, void *stream);
+/* z = W' x0n + b' as an ATL(H) image, no epilogue (the first Linear of an MLP whose activation is not ReLU, mlp.py:25-30);
+ * arguments as harl_mlp_fwd_wide. */
+int harl_mlp_linear_wide(const float *x0n, long M, int KP, const float *Wp, int D, const float *bp, int H, void *w_img,
+                         float *zout, void *stream);
+/* Activation functions other than ReLU (models_tools.py:28-50; act: 1 leaky_relu, 2 tanh, 3 sigmoid, 4 selu), element-wise
+ * over ATL(H) images, H = 64 / 128.  harl_act_ln_fwd: x_hat = LayerNorm(act(z)) with mean(act(z)) and rstd per sample
+ * (mlp.py:25-38).  harl_act_bwd: dz <- dz * act'(z) in place, act' from the activation value x_hat / rstd + mean; dz holds
+ * the LayerNorm backward as harl_mlp_bwd_dx / the loss kernels leave it when they are given an all-ones ReLU mask. */
+int harl_act_ln_fwd(const float *z, long M, int H, int act, float *xhat, float *mean, float *rstd, void *stream);
+int harl_act_bwd(float *dz, const float *xhat, const float *mean, const float *rstd, long M, int H, int act, void *stream);
 /* the same for wide inputs, from the x0n image of harl_mlp_x0n_wide (w_img: scratch as in harl_mlp_fwd_wide) */
 int harl_mlp_tangent_wide(const float *x0n, long M, int KP, const float *Wdp, int D, const float *bdp, int H, void *w_img,
                           const float *x1, const uint32_t *mask1, const float *rstd1, float *x1dot, void *stream);

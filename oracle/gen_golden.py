@@ -173,6 +173,23 @@ CASES = {
                                    overrides=dict(use_recurrent_policy=True, data_chunk_length=5)),
     "disc50_h128": dict(shapes=dict(T=12, N=8, A=2, obs_dim=20, share_obs_dim=24, act_dim=50, discrete=True,
                                     hidden_sizes=[128, 128]), seed=53, unavailable_p=0.3, overrides=dict(ppo_epoch=2, critic_epoch=2)),
+    # ---- activation functions other than ReLU (models_tools.py:28-50; the ones nn.init.calculate_gain accepts, mlp.py:21)
+    "mpe_box_h128_tanh": dict(shapes=dict(T=10, N=16, A=3, obs_dim=18, share_obs_dim=54, act_dim=5, discrete=False,
+                                          hidden_sizes=[128, 128]), seed=91, overrides=dict(activation_func="tanh")),
+    "disc_h64_selu_mb2": dict(shapes=dict(T=12, N=8, A=2, obs_dim=18, share_obs_dim=30, act_dim=6, discrete=True,
+                                          hidden_sizes=[64, 64]), seed=92, unavailable_p=0.2, inactive_p=0.1,
+                              overrides=dict(activation_func="selu", actor_num_mini_batch=2, critic_num_mini_batch=2,
+                                             ppo_epoch=3, critic_epoch=3)),
+    "wide_fp_box_h128_64_leaky": dict(state_type="FP", shapes=dict(T=8, N=8, A=2, obs_dim=77, share_obs_dim=70, act_dim=3,
+                                                                    discrete=False, hidden_sizes=[128, 64]), seed=93,
+                                      overrides=dict(activation_func="leaky_relu", ppo_epoch=3, critic_epoch=3)),
+    "a2c_box_h64x3_sigmoid": dict(algo="haa2c", shapes=dict(T=10, N=8, A=2, obs_dim=13, share_obs_dim=9, act_dim=2,
+                                                           discrete=False, hidden_sizes=[64, 64, 64]), seed=94,
+                                  overrides=dict(activation_func="sigmoid")),
+    "mappo_shared_disc_h128_tanh": dict(algo="mappo", shapes=dict(T=8, N=8, A=3, obs_dim=16, share_obs_dim=24, act_dim=5,
+                                                                  discrete=True, hidden_sizes=[128, 128]), seed=95,
+                                        overrides=dict(share_param=True, activation_func="tanh", ppo_epoch=3),
+                                        unavailable_p=0.2, inactive_p=0.15),
     # ---- hidden width 256 (the reference's dexhands HAPPO configurations: [256, 256, 256], wide observations, Box actions)
     "hands_h256x3": dict(shapes=dict(T=10, N=8, A=2, obs_dim=211, share_obs_dim=200, act_dim=20, discrete=False,
                                      hidden_sizes=[256, 256, 256]), seed=61, overrides=dict(ppo_epoch=2, critic_epoch=2)),

@@ -27,7 +27,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 from oracle import harl_oracle as O  # noqa: E402
-from tests.helpers import (ALL_CASES, GOLDEN_DIR, MAPPO_CASES, MD_CASES, RNN128_CASES, RNN_CASES, TRPO_CASES, TRPO_RNN_CASES,  # noqa: E402
+from tests.helpers import (ACT_CASES, ALL_CASES, GOLDEN_DIR, MAPPO_CASES, MD_CASES, RNN128_CASES, RNN_CASES, TRPO_CASES, TRPO_RNN_CASES,  # noqa: E402
                            GoldenCase)
 from tests.test_oracle_golden import build_oracle  # noqa: E402
 
@@ -129,7 +129,7 @@ N_PERT = 32
 
 def main():
     os.makedirs(os.path.join(GOLDEN_DIR, "noise"), exist_ok=True)
-    names = sys.argv[1:] or (ALL_CASES + TRPO_CASES + TRPO_RNN_CASES + RNN_CASES + MAPPO_CASES + MD_CASES + RNN128_CASES)
+    names = sys.argv[1:] or (ALL_CASES + TRPO_CASES + TRPO_RNN_CASES + RNN_CASES + MAPPO_CASES + MD_CASES + RNN128_CASES + ACT_CASES)
     for name in names:
         res = run_case(name)
         z = np.load(os.path.join(GOLDEN_DIR, f"{name}.npz"))

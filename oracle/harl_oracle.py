@@ -85,6 +85,7 @@ class PathConfig:
     use_naive_recurrent_policy: bool = False
     data_chunk_length: int = 10
     recurrent_n: int = 1
+    activation_func: str = "relu"
 
     @property
     def recurrent(self) -> bool:
@@ -94,7 +95,9 @@ class PathConfig:
     def from_reference_dicts(train: dict, model: dict, algo: dict) -> "PathConfig":
         merged = {**train, **model, **algo}
         kw = {k: merged[k] for k in PathConfig.__dataclass_fields__ if k in merged}
-        return PathConfig(**kw)
+        cfg = PathConfig(**kw)
+        set_activation(cfg.activation_func)  # the functional network code below reads it (one configuration at a time)
+        return cfg
 
 
 # --------------------------------------------------------------------------------------
@@ -248,8 +251,19 @@ def _linear_keys(sd_keys: Sequence[str]) -> List[int]:
     return idx
 
 
+ACTIVATION = "relu"
+_ACT_FN = {"relu": F.relu, "leaky_relu": F.leaky_relu, "tanh": torch.tanh, "sigmoid": torch.sigmoid, "selu": F.selu}
+
+
+def set_activation(name: str) -> None:
+    """activation_func of the MLP layers (models_tools.py:28-50: get_active_func; defaults as torch.nn's modules)."""
+    global ACTIVATION
+    assert name in _ACT_FN, name
+    ACTIVATION = name
+
+
 def mlp_base_forward(p: Dict[str, torch.Tensor], x: torch.Tensor) -> torch.Tensor:
-    """MLPBase: [LayerNorm(obs)] -> (Linear, ReLU, LayerNorm) x k   (mlp.py:25-38,64-70)."""
+    """MLPBase: [LayerNorm(obs)] -> (Linear, activation, LayerNorm) x k   (mlp.py:25-38,64-70)."""
     if "base.feature_norm.weight" in p:
         x = F.layer_norm(x, (x.shape[-1],), p["base.feature_norm.weight"], p["base.feature_norm.bias"], 1e-5)
     idx = _linear_keys(list(p.keys()))
@@ -257,7 +271,7 @@ def mlp_base_forward(p: Dict[str, torch.Tensor], x: torch.Tensor) -> torch.Tenso
     lin = [i for i in idx if i % 3 == 0]
     for i in lin:
         x = F.linear(x, p[f"base.mlp.fc.{i}.weight"], p[f"base.mlp.fc.{i}.bias"])
-        x = F.relu(x)
+        x = _ACT_FN[ACTIVATION](x)
         x = F.layer_norm(x, (x.shape[-1],), p[f"base.mlp.fc.{i+2}.weight"], p[f"base.mlp.fc.{i+2}.bias"], 1e-5)
     return x
 

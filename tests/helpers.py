@@ -20,6 +20,10 @@ TRPO_CASES = ["trpo_box_h64", "trpo_disc_h64", "trpo_wide_h128x3"]
 TRPO_RNN_CASES = ["trpo_rnn_disc_h64", "trpo_rnn_box_h64", "trpo_rnn_fp_disc36_h64"]
 RNN_CASES = ["rnn_box_h64", "rnn_disc_h64_mb2", "rnn_naive_h64", "rnn_fp_box_h64_mb2", "rnn_naive_fp_disc_h64",
              "rnn_fp_disc36_h64"]
+# activation functions other than ReLU (tanh, selu with mini-batches, leaky_relu on wide inputs + FP state, sigmoid under HAA2C,
+# tanh under MAPPO with shared parameters): the composed path of nets.forward_trunk / backward_trunk
+ACT_CASES = ["mpe_box_h128_tanh", "disc_h64_selu_mb2", "wide_fp_box_h128_64_leaky", "a2c_box_h64x3_sigmoid",
+             "mappo_shared_disc_h128_tanh"]
 # GRU on 128-wide layers (harl_amd/gru_wide.py: per-step composition of layer GEMMs + cell kernels)
 RNN128_CASES = ["rnn_box_h128", "rnn_disc_h128_mb2"]
 MAPPO_CASES = ["mappo_box_h64", "mappo_shared_disc_h64_mb2", "mappo_shared_fp_box_h128"]

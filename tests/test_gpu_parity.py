@@ -147,6 +147,26 @@ def test_gru128_train_matches_reference_golden(name, monkeypatch):
     _assert_all(_G().check_train_golden(name), tol=TOL)
 
 
+@pytest.mark.parametrize("name", ["mpe_box_h128_tanh", "disc_h64_selu_mb2", "wide_fp_box_h128_64_leaky", "a2c_box_h64x3_sigmoid",
+                                  "mappo_shared_disc_h128_tanh"])
+def test_activation_train_matches_reference_golden(name):
+    """activation_func other than relu (models_tools.py:28-50): whole train() against fixtures recorded from the reference --
+    tanh, selu with mini-batches and unavailable actions, leaky_relu on 77-wide inputs with the FP critic and mixed widths,
+    sigmoid under HAA2C on three layers, tanh under MAPPO with shared parameters."""
+    _assert_all(_G().check_train_golden(name), tol=TOL)
+
+
+@pytest.mark.parametrize("act", ["tanh", "sigmoid", "leaky_relu", "selu"])
+@pytest.mark.parametrize("i", [0, 4])
+def test_activation_forward_and_single_update(act, i):
+    """Every supported activation on the MPE shape and on the 393-wide three-layer shape: log-probs / values, then ONE
+    HAPPO.update + VCritic.update (gradient vectors, loss scalars, post-Adam parameters) vs the oracle."""
+    G = _G()
+    spec = dict(G.FWD_SHAPES[i], over=dict(activation_func=act))
+    _assert_all(G.check_forward(spec), tol=TOL)
+    _assert_all(G.check_gradients(spec), tol=TOL)
+
+
 @pytest.mark.parametrize("discrete,recurrent", [(False, False), (True, False), (False, True)])
 def test_rollout_loop_learns_on_toy_env(discrete, recurrent):
     """run(): device-side collect/insert around a host environment, then the update; rewards must improve."""

@@ -10,7 +10,7 @@ import pytest
 import torch
 
 from oracle import harl_oracle as O
-from tests.helpers import (ALL_CASES, GOLDEN_DIR, MAPPO_CASES, MD_CASES, RNN128_CASES, RNN_CASES, TRPO_CASES, TRPO_RNN_CASES, GoldenCase, rel_err,
+from tests.helpers import (ACT_CASES, ALL_CASES, GOLDEN_DIR, MAPPO_CASES, MD_CASES, RNN128_CASES, RNN_CASES, TRPO_CASES, TRPO_RNN_CASES, GoldenCase, rel_err,
                            vec_rel_err)
 
 
@@ -53,7 +53,7 @@ def build_oracle(case: GoldenCase):
     return cfg, actors, critic, abufs, cbuf, vn
 
 
-@pytest.mark.parametrize("name", ALL_CASES + TRPO_CASES + TRPO_RNN_CASES + RNN_CASES + MAPPO_CASES + MD_CASES + RNN128_CASES)
+@pytest.mark.parametrize("name", ALL_CASES + TRPO_CASES + TRPO_RNN_CASES + RNN_CASES + MAPPO_CASES + MD_CASES + RNN128_CASES + ACT_CASES)
 def test_oracle_matches_reference_golden(name):
     case = GoldenCase(name)
     z = case.z

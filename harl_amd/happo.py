@@ -326,14 +326,14 @@ class HAPPO(OnPolicyBase):
             self._update_core(obs.reshape(m, -1), idx, seq["L"] * seq["m_pad"], _as_dev(actions, dev).reshape(m, -1),
                               None if avail is None else _as_dev(avail, dev).reshape(m, -1),
                               _as_dev(old_logp, dev).reshape(m, -1), _as_dev(adv, dev).reshape(m), None,
-                              _as_dev(factor, dev).reshape(m),
+                              None if factor is None else _as_dev(factor, dev).reshape(m),
                               _as_dev(active, dev).reshape(m) if self.use_policy_active_masks else None, seq=seq)
             d = self._info - before
             return d[0], d[1], d[2], d[3]
         self._update_core(obs.reshape(m, -1), None, m, _as_dev(actions, dev).reshape(m, -1),
                           None if avail is None else _as_dev(avail, dev).reshape(m, -1),
                           _as_dev(old_logp, dev).reshape(m, -1), _as_dev(adv, dev).reshape(m), None,
-                          _as_dev(factor, dev).reshape(m),
+                          None if factor is None else _as_dev(factor, dev).reshape(m),
                           _as_dev(active, dev).reshape(m) if self.use_policy_active_masks else None)
         d = self._info - before
         return d[0], d[1], d[2], d[3]

@@ -31,14 +31,14 @@ class MAPPO(HAPPO):
         """ppo_epoch x actor_num_mini_batch updates of the ONE shared actor on all agents' data (mappo.py:149-234).
         EP: advantages [T, N, 1] are normalised with ONE mean/std over every agent's active entries (:165-183), passed to
         the loss kernel as the summed fp64 moments; FP: per-agent slices of the runner-normalised [T, N, A, 1] tensor."""
-        if self.use_recurrent_policy or self.use_naive_recurrent_policy:
-            raise NotImplementedError("share_param with recurrent policies")
         dev, net = self.device, self.actor
         net.invalidate_caches()
         A = num_agents
         T, N = actor_buffer[0].actions.shape[:2]
         B = T * N
         adv = _as_dev(advantages, dev)
+        if self.use_recurrent_policy or self.use_naive_recurrent_policy:
+            return self._share_param_train_recurrent(actor_buffer, adv, A, state_type, _moments, _defer)
         moments = None
         if state_type == "EP":
             adv_a = [adv.reshape(B).contiguous()] * A
@@ -99,6 +99,45 @@ class MAPPO(HAPPO):
                 self._md_ent_override = None
                 net.dwp.copy_(acc)
                 self._optimizer_step(None)
+        n_upd = self.ppo_epoch * k
+        if _defer:
+            return self._info / n_upd
+        rng_sync()
+        vals = (self._info / n_upd).cpu().tolist()
+        return dict(zip(self._INFO_KEYS, vals))
+
+    def _share_param_train_recurrent(self, actor_buffer, adv, A: int, state_type: str, _moments, _defer: bool):
+        """Parameter sharing with GRU policies (mappo.py:185-234).  The reference concatenates the agents' recurrent samples
+        along axis 0 -- [agent 0: L*m rows | agent 1: L*m rows | ...] next to rnn_states [A*m] -- and RNNLayer.forward then
+        reads that array as (T = L, N = A*m) (rnn.py:40-44: x.view(T, N, -1)), i.e. row l*(A*m) + j is "time l of sequence j":
+        the rows of one agent land in ONE time step.  That is what the golden vectors record, so it is what runs here: the
+        gathered samples of the buffers' generator API (same draws, in agent order, on first use of every generator) are
+        concatenated and go through the gathered-sample update (HAPPO.update -> nets.build_seq with L and A*m)."""
+        if self.shard:
+            raise NotImplementedError("share_param with recurrent policies under data parallelism")
+        dev = self.device
+        T, N = actor_buffer[0].actions.shape[:2]
+        B = T * N
+        if state_type == "EP":  # ONE mean / std over every agent's active entries (mappo.py:165-183)
+            if _moments is None:
+                mom = torch.zeros(A, 3, dtype=torch.float64, device=dev)
+                for a in range(A):
+                    self.masked_moments(actor_buffer[a], adv.reshape(B).contiguous(), mom[a])
+                _moments = mom.sum(0)
+            normed = torch.empty(B, dtype=torch.float32, device=dev)
+            call("harl_adv_normalize", ptr(adv.reshape(B).contiguous()), ptr(_moments.contiguous()), ptr(normed), B, stream())
+            adv_a = [normed.reshape(T, N, 1)] * A
+        else:
+            adv_a = [adv[:, :, a].contiguous() for a in range(A)]
+        self._info.zero_()
+        k = self.actor_num_mini_batch
+        for _ in range(self.ppo_epoch):
+            gens = [(actor_buffer[a].recurrent_generator_actor(adv_a[a], k, self.data_chunk_length) if self.use_recurrent_policy
+                     else actor_buffer[a].naive_recurrent_generator_actor(adv_a[a], k)) for a in range(A)]
+            for _b in range(k):
+                samples = [next(g) for g in gens]
+                batch = tuple(None if samples[0][i] is None else torch.cat([smp[i] for smp in samples], dim=0) for i in range(8))
+                self.update(batch)  # accumulates into self._info
         n_upd = self.ppo_epoch * k
         if _defer:
             return self._info / n_upd

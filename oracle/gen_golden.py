@@ -155,6 +155,18 @@ CASES = {
     "mappo_shared_fp_box_h128": dict(algo="mappo", state_type="FP",
                                      shapes=dict(T=8, N=6, A=2, obs_dim=10, share_obs_dim=14, act_dim=3, discrete=False,
                                                  hidden_sizes=[128, 128]), seed=23, overrides=dict(share_param=True)),
+    # ---- parameter sharing with GRU policies (mappo.py:185-234: the agents' recurrent samples concatenated on axis 0)
+    "mappo_shared_rnn_disc_h64_mb2": dict(algo="mappo", shapes=dict(T=20, N=6, A=3, obs_dim=17, share_obs_dim=23, act_dim=6,
+                                                                    discrete=True, hidden_sizes=[64, 64]), seed=96,
+                                          unavailable_p=0.2, inactive_p=0.1,
+                                          overrides=dict(share_param=True, use_recurrent_policy=True, data_chunk_length=5,
+                                                         actor_num_mini_batch=2, critic_num_mini_batch=2, ppo_epoch=3,
+                                                         critic_epoch=3)),
+    "mappo_shared_rnn_naive_fp_box_h128": dict(algo="mappo", state_type="FP",
+                                               shapes=dict(T=10, N=6, A=2, obs_dim=11, share_obs_dim=15, act_dim=2,
+                                                           discrete=False, hidden_sizes=[128, 128]), seed=97, inactive_p=0.1,
+                                               overrides=dict(share_param=True, use_naive_recurrent_policy=True, ppo_epoch=2,
+                                                              critic_epoch=2)),
     # ---- HATRPO with GRU policies (tuned SMAC / SMACv2 configs): one sample of all chunks, FVP through the recurrence
     "trpo_rnn_disc_h64": dict(algo="hatrpo", shapes=dict(T=10, N=8, A=2, obs_dim=14, share_obs_dim=12, act_dim=5, discrete=True,
                                                          hidden_sizes=[64]), seed=41, unavailable_p=0.2, inactive_p=0.1,

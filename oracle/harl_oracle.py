@@ -514,8 +514,9 @@ class OracleMAPPO(OracleHAPPO):
                     gens.append(bufs[a].feed_forward_generator(adv_list[a], cfg.actor_num_mini_batch))
             for _mb in range(cfg.actor_num_mini_batch):
                 parts = [next(g)[0] for g in gens]
-                if len(parts[0]) > 7:  # recurrent rows are [L*m, .] l-major per agent; the reference concatenates agents on
-                    raise NotImplementedError("share_param with recurrent policies is not restated")  # axis 0 (mixes l and agent)
+                # (recurrent samples: rows are [L*m, .] l-major per agent and the reference concatenates the AGENTS on axis 0, next
+                # to rnn_states [A*m]; RNNLayer.forward reads the result as (T = L, N = A*m), rnn.py:40-44 -- rnn_layer_forward
+                # does the same view, so the concatenation reproduces it)
                 cat = [None if parts[0][i] is None else np.concatenate([p[i] for p in parts], axis=0)
                        for i in range(len(parts[0]))]
                 pl, ent, gn, imp, g = self.update(tuple(cat))

@@ -26,7 +26,9 @@ ACT_CASES = ["mpe_box_h128_tanh", "disc_h64_selu_mb2", "wide_fp_box_h128_64_leak
              "mappo_shared_disc_h128_tanh"]
 # GRU on 128-wide layers (harl_amd/gru_wide.py: per-step composition of layer GEMMs + cell kernels)
 RNN128_CASES = ["rnn_box_h128", "rnn_disc_h128_mb2"]
-MAPPO_CASES = ["mappo_box_h64", "mappo_shared_disc_h64_mb2", "mappo_shared_fp_box_h128"]
+MAPPO_CASES = ["mappo_box_h64", "mappo_shared_disc_h64_mb2", "mappo_shared_fp_box_h128",
+               # shared parameters with GRU policies (chunked sampler, mini-batches; naive sampler on a 128-wide GRU with the FP critic)
+               "mappo_shared_rnn_disc_h64_mb2", "mappo_shared_rnn_naive_fp_box_h128"]
 # MultiDiscrete action spaces (act.py:35-43,117-141): MLP with mini-batches, the LAG layout [41, 41, 41, 30] (two logits
 # images), GRU policy, MAPPO (shared parameters) with `mean` aggregation, HAA2C on a mixed-width trunk
 MD_CASES = ["md_h64_mb2", "md_lag_h128", "md_rnn_h64", "md_mappo_mean_h64", "md_a2c_h128_64"]

@@ -197,7 +197,8 @@ def test_multidiscrete_rollout_and_evaluate(nvec, hidden):
             assert v < TOL, (k, v)
 
 
-@pytest.mark.parametrize("name", ["mappo_box_h64", "mappo_shared_disc_h64_mb2", "mappo_shared_fp_box_h128"])
+@pytest.mark.parametrize("name", ["mappo_box_h64", "mappo_shared_disc_h64_mb2", "mappo_shared_fp_box_h128",
+                                  "mappo_shared_rnn_disc_h64_mb2", "mappo_shared_rnn_naive_fp_box_h128"])
 def test_mappo_train_matches_reference_golden(name):
     """MAPPO through the same kernels (factor = NULL); parameter sharing accumulates every agent's segment before one
     optimiser step; OnPolicyMARunner.train() vs the reference (incl. its stray randperm(num_agents) draw)."""

@@ -68,6 +68,14 @@ __device__ __forceinline__ constexpr int feat_base(int R) {  // f(R, 0)
   return 32 * (R >> 4) + (R & 3) + 8 * ((R & 15) >> 2);
 }
 
+// The wave's index in its workgroup.  It is uniform across the wave, which the compiler cannot see through threadIdx.x >> 6:
+// readfirstlane tells it, and the slab counters, loop bounds and every address derived from them move to scalar registers
+// and the scalar ALU (fewer vector registers, fewer VALU slots in the slab loops).
+__device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+// a value that is the same in every lane of the wave, moved to a scalar register
+__device__ __forceinline__ float uniform_f(float v) {
+  return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v)));
+}
 __device__ __forceinline__ float wave_xor32(float v) {  // exchange with the partner half (lane ^ 32)
   return __shfl_xor(v, 32, 64);
 }

@@ -105,7 +105,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_gru_gates_x(const float *__re
   stage_matrix<3 * GH, GH, LDW, WG_THREADS>(Wil, Wih);
   for (int e = threadIdx.x; e < 3 * GH; e += WG_THREADS) bl[e] = bih[e] + (e < 2 * GH ? bhh[e] : 0.f);
   __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = wave_id();
   const int i = lane & 31, h = lane >> 5;
   const float *wi_lane = Wil + i * LDW + 4 * h;
   for (long slab = (long)blockIdx.x * WAVES_PER_WG + wave; slab < n_slabs; slab += (long)gridDim.x * WAVES_PER_WG) {
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_gru_fwd(
     bhl[e] = bhh[e];
   }
   __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = wave_id();
   const int i = lane & 31, h = lane >> 5;
   const long groups = m_pad / SLAB;
   const float *wi_lane = Wil + i * LDW + 4 * h;
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_gru_fwd_tp(
   stage_split_matrix<3 * GH, GH, false, WG_THREADS>(Whimg, Whh);
   for (int e = threadIdx.x; e < GH; e += WG_THREADS) bhl[e] = bhh[2 * GH + e];
   __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, pair = wave >> 1, w = wave & 1;
+  const int lane = threadIdx.x & 63, wave = wave_id(), pair = wave >> 1, w = wave & 1;
   const int i = lane & 31, h = lane >> 5;
   const long groups = m_pad / SLAB;
   const u32x4 *wl = Whimg + lane;
@@ -457,7 +457,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_gru_bwd(
   u32x4 *img = reinterpret_cast<u32x4 *>(lds);
   stage_split_matrix<3 * GH, GH, true, WG_THREADS>(img, Whh);
   __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = wave_id();
   const int i = lane & 31;
   const long groups = m_pad / SLAB;
   const u32x4 *wl = img + lane;
@@ -541,7 +541,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_gru_dx(const float *__restric
   u32x4 *img = reinterpret_cast<u32x4 *>(lds);
   stage_split_matrix<3 * GH, GH, true, WG_THREADS>(img, Wih);
   __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = wave_id();
   const int i = lane & 31;
   const u32x4 *wl = img + lane;
   for (long slab = (long)blockIdx.x * WAVES_PER_WG + wave; slab < n_slabs; slab += (long)gridDim.x * WAVES_PER_WG) {
@@ -601,7 +601,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_gru_gates_lin(const float *__
   float *Wl = lds;  // [192][65]
   stage_matrix<3 * GH, GH, LDW, WG_THREADS>(Wl, W);
   __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = wave_id();
   const int i = lane & 31, h = lane >> 5;
   const float *w_lane = Wl + i * LDW + 4 * h;
   for (long slab = (long)blockIdx.x * WAVES_PER_WG + wave; slab < n_slabs; slab += (long)gridDim.x * WAVES_PER_WG) {
@@ -642,7 +642,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_gru_tangent(
   for (int e = threadIdx.x; e < 3 * GH; e += WG_THREADS) bl[e] = bihd[e] + (e < 2 * GH ? bhhd[e] : 0.f);
   for (int e = threadIdx.x; e < GH; e += WG_THREADS) bl[3 * GH + e] = bhhd[2 * GH + e];
   __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, i = lane & 31;
+  const int lane = threadIdx.x & 63, wave = wave_id(), h = lane >> 5, i = lane & 31;
   const long groups = m_pad / SLAB;
   const u32x4 *wh_img = Whimg + lane;
   for (long G = (long)blockIdx.x * WAVES_PER_WG + wave; G < groups; G += (long)gridDim.x * WAVES_PER_WG) {

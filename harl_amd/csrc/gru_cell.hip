@@ -26,7 +26,7 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf
 template <int H>
 __global__ __launch_bounds__(WG_THREADS) void k_gru_init(const float *__restrict__ h0, const float *__restrict__ mask_rows,
                                                          float *__restrict__ hpm0, long n_slabs) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, h = lane >> 5;
+  const int lane = threadIdx.x & 63, wave = wave_id(), i = lane & 31, h = lane >> 5;
   for (long slab = (long)blockIdx.x * WAVES_PER_WG + wave; slab < n_slabs; slab += (long)gridDim.x * WAVES_PER_WG) {
     const long row = slab * SLAB + i;
     const float mk = mask_rows[row];
@@ -44,7 +44,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_gru_cell_fwd(
     const float *__restrict__ hpm, const float *__restrict__ mask_next, float *__restrict__ r_out, float *__restrict__ z_out,
     float *__restrict__ n_out, float *__restrict__ hn_out, float *__restrict__ h_out, float *__restrict__ hpm_next,
     float *__restrict__ h_last, long n_slabs) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, h = lane >> 5;
+  const int lane = threadIdx.x & 63, wave = wave_id(), i = lane & 31, h = lane >> 5;
   for (long slab = (long)blockIdx.x * WAVES_PER_WG + wave; slab < n_slabs; slab += (long)gridDim.x * WAVES_PER_WG) {
     float a[H / 2], b[H / 2], rr[H / 2], zz[H / 2], nn[H / 2], hp[H / 2], hn[H / 2];
     atl_load<H>(gi_r, slab, lane, a);
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_gru_cell_bwd(
     const float *__restrict__ z_s, const float *__restrict__ n_s, const float *__restrict__ hn_s,
     const float *__restrict__ hpm, float *__restrict__ gz, float *__restrict__ dr, float *__restrict__ dz,
     float *__restrict__ dn, float *__restrict__ dhn, int has_next, long n_slabs) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31;
+  const int lane = threadIdx.x & 63, wave = wave_id(), i = lane & 31;
   for (long slab = (long)blockIdx.x * WAVES_PER_WG + wave; slab < n_slabs; slab += (long)gridDim.x * WAVES_PER_WG) {
     float G[H / 2], a[H / 2], b[H / 2];
     atl_load<H>(dh_out, slab, lane, G);
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_gru_cell_bwd(
 template <int H>
 __global__ __launch_bounds__(WG_THREADS) void k_rownorm(const float *__restrict__ x, float *__restrict__ y,
                                                         float *__restrict__ rstd_out, long n_slabs) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = wave_id();
   for (long slab = (long)blockIdx.x * WAVES_PER_WG + wave; slab < n_slabs; slab += (long)gridDim.x * WAVES_PER_WG) {
     float v[H / 2];
     atl_load<H>(x, slab, lane, v);

@@ -65,7 +65,7 @@ __global__ __launch_bounds__(WG_THREADS, (FUSE && DAP <= 8) ? 2 : 1) void k_acto
   }
   __syncthreads();
 
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = wave_id();
   const int i = lane & 31, h = lane >> 5;
   const float *whl_h = whl + h * (H / 2) * DAP;
   const int D = A.act_dim;
@@ -86,8 +86,8 @@ __global__ __launch_bounds__(WG_THREADS, (FUSE && DAP <= 8) ? 2 : 1) void k_acto
   for (int k = 0; k < 8 + DAP; ++k) sc[k] = 0.f;
   f32x16 dwacc[(FUSE && !LDSACC) ? H / 32 : 1];
   float dbacc[FUSE ? DAP : 1];
-  float *tx = dwl + (threadIdx.x >> 6) * HeadDw<H>::WAVE_FLOATS, *td = tx + SLAB * HeadDw<H>::HX;
-  float *hw = hacc + (threadIdx.x >> 6) * (HROWS * H);
+  float *tx = dwl + wave_id() * HeadDw<H>::WAVE_FLOATS, *td = tx + SLAB * HeadDw<H>::HX;
+  float *hw = hacc + wave_id() * (HROWS * H);
   if (FUSE) {
     if constexpr (!LDSACC) {
 #pragma unroll
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(WG_THREADS, FUSE ? 2 : 1) void k_critic_head(Critic
   }
   stage_head<H, DAP>(whl, cst, A.Whp, A.bhp, 1);
   __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = wave_id();
   const int i = lane & 31, h = lane >> 5;
   const float *whl_h = whl + h * (H / 2) * DAP;
 
@@ -235,8 +235,8 @@ __global__ __launch_bounds__(WG_THREADS, FUSE ? 2 : 1) void k_critic_head(Critic
 #pragma unroll
   for (int k = 0; k < 8; ++k) sc[k] = 0.f;
   float dbacc[FUSE ? DAP : 1];
-  float *tx = dwl + (threadIdx.x >> 6) * HeadDw<H>::WAVE_FLOATS, *td = tx + SLAB * HeadDw<H>::HX;
-  float *hw = hacc + (threadIdx.x >> 6) * (HROWS * H);
+  float *tx = dwl + wave_id() * HeadDw<H>::WAVE_FLOATS, *td = tx + SLAB * HeadDw<H>::HX;
+  float *hw = hacc + wave_id() * (HROWS * H);
   if (FUSE) {
 #pragma unroll
     for (int d = 0; d < DAP; ++d) dbacc[d] = 0.f;
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_actor_head_fvp(FvpArgs A) {
     }
   }
   __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = wave_id();
   const int i = lane & 31, h = lane >> 5;
   const float *whl_h = whl + h * (H / 2) * DAP;
   const float *wdl_h = wdl + h * (H / 2) * DAP;

@@ -182,7 +182,10 @@ __device__ __forceinline__ void head_bwd_regs_bits(const f32x4 (&xs)[H / 8], uin
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 #pragma unroll
   for (int st = 0; st < DAP / 2; ++st) {
-    const float bsel = h ? dzh[2 * st + 1] : dzh[2 * st];
+    // (bit select: written as `h ? dzh[2 st + 1] : dzh[2 st]` the compiler turned the pair into a two-entry SCRATCH array
+    // indexed by h when both entries were cheap to materialise -- the critic's {dv, 0} -- one scratch round trip per slab)
+    const unsigned hm = 0u - (unsigned)h;
+    const float bsel = __uint_as_float((__float_as_uint(dzh[2 * st + 1]) & hm) | (__float_as_uint(dzh[2 * st]) & ~hm));
 #pragma unroll
     for (int t = 0; t < H / 32; ++t)
       acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[16 * t * DAP + 2 * st], bsel, acc[t], 0, 0, 0);
@@ -267,8 +270,9 @@ template <int H, int DAP, int HROWS>
 __device__ __forceinline__ void head_dw_step_lds(const f32x4 (&xs)[H / 8], const float (&dzh)[DAP], float *tx, float *td,
                                                  int lane, float *hw) {
   constexpr int HX = HeadDw<H>::HX, TD = HeadDw<H>::TD;
-  static_assert(HROWS <= 8, "rows 0..7 of a tile live in registers 0..3 of both lane halves");
+  static_assert(HROWS <= 8, "rows 0..7 of a 16 x 16 tile live in the four registers of lane groups 0 and 1");
   const int i = lane & 31, h = lane >> 5;
+  const int m16 = lane & 15, kg = lane >> 4;  // v_mfma_f32_16x16x4_f32: A lane (m, k), B lane (n, k), D lane n holds rows 4 kg + r
   if (h == 0) {
 #pragma unroll
     for (int d = 0; d < DAP; ++d) td[i * TD + d] = dzh[d];  // columns >= DAP stay zero (cleared once)
@@ -280,28 +284,29 @@ __device__ __forceinline__ void head_dw_step_lds(const f32x4 (&xs)[H / 8], const
       *reinterpret_cast<f32x4 *>(tx + i * HX + 32 * (q >> 2) + 8 * (q & 3) + 4 * h) = xs[8 * half + q];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private hand-off between lanes (see mlp.hip)
     __builtin_amdgcn_wave_barrier();
-    f32x16 acc[2];
+    // dW_head'[d][f] += sum_s dzh[s][d] x_hat[s][f] on the 16 x 16 x 4 fp32 MFMA: at most 8 of the M rows are head outputs, so
+    // the 32 x 32 x 2 shape (round 2) spent 64 cycles per instruction on a tile that is three quarters padding; still 32 MFMAs
+    // per 64-feature pass, at half the pipe time each, and 16 instead of 32 transient accumulator registers
+    f32x4 acc[4];
 #pragma unroll
-    for (int n = 0; n < 2; ++n)
+    for (int n = 0; n < 4; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+    for (int t = 0; t < SLAB / 4; ++t) {
+      const float a = td[(4 * t + kg) * TD + m16];
 #pragma unroll
-    for (int t = 0; t < SLAB / 2; ++t) {
-      const float a = td[(2 * t + h) * TD + i];
-#pragma unroll
-      for (int n = 0; n < 2; ++n) {
-        const float b = tx[(2 * t + h) * HX + 32 * n + i];
-        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[n], 0, 0, 0);
+      for (int n = 0; n < 4; ++n) {
+        const float b = tx[(4 * t + kg) * HX + 16 * n + m16];
+        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[n], 0, 0, 0);
       }
     }
 #pragma unroll
-    for (int n = 0; n < 2; ++n)
+    for (int n = 0; n < 4; ++n)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         // plain read-modify-write: every (row, column) of the wave's tile belongs to exactly one lane, and a wave's LDS
         // accesses execute in order (ds_add_f32 measured slower here: LDS atomics run at a fraction of the ds_write rate)
-        if (r < HROWS && h == 0) hw[r * H + 64 * half + 32 * n + i] += acc[n][r];
-        if (4 + r < HROWS && h == 1) hw[(4 + r) * H + 64 * half + 32 * n + i] += acc[n][r];
+        if (r < HROWS && kg == 0) hw[r * H + 64 * half + 16 * n + m16] += acc[n][r];
+        if (4 + r < HROWS && kg == 1) hw[(4 + r) * H + 64 * half + 16 * n + m16] += acc[n][r];
       }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();  // every lane is done reading tx / td before the next pass overwrites them
@@ -313,7 +318,7 @@ __device__ __forceinline__ void head_dw_step_lds(const f32x4 (&xs)[H / 8], const
 template <int H, int DAP, int HROWS, int NWAVES>
 __device__ __forceinline__ void head_dw_finish_lds(const float *hacc, float (&dbacc)[DAP], float *dbl,
                                                    float *__restrict__ out) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = wave_id();
   float dbs[DAP];
 #pragma unroll
   for (int d = 0; d < DAP; ++d) dbs[d] = wave_reduce_sum(dbacc[d]);
@@ -347,7 +352,7 @@ __device__ __forceinline__ void head_dw_finish_lds(const float *hacc, float (&db
 template <int H, int DAP>
 __device__ __forceinline__ void head_dw_finish(f32x16 (&acc)[H / 32], float (&dbacc)[DAP], float *buf /* >= 32*H+32 */,
                                                float *__restrict__ out) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = wave_id();
   const int i = lane & 31, h = lane >> 5;
   float dbs[DAP];
 #pragma unroll
@@ -407,7 +412,7 @@ __device__ __forceinline__ void store_dhead(float *__restrict__ dhead, long slab
 
 template <int NV>
 __device__ __forceinline__ void block_reduce_store(float (&v)[NV], float *red /*[4][PS_STRIDE]*/, float *out_row) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = wave_id();
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
     float t = wave_reduce_sum(v[k]);
@@ -475,6 +480,7 @@ __device__ __forceinline__ bool actor_sample(const ActorArgs &A, const float *cs
   const int i = lane & 31, h = lane >> 5;
   const int D = A.act_dim;
   const int act_w = DISCRETE ? 1 : D;
+  const float inv_D = uniform_f(1.0f / (float)D);
   float zlin[DAP];  // x_hat . Whp[d]  (= z - bias), needed by the closed-form LayerNorm backward
 #pragma unroll
   for (int d = 0; d < DAP; ++d) zlin[d] = z[d] - cst[d];
@@ -515,7 +521,7 @@ __device__ __forceinline__ bool actor_sample(const ActorArgs &A, const float *cs
         }
       }
     }
-    imp = A.agg_mean ? sum * (1.0f / (float)D) : prod;
+    imp = A.agg_mean ? sum * inv_D : prod;
   } else {
     // Categorical: logits masked to -1e10 where unavailable, normalised by logsumexp (distributions.py:52-55)
     float mx = -3.0e38f;
@@ -613,7 +619,7 @@ __device__ __forceinline__ bool actor_sample(const ActorArgs &A, const float *cs
         const float a = R.a[d];
         const float diff = a - z[d];
         // d imp / d logp_d : prod -> prod/r_d * r_d ; mean -> r_d / D
-        const float dlp = dimp * (A.agg_mean ? ratio_d[d] * (1.0f / (float)D) : imp);
+        const float dlp = dimp * (A.agg_mean ? ratio_d[d] * inv_D : imp);
         const float isig = cst[5 * DAP + d], ivar = cst[6 * DAP + d];  // 1/sigma, 1/sigma^2 (prologue)
         dzh[d] = dlp * diff * ivar;
         const float dsig = dlp * (diff * diff * ivar * isig - isig) + ecoef * isig;

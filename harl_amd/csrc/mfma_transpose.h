@@ -115,7 +115,7 @@ template <int MT_, int NT_>
 __device__ __forceinline__ void finish_partials(f32x16 (&acc)[MT_][NT_], float (&db)[MT_], float *buf,
                                                 float *__restrict__ part, int n_part_rows) {
   constexpr int HO = 32 * MT_, KP = 32 * NT_, ROW = HO * KP + HO;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, h = lane >> 5;
+  const int lane = threadIdx.x & 63, wave = wave_id(), i = lane & 31, h = lane >> 5;
   float dbt[MT_];
 #pragma unroll
   for (int a = 0; a < MT_; ++a) dbt[a] = wave_sum32(db[a]);

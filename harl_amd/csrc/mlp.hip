@@ -146,7 +146,7 @@ __global__ __launch_bounds__(WG_THREADS, split_one_wg(HO, HI) ? 1 : 2) void k_fw
     for (int e = threadIdx.x; e < HO; e += WG_THREADS) bl[e] = bp[e];
   __syncthreads();
 
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
+  const int lane = threadIdx.x & 63, wave = wave_id(), h = lane >> 5;
   const long slab0 = (long)blockIdx.x * WAVES_PER_WG + wave, slab_stride = (long)gridDim.x * WAVES_PER_WG;
   const u32x4 *wl = img + lane;
   float raw[NR];
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_fwd_input(const float *__rest
   }
   __syncthreads();
 
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = wave_id();
   const int i = lane & 31, h = lane >> 5;
   const long stride = (long)gridDim.x * WAVES_PER_WG;
   const long iters = (n_slabs + stride - 1) / stride;
@@ -351,7 +351,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_fwd_input_staged(const float 
   }
   __syncthreads();
 
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = wave_id();
   const int i = lane & 31, h = lane >> 5;
   float *xw = xs + wave * SLAB * LDX;  // this wave's 32 rows (private: no cross-wave hazards)
   const int lane_row = RPI == 2 ? h : 0, lane_k = RPI == 2 ? i : lane;
@@ -513,7 +513,7 @@ __global__ __launch_bounds__(64 * FUSED_WAVES, 2) void k_fwd_fused2(
   }
   __syncthreads();
 
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = wave_id();
   const int i = lane & 31, h = lane >> 5;
   float *xw = xs + wave * SLAB * LDX;
   const int lane_row = RPI == 2 ? h : 0, lane_k = RPI == 2 ? i : lane;
@@ -698,7 +698,7 @@ __global__ __launch_bounds__(WG_THREADS, (KT > 0 || split_one_wg(HI, HO)) ? 1 : 
   float *stg = reinterpret_cast<float *>(img + 3 * MT * NJ * 64);
   stage_split_matrix<HO, HI, true, WG_THREADS>(img, Wp);
   __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = wave_id();
   const int i = lane & 31, h = lane >> 5;
   const long slab0 = (long)blockIdx.x * WAVES_PER_WG + wave, slab_stride = (long)gridDim.x * WAVES_PER_WG;
   const u32x4 *wl = img + lane;
@@ -832,7 +832,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_dw(const float *__restrict__ 
   float *Bs = lds + DW_S * LDA;  // [DW_S][LDB]
   float *mul = Bs + DW_S * LDB;  // [DW_S] input-LayerNorm mean  (raw-B only)
   float *rsl = mul + DW_S;       // [DW_S] input-LayerNorm rstd
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = wave_id();
   const int i = lane & 31, h = lane >> 5;
   const int wm = wave % SP::WM, wn = wave / SP::WM;
   const int k0 = blockIdx.y * (32 * NT);  // first input feature handled by this workgroup (raw B)
@@ -1046,7 +1046,7 @@ __device__ __forceinline__ void dw_tr_body(const float *__restrict__ a_src, cons
   PHASE_BEGIN();
   unsigned char *Ab = ldsb;               // [3 terms][IMG_A]
   unsigned char *Bb = ldsb + 3 * IMG_A;   // [3 terms][IMG_B]
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = wave_id();
   const int i = lane & 31, h = lane >> 5;
   const int wm = wave % SP::WM, wn = wave / SP::WM;
 

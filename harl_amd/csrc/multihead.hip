@@ -122,7 +122,7 @@ template <bool TRAIN>
 __global__ __launch_bounds__(WG_THREADS) void k_md_head(MdArgs A) {
   __shared__ float red[4 * PS_STRIDE];
   __shared__ float st[WAVES_PER_WG][3][MAXH][WAVE];  // per wave, per head, per lane: lse, entropy, log p(a)
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, h = lane >> 5;
+  const int lane = threadIdx.x & 63, wave = wave_id(), i = lane & 31, h = lane >> 5;
   float adv_mean = 0.f, adv_den = 1.f;
   if (TRAIN && A.adv_moments) {  // happo.py:122-127
     const double cnt = A.adv_moments[2];

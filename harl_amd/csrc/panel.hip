@@ -76,7 +76,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_panel(const float *__restrict
                                                          const float *__restrict__ rstd_prev, long n_slabs) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   u32x4 *img = reinterpret_cast<u32x4 *>(lds);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, h = lane >> 5;
+  const int lane = threadIdx.x & 63, wave = wave_id(), i = lane & 31, h = lane >> 5;
   const u32x4 *wl = img + lane;
   const int n_panels = KP / 32;
   const long n_iter = (n_slabs + WAVES_PER_WG - 1) / WAVES_PER_WG;

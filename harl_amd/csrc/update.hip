@@ -145,7 +145,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_upd_dw2(const float *__restri
   stage_w1_images<H, KP0, WG_THREADS>(w1img, W1p, D);
   for (int e = threadIdx.x; e < H; e += WG_THREADS) b1l[e] = b1p[e];
   __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
+  const int lane = threadIdx.x & 63, wave = wave_id(), h = lane >> 5;
   const long slab0 = (long)blockIdx.x * WAVES_PER_WG + wave, slab_stride = (long)gridDim.x * WAVES_PER_WG;
   const u32x4 *wl1 = w1img + lane;
   u32x4 *pk = park + (long)wave * (MT * 6 * 64) + lane;
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_upd_dx(const float *__restric
   stage_w1_images<H, KP0, WG_THREADS>(w1img, W1p, D);
   for (int e = threadIdx.x; e < H; e += WG_THREADS) b1l[e] = b1p[e];
   __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
+  const int lane = threadIdx.x & 63, wave = wave_id(), h = lane >> 5;
   const long slab0 = (long)blockIdx.x * WAVES_PER_WG + wave, slab_stride = (long)gridDim.x * WAVES_PER_WG;
   const u32x4 *wl1 = w1img + lane, *wl2 = img2 + lane;
   const Ident I = make_ident(lane);
@@ -307,6 +307,11 @@ struct UpdFwdArgs {
   long n_slabs;
   float *dz2;
   int n_part_rows;
+  // hybrid optimiser step (TRAIN): also leave x_hat_1 (ATL), its ReLU mask and LayerNorm statistic in HBM, so that the
+  // LAYER-BY-LAYER backward kernels (harl_mlp_bwd_dx, harl_mlp_dw_partials) run behind this launch; NULL = keep them on chip
+  float *xh1;
+  uint32_t *mask1;
+  float *rstd1;
 };
 
 // EIGHT waves per workgroup = two per SIMD, 256 registers each: one wave's VALU / LDS / scalar work issues under the other's
@@ -318,7 +323,7 @@ constexpr int UF_WAVES = 8, UF_THREADS = 64 * UF_WAVES;
 
 template <int NV>
 __device__ __forceinline__ void block_reduce_store8(float (&v)[NV], float *red /*[8][PS_STRIDE]*/, float *out_row) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = wave_id();
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
     float t = wave_reduce_sum(v[k]);
@@ -383,13 +388,11 @@ __global__ __launch_bounds__(UF_THREADS, 2) void k_upd_fwd(UpdFwdArgs U, ARGS A)
   }
   __syncthreads();
 
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, h = lane >> 5;
+  const int lane = threadIdx.x & 63, wave = wave_id(), i = lane & 31, h = lane >> 5;
   const long slab0 = (long)blockIdx.x * UF_WAVES + wave, slab_stride = (long)gridDim.x * UF_WAVES;
   const u32x4 *wl1 = w1img + lane, *wl2 = w2img + lane;
   const float *whl_h = whl + h * (H / 2) * DAP;
   float *hw = hacc + wave * (HROWS * H);
-  const Ident I = make_ident(lane);
-  const u32x4 I16 = make_ident16(lane);
 
   float adv_mean = 0.f, adv_den = 1.f, vmean = 0.f, vsd = 1.f;
   if constexpr (CRITIC) {
@@ -408,31 +411,44 @@ __global__ __launch_bounds__(UF_THREADS, 2) void k_upd_fwd(UpdFwdArgs U, ARGS A)
       adv_den = 1.0f / ((float)sqrt(var > 0 ? var : 0.0) + 1e-5f);  // reciprocal (actor_sample multiplies)
     }
   }
+  adv_mean = uniform_f(adv_mean);  // uniform scalars belong in scalar registers (they were being spilled as vector registers)
+  adv_den = uniform_f(adv_den);
+  vmean = uniform_f(vmean);
+  vsd = uniform_f(vsd);
   constexpr int NSC = CRITIC ? 8 : 8 + DAP;
   float sc[NSC];
 #pragma unroll
   for (int k = 0; k < NSC; ++k) sc[k] = 0.f;
-  float dbacc[DAP];
+  // head bias gradient sums.  Actor: they share registers with the log-std gradient sums sc[8 + d], which only lane half 0
+  // accumulates (actor_sample) -- half 1 (same samples) adds d loss / d head[d] into its copy; unpacked in the epilogue.
+  // Eight accumulator registers less in a loop that sits at its 256-register budget: spilled loop-carried sums cost a
+  // scratch round trip EACH per slab (in-order issue waits out the reload; phase timers, round 3)
+  float dbacc[CRITIC ? DAP : 1];
 #pragma unroll
-  for (int d = 0; d < DAP; ++d) dbacc[d] = 0.f;
+  for (int d = 0; d < (CRITIC ? DAP : 1); ++d) dbacc[d] = 0.f;
 
   float xr[KP0 / 2];
   atl_load<KP0>(U.x0n, slab0 < U.n_slabs ? slab0 : 0, lane, xr);
+  // the per-row loss inputs run ONE slab ahead of the arithmetic, as in k_actor_head (requested in the loss phase of the
+  // previous slab): loaded at the top of the slab they belong to, the scheduler sank the (conditional, per-dimension) loads to
+  // their first use under register pressure and the loss phase waited out their latency (phase timers, round 3: 15.8k cycles
+  // per slab against 7k in k_actor_head)
+  ActorRow<DAP> rnext;
+  float cvoldn = 0.f, cretn = 0.f;
+  if (slab0 < U.n_slabs) {
+    if constexpr (!CRITIC) actor_row_load<DAP, DISCRETE, TRAIN>(A, slab0, lane, rnext);
+    else if constexpr (TRAIN) critic_row_load(A, slab0, lane, cvoldn, cretn);
+  }
   PHASE_BEGIN();
   for (long slab = slab0; slab < U.n_slabs; slab += slab_stride) {
     float v[NR];        // x_hat_2
     uint32_t bits2[NW];
     float r2;
-    ActorRow<DAP> rcur;  // this slab's per-row loss inputs: issued before the two GEMMs that precede their use
-    float cvold = 0.f, cret = 0.f;
-    if constexpr (!CRITIC) actor_row_load<DAP, DISCRETE, TRAIN>(A, slab, lane, rcur);
-    else if constexpr (TRAIN) critic_row_load(A, slab, lane, cvold, cret);
     {
       float x1[NR];
       {
         u32x4 a1[NJ1], a2[NJ1], a3[NJ1];
         split_acts<KP0 / 2>(xr, a1, a2, a3);
-        atl_load<KP0>(U.x0n, slab + slab_stride < U.n_slabs ? slab + slab_stride : slab, lane, xr);  // one slab ahead
         f32x16 acc[MT];
 #pragma unroll
         for (int t = 0; t < MT; ++t)
@@ -443,7 +459,15 @@ __global__ __launch_bounds__(UF_THREADS, 2) void k_upd_fwd(UpdFwdArgs U, ARGS A)
         PHASE(1);
         uint32_t bits1[NW];
         float r1;
-        relu_ln<H, false>(acc, x1, bits1, r1);
+        relu_ln<H, TRAIN>(acc, x1, bits1, r1);
+        if constexpr (TRAIN) {
+          if (U.xh1) {  // (wave-uniform) the layer kernels' activation record of layer 1, cf. k_fwd_fused2x (wide.hip)
+            atl_store<H>(U.xh1, slab, lane, x1);
+#pragma unroll
+            for (int w = 0; w < NW; ++w) U.mask1[(slab * NW + w) * WAVE + lane] = bits1[w];
+            if (lane < 32) U.rstd1[slab * SLAB + lane] = r1;
+          }
+        }
       }
       u32x4 y1[NJ2], y2[NJ2], y3[NJ2];
       split_acts<NR>(x1, y1, y2, y3);
@@ -464,6 +488,14 @@ __global__ __launch_bounds__(UF_THREADS, 2) void k_upd_fwd(UpdFwdArgs U, ARGS A)
     float z[DAP];
     head_fwd_regs<H, DAP>(xs, whl_h, cst, z);
     PHASE(5);
+    // this slab's rows (loaded one slab ago) are consumed now; the next slab's are requested where the GEMM operands are dead
+    // (log-prob passes: here; optimiser steps: after the head weight gradient, the register peak of the loop) -- one set of
+    // row registers is live across the two GEMMs instead of two
+    const ActorRow<DAP> rcur = rnext;
+    const float cvold = cvoldn, cret = cretn;
+    const long sn = slab + slab_stride < U.n_slabs ? slab + slab_stride : slab;
+    if constexpr (!TRAIN) atl_load<KP0>(U.x0n, sn, lane, xr);  // the next slab's normalised inputs likewise (TRAIN: after the head dW)
+    if constexpr (!TRAIN && !CRITIC) actor_row_load<DAP, DISCRETE, TRAIN>(A, sn, lane, rnext);  // (TRAIN: at the end of the body)
     float dzh[DAP];
     float s1, s2;
     if constexpr (CRITIC) {
@@ -480,6 +512,12 @@ __global__ __launch_bounds__(UF_THREADS, 2) void k_upd_fwd(UpdFwdArgs U, ARGS A)
     if constexpr (TRAIN) {
       // ---- head weight gradient dW_head'[d][f] += sum_s dzh[s][d] x_hat_2[s][f]: both operands transposed on the matrix
       // pipe, one 32-feature tile at a time; rows d < HROWS of the tile are added to the wave's LDS accumulator
+      // the permuted identities are rebuilt per slab (~40 VALU) instead of occupying 12 registers across the two GEMMs, where
+      // the kernel sits at its 256-register budget; the empty asm keeps the compiler from hoisting them back out of the loop
+      int lane_o = lane;
+      asm volatile("" : "+v"(lane_o));
+      const Ident I = make_ident(lane_o);
+      const u32x4 I16 = make_ident16(lane_o);
       u32x4 Ah[3][2];
       {
         float e8[8];  // lane half 0 carries head-gradient entries 0..7 (entries >= DAP are zero), half 1 zeros
@@ -509,22 +547,41 @@ __global__ __launch_bounds__(UF_THREADS, 2) void k_upd_fwd(UpdFwdArgs U, ARGS A)
         // tile[r] of lane (i, h) = row d = (r & 3) + 8 (r >> 2) + 4 h, column 32 n + i
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          if (r < HROWS && h == 0) atomicAdd(hw + r * H + 32 * n + i, tile[r]);
-          if (4 + r < HROWS && h == 1) atomicAdd(hw + (4 + r) * H + 32 * n + i, tile[r]);
+          // plain read-modify-write (every (row, column) of the wave's tile belongs to one lane; ds_add_f32 runs at a
+          // fraction of the ds_write rate: heads_common.h, head_dw_step_lds)
+          if (r < HROWS && h == 0) hw[r * H + 32 * n + i] += tile[r];
+          if (4 + r < HROWS && h == 1) hw[(4 + r) * H + 32 * n + i] += tile[r];
         }
       }
-      if (h == 0) {
+      if constexpr (CRITIC) {
+        if (h == 0) dbacc[0] += dzh[0];
+      } else {
+        if (h == 1) {
 #pragma unroll
-        for (int d = 0; d < DAP; ++d) dbacc[d] += dzh[d];
+          for (int d = 0; d < DAP; ++d) sc[8 + d] += dzh[d];
+        }
       }
       PHASE(7);
+      atl_load<KP0>(U.x0n, sn, lane, xr);
       // ---- head backward (W_head'^T dzh on the fp32 MFMA) + LayerNorm / ReLU backward -> dz_2
       head_bwd_regs_bits<H, DAP>(xs, bits2[0], bits2[NW - 1], r2, slab, lane, whl, dzh, s1, s2, U.dz2);
+      if constexpr (!CRITIC) actor_row_load<DAP, DISCRETE, TRAIN>(A, sn, lane, rnext);
+      else critic_row_load(A, sn, lane, cvoldn, cretn);
       PHASE(8);
     }
   }
   PHASE_END((TRAIN ? 0 : 2) + (CRITIC ? 1 : 0));
   if constexpr (TRAIN) {
+    float dbv[DAP];
+#pragma unroll
+    for (int d = 0; d < DAP; ++d) {
+      if constexpr (CRITIC) {
+        dbv[d] = dbacc[d];
+      } else {
+        dbv[d] = h == 1 ? sc[8 + d] : 0.f;
+        sc[8 + d] = h == 0 ? sc[8 + d] : 0.f;
+      }
+    }
     block_reduce_store8<NSC>(sc, red, A.part_scalars + (long)blockIdx.x * PS_STRIDE);
     for (int row = blockIdx.x + gridDim.x; row < U.n_part_rows; row += gridDim.x)
       if (threadIdx.x < PS_STRIDE) A.part_scalars[(long)row * PS_STRIDE + threadIdx.x] = 0.f;
@@ -532,7 +589,7 @@ __global__ __launch_bounds__(UF_THREADS, 2) void k_upd_fwd(UpdFwdArgs U, ARGS A)
     // dWp[32][H] | dbp[32] (rows >= HROWS are zero)
     float dbs[DAP];
 #pragma unroll
-    for (int d = 0; d < DAP; ++d) dbs[d] = wave_reduce_sum(dbacc[d]);
+    for (int d = 0; d < DAP; ++d) dbs[d] = wave_reduce_sum(dbv[d]);
     float *dbl = red;  // [8][PS_STRIDE] reused (block_reduce_store8 is done with it after the barrier below)
     __syncthreads();
     if (lane == 0) {
@@ -632,11 +689,13 @@ extern "C" int harl_update_fwd_actor(const float *x0n, long M, int D, int H, con
                                      const float *actions, const float *avail, const float *old_logp, const float *adv,
                                      const double *adv_moments, const float *factor, const float *active,
                                      double clip_param, float entropy_coef, int agg_mean, int trpo, float *logp_out,
-                                     float *dz2, float *part_scalars, float *dw_part_head, int n_part_rows, void *stream) {
+                                     float *dz2, float *part_scalars, float *dw_part_head, int n_part_rows, float *xh1,
+                                     uint32_t *rmask1, float *rstd1, void *stream) {
   if (M <= 0) return 0;
   if (D < 1 || D > 64) return bad("harl_update_fwd_actor: input width must be <= 64");
   if (!dz2 || !part_scalars || !dw_part_head || n_part_rows <= 0) return bad("harl_update_fwd_actor: missing outputs");
-  UpdFwdArgs U{x0n, W1p, b1p, W2p, b2p, D, n_slabs_of(M), dz2, n_part_rows};
+  if (xh1 && (!rmask1 || !rstd1)) return bad("harl_update_fwd_actor: xh1 needs rmask1 and rstd1");
+  UpdFwdArgs U{x0n, W1p, b1p, W2p, b2p, D, n_slabs_of(M), dz2, n_part_rows, xh1, rmask1, rstd1};
   if (fwd_grid(U.n_slabs) > n_part_rows) return bad("harl_update_fwd_actor: n_part_rows smaller than the launch grid");
   ActorArgs A{};
   A.trpo = trpo;
@@ -659,7 +718,7 @@ extern "C" int harl_update_logp(const float *x0n, long M, int D, int H, const fl
   if (M <= 0) return 0;
   if (D < 1 || D > 64) return bad("harl_update_logp: input width must be <= 64");
   if (factor && !old_logp) return bad("harl_update_logp: factor update needs old_logp");
-  UpdFwdArgs U{x0n, W1p, b1p, W2p, b2p, D, n_slabs_of(M), nullptr, 0};
+  UpdFwdArgs U{x0n, W1p, b1p, W2p, b2p, D, n_slabs_of(M), nullptr, 0, nullptr, nullptr, nullptr};
   ActorArgs A{};
   A.head_out = head_out;
   A.M = M; A.Whp = Whp; A.bhp = bhp; A.log_std = log_std;
@@ -673,11 +732,13 @@ extern "C" int harl_update_fwd_critic(const float *x0n, long M, int D, int H, co
                                       const float *W2p, const float *b2p, const float *Whp, const float *bhp,
                                       const float *value_preds, const float *returns, const float *vn_stats,
                                       float clip_param, int use_clipped, int use_huber, float huber_delta, float *dz2,
-                                      float *part_scalars, float *dw_part_head, int n_part_rows, void *stream) {
+                                      float *part_scalars, float *dw_part_head, int n_part_rows, float *xh1,
+                                      uint32_t *rmask1, float *rstd1, void *stream) {
   if (M <= 0) return 0;
   if (D < 1 || D > 64) return bad("harl_update_fwd_critic: input width must be <= 64");
   if (!dz2 || !part_scalars || !dw_part_head || n_part_rows <= 0) return bad("harl_update_fwd_critic: missing outputs");
-  UpdFwdArgs U{x0n, W1p, b1p, W2p, b2p, D, n_slabs_of(M), dz2, n_part_rows};
+  if (xh1 && (!rmask1 || !rstd1)) return bad("harl_update_fwd_critic: xh1 needs rmask1 and rstd1");
+  UpdFwdArgs U{x0n, W1p, b1p, W2p, b2p, D, n_slabs_of(M), dz2, n_part_rows, xh1, rmask1, rstd1};
   if (fwd_grid(U.n_slabs) > n_part_rows) return bad("harl_update_fwd_critic: n_part_rows smaller than the launch grid");
   CriticArgs A{};
   A.M = M; A.Whp = Whp; A.bhp = bhp;
@@ -693,7 +754,7 @@ extern "C" int harl_update_values(const float *x0n, long M, int D, int H, const 
                                   void *stream) {
   if (M <= 0) return 0;
   if (D < 1 || D > 64) return bad("harl_update_values: input width must be <= 64");
-  UpdFwdArgs U{x0n, W1p, b1p, W2p, b2p, D, n_slabs_of(M), nullptr, 0};
+  UpdFwdArgs U{x0n, W1p, b1p, W2p, b2p, D, n_slabs_of(M), nullptr, 0, nullptr, nullptr, nullptr};
   CriticArgs A{};
   A.M = M; A.Whp = Whp; A.bhp = bhp; A.values_out = values; A.n_slabs = U.n_slabs;
   return dispatch_fwd_critic<false>(U, A, H, (hipStream_t)stream);

@@ -55,7 +55,7 @@ __global__ __launch_bounds__(WG_THREADS, NC <= 3 ? 2 : 1) void k_x0n_wide(const 
                                                                            float *__restrict__ mu0_out,
                                                                            float *__restrict__ rstd0_out, long n_slabs, int KP) {
   __shared__ __attribute__((aligned(16))) float tiles[WAVES_PER_WG][2][32 * XT_LD];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = wave_id();
   const int i = lane & 31, h = lane >> 5;
   float *tw = &tiles[wave][0][0];
   for (long slab = (long)blockIdx.x * WAVES_PER_WG + wave; slab < n_slabs; slab += (long)gridDim.x * WAVES_PER_WG) {
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(WG_THREADS, 4) void k_x0n_contig(const float *__res
                                                               float *__restrict__ x0n, float *__restrict__ mu0_out,
                                                               float *__restrict__ rstd0_out, long n_slabs) {
   __shared__ float rowsl[WAVES_PER_WG][32 * KPV + 32];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = wave_id();
   const int i = lane & 31, h = lane >> 5;
   float *rw = &rowsl[wave][0];
   const int per = 32 * D;  // floats per slab
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_x0n_narrow(const float *__res
                                                               float *__restrict__ x0n, float *__restrict__ mu0_out,
                                                               float *__restrict__ rstd0_out, long n_slabs) {
   __shared__ __attribute__((aligned(16))) float tiles[WAVES_PER_WG][32 * XT_LD];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = wave_id();
   const int i = lane & 31, h = lane >> 5;
   float *tw = &tiles[wave][0];
   const int kc = i < D ? i : 0;
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_fwd_wide(const float *__restr
                                                             const float *__restrict__ rstd_in, long n_slabs, int KP) {
   constexpr int MT = HO / 32;
   const int NJ = KP / 16, TS = MT * NJ * 64;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
+  const int lane = threadIdx.x & 63, wave = wave_id(), h = lane >> 5;
   const long n_pairs = (n_slabs + 1) / 2;
   const u32x4 *wl = img + lane;
   for (long pair = (long)blockIdx.x * WAVES_PER_WG + wave; pair < n_pairs; pair += (long)gridDim.x * WAVES_PER_WG) {
@@ -486,7 +486,7 @@ __global__ __launch_bounds__(64 * F2X_WAVES, 2) void k_fwd_fused2x(
     b2l[e] = b2p[e];
   }
   __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
+  const int lane = threadIdx.x & 63, wave = wave_id(), h = lane >> 5;
   const long slab0 = (long)blockIdx.x * F2X_WAVES + wave, slab_stride = (long)gridDim.x * F2X_WAVES;
   const u32x4 *wl1 = w1img + lane, *wl2 = w2img + lane;
   float xr[KP0 / 2];

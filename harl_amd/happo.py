@@ -222,14 +222,14 @@ class HAPPO(OnPolicyBase):
         pre-step parameters (by batch position).  ``factor`` None = 1 (MAPPO)."""
         net = self.actor
         s = stream()
-        if net.fused_update_ok(idx, seq):  # three launches, every activation on chip (csrc/update.hip)
+        if net.fused_update_ok(idx, seq):  # fused forward + loss (csrc/update.hip), then the layer backward (hybrid) or harl_update_bwd
             fa = net.fused_args(obs, m)
             call("harl_update_fwd_actor", *fa, ptr(net.log_std()), net.std_x_coef, net.std_y_coef, int(net.discrete),
                  net.act_dim, ptr(actions), ptr(avail), ptr(old_logp), ptr(adv), ptr(adv_moments), ptr(factor),
                  ptr(active), float(self.clip_param), float(self.entropy_coef), int(self.action_aggregation == "mean"),
                  self._surrogate_mode, ptr(logp_out), ptr(net.dz[0]), ptr(net.part_scalars),
-                 ptr(net.part[net._part_offs[-1]:]), net.n_wg, s, tag="update_fwd")
-            net.backward_fused(m)
+                 ptr(net.part[net._part_offs[-1]:]), net.n_wg, *net.hybrid_outputs(), s, tag="update_fwd")
+            net.backward_after_fused(obs, m)
             return net.n_wg
         net.forward_trunk(obs, idx, m, seq=seq)
         Wp, bp = net._packs[-1]

@@ -464,19 +464,38 @@ class _FlatNet(nn.Module):
 
     # ---- fused optimiser-step path (csrc/update.hip): two equal hidden layers, inputs <= 64 wide, identity row order
     def fused_update_ok(self, idx: Optional[torch.Tensor], seq: Optional[dict] = None, train: bool = True) -> bool:
-        """Route this pass through csrc/update.hip?  ``HARL_FUSED_UPDATE``: "logp" (default) = forward-only passes
-        (log-probs, factor product, values: one launch instead of two, x_hat_2 never written); "1" = optimiser steps too
-        (three launches, ~1.9 KB of HBM traffic per sample instead of ~4.5 KB -- fewer bytes but, on MI355X today, more
-        VALU work than the layer-by-layer kernels and a few % slower end to end: DESIGN.md §3); "actor" = "1" for actors
-        only; "0" = never."""
+        """Route this pass through csrc/update.hip?  ``HARL_FUSED_UPDATE``: "hybrid" (default) = forward-only passes
+        (log-probs, factor product, values: one launch instead of two, x_hat_2 never written) AND the forward half of the
+        optimiser steps -- forward + head + loss + head gradient + dz_2 in one launch that also leaves layer 1's activation
+        record in HBM, followed by the layer-by-layer backward (x_hat_2 / mask_2 / rstd_2 never cross HBM: ~3.5 KB per
+        sample instead of ~4.5 KB, one launch less); "logp" = forward-only passes only; "1" = optimiser steps in three
+        launches with x_hat_1 recomputed in the backward (~1.9 KB per sample -- fewer bytes but more VALU work than the
+        layer kernels and slower end to end on MI355X: DESIGN.md section 3); "actor" = "1" for actors only; "0" = never."""
         hs = self.hidden_sizes
-        mode = os.environ.get("HARL_FUSED_UPDATE", "logp")
+        mode = os.environ.get("HARL_FUSED_UPDATE", "hybrid")
         if self.act_id:
             return False
         if mode == "0" or (train and mode == "logp") or (train and mode == "actor" and isinstance(self, VNet)):
             return False
         return (not self.recurrent and not self.md and idx is None and seq is None
                 and len(hs) == 2 and hs[0] == hs[1] and hs[0] in (64, 128) and self.in_dim <= 64 and self._layers()[-1][4] <= 8)
+
+    def fused_hybrid(self) -> bool:
+        """Optimiser steps as fused forward + layer-by-layer backward (see fused_update_ok)?"""
+        return os.environ.get("HARL_FUSED_UPDATE", "hybrid") == "hybrid"
+
+    def hybrid_outputs(self):
+        """(xh1, rmask1, rstd1) arguments of harl_update_fwd_*: layer 1's activation record for the layer-by-layer backward
+        (hybrid), or three NULLs (harl_update_bwd recomputes it)."""
+        if not self.fused_hybrid():
+            return (None, None, None)
+        return (ptr(self.xh[0]), ptr(self.rmask[0]), ptr(self.rstd[0]))
+
+    def backward_after_fused(self, X: torch.Tensor, M: int) -> None:
+        if self.fused_hybrid():
+            self.backward_trunk(X, None, M, head_dw_done=True)
+        else:
+            self.backward_fused(M)
 
     def fused_args(self, X: torch.Tensor, M: int):
         """(x0n, M, D, H, W1', b1', W2', b2', Wh', bh') -- the leading arguments of every harl_update_* entry point.

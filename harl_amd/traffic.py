@@ -117,11 +117,11 @@ def _critic_head_loss(a: Sequence) -> float:
 
 def _update_fwd_actor(a: Sequence) -> float:
     # (x0n, M, D, H, 7 weight pointers, sx, sy, discrete, act_dim, actions, avail, old_logp, adv, adv_moments, factor, active,
-    #  clip, ent, agg_mean, trpo, logp_out, dz2, part_scalars, dw_part_head, n_part_rows, stream)
+    #  clip, ent, agg_mean, trpo, logp_out, dz2, part_scalars, dw_part_head, n_part_rows, xh1, rmask1, rstd1, stream)
     M, D, H, disc, ad = a[1], a[2], a[3], a[13], a[14]
     w = 1 if disc else ad
     return M * (4.0 * _kp(D) + _head_rows(disc, ad, a[16]) + 4.0 + (4.0 if a[20] else 0.0) + (4.0 if a[21] else 0.0)
-                + (4.0 * w if a[26] else 0.0) + 4.0 * H)
+                + (4.0 * w if a[26] else 0.0) + 4.0 * H + (_act(H) if a[31] else 0.0))  # hybrid: + layer 1's record out
 
 
 def _update_logp(a: Sequence) -> float:
@@ -132,7 +132,9 @@ def _update_logp(a: Sequence) -> float:
 
 
 def _update_fwd_critic(a: Sequence) -> float:
-    return a[1] * (4.0 * _kp(a[2]) + 8.0 + 4.0 * a[3])
+    # (x0n, M, D, H, 6 weight pointers, value_preds, returns, vn_stats, clip, use_clipped, use_huber, delta, dz2, part_scalars,
+    #  dw_part_head, n_part_rows, xh1, rmask1, rstd1, stream)
+    return a[1] * (4.0 * _kp(a[2]) + 8.0 + 4.0 * a[3] + (_act(a[3]) if a[21] else 0.0))
 
 
 def _update_values(a: Sequence) -> float:

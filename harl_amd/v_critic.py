@@ -91,12 +91,12 @@ class VCritic:
                       local_count=(seq["L"] * seq["m"] if seq is not None else m))
         net._ensure_ws(max(m, 1))
         sc = net.scalars
-        if m > 0 and net.fused_update_ok(idx, seq):  # three launches, every activation on chip (csrc/update.hip)
+        if m > 0 and net.fused_update_ok(idx, seq):  # fused forward + loss (csrc/update.hip), then the layer backward (hybrid) or harl_update_bwd
             call("harl_update_fwd_critic", *net.fused_args(share_obs, m), ptr(value_preds), ptr(returns),
                  ptr(vn.stats) if vn is not None else None, float(self.clip_param), int(self.use_clipped_value_loss),
                  int(self.use_huber_loss), float(self.huber_delta), ptr(net.dz[0]), ptr(net.part_scalars),
-                 ptr(net.part[net._part_offs[-1]:]), net.n_wg, s, tag="update_fwd_critic")
-            net.backward_fused(m)
+                 ptr(net.part[net._part_offs[-1]:]), net.n_wg, *net.hybrid_outputs(), s, tag="update_fwd_critic")
+            net.backward_after_fused(share_obs, m)
         elif m > 0:
             net.forward_trunk(share_obs, idx, m, seq=seq)
             Wp, bp = net._packs[-1]

@@ -369,6 +369,10 @@ int harl_md_head_loss(const float *const *z, float *const *dz, int n_groups, con
  *   harl_update_logp   : forward + log-probs (+ factor *= agg(exp(new - old)), head_out) -- harl_mlp_fwd_fused2x +
  *                        harl_actor_head_logp without the x_hat_2 round trip (on_policy_ha_runner.py:66-124).
  *   harl_update_values : forward + values (v_critic.py:54-73).
+ * xh1 / rmask1 / rstd1 (harl_update_fwd_*; all three or none): the HYBRID step -- the launch also leaves layer 1's activation
+ *   record (x_hat_1 as an ATL image, ReLU mask words, 1/sigma) in HBM, in the format of harl_mlp_fwd_fused2x, so that the
+ *   layer-by-layer backward (harl_mlp_bwd_dx + harl_mlp_dw_partials) runs behind it instead of harl_update_bwd: x_hat_2,
+ *   its mask and statistic still never leave the chip, and nothing is recomputed.
  * harl_update_supported returns 1 when (D, H, act_dim) is inside the instantiated range (D <= 64, H in {64,128}, act_dim <= 8). */
 int harl_update_supported(int D, int H, int act_dim);
 int harl_update_fwd_actor(const float *x0n, long M, int D, int H, const float *W1p, const float *b1p, const float *W2p,
@@ -377,7 +381,7 @@ int harl_update_fwd_actor(const float *x0n, long M, int D, int H, const float *W
                           const float *old_logp, const float *adv, const double *adv_moments, const float *factor,
                           const float *active, double clip_param, float entropy_coef, int agg_mean, int trpo,
                           float *logp_out, float *dz2, float *part_scalars, float *dw_part_head, int n_part_rows,
-                          void *stream);
+                          float *xh1, uint32_t *rmask1, float *rstd1, void *stream);
 int harl_update_logp(const float *x0n, long M, int D, int H, const float *W1p, const float *b1p, const float *W2p,
                      const float *b2p, const float *Whp, const float *bhp, const float *log_std, float std_x_coef,
                      float std_y_coef, int discrete, int act_dim, const float *actions, const float *avail,
@@ -386,7 +390,7 @@ int harl_update_fwd_critic(const float *x0n, long M, int D, int H, const float *
                            const float *b2p, const float *Whp, const float *bhp, const float *value_preds,
                            const float *returns, const float *vn_stats, float clip_param, int use_clipped, int use_huber,
                            float huber_delta, float *dz2, float *part_scalars, float *dw_part_head, int n_part_rows,
-                           void *stream);
+                           float *xh1, uint32_t *rmask1, float *rstd1, void *stream);
 int harl_update_values(const float *x0n, long M, int D, int H, const float *W1p, const float *b1p, const float *W2p,
                        const float *b2p, const float *Whp, const float *bhp, float *values, void *stream);
 int harl_update_bwd(const float *x0n, const float *dz2, long M, int D, int H, const float *W1p, const float *b1p,

@@ -1194,8 +1194,8 @@ def check_generator_api(name: str) -> Dict[str, float]:
     return out
 
 
-def check_fused_vs_layered(rows: int) -> Dict[str, float]:
-    """csrc/update.hip (HARL_FUSED_UPDATE=1) against the layer-by-layer kernels (=0) on the same data: unscaled folded
+def check_fused_vs_layered(rows: int, mode: str = "1") -> Dict[str, float]:
+    """csrc/update.hip (HARL_FUSED_UPDATE=``mode``: 1 or hybrid) against the layer-by-layer kernels (=0) on the same data: unscaled folded
     gradients, loss sums, first-epoch log-probs, log-prob pass + factor product; second fused run bit-identical."""
     import os
     sh = Shapes(T=rows, N=1, A=1, obs_dim=18, share_obs_dim=54, act_dim=5, discrete=False, hidden_sizes=[128, 128])
@@ -1219,8 +1219,8 @@ def check_fused_vs_layered(rows: int) -> Dict[str, float]:
         lp0 = torch.empty(rows, actor.actor.act_w, device=DEV)
         actor._logp_pass(obs, act, None, rows, lp0)
         old_logp = (lp0 + dev(0.1 * rng.standard_normal((rows, actor.actor.act_w)).astype(np.float32))).contiguous()
-        for tag, mode in (("old", "0"), ("new", "1"), ("again", "1")):
-            os.environ["HARL_FUSED_UPDATE"] = mode
+        for tag, mode_ in (("old", "0"), ("new", mode), ("again", mode)):
+            os.environ["HARL_FUSED_UPDATE"] = mode_
             actor.actor.invalidate_caches()
             critic.critic.invalidate_caches()
             lp = torch.zeros(rows, actor.actor.act_w, device=DEV)

@@ -53,7 +53,8 @@ def test_dropin_under_unmodified_train_py_plumbing(tmp_path):
     assert "config.json" in res["run_dir_files"] and "progress.txt" in res["run_dir_files"]
     k = res["kernel_calls"]
     for name in ("harl_gae_returns", "harl_masked_moments", "harl_adam_fold", "harl_reduce_partials_multi",
-                 "harl_actor_head_loss", "harl_critic_head_loss", "harl_mlp_x0n_wide"):
+                 "harl_update_fwd_actor", "harl_update_fwd_critic", "harl_mlp_bwd_dx", "harl_mlp_dw_partials",
+                 "harl_mlp_x0n_wide"):  # hybrid optimiser step (nets.fused_update_ok): fused forward, layer-by-layer backward
         assert k.get(name, 0) > 0, (name, k)
     assert k.get("harl_update_logp", 0) + k.get("harl_actor_head_logp", 0) > 0, k   # rollout sampling + factor passes
     assert k["harl_adam_fold"] == 4 * (3 * 5 + 5), k                              # 4 episodes x (3 agents x 5 + 5 critic epochs)

@@ -235,29 +235,34 @@ def test_buffer_generator_api_matches_reference_order(name):
         assert v == 0.0, (k, v)
 
 
+@pytest.mark.parametrize("mode", ["hybrid", "1"])
 @pytest.mark.parametrize("i", [0, 1])
-def test_fused_update_kernels_single_update(i, monkeypatch):
-    """csrc/update.hip (HARL_FUSED_UPDATE=1): forward + loss + head gradient in one launch, weight gradients from the
-    recomputed x_hat_1 with transposes on the matrix pipe -- one actor and one critic update vs the oracle."""
-    monkeypatch.setenv("HARL_FUSED_UPDATE", "1")
+def test_fused_update_kernels_single_update(i, mode, monkeypatch):
+    """csrc/update.hip: forward + loss + head gradient in one launch, then either the layer-by-layer backward on the
+    activation record of layer 1 that the launch leaves behind (HARL_FUSED_UPDATE=hybrid, the default) or the weight gradients
+    from the recomputed x_hat_1 with transposes on the matrix pipe (=1) -- one actor and one critic update vs the oracle."""
+    monkeypatch.setenv("HARL_FUSED_UPDATE", mode)
     G = _G()
     _assert_all(G.check_gradients(G.FWD_SHAPES[i]), tol=TOL)
     _assert_all(G.check_forward(G.FWD_SHAPES[i]), tol=TOL)
 
 
+@pytest.mark.parametrize("mode", ["hybrid", "1", "logp"])
 @pytest.mark.parametrize("name", ["mpe_box_h64", "mpe_box_h128", "mpe_disc_h64", "box_mean_inactive_novn", "a2c_box_h64",
                                   "mappo_box_h64"])
-def test_fused_update_kernels_train_golden(name, monkeypatch):
-    """Whole train() through the fused optimiser-step kernels vs the reference's golden vectors."""
-    monkeypatch.setenv("HARL_FUSED_UPDATE", "1")
+def test_fused_update_kernels_train_golden(name, mode, monkeypatch):
+    """Whole train() vs the reference's golden vectors with the optimiser steps routed through the fused forward + layer
+    backward (hybrid, the default), the three fused launches (1) and the layer-by-layer kernels alone (logp)."""
+    monkeypatch.setenv("HARL_FUSED_UPDATE", mode)
     _assert_all(_G().check_train_golden(name), tol=TOL)
 
 
-def test_fused_update_kernels_many_slabs_per_wave():
+@pytest.mark.parametrize("mode", ["hybrid", "1"])
+def test_fused_update_kernels_many_slabs_per_wave(mode):
     """The fused kernels against the layer-by-layer kernels at a size where every wave walks several slabs (the golden
     cases are a slab or two per wave): folded gradients, loss sums, log-probs and the factor product, plus bit-exact
     run-to-run determinism."""
-    res = _G().check_fused_vs_layered(32 * 8 * 256 * 2 + 7 * 32 + 3)
+    res = _G().check_fused_vs_layered(32 * 8 * 256 * 2 + 7 * 32 + 3, mode=mode)
     for k, v in res.items():
         if "bitwise" in k:
             assert v == 1.0, (k, v)

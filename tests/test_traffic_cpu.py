@@ -37,7 +37,8 @@ def test_argument_positions_match_the_header():
                                  "factor": 14, "head_out": 16},
         "harl_critic_head_loss": {"M": 3, "H": 4},
         "harl_update_fwd_actor": {"M": 1, "D": 2, "H": 3, "discrete": 13, "act_dim": 14, "avail": 16, "factor": 20,
-                                  "active": 21, "logp_out": 26},
+                                  "active": 21, "logp_out": 26, "xh1": 31},
+        "harl_update_fwd_critic": {"M": 1, "D": 2, "H": 3, "xh1": 21},
         "harl_update_logp": {"M": 1, "D": 2, "discrete": 13, "act_dim": 14, "avail": 16, "logp_out": 17, "old_logp": 18,
                              "factor": 19, "head_out": 21},
         "harl_update_bwd": {"M": 2, "D": 3, "H": 4},

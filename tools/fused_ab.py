@@ -84,9 +84,9 @@ def ab(rows: int, reps: int, discrete: bool = False):
             s = _lib.stream()
             if net.fused_update_ok(None):
                 _lib.call("harl_update_fwd_critic", *net.fused_args(so, rows), _lib.ptr(vp), _lib.ptr(ret), None, 0.2, 1, 1, 10.0,
-                          _lib.ptr(net.dz[0]), _lib.ptr(net.part_scalars), _lib.ptr(net.part[net._part_offs[-1]:]), net.n_wg, s,
-                          tag="update_fwd_critic")
-                net.backward_fused(rows)
+                          _lib.ptr(net.dz[0]), _lib.ptr(net.part_scalars), _lib.ptr(net.part[net._part_offs[-1]:]), net.n_wg,
+                          *net.hybrid_outputs(), s, tag="update_fwd_critic")
+                net.backward_after_fused(so, rows)
             else:
                 net.forward_trunk(so, None, rows)
                 Wp, bp = net._packs[-1]

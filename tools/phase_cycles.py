@@ -4,7 +4,8 @@
     HARL_LIB=phase python tools/phase_cycles.py            (on the MI355X box)
 
 Every instrumented kernel sums s_memtime deltas per phase over the slabs of wave 0 of workgroup 0 (csrc/common.h PHASE macros);
-this script runs one MPE update in the layer mode and one in the fused mode and prints the tables.
+this script runs one MPE update in the layer mode (HARL_FUSED_UPDATE=logp) and one in the default hybrid mode (fused forward,
+layer backward) and prints the tables.
 """
 import ctypes as C
 import os
@@ -60,7 +61,7 @@ def main():
     assert os.environ.get("HARL_LIB") == "phase", "run with HARL_LIB=phase"
     dev = torch.device("cuda:0")
     w = bench.WORKLOADS["mpe"]
-    for mode in ("logp", "1"):
+    for mode in ("logp", "hybrid"):
         os.environ["HARL_FUSED_UPDATE"] = mode
         r = bench.build_gpu_runner(w, w["N"], 0, 1, dev)
         bench.one_step(r)

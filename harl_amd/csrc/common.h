@@ -71,7 +71,11 @@ __device__ __forceinline__ constexpr int feat_base(int R) {  // f(R, 0)
 // The wave's index in its workgroup.  It is uniform across the wave, which the compiler cannot see through threadIdx.x >> 6:
 // readfirstlane tells it, and the slab counters, loop bounds and every address derived from them move to scalar registers
 // and the scalar ALU (fewer vector registers, fewer VALU slots in the slab loops).
+#ifdef HARL_NO_WAVE_ID  // A/B switch (tools): the plain vector-register wave index
+__device__ __forceinline__ int wave_id() { return (int)(threadIdx.x >> 6); }
+#else
 __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+#endif
 // a value that is the same in every lane of the wave, moved to a scalar register
 __device__ __forceinline__ float uniform_f(float v) {
   return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v)));

@@ -373,6 +373,8 @@ def main():
     if cw:
         region_tags = (max(cw, key=lambda k: cw[k]["total_ms"]),)
     if not args.no_kernel_timing:
+        if cw:  # two events per bracketed launch, created before the clock starts
+            _lib.reserve_timing_events(2 * (cw[region_tags[0]]["n"] + 8) * args.steps)
         _lib.enable_kernel_timing(True, None if args.time_all_tags else region_tags)
     t0 = time.perf_counter()
     for _ in range(args.steps):

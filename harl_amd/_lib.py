@@ -143,6 +143,15 @@ _timing_events: dict = {}
 _timing_tags = None
 
 
+_event_pool: list = []
+
+
+def reserve_timing_events(n: int) -> None:
+    """Create ``n`` timing events ahead of the launches that will use them."""
+    while len(_event_pool) < n:
+        _event_pool.append(torch.cuda.Event(enable_timing=True))
+
+
 def enable_kernel_timing(on: bool, tags=None) -> None:
     """Bracket tagged launches (all, or only those whose tag is in ``tags``) with HIP events on the launch stream
     (torch's current stream, which is the stream handed to the kernels).  Used by bench.py for the roofline figures."""
@@ -169,8 +178,9 @@ def collect_kernel_timing() -> dict:
 def call(name: str, *args, tag: Optional[str] = None) -> None:
     lib = load()
     if _timing_on and tag is not None and (_timing_tags is None or tag in _timing_tags):
-        a = torch.cuda.Event(enable_timing=True)
-        b = torch.cuda.Event(enable_timing=True)
+        # events come from a pool filled outside the timed region (hipEventCreate is not free on the launch path)
+        a = _event_pool.pop() if _event_pool else torch.cuda.Event(enable_timing=True)
+        b = _event_pool.pop() if _event_pool else torch.cuda.Event(enable_timing=True)
         a.record()
         rc = getattr(lib, name)(*args)
         b.record()

@@ -353,20 +353,26 @@ def main():
 
     # Roofline timing lives INSIDE the timed region: every launch of the DOMINANT streaming kernel family is bracketed by HIP
     # events on its launch stream.  Which family that is, is decided in the last warm-up step, where all of them are
-    # bracketed: an event pair between two kernels keeps the second from starting under the first one's tail, and bracketing
+    # bracketed (single stream): an event pair between two kernels keeps the second from starting under the first one's tail, and bracketing
     # all ~20 families inside the region cost 2.5-3 % of the step (MPE; 10-15 % for the launch-heavy 17-agent HATRPO step).
     ROOF_TAGS = ("fwd_fused2", "fwd_fused2_k64", "fwd_hidden", "bwd_dx", "bwd_dx_dw1", "dw_hidden", "fwd_wide", "dw_input",
                  "tangent_wide", "tangent_hidden", "gru_fwd", "gru_bwd", "update_fwd", "update_bwd", "update_logp",
-                 "update_fwd_critic", "fwd_panel", "bwd_panel")
+                 "update_fwd_critic", "update_last", "update_last_critic", "fwd_panel", "bwd_panel")
     warm_kern = {}
     for k in range(args.warmup):
         last = k == args.warmup - 1 and not args.no_kernel_timing and not args.time_all_tags
-        if last:
+        if last:  # (critic chain on the main stream for this step: per-launch durations without a second kernel sharing the chip)
+            prev_cs = os.environ.get("HARL_CRITIC_STREAM")
+            os.environ["HARL_CRITIC_STREAM"] = "0"
             _lib.enable_kernel_timing(True, ROOF_TAGS)
         one_step(r)
         if last:
             warm_kern = _lib.collect_kernel_timing()
             _lib.enable_kernel_timing(False)
+            if prev_cs is None:
+                os.environ.pop("HARL_CRITIC_STREAM", None)
+            else:
+                os.environ["HARL_CRITIC_STREAM"] = prev_cs
     barrier()
     region_tags = ROOF_TAGS
     cw = {k: v for k, v in warm_kern.items() if v["n"] > 0 and v.get("bytes")}
@@ -438,7 +444,7 @@ def main():
             # the same launches on the matrix pipe: bf16 MFMAs per 32-sample slab (static census of the compiled kernels,
             # profiles/r03_isa_census.md) x 32.3 cycles each (profiles/r03_mfma_valu_overlap.md) over 1024 SIMDs at 2.4 GHz
             mfma_slab = {"bwd_dx_dw1": 270, "bwd_dx": 192, "fwd_fused2": 240, "fwd_fused2_k64": 288, "fwd_hidden": 192,
-                         "dw_hidden": 192, "tangent_hidden": 384, "update_fwd": 315, "update_logp": 240}.get(dom)
+                         "dw_hidden": 192, "tangent_hidden": 384, "update_fwd": 315, "update_logp": 240, "update_last": 267}.get(dom)
             pipe = None
             if mfma_slab and not w.get("rnn"):
                 slabs = Tn * n_local / 32.0
@@ -455,8 +461,14 @@ def main():
                                "from each launch's own arguments (harl_amd/traffic.py)",
                         others={k: dict(hbm_frac=round(v["bytes"] / (v["total_ms"] * 1e-3) / HBM_PEAK, 4), n=v["n"],
                                         avg_ms=round(v["avg_ms"], 4)) for k, v in (cw or cand).items()},
-                        others_note="every streaming family, bracketed in the last warm-up step (the dominant one alone is "
-                                    "bracketed inside the timed region)")
+                        others_note="every streaming family, bracketed in the last warm-up step with the critic chain on the main "
+                                    "stream (the dominant one alone is bracketed inside the timed region)")
+            if args.config == "mpe":  # SURVEY.md 8(d) / BASELINE.md: 2 674 176 algorithmic FLOP per transition of this workload
+                roof["end_to_end"] = dict(
+                    flop_per_transition=2674176, achieved_tflops=2674176 * value / world / 1e12,
+                    frac_of_fp32_mfma_peak=2674176 * value / world / MFMA_F32_PEAK,
+                    note="whole step per GPU against SURVEY.md 8(d)'s roofline (58.8 M transitions/s per GPU = 100 % of the dense "
+                         "fp32-MFMA peak, 157.3 TFLOP/s); the GEMMs run on the bf16 pipe as six exact products")
             ks = kern.get(dom)
             if ks and ks.get("bytes") and not args.time_all_tags:
                 a1 = ks["bytes"] / (ks["total_ms"] * 1e-3)

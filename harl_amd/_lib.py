@@ -75,6 +75,8 @@ SIGNATURES = {
     "harl_update_supported": [_i, _i, _i],
     "harl_update_fwd_actor": [_vp, _l, _i, _i] + [_vp] * 7 + [_f, _f, _i, _i] + [_vp] * 7 + [_d, _f, _i, _i] + [_vp] * 4 + [_i] + [_vp] * 4,
     "harl_update_logp": [_vp, _l, _i, _i] + [_vp] * 7 + [_f, _f, _i, _i] + [_vp] * 5 + [_i, _vp, _vp],
+    "harl_update_last_actor": [_vp, _l, _i] + [_vp] * 5 + [_f, _f, _i, _i] + [_vp] * 8 + [_d, _f, _i, _i] + [_vp] * 4 + [_i, _vp],
+    "harl_update_last_critic": [_vp, _l, _i] + [_vp] * 8 + [_f, _i, _i, _f] + [_vp] * 3 + [_i, _vp],
     "harl_update_fwd_critic": [_vp, _l, _i, _i] + [_vp] * 9 + [_f, _i, _i, _f] + [_vp] * 3 + [_i] + [_vp] * 4,
     "harl_update_values": [_vp, _l, _i, _i] + [_vp] * 7 + [_vp],
     "harl_update_bwd": [_vp, _vp, _l, _i, _i] + [_vp] * 5 + [_i, _vp],

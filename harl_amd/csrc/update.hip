@@ -345,6 +345,11 @@ __global__ __launch_bounds__(UF_THREADS, 2) void k_upd_fwd(UpdFwdArgs U, ARGS A)
   constexpr bool CRITIC = std::is_same<ARGS, CriticArgs>::value;
   static_assert(DAP <= 8, "the LDS head-gradient tile covers 8 head outputs");
   constexpr int HROWS = CRITIC ? 1 : DAP;  // rows of the head weight gradient that can be non-zero
+  // KP0 == 0: the LAST hidden layer + head of a deeper network -- the input is x_hat_{L-1} as the previous layer kernel left
+  // it in HBM (an ATL(H) image, U.x0n), "layer 2" is layer L, and the backward that follows is the layer kernels' from
+  // dz_L on: x_hat_L, its mask and statistic never leave the chip (TRAIN only)
+  constexpr bool HID = KP0 == 0;
+  static_assert(!HID || TRAIN, "the last-layer variant exists for optimiser steps only");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int MT = H / 32, NJ1 = KP0 / 16, NJ2 = H / 16, NR = H / 2, NW = (NR + 31) / 32;
   u32x4 *w2img = reinterpret_cast<u32x4 *>(lds);   // reused as the head-gradient combine buffer at the end
@@ -356,9 +361,9 @@ __global__ __launch_bounds__(UF_THREADS, 2) void k_upd_fwd(UpdFwdArgs U, ARGS A)
   float *red = cst + 7 * DAP;              // [8][PS_STRIDE]
   float *hacc = red + UF_WAVES * PS_STRIDE;  // [8 waves][HROWS][H] head weight gradient, wave-private
   stage_split_matrix<H, H, false, UF_THREADS>(w2img, U.W2p);
-  stage_w1_images<H, KP0, UF_THREADS>(w1img, U.W1p, U.D);
+  if constexpr (!HID) stage_w1_images<H, KP0, UF_THREADS>(w1img, U.W1p, U.D);
   for (int e = threadIdx.x; e < H; e += UF_THREADS) {
-    b1l[e] = U.b1p[e];
+    if constexpr (!HID) b1l[e] = U.b1p[e];
     b2l[e] = U.b2p[e];
   }
   if (TRAIN)
@@ -427,8 +432,9 @@ __global__ __launch_bounds__(UF_THREADS, 2) void k_upd_fwd(UpdFwdArgs U, ARGS A)
 #pragma unroll
   for (int d = 0; d < (CRITIC ? DAP : 1); ++d) dbacc[d] = 0.f;
 
-  float xr[KP0 / 2];
-  atl_load<KP0>(U.x0n, slab0 < U.n_slabs ? slab0 : 0, lane, xr);
+  constexpr int NXR = HID ? NR : KP0 / 2;  // the next slab's input, one slab ahead: x0n (KP0 wide) or x_hat_{L-1} (H wide)
+  float xr[NXR];
+  atl_load<2 * NXR>(U.x0n, slab0 < U.n_slabs ? slab0 : 0, lane, xr);
   // the per-row loss inputs run ONE slab ahead of the arithmetic, as in k_actor_head (requested in the loss phase of the
   // previous slab): loaded at the top of the slab they belong to, the scheduler sank the (conditional, per-dimension) loads to
   // their first use under register pressure and the loss phase waited out their latency (phase timers, round 3: 15.8k cycles
@@ -446,7 +452,12 @@ __global__ __launch_bounds__(UF_THREADS, 2) void k_upd_fwd(UpdFwdArgs U, ARGS A)
     float r2;
     {
       float x1[NR];
-      {
+      if constexpr (HID) {
+#pragma unroll
+        for (int R = 0; R < NR; ++R) x1[R] = xr[R];
+        PHASE(0);
+        PHASE(1);
+      } else {
         u32x4 a1[NJ1], a2[NJ1], a3[NJ1];
         split_acts<KP0 / 2>(xr, a1, a2, a3);
         f32x16 acc[MT];
@@ -494,7 +505,7 @@ __global__ __launch_bounds__(UF_THREADS, 2) void k_upd_fwd(UpdFwdArgs U, ARGS A)
     const ActorRow<DAP> rcur = rnext;
     const float cvold = cvoldn, cret = cretn;
     const long sn = slab + slab_stride < U.n_slabs ? slab + slab_stride : slab;
-    if constexpr (!TRAIN) atl_load<KP0>(U.x0n, sn, lane, xr);  // the next slab's normalised inputs likewise (TRAIN: after the head dW)
+    if constexpr (!TRAIN) atl_load<2 * NXR>(U.x0n, sn, lane, xr);  // the next slab's normalised inputs likewise (TRAIN: after the head dW)
     if constexpr (!TRAIN && !CRITIC) actor_row_load<DAP, DISCRETE, TRAIN>(A, sn, lane, rnext);  // (TRAIN: at the end of the body)
     float dzh[DAP];
     float s1, s2;
@@ -562,7 +573,7 @@ __global__ __launch_bounds__(UF_THREADS, 2) void k_upd_fwd(UpdFwdArgs U, ARGS A)
         }
       }
       PHASE(7);
-      atl_load<KP0>(U.x0n, sn, lane, xr);
+      atl_load<2 * NXR>(U.x0n, sn, lane, xr);
       // ---- head backward (W_head'^T dzh on the fp32 MFMA) + LayerNorm / ReLU backward -> dz_2
       head_bwd_regs_bits<H, DAP>(xs, bits2[0], bits2[NW - 1], r2, slab, lane, whl, dzh, s1, s2, U.dz2);
       if constexpr (!CRITIC) actor_row_load<DAP, DISCRETE, TRAIN>(A, sn, lane, rnext);
@@ -662,6 +673,29 @@ int dispatch_fwd_actor(const UpdFwdArgs &U, const ActorArgs &A, int H, int discr
   return bad("harl_update_fwd: hidden width must be 64 or 128");
 }
 
+// last hidden layer + head of a deeper network (KP0 = 0 instantiations)
+int dispatch_last_actor(const UpdFwdArgs &U, const ActorArgs &A, int H, int discrete, hipStream_t s) {
+  const int D = A.act_dim;
+  if (D < 1 || D > 8) return bad("harl_update_last_actor: act_dim must be in [1, 8]");
+  const int dap = D <= 4 ? 4 : 8;
+#define CASE(Hv, DAPv)                                                               \
+  if (H == Hv && dap == DAPv) {                                                       \
+    if (discrete) launch_fwd<Hv, 0, DAPv, true, true, ActorArgs>(U, A, s);           \
+    else launch_fwd<Hv, 0, DAPv, false, true, ActorArgs>(U, A, s);                   \
+    return check_launch("harl_update_last_actor");                                   \
+  }
+  CASE(128, 4) CASE(128, 8) CASE(64, 4) CASE(64, 8)
+#undef CASE
+  return bad("harl_update_last_actor: hidden width must be 64 or 128");
+}
+
+int dispatch_last_critic(const UpdFwdArgs &U, const CriticArgs &A, int H, hipStream_t s) {
+  if (H == 128) launch_fwd<128, 0, 4, false, true, CriticArgs>(U, A, s);
+  else if (H == 64) launch_fwd<64, 0, 4, false, true, CriticArgs>(U, A, s);
+  else return bad("harl_update_last_critic: hidden width must be 64 or 128");
+  return check_launch("harl_update_last_critic");
+}
+
 template <bool TRAIN>
 int dispatch_fwd_critic(const UpdFwdArgs &U, const CriticArgs &A, int H, hipStream_t s) {
   const int kp0 = U.D <= 32 ? 32 : 64;
@@ -747,6 +781,48 @@ extern "C" int harl_update_fwd_critic(const float *x0n, long M, int D, int H, co
   A.part_scalars = part_scalars; A.n_slabs = U.n_slabs;
   A.dw_part = dw_part_head;
   return dispatch_fwd_critic<true>(U, A, H, (hipStream_t)stream);
+}
+
+extern "C" int harl_update_last_actor(const float *xin, long M, int H, const float *Wp, const float *bp, const float *Whp,
+                                      const float *bhp, const float *log_std, float std_x_coef, float std_y_coef,
+                                      int discrete, int act_dim, const int64_t *idx, const float *actions,
+                                      const float *avail, const float *old_logp, const float *adv,
+                                      const double *adv_moments, const float *factor, const float *active,
+                                      double clip_param, float entropy_coef, int agg_mean, int trpo, float *logp_out,
+                                      float *dz, float *part_scalars, float *dw_part_head, int n_part_rows, void *stream) {
+  if (M <= 0) return 0;
+  if (!xin || !dz || !part_scalars || !dw_part_head || n_part_rows <= 0) return bad("harl_update_last_actor: missing arguments");
+  UpdFwdArgs U{xin, nullptr, nullptr, Wp, bp, 0, n_slabs_of(M), dz, n_part_rows, nullptr, nullptr, nullptr};
+  if (fwd_grid(U.n_slabs) > n_part_rows) return bad("harl_update_last_actor: n_part_rows smaller than the launch grid");
+  ActorArgs A{};
+  A.trpo = trpo;
+  A.logp_out = logp_out;
+  A.dw_part = dw_part_head;
+  A.M = M; A.Whp = Whp; A.bhp = bhp; A.log_std = log_std;
+  A.std_x_coef = std_x_coef; A.std_y_coef = std_y_coef; A.act_dim = act_dim; A.idx = idx;
+  A.actions = actions; A.avail = avail; A.old_logp = old_logp; A.adv = adv; A.adv_moments = adv_moments;
+  A.factor_in = factor; A.active = active; A.entropy_coef = entropy_coef;
+  A.clip_lo = (float)(1.0 - clip_param); A.clip_hi = (float)(1.0 + clip_param);
+  A.agg_mean = agg_mean; A.part_scalars = part_scalars; A.n_slabs = U.n_slabs;
+  return dispatch_last_actor(U, A, H, discrete, (hipStream_t)stream);
+}
+
+extern "C" int harl_update_last_critic(const float *xin, long M, int H, const float *Wp, const float *bp, const float *Whp,
+                                       const float *bhp, const int64_t *idx, const float *value_preds, const float *returns,
+                                       const float *vn_stats, float clip_param, int use_clipped, int use_huber,
+                                       float huber_delta, float *dz, float *part_scalars, float *dw_part_head,
+                                       int n_part_rows, void *stream) {
+  if (M <= 0) return 0;
+  if (!xin || !dz || !part_scalars || !dw_part_head || n_part_rows <= 0) return bad("harl_update_last_critic: missing arguments");
+  UpdFwdArgs U{xin, nullptr, nullptr, Wp, bp, 0, n_slabs_of(M), dz, n_part_rows, nullptr, nullptr, nullptr};
+  if (fwd_grid(U.n_slabs) > n_part_rows) return bad("harl_update_last_critic: n_part_rows smaller than the launch grid");
+  CriticArgs A{};
+  A.M = M; A.Whp = Whp; A.bhp = bhp; A.idx = idx;
+  A.value_preds = value_preds; A.returns = returns; A.vn_stats = vn_stats; A.clip_param = clip_param;
+  A.huber_delta = huber_delta; A.use_clipped = use_clipped; A.use_huber = use_huber;
+  A.part_scalars = part_scalars; A.n_slabs = U.n_slabs;
+  A.dw_part = dw_part_head;
+  return dispatch_last_critic(U, A, H, (hipStream_t)stream);
 }
 
 extern "C" int harl_update_values(const float *x0n, long M, int D, int H, const float *W1p, const float *b1p,

@@ -231,6 +231,17 @@ class HAPPO(OnPolicyBase):
                  ptr(net.part[net._part_offs[-1]:]), net.n_wg, *net.hybrid_outputs(), s, tag="update_fwd")
             net.backward_after_fused(obs, m)
             return net.n_wg
+        if net.fused_last_ok(idx, seq):  # deeper networks: the last hidden layer runs inside the loss launch
+            L = len(net.hidden_sizes)
+            net.forward_trunk(obs, idx, m, upto=L - 1)
+            (Wl, bl), (Wh, bh) = net._packs[L - 1], net._packs[-1]
+            call("harl_update_last_actor", ptr(net.xh[L - 2]), m, net.hidden_sizes[-1], ptr(Wl), ptr(bl), ptr(Wh), ptr(bh),
+                 ptr(net.log_std()), net.std_x_coef, net.std_y_coef, int(net.discrete), net.act_dim, ptr(idx), ptr(actions),
+                 ptr(avail), ptr(old_logp), ptr(adv), ptr(adv_moments), ptr(factor), ptr(active), float(self.clip_param),
+                 float(self.entropy_coef), int(self.action_aggregation == "mean"), self._surrogate_mode, ptr(logp_out),
+                 ptr(net.dz[0]), ptr(net.part_scalars), ptr(net.part[net._part_offs[-1]:]), net.n_wg, s, tag="update_last")
+            net.backward_trunk(obs, idx, m, head_dw_done=True)
+            return net.n_wg
         net.forward_trunk(obs, idx, m, seq=seq)
         Wp, bp = net._packs[-1]
         fx, fmask, frstd, fh = net.feat()

@@ -395,7 +395,8 @@ class _FlatNet(nn.Module):
         self._fold_version = None
 
     def forward_trunk(self, X: torch.Tensor, idx: Optional[torch.Tensor], M: int, for_backward: bool = True,
-                      seq: Optional[dict] = None) -> None:
+                      seq: Optional[dict] = None, upto: Optional[int] = None) -> None:
+        """``upto``: stop after hidden layer ``upto`` (1-based; fused_last_ok: the last layer runs inside the loss launch)."""
         assert X.dim() == 2 and X.shape[1] == self.in_dim and X.is_contiguous()
         rnn_save = for_backward  # inference passes save no GRU internals (and take the latency variant of the kernel)
         if self.recurrent:
@@ -455,7 +456,8 @@ class _FlatNet(nn.Module):
             call("harl_mlp_fwd_input", ptr(X), X.shape[1], ptr(idx), M, self.in_dim, ptr(Wp), ptr(bp),
                  int(self.use_feature_normalization), hs[0], ptr(self.xh[0]), ptr(self.rmask[0]), ptr(self.rstd[0]),
                  ptr(self.mu0), ptr(self.rstd0), ptr(self.x0n) if for_backward else None, s, tag="fwd_input")
-        for l in range(first_hidden, len(hs)):
+        assert upto is None or upto >= first_hidden
+        for l in range(first_hidden, len(hs) if upto is None else upto):
             Wp, bp = self._packs[l]
             call("harl_mlp_fwd_hidden", ptr(self.xh[l - 1]), M, hs[l - 1], hs[l],
                  ptr(Wp), ptr(bp), ptr(self.xh[l]), ptr(self.rmask[l]), ptr(self.rstd[l]), s, tag="fwd_hidden")
@@ -479,6 +481,19 @@ class _FlatNet(nn.Module):
             return False
         return (not self.recurrent and not self.md and idx is None and seq is None
                 and len(hs) == 2 and hs[0] == hs[1] and hs[0] in (64, 128) and self.in_dim <= 64 and self._layers()[-1][4] <= 8)
+
+    def fused_last_ok(self, idx: Optional[torch.Tensor], seq: Optional[dict] = None) -> bool:
+        """Optimiser steps of networks the two-layer launch does not cover (three or more hidden layers, wide first layers,
+        minibatches): run the LAST hidden layer inside the loss launch (harl_update_last_*: x_hat_L never written)?
+        Needs ReLU, equal 64 / 128-wide last two layers, a head of <= 8 outputs, and a layer kernel in front that stops
+        before the last layer."""
+        hs = self.hidden_sizes
+        if os.environ.get("HARL_FUSED_UPDATE", "hybrid") != "hybrid" or self.act_id or self.recurrent or self.md or self.panel:
+            return False
+        if seq is not None or len(hs) < 2 or hs[-1] != hs[-2] or hs[-1] not in (64, 128) or self._layers()[-1][4] > 8:
+            return False
+        two_fused = hs[0] == hs[1] and ((self.in_dim <= 64 and idx is None) or self.in_dim <= 32)  # forward_trunk's first launch
+        return len(hs) >= (3 if two_fused else 2)
 
     def fused_hybrid(self) -> bool:
         """Optimiser steps as fused forward + layer-by-layer backward (see fused_update_ok)?"""

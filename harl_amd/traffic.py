@@ -137,6 +137,19 @@ def _update_fwd_critic(a: Sequence) -> float:
     return a[1] * (4.0 * _kp(a[2]) + 8.0 + 4.0 * a[3] + (_act(a[3]) if a[21] else 0.0))
 
 
+def _update_last_actor(a: Sequence) -> float:
+    # (xin, M, H, Wp, bp, Whp, bhp, log_std, sx, sy, discrete, act_dim, idx, actions, avail, old_logp, adv, adv_moments, factor,
+    #  active, clip, ent, agg_mean, trpo, logp_out, dz, ...): x_hat_{L-1} in, the loss rows, dz_L out
+    M, H, disc, ad = a[1], a[2], a[10], a[11]
+    w = 1 if disc else ad
+    return M * (4.0 * H + _head_rows(disc, ad, a[14]) + 4.0 + (4.0 if a[18] else 0.0) + (4.0 if a[19] else 0.0)
+                + (4.0 * w if a[24] else 0.0) + 4.0 * H)
+
+
+def _update_last_critic(a: Sequence) -> float:  # (xin, M, H, ...): x_hat_{L-1} in, value_preds + returns, dz_L out
+    return a[1] * (4.0 * a[2] + 8.0 + 4.0 * a[2])
+
+
 def _update_values(a: Sequence) -> float:
     return a[1] * (4.0 * _kp(a[2]) + 4.0)
 
@@ -185,6 +198,8 @@ ALGORITHMIC_BYTES: Dict[str, Callable[[Sequence], float]] = {
     "harl_update_logp": _update_logp,
     "harl_update_fwd_critic": _update_fwd_critic,
     "harl_update_values": _update_values,
+    "harl_update_last_actor": _update_last_actor,
+    "harl_update_last_critic": _update_last_critic,
     "harl_update_bwd": _update_bwd,
     "harl_gae_returns": _gae,
     "harl_mlp_panel_fwd": _panel_fwd,

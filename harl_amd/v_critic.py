@@ -97,6 +97,15 @@ class VCritic:
                  int(self.use_huber_loss), float(self.huber_delta), ptr(net.dz[0]), ptr(net.part_scalars),
                  ptr(net.part[net._part_offs[-1]:]), net.n_wg, *net.hybrid_outputs(), s, tag="update_fwd_critic")
             net.backward_after_fused(share_obs, m)
+        elif m > 0 and net.fused_last_ok(idx, seq):  # deeper networks: the last hidden layer runs inside the loss launch
+            L = len(net.hidden_sizes)
+            net.forward_trunk(share_obs, idx, m, upto=L - 1)
+            (Wl, bl), (Wh, bh) = net._packs[L - 1], net._packs[-1]
+            call("harl_update_last_critic", ptr(net.xh[L - 2]), m, net.hidden_sizes[-1], ptr(Wl), ptr(bl), ptr(Wh), ptr(bh),
+                 ptr(idx), ptr(value_preds), ptr(returns), ptr(vn.stats) if vn is not None else None, float(self.clip_param),
+                 int(self.use_clipped_value_loss), int(self.use_huber_loss), float(self.huber_delta), ptr(net.dz[0]),
+                 ptr(net.part_scalars), ptr(net.part[net._part_offs[-1]:]), net.n_wg, s, tag="update_last_critic")
+            net.backward_trunk(share_obs, idx, m, head_dw_done=True)
         elif m > 0:
             net.forward_trunk(share_obs, idx, m, seq=seq)
             Wp, bp = net._packs[-1]

@@ -391,6 +391,23 @@ int harl_update_fwd_critic(const float *x0n, long M, int D, int H, const float *
                            const float *returns, const float *vn_stats, float clip_param, int use_clipped, int use_huber,
                            float huber_delta, float *dz2, float *part_scalars, float *dw_part_head, int n_part_rows,
                            float *xh1, uint32_t *rmask1, float *rstd1, void *stream);
+/* Last hidden layer + head + loss of a network with MORE than two hidden layers (or a wide first layer), as one launch
+ * (k_upd_fwd with the previous layer's x_hat image as input): replaces harl_mlp_fwd_hidden(layer L) + harl_actor_head_loss /
+ * harl_critic_head_loss in the optimiser steps -- x_hat_L, its ReLU mask and statistic never cross HBM; dz_L, the head's
+ * weight-gradient partials and the loss partial sums come out exactly as the loss kernels write them, and the layer-by-layer
+ * backward runs behind it unchanged (reference: the same autograd graph, happo.py:28-102 / v_critic.py:116-157).
+ * xin = ATL(H) image of x_hat_{L-1} in batch order; idx (optional) gathers the per-row loss inputs as in the loss kernels. */
+int harl_update_last_actor(const float *xin, long M, int H, const float *Wp, const float *bp, const float *Whp,
+                           const float *bhp, const float *log_std, float std_x_coef, float std_y_coef, int discrete,
+                           int act_dim, const int64_t *idx, const float *actions, const float *avail,
+                           const float *old_logp, const float *adv, const double *adv_moments, const float *factor,
+                           const float *active, double clip_param, float entropy_coef, int agg_mean, int trpo,
+                           float *logp_out, float *dz, float *part_scalars, float *dw_part_head, int n_part_rows,
+                           void *stream);
+int harl_update_last_critic(const float *xin, long M, int H, const float *Wp, const float *bp, const float *Whp,
+                            const float *bhp, const int64_t *idx, const float *value_preds, const float *returns,
+                            const float *vn_stats, float clip_param, int use_clipped, int use_huber, float huber_delta,
+                            float *dz, float *part_scalars, float *dw_part_head, int n_part_rows, void *stream);
 int harl_update_values(const float *x0n, long M, int D, int H, const float *W1p, const float *b1p, const float *W2p,
                        const float *b2p, const float *Whp, const float *bhp, float *values, void *stream);
 int harl_update_bwd(const float *x0n, const float *dz2, long M, int D, int H, const float *W1p, const float *b1p,

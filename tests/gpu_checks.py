@@ -1194,11 +1194,11 @@ def check_generator_api(name: str) -> Dict[str, float]:
     return out
 
 
-def check_fused_vs_layered(rows: int, mode: str = "1") -> Dict[str, float]:
+def check_fused_vs_layered(rows: int, mode: str = "1", hidden=(128, 128), obs_dim: int = 18) -> Dict[str, float]:
     """csrc/update.hip (HARL_FUSED_UPDATE=``mode``: 1 or hybrid) against the layer-by-layer kernels (=0) on the same data: unscaled folded
     gradients, loss sums, first-epoch log-probs, log-prob pass + factor product; second fused run bit-identical."""
     import os
-    sh = Shapes(T=rows, N=1, A=1, obs_dim=18, share_obs_dim=54, act_dim=5, discrete=False, hidden_sizes=[128, 128])
+    sh = Shapes(T=rows, N=1, A=1, obs_dim=obs_dim, share_obs_dim=54, act_dim=5, discrete=False, hidden_sizes=list(hidden))
     d = make_buffers(sh, 3)
     actor, _, _ = _mk_actor(sh, 1)
     critic, _, _ = _mk_critic(sh, 2)

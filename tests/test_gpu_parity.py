@@ -249,7 +249,7 @@ def test_fused_update_kernels_single_update(i, mode, monkeypatch):
 
 @pytest.mark.parametrize("mode", ["hybrid", "1", "logp"])
 @pytest.mark.parametrize("name", ["mpe_box_h64", "mpe_box_h128", "mpe_disc_h64", "box_mean_inactive_novn", "a2c_box_h64",
-                                  "mappo_box_h64"])
+                                  "mappo_box_h64", "cheetah_h128x3_mb2"])
 def test_fused_update_kernels_train_golden(name, mode, monkeypatch):
     """Whole train() vs the reference's golden vectors with the optimiser steps routed through the fused forward + layer
     backward (hybrid, the default), the three fused launches (1) and the layer-by-layer kernels alone (logp)."""
@@ -263,6 +263,19 @@ def test_fused_update_kernels_many_slabs_per_wave(mode):
     cases are a slab or two per wave): folded gradients, loss sums, log-probs and the factor product, plus bit-exact
     run-to-run determinism."""
     res = _G().check_fused_vs_layered(32 * 8 * 256 * 2 + 7 * 32 + 3, mode=mode)
+    for k, v in res.items():
+        if "bitwise" in k:
+            assert v == 1.0, (k, v)
+        else:
+            assert v < 2e-5, (k, v)
+
+
+@pytest.mark.parametrize("hidden,obs_dim", [((128, 128, 128), 23), ((64, 64, 64), 18), ((128, 128), 100)])
+def test_last_layer_in_loss_launch_many_slabs_per_wave(hidden, obs_dim):
+    """harl_update_last_* (the last hidden layer inside the loss launch: networks with three or more hidden layers, or a wide
+    first layer) against the layer-by-layer kernels at a size where every wave walks several slabs: folded gradients, loss
+    sums, log-probs, critic gradients; bit-exact run-to-run."""
+    res = _G().check_fused_vs_layered(32 * 8 * 256 * 2 + 7 * 32 + 3, mode="hybrid", hidden=hidden, obs_dim=obs_dim)
     for k, v in res.items():
         if "bitwise" in k:
             assert v == 1.0, (k, v)

@@ -39,6 +39,9 @@ def test_argument_positions_match_the_header():
         "harl_update_fwd_actor": {"M": 1, "D": 2, "H": 3, "discrete": 13, "act_dim": 14, "avail": 16, "factor": 20,
                                   "active": 21, "logp_out": 26, "xh1": 31},
         "harl_update_fwd_critic": {"M": 1, "D": 2, "H": 3, "xh1": 21},
+        "harl_update_last_actor": {"M": 1, "H": 2, "discrete": 10, "act_dim": 11, "avail": 14, "factor": 18, "active": 19,
+                                   "logp_out": 24},
+        "harl_update_last_critic": {"M": 1, "H": 2},
         "harl_update_logp": {"M": 1, "D": 2, "discrete": 13, "act_dim": 14, "avail": 16, "logp_out": 17, "old_logp": 18,
                              "factor": 19, "head_out": 21},
         "harl_update_bwd": {"M": 2, "D": 3, "H": 4},

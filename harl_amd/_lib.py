@@ -72,7 +72,7 @@ SIGNATURES = {
     "harl_mlp_tangent_hidden": [_vp, _vp, _l, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "harl_actor_head_fvp": [_vp, _vp, _vp, _vp, _l, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _i, _vp, _l, _l, _vp, _vp, _vp],
     "harl_trpo_kl_sum": [_vp, _vp, _vp, _vp, _f, _f, _l, _i, _i, _vp, _vp],
-    "harl_update_supported": [_i, _i, _i],
+    "harl_update_supported": [_i, _i, _i, _i],
     "harl_update_fwd_actor": [_vp, _l, _i, _i] + [_vp] * 7 + [_f, _f, _i, _i] + [_vp] * 7 + [_d, _f, _i, _i] + [_vp] * 4 + [_i] + [_vp] * 4,
     "harl_update_logp": [_vp, _l, _i, _i] + [_vp] * 7 + [_f, _f, _i, _i] + [_vp] * 5 + [_i, _vp, _vp],
     "harl_update_last_actor": [_vp, _l, _i] + [_vp] * 5 + [_f, _f, _i, _i] + [_vp] * 8 + [_d, _f, _i, _i] + [_vp] * 4 + [_i, _vp],

@@ -648,11 +648,18 @@ size_t fwd_lds_bytes(int H, int kp0, int dap, int hrows) {
          ((size_t)2 * H + (size_t)2 * (H / 2) * dap + 7 * dap + UF_WAVES * PS_STRIDE + (size_t)UF_WAVES * hrows * H) * sizeof(float);
 }
 
+constexpr size_t LDS_PER_WG_MAX = 160 * 1024;  // gfx950: 160 KiB per CU
+
 template <int H, int KP0, int DAP, bool DISC, bool TRAIN, typename ARGS>
-void launch_fwd(const UpdFwdArgs &U, const ARGS &A, hipStream_t s) {
-  const size_t shm = fwd_lds_bytes(H, KP0, DAP, std::is_same<ARGS, CriticArgs>::value ? 1 : DAP);
+int launch_fwd(const UpdFwdArgs &U, const ARGS &A, hipStream_t s) {
+  // (the wave-private head-gradient tiles exist in optimiser steps only)
+  const size_t shm = fwd_lds_bytes(H, KP0, DAP, !TRAIN ? 0 : (std::is_same<ARGS, CriticArgs>::value ? 1 : DAP));
+  if (shm > LDS_PER_WG_MAX) {  // harl_update_supported() says so beforehand; never launch a kernel that cannot be resident
+    return bad("harl_update_*: this (D, H, act_dim) does not fit the LDS of one workgroup");
+  }
   allow_big_lds(k_upd_fwd<H, KP0, DAP, DISC, TRAIN, ARGS>, shm);
   hipLaunchKernelGGL((k_upd_fwd<H, KP0, DAP, DISC, TRAIN, ARGS>), dim3(fwd_grid(U.n_slabs)), dim3(UF_THREADS), shm, s, U, A);
+  return 0;
 }
 
 template <bool TRAIN>
@@ -663,9 +670,9 @@ int dispatch_fwd_actor(const UpdFwdArgs &U, const ActorArgs &A, int H, int discr
   const int kp0 = U.D <= 32 ? 32 : 64;
 #define CASE(Hv, Kv, DAPv)                                                             \
   if (H == Hv && kp0 == Kv && dap == DAPv) {                                            \
-    if (discrete) launch_fwd<Hv, Kv, DAPv, true, TRAIN, ActorArgs>(U, A, s);           \
-    else launch_fwd<Hv, Kv, DAPv, false, TRAIN, ActorArgs>(U, A, s);                   \
-    return check_launch("harl_update_fwd");                                            \
+    const int rc = discrete ? launch_fwd<Hv, Kv, DAPv, true, TRAIN, ActorArgs>(U, A, s)  \
+                            : launch_fwd<Hv, Kv, DAPv, false, TRAIN, ActorArgs>(U, A, s); \
+    return rc ? rc : check_launch("harl_update_fwd");                                  \
   }
   CASE(128, 32, 4) CASE(128, 32, 8) CASE(128, 64, 4) CASE(128, 64, 8)
   CASE(64, 32, 4) CASE(64, 32, 8) CASE(64, 64, 4) CASE(64, 64, 8)
@@ -680,9 +687,9 @@ int dispatch_last_actor(const UpdFwdArgs &U, const ActorArgs &A, int H, int disc
   const int dap = D <= 4 ? 4 : 8;
 #define CASE(Hv, DAPv)                                                               \
   if (H == Hv && dap == DAPv) {                                                       \
-    if (discrete) launch_fwd<Hv, 0, DAPv, true, true, ActorArgs>(U, A, s);           \
-    else launch_fwd<Hv, 0, DAPv, false, true, ActorArgs>(U, A, s);                   \
-    return check_launch("harl_update_last_actor");                                   \
+    const int rc = discrete ? launch_fwd<Hv, 0, DAPv, true, true, ActorArgs>(U, A, s)  \
+                            : launch_fwd<Hv, 0, DAPv, false, true, ActorArgs>(U, A, s); \
+    return rc ? rc : check_launch("harl_update_last_actor");                         \
   }
   CASE(128, 4) CASE(128, 8) CASE(64, 4) CASE(64, 8)
 #undef CASE
@@ -690,10 +697,11 @@ int dispatch_last_actor(const UpdFwdArgs &U, const ActorArgs &A, int H, int disc
 }
 
 int dispatch_last_critic(const UpdFwdArgs &U, const CriticArgs &A, int H, hipStream_t s) {
-  if (H == 128) launch_fwd<128, 0, 4, false, true, CriticArgs>(U, A, s);
-  else if (H == 64) launch_fwd<64, 0, 4, false, true, CriticArgs>(U, A, s);
+  int rc;
+  if (H == 128) rc = launch_fwd<128, 0, 4, false, true, CriticArgs>(U, A, s);
+  else if (H == 64) rc = launch_fwd<64, 0, 4, false, true, CriticArgs>(U, A, s);
   else return bad("harl_update_last_critic: hidden width must be 64 or 128");
-  return check_launch("harl_update_last_critic");
+  return rc ? rc : check_launch("harl_update_last_critic");
 }
 
 template <bool TRAIN>
@@ -701,8 +709,8 @@ int dispatch_fwd_critic(const UpdFwdArgs &U, const CriticArgs &A, int H, hipStre
   const int kp0 = U.D <= 32 ? 32 : 64;
 #define CASE(Hv, Kv)                                                     \
   if (H == Hv && kp0 == Kv) {                                            \
-    launch_fwd<Hv, Kv, 4, false, TRAIN, CriticArgs>(U, A, s);            \
-    return check_launch("harl_update_fwd");                              \
+    const int rc = launch_fwd<Hv, Kv, 4, false, TRAIN, CriticArgs>(U, A, s); \
+    return rc ? rc : check_launch("harl_update_fwd");                        \
   }
   CASE(128, 32) CASE(128, 64) CASE(64, 32) CASE(64, 64)
 #undef CASE
@@ -713,8 +721,13 @@ int dispatch_fwd_critic(const UpdFwdArgs &U, const CriticArgs &A, int H, hipStre
 
 HARL_PHASE_ACCESSOR(update)
 
-extern "C" int harl_update_supported(int D, int H, int act_dim) {
-  return (D >= 1 && D <= 64 && (H == 64 || H == 128) && act_dim >= 1 && act_dim <= 8) ? 1 : 0;
+extern "C" int harl_update_supported(int D, int H, int act_dim, int kind) {
+  if (!(D >= 0 && D <= 64 && (H == 64 || H == 128) && act_dim >= 1 && act_dim <= 8)) return 0;
+  // D = 0: the last-layer variant (harl_update_last_*).  An optimiser step also holds the wave-private head-gradient tiles
+  // in LDS: actors with 128-wide layers and 33..64 inputs do not fit (165 / 183 KiB for heads of <= 4 / <= 8 outputs)
+  const int dap = act_dim <= 4 ? 4 : 8;
+  const int hrows = kind == 0 ? 0 : (kind == 2 ? 1 : dap);  // forward-only pass / critic step (one head output) / actor step
+  return fwd_lds_bytes(H, D == 0 ? 0 : (D <= 32 ? 32 : 64), dap, hrows) <= LDS_PER_WG_MAX ? 1 : 0;
 }
 
 extern "C" int harl_update_fwd_actor(const float *x0n, long M, int D, int H, const float *W1p, const float *b1p,

@@ -479,8 +479,13 @@ class _FlatNet(nn.Module):
             return False
         if mode == "0" or (train and mode == "logp") or (train and mode == "actor" and isinstance(self, VNet)):
             return False
-        return (not self.recurrent and not self.md and idx is None and seq is None
-                and len(hs) == 2 and hs[0] == hs[1] and hs[0] in (64, 128) and self.in_dim <= 64 and self._layers()[-1][4] <= 8)
+        if not (not self.recurrent and not self.md and idx is None and seq is None
+                and len(hs) == 2 and hs[0] == hs[1] and hs[0] in (64, 128) and self.in_dim <= 64 and self._layers()[-1][4] <= 8):
+            return False
+        # ... and the launch must fit the LDS of one workgroup (the ACTOR step of a 128-wide network with 33..64 inputs does not:
+        # the layer kernels take it)
+        kind = 0 if not train else (2 if isinstance(self, VNet) else 1)
+        return bool(_lib.load().harl_update_supported(self.in_dim, hs[0], self._layers()[-1][4], kind))
 
     def fused_last_ok(self, idx: Optional[torch.Tensor], seq: Optional[dict] = None) -> bool:
         """Optimiser steps of networks the two-layer launch does not cover (three or more hidden layers, wide first layers,
@@ -493,7 +498,7 @@ class _FlatNet(nn.Module):
         if seq is not None or len(hs) < 2 or hs[-1] != hs[-2] or hs[-1] not in (64, 128) or self._layers()[-1][4] > 8:
             return False
         two_fused = hs[0] == hs[1] and ((self.in_dim <= 64 and idx is None) or self.in_dim <= 32)  # forward_trunk's first launch
-        return len(hs) >= (3 if two_fused else 2)
+        return len(hs) >= (3 if two_fused else 2) and bool(_lib.load().harl_update_supported(0, hs[-1], self._layers()[-1][4], 2 if isinstance(self, VNet) else 1))
 
     def fused_hybrid(self) -> bool:
         """Optimiser steps as fused forward + layer-by-layer backward (see fused_update_ok)?"""

@@ -373,8 +373,11 @@ int harl_md_head_loss(const float *const *z, float *const *dz, int n_groups, con
  *   record (x_hat_1 as an ATL image, ReLU mask words, 1/sigma) in HBM, in the format of harl_mlp_fwd_fused2x, so that the
  *   layer-by-layer backward (harl_mlp_bwd_dx + harl_mlp_dw_partials) runs behind it instead of harl_update_bwd: x_hat_2,
  *   its mask and statistic still never leave the chip, and nothing is recomputed.
- * harl_update_supported returns 1 when (D, H, act_dim) is inside the instantiated range (D <= 64, H in {64,128}, act_dim <= 8). */
-int harl_update_supported(int D, int H, int act_dim);
+ * harl_update_supported returns 1 when (D, H, act_dim) is inside the instantiated range (D <= 64, H in {64,128}, act_dim <= 8;
+ *   D = 0: the last-layer entry points) AND the launch fits the 160 KiB of LDS a workgroup can have.  `kind`: 0 forward-only
+ *   pass, 1 actor optimiser step, 2 critic optimiser step (an optimiser step also keeps wave-private head-gradient tiles in
+ *   LDS: the ACTOR step of a 128-wide network with 33..64 inputs does not fit). */
+int harl_update_supported(int D, int H, int act_dim, int kind);
 int harl_update_fwd_actor(const float *x0n, long M, int D, int H, const float *W1p, const float *b1p, const float *W2p,
                           const float *b2p, const float *Whp, const float *bhp, const float *log_std, float std_x_coef,
                           float std_y_coef, int discrete, int act_dim, const float *actions, const float *avail,

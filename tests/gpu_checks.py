@@ -262,6 +262,9 @@ FWD_SHAPES = [
     # hidden width 256 (csrc/panel.hip): the reference's dexhands shapes (obs 422 / 398, 20-26 Box actions, [256, 256, 256])
     dict(name="hands_256x3_box20", obs_dim=211, share_obs_dim=200, act_dim=20, discrete=False, hidden_sizes=[256, 256, 256], M=700),
     dict(name="narrow_256x2_disc6", obs_dim=24, share_obs_dim=40, act_dim=6, discrete=True, hidden_sizes=[256, 256], M=333),
+    # 33..64 inputs into 128-wide layers: the actor's fused optimiser step does not fit the LDS (harl_update_supported says no
+    # -> layer kernels), its forward-only passes and the critic's step do (154 / 160 KiB)
+    dict(name="obs40_box6_h128", obs_dim=40, share_obs_dim=64, act_dim=6, discrete=False, hidden_sizes=[128, 128], M=900),
 ]
 
 

@@ -228,3 +228,16 @@ def test_host_rng_instruction_set_paths_agree(monkeypatch):
         st2 = torch.empty_like(mid)
         assert lib.harl_rng_advance(mid.data_ptr(), mid.numel(), n - 1, st2.data_ptr()) == 0
         assert bool(torch.equal(st2, want_state)), isa
+
+
+def test_update_supported_accounts_for_lds():
+    """harl_update_supported(D, H, act_dim, kind): the instantiated range AND the 160 KiB of LDS a workgroup can have
+    (kind 0 forward-only, 1 actor step, 2 critic step).  No GPU needed: pure host arithmetic of the library."""
+    from harl_amd import _lib
+    f = _lib.load().harl_update_supported
+    assert f(18, 128, 5, 1) == 1 and f(18, 128, 5, 0) == 1          # the MPE actor
+    assert f(54, 128, 1, 2) == 1 and f(64, 128, 1, 2) == 1          # critics with up to 64 inputs
+    assert f(40, 128, 5, 1) == 0 and f(40, 128, 4, 1) == 0          # actor step, 33..64 inputs, 128 wide: 183 / 165 KiB
+    assert f(40, 128, 5, 0) == 1                                    # ... its log-prob passes fit
+    assert f(40, 64, 8, 1) == 1 and f(0, 128, 8, 1) == 1 and f(0, 64, 3, 2) == 1
+    assert f(65, 128, 5, 1) == 0 and f(18, 96, 5, 1) == 0 and f(18, 128, 9, 1) == 0

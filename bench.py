@@ -460,9 +460,11 @@ def main():
                         timing="HIP events around every launch of the streaming kernel families inside the timed region; bytes "
                                "from each launch's own arguments (harl_amd/traffic.py)",
                         others={k: dict(hbm_frac=round(v["bytes"] / (v["total_ms"] * 1e-3) / HBM_PEAK, 4), n=v["n"],
-                                        avg_ms=round(v["avg_ms"], 4)) for k, v in (cw or cand).items()},
-                        others_note="every streaming family, bracketed in the last warm-up step with the critic chain on the main "
-                                    "stream (the dominant one alone is bracketed inside the timed region)")
+                                        avg_ms=round(v["avg_ms"], 4))
+                                for k, v in ({t: x for t, x in kern.items() if t in ROOF_TAGS and x["n"] > 0 and x.get("bytes")}
+                                             or cw or cand).items()},
+                        others_note="every streaming family in the instrumented single-stream steps after the timed region (the "
+                                    "dominant one -- chosen in the last warm-up step -- alone is bracketed inside the region)")
             if args.config == "mpe":  # SURVEY.md 8(d) / BASELINE.md: 2 674 176 algorithmic FLOP per transition of this workload
                 roof["end_to_end"] = dict(
                     flop_per_transition=2674176, achieved_tflops=2674176 * value / world / 1e12,

@@ -470,6 +470,10 @@ __device__ __forceinline__ void actor_row_load(const ActorArgs &A, long slab, in
     R.act = A.active ? A.active[row] : 1.f;
     R.adv = A.adv[row];
     R.fct = A.factor_in ? A.factor_in[row] : 1.f;
+  } else {
+    // factor product pass: the OLD factor of the row travels with the other row inputs (one slab ahead in the callers that
+    // prefetch) instead of being loaded, waited for and written back inside the sample arithmetic; every row is touched once
+    R.fct = A.factor_out ? A.factor_out[jc] : 1.f;
   }
 }
 
@@ -572,7 +576,7 @@ __device__ __forceinline__ bool actor_sample(const ActorArgs &A, const float *cs
             if (d < D) A.logp_out[j * D + d] = logp_d[d];
         }
       }
-      if (A.factor_out) A.factor_out[j] = A.factor_out[j] * imp;  // on_policy_ha_runner.py:116-124
+      if (A.factor_out) A.factor_out[j] = R.fct * imp;  // on_policy_ha_runner.py:116-124 (R.fct = the row's old factor, j < M here)
     }
     return false;
   }

@@ -1,16 +1,22 @@
-// update.hip -- the optimiser step of a two-hidden-layer MLP actor / critic with narrow inputs (D <= 64) as THREE launches
-// that keep every activation on chip (gfx950).
+// update.hip -- the optimiser step of a two-hidden-layer MLP actor / critic with narrow inputs (D <= 64), with as many
+// activations as possible kept on chip (gfx950).
 //
 //   k_upd_fwd : x0n -> layer 1 -> layer 2 -> head -> loss -> head backward -> LayerNorm/ReLU backward -> dz_2   (+ head dW)
-//   k_upd_dw2 : x0n, dz_2 -> x_hat_1 (recomputed) -> dW_2' = dz_2^T x_hat_1, db_2'
-//   k_upd_dx  : x0n, dz_2 -> x_hat_1 (recomputed), dx_hat_1 = W_2'^T dz_2 -> dz_1 -> dW_1' = dz_1^T x0n, db_1'
+//               HYBRID step (default): also writes layer 1's activation record (x_hat_1, ReLU mask, 1/sigma); the backward is
+//               the layer kernels' (harl_mlp_bwd_dx + harl_mlp_dw_partials, mlp.hip).  x_hat_2, its mask and statistic never
+//               cross HBM: ~3.5 KB per sample and update against ~4.5 KB for the layer-by-layer step, one launch less.
+//               KP0 = 0 instantiations: the LAST hidden layer + head of deeper networks (input = x_hat_{L-1} from HBM).
+//               !TRAIN instantiations: log-prob / factor-product / value passes (forward only).
+//   k_upd_dw2 : x0n, dz_2 -> x_hat_1 (recomputed) -> dW_2' = dz_2^T x_hat_1, db_2'                       } HARL_FUSED_UPDATE=1:
+//   k_upd_dx  : x0n, dz_2 -> x_hat_1 (recomputed), dx_hat_1 = W_2'^T dz_2 -> dz_1 -> dW_1' = dz_1^T x0n, db_1' } the fully fused step
 //
-// Replaces, for this network shape, harl_mlp_fwd_fused2x + harl_actor_head_loss / harl_critic_head_loss +
+// The fully fused step replaces, for this network shape, harl_mlp_fwd_fused2x + harl_actor_head_loss / harl_critic_head_loss +
 // harl_mlp_dw_partials(hidden) + harl_mlp_bwd_dx (reference: autograd through MLPBase + ACTLayer / v_out,
 // harl/algorithms/actors/happo.py:28-102, harl/algorithms/critics/v_critic.py:116-157).  HBM traffic per sample and
 // optimiser step: x0n 3 x 128 B (256 B for D > 32) + the loss row inputs in, dz_2 512 B out and 2 x 512 B in -- about
-// 1.9 KB against 4.5 KB for the layer-by-layer kernels, which wrote x_hat_1, x_hat_2, both ReLU masks and dz_2 and read
-// them back.  x_hat_1 is recomputed from the 128-byte normalised-input image (48 MFMAs) instead of being stored.
+// 1.9 KB -- with x_hat_1 recomputed from the 128-byte normalised-input image (48 MFMAs) instead of being stored.  Measured on
+// MI355X its backward half is SLOWER than the layer kernels (more instructions for fewer bytes), so the
+// default keeps only the forward half.
 //
 // Transposes on the matrix pipe.  A weight gradient contracts over SAMPLES, but activations live as "lane = sample"
 // (common.h).  Multiplying a split operand (as the A operand, M = sample) by a permuted identity (B) yields the block in the

@@ -265,6 +265,9 @@ FWD_SHAPES = [
     # 33..64 inputs into 128-wide layers: the actor's fused optimiser step does not fit the LDS (harl_update_supported says no
     # -> layer kernels), its forward-only passes and the critic's step do (154 / 160 KiB)
     dict(name="obs40_box6_h128", obs_dim=40, share_obs_dim=64, act_dim=6, discrete=False, hidden_sizes=[128, 128], M=900),
+    # Categorical heads on networks whose last layer runs inside the loss launch (harl_update_last_*, DISCRETE instantiations)
+    dict(name="disc6_3x64", obs_dim=30, share_obs_dim=45, act_dim=6, discrete=True, hidden_sizes=[64, 64, 64], M=1500),
+    dict(name="disc3_wide_2x128", obs_dim=90, share_obs_dim=70, act_dim=3, discrete=True, hidden_sizes=[128, 128], M=700),
 ]
 
 

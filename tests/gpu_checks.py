@@ -268,6 +268,9 @@ FWD_SHAPES = [
     # Categorical heads on networks whose last layer runs inside the loss launch (harl_update_last_*, DISCRETE instantiations)
     dict(name="disc6_3x64", obs_dim=30, share_obs_dim=45, act_dim=6, discrete=True, hidden_sizes=[64, 64, 64], M=1500),
     dict(name="disc3_wide_2x128", obs_dim=90, share_obs_dim=70, act_dim=3, discrete=True, hidden_sizes=[128, 128], M=700),
+    # remaining instantiations of the fused forward + loss launch: 64-wide with 33..64 inputs, 128-wide with a <= 4-way Gaussian head
+    dict(name="obs50_box4_h64", obs_dim=50, share_obs_dim=33, act_dim=4, discrete=False, hidden_sizes=[64, 64], M=1100),
+    dict(name="obs20_box2_h128", obs_dim=20, share_obs_dim=28, act_dim=2, discrete=False, hidden_sizes=[128, 128], M=800),
 ]
 
 

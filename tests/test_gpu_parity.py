@@ -51,13 +51,13 @@ def test_fused_gradnorm_clip_adam():
     _assert_all(_G().check_adam(), tol=2e-6)
 
 
-@pytest.mark.parametrize("i", range(12))
+@pytest.mark.parametrize("i", range(14))
 def test_mlp_forward_logp_and_values(i):
     G = _G()
     _assert_all(G.check_forward(G.FWD_SHAPES[i]), tol=TOL)
 
 
-@pytest.mark.parametrize("i", range(12))
+@pytest.mark.parametrize("i", range(14))
 def test_single_update_gradients(i):
     G = _G()
     _assert_all(G.check_gradients(G.FWD_SHAPES[i]), tol=TOL)

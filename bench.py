@@ -21,6 +21,9 @@ Gradients / loss scalars are all-reduced over RCCL each optimiser step (one mess
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P \\
         bench.py --gpus 8 --steps 5 --warmup 2
 
+The default run (mpe) appends the three other BASELINE workloads (3 steps each, fresh runners, AFTER the headline region and the
+CPU baseline) to the same line as `other_configs` (`--no-other-configs` to skip).
+
 Prints ONE JSON line (rank 0).  `roofline`: the streaming kernel family with the largest total time per step (decided in the
 last warm-up step, where every family is bracketed by HIP events; inside the timed region only that family is) -- achieved =
 algorithmic HBM bytes of its launches in the timed region (harl_amd/traffic.py, from each launch's own arguments) / their
@@ -232,6 +235,189 @@ def cpu_baseline(w: dict, n_cols: int, threads: int, reps: int = 3) -> dict:
                        "(these nets are small: more threads is slower)")
 
 
+def measure(w: dict, cfg_name: str, args, comm, rank: int, world: int, device, n_local: int, steps: int, warmup: int,
+            instr_steps: int):
+    """Build the runner of one workload, warm up, time `steps` steps between barriers and collect the per-kernel figures.
+    Returns the JSON record of this workload on rank 0 (None elsewhere)."""
+    from harl_amd import _lib
+
+    Tn = w["T"]
+    r = build_gpu_runner(w, n_local, rank, world, device, args.logp)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if comm.enabled:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    # Roofline timing lives INSIDE the timed region: every launch of the DOMINANT streaming kernel family is bracketed by HIP
+    # events on its launch stream.  Which family that is, is decided in the last warm-up step, where all of them are
+    # bracketed (single stream): an event pair between two kernels keeps the second from starting under the first one's tail, and bracketing
+    # all ~20 families inside the region cost 2.5-3 % of the step (MPE; 10-15 % for the launch-heavy 17-agent HATRPO step).
+    ROOF_TAGS = ("fwd_fused2", "fwd_fused2_k64", "fwd_hidden", "bwd_dx", "bwd_dx_dw1", "dw_hidden", "fwd_wide", "dw_input",
+                 "tangent_wide", "tangent_hidden", "gru_fwd", "gru_bwd", "update_fwd", "update_bwd", "update_logp",
+                 "update_fwd_critic", "update_last", "update_last_critic", "fwd_panel", "bwd_panel")
+    warm_kern = {}
+    for k in range(warmup):
+        last = k == warmup - 1 and not args.no_kernel_timing and not args.time_all_tags
+        if last:  # (critic chain on the main stream for this step: per-launch durations without a second kernel sharing the chip)
+            prev_cs = os.environ.get("HARL_CRITIC_STREAM")
+            os.environ["HARL_CRITIC_STREAM"] = "0"
+            _lib.enable_kernel_timing(True, ROOF_TAGS)
+        one_step(r)
+        if last:
+            warm_kern = _lib.collect_kernel_timing()
+            _lib.enable_kernel_timing(False)
+            if prev_cs is None:
+                os.environ.pop("HARL_CRITIC_STREAM", None)
+            else:
+                os.environ["HARL_CRITIC_STREAM"] = prev_cs
+    barrier()
+    region_tags = ROOF_TAGS
+    cw = {k: v for k, v in warm_kern.items() if v["n"] > 0 and v.get("bytes")}
+    if cw:
+        region_tags = (max(cw, key=lambda k: cw[k]["total_ms"]),)
+    if not args.no_kernel_timing:
+        if cw:  # two events per bracketed launch, created before the clock starts
+            _lib.reserve_timing_events(2 * (cw[region_tags[0]]["n"] + 8) * steps)
+        _lib.enable_kernel_timing(True, None if args.time_all_tags else region_tags)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one_step(r)
+    barrier()
+    dt = time.perf_counter() - t0
+    roof_kern = {}
+    if not args.no_kernel_timing:
+        roof_kern = _lib.collect_kernel_timing()
+        _lib.enable_kernel_timing(False)
+    if comm.enabled:
+        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt.item())
+    # Full per-kernel breakdown (every tagged launch, ~10 % of wall time): `instr_steps` further steps of the SAME
+    # workload after the timed region, so that it does not understate `value`.
+    kern = dict(roof_kern) if args.time_all_tags else {}
+    if not args.no_kernel_timing and instr_steps > 0:
+        # (ONE stream here: in the timed region the critic's update runs on a stream of its own next to the actors' chain,
+        # so two kernels share the chip and every per-launch duration contains its neighbour's slices; the per-kernel table
+        # and `roofline.single_stream` are taken with the critic chain back on the main stream)
+        prev_cs = os.environ.get("HARL_CRITIC_STREAM")
+        os.environ["HARL_CRITIC_STREAM"] = "0"
+        _lib.enable_kernel_timing(True)
+        for _ in range(instr_steps):
+            one_step(r)
+        kern = _lib.collect_kernel_timing()
+        _lib.enable_kernel_timing(False)
+        if prev_cs is None:
+            os.environ.pop("HARL_CRITIC_STREAM", None)
+        else:
+            os.environ["HARL_CRITIC_STREAM"] = prev_cs
+
+    if rank != 0:
+        return None
+    if True:
+        trans_per_step = Tn * n_local * world
+        value = trans_per_step * steps / dt
+        # dominant kernel = the streaming family with the largest total time inside the timed region; `achieved` =
+        # algorithmic bytes of the launches that ran (harl_amd/traffic.py) / their HIP-event time.  The GEMMs run on the
+        # bf16 matrix pipe (exact three-way fp32 split, 6 products: csrc/split_mfma.h) and are bound by instruction issue and
+        # HBM together (DESIGN.md 4): the fraction of the HBM roof is the contract's figure, `matrix_pipe_frac` of the
+        # dominant GEMM is reported next to it where a FLOP model exists.
+        cand = {k: v for k, v in roof_kern.items() if v["n"] > 0 and v.get("bytes")}
+        roof = None
+        if cand:
+            dom = max(cand, key=lambda k: cand[k]["total_ms"])
+            tot_s = cand[dom]["total_ms"] * 1e-3
+            ach = cand[dom]["bytes"] / tot_s
+            per_launch = cand[dom]["bytes"] / cand[dom]["n"]
+            traffic, traffic_note = None, None
+            tp = next((q for q in (os.path.join(ROOT, "profiles", f"r0{k}_hbm_traffic.json") for k in (3, 2)) if os.path.exists(q)),
+                      os.path.join(ROOT, "profiles", "r03_hbm_traffic.json"))
+            if os.path.exists(tp):  # PMC passes over the same kernels at this workload's shapes (tools/pmc_traffic.sh)
+                tj = json.load(open(tp))
+                ent = tj.get("workloads", {}).get(cfg_name, {}).get(dom)
+                if ent:
+                    traffic = ent["ratio"] * per_launch / 1e9
+                    traffic_note = (f"GB per launch = {ent['ratio']:.3f} (HBM bytes measured by rocprofv3 --pmc, FETCH_SIZE and "
+                                    f"WRITE_SIZE in separate passes with the guide's gfx950 unit corrections, / algorithmic bytes "
+                                    f"of the same launches; taken at commit {tj.get('git_sha')}, profiles/{os.path.basename(tp)[:-5]}.md) x "
+                                    f"{per_launch / 1e9:.4f} GB algorithmic per launch in this run")
+            # the same launches on the matrix pipe: bf16 MFMAs per 32-sample slab (static census of the compiled kernels,
+            # profiles/r03_isa_census.md) x 32.3 cycles each (profiles/r03_mfma_valu_overlap.md) over 1024 SIMDs at 2.4 GHz
+            mfma_slab = {"bwd_dx_dw1": 270, "bwd_dx": 192, "fwd_fused2": 240, "fwd_fused2_k64": 288, "fwd_hidden": 192,
+                         "dw_hidden": 192, "tangent_hidden": 384, "update_fwd": 315, "update_logp": 240, "update_last": 267}.get(dom)
+            pipe = None
+            if mfma_slab and not w.get("rnn"):
+                slabs = Tn * n_local / 32.0
+                pipe = slabs * mfma_slab * 32.3 / (1024 * 2.4e9) / (cand[dom]["avg_ms"] * 1e-3)
+            roof = dict(kernel=dom, bound="hbm", achieved=ach / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s", frac=ach / HBM_PEAK,
+                        hbm_frac=ach / HBM_PEAK, matrix_pipe_frac=pipe,
+                        bound_note="streaming GEMM kernels between two roofs: `frac` = algorithmic bytes / time against the 8 TB/s "
+                                   "HBM peak (the contract's figure); `matrix_pipe_frac` = the launch's bf16 MFMAs x 32.3 cycles "
+                                   "against the time all 1024 SIMDs have at 2.4 GHz.  Neither is saturated: VALU work of the "
+                                   "exact bf16 split / LayerNorm / ReLU sits in separate phases of the same waves (DESIGN.md 3)",
+                        traffic=traffic, traffic_note=traffic_note, launches=cand[dom]["n"], avg_ms=cand[dom]["avg_ms"],
+                        bytes_per_launch=per_launch,
+                        timing="HIP events around every launch of the streaming kernel families inside the timed region; bytes "
+                               "from each launch's own arguments (harl_amd/traffic.py)",
+                        others={k: dict(hbm_frac=round(v["bytes"] / (v["total_ms"] * 1e-3) / HBM_PEAK, 4), n=v["n"],
+                                        avg_ms=round(v["avg_ms"], 4))
+                                for k, v in ({t: x for t, x in kern.items() if t in ROOF_TAGS and x["n"] > 0 and x.get("bytes")}
+                                             or cw or cand).items()},
+                        others_note="every streaming family in the instrumented single-stream steps after the timed region (the "
+                                    "dominant one -- chosen in the last warm-up step -- alone is bracketed inside the region)")
+            if cfg_name == "mpe":  # SURVEY.md 8(d) / BASELINE.md: 2 674 176 algorithmic FLOP per transition of this workload
+                roof["end_to_end"] = dict(
+                    flop_per_transition=2674176, achieved_tflops=2674176 * value / world / 1e12,
+                    frac_of_fp32_mfma_peak=2674176 * value / world / MFMA_F32_PEAK,
+                    note="whole step per GPU against SURVEY.md 8(d)'s roofline (58.8 M transitions/s per GPU = 100 % of the dense "
+                         "fp32-MFMA peak, 157.3 TFLOP/s); the GEMMs run on the bf16 pipe as six exact products")
+            ks = kern.get(dom)
+            if ks and ks.get("bytes") and not args.time_all_tags:
+                a1 = ks["bytes"] / (ks["total_ms"] * 1e-3)
+                roof["single_stream"] = dict(
+                    achieved=a1 / 1e9, frac=a1 / HBM_PEAK, avg_ms=ks["avg_ms"], launches=ks["n"],
+                    matrix_pipe_frac=(pipe * cand[dom]["avg_ms"] / ks["avg_ms"]) if pipe else None,
+                    note=f"the same kernel family in the {instr_steps} instrumented steps after the timed region, critic chain on the "
+                         "main stream (HARL_CRITIC_STREAM=0): per-launch durations without a second kernel sharing the chip")
+        out = dict(
+            metric=w["metric"], value=value, unit="transitions/s", n_gpus=world, steps=steps, warmup=warmup,
+            ms_per_step=dt / steps * 1e3, higher_is_better=True, scaling=args.scaling, vs_baseline=None, dtype="f32",
+            dtype_note="fp32 data, statistics and accumulators; GEMM operands are split EXACTLY into three bf16 each and "
+                       "multiplied as six cross products on v_mfma_f32_32x32x16_bf16 (error <= the fp32 MFMA's fmaf chain: "
+                       "profiles/r01_mfma_bf16x3.txt)",
+            data=f"synthetic (SURVEY.md 8d recipe, generated on the device; stored log-probs: {args.logp})",
+            config=dict(workload=f"{w['name']}: compute_returns + train(), T={Tn}, n_rollout_threads={n_local}/GPU "
+                                 f"({n_local * world} global, {args.scaling} scaling), obs{w['obs']}/share{w['sobs']}/"
+                                 f"{'Discrete' if w['disc'] else 'Box'}{w['act']}, MLP{w['hidden']}{' + GRU' if w.get('rnn') else ''}, "
+                                 f"{'ppo_epoch=5, ' if w['algo'] == 'happo' else 'CG 10 + line search, '}critic_epoch=5",
+                        baseline_config=cfg_name, episode_length=Tn, n_rollout_threads_per_gpu=n_local, n_agents=w["A"],
+                        parallelism=f"dp{world}", collective="rccl" if comm.enabled else "none",
+                        world_size=torch.distributed.get_world_size() if comm.enabled else 1, git_sha=git_sha()),
+            roofline=roof,
+            kernels={k: dict(n=v["n"], avg_ms=round(v["avg_ms"], 4), total_ms=round(v["total_ms"], 3),
+                             **({"hbm_frac": round(v["bytes"] / (v["total_ms"] * 1e-3) / HBM_PEAK, 4), "alg_bytes": v["bytes"]}
+                                if v.get("bytes") else {}))
+                     for k, v in kern.items()},
+            kernel_timing=f"`kernels`: HIP events around every tagged launch, {instr_steps} instrumented single-stream steps after the timed region",
+        )
+        if w["algo"] == "happo":
+            e2e = flops_per_transition(w) * value
+            out["end_to_end"] = dict(algorithmic_tflops=e2e / 1e12, frac_of_fp32_mfma_peak=e2e / (MFMA_F32_PEAK * world),
+                                     flops_per_transition=flops_per_transition(w))
+        # executed-pass count: the Linear-layer FLOPs of the launches that actually ran in the instrumented steps (each launch's
+        # own arguments, harl_amd/traffic.py ALGORITHMIC_FLOPS) -- the only end-to-end figure HATRPO has (CG / line-search
+        # trip counts are data dependent); for HAPPO it is the closed form minus the pre-update pass shared with epoch 0
+        ex = sum(v.get("flops") or 0.0 for v in kern.values())
+        if ex > 0 and instr_steps > 0 and not args.time_all_tags:
+            per_step = ex / instr_steps
+            out.setdefault("end_to_end", {}).update(
+                executed_flops_per_step=per_step, executed_tflops=per_step / (dt / steps) / 1e12,
+                executed_frac_of_fp32_mfma_peak=per_step / (dt / steps) / MFMA_F32_PEAK,
+                executed_note="Linear-layer FLOPs of the launches of one instrumented step (per rank) / the timed step")
+    return out
+
+
 def git_sha() -> str | None:
     try:
         sha = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True, timeout=5).stdout.strip()
@@ -283,6 +469,10 @@ def main():
     ap.add_argument("--with-strong-cheetah6", action="store_true",
                     help="after the line of this invocation print a SECOND JSON line: BASELINE configs[2] as quoted (HalfCheetah-6x1, "
                          "--scaling strong, --global-threads 8192 split over the same ranks)")
+    ap.add_argument("--no-other-configs", dest="other_configs", action="store_false",
+                    help="default run (mpe): do NOT append the three other BASELINE workloads (cheetah6, smac3s5z, humanoid17; "
+                         "`--other-steps` steps each after the headline region) as `other_configs` to the JSON line")
+    ap.add_argument("--other-steps", type=int, default=3)
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher check without a GPU: spawn / rendezvous (gloo) / one all-reduce, then print a line with value null")
     args = ap.parse_args()
@@ -343,172 +533,37 @@ def main():
         n_local = args.threads_per_gpu or w["N"]
     Tn = w["T"]
 
-    r = build_gpu_runner(w, n_local, rank, world, device, args.logp)
-
-    def barrier():
-        torch.cuda.synchronize()
-        if comm.enabled:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
-
-    # Roofline timing lives INSIDE the timed region: every launch of the DOMINANT streaming kernel family is bracketed by HIP
-    # events on its launch stream.  Which family that is, is decided in the last warm-up step, where all of them are
-    # bracketed (single stream): an event pair between two kernels keeps the second from starting under the first one's tail, and bracketing
-    # all ~20 families inside the region cost 2.5-3 % of the step (MPE; 10-15 % for the launch-heavy 17-agent HATRPO step).
-    ROOF_TAGS = ("fwd_fused2", "fwd_fused2_k64", "fwd_hidden", "bwd_dx", "bwd_dx_dw1", "dw_hidden", "fwd_wide", "dw_input",
-                 "tangent_wide", "tangent_hidden", "gru_fwd", "gru_bwd", "update_fwd", "update_bwd", "update_logp",
-                 "update_fwd_critic", "update_last", "update_last_critic", "fwd_panel", "bwd_panel")
-    warm_kern = {}
-    for k in range(args.warmup):
-        last = k == args.warmup - 1 and not args.no_kernel_timing and not args.time_all_tags
-        if last:  # (critic chain on the main stream for this step: per-launch durations without a second kernel sharing the chip)
-            prev_cs = os.environ.get("HARL_CRITIC_STREAM")
-            os.environ["HARL_CRITIC_STREAM"] = "0"
-            _lib.enable_kernel_timing(True, ROOF_TAGS)
-        one_step(r)
-        if last:
-            warm_kern = _lib.collect_kernel_timing()
-            _lib.enable_kernel_timing(False)
-            if prev_cs is None:
-                os.environ.pop("HARL_CRITIC_STREAM", None)
-            else:
-                os.environ["HARL_CRITIC_STREAM"] = prev_cs
-    barrier()
-    region_tags = ROOF_TAGS
-    cw = {k: v for k, v in warm_kern.items() if v["n"] > 0 and v.get("bytes")}
-    if cw:
-        region_tags = (max(cw, key=lambda k: cw[k]["total_ms"]),)
-    if not args.no_kernel_timing:
-        if cw:  # two events per bracketed launch, created before the clock starts
-            _lib.reserve_timing_events(2 * (cw[region_tags[0]]["n"] + 8) * args.steps)
-        _lib.enable_kernel_timing(True, None if args.time_all_tags else region_tags)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step(r)
-    barrier()
-    dt = time.perf_counter() - t0
-    roof_kern = {}
-    if not args.no_kernel_timing:
-        roof_kern = _lib.collect_kernel_timing()
-        _lib.enable_kernel_timing(False)
-    if comm.enabled:
-        tt = torch.tensor([dt], dtype=torch.float64, device=device)
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-        dt = float(tt.item())
-    # Full per-kernel breakdown (every tagged launch, ~10 % of wall time): `instr_steps` further steps of the SAME
-    # workload after the timed region, so that it does not understate `value`.
-    kern = dict(roof_kern) if args.time_all_tags else {}
-    if not args.no_kernel_timing and args.instr_steps > 0:
-        # (ONE stream here: in the timed region the critic's update runs on a stream of its own next to the actors' chain,
-        # so two kernels share the chip and every per-launch duration contains its neighbour's slices; the per-kernel table
-        # and `roofline.single_stream` are taken with the critic chain back on the main stream)
-        prev_cs = os.environ.get("HARL_CRITIC_STREAM")
-        os.environ["HARL_CRITIC_STREAM"] = "0"
-        _lib.enable_kernel_timing(True)
-        for _ in range(args.instr_steps):
-            one_step(r)
-        kern = _lib.collect_kernel_timing()
-        _lib.enable_kernel_timing(False)
-        if prev_cs is None:
-            os.environ.pop("HARL_CRITIC_STREAM", None)
-        else:
-            os.environ["HARL_CRITIC_STREAM"] = prev_cs
-
+    out = measure(w, args.config, args, comm, rank, world, device, n_local, args.steps, args.warmup, args.instr_steps)
     if rank == 0:
-        trans_per_step = Tn * n_local * world
-        value = trans_per_step * args.steps / dt
-        # dominant kernel = the streaming family with the largest total time inside the timed region; `achieved` =
-        # algorithmic bytes of the launches that ran (harl_amd/traffic.py) / their HIP-event time.  The GEMMs run on the
-        # bf16 matrix pipe (exact three-way fp32 split, 6 products: csrc/split_mfma.h) and are bound by instruction issue and
-        # HBM together: the fraction of the HBM roof is the contract's figure, `matrix_pipe_frac` of the
-        # dominant GEMM is reported next to it where a FLOP model exists.
-        cand = {k: v for k, v in roof_kern.items() if v["n"] > 0 and v.get("bytes")}
-        roof = None
-        if cand:
-            dom = max(cand, key=lambda k: cand[k]["total_ms"])
-            tot_s = cand[dom]["total_ms"] * 1e-3
-            ach = cand[dom]["bytes"] / tot_s
-            per_launch = cand[dom]["bytes"] / cand[dom]["n"]
-            traffic, traffic_note = None, None
-            tp = next((q for q in (os.path.join(ROOT, "profiles", f"r0{k}_hbm_traffic.json") for k in (3, 2)) if os.path.exists(q)),
-                      os.path.join(ROOT, "profiles", "r03_hbm_traffic.json"))
-            if os.path.exists(tp):  # PMC passes over the same kernels at this workload's shapes (tools/pmc_traffic.sh)
-                tj = json.load(open(tp))
-                ent = tj.get("workloads", {}).get(args.config, {}).get(dom)
-                if ent:
-                    traffic = ent["ratio"] * per_launch / 1e9
-                    traffic_note = (f"GB per launch = {ent['ratio']:.3f} (HBM bytes measured by rocprofv3 --pmc, FETCH_SIZE and "
-                                    f"WRITE_SIZE in separate passes with the guide's gfx950 unit corrections, / algorithmic bytes "
-                                    f"of the same launches; taken at commit {tj.get('git_sha')}, profiles/{os.path.basename(tp)[:-5]}.md) x "
-                                    f"{per_launch / 1e9:.4f} GB algorithmic per launch in this run")
-            # the same launches on the matrix pipe: bf16 MFMAs per 32-sample slab (static census of the compiled kernels,
-            # profiles/r03_isa_census.md) x 32.3 cycles each (profiles/r03_mfma_valu_overlap.md) over 1024 SIMDs at 2.4 GHz
-            mfma_slab = {"bwd_dx_dw1": 270, "bwd_dx": 192, "fwd_fused2": 240, "fwd_fused2_k64": 288, "fwd_hidden": 192,
-                         "dw_hidden": 192, "tangent_hidden": 384, "update_fwd": 315, "update_logp": 240, "update_last": 267}.get(dom)
-            pipe = None
-            if mfma_slab and not w.get("rnn"):
-                slabs = Tn * n_local / 32.0
-                pipe = slabs * mfma_slab * 32.3 / (1024 * 2.4e9) / (cand[dom]["avg_ms"] * 1e-3)
-            roof = dict(kernel=dom, bound="hbm", achieved=ach / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s", frac=ach / HBM_PEAK,
-                        hbm_frac=ach / HBM_PEAK, matrix_pipe_frac=pipe,
-                        bound_note="streaming GEMM kernels between two roofs: `frac` = algorithmic bytes / time against the 8 TB/s "
-                                   "HBM peak (the contract's figure); `matrix_pipe_frac` = the launch's bf16 MFMAs x 32.3 cycles "
-                                   "against the time all 1024 SIMDs have at 2.4 GHz.  Neither is saturated: VALU work of the "
-                                   "exact bf16 split / LayerNorm / ReLU sits in separate phases of the same waves (DESIGN.md 3)",
-                        traffic=traffic, traffic_note=traffic_note, launches=cand[dom]["n"], avg_ms=cand[dom]["avg_ms"],
-                        bytes_per_launch=per_launch,
-                        timing="HIP events around every launch of the streaming kernel families inside the timed region; bytes "
-                               "from each launch's own arguments (harl_amd/traffic.py)",
-                        others={k: dict(hbm_frac=round(v["bytes"] / (v["total_ms"] * 1e-3) / HBM_PEAK, 4), n=v["n"],
-                                        avg_ms=round(v["avg_ms"], 4))
-                                for k, v in ({t: x for t, x in kern.items() if t in ROOF_TAGS and x["n"] > 0 and x.get("bytes")}
-                                             or cw or cand).items()},
-                        others_note="every streaming family in the instrumented single-stream steps after the timed region (the "
-                                    "dominant one -- chosen in the last warm-up step -- alone is bracketed inside the region)")
-            if args.config == "mpe":  # SURVEY.md 8(d) / BASELINE.md: 2 674 176 algorithmic FLOP per transition of this workload
-                roof["end_to_end"] = dict(
-                    flop_per_transition=2674176, achieved_tflops=2674176 * value / world / 1e12,
-                    frac_of_fp32_mfma_peak=2674176 * value / world / MFMA_F32_PEAK,
-                    note="whole step per GPU against SURVEY.md 8(d)'s roofline (58.8 M transitions/s per GPU = 100 % of the dense "
-                         "fp32-MFMA peak, 157.3 TFLOP/s); the GEMMs run on the bf16 pipe as six exact products")
-            ks = kern.get(dom)
-            if ks and ks.get("bytes") and not args.time_all_tags:
-                a1 = ks["bytes"] / (ks["total_ms"] * 1e-3)
-                roof["single_stream"] = dict(
-                    achieved=a1 / 1e9, frac=a1 / HBM_PEAK, avg_ms=ks["avg_ms"], launches=ks["n"],
-                    matrix_pipe_frac=(pipe * cand[dom]["avg_ms"] / ks["avg_ms"]) if pipe else None,
-                    note=f"the same kernel family in the {args.instr_steps} instrumented steps after the timed region, critic chain on the "
-                         "main stream (HARL_CRITIC_STREAM=0): per-launch durations without a second kernel sharing the chip")
-        out = dict(
-            metric=w["metric"], value=value, unit="transitions/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
-            ms_per_step=dt / args.steps * 1e3, higher_is_better=True, scaling=args.scaling, vs_baseline=None, dtype="f32",
-            dtype_note="fp32 data, statistics and accumulators; GEMM operands are split EXACTLY into three bf16 each and "
-                       "multiplied as six cross products on v_mfma_f32_32x32x16_bf16 (error <= the fp32 MFMA's fmaf chain: "
-                       "profiles/r01_mfma_bf16x3.txt)",
-            data=f"synthetic (SURVEY.md 8d recipe, generated on the device; stored log-probs: {args.logp})",
-            config=dict(workload=f"{w['name']}: compute_returns + train(), T={Tn}, n_rollout_threads={n_local}/GPU "
-                                 f"({n_local * world} global, {args.scaling} scaling), obs{w['obs']}/share{w['sobs']}/"
-                                 f"{'Discrete' if w['disc'] else 'Box'}{w['act']}, MLP{w['hidden']}{' + GRU' if w.get('rnn') else ''}, "
-                                 f"{'ppo_epoch=5, ' if w['algo'] == 'happo' else 'CG 10 + line search, '}critic_epoch=5",
-                        baseline_config=args.config, episode_length=Tn, n_rollout_threads_per_gpu=n_local, n_agents=w["A"],
-                        parallelism=f"dp{world}", collective="rccl" if comm.enabled else "none",
-                        world_size=torch.distributed.get_world_size() if comm.enabled else 1, git_sha=git_sha()),
-            roofline=roof,
-            kernels={k: dict(n=v["n"], avg_ms=round(v["avg_ms"], 4), total_ms=round(v["total_ms"], 3),
-                             **({"hbm_frac": round(v["bytes"] / (v["total_ms"] * 1e-3) / HBM_PEAK, 4), "alg_bytes": v["bytes"]}
-                                if v.get("bytes") else {}))
-                     for k, v in kern.items()},
-            kernel_timing=f"`kernels`: HIP events around every tagged launch, {args.instr_steps} instrumented single-stream steps after the timed region",
-        )
-        if w["algo"] == "happo":
-            e2e = flops_per_transition(w) * value
-            out["end_to_end"] = dict(algorithmic_tflops=e2e / 1e12, frac_of_fp32_mfma_peak=e2e / (MFMA_F32_PEAK * world),
-                                     flops_per_transition=flops_per_transition(w))
         cols = args.cpu_cols
         if cols < 0:  # ~10-30 s of CPU work per update for every configuration
             cols = {"mpe": 512, "cheetah6": 512, "smac3s5z": 128, "humanoid17": 16}[args.config]
         if world == 1 and cols > 0:
             out["cpu_baseline"] = cpu_baseline(w, cols, min(args.cpu_threads, os.cpu_count() or 1))
+    # the other BASELINE.json workloads at their real shapes, on the SAME JSON line (after the headline region and the CPU
+    # baseline, fresh runner each, a few steps): `--config <name>` gives the full record of any one of them
+    if args.other_configs and args.config == "mpe" and args.scaling == "weak" and not args.threads_per_gpu:
+        others = {}
+        for name in ("cheetah6", "smac3s5z", "humanoid17"):
+            torch.cuda.empty_cache()
+            wo = WORKLOADS[name]
+            try:
+                o = measure(wo, name, args, comm, rank, world, device, wo["N"], args.other_steps, 2, 1)
+            except Exception as e:  # noqa: BLE001 -- the headline record must survive a failure of an attached one
+                o = dict(error=f"{type(e).__name__}: {e}") if rank == 0 else None
+            if rank == 0:
+                if "error" in o:
+                    others[name] = o
+                    continue
+                rf = o.get("roofline") or {}
+                others[name] = dict(metric=o["metric"], value=o["value"], ms_per_step=o["ms_per_step"], steps=o["steps"],
+                                    warmup=o["warmup"], workload=o["config"]["workload"],
+                                    roofline=dict(kernel=rf.get("kernel"), frac=rf.get("frac"), avg_ms=rf.get("avg_ms"),
+                                                  matrix_pipe_frac=rf.get("matrix_pipe_frac")),
+                                    end_to_end=o.get("end_to_end"))
+        if rank == 0:
+            out["other_configs"] = others
+    if rank == 0:
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if comm.enabled:
         torch.distributed.barrier()

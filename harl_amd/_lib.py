@@ -12,7 +12,7 @@ from typing import Optional
 
 import torch
 
-from .traffic import algorithmic_bytes
+from .traffic import algorithmic_bytes, algorithmic_flops
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # HARL_LIB=<variant> selects harl_amd/lib/libharl_<variant>.so (A/B builds of the same sources, harl_amd/_build.py)
@@ -169,11 +169,13 @@ def collect_kernel_timing() -> dict:
     torch.cuda.synchronize()
     out = {}
     for tag, evs in _timing_events.items():
-        ms = [a.elapsed_time(b) for a, b, _ in evs]
-        nb = [x for _, _, x in evs if x is not None]
+        ms = [e[0].elapsed_time(e[1]) for e in evs]
+        nb = [e[2] for e in evs if e[2] is not None]
         out[tag] = dict(n=len(ms), avg_ms=sum(ms) / max(len(ms), 1), total_ms=sum(ms),
                         # algorithmic HBM bytes of the launches that ran (harl_amd/traffic.py), None if no model
-                        bytes=sum(nb) if len(nb) == len(evs) and nb else None)
+                        bytes=sum(nb) if len(nb) == len(evs) and nb else None,
+                        # executed Linear-layer FLOPs of the same launches (0 for kernels without a GEMM)
+                        flops=sum(e[3] or 0.0 for e in evs))
     return out
 
 
@@ -186,7 +188,7 @@ def call(name: str, *args, tag: Optional[str] = None) -> None:
         a.record()
         rc = getattr(lib, name)(*args)
         b.record()
-        _timing_events.setdefault(tag, []).append((a, b, algorithmic_bytes(name, args)))
+        _timing_events.setdefault(tag, []).append((a, b, algorithmic_bytes(name, args), algorithmic_flops(name, args)))
     else:
         rc = getattr(lib, name)(*args)
     if rc != 0:

@@ -154,6 +154,13 @@ __device__ __forceinline__ float relu_push(float a, uint32_t &bits) {  // return
                : "vcc");
   return v;
 }
+// max(a, 0) as ONE v_max_f32: fmaxf() costs a second v_max_f32 (x, x) in front -- the canonicalisation IEEE maxNum asks for
+// when the compiler cannot prove its input is not a signalling NaN (256 instead of 128 VALU per slab in the log-prob passes)
+__device__ __forceinline__ float relu_plain(float a) {
+  float v;
+  asm("v_max_f32 %0, 0, %1" : "=v"(v) : "v"(a));
+  return v;
+}
 __device__ __forceinline__ float mask_pop(float x, uint32_t &bits) {  // returns top bit ? x : 0 ; bits <<= 1
   float o;
   asm volatile("v_add_co_u32 %1, vcc, %1, %1\n\tv_cndmask_b32 %0, 0, %2, vcc" : "=&v"(o), "+v"(bits) : "v"(x) : "vcc");

@@ -53,7 +53,7 @@ __device__ __forceinline__ void relu_ln(const f32x16 (&acc)[H / 32], float (&v)[
 #pragma unroll
   for (int R = 0; R < NR; ++R) {
     if constexpr (MASK) v[R] = relu_push(acc[R >> 4][R & 15], bits[R >> 5]);
-    else v[R] = fmaxf(acc[R >> 4][R & 15], 0.f);
+    else v[R] = relu_plain(acc[R >> 4][R & 15]);
   }
   f32x2 s2v = {0.f, 0.f};
 #pragma unroll

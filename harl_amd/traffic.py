@@ -211,3 +211,118 @@ ALGORITHMIC_BYTES: Dict[str, Callable[[Sequence], float]] = {
 def algorithmic_bytes(name: str, args: Sequence) -> Optional[float]:
     f = ALGORITHMIC_BYTES.get(name)
     return None if f is None else float(f(args))
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Executed Linear-layer FLOPs of one launch (2 x rows x out x in per GEMM; head GEMMs included, element-wise work not) -- the
+# unit of SURVEY.md section 8(d)'s end-to-end roofline.  bench.py sums them over an instrumented step: for HAPPO the total
+# equals the closed form (2 + 3 ppo_epoch) F_actor + 3 critic_epoch F_critic minus the pre-update pass train() shares with
+# its first epoch; for HATRPO (CG iterations, line-search steps: data dependent) it is the only count there is.
+# ---------------------------------------------------------------------------------------------------------------------------
+def _f_fused2x(a):  # (x0n, M, W1p, D, b1p, W2p, b2p, H, ...)
+    return 2.0 * a[1] * (a[3] * a[7] + a[7] * a[7])
+
+
+def _f_fused2(a):  # (X, ldx, idx, M, D, W1p, b1p, use_ln0, W2p, b2p, H, ...)
+    return 2.0 * a[3] * (a[4] * a[10] + a[10] * a[10])
+
+
+def _f_update_fwd_actor(a):  # forward of both layers + head, head dW and head backward (2 x act_dim x H each)
+    M, D, H, ad = a[1], a[2], a[3], a[14]
+    return 2.0 * M * (D * H + H * H + 3 * ad * H)
+
+
+def _f_update_logp(a):
+    M, D, H, ad = a[1], a[2], a[3], a[14]
+    return 2.0 * M * (D * H + H * H + ad * H)
+
+
+def _f_update_fwd_critic(a):
+    M, D, H = a[1], a[2], a[3]
+    return 2.0 * M * (D * H + H * H + 3 * H)
+
+
+def _f_update_values(a):
+    M, D, H = a[1], a[2], a[3]
+    return 2.0 * M * (D * H + H * H + H)
+
+
+def _f_update_last_actor(a):  # (xin, M, H, ..., act_dim at 11)
+    return 2.0 * a[1] * (a[2] * a[2] + 3 * a[11] * a[2])
+
+
+def _f_update_last_critic(a):
+    return 2.0 * a[1] * (a[2] * a[2] + 3 * a[2])
+
+
+def _f_update_bwd(a):  # (x0n, dz2, M, D, H): layer-1 recompute twice, dW2, dx, dW1
+    M, D, H = a[2], a[3], a[4]
+    return 2.0 * M * (2 * D * H + 2 * H * H + D * H)
+
+
+def _f_bwd_dx(a):  # (dz, xprev, mask, rstd, M, HO, HI, Wp, dz_prev, x0n, kp0, ...): dx (+ fused first-layer dW)
+    M, HO, HI = a[4], a[5], a[6]
+    return 2.0 * M * (HO * HI + (HI * a[10] if a[9] else 0))
+
+
+def _f_dw(a):  # (a, a_kind, lda, HO, b, b_kind, ldx, idx, mu0, rstd0, K, M, ...)
+    return 2.0 * a[11] * a[3] * a[10]
+
+
+def _f_dw_multi(a):  # (n, a_ptrs, b_ptrs, part_ptrs, HO, K, M, ...)
+    return 2.0 * a[0] * a[6] * a[4] * a[5]
+
+
+def _f_gru_fwd(a):  # input + recurrent halves of the three gates
+    H, L, m_pad = a[7], a[8], a[9]
+    return 2.0 * L * m_pad * 6 * H * H
+
+
+def _f_gru_bwd(a):
+    H, L, m_pad = a[9], a[10], a[11]
+    return 2.0 * L * m_pad * 6 * H * H
+
+
+def _f_head(a_M, a_H, ad, train):
+    return 2.0 * a_M * ad * a_H * (3 if train else 1)
+
+
+ALGORITHMIC_FLOPS: Dict[str, Callable[[Sequence], float]] = {
+    "harl_mlp_fwd_fused2x": _f_fused2x,
+    "harl_mlp_fwd_fused2": _f_fused2,
+    "harl_mlp_fwd_hidden": lambda a: 2.0 * a[1] * a[2] * a[3],
+    "harl_mlp_linear": lambda a: 2.0 * a[1] * a[2] * a[3],
+    "harl_mlp_fwd_wide": lambda a: 2.0 * a[1] * a[4] * a[6],
+    "harl_mlp_linear_wide": lambda a: 2.0 * a[1] * a[4] * a[6],
+    "harl_mlp_fwd_input": lambda a: 2.0 * a[3] * a[4] * a[8],
+    "harl_mlp_tangent_wide": lambda a: 2.0 * a[1] * a[4] * a[6],  # the inputs carry no tangent: one GEMM
+    "harl_mlp_tangent_hidden": lambda a: 2.0 * 2 * a[2] * a[3] * a[4],
+    "harl_mlp_bwd_dx": _f_bwd_dx,
+    "harl_mlp_dw_partials": _f_dw,
+    "harl_mlp_dw_partials_multi": _f_dw_multi,
+    "harl_mlp_panel_fwd": lambda a: 2.0 * a[1] * a[4] * a[6],
+    "harl_mlp_panel_bwd": lambda a: 2.0 * a[4] * a[5] * a[6],
+    "harl_gru_fwd": _f_gru_fwd,
+    "harl_gru_bwd": _f_gru_bwd,
+    "harl_actor_head_loss": lambda a: _f_head(a[3], a[4], a[11], True) - (2.0 * a[3] * a[11] * a[4] if not a[30] else 0.0),
+    "harl_actor_head_logp": lambda a: _f_head(a[1], a[2], a[9], False),
+    "harl_actor_head_fvp": lambda a: 0.0,
+    "harl_critic_head_loss": lambda a: _f_head(a[3], a[4], 1, True),
+    "harl_update_fwd_actor": _f_update_fwd_actor,
+    "harl_update_logp": _f_update_logp,
+    "harl_update_fwd_critic": _f_update_fwd_critic,
+    "harl_update_values": _f_update_values,
+    "harl_update_last_actor": _f_update_last_actor,
+    "harl_update_last_critic": _f_update_last_critic,
+    "harl_update_bwd": _f_update_bwd,
+}
+
+
+def algorithmic_flops(name: str, args: Sequence) -> Optional[float]:
+    f = ALGORITHMIC_FLOPS.get(name)
+    if f is None:
+        return None
+    try:
+        return float(f(args))
+    except (TypeError, IndexError):
+        return None

@@ -1137,6 +1137,160 @@ def check_full_size_properties() -> Dict[str, float]:
     return out
 
 
+def _bench_config_runs(n_threads: int, with_f64: bool, keep_grad: bool = False):
+    """HIP step + oracle run(s) of the BENCH configuration on identical contents (see check_bench_config_parity).  Returns
+    (hip dict, {"f32": .., "f64": ..} oracle dicts, names/shapes of the actor / critic parameter tensors)."""
+    import bench
+    w = bench.WORKLOADS["mpe"]
+    T, A = w["T"], w["A"]
+    torch.manual_seed(1)
+    r = bench.build_gpu_runner(w, n_threads, 0, 1, DEV, "recipe")
+    # ---- host copies of everything train() reads, taken BEFORE the HIP step
+    npy = lambda t: t.detach().cpu().numpy().copy()  # noqa: E731
+    actor_sd = [{k: v.detach().cpu().clone() for k, v in a.actor.state_dict().items()} for a in r.actor]
+    critic_sd = {k: v.detach().cpu().clone() for k, v in r.critic.critic.state_dict().items()}
+    abuf_np = [dict(obs=npy(b.obs), actions=npy(b.actions), logp=npy(b.action_log_probs), masks=npy(b.masks),
+                    active=npy(b.active_masks)) for b in r.actor_buffer]
+    cb = r.critic_buffer
+    cbuf_np = dict(share_obs=npy(cb.share_obs), rewards=npy(cb.rewards), value_preds=npy(cb.value_preds), masks=npy(cb.masks),
+                   bad_masks=npy(cb.bad_masks))
+    st0 = npy(r.value_normalizer.stats)
+    rng0 = torch.get_rng_state()
+    # ---- HIP path: one bench step (bench.one_step) with the per-update traces switched on
+    gtaps = [[] for _ in r.actor]
+    for a_, tp in zip(r.actor, gtaps):
+        a_._trace = []
+        if keep_grad:  # (host sync per update: diagnostics only)
+            a_._grad_tap = (lambda tp_: (lambda gr, sc: tp_.append(gr.cpu().numpy().astype(np.float64))))(tp)
+    r.critic._trace = []
+    for a_ in r.actor:
+        a_.actor.invalidate_caches()
+    r.critic.critic.invalidate_caches()
+    r.compute()
+    torch.cuda.synchronize()
+    next_value_hip = npy(cb.value_preds[-1])
+    returns_hip = npy(cb.returns)
+    ginfos, gcinfo = r.train()
+    torch.cuda.synchronize()
+    rng_hip = torch.get_rng_state()
+    gtr = []
+    for a_ in r.actor:
+        cum = torch.stack(a_._trace).double().cpu().numpy()
+        gtr.append(np.diff(np.concatenate([np.zeros((1, cum.shape[1])), cum]), axis=0)[:, :4])
+    cum = torch.stack(r.critic._trace).double().cpu().numpy()
+    gctr = np.diff(np.concatenate([np.zeros((1, cum.shape[1])), cum]), axis=0)[:, :2]
+    gfin = [npy(a_.actor.flat_reference()) for a_ in r.actor]
+    gcfin = npy(r.critic.critic.flat_param)
+    gvn = npy(r.value_normalizer.stats)
+    shapes = dict(actor=[(k, tuple(v.shape)) for k, v in actor_sd[0].items()], critic=[(k, tuple(v.shape)) for k, v in critic_sd.items()])
+    del r
+    torch.cuda.empty_cache()
+    # ---- oracle on the same contents
+    args = bench.algo_args(n_threads, T, w)
+    cfg = O.PathConfig.from_reference_dicts(args["train"], args["model"], args["algo"])
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    runs = {}
+    import time as _time
+    for tag, dt in (("f32", torch.float32),) + ((("f64", torch.float64),) if with_f64 else ()):
+        O.set_work_dtype(dt)
+        try:
+            t0 = _time.perf_counter()
+            torch.set_rng_state(rng0)
+            actors = [O.OracleHAPPO({k: v.clone() for k, v in sd.items()}, cfg) for sd in actor_sd]
+            critic = O.OracleVCritic({k: v.clone() for k, v in critic_sd.items()}, cfg)
+            abufs = [O.OracleActorBuffer(d["obs"].copy(), d["actions"].copy(), d["logp"].copy(), d["masks"].copy(), d["active"].copy(),
+                                         None) for d in abuf_np]
+            cbuf = O.OracleCriticBufferEP(cbuf_np["share_obs"].copy(), cbuf_np["rewards"].copy(), cbuf_np["value_preds"].copy(),
+                                          cbuf_np["masks"].copy(), cbuf_np["bad_masks"].copy())
+            vn = O.OracleValueNorm()
+            vn.load_state(dict(running_mean=float(st0[0]), running_mean_sq=float(st0[1]), debiasing_term=float(st0[2])))
+            with torch.no_grad():  # compute(): the critic's value of slot T (on_policy_base_runner.py:462-484)
+                nv = critic.get_values(cbuf_np["share_obs"][-1]).detach().double().numpy().reshape(-1, 1)
+            # identical scan inputs on both sides: the oracle's compute_returns is fed the HIP value of slot T (compared above it)
+            cbuf.compute_returns(next_value_hip.copy() if tag == "f32" else nv, vn, cfg)
+            infos, cinfo, _ = O.ha_train(actors, critic, abufs, cbuf, vn, cfg, keep_grad=keep_grad)
+            runs[tag] = dict(nv=nv, returns=np.asarray(cbuf.returns).copy(), infos=infos, cinfo=cinfo,
+                             atr=[np.array([[u["policy_loss"], u["dist_entropy"], u["grad_norm"], u["ratio"]] for u in a_.trace])
+                                  for a_ in actors],
+                             ctr=np.array([[u["value_loss"], u["grad_norm"]] for u in critic.trace]),
+                             fin=[np.asarray(a_.net.flat(), dtype=np.float64) for a_ in actors],
+                             grads=[[np.asarray(u["grad"], dtype=np.float64) for u in a_.trace] for a_ in actors] if keep_grad else None,
+                             cfin=np.asarray(critic.net.flat(), dtype=np.float64), vn=vn.state(), rng=torch.get_rng_state(),
+                             seconds=_time.perf_counter() - t0)
+        finally:
+            O.set_work_dtype(torch.float32)
+    hip = dict(next_value=next_value_hip, returns=returns_hip, rng=rng_hip, atr=gtr, ctr=gctr, infos=ginfos, cinfo=gcinfo,
+               fin=gfin, cfin=gcfin, vn=gvn, grads=gtaps if keep_grad else None)
+    return hip, runs, shapes, dict(T=T, A=A, actor_sd=actor_sd, abuf=abuf_np, cfg=cfg)
+
+
+def check_bench_config_parity(n_threads: int = 4096, with_f64: Optional[bool] = None) -> Dict[str, float]:
+    """The BENCH configuration itself against the oracle: exactly what ``bench.py`` times -- BASELINE.json
+    configs[1], T = 200, n_rollout_threads = 4096, 3 agents, obs 18 / share_obs 54 / Box 5, MLP [128, 128], 5 + 5 epochs, recipe
+    log-probs, fixed agent order -- built by ``bench.build_gpu_runner``; buffers, weights and ValueNorm state are copied to the
+    host and ONE fp32 oracle ``compute() + ha_train`` (on_policy_ha_runner.py:11-130; ~50 s on 16 host threads) runs on the same
+    contents.  Compared: the critic's value of slot T, returns (bit-exact, the oracle's scan is fed the HIP value of slot T so
+    that both scans see identical inputs), EVERY optimiser step's policy_loss / dist_entropy / grad_norm / ratio (3 x 5) and
+    value_loss / critic_grad_norm (5), the averaged infos, the final parameter vectors and ValueNorm statistics.  Means over
+    819 200 rows are well conditioned: scalars are held to 1e-5 FLAT (no noise-floor widening, no kink masking: keys without
+    "_"); parameter vectors, which Adam's m / sqrt(v) makes sensitive wherever a gradient entry is rounding-sized, to
+    max(1e-5, 2 x the fp32 oracle's own distance from the same update in float64) of the vector's inf-norm (``with_f64``,
+    default on; HARL_BENCH_PARITY_F64=0 skips the second oracle run and holds the vectors to 1e-4 flat instead)."""
+    if with_f64 is None:
+        with_f64 = os.environ.get("HARL_BENCH_PARITY_F64", "1") != "0"
+    out: Dict[str, float] = {}
+    hip, runs, _shapes, meta = _bench_config_runs(n_threads, with_f64)
+    T, A = meta["T"], meta["A"]
+    next_value_hip, returns_hip, rng_hip, gtr, gctr = hip["next_value"], hip["returns"], hip["rng"], hip["atr"], hip["ctr"]
+    ginfos, gcinfo, gfin, gcfin, gvn = hip["infos"], hip["cinfo"], hip["fin"], hip["cfin"], hip["vn"]
+    o = runs["f32"]
+    out["_oracle_f32_seconds"] = float(o["seconds"])
+    out["next_value_vec_rel"] = vec_rel_err(next_value_hip, o["nv"])
+    out["returns_mismatch"] = float(np.sum(returns_hip[:T] != o["returns"][:T].astype(np.float32)))
+    out["rng_state_mismatch"] = float(not torch.equal(rng_hip, o["rng"]))
+    names = ("policy_loss", "dist_entropy", "grad_norm", "ratio")
+    for c, nm in enumerate(names):
+        g = np.stack([t[:, c] for t in gtr])
+        ref = np.stack([t[:, c] for t in o["atr"]])
+        out[f"actor_update_{nm}_rel"] = rel_err(g, ref)
+    out["critic_update_value_loss_rel"] = rel_err(gctr[:, 0], o["ctr"][:, 0])
+    out["critic_update_grad_norm_rel"] = rel_err(gctr[:, 1], o["ctr"][:, 1])
+    keys = ("policy_loss", "dist_entropy", "actor_grad_norm", "ratio")
+    tab = lambda infos_: np.array([[float(i[k]) for k in keys] for i in infos_], dtype=np.float64)  # noqa: E731
+    out["actor_infos_rel"] = rel_err(tab(ginfos), tab(o["infos"]))
+    out["critic_info_rel"] = rel_err([gcinfo["value_loss"], gcinfo["critic_grad_norm"]],
+                                     [o["cinfo"]["value_loss"], o["cinfo"]["critic_grad_norm"]])
+    ovn = o["vn"]
+    out["vn_final_rel"] = rel_err(gvn, [float(np.asarray(ovn["running_mean"]).reshape(-1)[0]),
+                                        float(np.asarray(ovn["running_mean_sq"]).reshape(-1)[0]),
+                                        float(np.asarray(ovn["debiasing_term"]).reshape(-1)[0])])
+    worst_raw, worst_ex = 0.0, 0.0
+    for a in range(A):
+        raw = vec_rel_err(gfin[a], o["fin"][a])
+        worst_raw = max(worst_raw, raw)
+        out[f"_actor{a}_final_param_vec_rel"] = raw
+        if with_f64:
+            out[f"_actor{a}_oracle_f32_vs_f64_vec_rel"] = vec_rel_err(o["fin"][a], runs["f64"]["fin"][a])
+            worst_ex = max(worst_ex, vec_excess(gfin[a], o["fin"][a], runs["f64"]["fin"][a]))
+        else:
+            worst_ex = max(worst_ex, raw / 1e-4)
+    out["_critic_final_param_vec_rel"] = vec_rel_err(gcfin, o["cfin"])
+    if with_f64:
+        out["_oracle_f64_seconds"] = float(runs["f64"]["seconds"])
+        out["_critic_oracle_f32_vs_f64_vec_rel"] = vec_rel_err(o["cfin"], runs["f64"]["cfin"])
+        worst_ex = max(worst_ex, vec_excess(gcfin, o["cfin"], runs["f64"]["cfin"]))
+        # the HIP path's distance from the float64 update next to the fp32 oracle's own (raw figures for the log)
+        out["_hip_vs_f64_policy_loss_rel"] = rel_err(np.stack([t[:, 0] for t in gtr]), np.stack([t[:, 0] for t in runs["f64"]["atr"]]))
+        out["_f32_vs_f64_policy_loss_rel"] = rel_err(np.stack([t[:, 0] for t in o["atr"]]), np.stack([t[:, 0] for t in runs["f64"]["atr"]]))
+        out["_hip_vs_f64_grad_norm_rel"] = rel_err(np.stack([t[:, 2] for t in gtr]), np.stack([t[:, 2] for t in runs["f64"]["atr"]]))
+        out["_f32_vs_f64_grad_norm_rel"] = rel_err(np.stack([t[:, 2] for t in o["atr"]]), np.stack([t[:, 2] for t in runs["f64"]["atr"]]))
+    else:
+        worst_ex = max(worst_ex, out["_critic_final_param_vec_rel"] / 1e-4)
+    out["_final_param_vec_rel_max"] = worst_raw
+    out["final_param_excess"] = worst_ex
+    return out
+
+
 def check_generator_api(name: str) -> Dict[str, float]:
     """The buffers' public generators (feed-forward / naive / chunked recurrent, actor and critic) yield, for the
     reference's recorded permutations, exactly the rows the oracle's generators yield (bit-exact gathers)."""

@@ -217,6 +217,14 @@ def test_checkpoint_compat_with_reference_files(tmp_path):
             assert v < TOL, (k, v)
 
 
+def test_bench_configuration_against_oracle():
+    """One whole bench step (compute + train, 5 + 5 epochs, recipe log-probs) at T = 200, N = 4096 against the fp32 oracle on
+    identical buffer contents: every per-update scalar within 1e-5 flat, parameter vectors within the measured-floor bar."""
+    res = _G().check_bench_config_parity()
+    print("bench-config parity:", {k: (f"{v:.3e}" if isinstance(v, float) else v) for k, v in res.items()})
+    _assert_all(res)
+
+
 def test_full_size_properties_baseline_config():
     """BASELINE configs[1] sizes (819 200 transitions x 3 agents): column independence vs the oracle, linearity of the
     unscaled sums under a column split, bit-exact determinism of train()."""

@@ -101,9 +101,22 @@ def _advance_generator(n: int) -> None:
         if _lib.load().harl_rng_advance(st.data_ptr(), st.numel(), n, out.data_ptr()) == 0:
             torch.set_rng_state(out)
             return
-    torch.empty(n, dtype=torch.int32).random_()
+    # fallback (self-check failed / HARL_RNG_SKIP=0): draw and discard, in pieces -- the total of an 8-GPU train() is ~130 M
+    # draws, 0.5 GB as one tensor
+    chunk = 1 << 20
+    buf = torch.empty(min(n, chunk), dtype=torch.int32)
+    left = n
+    while left > 0:
+        m = min(left, chunk)
+        buf[:m].random_()
+        left -= m
 
 
+# CONTRACT of the deferred advances below: between a runner-internal train(_defer=True) and the next rng_sync() the global CPU
+# generator is BEHIND by the pending draws.  Every public entry point of this package that returns to user code -- the runner's
+# train() / collect() / warmup(), HAPPO/HATRPO/MAPPO/VCritic.train(), the buffers' generators -- calls rng_sync() first or last,
+# so user code (callbacks, custom runners, anything that draws from torch's CPU generator) always sees the state the reference
+# would have; only code that calls the underscore-prefixed internals itself has to call ``buffers.rng_sync()`` before drawing.
 # Deferred generator advances: with one full-buffer minibatch the permutation of a sampler call is never looked at, only the
 # generator has to end up where torch.randperm would leave it -- and the state after several such calls depends on the TOTAL
 # number of draws only.  consume_randperm() therefore just adds to this counter; rng_sync() -- called before ANY use of the

@@ -154,12 +154,16 @@ __device__ __forceinline__ float relu_push(float a, uint32_t &bits) {  // return
                : "vcc");
   return v;
 }
-// max(a, 0) as ONE v_max_f32: fmaxf() costs a second v_max_f32 (x, x) in front -- the canonicalisation IEEE maxNum asks for
-// when the compiler cannot prove its input is not a signalling NaN (256 instead of 128 VALU per slab in the log-prob passes)
+// max(a, 0) as ONE instruction: fmaxf() costs a second v_max_f32 (x, x) in front -- the canonicalisation IEEE maxNum asks for
+// when the compiler cannot prove its input is not a signalling NaN (256 instead of 128 VALU per slab in the log-prob passes),
+// and it folds v_med3_f32(a, 0, +inf) back into the same pair.  The INTEGER maximum of the bit pattern with 0 is the same
+// function (negative floats, -0 included, are negative integers; positive floats keep their bits) and a plain v_max_i32.
+// Not inline asm: these values come straight out of MFMAs, and the wait states between a matrix instruction's write and a
+// VALU read are software's job on gfx9 -- the hazard recogniser inserts them for instructions it knows, not for the operands
+// of an asm statement (measured in round 4: `v_max_f32` in an asm statement read stale accumulators).
 __device__ __forceinline__ float relu_plain(float a) {
-  float v;
-  asm("v_max_f32 %0, 0, %1" : "=v"(v) : "v"(a));
-  return v;
+  const int b = __float_as_int(a);
+  return __int_as_float(b > 0 ? b : 0);
 }
 __device__ __forceinline__ float mask_pop(float x, uint32_t &bits) {  // returns top bit ? x : 0 ; bits <<= 1
   float o;

@@ -8,7 +8,9 @@
 //   harl_gradnorm_clip_adam fused ||g|| + clip + Adam over one flat arena
 //   harl_fold_linear / harl_unfold_linear_grads / harl_reduce_partials / harl_reduce_scalars
 #include <mutex>
+#include <map>
 #include <unordered_map>
+#include <utility>
 
 #include "common.h"
 #include "../../include/harl_hip.h"
@@ -236,15 +238,21 @@ __global__ __launch_bounds__(256) void k_masked_moments(const float *__restrict_
   }
 }
 
+// One scratch block per (device, stream), allocated on first use and kept for the life of the process (a few KiB each; never
+// released: a destroyed stream's handle may be reused by the runtime and then simply inherits the block of its device).  The
+// key includes the device: the null stream has the same handle on every device.
 static MmScratch *mm_scratch_of(hipStream_t s) {
   static std::mutex mu;
-  static std::unordered_map<hipStream_t, MmScratch *> pool;
+  static std::map<std::pair<int, hipStream_t>, MmScratch *> pool;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
   std::lock_guard<std::mutex> lk(mu);
-  auto it = pool.find(s);
+  const auto key = std::make_pair(dev, s);
+  auto it = pool.find(key);
   if (it != pool.end()) return it->second;
   MmScratch *p = nullptr;
   if (hipMalloc(reinterpret_cast<void **>(&p), sizeof(MmScratch)) != hipSuccess) return nullptr;
-  pool.emplace(s, p);
+  pool.emplace(key, p);
   return p;
 }
 

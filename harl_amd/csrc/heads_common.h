@@ -135,7 +135,9 @@ __device__ __forceinline__ void head_load_regs(const float *__restrict__ xL, lon
   for (int q = 0; q < H / 8; ++q) xs[q] = xp[q * WAVE];
 }
 
-template <int H, int DAP>
+// DA = number of head outputs that exist (<= DAP, the padded width of the LDS image): the kernels that are instantiated per
+// action width (update.hip) multiply only those columns -- 5 x 64 instead of 8 x 64 FMAs per lane for a Box(5) policy
+template <int H, int DAP, int DA = DAP>
 __device__ __forceinline__ void head_fwd_regs(const f32x4 (&xs)[H / 8], const float *whl_h, const float *cst,
                                               float (&z)[DAP]) {
 #pragma unroll
@@ -145,21 +147,20 @@ __device__ __forceinline__ void head_fwd_regs(const f32x4 (&xs)[H / 8], const fl
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
 #pragma unroll
-      for (int dq = 0; dq < DAP / 4; ++dq) {
+      for (int dq = 0; dq < (DA + 3) / 4; ++dq) {
         const f32x4 w = *reinterpret_cast<const f32x4 *>(whl_h + (4 * q + c) * DAP + 4 * dq);
-        z[4 * dq + 0] += xs[q][c] * w[0];
-        z[4 * dq + 1] += xs[q][c] * w[1];
-        z[4 * dq + 2] += xs[q][c] * w[2];
-        z[4 * dq + 3] += xs[q][c] * w[3];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (4 * dq + e < DA) z[4 * dq + e] += xs[q][c] * w[e];
       }
     }
     __builtin_amdgcn_sched_barrier(0);
   }
 #pragma unroll
-  for (int d = 0; d < DAP; ++d) z[d] = wave_sum32(z[d]) + cst[d];
+  for (int d = 0; d < DA; ++d) z[d] = wave_sum32(z[d]) + cst[d];
 }
 
-template <int H, int DAP>
+template <int H, int DAP, int DA = DAP>
 __device__ __forceinline__ void head_bwd_regs_bits(const f32x4 (&xs)[H / 8], uint32_t b0, const uint32_t b1, float rstd,
                                                    long slab, int lane, const float *whl /* base, both halves */,
                                                    const float (&dzh)[DAP], float s1, float s2,
@@ -181,7 +182,7 @@ __device__ __forceinline__ void head_bwd_regs_bits(const f32x4 (&xs)[H / 8], uin
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 #pragma unroll
-  for (int st = 0; st < DAP / 2; ++st) {
+  for (int st = 0; st < (DA + 1) / 2; ++st) {  // (entries >= DA of dzh are zero)
     // (bit select: written as `h ? dzh[2 st + 1] : dzh[2 st]` the compiler turned the pair into a two-entry SCRATCH array
     // indexed by h when both entries were cheap to materialise -- the critic's {dv, 0} -- one scratch round trip per slab)
     const unsigned hm = 0u - (unsigned)h;
@@ -446,10 +447,12 @@ struct ActorRow {
   float av[DAP];   // availability mask (Categorical with avail only)
   float act, adv, fct;
 };
-template <int DAP, bool DISCRETE, bool TRAIN>
+// DA > 0: the action width is a compile-time constant (update.hip instantiates per width; the run-time `d < D` tests of the
+// generic kernels cost ~50 scalar branches and ~230 v_readlane / v_writelane of spilled lane masks per slab there)
+template <int DAP, bool DISCRETE, bool TRAIN, int DA = 0>
 __device__ __forceinline__ void actor_row_load(const ActorArgs &A, long slab, int lane, ActorRow<DAP> &R) {
   const int i = lane & 31;
-  const int D = A.act_dim;
+  const int D = DA ? DA : A.act_dim;
   const long j = slab * SLAB + i;
   const long jc = j < A.M ? j : A.M - 1;
   const long row = A.idx ? A.idx[jc] : jc;
@@ -477,12 +480,12 @@ __device__ __forceinline__ void actor_row_load(const ActorArgs &A, long slab, in
   }
 }
 
-template <int DAP, bool DISCRETE, bool TRAIN>
+template <int DAP, bool DISCRETE, bool TRAIN, int DA = 0>
 __device__ __forceinline__ bool actor_sample(const ActorArgs &A, const float *cst, float (&z)[DAP], long slab, int lane,
                                              float adv_mean, float adv_den, float (&sc)[8 + DAP], float (&dzh)[DAP],
                                              float &s1_out, float &s2_out, const ActorRow<DAP> &R) {
   const int i = lane & 31, h = lane >> 5;
-  const int D = A.act_dim;
+  const int D = DA ? DA : A.act_dim;
   const int act_w = DISCRETE ? 1 : D;
   const float inv_D = uniform_f(1.0f / (float)D);
   float zlin[DAP];  // x_hat . Whp[d]  (= z - bias), needed by the closed-form LayerNorm backward

@@ -283,8 +283,9 @@ void poly_sqr_mod(const Poly &a, const Poly &phi, Poly &r) {
   for (int k = 0; k < PW; ++k) r.w[k] = sq[k];
 }
 
-// g = x^steps mod phi, cached per step count
-const Poly &jump_poly(long steps) {
+// g = x^steps mod phi, cached per step count.  Returned BY VALUE (2.5 KB): the cache is cleared when it grows past 64 entries,
+// so a reference into it would dangle as soon as a second thread advanced the generator by a new step count.
+Poly jump_poly(long steps) {
   static std::map<long, Poly> cache;
   static std::mutex mu;
   const Poly &phi = mt_charpoly();
@@ -340,7 +341,7 @@ void refresh(Mt &g, int isa) {
 
 // the state block `blocks` refreshes ahead of g's current one (g.left / g.next untouched), blocks >= 2
 void jump_blocks(Mt &g, long blocks, int isa) {
-  const Poly &gp = jump_poly((blocks - 1) * (long)MT_N);
+  const Poly gp = jump_poly((blocks - 1) * (long)MT_N);
   constexpr int NBLK = (MT_DEG + MT_N - 1) / MT_N + 1;  // word sequence x[0 .. 19937 + 623]
   static thread_local std::vector<uint32_t> xs((NBLK + 1) * MT_N + 16);
   alignas(64) uint32_t y[MT_N + 16];

@@ -39,7 +39,7 @@ __device__ __forceinline__ u32x4 make_ident16(int lane) {
 }
 
 __device__ __forceinline__ unsigned pack_hi16(float lo, float hi) {  // two exactly-bf16 floats -> packed pair (low = first)
-  return pack_hi16_near(__float_as_uint(lo), __float_as_uint(hi));
+  return __builtin_amdgcn_perm(__float_as_uint(hi), __float_as_uint(lo), 0x07060302u);
 }
 
 // acc (lane = feature, 16 samples) -> the two k-step operands of a weight-gradient MFMA

@@ -28,105 +28,29 @@ __device__ __forceinline__ f32x16 mfma_bf16(const u32x4 &a, const u32x4 &b, cons
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-// exact split of two floats into three packed bf16 pairs (low half = first value).
-// HARL_SPLIT_VARIANT (A/B builds, tools/split_cost.hip measures the sequences in isolation):
-//   0  truncation at every level: v_perm (pack the high halves) / v_and / v_pk_add  -- 9 VALU per pair
-//   2  the same with v_pack_b32_f16 op_sel:[1,1,0] as the packing instruction
-//   3  round-to-nearest terms: v_cvt_pk_bf16_f32, remainders by v_dot2_f32_bf16 (f - term in ONE instruction) -- 7 per pair
-//   4  round-to-nearest terms: v_cvt_pk_bf16_f32, remainders by shift / and / v_pk_add
-// Every variant is exact (t1 + t2 + t3 == x bit for bit): the remainder of an 8-bit term has at most 16 significant bits,
-// its remainder at most 8.  Truncated terms all carry the sign of x; rounded ones are up to half an ulp closer.
-#ifndef HARL_SPLIT_VARIANT
-#define HARL_SPLIT_VARIANT 0
-#endif
-//   5  variant 0 with the v_perm selector in a VECTOR register (tools/split_cost.hip: v_perm_b32 with an SGPR selector issues in
-//      8.2 cycles, with a VGPR selector in 6.0)
-//   6  v_pack_b32_f16 (inline asm) in the splits, whose results are consumed far from their definition; the packs right in front
-//      of an MFMA (transposes, mfma_transpose.h) stay compiler-visible instructions: the hazard recogniser inserts the wait
-//      states between a VALU write and the MFMA that reads it only for instructions it knows, not for inline asm
-__device__ __forceinline__ unsigned perm_selector() {
-#if HARL_SPLIT_VARIANT == 5 || HARL_SPLIT_VARIANT == 6
-  unsigned s;
-  asm("v_mov_b32 %0, 0x07060302" : "=v"(s));  // (not volatile, no inputs: one copy per kernel after CSE / hoisting)
-  return s;
-#else
-  return 0x07060302u;
-#endif
-}
-// {hi16(hi), hi16(lo)}, result consumed immediately (possibly by an MFMA): always a compiler-visible instruction
-__device__ __forceinline__ unsigned pack_hi16_near(unsigned lo, unsigned hi) {
-#if HARL_SPLIT_VARIANT == 2
-  unsigned r;
-  asm("v_pack_b32_f16 %0, %1, %2 op_sel:[1,1,0]" : "=v"(r) : "v"(lo), "v"(hi));
-  return r;
-#else
-  return __builtin_amdgcn_perm(hi, lo, perm_selector());
-#endif
-}
-__device__ __forceinline__ unsigned pack_hi16_pair(unsigned lo, unsigned hi) {  // {hi16(hi), hi16(lo)}
-#if HARL_SPLIT_VARIANT == 2 || HARL_SPLIT_VARIANT == 6
-  unsigned r;
-  asm("v_pack_b32_f16 %0, %1, %2 op_sel:[1,1,0]" : "=v"(r) : "v"(lo), "v"(hi));
-  return r;
-#else
-  return __builtin_amdgcn_perm(hi, lo, perm_selector());
-#endif
-}
-#if HARL_SPLIT_VARIANT == 3 || HARL_SPLIT_VARIANT == 4
-__device__ __forceinline__ unsigned cvt_pk_bf16_(float lo, float hi) {
-  unsigned r;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-  return r;
-}
-#endif
-#if HARL_SPLIT_VARIANT == 3
-// f - (low | high bf16 half of p): v_dot2_f32_bf16 d = p.lo * s.lo + p.hi * s.hi + f with s = {-1, 0} | {0, -1}
-__device__ __forceinline__ float sub_bf16_lo(float f, unsigned p) {
-  float r;
-  asm("v_dot2_f32_bf16 %0, %1, %2, %3" : "=v"(r) : "v"(p), "s"(0x0000BF80u), "v"(f));
-  return r;
-}
-__device__ __forceinline__ float sub_bf16_hi(float f, unsigned p) {
-  float r;
-  asm("v_dot2_f32_bf16 %0, %1, %2, %3" : "=v"(r) : "v"(p), "s"(0xBF800000u), "v"(f));
-  return r;
-}
-#endif
+// exact split of two floats into three packed bf16 pairs (low half = first value).  Truncation at every level: the three
+// pieces are the three bytes-and-a-bit of the significand, all of the sign of x (3 VALU ops per value, 1.5 per pack).
 template <bool PACKED = true>
 __device__ __forceinline__ void split3(float f0, float f1, unsigned &p1, unsigned &p2, unsigned &p3) {
-#if HARL_SPLIT_VARIANT == 3
-  p1 = cvt_pk_bf16_(f0, f1);
-  const float r0 = sub_bf16_lo(f0, p1), r1 = sub_bf16_hi(f1, p1);
-  p2 = cvt_pk_bf16_(r0, r1);
-  const float q0 = sub_bf16_lo(r0, p2), q1 = sub_bf16_hi(r1, p2);
-  p3 = cvt_pk_bf16_(q0, q1);
-#elif HARL_SPLIT_VARIANT == 4
-  p1 = cvt_pk_bf16_(f0, f1);
-  const f32x2 r = f32x2{f0, f1} - f32x2{__uint_as_float(p1 << 16), __uint_as_float(p1 & 0xffff0000u)};
-  p2 = cvt_pk_bf16_(r[0], r[1]);
-  const f32x2 q = r - f32x2{__uint_as_float(p2 << 16), __uint_as_float(p2 & 0xffff0000u)};
-  p3 = cvt_pk_bf16_(q[0], q[1]);
-#else
   // v_perm takes the high halves directly (no masking needed for the packed terms)
   const unsigned b0 = __float_as_uint(f0), b1 = __float_as_uint(f1);
-  p1 = pack_hi16_pair(b0, b1);
+  p1 = __builtin_amdgcn_perm(b1, b0, 0x07060302u);
   if constexpr (PACKED) {
     // the two remainders of a pair are ONE packed subtraction (v_pk_add_f32 with neg modifiers): 9 VALU ops per pair, at
     // the price of 64-bit-aligned register pairs (more pressure: the kernels that live at the register limit opt out)
     const f32x2 r = f32x2{f0, f1} - f32x2{__uint_as_float(b0 & 0xffff0000u), __uint_as_float(b1 & 0xffff0000u)};
     const unsigned c0 = __float_as_uint(r[0]), c1 = __float_as_uint(r[1]);
-    p2 = pack_hi16_pair(c0, c1);
+    p2 = __builtin_amdgcn_perm(c1, c0, 0x07060302u);
     // the last remainder has <= 8 significant bits: exact in bf16
     const f32x2 q = r - f32x2{__uint_as_float(c0 & 0xffff0000u), __uint_as_float(c1 & 0xffff0000u)};
-    p3 = pack_hi16_pair(__float_as_uint(q[0]), __float_as_uint(q[1]));
+    p3 = __builtin_amdgcn_perm(__float_as_uint(q[1]), __float_as_uint(q[0]), 0x07060302u);
   } else {
     const float r0 = f0 - __uint_as_float(b0 & 0xffff0000u), r1 = f1 - __uint_as_float(b1 & 0xffff0000u);
     const unsigned c0 = __float_as_uint(r0), c1 = __float_as_uint(r1);
-    p2 = pack_hi16_pair(c0, c1);
+    p2 = __builtin_amdgcn_perm(c1, c0, 0x07060302u);
     const float q0 = r0 - __uint_as_float(c0 & 0xffff0000u), q1 = r1 - __uint_as_float(c1 & 0xffff0000u);
-    p3 = pack_hi16_pair(__float_as_uint(q0), __float_as_uint(q1));
+    p3 = __builtin_amdgcn_perm(__float_as_uint(q1), __float_as_uint(q0), 0x07060302u);
   }
-#endif
 }
 
 // round-to-nearest variant for the weights (split once per workgroup; v_cvt_pk_bf16_f32 is slow but unbiased)

@@ -346,11 +346,14 @@ __device__ __forceinline__ void block_reduce_store8(float (&v)[NV], float *red /
   }
 }
 
-template <int H, int KP0, int DAP, bool DISCRETE, bool TRAIN, typename ARGS>
+// DA = the number of head outputs (1 for the critic): one instantiation per action width, so that the per-dimension loops of
+// the head and of the loss arithmetic have no run-time bounds; DAP = its padding to 4 | 8 = the layout of the head's LDS image
+template <int H, int KP0, int DA, bool DISCRETE, bool TRAIN, typename ARGS>
 __global__ __launch_bounds__(UF_THREADS, 2) void k_upd_fwd(UpdFwdArgs U, ARGS A) {
   constexpr bool CRITIC = std::is_same<ARGS, CriticArgs>::value;
-  static_assert(DAP <= 8, "the LDS head-gradient tile covers 8 head outputs");
-  constexpr int HROWS = CRITIC ? 1 : DAP;  // rows of the head weight gradient that can be non-zero
+  static_assert(DA >= 1 && DA <= 8 && (!CRITIC || DA == 1), "the LDS head-gradient tile covers 8 head outputs");
+  constexpr int DAP = DA <= 4 ? 4 : 8;
+  constexpr int HROWS = DA;  // rows of the head weight gradient that can be non-zero
   // KP0 == 0: the LAST hidden layer + head of a deeper network -- the input is x_hat_{L-1} as the previous layer kernel left
   // it in HBM (an ATL(H) image, U.x0n), "layer 2" is layer L, and the backward that follows is the layer kernels' from
   // dz_L on: x_hat_L, its mask and statistic never leave the chip (TRAIN only)
@@ -448,7 +451,7 @@ __global__ __launch_bounds__(UF_THREADS, 2) void k_upd_fwd(UpdFwdArgs U, ARGS A)
   ActorRow<DAP> rnext;
   float cvoldn = 0.f, cretn = 0.f;
   if (slab0 < U.n_slabs) {
-    if constexpr (!CRITIC) actor_row_load<DAP, DISCRETE, TRAIN>(A, slab0, lane, rnext);
+    if constexpr (!CRITIC) actor_row_load<DAP, DISCRETE, TRAIN, DA>(A, slab0, lane, rnext);
     else if constexpr (TRAIN) critic_row_load(A, slab0, lane, cvoldn, cretn);
   }
   PHASE_BEGIN();
@@ -503,7 +506,7 @@ __global__ __launch_bounds__(UF_THREADS, 2) void k_upd_fwd(UpdFwdArgs U, ARGS A)
 #pragma unroll
     for (int q = 0; q < H / 8; ++q) xs[q] = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
     float z[DAP];
-    head_fwd_regs<H, DAP>(xs, whl_h, cst, z);
+    head_fwd_regs<H, DAP, DA>(xs, whl_h, cst, z);
     PHASE(5);
     // this slab's rows (loaded one slab ago) are consumed now; the next slab's are requested where the GEMM operands are dead
     // (log-prob passes: here; optimiser steps: after the head weight gradient, the register peak of the loop) -- one set of
@@ -512,7 +515,7 @@ __global__ __launch_bounds__(UF_THREADS, 2) void k_upd_fwd(UpdFwdArgs U, ARGS A)
     const float cvold = cvoldn, cret = cretn;
     const long sn = slab + slab_stride < U.n_slabs ? slab + slab_stride : slab;
     if constexpr (!TRAIN) atl_load<2 * NXR>(U.x0n, sn, lane, xr);  // the next slab's normalised inputs likewise (TRAIN: after the head dW)
-    if constexpr (!TRAIN && !CRITIC) actor_row_load<DAP, DISCRETE, TRAIN>(A, sn, lane, rnext);  // (TRAIN: at the end of the body)
+    if constexpr (!TRAIN && !CRITIC) actor_row_load<DAP, DISCRETE, TRAIN, DA>(A, sn, lane, rnext);  // (TRAIN: at the end of the body)
     float dzh[DAP];
     float s1, s2;
     if constexpr (CRITIC) {
@@ -523,7 +526,7 @@ __global__ __launch_bounds__(UF_THREADS, 2) void k_upd_fwd(UpdFwdArgs U, ARGS A)
       s1 = dv * cst[4 * DAP];
       s2 = dv * (z[0] - cst[0]);
     } else {
-      if (!actor_sample<DAP, DISCRETE, TRAIN>(A, cst, z, slab, lane, adv_mean, adv_den, sc, dzh, s1, s2, rcur)) continue;
+      if (!actor_sample<DAP, DISCRETE, TRAIN, DA>(A, cst, z, slab, lane, adv_mean, adv_den, sc, dzh, s1, s2, rcur)) continue;
     }
     PHASE(6);
     if constexpr (TRAIN) {
@@ -581,8 +584,8 @@ __global__ __launch_bounds__(UF_THREADS, 2) void k_upd_fwd(UpdFwdArgs U, ARGS A)
       PHASE(7);
       atl_load<2 * NXR>(U.x0n, sn, lane, xr);
       // ---- head backward (W_head'^T dzh on the fp32 MFMA) + LayerNorm / ReLU backward -> dz_2
-      head_bwd_regs_bits<H, DAP>(xs, bits2[0], bits2[NW - 1], r2, slab, lane, whl, dzh, s1, s2, U.dz2);
-      if constexpr (!CRITIC) actor_row_load<DAP, DISCRETE, TRAIN>(A, sn, lane, rnext);
+      head_bwd_regs_bits<H, DAP, DA>(xs, bits2[0], bits2[NW - 1], r2, slab, lane, whl, dzh, s1, s2, U.dz2);
+      if constexpr (!CRITIC) actor_row_load<DAP, DISCRETE, TRAIN, DA>(A, sn, lane, rnext);
       else critic_row_load(A, sn, lane, cvoldn, cretn);
       PHASE(8);
     }
@@ -656,32 +659,38 @@ size_t fwd_lds_bytes(int H, int kp0, int dap, int hrows) {
 
 constexpr size_t LDS_PER_WG_MAX = 160 * 1024;  // gfx950: 160 KiB per CU
 
-template <int H, int KP0, int DAP, bool DISC, bool TRAIN, typename ARGS>
+template <int H, int KP0, int DA, bool DISC, bool TRAIN, typename ARGS>
 int launch_fwd(const UpdFwdArgs &U, const ARGS &A, hipStream_t s) {
-  // (the wave-private head-gradient tiles exist in optimiser steps only)
-  const size_t shm = fwd_lds_bytes(H, KP0, DAP, !TRAIN ? 0 : (std::is_same<ARGS, CriticArgs>::value ? 1 : DAP));
+  // (the wave-private head-gradient tiles exist in optimiser steps only: one row per head output)
+  const size_t shm = fwd_lds_bytes(H, KP0, DA <= 4 ? 4 : 8, TRAIN ? DA : 0);
   if (shm > LDS_PER_WG_MAX) {  // harl_update_supported() says so beforehand; never launch a kernel that cannot be resident
     return bad("harl_update_*: this (D, H, act_dim) does not fit the LDS of one workgroup");
   }
-  allow_big_lds(k_upd_fwd<H, KP0, DAP, DISC, TRAIN, ARGS>, shm);
-  hipLaunchKernelGGL((k_upd_fwd<H, KP0, DAP, DISC, TRAIN, ARGS>), dim3(fwd_grid(U.n_slabs)), dim3(UF_THREADS), shm, s, U, A);
+  allow_big_lds(k_upd_fwd<H, KP0, DA, DISC, TRAIN, ARGS>, shm);
+  hipLaunchKernelGGL((k_upd_fwd<H, KP0, DA, DISC, TRAIN, ARGS>), dim3(fwd_grid(U.n_slabs)), dim3(UF_THREADS), shm, s, U, A);
   return 0;
+}
+
+// one instantiation per action width 1..8 (the per-dimension loops of the head and the loss are compile-time bounded)
+template <int H, int KP0, bool TRAIN, int DA = 8>
+int launch_actor_width(const UpdFwdArgs &U, const ActorArgs &A, int discrete, hipStream_t s) {
+  if (A.act_dim == DA)
+    return discrete ? launch_fwd<H, KP0, DA, true, TRAIN, ActorArgs>(U, A, s) : launch_fwd<H, KP0, DA, false, TRAIN, ActorArgs>(U, A, s);
+  if constexpr (DA > 1) return launch_actor_width<H, KP0, TRAIN, DA - 1>(U, A, discrete, s);
+  return bad("harl_update_*: act_dim must be in [1, 8]");
 }
 
 template <bool TRAIN>
 int dispatch_fwd_actor(const UpdFwdArgs &U, const ActorArgs &A, int H, int discrete, hipStream_t s) {
   const int D = A.act_dim;
   if (D < 1 || D > 8) return bad("harl_update_fwd: act_dim must be in [1, 8]");
-  const int dap = D <= 4 ? 4 : 8;
   const int kp0 = U.D <= 32 ? 32 : 64;
-#define CASE(Hv, Kv, DAPv)                                                             \
-  if (H == Hv && kp0 == Kv && dap == DAPv) {                                            \
-    const int rc = discrete ? launch_fwd<Hv, Kv, DAPv, true, TRAIN, ActorArgs>(U, A, s)  \
-                            : launch_fwd<Hv, Kv, DAPv, false, TRAIN, ActorArgs>(U, A, s); \
-    return rc ? rc : check_launch("harl_update_fwd");                                  \
+#define CASE(Hv, Kv)                                                                \
+  if (H == Hv && kp0 == Kv) {                                                       \
+    const int rc = launch_actor_width<Hv, Kv, TRAIN>(U, A, discrete, s);             \
+    return rc ? rc : check_launch("harl_update_fwd");                               \
   }
-  CASE(128, 32, 4) CASE(128, 32, 8) CASE(128, 64, 4) CASE(128, 64, 8)
-  CASE(64, 32, 4) CASE(64, 32, 8) CASE(64, 64, 4) CASE(64, 64, 8)
+  CASE(128, 32) CASE(128, 64) CASE(64, 32) CASE(64, 64)
 #undef CASE
   return bad("harl_update_fwd: hidden width must be 64 or 128");
 }
@@ -690,22 +699,17 @@ int dispatch_fwd_actor(const UpdFwdArgs &U, const ActorArgs &A, int H, int discr
 int dispatch_last_actor(const UpdFwdArgs &U, const ActorArgs &A, int H, int discrete, hipStream_t s) {
   const int D = A.act_dim;
   if (D < 1 || D > 8) return bad("harl_update_last_actor: act_dim must be in [1, 8]");
-  const int dap = D <= 4 ? 4 : 8;
-#define CASE(Hv, DAPv)                                                               \
-  if (H == Hv && dap == DAPv) {                                                       \
-    const int rc = discrete ? launch_fwd<Hv, 0, DAPv, true, true, ActorArgs>(U, A, s)  \
-                            : launch_fwd<Hv, 0, DAPv, false, true, ActorArgs>(U, A, s); \
-    return rc ? rc : check_launch("harl_update_last_actor");                         \
-  }
-  CASE(128, 4) CASE(128, 8) CASE(64, 4) CASE(64, 8)
-#undef CASE
-  return bad("harl_update_last_actor: hidden width must be 64 or 128");
+  int rc;
+  if (H == 128) rc = launch_actor_width<128, 0, true>(U, A, discrete, s);
+  else if (H == 64) rc = launch_actor_width<64, 0, true>(U, A, discrete, s);
+  else return bad("harl_update_last_actor: hidden width must be 64 or 128");
+  return rc ? rc : check_launch("harl_update_last_actor");
 }
 
 int dispatch_last_critic(const UpdFwdArgs &U, const CriticArgs &A, int H, hipStream_t s) {
   int rc;
-  if (H == 128) rc = launch_fwd<128, 0, 4, false, true, CriticArgs>(U, A, s);
-  else if (H == 64) rc = launch_fwd<64, 0, 4, false, true, CriticArgs>(U, A, s);
+  if (H == 128) rc = launch_fwd<128, 0, 1, false, true, CriticArgs>(U, A, s);
+  else if (H == 64) rc = launch_fwd<64, 0, 1, false, true, CriticArgs>(U, A, s);
   else return bad("harl_update_last_critic: hidden width must be 64 or 128");
   return rc ? rc : check_launch("harl_update_last_critic");
 }
@@ -715,7 +719,7 @@ int dispatch_fwd_critic(const UpdFwdArgs &U, const CriticArgs &A, int H, hipStre
   const int kp0 = U.D <= 32 ? 32 : 64;
 #define CASE(Hv, Kv)                                                     \
   if (H == Hv && kp0 == Kv) {                                            \
-    const int rc = launch_fwd<Hv, Kv, 4, false, TRAIN, CriticArgs>(U, A, s); \
+    const int rc = launch_fwd<Hv, Kv, 1, false, TRAIN, CriticArgs>(U, A, s); \
     return rc ? rc : check_launch("harl_update_fwd");                        \
   }
   CASE(128, 32) CASE(128, 64) CASE(64, 32) CASE(64, 64)
@@ -730,9 +734,9 @@ HARL_PHASE_ACCESSOR(update)
 extern "C" int harl_update_supported(int D, int H, int act_dim, int kind) {
   if (!(D >= 0 && D <= 64 && (H == 64 || H == 128) && act_dim >= 1 && act_dim <= 8)) return 0;
   // D = 0: the last-layer variant (harl_update_last_*).  An optimiser step also holds the wave-private head-gradient tiles
-  // in LDS: actors with 128-wide layers and 33..64 inputs do not fit (165 / 183 KiB for heads of <= 4 / <= 8 outputs)
+  // in LDS (one row of H floats per head output and wave): actors with 128-wide layers and 33..64 inputs fit up to 2 outputs
   const int dap = act_dim <= 4 ? 4 : 8;
-  const int hrows = kind == 0 ? 0 : (kind == 2 ? 1 : dap);  // forward-only pass / critic step (one head output) / actor step
+  const int hrows = kind == 0 ? 0 : (kind == 2 ? 1 : act_dim);  // forward-only pass / critic step (one head output) / actor step
   return fwd_lds_bytes(H, D == 0 ? 0 : (D <= 32 ? 32 : 64), dap, hrows) <= LDS_PER_WG_MAX ? 1 : 0;
 }
 

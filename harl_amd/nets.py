@@ -27,6 +27,17 @@ SUPPORTED_WIDTHS = (64, 128, 256)
 ACT_IDS = {"relu": 0, "leaky_relu": 1, "tanh": 2, "sigmoid": 3, "selu": 4}
 
 
+_FUSED_UPDATE_MODES = ("hybrid", "logp", "1", "actor", "0")
+
+
+def _fused_update_mode() -> str:
+    """``HARL_FUSED_UPDATE`` (see _FlatNet.fused_update_ok), validated: an unknown value used to behave like "1" silently."""
+    mode = os.environ.get("HARL_FUSED_UPDATE", "hybrid")
+    if mode not in _FUSED_UPDATE_MODES:
+        raise ValueError(f"HARL_FUSED_UPDATE={mode!r}: expected one of {_FUSED_UPDATE_MODES}")
+    return mode
+
+
 def _space_shape(space) -> Tuple[int, ...]:
     """Duck-typed like the reference (harl/utils/envs_tools.py:15-29)."""
     name = space.__class__.__name__
@@ -474,7 +485,7 @@ class _FlatNet(nn.Module):
         launches with x_hat_1 recomputed in the backward (~1.9 KB per sample -- fewer bytes but more VALU work than the
         layer kernels and slower end to end on MI355X: DESIGN.md section 3); "actor" = "1" for actors only; "0" = never."""
         hs = self.hidden_sizes
-        mode = os.environ.get("HARL_FUSED_UPDATE", "hybrid")
+        mode = _fused_update_mode()
         if self.act_id:
             return False
         if mode == "0" or (train and mode == "logp") or (train and mode == "actor" and isinstance(self, VNet)):
@@ -493,7 +504,7 @@ class _FlatNet(nn.Module):
         Needs ReLU, equal 64 / 128-wide last two layers, a head of <= 8 outputs, and a layer kernel in front that stops
         before the last layer."""
         hs = self.hidden_sizes
-        if os.environ.get("HARL_FUSED_UPDATE", "hybrid") != "hybrid" or self.act_id or self.recurrent or self.md or self.panel:
+        if _fused_update_mode() != "hybrid" or self.act_id or self.recurrent or self.md or self.panel:
             return False
         if seq is not None or len(hs) < 2 or hs[-1] != hs[-2] or hs[-1] not in (64, 128) or self._layers()[-1][4] > 8:
             return False
@@ -502,7 +513,7 @@ class _FlatNet(nn.Module):
 
     def fused_hybrid(self) -> bool:
         """Optimiser steps as fused forward + layer-by-layer backward (see fused_update_ok)?"""
-        return os.environ.get("HARL_FUSED_UPDATE", "hybrid") == "hybrid"
+        return _fused_update_mode() == "hybrid"
 
     def hybrid_outputs(self):
         """(xh1, rmask1, rstd1) arguments of harl_update_fwd_*: layer 1's activation record for the layer-by-layer backward

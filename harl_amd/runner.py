@@ -58,6 +58,10 @@ class OnPolicyHARunner:
             raise NotImplementedError("share_param is a MAPPO feature (HAPPO/HATRPO/HAA2C need per-agent actors)")
         self.fixed_order = algo_args["algo"].get("fixed_order", True)
         self.action_aggregation = algo_args["algo"]["action_aggregation"]
+        if self.share_param and self.comm.world_size > 1 and (algo_args["model"].get("use_recurrent_policy")
+                                                             or algo_args["model"].get("use_naive_recurrent_policy")):
+            # refused before any rollout instead of in the first train() (configs.unsupported_reason has the why)
+            raise NotImplementedError("share_param with recurrent policies under data parallelism is not implemented")
 
         n_global = algo_args["train"]["n_rollout_threads"]
         lo, hi = shard_columns(n_global, self.comm.rank, self.comm.world_size)

@@ -32,10 +32,20 @@ def pytest_collection_modifyitems(config, items):
 
 @pytest.fixture(scope="session", autouse=True)
 def _library_present():
-    """A fresh checkout has no libharl_hip.so (built artefacts stay out of history): build it once before the first test that
-    loads it -- the CPU suite uses the library's host-side entry points (generator replay, harl_update_supported) even where the
-    kernels are stubbed.  Only when it is MISSING: an existing library is left alone (the GPU box receives the built one)."""
+    """A fresh checkout has no libharl_hip.so (built artefacts stay out of history), and an edited source tree may hold a STALE
+    one (new entry points missing -> AttributeError at load time): ``build()`` is called unconditionally -- it recompiles only
+    what its flag stamp / source mtimes say is out of date -- before the first test that loads the library.  The CPU suite uses
+    the library's host-side entry points (generator replay, harl_update_supported) even where the kernels are stubbed.  Without
+    hipcc and without a library there is nothing to run against: every test is skipped with that reason instead of erroring."""
+    import shutil
     from harl_amd import _lib
-    if not os.path.exists(_lib.LIB_PATH):
-        from harl_amd._build import build
-        build()
+    have_hipcc = bool(shutil.which("hipcc")) or os.path.exists("/opt/rocm/bin/hipcc")
+    if not have_hipcc:
+        if not os.path.exists(_lib.LIB_PATH):
+            pytest.skip("libharl_hip.so is missing and hipcc is not installed: build the library on a ROCm host "
+                        "(python -m harl_amd._build)", allow_module_level=False)
+        return
+    if os.environ.get("HARL_LIB"):  # an A/B variant was selected explicitly: leave it alone
+        return
+    from harl_amd._build import build
+    build()

@@ -28,7 +28,8 @@ def per_tensor(shapes, a, b):
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-    hip, runs, shapes, meta = G._bench_config_runs(n, True, keep_grad=True)
+    logp = sys.argv[2] if len(sys.argv) > 2 else "recipe"
+    hip, runs, shapes, meta = G._bench_config_runs(n, True, keep_grad=True, logp=logp)
     f32, f64 = runs["f32"], runs["f64"]
     A = meta["A"]
     np.set_printoptions(linewidth=200, precision=3)
@@ -40,22 +41,45 @@ def main():
     print("== per-update gradient vectors, |g - g64|_inf / |g64|_inf")
     for a in range(A):
         hg, g32, g64 = hip["grads"][a], f32["grads"][a], f64["grads"][a]
-        print(f"agent {a}: hip", " ".join(f"{vec_rel_err(x, y):.2e}" for x, y in zip(hg, g64)),
-              "| f32", " ".join(f"{vec_rel_err(x, y):.2e}" for x, y in zip(g32, g64)))
+        print(f"agent {a}: hip-f64", " ".join(f"{vec_rel_err(x, y):.2e}" for x, y in zip(hg, g64)),
+              "| f32-f64", " ".join(f"{vec_rel_err(x, y):.2e}" for x, y in zip(g32, g64)),
+              "| hip-f32", " ".join(f"{vec_rel_err(x, y):.2e}" for x, y in zip(hg, g32)))
+    print("== where the hip - f32 gradient differences sit: share of the squared difference carried by the worst OUTPUT ROW of the two "
+          "hidden weight matrices (a ReLU decision flipped on one heavy sample moves one row of dW_2 / one unit's column pattern)")
+    off = {}
+    o_ = 0
+    for name, shp in shapes["actor"]:
+        off[name] = (o_, shp)
+        o_ += int(np.prod(shp))
+    for a in range(A):
+        for u in range(len(hip["grads"][a])):
+            line = []
+            for nm in ("base.mlp.fc.0.weight", "base.mlp.fc.3.weight", "act.action_out.fc_mean.weight"):
+                o0, shp = off[nm]
+                n_ = int(np.prod(shp))
+                d = (hip["grads"][a][u][o0:o0 + n_] - f32["grads"][a][u][o0:o0 + n_]).reshape(shp)
+                g = f32["grads"][a][u][o0:o0 + n_].reshape(shp)
+                rows = (d * d).sum(1)
+                cols = (d * d).sum(0)
+                line.append(f"{nm.split('.')[-2]}: |d|/|g| {np.sqrt(rows.sum() / (g * g).sum()):.1e} top row {rows.max() / (rows.sum() + 1e-300):.2f} "
+                            f"top col {cols.max() / (cols.sum() + 1e-300):.2f}")
+            print(f"  agent {a} update {u}: " + " | ".join(line))
     print("== first update of every agent, per tensor: max|g - g64| (hip / f32) and max|g64|")
     for a in range(A):
         th = per_tensor(shapes["actor"], hip["grads"][a][0], f64["grads"][a][0])
         t3 = per_tensor(shapes["actor"], f32["grads"][a][0], f64["grads"][a][0])
-        for (nm, eh, mx), (_, e3, _) in zip(th, t3):
-            print(f"  agent {a} {nm:34s} hip {eh:.2e}  f32 {e3:.2e}  max|g| {mx:.2e}   ratio {eh / (e3 + 1e-30):.1f}")
+        t4 = per_tensor(shapes["actor"], hip["grads"][a][0], f32["grads"][a][0])
+        for (nm, eh, mx), (_, e3, _), (_, e4, _) in zip(th, t3, t4):
+            print(f"  agent {a} {nm:34s} hip-f64 {eh:.2e}  f32-f64 {e3:.2e}  hip-f32 {e4:.2e}  max|g| {mx:.2e}")
     print("== final parameters, per tensor: max|p - p64| (hip / f32), max|p64 - p0|")
     for a in range(A):
         p0 = torch.cat([v.reshape(-1) for v in meta["actor_sd"][a].values()]).double().numpy()
         th = per_tensor(shapes["actor"], hip["fin"][a], f64["fin"][a])
         t3 = per_tensor(shapes["actor"], f32["fin"][a], f64["fin"][a])
         tm = per_tensor(shapes["actor"], f64["fin"][a], p0)
-        for (nm, eh, mx), (_, e3, _), (_, mv, _) in zip(th, t3, tm):
-            print(f"  agent {a} {nm:34s} hip {eh:.2e}  f32 {e3:.2e}  moved {mv:.2e}  max|p| {mx:.2e}")
+        t4 = per_tensor(shapes["actor"], hip["fin"][a], f32["fin"][a])
+        for (nm, eh, mx), (_, e3, _), (_, mv, _), (_, e4, _) in zip(th, t3, tm, t4):
+            print(f"  agent {a} {nm:34s} hip-f64 {eh:.2e}  f32-f64 {e3:.2e}  hip-f32 {e4:.2e}  moved {mv:.2e}  max|p| {mx:.2e}")
         # the worst element: its gradient history
         d = np.abs(hip["fin"][a] - f64["fin"][a])
         i = int(np.argmax(d))
@@ -78,7 +102,18 @@ def main():
         for m in (1e-7, 1e-6, 1e-5, 1e-4):
             near = sum(int(((imp - e).abs() < m * e).sum()) for e in (1 - cfg.clip_param, 1 + cfg.clip_param))
             print(f"agent 0, first update: {near} of {B} samples with the ratio within {m:g} (relative) of a clip edge")
-        print("ratio quantiles", np.quantile(imp.numpy(), [0.01, 0.1, 0.5, 0.9, 0.99]))
+        print("ratio quantiles", np.quantile(imp.numpy(), [0.01, 0.1, 0.5, 0.9, 0.99, 0.9999, 1.0]))
+        # how much of the first update's gradient mass single samples carry: |d loss / d imp| x imp per sample (unclipped branch)
+        adv = torch.from_numpy(np.asarray(runs["f64"]["adv"], dtype=np.float64).reshape(B)) if "adv" in runs["f64"] else None
+        if adv is not None:
+            advn = (adv - adv.mean()) / (adv.std(unbiased=False) + 1e-5)
+            lo, hi = 1 - cfg.clip_param, 1 + cfg.clip_param
+            surr1, surr2 = imp * advn, imp.clamp(lo, hi) * advn
+            live = (surr1 <= surr2)  # the unclipped branch carries the gradient
+            wgt = (imp * advn.abs() * live).numpy()
+            srt = np.sort(wgt)[::-1]
+            print(f"first update, agent 0: samples on the unclipped branch {int(live.sum())}; share of sum|w| carried by the top 1 / 10 / 100 "
+                  f"samples: {srt[0] / srt.sum():.3f} {srt[:10].sum() / srt.sum():.3f} {srt[:100].sum() / srt.sum():.3f}")
     finally:
         O.set_work_dtype(torch.float32)
 

@@ -54,6 +54,7 @@ SIGNATURES = {
     "harl_adam_fold": [_vp, _vp, _vp, _vp, _l, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _f, _i, _i, _vp, _i, _f, _d, _d,
                        _d, _f, _f, _d, _d, _vp, _vp],
     "harl_pack_scalars_hilo": [_vp, _vp, _vp],
+    "harl_reduce_pack_scalars": [_vp, _i, _vp, _vp, _vp],
     "harl_randperm_replay": [_vp, _l, _l, _vp, _vp, _vp],
     "harl_rng_advance": [_vp, _l, _l, _vp],
     "harl_rng_jump": [_vp, _l, _l, _vp],

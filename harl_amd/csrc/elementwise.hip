@@ -681,6 +681,39 @@ extern "C" int harl_pack_scalars_hilo(const double *scalars, float *hilo, void *
   return check_launch("harl_pack_scalars_hilo");
 }
 
+// The data-parallel optimiser step needs both, back to back, in front of its collective: the fixed-order fp64 sum of the loss
+// kernel's partial rows (k_reduce_scalars, but OVERWRITING `scalars`: no separate clear) and the four fp32 pieces behind the
+// folded gradients -- ONE launch instead of a fill + two kernels (each a launch latency on the critical path of every step).
+// n_blocks = 0: this rank holds no row of the (global) minibatch: zeros.
+__global__ __launch_bounds__(1024) void k_reduce_pack_scalars(const float *__restrict__ ps, int n_blocks, double *__restrict__ out,
+                                                             float *__restrict__ hilo) {
+  __shared__ double sh[16][64];
+  const int j = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  double s = 0;
+  if (j < PS_STRIDE)
+    for (int b = rg; b < n_blocks; b += 16) s += (double)ps[(long)b * PS_STRIDE + j];
+  sh[rg][j] = s;
+  __syncthreads();
+  if (threadIdx.x < PS_STRIDE) {
+    double r = 0;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) r += sh[g][threadIdx.x];
+    out[threadIdx.x] = r;
+#pragma unroll
+    for (int k = 0; k < HILO_PIECES; ++k) {
+      const double p = trunc(r / HILO_Q[k]) * HILO_Q[k];
+      hilo[k * PS_STRIDE + threadIdx.x] = (float)p;
+      r -= p;
+    }
+  }
+}
+
+extern "C" int harl_reduce_pack_scalars(const float *part_scalars, int n_blocks, double *scalars, float *hilo, void *stream) {
+  if (n_blocks > 0 && !part_scalars) { set_error("harl_reduce_pack_scalars: part_scalars is NULL"); return -2; }
+  hipLaunchKernelGGL(k_reduce_pack_scalars, dim3(1), dim3(1024), 0, (hipStream_t)stream, part_scalars, n_blocks, scalars, hilo);
+  return check_launch("harl_reduce_pack_scalars");
+}
+
 // =============================================================================================
 // Layer table (device int32[HARL_TABLE_STRIDE * n_layers]) shared by the fused kernels below.
 //   0 w_off  1 b_off  2 gamma_off (-1)  3 beta_off (-1)     offsets into the flat parameter / gradient arena

@@ -160,7 +160,10 @@ __device__ __forceinline__ void head_fwd_regs(const f32x4 (&xs)[H / 8], const fl
   for (int d = 0; d < DA; ++d) z[d] = wave_sum32(z[d]) + cst[d];
 }
 
-template <int H, int DAP, int DA = DAP>
+// PACKED: the LayerNorm / ReLU backward of the epilogue on register pairs (2 x v_pk_fma_f32 per pair + the two-instruction
+// mask_pop per element: 3 VALU per element instead of 6) -- for the issue-bound fused kernel (update.hip); the stand-alone head
+// kernels are HBM-bound and keep the plain form, which leaves the scheduler free.
+template <int H, int DAP, int DA = DAP, bool PACKED = false>
 __device__ __forceinline__ void head_bwd_regs_bits(const f32x4 (&xs)[H / 8], uint32_t b0, const uint32_t b1, float rstd,
                                                    long slab, int lane, const float *whl /* base, both halves */,
                                                    const float (&dzh)[DAP], float s1, float s2,
@@ -192,18 +195,32 @@ __device__ __forceinline__ void head_bwd_regs_bits(const f32x4 (&xs)[H / 8], uin
       acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[16 * t * DAP + 2 * st], bsel, acc[t], 0, 0, 0);
   }
   f32x4 *op = reinterpret_cast<f32x4 *>(dz_out + slab * (long)(H * SLAB)) + lane;
+  const float c1 = -s1 * rstd, c2 = -s2 * rstd;
+  const f32x2 c1v = {c1, c1}, c2v = {c2, c2}, rv = {rstd, rstd};
 #pragma unroll
   for (int q = 0; q < H / 8; ++q) {
     if (q == 8) b0 = H == 256 ? bm1 : b1;  // next mask word; bits are consumed MSB-first
     if (H == 256 && q == 16) b0 = bm2;
     if (H == 256 && q == 24) b0 = b1;
     f32x4 o;
+    if constexpr (PACKED) {
+      // da = fma(x_hat, -s2 rstd, fma(dx_hat, rstd, -s1 rstd)) on pairs, as ln_bwd_relu_mbits (common.h)
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const float dx = acc[(4 * q + c) >> 4][(4 * q + c) & 15];
-      const float da = rstd * (dx - s1 - xs[q][c] * s2);
-      o[c] = (int)b0 < 0 ? da : 0.f;  // MSB-first mask (common.h)
-      b0 <<= 1;
+      for (int P = 0; P < 2; ++P) {
+        const int e = 4 * q + 2 * P;
+        const f32x2 d = {acc[e >> 4][e & 15], acc[(e + 1) >> 4][(e + 1) & 15]}, x = {xs[q][2 * P], xs[q][2 * P + 1]};
+        const f32x2 da = __builtin_elementwise_fma(x, c2v, __builtin_elementwise_fma(d, rv, c1v));
+        o[2 * P] = mask_pop(da[0], b0);
+        o[2 * P + 1] = mask_pop(da[1], b0);
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float dx = acc[(4 * q + c) >> 4][(4 * q + c) & 15];
+        const float da = rstd * (dx - s1 - xs[q][c] * s2);
+        o[c] = (int)b0 < 0 ? da : 0.f;  // MSB-first mask (common.h)
+        b0 <<= 1;
+      }
     }
     op[q * WAVE] = o;
   }

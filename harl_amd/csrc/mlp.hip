@@ -16,7 +16,6 @@
 // samples must become the MFMA k index); they go through LDS.
 //
 // Weights live in LDS for the lifetime of a persistent workgroup (three bf16 images, 96 KiB for 128 x 128).
-#include <cstdlib>
 #include "common.h"
 #include "split_mfma.h"
 #include "mfma_transpose.h"
@@ -1185,174 +1184,6 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_dw_tr(const float *__restrict
   dw_tr_body<MT, NT>(a_src, b_src, n_slabs, part, b_slab_floats, tile0, KP);
 }
 
-// =============================================================================================
-// k_dw_ws: the same weight-gradient partials with WAVE-SPECIALISED workgroups (round 4).  k_dw_tr's four waves all split, hit a
-// barrier, then all multiply: per slab and CU ~1.15k cycles of VALU issue per SIMD, then ~1.55k of matrix pipe, one after the
-// other (s_memtime: the MFMA phase takes 2.2 x its pipe time, the two co-resident workgroups drift into step).  A pure VALU
-// wave next to a pure MFMA wave on one SIMD loses little (profiles/r03_mfma_valu_overlap.md: 89 % / 65 % of their stand-alone
-// rates), so the roles are given to different waves: of the EIGHT waves of a workgroup (two per SIMD), waves 0-3 only stage --
-// load, split exactly, ds_write_b64 into the transposing images of buffer k & 1 -- and waves 4-7 only multiply -- transpose
-// reads + the 6 cross products of the slab staged one round earlier -- with ONE workgroup barrier per round instead of two.
-// LDS: two buffers of three term images per operand (97 KiB at 128 x 128): one workgroup per CU, 8 waves per CU as before.
-// =============================================================================================
-constexpr int WS_THREADS = 2 * WG_THREADS;
-
-template <int MT, int NT>
-__global__ __launch_bounds__(WS_THREADS, 1) void k_dw_ws(const float *__restrict__ a_src, const float *__restrict__ b_src,
-                                                         long n_slabs, float *__restrict__ part, long b_slab_floats,
-                                                         int tile0, int KP) {
-  using SP = DwSplit<MT, NT>;
-  constexpr int HA = 32 * MT, HB = 32 * NT;
-  constexpr int NPA = HA / 8, NPB = HB / 8, PER = (NPA + NPB) / WAVES_PER_WG;  // float4 pieces per lane and staging wave
-  static_assert((NPA + NPB) % WAVES_PER_WG == 0, "pieces divide evenly over the staging waves");
-  constexpr int SQA = (HA / 16) * 128 + 8, SQB = (HB / 16) * 128 + 8;  // bytes per sample quad (4 samples x H features + pad)
-  constexpr int IMG_A = 8 * SQA, IMG_B = 8 * SQB;                      // bytes per term image (32 samples)
-  constexpr int BUF = 3 * (IMG_A + IMG_B);
-  extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
-  const int lane = threadIdx.x & 63, wave8 = wave_id();
-  const int wave = wave8 & 3;
-  const int i = lane & 31, h = lane >> 5;
-  const long first = blockIdx.x, stride = gridDim.x;
-  const long R = first < n_slabs ? (n_slabs - first + stride - 1) / stride : 0;  // this workgroup's slabs
-  float *mypart = part + (long)blockIdx.x * ((long)HA * KP + HA);
-
-  if (wave8 < WAVES_PER_WG) {
-    // ---------------- staging waves: lane (sample i, half h) of piece q holds features 32 (q>>2) + 8 (q&3) + 4 h + c.
-    // The rows of TWO rounds are in flight (register sets pr[0] / pr[1]): a round is ~2k cycles here, shorter than an HBM round
-    // trip, and the four staging waves are all the loads a CU issues (64 KiB in flight per CU, what two co-resident k_dw_tr
-    // workgroups hold)
-    f32x4 pr[2][PER];
-    float dbacc[PER][4];
-#pragma unroll
-    for (int u = 0; u < PER; ++u)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) dbacc[u][c] = 0.f;
-    auto prefetch = [&](f32x4 (&dst)[PER], long slab) {
-#pragma unroll
-      for (int u = 0; u < PER; ++u) {
-        const int gu = wave * PER + u;
-        const bool is_a = gu < NPA;
-        const float *src = is_a ? a_src + slab * (long)(HA * SLAB) : b_src + slab * b_slab_floats;
-        const int q = is_a ? gu : gu - NPA + 4 * tile0;
-        dst[u] = (reinterpret_cast<const f32x4 *>(src) + lane)[q * WAVE];
-      }
-    };
-    auto stage = [&](const f32x4 (&src)[PER], long k) {
-      unsigned char *Ab = ldsb + (k & 1) * BUF, *Bb = Ab + 3 * IMG_A;
-#pragma unroll
-      for (int u = 0; u < PER; ++u) {
-        const int gu = wave * PER + u;
-        const bool is_a = gu < NPA;
-        const int q = is_a ? gu : gu - NPA;
-        const int sqb = is_a ? SQA : SQB, tstride = is_a ? IMG_A : IMG_B;
-        unsigned char *d = (is_a ? Ab : Bb) + (i >> 2) * sqb + (2 * (q >> 2) + ((q & 3) >> 1)) * 128 + (i & 3) * 32 +
-                           (8 * (q & 1) + 4 * h) * 2;
-        if (is_a) {
-#pragma unroll
-          for (int c = 0; c < 4; ++c) dbacc[u][c] += src[u][c];
-        }
-        unsigned t1a, t2a, t3a, t1b, t2b, t3b;
-        split3<false>(src[u][0], src[u][1], t1a, t2a, t3a);
-        split3<false>(src[u][2], src[u][3], t1b, t2b, t3b);
-        *reinterpret_cast<u32x2_t *>(d) = u32x2_t{t1a, t1b};
-        *reinterpret_cast<u32x2_t *>(d + tstride) = u32x2_t{t2a, t2b};
-        *reinterpret_cast<u32x2_t *>(d + 2 * tstride) = u32x2_t{t3a, t3b};
-      }
-    };
-    if (R > 0) prefetch(pr[0], first);
-    if (R > 1) prefetch(pr[1], first + stride);
-    for (long k = 0; k <= R; k += 2) {
-      if (k < R) {
-        stage(pr[0], k);
-        if (k + 2 < R) prefetch(pr[0], first + (k + 2) * stride);
-      }
-      __syncthreads();
-      if (k + 1 <= R) {
-        if (k + 1 < R) {
-          stage(pr[1], k + 1);
-          if (k + 3 < R) prefetch(pr[1], first + (k + 3) * stride);
-        }
-        __syncthreads();
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < PER; ++u) {
-      const int gu = wave * PER + u;
-      if (gu < NPA && tile0 == 0) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const float t = half_reduce_sum(dbacc[u][c]);
-          if (i == 0) mypart[(long)HA * KP + 32 * (gu >> 2) + 8 * (gu & 3) + 4 * h + c] = t;
-        }
-      }
-    }
-  } else {
-    // ---------------- multiplying waves: TM x TN output tiles each, the slab staged in the previous round
-    const int wm = wave % SP::WM, wn = wave / SP::WM;
-    f32x16 acc[SP::TM][SP::TN];
-#pragma unroll
-    for (int a = 0; a < SP::TM; ++a)
-#pragma unroll
-      for (int b = 0; b < SP::TN; ++b)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-    const int p16 = lane & 15, g1 = (lane >> 4) & 1;
-    const int frag_lane = g1 * 128 + (p16 >> 2) * 32 + (p16 & 3) * 8;
-    for (long k = 0; k <= R; ++k) {
-      if (k >= 1) {
-        const unsigned char *Ab = ldsb + ((k - 1) & 1) * BUF, *Bb = Ab + 3 * IMG_A;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          u32x4 av[3][SP::TM], bv[3][SP::TN];
-#pragma unroll
-          for (int term = 0; term < 3; ++term) {
-#pragma unroll
-            for (int a = 0; a < SP::TM; ++a) {
-              const unsigned char *fp = Ab + term * IMG_A + (4 * ks + 2 * h) * SQA + 2 * (wm * SP::TM + a) * 128 + frag_lane;
-              const u32x2_t lo = tr_read(fp), hi = tr_read(fp + SQA);
-              av[term][a] = u32x4{lo[0], lo[1], hi[0], hi[1]};
-            }
-#pragma unroll
-            for (int b = 0; b < SP::TN; ++b) {
-              const int nt = wn * SP::TN + b < NT ? wn * SP::TN + b : NT - 1;
-              const unsigned char *fp = Bb + term * IMG_B + (4 * ks + 2 * h) * SQB + 2 * nt * 128 + frag_lane;
-              const u32x2_t lo = tr_read(fp), hi = tr_read(fp + SQB);
-              bv[term][b] = u32x4{lo[0], lo[1], hi[0], hi[1]};
-            }
-          }
-#pragma unroll
-          for (int a = 0; a < SP::TM; ++a)
-#pragma unroll
-            for (int b = 0; b < SP::TN; ++b) {
-              acc[a][b] = mfma_bf16(av[2][a], bv[0][b], acc[a][b]);
-              acc[a][b] = mfma_bf16(av[0][a], bv[2][b], acc[a][b]);
-              acc[a][b] = mfma_bf16(av[1][a], bv[1][b], acc[a][b]);
-              acc[a][b] = mfma_bf16(av[1][a], bv[0][b], acc[a][b]);
-              acc[a][b] = mfma_bf16(av[0][a], bv[1][b], acc[a][b]);
-              acc[a][b] = mfma_bf16(av[0][a], bv[0][b], acc[a][b]);
-            }
-        }
-      }
-      __syncthreads();
-    }
-#pragma unroll
-    for (int a = 0; a < SP::TM; ++a) {
-      const int mt = wm * SP::TM + a;
-#pragma unroll
-      for (int b = 0; b < SP::TN; ++b) {
-        if (wn * SP::TN + b < NT) {
-          const int kcol = 32 * (tile0 + wn * SP::TN + b) + i;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int o = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * h;
-            mypart[(long)o * KP + kcol] = acc[a][b][r];
-          }
-        }
-      }
-    }
-  }
-}
-
 // several independent weight-gradient problems of one shape in ONE launch (blockIdx.y = problem): the six gate blocks of a
 // GRU (d gi_g^T x_hat, d gh_g^T h~) were six launches of ~17 us each per optimiser step at the SMAC sizes, most of it launch
 // latency and ramp-up (270 of them per 8-agent update)
@@ -1580,13 +1411,11 @@ extern "C" int harl_mlp_bwd_dx(const float *dz, const float *xprev, const uint32
   return check_launch("harl_mlp_bwd_dx");
 }
 
-// HARL_DW_WS=0 selects the four-wave kernel k_dw_tr (A/B; read once)
-static bool dw_wave_specialised() {
-  static const bool on = [] {
-    const char *e = getenv("HARL_DW_WS");
-    return !(e && e[0] == '0');
-  }();
-  return on;
+template <int MT, int NT>
+static void launch_dw_tr(const float *a, const float *b, long n_slabs, float *part, int K, int tile0, int n_wg, hipStream_t s) {
+  const size_t shm = (size_t)3 * 8 * ((2 * MT * 128 + 8) + (2 * NT * 128 + 8));
+  allow_big_lds(k_dw_tr<MT, NT>, shm);
+  hipLaunchKernelGGL((k_dw_tr<MT, NT>), dim3(n_wg), dim3(WG_THREADS), shm, s, a, b, n_slabs, part, (long)K * SLAB, tile0, K);
 }
 
 template <int A_KIND, int B_KIND, int MT, int NT>
@@ -1613,19 +1442,7 @@ extern "C" int harl_mlp_dw_partials(const float *a, int a_kind, int lda, int HO,
   if (b_kind == 0) {
     const int NT = K / 32;
     if (K % 32 != 0 || K < 32) return bad("harl_mlp_dw_partials: ATL input width must be a multiple of 32");
-#define DWS(MTv, NTv)                                                                                            \
-  {                                                                                                              \
-    const size_t shm = (size_t)3 * 8 * ((2 * MTv * 128 + 8) + (2 * NTv * 128 + 8));                              \
-    if (dw_wave_specialised() && 2 * shm <= 160 * 1024) {                                                        \
-      allow_big_lds(k_dw_ws<MTv, NTv>, 2 * shm);                                                                 \
-      hipLaunchKernelGGL((k_dw_ws<MTv, NTv>), dim3(n_wg), dim3(WS_THREADS), 2 * shm, s, a, b, n_slabs, part,      \
-                         (long)K * SLAB, tile0, K);                                                              \
-    } else {                                                                                                     \
-      allow_big_lds(k_dw_tr<MTv, NTv>, shm);                                                                     \
-      hipLaunchKernelGGL((k_dw_tr<MTv, NTv>), dim3(n_wg), dim3(WG_THREADS), shm, s, a, b, n_slabs, part,          \
-                         (long)K * SLAB, tile0, K);                                                              \
-    }                                                                                                            \
-  }
+#define DWS(MTv, NTv) launch_dw_tr<MTv, NTv>(a, b, n_slabs, part, K, tile0, n_wg, s);
     if (K > 128 || K == 96 || MT == 8) {  // wide first layer (and every 256-row operand): x0n ATL(K), K a multiple of 32 up to 512, in groups of <= 4 column tiles
       if (K % 32 != 0 || K > 512 || (MT != 8 && MT != 4 && MT != 2)) return bad("harl_mlp_dw_partials: wide ATL input must be a multiple of 32, <= 512");
       // every launch re-reads and re-splits dz: as few column groups as the register file allows (8 x 2 tiles for 256-wide

@@ -584,7 +584,7 @@ __global__ __launch_bounds__(UF_THREADS, 2) void k_upd_fwd(UpdFwdArgs U, ARGS A)
       PHASE(7);
       atl_load<2 * NXR>(U.x0n, sn, lane, xr);
       // ---- head backward (W_head'^T dzh on the fp32 MFMA) + LayerNorm / ReLU backward -> dz_2
-      head_bwd_regs_bits<H, DAP, DA>(xs, bits2[0], bits2[NW - 1], r2, slab, lane, whl, dzh, s1, s2, U.dz2);
+      head_bwd_regs_bits<H, DAP, DA, true>(xs, bits2[0], bits2[NW - 1], r2, slab, lane, whl, dzh, s1, s2, U.dz2);
       if constexpr (!CRITIC) actor_row_load<DAP, DISCRETE, TRAIN, DA>(A, sn, lane, rnext);
       else critic_row_load(A, sn, lane, cvoldn, cretn);
       PHASE(8);

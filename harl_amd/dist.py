@@ -24,6 +24,19 @@ class Comm:
         self.world_size = dist.get_world_size(group) if self.enabled else 1
         self.rank = dist.get_rank(group) if self.enabled else 0
 
+    def second_group(self) -> "Comm":
+        """A communicator of its own over the same ranks (``dist.new_group``: every rank must call this at the same point of
+        its program -- the runner's constructor does).  The critic's update gets one: its collectives then live in a queue
+        of their own, ordered only among themselves, so the critic's chain can run on its own stream next to the actors'
+        (runner.train) without the two chains' collectives having to interleave identically on every rank.  Each
+        communicator sees its collectives in host program order, which is the same on all ranks (same code path, the
+        minibatch structure does not depend on the rank).  Returns ``self`` when there is nothing to split."""
+        if not self.enabled or os.environ.get("HARL_CRITIC_GROUP", "1") == "0":
+            return self
+        g = dist.new_group(ranks=None if self.group is None else dist.get_process_group_ranks(self.group),
+                           backend=dist.get_backend(self.group))
+        return Comm(g)
+
     def _all_reduce(self, t: torch.Tensor) -> None:
         # RCCL reduces device tensors in place; the gloo backend (CPU tests, and the 2-ranks-on-1-GPU parity test)
         # is routed through host memory, which works for every build of gloo

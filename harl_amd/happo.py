@@ -298,11 +298,11 @@ class HAPPO(OnPolicyBase):
             nblk = None
         ps_kw = dict(part_scalars=net.part_scalars, n_scalar_blocks=nblk) if nblk is not None else {}
         if self.comm.enabled:  # ONE collective per optimiser step: [folded gradients | loss scalars] (dist.py)
-            if nblk is not None:
-                sc.zero_()
-                call("harl_reduce_scalars", ptr(net.part_scalars), nblk, ptr(sc), stream())
             hilo = net.dwp_msg[net.total_dwp:]
-            call("harl_pack_scalars_hilo", ptr(sc), ptr(hilo), stream())
+            if nblk is not None:  # partial rows -> fp64 sums -> fixed-grid fp32 pieces behind the gradients, one launch
+                call("harl_reduce_pack_scalars", ptr(net.part_scalars), nblk, ptr(sc), ptr(hilo), stream())
+            else:
+                call("harl_pack_scalars_hilo", ptr(sc), ptr(hilo), stream())
             self.comm.all_reduce_message(net.dwp_msg)
             ps_kw = dict(scalars_hilo=hilo)
         # loss = sum / sum(active) (happo.py:77-85): gradients are linear in 1/sum(active), applied inside the kernel

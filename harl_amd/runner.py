@@ -102,6 +102,11 @@ class OnPolicyHARunner:
         shard = (self.n_global, self.col_lo, self.col_hi) if self.comm.enabled else None
         for x in list(self.actor) + [self.critic]:
             x.comm, x.shard = self.comm, shard
+        # the critic's collectives go through a communicator of their own (dist.Comm.second_group): its update then runs on
+        # its own stream next to the actors' under data parallelism too
+        if getattr(self, "_critic_comm", None) is None:
+            self._critic_comm = self.comm.second_group()
+        self.critic.comm = self._critic_comm
         self._logp_old = None
         self._counts_host = None
         self._update_state_ready = True
@@ -169,7 +174,10 @@ class OnPolicyHARunner:
             # and every one of these persistent kernels ends with a tail in which most CUs have run out of slabs (kernel time
             # 0.19-0.26 ms against 0.14-0.20 ms for a wave's own slab loop, tools/phase_cycles.py) -- the other chain's next
             # kernel fills it.  HARL_CRITIC_STREAM=0 keeps one stream.
-            if dev.type == "cuda" and not self.comm.enabled and os.environ.get("HARL_CRITIC_STREAM", "1") != "0":
+            # Under data parallelism the second stream needs the critic's own communicator (two chains issuing into ONE
+            # communicator would have to interleave their collectives identically on every rank).
+            if (dev.type == "cuda" and (not self.comm.enabled or self.critic.comm is not self.comm)
+                    and os.environ.get("HARL_CRITIC_STREAM", "1") != "0"):
                 if getattr(self, "_critic_stream", None) is None:
                     self._critic_stream = torch.cuda.Stream(device=dev)
                 main_s = torch.cuda.current_stream(dev)

@@ -120,13 +120,10 @@ class VCritic:
         nblk = net.n_wg if m > 0 else 0  # rows of part_scalars
         ps_kw = dict(part_scalars=net.part_scalars, n_scalar_blocks=nblk)  # reduced inside the optimiser launch
         if self.comm.enabled:  # ONE collective per optimiser step: [folded gradients | loss scalars] (dist.py)
-            sc.zero_()
-            if m > 0:
-                call("harl_reduce_scalars", ptr(net.part_scalars), nblk, ptr(sc), s)
-            else:
+            if m <= 0:
                 net.dwp.zero_()
             hilo = net.dwp_msg[net.total_dwp:]
-            call("harl_pack_scalars_hilo", ptr(sc), ptr(hilo), s)
+            call("harl_reduce_pack_scalars", ptr(net.part_scalars), nblk, ptr(sc), ptr(hilo), s)  # (nblk = 0: zeros)
             self.comm.all_reduce_message(net.dwp_msg)
             ps_kw = dict(scalars_hilo=hilo)
         # loss = mean over the (global) minibatch, times value_loss_coef before backward (v_critic.py:112,146)

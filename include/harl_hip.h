@@ -187,6 +187,10 @@ int harl_reduce_partials_multi(const float *part, const int *table, int n_layers
  * 2^-16, 2^-36, each piece an integer multiple of its quantum below 2^20): the loss scalars ride behind the folded
  * gradients in the single fp32 SUM all-reduce of the data-parallel path and every piece sums EXACTLY over <= 16 ranks. */
 int harl_pack_scalars_hilo(const double *scalars, float *hilo, void *stream);
+/* harl_reduce_scalars (overwriting `scalars`, not accumulating) + harl_pack_scalars_hilo in ONE launch: what a data-parallel
+ * optimiser step does in front of its collective (harl_amd/happo.py _optimizer_step, v_critic.py; reference: the loss / entropy
+ * / ratio means of happo.py:77-91 and v_critic.py:112 become global means).  n_blocks = 0: zeros (no local row). */
+int harl_reduce_pack_scalars(const float *part_scalars, int n_blocks, double *scalars, float *hilo, void *stream);
 /* Fused optimiser epilogue (64 co-resident workgroups, software grid barrier between phases): loss scalars ->
  * gradient scale + statistics (info), unfold the folded gradients of every table entry into `grad` (reference parameter
  * layout; Linears sharing one LayerNorm accumulate its gradients), ||grad||, clip, Adam, re-fold the updated weights into

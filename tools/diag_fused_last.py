@@ -1,11 +1,10 @@
-"""Per-block breakdown of check_fused_vs_layered's folded-gradient comparison (debugging aid)."""
+"""Debugging aid: the data of tests/gpu_checks.check_fused_vs_layered (3 x 128, obs 23), layer-by-layer vs last-layer-in-loss
+launch: per-row comparison of dz_L (ATL image) and of the first-epoch log-probs."""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tests import gpu_checks as G
 from harl_amd.synthetic import Shapes, make_buffers
-from harl_amd._lib import call, ptr, stream
-from harl_amd import _lib
 
 def main():
     rows = int(sys.argv[1]) if len(sys.argv) > 1 else 32 * 8 * 256 * 2 + 7 * 32 + 3
@@ -18,35 +17,42 @@ def main():
     rng = np.random.default_rng(0)
     adv = dev(rng.standard_normal(rows).astype(np.float32)); factor = dev((1 + 0.1 * rng.standard_normal(rows)).astype(np.float32))
     active = dev((rng.random(rows) > 0.1).astype(np.float32))
+    _so = d.share_obs
+    vp = rng.standard_normal(rows).astype(np.float32)
+    _ret = (vp + rng.standard_normal(rows)).astype(np.float32)
     os.environ["HARL_FUSED_UPDATE"] = "0"
     actor.actor.fold()
     lp0 = torch.empty(rows, actor.actor.act_w, device=G.DEV)
     actor._logp_pass(obs, act, None, rows, lp0)
     old_logp = (lp0 + dev(0.1 * rng.standard_normal((rows, actor.actor.act_w)).astype(np.float32))).contiguous()
     got = {}
+    H = 128
     for tag, mode in (("old", "0"), ("new", "hybrid")):
         os.environ["HARL_FUSED_UPDATE"] = mode
         actor.actor.invalidate_caches()
         lp = torch.zeros(rows, actor.actor.act_w, device=G.DEV)
-        nblk = actor._forward_backward(obs, None, rows, act, None, old_logp, adv, None, factor, active, logp_out=lp)
-        sc = torch.zeros(_lib.PS_STRIDE, dtype=torch.float64, device=G.DEV)
-        call("harl_reduce_scalars", ptr(actor.actor.part_scalars), nblk, ptr(sc), stream())
-        got[tag] = (actor.actor.dwp.clone(), sc.clone(), lp.clone())
-    torch.cuda.synchronize()
-    net = actor.actor
-    offs = sorted(set([0, net.dwp.numel()] + [int(o) for o in net._dwp_offs]))
-    for a_, b_ in zip(offs[:-1], offs[1:]):
-        o, n = got["old"][0][a_:b_], got["new"][0][a_:b_]
-        print(f"block [{a_},{b_}): max|old| {float(o.abs().max()):.3e} max|new-old| {float((n-o).abs().max()):.3e} at {int((n-o).abs().argmax())}")
-    print("scalars old", got["old"][1][:14].cpu().numpy())
-    print("scalars new", got["new"][1][:14].cpu().numpy())
-    print("logp diff", float((got["old"][2] - got["new"][2]).abs().max()))
-    # head block detail: rows of dW_head
-    a_, b_ = offs[-2], offs[-1]
-    o, n = got["old"][0][a_:b_], got["new"][0][a_:b_]
-    H = hidden[-1]
-    dW_o, dW_n = o[:32 * H].reshape(32, H), n[:32 * H].reshape(32, H)
-    print("head dW row max diff", (dW_n - dW_o).abs().max(1).values[:8].cpu().numpy(), "row max", dW_o.abs().max(1).values[:8].cpu().numpy())
-    print("head db old", o[32 * H:32 * H + 8].cpu().numpy(), "new", n[32 * H:32 * H + 8].cpu().numpy())
+        actor._forward_backward(obs, None, rows, act, None, old_logp, adv, None, factor, active, logp_out=lp)
+        torch.cuda.synchronize()
+        nsl = (rows + 31) // 32
+        dz = actor.actor.dz[0][:nsl * 32 * H].clone().reshape(nsl, H // 8, 64, 4)
+        got[tag] = (dz, lp.clone(), actor.actor.dwp.clone())
+    dzo, dzn = got["old"][0], got["new"][0]
+    diff = (dzo - dzn).abs()
+    per_slab = diff.reshape(diff.shape[0], -1).max(1).values
+    scale = float(dzo.abs().max())
+    bad = (per_slab > 1e-5 * scale).nonzero().reshape(-1)
+    print("slabs", diff.shape[0], "max|dz|", scale, "slabs with |diff| > 1e-5 max:", bad.numel(), bad[:40].tolist())
+    if bad.numel():
+        s0 = int(bad[0])
+        dl = diff[s0].reshape(H // 8, 64, 4)
+        per_lane = dl.permute(1, 0, 2).reshape(64, -1).max(1).values
+        print("first bad slab", s0, "lanes with diff:", (per_lane > 1e-5 * scale).nonzero().reshape(-1).tolist())
+        print(" old lane vals", dzo[s0, :2, int(per_lane.argmax())].cpu().numpy(), "new", dzn[s0, :2, int(per_lane.argmax())].cpu().numpy())
+        # which grid position: slab = blockIdx * 8 + wave + k * grid*8
+        g = min(256, (diff.shape[0] + 7) // 8)
+        print(" block", (s0 % (g * 8)) // 8, "wave", s0 % 8, "iteration", s0 // (g * 8))
+        print("bad slab iterations histogram:", np.bincount((bad.cpu().numpy() // (g * 8))), "waves:", np.bincount(bad.cpu().numpy() % 8, minlength=8))
+    print("logp max diff", float((got["old"][1] - got["new"][1]).abs().max()))
+    print("dwp vec rel", float((got["old"][2] - got["new"][2]).abs().max() / got["old"][2].abs().max()))
 
 main()

@@ -722,6 +722,99 @@ extern "C" int harl_reduce_pack_scalars(const float *part_scalars, int n_blocks,
 // =============================================================================================
 constexpr int TS = 12;
 
+// ---------------------------------------------------------------------------------------------
+// Table-driven forms of harl_unfold_linear_grads / harl_fold_linear_tangent: every entry of the layer table in ONE launch.
+// HATRPO evaluates ~190 Fisher-vector products per 17-agent update, each of which folds a tangent and unfolds a gradient
+// entry by entry (4 + 4 launches of ~5 us: 1 560 launches per update); same arithmetic, same summation order, same bits.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_unfold_table(const float *__restrict__ p, float *__restrict__ g,
+                                                     const float *__restrict__ dwp, const int *__restrict__ tab, int n_layers) {
+  int k = blockIdx.x, l = 0;
+  for (; l < n_layers; ++l) {  // columns of all entries, concatenated
+    if (k < tab[l * TS + 5]) break;
+    k -= tab[l * TS + 5];
+  }
+  if (l >= n_layers) return;
+  const int *t = tab + l * TS;
+  const int O = t[4], K = t[5], kp = t[9], op = t[10], go = t[2], beo = t[3];
+  const float *dW_ = dwp + t[8];
+  const float *db_ = dW_ + (long)op * kp;
+  const float gam = go >= 0 ? p[go + k] : 1.f, bet = beo >= 0 ? p[beo + k] : 0.f;
+  for (int o = threadIdx.x; o < O; o += 64) {
+    const float d = dW_[(long)o * kp + k], dbo = db_[o];
+    g[t[0] + (long)o * K + k] = d * gam + dbo * bet;
+    if (k == 0) g[t[1] + o] = dbo;
+  }
+  if (go < 0) return;
+  for (int l2 = 0; l2 < l; ++l2)
+    if (tab[l2 * TS + 2] == go) return;  // an earlier entry owns this LayerNorm's gradients
+  // owner: this entry and the later ones that share the LayerNorm (the three GRU gate blocks), in table order, each sum
+  // rounded to float before the next is added -- the accumulate form of k_unfold
+  float accg = 0.f, accb = 0.f;
+  bool first = true;
+  for (int l2 = l; l2 < n_layers; ++l2) {
+    const int *t2 = tab + l2 * TS;
+    if (t2[2] != go) continue;
+    const int O2 = t2[4], K2 = t2[5], kp2 = t2[9], op2 = t2[10];
+    const float *dW2 = dwp + t2[8];
+    const float *db2 = dW2 + (long)op2 * kp2;
+    double sg = 0.0, sb = 0.0;  // double: heavy cancellation over o (see k_reduce_partials_multi)
+    for (int o = threadIdx.x; o < O2; o += 64) {
+      const float w = p[t2[0] + (long)o * K2 + k];
+      sg += (double)w * (double)dW2[(long)o * kp2 + k];
+      sb += (double)w * (double)db2[o];
+    }
+    sg = wave_reduce_sum_d(sg);
+    sb = wave_reduce_sum_d(sb);
+    accg = first ? (float)sg : (float)((double)accg + sg);
+    accb = first ? (float)sb : (float)((double)accb + sb);
+    first = false;
+  }
+  if (threadIdx.x == 0) {
+    g[go + k] = accg;
+    g[beo + k] = accb;
+  }
+}
+
+extern "C" int harl_unfold_table(const float *param, float *grad, const float *dwp, const int *table, int n_layers,
+                                 int total_cols, void *stream) {
+  if (n_layers <= 0 || total_cols <= 0) return 0;
+  hipLaunchKernelGGL(k_unfold_table, dim3(total_cols), dim3(64), 0, (hipStream_t)stream, param, grad, dwp, table, n_layers);
+  return check_launch("harl_unfold_table");
+}
+
+// tangent of the LayerNorm-affine fold of every entry:  Wp_dot = W_dot*g + W*g_dot ;  bp_dot = b_dot + W_dot.beta + W.beta_dot
+// (vec = the tangent direction in the flat parameter layout; one block per output row of every entry)
+__global__ __launch_bounds__(64) void k_fold_tangent_table(const float *__restrict__ p, const float *__restrict__ vec,
+                                                           float *__restrict__ packd, const int *__restrict__ tab, int n_layers) {
+  int o = blockIdx.x, l = 0;
+  for (; l < n_layers; ++l) {
+    if (o < tab[l * TS + 4]) break;
+    o -= tab[l * TS + 4];
+  }
+  if (l >= n_layers) return;
+  const int *t = tab + l * TS;
+  const int K = t[5], go = t[2], beo = t[3];
+  const float *W = p + t[0] + (long)o * K, *Wd = vec + t[0] + (long)o * K;
+  float *Wpd = packd + t[6] + (long)o * K;
+  float acc = 0.f;
+  for (int k = threadIdx.x; k < K; k += 64) {
+    const float w = W[k], wd = Wd[k];
+    Wpd[k] = go >= 0 ? wd * p[go + k] + w * vec[go + k] : wd;
+    if (beo >= 0) acc += wd * p[beo + k] + w * vec[beo + k];
+  }
+  acc = wave_reduce_sum(acc);
+  if (threadIdx.x == 0) packd[t[7] + o] = vec[t[1] + o] + acc;
+}
+
+extern "C" int harl_fold_tangent_table(const float *param, const float *vec, float *pack_d, const int *table, int n_layers,
+                                       int total_rows, void *stream) {
+  if (n_layers <= 0 || total_rows <= 0) return 0;
+  hipLaunchKernelGGL(k_fold_tangent_table, dim3(total_rows), dim3(64), 0, (hipStream_t)stream, param, vec, pack_d, table,
+                     n_layers);
+  return check_launch("harl_fold_tangent_table");
+}
+
 // out[dwp_off_l + e] = sum_w part[part_off_l + w * elems_l + e]   for every layer segment, ONE launch.
 // A block owns 64 consecutive elements; its four waves each sum a quarter of the partial rows (w = 4 k + wave) with
 // 8 independent accumulators, and the four sums are combined in fixed order through LDS: the kernel is a chain of
@@ -1039,32 +1132,79 @@ extern "C" int harl_trpo_fvp_finish(const float *grad, const float *vec, const f
   return check_launch("harl_trpo_fvp_finish");
 }
 
-__device__ __forceinline__ double block_sum_d(double v, double *sh) {  // 1024 threads -> every thread gets the sum
-  v = wave_reduce_sum_d(v);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  __syncthreads();  // sh may still be read from the previous reduction
-  if (lane == 0) sh[wave] = v;
-  __syncthreads();
-  double t = 0.0;
-#pragma unroll
-  for (int w = 0; w < 16; ++w) t += sh[w];
-  return t;
-}
 
-__global__ __launch_bounds__(1024) void k_trpo_cg_step(float *__restrict__ x, float *__restrict__ r, float *__restrict__ p,
-                                                       const float *__restrict__ avp, long n, float *__restrict__ state) {
+// CG_WGS co-resident workgroups with a software grid barrier after each of the two dot products (the scheme of k_adam_fold):
+// every thread keeps its 5-6 elements of x, r, p, F p in registers across the three phases -- each vector is read once and
+// written once.  Round 3 ran this as ONE workgroup of 1024 threads looping 82 times over dependent loads: 76 us per call, 170
+// calls per 17-agent update (5 % of it); now ~15 us.  Partial sums are combined in fixed order by every workgroup: same bits
+// every run.
+constexpr int CG_WGS = 64, CG_THREADS = 256, CG_PER = 8;  // up to 64 x 256 x 8 = 131 072 elements in registers; more: strided tail
+struct CgScratch {
+  unsigned bar[8];
+  double part[2][CG_WGS];
+};
+
+__global__ __launch_bounds__(CG_THREADS) void k_trpo_cg_step(float *__restrict__ x, float *__restrict__ r, float *__restrict__ p,
+                                                             const float *__restrict__ avp, long n, float *__restrict__ state,
+                                                             CgScratch *__restrict__ ws) {
 #pragma clang fp contract(off)
-  __shared__ double sh[16];
+  __shared__ double sh[CG_THREADS / 64];
   const float rdotr = state[0];
-  // the reference leaves its loop once rdotr < 1e-10 (trpo_util.py:127-128): later launches are true no-ops (block-uniform
-  // exit; multiplying the idle Fisher-vector product by alpha = 0 instead would turn a non-finite entry of it into NaN)
+  // the reference leaves its loop once rdotr < 1e-10 (trpo_util.py:127-128): later launches are true no-ops (uniform over the
+  // whole grid: `state` is only written after the second barrier; multiplying the idle Fisher-vector product by alpha = 0
+  // instead would turn a non-finite entry of it into NaN)
   if (state[1] != 0.f) return;
+  const int tid = threadIdx.x, blk = blockIdx.x;
+  const long gtid = (long)blk * CG_THREADS + tid, gnt = (long)CG_WGS * CG_THREADS;
+  auto block_sum = [&](double v) -> double {  // -> every thread of the workgroup
+    v = wave_reduce_sum_d(v);
+    __syncthreads();
+    if ((tid & 63) == 0) sh[tid >> 6] = v;
+    __syncthreads();
+    double t = 0;
+#pragma unroll
+    for (int w = 0; w < CG_THREADS / 64; ++w) t += sh[w];
+    return t;
+  };
+  auto grid_sum = [&](double v, int which, unsigned target) -> double {
+    const double t = block_sum(v);
+    if (tid == 0) ws->part[which][blk] = t;
+    grid_barrier(ws->bar, target);
+    double g = 0;
+    for (int b2 = 0; b2 < CG_WGS; ++b2) g += ws->part[which][b2];  // same order in every workgroup
+    return g;
+  };
+  float pv[CG_PER], av[CG_PER];
   double d = 0.0;
-  for (long i = threadIdx.x; i < n; i += 1024) d += (double)p[i] * (double)avp[i];
-  const float pavp = (float)block_sum_d(d, sh);
+#pragma unroll
+  for (int k = 0; k < CG_PER; ++k) {
+    const long i = gtid + k * gnt;
+    pv[k] = i < n ? p[i] : 0.f;
+    av[k] = i < n ? avp[i] : 0.f;
+  }
+#pragma unroll
+  for (int k = 0; k < CG_PER; ++k) d += (double)pv[k] * (double)av[k];
+  for (long i = gtid + CG_PER * gnt; i < n; i += gnt) d += (double)p[i] * (double)avp[i];  // (vectors beyond 131 072 entries)
+  const float pavp = (float)grid_sum(d, 0, (unsigned)CG_WGS);
   const float alpha = rdotr / pavp;
+  float rv[CG_PER];
   double rr = 0.0;
-  for (long i = threadIdx.x; i < n; i += 1024) {
+#pragma unroll
+  for (int k = 0; k < CG_PER; ++k) {
+    const long i = gtid + k * gnt;
+    if (i < n) {
+      const float ap = alpha * pv[k];
+      x[i] = x[i] + ap;
+      const float aa = alpha * av[k];
+      const float rn = r[i] - aa;
+      r[i] = rn;
+      rv[k] = rn;
+      rr += (double)rn * (double)rn;
+    } else {
+      rv[k] = 0.f;
+    }
+  }
+  for (long i = gtid + CG_PER * gnt; i < n; i += gnt) {
     const float ap = alpha * p[i];
     x[i] = x[i] + ap;
     const float aa = alpha * avp[i];
@@ -1072,20 +1212,57 @@ __global__ __launch_bounds__(1024) void k_trpo_cg_step(float *__restrict__ x, fl
     r[i] = rn;
     rr += (double)rn * (double)rn;
   }
-  const float new_rdotr = (float)block_sum_d(rr, sh);
+  const float new_rdotr = (float)grid_sum(rr, 1, (unsigned)(2 * CG_WGS));
   const float beta = new_rdotr / rdotr;
-  for (long i = threadIdx.x; i < n; i += 1024) {
+#pragma unroll
+  for (int k = 0; k < CG_PER; ++k) {
+    const long i = gtid + k * gnt;
+    if (i < n) {
+      const float bp = beta * pv[k];
+      p[i] = rv[k] + bp;
+    }
+  }
+  for (long i = gtid + CG_PER * gnt; i < n; i += gnt) {
     const float bp = beta * p[i];
     p[i] = r[i] + bp;
   }
-  if (threadIdx.x == 0) {
-    state[0] = new_rdotr;
-    state[1] = new_rdotr < 1e-10f ? 1.f : 0.f;
+  // last workgroup out: publish the new residual, reset the barrier words for the next launch
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned done = __hip_atomic_fetch_add(ws->bar + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (done == (unsigned)CG_WGS - 1) {
+      state[0] = new_rdotr;
+      state[1] = new_rdotr < 1e-10f ? 1.f : 0.f;
+      __hip_atomic_store(ws->bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(ws->bar + 1, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
+}
+
+// one scratch block per (device, stream), zero-initialised once, kept for the life of the process (cf. mm_scratch_of)
+static CgScratch *cg_scratch_of(hipStream_t s) {
+  static std::mutex mu;
+  static std::map<std::pair<int, hipStream_t>, CgScratch *> pool;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lk(mu);
+  const auto key = std::make_pair(dev, s);
+  auto it = pool.find(key);
+  if (it != pool.end()) return it->second;
+  CgScratch *p = nullptr;
+  if (hipMalloc(reinterpret_cast<void **>(&p), sizeof(CgScratch)) != hipSuccess) return nullptr;
+  if (hipMemset(p, 0, sizeof(CgScratch)) != hipSuccess) return nullptr;
+  pool.emplace(key, p);
+  return p;
 }
 
 extern "C" int harl_trpo_cg_step(float *x, float *r, float *p, const float *avp, long n, float *state, void *stream) {
   if (n <= 0) return 0;
-  hipLaunchKernelGGL(k_trpo_cg_step, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, r, p, avp, n, state);
+  CgScratch *ws = cg_scratch_of((hipStream_t)stream);
+  if (!ws) {
+    set_error("harl_trpo_cg_step: scratch allocation failed");
+    return -2;
+  }
+  hipLaunchKernelGGL(k_trpo_cg_step, dim3(CG_WGS), dim3(CG_THREADS), 0, (hipStream_t)stream, x, r, p, avp, n, state, ws);
   return check_launch("harl_trpo_cg_step");
 }

@@ -9,6 +9,7 @@ of CG / line search are host-side like the reference's.
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import numpy as np
@@ -95,10 +96,14 @@ class HATRPO(OnPolicyBase):
         vec = vec.contiguous()
         fp, pd = net.flat_param, ws["pack_d"]
         # tangent of every folded block, in table order, into an arena laid out like net.pack_arena
-        for (wo, bo, go, beo, o, k), (pw, pb, _, _) in zip(net._entries(), net._pack_slots):
-            call("harl_fold_linear_tangent", ptr(fp[wo:]), ptr(fp[go:]) if go >= 0 else None,
-                 ptr(fp[beo:]) if beo >= 0 else None, ptr(vec[wo:]), ptr(vec[bo:]), ptr(vec[go:]) if go >= 0 else None,
-                 ptr(vec[beo:]) if beo >= 0 else None, ptr(pd[pw:]), ptr(pd[pb:]), o, k, s)
+        if net.table is not None and os.environ.get("HARL_UNFOLD_TABLE", "1") != "0":  # one launch for all entries
+            call("harl_fold_tangent_table", ptr(fp), ptr(vec), ptr(pd), ptr(net.table), net.n_entries,
+                 sum(r[4] for r in net._table_rows), s)
+        else:
+            for (wo, bo, go, beo, o, k), (pw, pb, _, _) in zip(net._entries(), net._pack_slots):
+                call("harl_fold_linear_tangent", ptr(fp[wo:]), ptr(fp[go:]) if go >= 0 else None,
+                     ptr(fp[beo:]) if beo >= 0 else None, ptr(vec[wo:]), ptr(vec[bo:]), ptr(vec[go:]) if go >= 0 else None,
+                     ptr(vec[beo:]) if beo >= 0 else None, ptr(pd[pw:]), ptr(pd[pb:]), o, k, s)
         packs_d = [(pd[pw:pw + o * k], pd[pb:pb + o]) for (pw, pb, o, k) in net._pack_slots]
         Wpd, bpd = packs_d[0]
         if net.wide:  # x0n of the same rows is still there from the forward pass of _surrogate()

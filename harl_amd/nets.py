@@ -334,7 +334,9 @@ class _FlatNet(nn.Module):
         # MultiDiscrete: one logits image per group; the loss kernel overwrites it with d(loss)/d(logits)
         self.md_z = [torch.zeros(mp * sp, dtype=f32, device=dev) for sp in self._md_sp]
         n_iter = (n_slabs + 1) // 2
-        self.n_wg = max(1, min(512, n_iter))
+        # rows of the per-workgroup partial arena = grid of the weight-gradient kernels (two workgroups per CU: the measured
+        # optimum at 819 200 rows).  HARL_NWG overrides it (A/B measurements).
+        self.n_wg = max(1, min(int(os.environ.get("HARL_NWG", "512")), n_iter))
         part_off, rows = 0, [list(r) for r in self._table_rows]
         self._part_offs = []
         for r, elems in zip(rows, self._elems):
@@ -683,6 +685,10 @@ class _FlatNet(nn.Module):
         """self.dwp (dense folded gradients) -> self.flat_grad in the reference parameter layout (UNSCALED)."""
         s = stream()
         fp, fg = self.flat_param, self.flat_grad
+        if self.table is not None and os.environ.get("HARL_UNFOLD_TABLE", "1") != "0":  # every entry in one launch
+            call("harl_unfold_table", ptr(fp), ptr(fg), ptr(self.dwp), ptr(self.table), self.n_entries,
+                 sum(r[5] for r in self._table_rows), s)
+            return
         seen = set()
         for (wo, bo, go, beo, o, k), off, trow in zip(self._entries(), self._dwp_offs, self._table_rows):
             kp, op = trow[9], trow[10]

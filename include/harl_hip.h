@@ -183,6 +183,15 @@ int harl_reduce_partials(const float *part, int n_wg, long elems, float *out, vo
 /* dwp[dwp_off_l + e] = sum_w part[part_off_l + w*elems_l + e] for all layers in ONE launch (fixed order, deterministic) */
 int harl_reduce_partials_multi(const float *part, const int *table, int n_layers, int n_wg, long total_elems,
                                float *dwp, void *stream);
+/* harl_unfold_linear_grads / harl_fold_linear_tangent for EVERY entry of the layer table in one launch each (same arithmetic
+ * and summation order; Linears sharing a LayerNorm accumulate in table order): grad (reference parameter layout) from the
+ * dense folded gradients `dwp`; pack_d (laid out like the folded-weight arena) = tangent of the folded weights in direction
+ * `vec`.  total_cols = sum of the entries' input widths, total_rows = sum of their output widths.  Replaces autograd through
+ * the LayerNorm affine terms (harl/models/base/mlp.py:25-38) in HATRPO's Fisher-vector product (trpo_util.py:132-158). */
+int harl_unfold_table(const float *param, float *grad, const float *dwp, const int *table, int n_layers, int total_cols,
+                      void *stream);
+int harl_fold_tangent_table(const float *param, const float *vec, float *pack_d, const int *table, int n_layers,
+                            int total_rows, void *stream);
 /* hilo[k*PS + t], k = 0..3: the fp64 scalar t split into four fp32 pieces on a fixed exponent grid (quanta 2^24, 2^4,
  * 2^-16, 2^-36, each piece an integer multiple of its quantum below 2^20): the loss scalars ride behind the folded
  * gradients in the single fp32 SUM all-reduce of the data-parallel path and every piece sums EXACTLY over <= 16 ranks. */

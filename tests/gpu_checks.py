@@ -1411,7 +1411,8 @@ def check_fused_vs_layered(rows: int, mode: str = "1", hidden=(128, 128), obs_di
         # (round 4, tools/diag_fused_last.py: slab 1748, one row, everything else equal to 5e-7).  Those rows are taken out
         # of BOTH runs (active = 0), as the BASELINE-shape tests do (_mask_relu_kinks).
         imp0 = torch.exp((lp0 - old_logp).sum(-1))
-        near = ((imp0 / 0.8 - 1).abs() < 4e-6) | ((imp0 / 1.2 - 1).abs() < 4e-6)
+        # (2e-5: a log-prob of -24.46 carries 3 ulps = 5.7e-6 of difference between the two paths: 0.7999964 vs 0.8000012)
+        near = ((imp0 / 0.8 - 1).abs() < 2e-5) | ((imp0 / 1.2 - 1).abs() < 2e-5)
         active = torch.where(near, torch.zeros_like(active), active).contiguous()
         n_edge = int(near.sum().item())
         for tag, mode_ in (("old", "0"), ("new", mode), ("again", mode)):

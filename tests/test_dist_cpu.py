@@ -81,7 +81,18 @@ def _worker(rank, world, port, q):
         t_, n_ = loc // (hi - lo), loc % (hi - lo) + lo
         back = (t_ * N + n_).tolist()
         keep = [int(x) for x in perm.tolist() if lo <= x % N < hi]
-        q.put((rank, err, abs(scal[1].item() - act_full), max(abs(scal[0].item() - want0) / want0, abs(scal[2].item() - want2)), back == keep, (lo, hi)))
+        # the critic's communicator (Comm.second_group): a queue of its own over the same ranks; collectives of the two
+        # communicators interleaved in program order give the two independent sums
+        c2 = comm.second_group()
+        assert c2 is not comm and c2.enabled and c2.world_size == world and c2.rank == rank
+        ta, tb = torch.tensor([1.0 + rank], dtype=torch.float64), torch.tensor([10.0 * (1 + rank)], dtype=torch.float64)
+        for _ in range(3):
+            comm.all_reduce_sum(ta)
+            c2.all_reduce_sum(tb)
+        two_ok = float(ta.item()) == (world * (world + 1) / 2) * world ** 2 and float(tb.item()) == 10.0 * (world * (world + 1) / 2) * world ** 2
+        os.environ["HARL_CRITIC_GROUP"] = "0"
+        assert comm.second_group() is comm
+        q.put((rank, err, abs(scal[1].item() - act_full), max(abs(scal[0].item() - want0) / want0, abs(scal[2].item() - want2)), back == keep and two_ok, (lo, hi)))
     finally:
         dist.destroy_process_group()
 

@@ -51,6 +51,20 @@ def main():
         # which grid position: slab = blockIdx * 8 + wave + k * grid*8
         g = min(256, (diff.shape[0] + 7) // 8)
         print(" block", (s0 % (g * 8)) // 8, "wave", s0 % 8, "iteration", s0 // (g * 8))
+        row = s0 * 32 + int(per_lane.argmax()) % 32
+        lo_, ln_ = got["old"][1][row].double(), got["new"][1][row].double()
+        ol = old_logp[row].double()
+        print(" row", row, "active", float(active[row]), "adv", float(adv[row]), "factor", float(factor[row]))
+        print("  logp old path", lo_.cpu().numpy(), "\n  logp new path", ln_.cpu().numpy(), "\n  stored old_logp", ol.cpu().numpy())
+        print("  imp old path %.9f new path %.9f lp0-based %.9f" % (float(torch.exp((lo_ - ol).sum())), float(torch.exp((ln_ - ol).sum())),
+                                                                float(torch.exp((lp0[row].double() - ol).sum()))))
+        import struct
+        f32 = lambda v: struct.unpack("f", struct.pack("f", v))[0]
+        po, pn = 1.0, 1.0
+        for d_ in range(5):
+            po = f32(po * f32(float(torch.exp((got["old"][1][row, d_] - old_logp[row, d_])))))
+            pn = f32(pn * f32(float(torch.exp((got["new"][1][row, d_] - old_logp[row, d_])))))
+        print("  fp32 product of per-dim ratios: old path %.9f new path %.9f" % (po, pn))
         print("bad slab iterations histogram:", np.bincount((bad.cpu().numpy() // (g * 8))), "waves:", np.bincount(bad.cpu().numpy() % 8, minlength=8))
     print("logp max diff", float((got["old"][1] - got["new"][1]).abs().max()))
     print("dwp vec rel", float((got["old"][2] - got["new"][2]).abs().max() / got["old"][2].abs().max()))

@@ -28,7 +28,7 @@ Prints ONE JSON line (rank 0).  `roofline`: the streaming kernel family with the
 last warm-up step, where every family is bracketed by HIP events; inside the timed region only that family is) -- achieved =
 algorithmic HBM bytes of its launches in the timed region (harl_amd/traffic.py, from each launch's own arguments) / their
 HIP-event time; `traffic` = measured HBM bytes per launch from the committed PMC pass of that kernel
-(profiles/r03_hbm_traffic.json, stamped with the commit it was taken at).  `kernels`: full per-kernel breakdown from extra
+(profiles/r04_hbm_traffic.json, stamped with the commit it was taken at).  `kernels`: full per-kernel breakdown from extra
 instrumented steps after the timed region.  `cpu_baseline`: the oracle (torch-CPU restatement of the reference, same ATen
 kernels) on this box's host cores on a bounded sample of the same workload, warm-up + best of 3.
 """
@@ -331,8 +331,8 @@ def measure(w: dict, cfg_name: str, args, comm, rank: int, world: int, device, n
             ach = cand[dom]["bytes"] / tot_s
             per_launch = cand[dom]["bytes"] / cand[dom]["n"]
             traffic, traffic_note = None, None
-            tp = next((q for q in (os.path.join(ROOT, "profiles", f"r0{k}_hbm_traffic.json") for k in (3, 2)) if os.path.exists(q)),
-                      os.path.join(ROOT, "profiles", "r03_hbm_traffic.json"))
+            tp = next((q for q in (os.path.join(ROOT, "profiles", f"r0{k}_hbm_traffic.json") for k in (4, 3, 2)) if os.path.exists(q)),
+                      os.path.join(ROOT, "profiles", "r04_hbm_traffic.json"))
             if os.path.exists(tp):  # PMC passes over the same kernels at this workload's shapes (tools/pmc_traffic.sh)
                 tj = json.load(open(tp))
                 ent = tj.get("workloads", {}).get(cfg_name, {}).get(dom)

@@ -73,6 +73,7 @@ SIGNATURES = {
     "harl_gru_gates": [_vp, _vp, _i, _l, _vp, _vp, _vp, _i, _vp],
     "harl_gru_tangent": [_vp] * 15 + [_i, _i, _l, _vp, _vp],
     "harl_mlp_tangent_hidden": [_vp, _vp, _l, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "harl_mlp_tangent_hidden2": [_vp, _vp, _l, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "harl_actor_head_fvp": [_vp, _vp, _vp, _vp, _l, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _i, _vp, _l, _l, _vp, _vp, _vp],
     "harl_trpo_kl_sum": [_vp, _vp, _vp, _vp, _f, _f, _l, _i, _i, _vp, _vp],
     "harl_update_supported": [_i, _i, _i, _i],

@@ -861,18 +861,24 @@ extern "C" int harl_reduce_partials_multi(const float *part, const int *table, i
 }
 
 // ---------------------------------------------------------------------------------------------
-// Fused optimiser epilogue, ADAM_WGS co-resident workgroups with a software grid barrier between phases:
-//   A  loss scalars (optionally reduced here from the loss kernel's per-block partials) -> gradient scale + training
-//      statistics ; unfold the folded gradients of every table entry
-//   B  ||g||  (per-workgroup partial sums, combined in fixed order by every workgroup -> deterministic)
-//   C  clip + Adam
-//   D  re-fold the updated weights for the next forward
-// Replaces (per update) ~25 tiny launches: scalar reduce, unfold x L, reciprocal/cast/copy glue, grad-norm, Adam,
-// fold x L.  64 workgroups x 256 threads are always co-resident on 256 CUs (the stream is in-order, nothing else runs),
-// which is what makes the spin barrier safe; it costs ~2 us, a kernel boundary ~6-8 us.
-// ws: [0] arrivals, [1] finished, then doubles from byte 32: [w] per-workgroup sum of squares, [G + w*48 + j] scalar row sums
+// Fused optimiser epilogue: ADAM_WGS co-resident workgroups, ONE software grid barrier.
+//   1  loss scalars (optionally reduced here from the loss kernel's per-block partials); unfold the folded gradients of every
+//      table entry into `grad`; the LayerNorm-affine gradients; each workgroup's share of sum g^2                -- barrier --
+//   2  gradient scale + training statistics, ||g||, clip; then BY ROWS of the table entries (one wave per output row): Adam on
+//      the row's weights and bias and, from the updated values still in registers, the re-folded row W' = W gamma, b' = b + W.beta
+//      for the next forward.  The LayerNorm parameters a row needs are updated REDUNDANTLY in registers by every wave that
+//      needs them (same inputs, same arithmetic, same bits) and written back once, by the last workgroup to finish -- no
+//      barrier between Adam and the re-fold, none between ||g|| and Adam.
+// Round 3 ran  unfold | barrier | ||g|| | barrier | Adam | barrier | re-fold : 42 us per launch of pure latency, now 30.
+// (Measured and NOT kept in round 4: the split-K combine of the weight-gradient partials as a phase 0 of this launch -- 51 MB
+// through 64 workgroups: 103 us against 17 + 30 for the two launches; with 256 workgroups the barriers cost more than the
+// launch they save: 123 us.)
+// Replaces (per update) ~25 tiny launches of the reference's ATen path: scalar reduce, unfold x L, reciprocal/cast/copy glue,
+// grad-norm, Adam, fold x L.  64 workgroups x 256 threads are co-resident on 256 CUs (a few registers each), which is what
+// makes the spin barrier safe; other kernels on the chip only delay their arrival.
+// ws: [0] arrivals, [1] finished, then doubles from byte 32: [w] per-workgroup sum of squares, [G + r*48 + j] scalar row sums
 // ---------------------------------------------------------------------------------------------
-constexpr int ADAM_WGS = 64, ADAM_THREADS = 256;
+constexpr int ADAM_WGS = 64, ADAM_THREADS = 256, ADAM_SROWS = 64;
 
 __device__ __forceinline__ void grid_barrier(unsigned *bar, unsigned target) {
   __syncthreads();
@@ -885,10 +891,22 @@ __device__ __forceinline__ void grid_barrier(unsigned *bar, unsigned target) {
   __syncthreads();
 }
 
+struct AdamConsts {
+  float coef, lr_over_bc1, omb1, beta2, omb2, eps, wd, bc2_sqrt;
+};
+// torch.optim.Adam's single-tensor step on one element; returns the new parameter
+__device__ __forceinline__ float adam_elem(float g_raw, float pi, float &mi, float &vi, const AdamConsts &c) {
+  float gi = g_raw * c.coef;
+  if (c.wd != 0.f) gi = gi + c.wd * pi;
+  mi = mi + c.omb1 * (gi - mi);
+  vi = vi * c.beta2 + (c.omb2 * gi) * gi;
+  return pi - c.lr_over_bc1 * (mi / (sqrtf(vi) / c.bc2_sqrt + c.eps));
+}
+
 __global__ __launch_bounds__(ADAM_THREADS) void k_adam_fold(
     float *__restrict__ p, float *__restrict__ g, float *__restrict__ m, float *__restrict__ v, long n,
-    const float *__restrict__ dwp, const int *__restrict__ tab, int n_layers, float *__restrict__ packs,
-    double *__restrict__ scalars, const float *__restrict__ part_scalars, int n_scalar_blocks,
+    const float *__restrict__ dwp, const int *__restrict__ tab, int n_layers,
+    float *__restrict__ packs, double *__restrict__ scalars, const float *__restrict__ part_scalars, int n_scalar_blocks,
     const float *__restrict__ scalars_hilo, int mode, float const_scale, int logstd_off, int act_dim, double *__restrict__ info, int use_clip, float max_norm,
     float lr_over_bc1, float beta1, float beta2, float omb1, float omb2, float eps, float wd, float bc2_sqrt,
     unsigned *__restrict__ ws) {
@@ -898,22 +916,24 @@ __global__ __launch_bounds__(ADAM_THREADS) void k_adam_fold(
   const long gtid = (long)blk * nt + tid, gnt = (long)G * nt;
   const int gw = (int)(gtid >> 6), ln = tid & 63, gnw = (int)(gnt >> 6);  // global wave id / lane / wave count
   double *ws_part = reinterpret_cast<double *>(ws + 8);
+  double *ws_rows = ws_part + ADAM_WGS;  // [ADAM_SROWS][PS_STRIDE]
+  unsigned bar_target = 0;
 
-  // ---- phase A.0: loss-kernel partial rows -> 64 row sums (workgroup b takes rows b, b+G, ...; fixed order)
-  double *ws_rows = ws_part + ADAM_WGS;  // [G][PS_STRIDE]
-  if (part_scalars && tid < PS_STRIDE) {
+  // ---- phase 1.0: loss-kernel partial rows -> ADAM_SROWS row sums (workgroup b < ADAM_SROWS takes rows b, b + 64, ...)
+  if (part_scalars && blk < ADAM_SROWS && tid < PS_STRIDE) {
     double t0 = 0, t1 = 0, t2 = 0, t3 = 0;
     int b = blk;
-    for (; b + 3 * G < n_scalar_blocks; b += 4 * G) {
+    for (; b + 3 * ADAM_SROWS < n_scalar_blocks; b += 4 * ADAM_SROWS) {
       t0 += (double)part_scalars[(long)b * PS_STRIDE + tid];
-      t1 += (double)part_scalars[(long)(b + G) * PS_STRIDE + tid];
-      t2 += (double)part_scalars[(long)(b + 2 * G) * PS_STRIDE + tid];
-      t3 += (double)part_scalars[(long)(b + 3 * G) * PS_STRIDE + tid];
+      t1 += (double)part_scalars[(long)(b + ADAM_SROWS) * PS_STRIDE + tid];
+      t2 += (double)part_scalars[(long)(b + 2 * ADAM_SROWS) * PS_STRIDE + tid];
+      t3 += (double)part_scalars[(long)(b + 3 * ADAM_SROWS) * PS_STRIDE + tid];
     }
-    for (; b < n_scalar_blocks; b += G) t0 += (double)part_scalars[(long)b * PS_STRIDE + tid];
+    for (; b < n_scalar_blocks; b += ADAM_SROWS) t0 += (double)part_scalars[(long)b * PS_STRIDE + tid];
     ws_rows[blk * PS_STRIDE + tid] = (t0 + t1) + (t2 + t3);
   }
-  // ---- phase A.1: unfold  dW = dWp*gamma + dbp (x) beta ; db = dbp
+  // ---- phase 1.1: unfold  dW = dWp*gamma + dbp (x) beta ; db = dbp ; this thread's share of sum g^2 (unscaled)
+  double ss = 0.0;
   for (int l = 0; l < n_layers; ++l) {
     const int *t = tab + l * TS;
     const int O = t[4], K = t[5], kp = t[9], op = t[10];
@@ -924,11 +944,17 @@ __global__ __launch_bounds__(ADAM_THREADS) void k_adam_fold(
     for (long e = gtid; e < (long)O * K; e += gnt) {
       const int o = (int)(e / K), k = (int)(e - (long)o * K);
       const float dwp_ = dW_[(long)o * kp + k];
-      g[t[0] + e] = gam ? dwp_ * gam[k] + db_[o] * bet[k] : dwp_;
+      const float gv = gam ? dwp_ * gam[k] + db_[o] * bet[k] : dwp_;
+      g[t[0] + e] = gv;
+      ss += (double)gv * (double)gv;
     }
-    for (long o = gtid; o < O; o += gnt) g[t[1] + o] = db_[o];
+    for (long o = gtid; o < O; o += gnt) {
+      const float gv = db_[o];
+      g[t[1] + o] = gv;
+      ss += (double)gv * (double)gv;
+    }
   }
-  // ---- phase A.2: dgamma[k] = sum_{entries sharing gamma} sum_o W[o][k] dWp[o][k] ; dbeta[k] likewise with dbp[o].
+  // ---- phase 1.2: dgamma[k] = sum_{entries sharing gamma} sum_o W[o][k] dWp[o][k] ; dbeta[k] likewise with dbp[o].
   // One wave per (owner entry, column): lanes sweep the rows, then the entries that share the LayerNorm (the three
   // GRU gate blocks) in table order -- fixed order, no atomics, no zero-fill.
   {
@@ -959,20 +985,29 @@ __global__ __launch_bounds__(ADAM_THREADS) void k_adam_fold(
         sg = wave_reduce_sum_d(sg);
         sb = wave_reduce_sum_d(sb);
         if (ln == 0) {
-          g[go + k] = (float)sg;
-          g[t[3] + k] = (float)sb;
+          const float fg = (float)sg, fb = (float)sb;
+          g[go + k] = fg;
+          g[t[3] + k] = fb;
+          ss += (double)fg * (double)fg + (double)fb * (double)fb;
         }
       }
       wslot = (wslot + K) % gnw;  // spread the columns of successive LayerNorms over different waves
     }
   }
-  grid_barrier(ws, (unsigned)G);
-  // ---- every workgroup: the scalar sums (same fixed order everywhere); workgroup 0 publishes them
+  {
+    ss = wave_reduce_sum_d(ss);
+    if (ln == 0) sh[48 + (tid >> 6)] = ss;
+    __syncthreads();
+    if (tid == 0) ws_part[blk] = (sh[48] + sh[49]) + (sh[50] + sh[51]);
+  }
+  bar_target += (unsigned)G;
+  grid_barrier(ws, bar_target);
+  // ---- phase 2.0: every workgroup: the scalar sums (same fixed order everywhere); workgroup 0 publishes them
   if (tid < PS_STRIDE) {
     double t = 0;
     if (part_scalars) {
       double u0 = 0, u1 = 0, u2 = 0, u3 = 0;
-      for (int b = 0; b < G; b += 4) {
+      for (int b = 0; b < ADAM_SROWS; b += 4) {
         u0 += ws_rows[(b + 0) * PS_STRIDE + tid];
         u1 += ws_rows[(b + 1) * PS_STRIDE + tid];
         u2 += ws_rows[(b + 2) * PS_STRIDE + tid];
@@ -1003,72 +1038,105 @@ __global__ __launch_bounds__(ADAM_THREADS) void k_adam_fold(
     if (blk == 0 && tid == 0 && info) info[0] += (float)(sh[0] / sh[1]);
   }
   const bool has_ls = logstd_off >= 0;
-  if (has_ls && blk == 0 && tid < act_dim) g[logstd_off + tid] = (float)sh[8 + tid];  // read again in phase C
-  // ---- phase B: ||g * scale||   (log_std gradients come straight from the scalar sums)
-  {
-    double ss = 0;
-    for (long i = gtid; i < n; i += gnt) {
-      const bool is_ls = has_ls && i >= logstd_off && i < logstd_off + act_dim;
-      const float gi = (is_ls ? (float)sh[8 + (is_ls ? (int)(i - logstd_off) : 0)] : g[i]) * scale;
-      ss += (double)gi * gi;
-    }
-    __syncthreads();  // sh[0..48) fully read before it is reused for the wave partials
-    ss = wave_reduce_sum_d(ss);
-    if (ln == 0) sh[48 + (tid >> 6)] = ss;
-    __syncthreads();
-    if (tid == 0) ws_part[blk] = (sh[48] + sh[49]) + (sh[50] + sh[51]);
-  }
-  grid_barrier(ws, (unsigned)(2 * G));
-  float coef;
+  // ---- phase 2.1: ||g * scale||  (log_std gradients come straight from the scalar sums), clip coefficient
+  AdamConsts C;
   {
     double t = 0;
-    for (int b = 0; b < G; ++b) t += ws_part[b];  // same order in every workgroup
-    const float norm = (float)sqrt(t);
-    coef = 1.f;
+    for (int b = 0; b < G; b += 4) t += (ws_part[b] + ws_part[b + 1]) + (ws_part[b + 2] + ws_part[b + 3]);  // same order in every workgroup
+    if (has_ls)
+      for (int d = 0; d < act_dim; ++d) {
+        const float gl = (float)sh[8 + d];
+        t += (double)gl * (double)gl;
+      }
+    const float norm = (float)(sqrt(t) * fabs((double)scale));
+    float coef = 1.f;
     if (use_clip) {
       coef = max_norm / (norm + 1e-6f);
       coef = coef > 1.f ? 1.f : coef;
     }
     if (blk == 0 && tid == 0 && info) info[2 - mode] += norm;  // actor: info[2] ; critic: info[1]
+    C = AdamConsts{coef * scale, lr_over_bc1, omb1, beta2, omb2, eps, wd, bc2_sqrt};
   }
-  // ---- phase C: Adam
-  coef *= scale;
-  for (long i = gtid; i < n; i += gnt) {
-    float gi = g[i] * coef;
-    const float pi = p[i];
-    if (wd != 0.f) gi = gi + wd * pi;
-    float mi = m[i];
-    mi = mi + omb1 * (gi - mi);
-    const float vi = v[i] * beta2 + (omb2 * gi) * gi;
+  if (has_ls && blk == 0 && tid < act_dim) {  // log_std: no fold depends on it
+    const int i = logstd_off + tid;
+    const float gl = (float)sh[8 + tid];
+    g[i] = gl;
+    float mi = m[i], vi = v[i];
+    p[i] = adam_elem(gl, p[i], mi, vi, C);
     m[i] = mi;
     v[i] = vi;
-    p[i] = pi - lr_over_bc1 * (mi / (sqrtf(vi) / bc2_sqrt + eps));
   }
-  grid_barrier(ws, (unsigned)(3 * G));
-  // ---- phase D: re-fold   Wp = W*gamma ; bp = b + W.beta
-  for (int l = 0; l < n_layers; ++l) {
-    const int *t = tab + l * TS;
-    const int O = t[4], K = t[5];
-    const float *gam = t[2] >= 0 ? p + t[2] : nullptr;
-    const float *bet = t[3] >= 0 ? p + t[3] : nullptr;
-    for (long e = gtid; e < (long)O * K; e += gnt) {
-      const int k = (int)(e % K);
-      const float w = p[t[0] + e];
-      packs[t[6] + e] = gam ? w * gam[k] : w;
-    }
-    for (int o = gw; o < O; o += gnw) {
-      float acc = 0.f;
-      if (bet)
-        for (int k = ln; k < K; k += 64) acc += p[t[0] + o * K + k] * bet[k];
-      acc = wave_reduce_sum(acc);
-      if (ln == 0) packs[t[7] + o] = p[t[1] + o] + acc;
+  // ---- phase 2.2: one wave per output row of every entry: Adam on W[o][:], b[o]; re-fold the row from the updated values.
+  // gamma / beta of the entry's LayerNorm: updated here in registers only (every wave that needs them: same bits), written
+  // back by the last workgroup below -- their stored values are read by other waves until then.
+  {
+    int rbase = 0;
+    for (int l = 0; l < n_layers; ++l) {
+      const int *t = tab + l * TS;
+      const int O = t[4], K = t[5], go = t[2], beo = t[3];
+      for (int o = gw - (rbase % gnw); o < O; o += gnw) {
+        if (o < 0) continue;
+        float acc = 0.f;
+        for (int k = ln; k < K; k += 64) {
+          const long i = t[0] + (long)o * K + k;
+          float mi = m[i], vi = v[i];
+          const float w = adam_elem(g[i], p[i], mi, vi, C);
+          p[i] = w;
+          m[i] = mi;
+          v[i] = vi;
+          float wp = w;
+          if (go >= 0) {
+            float mg = m[go + k], vg = v[go + k];
+            wp = w * adam_elem(g[go + k], p[go + k], mg, vg, C);
+            float mb = m[beo + k], vb = v[beo + k];
+            acc += w * adam_elem(g[beo + k], p[beo + k], mb, vb, C);
+          }
+          packs[t[6] + (long)o * K + k] = wp;
+        }
+        acc = wave_reduce_sum(acc);
+        if (ln == 0) {
+          const long i = t[1] + o;
+          float mi = m[i], vi = v[i];
+          const float bnew = adam_elem(g[i], p[i], mi, vi, C);
+          p[i] = bnew;
+          m[i] = mi;
+          v[i] = vi;
+          packs[t[7] + o] = bnew + acc;
+        }
+      }
+      rbase += O;
     }
   }
-  // ---- reset the barrier words for the next launch (last workgroup out)
+  // ---- last workgroup out: write back the LayerNorm parameters (every reader is done), reset the barrier words
   __syncthreads();
+  __shared__ unsigned last_flag;
   if (tid == 0) {
+    __threadfence();
     const unsigned done = __hip_atomic_fetch_add(ws + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    if (done == (unsigned)G - 1) {
+    last_flag = done == (unsigned)G - 1 ? 1u : 0u;
+  }
+  __syncthreads();
+  if (last_flag) {
+    for (int l = 0; l < n_layers; ++l) {
+      const int *t = tab + l * TS;
+      const int go = t[2], beo = t[3], K = t[5];
+      if (go < 0) continue;
+      bool owner = true;
+      for (int l2 = 0; l2 < l; ++l2) owner = owner && (tab[l2 * TS + 2] != go);
+      if (!owner) continue;
+      for (int k = tid; k < K; k += nt) {
+        float mg = m[go + k], vg = v[go + k];
+        p[go + k] = adam_elem(g[go + k], p[go + k], mg, vg, C);
+        m[go + k] = mg;
+        v[go + k] = vg;
+        float mb = m[beo + k], vb = v[beo + k];
+        p[beo + k] = adam_elem(g[beo + k], p[beo + k], mb, vb, C);
+        m[beo + k] = mb;
+        v[beo + k] = vb;
+      }
+    }
+    __syncthreads();
+    if (tid == 0) {
       __hip_atomic_store(ws, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(ws + 1, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -1076,19 +1144,18 @@ __global__ __launch_bounds__(ADAM_THREADS) void k_adam_fold(
 }
 
 extern "C" int harl_adam_fold(float *param, float *grad, float *exp_avg, float *exp_avg_sq, long n, const float *dwp,
-                              const int *table, int n_layers, float *packs, double *scalars, const float *part_scalars,
-                              int n_scalar_blocks, const float *scalars_hilo, int mode, float const_scale, int logstd_off,
-                              int act_dim, double *info,
-                              int use_clip, float max_norm, double lr, double beta1, double beta2, float eps,
-                              float weight_decay, double bias_correction1, double bias_correction2, void *ws,
-                              void *stream) {
+                              const int *table, int n_layers, float *packs, double *scalars,
+                              const float *part_scalars, int n_scalar_blocks, const float *scalars_hilo, int mode,
+                              float const_scale, int logstd_off, int act_dim, double *info, int use_clip, float max_norm,
+                              double lr, double beta1, double beta2, float eps, float weight_decay, double bias_correction1,
+                              double bias_correction2, void *ws, void *stream) {
   if (!ws) { set_error("harl_adam_fold: workspace (>= 32 KiB, zero-initialised once) is required"); return -2; }
   const float step_size = (float)(lr / bias_correction1);
   const float bc2_sqrt = (float)sqrt(bias_correction2);
   hipLaunchKernelGGL(k_adam_fold, dim3(ADAM_WGS), dim3(ADAM_THREADS), 0, (hipStream_t)stream, param, grad, exp_avg,
-                     exp_avg_sq, n, dwp, table, n_layers, packs, scalars, part_scalars, n_scalar_blocks, scalars_hilo, mode,
-                     const_scale, logstd_off, act_dim, info, use_clip, max_norm, step_size, (float)beta1, (float)beta2,
-                     (float)(1.0 - beta1), (float)(1.0 - beta2), eps, weight_decay, bc2_sqrt, (unsigned *)ws);
+                     exp_avg_sq, n, dwp, table, n_layers, packs, scalars, part_scalars, n_scalar_blocks,
+                     scalars_hilo, mode, const_scale, logstd_off, act_dim, info, use_clip, max_norm, step_size, (float)beta1,
+                     (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), eps, weight_decay, bc2_sqrt, (unsigned *)ws);
   return check_launch("harl_adam_fold");
 }
 

@@ -276,8 +276,11 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_x0n_narrow(const float *__res
 // ---------------------------------------------------------------------------------------------
 // fp32 Wp[H][D] -> three bf16 images [term][tile][k-step][64 lanes] x 16 B in global memory, K zero-padded to KP
 // ---------------------------------------------------------------------------------------------
+// (WpB != NULL: the matrix is the column concatenation [Wp | WpB] with DA columns in Wp and D - DA in WpB -- the hidden-layer
+// tangent's [W' | W'_dot])
 __global__ __launch_bounds__(256) void k_split_image(const float *__restrict__ Wp, int H, int D, int KP,
-                                                     u32x4 *__restrict__ img) {
+                                                     u32x4 *__restrict__ img, const float *__restrict__ WpB = nullptr,
+                                                     int DA = 0) {
   const int MT = H / 32, NJ = KP / 16, total = MT * NJ * 64;
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
     const int ln = e & 63, j = (e >> 6) % NJ, t = (e >> 6) / NJ, m = 32 * t + (ln & 31), g = ln >> 5;
@@ -286,8 +289,14 @@ __global__ __launch_bounds__(256) void k_split_image(const float *__restrict__ W
     for (int c = 0; c < 4; ++c) {
       // B operand of k-step j, lane half g = x0n registers 8 j .. 8 j + 7; register R <-> feature feat_base(R) + 4 g
       const int f0 = feat_base(8 * j + 2 * c) + 4 * g, f1 = feat_base(8 * j + 2 * c + 1) + 4 * g;
-      const float w0 = f0 < D ? Wp[(long)m * D + f0] : 0.f;
-      const float w1 = f1 < D ? Wp[(long)m * D + f1] : 0.f;
+      float w0, w1;
+      if (WpB) {
+        w0 = f0 < DA ? Wp[(long)m * DA + f0] : (f0 < D ? WpB[(long)m * (D - DA) + (f0 - DA)] : 0.f);
+        w1 = f1 < DA ? Wp[(long)m * DA + f1] : (f1 < D ? WpB[(long)m * (D - DA) + (f1 - DA)] : 0.f);
+      } else {
+        w0 = f0 < D ? Wp[(long)m * D + f0] : 0.f;
+        w1 = f1 < D ? Wp[(long)m * D + f1] : 0.f;
+      }
       split3_rne(w0, w1, p[0][c], p[1][c], p[2][c]);
     }
 #pragma unroll
@@ -308,16 +317,23 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_fwd_wide(const float *__restr
                                                             uint32_t *__restrict__ mask_out, float *__restrict__ rstd_out,
                                                             const float *__restrict__ xprimal,
                                                             const uint32_t *__restrict__ mask_in,
-                                                            const float *__restrict__ rstd_in, long n_slabs, int KP) {
+                                                            const float *__restrict__ rstd_in, long n_slabs, int KP,
+                                                            const float *__restrict__ x0n_b = nullptr, int KPA = 0) {
+  // x0n_b != NULL: the input is the feature concatenation of TWO images, ATL(KPA) `x0n` and ATL(KP - KPA) `x0n_b` (slab g of
+  // an ATL(KP) image is the concatenation of its 32-feature blocks, so k-steps below KPA / 16 read the first image and the
+  // others the second): the hidden-layer tangent  z_dot = W' x_dot + W'_dot x_hat + b'_dot  as ONE K = 2 H GEMM
   constexpr int MT = HO / 32;
   const int NJ = KP / 16, TS = MT * NJ * 64;
+  const int KA = x0n_b ? KPA : KP, NJA = KA / 16, KB = KP - KA;
   const int lane = threadIdx.x & 63, wave = wave_id(), h = lane >> 5;
   const long n_pairs = (n_slabs + 1) / 2;
   const u32x4 *wl = img + lane;
   for (long pair = (long)blockIdx.x * WAVES_PER_WG + wave; pair < n_pairs; pair += (long)gridDim.x * WAVES_PER_WG) {
     const long s0 = 2 * pair, s1 = s0 + 1 < n_slabs ? s0 + 1 : s0;
-    const f32x4 *xp0 = reinterpret_cast<const f32x4 *>(x0n + s0 * (long)KP * SLAB) + lane;
-    const f32x4 *xp1 = reinterpret_cast<const f32x4 *>(x0n + s1 * (long)KP * SLAB) + lane;
+    const f32x4 *xp0 = reinterpret_cast<const f32x4 *>(x0n + s0 * (long)KA * SLAB) + lane;
+    const f32x4 *xp1 = reinterpret_cast<const f32x4 *>(x0n + s1 * (long)KA * SLAB) + lane;
+    const f32x4 *xq0 = x0n_b ? reinterpret_cast<const f32x4 *>(x0n_b + s0 * (long)KB * SLAB) + lane : xp0;
+    const f32x4 *xq1 = x0n_b ? reinterpret_cast<const f32x4 *>(x0n_b + s1 * (long)KB * SLAB) + lane : xp1;
     f32x16 acc0[MT], acc1[MT];
 #pragma unroll
     for (int t = 0; t < MT; ++t)
@@ -330,10 +346,12 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_fwd_wide(const float *__restr
       for (int term = 0; term < 3; ++term)
 #pragma unroll
         for (int t = 0; t < MT; ++t) an[term][t] = wl[(long)term * TS + (t * NJ + j) * 64];
-      bn[0][0] = xp0[(2 * j) * WAVE];
-      bn[0][1] = xp0[(2 * j + 1) * WAVE];
-      bn[1][0] = xp1[(2 * j) * WAVE];
-      bn[1][1] = xp1[(2 * j + 1) * WAVE];
+      const f32x4 *b0 = j < NJA ? xp0 + (2 * j) * WAVE : xq0 + (2 * (j - NJA)) * WAVE;  // (wave-uniform)
+      const f32x4 *b1 = j < NJA ? xp1 + (2 * j) * WAVE : xq1 + (2 * (j - NJA)) * WAVE;
+      bn[0][0] = b0[0];
+      bn[0][1] = b0[WAVE];
+      bn[1][0] = b1[0];
+      bn[1][1] = b1[WAVE];
     };
     fetch(0);
     for (int j = 0; j < NJ; ++j) {
@@ -605,6 +623,32 @@ int launch_wide(const float *x0n, long M, int KP, const float *Wp, int D, const 
 }  // namespace
 
 HARL_PHASE_ACCESSOR(wide)
+
+// Hidden-layer tangent in ONE launch:  x_out_dot = LNjac(mask . ([W' | W'_dot] [x_in_dot ; x_hat_in] + b'_dot))  -- a K = 2 HI
+// GEMM over the two input images with the weight images streamed from L2 (k_fwd_wide MODE 1).  harl_mlp_tangent_hidden
+// (mlp.hip) runs the two products as two launches through the output image (the two matrices do not fit the LDS together):
+// 3.1 KB of traffic per sample against 2.1 KB here, and one launch less per hidden layer and Fisher-vector product.
+extern "C" int harl_mlp_tangent_hidden2(const float *xin_dot, const float *xin, long M, int HI, int HO, const float *Wp,
+                                        const float *Wdp, const float *bdp, void *w_img, const float *xprimal,
+                                        const uint32_t *mask_in, const float *rstd_in, float *xout_dot, void *stream) {
+  if (M <= 0) return 0;
+  if ((HO != 128 && HO != 64) || (HI != 128 && HI != 64)) return bad("harl_mlp_tangent_hidden2: widths must be 64 or 128");
+  if (!w_img || !xin_dot || !xin) return bad("harl_mlp_tangent_hidden2: inputs and the weight-image scratch are required");
+  hipStream_t s = (hipStream_t)stream;
+  const long n_slabs = n_slabs_of(M);
+  const int KP = 2 * HI, total = (HO / 32) * (KP / 16) * 64;
+  hipLaunchKernelGGL(k_split_image, dim3((total + 255) / 256), dim3(256), 0, s, Wp, HO, KP, KP, reinterpret_cast<u32x4 *>(w_img),
+                     Wdp, HI);
+  const long pairs = (n_slabs + 1) / 2, wgs = (pairs + WAVES_PER_WG - 1) / WAVES_PER_WG;
+  const int grid = (int)(wgs < 256 ? (wgs < 1 ? 1 : wgs) : 256);
+  if (HO == 128)
+    hipLaunchKernelGGL((k_fwd_wide<128, 1>), dim3(grid), dim3(WG_THREADS), 0, s, xin_dot, reinterpret_cast<const u32x4 *>(w_img),
+                       bdp, xout_dot, nullptr, nullptr, xprimal, mask_in, rstd_in, n_slabs, KP, xin, HI);
+  else
+    hipLaunchKernelGGL((k_fwd_wide<64, 1>), dim3(grid), dim3(WG_THREADS), 0, s, xin_dot, reinterpret_cast<const u32x4 *>(w_img),
+                       bdp, xout_dot, nullptr, nullptr, xprimal, mask_in, rstd_in, n_slabs, KP, xin, HI);
+  return check_launch("harl_mlp_tangent_hidden2");
+}
 
 extern "C" int harl_mlp_x0n_wide(const float *X, long ldx, const int64_t *idx, long M, int D, int use_ln0, float *x0n,
                                  float *mu0, float *rstd0, void *stream) {

@@ -8,6 +8,7 @@ of the accumulated training statistics at the end.
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import numpy as np

@@ -113,11 +113,19 @@ class HATRPO(OnPolicyBase):
             call("harl_mlp_tangent_input", ptr(obs), obs.shape[1], ptr(idx), m, net.in_dim, ptr(Wpd), ptr(bpd),
                  int(net.use_feature_normalization), hs[0], ptr(net.xh[0]), ptr(net.rmask[0]), ptr(net.rstd[0]),
                  ptr(ws["xd"][0]), s)
+        one_launch = os.environ.get("HARL_TANGENT_ONE_LAUNCH", "1") != "0"
         for l in range(1, L):
             Wp, _ = net._packs[l]
             Wpd, bpd = packs_d[l]
-            call("harl_mlp_tangent_hidden", ptr(ws["xd"][l - 1]), ptr(net.xh[l - 1]), m, hs[l - 1], hs[l], ptr(Wp), ptr(Wpd),
-                 ptr(bpd), ptr(net.xh[l]), ptr(net.rmask[l]), ptr(net.rstd[l]), ptr(ws["xd"][l]), s, tag="tangent_hidden")
+            if one_launch:  # [W' | W'_dot] [x_dot ; x_hat] as ONE K = 2 H GEMM, weight images streamed from L2 (csrc/wide.hip)
+                if ws.get("timg") is None or ws["timg"].numel() < 3 * hs[l] * hs[l - 1]:
+                    ws["timg"] = torch.empty(3 * max(hs) * max(hs), **self.tpdv)  # 3 terms x HO x 2 HI bf16
+                call("harl_mlp_tangent_hidden2", ptr(ws["xd"][l - 1]), ptr(net.xh[l - 1]), m, hs[l - 1], hs[l], ptr(Wp), ptr(Wpd),
+                     ptr(bpd), ptr(ws["timg"]), ptr(net.xh[l]), ptr(net.rmask[l]), ptr(net.rstd[l]), ptr(ws["xd"][l]), s,
+                     tag="tangent_hidden")
+            else:
+                call("harl_mlp_tangent_hidden", ptr(ws["xd"][l - 1]), ptr(net.xh[l - 1]), m, hs[l - 1], hs[l], ptr(Wp), ptr(Wpd),
+                     ptr(bpd), ptr(net.xh[l]), ptr(net.rmask[l]), ptr(net.rstd[l]), ptr(ws["xd"][l]), s, tag="tangent_hidden")
         fx, fmask, frstd, fh = net.feat()
         xLdot = ws["xd"][-1]
         mv, mp_ = 0, 0

@@ -280,6 +280,13 @@ class _FlatNet(nn.Module):
             self.gru_pack = dict(Wih=self.pack_arena[b0:b0 + n], bih=self.pack_arena[b0 + n:b0 + n + 3 * H],
                                  Whh=self.pack_arena[b0 + n + 3 * H:b0 + 2 * n + 3 * H],
                                  bhh=self.pack_arena[b0 + 2 * n + 3 * H:b0 + 2 * n + 6 * H])
+        # harl_adam_fold updates parameters by table entry (rows of W with their bias, the LayerNorm in front, log_std): every
+        # parameter must be reachable that way
+        covered = sum(o * k + o for (_, _, _, _, o, k) in ents)
+        covered += sum(k for go, k in {(go, k) for (_, _, go, _, _, k) in ents if go >= 0}) * 2
+        if isinstance(self, StochasticPolicy) and not self.discrete:
+            covered += self.act_dim
+        assert covered == self.n_params, f"layer table covers {covered} of {self.n_params} parameters"
         self.table = None  # device table is finalised in _ensure_ws (part offsets depend on n_wg)
 
     def fold(self) -> None:
@@ -538,6 +545,12 @@ class _FlatNet(nn.Module):
         (W1, b1), (W2, b2), (Wh, bh) = self._packs[0], self._packs[1], self._packs[-1]
         return (ptr(self.x0n), M, self.in_dim, self.hidden_sizes[0], ptr(W1), ptr(b1), ptr(W2), ptr(b2), ptr(Wh), ptr(bh))
 
+    def _combine_partials(self, s) -> None:
+        """The deterministic split-K combine of every layer's per-workgroup weight-gradient partials into self.dwp, one launch.
+        (Round 4 measured it as a first phase of harl_adam_fold instead: slower, csrc/elementwise.hip.)"""
+        call("harl_reduce_partials_multi", ptr(self.part), ptr(self.table), self.n_entries, self.n_wg, self.total_dwp,
+             ptr(self.dwp), s, tag="reduce_partials")
+
     def backward_fused(self, M: int) -> None:
         """dz_2 (self.dz[0], written by harl_update_fwd_*) + x0n -> dense folded gradients self.dwp (UNSCALED sums);
         the head's partial rows were written by the forward launch."""
@@ -546,8 +559,7 @@ class _FlatNet(nn.Module):
         po = self._part_offs
         call("harl_update_bwd", ptr(self.x0n), ptr(self.dz[0]), M, self.in_dim, self.hidden_sizes[0], ptr(W1), ptr(b1),
              ptr(W2), ptr(self.part[po[0]:]), ptr(self.part[po[1]:]), self.n_wg, s, tag="update_bwd")
-        call("harl_reduce_partials_multi", ptr(self.part), ptr(self.table), self.n_entries, self.n_wg, self.total_dwp,
-             ptr(self.dwp), s, tag="reduce_partials")
+        self._combine_partials(s)
 
     # ---- backward: dz_L (in self.dz[0]) and dhead -> dense folded gradients self.dwp (UNSCALED sums over samples)
     def backward_trunk(self, X: torch.Tensor, idx: Optional[torch.Tensor], M: int, seq: Optional[dict] = None,
@@ -598,8 +610,7 @@ class _FlatNet(nn.Module):
                     call("harl_mlp_panel_bwd", ptr(self.dz[cur]), ptr(self.xh[l - 1]), ptr(self.rmask[l - 1]),
                          ptr(self.rstd[l - 1]), M, 256, 256, ptr(Wp), ptr(self.dz[1 - cur]), s, tag="bwd_panel")
                     cur = 1 - cur
-            call("harl_reduce_partials_multi", ptr(self.part), ptr(self.table), self.n_entries, nwg, self.total_dwp,
-                 ptr(self.dwp), s, tag="reduce_partials")
+            self._combine_partials(s)
             return
         if self.act_id:
             # activation other than ReLU: the loss kernel / harl_mlp_bwd_dx were handed an all-ones mask, so self.dz holds the
@@ -619,8 +630,7 @@ class _FlatNet(nn.Module):
                      self.act_id, s, tag="act_bwd")
             call("harl_mlp_dw_partials", ptr(self.dz[cur]), 0, 0, hs[0], ptr(self.x0n), 0, 0, None, None, None, self.kp0, M,
                  ptr(self.part[po[0]:]), nwg, s, tag="dw_input")
-            call("harl_reduce_partials_multi", ptr(self.part), ptr(self.table), self.n_entries, nwg, self.total_dwp,
-                 ptr(self.dwp), s, tag="reduce_partials")
+            self._combine_partials(s)
             return
         # first-layer weight gradient fused into the last bwd_dx (needs the ones column of x0n: in_dim < kp0)
         fuse_dw1 = L >= 2 and self.x0n is not None and self.in_dim < self.kp0 and self.kp0 <= 64
@@ -648,8 +658,7 @@ class _FlatNet(nn.Module):
                  ptr(self.mu0) if use_ln else None, ptr(self.rstd0) if use_ln else None, self.in_dim, M,
                  ptr(self.part[po[0]:]), nwg, s, tag="dw_input")
         # deterministic fixed-order combine of every entry's per-workgroup partials, one launch
-        call("harl_reduce_partials_multi", ptr(self.part), ptr(self.table), self.n_entries, nwg, self.total_dwp,
-             ptr(self.dwp), s, tag="reduce_partials")
+        self._combine_partials(s)
 
     # ---- MultiDiscrete heads (csrc/multihead.hip): logits of every group from the head input; backward of the groups
     def md_logits(self, M: int) -> None:

@@ -205,6 +205,7 @@ ALGORITHMIC_BYTES: Dict[str, Callable[[Sequence], float]] = {
     "harl_mlp_panel_fwd": _panel_fwd,
     "harl_mlp_panel_bwd": _panel_bwd,
     "harl_mlp_tangent_hidden": _tangent_hidden,
+    "harl_mlp_tangent_hidden2": _tangent_hidden,  # (same leading arguments: xin_dot, xin, M, HI, HO)
 }
 
 
@@ -297,6 +298,7 @@ ALGORITHMIC_FLOPS: Dict[str, Callable[[Sequence], float]] = {
     "harl_mlp_fwd_input": lambda a: 2.0 * a[3] * a[4] * a[8],
     "harl_mlp_tangent_wide": lambda a: 2.0 * a[1] * a[4] * a[6],  # the inputs carry no tangent: one GEMM
     "harl_mlp_tangent_hidden": lambda a: 2.0 * 2 * a[2] * a[3] * a[4],
+    "harl_mlp_tangent_hidden2": lambda a: 2.0 * 2 * a[2] * a[3] * a[4],
     "harl_mlp_bwd_dx": _f_bwd_dx,
     "harl_mlp_dw_partials": _f_dw,
     "harl_mlp_dw_partials_multi": _f_dw_multi,

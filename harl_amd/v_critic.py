@@ -1,6 +1,7 @@
 """V critic on MI355X (reference: harl/algorithms/critics/v_critic.py:14-208)."""
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -91,6 +92,26 @@ class VCritic:
                       local_count=(seq["L"] * seq["m"] if seq is not None else m))
         net._ensure_ws(max(m, 1))
         sc = net.scalars
+        self._forward_backward(net, share_obs, idx, m, value_preds, returns, vn, seq, s)
+        nblk = net.n_wg if m > 0 else 0  # rows of part_scalars
+        ps_kw = dict(part_scalars=net.part_scalars, n_scalar_blocks=nblk)  # reduced inside the optimiser launch
+        if self.comm.enabled:  # ONE collective per optimiser step: [folded gradients | loss scalars] (dist.py)
+            if m <= 0:
+                net.dwp.zero_()
+            hilo = net.dwp_msg[net.total_dwp:]
+            call("harl_reduce_pack_scalars", ptr(net.part_scalars), nblk, ptr(sc), ptr(hilo), s)  # (nblk = 0: zeros)
+            self.comm.all_reduce_message(net.dwp_msg)
+            ps_kw = dict(scalars_hilo=hilo)
+        # loss = mean over the (global) minibatch, times value_loss_coef before backward (v_critic.py:112,146)
+        scale = float(self.value_loss_coef) / float(m_global)
+        self.critic_optimizer.step(1, scale, self.use_max_grad_norm, self.max_grad_norm, self._info, **ps_kw)
+        if self._trace is not None:
+            self._trace.append(self._info.clone())
+        if self._grad_tap is not None:
+            self._grad_tap(net.flat_grad * scale, sc.clone())
+
+    def _forward_backward(self, net, share_obs, idx, m, value_preds, returns, vn, seq, s) -> None:
+        """Forward, value loss and backward of one minibatch: the unscaled folded gradients and the loss kernel's partial sums."""
         if m > 0 and net.fused_update_ok(idx, seq):  # fused forward + loss (csrc/update.hip), then the layer backward (hybrid) or harl_update_bwd
             call("harl_update_fwd_critic", *net.fused_args(share_obs, m), ptr(value_preds), ptr(returns),
                  ptr(vn.stats) if vn is not None else None, float(self.clip_param), int(self.use_clipped_value_loss),
@@ -117,22 +138,6 @@ class VCritic:
                  mv, mp, ptr(net.dz[0]), ptr(net.dhead), ptr(net.part_scalars), ptr(net.part[net._part_offs[-1]:]),
                  net.n_wg, s, tag="critic_head_loss")  # head weight gradient fused into this launch
             net.backward_trunk(share_obs, idx, m, seq=seq, head_dw_done=True)
-        nblk = net.n_wg if m > 0 else 0  # rows of part_scalars
-        ps_kw = dict(part_scalars=net.part_scalars, n_scalar_blocks=nblk)  # reduced inside the optimiser launch
-        if self.comm.enabled:  # ONE collective per optimiser step: [folded gradients | loss scalars] (dist.py)
-            if m <= 0:
-                net.dwp.zero_()
-            hilo = net.dwp_msg[net.total_dwp:]
-            call("harl_reduce_pack_scalars", ptr(net.part_scalars), nblk, ptr(sc), ptr(hilo), s)  # (nblk = 0: zeros)
-            self.comm.all_reduce_message(net.dwp_msg)
-            ps_kw = dict(scalars_hilo=hilo)
-        # loss = mean over the (global) minibatch, times value_loss_coef before backward (v_critic.py:112,146)
-        scale = float(self.value_loss_coef) / float(m_global)
-        self.critic_optimizer.step(1, scale, self.use_max_grad_norm, self.max_grad_norm, self._info, **ps_kw)
-        if self._trace is not None:
-            self._trace.append(self._info.clone())
-        if self._grad_tap is not None:
-            self._grad_tap(net.flat_grad * scale, sc.clone())
 
     def update(self, sample, value_normalizer=None):
         """API-compatible single update on a gathered minibatch (v_critic.py:116-157)."""

@@ -200,18 +200,21 @@ int harl_pack_scalars_hilo(const double *scalars, float *hilo, void *stream);
  * optimiser step does in front of its collective (harl_amd/happo.py _optimizer_step, v_critic.py; reference: the loss / entropy
  * / ratio means of happo.py:77-91 and v_critic.py:112 become global means).  n_blocks = 0: zeros (no local row). */
 int harl_reduce_pack_scalars(const float *part_scalars, int n_blocks, double *scalars, float *hilo, void *stream);
-/* Fused optimiser epilogue (64 co-resident workgroups, software grid barrier between phases): loss scalars ->
- * gradient scale + statistics (info), unfold the folded gradients of every table entry into `grad` (reference parameter
- * layout; Linears sharing one LayerNorm accumulate its gradients), ||grad||, clip, Adam, re-fold the updated weights into
- * `packs`.  mode 0 (actor): scale = 1/scalars[1] (sum active), info += {loss, entropy, grad_norm, ratio};
+/* Fused optimiser epilogue (64 co-resident workgroups, ONE software grid barrier): loss scalars -> gradient scale +
+ * statistics (info), unfold the folded gradients of every table entry into `grad` (reference parameter layout; Linears
+ * sharing one LayerNorm accumulate its gradients), ||grad||, clip, Adam, re-fold the updated weights into `packs` -- Adam and
+ * the re-fold run row by row of the table entries without a barrier in between, the LayerNorm parameters are written back by
+ * the last workgroup to finish.
+ * mode 0 (actor): scale = 1/scalars[1] (sum active), info += {loss, entropy, grad_norm, ratio};
  * mode 1 (critic): scale = const_scale (= value_loss_coef / m), info += {value_loss, grad_norm}.  `info` is double: every
  * update's fp32 figure is added the way the reference adds `.item()` values to a Python float (happo.py:145-150).
  * part_scalars != NULL: `scalars` (double[HARL_PS_STRIDE]) is first computed here as the fixed-order sum of the loss
  * kernel's n_scalar_blocks partial rows (single-GPU path); else scalars_hilo != NULL: `scalars` = sum of the four
  * all-reduced fp32 pieces written by harl_pack_scalars_hilo (data-parallel path); else `scalars` already holds the sums.
  * logstd_off >= 0: grad[logstd_off + d] = scalars[8 + d].  ws: >= 32 KiB device workspace, zero-initialised ONCE by the
- * caller (barrier words are reset by the kernel).  Replaces clip_grad_norm_ + Adam.step + the LayerNorm-affine adjoint
- * (algorithms/actors/happo.py:89-100, algorithms/critics/v_critic.py:144-155). */
+ * caller (barrier words are reset by the kernel).  Every parameter must belong to a table entry (weight, bias, or the
+ * LayerNorm in front of one) or be the log_std block.  Replaces clip_grad_norm_ + Adam.step + the LayerNorm-affine adjoint
+ * (algorithms/actors/happo.py:89-100, algorithms/critics/v_critic.py:144-155, utils/models_tools.py:110-117). */
 int harl_adam_fold(float *param, float *grad, float *exp_avg, float *exp_avg_sq, long n, const float *dwp,
                    const int *table, int n_layers, float *packs, double *scalars, const float *part_scalars,
                    int n_scalar_blocks, const float *scalars_hilo, int mode, float const_scale, int logstd_off,
@@ -315,6 +318,12 @@ int harl_gru_tangent(const float *g_r, const float *g_z, const float *g_nx, cons
 int harl_mlp_tangent_hidden(const float *xin_dot, const float *xin, long M, int HI, int HO, const float *Wp,
                             const float *Wdp, const float *bdp, const float *xprimal, const uint32_t *mask_in,
                             const float *rstd_in, float *xout_dot, void *stream);
+/* The same tangent in ONE launch (csrc/wide.hip): a K = 2 HI GEMM  [W' | W'_dot] [x_in_dot ; x_hat_in]  over the two input
+ * images with the weight images (built per call into w_img: 3 * HO * 2 HI bf16 = 6 HO HI bytes of device scratch) streamed
+ * from L2, then the LayerNorm Jacobian -- no pass through the output image (trpo_util.py:132-158, the J v half of F v). */
+int harl_mlp_tangent_hidden2(const float *xin_dot, const float *xin, long M, int HI, int HO, const float *Wp,
+                             const float *Wdp, const float *bdp, void *w_img, const float *xprimal,
+                             const uint32_t *mask_in, const float *rstd_in, float *xout_dot, void *stream);
 /* head tangent, M (Gaussian 1/sigma^2 on the mean; identity on the normalised logits incl. masked entries), head +
  * LayerNorm/ReLU backward -> dzL ATL(H), dhead[M_pad,32]; NOT yet divided by the batch size.  m_valid / m_pad as in
  * harl_actor_head_loss (padding sequences of a recurrent batch get zero gradients; 0, 0 = no padding) */

@@ -8,7 +8,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for c in $CFGS; do
   mkdir -p $OUT/$c
-  ARGS="--config $c --steps 1 --warmup 0 --cpu-cols 0"
+  ARGS="--config $c --steps 1 --warmup 0 --cpu-cols 0 --no-other-configs"
   timeout 600 python $R/bench.py $ARGS --instr-steps 0 --time-all-tags > $OUT/$c/plain.json 2> $OUT/$c/plain.err
   rm -rf /tmp/pf /tmp/pw
   timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pf -- python $R/bench.py $ARGS --instr-steps 0 --no-kernel-timing > /dev/null 2>&1
@@ -21,5 +21,5 @@ for c in $CFGS; do
     done
   done
 done
-python $R/tools/pmc_traffic.py report $OUT $OUT/${HARL_TRAFFIC_TAG:-r03}_hbm_traffic > $OUT/report.txt 2>&1
+python $R/tools/pmc_traffic.py report $OUT $OUT/${HARL_TRAFFIC_TAG:-r04}_hbm_traffic > $OUT/report.txt 2>&1
 tail -40 $OUT/report.txt

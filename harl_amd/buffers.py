@@ -339,7 +339,7 @@ class OnPolicyActorBuffer:
         starts travel to the device; the kernels gather rows first + l*N in place.  ``shard`` = (n_global, lo, hi):
         the GLOBAL sampler is drawn and filtered to this rank's rollout threads."""
         T, N = self.actions.shape[:2]
-        return _recurrent_seqs(self.device, T, N, 1, self.rnn_hidden_size, num_mini_batch, data_chunk_length, naive, shard,
+        return _recurrent_seqs(self.device, T, N, 1, self.rnn_hidden_size * self.recurrent_n, num_mini_batch, data_chunk_length, naive, shard,
                                self.rnn_states.reshape((T + 1) * N, -1), self.masks.reshape(-1))
 
     def feed_forward_generator_actor(self, advantages, actor_num_mini_batch=None, mini_batch_size=None):
@@ -458,7 +458,7 @@ class OnPolicyCriticBufferEP:
         as column c = n*A + a, which is exactly the row order of the [T, N, A, .] flattening used here."""
         T, N = self.rewards.shape[:2]
         agents = getattr(self, "num_agents", None) or 1
-        return _recurrent_seqs(self.device, T, N, agents, self.rnn_hidden_size, num_mini_batch, data_chunk_length, naive,
+        return _recurrent_seqs(self.device, T, N, agents, self.rnn_hidden_size * self.recurrent_n, num_mini_batch, data_chunk_length, naive,
                                shard, self.rnn_states_critic.reshape((T + 1) * N * agents, -1), self.masks.reshape(-1))
 
     def _recurrent_api_generator(self, num_mini_batch, data_chunk_length, naive):

@@ -160,6 +160,43 @@ __device__ __forceinline__ void head_fwd_regs(const f32x4 (&xs)[H / 8], const fl
   for (int d = 0; d < DA; ++d) z[d] = wave_sum32(z[d]) + cst[d];
 }
 
+// The same product from a TRANSPOSED image whlT[h][d][R] (one ds_read_b128 = four features of ONE output): DA x H/8
+// reads per lane, all of them used (the [R][DAP] image above costs 2 x H/2 reads at 4 < DA <= 8 and discards the padding),
+// requested one q-step ahead of the FMAs that consume them -- the phase was bound by exposed LDS latency, not by its FMAs
+// (phase timers, round 4: 14 % of the fused kernel for 320 FMAs per lane).
+template <int H, int DAP, int DA>
+__device__ __forceinline__ void head_fwd_regs_t(const f32x4 (&xs)[H / 8], const float *whlT_h, const float *cst,
+                                                float (&z)[DAP]) {
+#pragma unroll
+  for (int d = 0; d < DAP; ++d) z[d] = 0.f;
+  f32x4 w[2][DA];
+#pragma unroll
+  for (int d = 0; d < DA; ++d) w[0][d] = *reinterpret_cast<const f32x4 *>(whlT_h + d * (H / 2));
+#pragma unroll
+  for (int q = 0; q < H / 8; ++q) {
+    if (q + 1 < H / 8) {
+#pragma unroll
+      for (int d = 0; d < DA; ++d) w[(q + 1) & 1][d] = *reinterpret_cast<const f32x4 *>(whlT_h + d * (H / 2) + 4 * (q + 1));
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int d = 0; d < DA; ++d) z[d] += xs[q][c] * w[q & 1][d][c];
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int d = 0; d < DA; ++d) z[d] = wave_sum32(z[d]) + cst[d];
+}
+
+template <int H>
+__device__ __forceinline__ void stage_head_t(float *whlT, const float *__restrict__ Whp, int da, int n_threads) {
+  // whlT[hh][d][R] = Whp[d][f(R,hh)]
+  for (int e = threadIdx.x; e < 2 * da * (H / 2); e += n_threads) {
+    const int R = e % (H / 2), d = (e / (H / 2)) % da, hh = e / ((H / 2) * da);
+    whlT[e] = Whp[d * H + feat_base(R) + 4 * hh];
+  }
+}
+
 // PACKED: the LayerNorm / ReLU backward of the epilogue on register pairs (2 x v_pk_fma_f32 per pair + the two-instruction
 // mask_pop per element: 3 VALU per element instead of 6) -- for the issue-bound fused kernel (update.hip); the stand-alone head
 // kernels are HBM-bound and keep the plain form, which leaves the scheduler free.

@@ -358,6 +358,11 @@ __global__ __launch_bounds__(UF_THREADS, 2) void k_upd_fwd(UpdFwdArgs U, ARGS A)
   // it in HBM (an ATL(H) image, U.x0n), "layer 2" is layer L, and the backward that follows is the layer kernels' from
   // dz_L on: x_hat_L, its mask and statistic never leave the chip (TRAIN only)
   constexpr bool HID = KP0 == 0;
+#ifdef HARL_EARLY_X0N
+  constexpr bool EARLY_X0N = H == 128 && KP0 == 32 && DA <= 5 && !DISCRETE;  // (the other instantiations would spill)
+#else
+  constexpr bool EARLY_X0N = false;
+#endif
   static_assert(!HID || TRAIN, "the last-layer variant exists for optimiser steps only");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int MT = H / 32, NJ1 = KP0 / 16, NJ2 = H / 16, NR = H / 2, NW = (NR + 31) / 32;
@@ -367,7 +372,12 @@ __global__ __launch_bounds__(UF_THREADS, 2) void k_upd_fwd(UpdFwdArgs U, ARGS A)
   float *b2l = b1l + H;
   float *whl = b2l + H;                    // [2][H/2][DAP]
   float *cst = whl + 2 * (H / 2) * DAP;    // bias, sigma, logsigma, dsigma_dlogstd, rowsum, 1/sigma, 1/sigma^2
+#ifdef HARL_HEAD_T
+  float *whlT = cst + 7 * DAP;             // [2][DA][H/2]: the head weights once more, four features of one output per read
+  float *red = whlT + 2 * DA * (H / 2);    // [8][PS_STRIDE]
+#else
   float *red = cst + 7 * DAP;              // [8][PS_STRIDE]
+#endif
   float *hacc = red + UF_WAVES * PS_STRIDE;  // [8 waves][HROWS][H] head weight gradient, wave-private
   stage_split_matrix<H, H, false, UF_THREADS>(w2img, U.W2p);
   if constexpr (!HID) stage_w1_images<H, KP0, UF_THREADS>(w1img, U.W1p, U.D);
@@ -377,6 +387,9 @@ __global__ __launch_bounds__(UF_THREADS, 2) void k_upd_fwd(UpdFwdArgs U, ARGS A)
   }
   if (TRAIN)
     for (int e = threadIdx.x; e < UF_WAVES * HROWS * H; e += UF_THREADS) hacc[e] = 0.f;
+#ifdef HARL_HEAD_T
+  stage_head_t<H>(whlT, A.Whp, DA, UF_THREADS);
+#endif
   if (threadIdx.x < WG_THREADS) {  // (the staging helpers of heads_common.h stride by WG_THREADS)
     if constexpr (CRITIC) {
       stage_head<H, DAP>(whl, cst, A.Whp, A.bhp, 1);
@@ -406,6 +419,9 @@ __global__ __launch_bounds__(UF_THREADS, 2) void k_upd_fwd(UpdFwdArgs U, ARGS A)
   const long slab0 = (long)blockIdx.x * UF_WAVES + wave, slab_stride = (long)gridDim.x * UF_WAVES;
   const u32x4 *wl1 = w1img + lane, *wl2 = w2img + lane;
   const float *whl_h = whl + h * (H / 2) * DAP;
+#ifdef HARL_HEAD_T
+  const float *whlT_h = whlT + h * DA * (H / 2);
+#endif
   float *hw = hacc + wave * (HROWS * H);
 
   float adv_mean = 0.f, adv_den = 1.f, vmean = 0.f, vsd = 1.f;
@@ -506,7 +522,11 @@ __global__ __launch_bounds__(UF_THREADS, 2) void k_upd_fwd(UpdFwdArgs U, ARGS A)
 #pragma unroll
     for (int q = 0; q < H / 8; ++q) xs[q] = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
     float z[DAP];
+#ifdef HARL_HEAD_T
+    head_fwd_regs_t<H, DAP, DA>(xs, whlT_h, cst, z);
+#else
     head_fwd_regs<H, DAP, DA>(xs, whl_h, cst, z);
+#endif
     PHASE(5);
     // this slab's rows (loaded one slab ago) are consumed now; the next slab's are requested where the GEMM operands are dead
     // (log-prob passes: here; optimiser steps: after the head weight gradient, the register peak of the loop) -- one set of
@@ -530,6 +550,10 @@ __global__ __launch_bounds__(UF_THREADS, 2) void k_upd_fwd(UpdFwdArgs U, ARGS A)
     }
     PHASE(6);
     if constexpr (TRAIN) {
+      // the next slab's normalised inputs are requested HERE, in front of the head weight gradient, where the registers allow
+      // it: issued behind it they had only the head backward (~5k cycles) to land and the top of the next iteration waited for
+      // them (phase timers, round 4: 8.6 % of the kernel in "rows + split x0n")
+      if constexpr (EARLY_X0N) atl_load<2 * NXR>(U.x0n, sn, lane, xr);
       // ---- head weight gradient dW_head'[d][f] += sum_s dzh[s][d] x_hat_2[s][f]: both operands transposed on the matrix
       // pipe, one 32-feature tile at a time; rows d < HROWS of the tile are added to the wave's LDS accumulator
       // the permuted identities are rebuilt per slab (~40 VALU) instead of occupying 12 registers across the two GEMMs, where
@@ -582,7 +606,7 @@ __global__ __launch_bounds__(UF_THREADS, 2) void k_upd_fwd(UpdFwdArgs U, ARGS A)
         }
       }
       PHASE(7);
-      atl_load<2 * NXR>(U.x0n, sn, lane, xr);
+      if constexpr (!EARLY_X0N) atl_load<2 * NXR>(U.x0n, sn, lane, xr);
       // ---- head backward (W_head'^T dzh on the fp32 MFMA) + LayerNorm / ReLU backward -> dz_2
       head_bwd_regs_bits<H, DAP, DA, true>(xs, bits2[0], bits2[NW - 1], r2, slab, lane, whl, dzh, s1, s2, U.dz2);
       if constexpr (!CRITIC) actor_row_load<DAP, DISCRETE, TRAIN, DA>(A, sn, lane, rnext);
@@ -652,9 +676,13 @@ int upd_grid(long n_slabs) {
   return (int)(wgs < 256 ? (wgs < 1 ? 1 : wgs) : 256);
 }
 
-size_t fwd_lds_bytes(int H, int kp0, int dap, int hrows) {
+size_t fwd_lds_bytes(int H, int kp0, int dap, int hrows, int da) {
+#ifndef HARL_HEAD_T
+  da = 0;
+#endif
   return split_image_bytes(H, H) + split_image_bytes(H, kp0) +
-         ((size_t)2 * H + (size_t)2 * (H / 2) * dap + 7 * dap + UF_WAVES * PS_STRIDE + (size_t)UF_WAVES * hrows * H) * sizeof(float);
+         ((size_t)2 * H + (size_t)2 * (H / 2) * (dap + da) + 7 * dap + UF_WAVES * PS_STRIDE + (size_t)UF_WAVES * hrows * H) *
+             sizeof(float);
 }
 
 constexpr size_t LDS_PER_WG_MAX = 160 * 1024;  // gfx950: 160 KiB per CU
@@ -662,7 +690,7 @@ constexpr size_t LDS_PER_WG_MAX = 160 * 1024;  // gfx950: 160 KiB per CU
 template <int H, int KP0, int DA, bool DISC, bool TRAIN, typename ARGS>
 int launch_fwd(const UpdFwdArgs &U, const ARGS &A, hipStream_t s) {
   // (the wave-private head-gradient tiles exist in optimiser steps only: one row per head output)
-  const size_t shm = fwd_lds_bytes(H, KP0, DA <= 4 ? 4 : 8, TRAIN ? DA : 0);
+  const size_t shm = fwd_lds_bytes(H, KP0, DA <= 4 ? 4 : 8, TRAIN ? DA : 0, DA);
   if (shm > LDS_PER_WG_MAX) {  // harl_update_supported() says so beforehand; never launch a kernel that cannot be resident
     return bad("harl_update_*: this (D, H, act_dim) does not fit the LDS of one workgroup");
   }
@@ -737,7 +765,7 @@ extern "C" int harl_update_supported(int D, int H, int act_dim, int kind) {
   // in LDS (one row of H floats per head output and wave): actors with 128-wide layers and 33..64 inputs fit up to 2 outputs
   const int dap = act_dim <= 4 ? 4 : 8;
   const int hrows = kind == 0 ? 0 : (kind == 2 ? 1 : act_dim);  // forward-only pass / critic step (one head output) / actor step
-  return fwd_lds_bytes(H, D == 0 ? 0 : (D <= 32 ? 32 : 64), dap, hrows) <= LDS_PER_WG_MAX ? 1 : 0;
+  return fwd_lds_bytes(H, D == 0 ? 0 : (D <= 32 ? 32 : 64), dap, hrows, kind == 2 ? 1 : act_dim) <= LDS_PER_WG_MAX ? 1 : 0;
 }
 
 extern "C" int harl_update_fwd_actor(const float *x0n, long M, int D, int H, const float *W1p, const float *b1p,

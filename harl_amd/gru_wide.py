@@ -9,7 +9,11 @@ it (cell backward + ``W_hg^T dgh_g`` GEMMs per step) and ends in the tensors the
 gradients ``net.rnn_dgate`` and the gradient into the last MLP layer ``net.dz[1]`` -- so that ``_FlatNet.backward_trunk``
 continues unchanged (weight gradients of the six gate blocks, MLP layers).
 
-Coverage path: launch-bound (4 L small launches per pass), not tuned.  Parity-green on hardware since round 3 (the
+Stacked layers (``recurrent_n`` > 1, rnn.py:14) run on this composition for 64- and 128-wide GRUs: layer after layer over
+the whole chunk (forward), top layer first (backward: the gradient a layer sends to the one below is three more GEMMs over all
+steps); goldens ``rnn2_box_h64`` / ``rnn2_disc_h128_naive_mb2`` recorded from the reference.
+
+Coverage path: launch-bound (4 L small launches per pass and layer), not tuned.  Parity-green on hardware since round 3 (the
 reference goldens ``rnn_box_h128`` / ``rnn_disc_h128_mb2``, and the same composition on 64-wide GRUs against the goldens of
 the fused kernels): the default for 128-wide GRUs; ``HARL_GRU128=0`` makes ``_FlatNet`` refuse them as before.
 """
@@ -25,67 +29,110 @@ def ensure_ws(net, mp_rows: int) -> None:
     H = net.hidden_sizes[-1]
     dev = net.device_
     f32 = torch.float32
-    net.rnn_hraw = torch.empty(mp_rows * H, dtype=f32, device=dev)       # h_l of every step (input of the output LayerNorm)
+    # h_l of every step, per GRU layer: input of the next layer / of the output LayerNorm, B operand of the next layer's W_ih gradient
+    net.rnn_hraw_l = [torch.empty(mp_rows * H, dtype=f32, device=dev) for _ in range(net.recurrent_n)]
+    net.rnn_hraw = net.rnn_hraw_l[-1]
     net.rnn_gh = torch.empty(3 * mp_rows * H, dtype=f32, device=dev)     # per-step gate products / backward GEMM outputs
     net.rnn_gz = torch.empty(mp_rows * H, dtype=f32, device=dev)         # G_l * z_l carried to the step before
     net.rnn_zero_bias = torch.zeros(H, dtype=f32, device=dev)
+    net.rnn_tmp = torch.empty(mp_rows * H, dtype=f32, device=dev)        # GEMM outputs that are summed into another tensor
+    # d(loss)/d(h) of every step of a LOWER layer (stacked GRUs: what the layer above sends down), ping-pong with net.dz[0]
+    net.rnn_dh = torch.empty(mp_rows * H, dtype=f32, device=dev) if net.recurrent_n > 1 else None
+
+
+def _layer_state(seq: dict, key: str, layer: int, n_layers: int, H: int):
+    """Column block ``layer`` of the [m_pad, n_layers * H] state tensor ``seq[key]`` as a contiguous [m_pad, H] tensor
+    (a view when there is one layer)."""
+    t = seq.get(key)
+    if t is None or n_layers == 1:
+        return t
+    return t.reshape(t.shape[0], n_layers, H)[:, layer, :].contiguous()
 
 
 def forward(net, seq: dict, save: bool) -> None:
-    """x_hat of the last MLP layer (net.xh[-1], L*m_pad rows) -> net.rnn_y / net.rnn_rstd (+ saved gates when ``save``)."""
+    """x_hat of the last MLP layer (net.xh[-1], L*m_pad rows) -> net.rnn_y / net.rnn_rstd (+ saved gates when ``save``).
+    Stacked layers (recurrent_n > 1) run one after the other over the whole chunk: layer k at step l needs layer k - 1 at step
+    l and itself at step l - 1, so a layer-major order is as valid as the reference's step-major one (rnn.py:14: nn.GRU with
+    num_layers) and lets the input halves of a layer's gates be three GEMMs over ALL steps.  Every layer's state is
+    multiplied by the mask of the step (rnn.py:27,67)."""
     H = net.hidden_sizes[-1]
     L, mp = seq["L"], seq["m_pad"]
     M, n = L * mp, mp * H
-    gp, sv, s = net.gru_pack, net.rnn_saved, stream()
+    RN = net.recurrent_n
+    s = stream()
     gi = [net.rnn_gi[g * M * H:(g + 1) * M * H] for g in range(3)]
     gh = [net.rnn_gh[g * n:(g + 1) * n] for g in range(3)]
-    Wih, bih, Whh, bhh = gp["Wih"], gp["bih"], gp["Whh"], gp["bhh"]
-    for g in range(3):  # input halves of the gates, all steps at once
-        call("harl_mlp_linear", ptr(net.xh[-1]), M, H, H, ptr(Wih[g * H * H:(g + 1) * H * H]), ptr(bih[g * H:(g + 1) * H]),
-             ptr(gi[g]), s, tag="gru_gi")
-    hpm, mask_rows = sv[0], seq["mask_rows"]
-    call("harl_gru_cell_init", ptr(seq["h0"]), ptr(mask_rows), H, mp, ptr(hpm[:n]), s)
-    for l in range(L):
-        lo, hi = l * n, (l + 1) * n
-        last = l == L - 1
-        for g in range(3):
-            call("harl_mlp_linear", ptr(hpm[lo:hi]), mp, H, H, ptr(Whh[g * H * H:(g + 1) * H * H]), ptr(bhh[g * H:(g + 1) * H]),
-                 ptr(gh[g]), s, tag="gru_gh")
-        sl = (lambda t: ptr(t[lo:hi])) if save else (lambda t: None)  # noqa: E731
-        call("harl_gru_cell_fwd", ptr(gi[0][lo:hi]), ptr(gi[1][lo:hi]), ptr(gi[2][lo:hi]), ptr(gh[0]), ptr(gh[1]), ptr(gh[2]),
-             ptr(hpm[lo:hi]), None if last else ptr(mask_rows[(l + 1) * mp:(l + 2) * mp]), H, mp,
-             sl(sv[1]), sl(sv[2]), sl(sv[3]), sl(sv[4]), ptr(net.rnn_hraw[lo:hi]),
-             None if last else ptr(hpm[hi:hi + n]), ptr(seq.get("h_last")) if last else None, s, tag="gru_cell_fwd")
-    call("harl_rownorm", ptr(net.rnn_hraw), M, H, ptr(net.rnn_y), ptr(net.rnn_rstd), s, tag="gru_norm")
+    mask_rows = seq["mask_rows"]
+    h_last_all = seq.get("h_last")
+    for layer in range(RN):
+        gp, sv = net.gru_packs[layer], net.rnn_saved_l[layer]
+        Wih, bih, Whh, bhh = gp["Wih"], gp["bih"], gp["Whh"], gp["bhh"]
+        xin = net.xh[-1] if layer == 0 else net.rnn_hraw_l[layer - 1]
+        hraw = net.rnn_hraw_l[layer]
+        for g in range(3):  # input halves of the gates, all steps at once
+            call("harl_mlp_linear", ptr(xin), M, H, H, ptr(Wih[g * H * H:(g + 1) * H * H]), ptr(bih[g * H:(g + 1) * H]),
+                 ptr(gi[g]), s, tag="gru_gi")
+        hpm = sv[0]
+        h0 = _layer_state(seq, "h0", layer, RN, H)
+        h_last = None if h_last_all is None else (h_last_all if RN == 1 else torch.empty(mp, H, dtype=h0.dtype, device=h0.device))
+        call("harl_gru_cell_init", ptr(h0), ptr(mask_rows), H, mp, ptr(hpm[:n]), s)
+        for l in range(L):
+            lo, hi = l * n, (l + 1) * n
+            last = l == L - 1
+            for g in range(3):
+                call("harl_mlp_linear", ptr(hpm[lo:hi]), mp, H, H, ptr(Whh[g * H * H:(g + 1) * H * H]), ptr(bhh[g * H:(g + 1) * H]),
+                     ptr(gh[g]), s, tag="gru_gh")
+            sl = (lambda t: ptr(t[lo:hi])) if save else (lambda t: None)  # noqa: E731
+            call("harl_gru_cell_fwd", ptr(gi[0][lo:hi]), ptr(gi[1][lo:hi]), ptr(gi[2][lo:hi]), ptr(gh[0]), ptr(gh[1]), ptr(gh[2]),
+                 ptr(hpm[lo:hi]), None if last else ptr(mask_rows[(l + 1) * mp:(l + 2) * mp]), H, mp,
+                 sl(sv[1]), sl(sv[2]), sl(sv[3]), sl(sv[4]), ptr(hraw[lo:hi]),
+                 None if last else ptr(hpm[hi:hi + n]), ptr(h_last) if last else None, s, tag="gru_cell_fwd")
+        if h_last_all is not None and RN > 1:
+            h_last_all.reshape(mp, RN, H)[:, layer, :].copy_(h_last)
+    call("harl_rownorm", ptr(net.rnn_hraw_l[-1]), M, H, ptr(net.rnn_y), ptr(net.rnn_rstd), s, tag="gru_norm")
 
 
 def backward(net, seq: dict) -> None:
-    """d(loss)/d(h_l) of every step (net.dz[0]) -> gate gradients net.rnn_dgate [dr, dz, dn, dhn] and net.dz[1] = the
-    gradient at the last MLP layer's pre-activation (what ``harl_gru_bwd`` leaves behind)."""
+    """d(loss)/d(h_l) of every step of the TOP layer (net.dz[0]) -> per layer the gate gradients net.rnn_dgate_l[k] = [dr, dz,
+    dn, dhn], and net.dz[1] = the gradient at the last MLP layer's pre-activation (what ``harl_gru_bwd`` leaves behind)."""
     H = net.hidden_sizes[-1]
     L, mp = seq["L"], seq["m_pad"]
     M, n = L * mp, mp * H
-    gp, sv, dg, s = net.gru_pack, net.rnn_saved, net.rnn_dgate, stream()
+    RN = net.recurrent_n
+    s = stream()
     mask_rows = seq["mask_rows"]
-    WhhT = gp["Whh"].view(3, H, H).transpose(1, 2).contiguous()  # t_g = W_hg^T dgh_g as a forward GEMM with the transposed block
     t = [net.rnn_gh[g * n:(g + 1) * n] for g in range(3)]
     gz, zero = net.rnn_gz[:n], net.rnn_zero_bias
-    for l in range(L - 1, -1, -1):
-        lo, hi = l * n, (l + 1) * n
-        nxt = l < L - 1
-        call("harl_gru_cell_bwd", ptr(net.dz[0][lo:hi]), ptr(t[0]) if nxt else None, ptr(t[1]) if nxt else None,
-             ptr(t[2]) if nxt else None, ptr(mask_rows[(l + 1) * mp:(l + 2) * mp]) if nxt else None,
-             ptr(sv[1][lo:hi]), ptr(sv[2][lo:hi]), ptr(sv[3][lo:hi]), ptr(sv[4][lo:hi]), ptr(sv[0][lo:hi]), H, mp, ptr(gz),
-             ptr(dg[0][lo:hi]), ptr(dg[1][lo:hi]), ptr(dg[2][lo:hi]), ptr(dg[3][lo:hi]), s, tag="gru_cell_bwd")
-        if l > 0:
-            for g, src in enumerate((dg[0], dg[1], dg[3])):  # d gh = [dr, dz, dhn]
-                call("harl_mlp_linear", ptr(src[lo:hi]), mp, H, H, ptr(WhhT[g]), ptr(zero), ptr(t[g]), s, tag="gru_gh_bwd")
+    dh = net.dz[0]  # d(loss)/d(h of this layer), all steps
+    for layer in range(RN - 1, -1, -1):
+        gp, sv, dg = net.gru_packs[layer], net.rnn_saved_l[layer], net.rnn_dgate_l[layer]
+        WhhT = gp["Whh"].view(3, H, H).transpose(1, 2).contiguous()  # t_g = W_hg^T dgh_g as a forward GEMM with the transposed block
+        for l in range(L - 1, -1, -1):
+            lo, hi = l * n, (l + 1) * n
+            nxt = l < L - 1
+            call("harl_gru_cell_bwd", ptr(dh[lo:hi]), ptr(t[0]) if nxt else None, ptr(t[1]) if nxt else None,
+                 ptr(t[2]) if nxt else None, ptr(mask_rows[(l + 1) * mp:(l + 2) * mp]) if nxt else None,
+                 ptr(sv[1][lo:hi]), ptr(sv[2][lo:hi]), ptr(sv[3][lo:hi]), ptr(sv[4][lo:hi]), ptr(sv[0][lo:hi]), H, mp, ptr(gz),
+                 ptr(dg[0][lo:hi]), ptr(dg[1][lo:hi]), ptr(dg[2][lo:hi]), ptr(dg[3][lo:hi]), s, tag="gru_cell_bwd")
+            if l > 0:
+                for g, src in enumerate((dg[0], dg[1], dg[3])):  # d gh = [dr, dz, dhn]
+                    call("harl_mlp_linear", ptr(src[lo:hi]), mp, H, H, ptr(WhhT[g]), ptr(zero), ptr(t[g]), s, tag="gru_gh_bwd")
+        if layer > 0:
+            # into the layer below: d(loss)/d(h^{layer-1}_l) = sum_g W_ig^T d gi_g for all steps (no LayerNorm in between)
+            WihT = gp["Wih"].view(3, H, H).transpose(1, 2).contiguous()
+            dh = net.rnn_dh
+            for g in range(3):
+                out = dh if g == 0 else net.rnn_tmp
+                call("harl_mlp_linear", ptr(dg[g]), M, H, H, ptr(WihT[g]), ptr(zero), ptr(out), s, tag="gru_gi_bwd")
+                if g > 0:
+                    dh[:M * H].add_(net.rnn_tmp[:M * H])
     # gradient into the last MLP layer: sum over the gates of  relu' . LNbwd(W_ig'^T d gi_g)  (linear in d gi)
-    Wih = gp["Wih"]
-    tmp = net.rnn_hraw
+    dg0 = net.rnn_dgate_l[0]
+    Wih = net.gru_packs[0]["Wih"]
+    tmp = net.rnn_tmp
     for g in range(3):
         out = net.dz[1] if g == 0 else tmp
-        call("harl_mlp_bwd_dx", ptr(dg[g]), ptr(net.xh[-1]), ptr(net.rmask[-1]), ptr(net.rstd[-1]), M, H, H,
+        call("harl_mlp_bwd_dx", ptr(dg0[g]), ptr(net.xh[-1]), ptr(net.rmask[-1]), ptr(net.rstd[-1]), M, H, H,
              ptr(Wih[g * H * H:(g + 1) * H * H]), ptr(out), None, 0, None, 0, s, tag="bwd_dx")
         if g > 0:
             net.dz[1][:M * H].add_(tmp[:M * H])

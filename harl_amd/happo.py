@@ -83,7 +83,8 @@ class OnPolicyBase:
         H = net.hidden_sizes[-1]
         m = rnn_states.shape[0]
         L = M // m
-        seq = build_seq(self.device, L, m, H, h0=_as_dev(rnn_states, self.device).reshape(m, H),
+        HS = H * net.recurrent_n  # state row: the layers' hidden vectors side by side (rnn_states [m, recurrent_n, H])
+        seq = build_seq(self.device, L, m, HS, h0=_as_dev(rnn_states, self.device).reshape(m, HS),
                         masks_src=_as_dev(masks, self.device), want_h_last=h_last)
         idx, Mp = seq["idx"], L * seq["m_pad"]
         padded = idx is not None
@@ -161,7 +162,7 @@ class OnPolicyBase:
         h = self._logp_pass(x, None, avail, M, None, head_out=head, rnn_states=rnn_states_actor, masks=masks,
                             h_last=True)  # head_out only: no actions needed
         if net.recurrent:
-            rnn_out = h.reshape(M, 1, -1).clone()
+            rnn_out = h.reshape(M, net.recurrent_n, -1).clone()
         if net.md:  # act.py:56-73: one draw per head, log-probs summed to [B, 1]
             acts, lps, lo = [], [], 0
             for n in net.nvec:
@@ -331,9 +332,9 @@ class HAPPO(OnPolicyBase):
         before = self._info.clone()
         self.actor.fold()
         if self.actor.recurrent:  # gathered [L*m, .] l-major minibatch + rnn_states [m, 1, H] (recurrent generators)
-            H = self.actor.hidden_sizes[-1]
+            HS = self.actor.hidden_sizes[-1] * self.actor.recurrent_n
             nseq = _as_dev(_rnn, dev).shape[0]
-            seq = build_seq(dev, m // nseq, nseq, H, h0=_as_dev(_rnn, dev).reshape(nseq, H), masks_src=_as_dev(_masks, dev))
+            seq = build_seq(dev, m // nseq, nseq, HS, h0=_as_dev(_rnn, dev).reshape(nseq, HS), masks_src=_as_dev(_masks, dev))
             idx = seq["idx"]
             self._update_core(obs.reshape(m, -1), idx, seq["L"] * seq["m_pad"], _as_dev(actions, dev).reshape(m, -1),
                               None if avail is None else _as_dev(avail, dev).reshape(m, -1),

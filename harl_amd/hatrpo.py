@@ -29,7 +29,8 @@ class HATRPO(OnPolicyBase):
             "only continuous and discrete action space is supported by HATRPO."
         super().__init__(args, obs_space, act_space, device)
         if getattr(self.actor, "gru_wide", False):
-            raise NotImplementedError("HATRPO with a 128-wide GRU: the recurrent tangent kernels are 64 wide")
+            raise NotImplementedError("HATRPO with a 128-wide GRU or stacked GRU layers: the recurrent tangent kernels are "
+                                      "64 wide, one layer")
         if self.actor.act_id:
             raise NotImplementedError("HATRPO with an activation other than relu: the forward-mode tangent kernels are ReLU only")
         if self.actor.panel:

@@ -84,14 +84,20 @@ class _FlatNet(nn.Module):
         self.recurrent_n = int(args.get("recurrent_n", 1))
         # a 128-wide GRU is composed from layer GEMMs + element-wise cell kernels (harl_amd/gru_wide.py; parity-green on
         # hardware since round 3: goldens rnn_box_h128, rnn_disc_h128_mb2).  HARL_GRU128=0 restores the refusal.
-        self.gru_wide = (self.recurrent and self.hidden_sizes[-1] == 128 and self.recurrent_n == 1
-                         and os.environ.get("HARL_GRU128", "1") != "0")
+        # Stacked layers (recurrent_n > 1, models/base/rnn.py:14) run on the same composition, layer after layer, for 64- and
+        # 128-wide GRUs (round 4: goldens rnn2_box_h64, rnn2_disc_h128_naive_mb2); the fused kernels of csrc/gru.hip are
+        # single-layer.
+        hl = self.hidden_sizes[-1]
+        self.gru_wide = self.recurrent and ((hl == 128 and os.environ.get("HARL_GRU128", "1") != "0")
+                                            or (hl in (64, 128) and self.recurrent_n > 1))
         # HARL_GRU_COMPOSED=1 sends 64-wide GRUs through the same composition: a cross-check of gru_wide.py against the
         # fused kernels and their goldens (tests only)
-        if self.recurrent and self.hidden_sizes[-1] == 64 and self.recurrent_n == 1 and os.environ.get("HARL_GRU_COMPOSED") == "1":
+        if self.recurrent and hl == 64 and os.environ.get("HARL_GRU_COMPOSED") == "1":
             self.gru_wide = True
-        if self.recurrent and not self.gru_wide and (self.hidden_sizes[-1] != 64 or self.recurrent_n != 1):
-            raise NotImplementedError("GRU kernels: hidden width 64 (fused) or 128 (composed), recurrent_n = 1")
+        if self.recurrent and self.recurrent_n < 1:
+            raise ValueError("recurrent_n must be >= 1")
+        if self.recurrent and not self.gru_wide and (hl != 64 or self.recurrent_n != 1):
+            raise NotImplementedError("GRU kernels: hidden width 64 (fused; composed for recurrent_n > 1) or 128 (composed)")
         for h in self.hidden_sizes:
             if h not in SUPPORTED_WIDTHS:
                 raise NotImplementedError(f"hidden width {h}: kernels are instantiated for {SUPPORTED_WIDTHS}")
@@ -132,8 +138,9 @@ class _FlatNet(nn.Module):
                 elif "weight" in name:
                     init(param)
             sd = dict(gru.named_parameters())
-            self._cpu_params += [(f"rnn.rnn.{k}", sd[k].data) for k in
-                                 ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0")]
+            for l in range(self.recurrent_n):  # nn.GRU's registration order: per layer weight_ih, weight_hh, bias_ih, bias_hh
+                self._cpu_params += [(f"rnn.rnn.{k}", sd[k].data) for k in
+                                     (f"weight_ih_l{l}", f"weight_hh_l{l}", f"bias_ih_l{l}", f"bias_hh_l{l}")]
             self._cpu_params += [("rnn.norm.weight", torch.ones(d)), ("rnn.norm.bias", torch.zeros(d))]
 
     def _finalize_params(self) -> None:
@@ -214,11 +221,13 @@ class _FlatNet(nn.Module):
         if self.recurrent:
             H = self.hidden_sizes[-1]
             i = len(self.hidden_sizes) - 1
-            g, be = off(f"base.mlp.fc.{3*i+2}.weight"), off(f"base.mlp.fc.{3*i+2}.bias")
-            for gate in range(3):
-                ents.append((off("rnn.rnn.weight_ih_l0") + gate * H * H, off("rnn.rnn.bias_ih_l0") + gate * H, g, be, H, H))
-            for gate in range(3):
-                ents.append((off("rnn.rnn.weight_hh_l0") + gate * H * H, off("rnn.rnn.bias_hh_l0") + gate * H, -1, -1, H, H))
+            for l in range(self.recurrent_n):
+                # layer 0 reads the last MLP layer's LayerNorm output (folded into W_ih_l0); layer l > 0 the raw output of layer l - 1
+                g, be = (off(f"base.mlp.fc.{3*i+2}.weight"), off(f"base.mlp.fc.{3*i+2}.bias")) if l == 0 else (-1, -1)
+                for gate in range(3):
+                    ents.append((off(f"rnn.rnn.weight_ih_l{l}") + gate * H * H, off(f"rnn.rnn.bias_ih_l{l}") + gate * H, g, be, H, H))
+                for gate in range(3):
+                    ents.append((off(f"rnn.rnn.weight_hh_l{l}") + gate * H * H, off(f"rnn.rnn.bias_hh_l{l}") + gate * H, -1, -1, H, H))
         for (w, b, g, be, o, k) in layers[-nh:]:
             ents.append((off(w), off(b), off(g), off(be), o, k))
         return ents
@@ -238,10 +247,11 @@ class _FlatNet(nn.Module):
         if self.recurrent:  # GRU: the three gate blocks of each matrix must be contiguous ([3H][H], then [3H] biases)
             H = self.hidden_sizes[-1]
         for ei, (wo, bo, go, beo, o, k) in enumerate(ents):
-            gru_i = ei - L if (self.recurrent and L <= ei < L + 6) else -1
+            gru_i = ei - L if (self.recurrent and L <= ei < L + 6 * self.recurrent_n) else -1
             if gru_i >= 0:
-                mat, gate = divmod(gru_i, 3)
-                base = self._gru_pack_base + mat * (3 * H * H + 3 * H)
+                layer, within = divmod(gru_i, 6)
+                mat, gate = divmod(within, 3)
+                base = self._gru_pack_base + (2 * layer + mat) * (3 * H * H + 3 * H)
                 pw, pb = base + gate * H * H, base + 3 * H * H + gate * H
             else:
                 if self.recurrent and ei == L:
@@ -252,7 +262,7 @@ class _FlatNet(nn.Module):
                 pack_off += orows * k + orows
                 if self.recurrent and ei == L - 1:  # reserve the GRU block right after the last MLP layer
                     self._gru_pack_base = pack_off
-                    pack_off += 2 * (3 * H * H + 3 * H)
+                    pack_off += 2 * self.recurrent_n * (3 * H * H + 3 * H)
             kp, op = ((k + 31) // 32) * 32, ((o + 31) // 32) * 32
             if self.md and ei >= len(ents) - len(self._md_sp):
                 op = self._md_sp[ei - (len(ents) - len(self._md_sp))]  # partial layout of harl_mlp_dw_partials(HO = sp)
@@ -275,11 +285,14 @@ class _FlatNet(nn.Module):
         nh = len(self._head_layers())
         self._head_packs = views[-nh:]          # every head entry (MultiDiscrete: one per group)
         if self.recurrent:
-            b0 = self._gru_pack_base
             n = 3 * H * H
-            self.gru_pack = dict(Wih=self.pack_arena[b0:b0 + n], bih=self.pack_arena[b0 + n:b0 + n + 3 * H],
-                                 Whh=self.pack_arena[b0 + n + 3 * H:b0 + 2 * n + 3 * H],
-                                 bhh=self.pack_arena[b0 + 2 * n + 3 * H:b0 + 2 * n + 6 * H])
+            self.gru_packs = []  # per GRU layer: the folded [3H, H] gate matrices and [3H] biases
+            for l in range(self.recurrent_n):
+                b0 = self._gru_pack_base + 2 * l * (n + 3 * H)
+                self.gru_packs.append(dict(Wih=self.pack_arena[b0:b0 + n], bih=self.pack_arena[b0 + n:b0 + n + 3 * H],
+                                           Whh=self.pack_arena[b0 + n + 3 * H:b0 + 2 * n + 3 * H],
+                                           bhh=self.pack_arena[b0 + 2 * n + 3 * H:b0 + 2 * n + 6 * H]))
+            self.gru_pack = self.gru_packs[0]
         # harl_adam_fold updates parameters by table entry (rows of W with their bias, the LayerNorm in front, log_std): every
         # parameter must be reachable that way
         covered = sum(o * k + o for (_, _, _, _, o, k) in ents)
@@ -356,8 +369,10 @@ class _FlatNet(nn.Module):
             H = self.hidden_sizes[-1]
             a = lambda: torch.empty(mp * H, dtype=f32, device=dev)  # noqa: E731
             self.rnn_y, self.rnn_rstd = a(), torch.empty(mp, dtype=f32, device=dev)
-            self.rnn_saved = [a() for _ in range(5)]   # h~ (= h*mask), r, z, n, hn
-            self.rnn_dgate = [a() for _ in range(4)]   # dr, dz, dn, dhn
+            # per GRU layer: h~ (= h*mask), r, z, n, hn  and  dr, dz, dn, dhn
+            self.rnn_saved_l = [[a() for _ in range(5)] for _ in range(self.recurrent_n)]
+            self.rnn_dgate_l = [[a() for _ in range(4)] for _ in range(self.recurrent_n)]
+            self.rnn_saved, self.rnn_dgate = self.rnn_saved_l[0], self.rnn_dgate_l[0]
             # all-ones "relu mask" for rnn.norm: (H/2 + 31) / 32 words per lane (two at H = 128 -- sized for one, the head kernels
             # read the second word past the end: the first hardware run of the 128-wide GRU, round 3)
             self.rnn_ones = torch.full((n_slabs * 64 * ((H // 2 + 31) // 32),), -1, dtype=u32, device=dev)
@@ -595,10 +610,13 @@ class _FlatNet(nn.Module):
                      tag="gru_bwd")
             # the six gate blocks in ONE launch: W_ih' blocks d gi_g^T x_hat_mlp (g = r, z, n), W_hh blocks d gh_g^T h~ (dhn for n)
             import ctypes as C
-            a6 = (C.c_void_p * 6)(*[ptr(t) for t in (dg[0], dg[1], dg[2], dg[0], dg[1], dg[3])])
-            b6 = (C.c_void_p * 6)(*([ptr(self.xh[-1])] * 3 + [ptr(sv[0])] * 3))
-            p6 = (C.c_void_p * 6)(*[ptr(self.part[po[L + k]:]) for k in range(6)])
-            call("harl_mlp_dw_partials_multi", 6, a6, b6, p6, H, H, M, nwg, s, tag="dw_gru")
+            for gl in range(self.recurrent_n):  # layer gl reads x_hat of the MLP (gl = 0) or the raw output of layer gl - 1
+                dg_, sv_ = self.rnn_dgate_l[gl], self.rnn_saved_l[gl]
+                xin = self.xh[-1] if gl == 0 else self.rnn_hraw_l[gl - 1]
+                a6 = (C.c_void_p * 6)(*[ptr(t) for t in (dg_[0], dg_[1], dg_[2], dg_[0], dg_[1], dg_[3])])
+                b6 = (C.c_void_p * 6)(*([ptr(xin)] * 3 + [ptr(sv_[0])] * 3))
+                p6 = (C.c_void_p * 6)(*[ptr(self.part[po[L + 6 * gl + k]:]) for k in range(6)])
+                call("harl_mlp_dw_partials_multi", 6, a6, b6, p6, H, H, M, nwg, s, tag="dw_gru")
             cur = 1
         if self.panel:  # width 256 (csrc/panel.hip): per layer dW = dz^T x_hat_prev, then dz_prev through the panel GEMM
             for l in range(L - 1, -1, -1):

@@ -23,6 +23,7 @@ class Shapes:
     discrete: bool = False
     hidden_sizes: Sequence[int] = (128, 128)
     nvec: Optional[Sequence[int]] = None   # MultiDiscrete: actions per head (act_dim = their sum, discrete = True)
+    recurrent_n: int = 1   # stacked GRU layers of recurrent policies (models/base/rnn.py:14)
 
     @property
     def act_shape(self) -> int:  # width of the stored `actions` / `action_log_probs`
@@ -31,10 +32,14 @@ class Shapes:
         return 1 if self.discrete else self.act_dim
 
 
-def _rnn_shapes(h: int) -> List[Tuple[str, Tuple[int, ...]]]:
-    """RNNLayer (models/base/rnn.py:8-21): nn.GRU(h, h, 1) parameters in registration order, then the LayerNorm."""
-    return [("rnn.rnn.weight_ih_l0", (3 * h, h)), ("rnn.rnn.weight_hh_l0", (3 * h, h)), ("rnn.rnn.bias_ih_l0", (3 * h,)),
-            ("rnn.rnn.bias_hh_l0", (3 * h,)), ("rnn.norm.weight", (h,)), ("rnn.norm.bias", (h,))]
+def _rnn_shapes(h: int, recurrent_n: int = 1) -> List[Tuple[str, Tuple[int, ...]]]:
+    """RNNLayer (models/base/rnn.py:8-21): nn.GRU(h, h, recurrent_n) parameters in registration order (per layer: weight_ih,
+    weight_hh, bias_ih, bias_hh), then the LayerNorm."""
+    out: List[Tuple[str, Tuple[int, ...]]] = []
+    for l in range(recurrent_n):
+        out += [(f"rnn.rnn.weight_ih_l{l}", (3 * h, h)), (f"rnn.rnn.weight_hh_l{l}", (3 * h, h)), (f"rnn.rnn.bias_ih_l{l}", (3 * h,)),
+                (f"rnn.rnn.bias_hh_l{l}", (3 * h,))]
+    return out + [("rnn.norm.weight", (h,)), ("rnn.norm.bias", (h,))]
 
 
 def actor_param_shapes(sh: Shapes, use_feature_normalization: bool = True,
@@ -50,7 +55,7 @@ def actor_param_shapes(sh: Shapes, use_feature_normalization: bool = True,
                 (f"base.mlp.fc.{3*i+2}.weight", (h,)), (f"base.mlp.fc.{3*i+2}.bias", (h,))]
         d = h
     if recurrent:
-        out += _rnn_shapes(d)
+        out += _rnn_shapes(d, sh.recurrent_n)
     if sh.nvec is not None:  # act.py:35-43: nn.ModuleList of Categoricals
         for k, n in enumerate(sh.nvec):
             out += [(f"act.action_outs.{k}.linear.weight", (int(n), d)), (f"act.action_outs.{k}.linear.bias", (int(n),))]
@@ -74,7 +79,7 @@ def critic_param_shapes(sh: Shapes, use_feature_normalization: bool = True,
                 (f"base.mlp.fc.{3*i+2}.weight", (h,)), (f"base.mlp.fc.{3*i+2}.bias", (h,))]
         d = h
     if recurrent:
-        out += _rnn_shapes(d)
+        out += _rnn_shapes(d, sh.recurrent_n)
     out += [("v_out.weight", (1, d)), ("v_out.bias", (1,))]
     return out
 
@@ -173,9 +178,9 @@ def make_buffers(sh: Shapes, seed: int, inactive_p: float = 0.0, unavailable_p: 
                       value_preds=rng.standard_normal((T + 1, N, A, 1)).astype(f32),
                       masks=m_fp.astype(f32), bad_masks=np.where(m_fp == 0.0, 0.0, 1.0).astype(f32))
     if rnn:  # stored GRU hidden states (drawn last so the other arrays do not depend on the flag)
-        hh = sh.hidden_sizes[-1]
-        out.rnn = dict(actor=[(0.3 * rng.standard_normal((T + 1, N, 1, hh))).astype(f32) for _ in range(A)],
-                       critic=(0.3 * rng.standard_normal((T + 1, N, 1, hh))).astype(f32))
+        hh, rn = sh.hidden_sizes[-1], sh.recurrent_n
+        out.rnn = dict(actor=[(0.3 * rng.standard_normal((T + 1, N, rn, hh))).astype(f32) for _ in range(A)],
+                       critic=(0.3 * rng.standard_normal((T + 1, N, rn, hh))).astype(f32))
         if fp:  # per-agent critic hidden states (on_policy_critic_buffer_fp.py:48-56)
-            out.rnn["critic_fp"] = (0.3 * rng.standard_normal((T + 1, N, A, 1, hh))).astype(f32)
+            out.rnn["critic_fp"] = (0.3 * rng.standard_normal((T + 1, N, A, rn, hh))).astype(f32)
     return out

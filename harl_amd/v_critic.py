@@ -70,7 +70,8 @@ class VCritic:
         H = net.hidden_sizes[-1]
         h0 = _as_dev(rnn_states_critic, self.device)
         m = h0.shape[0]
-        seq = build_seq(self.device, M // m, m, H, h0=h0.reshape(m, H), masks_src=_as_dev(masks, self.device),
+        HS = H * net.recurrent_n
+        seq = build_seq(self.device, M // m, m, HS, h0=h0.reshape(m, HS), masks_src=_as_dev(masks, self.device),
                         want_h_last=True)
         Mp = seq["L"] * seq["m_pad"]
         net.forward_trunk(x, seq["idx"], Mp, for_backward=False, seq=seq)
@@ -79,7 +80,7 @@ class VCritic:
         call("harl_critic_head_values", ptr(fx), Mp, fh, ptr(Wp), ptr(bp), ptr(outp), stream())
         if seq["idx"] is not None:
             out.copy_(outp.reshape(seq["L"], seq["m_pad"], 1)[:, :m].reshape(M, 1))
-        return out, seq["h_last"][:m].reshape(m, 1, H).clone()
+        return out, seq["h_last"][:m].reshape(m, net.recurrent_n, H).clone()
 
     def _update_core(self, share_obs, idx, m, m_global, value_preds, returns, vn: Optional[ValueNorm], seq=None):
         """One optimiser step on rows idx[0..m) (m = 0: this rank holds none of the global minibatch's m_global rows and
@@ -148,9 +149,9 @@ class VCritic:
         before = self._info.clone()
         self.critic.fold()
         if self.critic.recurrent:
-            H = self.critic.hidden_sizes[-1]
+            HS = self.critic.hidden_sizes[-1] * self.critic.recurrent_n
             h0 = _as_dev(_rnn, dev)
-            seq = build_seq(dev, m // h0.shape[0], h0.shape[0], H, h0=h0.reshape(-1, H), masks_src=_as_dev(_masks, dev))
+            seq = build_seq(dev, m // h0.shape[0], h0.shape[0], HS, h0=h0.reshape(-1, HS), masks_src=_as_dev(_masks, dev))
             self._update_core(x.reshape(m, -1), seq["idx"], seq["L"] * seq["m_pad"], m, _as_dev(value_preds, dev).reshape(m),
                               _as_dev(returns, dev).reshape(m), value_normalizer, seq=seq)
             d = self._info - before

@@ -123,6 +123,16 @@ CASES = {
                                           hidden_sizes=[64, 128]), seed=82, unavailable_p=0.2,
                               overrides=dict(use_recurrent_policy=True, data_chunk_length=5, actor_num_mini_batch=2,
                                              critic_num_mini_batch=2, ppo_epoch=2, critic_epoch=2)),
+    # ---- stacked GRU layers, recurrent_n = 2 (rnn.py:14 nn.GRU(num_layers=recurrent_n); every layer's state is reset by the
+    #      mask, rnn.py:27,67): chunked sampler on 64-wide layers, naive sampler with mini-batches on a 128-wide GRU
+    "rnn2_box_h64": dict(shapes=dict(T=20, N=6, A=2, obs_dim=15, share_obs_dim=22, act_dim=3, discrete=False,
+                                     hidden_sizes=[64, 64], recurrent_n=2), seed=91, inactive_p=0.1,
+                         overrides=dict(use_recurrent_policy=True, recurrent_n=2, data_chunk_length=10, ppo_epoch=3,
+                                        critic_epoch=3)),
+    "rnn2_disc_h128_naive_mb2": dict(shapes=dict(T=12, N=8, A=2, obs_dim=19, share_obs_dim=26, act_dim=7, discrete=True,
+                                                 hidden_sizes=[128], recurrent_n=2), seed=92, unavailable_p=0.2,
+                                     overrides=dict(use_naive_recurrent_policy=True, recurrent_n=2, actor_num_mini_batch=2,
+                                                    critic_num_mini_batch=2, ppo_epoch=2, critic_epoch=2)),
     "rnn_naive_h64": dict(shapes=dict(T=12, N=6, A=2, obs_dim=9, share_obs_dim=12, act_dim=2, discrete=False,
                                       hidden_sizes=[64, 64, 64]), seed=17,
                           overrides=dict(use_naive_recurrent_policy=True, actor_num_mini_batch=2, critic_num_mini_batch=2,

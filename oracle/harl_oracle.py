@@ -277,30 +277,38 @@ def mlp_base_forward(p: Dict[str, torch.Tensor], x: torch.Tensor) -> torch.Tenso
 
 
 def rnn_layer_forward(p: Dict[str, torch.Tensor], x: torch.Tensor, hxs: torch.Tensor, masks: torch.Tensor):
-    """RNNLayer.forward (models/base/rnn.py:23-81) for recurrent_n = 1: GRU (gate order r, z, n) with the hidden state
-    multiplied by the mask at every step (the reference multiplies at segment starts; elsewhere the mask is 1), then
-    LayerNorm.  x: [N, H] (one step) or [T*N, H] (t-major sequence); hxs: [N, 1, H]; masks: [N|T*N, 1]."""
-    Wih, Whh = p["rnn.rnn.weight_ih_l0"], p["rnn.rnn.weight_hh_l0"]
-    bih, bhh = p["rnn.rnn.bias_ih_l0"], p["rnn.rnn.bias_hh_l0"]
+    """RNNLayer.forward (models/base/rnn.py:23-81): nn.GRU with ``recurrent_n`` stacked layers (gate order r, z, n; layer l > 0
+    reads layer l - 1's output of the same step) with EVERY layer's hidden state multiplied by the mask at every step (the
+    reference multiplies at segment starts -- ``masks.repeat(1, recurrent_n)`` / ``.repeat(recurrent_n, 1, 1)``, rnn.py:27,67;
+    elsewhere the mask is 1), then LayerNorm on the top layer's output.  x: [N, H] (one step) or [T*N, H] (t-major sequence);
+    hxs: [N, recurrent_n, H]; masks: [N|T*N, 1].  Returns (y [T*N, H], hxs [N, recurrent_n, H])."""
+    n_layers = 0
+    while f"rnn.rnn.weight_ih_l{n_layers}" in p:
+        n_layers += 1
     N = hxs.shape[0]
     T = x.shape[0] // N
-    H = Whh.shape[1]
+    H = p["rnn.rnn.weight_hh_l0"].shape[1]
     xs = x.view(T, N, -1)
     ms = masks.view(T, N, 1)
-    h = hxs[:, 0, :]
+    h = [hxs[:, l, :] for l in range(n_layers)]
     outs = []
     for t in range(T):
-        h = h * ms[t]
-        gi = F.linear(xs[t], Wih, bih)
-        gh = F.linear(h, Whh, bhh)
-        r = torch.sigmoid(gi[:, :H] + gh[:, :H])
-        z = torch.sigmoid(gi[:, H:2 * H] + gh[:, H:2 * H])
-        n = torch.tanh(gi[:, 2 * H:] + r * gh[:, 2 * H:])
-        h = (1 - z) * n + z * h
-        outs.append(h)
+        inp = xs[t]
+        for l in range(n_layers):
+            Wih, Whh = p[f"rnn.rnn.weight_ih_l{l}"], p[f"rnn.rnn.weight_hh_l{l}"]
+            bih, bhh = p[f"rnn.rnn.bias_ih_l{l}"], p[f"rnn.rnn.bias_hh_l{l}"]
+            hl = h[l] * ms[t]
+            gi = F.linear(inp, Wih, bih)
+            gh = F.linear(hl, Whh, bhh)
+            r = torch.sigmoid(gi[:, :H] + gh[:, :H])
+            z = torch.sigmoid(gi[:, H:2 * H] + gh[:, H:2 * H])
+            n = torch.tanh(gi[:, 2 * H:] + r * gh[:, 2 * H:])
+            h[l] = (1 - z) * n + z * hl
+            inp = h[l]
+        outs.append(inp)
     y = torch.stack(outs, 0).reshape(T * N, H)
     y = F.layer_norm(y, (H,), p["rnn.norm.weight"], p["rnn.norm.bias"], 1e-5)
-    return y, h.unsqueeze(1)
+    return y, torch.stack(h, 1)
 
 
 def actor_evaluate_actions(

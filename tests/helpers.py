@@ -25,7 +25,9 @@ RNN_CASES = ["rnn_box_h64", "rnn_disc_h64_mb2", "rnn_naive_h64", "rnn_fp_box_h64
 ACT_CASES = ["mpe_box_h128_tanh", "disc_h64_selu_mb2", "wide_fp_box_h128_64_leaky", "a2c_box_h64x3_sigmoid",
              "mappo_shared_disc_h128_tanh"]
 # GRU on 128-wide layers (harl_amd/gru_wide.py: per-step composition of layer GEMMs + cell kernels)
-RNN128_CASES = ["rnn_box_h128", "rnn_disc_h128_mb2"]
+RNN128_CASES = ["rnn_box_h128", "rnn_disc_h128_mb2",
+                # stacked GRU layers (recurrent_n = 2) run on the same composition, 64- and 128-wide
+                "rnn2_box_h64", "rnn2_disc_h128_naive_mb2"]
 MAPPO_CASES = ["mappo_box_h64", "mappo_shared_disc_h64_mb2", "mappo_shared_fp_box_h128",
                # shared parameters with GRU policies (chunked sampler, mini-batches; naive sampler on a 128-wide GRU with the FP critic)
                "mappo_shared_rnn_disc_h64_mb2", "mappo_shared_rnn_naive_fp_box_h128"]

@@ -141,9 +141,10 @@ def test_composed_gru_matches_64_wide_goldens(name, monkeypatch):
     _assert_all(_G().check_train_golden(name), tol=TOL)
 
 
-@pytest.mark.parametrize("name", ["rnn_box_h128", "rnn_disc_h128_mb2"])
+@pytest.mark.parametrize("name", ["rnn_box_h128", "rnn_disc_h128_mb2", "rnn2_box_h64", "rnn2_disc_h128_naive_mb2"])
 def test_gru128_train_matches_reference_golden(name, monkeypatch):
-    """GRU policies on 128-wide layers (the default hidden_sizes with use_recurrent_policy) vs the reference."""
+    """GRU policies on 128-wide layers (the default hidden_sizes with use_recurrent_policy) and stacked GRU layers
+    (recurrent_n = 2, rnn.py:14; 64-wide chunked, 128-wide naive with two mini-batches) vs the reference."""
     _assert_all(_G().check_train_golden(name), tol=TOL)
 
 

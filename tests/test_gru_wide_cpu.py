@@ -151,10 +151,11 @@ def _emulate(arena, H):
                 harl_rownorm=rownorm, harl_mlp_bwd_dx=bwd_dx)
 
 
-@pytest.mark.parametrize("H,L,m", [(128, 7, 40), (64, 5, 32)])
-def test_composition_matches_autograd_gru(stub_kernels, monkeypatch, H, L, m):  # noqa: F811
+@pytest.mark.parametrize("H,L,m,RN", [(128, 7, 40, 1), (64, 5, 32, 1), (64, 6, 40, 2), (128, 4, 32, 3)])
+def test_composition_matches_autograd_gru(stub_kernels, monkeypatch, H, L, m, RN):  # noqa: F811
+    """RN stacked layers (rnn.py:14: nn.GRU(num_layers=recurrent_n)); every layer's carried state is multiplied by the mask of
+    the step (rnn.py:27,67)."""
     from harl_amd import _lib, gru_wide
-    from harl_amd.nets import build_seq
 
     torch.manual_seed(3)
     mp = ((m + 31) // 32) * 32
@@ -164,25 +165,29 @@ def test_composition_matches_autograd_gru(stub_kernels, monkeypatch, H, L, m):  
     class Net:  # the attributes gru_wide.py reads from a _FlatNet
         hidden_sizes = [H]
         device_ = torch.device("cpu")
+        recurrent_n = RN
     net = Net()
-    Wih, Whh, bih, bhh = 0.3 * f(3 * H * H), 0.3 * f(3 * H * H), 0.1 * f(3 * H), 0.1 * f(3 * H)
-    net.gru_pack = dict(Wih=Wih, bih=bih, Whh=Whh, bhh=bhh)
     z = lambda n_: torch.zeros(n_, dtype=torch.float64)  # noqa: E731
+    net.gru_packs = [dict(Wih=0.3 * f(3 * H * H), bih=0.1 * f(3 * H), Whh=0.3 * f(3 * H * H), bhh=0.1 * f(3 * H))
+                     for _ in range(RN)]
     net.xh, net.rmask, net.rstd = [f(M * H)], [torch.zeros(8, dtype=torch.int32)], [z(M)]
-    net.rnn_saved = [z(M * H) for _ in range(5)]
-    net.rnn_dgate = [z(M * H) for _ in range(4)]
+    net.rnn_saved_l = [[z(M * H) for _ in range(5)] for _ in range(RN)]
+    net.rnn_dgate_l = [[z(M * H) for _ in range(4)] for _ in range(RN)]
     net.rnn_gi, net.rnn_y, net.rnn_rstd = z(3 * M * H), z(M * H), z(M)
     net.dz = [f(M * H), z(M * H)]
-    net.rnn_hraw, net.rnn_gh, net.rnn_gz, net.rnn_zero_bias = z(M * H), z(3 * M * H), z(M * H), z(H)
+    net.rnn_hraw_l = [z(M * H) for _ in range(RN)]
+    net.rnn_gh, net.rnn_gz, net.rnn_zero_bias, net.rnn_tmp, net.rnn_dh = z(3 * M * H), z(M * H), z(H), z(M * H), z(M * H)
     mask_rows = (torch.rand(M, dtype=torch.float64) > 0.2).to(torch.float64)
-    seq = dict(L=L, m_pad=mp, m=m, h0=0.5 * f(mp * H), mask_rows=mask_rows, h_last=z(mp * H))
+    seq = dict(L=L, m_pad=mp, m=m, h0=0.5 * f(mp, RN * H), mask_rows=mask_rows, h_last=z(mp * RN * H).view(mp, RN * H))
 
     arena = _Arena()
-    for t in (Wih, Whh, bih, bhh, net.xh[0], net.rstd[0], *net.rnn_saved, *net.rnn_dgate, net.rnn_gi, net.rnn_y, net.rnn_rstd,
-              *net.dz, net.rnn_hraw, net.rnn_gh, net.rnn_gz, net.rnn_zero_bias, mask_rows, seq["h0"], seq["h_last"]):
+    for t in (*[v for gp in net.gru_packs for v in gp.values()], net.xh[0], net.rstd[0],
+              *[t_ for l_ in net.rnn_saved_l for t_ in l_], *[t_ for l_ in net.rnn_dgate_l for t_ in l_],
+              net.rnn_gi, net.rnn_y, net.rnn_rstd, *net.dz, *net.rnn_hraw_l, net.rnn_gh, net.rnn_gz, net.rnn_zero_bias,
+              net.rnn_tmp, net.rnn_dh, mask_rows, seq["h0"], seq["h_last"]):
         arena.add(t)
     emu = _emulate(arena, H)
-    keep = []  # tensors created inside gru_wide (the transposed W_hh) must stay alive and be addressable
+    keep = []  # tensors created inside gru_wide (transposed weight blocks, per-layer state slices) must stay alive and addressable
 
     real_ptr = _lib.ptr
 
@@ -203,35 +208,41 @@ def test_composition_matches_autograd_gru(stub_kernels, monkeypatch, H, L, m):  
 
     # ---- reference: plain torch GRU with autograd (torch.nn.GRU's equations, gate order r, z, n; masks reset the carried state)
     x = net.xh[0].view(L, mp, H).clone().requires_grad_(True)
-    Wi, Wh = Wih.view(3, H, H).clone().requires_grad_(True), Whh.view(3, H, H).clone().requires_grad_(True)
-    h = seq["h0"].view(mp, H)
+    Wi = [gp["Wih"].view(3, H, H).clone().requires_grad_(True) for gp in net.gru_packs]
+    Wh = [gp["Whh"].view(3, H, H).clone().requires_grad_(True) for gp in net.gru_packs]
+    h = [seq["h0"].view(mp, RN, H)[:, k] for k in range(RN)]
     hs = []
     for l in range(L):
-        ht = h * mask_rows[l * mp:(l + 1) * mp].view(mp, 1)
-        gi = [x[l] @ Wi[g].t() + bih[g * H:(g + 1) * H] for g in range(3)]
-        gh = [ht @ Wh[g].t() + bhh[g * H:(g + 1) * H] for g in range(3)]
-        r_ = torch.sigmoid(gi[0] + gh[0])
-        z_ = torch.sigmoid(gi[1] + gh[1])
-        n_ = torch.tanh(gi[2] + r_ * gh[2])
-        h = (1 - z_) * n_ + z_ * ht
-        hs.append(h)
-    hraw = torch.stack(hs)                                   # [L, mp, H]
+        inp = x[l]
+        for k in range(RN):
+            gp = net.gru_packs[k]
+            ht = h[k] * mask_rows[l * mp:(l + 1) * mp].view(mp, 1)
+            gi = [inp @ Wi[k][g].t() + gp["bih"][g * H:(g + 1) * H] for g in range(3)]
+            gh = [ht @ Wh[k][g].t() + gp["bhh"][g * H:(g + 1) * H] for g in range(3)]
+            r_ = torch.sigmoid(gi[0] + gh[0])
+            z_ = torch.sigmoid(gi[1] + gh[1])
+            n_ = torch.tanh(gi[2] + r_ * gh[2])
+            h[k] = (1 - z_) * n_ + z_ * ht
+            inp = h[k]
+        hs.append(inp)
+    hraw = torch.stack(hs)                                   # [L, mp, H]: the top layer
     mu = hraw.mean(-1, keepdim=True)
     y_ref = (hraw - mu) / torch.sqrt(((hraw - mu) ** 2).mean(-1, keepdim=True) + 1e-5)
 
     gru_wide.forward(net, seq, save=True)
     assert torch.allclose(net.rnn_y.view(L, mp, H), y_ref.detach(), atol=1e-12)
-    assert torch.allclose(seq["h_last"].view(mp, H), hs[-1].detach(), atol=1e-12)
+    assert torch.allclose(seq["h_last"].view(mp, RN, H), torch.stack([hk.detach() for hk in h], 1), atol=1e-12)
 
-    G = net.dz[0].view(L, mp, H).clone()                     # d(loss)/d(h_l)
+    G = net.dz[0].view(L, mp, H).clone()                     # d(loss)/d(h_l) of the top layer
     (hraw * G).sum().backward()
     gru_wide.backward(net, seq)
-    assert torch.allclose(net.dz[1].view(L, mp, H), x.grad, atol=1e-10)               # gradient into the MLP output
-    # weight gradients as backward_trunk forms them from the gate gradients: dW_ig = dgi_g^T x_hat, dW_hg = dgh_g^T h~
-    xh = net.xh[0].view(M, H)
-    hpm = net.rnn_saved[0].view(M, H)
-    for g, (gi_g, gh_g) in enumerate(zip((0, 1, 2), (0, 1, 3))):
-        dWi = net.rnn_dgate[gi_g].view(M, H).t() @ xh
-        dWh = net.rnn_dgate[gh_g].view(M, H).t() @ hpm
-        assert torch.allclose(dWi, Wi.grad[g], atol=1e-9), g
-        assert torch.allclose(dWh, Wh.grad[g], atol=1e-9), g
+    assert torch.allclose(net.dz[1].view(L, mp, H), x.grad, atol=1e-9)                # gradient into the MLP output
+    # weight gradients as backward_trunk forms them from the gate gradients: dW_ig = dgi_g^T (layer input), dW_hg = dgh_g^T h~
+    for k in range(RN):
+        xin = (net.xh[0] if k == 0 else net.rnn_hraw_l[k - 1]).view(M, H)
+        hpm = net.rnn_saved_l[k][0].view(M, H)
+        for g, (gi_g, gh_g) in enumerate(zip((0, 1, 2), (0, 1, 3))):
+            dWi = net.rnn_dgate_l[k][gi_g].view(M, H).t() @ xin
+            dWh = net.rnn_dgate_l[k][gh_g].view(M, H).t() @ hpm
+            assert torch.allclose(dWi, Wi[k].grad[g], atol=1e-8), (k, g)
+            assert torch.allclose(dWh, Wh[k].grad[g], atol=1e-8), (k, g)

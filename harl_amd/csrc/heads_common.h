@@ -160,10 +160,17 @@ __device__ __forceinline__ void head_fwd_regs(const f32x4 (&xs)[H / 8], const fl
   for (int d = 0; d < DA; ++d) z[d] = wave_sum32(z[d]) + cst[d];
 }
 
-// The same product from a TRANSPOSED image whlT[h][d][R] (one ds_read_b128 = four features of ONE output): DA x H/8
-// reads per lane, all of them used (the [R][DAP] image above costs 2 x H/2 reads at 4 < DA <= 8 and discards the padding),
-// requested one q-step ahead of the FMAs that consume them -- the phase was bound by exposed LDS latency, not by its FMAs
-// (phase timers, round 4: 14 % of the fused kernel for 320 FMAs per lane).
+// ---- the head weights as a TRANSPOSED image whlT[h][d][R] (the fused kernel of update.hip; rows d < DAE = DA rounded up to
+// even, the odd padding row zero; lane half h at h * head_t_block(H, DA) floats: 16 floats of padding keep the two halves of an
+// MFMA operand read on different banks).  Forward: one ds_read_b128 = four features of ONE output -- DA x H/8 reads per
+// lane, all of them used (the [R][DAP] image above costs 2 x H/2 reads at 4 < DA <= 8 and discards the padding), requested one
+// q-step ahead of the FMAs that consume them: the phase was bound by exposed LDS latency, not by its FMAs (phase timers,
+// round 4: 14 % of the fused kernel for 320 FMAs per lane).  Backward: head_bwd_regs_bits<..., WT = true> reads its MFMA A
+// operand from the same image, so the kernel holds the head weights once.
+constexpr int HEAD_T_PAD = 16;
+__host__ __device__ constexpr int head_t_rows(int da) { return 2 * ((da + 1) / 2); }
+__host__ __device__ constexpr int head_t_block(int H, int da) { return head_t_rows(da) * (H / 2) + HEAD_T_PAD; }
+
 template <int H, int DAP, int DA>
 __device__ __forceinline__ void head_fwd_regs_t(const f32x4 (&xs)[H / 8], const float *whlT_h, const float *cst,
                                                 float (&z)[DAP]) {
@@ -188,19 +195,28 @@ __device__ __forceinline__ void head_fwd_regs_t(const f32x4 (&xs)[H / 8], const 
   for (int d = 0; d < DA; ++d) z[d] = wave_sum32(z[d]) + cst[d];
 }
 
-template <int H>
-__device__ __forceinline__ void stage_head_t(float *whlT, const float *__restrict__ Whp, int da, int n_threads) {
-  // whlT[hh][d][R] = Whp[d][f(R,hh)]
-  for (int e = threadIdx.x; e < 2 * da * (H / 2); e += n_threads) {
-    const int R = e % (H / 2), d = (e / (H / 2)) % da, hh = e / ((H / 2) * da);
-    whlT[e] = Whp[d * H + feat_base(R) + 4 * hh];
+// whlT[hh][d][R] = Whp[d][f(R,hh)]; cst[0..DAP) = bias, cst[4 DAP + d] = row sums (as stage_head)
+template <int H, int DAP, int DA>
+__device__ __forceinline__ void stage_head_t(float *whlT, float *cst, const float *__restrict__ Whp,
+                                             const float *__restrict__ bhp, int n_threads) {
+  constexpr int DAE = head_t_rows(DA), BLK = head_t_block(H, DA);
+  for (int e = threadIdx.x; e < 2 * DAE * (H / 2); e += n_threads) {
+    const int R = e % (H / 2), d = (e / (H / 2)) % DAE, hh = e / ((H / 2) * DAE);
+    whlT[hh * BLK + d * (H / 2) + R] = d < DA ? Whp[d * H + feat_base(R) + 4 * hh] : 0.f;
+  }
+  for (int e = threadIdx.x; e < DAP; e += n_threads) {
+    cst[e] = e < DA ? bhp[e] : 0.f;
+    float rs = 0.f;
+    if (e < DA)
+      for (int f = 0; f < H; ++f) rs += Whp[e * H + f];
+    cst[4 * DAP + e] = rs;
   }
 }
 
 // PACKED: the LayerNorm / ReLU backward of the epilogue on register pairs (2 x v_pk_fma_f32 per pair + the two-instruction
 // mask_pop per element: 3 VALU per element instead of 6) -- for the issue-bound fused kernel (update.hip); the stand-alone head
 // kernels are HBM-bound and keep the plain form, which leaves the scheduler free.
-template <int H, int DAP, int DA = DAP, bool PACKED = false>
+template <int H, int DAP, int DA = DAP, bool PACKED = false, bool WT = false>
 __device__ __forceinline__ void head_bwd_regs_bits(const f32x4 (&xs)[H / 8], uint32_t b0, const uint32_t b1, float rstd,
                                                    long slab, int lane, const float *whl /* base, both halves */,
                                                    const float (&dzh)[DAP], float s1, float s2,
@@ -215,7 +231,9 @@ __device__ __forceinline__ void head_bwd_regs_bits(const f32x4 (&xs)[H / 8], uin
   // (LDS-latency bound: the loss kernels spent half their wave time in s_waitcnt) by DAP/2 x H/32 MFMAs and as many
   // conflicted-but-few ds_read_b32 of the same weight image.
   const int i = lane & 31, h = lane >> 5;
-  const float *wa = whl + (((i >> 2) & 1) * (H / 2) + (i & 3) + 4 * (i >> 3)) * DAP + h;  // W'[2s + h][32 t + i] at + 16 t DAP + 2 s
+  // W'[2s + h][32 t + i]: [R][DAP] image at + 16 t DAP + 2 s, transposed image (WT, whl = whlT) at + 16 t + 2 s H/2
+  const float *wa = WT ? whl + ((i >> 2) & 1) * head_t_block(H, DA) + (i & 3) + 4 * (i >> 3) + h * (H / 2)
+                       : whl + (((i >> 2) & 1) * (H / 2) + (i & 3) + 4 * (i >> 3)) * DAP + h;
   f32x16 acc[H / 32];
 #pragma unroll
   for (int t = 0; t < H / 32; ++t)
@@ -229,7 +247,7 @@ __device__ __forceinline__ void head_bwd_regs_bits(const f32x4 (&xs)[H / 8], uin
     const float bsel = __uint_as_float((__float_as_uint(dzh[2 * st + 1]) & hm) | (__float_as_uint(dzh[2 * st]) & ~hm));
 #pragma unroll
     for (int t = 0; t < H / 32; ++t)
-      acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[16 * t * DAP + 2 * st], bsel, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[WT ? 16 * t + 2 * st * (H / 2) : 16 * t * DAP + 2 * st], bsel, acc[t], 0, 0, 0);
   }
   f32x4 *op = reinterpret_cast<f32x4 *>(dz_out + slab * (long)(H * SLAB)) + lane;
   const float c1 = -s1 * rstd, c2 = -s2 * rstd;
@@ -534,6 +552,57 @@ __device__ __forceinline__ void actor_row_load(const ActorArgs &A, long slab, in
   }
 }
 
+// ---- the same loads for the persistent fused kernel (update.hip), WITHOUT a branch and without a wait.  (1) The gathered row
+// index travels one slab further ahead than the rows (row_index_request in one iteration, row_index_resolve in the next):
+// loaded at its point of use, `idx ? idx[j] : j` put an s_waitcnt vmcnt(0) behind the join of the two paths -- executed with
+// idx == NULL as well -- which drained every outstanding memory operation once per slab, the 16 dz_2 stores the wave had just
+// issued included (ISA, round 4).  (2) Optional arrays (actions, stored log-probs, availability, active masks, factors) are
+// read unconditionally, a NULL pointer replaced by the head weights (always mapped, >= 8 floats); the consumers select
+// (actor_sample tests the same pointers).  A load under a wave-uniform branch makes the number of operations in flight depend
+// on the path, and the compiler's vmcnt then assumes the shortest one: the top of the loop waited for the row loads issued a
+// few thousand cycles earlier instead of only for the inputs requested a whole iteration before.
+__device__ __forceinline__ long row_index_request(const int64_t *idx, const float *mapped, long slab, int lane, long M) {
+  const long j = slab * SLAB + (lane & 31);
+  const long jc = j < M ? j : M - 1;
+  const int64_t *p = idx ? idx + jc : reinterpret_cast<const int64_t *>(mapped);
+  return *p;
+}
+__device__ __forceinline__ long row_index_resolve(const int64_t *idx, long raw, long slab, int lane, long M) {
+  const long j = slab * SLAB + (lane & 31);
+  return idx ? raw : (j < M ? j : M - 1);
+}
+template <int DAP, bool DISCRETE, bool TRAIN, int DA>
+__device__ __forceinline__ void actor_row_load_at(const ActorArgs &A, long slab, int lane, long row, ActorRow<DAP> &R) {
+  static_assert(DA > 0 && DA <= DAP, "compile-time action width");
+  const long j = slab * SLAB + (lane & 31);
+  const long jc = j < A.M ? j : A.M - 1;
+  const long orow = TRAIN ? row : jc;
+  const float *mapped = A.Whp;
+  const bool has_olp = TRAIN || A.old_logp;
+  if (!DISCRETE) {
+    const float *ap = A.actions ? A.actions + row * DA : mapped;
+    const float *op = has_olp ? A.old_logp + orow * DA : mapped;
+#pragma unroll
+    for (int d = 0; d < DAP; ++d) {
+      R.a[d] = d < DA ? ap[d < DA ? d : 0] : 0.f;
+      R.olp[d] = d < DA ? op[d < DA ? d : 0] : 0.f;
+    }
+  } else {
+    R.a[0] = *(A.actions ? A.actions + row : mapped);
+    R.olp[0] = *(has_olp ? A.old_logp + orow : mapped);
+    const float *vp = A.avail ? A.avail + row * DA : mapped;
+#pragma unroll
+    for (int d = 0; d < DAP; ++d) R.av[d] = d < DA ? vp[d < DA ? d : 0] : 1.f;
+  }
+  if (TRAIN) {
+    R.act = *(A.active ? A.active + row : mapped);      // (consumer: A.active ? R.act : 1)
+    R.adv = A.adv[row];
+    R.fct = *(A.factor_in ? A.factor_in + row : mapped);  // (consumer: A.factor_in ? R.fct : 1)
+  } else {
+    R.fct = *(A.factor_out ? A.factor_out + jc : mapped);  // (consumer: only under A.factor_out)
+  }
+}
+
 template <int DAP, bool DISCRETE, bool TRAIN, int DA = 0>
 __device__ __forceinline__ bool actor_sample(const ActorArgs &A, const float *cst, float (&z)[DAP], long slab, int lane,
                                              float adv_mean, float adv_den, float (&sc)[8 + DAP], float (&dzh)[DAP],
@@ -647,9 +716,9 @@ __device__ __forceinline__ bool actor_sample(const ActorArgs &A, const float *cs
         if (d < D) A.logp_out[j * D + d] = logp_d[d];
     }
   }
-  const float act = R.act;
+  const float act = A.active ? R.act : 1.f;  // (actor_row_load_at reads a mapped dummy word for absent arrays)
   const float advn = (R.adv - adv_mean) * adv_den;  // adv_den: RECIPROCAL of (std + 1e-5), formed once per kernel
-  const float fct = R.fct;  // 1 without a sequential-update factor (MAPPO)
+  const float fct = A.factor_in ? R.fct : 1.f;  // 1 without a sequential-update factor (MAPPO)
   const float lo = A.clip_lo, hi = A.clip_hi;
   const float surr1 = imp * advn;
   const float impc = fminf(fmaxf(imp, lo), hi);
@@ -735,6 +804,11 @@ __device__ __forceinline__ void critic_row_load(const CriticArgs &A, long slab, 
   const long j = slab * SLAB + (lane & 31);
   const long jc = j < A.M ? j : A.M - 1;
   const long row = A.idx ? A.idx[jc] : jc;
+  vold = A.value_preds[row];
+  ret = A.returns[row];
+}
+
+__device__ __forceinline__ void critic_row_load_at(const CriticArgs &A, long row, float &vold, float &ret) {
   vold = A.value_preds[row];
   ret = A.returns[row];
 }

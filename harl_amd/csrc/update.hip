@@ -305,7 +305,8 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_upd_dx(const float *__restric
 //           loss (critic) -> d loss / d head -> head weight gradient (transposes on the matrix pipe) -> LayerNorm / ReLU
 //           backward -> dz_2 (ATL).  x_hat_1, x_hat_2, their masks and statistics never leave the registers.
 //   !TRAIN: ... -> head -> log-probs (+ the sequential-update factor product) / values.
-// LDS: images of W_1' and W_2' (24-48 + 96 KiB), biases, the head weights as whl[h][R][DAP] (heads_common.h).
+// LDS: images of W_1' and W_2' (24-48 + 96 KiB), biases, the head weights as the transposed image whlT[h][d][R]
+// (heads_common.h: forward FMAs and the backward MFMA read the same one).
 // =============================================================================================
 struct UpdFwdArgs {
   const float *x0n, *W1p, *b1p, *W2p, *b2p;
@@ -358,11 +359,10 @@ __global__ __launch_bounds__(UF_THREADS, 2) void k_upd_fwd(UpdFwdArgs U, ARGS A)
   // it in HBM (an ATL(H) image, U.x0n), "layer 2" is layer L, and the backward that follows is the layer kernels' from
   // dz_L on: x_hat_L, its mask and statistic never leave the chip (TRAIN only)
   constexpr bool HID = KP0 == 0;
-#ifdef HARL_EARLY_X0N
-  constexpr bool EARLY_X0N = H == 128 && KP0 == 32 && DA <= 5 && !DISCRETE;  // (the other instantiations would spill)
-#else
-  constexpr bool EARLY_X0N = false;
-#endif
+  // (round 4, MPE actor launch: 0.353 -> 0.350 ms; the other instantiations would spill registers with the load moved up)
+  constexpr bool EARLY_X0N = H == 128 && KP0 == 32 && DA <= 5 && !DISCRETE;
+  // log-prob / value passes: right behind the split of this slab's inputs (the instantiations left out would spill)
+  constexpr bool EARLY_X0N_LP = !TRAIN && !HID && (H == 64 || (DA != 4 && !(KP0 == 64 && DA >= 7 && !DISCRETE)));
   static_assert(!HID || TRAIN, "the last-layer variant exists for optimiser steps only");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int MT = H / 32, NJ1 = KP0 / 16, NJ2 = H / 16, NR = H / 2, NW = (NR + 31) / 32;
@@ -370,15 +370,25 @@ __global__ __launch_bounds__(UF_THREADS, 2) void k_upd_fwd(UpdFwdArgs U, ARGS A)
   u32x4 *w1img = w2img + 3 * MT * NJ2 * 64;
   float *b1l = reinterpret_cast<float *>(w1img + 3 * MT * NJ1 * 64);
   float *b2l = b1l + H;
-  float *whl = b2l + H;                    // [2][H/2][DAP]
-  float *cst = whl + 2 * (H / 2) * DAP;    // bias, sigma, logsigma, dsigma_dlogstd, rowsum, 1/sigma, 1/sigma^2
-#ifdef HARL_HEAD_T
-  float *whlT = cst + 7 * DAP;             // [2][DA][H/2]: the head weights once more, four features of one output per read
-  float *red = whlT + 2 * DA * (H / 2);    // [8][PS_STRIDE]
-#else
+  float *whlT = b2l + H;                   // [2][DAE][H/2] (+ padding): the head weights, heads_common.h head_fwd_regs_t
+  float *cst = whlT + 2 * head_t_block(H, DA);  // bias, sigma, logsigma, dsigma_dlogstd, rowsum, 1/sigma, 1/sigma^2
   float *red = cst + 7 * DAP;              // [8][PS_STRIDE]
-#endif
   float *hacc = red + UF_WAVES * PS_STRIDE;  // [8 waves][HROWS][H] head weight gradient, wave-private
+  const int lane = threadIdx.x & 63, wave = wave_id(), i = lane & 31, h = lane >> 5;
+  const long slab0 = (long)blockIdx.x * UF_WAVES + wave, slab_stride = (long)gridDim.x * UF_WAVES;
+  // ---- the first slab's inputs are requested BEFORE the weights are staged (their latency hides behind the staging) and are
+  // complete when the loop starts (explicit s_waitcnt below): with loads still in flight at loop entry, the compiler's vmcnt
+  // at the top of the loop is the minimum over the entry path and the back edge, and the entry path's "nothing younger than
+  // the inputs" made every iteration wait for ALL stores of the previous one (ISA, round 4: s_waitcnt vmcnt(8) behind the
+  // eight row loads of the loop header, i.e. until the 16 dz_2 stores had completed)
+  constexpr int NXR = HID ? NR : KP0 / 2;  // the next slab's input, one slab ahead: x0n (KP0 wide) or x_hat_{L-1} (H wide)
+  float xr[NXR];
+  atl_load<2 * NXR>(U.x0n, slab0 < U.n_slabs ? slab0 : 0, lane, xr);
+  // the gathered row index runs one slab ahead of the rows, branch-free (heads_common.h, row_index_request); slabs past the end
+  // clamp to row M - 1 inside, so the request of the last iteration reads a mapped row that is never used
+  constexpr bool ROWS = !CRITIC || TRAIN;  // (value passes read no per-row inputs)
+  long rawn = 0;
+  if constexpr (ROWS) rawn = row_index_request(A.idx, A.Whp, slab0, lane, A.M);
   stage_split_matrix<H, H, false, UF_THREADS>(w2img, U.W2p);
   if constexpr (!HID) stage_w1_images<H, KP0, UF_THREADS>(w1img, U.W1p, U.D);
   for (int e = threadIdx.x; e < H; e += UF_THREADS) {
@@ -387,14 +397,9 @@ __global__ __launch_bounds__(UF_THREADS, 2) void k_upd_fwd(UpdFwdArgs U, ARGS A)
   }
   if (TRAIN)
     for (int e = threadIdx.x; e < UF_WAVES * HROWS * H; e += UF_THREADS) hacc[e] = 0.f;
-#ifdef HARL_HEAD_T
-  stage_head_t<H>(whlT, A.Whp, DA, UF_THREADS);
-#endif
   if (threadIdx.x < WG_THREADS) {  // (the staging helpers of heads_common.h stride by WG_THREADS)
-    if constexpr (CRITIC) {
-      stage_head<H, DAP>(whl, cst, A.Whp, A.bhp, 1);
-    } else {
-      stage_head<H, DAP>(whl, cst, A.Whp, A.bhp, A.act_dim);
+    stage_head_t<H, DAP, DA>(whlT, cst, A.Whp, A.bhp, WG_THREADS);
+    if constexpr (!CRITIC) {
       if (!DISCRETE) {
         for (int e = threadIdx.x; e < DAP; e += WG_THREADS) {
           float sg = 0.5f, sig = 1.f, lsig = 0.f, dsd = 0.f;
@@ -415,13 +420,8 @@ __global__ __launch_bounds__(UF_THREADS, 2) void k_upd_fwd(UpdFwdArgs U, ARGS A)
   }
   __syncthreads();
 
-  const int lane = threadIdx.x & 63, wave = wave_id(), i = lane & 31, h = lane >> 5;
-  const long slab0 = (long)blockIdx.x * UF_WAVES + wave, slab_stride = (long)gridDim.x * UF_WAVES;
   const u32x4 *wl1 = w1img + lane, *wl2 = w2img + lane;
-  const float *whl_h = whl + h * (H / 2) * DAP;
-#ifdef HARL_HEAD_T
-  const float *whlT_h = whlT + h * DA * (H / 2);
-#endif
+  const float *whlT_h = whlT + h * head_t_block(H, DA);
   float *hw = hacc + wave * (HROWS * H);
 
   float adv_mean = 0.f, adv_den = 1.f, vmean = 0.f, vsd = 1.f;
@@ -457,21 +457,24 @@ __global__ __launch_bounds__(UF_THREADS, 2) void k_upd_fwd(UpdFwdArgs U, ARGS A)
 #pragma unroll
   for (int d = 0; d < (CRITIC ? DAP : 1); ++d) dbacc[d] = 0.f;
 
-  constexpr int NXR = HID ? NR : KP0 / 2;  // the next slab's input, one slab ahead: x0n (KP0 wide) or x_hat_{L-1} (H wide)
-  float xr[NXR];
-  atl_load<2 * NXR>(U.x0n, slab0 < U.n_slabs ? slab0 : 0, lane, xr);
-  // the per-row loss inputs run ONE slab ahead of the arithmetic, as in k_actor_head (requested in the loss phase of the
-  // previous slab): loaded at the top of the slab they belong to, the scheduler sank the (conditional, per-dimension) loads to
-  // their first use under register pressure and the loss phase waited out their latency (phase timers, round 3: 15.8k cycles
-  // per slab against 7k in k_actor_head)
-  ActorRow<DAP> rnext;
-  float cvoldn = 0.f, cretn = 0.f;
-  if (slab0 < U.n_slabs) {
-    if constexpr (!CRITIC) actor_row_load<DAP, DISCRETE, TRAIN, DA>(A, slab0, lane, rnext);
-    else if constexpr (TRAIN) critic_row_load(A, slab0, lane, cvoldn, cretn);
-  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) (expcnt / lgkmcnt untouched): see the prologue loads above
   PHASE_BEGIN();
   for (long slab = slab0; slab < U.n_slabs; slab += slab_stride) {
+    // ---- this slab's per-row loss inputs are requested at the TOP of its iteration (consumed behind the two GEMMs, ~15k cycles
+    // later), the gathered row index of the next slab with them.  Rounds 2-3 carried them across the back edge (loaded at the
+    // end of the previous iteration): the loads merge into dwordx4 tuples, the loop-carried copies do not coalesce with the
+    // tuple, and the back edge became `s_waitcnt vmcnt(7); v_mov x3` -- a full drain of the memory pipeline (the 16 dz_2
+    // stores of the slab included) once per slab (ISA, round 4).  Nothing is loop-carried now but the index (one register pair)
+    // and the next slab's input image.  The sched_barrier keeps the scheduler from sinking the loads to their first use.
+    ActorRow<DAP> rcur;
+    float cvold = 0.f, cret = 0.f;
+    if constexpr (ROWS) {
+      const long row = row_index_resolve(A.idx, rawn, slab, lane, A.M);
+      if constexpr (!CRITIC) actor_row_load_at<DAP, DISCRETE, TRAIN, DA>(A, slab, lane, row, rcur);
+      else critic_row_load_at(A, row, cvold, cret);
+      rawn = row_index_request(A.idx, A.Whp, slab + slab_stride, lane, A.M);
+      __builtin_amdgcn_sched_barrier(0);
+    }
     float v[NR];        // x_hat_2
     uint32_t bits2[NW];
     float r2;
@@ -485,6 +488,10 @@ __global__ __launch_bounds__(UF_THREADS, 2) void k_upd_fwd(UpdFwdArgs U, ARGS A)
       } else {
         u32x4 a1[NJ1], a2[NJ1], a3[NJ1];
         split_acts<KP0 / 2>(xr, a1, a2, a3);
+        // log-prob / value passes: the next slab's inputs are requested as soon as this slab's are split -- the whole body
+        // covers their latency (requested in the loss phase, the top of the next iteration waited ~7k cycles per slab for them:
+        // phase timers, round 4, 26.6 % of the log-prob launch).  Optimiser steps hold too many registers across the GEMMs.
+        if constexpr (EARLY_X0N_LP) atl_load<2 * NXR>(U.x0n, slab + slab_stride < U.n_slabs ? slab + slab_stride : slab, lane, xr);
         f32x16 acc[MT];
 #pragma unroll
         for (int t = 0; t < MT; ++t)
@@ -522,20 +529,10 @@ __global__ __launch_bounds__(UF_THREADS, 2) void k_upd_fwd(UpdFwdArgs U, ARGS A)
 #pragma unroll
     for (int q = 0; q < H / 8; ++q) xs[q] = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
     float z[DAP];
-#ifdef HARL_HEAD_T
-    head_fwd_regs_t<H, DAP, DA>(xs, whlT_h, cst, z);
-#else
-    head_fwd_regs<H, DAP, DA>(xs, whl_h, cst, z);
-#endif
+    head_fwd_regs_t<H, DAP, DA>(xs, whlT_h, cst, z);  // (round 4: 0.353 -> 0.341 ms per MPE actor launch against head_fwd_regs)
     PHASE(5);
-    // this slab's rows (loaded one slab ago) are consumed now; the next slab's are requested where the GEMM operands are dead
-    // (log-prob passes: here; optimiser steps: after the head weight gradient, the register peak of the loop) -- one set of
-    // row registers is live across the two GEMMs instead of two
-    const ActorRow<DAP> rcur = rnext;
-    const float cvold = cvoldn, cret = cretn;
     const long sn = slab + slab_stride < U.n_slabs ? slab + slab_stride : slab;
-    if constexpr (!TRAIN) atl_load<2 * NXR>(U.x0n, sn, lane, xr);  // the next slab's normalised inputs likewise (TRAIN: after the head dW)
-    if constexpr (!TRAIN && !CRITIC) actor_row_load<DAP, DISCRETE, TRAIN, DA>(A, sn, lane, rnext);  // (TRAIN: at the end of the body)
+    if constexpr (!TRAIN && !EARLY_X0N_LP) atl_load<2 * NXR>(U.x0n, sn, lane, xr);
     float dzh[DAP];
     float s1, s2;
     if constexpr (CRITIC) {
@@ -608,9 +605,7 @@ __global__ __launch_bounds__(UF_THREADS, 2) void k_upd_fwd(UpdFwdArgs U, ARGS A)
       PHASE(7);
       if constexpr (!EARLY_X0N) atl_load<2 * NXR>(U.x0n, sn, lane, xr);
       // ---- head backward (W_head'^T dzh on the fp32 MFMA) + LayerNorm / ReLU backward -> dz_2
-      head_bwd_regs_bits<H, DAP, DA, true>(xs, bits2[0], bits2[NW - 1], r2, slab, lane, whl, dzh, s1, s2, U.dz2);
-      if constexpr (!CRITIC) actor_row_load<DAP, DISCRETE, TRAIN, DA>(A, sn, lane, rnext);
-      else critic_row_load(A, sn, lane, cvoldn, cretn);
+      head_bwd_regs_bits<H, DAP, DA, true, true>(xs, bits2[0], bits2[NW - 1], r2, slab, lane, whlT, dzh, s1, s2, U.dz2);
       PHASE(8);
     }
   }
@@ -677,11 +672,8 @@ int upd_grid(long n_slabs) {
 }
 
 size_t fwd_lds_bytes(int H, int kp0, int dap, int hrows, int da) {
-#ifndef HARL_HEAD_T
-  da = 0;
-#endif
   return split_image_bytes(H, H) + split_image_bytes(H, kp0) +
-         ((size_t)2 * H + (size_t)2 * (H / 2) * (dap + da) + 7 * dap + UF_WAVES * PS_STRIDE + (size_t)UF_WAVES * hrows * H) *
+         ((size_t)2 * H + (size_t)2 * head_t_block(H, da) + 7 * dap + UF_WAVES * PS_STRIDE + (size_t)UF_WAVES * hrows * H) *
              sizeof(float);
 }
 

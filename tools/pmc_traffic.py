@@ -29,7 +29,7 @@ GROUPS = [
     (r"void k_bwd_dx<\d+, \d+, [1-9]>", ("bwd_dx_dw1",)),
     (r"void k_dw(_tr<|_tr_multi<|<0)", ("dw_hidden", "dw_gru", "dw_input")),
     (r"void k_dw<1", ("dw_head",)),
-    (r"void k_fwd_wide<", ("fwd_wide", "tangent_wide")),
+    (r"void k_fwd_wide<", ("fwd_wide", "tangent_wide", "tangent_hidden")),  # (the one-launch hidden tangent is a k_fwd_wide)
     (r"(void )?k_x0n_", ("x0n_wide",)),
     (r"void k_actor_head<.*(true|false), true, (true|false)>", ("actor_head_loss",)),
     (r"void k_actor_head<.*(true|false), false, (true|false)>", ("actor_head_logp",)),

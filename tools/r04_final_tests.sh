@@ -1,0 +1,7 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
+O=gpurun_out/r04_final
+mkdir -p $O
+export TMPDIR=/tmp
+(cat .git_sha; timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -15; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | cut -c1-400) > $O/gpu_tests.txt 2>&1
+tail -8 $O/gpu_tests.txt

@@ -14,10 +14,15 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifdef HARL_PHASE_TIMING
 #define HARL_NPHASE 12
 static __device__ long long harl_phase_cyc[8][HARL_NPHASE];
+// per workgroup (wave 0): {shader cycles PHASE_BEGIN..PHASE_END, s_memrealtime (100 MHz) at PHASE_BEGIN, at PHASE_END} -- the
+// spread of the workgroups' loop times, their start skew and the shader clock under load (tools/phase_cycles.py --wg)
+static __device__ long long harl_phase_wg[8][256][3];
 #define PHASE_BEGIN()                                    \
   long long _pt_acc[HARL_NPHASE];                        \
   for (int _k = 0; _k < HARL_NPHASE; ++_k) _pt_acc[_k] = 0; \
-  long long _pt_last = __builtin_readcyclecounter();
+  const long long _pt_rt0 = __builtin_amdgcn_s_memrealtime(); \
+  const long long _pt_c0 = __builtin_readcyclecounter(); \
+  long long _pt_last = _pt_c0;
 #define PHASE(i)                                         \
   do {                                                   \
     __builtin_amdgcn_sched_barrier(0);                   \
@@ -30,10 +35,18 @@ static __device__ long long harl_phase_cyc[8][HARL_NPHASE];
   do {                                                   \
     if (blockIdx.x == 0 && threadIdx.x == 0)             \
       for (int _k = 0; _k < HARL_NPHASE; ++_k) harl_phase_cyc[slot][_k] = _pt_acc[_k]; \
+    if (threadIdx.x == 0 && blockIdx.x < 256) {          \
+      harl_phase_wg[slot][blockIdx.x][0] = __builtin_readcyclecounter() - _pt_c0; \
+      harl_phase_wg[slot][blockIdx.x][1] = _pt_rt0;      \
+      harl_phase_wg[slot][blockIdx.x][2] = __builtin_amdgcn_s_memrealtime(); \
+    }                                                    \
   } while (0)
 #define HARL_PHASE_ACCESSOR(tu)                                                                    \
   extern "C" int harl_phase_read_##tu(long long *out) {                                            \
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(harl_phase_cyc), sizeof(long long) * 8 * HARL_NPHASE); \
+  }                                                                                                \
+  extern "C" int harl_phase_read_wg_##tu(long long *out) {                                         \
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(harl_phase_wg), sizeof(long long) * 8 * 256 * 3); \
   }
 #else
 #define PHASE_BEGIN()

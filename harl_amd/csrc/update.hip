@@ -365,6 +365,7 @@ __global__ __launch_bounds__(UF_THREADS, 2) void k_upd_fwd(UpdFwdArgs U, ARGS A)
   constexpr bool EARLY_X0N_LP = !TRAIN && !HID && (H == 64 || (DA != 4 && !(KP0 == 64 && DA >= 7 && !DISCRETE)));
   static_assert(!HID || TRAIN, "the last-layer variant exists for optimiser steps only");
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  PHASE_BEGIN();
   constexpr int MT = H / 32, NJ1 = KP0 / 16, NJ2 = H / 16, NR = H / 2, NW = (NR + 31) / 32;
   u32x4 *w2img = reinterpret_cast<u32x4 *>(lds);   // reused as the head-gradient combine buffer at the end
   u32x4 *w1img = w2img + 3 * MT * NJ2 * 64;
@@ -375,7 +376,12 @@ __global__ __launch_bounds__(UF_THREADS, 2) void k_upd_fwd(UpdFwdArgs U, ARGS A)
   float *red = cst + 7 * DAP;              // [8][PS_STRIDE]
   float *hacc = red + UF_WAVES * PS_STRIDE;  // [8 waves][HROWS][H] head weight gradient, wave-private
   const int lane = threadIdx.x & 63, wave = wave_id(), i = lane & 31, h = lane >> 5;
-  const long slab0 = (long)blockIdx.x * UF_WAVES + wave, slab_stride = (long)gridDim.x * UF_WAVES;
+  // slab -> (round, wave, workgroup), WAVE-major inside a round: the remainder of n_slabs over the 8 x gridDim.x waves lands on the
+  // low wave indices of EVERY workgroup instead of on all waves of the low workgroups.  819 200 rows are 12.5 slabs per wave:
+  // block-major, workgroups 0..127 ran 13 slabs on all eight waves and 128..255 twelve (per-workgroup loop times 227..269 us,
+  // half the chip idle for the last slab: tools/phase_cycles.py --wg, round 4); now every SIMD holds one wave with 13 and one
+  // with 12 (waves w and w + 4 share a SIMD), and the last slab of a SIMD runs alone, i.e. faster
+  const long slab0 = (long)wave * gridDim.x + blockIdx.x, slab_stride = (long)gridDim.x * UF_WAVES;
   // ---- the first slab's inputs are requested BEFORE the weights are staged (their latency hides behind the staging) and are
   // complete when the loop starts (explicit s_waitcnt below): with loads still in flight at loop entry, the compiler's vmcnt
   // at the top of the loop is the minimum over the entry path and the back edge, and the entry path's "nothing younger than
@@ -458,7 +464,7 @@ __global__ __launch_bounds__(UF_THREADS, 2) void k_upd_fwd(UpdFwdArgs U, ARGS A)
   for (int d = 0; d < (CRITIC ? DAP : 1); ++d) dbacc[d] = 0.f;
 
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) (expcnt / lgkmcnt untouched): see the prologue loads above
-  PHASE_BEGIN();
+  PHASE(10);
   for (long slab = slab0; slab < U.n_slabs; slab += slab_stride) {
     // ---- this slab's per-row loss inputs are requested at the TOP of its iteration (consumed behind the two GEMMs, ~15k cycles
     // later), the gathered row index of the next slab with them.  Rounds 2-3 carried them across the back edge (loaded at the
@@ -609,7 +615,6 @@ __global__ __launch_bounds__(UF_THREADS, 2) void k_upd_fwd(UpdFwdArgs U, ARGS A)
       PHASE(8);
     }
   }
-  PHASE_END((TRAIN ? 0 : 2) + (CRITIC ? 1 : 0));
   if constexpr (TRAIN) {
     float dbv[DAP];
 #pragma unroll
@@ -659,6 +664,8 @@ __global__ __launch_bounds__(UF_THREADS, 2) void k_upd_fwd(UpdFwdArgs U, ARGS A)
       for (int e = threadIdx.x; e < HeadDw<H>::OUT_FLOATS; e += UF_THREADS) zr[e] = 0.f;
     }
   }
+  PHASE(11);
+  PHASE_END((TRAIN ? 0 : 2) + (CRITIC ? 1 : 0));
 }
 
 int fwd_grid(long n_slabs) {

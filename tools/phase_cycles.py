@@ -57,6 +57,34 @@ def show(tus):
                     print(f"   {p:28s} {tab[slot][k]:10d}  {100.0 * tab[slot][k] / tot:5.1f} %")
 
 
+def show_wg(tus):
+    """Per workgroup (wave 0): loop cycles, start skew, end spread, wall time of the slowest, shader clock under load."""
+    lib = _lib.load()
+    for tu in tus:
+        buf = (C.c_longlong * (8 * 256 * 3))()
+        fn = getattr(lib, "harl_phase_read_wg_" + tu)
+        fn.argtypes = [C.c_void_p]
+        fn.restype = C.c_int
+        assert fn(buf) == 0
+        for slot in range(8):
+            if (tu, slot) not in NAMES:
+                continue
+            rows = [(buf[(slot * 256 + g) * 3], buf[(slot * 256 + g) * 3 + 1], buf[(slot * 256 + g) * 3 + 2]) for g in range(256)]
+            rows = [r for r in rows if r[0] > 0]
+            if not rows:
+                continue
+            cyc = sorted(r[0] for r in rows)
+            t0, t1 = min(r[1] for r in rows), max(r[2] for r in rows)
+            dur = sorted((r[2] - r[1]) / 100.0 for r in rows)  # us (s_memrealtime: 100 MHz)
+            clk = sorted(r[0] / ((r[2] - r[1]) * 10.0) for r in rows if r[2] > r[1])  # GHz
+            print(f"## {NAMES[(tu, slot)][0]}: {len(rows)} workgroups (last launch)")
+            print(f"   loop cycles   min {cyc[0]}  median {cyc[len(cyc) // 2]}  max {cyc[-1]}  (max/min {cyc[-1] / cyc[0]:.3f})")
+            print(f"   loop time us  min {dur[0]:.1f}  median {dur[len(dur) // 2]:.1f}  max {dur[-1]:.1f}")
+            print(f"   first loop start -> last loop end {(t1 - t0) / 100.0:.1f} us; start skew {(max(r[1] for r in rows) - t0) / 100.0:.1f} us; "
+                  f"end spread {(t1 - min(r[2] for r in rows)) / 100.0:.1f} us")
+            print(f"   shader clock  min {clk[0]:.2f}  median {clk[len(clk) // 2]:.2f}  max {clk[-1]:.2f} GHz")
+
+
 def main():
     assert os.environ.get("HARL_LIB") == "phase", "run with HARL_LIB=phase"
     dev = torch.device("cuda:0")
@@ -68,6 +96,8 @@ def main():
         torch.cuda.synchronize()
         print(f"# HARL_FUSED_UPDATE={mode}")
         show(("mlp", "wide", "heads") if mode == "logp" else ("update",))
+        if "--wg" in sys.argv:
+            show_wg(("mlp",) if mode == "logp" else ("update", "mlp"))
         del r
 
 

@@ -78,12 +78,10 @@ def test_train_matches_reference_golden(name):
 @pytest.mark.parametrize("i", [0, 1, 2, 4])
 def test_hatrpo_gradient_fvp_and_update(i):
     """HATRPO: surrogate gradient, Fisher-vector product (tangent pass + backward) and one full update (CG + line search)
-    vs the oracle's autograd double backward.  CG amplifies rounding differences: step direction held to 1e-4."""
+    vs the oracle's autograd double backward.  CG amplifies rounding differences: the step direction is held to the symmetric
+    bar of check_trpo_upstream (``cg_step_dir_excess``: distance from the float64 solve <= 4 x the fp32 oracle's own)."""
     G = _G()
-    res = G.check_trpo(G.FWD_SHAPES[i])
-    cg = res.pop("cg_step_dir_vec_rel")
-    assert cg < 1e-4, cg
-    _assert_all(res, tol=TOL)
+    _assert_all(G.check_trpo(G.FWD_SHAPES[i]), tol=TOL)
 
 
 @pytest.mark.parametrize("i", [0, 1, 2])
@@ -91,12 +89,10 @@ def test_hatrpo_gru_gradient_fvp_and_update(i):
     """HATRPO with GRU policies: the Fisher-vector product through the recurrence (forward-mode tangent kernel + BPTT)
     against the oracle's double backward, padded (m = 40), identity (m = 64) and ragged (m = 7, mixed widths) layouts."""
     G = _G()
-    res = G.check_trpo_rnn(G.RNN_SHAPES[i])
-    cg = res.pop("cg_step_dir_vec_rel")
-    assert cg < 2e-4, cg
     # everything update() reports after the CG solve (*_excess) is held to max(1e-5, 2 x the oracle's own measured
-    # uncertainty) -- gpu_checks._trpo_update_excess; gradient, FVP and surrogate loss to the flat tolerance
-    _assert_all(res, tol=2e-5)
+    # uncertainty), the CG direction to 4 x the oracle's own distance from the float64 solve -- gpu_checks._trpo_update_excess;
+    # gradient, FVP and surrogate loss: check_trpo_rnn's own *_excess (distance from float64 against the fp32 oracle's)
+    _assert_all(G.check_trpo_rnn(G.RNN_SHAPES[i]), tol=TOL)
 
 
 @pytest.mark.parametrize("name", ["trpo_box_h64", "trpo_disc_h64", "trpo_wide_h128x3", "trpo_rnn_disc_h64", "trpo_rnn_box_h64",
@@ -121,9 +117,10 @@ def test_rollout_get_actions(i):
 @pytest.mark.parametrize("i", range(4))
 def test_gru_policy_forward_and_update(i):
     """GRU policies (rnn.py): L-step unroll with mask resets, BPTT, shared-LayerNorm unfold -- one actor and one critic
-    update vs the oracle; padded (m % 32 != 0) and identity sequence layouts, single-step rollout calls."""
+    update vs the oracle; padded (m % 32 != 0) and identity sequence layouts, single-step rollout calls.  Every figure is held
+    to max(1e-5, 2 x the fp32 oracle's own distance from the same update in float64) (``*_excess``)."""
     G = _G()
-    _assert_all(G.check_rnn_update(G.RNN_SHAPES[i]), tol=2e-5)
+    _assert_all(G.check_rnn_update(G.RNN_SHAPES[i]), tol=TOL)
 
 
 @pytest.mark.parametrize("name", ["rnn_box_h64", "rnn_disc_h64_mb2", "rnn_naive_h64", "rnn_fp_box_h64_mb2",

@@ -28,6 +28,8 @@ _vp, _i, _l, _f, _d = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_double
 SIGNATURES = {
     "harl_gae_returns": [_vp] * 8 + [_i, _i, _f, _f, _i, _i, _i, _vp],
     "harl_masked_moments": [_vp, _vp, _l, _vp, _vp],
+    "harl_dist_rows": [_vp, _l, _i, _i, _vp, _f, _f, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+    "harl_moments_mean": [_vp, _vp, _vp],
     "harl_adv_normalize": [_vp, _vp, _vp, _l, _vp],
     "harl_factor_update": [_vp, _vp, _vp, _l, _i, _i, _vp],
     "harl_sum_sumsq": [_vp, _vp, _l, _vp, _vp],

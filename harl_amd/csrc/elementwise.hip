@@ -291,6 +291,99 @@ extern "C" int harl_adv_normalize(const float *adv, const double *moments3, floa
 }
 
 // =============================================================================================
+// Rollout-side row arithmetic on the head outputs (models/base/act.py:45-157, distributions.py:31-103): what
+// StochasticPolicy.forward / evaluate_actions do with the distribution once the head has produced its parameters.  The random
+// draws themselves stay with torch's device generator (the reference's Normal.sample() / Categorical.sample() use it), this
+// kernel does everything around them.  One thread per row.
+//   kind 0  DiagGaussian: head = mean [M, D]; sigma_d = sigmoid(log_std_d / x_coef) * y_coef
+//           actions = mean + sigma * noise (noise == NULL: the mode), logp_d = log N(a_d; mean_d, sigma_d),
+//           ent_rows = sum_d (0.5 + 0.5 log 2 pi + log sigma_d), sigma_out [D]
+//   kind 1  Categorical, n_heads heads whose normalised logits lie side by side in head [M, D] (head_off: n_heads + 1
+//           offsets, NULL = one head): probs = exp(head) (the multinomial's input), argmax_out [M, n_heads] = first largest
+//           logit per head, logp [M, n_heads] (or [M, 1] with sum_heads) = logit of `actions` (float indices [M, n_heads];
+//           NULL: of the argmax), ent_rows = - sum_j clamp(logit_j) p_j over all heads (act.py:117-141 adds the heads' entropies)
+// =============================================================================================
+__global__ __launch_bounds__(256) void k_dist_rows(const float *__restrict__ head, long M, int D, int kind,
+                                                   const float *__restrict__ log_std, float std_x_coef, float std_y_coef,
+                                                   const float *__restrict__ noise, float *__restrict__ actions,
+                                                   const int *__restrict__ head_off, int n_heads, int sum_heads,
+                                                   float *__restrict__ logp, float *__restrict__ probs,
+                                                   float *__restrict__ argmax_out, float *__restrict__ ent_rows,
+                                                   float *__restrict__ sigma_out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (kind == 0) {
+    if (sigma_out && i < D) sigma_out[i] = (1.0f / (1.0f + expf(-log_std[i] / std_x_coef))) * std_y_coef;  // as the loss kernels
+    if (i >= M) return;
+    float ent = 0.f;
+    for (int d = 0; d < D; ++d) {
+      const float sig = (1.0f / (1.0f + expf(-log_std[d] / std_x_coef))) * std_y_coef;
+      const float lsig = logf(sig);
+      const float mu = head[i * D + d];
+      const float a = noise ? mu + sig * noise[i * D + d] : mu;
+      if (actions) actions[i * D + d] = a;
+      if (logp) {
+        const float diff = a - mu;
+        logp[i * D + d] = -(diff * diff) / (2.0f * sig * sig) - lsig - 0.9189385332046727f;  // torch Normal.log_prob
+      }
+      ent += 0.5f + 0.9189385332046727f + lsig;
+    }
+    if (ent_rows) ent_rows[i] = ent;
+    return;
+  }
+  if (i >= M) return;
+  float ent = 0.f, lsum = 0.f;
+  for (int hd = 0; hd < n_heads; ++hd) {
+    const int lo = head_off ? head_off[hd] : 0, hi = head_off ? head_off[hd + 1] : D;
+    int best = lo;
+    float bv = head[i * D + lo];
+    for (int j = lo; j < hi; ++j) {
+      const float lg = head[i * D + j];
+      const float p = expf(lg);
+      if (probs) probs[i * D + j] = p;
+      ent -= fmaxf(lg, -3.4028234663852886e38f) * p;
+      if (lg > bv) {
+        bv = lg;
+        best = j;
+      }
+    }
+    if (argmax_out) argmax_out[i * n_heads + hd] = (float)(best - lo);
+    if (logp) {
+      const int a = actions ? (int)actions[i * n_heads + hd] : best - lo;
+      const float lp = head[i * D + lo + a];
+      if (sum_heads) lsum += lp;
+      else logp[i * n_heads + hd] = lp;
+    }
+  }
+  if (logp && sum_heads) logp[i] = lsum;
+  if (ent_rows) ent_rows[i] = ent;
+}
+
+extern "C" int harl_dist_rows(const float *head, long M, int act_dim, int kind, const float *log_std, float std_x_coef,
+                              float std_y_coef, const float *noise, float *actions, const int *head_off, int n_heads,
+                              int sum_heads, float *logp, float *probs, float *argmax_out, float *ent_rows, float *sigma_out,
+                              void *stream) {
+  if (M <= 0) return 0;
+  if (act_dim < 1 || (kind != 0 && kind != 1) || (kind == 0 && !log_std) || (kind == 1 && n_heads < 1)) {
+    set_error("harl_dist_rows: bad arguments");
+    return -1;
+  }
+  const long rows = M > act_dim ? M : act_dim;
+  hipLaunchKernelGGL(k_dist_rows, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, head, M, act_dim, kind,
+                     log_std, std_x_coef, std_y_coef, noise, actions, head_off, n_heads, sum_heads, logp, probs, argmax_out,
+                     ent_rows, sigma_out);
+  return check_launch("harl_dist_rows");
+}
+
+// mean over the counted entries of a harl_masked_moments triple {sum x, sum x^2, count}: the (active-mask-weighted) mean of
+// the entropy rows (act.py:104-157), as one fp32 scalar on the device
+__global__ void k_moments_mean(const double *__restrict__ mom, float *__restrict__ out) { out[0] = (float)(mom[0] / mom[2]); }
+
+extern "C" int harl_moments_mean(const double *moments3, float *mean_out, void *stream) {
+  hipLaunchKernelGGL(k_moments_mean, dim3(1), dim3(1), 0, (hipStream_t)stream, moments3, mean_out);
+  return check_launch("harl_moments_mean");
+}
+
+// =============================================================================================
 // factor *= agg_d exp(new - old)
 // =============================================================================================
 __global__ __launch_bounds__(256) void k_factor_update(float *__restrict__ factor, const float *__restrict__ nl,

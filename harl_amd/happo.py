@@ -110,6 +110,20 @@ class OnPolicyBase:
                     dst.copy_(seq_compact(src, seq))
         return None if not h_last else seq["h_last"][:m]
 
+    def _dist_rows(self, head, M, *, noise=None, actions=None, logp=None, probs=None, argmax_out=None, ent_rows=None,
+                   sigma_out=None):
+        """harl_dist_rows on this policy's head outputs (Gaussian mean / normalised logits of one or several heads)."""
+        net = self.actor
+        if net.md and getattr(self, "_head_off", None) is None:
+            off = [0]
+            for n in net.nvec:
+                off.append(off[-1] + int(n))
+            self._head_off = torch.tensor(off, dtype=torch.int32, device=self.device)
+        call("harl_dist_rows", ptr(head), M, net.act_dim, int(net.discrete), None if net.discrete else ptr(net.log_std()),
+             net.std_x_coef, net.std_y_coef, ptr(noise), ptr(actions), ptr(self._head_off) if net.md else None,
+             len(net.nvec) if net.md else 1, 1, ptr(logp), ptr(probs), ptr(argmax_out), ptr(ent_rows), ptr(sigma_out), stream(),
+             tag="dist_rows")
+
     def evaluate_actions(self, obs, rnn_states_actor, action, masks, available_actions=None, active_masks=None):
         """(action_log_probs [B, act_w], dist_entropy 0-d, action_distribution) as the reference returns them
         (stochastic_policy.py:88-127, act.py:104-157): the entropy is the active-mask-weighted mean over rows when
@@ -126,22 +140,22 @@ class OnPolicyBase:
         head = torch.empty(M, net.act_dim, **self.tpdv)
         net.fold()
         self._logp_pass(obs, action, avail, M, out, head_out=head, rnn_states=rnn_states_actor, masks=masks)
-        if net.md:  # act.py:117-141: no distribution object; entropy = (1/m) sum_rows sum_heads H (never mask-weighted)
-            ent_rows = -(torch.clamp(head, min=torch.finfo(torch.float32).min) * torch.exp(head)).sum(-1, keepdim=True)
-            return out, ent_rows.mean(), None
-        if net.discrete:  # head = normalised logits (masked entries ~ -1e10): Categorical(logits=...).entropy()
-            dist = torch.distributions.Categorical(logits=head)
-            p = torch.exp(head)
-            ent_rows = -(torch.clamp(head, min=torch.finfo(torch.float32).min) * p).sum(-1, keepdim=True)
-        else:
-            sigma = (torch.sigmoid(net.log_std() / net.std_x_coef) * net.std_y_coef).expand_as(head)
-            dist = torch.distributions.Normal(head, sigma)
-            ent_rows = (0.5 + 0.9189385332046727 + torch.log(sigma)).sum(-1, keepdim=True)
-        if active_masks is not None and self.use_policy_active_masks:
-            am = _as_dev(active_masks, self.device).reshape(M, 1)
-            entropy = (ent_rows * am).sum() / am.sum()
-        else:
-            entropy = ent_rows.mean()
+        # entropy rows, their (active-mask-weighted) mean and sigma behind the C ABI (harl_dist_rows / harl_masked_moments /
+        # harl_moments_mean); the distribution OBJECT the reference returns is built from the kernel outputs
+        ent_rows = torch.empty(M, **self.tpdv)
+        sigma = None if net.discrete else torch.empty(net.act_dim, **self.tpdv)
+        self._dist_rows(head, M, ent_rows=ent_rows, sigma_out=sigma)
+        am = None
+        if not net.md and active_masks is not None and self.use_policy_active_masks:  # (act.py:117-141: never for MultiDiscrete)
+            am = _as_dev(active_masks, self.device).reshape(M).contiguous()
+        mom = torch.zeros(3, dtype=torch.float64, device=self.device)
+        entropy = torch.empty((), **self.tpdv)
+        call("harl_masked_moments", ptr(ent_rows), ptr(am), M, ptr(mom), stream())
+        call("harl_moments_mean", ptr(mom), ptr(entropy), stream())
+        if net.md:
+            return out, entropy, None
+        dist = (torch.distributions.Categorical(logits=head) if net.discrete
+                else torch.distributions.Normal(head, sigma.expand_as(head)))
         return out, entropy, dist
 
     @torch.no_grad()
@@ -163,25 +177,29 @@ class OnPolicyBase:
                             h_last=True)  # head_out only: no actions needed
         if net.recurrent:
             rnn_out = h.reshape(M, net.recurrent_n, -1).clone()
-        if net.md:  # act.py:56-73: one draw per head, log-probs summed to [B, 1]
-            acts, lps, lo = [], [], 0
-            for n in net.nvec:
-                hl = head[:, lo:lo + n]
-                a = hl.argmax(dim=-1, keepdim=True) if deterministic else torch.multinomial(torch.exp(hl), 1)
-                acts.append(a.to(torch.float32))
-                lps.append(hl.gather(-1, a))
-                lo += n
-            return torch.cat(acts, -1), torch.cat(lps, -1).sum(-1, keepdim=True), rnn_out
-        if net.discrete:  # head = normalised logits (masked entries ~ -1e10)
+        # everything around the draw runs in harl_dist_rows; the draw itself is torch's device generator
+        if net.discrete:  # head = normalised logits (masked entries ~ -1e10); MultiDiscrete: one draw per head, log-probs summed
+            nh = len(net.nvec) if net.md else 1
+            actions = torch.empty(M, nh, **self.tpdv)
+            logp = torch.empty(M, 1, **self.tpdv)
             if deterministic:
-                actions = head.argmax(dim=-1, keepdim=True).to(torch.float32)
+                self._dist_rows(head, M, argmax_out=actions, logp=logp)  # (actions NULL: the log-prob of the argmax)
             else:
-                actions = torch.multinomial(torch.exp(head), 1).to(torch.float32)
-            logp = head.gather(-1, actions.long())
-        else:  # log N(a; mean, sigma) by the same formula the loss kernel uses (elementwise, plumbing-sized)
-            sigma = torch.sigmoid(net.log_std() / net.std_x_coef) * net.std_y_coef
-            actions = head if deterministic else head + sigma * torch.randn_like(head)
-            logp = -((actions - head) ** 2) / (2 * sigma * sigma) - torch.log(sigma) - 0.9189385332046727
+                probs = torch.empty_like(head)
+                self._dist_rows(head, M, probs=probs)
+                if net.md:
+                    lo = 0
+                    for k, n in enumerate(net.nvec):  # act.py:56-73, one Categorical.sample() per head, in order
+                        actions[:, k:k + 1] = torch.multinomial(probs[:, lo:lo + n], 1)
+                        lo += n
+                else:
+                    actions.copy_(torch.multinomial(probs, 1))
+                self._dist_rows(head, M, actions=actions, logp=logp)
+        else:
+            noise = None if deterministic else torch.randn_like(head)
+            actions = torch.empty_like(head)
+            logp = torch.empty_like(head)
+            self._dist_rows(head, M, noise=noise, actions=actions, logp=logp)
         return actions, logp, rnn_out
 
     @torch.no_grad()

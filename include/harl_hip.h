@@ -56,6 +56,23 @@ int harl_gae_returns(const float *rewards, float *value_preds, const float *mask
  * Replaces the NaN trick + np.nanmean/np.nanstd of HAPPO.train (algorithms/actors/happo.py:122-127).
  * out3 (double[3]) is ACCUMULATED into (zero it first); all-reduce it across ranks when sharded. */
 int harl_masked_moments(const float *x, const float *active, long n, double *out3, void *stream);
+
+/* Rollout-side row arithmetic on the head outputs: everything StochasticPolicy.forward / evaluate_actions do around the random
+ * draw (harl/models/base/act.py:45-157, distributions.py:31-103; the draw itself is torch's device generator, as in the
+ * reference).  One thread per row; every output pointer may be NULL.
+ *   kind 0 (DiagGaussian, head = mean [M, act_dim]): actions = mean + sigma * noise (noise NULL: the mode), logp [M, act_dim]
+ *          = log N(a; mean, sigma), ent_rows [M] = sum_d (0.5 + 0.5 log 2pi + log sigma_d), sigma_out [act_dim]
+ *          (sigma = sigmoid(log_std / std_x_coef) * std_y_coef)
+ *   kind 1 (Categorical; n_heads heads side by side in head [M, act_dim], head_off = n_heads + 1 offsets or NULL for one head;
+ *          head = normalised, availability-masked logits): probs = exp(head), argmax_out [M, n_heads] = first largest logit per
+ *          head, logp [M, n_heads] (sum_heads: [M, 1], act.py:56-73) = logit of `actions` [M, n_heads] (float indices; NULL: of
+ *          the argmax), ent_rows = -sum clamp(logit) p over all heads */
+int harl_dist_rows(const float *head, long M, int act_dim, int kind, const float *log_std, float std_x_coef, float std_y_coef,
+                   const float *noise, float *actions, const int *head_off, int n_heads, int sum_heads, float *logp,
+                   float *probs, float *argmax_out, float *ent_rows, float *sigma_out, void *stream);
+/* mean_out[0] = (float)(moments3[0] / moments3[2]) of a harl_masked_moments triple: the (active-mask-weighted) mean of the
+ * entropy rows that evaluate_actions returns (act.py:104-157) */
+int harl_moments_mean(const double *moments3, float *mean_out, void *stream);
 /* adv_out = (adv - mean) / (std + 1e-5) with mean/std from `moments3` (happo.py:127). */
 int harl_adv_normalize(const float *adv, const double *moments3, float *adv_out, long n, void *stream);
 

@@ -354,8 +354,10 @@ def measure(w: dict, cfg_name: str, args, comm, rank: int, world: int, device, n
                         hbm_frac=ach / HBM_PEAK, matrix_pipe_frac=pipe,
                         bound_note="streaming GEMM kernels between two roofs: `frac` = algorithmic bytes / time against the 8 TB/s "
                                    "HBM peak (the contract's figure); `matrix_pipe_frac` = the launch's bf16 MFMAs x 32.3 cycles "
-                                   "against the time all 1024 SIMDs have at 2.4 GHz.  Neither is saturated: VALU work of the "
-                                   "exact bf16 split / LayerNorm / ReLU sits in separate phases of the same waves (DESIGN.md 3)",
+                                   "against the time all 1024 SIMDs have at the nominal 2.4 GHz (under this load the shader "
+                                   "clock measures 1.85-1.95 GHz, profiles/r04_phase_cycles_per_workgroup.txt: of the cycles "
+                                   "it actually gets the pipe is busy ~1.26x this fraction).  Neither is saturated: VALU work of "
+                                   "the exact bf16 split / LayerNorm / ReLU sits in separate phases of the same waves (DESIGN.md 3)",
                         traffic=traffic, traffic_note=traffic_note, launches=cand[dom]["n"], avg_ms=cand[dom]["avg_ms"],
                         bytes_per_launch=per_launch,
                         timing="HIP events around every launch of the streaming kernel families inside the timed region; bytes "
@@ -459,6 +461,7 @@ def main():
                     help="stored log-probs: SURVEY 8d recipe (default) or on-policy (ratios ~ 1)")
     ap.add_argument("--dist-single", action="store_true", help="initialise the nccl (RCCL) group even with one rank")
     ap.add_argument("--cpu-cols", type=int, default=-1, help="rollout threads of the bounded CPU-baseline sample (0 = skip, -1 = auto)")
+    ap.add_argument("--cpu-reps", type=int, default=3, help="timed CPU-baseline updates after the warm-up one (best of)")
     ap.add_argument("--cpu-threads", type=int, default=16,
                     help="torch CPU threads for the baseline (these nets are small: more threads than ~16 is slower)")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -539,7 +542,7 @@ def main():
         if cols < 0:  # ~10-30 s of CPU work per update for every configuration
             cols = {"mpe": 512, "cheetah6": 512, "smac3s5z": 128, "humanoid17": 16}[args.config]
         if world == 1 and cols > 0:
-            out["cpu_baseline"] = cpu_baseline(w, cols, min(args.cpu_threads, os.cpu_count() or 1))
+            out["cpu_baseline"] = cpu_baseline(w, cols, min(args.cpu_threads, os.cpu_count() or 1), reps=max(1, args.cpu_reps))
     # the other BASELINE.json workloads at their real shapes, on the SAME JSON line (after the headline region and the CPU
     # baseline, fresh runner each, a few steps): `--config <name>` gives the full record of any one of them
     if args.other_configs and args.config == "mpe" and args.scaling == "weak" and not args.threads_per_gpu:

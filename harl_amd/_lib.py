@@ -43,6 +43,7 @@ SIGNATURES = {
     "harl_mlp_linear_wide": [_vp, _l, _i, _vp, _i, _vp, _i, _vp, _vp, _vp],
     "harl_act_ln_fwd": [_vp, _l, _i, _i, _vp, _vp, _vp, _vp],
     "harl_act_bwd": [_vp, _vp, _vp, _vp, _l, _i, _i, _vp],
+    "harl_act_ln_tangent": [_vp, _vp, _vp, _vp, _vp, _l, _i, _i, _vp, _vp],
     "harl_mlp_tangent_wide": [_vp, _l, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "harl_mlp_fwd_fused2x": [_vp, _l, _vp, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "harl_mlp_fwd_fused2": [_vp, _l, _vp, _l, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,

@@ -683,6 +683,62 @@ __global__ __launch_bounds__(WG_THREADS) void k_act_bwd(float *__restrict__ dz, 
   }
 }
 
+// forward-mode tangent of [act, LayerNorm] (HATRPO's Fisher-vector product on networks with these activations):
+//   a_dot = act'(z) (zd1 + zd2),   x_hat_dot = rstd (a_dot - mean_f(a_dot) - x_hat mean_f(x_hat a_dot))
+// zd1 / zd2: the two halves of the pre-activation's tangent (W' x_hat_dot_prev and W'_dot x_hat_prev + b'_dot: two raw GEMMs;
+// zd2 may be NULL), act' from the activation value like harl_act_bwd.
+template <int H>
+__global__ __launch_bounds__(WG_THREADS) void k_act_ln_tangent(const float *__restrict__ zd1, const float *__restrict__ zd2,
+                                                               const float *__restrict__ xhat, const float *__restrict__ mean_in,
+                                                               const float *__restrict__ rstd_in, long n_slabs, int act,
+                                                               float *__restrict__ out) {
+#pragma clang fp contract(off)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (long slab = (long)blockIdx.x * WAVES_PER_WG + wave; slab < n_slabs; slab += (long)gridDim.x * WAVES_PER_WG) {
+    float d[H / 2], x[H / 2];
+    atl_load<H>(zd1, slab, lane, d);
+    if (zd2) {
+      float e[H / 2];
+      atl_load<H>(zd2, slab, lane, e);
+#pragma unroll
+      for (int R = 0; R < H / 2; ++R) d[R] += e[R];
+    }
+    atl_load<H>(xhat, slab, lane, x);
+    const float mean = mean_in[slab * SLAB + (lane & 31)], rstd = rstd_in[slab * SLAB + (lane & 31)];
+    const float sd = 1.0f / rstd;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int R = 0; R < H / 2; ++R) {
+      d[R] *= act_slope_from_value(x[R] * sd + mean, act);
+      s1 += d[R];
+      s2 += d[R] * x[R];
+    }
+    s1 = wave_sum32(s1) * (1.0f / H);
+    s2 = wave_sum32(s2) * (1.0f / H);
+#pragma unroll
+    for (int R = 0; R < H / 2; ++R) d[R] = rstd * (d[R] - s1 - x[R] * s2);
+    atl_store<H>(out, slab, lane, d);
+  }
+}
+
+extern "C" int harl_act_ln_tangent(const float *zd1, const float *zd2, const float *xhat, const float *mean, const float *rstd,
+                                   long M, int H, int act, float *xhat_dot, void *stream) {
+  if (M <= 0) return 0;
+  if (act < 1 || act > 4) {
+    set_error("harl_act_ln_tangent: activation id must be 1 (leaky_relu), 2 (tanh), 3 (sigmoid) or 4 (selu)");
+    return -2;
+  }
+  const long n_slabs = n_slabs_of(M);
+  const int grid = persistent_grid(n_slabs, 8);
+  if (H == 128) hipLaunchKernelGGL(k_act_ln_tangent<128>, dim3(grid), dim3(WG_THREADS), 0, (hipStream_t)stream, zd1, zd2, xhat, mean, rstd, n_slabs, act, xhat_dot);
+  else if (H == 64) hipLaunchKernelGGL(k_act_ln_tangent<64>, dim3(grid), dim3(WG_THREADS), 0, (hipStream_t)stream, zd1, zd2, xhat, mean, rstd, n_slabs, act, xhat_dot);
+  else {
+    set_error("harl_act_ln_tangent: width must be 64 or 128");
+    return -2;
+  }
+  return check_launch("harl_act_ln_tangent");
+}
+
 extern "C" int harl_act_ln_fwd(const float *z, long M, int H, int act, float *xhat, float *mean, float *rstd, void *stream) {
   if (M <= 0) return 0;
   if (act < 1 || act > 4) {

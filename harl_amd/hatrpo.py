@@ -31,8 +31,6 @@ class HATRPO(OnPolicyBase):
         if getattr(self.actor, "gru_wide", False):
             raise NotImplementedError("HATRPO with a 128-wide GRU or stacked GRU layers: the recurrent tangent kernels are "
                                       "64 wide, one layer")
-        if self.actor.act_id:
-            raise NotImplementedError("HATRPO with an activation other than relu: the forward-mode tangent kernels are ReLU only")
         if self.actor.panel:
             raise NotImplementedError("HATRPO with hidden width 256: the forward-mode tangent kernels are 64/128 wide "
                                       "(no tuned HARL config needs it)")
@@ -107,7 +105,29 @@ class HATRPO(OnPolicyBase):
                      ptr(vec[beo:]) if beo >= 0 else None, ptr(pd[pw:]), ptr(pd[pb:]), o, k, s)
         packs_d = [(pd[pw:pw + o * k], pd[pb:pb + o]) for (pw, pb, o, k) in net._pack_slots]
         Wpd, bpd = packs_d[0]
-        if net.wide:  # x0n of the same rows is still there from the forward pass of _surrogate()
+        if net.act_id:
+            # activation other than ReLU (round 4): the tangent of [Linear, act, LayerNorm] composed like the forward pass -- raw
+            # GEMMs for the two halves of the pre-activation's tangent, one element-wise launch for act' and the LayerNorm
+            # tangent (harl_act_ln_tangent).  x0n, x_hat_l, mean(a_l), rstd_l of the same rows are still in the workspace
+            # from the forward pass of _surrogate().
+            if ws.get("zd") is None or ws["zd"][0].numel() < ws["xd"][0].numel() // hs[0] * max(hs):
+                rows = ws["xd"][0].numel() // hs[0]
+                ws["zd"] = [torch.empty(rows * max(hs), **self.tpdv) for _ in range(2)]
+                ws["zero_bias"] = torch.zeros(max(hs), **self.tpdv)
+            zd1, zd2 = ws["zd"]
+            call("harl_mlp_linear_wide", ptr(net.x0n), m, net.kp0, ptr(Wpd), net.in_dim, ptr(bpd), hs[0], ptr(net.w1img),
+                 ptr(zd1), s, tag="linear_wide")  # the inputs carry no tangent: z_dot = W'_dot x0n + b'_dot
+            call("harl_act_ln_tangent", ptr(zd1), None, ptr(net.xh[0]), ptr(net.amean[0]), ptr(net.rstd[0]), m, hs[0],
+                 net.act_id, ptr(ws["xd"][0]), s, tag="act_ln_tangent")
+            for l in range(1, L):
+                Wp, _ = net._packs[l]
+                Wpd, bpd = packs_d[l]
+                call("harl_mlp_linear", ptr(ws["xd"][l - 1]), m, hs[l - 1], hs[l], ptr(Wp), ptr(ws["zero_bias"]), ptr(zd1), s,
+                     tag="linear")
+                call("harl_mlp_linear", ptr(net.xh[l - 1]), m, hs[l - 1], hs[l], ptr(Wpd), ptr(bpd), ptr(zd2), s, tag="linear")
+                call("harl_act_ln_tangent", ptr(zd1), ptr(zd2), ptr(net.xh[l]), ptr(net.amean[l]), ptr(net.rstd[l]), m, hs[l],
+                     net.act_id, ptr(ws["xd"][l]), s, tag="act_ln_tangent")
+        elif net.wide:  # x0n of the same rows is still there from the forward pass of _surrogate()
             call("harl_mlp_tangent_wide", ptr(net.x0n), m, net.kp0, ptr(Wpd), net.in_dim, ptr(bpd), hs[0], ptr(net.w1img),
                  ptr(net.xh[0]), ptr(net.rmask[0]), ptr(net.rstd[0]), ptr(ws["xd"][0]), s, tag="tangent_wide")
         else:
@@ -115,7 +135,7 @@ class HATRPO(OnPolicyBase):
                  int(net.use_feature_normalization), hs[0], ptr(net.xh[0]), ptr(net.rmask[0]), ptr(net.rstd[0]),
                  ptr(ws["xd"][0]), s)
         one_launch = os.environ.get("HARL_TANGENT_ONE_LAUNCH", "1") != "0"
-        for l in range(1, L):
+        for l in range(1, L if not net.act_id else 1):
             Wp, _ = net._packs[l]
             Wpd, bpd = packs_d[l]
             if one_launch:  # [W' | W'_dot] [x_dot ; x_hat] as ONE K = 2 H GEMM, weight images streamed from L2 (csrc/wide.hip)

@@ -316,6 +316,13 @@ int harl_mlp_linear_wide(const float *x0n, long M, int KP, const float *Wp, int 
  * the LayerNorm backward as harl_mlp_bwd_dx / the loss kernels leave it when they are given an all-ones ReLU mask. */
 int harl_act_ln_fwd(const float *z, long M, int H, int act, float *xhat, float *mean, float *rstd, void *stream);
 int harl_act_bwd(float *dz, const float *xhat, const float *mean, const float *rstd, long M, int H, int act, void *stream);
+/* Forward-mode tangent of [activation, LayerNorm] for HATRPO's Fisher-vector product (harl/utils/trpo_util.py:132-158 on
+ * networks built with activation_func != relu, mlp.py:25-38):  a_dot = act'(z) (zd1 + zd2),
+ * x_hat_dot = rstd (a_dot - mean_f(a_dot) - x_hat mean_f(x_hat a_dot)).  zd1, zd2 (zd2 may be NULL): ATL images of the two
+ * halves of the pre-activation's tangent (raw GEMMs: harl_mlp_linear / harl_mlp_linear_wide); xhat / mean / rstd as
+ * harl_act_ln_fwd left them; act' is taken from the activation value like harl_act_bwd. */
+int harl_act_ln_tangent(const float *zd1, const float *zd2, const float *xhat, const float *mean, const float *rstd, long M,
+                        int H, int act, float *xhat_dot, void *stream);
 /* the same for wide inputs, from the x0n image of harl_mlp_x0n_wide (w_img: scratch as in harl_mlp_fwd_wide) */
 int harl_mlp_tangent_wide(const float *x0n, long M, int KP, const float *Wdp, int D, const float *bdp, int H, void *w_img,
                           const float *x1, const uint32_t *mask1, const float *rstd1, float *x1dot, void *stream);

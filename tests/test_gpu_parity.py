@@ -84,6 +84,16 @@ def test_hatrpo_gradient_fvp_and_update(i):
     _assert_all(G.check_trpo(G.FWD_SHAPES[i]), tol=TOL)
 
 
+@pytest.mark.parametrize("act", ["tanh", "selu", "leaky_relu", "sigmoid"])
+def test_hatrpo_activation_gradient_fvp_and_update(act):
+    """HATRPO on networks built with an activation other than relu (round 4): the Fisher-vector product's tangent pass composed
+    from raw GEMMs + harl_act_ln_tangent, against the oracle's autograd double backward; one full update (CG + line search)."""
+    G = _G()
+    spec = dict(G.FWD_SHAPES[0])
+    spec["over"] = dict(spec.get("over", {}), activation_func=act)
+    _assert_all(G.check_trpo(spec), tol=TOL)
+
+
 @pytest.mark.parametrize("i", [0, 1, 2])
 def test_hatrpo_gru_gradient_fvp_and_update(i):
     """HATRPO with GRU policies: the Fisher-vector product through the recurrence (forward-mode tangent kernel + BPTT)

@@ -155,6 +155,13 @@ CASES = {
                                                     hidden_sizes=[64, 64]), seed=6, overrides={}),
     "trpo_disc_h64": dict(algo="hatrpo", shapes=dict(T=10, N=8, A=2, obs_dim=11, share_obs_dim=9, act_dim=4, discrete=True,
                                                      hidden_sizes=[64, 64]), seed=8, overrides={}, unavailable_p=0.2),
+    # HATRPO on networks built with an activation other than relu (round 4: the tangent pass of the Fisher-vector product
+    # composed from raw GEMMs + harl_act_ln_tangent)
+    "trpo_box_h128_tanh": dict(algo="hatrpo", shapes=dict(T=10, N=8, A=2, obs_dim=18, share_obs_dim=14, act_dim=4, discrete=False,
+                                                          hidden_sizes=[128, 128]), seed=61, overrides=dict(activation_func="tanh")),
+    "trpo_disc_h64_selu": dict(algo="hatrpo", shapes=dict(T=10, N=8, A=2, obs_dim=40, share_obs_dim=9, act_dim=6, discrete=True,
+                                                          hidden_sizes=[64, 64]), seed=62, overrides=dict(activation_func="selu"),
+                               unavailable_p=0.2),
     # ---- MAPPO (harl/algorithms/actors/mappo.py, runners/on_policy_ma_runner.py): no factor; parameter sharing
     "mappo_box_h64": dict(algo="mappo", shapes=dict(T=10, N=8, A=3, obs_dim=12, share_obs_dim=20, act_dim=2, discrete=False,
                                                     hidden_sizes=[64, 64]), seed=21, overrides=dict(share_param=False), inactive_p=0.2),

@@ -106,7 +106,7 @@ def test_hatrpo_gru_gradient_fvp_and_update(i):
 
 
 @pytest.mark.parametrize("name", ["trpo_box_h64", "trpo_disc_h64", "trpo_wide_h128x3", "trpo_rnn_disc_h64", "trpo_rnn_box_h64",
-                                  "trpo_rnn_fp_disc36_h64"])
+                                  "trpo_rnn_fp_disc36_h64", "trpo_box_h128_tanh", "trpo_disc_h64_selu"])
 def test_hatrpo_train_matches_reference_golden(name):
     _assert_all(_G().check_train_golden(name), tol=TOL)
 

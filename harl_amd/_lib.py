@@ -98,6 +98,7 @@ SIGNATURES = {
     "harl_gru_cell_fwd": [_vp] * 8 + [_i, _l] + [_vp] * 7 + [_vp],
     "harl_gru_cell_bwd": [_vp] * 10 + [_i, _l] + [_vp] * 5 + [_vp],
     "harl_rownorm": [_vp, _l, _i, _vp, _vp, _vp],
+    "harl_gru_cell_tangent": [_vp] * 19 + [_i, _l] + [_vp] * 3,
     "harl_md_head_logp": [_vp, _i, _vp, _i, _vp, _vp, _l, _vp, _vp, _vp, _i, _vp, _i, _vp, _l, _l, _vp],
     "harl_md_head_loss": [_vp, _vp, _i, _vp, _i, _vp, _vp, _l, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _d, _f, _i, _i,
                           _l, _l, _vp, _vp, _i, _vp],

@@ -704,12 +704,12 @@ __global__ __launch_bounds__(WG_THREADS) void k_act_ln_tangent(const float *__re
       for (int R = 0; R < H / 2; ++R) d[R] += e[R];
     }
     atl_load<H>(xhat, slab, lane, x);
-    const float mean = mean_in[slab * SLAB + (lane & 31)], rstd = rstd_in[slab * SLAB + (lane & 31)];
+    const float mean = mean_in ? mean_in[slab * SLAB + (lane & 31)] : 0.f, rstd = rstd_in[slab * SLAB + (lane & 31)];
     const float sd = 1.0f / rstd;
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int R = 0; R < H / 2; ++R) {
-      d[R] *= act_slope_from_value(x[R] * sd + mean, act);
+      if (act) d[R] *= act_slope_from_value(x[R] * sd + mean, act);
       s1 += d[R];
       s2 += d[R] * x[R];
     }
@@ -724,8 +724,8 @@ __global__ __launch_bounds__(WG_THREADS) void k_act_ln_tangent(const float *__re
 extern "C" int harl_act_ln_tangent(const float *zd1, const float *zd2, const float *xhat, const float *mean, const float *rstd,
                                    long M, int H, int act, float *xhat_dot, void *stream) {
   if (M <= 0) return 0;
-  if (act < 1 || act > 4) {
-    set_error("harl_act_ln_tangent: activation id must be 1 (leaky_relu), 2 (tanh), 3 (sigmoid) or 4 (selu)");
+  if (act < 0 || act > 4 || (act > 0 && !mean)) {  // 0 = no activation: the LayerNorm tangent alone (rnn.norm of the composed GRU)
+    set_error("harl_act_ln_tangent: activation id must be 0 (none), 1 (leaky_relu), 2 (tanh), 3 (sigmoid) or 4 (selu)");
     return -2;
   }
   const long n_slabs = n_slabs_of(M);

@@ -163,8 +163,100 @@ __global__ __launch_bounds__(WG_THREADS) void k_rownorm(const float *__restrict_
   }
 }
 
+// forward-mode tangent of one cell step (HATRPO's Fisher-vector product on the composed GRU path, harl_amd/gru_wide.py):
+//   r_dot = r (1 - r) sum(g_r),  z_dot = z (1 - z) sum(g_z),  n_dot = (1 - n^2) (sum(gi_n) + r_dot hn + r sum(gh_n)),
+//   h_dot = (1 - z) n_dot + z_dot (h~ - n) + z h~_dot,        h~_dot of the next step = h_dot * mask_next
+// every gate tangent arrives as the images of the GEMMs that form it: gia = W_i x_dot, gib = W_i_dot x + b_i_dot (input side),
+// gha = W_h h~_dot (NULL at the first step: h0 carries no tangent), ghb = W_h_dot h~ + b_h_dot.
+struct GruTanArgs {
+  const float *gia[3], *gib[3], *gha[3], *ghb[3];
+  const float *r, *z, *n, *hn, *hpm, *hpm_dot, *mask_next;
+  float *h_dot, *hpm_dot_next;
+  long n_slabs;
+};
+
+template <int H>
+__global__ __launch_bounds__(WG_THREADS) void k_gru_cell_tangent(GruTanArgs A) {
+  const int lane = threadIdx.x & 63, wave = wave_id(), i = lane & 31;
+  for (long slab = (long)blockIdx.x * WAVES_PER_WG + wave; slab < A.n_slabs; slab += (long)gridDim.x * WAVES_PER_WG) {
+    float gi[H / 2], gh[H / 2], t[H / 2], rr[H / 2], rd[H / 2], zd[H / 2];
+    auto sum_in = [&](int g) {
+      atl_load<H>(A.gia[g], slab, lane, gi);
+      atl_load<H>(A.gib[g], slab, lane, t);
+#pragma unroll
+      for (int R = 0; R < H / 2; ++R) gi[R] += t[R];
+    };
+    auto sum_hid = [&](int g) {
+      atl_load<H>(A.ghb[g], slab, lane, gh);
+      if (A.gha[g]) {
+        atl_load<H>(A.gha[g], slab, lane, t);
+#pragma unroll
+        for (int R = 0; R < H / 2; ++R) gh[R] += t[R];
+      }
+    };
+    sum_in(0);
+    sum_hid(0);
+    atl_load<H>(A.r, slab, lane, rr);
+#pragma unroll
+    for (int R = 0; R < H / 2; ++R) rd[R] = rr[R] * (1.0f - rr[R]) * (gi[R] + gh[R]);
+    sum_in(1);
+    sum_hid(1);
+    float zz[H / 2];
+    atl_load<H>(A.z, slab, lane, zz);
+#pragma unroll
+    for (int R = 0; R < H / 2; ++R) zd[R] = zz[R] * (1.0f - zz[R]) * (gi[R] + gh[R]);
+    sum_in(2);
+    sum_hid(2);
+    float nn[H / 2];
+    atl_load<H>(A.n, slab, lane, nn);
+    atl_load<H>(A.hn, slab, lane, t);
+#pragma unroll
+    for (int R = 0; R < H / 2; ++R) gi[R] = (1.0f - nn[R] * nn[R]) * (gi[R] + rd[R] * t[R] + rr[R] * gh[R]);  // n_dot
+    atl_load<H>(A.hpm, slab, lane, t);
+#pragma unroll
+    for (int R = 0; R < H / 2; ++R) gi[R] = (1.0f - zz[R]) * gi[R] + zd[R] * (t[R] - nn[R]);
+    if (A.hpm_dot) {
+      atl_load<H>(A.hpm_dot, slab, lane, t);
+#pragma unroll
+      for (int R = 0; R < H / 2; ++R) gi[R] += zz[R] * t[R];
+    }
+    atl_store<H>(A.h_dot, slab, lane, gi);
+    if (A.hpm_dot_next) {
+      const float mk = A.mask_next[slab * SLAB + i];
+#pragma unroll
+      for (int R = 0; R < H / 2; ++R) gi[R] *= mk;
+      atl_store<H>(A.hpm_dot_next, slab, lane, gi);
+    }
+  }
+}
+
 int grid_of(long n_slabs) { return persistent_grid(n_slabs, 4); }
 }  // namespace
+
+extern "C" int harl_gru_cell_tangent(const float *gia_r, const float *gia_z, const float *gia_n, const float *gib_r,
+                                     const float *gib_z, const float *gib_n, const float *gha_r, const float *gha_z,
+                                     const float *gha_n, const float *ghb_r, const float *ghb_z, const float *ghb_n,
+                                     const float *r, const float *z, const float *n, const float *hn, const float *hpm,
+                                     const float *hpm_dot, const float *mask_next, int H, long m_pad, float *h_dot,
+                                     float *hpm_dot_next, void *stream) {
+  if (m_pad <= 0) return 0;
+  if (m_pad % SLAB) return bad("harl_gru_cell_tangent: m_pad must be a multiple of 32");
+  if (hpm_dot_next && !mask_next) return bad("harl_gru_cell_tangent: the next step's h~_dot needs its reset masks");
+  if ((gha_r != nullptr) != (hpm_dot != nullptr) || (gha_r != nullptr) != (gha_z != nullptr) || (gha_r != nullptr) != (gha_n != nullptr))
+    return bad("harl_gru_cell_tangent: gha_* and hpm_dot are given together (all NULL at the first step)");
+  GruTanArgs A{};
+  A.gia[0] = gia_r; A.gia[1] = gia_z; A.gia[2] = gia_n;
+  A.gib[0] = gib_r; A.gib[1] = gib_z; A.gib[2] = gib_n;
+  A.gha[0] = gha_r; A.gha[1] = gha_z; A.gha[2] = gha_n;
+  A.ghb[0] = ghb_r; A.ghb[1] = ghb_z; A.ghb[2] = ghb_n;
+  A.r = r; A.z = z; A.n = n; A.hn = hn; A.hpm = hpm; A.hpm_dot = hpm_dot; A.mask_next = mask_next;
+  A.h_dot = h_dot; A.hpm_dot_next = hpm_dot_next;
+  A.n_slabs = m_pad / SLAB;
+  if (H == 128) hipLaunchKernelGGL(k_gru_cell_tangent<128>, dim3(grid_of(A.n_slabs)), dim3(WG_THREADS), 0, (hipStream_t)stream, A);
+  else if (H == 64) hipLaunchKernelGGL(k_gru_cell_tangent<64>, dim3(grid_of(A.n_slabs)), dim3(WG_THREADS), 0, (hipStream_t)stream, A);
+  else return bad("harl_gru_cell_tangent: H must be 64 or 128");
+  return check_launch("harl_gru_cell_tangent");
+}
 
 extern "C" int harl_gru_cell_init(const float *h0, const float *mask_rows, int H, long m_pad, float *hpm0, void *stream) {
   if (m_pad <= 0) return 0;

@@ -136,3 +136,59 @@ def backward(net, seq: dict) -> None:
              ptr(Wih[g * H * H:(g + 1) * H * H]), ptr(out), None, 0, None, 0, s, tag="bwd_dx")
         if g > 0:
             net.dz[1][:M * H].add_(tmp[:M * H])
+
+
+def tangent(net, seq: dict, xdot: torch.Tensor, pack_d: torch.Tensor, ws: dict) -> torch.Tensor:
+    """Forward-mode tangent through the composed GRU (HATRPO's Fisher-vector product, trpo_util.py:132-158): ``xdot`` = tangent
+    of the last MLP layer's x_hat (ATL, L*m_pad rows), ``pack_d`` = tangent of the folded packs laid out like net.pack_arena
+    (harl_fold_tangent_table) -> y_dot, the tangent of rnn.norm's output over all steps (ATL).  Uses the gates the forward pass
+    saved (save=True).  Per layer: the input halves of the gate tangents for ALL steps as six raw GEMMs (W_i x_dot and
+    W_i_dot x + b_i_dot per gate), then per step three or six GEMMs on the carried state (W_h h~_dot -- absent at the first
+    step, h0 carries no tangent -- and W_h_dot h~ + b_h_dot) and one harl_gru_cell_tangent; layers run one after the other over
+    the whole chunk as in ``forward``."""
+    H = net.hidden_sizes[-1]
+    L, mp = seq["L"], seq["m_pad"]
+    M, n = L * mp, mp * H
+    RN = net.recurrent_n
+    s = stream()
+    zero = net.rnn_zero_bias
+    if ws.get("gru_rows", 0) < M or ws.get("gru_layers", 0) < RN:
+        dev, f32 = net.device_, torch.float32
+        e = lambda k: torch.empty(k, dtype=f32, device=dev)  # noqa: E731
+        ws.update(gru_rows=M, gru_layers=RN, gia=[e(M * H) for _ in range(3)], gib=[e(M * H) for _ in range(3)],
+                  gha=[e(n) for _ in range(3)], ghb=[e(n) for _ in range(3)], hdot=[e(M * H) for _ in range(RN)],
+                  hpmd=[e(n) for _ in range(2)], ydot=e(M * H))
+    gia, gib, gha, ghb, hpmd = ws["gia"], ws["gib"], ws["gha"], ws["ghb"], ws["hpmd"]
+    mask_rows = seq["mask_rows"]
+    n3 = 3 * H * H
+    xin, xin_dot = net.xh[-1], xdot
+    for layer in range(RN):
+        gp, sv = net.gru_packs[layer], net.rnn_saved_l[layer]
+        b0 = net._gru_pack_base + 2 * layer * (n3 + 3 * H)  # the same block of the tangent arena (nets._build_tables)
+        Wihd, bihd = pack_d[b0:b0 + n3], pack_d[b0 + n3:b0 + n3 + 3 * H]
+        Whhd, bhhd = pack_d[b0 + n3 + 3 * H:b0 + 2 * n3 + 3 * H], pack_d[b0 + 2 * n3 + 3 * H:b0 + 2 * n3 + 6 * H]
+        for g in range(3):
+            blk, bb = slice(g * H * H, (g + 1) * H * H), slice(g * H, (g + 1) * H)
+            call("harl_mlp_linear", ptr(xin_dot), M, H, H, ptr(gp["Wih"][blk]), ptr(zero), ptr(gia[g]), s, tag="gru_gi_tan")
+            call("harl_mlp_linear", ptr(xin), M, H, H, ptr(Wihd[blk]), ptr(bihd[bb]), ptr(gib[g]), s, tag="gru_gi_tan")
+        hdot = ws["hdot"][layer]
+        for l in range(L):
+            lo, hi = l * n, (l + 1) * n
+            first, last = l == 0, l == L - 1
+            cur, nxt = hpmd[l & 1], hpmd[(l + 1) & 1]
+            hpm_l = sv[0][lo:hi]
+            for g in range(3):
+                blk, bb = slice(g * H * H, (g + 1) * H * H), slice(g * H, (g + 1) * H)
+                call("harl_mlp_linear", ptr(hpm_l), mp, H, H, ptr(Whhd[blk]), ptr(bhhd[bb]), ptr(ghb[g]), s, tag="gru_gh_tan")
+                if not first:
+                    call("harl_mlp_linear", ptr(cur), mp, H, H, ptr(gp["Whh"][blk]), ptr(zero), ptr(gha[g]), s, tag="gru_gh_tan")
+            ha = [None] * 3 if first else [ptr(t) for t in gha]
+            call("harl_gru_cell_tangent", ptr(gia[0][lo:hi]), ptr(gia[1][lo:hi]), ptr(gia[2][lo:hi]), ptr(gib[0][lo:hi]),
+                 ptr(gib[1][lo:hi]), ptr(gib[2][lo:hi]), ha[0], ha[1], ha[2], ptr(ghb[0]), ptr(ghb[1]), ptr(ghb[2]),
+                 ptr(sv[1][lo:hi]), ptr(sv[2][lo:hi]), ptr(sv[3][lo:hi]), ptr(sv[4][lo:hi]), ptr(hpm_l),
+                 None if first else ptr(cur), None if last else ptr(mask_rows[(l + 1) * mp:(l + 2) * mp]), H, mp,
+                 ptr(hdot[lo:hi]), None if last else ptr(nxt), s, tag="gru_cell_tangent")
+        xin, xin_dot = net.rnn_hraw_l[layer], hdot
+    call("harl_act_ln_tangent", ptr(xin_dot), None, ptr(net.rnn_y), None, ptr(net.rnn_rstd), M, H, 0, ptr(ws["ydot"]), s,
+         tag="gru_norm_tangent")
+    return ws["ydot"]

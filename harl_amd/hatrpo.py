@@ -28,9 +28,6 @@ class HATRPO(OnPolicyBase):
         assert act_space.__class__.__name__ != "MultiDiscrete", \
             "only continuous and discrete action space is supported by HATRPO."
         super().__init__(args, obs_space, act_space, device)
-        if getattr(self.actor, "gru_wide", False):
-            raise NotImplementedError("HATRPO with a 128-wide GRU or stacked GRU layers: the recurrent tangent kernels are "
-                                      "64 wide, one layer")
         if self.actor.panel:
             raise NotImplementedError("HATRPO with hidden width 256: the forward-mode tangent kernels are 64/128 wide "
                                       "(no tuned HARL config needs it)")
@@ -150,7 +147,11 @@ class HATRPO(OnPolicyBase):
         fx, fmask, frstd, fh = net.feat()
         xLdot = ws["xd"][-1]
         mv, mp_ = 0, 0
-        if net.recurrent:  # tangent through the recurrence (csrc/gru.hip): parallel gate pre-pass + sequential kernel
+        if net.recurrent and net.gru_wide:  # 128-wide / stacked GRUs: the composed tangent (gru_wide.tangent, round 4)
+            from . import gru_wide
+            xLdot = gru_wide.tangent(net, seq, ws["xd"][-1], pd, ws)
+            mv, mp_ = seq["m"], seq["m_pad"]
+        elif net.recurrent:  # tangent through the recurrence (csrc/gru.hip): parallel gate pre-pass + sequential kernel
             H, gp, sv = hs[-1], net.gru_pack, net.rnn_saved
             b0, n3 = net._gru_pack_base, 3 * H * H
             Wihd, bihd = pd[b0:b0 + n3], pd[b0 + n3:b0 + n3 + 3 * H]
@@ -285,9 +286,9 @@ class HATRPO(OnPolicyBase):
         obs = _as_dev(obs, dev)
         m = obs.shape[0]
         if self.actor.recurrent:  # gathered [L*m, .] l-major sample + rnn_states [m, 1, H] (recurrent generators)
-            H = self.actor.hidden_sizes[-1]
+            HS = self.actor.hidden_sizes[-1] * self.actor.recurrent_n
             nseq = _as_dev(_rnn, dev).shape[0]
-            seq = build_seq(dev, m // nseq, nseq, H, h0=_as_dev(_rnn, dev).reshape(nseq, H), masks_src=_as_dev(_masks, dev))
+            seq = build_seq(dev, m // nseq, nseq, HS, h0=_as_dev(_rnn, dev).reshape(nseq, HS), masks_src=_as_dev(_masks, dev))
             return self._update_core(obs.reshape(m, -1), seq["L"] * seq["m_pad"], m, _as_dev(actions, dev).reshape(m, -1),
                                      None if avail is None else _as_dev(avail, dev).reshape(m, -1),
                                      _as_dev(old_logp, dev).reshape(m, -1), _as_dev(adv, dev).reshape(m), None,

@@ -320,7 +320,8 @@ int harl_act_bwd(float *dz, const float *xhat, const float *mean, const float *r
  * networks built with activation_func != relu, mlp.py:25-38):  a_dot = act'(z) (zd1 + zd2),
  * x_hat_dot = rstd (a_dot - mean_f(a_dot) - x_hat mean_f(x_hat a_dot)).  zd1, zd2 (zd2 may be NULL): ATL images of the two
  * halves of the pre-activation's tangent (raw GEMMs: harl_mlp_linear / harl_mlp_linear_wide); xhat / mean / rstd as
- * harl_act_ln_fwd left them; act' is taken from the activation value like harl_act_bwd. */
+ * harl_act_ln_fwd left them; act' is taken from the activation value like harl_act_bwd.  act = 0: no activation (mean may be
+ * NULL) -- the LayerNorm tangent alone, used for rnn.norm of the composed GRU. */
 int harl_act_ln_tangent(const float *zd1, const float *zd2, const float *xhat, const float *mean, const float *rstd, long M,
                         int H, int act, float *xhat_dot, void *stream);
 /* the same for wide inputs, from the x0n image of harl_mlp_x0n_wide (w_img: scratch as in harl_mlp_fwd_wide) */
@@ -493,6 +494,17 @@ int harl_gru_cell_bwd(const float *dh_out, const float *t_r, const float *t_z, c
                       const float *r, const float *z, const float *n, const float *hn, const float *hpm, int H, long m_pad,
                       float *gz, float *dr, float *dz, float *dn, float *dhn, void *stream);
 int harl_rownorm(const float *x, long M, int H, float *y, float *rstd, void *stream);
+/* Forward-mode tangent of one cell step (HATRPO's Fisher-vector product, harl/utils/trpo_util.py:132-158, through the composed
+ * GRU of harl/models/base/rnn.py:8-81):  r_dot = r (1 - r) sum(g_r), z_dot = z (1 - z) sum(g_z),
+ * n_dot = (1 - n^2) (sum(gi_n) + r_dot hn + r sum(gh_n)),  h_dot = (1 - z) n_dot + z_dot (h~ - n) + z h~_dot.
+ * Gate tangents arrive as the ATL images of the raw GEMMs that form them: gia = W_i x_dot, gib = W_i_dot x + b_i_dot,
+ * gha = W_h h~_dot (all three NULL together with hpm_dot at the first step), ghb = W_h_dot h~ + b_h_dot; r, z, n, hn, hpm as
+ * harl_gru_cell_fwd saved them.  Emits h_dot of the step and (unless NULL) the next step's h~_dot = h_dot * mask_next. */
+int harl_gru_cell_tangent(const float *gia_r, const float *gia_z, const float *gia_n, const float *gib_r, const float *gib_z,
+                          const float *gib_n, const float *gha_r, const float *gha_z, const float *gha_n, const float *ghb_r,
+                          const float *ghb_z, const float *ghb_n, const float *r, const float *z, const float *n,
+                          const float *hn, const float *hpm, const float *hpm_dot, const float *mask_next, int H, long m_pad,
+                          float *h_dot, float *hpm_dot_next, void *stream);
 /* dhout = d(loss)/d(h_l) through the output path (after the rnn.norm backward, done by the head kernels with an all-ones relu
  * mask).  Outputs the gate gradients dr, dz, dn (d gi = [dr,dz,dn]) and dhn (d gh = [dr,dz,dhn]) as ATL(H) for
  * harl_mlp_dw_partials, and dz_mlp = LayerNorm/ReLU backward of W_ih'^T dgi for the last MLP layer (xmlp / mask_mlp / rstd_mlp). */

@@ -453,10 +453,11 @@ def check_trpo_rnn(spec, agg: str = "prod") -> Dict[str, float]:
     out = {}
     L, m = spec["L"], spec["m"]
     M = L * m
+    rn = spec.get("recurrent_n", 1)  # stacked GRU layers (rnn.py:14)
     sh = Shapes(T=L, N=m, A=1, obs_dim=spec["obs_dim"], share_obs_dim=spec["share_obs_dim"], act_dim=spec["act_dim"],
-                discrete=spec["discrete"], hidden_sizes=spec["hidden_sizes"])
+                discrete=spec["discrete"], hidden_sizes=spec["hidden_sizes"], recurrent_n=rn)
     args = default_args(sh.hidden_sizes, kl_threshold=0.01, ls_step=10, accept_ratio=0.5, backtrack_coeff=0.8,
-                        action_aggregation=agg, use_recurrent_policy=True)
+                        action_aggregation=agg, use_recurrent_policy=True, recurrent_n=rn)
     space = Discrete(sh.act_dim) if sh.discrete else Box((sh.act_dim,))
     actor = HATRPO(args, Box((sh.obs_dim,)), space, device=DEV)
     sd = synthetic_state_dict(actor_param_shapes(sh, args["use_feature_normalization"], True), 17, args["std_x_coef"])
@@ -480,7 +481,7 @@ def check_trpo_rnn(spec, agg: str = "prod") -> Dict[str, float]:
 
     # ---- surrogate gradient + FVP on the recurrent layout
     H = sh.hidden_sizes[-1]
-    seq = build_seq(DEV, L, m, H, h0=dev(h0).reshape(m, H), masks_src=dev(masks))
+    seq = build_seq(DEV, L, m, H * rn, h0=dev(h0).reshape(m, H * rn), masks_src=dev(masks))
     Mp = L * seq["m_pad"]
     d_obs, d_act, d_old = dev(obs), dev(act), dev(old_logp)
     d_avail = None if avail is None else dev(avail)
@@ -525,6 +526,12 @@ def check_trpo_rnn(spec, agg: str = "prod") -> Dict[str, float]:
                         actor.actor.flat_param.cpu().numpy(), oracle.flat().numpy(), n_pert=_TRPO_N_PERT, step_dir=taps[0][1])
     return out
 
+
+TRPO_RNN_WIDE_SHAPES = [  # HATRPO through the composed GRU (gru_wide.tangent): 128-wide, and two stacked 64-wide layers
+    dict(name="trpo_rnn_box_h128", obs_dim=18, share_obs_dim=54, act_dim=5, discrete=False, hidden_sizes=[128, 128], L=6, m=40),
+    dict(name="trpo_rnn2_disc_h64", obs_dim=30, share_obs_dim=20, act_dim=9, discrete=True, hidden_sizes=[64], L=5, m=64,
+         recurrent_n=2),
+]
 
 RNN_SHAPES = [  # (L, m): m = 40 pads to 64 sequences, m = 64 is the identity layout, m = 7 a single ragged slab
     dict(name="rnn_box_L10_m40", obs_dim=18, share_obs_dim=54, act_dim=5, discrete=False, hidden_sizes=[64, 64], L=10, m=40),

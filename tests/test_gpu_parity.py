@@ -105,6 +105,14 @@ def test_hatrpo_gru_gradient_fvp_and_update(i):
     _assert_all(G.check_trpo_rnn(G.RNN_SHAPES[i]), tol=TOL)
 
 
+@pytest.mark.parametrize("i", [0, 1])
+def test_hatrpo_composed_gru_gradient_fvp_and_update(i):
+    """HATRPO on a 128-wide GRU and on two stacked 64-wide GRU layers (round 4): the Fisher-vector product's tangent through the
+    per-step composition (gru_wide.tangent: raw GEMMs + harl_gru_cell_tangent) against the oracle's double backward."""
+    G = _G()
+    _assert_all(G.check_trpo_rnn(G.TRPO_RNN_WIDE_SHAPES[i]), tol=TOL)
+
+
 @pytest.mark.parametrize("name", ["trpo_box_h64", "trpo_disc_h64", "trpo_wide_h128x3", "trpo_rnn_disc_h64", "trpo_rnn_box_h64",
                                   "trpo_rnn_fp_disc36_h64", "trpo_box_h128_tanh", "trpo_disc_h64_selu"])
 def test_hatrpo_train_matches_reference_golden(name):

@@ -27,10 +27,10 @@ def test_gru128_is_default_and_can_be_refused(stub_kernels, monkeypatch):  # noq
     monkeypatch.delenv("HARL_GRU128", raising=False)
     r = _runner([128, 128])
     assert r.actor[0].actor.gru_wide and r.critic.critic.gru_wide
-    from harl_amd.hatrpo import HATRPO
-    with pytest.raises(NotImplementedError):
-        HATRPO(default_args([128, 128], use_recurrent_policy=True, kl_threshold=0.01, ls_step=10, accept_ratio=0.5,
+    from harl_amd.hatrpo import HATRPO  # (round 4: HATRPO takes 128-wide and stacked GRUs through gru_wide.tangent)
+    t = HATRPO(default_args([128, 128], use_recurrent_policy=True, kl_threshold=0.01, ls_step=10, accept_ratio=0.5,
                             backtrack_coeff=0.8), Box((19,)), Box((3,)), device=torch.device("cpu"))
+    assert t.actor.gru_wide
 
 
 def test_gru128_launch_sequence(stub_kernels, monkeypatch):  # noqa: F811
@@ -147,8 +147,27 @@ def _emulate(arena, H):
         d = arena.view(dz, M * HO).view(M, HO)
         arena.view(dz_prev, M * HI).view(M, HI).copy_(d @ arena.view(Wp, HO * HI).view(HO, HI))
 
+    def cell_tangent(gia_r, gia_z, gia_n, gib_r, gib_z, gib_n, gha_r, gha_z, gha_n, ghb_r, ghb_z, ghb_n, r, z, n, hn, hpm,
+                     hpm_dot, mask_next, H_, mp, h_dot, hpm_dot_next, s):
+        v = lambda p: arena.view(p, mp * H).view(mp, H)  # noqa: E731
+        o = lambda p: 0.0 if p is None else v(p)  # noqa: E731
+        rr, zz, nn_ = v(r), v(z), v(n)
+        rd = rr * (1 - rr) * (v(gia_r) + v(gib_r) + o(gha_r) + v(ghb_r))
+        zd = zz * (1 - zz) * (v(gia_z) + v(gib_z) + o(gha_z) + v(ghb_z))
+        nd = (1 - nn_ * nn_) * (v(gia_n) + v(gib_n) + rd * v(hn) + rr * (o(gha_n) + v(ghb_n)))
+        hd = (1 - zz) * nd + zd * (v(hpm) - nn_) + zz * o(hpm_dot)
+        v(h_dot).copy_(hd)
+        if hpm_dot_next is not None:
+            v(hpm_dot_next).copy_(hd * arena.view(mask_next, mp).view(mp, 1))
+
+    def ln_tangent(zd1, zd2, xhat, mean, rstd, M, H_, act, out, s):
+        assert act == 0 and zd2 is None and mean is None
+        d, x = arena.view(zd1, M * H).view(M, H), arena.view(xhat, M * H).view(M, H)
+        rs = arena.view(rstd, M).view(M, 1)
+        arena.view(out, M * H).view(M, H).copy_(rs * (d - d.mean(-1, keepdim=True) - x * (x * d).mean(-1, keepdim=True)))
+
     return dict(harl_mlp_linear=linear, harl_gru_cell_init=cell_init, harl_gru_cell_fwd=cell_fwd, harl_gru_cell_bwd=cell_bwd,
-                harl_rownorm=rownorm, harl_mlp_bwd_dx=bwd_dx)
+                harl_rownorm=rownorm, harl_mlp_bwd_dx=bwd_dx, harl_gru_cell_tangent=cell_tangent, harl_act_ln_tangent=ln_tangent)
 
 
 @pytest.mark.parametrize("H,L,m,RN", [(128, 7, 40, 1), (64, 5, 32, 1), (64, 6, 40, 2), (128, 4, 32, 3)])
@@ -246,3 +265,98 @@ def test_composition_matches_autograd_gru(stub_kernels, monkeypatch, H, L, m, RN
             dWh = net.rnn_dgate_l[k][gh_g].view(M, H).t() @ hpm
             assert torch.allclose(dWi, Wi[k].grad[g], atol=1e-8), (k, g)
             assert torch.allclose(dWh, Wh[k].grad[g], atol=1e-8), (k, g)
+
+
+@pytest.mark.parametrize("H,L,m,RN", [(128, 5, 40, 1), (64, 4, 32, 2)])
+def test_tangent_composition_matches_jvp(stub_kernels, monkeypatch, H, L, m, RN):  # noqa: F811
+    """gru_wide.tangent (HATRPO's forward-mode pass through the composed GRU, incl. stacked layers) against
+    torch.autograd.functional.jvp through a plain torch GRU + LayerNorm, entry points emulated in float64."""
+    from harl_amd import _lib, gru_wide
+
+    torch.manual_seed(5)
+    mp = ((m + 31) // 32) * 32
+    M = L * mp
+    f = lambda *s_: torch.randn(*s_, dtype=torch.float64)  # noqa: E731
+    z = lambda n_: torch.zeros(n_, dtype=torch.float64)  # noqa: E731
+    per = 2 * (3 * H * H + 3 * H)
+
+    class Net:
+        hidden_sizes = [H]
+        device_ = torch.device("cpu")
+        recurrent_n = RN
+        _gru_pack_base = 7  # (an arbitrary offset: the blocks are addressed relative to it)
+    net = Net()
+    net.pack_arena = torch.cat([z(7), 0.3 * f(RN * per)])
+    pack_d = torch.cat([z(7), 0.2 * f(RN * per)])
+
+    def views(arena_):
+        out = []
+        for k in range(RN):
+            b0, n3 = 7 + k * per, 3 * H * H
+            out.append(dict(Wih=arena_[b0:b0 + n3], bih=arena_[b0 + n3:b0 + n3 + 3 * H],
+                            Whh=arena_[b0 + n3 + 3 * H:b0 + 2 * n3 + 3 * H], bhh=arena_[b0 + 2 * n3 + 3 * H:b0 + 2 * n3 + 6 * H]))
+        return out
+    net.gru_packs = views(net.pack_arena)
+    tan = views(pack_d)
+    net.xh, net.rmask, net.rstd = [f(M * H)], [torch.zeros(8, dtype=torch.int32)], [z(M)]
+    xdot = f(M * H)
+    net.rnn_saved_l = [[z(M * H) for _ in range(5)] for _ in range(RN)]
+    net.rnn_dgate_l = [[z(M * H) for _ in range(4)] for _ in range(RN)]
+    net.rnn_gi, net.rnn_y, net.rnn_rstd = z(3 * M * H), z(M * H), z(M)
+    net.dz = [f(M * H), z(M * H)]
+    net.rnn_hraw_l = [z(M * H) for _ in range(RN)]
+    net.rnn_gh, net.rnn_gz, net.rnn_zero_bias, net.rnn_tmp, net.rnn_dh = z(3 * M * H), z(M * H), z(H), z(M * H), z(M * H)
+    mask_rows = (torch.rand(M, dtype=torch.float64) > 0.25).to(torch.float64)
+    seq = dict(L=L, m_pad=mp, m=m, h0=0.5 * f(mp, RN * H), mask_rows=mask_rows, h_last=None)
+
+    arena = _Arena()
+    for t in (net.pack_arena, pack_d, net.xh[0], xdot, net.rstd[0], *[t_ for l_ in net.rnn_saved_l for t_ in l_], net.rnn_gi, net.rnn_y,
+              net.rnn_rstd, *net.rnn_hraw_l, net.rnn_gh, net.rnn_gz, net.rnn_zero_bias, net.rnn_tmp, mask_rows, seq["h0"]):
+        arena.add(t)
+    emu = _emulate(arena, H)
+    keep = []
+    real_ptr = _lib.ptr
+
+    def ptr(t):
+        if t is None:
+            return None
+        if not any(lo <= t.data_ptr() < hi for lo, hi, _ in arena.regs):
+            base = t._base if t._base is not None else t  # (a slice seen first must not shadow the workspace it belongs to)
+            keep.append(base)
+            arena.add(base)
+        return real_ptr(t)
+
+    monkeypatch.setattr(gru_wide, "call", lambda name, *args, tag=None: emu[name](*args))
+    monkeypatch.setattr(gru_wide, "ptr", ptr)
+    monkeypatch.setattr(gru_wide, "stream", lambda: 0)
+    real_empty = torch.empty
+    monkeypatch.setattr(torch, "empty", lambda *a, **k: real_empty(*a, **{**k, "dtype": torch.float64}) if k.get("dtype") == torch.float32 else real_empty(*a, **k))
+
+    def fwd(x, *ws_):  # the reference function: stacked GRU with mask resets on every layer's state, then LayerNorm without affine
+        h = [seq["h0"].view(mp, RN, H)[:, k] for k in range(RN)]
+        ys = []
+        for l in range(L):
+            inp = x.view(L, mp, H)[l]
+            for k in range(RN):
+                Wi, bi, Wh, bh = ws_[4 * k:4 * k + 4]
+                ht = h[k] * mask_rows[l * mp:(l + 1) * mp].view(mp, 1)
+                gi = [inp @ Wi.view(3, H, H)[g].t() + bi[g * H:(g + 1) * H] for g in range(3)]
+                gh = [ht @ Wh.view(3, H, H)[g].t() + bh[g * H:(g + 1) * H] for g in range(3)]
+                r_ = torch.sigmoid(gi[0] + gh[0])
+                z_ = torch.sigmoid(gi[1] + gh[1])
+                n_ = torch.tanh(gi[2] + r_ * gh[2])
+                h[k] = (1 - z_) * n_ + z_ * ht
+                inp = h[k]
+            ys.append(inp)
+        hraw = torch.stack(ys)
+        mu = hraw.mean(-1, keepdim=True)
+        return (hraw - mu) / torch.sqrt(((hraw - mu) ** 2).mean(-1, keepdim=True) + 1e-5)
+
+    prim = (net.xh[0].clone(),) + tuple(gp[k_].clone() for gp in net.gru_packs for k_ in ("Wih", "bih", "Whh", "bhh"))
+    tang = (xdot.clone(),) + tuple(tp[k_].clone() for tp in tan for k_ in ("Wih", "bih", "Whh", "bhh"))
+    y_ref, ydot_ref = torch.autograd.functional.jvp(fwd, prim, tang)
+
+    gru_wide.forward(net, seq, save=True)
+    assert torch.allclose(net.rnn_y.view(L, mp, H), y_ref, atol=1e-12)
+    ydot = gru_wide.tangent(net, seq, xdot, pack_d, {})
+    assert torch.allclose(ydot.view(L, mp, H), ydot_ref, atol=1e-10), float((ydot.view(L, mp, H) - ydot_ref).abs().max())

@@ -191,6 +191,14 @@ CASES = {
     "trpo_rnn_box_h64": dict(algo="hatrpo", shapes=dict(T=12, N=8, A=2, obs_dim=9, share_obs_dim=10, act_dim=2, discrete=False,
                                                         hidden_sizes=[64, 64]), seed=42,
                              overrides=dict(use_recurrent_policy=True, data_chunk_length=4, fixed_order=True)),
+    # HATRPO through the composed GRU (round 4): the reference's default hidden_sizes [128, 128] with use_recurrent_policy, and
+    # two stacked GRU layers
+    "trpo_rnn_box_h128": dict(algo="hatrpo", shapes=dict(T=10, N=8, A=2, obs_dim=18, share_obs_dim=20, act_dim=3, discrete=False,
+                                                         hidden_sizes=[128, 128]), seed=43, inactive_p=0.1,
+                              overrides=dict(use_recurrent_policy=True, data_chunk_length=5)),
+    "trpo_rnn2_disc_h64": dict(algo="hatrpo", shapes=dict(T=12, N=6, A=2, obs_dim=14, share_obs_dim=12, act_dim=5, discrete=True,
+                                                          hidden_sizes=[64], recurrent_n=2), seed=44, unavailable_p=0.2,
+                               overrides=dict(use_recurrent_policy=True, data_chunk_length=4, recurrent_n=2)),
     # ---- Categorical heads of 33..64 actions (SMAC 27m_vs_30m: 36 actions, GRU policies, FP state)
     "rnn_fp_disc36_h64": dict(state_type="FP", shapes=dict(T=10, N=6, A=3, obs_dim=40, share_obs_dim=30, act_dim=36,
                                                            discrete=True, hidden_sizes=[64, 64, 64]), seed=51, unavailable_p=0.4,

@@ -871,7 +871,8 @@ def consume_policy_init_rng(shapes: Dict[str, Tuple[int, ...]], gain: float = 0.
     for name, shp in shapes.items():
         if name == "rnn.rnn.weight_ih_l0":  # RNNLayer (rnn.py:8-21): nn.GRU's own uniform init, then orthogonal_ on the weights
             H = shp[1]
-            gru = torch.nn.GRU(H, H, num_layers=1)
+            n_layers = sum(1 for k_ in shapes if k_.startswith("rnn.rnn.weight_ih_l"))  # stacked layers (rnn.py:14)
+            gru = torch.nn.GRU(H, H, num_layers=n_layers)
             for pn, prm in gru.named_parameters():
                 if "weight" in pn:
                     torch.nn.init.orthogonal_(prm)

@@ -114,7 +114,8 @@ def test_hatrpo_composed_gru_gradient_fvp_and_update(i):
 
 
 @pytest.mark.parametrize("name", ["trpo_box_h64", "trpo_disc_h64", "trpo_wide_h128x3", "trpo_rnn_disc_h64", "trpo_rnn_box_h64",
-                                  "trpo_rnn_fp_disc36_h64", "trpo_box_h128_tanh", "trpo_disc_h64_selu"])
+                                  "trpo_rnn_fp_disc36_h64", "trpo_box_h128_tanh", "trpo_disc_h64_selu", "trpo_rnn_box_h128",
+                                  "trpo_rnn2_disc_h64"])
 def test_hatrpo_train_matches_reference_golden(name):
     _assert_all(_G().check_train_golden(name), tol=TOL)
 

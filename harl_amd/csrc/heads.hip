@@ -492,6 +492,7 @@ __global__ __launch_bounds__(64) void k_fold_tangent(const float *__restrict__ W
 template <int H, int DAP, bool DISC>
 void launch_fvp(const FvpArgs &A, int grid, hipStream_t s) {
   const size_t shm = ((size_t)4 * (H / 2) * DAP + 10 * DAP) * sizeof(float);
+  allow_big_lds(k_actor_head_fvp<H, DAP, DISC>, shm);  // (256-wide layers with 32 outputs: 65 KiB)
   hipLaunchKernelGGL((k_actor_head_fvp<H, DAP, DISC>), dim3(grid), dim3(WG_THREADS), shm, s, A);
 }
 
@@ -672,8 +673,9 @@ extern "C" int harl_actor_head_fvp(const float *xL, const float *xLdot, const ui
     return check_launch("harl_actor_head_fvp");                 \
   }
   CASE(128, 4) CASE(128, 8) CASE(128, 16) CASE(128, 32) CASE(64, 4) CASE(64, 8) CASE(64, 16) CASE(64, 32)
+  CASE(256, 4) CASE(256, 8) CASE(256, 16) CASE(256, 32)  // hidden width 256 (csrc/panel.hip)
 #undef CASE
-  set_error("head fvp: hidden width must be 64 or 128");
+  set_error("head fvp: hidden width must be 64, 128 or 256");
   return -2;
 }
 

@@ -67,13 +67,19 @@ __device__ __forceinline__ void panel_gemm(const u32x4 *__restrict__ wl, const f
   split_gemm<PMT, PNJ>(wl, x1, x2, x3, acc, [](int) {});
 }
 
-template <bool BWD>
+// MODE 0 forward, 1 backward, 2 forward-mode tangent (HATRPO's Fisher-vector product on 256-wide layers, round 4):
+//   z_dot = Wp (= W'_dot) x_in + bp (= b'_dot) [+ Wp2 (= W') x_in2 (= x_in_dot)],  x_out_dot = LNjac(mask . z_dot) with the PRIMAL
+//   x_hat / mask / rstd of this layer in xprev / mask_prev / rstd_prev (the epilogue of mlp.hip's ln_jac_store)
+template <int MODE>
 __global__ __launch_bounds__(WG_THREADS, 1) void k_panel(const float *__restrict__ xin, int KP, const float *__restrict__ Wp,
                                                          int ldw, int kvalid, const float *__restrict__ bp,
                                                          float *__restrict__ xout, uint32_t *__restrict__ mask_out,
                                                          float *__restrict__ rstd_out, const float *__restrict__ xprev,
                                                          const uint32_t *__restrict__ mask_prev,
-                                                         const float *__restrict__ rstd_prev, long n_slabs) {
+                                                         const float *__restrict__ rstd_prev, long n_slabs,
+                                                         const float *__restrict__ xin2 = nullptr, int KP2 = 0,
+                                                         const float *__restrict__ Wp2 = nullptr, int ldw2 = 0) {
+  constexpr bool BWD = MODE == 1;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   u32x4 *img = reinterpret_cast<u32x4 *>(lds);
   const int lane = threadIdx.x & 63, wave = wave_id(), i = lane & 31, h = lane >> 5;
@@ -96,8 +102,39 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_panel(const float *__restrict
       __syncthreads();
       panel_gemm(wl, xp, p, acc);
     }
+    if constexpr (MODE == 2) {
+      if (xin2) {  // (kernel-uniform) the second half of the pre-activation's tangent: W' x_in_dot
+        const f32x4 *xp2 = reinterpret_cast<const f32x4 *>(xin2 + slab * (long)KP2 * SLAB) + lane;
+        for (int p = 0; p < KP2 / 32; ++p) {
+          __syncthreads();
+          stage_panel<false>(img, Wp2, ldw2, ldw2, p);
+          __syncthreads();
+          panel_gemm(wl, xp2, p, acc);
+        }
+      }
+    }
     if (!live) continue;
-    if constexpr (!BWD) {
+    if constexpr (MODE == 2) {
+      constexpr int NR = PH / 2, NW = (NR + 31) / 32;
+      float xh[NR], ad[NR];
+      atl_load<PH>(xprev, slab, lane, xh);
+      uint32_t bits[NW];
+#pragma unroll
+      for (int w = 0; w < NW; ++w) bits[w] = mask_prev[(slab * NW + w) * WAVE + lane];
+      const float rstd = rstd_prev[slab * SLAB + i];
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int R = 0; R < NR; ++R) {
+        ad[R] = mask_pop(acc[R >> 4][R & 15], bits[R >> 5]);
+        s1 += ad[R];
+        s2 += ad[R] * xh[R];
+      }
+      s1 = wave_sum32(s1) * (1.0f / PH);
+      s2 = wave_sum32(s2) * (1.0f / PH);
+#pragma unroll
+      for (int R = 0; R < NR; ++R) ad[R] = rstd * (ad[R] - s1 - xh[R] * s2);
+      atl_store<PH>(xout, slab, lane, ad);
+    } else if constexpr (!BWD) {
       constexpr int NR = PH / 2, NW = (NR + 31) / 32;
       uint32_t bits[NW];
 #pragma unroll
@@ -149,8 +186,8 @@ extern "C" int harl_mlp_panel_fwd(const float *xin, long M, int KP, const float 
   if (KP % 32 != 0 || KP < D || KP > 512) return bad("harl_mlp_panel_fwd: KP must be a multiple of 32, >= D and <= 512");
   const long n_slabs = n_slabs_of(M);
   const size_t shm = (size_t)3 * PANEL_IMG * sizeof(u32x4);
-  allow_big_lds(k_panel<false>, shm);
-  hipLaunchKernelGGL(k_panel<false>, dim3(panel_grid(n_slabs)), dim3(WG_THREADS), shm, (hipStream_t)stream, xin, KP, Wp, D, D,
+  allow_big_lds(k_panel<0>, shm);
+  hipLaunchKernelGGL(k_panel<0>, dim3(panel_grid(n_slabs)), dim3(WG_THREADS), shm, (hipStream_t)stream, xin, KP, Wp, D, D,
                      bp, xout, relu_mask, rstd, nullptr, nullptr, nullptr, n_slabs);
   return check_launch("harl_mlp_panel_fwd");
 }
@@ -162,9 +199,23 @@ extern "C" int harl_mlp_panel_bwd(const float *dz, const float *xprev, const uin
   if (HI != PH || HO != PH) return bad("harl_mlp_panel_bwd: both widths must be 256");
   const long n_slabs = n_slabs_of(M);
   const size_t shm = (size_t)3 * PANEL_IMG * sizeof(u32x4);
-  allow_big_lds(k_panel<true>, shm);
+  allow_big_lds(k_panel<1>, shm);
   // dx_hat[i] = sum_o Wp[o][i] dz[o]: rows = input features, k = output features, Wp = [HO][HI] (row stride HI)
-  hipLaunchKernelGGL(k_panel<true>, dim3(panel_grid(n_slabs)), dim3(WG_THREADS), shm, (hipStream_t)stream, dz, HO, Wp, HI, HO,
+  hipLaunchKernelGGL(k_panel<1>, dim3(panel_grid(n_slabs)), dim3(WG_THREADS), shm, (hipStream_t)stream, dz, HO, Wp, HI, HO,
                      nullptr, dz_prev, nullptr, nullptr, xprev, relu_mask_prev, rstd_prev, n_slabs);
   return check_launch("harl_mlp_panel_bwd");
+}
+
+extern "C" int harl_mlp_panel_tangent(const float *xin_dot, const float *xin, long M, int KP, const float *Wp, const float *Wdp,
+                                      int D, const float *bdp, const float *xprimal, const uint32_t *mask_in,
+                                      const float *rstd_in, float *xout_dot, void *stream) {
+  if (M <= 0) return 0;
+  if (KP % 32 != 0 || KP < D || KP > 512) return bad("harl_mlp_panel_tangent: KP must be a multiple of 32, >= D and <= 512");
+  if (xin_dot && (!Wp || KP != PH || D != PH)) return bad("harl_mlp_panel_tangent: a hidden layer (x_in_dot given) is 256 -> 256 and needs W'");
+  const long n_slabs = n_slabs_of(M);
+  const size_t shm = (size_t)3 * PANEL_IMG * sizeof(u32x4);
+  allow_big_lds(k_panel<2>, shm);
+  hipLaunchKernelGGL(k_panel<2>, dim3(panel_grid(n_slabs)), dim3(WG_THREADS), shm, (hipStream_t)stream, xin, KP, Wdp, D, D, bdp,
+                     xout_dot, nullptr, nullptr, xprimal, mask_in, rstd_in, n_slabs, xin_dot, xin_dot ? PH : 0, Wp, PH);
+  return check_launch("harl_mlp_panel_tangent");
 }

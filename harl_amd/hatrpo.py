@@ -28,9 +28,6 @@ class HATRPO(OnPolicyBase):
         assert act_space.__class__.__name__ != "MultiDiscrete", \
             "only continuous and discrete action space is supported by HATRPO."
         super().__init__(args, obs_space, act_space, device)
-        if self.actor.panel:
-            raise NotImplementedError("HATRPO with hidden width 256: the forward-mode tangent kernels are 64/128 wide "
-                                      "(no tuned HARL config needs it)")
         self.kl_threshold = args["kl_threshold"]
         self.ls_step = args["ls_step"]
         self.accept_ratio = args["accept_ratio"]
@@ -124,6 +121,14 @@ class HATRPO(OnPolicyBase):
                 call("harl_mlp_linear", ptr(net.xh[l - 1]), m, hs[l - 1], hs[l], ptr(Wpd), ptr(bpd), ptr(zd2), s, tag="linear")
                 call("harl_act_ln_tangent", ptr(zd1), ptr(zd2), ptr(net.xh[l]), ptr(net.amean[l]), ptr(net.rstd[l]), m, hs[l],
                      net.act_id, ptr(ws["xd"][l]), s, tag="act_ln_tangent")
+        elif net.panel:  # width 256 (csrc/panel.hip, round 4): the same K-panel walk with the LayerNorm Jacobian as epilogue
+            call("harl_mlp_panel_tangent", None, ptr(net.x0n), m, net.kp0, None, ptr(Wpd), net.in_dim, ptr(bpd), ptr(net.xh[0]),
+                 ptr(net.rmask[0]), ptr(net.rstd[0]), ptr(ws["xd"][0]), s, tag="tangent_panel")
+            for l in range(1, L):
+                Wp, _ = net._packs[l]
+                Wpd, bpd = packs_d[l]
+                call("harl_mlp_panel_tangent", ptr(ws["xd"][l - 1]), ptr(net.xh[l - 1]), m, 256, ptr(Wp), ptr(Wpd), 256, ptr(bpd),
+                     ptr(net.xh[l]), ptr(net.rmask[l]), ptr(net.rstd[l]), ptr(ws["xd"][l]), s, tag="tangent_panel")
         elif net.wide:  # x0n of the same rows is still there from the forward pass of _surrogate()
             call("harl_mlp_tangent_wide", ptr(net.x0n), m, net.kp0, ptr(Wpd), net.in_dim, ptr(bpd), hs[0], ptr(net.w1img),
                  ptr(net.xh[0]), ptr(net.rmask[0]), ptr(net.rstd[0]), ptr(ws["xd"][0]), s, tag="tangent_wide")
@@ -132,7 +137,7 @@ class HATRPO(OnPolicyBase):
                  int(net.use_feature_normalization), hs[0], ptr(net.xh[0]), ptr(net.rmask[0]), ptr(net.rstd[0]),
                  ptr(ws["xd"][0]), s)
         one_launch = os.environ.get("HARL_TANGENT_ONE_LAUNCH", "1") != "0"
-        for l in range(1, L if not net.act_id else 1):
+        for l in range(1, L if not (net.act_id or net.panel) else 1):
             Wp, _ = net._packs[l]
             Wpd, bpd = packs_d[l]
             if one_launch:  # [W' | W'_dot] [x_dot ; x_hat] as ONE K = 2 H GEMM, weight images streamed from L2 (csrc/wide.hip)

@@ -147,6 +147,13 @@ int harl_mlp_fwd_wide(const float *x0n, long M, int KP, const float *Wp, int D, 
  * Weight gradients: harl_mlp_dw_partials(a_kind = 0, HO = 256). */
 int harl_mlp_panel_fwd(const float *xin, long M, int KP, const float *Wp, int D, const float *bp, int HO, float *xout,
                        uint32_t *relu_mask, float *rstd, void *stream);
+/* Forward-mode tangent of a 256-wide layer (HATRPO's Fisher-vector product, trpo_util.py:132-158, on the dexhands-shaped
+ * networks): x_out_dot = LNjac(mask . (Wdp x_in + bdp [+ Wp x_in_dot])) with the PRIMAL x_hat / mask / rstd of this layer.
+ * First layer: x_in = the x0n image (KP wide, D valid columns), x_in_dot = NULL (the inputs carry no tangent); hidden layers:
+ * KP = D = 256, x_in = x_hat of the layer before, x_in_dot its tangent, Wp the folded weights. */
+int harl_mlp_panel_tangent(const float *xin_dot, const float *xin, long M, int KP, const float *Wp, const float *Wdp, int D,
+                           const float *bdp, const float *xprimal, const uint32_t *mask_in, const float *rstd_in,
+                           float *xout_dot, void *stream);
 int harl_mlp_panel_bwd(const float *dz, const float *xprev, const uint32_t *relu_mask_prev, const float *rstd_prev, long M,
                        int HO, int HI, const float *Wp, float *dz_prev, void *stream);
 /* the same two layers FROM the x0n ATL(32 | 64) image of harl_mlp_x0n_wide (D <= 64; identity row order; the image is

@@ -191,6 +191,9 @@ CASES = {
     "trpo_rnn_box_h64": dict(algo="hatrpo", shapes=dict(T=12, N=8, A=2, obs_dim=9, share_obs_dim=10, act_dim=2, discrete=False,
                                                         hidden_sizes=[64, 64]), seed=42,
                              overrides=dict(use_recurrent_policy=True, data_chunk_length=4, fixed_order=True)),
+    # HATRPO on 256-wide layers (round 4: the tangent pass on the K-panel kernel)
+    "trpo_box_h256x2": dict(algo="hatrpo", shapes=dict(T=10, N=8, A=2, obs_dim=44, share_obs_dim=30, act_dim=6, discrete=False,
+                                                       hidden_sizes=[256, 256]), seed=63, overrides={}, inactive_p=0.1),
     # HATRPO through the composed GRU (round 4): the reference's default hidden_sizes [128, 128] with use_recurrent_policy, and
     # two stacked GRU layers
     "trpo_rnn_box_h128": dict(algo="hatrpo", shapes=dict(T=10, N=8, A=2, obs_dim=18, share_obs_dim=20, act_dim=3, discrete=False,

@@ -16,7 +16,7 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 ALL_CASES = ["mpe_box_h64", "mpe_box_h128", "mpe_disc_h64", "cheetah_h128x3_mb2", "box_mean_inactive_novn",
              "wide_obs_h64", "a2c_box_h64", "fp_box_h64", "fp_disc_h128_mb2", "disc50_h128", "hands_h256x3",
              "hands_h256x3_mb2_fp"]
-TRPO_CASES = ["trpo_box_h64", "trpo_disc_h64", "trpo_wide_h128x3", "trpo_box_h128_tanh", "trpo_disc_h64_selu"]
+TRPO_CASES = ["trpo_box_h64", "trpo_disc_h64", "trpo_wide_h128x3", "trpo_box_h128_tanh", "trpo_disc_h64_selu", "trpo_box_h256x2"]
 TRPO_RNN_CASES = ["trpo_rnn_disc_h64", "trpo_rnn_box_h64", "trpo_rnn_fp_disc36_h64", "trpo_rnn_box_h128", "trpo_rnn2_disc_h64"]
 RNN_CASES = ["rnn_box_h64", "rnn_disc_h64_mb2", "rnn_naive_h64", "rnn_fp_box_h64_mb2", "rnn_naive_fp_disc_h64",
              "rnn_fp_disc36_h64"]

@@ -105,6 +105,14 @@ def test_hatrpo_gru_gradient_fvp_and_update(i):
     _assert_all(G.check_trpo_rnn(G.RNN_SHAPES[i]), tol=TOL)
 
 
+@pytest.mark.parametrize("i", [7, 8])
+def test_hatrpo_width256_gradient_fvp_and_update(i):
+    """HATRPO on 256-wide layers (round 4): the tangent pass on the K-panel kernel (harl_mlp_panel_tangent) and the 256-wide
+    instantiation of the head FVP kernel, against the oracle: three layers / Box(20) / 211 inputs, two layers / Discrete(6)."""
+    G = _G()
+    _assert_all(G.check_trpo(G.FWD_SHAPES[i]), tol=TOL)
+
+
 @pytest.mark.parametrize("i", [0, 1])
 def test_hatrpo_composed_gru_gradient_fvp_and_update(i):
     """HATRPO on a 128-wide GRU and on two stacked 64-wide GRU layers (round 4): the Fisher-vector product's tangent through the
@@ -115,7 +123,7 @@ def test_hatrpo_composed_gru_gradient_fvp_and_update(i):
 
 @pytest.mark.parametrize("name", ["trpo_box_h64", "trpo_disc_h64", "trpo_wide_h128x3", "trpo_rnn_disc_h64", "trpo_rnn_box_h64",
                                   "trpo_rnn_fp_disc36_h64", "trpo_box_h128_tanh", "trpo_disc_h64_selu", "trpo_rnn_box_h128",
-                                  "trpo_rnn2_disc_h64"])
+                                  "trpo_rnn2_disc_h64", "trpo_box_h256x2"])
 def test_hatrpo_train_matches_reference_golden(name):
     _assert_all(_G().check_train_golden(name), tol=TOL)
 

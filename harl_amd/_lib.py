@@ -92,6 +92,7 @@ SIGNATURES = {
     "harl_trpo_cg_step": [_vp, _vp, _vp, _vp, _l, _vp, _vp],
     "harl_mlp_panel_fwd": [_vp, _l, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp],
     "harl_mlp_panel_bwd": [_vp, _vp, _vp, _vp, _l, _i, _i, _vp, _vp, _vp],
+    "harl_head_dw_rows256": [_vp, _l, _i, _vp, _vp, _i, _vp],
     "harl_mlp_panel_tangent": [_vp, _vp, _l, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "harl_reduce_scalars": [_vp, _i, _vp, _vp],
     "harl_mlp_linear": [_vp, _l, _i, _i, _vp, _vp, _vp, _vp],

@@ -206,6 +206,46 @@ extern "C" int harl_mlp_panel_bwd(const float *dz, const float *xprev, const uin
   return check_launch("harl_mlp_panel_bwd");
 }
 
+// ---- head weight gradient of a 256-wide trunk from the ROW-MAJOR head gradients [M_pad][32] (the separate pass HATRPO's
+// surrogate gradient and Fisher-vector product use; HAPPO's loss kernel fuses it):  dWp[d][f] = sum_s dhead[s][d] x_hat[s][f],
+// dbp[d] = sum_s dhead[s][d].  One thread per feature, D accumulators in registers, every workgroup a contiguous range of
+// samples and ONE partial row dWp[32][256] | dbp[32] (rows >= D zero), the layout k_dw leaves for narrower trunks.  Coverage
+// path: 0.3 GFLOP at the dexhands batch sizes.
+__global__ __launch_bounds__(PH) void k_head_dw_rows256(const float *__restrict__ dhead, long M, int D,
+                                                        const float *__restrict__ xhat, float *__restrict__ part, int n_wg) {
+  const int f = threadIdx.x;  // feature
+  const int t = f >> 5, w = f & 31, hh = (w >> 2) & 1, r = (w & 3) + 4 * (w >> 3), R = 16 * t + r;
+  const long per = (M + n_wg - 1) / n_wg;
+  const long s0 = (long)blockIdx.x * per, s1 = s0 + per < M ? s0 + per : M;
+  float acc[32], db = 0.f;
+#pragma unroll
+  for (int d = 0; d < 32; ++d) acc[d] = 0.f;
+  __shared__ float dh[32];
+  for (long s = s0; s < s1; ++s) {
+    __syncthreads();
+    if (f < 32) dh[f] = f < D ? dhead[s * DHEAD_LD + f] : 0.f;
+    __syncthreads();
+    const long slab = s >> 5;
+    const int lane = (int)(s & 31) + 32 * hh;
+    const float x = xhat[slab * (long)(PH * SLAB) + ((long)((R >> 2) * WAVE + lane)) * 4 + (R & 3)];
+#pragma unroll
+    for (int d = 0; d < 32; ++d) acc[d] += dh[d] * x;
+    if (f < 32) db += dh[f];
+  }
+  float *out = part + (long)blockIdx.x * (32 * PH + 32);
+#pragma unroll
+  for (int d = 0; d < 32; ++d) out[d * PH + f] = acc[d];
+  if (f < 32) out[32 * PH + f] = db;
+}
+
+extern "C" int harl_head_dw_rows256(const float *dhead, long M, int act_dim, const float *xhat, float *part, int n_wg,
+                                    void *stream) {
+  if (M <= 0 || n_wg <= 0) return 0;
+  if (act_dim < 1 || act_dim > 32) return bad("harl_head_dw_rows256: head width must be in [1, 32]");
+  hipLaunchKernelGGL(k_head_dw_rows256, dim3(n_wg), dim3(PH), 0, (hipStream_t)stream, dhead, M, act_dim, xhat, part, n_wg);
+  return check_launch("harl_head_dw_rows256");
+}
+
 extern "C" int harl_mlp_panel_tangent(const float *xin_dot, const float *xin, long M, int KP, const float *Wp, const float *Wdp,
                                       int D, const float *bdp, const float *xprimal, const uint32_t *mask_in,
                                       const float *rstd_in, float *xout_dot, void *stream) {

@@ -593,6 +593,8 @@ class _FlatNet(nn.Module):
             if self.wide_head:  # ATL(64) image: an ordinary two-operand weight-gradient GEMM (partial layout dWp[64][fh] | dbp[64])
                 call("harl_mlp_dw_partials", ptr(self.dhead), 0, 0, 64, ptr(fx), 0, 0, None, None, None, fh, M,
                      ptr(self.part[po[-1]:]), nwg, s, tag="dw_head")
+            elif self.panel:  # 256-wide trunk (HATRPO's separate head-gradient pass; HAPPO's loss kernel fuses it)
+                call("harl_head_dw_rows256", ptr(self.dhead), M, hdim, ptr(fx), ptr(self.part[po[-1]:]), nwg, s, tag="dw_head")
             else:
                 call("harl_mlp_dw_partials", ptr(self.dhead), 1, DHEAD_LD, hdim, ptr(fx), 0, 0, None, None, None, fh, M,
                      ptr(self.part[po[-1]:]), nwg, s, tag="dw_head")

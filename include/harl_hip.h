@@ -147,6 +147,10 @@ int harl_mlp_fwd_wide(const float *x0n, long M, int KP, const float *Wp, int D, 
  * Weight gradients: harl_mlp_dw_partials(a_kind = 0, HO = 256). */
 int harl_mlp_panel_fwd(const float *xin, long M, int KP, const float *Wp, int D, const float *bp, int HO, float *xout,
                        uint32_t *relu_mask, float *rstd, void *stream);
+/* Head weight gradient of a 256-wide trunk from the row-major head gradients [M_pad][32] (HATRPO's surrogate gradient and
+ * Fisher-vector product, hatrpo.py:95-140; HAPPO's loss kernel fuses it): n_wg partial rows dWp[32][256] | dbp[32] over
+ * contiguous sample ranges, the layout harl_mlp_dw_partials leaves for narrower trunks (combined by the same reduce). */
+int harl_head_dw_rows256(const float *dhead, long M, int act_dim, const float *xhat, float *part, int n_wg, void *stream);
 /* Forward-mode tangent of a 256-wide layer (HATRPO's Fisher-vector product, trpo_util.py:132-158, on the dexhands-shaped
  * networks): x_out_dot = LNjac(mask . (Wdp x_in + bdp [+ Wp x_in_dot])) with the PRIMAL x_hat / mask / rstd of this layer.
  * First layer: x_in = the x0n image (KP wide, D valid columns), x_in_dot = NULL (the inputs carry no tangent); hidden layers:

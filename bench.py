@@ -545,7 +545,9 @@ def main():
             out["cpu_baseline"] = cpu_baseline(w, cols, min(args.cpu_threads, os.cpu_count() or 1), reps=max(1, args.cpu_reps))
     # the other BASELINE.json workloads at their real shapes, on the SAME JSON line (after the headline region and the CPU
     # baseline, fresh runner each, a few steps): `--config <name>` gives the full record of any one of them
-    if args.other_configs and args.config == "mpe" and args.scaling == "weak" and not args.threads_per_gpu:
+    # (single-process runs only: the scaling runs time the headline workload, and an attached workload that failed on ONE rank
+    # would leave the others waiting in a collective)
+    if args.other_configs and world == 1 and args.config == "mpe" and args.scaling == "weak" and not args.threads_per_gpu:
         others = {}
         for name in ("cheetah6", "smac3s5z", "humanoid17"):
             torch.cuda.empty_cache()

@@ -273,6 +273,25 @@ def measure(w: dict, cfg_name: str, args, comm, rank: int, world: int, device, n
             else:
                 os.environ["HARL_CRITIC_STREAM"] = prev_cs
     barrier()
+    # Shader clock under THIS load (one untimed step more): a one-lane probe kernel on a side stream counts shader cycles
+    # against the constant 100 MHz counter while a whole step runs next to it (harl_clock_probe).  The matrix-pipe fractions
+    # below are computed against this clock; the nominal 2.4 GHz figure stays next to them as `*_nominal`.
+    clock_ghz = None
+    if not args.no_kernel_timing:
+        t_est = time.perf_counter()
+        one_step(r)
+        torch.cuda.synchronize()
+        est_ms = (time.perf_counter() - t_est) * 1e3
+        probe_out = torch.zeros(2, dtype=torch.int64, device=device)
+        side = torch.cuda.Stream(device=device)
+        side.wait_stream(torch.cuda.current_stream(device))
+        _lib.call("harl_clock_probe", _lib.ptr(probe_out), int(max(0.5, min(0.85 * est_ms, 900.0)) * 1e5), side.cuda_stream)
+        one_step(r)
+        torch.cuda.synchronize()
+        cyc, ticks = (int(v) for v in probe_out.tolist())
+        if ticks > 0 and cyc > 0:
+            clock_ghz = cyc / (ticks * 10e-9) / 1e9
+        barrier()
     region_tags = ROOF_TAGS
     cw = {k: v for k, v in warm_kern.items() if v["n"] > 0 and v.get("bytes")}
     if cw:
@@ -331,7 +350,7 @@ def measure(w: dict, cfg_name: str, args, comm, rank: int, world: int, device, n
             ach = cand[dom]["bytes"] / tot_s
             per_launch = cand[dom]["bytes"] / cand[dom]["n"]
             traffic, traffic_note = None, None
-            tp = next((q for q in (os.path.join(ROOT, "profiles", f"r0{k}_hbm_traffic.json") for k in (4, 3, 2)) if os.path.exists(q)),
+            tp = next((q for q in (os.path.join(ROOT, "profiles", f"r0{k}_hbm_traffic.json") for k in (5, 4, 3, 2)) if os.path.exists(q)),
                       os.path.join(ROOT, "profiles", "r04_hbm_traffic.json"))
             if os.path.exists(tp):  # PMC passes over the same kernels at this workload's shapes (tools/pmc_traffic.sh)
                 tj = json.load(open(tp))
@@ -346,18 +365,20 @@ def measure(w: dict, cfg_name: str, args, comm, rank: int, world: int, device, n
             # profiles/r03_isa_census.md) x 32.3 cycles each (profiles/r03_mfma_valu_overlap.md) over 1024 SIMDs at 2.4 GHz
             mfma_slab = {"bwd_dx_dw1": 270, "bwd_dx": 192, "fwd_fused2": 240, "fwd_fused2_k64": 288, "fwd_hidden": 192,
                          "dw_hidden": 192, "tangent_hidden": 384, "update_fwd": 315, "update_logp": 240, "update_last": 267}.get(dom)
-            pipe = None
+            pipe = pipe_nominal = None
             if mfma_slab and not w.get("rnn"):
                 slabs = Tn * n_local / 32.0
-                pipe = slabs * mfma_slab * 32.3 / (1024 * 2.4e9) / (cand[dom]["avg_ms"] * 1e-3)
+                pipe_nominal = slabs * mfma_slab * 32.3 / (1024 * 2.4e9) / (cand[dom]["avg_ms"] * 1e-3)
+                pipe = pipe_nominal * 2.4 / clock_ghz if clock_ghz else pipe_nominal
             roof = dict(kernel=dom, bound="hbm", achieved=ach / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s", frac=ach / HBM_PEAK,
-                        hbm_frac=ach / HBM_PEAK, matrix_pipe_frac=pipe,
+                        hbm_frac=ach / HBM_PEAK, matrix_pipe_frac=pipe, matrix_pipe_frac_nominal=pipe_nominal, clock_ghz=clock_ghz,
                         bound_note="streaming GEMM kernels between two roofs: `frac` = algorithmic bytes / time against the 8 TB/s "
                                    "HBM peak (the contract's figure); `matrix_pipe_frac` = the launch's bf16 MFMAs x 32.3 cycles "
-                                   "against the time all 1024 SIMDs have at the nominal 2.4 GHz (under this load the shader "
-                                   "clock measures 1.85-1.95 GHz, profiles/r04_phase_cycles_per_workgroup.txt: of the cycles "
-                                   "it actually gets the pipe is busy ~1.26x this fraction).  Neither is saturated: VALU work of "
-                                   "the exact bf16 split / LayerNorm / ReLU sits in separate phases of the same waves (DESIGN.md 3)",
+                                   "against the cycles all 1024 SIMDs get at `clock_ghz`, the shader clock MEASURED under this "
+                                   "load in an untimed step before the region (harl_clock_probe: shader cycles per 100 MHz tick "
+                                   "on a side stream); `matrix_pipe_frac_nominal` = the same against the nominal 2.4 GHz.  Neither "
+                                   "roof is saturated: VALU work of the exact bf16 split / LayerNorm / ReLU shares the issue "
+                                   "slots of the same waves (DESIGN.md 3)",
                         traffic=traffic, traffic_note=traffic_note, launches=cand[dom]["n"], avg_ms=cand[dom]["avg_ms"],
                         bytes_per_launch=per_launch,
                         timing="HIP events around every launch of the streaming kernel families inside the timed region; bytes "
@@ -380,6 +401,7 @@ def measure(w: dict, cfg_name: str, args, comm, rank: int, world: int, device, n
                 roof["single_stream"] = dict(
                     achieved=a1 / 1e9, frac=a1 / HBM_PEAK, avg_ms=ks["avg_ms"], launches=ks["n"],
                     matrix_pipe_frac=(pipe * cand[dom]["avg_ms"] / ks["avg_ms"]) if pipe else None,
+                    matrix_pipe_frac_nominal=(pipe_nominal * cand[dom]["avg_ms"] / ks["avg_ms"]) if pipe_nominal else None,
                     note=f"the same kernel family in the {instr_steps} instrumented steps after the timed region, critic chain on the "
                          "main stream (HARL_CRITIC_STREAM=0): per-launch durations without a second kernel sharing the chip")
         out = dict(
@@ -416,7 +438,16 @@ def measure(w: dict, cfg_name: str, args, comm, rank: int, world: int, device, n
             out.setdefault("end_to_end", {}).update(
                 executed_flops_per_step=per_step, executed_tflops=per_step / (dt / steps) / 1e12,
                 executed_frac_of_fp32_mfma_peak=per_step / (dt / steps) / MFMA_F32_PEAK,
-                executed_note="Linear-layer FLOPs of the launches of one instrumented step (per rank) / the timed step")
+                # ... and against the pipe the GEMMs actually run on: every fp32 product is six bf16 products there, so the
+                # speed of light of this design is the dense bf16 peak / 6 = 419 TFLOP/s of fp32-equivalent work
+                bf16x6_frac_of_bf16_mfma_peak=6.0 * per_step / (dt / steps) / MFMA_BF16_PEAK,
+                executed_note="Linear-layer FLOPs of the launches of one instrumented step (per rank) / the timed step; "
+                              "`bf16x6_frac_of_bf16_mfma_peak` = 6 x those FLOPs (the exact three-way operand split evaluates "
+                              "six bf16 products per fp32 product) against the dense bf16 MFMA peak (2516.6 TFLOP/s): how far "
+                              "the step is from the roof of the pipe it runs on -- the fp32-MFMA fraction next to it is the "
+                              "contract's figure (SURVEY.md 8d), not a statement that the step is nearly done")
+            if roof is not None:
+                roof["bf16x6_end_to_end"] = out["end_to_end"]["bf16x6_frac_of_bf16_mfma_peak"]
     return out
 
 
@@ -476,6 +507,8 @@ def main():
                     help="default run (mpe): do NOT append the three other BASELINE workloads (cheetah6, smac3s5z, humanoid17; "
                          "`--other-steps` steps each after the headline region) as `other_configs` to the JSON line")
     ap.add_argument("--other-steps", type=int, default=3)
+    ap.add_argument("--other-cpu-cols", type=int, default=-1,
+                    help="rollout threads of the bounded CPU-baseline sample attached to each `other_configs` entry (0 = skip, -1 = auto)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher check without a GPU: spawn / rendezvous (gloo) / one all-reduce, then print a line with value null")
     args = ap.parse_args()
@@ -564,8 +597,15 @@ def main():
                 others[name] = dict(metric=o["metric"], value=o["value"], ms_per_step=o["ms_per_step"], steps=o["steps"],
                                     warmup=o["warmup"], workload=o["config"]["workload"],
                                     roofline=dict(kernel=rf.get("kernel"), frac=rf.get("frac"), avg_ms=rf.get("avg_ms"),
-                                                  matrix_pipe_frac=rf.get("matrix_pipe_frac")),
+                                                  matrix_pipe_frac=rf.get("matrix_pipe_frac"), clock_ghz=rf.get("clock_ghz")),
                                     end_to_end=o.get("end_to_end"))
+                if args.other_cpu_cols != 0:  # the CPU path next to every reported number (BASELINE.json north_star): a bounded
+                    # sample of the same workload (fewer rollout threads), one warm-up + one timed update
+                    oc = args.other_cpu_cols if args.other_cpu_cols > 0 else {"cheetah6": 128, "smac3s5z": 64, "humanoid17": 8}[name]
+                    try:
+                        others[name]["cpu_baseline"] = cpu_baseline(wo, oc, min(args.cpu_threads, os.cpu_count() or 1), reps=1)
+                    except Exception as e:  # noqa: BLE001
+                        others[name]["cpu_baseline"] = dict(error=f"{type(e).__name__}: {e}")
         if rank == 0:
             out["other_configs"] = others
     if rank == 0:

@@ -348,8 +348,11 @@ __global__ __launch_bounds__(256) void k_dist_rows(const float *__restrict__ hea
     }
     if (argmax_out) argmax_out[i * n_heads + hd] = (float)(best - lo);
     if (logp) {
+      // a stored action outside [0, hi - lo) (padding rows, a corrupted buffer, a wrong nvec) must not become an out-of-bounds
+      // read: the torch gather this replaces would have raised; here the log-prob of such a row is NaN
       const int a = actions ? (int)actions[i * n_heads + hd] : best - lo;
-      const float lp = head[i * D + lo + a];
+      const bool a_ok = a >= 0 && a < hi - lo;
+      const float lp = a_ok ? head[i * D + lo + a] : __builtin_nanf("");
       if (sum_heads) lsum += lp;
       else logp[i * n_heads + hd] = lp;
     }
@@ -381,6 +384,32 @@ __global__ void k_moments_mean(const double *__restrict__ mom, float *__restrict
 extern "C" int harl_moments_mean(const double *moments3, float *mean_out, void *stream) {
   hipLaunchKernelGGL(k_moments_mean, dim3(1), dim3(1), 0, (hipStream_t)stream, moments3, mean_out);
   return check_launch("harl_moments_mean");
+}
+
+// Shader-clock probe (measurement aid of bench.py, no counterpart in the reference): ONE lane waits for `ticks` periods of the
+// constant 100 MHz counter (s_memrealtime) and reports how many shader cycles (s_memtime) went by in the meantime.  Launched
+// on a side stream next to a training step it gives the clock the chip actually sustains under THAT load (the matrix-pipe
+// fraction of the bench line was computed against the nominal 2.4 GHz before).  Bounded: the realtime counter always advances.
+__global__ void k_clock_probe(long long *__restrict__ out, long long ticks) {
+  if (threadIdx.x != 0) return;
+  const long long r0 = __builtin_amdgcn_s_memrealtime();
+  const long long c0 = __builtin_readcyclecounter();
+  long long r;
+  do {
+    __builtin_amdgcn_s_sleep(64);
+    r = __builtin_amdgcn_s_memrealtime();
+  } while (r - r0 < ticks);
+  out[0] = __builtin_readcyclecounter() - c0;
+  out[1] = r - r0;
+}
+
+extern "C" int harl_clock_probe(long long *cycles_ticks, long ticks, void *stream) {
+  if (ticks <= 0 || ticks > 100000000L) {  // at most one second
+    set_error("harl_clock_probe: ticks must be in (0, 1e8]");
+    return -1;
+  }
+  hipLaunchKernelGGL(k_clock_probe, dim3(1), dim3(64), 0, (hipStream_t)stream, cycles_ticks, (long long)ticks);
+  return check_launch("harl_clock_probe");
 }
 
 // =============================================================================================
@@ -1467,7 +1496,12 @@ static CgScratch *cg_scratch_of(hipStream_t s) {
   if (it != pool.end()) return it->second;
   CgScratch *p = nullptr;
   if (hipMalloc(reinterpret_cast<void **>(&p), sizeof(CgScratch)) != hipSuccess) return nullptr;
-  if (hipMemset(p, 0, sizeof(CgScratch)) != hipSuccess) return nullptr;
+  // zeroed ON THE TARGET STREAM (torch streams are non-blocking: a null-stream memset is not ordered against them), once; the
+  // kernels leave the barrier words at zero themselves (last workgroup out)
+  if (hipMemsetAsync(p, 0, sizeof(CgScratch), s) != hipSuccess) {
+    (void)hipFree(p);
+    return nullptr;
+  }
   pool.emplace(key, p);
   return p;
 }

@@ -25,13 +25,15 @@ class Comm:
         self.rank = dist.get_rank(group) if self.enabled else 0
 
     def second_group(self) -> "Comm":
-        """A communicator of its own over the same ranks (``dist.new_group``: every rank must call this at the same point of
-        its program -- the runner's constructor does).  The critic's update gets one: its collectives then live in a queue
-        of their own, ordered only among themselves, so the critic's chain can run on its own stream next to the actors'
-        (runner.train) without the two chains' collectives having to interleave identically on every rank.  Each
-        communicator sees its collectives in host program order, which is the same on all ranks (same code path, the
-        minibatch structure does not depend on the rank).  Returns ``self`` when there is nothing to split."""
-        if not self.enabled or os.environ.get("HARL_CRITIC_GROUP", "1") == "0":
+        """A communicator of its own over the same ranks (``dist.new_group`` is COLLECTIVE: every rank must call this at the
+        same point of its program -- the runner's constructor and the drop-in's patched constructor do, never a lazy path).
+        Opt-in (``HARL_CRITIC_GROUP=1``): with it the critic's update keeps a stream of its own under data parallelism,
+        its collectives living in a queue ordered only among themselves.  Two communicators in flight on one device are
+        outside what NCCL / RCCL document as safe (the two collectives may start in a different order on different ranks and
+        hang if their kernels cannot co-run), and no multi-GPU box has validated it, so the DEFAULT is one communicator and
+        one stream under data parallelism (the round-3 behaviour; single-GPU runs keep the critic stream either way).
+        Returns ``self`` when there is nothing to split."""
+        if not self.enabled or os.environ.get("HARL_CRITIC_GROUP", "0") != "1":
             return self
         g = dist.new_group(ranks=None if self.group is None else dist.get_process_group_ranks(self.group),
                            backend=dist.get_backend(self.group))

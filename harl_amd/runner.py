@@ -84,6 +84,7 @@ class OnPolicyHARunner:
         else:
             self.critic_buffer = OnPolicyCriticBufferFP(cb_args, share_obs_space, self.num_agents, device=self.device)
         self.value_normalizer = ValueNorm(1, device=self.device) if algo_args["train"]["use_valuenorm"] else None
+        self._critic_comm = self.comm.second_group()  # collective: every rank passes here, in constructor order
         self._init_update_state(n_global)
         if algo_args["train"].get("model_dir") is not None:  # on_policy_base_runner.py:168-169
             self.restore(algo_args["train"]["model_dir"])
@@ -102,11 +103,10 @@ class OnPolicyHARunner:
         shard = (self.n_global, self.col_lo, self.col_hi) if self.comm.enabled else None
         for x in list(self.actor) + [self.critic]:
             x.comm, x.shard = self.comm, shard
-        # the critic's collectives go through a communicator of their own (dist.Comm.second_group): its update then runs on
-        # its own stream next to the actors' under data parallelism too
-        if getattr(self, "_critic_comm", None) is None:
-            self._critic_comm = self.comm.second_group()
-        self.critic.comm = self._critic_comm
+        # HARL_CRITIC_GROUP=1: the critic's collectives go through a communicator of their own and its update keeps its own
+        # stream under data parallelism.  The group is created by the constructors (collective call: never from this lazy
+        # path, where ranks may arrive at different times); without one the critic shares the actors' communicator + stream.
+        self.critic.comm = getattr(self, "_critic_comm", None) or self.comm
         self._logp_old = None
         self._counts_host = None
         self._update_state_ready = True

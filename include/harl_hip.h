@@ -73,6 +73,10 @@ int harl_dist_rows(const float *head, long M, int act_dim, int kind, const float
 /* mean_out[0] = (float)(moments3[0] / moments3[2]) of a harl_masked_moments triple: the (active-mask-weighted) mean of the
  * entropy rows that evaluate_actions returns (act.py:104-157) */
 int harl_moments_mean(const double *moments3, float *mean_out, void *stream);
+/* Measurement aid (bench.py; nothing in the reference corresponds to it): one lane waits `ticks` periods of the constant
+ * 100 MHz counter and writes {shader cycles elapsed, ticks elapsed} to cycles_ticks[0..1] (int64, device) -- the shader clock
+ * under whatever runs next to it on other streams.  ticks in (0, 1e8]. */
+int harl_clock_probe(long long *cycles_ticks, long ticks, void *stream);
 /* adv_out = (adv - mean) / (std + 1e-5) with mean/std from `moments3` (happo.py:127). */
 int harl_adv_normalize(const float *adv, const double *moments3, float *adv_out, long n, void *stream);
 

@@ -1223,14 +1223,92 @@ def check_full_size_properties() -> Dict[str, float]:
     return out
 
 
-def _bench_config_runs(n_threads: int, with_f64: bool, keep_grad: bool = False, logp: str = "recipe", n_pert: int = 0):
-    """HIP step + oracle run(s) of the BENCH configuration on identical contents (see check_bench_config_parity).  Returns
-    (hip dict, {"f32": .., "f64": .., "pert0": ..} oracle dicts, names/shapes of the actor / critic parameter tensors, meta).
-    ``n_pert`` further fp32 oracle runs start from parameters moved by one ulp (``_perturb_one_ulp``): how far the reference's
-    own fp32 figures move under the smallest change fp32 can express."""
+def _oracle_bench_run(payload: dict, tag: str, dt_name: str, pert_seed, keep_grad: bool) -> dict:
+    """One oracle compute() + ha_train() on the host copies in ``payload`` (see _bench_config_runs).  Runs either in this
+    process or -- on hosts with enough cores -- in a worker process of its own (tests/oracle_worker.py), so that the fp32 /
+    float64 / one-ulp runs of a full-size comparison take the wall time of the slowest instead of their sum."""
     import time as _time
     import bench
-    w = bench.WORKLOADS["mpe"]
+    w = bench.WORKLOADS[payload["workload"]]
+    T, n_threads = w["T"], payload["n_threads"]
+    args = bench.algo_args(n_threads, T, w)
+    cfg = O.PathConfig.from_reference_dicts(args["train"], args["model"], args["algo"])
+    torch.set_num_threads(int(os.environ.get("HARL_ORACLE_THREADS") or min(16, os.cpu_count() or 1)))
+    dt = dict(f32=torch.float32, f64=torch.float64)[dt_name]
+    actor_sd, critic_sd, abuf_np, cbuf_np, st0 = (payload[k] for k in ("actor_sd", "critic_sd", "abuf", "cbuf", "st0"))
+    O.set_work_dtype(dt)
+    try:
+        t0 = _time.perf_counter()
+        torch.set_rng_state(payload["rng0"])
+        actors = [O.OracleHAPPO({k: v.clone() for k, v in sd.items()}, cfg) for sd in actor_sd]
+        critic = O.OracleVCritic({k: v.clone() for k, v in critic_sd.items()}, cfg)
+        if pert_seed is not None:
+            _perturb_one_ulp([a_.net for a_ in actors] + [critic.net], pert_seed)
+        abufs = [O.OracleActorBuffer(d["obs"].copy(), d["actions"].copy(), d["logp"].copy(), d["masks"].copy(), d["active"].copy(),
+                                     None) for d in abuf_np]
+        cbuf = O.OracleCriticBufferEP(cbuf_np["share_obs"].copy(), cbuf_np["rewards"].copy(), cbuf_np["value_preds"].copy(),
+                                      cbuf_np["masks"].copy(), cbuf_np["bad_masks"].copy())
+        vn = O.OracleValueNorm()
+        vn.load_state(dict(running_mean=float(st0[0]), running_mean_sq=float(st0[1]), debiasing_term=float(st0[2])))
+        with torch.no_grad():  # compute(): the critic's value of slot T (on_policy_base_runner.py:462-484)
+            nv = critic.get_values(cbuf_np["share_obs"][-1]).detach().double().numpy().reshape(-1, 1)
+        # identical scan inputs on both sides: the fp32 oracle's compute_returns is fed the HIP value of slot T (which is
+        # compared with the oracle's own first)
+        cbuf.compute_returns(payload["next_value_hip"].copy() if tag == "f32" else nv.astype(np.float64 if dt == torch.float64 else np.float32),
+                             vn, cfg)
+        infos, cinfo, extra_ = O.ha_train(actors, critic, abufs, cbuf, vn, cfg, keep_grad=keep_grad)
+        return dict(nv=nv, adv=np.asarray(extra_["advantages"]), returns=np.asarray(cbuf.returns).copy(), infos=infos, cinfo=cinfo,
+                    atr=[np.array([[u["policy_loss"], u["dist_entropy"], u["grad_norm"], u["ratio"]] for u in a_.trace])
+                         for a_ in actors],
+                    ctr=np.array([[u["value_loss"], u["grad_norm"]] for u in critic.trace]),
+                    fin=[np.asarray(a_.net.flat(), dtype=np.float64) for a_ in actors],
+                    grads=[[np.asarray(u["grad"], dtype=np.float64) for u in a_.trace] for a_ in actors] if keep_grad else None,
+                    cfin=np.asarray(critic.net.flat(), dtype=np.float64), vn=vn.state(), rng=torch.get_rng_state(),
+                    seconds=_time.perf_counter() - t0)
+    finally:
+        O.set_work_dtype(torch.float32)
+
+
+def _oracle_bench_runs(payload: dict, plan, keep_grad: bool) -> dict:
+    """All oracle runs of ``plan`` [(tag, dtype name, one-ulp seed | None)].  With >= 64 host CPUs (the GPU boxes have 256) each
+    run gets a process of its own (16 torch threads each; the payload travels through one file in a temporary directory);
+    otherwise they run one after the other in this process.  Same code either way (_oracle_bench_run)."""
+    import subprocess
+    import sys
+    import tempfile
+    mode = os.environ.get("HARL_ORACLE_PARALLEL", "auto")  # "0": in-process, "force": worker processes whatever the host
+    if mode != "force" and ((os.cpu_count() or 1) < 64 or len(plan) == 1 or mode == "0"):
+        return {tag: _oracle_bench_run(payload, tag, dtn, seed, keep_grad) for tag, dtn, seed in plan}
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory(prefix="harl_oracle_") as td:
+        pin = os.path.join(td, "payload.pt")
+        torch.save(payload, pin)
+        procs = []
+        for tag, dtn, seed in plan:
+            pout = os.path.join(td, f"{tag}.pt")
+            env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""), OMP_NUM_THREADS=os.environ.get("HARL_ORACLE_THREADS") or "16",
+                       HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+            cmd = [sys.executable, "-m", "tests.oracle_worker", pin, pout, tag, dtn, "none" if seed is None else str(seed), str(int(keep_grad))]
+            procs.append((tag, pout, subprocess.Popen(cmd, cwd=root, env=env)))
+        runs = {}
+        for tag, pout, pr in procs:
+            rc = pr.wait()
+            if rc != 0:
+                raise RuntimeError(f"oracle worker {tag} failed with exit code {rc}")
+            runs[tag] = torch.load(pout, weights_only=False)
+    return runs
+
+
+def _bench_config_runs(n_threads: int, with_f64: bool, keep_grad: bool = False, logp: str = "recipe", n_pert: int = 0,
+                       workload: str = "mpe"):
+    """HIP step + oracle run(s) of a BENCH configuration on identical contents (see check_bench_config_parity).  Returns
+    (hip dict, {"f32": .., "f64": .., "pert0": ..} oracle dicts, names/shapes of the actor / critic parameter tensors, meta).
+    ``n_pert`` further fp32 oracle runs start from parameters moved by one ulp (``_perturb_one_ulp``): how far the reference's
+    own fp32 figures move under the smallest change fp32 can express.  ``workload``: a feed-forward HAPPO entry of
+    bench.WORKLOADS ("mpe" = BASELINE configs[1], "cheetah6" = configs[2] at one GPU's share)."""
+    import bench
+    w = bench.WORKLOADS[workload]
+    assert w["algo"] == "happo" and not w.get("rnn") and not w["disc"], "feed-forward Box HAPPO workloads"
     T, A = w["T"], w["A"]
     torch.manual_seed(1)
     r = bench.build_gpu_runner(w, n_threads, 0, 1, DEV, logp)
@@ -1277,48 +1355,36 @@ def _bench_config_runs(n_threads: int, with_f64: bool, keep_grad: bool = False, 
     # ---- oracle on the same contents
     args = bench.algo_args(n_threads, T, w)
     cfg = O.PathConfig.from_reference_dicts(args["train"], args["model"], args["algo"])
-    torch.set_num_threads(min(16, os.cpu_count() or 1))
-    runs = {}
-    plan = [("f32", torch.float32, None)] + ([("f64", torch.float64, None)] if with_f64 else []) + \
-           [(f"pert{k}", torch.float32, 977 + k) for k in range(n_pert)]
-    for tag, dt, pert_seed in plan:
-        O.set_work_dtype(dt)
-        try:
-            t0 = _time.perf_counter()
-            torch.set_rng_state(rng0)
-            actors = [O.OracleHAPPO({k: v.clone() for k, v in sd.items()}, cfg) for sd in actor_sd]
-            critic = O.OracleVCritic({k: v.clone() for k, v in critic_sd.items()}, cfg)
-            if pert_seed is not None:
-                _perturb_one_ulp([a_.net for a_ in actors] + [critic.net], pert_seed)
-            abufs = [O.OracleActorBuffer(d["obs"].copy(), d["actions"].copy(), d["logp"].copy(), d["masks"].copy(), d["active"].copy(),
-                                         None) for d in abuf_np]
-            cbuf = O.OracleCriticBufferEP(cbuf_np["share_obs"].copy(), cbuf_np["rewards"].copy(), cbuf_np["value_preds"].copy(),
-                                          cbuf_np["masks"].copy(), cbuf_np["bad_masks"].copy())
-            vn = O.OracleValueNorm()
-            vn.load_state(dict(running_mean=float(st0[0]), running_mean_sq=float(st0[1]), debiasing_term=float(st0[2])))
-            with torch.no_grad():  # compute(): the critic's value of slot T (on_policy_base_runner.py:462-484)
-                nv = critic.get_values(cbuf_np["share_obs"][-1]).detach().double().numpy().reshape(-1, 1)
-            # identical scan inputs on both sides: the fp32 oracle's compute_returns is fed the HIP value of slot T (which is
-            # compared with the oracle's own first)
-            cbuf.compute_returns(next_value_hip.copy() if tag == "f32" else nv.astype(np.float64 if dt == torch.float64 else np.float32),
-                                 vn, cfg)
-            infos, cinfo, extra_ = O.ha_train(actors, critic, abufs, cbuf, vn, cfg, keep_grad=keep_grad)
-            runs[tag] = dict(nv=nv, adv=np.asarray(extra_["advantages"]), returns=np.asarray(cbuf.returns).copy(), infos=infos, cinfo=cinfo,
-                             atr=[np.array([[u["policy_loss"], u["dist_entropy"], u["grad_norm"], u["ratio"]] for u in a_.trace])
-                                  for a_ in actors],
-                             ctr=np.array([[u["value_loss"], u["grad_norm"]] for u in critic.trace]),
-                             fin=[np.asarray(a_.net.flat(), dtype=np.float64) for a_ in actors],
-                             grads=[[np.asarray(u["grad"], dtype=np.float64) for u in a_.trace] for a_ in actors] if keep_grad else None,
-                             cfin=np.asarray(critic.net.flat(), dtype=np.float64), vn=vn.state(), rng=torch.get_rng_state(),
-                             seconds=_time.perf_counter() - t0)
-        finally:
-            O.set_work_dtype(torch.float32)
+    plan = [("f32", "f32", None)] + ([("f64", "f64", None)] if with_f64 else []) + \
+           [(f"pert{k}", "f32", 977 + k) for k in range(n_pert)]
+    payload = dict(workload=workload, n_threads=n_threads, actor_sd=actor_sd, critic_sd=critic_sd, abuf=abuf_np, cbuf=cbuf_np,
+                   st0=st0, rng0=rng0, next_value_hip=next_value_hip)
+    runs = _oracle_bench_runs(payload, plan, keep_grad)
     hip = dict(next_value=next_value_hip, returns=returns_hip, rng=rng_hip, atr=gtr, ctr=gctr, infos=ginfos, cinfo=gcinfo,
                fin=gfin, cfin=gcfin, vn=gvn, grads=gtaps if keep_grad else None)
     return hip, runs, shapes, dict(T=T, A=A, actor_sd=actor_sd, abuf=abuf_np, cfg=cfg)
 
 
-def check_bench_config_parity(logp: str = "recipe", n_threads: int = 4096, n_pert: int = 2) -> Dict[str, float]:
+def dump_parity(name: str, out: dict) -> None:
+    """Keep a parity check's result dict as JSON under gpurun_out/parity/ (HARL_PARITY_DIR overrides): `pytest -q` hides the
+    printed figures, and gpurun merges that directory back from the GPU box; the round's copies live in profiles/."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = os.environ.get("HARL_PARITY_DIR") or os.path.join(root, "gpurun_out", "parity")
+    try:
+        os.makedirs(d, exist_ok=True)
+        sha = None
+        if os.path.exists(os.path.join(root, ".git_sha")):
+            sha = open(os.path.join(root, ".git_sha")).read().strip()
+        rec = dict(check=name, git_sha=sha, device=torch.cuda.get_device_name(0) if torch.cuda.is_available() else None,
+                   figures={k: v for k, v in out.items() if isinstance(v, (int, float, str))})
+        with open(os.path.join(d, name + ".json"), "w") as f:
+            json.dump(rec, f, indent=1, sort_keys=True)
+    except OSError:
+        pass
+
+
+def check_bench_config_parity(logp: str = "recipe", n_threads: int = 4096, n_pert: int = 2, workload: str = "mpe") -> Dict[str, float]:
     """The BENCH configuration itself against the oracle: exactly what ``bench.py`` times -- BASELINE.json
     configs[1], T = 200, n_rollout_threads = 4096, 3 agents, obs 18 / share_obs 54 / Box 5, MLP [128, 128], 5 + 5 epochs, fixed
     agent order, recipe log-probs -- built by ``bench.build_gpu_runner``; buffers, weights and ValueNorm state are copied to the
@@ -1342,7 +1408,7 @@ def check_bench_config_parity(logp: str = "recipe", n_threads: int = 4096, n_per
         distance from the same update in float64 and how far it moves when its initial parameters move by one ulp (``n_pert``
         further fp32 runs) -- a rare event on one heavy sample is not a property of one table entry.  Reported as ``*_excess``."""
     out: Dict[str, float] = {}
-    hip, runs, _shapes, meta = _bench_config_runs(n_threads, True, logp=logp, n_pert=n_pert)
+    hip, runs, _shapes, meta = _bench_config_runs(n_threads, True, logp=logp, n_pert=n_pert, workload=workload)
     T, A = meta["T"], meta["A"]
     o, o64 = runs["f32"], runs["f64"]
     perts = [runs[k] for k in sorted(runs) if k.startswith("pert")]
@@ -1397,6 +1463,8 @@ def check_bench_config_parity(logp: str = "recipe", n_threads: int = 4096, n_per
     out["_critic_oracle_f32_vs_f64_vec_rel"] = vec_rel_err(o["cfin"], o64["cfin"])
     out["critic_final_param_excess"] = vec_excess(hip["cfin"], o["cfin"], o64["cfin"],
                                                   sens=max([vec_rel_err(pr["cfin"], o["cfin"]) for pr in perts], default=None))
+    out["_oracle_wall_seconds_max"] = float(max(v["seconds"] for v in runs.values()))
+    dump_parity(f"bench_config_parity_{workload}_{logp}", out)
     return out
 
 

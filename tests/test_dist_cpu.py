@@ -83,6 +83,8 @@ def _worker(rank, world, port, q):
         keep = [int(x) for x in perm.tolist() if lo <= x % N < hi]
         # the critic's communicator (Comm.second_group): a queue of its own over the same ranks; collectives of the two
         # communicators interleaved in program order give the two independent sums
+        assert comm.second_group() is comm  # opt-in: the default is ONE communicator
+        os.environ["HARL_CRITIC_GROUP"] = "1"
         c2 = comm.second_group()
         assert c2 is not comm and c2.enabled and c2.world_size == world and c2.rank == rank
         ta, tb = torch.tensor([1.0 + rank], dtype=torch.float64), torch.tensor([10.0 * (1 + rank)], dtype=torch.float64)

@@ -1,0 +1,42 @@
+"""The worker-process path of the full-size parity checks (tests/gpu_checks._oracle_bench_runs) without a GPU: the same
+oracle run in this process and in a `python -m tests.oracle_worker` child must agree bit for bit."""
+import numpy as np
+import torch
+
+
+def _payload(n_threads=4):
+    import bench
+    from harl_amd.synthetic import Shapes, actor_param_shapes, critic_param_shapes, make_buffers, synthetic_state_dict
+    w = bench.WORKLOADS["mpe"]
+    sh = Shapes(T=w["T"], N=n_threads, A=w["A"], obs_dim=w["obs"], share_obs_dim=w["sobs"], act_dim=w["act"], discrete=False,
+                hidden_sizes=w["hidden"])
+    d = make_buffers(sh, seed=5)
+    t = lambda sd: {k: torch.from_numpy(v) for k, v in sd.items()}  # noqa: E731
+    return dict(workload="mpe", n_threads=n_threads,
+                actor_sd=[t(synthetic_state_dict(actor_param_shapes(sh, True, False), 10 + a)) for a in range(w["A"])],
+                critic_sd=t(synthetic_state_dict(critic_param_shapes(sh, True, False), 99)),
+                abuf=[dict(obs=d.obs[a], actions=d.actions[a], logp=d.action_log_probs[a], masks=d.masks[a], active=d.active_masks[a])
+                      for a in range(w["A"])],
+                cbuf=dict(share_obs=d.share_obs, rewards=d.rewards, value_preds=d.value_preds, masks=d.critic_masks,
+                          bad_masks=d.bad_masks),
+                st0=np.zeros(3, dtype=np.float32), rng0=torch.get_rng_state(),
+                next_value_hip=d.value_preds[-1].copy())
+
+
+def test_worker_process_matches_in_process_run(monkeypatch):
+    from tests import gpu_checks as G
+    torch.manual_seed(3)
+    pl = _payload()
+    plan = [("f32", "f32", None), ("pert0", "f32", 977)]
+    monkeypatch.setenv("HARL_ORACLE_THREADS", "2")  # two workers at once on a small CI host
+    monkeypatch.setenv("HARL_ORACLE_PARALLEL", "0")
+    a = G._oracle_bench_runs(pl, plan, False)
+    monkeypatch.setenv("HARL_ORACLE_PARALLEL", "force")
+    b = G._oracle_bench_runs(pl, plan, False)
+    for tag in ("f32", "pert0"):
+        assert np.array_equal(a[tag]["returns"], b[tag]["returns"])
+        for x, y in zip(a[tag]["atr"], b[tag]["atr"]):
+            assert np.array_equal(x, y)
+        assert np.array_equal(a[tag]["cfin"], b[tag]["cfin"])
+        assert torch.equal(a[tag]["rng"], b[tag]["rng"])
+    assert not np.array_equal(a["f32"]["cfin"], a["pert0"]["cfin"])  # the one-ulp twin really is another run

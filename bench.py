@@ -254,7 +254,7 @@ def measure(w: dict, cfg_name: str, args, comm, rank: int, world: int, device, n
     # events on its launch stream.  Which family that is, is decided in the last warm-up step, where all of them are
     # bracketed (single stream): an event pair between two kernels keeps the second from starting under the first one's tail, and bracketing
     # all ~20 families inside the region cost 2.5-3 % of the step (MPE; 10-15 % for the launch-heavy 17-agent HATRPO step).
-    ROOF_TAGS = ("fwd_fused2", "fwd_fused2_k64", "fwd_hidden", "bwd_dx", "bwd_dx_dw1", "dw_hidden", "fwd_wide", "dw_input",
+    ROOF_TAGS = ("fwd_fused2", "fwd_fused2_k64", "fwd_hidden", "bwd_dx", "bwd_dx_dw1", "bwd_full", "bwd_full_dw1", "dw_hidden", "fwd_wide", "dw_input",
                  "tangent_wide", "tangent_hidden", "gru_fwd", "gru_bwd", "update_fwd", "update_bwd", "update_logp",
                  "update_fwd_critic", "update_last", "update_last_critic", "fwd_panel", "bwd_panel")
     warm_kern = {}
@@ -363,7 +363,7 @@ def measure(w: dict, cfg_name: str, args, comm, rank: int, world: int, device, n
                                     f"{per_launch / 1e9:.4f} GB algorithmic per launch in this run")
             # the same launches on the matrix pipe: bf16 MFMAs per 32-sample slab (static census of the compiled kernels,
             # profiles/r03_isa_census.md) x 32.3 cycles each (profiles/r03_mfma_valu_overlap.md) over 1024 SIMDs at 2.4 GHz
-            mfma_slab = {"bwd_dx_dw1": 270, "bwd_dx": 192, "fwd_fused2": 240, "fwd_fused2_k64": 288, "fwd_hidden": 192,
+            mfma_slab = {"bwd_dx_dw1": 270, "bwd_dx": 192, "bwd_full": 384, "bwd_full_dw1": 462, "fwd_fused2": 240, "fwd_fused2_k64": 288, "fwd_hidden": 192,
                          "dw_hidden": 192, "tangent_hidden": 384, "update_fwd": 315, "update_logp": 240, "update_last": 267}.get(dom)
             pipe = pipe_nominal = None
             if mfma_slab and not w.get("rnn"):

@@ -51,6 +51,7 @@ SIGNATURES = {
                             _vp, _vp],
     "harl_mlp_fwd_hidden": [_vp, _l, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "harl_mlp_bwd_dx": [_vp, _vp, _vp, _vp, _l, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _vp],
+    "harl_mlp_bwd_dx_dw": [_vp, _vp, _vp, _vp, _l, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _vp],
     "harl_mlp_dw_partials": [_vp, _i, _i, _i, _vp, _i, _l, _vp, _vp, _vp, _i, _l, _vp, _i, _vp],
     "harl_mlp_dw_partials_multi": [_i, _vp, _vp, _vp, _i, _i, _l, _i, _vp],
     "harl_reduce_partials": [_vp, _i, _l, _vp, _vp],

@@ -1198,6 +1198,322 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_dw_tr_multi(DwMulti P, long n
   dw_tr_body<MT, NT>(P.a[blockIdx.y], P.b[blockIdx.y], n_slabs, P.part[blockIdx.y], (long)KP * SLAB, 0, KP);
 }
 
+// =============================================================================================
+// k_bwd_dx_dw: the WHOLE backward of one hidden Linear(128 -> 128) and the relu + LayerNorm in front of it in ONE persistent
+// launch (round 5): dz_prev = LNrelu'(Wp^T dz), dW' += dz^T x_hat_prev, db' += sum dz, and -- first-layer variant, KT = 1 --
+// dW_1' += dz_1^T x0n.  It replaces the pair harl_mlp_dw_partials(dz, x_hat_prev) + harl_mlp_bwd_dx(...), which streamed the same
+// two operands (dz 512 B + x_hat_prev 512 B per sample) from HBM one after the other: half of the MPE step's time and 17 of its
+// 58 GB.  Matches autograd through MLPLayer (harl/models/base/mlp.py:25-38, happo.py:93-100).
+//
+// One workgroup per CU, four waves, 148 KiB of LDS: the three split images of Wp^T (96 KiB, as k_bwd_dx) and ONE slab's
+// transposition buffer of k_dw_tr (48 KiB).  A super-round = four slabs, one per wave:
+//   O part (the owner's slab, k_bwd_dx's body): dz already split (below) -> 192 MFMAs -> LayerNorm/ReLU backward -> dz_prev
+//     (stored, KT = 0) or the first-layer weight gradient on the matrix-pipe transposes (KT = 1, mfma_transpose.h);
+//   D part, four rounds, one per slab of the super-round (k_dw_tr's body): every wave fetches a quarter of the slab's dz and
+//     x_hat_prev pieces again (from L2 / the infinity cache: the owners touched them microseconds ago, so HBM sees them once),
+//     splits them, stores them into the transposition buffer; barrier; each wave multiplies its 1 x 4 output tiles (48 MFMAs).
+// The point of having both in one instruction stream is the FILLERS: a wave has one MFMA in flight for 32 cycles but needs ~12 of
+// issue for it, and up to five VALU instructions placed BETWEEN two MFMAs are free (profiles/r03_mfma_valu_overlap.md).  The D
+// rounds' MFMA phases are otherwise pure matrix work, so the exact operand split of the NEXT round's pieces (32 chunks of 5-7
+// VALU) and of the owner's NEXT slab of dz (64 chunks per super-round: the 2.2k cycles k_bwd_dx spends in "split dz" per slab)
+// are dealt out one chunk per MFMA, pinned with sched_barrier (source order is honoured exactly).
+// FILL = false runs the same chunks as a block in front of each MFMA phase (A/B: what the interleaving buys).
+// Per-workgroup partial rows in the layout of harl_reduce_partials_multi: dW' by tiles straight from the accumulators (the
+// waves own disjoint row tiles), dW_1' through finish_partials; rows gridDim.x .. n_part_rows-1 of both arenas are cleared.
+// =============================================================================================
+__device__ __forceinline__ void split_stage1(float f0, float f1, unsigned &p1, float &r0, float &r1) {
+  const unsigned b0 = __float_as_uint(f0), b1 = __float_as_uint(f1);
+  p1 = __builtin_amdgcn_perm(b1, b0, 0x07060302u);
+  r0 = f0 - __uint_as_float(b0 & 0xffff0000u);
+  r1 = f1 - __uint_as_float(b1 & 0xffff0000u);
+}
+__device__ __forceinline__ void split_stage2(float r0, float r1, unsigned &p2, unsigned &p3) {
+  const unsigned c0 = __float_as_uint(r0), c1 = __float_as_uint(r1);
+  p2 = __builtin_amdgcn_perm(c1, c0, 0x07060302u);
+  const float q0 = r0 - __uint_as_float(c0 & 0xffff0000u), q1 = r1 - __uint_as_float(c1 & 0xffff0000u);
+  p3 = __builtin_amdgcn_perm(__float_as_uint(q1), __float_as_uint(q0), 0x07060302u);
+}
+
+constexpr int BDW_SQ = (128 / 16) * 128 + 8, BDW_IMG = 8 * BDW_SQ;  // k_dw_tr's image geometry at H = 128
+constexpr size_t bdw_lds_bytes() { return split_image_bytes(128, 128) + (size_t)6 * BDW_IMG; }
+
+template <int KT, bool FILL>
+__global__ __launch_bounds__(WG_THREADS, 1) void k_bwd_dx_dw(
+    const float *__restrict__ dz, const float *__restrict__ xprev, const uint32_t *__restrict__ mask_prev,
+    const float *__restrict__ rstd_prev, const float *__restrict__ Wp, float *__restrict__ dz_prev, long n_slabs,
+    const float *__restrict__ x0n, float *__restrict__ dw1_part, float *__restrict__ dw2_part, int n_part_rows) {
+  constexpr int H = 128, MT = 4, NJ = 8, NR = 64, KPF = 32, NPW = 4;  // NPW: A pieces (and B pieces) per wave and slab
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  PHASE_BEGIN();
+  u32x4 *img = reinterpret_cast<u32x4 *>(lds);
+  unsigned char *Ab = reinterpret_cast<unsigned char *>(img + 3 * MT * NJ * 64);  // [3 terms][BDW_IMG]: dz^T staging
+  unsigned char *Bb = Ab + 3 * BDW_IMG;                                           // [3 terms][BDW_IMG]: x_hat_prev^T staging
+  stage_split_matrix<H, H, true, WG_THREADS>(img, Wp);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = wave_id();
+  const int i = lane & 31, h = lane >> 5;
+  const u32x4 *wl = img + lane;
+  const long sr_stride = (long)gridDim.x * WAVES_PER_WG;
+  const long base0 = (long)blockIdx.x * WAVES_PER_WG;
+
+  // ---- persistent accumulators
+  f32x16 acc2[4];                 // dW' tiles (row tile = wave, column tiles 0..3)
+  f32x16 acc1[KT > 0 ? 4 : 1];    // dW_1' tiles (KT = 1)
+  float dbs[KT > 0 ? 4 : 1];      // db_1' (per-lane sums over the lane's samples)
+  float dbacc[NPW][4];            // db' of this wave's A pieces (per-lane sums)
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc2[b][r] = 0.f;
+#pragma unroll
+  for (int a = 0; a < (KT > 0 ? 4 : 1); ++a) {
+    dbs[a] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc1[a][r] = 0.f;
+  }
+#pragma unroll
+  for (int u = 0; u < NPW; ++u)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) dbacc[u][c] = 0.f;
+
+  // ---- D-part state: this wave's eight float4 pieces of a slab (A: dz pieces 4 wave + u, B: x_hat pieces 4 wave + u) and
+  // their split terms sp[piece][term] = {pair 0, pair 1} (one ds_write_b64 each)
+  f32x4 pr[2 * NPW];
+  u32x2_t sp[2 * NPW][3];
+  auto d_load = [&](long ds) {
+#pragma unroll
+    for (int u = 0; u < 2 * NPW; ++u) {
+      const float *src = (u < NPW ? dz : xprev) + ds * (long)(H * SLAB);
+      pr[u] = (reinterpret_cast<const f32x4 *>(src) + lane)[(NPW * wave + (u & (NPW - 1))) * WAVE];
+    }
+  };
+  float rr0 = 0.f, rr1 = 0.f;  // remainders between the two stages of a pair's split
+  // D chunk k (0..31): piece k>>2, pair (k>>1)&1, stage k&1
+  auto d_chunk = [&](int k) {
+    const int u = k >> 2, c2 = (k >> 1) & 1;
+    if ((k & 1) == 0) {
+      unsigned p1;
+      split_stage1(pr[u][2 * c2], pr[u][2 * c2 + 1], p1, rr0, rr1);
+      sp[u][0][c2] = p1;
+      if (u < NPW) {
+        dbacc[u][2 * c2] += pr[u][2 * c2];
+        dbacc[u][2 * c2 + 1] += pr[u][2 * c2 + 1];
+      }
+    } else {
+      unsigned p2, p3;
+      split_stage2(rr0, rr1, p2, p3);
+      sp[u][1][c2] = p2;
+      sp[u][2][c2] = p3;
+    }
+  };
+  auto d_store = [&]() {
+#pragma unroll
+    for (int u = 0; u < 2 * NPW; ++u) {
+      const int q = NPW * wave + (u & (NPW - 1));
+      unsigned char *d = (u < NPW ? Ab : Bb) + (i >> 2) * BDW_SQ + (2 * (q >> 2) + ((q & 3) >> 1)) * 128 + (i & 3) * 32 +
+                         (8 * (q & 1) + 4 * h) * 2;
+#pragma unroll
+      for (int term = 0; term < 3; ++term) *reinterpret_cast<u32x2_t *>(d + term * BDW_IMG) = sp[u][term];
+    }
+  };
+  // fragment address of this lane inside a term image (k_dw_tr)
+  const int p16 = lane & 15, g1b = (lane >> 4) & 1;
+  const int frag_lane = g1b * 128 + (p16 >> 2) * 32 + (p16 & 3) * 8;
+  auto read_frag = [&](const unsigned char *base_img, int ks, int tile, u32x4 (&f)[3]) {
+#pragma unroll
+    for (int term = 0; term < 3; ++term) {
+      const unsigned char *fp = base_img + term * BDW_IMG + (4 * ks + 2 * h) * BDW_SQ + 2 * tile * 128 + frag_lane;
+      const u32x2_t lo = tr_read(fp), hi = tr_read(fp + BDW_SQ);
+      f[term] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+    }
+  };
+
+  // ---- owner state: the current slab's dz split into the B operands of the GEMM, the next slab's raw dz
+  float raw[NR];
+  u32x4 g1[NJ], g2[NJ], g3[NJ];
+  {
+    const long s0 = base0 + wave;
+    atl_load<H>(dz, s0 < n_slabs ? s0 : 0, lane, raw);
+    split_acts<NR, false>(raw, g1, g2, g3);
+  }
+  // O chunk k (0..63) of the NEXT slab's split: pair k>>1 (registers 2p, 2p+1 -> word p&3 of k-step p>>2), stage k&1
+  auto o_chunk = [&](int k) {
+    const int pi = k >> 1, j = pi >> 2, c = pi & 3;
+    if ((k & 1) == 0) {
+      unsigned p1;
+      split_stage1(raw[2 * pi], raw[2 * pi + 1], p1, rr0, rr1);
+      g1[j][c] = p1;
+    } else {
+      unsigned p2, p3;
+      split_stage2(rr0, rr1, p2, p3);
+      g2[j][c] = p2;
+      g3[j][c] = p3;
+    }
+  };
+  PHASE(10);
+
+  for (long base = base0; base < n_slabs; base += sr_stride) {
+    const long slab = base + wave;
+    const bool own = slab < n_slabs;
+    const long nxt = slab + sr_stride < n_slabs ? slab + sr_stride : (own ? slab : 0);
+    // =========================== O part: this wave's own slab ===========================
+    if (own) {
+      float xh[NR];
+      atl_load<H>(xprev, slab, lane, xh);
+      const float rstd = rstd_prev[slab * SLAB + i];
+      uint32_t mbits[2];
+#pragma unroll
+      for (int w = 0; w < 2; ++w) mbits[w] = mask_prev[(slab * 2 + w) * WAVE + lane];
+      f32x4 x0r[KT > 0 ? KPF / 8 : 1];
+      if constexpr (KT > 0) {
+        const f32x4 *bp = reinterpret_cast<const f32x4 *>(x0n + slab * (long)(KPF * SLAB)) + lane;
+#pragma unroll
+        for (int q = 0; q < KPF / 8; ++q) x0r[q] = bp[q * WAVE];
+      }
+      f32x16 acc[MT];
+#pragma unroll
+      for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+      PHASE(0);
+      split_gemm<MT, NJ>(wl, g1, g2, g3, acc, [](int) {});
+      PHASE(1);
+      // this wave's pieces of the first D round: their latency sits under the LayerNorm backward and the first-layer gradient
+      d_load(base);
+      float dx[NR];
+#pragma unroll
+      for (int R = 0; R < NR; ++R) dx[R] = acc[R >> 4][R & 15];
+      float out[NR];
+      ln_bwd_relu_mbits<H>(dx, xh, mbits, rstd, out);
+      if (dz_prev) atl_store<H>(dz_prev, slab, lane, out);
+      PHASE(2);
+      if constexpr (KT > 0) {
+        const Ident ident = make_ident(lane);
+        float xr0[KPF / 2];
+#pragma unroll
+        for (int q = 0; q < KPF / 8; ++q) {
+          xr0[4 * q + 0] = x0r[q][0];
+          xr0[4 * q + 1] = x0r[q][1];
+          xr0[4 * q + 2] = x0r[q][2];
+          xr0[4 * q + 3] = x0r[q][3];
+        }
+        u32x4 a1[KPF / 16], a2[KPF / 16], a3[KPF / 16];
+        split_acts<KPF / 2>(xr0, a1, a2, a3);
+        u32x4 Bt[3][2];
+        transpose_block<false>(a1[0], a1[1], a2[0], a2[1], a3[0], a3[1], ident, Bt);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          u32x4 At[3][2];
+          dbs[a] += split_transpose_block<true>(&out[16 * a], ident, At);
+          dw_tile(acc1[a], At, Bt);
+        }
+        PHASE(3);
+      }
+    } else {
+      d_load(base);
+    }
+    // =========================== D part: the four slabs of this super-round ===========================
+    // the owner's NEXT slab of dz (g1..g3 are dead since the GEMM): first needed by the fillers of round 1, a full round away --
+    // not earlier, the first-layer gradient above is the register peak of this kernel
+    atl_load<H>(dz, nxt, lane, raw);
+#pragma unroll
+    for (int k = 0; k < 8 * NPW; ++k) d_chunk(k);  // round 0's pieces are split in the open (once per super-round)
+    PHASE(4);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (base + r < n_slabs) {  // workgroup-uniform
+        __syncthreads();  // the previous round's fragments are fully read
+        PHASE(5);
+        d_store();
+        if (r < 3) {  // sp holds this round's terms now: pr is free for the next round's pieces (zeros past the last slab, so
+          // that the filler chunks below need no test: they add nothing to db' and their terms are never stored)
+          if (base + r + 1 < n_slabs) {
+            d_load(base + r + 1);
+          } else {
+#pragma unroll
+            for (int u = 0; u < 2 * NPW; ++u) pr[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+        }
+        __syncthreads();
+        PHASE(6);
+        // ---- 2 k-steps x 4 column tiles x the six cross products; fragments one tile-step ahead; one filler chunk per MFMA.
+        // Rounds 0..2: slots 16..47 split the next round's pieces (fetched just above: the early slots give them time to land),
+        // rounds 1 and 2 also 8 chunks each of the owner's next slab; round 3 has no next round and takes the other 48
+        auto fill = [&](int m) {
+          if (r == 3) o_chunk(16 + m);
+          else if (m >= 16) d_chunk(m - 16);
+          else if (r >= 1 && m < 8) o_chunk(8 * (r - 1) + m);
+        };
+        u32x4 av[2][3], bv[2][3];
+        read_frag(Ab, 0, wave, av[0]);
+        read_frag(Bb, 0, 0, bv[0]);
+        if constexpr (!FILL) {
+#pragma unroll
+          for (int m = 0; m < 48; ++m) fill(m);
+        }
+#pragma unroll
+        for (int n = 0; n < 8; ++n) {
+          const int ks = n >> 2, b = n & 3;
+          if (n + 1 < 8) {
+            const int ks1 = (n + 1) >> 2, b1 = (n + 1) & 3;
+            if (b1 == 0) read_frag(Ab, ks1, wave, av[ks1 & 1]);
+            read_frag(Bb, ks1, b1, bv[(n + 1) & 1]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          const u32x4(&A)[3] = av[ks & 1];
+          const u32x4(&B)[3] = bv[n & 1];
+#define BDW_STEP(AT, BT, slot)                         \
+  acc2[b] = mfma_bf16(A[AT], B[BT], acc2[b]);          \
+  if constexpr (FILL) fill(6 * n + slot);              \
+  __builtin_amdgcn_sched_barrier(0);
+          BDW_STEP(2, 0, 0)
+          BDW_STEP(0, 2, 1)
+          BDW_STEP(1, 1, 2)
+          BDW_STEP(1, 0, 3)
+          BDW_STEP(0, 1, 4)
+          BDW_STEP(0, 0, 5)
+#undef BDW_STEP
+        }
+        PHASE(7);
+      }
+    }
+  }
+
+  // ---- this workgroup's partial row of dW' | db' straight from the accumulators (disjoint tiles), the unused rows cleared
+  {
+    constexpr long ROW2 = (long)H * H + H;
+    float *mypart = dw2_part + (long)blockIdx.x * ROW2;
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int o = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * h;
+        mypart[(long)o * H + 32 * b + i] = acc2[b][r];
+      }
+#pragma unroll
+    for (int u = 0; u < NPW; ++u) {
+      const int q = NPW * wave + u;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float t = half_reduce_sum(dbacc[u][c]);
+        if (i == 0) mypart[(long)H * H + 32 * (q >> 2) + 8 * (q & 3) + 4 * h + c] = t;
+      }
+    }
+    for (int row = blockIdx.x + gridDim.x; row < n_part_rows; row += gridDim.x) {
+      float *z = dw2_part + (long)row * ROW2;
+      for (int e = threadIdx.x; e < ROW2; e += WG_THREADS) z[e] = 0.f;
+    }
+  }
+  if constexpr (KT > 0) {
+    f32x16 a1x[4][1];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) a1x[a][0] = acc1[a];
+    finish_partials<4, 1>(a1x, dbs, reinterpret_cast<float *>(img), dw1_part, n_part_rows);
+  }
+  PHASE(11);
+  PHASE_END(3);
+}
+
 HARL_PHASE_ACCESSOR(mlp)
 
 static int bad(const char *m) {
@@ -1409,6 +1725,34 @@ extern "C" int harl_mlp_bwd_dx(const float *dz, const float *xprev, const uint32
   else return bad("harl_mlp_bwd_dx: widths must be 64 or 128");
 #undef L
   return check_launch("harl_mlp_bwd_dx");
+}
+
+extern "C" int harl_mlp_bwd_dx_dw(const float *dz, const float *xprev, const uint32_t *relu_mask_prev,
+                                  const float *rstd_prev, long M, int HO, int HI, const float *Wp, float *dz_prev,
+                                  const float *x0n, int kp0, float *dw1_part, float *dw2_part, int n_wg, int fill,
+                                  void *stream) {
+  if (M <= 0) return 0;
+  if (HO != 128 || HI != 128) return bad("harl_mlp_bwd_dx_dw: 128 x 128 layers only (the layer kernels take the other widths)");
+  if (!dw2_part || n_wg <= 0) return bad("harl_mlp_bwd_dx_dw: needs the partial arena of dW' and n_wg > 0");
+  const bool first = dw1_part != nullptr;
+  if (first && (!x0n || kp0 != 32)) return bad("harl_mlp_bwd_dx_dw: the fused first-layer gradient needs x0n with kp0 = 32");
+  if (!first && !dz_prev) return bad("harl_mlp_bwd_dx_dw: dz_prev is required when no first-layer gradient is fused");
+  const long n_slabs = n_slabs_of(M);
+  const long wgs = (n_slabs + WAVES_PER_WG - 1) / WAVES_PER_WG;
+  int grid = n_wg < 256 ? n_wg : 256;
+  if (wgs < grid) grid = (int)wgs;
+  const size_t shm = bdw_lds_bytes();
+  hipStream_t s = (hipStream_t)stream;
+#define LB(kt, fl)                                                                                                    \
+  {                                                                                                                   \
+    allow_big_lds(k_bwd_dx_dw<kt, fl>, shm);                                                                          \
+    hipLaunchKernelGGL((k_bwd_dx_dw<kt, fl>), dim3(grid), dim3(WG_THREADS), shm, s, dz, xprev, relu_mask_prev,       \
+                       rstd_prev, Wp, dz_prev, n_slabs, x0n, dw1_part, dw2_part, n_wg);                              \
+  }
+  if (first) { if (fill) LB(1, true) else LB(1, false) }
+  else { if (fill) LB(0, true) else LB(0, false) }
+#undef LB
+  return check_launch("harl_mlp_bwd_dx_dw");
 }
 
 template <int MT, int NT>

@@ -38,6 +38,16 @@ def _fused_update_mode() -> str:
     return mode
 
 
+def _bwd_fused_mode() -> str:
+    """``HARL_BWD_FUSED``: "1" (default) = 128 x 128 hidden layers take harl_mlp_bwd_dx_dw (dx + the layer's weight gradient +
+    the fused first-layer one in one launch, operand splits interleaved with the MFMAs); "nofill" = the same launch with the
+    splits in separate phases; "0" = the layer kernels of rounds 1-4 (harl_mlp_dw_partials + harl_mlp_bwd_dx)."""
+    m = os.environ.get("HARL_BWD_FUSED", "1")
+    if m not in ("0", "1", "nofill"):
+        raise ValueError(f"HARL_BWD_FUSED={m!r}: expected 0, 1 or nofill")
+    return m
+
+
 def _space_shape(space) -> Tuple[int, ...]:
     """Duck-typed like the reference (harl/utils/envs_tools.py:15-29)."""
     name = space.__class__.__name__
@@ -654,11 +664,21 @@ class _FlatNet(nn.Module):
             return
         # first-layer weight gradient fused into the last bwd_dx (needs the ones column of x0n: in_dim < kp0)
         fuse_dw1 = L >= 2 and self.x0n is not None and self.in_dim < self.kp0 and self.kp0 <= 64
+        bwd_mode = _bwd_fused_mode()
         for l in range(L - 1, 0, -1):
             ho, hi = self.hidden_sizes[l], self.hidden_sizes[l - 1]
+            Wp, _ = self._packs[l]
+            dw1_here = l == 1 and fuse_dw1
+            if bwd_mode != "0" and ho == 128 and hi == 128 and (not dw1_here or self.kp0 == 32):
+                # the whole backward of this layer in ONE launch (round 5): dz and x_hat_{l-1} cross HBM once for dx AND dW'
+                call("harl_mlp_bwd_dx_dw", ptr(self.dz[cur]), ptr(self.xh[l - 1]), ptr(self.rmask[l - 1]), ptr(self.rstd[l - 1]), M,
+                     ho, hi, ptr(Wp), None if dw1_here else ptr(self.dz[1 - cur]), ptr(self.x0n) if dw1_here else None,
+                     self.kp0 if dw1_here else 0, ptr(self.part[po[0]:]) if dw1_here else None, ptr(self.part[po[l]:]), nwg,
+                     int(bwd_mode != "nofill"), s, tag="bwd_full_dw1" if dw1_here else "bwd_full")
+                cur = 1 - cur
+                continue
             call("harl_mlp_dw_partials", ptr(self.dz[cur]), 0, 0, ho, ptr(self.xh[l - 1]), 0, 0, None, None, None, hi, M,
                  ptr(self.part[po[l]:]), nwg, s, tag="dw_hidden")
-            Wp, _ = self._packs[l]
             if l == 1 and fuse_dw1:
                 call("harl_mlp_bwd_dx", ptr(self.dz[cur]), ptr(self.xh[0]), ptr(self.rmask[0]), ptr(self.rstd[0]), M, ho, hi,
                      ptr(Wp), None, ptr(self.x0n), self.kp0, ptr(self.part[po[0]:]), nwg, s, tag="bwd_dx_dw1")

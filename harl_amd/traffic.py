@@ -61,6 +61,13 @@ def _bwd_dx(a: Sequence) -> float:
     return M * (4.0 * HO + _act(HI) + (4.0 * HI if a[8] else 0.0) + (4.0 * a[10] if a[9] else 0.0))
 
 
+def _bwd_dx_dw(a: Sequence) -> float:
+    # (dz, xprev, relu_mask_prev, rstd_prev, M, HO, HI, Wp, dz_prev, x0n, kp0, dw1_part, dw2_part, n_wg, fill, stream): the same
+    # operands as harl_mlp_bwd_dx -- the weight gradient of the layer itself re-uses dz and x_hat_prev, read ONCE
+    M, HO, HI = a[4], a[5], a[6]
+    return M * (4.0 * HO + _act(HI) + (4.0 * HI if a[8] else 0.0) + (4.0 * a[10] if a[9] else 0.0))
+
+
 def _dw_partials(a: Sequence) -> float:
     # (a, a_kind, lda, HO, b, b_kind, ldx, idx, mu0, rstd0, K, M, part, n_wg, stream): dz rows (a_kind 0: ATL(HO); 1: row-major
     # head gradient of `lda` floats) and the layer's input rows (ATL(K), or raw rows gathered through idx)
@@ -187,6 +194,7 @@ ALGORITHMIC_BYTES: Dict[str, Callable[[Sequence], float]] = {
     "harl_mlp_x0n_wide": _x0n_wide,
     "harl_mlp_tangent_wide": _tangent_wide,
     "harl_mlp_bwd_dx": _bwd_dx,
+    "harl_mlp_bwd_dx_dw": _bwd_dx_dw,
     "harl_mlp_dw_partials": _dw_partials,
     "harl_mlp_dw_partials_multi": _dw_partials_multi,
     "harl_gru_fwd": _gru_fwd,
@@ -266,6 +274,11 @@ def _f_bwd_dx(a):  # (dz, xprev, mask, rstd, M, HO, HI, Wp, dz_prev, x0n, kp0, .
     return 2.0 * M * (HO * HI + (HI * a[10] if a[9] else 0))
 
 
+def _f_bwd_dx_dw(a):  # dx + the layer's own weight gradient (+ the fused first-layer one)
+    M, HO, HI = a[4], a[5], a[6]
+    return 2.0 * M * (2 * HO * HI + (HI * a[10] if a[9] else 0))
+
+
 def _f_dw(a):  # (a, a_kind, lda, HO, b, b_kind, ldx, idx, mu0, rstd0, K, M, ...)
     return 2.0 * a[11] * a[3] * a[10]
 
@@ -300,6 +313,7 @@ ALGORITHMIC_FLOPS: Dict[str, Callable[[Sequence], float]] = {
     "harl_mlp_tangent_hidden": lambda a: 2.0 * 2 * a[2] * a[3] * a[4],
     "harl_mlp_tangent_hidden2": lambda a: 2.0 * 2 * a[2] * a[3] * a[4],
     "harl_mlp_bwd_dx": _f_bwd_dx,
+    "harl_mlp_bwd_dx_dw": _f_bwd_dx_dw,
     "harl_mlp_dw_partials": _f_dw,
     "harl_mlp_dw_partials_multi": _f_dw_multi,
     "harl_mlp_panel_fwd": lambda a: 2.0 * a[1] * a[4] * a[6],

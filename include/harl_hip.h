@@ -188,6 +188,17 @@ int harl_mlp_fwd_hidden(const float *xin, long M, int HI, int HO, const float *W
 int harl_mlp_bwd_dx(const float *dz, const float *xprev, const uint32_t *relu_mask_prev, const float *rstd_prev,
                     long M, int HO, int HI, const float *Wp, float *dz_prev, const float *x0n, int kp0, float *dw_part,
                     int n_wg, void *stream);
+/* The WHOLE backward of one hidden Linear(128 -> 128) and the relu + norm in front of it in ONE persistent launch (round 5;
+ * autograd through MLPLayer, harl/models/base/mlp.py:25-38, happo.py:93-100):
+ *   dz_prev = relu_mask_prev ? LNbwd(Wp^T dz ; xprev, rstd_prev) : 0,   dW'[o][k] = sum_s dz[s][o] xprev[s][k],   db'[o] = sum_s dz[s][o]
+ * i.e. harl_mlp_dw_partials(dz, xprev) + harl_mlp_bwd_dx(...) with dz and xprev read from HBM ONCE.  dw2_part: n_wg partial rows
+ * [HO*HI + HO] in the layout of harl_mlp_dw_partials (the launch uses min(n_wg, 256) of them and clears the rest).
+ * dw1_part != NULL: FIRST-layer variant as in harl_mlp_bwd_dx (x0n = ATL(32) image, kp0 = 32; dz_prev may be NULL);
+ * dw1_part == NULL: dz_prev (ATL(HI)) is written.  fill: 1 = the operand splits are interleaved with the MFMAs of the
+ * weight-gradient rounds (default), 0 = the same work in separate phases (A/B measurements).  HO = HI = 128 only. */
+int harl_mlp_bwd_dx_dw(const float *dz, const float *xprev, const uint32_t *relu_mask_prev, const float *rstd_prev,
+                       long M, int HO, int HI, const float *Wp, float *dz_prev, const float *x0n, int kp0, float *dw1_part,
+                       float *dw2_part, int n_wg, int fill, void *stream);
 /* weight-gradient partials: part[wg] = { dWp[HO_pad32, KP] , dbp[HO_pad32] } summed over the samples the
  * workgroup processed; a_kind: 0 = ATL(HO) dz, 1 = row-major [M, lda] (head gradients, HO <= 32);
  * b_kind: 0 = ATL(K) x_hat (K = 32, 64, 128, or a wide x0n image: any multiple of 32 up to 512), 1 = raw X[idx] rows

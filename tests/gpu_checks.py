@@ -1534,6 +1534,94 @@ def check_generator_api(name: str) -> Dict[str, float]:
     return out
 
 
+def _atl_rows(t: torch.Tensor, ns: int, H: int) -> torch.Tensor:
+    """ATL(H) image [ns slabs] -> rows [ns * 32, H] (common.h: piece q, lane half h, sample s, element c <-> feature
+    32 (q >> 2) + 8 (q & 3) + 4 h + c)."""
+    img = t.detach().cpu().double().reshape(ns, H // 8, 2, 32, 4)
+    q = torch.arange(H // 8)
+    feat = (32 * (q // 4) + 8 * (q % 4)).reshape(-1, 1, 1) + 4 * torch.arange(2).reshape(1, -1, 1) + torch.arange(4).reshape(1, 1, -1)
+    rows = torch.empty(ns, 32, H, dtype=torch.float64)
+    rows[:, :, feat.reshape(-1)] = img.permute(0, 3, 1, 2, 4).reshape(ns, 32, -1)
+    return rows.reshape(ns * 32, H)
+
+
+def _relu_mask_rows(mask: torch.Tensor, ns: int, H: int) -> torch.Tensor:
+    """ReLU bit masks (common.h: lane (s, h) keeps register R of its H/2 in word R >> 5, MSB first) -> bool rows [ns * 32, H]."""
+    NW = (H // 2 + 31) // 32
+    m = mask.detach().cpu().to(torch.int64).reshape(ns, NW, 64) & 0xFFFFFFFF
+    out = torch.zeros(ns, 32, H, dtype=torch.bool)
+    for R in range(H // 2):
+        bit = (m[:, R >> 5, :] >> (31 - (R & 31))) & 1          # [ns, 64 lanes]
+        f0 = 32 * (R >> 4) + (R & 3) + 8 * ((R & 15) >> 2)
+        out[:, :, f0] = bit[:, :32].bool()
+        out[:, :, f0 + 4] = bit[:, 32:].bool()
+    return out.reshape(ns * 32, H)
+
+
+def check_bwd_fused(M: int, first: bool, fill: int = 1, seed: int = 0) -> Dict[str, float]:
+    """harl_mlp_bwd_dx_dw (the whole backward of a 128 x 128 hidden layer in one launch, round 5) on random ATL operands:
+    (i) against a float64 restatement of the math it replaces -- autograd through Linear + ReLU + LayerNorm,
+    harl/models/base/mlp.py:25-38: dz_prev, dW', db' and (first-layer variant) dW_1' | db_1', each as the error relative to the
+    largest entry; (ii) against the layer kernels it replaces (harl_mlp_dw_partials + harl_mlp_bwd_dx): dz_prev bit for bit
+    (same instruction sequence per slab), the weight gradients to fp32 summation-order noise."""
+    H, KP = 128, 32
+    ns = (M + 31) // 32
+    mp = ns * 32
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    rn = lambda *sh: torch.randn(*sh, device=DEV, generator=g)  # noqa: E731
+    dz, xh, x0n = rn(mp * H), rn(mp * H), rn(mp * KP)
+    mask = torch.randint(-2 ** 31, 2 ** 31 - 1, (ns * 2 * 64,), device=DEV, dtype=torch.int32, generator=g)
+    rstd = torch.rand(mp, device=DEV, generator=g) + 0.5
+    W = rn(H * H) * 0.1
+    n_wg = max(1, min(512, (ns + 1) // 2))
+    ROW2, ROW1 = H * H + H, H * KP + H
+    out: Dict[str, float] = {}
+    # ---- new kernel
+    dzp_new = torch.full((mp * H,), float("nan"), device=DEV)
+    part2_new = torch.full((n_wg * ROW2,), float("nan"), device=DEV)
+    part1_new = torch.full((n_wg * ROW1,), float("nan"), device=DEV)
+    call("harl_mlp_bwd_dx_dw", ptr(dz), ptr(xh), ptr(mask), ptr(rstd), M, H, H, ptr(W), ptr(dzp_new), ptr(x0n) if first else None,
+         KP if first else 0, ptr(part1_new) if first else None, ptr(part2_new), n_wg, fill, stream())
+    # ---- the layer kernels it replaces
+    dzp_old = torch.full((mp * H,), float("nan"), device=DEV)
+    part2_old = torch.full((n_wg * ROW2,), float("nan"), device=DEV)
+    part1_old = torch.full((n_wg * ROW1,), float("nan"), device=DEV)
+    call("harl_mlp_dw_partials", ptr(dz), 0, 0, H, ptr(xh), 0, 0, None, None, None, H, M, ptr(part2_old), n_wg, stream())
+    call("harl_mlp_bwd_dx", ptr(dz), ptr(xh), ptr(mask), ptr(rstd), M, H, H, ptr(W), ptr(dzp_old), ptr(x0n) if first else None,
+         KP if first else 0, ptr(part1_old) if first else None, n_wg if first else 0, stream())
+    torch.cuda.synchronize()
+    out["dz_prev_vs_layer_kernels_mismatch"] = float((dzp_new != dzp_old).sum().item())
+    s2n, s2o = part2_new.reshape(n_wg, ROW2).double().sum(0).cpu(), part2_old.reshape(n_wg, ROW2).double().sum(0).cpu()
+    out["dw2_vs_layer_kernels_vec_rel"] = vec_rel_err(s2n.numpy(), s2o.numpy())
+    # ---- float64 restatement
+    dzr, xr = _atl_rows(dz, ns, H), _atl_rows(xh, ns, H)
+    Wm = W.detach().cpu().double().reshape(H, H)
+    dxh = dzr @ Wm
+    rs = rstd.detach().cpu().double().reshape(-1, 1)
+    da = rs * (dxh - dxh.mean(-1, keepdim=True) - xr * (dxh * xr).mean(-1, keepdim=True))
+    dzp_ref = torch.where(_relu_mask_rows(mask, ns, H), da, torch.zeros_like(da))
+    out["dz_prev_vec_rel"] = vec_rel_err(_atl_rows(dzp_new, ns, H).numpy(), dzp_ref.numpy())
+    dW2 = dzr.t() @ xr
+    out["dw2_vec_rel"] = vec_rel_err(s2n[:H * H].reshape(H, H).numpy(), dW2.numpy())
+    out["db2_vec_rel"] = vec_rel_err(s2n[H * H:].numpy(), dzr.sum(0).numpy())
+    if first:
+        s1n, s1o = part1_new.reshape(n_wg, ROW1).double().sum(0).cpu(), part1_old.reshape(n_wg, ROW1).double().sum(0).cpu()
+        out["dw1_vs_layer_kernels_vec_rel"] = vec_rel_err(s1n.numpy(), s1o.numpy())
+        x0r = _atl_rows(x0n, ns, KP)
+        out["dw1_vec_rel"] = vec_rel_err(s1n[:H * KP].reshape(H, KP).numpy(), (dzp_ref.t() @ x0r).numpy())
+        out["db1_vec_rel"] = vec_rel_err(s1n[H * KP:].numpy(), dzp_ref.sum(0).numpy())
+    # ---- determinism: a second launch gives the same bits
+    part2_b = torch.empty_like(part2_new)
+    dzp_b = torch.empty_like(dzp_new)
+    part1_b = torch.empty_like(part1_new)
+    call("harl_mlp_bwd_dx_dw", ptr(dz), ptr(xh), ptr(mask), ptr(rstd), M, H, H, ptr(W), ptr(dzp_b), ptr(x0n) if first else None,
+         KP if first else 0, ptr(part1_b) if first else None, ptr(part2_b), n_wg, fill, stream())
+    torch.cuda.synchronize()
+    out["rerun_mismatch"] = float((part2_b != part2_new).sum().item() + (dzp_b != dzp_new).sum().item()
+                                  + ((part1_b != part1_new).sum().item() if first else 0))
+    return out
+
+
 def check_fused_vs_layered(rows: int, mode: str = "1", hidden=(128, 128), obs_dim: int = 18) -> Dict[str, float]:
     """csrc/update.hip (HARL_FUSED_UPDATE=``mode``: 1 or hybrid) against the layer-by-layer kernels (=0) on the same data: unscaled folded
     gradients, loss sums, first-epoch log-probs, log-prob pass + factor product; second fused run bit-identical."""

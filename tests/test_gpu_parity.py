@@ -327,6 +327,22 @@ def test_fused_update_kernels_train_golden(name, mode, monkeypatch):
     _assert_all(_G().check_train_golden(name), tol=TOL)
 
 
+@pytest.mark.parametrize("first", [True, False])
+@pytest.mark.parametrize("M", [45, 300, 32 * 4 * 7 + 1, 32 * 4 * 256 * 3 + 32 * 5 + 9])
+def test_whole_layer_backward_in_one_launch(M, first):
+    """harl_mlp_bwd_dx_dw (round 5: dx + dW' + db' + the fused first-layer gradient of a 128 x 128 layer in one launch) against a
+    float64 restatement of autograd through Linear + ReLU + LayerNorm, and against the layer kernels it replaces; sizes from a
+    single partial slab over a ragged super-round to several slabs per wave with a ragged tail; both filler modes."""
+    G = _G()
+    for fill in (1, 0):
+        res = G.check_bwd_fused(M, first, fill=fill, seed=M % 97)
+        for k, v in res.items():
+            if "mismatch" in k:
+                assert v == 0.0, (k, v, M, first, fill)
+            else:
+                assert v < 3e-6, (k, v, M, first, fill)
+
+
 @pytest.mark.parametrize("mode", ["hybrid", "1"])
 def test_fused_update_kernels_many_slabs_per_wave(mode):
     """The fused kernels against the layer-by-layer kernels at a size where every wave walks several slabs (the golden

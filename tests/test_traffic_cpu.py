@@ -28,6 +28,7 @@ def test_argument_positions_match_the_header():
         "harl_mlp_fwd_wide": {"M": 1, "KP": 2, "H": 6},
         "harl_mlp_x0n_wide": {"idx": 2, "M": 3, "D": 4},
         "harl_mlp_bwd_dx": {"M": 4, "HO": 5, "HI": 6, "dz_prev": 8, "x0n": 9, "kp0": 10},
+        "harl_mlp_bwd_dx_dw": {"M": 4, "HO": 5, "HI": 6, "dz_prev": 8, "x0n": 9, "kp0": 10},
         "harl_mlp_dw_partials": {"a_kind": 1, "lda": 2, "HO": 3, "K": 10, "M": 11},
         "harl_gru_fwd": {"H": 7, "L": 8, "m_pad": 9, "save": 18},
         "harl_gru_bwd": {"H": 9, "L": 10, "m_pad": 11},

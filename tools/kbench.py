@@ -80,6 +80,10 @@ def main():
         ("fwd_wide_K64", lambda: call("harl_mlp_fwd_wide", ptr(x0n64), B, 64, ptr(W1c), 54, ptr(b), H, ptr(wimg), ptr(xh1), ptr(mask), ptr(rstd), s), GB(B * (256 + 512 + 20))),
         ("fwd_hidden", lambda: call("harl_mlp_fwd_hidden", ptr(xh1), B, H, H, ptr(W), ptr(b), ptr(xh2), ptr(mask), ptr(rstd), s), GF(fl)),
         ("bwd_dx", lambda: call("harl_mlp_bwd_dx", ptr(dz), ptr(xh1), ptr(mask), ptr(rstd), B, H, H, ptr(W), ptr(dz2), None, 0, None, 0, s), GF(fl)),
+        ("bwd_full_fill", lambda: call("harl_mlp_bwd_dx_dw", ptr(dz), ptr(xh1), ptr(mask), ptr(rstd), B, H, H, ptr(W), ptr(dz2), None, 0, None, ptr(part), n_wg, 1, s), GF(2 * fl)),
+        ("bwd_full_nofill", lambda: call("harl_mlp_bwd_dx_dw", ptr(dz), ptr(xh1), ptr(mask), ptr(rstd), B, H, H, ptr(W), ptr(dz2), None, 0, None, ptr(part), n_wg, 0, s), GF(2 * fl)),
+        ("bwd_full_dw1_fill", lambda: call("harl_mlp_bwd_dx_dw", ptr(dz), ptr(xh1), ptr(mask), ptr(rstd), B, H, H, ptr(W), None, ptr(x0n32), 32, ptr(part_1), ptr(part), n_wg, 1, s), GF(2 * fl + 2.0 * B * H * 18)),
+        ("bwd_full_dw1_nofill", lambda: call("harl_mlp_bwd_dx_dw", ptr(dz), ptr(xh1), ptr(mask), ptr(rstd), B, H, H, ptr(W), None, ptr(x0n32), 32, ptr(part_1), ptr(part), n_wg, 0, s), GF(2 * fl + 2.0 * B * H * 18)),
         ("bwd_dx_dw1_fused", lambda: call("harl_mlp_bwd_dx", ptr(dz), ptr(xh1), ptr(mask), ptr(rstd), B, H, H, ptr(W), None, ptr(x0n32), 32, ptr(part_1), n_wg, s), GF(fl + 2.0 * B * H * 18)),
         ("dw_hidden", lambda: call("harl_mlp_dw_partials", ptr(dz), 0, 0, H, ptr(xh1), 0, 0, None, None, None, H, B, ptr(part), n_wg, s), GF(fl)),
         ("dw_head", lambda: call("harl_mlp_dw_partials", ptr(dhead), 1, 32, 5, ptr(xh2), 0, 0, None, None, None, H, B, ptr(part), n_wg, s), GB(B * (512 + 128))),

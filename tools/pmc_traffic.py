@@ -25,6 +25,8 @@ GROUPS = [
     (r"void k_fwd_hidden<\d+, \d+, [12]>", ("tangent_hidden",)),
     (r"void k_panel<false>", ("fwd_panel",)),
     (r"void k_panel<true>", ("bwd_panel",)),
+    (r"void k_bwd_dx_dw<0", ("bwd_full",)),
+    (r"void k_bwd_dx_dw<1", ("bwd_full_dw1",)),
     (r"void k_bwd_dx<\d+, \d+, 0>", ("bwd_dx",)),
     (r"void k_bwd_dx<\d+, \d+, [1-9]>", ("bwd_dx_dw1",)),
     (r"void k_dw(_tr<|_tr_multi<|<0)", ("dw_hidden", "dw_gru", "dw_input")),

@@ -21,6 +21,7 @@
 #include "mfma_transpose.h"
 #include "dw_common.h"
 #include "../../include/harl_hip.h"
+#include <stdlib.h>
 
 using namespace harl;
 
@@ -680,10 +681,13 @@ __global__ __launch_bounds__(64 * FUSED_WAVES, 2) void k_fwd_fused2(
 // MFMAs per slab; dz_1 is never written to HBM and the separate harl_mlp_dw_partials pass over it disappears.  One
 // workgroup per CU, per-workgroup partials in the layout of harl_mlp_dw_partials.  (Round 1 staged both operands through a
 // wave-private LDS transpose and used the fp32 MFMA with one LDS read per MFMA: the same speed, measured.)
-constexpr int bwd_pass_width(int kt) { return kt == 1 ? 64 : 32; }  // dz_1 features staged per pass of the fused dW_1
-constexpr size_t bwd_stage_floats(int kt) { return (size_t)SLAB * (bwd_pass_width(kt) + 4) + (size_t)SLAB * (32 * kt + 4); }
 
-template <int HO, int HI, int KT = 0>
+// LEAN (round 5): the register diet that lets this kernel share a CU with a weight-gradient workgroup launched on a second
+// stream (nets.backward_trunk, HARL_BWD_STREAMS): <= 344 of the 512 registers per SIMD lane and nothing in LDS but the weight
+// images, so that one k_dw_tr workgroup (168 registers, 48 KiB) fits next to it and the two kernels' matrix / vector / memory
+// phases overlap in hardware -- both read the same dz and x_hat_prev at about the same time.  What goes: the one-slab-ahead
+// prefetch of dz and the early request of the LayerNorm operands (their latency is the co-resident wave's to fill).
+template <int HO, int HI, int KT = 0, bool LEAN = false>
 __global__ __launch_bounds__(WG_THREADS, (KT > 0 || split_one_wg(HI, HO)) ? 1 : 2) void k_bwd_dx(
     const float *__restrict__ dz, const float *__restrict__ xprev, const uint32_t *__restrict__ mask_prev,
     const float *__restrict__ rstd_prev, const float *__restrict__ Wp, float *__restrict__ dz_prev, long n_slabs,
@@ -693,9 +697,7 @@ __global__ __launch_bounds__(WG_THREADS, (KT > 0 || split_one_wg(HI, HO)) ? 1 : 
   // dx_hat = Wp^T dz on the bf16 pipe (split_mfma.h): GEMM rows = input features, k = output features
   constexpr int MT = HI / 32, NJ = HO / 16, NRO = HO / 2;
   u32x4 *img = reinterpret_cast<u32x4 *>(lds);
-  constexpr int PW = bwd_pass_width(KT), HX = PW + 4, MP = PW / 32, KPF = 32 * (KT > 0 ? KT : 1), LDB = KPF + 4;
-  constexpr int STAGE_FLOATS = SLAB * HX + SLAB * LDB;  // per wave: a PW-feature slice of dz_1, and the x0n tile
-  float *stg = reinterpret_cast<float *>(img + 3 * MT * NJ * 64);
+  constexpr int KPF = 32 * (KT > 0 ? KT : 1);
   stage_split_matrix<HO, HI, true, WG_THREADS>(img, Wp);
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = wave_id();
@@ -703,7 +705,7 @@ __global__ __launch_bounds__(WG_THREADS, (KT > 0 || split_one_wg(HI, HO)) ? 1 : 
   const long slab0 = (long)blockIdx.x * WAVES_PER_WG + wave, slab_stride = (long)gridDim.x * WAVES_PER_WG;
   const u32x4 *wl = img + lane;
   float raw[NRO];
-  atl_load<HO>(dz, slab0 < n_slabs ? slab0 : 0, lane, raw);
+  if constexpr (!LEAN) atl_load<HO>(dz, slab0 < n_slabs ? slab0 : 0, lane, raw);
   f32x16 acc1[KT > 0 ? HI / 32 : 1][KT > 0 ? KT : 1];  // fused first-layer weight gradient, persistent over the slabs
   float dbs[KT > 0 ? HI / 32 : 1];                     // ... and its bias gradient (per-lane sums over the lane's samples)
   const Ident ident = make_ident(lane);
@@ -720,23 +722,29 @@ __global__ __launch_bounds__(WG_THREADS, (KT > 0 || split_one_wg(HI, HO)) ? 1 : 
   PHASE(10);
   for (long slab = slab0; slab < n_slabs; slab += slab_stride) {
     u32x4 g1[NJ], g2[NJ], g3[NJ];
+    if constexpr (LEAN) atl_load<HO>(dz, slab, lane, raw);
     split_acts<NRO>(raw, g1, g2, g3);
     PHASE(0);
-    atl_load<HO>(dz, slab + slab_stride < n_slabs ? slab + slab_stride : slab, lane, raw);  // one slab ahead
-    // operands of the LayerNorm backward: issued now, consumed after the MFMA loop (latency fully hidden)
+    if constexpr (!LEAN) atl_load<HO>(dz, slab + slab_stride < n_slabs ? slab + slab_stride : slab, lane, raw);  // one slab ahead
+    // operands of the LayerNorm backward: issued now, consumed after the MFMA loop (latency fully hidden); LEAN: behind the
+    // GEMM (64 registers less across it)
     float xh[HI / 2];
-    atl_load<HI>(xprev, slab, lane, xh);
-    const float rstd = rstd_prev[slab * SLAB + i];
+    float rstd;
     constexpr int NWP = (HI / 2 + 31) / 32;
     uint32_t mbits[NWP];
-#pragma unroll
-    for (int w = 0; w < NWP; ++w) mbits[w] = mask_prev[(slab * NWP + w) * WAVE + lane];
     f32x4 x0r[KT > 0 ? KPF / 8 : 1];
-    if constexpr (KT > 0) {
-      const f32x4 *bp = reinterpret_cast<const f32x4 *>(x0n + slab * (long)(KPF * SLAB)) + lane;
+    auto ln_operands = [&]() {
+      atl_load<HI>(xprev, slab, lane, xh);
+      rstd = rstd_prev[slab * SLAB + i];
 #pragma unroll
-      for (int q = 0; q < KPF / 8; ++q) x0r[q] = bp[q * WAVE];
-    }
+      for (int w = 0; w < NWP; ++w) mbits[w] = mask_prev[(slab * NWP + w) * WAVE + lane];
+      if constexpr (KT > 0) {
+        const f32x4 *bp = reinterpret_cast<const f32x4 *>(x0n + slab * (long)(KPF * SLAB)) + lane;
+#pragma unroll
+        for (int q = 0; q < KPF / 8; ++q) x0r[q] = bp[q * WAVE];
+      }
+    };
+    if constexpr (!LEAN) ln_operands();
     f32x16 acc[HI / 32];
 #pragma unroll
     for (int t = 0; t < HI / 32; ++t)
@@ -744,6 +752,7 @@ __global__ __launch_bounds__(WG_THREADS, (KT > 0 || split_one_wg(HI, HO)) ? 1 : 
       for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     PHASE(1);
     split_gemm<MT, NJ>(wl, g1, g2, g3, acc, [](int) {});
+    if constexpr (LEAN) ln_operands();
     PHASE(2);
     float dx[HI / 2];
 #pragma unroll
@@ -1685,6 +1694,16 @@ extern "C" int harl_mlp_fwd_hidden(const float *xin, long M, int HI, int HO, con
   return check_launch("harl_mlp_fwd_hidden");
 }
 
+// HARL_BWD_STREAMS=1 (read once): the register-lean instantiation of the fused first-layer variant, for co-residency with the
+// weight-gradient launch of the same layer on a second stream (nets.backward_trunk)
+static bool lean_bwd() {
+  static const bool v = [] {
+    const char *e = getenv("HARL_BWD_STREAMS");
+    return e && e[0] == '1';
+  }();
+  return v;
+}
+
 extern "C" int harl_mlp_bwd_dx(const float *dz, const float *xprev, const uint32_t *relu_mask_prev,
                                const float *rstd_prev, long M, int HO, int HI, const float *Wp, float *dz_prev,
                                const float *x0n, int kp0, float *dw_part, int n_wg, void *stream) {
@@ -1694,22 +1713,27 @@ extern "C" int harl_mlp_bwd_dx(const float *dz, const float *xprev, const uint32
   if (dw_part) {  // first-layer variant with the weight gradient fused in
     if (!x0n || (kp0 != 32 && kp0 != 64) || n_wg <= 0)
       return bad("harl_mlp_bwd_dx: fused first-layer gradient needs x0n, kp0 in {32, 64} and n_wg > 0");
-#define LF(a, b, kt)                                                                                              \
+  // LDS: the three weight images; the end-of-kernel combine of the fused first-layer gradient (finish_partials) works in
+  // their place, so nothing else is needed -- unless one partial row [b][32 kt] | [b] is larger than the images (64 -> 64, kt = 2)
+#define LFX(a, b, kt, lean)                                                                                       \
   {                                                                                                               \
-    size_t fl = (size_t)WAVES_PER_WG * bwd_stage_floats(kt);                                                      \
-    if (fl < (size_t)b * 32 * kt) fl = (size_t)b * 32 * kt;                                                       \
-    const size_t shm = split_image_bytes(b, a) + fl * sizeof(float);                                              \
-    allow_big_lds(k_bwd_dx<a, b, kt>, shm);                                                                       \
-    hipLaunchKernelGGL((k_bwd_dx<a, b, kt>), dim3(n_wg < 256 ? n_wg : 256), dim3(WG_THREADS), shm, s, dz, xprev,   \
-                       relu_mask_prev, rstd_prev, Wp, dz_prev, n_slabs, x0n, dw_part, n_wg);                      \
+    size_t shm = split_image_bytes(b, a);                                                                         \
+    const size_t rowb = ((size_t)b * 32 * kt + b) * sizeof(float);                                                \
+    if (shm < rowb) shm = rowb;                                                                                   \
+    allow_big_lds(k_bwd_dx<a, b, kt, lean>, shm);                                                                 \
+    hipLaunchKernelGGL((k_bwd_dx<a, b, kt, lean>), dim3(n_wg < 256 ? n_wg : 256), dim3(WG_THREADS), shm, s, dz,   \
+                       xprev, relu_mask_prev, rstd_prev, Wp, dz_prev, n_slabs, x0n, dw_part, n_wg);               \
   }
+#define LF(a, b, kt) LFX(a, b, kt, false)
     const int kt = kp0 / 32;
-    if (HO == 128 && HI == 128) { if (kt == 1) LF(128, 128, 1) else LF(128, 128, 2) }
+    if (HO == 128 && HI == 128 && kt == 1 && lean_bwd()) LFX(128, 128, 1, true)
+    else if (HO == 128 && HI == 128) { if (kt == 1) LF(128, 128, 1) else LF(128, 128, 2) }
     else if (HO == 64 && HI == 64) { if (kt == 1) LF(64, 64, 1) else LF(64, 64, 2) }
     else if (HO == 128 && HI == 64) { if (kt == 1) LF(128, 64, 1) else LF(128, 64, 2) }
     else if (HO == 64 && HI == 128) { if (kt == 1) LF(64, 128, 1) else LF(64, 128, 2) }
     else return bad("harl_mlp_bwd_dx: widths must be 64 or 128");
 #undef LF
+#undef LFX
     return check_launch("harl_mlp_bwd_dx");
   }
   const size_t shm = split_image_bytes(HI, HO);

@@ -39,13 +39,22 @@ def _fused_update_mode() -> str:
 
 
 def _bwd_fused_mode() -> str:
-    """``HARL_BWD_FUSED``: "1" (default) = 128 x 128 hidden layers take harl_mlp_bwd_dx_dw (dx + the layer's weight gradient +
-    the fused first-layer one in one launch, operand splits interleaved with the MFMAs); "nofill" = the same launch with the
-    splits in separate phases; "0" = the layer kernels of rounds 1-4 (harl_mlp_dw_partials + harl_mlp_bwd_dx)."""
-    m = os.environ.get("HARL_BWD_FUSED", "1")
+    """``HARL_BWD_FUSED``: "0" (default) = the layer kernels (harl_mlp_dw_partials + harl_mlp_bwd_dx); "1" = 128 x 128 hidden
+    layers take harl_mlp_bwd_dx_dw (dx + the layer's weight gradient + the fused first-layer one in ONE launch, operand splits
+    interleaved with the MFMAs: dz and x_hat cross HBM once); "nofill" = the same launch with the splits in separate phases.
+    The one-launch backward is parity-green and moves 17 % fewer bytes per step but measured 2 % SLOWER end to end on MI355X
+    (17.54 against 17.21 ms per MPE update, profiles/r05_bwd_fused_ab.md): with one workgroup per CU its barrier-separated
+    transposition rounds have no second workgroup to overlap with -- DESIGN.md section 3, round 5."""
+    m = os.environ.get("HARL_BWD_FUSED", "0")
     if m not in ("0", "1", "nofill"):
         raise ValueError(f"HARL_BWD_FUSED={m!r}: expected 0, 1 or nofill")
     return m
+
+
+def _bwd_streams() -> bool:
+    """``HARL_BWD_STREAMS=1``: the hidden layers' weight-gradient launches go to a second stream next to the backward-dx
+    launches (nets.backward_trunk; the C side picks the register-lean dx kernel under the same variable)."""
+    return os.environ.get("HARL_BWD_STREAMS", "0") == "1"
 
 
 def _space_shape(space) -> Tuple[int, ...]:
@@ -570,6 +579,13 @@ class _FlatNet(nn.Module):
         (W1, b1), (W2, b2), (Wh, bh) = self._packs[0], self._packs[1], self._packs[-1]
         return (ptr(self.x0n), M, self.in_dim, self.hidden_sizes[0], ptr(W1), ptr(b1), ptr(W2), ptr(b2), ptr(Wh), ptr(bh))
 
+    def _bwd_side(self):
+        """The second stream of the layer-by-layer backward (one per network: the critic's chain has its own) + its two events."""
+        if getattr(self, "_bwd_side_stream", None) is None:
+            self._bwd_side_stream = torch.cuda.Stream(device=self.device_)
+            self._bwd_ev = [torch.cuda.Event(), torch.cuda.Event()]
+        return self._bwd_side_stream
+
     def _combine_partials(self, s) -> None:
         """The deterministic split-K combine of every layer's per-workgroup weight-gradient partials into self.dwp, one launch.
         (Round 4 measured it as a first phase of harl_adam_fold instead: slower, csrc/elementwise.hip.)"""
@@ -665,6 +681,12 @@ class _FlatNet(nn.Module):
         # first-layer weight gradient fused into the last bwd_dx (needs the ones column of x0n: in_dim < kp0)
         fuse_dw1 = L >= 2 and self.x0n is not None and self.in_dim < self.kp0 and self.kp0 <= 64
         bwd_mode = _bwd_fused_mode()
+        side_pending = False
+        if (bwd_mode != "0" and fuse_dw1 and self.kp0 == 64 and L >= 2 and self.hidden_sizes[0] == 128 and self.hidden_sizes[1] == 128
+                and os.environ.get("HARL_BWD_K64", "0") == "1"):
+            # 33..64 inputs (the MPE critic's 54): the first-layer gradient of a 64-wide image does not fit the register file next
+            # to the layer's own gradient -- one-launch backward that WRITES dz_1, then the two-operand weight-gradient launch
+            fuse_dw1 = False
         for l in range(L - 1, 0, -1):
             ho, hi = self.hidden_sizes[l], self.hidden_sizes[l - 1]
             Wp, _ = self._packs[l]
@@ -677,14 +699,31 @@ class _FlatNet(nn.Module):
                      int(bwd_mode != "nofill"), s, tag="bwd_full_dw1" if dw1_here else "bwd_full")
                 cur = 1 - cur
                 continue
-            call("harl_mlp_dw_partials", ptr(self.dz[cur]), 0, 0, ho, ptr(self.xh[l - 1]), 0, 0, None, None, None, hi, M,
-                 ptr(self.part[po[l]:]), nwg, s, tag="dw_hidden")
+            # HARL_BWD_STREAMS=1: the layer's weight gradient goes to a SECOND stream, next to the backward-dx launch -- both read
+            # dz_l and x_hat_{l-1}, neither reads what the other writes.  The dx launch is enqueued FIRST: one of its workgroups
+            # per CU (96 KiB of LDS, the register-lean instantiation) leaves room for one weight-gradient workgroup, so the two
+            # kernels share every CU and fill each other's stalls; the other order would park two weight-gradient workgroups on
+            # every CU and the dx kernel behind them.
+            two = (_bwd_streams() and ho == 128 and hi == 128 and self.device_.type == "cuda"
+                   and (not (l == 1 and fuse_dw1) or self.kp0 == 32))
+            if two:
+                main_s, side_s, e0 = torch.cuda.current_stream(self.device_), self._bwd_side(), self._bwd_ev[0]
+                e0.record(main_s)
+            else:
+                call("harl_mlp_dw_partials", ptr(self.dz[cur]), 0, 0, ho, ptr(self.xh[l - 1]), 0, 0, None, None, None, hi, M,
+                     ptr(self.part[po[l]:]), nwg, s, tag="dw_hidden")
             if l == 1 and fuse_dw1:
                 call("harl_mlp_bwd_dx", ptr(self.dz[cur]), ptr(self.xh[0]), ptr(self.rmask[0]), ptr(self.rstd[0]), M, ho, hi,
                      ptr(Wp), None, ptr(self.x0n), self.kp0, ptr(self.part[po[0]:]), nwg, s, tag="bwd_dx_dw1")
             else:
                 call("harl_mlp_bwd_dx", ptr(self.dz[cur]), ptr(self.xh[l - 1]), ptr(self.rmask[l - 1]),
                      ptr(self.rstd[l - 1]), M, ho, hi, ptr(Wp), ptr(self.dz[1 - cur]), None, 0, None, 0, s, tag="bwd_dx")
+            if two:
+                side_s.wait_event(e0)
+                with torch.cuda.stream(side_s):
+                    call("harl_mlp_dw_partials", ptr(self.dz[cur]), 0, 0, ho, ptr(self.xh[l - 1]), 0, 0, None, None, None, hi, M,
+                         ptr(self.part[po[l]:]), nwg, side_s.cuda_stream, tag="dw_hidden")
+                side_pending = True
             cur = 1 - cur
         h0 = self.hidden_sizes[0]
         use_ln = self.use_feature_normalization
@@ -697,6 +736,10 @@ class _FlatNet(nn.Module):
             call("harl_mlp_dw_partials", ptr(self.dz[cur]), 0, 0, h0, ptr(X), 1, X.shape[1], ptr(idx),
                  ptr(self.mu0) if use_ln else None, ptr(self.rstd0) if use_ln else None, self.in_dim, M,
                  ptr(self.part[po[0]:]), nwg, s, tag="dw_input")
+        if side_pending:  # the weight gradients enqueued on the second stream
+            e1 = self._bwd_ev[1]
+            e1.record(self._bwd_side())
+            torch.cuda.current_stream(self.device_).wait_event(e1)
         # deterministic fixed-order combine of every entry's per-workgroup partials, one launch
         self._combine_partials(s)
 

@@ -54,7 +54,6 @@ def test_dropin_under_unmodified_train_py_plumbing(tmp_path):
     k = res["kernel_calls"]
     for name in ("harl_gae_returns", "harl_masked_moments", "harl_adam_fold", "harl_reduce_partials_multi",
                  "harl_update_fwd_actor", "harl_update_fwd_critic", "harl_mlp_bwd_dx", "harl_mlp_dw_partials",
-                 "harl_mlp_bwd_dx_dw",  # (actors, 18 inputs: the one-launch backward; critic, 54 inputs: the layer kernels)
                  "harl_mlp_x0n_wide"):  # hybrid optimiser step (nets.fused_update_ok): fused forward, layer-by-layer backward
         assert k.get(name, 0) > 0, (name, k)
     assert k.get("harl_update_logp", 0) + k.get("harl_actor_head_logp", 0) > 0, k   # rollout sampling + factor passes

@@ -264,15 +264,18 @@ def test_bench_configuration_against_oracle():
 
 def test_bench_configuration_onpolicy_against_oracle():
     """The same whole step with ON-POLICY stored log-probs (`bench.py --logp onpolicy`: log pi(a|o) + 0.05 N(0,1) under the
-    initial weights, importance ratios ~ 1 -- the regime PPO actually runs in).  No sample carries a 1e+2 ratio here, so the
-    figures that do not divide by a near-zero number are held to 1e-5 FLAT on all 15 updates: entropy, ratio, grad-norm, and
-    the critic; the policy loss (a masked mean of advantage-normalised surrogates that is ~0 by construction) and everything
-    downstream of 15 chained Adam steps (averaged infos, final parameters) keep the measured bar."""
+    initial weights, importance ratios ~ 1 -- the regime PPO actually runs in).  Measured on MI355X
+    (profiles/r05_parity_bench_config_onpolicy.json): this variant is WORSE conditioned than the recipe one, not better --
+    the policy loss is a masked mean of advantage-normalised surrogates with ratios ~ 1, i.e. ~ 0 by construction, and the
+    gradient a sum of 819 200 terms that cancel to ~1e-3 of their mass: the fp32 oracle's own grad-norms sit 2.2e-3 from its
+    float64 twin over the 15 updates (HIP: 4.1e-3 from the fp32 oracle, 0.92 of the bar), its policy losses 1.2e-2 (HIP 7.6e-3).
+    What does not divide by a near-zero number is held to 1e-5 FLAT: every update's entropy, the critic throughout, the first
+    update's entropy / grad-norm / ratio; the rest keeps the measured bar."""
     res = _G().check_bench_config_parity(logp="onpolicy", n_pert=1)
     print("bench-config parity (on-policy):", {k: (f"{v:.3e}" if isinstance(v, float) else v) for k, v in res.items()})
     _assert_all(res)
-    for nm in ("dist_entropy", "ratio", "grad_norm"):
-        assert res[f"_actor_update_{nm}_rel"] < TOL, (nm, res[f"_actor_update_{nm}_rel"])
+    for k in ("_actor_update_dist_entropy_rel", "_first_update_dist_entropy_rel", "_first_update_grad_norm_rel", "_first_update_ratio_rel"):
+        assert res[k] < TOL, (k, res[k])
 
 
 def test_cheetah6_full_size_against_oracle():
@@ -324,6 +327,16 @@ def test_fused_update_kernels_train_golden(name, mode, monkeypatch):
     """Whole train() vs the reference's golden vectors with the optimiser steps routed through the fused forward + layer
     backward (hybrid, the default), the three fused launches (1) and the layer-by-layer kernels alone (logp)."""
     monkeypatch.setenv("HARL_FUSED_UPDATE", mode)
+    _assert_all(_G().check_train_golden(name), tol=TOL)
+
+
+@pytest.mark.parametrize("env", ["HARL_BWD_FUSED", "HARL_BWD_STREAMS"])
+@pytest.mark.parametrize("name", ["mpe_box_h128", "cheetah_h128x3_mb2", "disc50_h128", "fp_disc_h128_mb2"])
+def test_backward_variants_train_golden(name, env, monkeypatch):
+    """Whole train() vs the reference's golden vectors with the two round-5 variants of the hidden layers' backward: the one-launch
+    kernel (HARL_BWD_FUSED=1, harl_mlp_bwd_dx_dw) and the two-stream arrangement (HARL_BWD_STREAMS=1: weight gradients on a second
+    stream next to the register-lean backward-dx launch)."""
+    monkeypatch.setenv(env, "1")
     _assert_all(_G().check_train_golden(name), tol=TOL)
 
 
@@ -433,6 +446,8 @@ def test_dropin_under_reference_launcher_on_gpu(tmp_path):
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, PYTHONPATH=root), cwd=root)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
     res = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("DROPIN_RESULT ")][-1][len("DROPIN_RESULT "):])
+    print("dropin on the GPU:", {k: res[k] for k in ("runner_class", "actor_class", "critic_class", "buffer_class", "saved") if k in res},
+          "| last log lines:", [ln for ln in p.stdout.splitlines() if "reward" in ln.lower()][-2:])
     assert res["actor_class"] == "harl_amd.happo.HAPPO" and "critic_agent.pt" in res["saved"]
 
 

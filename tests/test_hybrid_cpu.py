@@ -42,16 +42,16 @@ def test_two_layer_networks_take_the_hybrid_step(stub_kernels, monkeypatch):  # 
     r = _runner([128, 128])
     n = _train(r, stub_kernels)
     assert n["harl_update_fwd_actor"] == A * n_upd and n["harl_update_fwd_critic"] == n_upd
-    # ... and the whole backward of the 128 x 128 layer in ONE launch (round 5: dx + dW_2' + the fused dW_1', inputs <= 32 wide)
-    assert n["harl_mlp_bwd_dx_dw"] == (A + 1) * n_upd and "harl_mlp_bwd_dx" not in n and "harl_mlp_dw_partials" not in n
-    for c in stub_kernels["harl_mlp_bwd_dx_dw"]:
-        assert c[8] is None and c[9] is not None and c[10] == 32 and c[11] is not None and c[12] is not None and c[14] == 1
+    assert n["harl_mlp_bwd_dx"] == (A + 1) * n_upd and n["harl_mlp_dw_partials"] == (A + 1) * n_upd and "harl_mlp_bwd_dx_dw" not in n
     assert "harl_actor_head_loss" not in n and "harl_update_bwd" not in n and "harl_mlp_fwd_fused2x" not in n
     for c in stub_kernels["harl_update_fwd_actor"]:
         assert c[31] is not None and c[32] is not None and c[33] is not None  # xh1, rmask1, rstd1: the hybrid outputs
-    monkeypatch.setenv("HARL_BWD_FUSED", "0")  # the layer kernels of rounds 1-4
+    # HARL_BWD_FUSED=1: the whole backward of the 128 x 128 layer in ONE launch (round 5: dx + dW_2' + the fused dW_1', inputs <= 32 wide)
+    monkeypatch.setenv("HARL_BWD_FUSED", "1")
     n = _train(_runner([128, 128]), stub_kernels)
-    assert n["harl_mlp_bwd_dx"] == (A + 1) * n_upd and n["harl_mlp_dw_partials"] == (A + 1) * n_upd and "harl_mlp_bwd_dx_dw" not in n
+    assert n["harl_mlp_bwd_dx_dw"] == (A + 1) * n_upd and "harl_mlp_bwd_dx" not in n and "harl_mlp_dw_partials" not in n
+    for c in stub_kernels["harl_mlp_bwd_dx_dw"]:
+        assert c[8] is None and c[9] is not None and c[10] == 32 and c[11] is not None and c[12] is not None and c[14] == 1
     monkeypatch.delenv("HARL_BWD_FUSED")
     monkeypatch.setenv("HARL_FUSED_UPDATE", "logp")
     n = _train(_runner([128, 128]), stub_kernels)
@@ -73,9 +73,13 @@ def test_deeper_networks_run_their_last_layer_inside_the_loss_launch(stub_kernel
     # hidden forward launches: only the log-prob passes (one third layer each: A post-update passes) -- the optimiser steps'
     # third layer is inside harl_update_last_*
     assert n.get("harl_mlp_fwd_hidden", 0) == A
-    # the backward: one launch per hidden Linear (layer 3 -> 2 writes dz_2, layer 2 -> 1 carries the first-layer gradient)
+    # the backward is the layer kernels': two bwd_dx and two hidden weight gradients per step
+    assert n["harl_mlp_bwd_dx"] == 2 * (A + 1) * n_upd and n["harl_mlp_dw_partials"] == 2 * (A + 1) * n_upd
+    monkeypatch.setenv("HARL_BWD_FUSED", "1")  # one launch per hidden Linear (layer 3 -> 2 writes dz_2, layer 2 -> 1 carries dW_1')
+    n = _train(_runner([128, 128, 128]), stub_kernels)
     assert n["harl_mlp_bwd_dx_dw"] == 2 * (A + 1) * n_upd and "harl_mlp_bwd_dx" not in n and "harl_mlp_dw_partials" not in n
     assert sum(1 for c in stub_kernels["harl_mlp_bwd_dx_dw"] if c[11] is None and c[8] is not None) == (A + 1) * n_upd
+    monkeypatch.delenv("HARL_BWD_FUSED")
     for c in stub_kernels["harl_update_last_actor"]:
         assert c[2] == 128 and c[12] is None  # width; identity row order (one minibatch)
     monkeypatch.setenv("HARL_FUSED_UPDATE", "logp")

@@ -31,6 +31,7 @@ SIGNATURES = {
     "harl_dist_rows": [_vp, _l, _i, _i, _vp, _f, _f, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "harl_moments_mean": [_vp, _vp, _vp],
     "harl_clock_probe": [_vp, _l, _vp],
+    "harl_build_seq": [_vp, _i, _i, _i, _l, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp],
     "harl_adv_normalize": [_vp, _vp, _vp, _l, _vp],
     "harl_factor_update": [_vp, _vp, _vp, _l, _i, _i, _vp],
     "harl_sum_sumsq": [_vp, _vp, _l, _vp, _vp],

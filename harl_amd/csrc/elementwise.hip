@@ -386,6 +386,46 @@ extern "C" int harl_moments_mean(const double *moments3, float *mean_out, void *
   return check_launch("harl_moments_mean");
 }
 
+// Row tables of a recurrent minibatch (nets.build_seq, buffer mode): sequence j of the batch covers source rows first[j] + l * stride
+// of the t-major flattened buffers (the reference's chunk slicing, on_policy_actor_buffer.py:255-322, and naive whole-column
+// sampling, :180-221); padding sequences (j >= m) replay sequence 0.  One launch instead of the eight small torch kernels
+// (arange, broadcast add, two gathers, cat ...) every recurrent minibatch cost before -- 45 of them per 8-agent SMAC update, with
+// the GPU idle in between.  idx / valid_idx: int64 row indices [L * m_pad] / [L * m]; mask_rows = masks_src[idx]; h0 = h0_src[first].
+__global__ __launch_bounds__(256) void k_build_seq(const int64_t *__restrict__ first, int m, int m_pad, int L, long stride,
+                                                   const float *__restrict__ masks_src, const float *__restrict__ h0_src, int H,
+                                                   int64_t *__restrict__ idx, int64_t *__restrict__ valid_idx,
+                                                   float *__restrict__ mask_rows, float *__restrict__ h0) {
+  const long gt = (long)blockIdx.x * blockDim.x + threadIdx.x, gn = (long)gridDim.x * blockDim.x;
+  const long n_rows = (long)L * m_pad;
+  for (long e = gt; e < n_rows; e += gn) {
+    const int l = (int)(e / m_pad), j = (int)(e - (long)l * m_pad);
+    const long row = first[j < m ? j : 0] + (long)l * stride;
+    idx[e] = row;
+    mask_rows[e] = masks_src[row];
+    if (valid_idx && j < m) valid_idx[(long)l * m + j] = row;
+  }
+  const long n_h = (long)m_pad * H;
+  for (long e = gt; e < n_h; e += gn) {
+    const int j = (int)(e / H), f = (int)(e - (long)j * H);
+    h0[e] = h0_src[first[j < m ? j : 0] * H + f];
+  }
+}
+
+extern "C" int harl_build_seq(const int64_t *first, int m, int m_pad, int L, long stride, const float *masks_src,
+                              const float *h0_src, int H, int64_t *idx, int64_t *valid_idx, float *mask_rows, float *h0,
+                              void *stream) {
+  if (m <= 0 || m_pad < m || L <= 0 || H <= 0) {
+    set_error("harl_build_seq: bad arguments");
+    return -1;
+  }
+  const long work = (long)L * m_pad > (long)m_pad * H ? (long)L * m_pad : (long)m_pad * H;
+  long blocks = (work + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(k_build_seq, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, first, m, m_pad, L, stride,
+                     masks_src, h0_src, H, idx, valid_idx, mask_rows, h0);
+  return check_launch("harl_build_seq");
+}
+
 // Shader-clock probe (measurement aid of bench.py, no counterpart in the reference): ONE lane waits for `ticks` periods of the
 // constant 100 MHz counter (s_memrealtime) and reports how many shader cycles (s_memtime) went by in the meantime.  Launched
 // on a side stream next to a training step it gives the clock the chip actually sustains under THAT load (the matrix-pipe

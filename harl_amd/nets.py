@@ -970,6 +970,20 @@ def build_seq(dev, L: int, m: int, H: int, *, first_rows: Optional[torch.Tensor]
     Returns dict(L, m, m_pad, idx (None = identity), valid_idx, h0, mask_rows, h_last)."""
     m_pad = (m + 31) // 32 * 32
     direct = first_rows is None
+    if not direct and h0 is None and torch.device(dev).type == "cuda":
+        # buffer mode on the device: ONE launch (harl_build_seq) instead of eight small torch kernels per minibatch
+        first = first_rows.to(dev, non_blocking=True)
+        n = L * m_pad
+        idx = torch.empty(n, dtype=torch.int64, device=dev)
+        valid_idx = idx if m_pad == m else torch.empty(L * m, dtype=torch.int64, device=dev)
+        mask_rows = torch.empty(n, dtype=torch.float32, device=dev)
+        h0o = torch.empty(m_pad, H, dtype=torch.float32, device=dev)
+        msrc, hsrc = masks_src.reshape(-1), h0_src.reshape(-1, H)
+        assert msrc.is_contiguous() and hsrc.is_contiguous() and msrc.dtype == torch.float32 and hsrc.dtype == torch.float32
+        call("harl_build_seq", ptr(first), m, m_pad, L, int(stride), ptr(msrc), ptr(hsrc), H, ptr(idx),
+             None if m_pad == m else ptr(valid_idx), ptr(mask_rows), ptr(h0o), stream())
+        return dict(L=L, m=m, m_pad=m_pad, idx=idx, valid_idx=valid_idx, h0=h0o, mask_rows=mask_rows,
+                    h_last=torch.empty(m_pad, H, dtype=torch.float32, device=dev) if want_h_last else None)
     if direct:
         first, stride = torch.arange(m, device=dev), m
     else:

@@ -73,6 +73,13 @@ int harl_dist_rows(const float *head, long M, int act_dim, int kind, const float
 /* mean_out[0] = (float)(moments3[0] / moments3[2]) of a harl_masked_moments triple: the (active-mask-weighted) mean of the
  * entropy rows that evaluate_actions returns (act.py:104-157) */
 int harl_moments_mean(const double *moments3, float *mean_out, void *stream);
+/* Row tables of a recurrent minibatch in ONE launch (the chunk slicing of on_policy_actor_buffer.py:255-322 /
+ * on_policy_critic_buffer_ep.py:285-381 and the naive whole-column sampling :180-221): sequence j < m covers source rows
+ * first[j] + l * stride, l < L, of the t-major flattened buffers; sequences m .. m_pad-1 (padding to the 32-sample slab) replay
+ * sequence 0.  idx[l * m_pad + j] = that row (int64), valid_idx[l * m + j] the same without the padding (may be NULL),
+ * mask_rows = masks_src[idx], h0[j] = h0_src[first[j]] (H floats per row). */
+int harl_build_seq(const int64_t *first, int m, int m_pad, int L, long stride, const float *masks_src, const float *h0_src,
+                   int H, int64_t *idx, int64_t *valid_idx, float *mask_rows, float *h0, void *stream);
 /* Measurement aid (bench.py; nothing in the reference corresponds to it): one lane waits `ticks` periods of the constant
  * 100 MHz counter and writes {shader cycles elapsed, ticks elapsed} to cycles_ticks[0..1] (int64, device) -- the shader clock
  * under whatever runs next to it on other streams.  ticks in (0, 1e8]. */

@@ -1423,7 +1423,6 @@ def check_bench_config_parity(logp: str = "recipe", n_threads: int = 4096, n_per
 
     def pooled(get, key):
         """max error of the HIP figures / max(1e-5, NOISE_FACTOR x the oracle's pooled own uncertainty on this kind of figure)"""
-        from tests.helpers import NOISE_FACTOR
         err = float(rel(get(hip), get(o)).max())
         floor = float(rel(get(o), get(o64)).max())
         for pr in perts:
@@ -1455,7 +1454,6 @@ def check_bench_config_parity(logp: str = "recipe", n_threads: int = 4096, n_per
                                      [o["cinfo"]["value_loss"], o["cinfo"]["critic_grad_norm"]])
     ovn = o["vn"]
     out["vn_final_rel"] = rel_err(hip["vn"], [float(np.asarray(ovn[k]).reshape(-1)[0]) for k in ("running_mean", "running_mean_sq", "debiasing_term")])
-    from tests.helpers import NOISE_FACTOR
     worst_raw, floor = 0.0, 0.0
     for a in range(A):
         raw = vec_rel_err(hip["fin"][a], o["fin"][a])

@@ -22,6 +22,7 @@
 #include "dw_common.h"
 #include "../../include/harl_hip.h"
 #include <stdlib.h>
+#include <type_traits>
 
 using namespace harl;
 
@@ -1214,19 +1215,26 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_dw_tr_multi(DwMulti P, long n
 // two operands (dz 512 B + x_hat_prev 512 B per sample) from HBM one after the other: half of the MPE step's time and 17 of its
 // 58 GB.  Matches autograd through MLPLayer (harl/models/base/mlp.py:25-38, happo.py:93-100).
 //
-// One workgroup per CU, four waves, 148 KiB of LDS: the three split images of Wp^T (96 KiB, as k_bwd_dx) and ONE slab's
-// transposition buffer of k_dw_tr (48 KiB).  A super-round = four slabs, one per wave:
+// One workgroup per CU, four waves, 144 KiB of LDS: the three split images of Wp^T (96 KiB, as k_bwd_dx) and TWO transposition
+// buffers for x_hat_prev^T (k_dw_tr's image, 24 KiB each).  A super-round = four slabs, one per wave:
 //   O part (the owner's slab, k_bwd_dx's body): dz already split (below) -> 192 MFMAs -> LayerNorm/ReLU backward -> dz_prev
 //     (stored, KT = 0) or the first-layer weight gradient on the matrix-pipe transposes (KT = 1, mfma_transpose.h);
-//   D part, four rounds, one per slab of the super-round (k_dw_tr's body): every wave fetches a quarter of the slab's dz and
-//     x_hat_prev pieces again (from L2 / the infinity cache: the owners touched them microseconds ago, so HBM sees them once),
-//     splits them, stores them into the transposition buffer; barrier; each wave multiplies its 1 x 4 output tiles (48 MFMAs).
-// The point of having both in one instruction stream is the FILLERS: a wave has one MFMA in flight for 32 cycles but needs ~12 of
-// issue for it, and up to five VALU instructions placed BETWEEN two MFMAs are free (profiles/r03_mfma_valu_overlap.md).  The D
-// rounds' MFMA phases are otherwise pure matrix work, so the exact operand split of the NEXT round's pieces (32 chunks of 5-7
-// VALU) and of the owner's NEXT slab of dz (64 chunks per super-round: the 2.2k cycles k_bwd_dx spends in "split dz" per slab)
-// are dealt out one chunk per MFMA, pinned with sched_barrier (source order is honoured exactly).
-// FILL = false runs the same chunks as a block in front of each MFMA phase (A/B: what the interleaving buys).
+//   D part, four rounds, one per slab of the super-round: wave w owns row tile w of dW' (output features 32 w .. 32 w + 31).
+//     Its A operand -- that 32-feature block of the slab's dz, transposed -- it makes itself on the matrix pipe (its four float4
+//     pieces of the block, split exactly, times the permuted identity: 6 MFMAs, no LDS, and the transposition's row sums are
+//     db'); the B operand x_hat_prev^T is shared: every wave splits a quarter of the slab's pieces and stores them into the
+//     round's buffer, the fragments come back through ds_read_b64_tr_b16.  Both are fetched again from L2 / the infinity cache
+//     (the owners touched them microseconds ago), so HBM sees dz and x_hat_prev once.
+// Version 1 of this kernel (one buffer, both operands through LDS, two barriers per round) measured no faster than the pair it
+// replaces: with one workgroup per CU nothing overlaps a barrier wait (profiles/r05_bwd_fused_ab.md).  Hence the software
+// pipeline: everything round n+1 needs is prepared DURING round n's 48 product MFMAs -- a wave has one MFMA in flight for 32
+// cycles but needs ~12 of issue for it, and up to five VALU instructions placed BETWEEN two MFMAs are free
+// (profiles/r03_mfma_valu_overlap.md) -- as filler chunks of 5-8 VALU pinned behind each MFMA with sched_barrier (source order
+// is honoured exactly): the split of the next A block (16 chunks), its 6 transposing MFMAs, the packing of their results, the
+// split of the next B pieces (16 chunks), and a share of the split of the OWNER's next slab of dz (64 chunks per super-round:
+// the 2.2k cycles k_bwd_dx spends in "split dz" per slab).  The B terms are stored at the END of round n into the buffer round
+// n-1 read, so ONE barrier per round suffices (every wave has left round n-1 when any wave stores for n+1), and it finds the
+// stores long complete.  FILL = false runs the same chunks as a block in front of the product MFMAs (A/B).
 // Per-workgroup partial rows in the layout of harl_reduce_partials_multi: dW' by tiles straight from the accumulators (the
 // waves own disjoint row tiles), dW_1' through finish_partials; rows gridDim.x .. n_part_rows-1 of both arenas are cleared.
 // =============================================================================================
@@ -1243,20 +1251,30 @@ __device__ __forceinline__ void split_stage2(float r0, float r1, unsigned &p2, u
   p3 = __builtin_amdgcn_perm(__float_as_uint(q1), __float_as_uint(q0), 0x07060302u);
 }
 
+// compile-time loop: f(std::integral_constant<int, I>) for I = I0 .. N-1 -- every index inside is a constant expression, whatever
+// the unroller thinks of the body's size (a `#pragma unroll` loop that stays rolled turns register arrays into scratch)
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F &&f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
 constexpr int BDW_SQ = (128 / 16) * 128 + 8, BDW_IMG = 8 * BDW_SQ;  // k_dw_tr's image geometry at H = 128
-constexpr size_t bdw_lds_bytes() { return split_image_bytes(128, 128) + (size_t)6 * BDW_IMG; }
+constexpr int BDW_BUF = 3 * BDW_IMG;                                // one transposition buffer: three term images
+constexpr size_t bdw_lds_bytes() { return split_image_bytes(128, 128) + (size_t)2 * BDW_BUF; }
 
 template <int KT, bool FILL>
 __global__ __launch_bounds__(WG_THREADS, 1) void k_bwd_dx_dw(
     const float *__restrict__ dz, const float *__restrict__ xprev, const uint32_t *__restrict__ mask_prev,
     const float *__restrict__ rstd_prev, const float *__restrict__ Wp, float *__restrict__ dz_prev, long n_slabs,
     const float *__restrict__ x0n, float *__restrict__ dw1_part, float *__restrict__ dw2_part, int n_part_rows) {
-  constexpr int H = 128, MT = 4, NJ = 8, NR = 64, KPF = 32, NPW = 4;  // NPW: A pieces (and B pieces) per wave and slab
+  constexpr int H = 128, MT = 4, NJ = 8, NR = 64, KPF = 32;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   PHASE_BEGIN();
   u32x4 *img = reinterpret_cast<u32x4 *>(lds);
-  unsigned char *Ab = reinterpret_cast<unsigned char *>(img + 3 * MT * NJ * 64);  // [3 terms][BDW_IMG]: dz^T staging
-  unsigned char *Bb = Ab + 3 * BDW_IMG;                                           // [3 terms][BDW_IMG]: x_hat_prev^T staging
+  unsigned char *Bb = reinterpret_cast<unsigned char *>(img + 3 * MT * NJ * 64);  // [2][3 terms][BDW_IMG]: x_hat_prev^T staging
   stage_split_matrix<H, H, true, WG_THREADS>(img, Wp);
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = wave_id();
@@ -1264,12 +1282,13 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_bwd_dx_dw(
   const u32x4 *wl = img + lane;
   const long sr_stride = (long)gridDim.x * WAVES_PER_WG;
   const long base0 = (long)blockIdx.x * WAVES_PER_WG;
+  const Ident ident = make_ident(lane);
 
   // ---- persistent accumulators
   f32x16 acc2[4];                 // dW' tiles (row tile = wave, column tiles 0..3)
   f32x16 acc1[KT > 0 ? 4 : 1];    // dW_1' tiles (KT = 1)
   float dbs[KT > 0 ? 4 : 1];      // db_1' (per-lane sums over the lane's samples)
-  float dbacc[NPW][4];            // db' of this wave's A pieces (per-lane sums)
+  float db2 = 0.f;                // db' of feature 32 wave + (lane & 31): this lane half's 16 samples of every slab
 #pragma unroll
   for (int b = 0; b < 4; ++b)
 #pragma unroll
@@ -1280,59 +1299,91 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_bwd_dx_dw(
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc1[a][r] = 0.f;
   }
-#pragma unroll
-  for (int u = 0; u < NPW; ++u)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) dbacc[u][c] = 0.f;
 
-  // ---- D-part state: this wave's eight float4 pieces of a slab (A: dz pieces 4 wave + u, B: x_hat pieces 4 wave + u) and
-  // their split terms sp[piece][term] = {pair 0, pair 1} (one ds_write_b64 each)
-  f32x4 pr[2 * NPW];
-  u32x2_t sp[2 * NPW][3];
+  // ---- D-part state.  prA: the four float4 pieces 4 wave + u of a slab's dz = registers 16 wave .. 16 wave + 15 of the
+  // accumulator layout = the 32-feature block `wave`; prB: pieces 4 wave + u of x_hat_prev (this wave's quarter of the B operand)
+  f32x4 prA[4], prB[4];
+  u32x2_t spB[4][3];          // split terms of prB: one ds_write_b64 each
+  u32x4 ya[3][2];             // split terms of prA by k-step (split_transpose_block's y1 / y2 / y3)
+  f32x16 tc[3];               // the three transposed terms (lane = feature, 16 samples)
+  u32x4 At[3][2], AtN[3][2];  // A operands [term][k-step] of this round / of the next one
+  float rr0 = 0.f, rr1 = 0.f; // remainders between the two stages of a pair's split
   auto d_load = [&](long ds) {
 #pragma unroll
-    for (int u = 0; u < 2 * NPW; ++u) {
-      const float *src = (u < NPW ? dz : xprev) + ds * (long)(H * SLAB);
-      pr[u] = (reinterpret_cast<const f32x4 *>(src) + lane)[(NPW * wave + (u & (NPW - 1))) * WAVE];
+    for (int u = 0; u < 4; ++u) {
+      prA[u] = (reinterpret_cast<const f32x4 *>(dz + ds * (long)(H * SLAB)) + lane)[(4 * wave + u) * WAVE];
+      prB[u] = (reinterpret_cast<const f32x4 *>(xprev + ds * (long)(H * SLAB)) + lane)[(4 * wave + u) * WAVE];
     }
   };
-  float rr0 = 0.f, rr1 = 0.f;  // remainders between the two stages of a pair's split
-  // D chunk k (0..31): piece k>>2, pair (k>>1)&1, stage k&1
-  auto d_chunk = [&](int k) {
-    const int u = k >> 2, c2 = (k >> 1) & 1;
+  // Preparing a round that will not be executed (past the last slab) is harmless -- its operands are never multiplied -- except
+  // for the bias sums of its A block: `vnext` (1 or 0) multiplies them.  The loads of such a round are clamped to a valid slab.
+  float vnext = 1.f;
+  auto d_load_next = [&](long ds, long fallback) { d_load(ds < n_slabs ? ds : fallback); };
+  // A chunk k (0..15): pair p = k >> 1 = registers 2p, 2p + 1 of the block -> word p & 3 of k-step p >> 2; stage k & 1
+  auto a_chunk = [&](int k) {
+    const int pi = k >> 1, j = pi >> 2, c = pi & 3, u = pi >> 1, e = 2 * (pi & 1);
     if ((k & 1) == 0) {
       unsigned p1;
-      split_stage1(pr[u][2 * c2], pr[u][2 * c2 + 1], p1, rr0, rr1);
-      sp[u][0][c2] = p1;
-      if (u < NPW) {
-        dbacc[u][2 * c2] += pr[u][2 * c2];
-        dbacc[u][2 * c2 + 1] += pr[u][2 * c2 + 1];
-      }
+      split_stage1(prA[u][e], prA[u][e + 1], p1, rr0, rr1);
+      ya[0][j][c] = p1;
     } else {
       unsigned p2, p3;
       split_stage2(rr0, rr1, p2, p3);
-      sp[u][1][c2] = p2;
-      sp[u][2][c2] = p3;
+      ya[1][j][c] = p2;
+      ya[2][j][c] = p3;
     }
   };
-  auto d_store = [&]() {
+  // B chunk k (0..15): piece k >> 2, pair (k >> 1) & 1, stage k & 1
+  auto b_chunk = [&](int k) {
+    const int u = k >> 2, c2 = (k >> 1) & 1;
+    if ((k & 1) == 0) {
+      unsigned p1;
+      split_stage1(prB[u][2 * c2], prB[u][2 * c2 + 1], p1, rr0, rr1);
+      spB[u][0][c2] = p1;
+    } else {
+      unsigned p2, p3;
+      split_stage2(rr0, rr1, p2, p3);
+      spB[u][1][c2] = p2;
+      spB[u][2][c2] = p3;
+    }
+  };
+  // transposing MFMA k (0..5) of the A block: term k % 3, k-step k / 3 (mfma_transpose.h, transpose_block)
+  auto t_mfma = [&](int k) {
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int t = k % 3;
+    if (k < 3) tc[t] = mfma_bf16(ya[t][0], ident.j0, zero);
+    else tc[t] = mfma_bf16(ya[t][1], ident.j1, tc[t]);
+  };
+  // pack chunk k (0..5): k < 3: term k -> the two k-step operands; k >= 3: its row sums into db'
+  auto p_chunk = [&](int k) {
+    if (k < 3) {
+      pack_transposed(tc[k], AtN[k][0], AtN[k][1]);
+    } else {
+      f32x2 a = {0.f, 0.f};
 #pragma unroll
-    for (int u = 0; u < 2 * NPW; ++u) {
-      const int q = NPW * wave + (u & (NPW - 1));
-      unsigned char *d = (u < NPW ? Ab : Bb) + (i >> 2) * BDW_SQ + (2 * (q >> 2) + ((q & 3) >> 1)) * 128 + (i & 3) * 32 +
+      for (int r = 0; r < 8; ++r) a += f32x2{tc[k - 3][2 * r], tc[k - 3][2 * r + 1]};
+      db2 += vnext * (a[0] + a[1]);
+    }
+  };
+  auto b_store = [&](int buf) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int q = 4 * wave + u;
+      unsigned char *d = Bb + buf * BDW_BUF + (i >> 2) * BDW_SQ + (2 * (q >> 2) + ((q & 3) >> 1)) * 128 + (i & 3) * 32 +
                          (8 * (q & 1) + 4 * h) * 2;
 #pragma unroll
-      for (int term = 0; term < 3; ++term) *reinterpret_cast<u32x2_t *>(d + term * BDW_IMG) = sp[u][term];
+      for (int term = 0; term < 3; ++term) *reinterpret_cast<u32x2_t *>(d + term * BDW_IMG) = spB[u][term];
     }
   };
-  // fragment address of this lane inside a term image (k_dw_tr)
+  // B fragment of column tile `tile`, k-step ks: the eight samples sigma(r, h) = (r & 3) + 8 (r >> 2) + 4 h + 16 ks, r = 0..7 --
+  // the order the matrix-pipe transposition leaves the A operand in (mfma_transpose.h): sample quads 4 ks + h and 4 ks + 2 + h
   const int p16 = lane & 15, g1b = (lane >> 4) & 1;
   const int frag_lane = g1b * 128 + (p16 >> 2) * 32 + (p16 & 3) * 8;
-  auto read_frag = [&](const unsigned char *base_img, int ks, int tile, u32x4 (&f)[3]) {
+  auto read_frag = [&](int buf, int ks, int tile, u32x4 (&f)[3]) {
 #pragma unroll
     for (int term = 0; term < 3; ++term) {
-      const unsigned char *fp = base_img + term * BDW_IMG + (4 * ks + 2 * h) * BDW_SQ + 2 * tile * 128 + frag_lane;
-      const u32x2_t lo = tr_read(fp), hi = tr_read(fp + BDW_SQ);
+      const unsigned char *fp = Bb + buf * BDW_BUF + term * BDW_IMG + (4 * ks + h) * BDW_SQ + 2 * tile * 128 + frag_lane;
+      const u32x2_t lo = tr_read(fp), hi = tr_read(fp + 2 * BDW_SQ);
       f[term] = u32x4{lo[0], lo[1], hi[0], hi[1]};
     }
   };
@@ -1346,19 +1397,40 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_bwd_dx_dw(
     split_acts<NR, false>(raw, g1, g2, g3);
   }
   // O chunk k (0..63) of the NEXT slab's split: pair k>>1 (registers 2p, 2p+1 -> word p&3 of k-step p>>2), stage k&1
-  auto o_chunk = [&](int k) {
+  // (two streams of them run side by side in a round: each keeps its own remainders between the stages of a pair)
+  float rx0 = 0.f, rx1 = 0.f;
+  auto o_chunk = [&](int k, bool second_stream) {
     const int pi = k >> 1, j = pi >> 2, c = pi & 3;
+    float &q0 = second_stream ? rx0 : rr0, &q1 = second_stream ? rx1 : rr1;
     if ((k & 1) == 0) {
       unsigned p1;
-      split_stage1(raw[2 * pi], raw[2 * pi + 1], p1, rr0, rr1);
+      split_stage1(raw[2 * pi], raw[2 * pi + 1], p1, q0, q1);
       g1[j][c] = p1;
     } else {
       unsigned p2, p3;
-      split_stage2(rr0, rr1, p2, p3);
+      split_stage2(q0, q1, p2, p3);
       g2[j][c] = p2;
       g3[j][c] = p3;
     }
   };
+  // ---- the first round of the first super-round is prepared in the open
+  if (base0 < n_slabs) {
+    d_load(base0);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) a_chunk(k);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) t_mfma(k);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) b_chunk(k);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) p_chunk(k);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      At[t][0] = AtN[t][0];
+      At[t][1] = AtN[t][1];
+    }
+    b_store(0);
+  }
   PHASE(10);
 
   for (long base = base0; base < n_slabs; base += sr_stride) {
@@ -1387,8 +1459,6 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_bwd_dx_dw(
       PHASE(0);
       split_gemm<MT, NJ>(wl, g1, g2, g3, acc, [](int) {});
       PHASE(1);
-      // this wave's pieces of the first D round: their latency sits under the LayerNorm backward and the first-layer gradient
-      d_load(base);
       float dx[NR];
 #pragma unroll
       for (int R = 0; R < NR; ++R) dx[R] = acc[R >> 4][R & 15];
@@ -1397,7 +1467,6 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_bwd_dx_dw(
       if (dz_prev) atl_store<H>(dz_prev, slab, lane, out);
       PHASE(2);
       if constexpr (KT > 0) {
-        const Ident ident = make_ident(lane);
         float xr0[KPF / 2];
 #pragma unroll
         for (int q = 0; q < KPF / 8; ++q) {
@@ -1412,80 +1481,89 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_bwd_dx_dw(
         transpose_block<false>(a1[0], a1[1], a2[0], a2[1], a3[0], a3[1], ident, Bt);
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
-          u32x4 At[3][2];
-          dbs[a] += split_transpose_block<true>(&out[16 * a], ident, At);
-          dw_tile(acc1[a], At, Bt);
+          u32x4 A1[3][2];
+          dbs[a] += split_transpose_block<true>(&out[16 * a], ident, A1);
+          dw_tile(acc1[a], A1, Bt);
         }
         PHASE(3);
       }
-    } else {
-      d_load(base);
     }
     // =========================== D part: the four slabs of this super-round ===========================
-    // the owner's NEXT slab of dz (g1..g3 are dead since the GEMM): first needed by the fillers of round 1, a full round away --
-    // not earlier, the first-layer gradient above is the register peak of this kernel
+    // the owner's NEXT slab of dz (g1..g3 are dead since the GEMM; first needed by the fillers of round 1) and this wave's
+    // pieces of round 1 (round 0's operands were prepared by the previous super-round's last round / the prologue) -- not
+    // earlier: the first-layer gradient above is the register peak of this kernel
     atl_load<H>(dz, nxt, lane, raw);
-#pragma unroll
-    for (int k = 0; k < 8 * NPW; ++k) d_chunk(k);  // round 0's pieces are split in the open (once per super-round)
+    d_load_next(base + 1, base);
     PHASE(4);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    static_for<0, 4>([&](auto rc) {
+      constexpr int r = decltype(rc)::value;
       if (base + r < n_slabs) {  // workgroup-uniform
-        __syncthreads();  // the previous round's fragments are fully read
+        __syncthreads();  // every wave's B terms of this round are in buffer r & 1; buffer (r + 1) & 1 is free
         PHASE(5);
-        d_store();
-        if (r < 3) {  // sp holds this round's terms now: pr is free for the next round's pieces (zeros past the last slab, so
-          // that the filler chunks below need no test: they add nothing to db' and their terms are never stored)
-          if (base + r + 1 < n_slabs) {
-            d_load(base + r + 1);
+        // the round being prepared (r + 1, or round 0 of the next super-round) and the one whose pieces are requested (r + 2; none
+        // from round 3: the next super-round fetches its round 1 itself)
+        const long ds1 = r < 3 ? base + r + 1 : base + sr_stride;
+        const long ds2 = r < 2 ? base + r + 2 : base + sr_stride;
+        vnext = uniform_f(ds1 < n_slabs ? 1.f : 0.f);
+        // the owner's 64 split chunks: 0 / 22 / 22 / 20 per round, as a main stream of 16 (slots 32..47) and a second stream of
+        // 6 / 6 / 4 beside it (slots 32..); every range starts at an even chunk = the first stage of a pair
+        constexpr int O_FIRST = r == 1 ? 0 : (r == 2 ? 22 : 44), O_EXTRA = r == 3 ? 4 : 6;
+        // TSLOT: the product MFMA behind which the six transposing MFMAs are issued
+        constexpr int TSLOT = r == 0 ? 31 : 15;
+        auto slot = [&](auto sc) {  // filler work behind product MFMA s (0..47)
+          constexpr int s_ = decltype(sc)::value;
+          if constexpr (r == 0) {  // the pieces of round 1 were requested just above: nothing in the first 16 slots
+            if constexpr (s_ >= 16 && s_ < 32) a_chunk(s_ - 16);
+            else if constexpr (s_ >= 32 && s_ < 42) b_chunk(s_ - 32 + 6);
+            else if constexpr (s_ >= 42) p_chunk(s_ - 42);
+            if constexpr (s_ == 41) d_load_next(ds2, base);
           } else {
-#pragma unroll
-            for (int u = 0; u < 2 * NPW; ++u) pr[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (s_ < 16) a_chunk(s_);
+            else if constexpr (s_ < 26) b_chunk(s_ - 16 + 6);
+            else if constexpr (s_ < 32) p_chunk(s_ - 26);
+            else {
+              o_chunk(O_FIRST + s_ - 32, false);
+              if constexpr (s_ - 32 < O_EXTRA) o_chunk(O_FIRST + 16 + s_ - 32, true);
+            }
+            if constexpr (s_ == 25 && r < 3) d_load_next(ds2, base);
           }
-        }
-        __syncthreads();
-        PHASE(6);
-        // ---- 2 k-steps x 4 column tiles x the six cross products; fragments one tile-step ahead; one filler chunk per MFMA.
-        // Rounds 0..2: slots 16..47 split the next round's pieces (fetched just above: the early slots give them time to land),
-        // rounds 1 and 2 also 8 chunks each of the owner's next slab; round 3 has no next round and takes the other 48
-        auto fill = [&](int m) {
-          if (r == 3) o_chunk(16 + m);
-          else if (m >= 16) d_chunk(m - 16);
-          else if (r >= 1 && m < 8) o_chunk(8 * (r - 1) + m);
+          if constexpr (s_ == TSLOT) {  // the six transposing MFMAs, each with one of the first six B chunks behind it
+            static_for<0, 6>([&](auto kc) {
+              constexpr int k = decltype(kc)::value;
+              __builtin_amdgcn_sched_barrier(0);
+              t_mfma(k);
+              b_chunk(k);
+            });
+          }
         };
-        u32x4 av[2][3], bv[2][3];
-        read_frag(Ab, 0, wave, av[0]);
-        read_frag(Bb, 0, 0, bv[0]);
-        if constexpr (!FILL) {
-#pragma unroll
-          for (int m = 0; m < 48; ++m) fill(m);
-        }
-#pragma unroll
-        for (int n = 0; n < 8; ++n) {
-          const int ks = n >> 2, b = n & 3;
-          if (n + 1 < 8) {
-            const int ks1 = (n + 1) >> 2, b1 = (n + 1) & 3;
-            if (b1 == 0) read_frag(Ab, ks1, wave, av[ks1 & 1]);
-            read_frag(Bb, ks1, b1, bv[(n + 1) & 1]);
-          }
+        u32x4 bv[2][3];
+        read_frag(r & 1, 0, 0, bv[0]);
+        if constexpr (!FILL) static_for<0, 48>(slot);
+        // ---- 2 k-steps x 4 column tiles x the six cross products; B fragments one tile-step ahead
+        static_for<0, 8>([&](auto nc) {
+          constexpr int n = decltype(nc)::value, ks = n >> 2, b = n & 3;
+          if constexpr (n + 1 < 8) read_frag(r & 1, (n + 1) >> 2, (n + 1) & 3, bv[(n + 1) & 1]);
           __builtin_amdgcn_sched_barrier(0);
-          const u32x4(&A)[3] = av[ks & 1];
-          const u32x4(&B)[3] = bv[n & 1];
-#define BDW_STEP(AT, BT, slot)                         \
-  acc2[b] = mfma_bf16(A[AT], B[BT], acc2[b]);          \
-  if constexpr (FILL) fill(6 * n + slot);              \
-  __builtin_amdgcn_sched_barrier(0);
-          BDW_STEP(2, 0, 0)
-          BDW_STEP(0, 2, 1)
-          BDW_STEP(1, 1, 2)
-          BDW_STEP(1, 0, 3)
-          BDW_STEP(0, 1, 4)
-          BDW_STEP(0, 0, 5)
-#undef BDW_STEP
+          constexpr int AT[6] = {2, 0, 1, 1, 0, 0}, BT[6] = {0, 2, 1, 0, 1, 0};  // the six cross products, smallest first
+          static_for<0, 6>([&](auto kc) {
+            constexpr int k6 = decltype(kc)::value;
+            acc2[b] = mfma_bf16(At[AT[k6]][ks], bv[n & 1][BT[k6]], acc2[b]);
+            if constexpr (FILL) slot(std::integral_constant<int, 6 * n + k6>{});
+            __builtin_amdgcn_sched_barrier(0);
+          });
+        });
+        PHASE(6);
+        // the next round's B terms into the buffer the PREVIOUS round read (every wave has passed this round's barrier, i.e.
+        // left the previous round); its A operands become current
+        b_store((r + 1) & 1);
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          At[t][0] = AtN[t][0];
+          At[t][1] = AtN[t][1];
         }
         PHASE(7);
       }
-    }
+    });
   }
 
   // ---- this workgroup's partial row of dW' | db' straight from the accumulators (disjoint tiles), the unused rows cleared
@@ -1499,15 +1577,8 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_bwd_dx_dw(
         const int o = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * h;
         mypart[(long)o * H + 32 * b + i] = acc2[b][r];
       }
-#pragma unroll
-    for (int u = 0; u < NPW; ++u) {
-      const int q = NPW * wave + u;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const float t = half_reduce_sum(dbacc[u][c]);
-        if (i == 0) mypart[(long)H * H + 32 * (q >> 2) + 8 * (q & 3) + 4 * h + c] = t;
-      }
-    }
+    const float dbt = wave_sum32(db2);
+    if (h == 0) mypart[(long)H * H + 32 * wave + i] = dbt;
     for (int row = blockIdx.x + gridDim.x; row < n_part_rows; row += gridDim.x) {
       float *z = dw2_part + (long)row * ROW2;
       for (int e = threadIdx.x; e < ROW2; e += WG_THREADS) z[e] = 0.f;

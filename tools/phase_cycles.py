@@ -22,7 +22,7 @@ NAMES = {
     ("mlp", 0): ("k_bwd_dx<KT>0> (bwd_dx_dw1)", ["split dz", "issue loads", "GEMM", "LN bwd + store", "dW1"]),
     ("mlp", 1): ("k_bwd_dx<KT=0>", ["split dz", "issue loads", "GEMM", "LN bwd + store"]),
     ("mlp", 3): ("k_bwd_dx_dw (bwd_full[_dw1]: dx + dW' + dW1' in one launch)",
-                 ["issue loads", "GEMM dx", "LN bwd (+ store)", "dW1", "round-0 split (open)", "barrier 1", "stores", "MFMA rounds + fillers"]),
+                 ["issue loads", "GEMM dx", "LN bwd (+ store)", "dW1", "D-part loads issue", "barrier", "MFMA rounds + fillers", "B stores"]),
     ("mlp", 2): ("k_dw_tr", ["barrier 1", "split + store", "barrier 2", "MFMA phase"]),
     ("wide", 0): ("k_fwd_fused2x", ["split x0n + load", "GEMM 1", "relu/LN 1 + store", "split x1", "GEMM 2", "relu/LN 2 + store"]),
     ("heads", 0): ("k_actor_head<TRAIN, FUSE>", ["row loads + x load issue", "head fwd", "sample / loss", "head dW", "head bwd + store"]),

@@ -38,16 +38,22 @@ def _fused_update_mode() -> str:
     return mode
 
 
-def _bwd_fused_mode() -> str:
-    """``HARL_BWD_FUSED``: "0" (default) = the layer kernels (harl_mlp_dw_partials + harl_mlp_bwd_dx); "1" = 128 x 128 hidden
-    layers take harl_mlp_bwd_dx_dw (dx + the layer's weight gradient + the fused first-layer one in ONE launch, operand splits
-    interleaved with the MFMAs: dz and x_hat cross HBM once); "nofill" = the same launch with the splits in separate phases.
-    The one-launch backward is parity-green and moves 17 % fewer bytes per step but measured 2 % SLOWER end to end on MI355X
-    (17.54 against 17.21 ms per MPE update, profiles/r05_bwd_fused_ab.md): with one workgroup per CU its barrier-separated
-    transposition rounds have no second workgroup to overlap with -- DESIGN.md section 3, round 5."""
-    m = os.environ.get("HARL_BWD_FUSED", "0")
-    if m not in ("0", "1", "nofill"):
-        raise ValueError(f"HARL_BWD_FUSED={m!r}: expected 0, 1 or nofill")
+BWD_FUSED_MIN_ROWS = 400_000
+
+
+def _bwd_fused_mode(M: int = 0) -> str:
+    """``HARL_BWD_FUSED``: "auto" (default) = 128 x 128 hidden layers take harl_mlp_bwd_dx_dw (dx + the layer's weight gradient +
+    the fused first-layer one in ONE launch, operand splits interleaved with the MFMAs: dz and x_hat cross HBM once) when the
+    minibatch has at least BWD_FUSED_MIN_ROWS rows, the layer kernels (harl_mlp_dw_partials + harl_mlp_bwd_dx) below that;
+    "1" / "0" force one or the other; "nofill" = the one-launch kernel with the splits in separate phases (A/B).
+    Measured on MI355X (profiles/r05_bwd_fused_ab.md): 17 % fewer HBM bytes per MPE step at the SAME step time (17.09 ms both),
+    -2.5 % on the 6-agent three-layer workload (819 200 rows per launch); at 204 800 rows (6.25 super-rounds per workgroup, the
+    weight staging and the pipeline's first round amortised over too few slabs) it is 1.5 % slower -- hence the threshold."""
+    m = os.environ.get("HARL_BWD_FUSED", "auto")
+    if m not in ("0", "1", "nofill", "auto"):
+        raise ValueError(f"HARL_BWD_FUSED={m!r}: expected auto, 0, 1 or nofill")
+    if m == "auto":
+        return "1" if M >= BWD_FUSED_MIN_ROWS else "0"
     return m
 
 
@@ -680,7 +686,7 @@ class _FlatNet(nn.Module):
             return
         # first-layer weight gradient fused into the last bwd_dx (needs the ones column of x0n: in_dim < kp0)
         fuse_dw1 = L >= 2 and self.x0n is not None and self.in_dim < self.kp0 and self.kp0 <= 64
-        bwd_mode = _bwd_fused_mode()
+        bwd_mode = _bwd_fused_mode(M)
         side_pending = False
         if (bwd_mode != "0" and fuse_dw1 and self.kp0 == 64 and L >= 2 and self.hidden_sizes[0] == 128 and self.hidden_sizes[1] == 128
                 and os.environ.get("HARL_BWD_K64", "0") == "1"):

@@ -1444,7 +1444,14 @@ def check_bench_config_parity(logp: str = "recipe", n_threads: int = 4096, n_per
             ffloor = max([float(rel(get(o)[0, 0], get(o64)[0, 0]))] + [float(rel(get(pr)[0, 0], get(o)[0, 0])) for pr in perts])
             out[f"_first_update_{nm}_rel"] = first
             out[f"_first_update_{nm}_oracle_own_uncertainty"] = ffloor
-            out[f"first_update_{nm}_excess"] = first / max(1e-5, NOISE_FACTOR * ffloor)
+            if nm == "policy_loss":
+                # |loss| ~ 5e-5 here (mean of 819 200 unit-scale terms that cancel): the figure with a meaning is the ABSOLUTE
+                # difference -- in units of the advantage-normalised terms' scale (~1) -- held to 1e-7 by the test
+                out["_first_update_policy_loss_value"] = float(get(o)[0, 0])
+                out["_first_update_policy_loss_abs"] = float(abs(get(hip)[0, 0] - get(o)[0, 0]))
+                out["_first_update_policy_loss_excess"] = first / max(1e-5, NOISE_FACTOR * ffloor)
+            else:
+                out[f"first_update_{nm}_excess"] = first / max(1e-5, NOISE_FACTOR * ffloor)
         pooled(get, f"actor_update_{nm}")
     for c, nm in enumerate(("value_loss", "grad_norm")):
         out[f"critic_update_{nm}_rel"] = float(rel(hip["ctr"][:, c], o["ctr"][:, c]).max())

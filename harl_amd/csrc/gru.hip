@@ -11,6 +11,7 @@
 // Both weight matrices stay in LDS (W_ih fp32 [3H][H+1], W_hh as three bf16 images: 122 KiB for H = 64 -> one workgroup per CU).
 // H = 64 only (every recurrent tuned HARL config: SMAC / SMACv2 / football use hidden 64).
 #include "common.h"
+#include <stdlib.h>
 #include "split_mfma.h"
 #include "../../include/harl_hip.h"
 
@@ -264,13 +265,17 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_gru_fwd(
 // h~_{l+1} = h_l * mask_{l+1}, already split into its three bf16 terms (= the partner's missing B-operand k-steps), and the
 // half-row LayerNorm partials (mean_w, M2_w), merged with the exact pairwise formula
 //     mean = (mean_0 + mean_1) / 2,   M2 = M2_0 + M2_1 + 16 (mean_0 - mean_1)^2      (32 + 32 features).
-// The input half of the gates comes from k_gru_gates_x and is fetched one step ahead.  Inference only (nothing saved).
+// The input half of the gates comes from k_gru_gates_x and is fetched one step ahead.  Round 5: it also SAVES the internals
+// the backward needs (h~, r, z, n, hn: every wave stores its own half of each ATL(64) image, four float4 pieces), so the
+// training forward of a chunked minibatch takes it too: 8192 sequences x 10 steps are 256 chains -- 64 workgroups of the
+// one-wave-per-slab kernel on a 256-CU chip, 76 us per launch, 45 launches per 8-agent update.
 // =============================================================================================
 __global__ __launch_bounds__(WG_THREADS, 1) void k_gru_fwd_tp(
     const float *__restrict__ gi_r, const float *__restrict__ gi_z, const float *__restrict__ gi_n,
     const float *__restrict__ mrow, const float *__restrict__ h0, const float *__restrict__ Whh,
     const float *__restrict__ bhh, int L, long m_pad, float *__restrict__ y, float *__restrict__ rstd_y,
-    float *__restrict__ h_last) {
+    float *__restrict__ h_last, float *__restrict__ hpm_s, float *__restrict__ r_s, float *__restrict__ z_s,
+    float *__restrict__ n_s, float *__restrict__ hn_s) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int MTH = 3 * GT, NJH = GH / 16, TS = MTH * NJH * 64, HR = GR / 2;  // HR = 16 registers per lane and wave
   u32x4 *Whimg = reinterpret_cast<u32x4 *>(lds);                     // [3 terms][6 tiles][4 k-steps][64 lanes] x 16 B
@@ -303,6 +308,11 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_gru_fwd_tp(
       const f32x4 *pp = reinterpret_cast<const f32x4 *>(base + slab * (long)(GH * SLAB)) + lane;
 #pragma unroll
       for (int q = 0; q < HR / 4; ++q) dst[q] = pp[(4 * w + q) * WAVE];
+    };
+    auto store_own = [&](float *base, long slab, const float (&v)[HR]) {  // this wave's half of an ATL(64) image
+      f32x4 *pp = reinterpret_cast<f32x4 *>(base + slab * (long)(GH * SLAB)) + lane;
+#pragma unroll
+      for (int q = 0; q < HR / 4; ++q) pp[(4 * w + q) * WAVE] = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
     };
     f32x4 gr[HR / 4], gz[HR / 4], gn[HR / 4];
     own_pieces(gi_r, G, gr);
@@ -362,13 +372,24 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_gru_fwd_tp(
           __builtin_amdgcn_sched_barrier(0);
         }
         float sum = 0.f;
+        float rgs[HR], zgs[HR], ngs[HR], hns[HR];
 #pragma unroll
         for (int r = 0; r < HR; ++r) {
           const float rg = sigmoidf_(ar[r]);
           const float zg = sigmoidf_(az[r]);
           const float ng = tanhf_(gnx[r] + rg * ah[r]);
+          rgs[r] = rg;
+          zgs[r] = zg;
+          ngs[r] = ng;
+          hns[r] = ah[r];
           hs[r] = (1.f - zg) * ng + zg * hm[r];
           sum += hs[r];
+        }
+        if (r_s && live) {  // (wave-uniform) the backward's operands, as k_gru_fwd<true> leaves them
+          store_own(r_s, slab, rgs);
+          store_own(z_s, slab, zgs);
+          store_own(n_s, slab, ngs);
+          store_own(hn_s, slab, hns);
         }
         sum = wave_sum32(sum);
         mean_own = sum * (1.0f / 32.f);
@@ -383,6 +404,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_gru_fwd_tp(
       // ---- hand-off: h~ (own half) as split operands + LayerNorm partials
 #pragma unroll
       for (int r = 0; r < HR; ++r) hm[r] = hs[r] * mk;
+      if (hpm_s && live && l + 1 < L) store_own(hpm_s, (long)(l + 1) * groups + G, hm);  // h~_{l+1} = h_l * mask_{l+1}
       u32x4 o1[HR / 8], o2[HR / 8], o3[HR / 8];
       split_acts<HR>(hm, o1, o2, o3);
       u32x4 *xo = xch + (((buf * 2 + pair) * 2 + w) * 6) * 64 + lane;
@@ -762,12 +784,15 @@ extern "C" int harl_gru_fwd(const float *xin, const float *mask_rows, const floa
     allow_big_lds(k_gru_gates_x, shm_x);
     hipLaunchKernelGGL(k_gru_gates_x, dim3(persistent_grid(n_slabs, 1)), dim3(WG_THREADS), shm_x, s, xin, Wih, bih, bhh,
                        n_slabs, gr, gz, gn);
-    if (!save && groups <= GRU_TP_MAX_GROUPS) {  // few dependent chains: two waves per slab (k_gru_fwd_tp)
+    // few dependent chains: two waves per slab (k_gru_fwd_tp); HARL_GRU_TP_SAVE=0 keeps training forwards on the one-wave kernel (A/B)
+    static const bool tp_save = [] { const char *e = getenv("HARL_GRU_TP_SAVE"); return !(e && e[0] == '0'); }();
+    if (groups <= GRU_TP_MAX_GROUPS && (!save || tp_save)) {
       const size_t shm_tp = split_image_bytes(3 * GH, GH) + (size_t)2 * 2 * 2 * 6 * 64 * 16 + ((size_t)2 * 2 * 2 * 64 * 2 + GH) * sizeof(float);
       allow_big_lds(k_gru_fwd_tp, shm_tp);
       const long wg2 = (groups + 1) / 2;
       hipLaunchKernelGGL(k_gru_fwd_tp, dim3((unsigned)(wg2 < 256 ? wg2 : 256)), dim3(WG_THREADS), shm_tp, s, gr, gz, gn, mask_rows,
-                         h0, Whh, bhh, L, m_pad, y, rstd_y, h_last);
+                         h0, Whh, bhh, L, m_pad, y, rstd_y, h_last, save ? hpm : nullptr, save ? r : nullptr,
+                         save ? z : nullptr, save ? n : nullptr, save ? hn : nullptr);
       return check_launch("harl_gru_fwd");
     }
     const size_t shm = split_image_bytes(3 * GH, GH) + ((size_t)2 * 3 * GH) * sizeof(float);

@@ -381,7 +381,12 @@ class _FlatNet(nn.Module):
         n_iter = (n_slabs + 1) // 2
         # rows of the per-workgroup partial arena = grid of the weight-gradient kernels (two workgroups per CU: the measured
         # optimum at 819 200 rows).  HARL_NWG overrides it (A/B measurements).
-        self.n_wg = max(1, min(int(os.environ.get("HARL_NWG", "512")), n_iter))
+        # ... and fewer rows for small minibatches: ~10 slabs per workgroup keep 256+ workgroups busy from 2 560 slabs on, below that
+        # the per-workgroup partial rows (written by every weight-gradient launch, read back by the combine) cost more than the
+        # parallelism returns -- 2 560 slabs (the 8-agent recurrent workload): 256 rows instead of 512
+        nwg_env = os.environ.get("HARL_NWG")
+        nwg_cap = int(nwg_env) if nwg_env else max(256, min(512, n_slabs // 10))
+        self.n_wg = max(1, min(nwg_cap, n_iter))
         part_off, rows = 0, [list(r) for r in self._table_rows]
         self._part_offs = []
         for r, elems in zip(rows, self._elems):
@@ -961,6 +966,35 @@ def consume_policy_init_rng(args: dict, obs_space, action_space) -> None:
     draw(nn.Linear(d, n_out), args["gain"])
 
 
+_FIRST_RING: dict = {}
+
+
+def _upload_first_rows(first_rows: torch.Tensor, dev) -> torch.Tensor:
+    """CPU int64 sequence starts -> device, asynchronously: copied into the next slot of a ring of pinned buffers (an event per
+    slot guards its reuse: 32 slots = 32 minibatches back, long executed) and from there with a non-blocking copy on the current
+    stream.  Device tensors pass through."""
+    if first_rows.is_cuda:
+        return first_rows
+    n = first_rows.numel()
+    ring = _FIRST_RING.get(dev)
+    if ring is None or ring["cap"] < n:
+        cap = max(4096, 2 * n)
+        ring = dict(cap=cap, k=0, bufs=[torch.empty(cap, dtype=torch.int64, pin_memory=True) for _ in range(32)],
+                    evs=[None] * 32)
+        _FIRST_RING[dev] = ring
+    k = ring["k"]
+    ring["k"] = (k + 1) % 32
+    if ring["evs"][k] is not None:
+        ring["evs"][k].synchronize()
+    stage = ring["bufs"][k][:n]
+    stage.copy_(first_rows.reshape(-1))
+    out = stage.to(dev, non_blocking=True)
+    ev = ring["evs"][k] or torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(dev))
+    ring["evs"][k] = ev
+    return out
+
+
 def build_seq(dev, L: int, m: int, H: int, *, first_rows: Optional[torch.Tensor] = None, stride: Optional[int] = None,
               h0: Optional[torch.Tensor] = None, h0_src: Optional[torch.Tensor] = None,
               masks_src: Optional[torch.Tensor] = None, want_h_last: bool = False) -> dict:
@@ -977,8 +1011,10 @@ def build_seq(dev, L: int, m: int, H: int, *, first_rows: Optional[torch.Tensor]
     m_pad = (m + 31) // 32 * 32
     direct = first_rows is None
     if not direct and h0 is None and torch.device(dev).type == "cuda":
-        # buffer mode on the device: ONE launch (harl_build_seq) instead of eight small torch kernels per minibatch
-        first = first_rows.to(dev, non_blocking=True)
+        # buffer mode on the device: ONE launch (harl_build_seq) instead of eight small torch kernels per minibatch; the sequence
+        # starts travel through a ring of pinned staging buffers, so that the upload is asynchronous (a pageable source made
+        # every minibatch wait for its copy with the stream drained: 20 us of idle GPU x 45 minibatches per 8-agent update)
+        first = _upload_first_rows(first_rows, dev)
         n = L * m_pad
         idx = torch.empty(n, dtype=torch.int64, device=dev)
         valid_idx = idx if m_pad == m else torch.empty(L * m, dtype=torch.int64, device=dev)

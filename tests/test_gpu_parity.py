@@ -270,14 +270,14 @@ def test_bench_configuration_onpolicy_against_oracle():
     gradient a sum of 819 200 terms that cancel to ~1e-3 of their mass: the fp32 oracle's own grad-norms sit 2.2e-3 from its
     float64 twin over the 15 updates (HIP: 4.1e-3 from the fp32 oracle, 0.92 of the bar), its policy losses 1.2e-2 (HIP 7.6e-3).
     What does not divide by a near-zero number is held to 1e-5 FLAT: every update's entropy, the critic throughout, the first
-    update's entropy / grad-norm / ratio; the first update's policy loss (|value| ~ 5e-5) to 1e-7 absolute; the rest keeps the
+    update's entropy / grad-norm / ratio; the first update's policy loss (|value| ~ 2e-3) to 1e-7 absolute; the rest keeps the
     measured bar."""
-    res = _G().check_bench_config_parity(logp="onpolicy", n_pert=1)
+    res = _G().check_bench_config_parity(logp="onpolicy", n_pert=3)  # (worker processes: three one-ulp twins cost no wall time)
     print("bench-config parity (on-policy):", {k: (f"{v:.3e}" if isinstance(v, float) else v) for k, v in res.items()})
     _assert_all(res)
     for k in ("_actor_update_dist_entropy_rel", "_first_update_dist_entropy_rel", "_first_update_grad_norm_rel", "_first_update_ratio_rel"):
         assert res[k] < TOL, (k, res[k])
-    # the first update's policy loss is ~5e-5 (a mean of unit-scale terms that cancel): 1e-7 ABSOLUTE = 1e-7 of the terms' scale
+    # the first update's policy loss is ~2e-3 (a mean of unit-scale terms that cancel): 1e-7 ABSOLUTE = 1e-7 of the terms' scale
     assert res["_first_update_policy_loss_abs"] < 1e-7, res["_first_update_policy_loss_abs"]
 
 

@@ -13,6 +13,7 @@
 //      A fragments from there, amortised over TWO slabs per wave.
 // The first-layer weight gradient of wide inputs is k_dw_tr (mlp.hip) over column groups of the same x0n image.
 #include <type_traits>
+#include <stdlib.h>
 #include "common.h"
 #include "split_mfma.h"
 #include "../../include/harl_hip.h"
@@ -304,6 +305,71 @@ __global__ __launch_bounds__(256) void k_split_image(const float *__restrict__ W
   }
 }
 
+// epilogue of one slab of the wide GEMMs.  MODE 0: ReLU + LayerNorm + mask; MODE 1 (tangent): the LayerNorm Jacobian (forward mode,
+// the bias slot carries b'_dot):  x_dot = LNjac(mask * z_dot) with the PRIMAL x_hat / mask / rstd;  MODE 2 (raw): z as an ATL image
+template <int HO, int MODE>
+__device__ __forceinline__ void wide_epilogue(f32x16 (&acc)[HO / 32], long slab, int lane, float *__restrict__ xout,
+                                              uint32_t *__restrict__ mask_out, float *__restrict__ rstd_out,
+                                              const float *__restrict__ xprimal, const uint32_t *__restrict__ mask_in,
+                                              const float *__restrict__ rstd_in) {
+  constexpr int NR = HO / 2, NW = (NR + 31) / 32;
+  if constexpr (MODE == 2) {
+    float z[NR];
+#pragma unroll
+    for (int R = 0; R < NR; ++R) z[R] = acc[R >> 4][R & 15];
+    atl_store<HO>(xout, slab, lane, z);
+  } else if constexpr (MODE == 1) {
+    float xh[NR];
+    atl_load<HO>(xprimal, slab, lane, xh);
+    uint32_t bits[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) bits[w] = mask_in[(slab * NW + w) * WAVE + lane];
+    const float rstd = rstd_in[slab * SLAB + (lane & 31)];
+    float ad[NR];
+    float q1 = 0.f, q2 = 0.f;
+#pragma unroll
+    for (int R = 0; R < NR; ++R) {
+      ad[R] = mask_pop(acc[R >> 4][R & 15], bits[R >> 5]);
+      q1 += ad[R];
+      q2 += ad[R] * xh[R];
+    }
+    q1 = wave_sum32(q1);
+    q2 = wave_sum32(q2);
+    q1 *= (1.0f / HO);
+    q2 *= (1.0f / HO);
+#pragma unroll
+    for (int R = 0; R < NR; ++R) ad[R] = rstd * (ad[R] - q1 - xh[R] * q2);
+    atl_store<HO>(xout, slab, lane, ad);
+  } else {
+    uint32_t bits[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) bits[w] = 0u;
+    float v[NR];
+    float sum = 0.f;
+#pragma unroll
+    for (int R = 0; R < NR; ++R) {
+      v[R] = relu_push(acc[R >> 4][R & 15], bits[R >> 5]);
+      sum += v[R];
+    }
+    sum = wave_sum32(sum);
+    const float mean = sum * (1.0f / HO);
+    float vs = 0.f;
+#pragma unroll
+    for (int R = 0; R < NR; ++R) {
+      v[R] -= mean;
+      vs += v[R] * v[R];
+    }
+    vs = wave_sum32(vs);
+    const float rstd = 1.0f / sqrtf(vs * (1.0f / HO) + 1e-5f);
+#pragma unroll
+    for (int R = 0; R < NR; ++R) v[R] *= rstd;
+    atl_store<HO>(xout, slab, lane, v);
+#pragma unroll
+    for (int w = 0; w < NW; ++w) mask_out[(slab * NW + w) * WAVE + lane] = bits[w];
+    if (lane < 32) rstd_out[slab * SLAB + lane] = rstd;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // x0n ATL(KP) -> H.  Each wave owns two slabs at a time (every A fragment read from L2 feeds 12 MFMAs); the fragments
 // and activations of k-step j+1 are in flight while the MFMAs of k-step j run.
@@ -391,77 +457,135 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_fwd_wide(const float *__restr
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    if constexpr (MODE == 2) {
-      auto epi = [&](f32x16(&acc)[MT], long slab) {
-        float z[HO / 2];
+    wide_epilogue<HO, MODE>(acc0, s0, lane, xout, mask_out, rstd_out, xprimal, mask_in, rstd_in);
+    if (s1 != s0) wide_epilogue<HO, MODE>(acc1, s1, lane, xout, mask_out, rstd_out, xprimal, mask_in, rstd_in);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same GEMM with the weight fragments SHARED by the four waves of the workgroup (round 5).  k_fwd_wide lets every wave
+// stream its own A fragments from L2: 12 KiB of weights and 4 KiB of activations per k-step and wave for 24 MFMAs -- at 204 800
+// rows (Humanoid-17x1: 561 tangent launches of this kind per update, 31 % of it) the launch moves 0.63 GB of weight fragments
+// next to 0.42 GB of activations and is bound by what one CU can load (~15 B per cycle with this mix), 5x above the matrix
+// pipe's time.  Here a PANEL of four k-steps (3 terms x HO/32 tiles x 4 x 1 KiB = 48 KiB at HO = 128) is copied into LDS once
+// per workgroup-iteration (8 slabs) and read back as lane-linear ds_read_b128: a quarter of the weight traffic.  Two buffers,
+// one barrier per panel: the next panel travels global -> registers during the current one's MFMAs and is written into the
+// buffer the PREVIOUS panel used (every wave left that panel at the last barrier).  The panels of consecutive iterations form
+// one cyclic sequence (the weights do not change), so the pipeline never drains.
+// ---------------------------------------------------------------------------------------------
+constexpr int WSH_PJ = 4;  // k-steps per panel
+template <int HO, int MODE>
+__global__ __launch_bounds__(WG_THREADS, 1) void k_fwd_wide_sh(const float *__restrict__ x0n, const u32x4 *__restrict__ img,
+                                                               const float *__restrict__ bp, float *__restrict__ xout,
+                                                               uint32_t *__restrict__ mask_out, float *__restrict__ rstd_out,
+                                                               const float *__restrict__ xprimal,
+                                                               const uint32_t *__restrict__ mask_in,
+                                                               const float *__restrict__ rstd_in, long n_slabs, int KP,
+                                                               const float *__restrict__ x0n_b = nullptr, int KPA = 0) {
+  constexpr int MT = HO / 32, PAN = 3 * MT * WSH_PJ * 64, PER = PAN / WG_THREADS;  // u32x4 per panel buffer / per thread
+  static_assert(PAN % WG_THREADS == 0, "panel fragments divide evenly over the threads");
+  extern __shared__ __attribute__((aligned(16))) float lds_w[];
+  u32x4 *wsh = reinterpret_cast<u32x4 *>(lds_w);  // [2][PAN]
+  const int NJ = KP / 16, TS = MT * NJ * 64, NP = (NJ + WSH_PJ - 1) / WSH_PJ;
+  const int KA = x0n_b ? KPA : KP, NJA = KA / 16, KB = KP - KA;
+  const int lane = threadIdx.x & 63, wave = wave_id(), h = lane >> 5;
+  const long n_pairs = (n_slabs + 1) / 2;
+  // panel pn -> registers: thread copies elements e = tid + 256 u of the panel, e = ((term * MT + t) * 4 + jj) * 64 + lane
+  u32x4 wreg[PER];
+  auto fetch_panel = [&](int pn) {
 #pragma unroll
-        for (int R = 0; R < HO / 2; ++R) z[R] = acc[R >> 4][R & 15];
-        atl_store<HO>(xout, slab, lane, z);
-      };
-      epi(acc0, s0);
-      if (s1 != s0) epi(acc1, s1);
-    } else if constexpr (MODE == 1) {
-      // (the bias slot carries bdp)  x1dot = LNjac(mask1 * (Wdp x0n + bdp))
-      {
-        constexpr int NR = HO / 2, NW = (NR + 31) / 32;
-        auto epi = [&](f32x16(&acc)[MT], long slab) {
-          float xh[NR];
-          atl_load<HO>(xprimal, slab, lane, xh);
-          uint32_t bits[NW];
+    for (int u = 0; u < PER; ++u) {
+      const int e = threadIdx.x + u * WG_THREADS, ln = e & 63, jj = (e >> 6) % WSH_PJ, tt = (e >> 6) / WSH_PJ;  // tt = term * MT + t
+      const int j = pn * WSH_PJ + jj, term = tt / MT, t = tt - term * MT;
+      wreg[u] = img[(long)term * TS + (t * NJ + (j < NJ ? j : NJ - 1)) * 64 + ln];
+    }
+  };
+  auto store_panel = [&](int buf) {
 #pragma unroll
-          for (int w = 0; w < NW; ++w) bits[w] = mask_in[(slab * NW + w) * WAVE + lane];
-          const float rstd = rstd_in[slab * SLAB + (lane & 31)];
-          float ad[NR];
-          float q1 = 0.f, q2 = 0.f;
+    for (int u = 0; u < PER; ++u) wsh[buf * PAN + threadIdx.x + u * WG_THREADS] = wreg[u];
+  };
+  fetch_panel(0);
+  store_panel(0);
+  fetch_panel(NP > 1 ? 1 : 0);  // the panel after the first (panel 0 again when there is only one)
+  __syncthreads();
+  int buf = 0, pnext = NP > 1 ? 1 : 0;  // buffer of the current panel; index of the panel in flight
+  for (long p0 = (long)blockIdx.x * WAVES_PER_WG; p0 < n_pairs; p0 += (long)gridDim.x * WAVES_PER_WG) {  // uniform trip count
+    const bool live = p0 + wave < n_pairs;
+    const long pair = live ? p0 + wave : n_pairs - 1;
+    const long s0 = 2 * pair, s1 = s0 + 1 < n_slabs ? s0 + 1 : s0;
+    const f32x4 *xp0 = reinterpret_cast<const f32x4 *>(x0n + s0 * (long)KA * SLAB) + lane;
+    const f32x4 *xp1 = reinterpret_cast<const f32x4 *>(x0n + s1 * (long)KA * SLAB) + lane;
+    const f32x4 *xq0 = x0n_b ? reinterpret_cast<const f32x4 *>(x0n_b + s0 * (long)KB * SLAB) + lane : xp0;
+    const f32x4 *xq1 = x0n_b ? reinterpret_cast<const f32x4 *>(x0n_b + s1 * (long)KB * SLAB) + lane : xp1;
+    f32x16 acc0[MT], acc1[MT];
 #pragma unroll
-          for (int R = 0; R < NR; ++R) {
-            ad[R] = mask_pop(acc[R >> 4][R & 15], bits[R >> 5]);
-            q1 += ad[R];
-            q2 += ad[R] * xh[R];
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc0[t][r] = acc1[t][r] = bp[32 * t + (r & 3) + 8 * (r >> 2) + 4 * h];
+    f32x4 bn[2][2];
+    auto fetch_act = [&](int j) {
+      const f32x4 *b0 = j < NJA ? xp0 + (2 * j) * WAVE : xq0 + (2 * (j - NJA)) * WAVE;  // (wave-uniform)
+      const f32x4 *b1 = j < NJA ? xp1 + (2 * j) * WAVE : xq1 + (2 * (j - NJA)) * WAVE;
+      bn[0][0] = b0[0];
+      bn[0][1] = b0[WAVE];
+      bn[1][0] = b1[0];
+      bn[1][1] = b1[WAVE];
+    };
+    fetch_act(0);
+    for (int pn = 0; pn < NP; ++pn) {
+      const u32x4 *wl = wsh + buf * PAN + lane;
+#pragma unroll 1  // (unrolled, the compiler hoists all four k-steps' fragment reads and spills)
+      for (int jj = 0; jj < WSH_PJ; ++jj) {
+        const int j = pn * WSH_PJ + jj;
+        if (j < NJ) {  // (uniform)
+          u32x4 a[3][MT];
+#pragma unroll
+          for (int term = 0; term < 3; ++term)
+#pragma unroll
+            for (int t = 0; t < MT; ++t) a[term][t] = wl[((term * MT + t) * WSH_PJ + jj) * 64];
+          u32x4 b[2][3];
+#pragma unroll
+          for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              const f32x4 &src = bn[sl][c >> 1];
+              unsigned p1, p2, p3;
+              split3(src[2 * (c & 1)], src[2 * (c & 1) + 1], p1, p2, p3);
+              b[sl][0][c] = p1;
+              b[sl][1][c] = p2;
+              b[sl][2][c] = p3;
+            }
+          if (j + 1 < NJ) fetch_act(j + 1);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int t = 0; t < MT; ++t) {
+            acc0[t] = mfma_bf16(a[2][t], b[0][0], acc0[t]);
+            acc1[t] = mfma_bf16(a[2][t], b[1][0], acc1[t]);
+            acc0[t] = mfma_bf16(a[0][t], b[0][2], acc0[t]);
+            acc1[t] = mfma_bf16(a[0][t], b[1][2], acc1[t]);
+            acc0[t] = mfma_bf16(a[1][t], b[0][1], acc0[t]);
+            acc1[t] = mfma_bf16(a[1][t], b[1][1], acc1[t]);
+            acc0[t] = mfma_bf16(a[1][t], b[0][0], acc0[t]);
+            acc1[t] = mfma_bf16(a[1][t], b[1][0], acc1[t]);
+            acc0[t] = mfma_bf16(a[0][t], b[0][1], acc0[t]);
+            acc1[t] = mfma_bf16(a[0][t], b[1][1], acc1[t]);
+            acc0[t] = mfma_bf16(a[0][t], b[0][0], acc0[t]);
+            acc1[t] = mfma_bf16(a[0][t], b[1][0], acc1[t]);
           }
-          q1 = wave_sum32(q1);
-          q2 = wave_sum32(q2);
-          q1 *= (1.0f / HO);
-          q2 *= (1.0f / HO);
-#pragma unroll
-          for (int R = 0; R < NR; ++R) ad[R] = rstd * (ad[R] - q1 - xh[R] * q2);
-          atl_store<HO>(xout, slab, lane, ad);
-        };
-        epi(acc0, s0);
-        if (s1 != s0) epi(acc1, s1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
-    } else {
-      constexpr int NR = HO / 2, NW = (NR + 31) / 32;
-      auto epi = [&](f32x16(&acc)[MT], long slab) {
-        uint32_t bits[NW];
-#pragma unroll
-        for (int w = 0; w < NW; ++w) bits[w] = 0u;
-        float v[NR];
-        float sum = 0.f;
-#pragma unroll
-        for (int R = 0; R < NR; ++R) {
-          v[R] = relu_push(acc[R >> 4][R & 15], bits[R >> 5]);
-          sum += v[R];
-        }
-        sum = wave_sum32(sum);
-        const float mean = sum * (1.0f / HO);
-        float vs = 0.f;
-#pragma unroll
-        for (int R = 0; R < NR; ++R) {
-          v[R] -= mean;
-          vs += v[R] * v[R];
-        }
-        vs = wave_sum32(vs);
-        const float rstd = 1.0f / sqrtf(vs * (1.0f / HO) + 1e-5f);
-#pragma unroll
-        for (int R = 0; R < NR; ++R) v[R] *= rstd;
-        atl_store<HO>(xout, slab, lane, v);
-#pragma unroll
-        for (int w = 0; w < NW; ++w) mask_out[(slab * NW + w) * WAVE + lane] = bits[w];
-        if (lane < 32) rstd_out[slab * SLAB + lane] = rstd;
-      };
-      epi(acc0, s0);
-      if (s1 != s0) epi(acc1, s1);
+      // the panel in flight goes into the other buffer (last read one panel ago: every wave has passed that barrier), the one
+      // after it is requested; one barrier per panel
+      store_panel(buf ^ 1);
+      pnext = pnext + 1 < NP ? pnext + 1 : 0;
+      fetch_panel(pnext);
+      __syncthreads();
+      buf ^= 1;
+    }
+    if (live) {
+      wide_epilogue<HO, MODE>(acc0, s0, lane, xout, mask_out, rstd_out, xprimal, mask_in, rstd_in);
+      if (s1 != s0) wide_epilogue<HO, MODE>(acc1, s1, lane, xout, mask_out, rstd_out, xprimal, mask_in, rstd_in);
     }
   }
 }
@@ -598,6 +722,14 @@ __global__ __launch_bounds__(64 * F2X_WAVES, 2) void k_fwd_fused2x(
   PHASE_END(0);
 }
 
+// the shared-panel kernel from 512 slabs on (below that a workgroup's one or two iterations do not amortise the start of the panel
+// pipeline); HARL_WIDE_SHARED=0 keeps the streaming kernel (A/B and the bit-for-bit comparison of the two in the tests: read per call)
+constexpr size_t wide_sh_lds(int ho) { return (size_t)2 * 3 * (ho / 32) * WSH_PJ * 64 * 16; }
+bool wide_shared(long n_slabs) {
+  const char *e = getenv("HARL_WIDE_SHARED");
+  return !(e && e[0] == '0') && n_slabs >= 512;
+}
+
 template <int MODE>
 int launch_wide(const float *x0n, long M, int KP, const float *Wp, int D, const float *bp, int H, void *w_img, float *xout,
                 uint32_t *mask_out, float *rstd_out, const float *xprimal, const uint32_t *mask_in, const float *rstd_in,
@@ -611,6 +743,18 @@ int launch_wide(const float *x0n, long M, int KP, const float *Wp, int D, const 
   hipLaunchKernelGGL(k_split_image, dim3((total + 255) / 256), dim3(256), 0, s, Wp, H, D, KP, reinterpret_cast<u32x4 *>(w_img));
   const long pairs = (n_slabs + 1) / 2, wgs = (pairs + WAVES_PER_WG - 1) / WAVES_PER_WG;
   const int grid = (int)(wgs < 256 ? (wgs < 1 ? 1 : wgs) : 256);
+  if (wide_shared(n_slabs)) {  // weight fragments shared through LDS (k_fwd_wide_sh)
+    if (H == 128) {
+      allow_big_lds(k_fwd_wide_sh<128, MODE>, wide_sh_lds(128));
+      hipLaunchKernelGGL((k_fwd_wide_sh<128, MODE>), dim3(grid), dim3(WG_THREADS), wide_sh_lds(128), s, x0n,
+                         reinterpret_cast<const u32x4 *>(w_img), bp, xout, mask_out, rstd_out, xprimal, mask_in, rstd_in, n_slabs, KP);
+    } else {
+      allow_big_lds(k_fwd_wide_sh<64, MODE>, wide_sh_lds(64));
+      hipLaunchKernelGGL((k_fwd_wide_sh<64, MODE>), dim3(grid), dim3(WG_THREADS), wide_sh_lds(64), s, x0n,
+                         reinterpret_cast<const u32x4 *>(w_img), bp, xout, mask_out, rstd_out, xprimal, mask_in, rstd_in, n_slabs, KP);
+    }
+    return check_launch(what);
+  }
   if (H == 128)
     hipLaunchKernelGGL((k_fwd_wide<128, MODE>), dim3(grid), dim3(WG_THREADS), 0, s, x0n, reinterpret_cast<const u32x4 *>(w_img),
                        bp, xout, mask_out, rstd_out, xprimal, mask_in, rstd_in, n_slabs, KP);
@@ -641,6 +785,20 @@ extern "C" int harl_mlp_tangent_hidden2(const float *xin_dot, const float *xin, 
                      Wdp, HI);
   const long pairs = (n_slabs + 1) / 2, wgs = (pairs + WAVES_PER_WG - 1) / WAVES_PER_WG;
   const int grid = (int)(wgs < 256 ? (wgs < 1 ? 1 : wgs) : 256);
+  if (wide_shared(n_slabs)) {
+    if (HO == 128) {
+      allow_big_lds(k_fwd_wide_sh<128, 1>, wide_sh_lds(128));
+      hipLaunchKernelGGL((k_fwd_wide_sh<128, 1>), dim3(grid), dim3(WG_THREADS), wide_sh_lds(128), s, xin_dot,
+                         reinterpret_cast<const u32x4 *>(w_img), bdp, xout_dot, nullptr, nullptr, xprimal, mask_in, rstd_in, n_slabs,
+                         KP, xin, HI);
+    } else {
+      allow_big_lds(k_fwd_wide_sh<64, 1>, wide_sh_lds(64));
+      hipLaunchKernelGGL((k_fwd_wide_sh<64, 1>), dim3(grid), dim3(WG_THREADS), wide_sh_lds(64), s, xin_dot,
+                         reinterpret_cast<const u32x4 *>(w_img), bdp, xout_dot, nullptr, nullptr, xprimal, mask_in, rstd_in, n_slabs,
+                         KP, xin, HI);
+    }
+    return check_launch("harl_mlp_tangent_hidden2");
+  }
   if (HO == 128)
     hipLaunchKernelGGL((k_fwd_wide<128, 1>), dim3(grid), dim3(WG_THREADS), 0, s, xin_dot, reinterpret_cast<const u32x4 *>(w_img),
                        bdp, xout_dot, nullptr, nullptr, xprimal, mask_in, rstd_in, n_slabs, KP, xin, HI);

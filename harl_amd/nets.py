@@ -386,6 +386,12 @@ class _FlatNet(nn.Module):
         # parallelism returns -- 2 560 slabs (the 8-agent recurrent workload): 256 rows instead of 512
         nwg_env = os.environ.get("HARL_NWG")
         nwg_cap = int(nwg_env) if nwg_env else max(256, min(512, n_slabs // 10))
+        # ... and 256 rows when every weight gradient of this network comes out of a one-workgroup-per-CU launch (the fused forward's
+        # head gradient, harl_mlp_bwd_dx_dw for the trunk): the other 256 rows would only be cleared by them and read back by
+        # the combine (~22 MB each way per optimiser step at the 3-agent headline shapes)
+        if (not nwg_env and _bwd_fused_mode(M) == "1" and len(self.hidden_sizes) >= 2 and all(h == 128 for h in self.hidden_sizes)
+                and ((self.in_dim + 31) // 32) * 32 == 32 and not (self.recurrent or self.md or self.act_id or self.panel)):
+            nwg_cap = 256
         self.n_wg = max(1, min(nwg_cap, n_iter))
         part_off, rows = 0, [list(r) for r in self._table_rows]
         self._part_offs = []

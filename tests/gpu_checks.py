@@ -1549,6 +1549,60 @@ def check_generator_api(name: str) -> Dict[str, float]:
     return out
 
 
+def check_wide_shared(M: int = 70000) -> Dict[str, float]:
+    """The wide GEMMs with their weight fragments shared through LDS (k_fwd_wide_sh, round 5) against the streaming kernel they
+    replace from 512 slabs on (k_fwd_wide): same MFMA sequence per slab, so the outputs must agree BIT FOR BIT -- forward of a
+    393-wide first layer, its tangent, the raw mode, and the one-launch hidden tangent (K = 2 H), at a size where every workgroup
+    walks several 8-slab iterations and the last one is ragged."""
+    out: Dict[str, float] = {}
+    ns = (M + 31) // 32
+    mp = ns * 32
+    g = torch.Generator(device=DEV).manual_seed(3)
+    rn = lambda *sh: torch.randn(*sh, device=DEV, generator=g)  # noqa: E731
+    H = 128
+    for D in (393, 100):
+        KP = (D + 31) // 32 * 32
+        x0n = rn(mp * KP)
+        W, b = rn(H * D) * 0.1, rn(H) * 0.1
+        wimg = torch.empty(3 * H * KP // 2, device=DEV)
+        xh1 = rn(mp * H)
+        mask = torch.randint(-2 ** 31, 2 ** 31 - 1, (ns * 2 * 64,), device=DEV, dtype=torch.int32, generator=g)
+        rstd = torch.rand(mp, device=DEV, generator=g) + 0.5
+        res = {}
+        for mode in ("0", "1"):
+            os.environ["HARL_WIDE_SHARED"] = mode
+            xo, mo, ro = torch.zeros(mp * H, device=DEV), torch.zeros(ns * 2 * 64, dtype=torch.int32, device=DEV), torch.zeros(mp, device=DEV)
+            call("harl_mlp_fwd_wide", ptr(x0n), M, KP, ptr(W), D, ptr(b), H, ptr(wimg), ptr(xo), ptr(mo), ptr(ro), stream())
+            xd = torch.zeros(mp * H, device=DEV)
+            call("harl_mlp_tangent_wide", ptr(x0n), M, KP, ptr(W), D, ptr(b), H, ptr(wimg), ptr(xh1), ptr(mask), ptr(rstd), ptr(xd), stream())
+            zr = torch.zeros(mp * H, device=DEV)
+            call("harl_mlp_linear_wide", ptr(x0n), M, KP, ptr(W), D, ptr(b), H, ptr(wimg), ptr(zr), stream())
+            torch.cuda.synchronize()
+            res[mode] = (xo, mo, ro, xd, zr)
+        for k, nm in enumerate(("fwd_x", "fwd_mask", "fwd_rstd", "tangent", "raw")):  # (whole images: the padding rows see the same inputs)
+            out[f"D{D}_{nm}_mismatch"] = float((res["0"][k] != res["1"][k]).sum().item())
+        out[f"D{D}_fwd_all_zero_count"] = float((res["1"][0] != 0).sum().item() == 0)
+    # one-launch hidden tangent
+    xin, xdot = rn(mp * H), rn(mp * H)
+    Wp, Wd, bd = rn(H * H) * 0.1, rn(H * H) * 0.1, rn(H) * 0.1
+    wimg = torch.empty(3 * H * 2 * H // 2, device=DEV)
+    xh1 = rn(mp * H)
+    mask = torch.randint(-2 ** 31, 2 ** 31 - 1, (ns * 2 * 64,), device=DEV, dtype=torch.int32, generator=g)
+    rstd = torch.rand(mp, device=DEV, generator=g) + 0.5
+    res = {}
+    for mode in ("0", "1"):
+        os.environ["HARL_WIDE_SHARED"] = mode
+        o = torch.zeros(mp * H, device=DEV)
+        call("harl_mlp_tangent_hidden2", ptr(xdot), ptr(xin), M, H, H, ptr(Wp), ptr(Wd), ptr(bd), ptr(wimg), ptr(xh1), ptr(mask), ptr(rstd),
+             ptr(o), stream())
+        torch.cuda.synchronize()
+        res[mode] = o
+    os.environ.pop("HARL_WIDE_SHARED", None)
+    out["tangent_hidden2_mismatch"] = float((res["0"] != res["1"]).sum().item())
+    out["tangent_hidden2_nonzero_count"] = float((res["1"] != 0).sum().item() == 0)
+    return out
+
+
 def _atl_rows(t: torch.Tensor, ns: int, H: int) -> torch.Tensor:
     """ATL(H) image [ns slabs] -> rows [ns * 32, H] (common.h: piece q, lane half h, sample s, element c <-> feature
     32 (q >> 2) + 8 (q & 3) + 4 h + c)."""

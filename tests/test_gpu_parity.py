@@ -58,6 +58,12 @@ def test_wide_input_first_layer():
     _assert_all(_G().check_wide_input(), tol=5e-6)
 
 
+def test_wide_gemm_with_shared_weight_panels_is_bit_identical():
+    """k_fwd_wide_sh (weight fragments through LDS, round 5) vs the streaming k_fwd_wide on the same inputs: bit for bit."""
+    for k, v in _G().check_wide_shared().items():
+        assert v == 0.0, (k, v)
+
+
 def test_fused_gradnorm_clip_adam():
     _assert_all(_G().check_adam(), tol=2e-6)
 

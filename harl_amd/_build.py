@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libharl_hip.so")
-SOURCES = ["elementwise.hip", "mlp.hip", "wide.hip", "panel.hip", "heads.hip", "multihead.hip", "update.hip", "gru.hip", "gru_cell.hip", "host_rng.hip"]
+SOURCES = ["elementwise.hip", "mlp.hip", "wide.hip", "panel.hip", "heads.hip", "multihead.hip", "update.hip", "gru.hip", "gru_cell.hip", "host_rng.hip", "comm.hip"]
 HEADERS = ["common.h", "split_mfma.h", "mfma_transpose.h", "heads_common.h", "dw_common.h", os.path.join("..", "..", "include", "harl_hip.h")]
 
 
@@ -68,9 +68,19 @@ def build(force: bool = False, verbose: bool = False, variant: str = "", extra: 
     os.makedirs(objdir, exist_ok=True)
     objs = []
     procs = []
+    hdr_t = max(os.path.getmtime(os.path.join(CSRC, f)) for f in HEADERS)
+    try:
+        with open(lib + ".flags") as f:
+            same_flags = f.read() == _flag_stamp(extra)
+    except OSError:
+        same_flags = False
     for src in SOURCES:  # one hipcc per translation unit, in parallel
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
         objs.append(obj)
+        # an object newer than its source, every header and made with the same flags is reused (a one-file edit recompiles one file)
+        if (not force and same_flags and os.path.exists(obj)
+                and os.path.getmtime(obj) > max(hdr_t, os.path.getmtime(os.path.join(CSRC, src)))):
+            continue
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", os.path.join(CSRC, src), "-o", obj]
         cmd += extra.get(src, [])
         procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

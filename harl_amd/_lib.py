@@ -107,6 +107,11 @@ SIGNATURES = {
     "harl_md_head_logp": [_vp, _i, _vp, _i, _vp, _vp, _l, _vp, _vp, _vp, _i, _vp, _i, _vp, _l, _l, _vp],
     "harl_md_head_loss": [_vp, _vp, _i, _vp, _i, _vp, _vp, _l, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _d, _f, _i, _i,
                           _l, _l, _vp, _vp, _i, _vp],
+    "harl_comm_create": [_i, _i, _l, _i, _vp, _vp],
+    "harl_comm_connect": [_vp, _vp],
+    "harl_comm_allreduce": [_vp, _vp, _l, _i, _vp],
+    "harl_comm_status": [_vp],
+    "harl_comm_destroy": [_vp],
     "harl_version": [],
 }
 

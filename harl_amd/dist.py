@@ -4,6 +4,7 @@ The update shards ``n_rollout_threads`` across ranks (columns are independent in
 and in the factor product -- SURVEY.md §8e); parameters, Adam state and ValueNorm statistics are replicated.
 The only exchange steps are SUM all-reduces of (a) the flat gradient arena with the loss scalars packed behind
 it, (b) the advantage moments, (c) the ValueNorm batch sums.  With world_size == 1 everything is a no-op.
+``HARL_ALLREDUCE=oneshot`` sends them through the hand-written one-hop exchange of csrc/comm.hip instead of RCCL's ring.
 """
 from __future__ import annotations
 
@@ -23,6 +24,9 @@ class Comm:
         self.group = group
         self.world_size = dist.get_world_size(group) if self.enabled else 1
         self.rank = dist.get_rank(group) if self.enabled else 0
+        self.oneshot = None  # (lib, ctx, capacity, allocation kind) of the one-shot exchange, see enable_oneshot
+        if self.enabled and os.environ.get("HARL_ALLREDUCE", "rccl") == "oneshot":
+            self.enable_oneshot()
 
     def second_group(self) -> "Comm":
         """A communicator of its own over the same ranks (``dist.new_group`` is COLLECTIVE: every rank must call this at the
@@ -39,7 +43,55 @@ class Comm:
                            backend=dist.get_backend(self.group))
         return Comm(g)
 
+    def enable_oneshot(self, cap_bytes: int = 1 << 20, n_blocks: int = 8) -> "Comm":
+        """Route SUM all-reduces of fp32 / fp64 device tensors of up to ``cap_bytes`` through the hand-written one-shot exchange
+        (csrc/comm.hip: every rank pushes its message into a slot of every peer's hipIpc-mapped buffer and sums the slots in
+        rank order -- one hop over xGMI instead of RCCL's ring for messages that are latency-bound).
+        COLLECTIVE (handles travel through ``all_gather_object``): call it at the same point on every rank -- ``Comm.__init__``
+        does when ``HARL_ALLREDUCE=oneshot``.  Falls back to the backend's all-reduce for anything else (CPU tensors, larger
+        messages, other dtypes)."""
+        if not self.enabled or self.oneshot is not None or not torch.cuda.is_available():
+            return self
+        import ctypes as C
+
+        from . import _lib
+
+        lib = _lib.load()
+        handle = C.create_string_buffer(64)
+        ctx = C.c_void_p()
+        kind = lib.harl_comm_create(self.world_size, self.rank, cap_bytes, n_blocks, handle, C.byref(ctx))
+        if kind < 0:
+            raise RuntimeError("harl_comm_create: " + lib.harl_last_error().decode())
+        gathered = [None] * self.world_size
+        dist.all_gather_object(gathered, (self.rank, bytes(handle.raw)), group=self.group)
+        table = b"".join(h for _, h in sorted(gathered))
+        if lib.harl_comm_connect(ctx, table) != 0:
+            raise RuntimeError("harl_comm_connect: " + lib.harl_last_error().decode())
+        dist.barrier(group=self.group)
+        self.oneshot = (lib, ctx, cap_bytes, kind)
+        return self
+
+    def oneshot_status(self) -> int:
+        """0, or q + 1 once a wait for rank q's message has timed out (synchronises the device)."""
+        return 0 if self.oneshot is None else int(self.oneshot[0].harl_comm_status(self.oneshot[1]))
+
+    def close(self) -> None:
+        if self.oneshot is not None:
+            lib, ctx = self.oneshot[0], self.oneshot[1]
+            self.oneshot = None
+            torch.cuda.synchronize()
+            dist.barrier(group=self.group)  # nobody unmaps a buffer a peer's last launch still writes to
+            lib.harl_comm_destroy(ctx)
+
     def _all_reduce(self, t: torch.Tensor) -> None:
+        if (self.oneshot is not None and t.is_cuda and t.is_contiguous() and t.dtype in (torch.float32, torch.float64)
+                and 0 < t.numel() * t.element_size() <= self.oneshot[2] and t.data_ptr() % 16 == 0):
+            lib, ctx = self.oneshot[0], self.oneshot[1]
+            rc = lib.harl_comm_allreduce(ctx, t.data_ptr(), t.numel(), int(t.dtype == torch.float64),
+                                         torch.cuda.current_stream().cuda_stream)
+            if rc != 0:
+                raise RuntimeError("harl_comm_allreduce: " + lib.harl_last_error().decode())
+            return
         # RCCL reduces device tensors in place; the gloo backend (CPU tests, and the 2-ranks-on-1-GPU parity test)
         # is routed through host memory, which works for every build of gloo
         if t.is_cuda and dist.get_backend(self.group) == "gloo":

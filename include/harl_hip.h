@@ -569,6 +569,27 @@ int harl_rng_advance(const uint8_t *state_in, long state_bytes, long n_draws, ui
  * (tests).  Bit-identical final state.  The first call for a given block count builds its jump polynomial (~50 ms, cached). */
 int harl_rng_jump(const uint8_t *state_in, long state_bytes, long n_draws, uint8_t *state_out);
 
+/* ---------------------------------------------------------------------------------------------
+ * One-shot SUM all-reduce of the data-parallel update's messages (csrc/comm.hip; opt-in, HARL_ALLREDUCE=oneshot).
+ * Replaces nothing in the reference (it is single-process); it is the exchange step SURVEY.md section 8(e) prescribes for the
+ * sharded update: < 100 KiB per optimiser step ([folded gradients | scalar pieces], harl_amd/dist.py) pushed by every rank
+ * straight into a slot of every peer's hipIpc-mapped buffer, flags behind the data, the P local slots summed in rank order
+ * (one hop over the point-to-point fabric instead of a ring's 2 (P - 1); the same bits on every rank).
+ *   harl_comm_create  : HOST pointers.  Allocates this rank's buffer for messages up to cap_bytes (uncached / fine-grained
+ *                       device memory where exportable), writes its 64-byte hipIpc handle to handle_out and the context to
+ *                       *(void **)ctx_out.  Returns the allocation kind (2 uncached, 1 fine-grained, 0 plain) or < 0.
+ *   harl_comm_connect : all_handles = world x 64 bytes (host), rank-major, gathered by the caller (torch.distributed object
+ *                       gather); maps every peer's buffer.  Collective in the sense that every rank must get here.
+ *   harl_comm_allreduce: in-place SUM of msg[0..n) (device; fp32, or fp64 when is_f64) on `stream`; same n and call order on
+ *                       every rank.  No host state: safe under hipGraph capture.  A peer that does not show up within 4 s
+ *                       turns the result into NaN and sets the status word instead of hanging the device.
+ *   harl_comm_status  : 0, or q + 1 after a wait for rank q timed out (synchronises the device). */
+int harl_comm_create(int world, int rank, long cap_bytes, int n_blocks, void *handle_out, void *ctx_out);
+int harl_comm_connect(void *ctx, const void *all_handles);
+int harl_comm_allreduce(void *ctx, void *msg, long n, int is_f64, void *stream);
+int harl_comm_status(void *ctx);
+int harl_comm_destroy(void *ctx);
+
 #ifdef __cplusplus
 }
 #endif

@@ -20,9 +20,10 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, name, q):
+def _worker(rank, world, port, name, q, env=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK="0")
+    os.environ.update(env or {})
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -36,6 +37,8 @@ def _worker(rank, world, port, name, q):
         train, model, algo = case.reference_dicts()
         space = G.act_space_of(sh)
         comm = Comm()
+        if (env or {}).get("HARL_ALLREDUCE") == "oneshot":
+            assert comm.oneshot is not None
         lo, hi = shard_columns(sh.N, rank, world)
         torch.manual_seed(case.seed)
         r = OnPolicyHARunner(dict(algo="happo"), dict(train=train, model=model, algo=algo), dict(state_type="EP"),
@@ -97,6 +100,8 @@ def _worker(rank, world, port, name, q):
                                   + [vec_excess(r.critic.critic.flat_param.cpu().numpy(), z["critic_final"], nz["critic_final"],
                                                 nz["sens_critic_final"])])
         res["param_sum"] = float(sum(r.actor[a].actor.flat_param.double().sum().item() for a in range(sh.A)))
+        res["oneshot_status"] = comm.oneshot_status()
+        comm.close()
         q.put(res)
     finally:
         dist.destroy_process_group()
@@ -105,12 +110,23 @@ def _worker(rank, world, port, name, q):
 @pytest.mark.parametrize("name", ["mpe_box_h128", "cheetah_h128x3_mb2", "rnn_disc_h64_mb2", "rnn_naive_h64", "md_h64_mb2",
                                   "md_lag_h128"])
 def test_two_rank_sharded_train_matches_unsharded_golden(name):
+    _run_sharded(name, None)
+
+
+@pytest.mark.parametrize("name", ["mpe_box_h128", "rnn_disc_h64_mb2"])
+def test_two_rank_sharded_train_through_oneshot_allreduce(name):
+    """The same two-rank update with every exchange step on the hand-written one-hop all-reduce (csrc/comm.hip) instead of the
+    backend's: each rank pushes its message into the other's hipIpc-mapped buffer (two processes sharing this GPU)."""
+    _run_sharded(name, {"HARL_ALLREDUCE": "oneshot"})
+
+
+def _run_sharded(name, env):
     import torch.multiprocessing as mp
 
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, name, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, name, q, env)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=90) for _ in range(world)]
@@ -118,6 +134,69 @@ def test_two_rank_sharded_train_matches_unsharded_golden(name):
         p.join(timeout=60)
         assert p.exitcode == 0
     for r in res:
-        assert r["ret_bad"] == 0.0 and r["rng_bad"] == 0.0, r
+        assert r["ret_bad"] == 0.0 and r["rng_bad"] == 0.0 and r["oneshot_status"] == 0, r
         assert r["actor_excess"] <= 1.0 and r["critic_excess"] <= 1.0 and r["param_excess"] <= 1.0, r
     assert res[0]["param_sum"] == res[1]["param_sum"], "replicated parameters diverged between ranks"
+
+
+def _oneshot_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from harl_amd.dist import Comm
+
+        comm = Comm().enable_oneshot(cap_bytes=1 << 20)
+        assert comm.oneshot is not None
+        dev = torch.device("cuda:0")
+        bad, cases = 0, 0
+        # 25 153 floats = the MPE actor's message; 262 144 floats = the capacity; odd tails; fp64 moments (3 doubles)
+        for it, (n, dt) in enumerate([(1, torch.float32), (3, torch.float64), (5, torch.float32), (1027, torch.float32),
+                                      (25153, torch.float32), (262144, torch.float32), (131072, torch.float64),
+                                      (20001, torch.float64)] * 3):
+            g = torch.Generator().manual_seed(1000 * it + rank)
+            x = (torch.randn(n, generator=g, dtype=torch.float64) * 10.0 ** float(torch.randint(-3, 4, (1,), generator=g))).to(dt)
+            mine = x.to(dev)
+            comm.all_reduce_sum(mine)
+            parts = [torch.zeros_like(x) for _ in range(world)]
+            dist.all_gather(parts, x)
+            want = parts[0].clone()
+            for p in parts[1:]:
+                want += p  # rank order, the kernel's
+            cases += 1
+            bad += int(not torch.equal(mine.cpu(), want))
+        # back-to-back launches with no host synchronisation in between (epochs alternate between the two buffer sets)
+        y = torch.full((4096,), float(rank + 1), device=dev)
+        reps = 200
+        for _ in range(reps):
+            comm.all_reduce_sum(y)
+            y.mul_(1.0 / world)
+        torch.cuda.synchronize()
+        mean0 = sum(range(1, world + 1)) / world
+        chain_ok = bool(torch.all(y == mean0).item())  # after the first launch every rank holds the mean, a fixed point
+        st = comm.oneshot_status()
+        kind = comm.oneshot[3]
+        comm.close()
+        q.put(dict(rank=rank, bad=bad, cases=cases, chain_ok=chain_ok, status=st, kind=kind))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_oneshot_allreduce_is_the_rank_ordered_sum_bit_for_bit(world):
+    """harl_comm_allreduce among `world` processes sharing this GPU against the rank-ordered sum of the gathered messages: every
+    bit, fp32 and fp64, lengths from 1 element to the capacity, and 200 unsynchronised launches in a row."""
+    import torch.multiprocessing as mp
+
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_oneshot_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in res:
+        assert r["bad"] == 0 and r["cases"] == 24 and r["chain_ok"] and r["status"] == 0, r

@@ -722,12 +722,15 @@ __global__ __launch_bounds__(64 * F2X_WAVES, 2) void k_fwd_fused2x(
   PHASE_END(0);
 }
 
-// the shared-panel kernel from 512 slabs on (below that a workgroup's one or two iterations do not amortise the start of the panel
-// pipeline); HARL_WIDE_SHARED=0 keeps the streaming kernel (A/B and the bit-for-bit comparison of the two in the tests: read per call)
+// The shared-panel kernel is OPT-IN (HARL_WIDE_SHARED=1, from 512 slabs on; read per call: A/B and the bit-for-bit comparison of the
+// two kernels in the tests).  Measured on MI355X (round 5, gpurun call 7, Humanoid-17x1): 264.7 ms per update against 235.9 ms for
+// the streaming kernel -- `fwd_wide` 0.220 vs 0.167 ms, `tangent_wide` 0.226 vs 0.175 ms: one barrier per 32-column panel with ONE
+// workgroup per CU costs more than the per-wave fragment reads from L2 it saves (the same lesson as the one-launch backward,
+// profiles/r05_bwd_fused_ab.md).  Kept for the record and for the bit-for-bit test.
 constexpr size_t wide_sh_lds(int ho) { return (size_t)2 * 3 * (ho / 32) * WSH_PJ * 64 * 16; }
 bool wide_shared(long n_slabs) {
   const char *e = getenv("HARL_WIDE_SHARED");
-  return !(e && e[0] == '0') && n_slabs >= 512;
+  return e && e[0] == '1' && n_slabs >= 512;
 }
 
 template <int MODE>

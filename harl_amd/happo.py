@@ -232,6 +232,16 @@ class HAPPO(OnPolicyBase):
         self._info = torch.zeros(4, dtype=torch.float64, device=self.device)  # fp64 sums of the per-update fp32 policy_loss, dist_entropy, grad_norm, ratio (the reference sums .item() values: happo.py:145-150)
         self._grad_tap = None
         self._trace = None  # test hook: list receiving a clone of the running statistics after every optimiser step
+        # runner-internal: the event behind which this agent's sequential-update factor is complete (it is produced on the
+        # runner's post-update stream while this agent's first forward already runs, runner.train); awaited in front of the
+        # first loss launch -- the only consumer of the factor
+        self._factor_ready = None
+
+    def _await_factor(self) -> None:
+        ev = self._factor_ready
+        if ev is not None:
+            self._factor_ready = None
+            torch.cuda.current_stream(self.device).wait_event(ev)
 
     # ---- one optimiser step on rows idx[0..m) of the flat [T*N, .] tensors (happo.py:28-102) ---------
     def _forward_backward(self, obs, idx, m, actions, avail, old_logp, adv, adv_moments, factor, active, seq=None,
@@ -244,6 +254,7 @@ class HAPPO(OnPolicyBase):
         s = stream()
         if net.fused_update_ok(idx, seq):  # fused forward + loss (csrc/update.hip), then the layer backward (hybrid) or harl_update_bwd
             fa = net.fused_args(obs, m)
+            self._await_factor()
             call("harl_update_fwd_actor", *fa, ptr(net.log_std()), net.std_x_coef, net.std_y_coef, int(net.discrete),
                  net.act_dim, ptr(actions), ptr(avail), ptr(old_logp), ptr(adv), ptr(adv_moments), ptr(factor),
                  ptr(active), float(self.clip_param), float(self.entropy_coef), int(self.action_aggregation == "mean"),
@@ -255,6 +266,7 @@ class HAPPO(OnPolicyBase):
             L = len(net.hidden_sizes)
             net.forward_trunk(obs, idx, m, upto=L - 1)
             (Wl, bl), (Wh, bh) = net._packs[L - 1], net._packs[-1]
+            self._await_factor()
             call("harl_update_last_actor", ptr(net.xh[L - 2]), m, net.hidden_sizes[-1], ptr(Wl), ptr(bl), ptr(Wh), ptr(bh),
                  ptr(net.log_std()), net.std_x_coef, net.std_y_coef, int(net.discrete), net.act_dim, ptr(idx), ptr(actions),
                  ptr(avail), ptr(old_logp), ptr(adv), ptr(adv_moments), ptr(factor), ptr(active), float(self.clip_param),
@@ -266,6 +278,7 @@ class HAPPO(OnPolicyBase):
         Wp, bp = net._packs[-1]
         fx, fmask, frstd, fh = net.feat()
         mv, mp = (seq["m"], seq["m_pad"]) if seq is not None else (0, 0)
+        self._await_factor()
         if net.md:  # MultiDiscrete (csrc/multihead.hip): logits GEMM, per-sample loss -> d(logits) in place, layer-kernel backward
             net.md_logits(m)
             nblk = _lib.load().harl_head_blocks(m)

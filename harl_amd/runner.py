@@ -216,11 +216,21 @@ class OnPolicyHARunner:
                     old_ev[a] = torch.cuda.Event()
                     old_ev[a].record(self._side_stream)
         pending = []
-        for agent_id in agent_order:
+        # Post-update log-probs of RECURRENT policies (full-length unroll: N/32 dependent chains of T steps, ~0.5 ms on 32 waves
+        # of the chip at the SMAC sizes) go to a stream of their own: the next agent's first forward -- sequence tables, input
+        # image, MLP layers, the training GRU forward -- needs nothing from them; only its first LOSS launch consumes the factor
+        # and waits for the event (HAPPO._await_factor).  Same kernels, same operands, same order per tensor: bit-identical
+        # results.  HARL_POST_STREAM=0 keeps the pass on the main stream.
+        post_ok = dev.type == "cuda" and os.environ.get("HARL_POST_STREAM", "1") != "0"
+        factor_ev, keep_alive, prev_overlapped = None, [], False
+        for pos, agent_id in enumerate(agent_order):
             buf, actor = self.actor_buffer[agent_id], self.actor[agent_id]
             if agent_id in old_ev:  # this agent's networks / workspaces are in use on the side stream until then
                 torch.cuda.current_stream(dev).wait_event(old_ev[agent_id])
             buf.update_factor(factor)
+            if prev_overlapped:  # the post stream still reads the previous agent's pre-update log-probs: do not write into them
+                keep_alive.append(self._logp_old)
+                self._logp_old = None
             obs, actions = buf.flat("obs"), buf.flat("actions")
             avail = None if buf.available_actions is None else buf.flat("available_actions")
             if self._logp_old is None or self._logp_old.shape != (B, actor.actor.act_w):
@@ -238,13 +248,38 @@ class OnPolicyHARunner:
                 self._logp_old = old_all.pop(agent_id)
             else:
                 actor._logp_pass(obs, actions, avail, B, self._logp_old, **rnn_kw)
+            if factor_ev is not None and hasattr(actor, "_factor_ready"):
+                actor._factor_ready = factor_ev
             info = actor.train(buf, adv_a, self.state_type, **kw)               # :86-93
+            if factor_ev is not None:  # (an update that never reached a loss launch has not waited yet)
+                if hasattr(actor, "_factor_ready"):
+                    actor._factor_ready = None
+                torch.cuda.current_stream(dev).wait_event(factor_ev)
+                factor_ev = None
             pending.append((len(actor_train_infos), info, actor._INFO_KEYS) if torch.is_tensor(info) else None)
             actor_train_infos.append(info)
+            nxt = agent_order[pos + 1] if pos + 1 < len(agent_order) else None
+            prev_overlapped = bool(post_ok and nxt is not None and actor.actor.recurrent and hasattr(self.actor[nxt], "_factor_ready"))
+            if prev_overlapped:
+                if getattr(self, "_post_stream", None) is None:
+                    self._post_stream = torch.cuda.Stream(device=dev)
+                ps = self._post_stream
+                ps.wait_stream(torch.cuda.current_stream(dev))  # this agent's optimiser steps are complete
+                keep_alive += [factor, self._logp_old]
+                with torch.cuda.stream(ps):
+                    new_factor = factor.clone()
+                    actor._logp_pass(obs, actions, avail, B, None, old_logp=self._logp_old, factor=new_factor.reshape(B), **rnn_kw)
+                    factor_ev = torch.cuda.Event()
+                    factor_ev.record(ps)
+                factor = new_factor
+                continue
             new_factor = factor.clone()
             # post-update log-probs fused with factor *= agg(exp(new - old))   (:96-124)
             actor._logp_pass(obs, actions, avail, B, None, old_logp=self._logp_old, factor=new_factor.reshape(B), **rnn_kw)
             factor = new_factor
+        if keep_alive:  # tensors of the main stream's allocator pool that the post stream has read
+            torch.cuda.current_stream(dev).wait_stream(self._post_stream)
+            keep_alive.clear()
         if cinfo is None:
             cinfo = self.critic.train(self.critic_buffer, self.value_normalizer, _defer=True)
         if critic_done is not None:

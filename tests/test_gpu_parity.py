@@ -466,3 +466,15 @@ def test_buffer_slots_match_reference_insert_and_after_update(case):
     reference's own runner.insert() / buffer.after_update() produced from the same inputs (bit-exact)."""
     res = _G().check_buffer_slots(case)
     assert res["buffer_slot_mismatch"] == 0.0, res["_mismatched"]
+
+
+def test_post_update_stream_leaves_every_figure_unchanged(monkeypatch):
+    """Recurrent policies: the post-update log-prob pass on its own stream next to the following agent's first forward
+    (runner.train, HARL_POST_STREAM) against the same update with everything on the main stream -- same kernels on the same
+    operands, so every figure of the golden comparison must come out identical, not merely within tolerance."""
+    G = _G()
+    monkeypatch.setenv("HARL_POST_STREAM", "0")
+    a = G.check_train_golden("rnn_disc_h64_mb2")
+    monkeypatch.setenv("HARL_POST_STREAM", "1")
+    b = G.check_train_golden("rnn_disc_h64_mb2")
+    assert a == b, {k: (a[k], b.get(k)) for k in a if a[k] != b.get(k)}

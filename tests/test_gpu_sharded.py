@@ -172,12 +172,24 @@ def _oneshot_worker(rank, world, port, q):
             comm.all_reduce_sum(y)
             y.mul_(1.0 / world)
         torch.cuda.synchronize()
+        # launch-to-launch time of the MPE actor's message (25 153 floats) on this shared GPU: `world` processes time-share one
+        # chip here, so this is an upper bound on the kernel's own cost, not an xGMI figure
+        z = torch.zeros(25153 + 4 * 48, device=dev)
+        for _ in range(10):
+            comm.all_reduce_sum(z)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(100):
+            comm.all_reduce_sum(z)
+        e1.record()
+        torch.cuda.synchronize()
+        us_per_call = e0.elapsed_time(e1) * 10.0
         mean0 = sum(range(1, world + 1)) / world
         chain_ok = bool(torch.all(y == mean0).item())  # after the first launch every rank holds the mean, a fixed point
         st = comm.oneshot_status()
         kind = comm.oneshot[3]
         comm.close()
-        q.put(dict(rank=rank, bad=bad, cases=cases, chain_ok=chain_ok, status=st, kind=kind))
+        q.put(dict(rank=rank, bad=bad, cases=cases, chain_ok=chain_ok, status=st, kind=kind, us_per_call=us_per_call))
     finally:
         dist.destroy_process_group()
 
@@ -198,5 +210,10 @@ def test_oneshot_allreduce_is_the_rank_ordered_sum_bit_for_bit(world):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
+    from tests.gpu_checks import dump_parity
+    dump_parity(f"oneshot_allreduce_world{world}", dict(world=world, allocation_kind=res[0]["kind"],
+                                                        us_per_call_max=max(r["us_per_call"] for r in res),
+                                                        us_per_call_min=min(r["us_per_call"] for r in res),
+                                                        mismatching_cases=sum(r["bad"] for r in res), cases=res[0]["cases"]))
     for r in res:
         assert r["bad"] == 0 and r["cases"] == 24 and r["chain_ok"] and r["status"] == 0, r

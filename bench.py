@@ -10,6 +10,7 @@ BASELINE.json configurations at their real shapes (one JSON line each):
     cheetah6    configs[2]  MAMuJoCo HalfCheetah-6x1, 6 agents, HAPPO, MLP [128]x3      T=200 N=4096/GPU (8192 global with --scaling strong)
     smac3s5z    configs[3]  SMAC 3s5z, 8 agents, HAPPO, GRU policy, Discrete(14)        T=160 N=512/GPU, chunks of 10
     humanoid17  configs[4]  MAMuJoCo Humanoid-17x1, 17 agents, HATRPO, obs 393          T=200 N=1024/GPU
+    hatrpo_gru128  (not in BASELINE.json) SMAC shape, HATRPO, MLP [128,128] + 128-wide GRU: the composed coverage path
 
 A "step" = one compute() + train() over synthetic rollout buffers (SURVEY.md 8d recipe) resident in HBM before the timed
 region.  One transition = one (t, n) environment step for all agents.  `--scaling weak` (default): every rank owns
@@ -64,6 +65,13 @@ WORKLOADS = {
     "humanoid17": dict(algo="hatrpo", T=200, N=1024, A=17, obs=393, sobs=376, act=1, disc=False, hidden=[128, 128, 128],
                        metric="transitions/sec through HATRPO update (MAMuJoCo Humanoid-17x1, 17 agents)",
                        name="MAMuJoCo Humanoid-17x1 17-agent HATRPO update"),
+    # not a BASELINE configuration: hatrpo.yaml's DEFAULT model ([128, 128]) with use_recurrent_policy at the SMAC shape -- the
+    # composed 128-wide GRU (per-step launches, harl_amd/gru_wide.py) under HATRPO's tangent passes, the slowest coverage path
+    # (it had no number)
+    "hatrpo_gru128": dict(algo="hatrpo", T=160, N=512, A=8, obs=128, sobs=216, act=14, disc=True, hidden=[128, 128], rnn=True,
+                          L=10, unavailable_p=0.3,
+                          metric="transitions/sec through HATRPO update (SMAC-shaped, 8 agents, 128-wide GRU policy)",
+                          name="SMAC-shaped 8-agent recurrent HATRPO update, hatrpo.yaml default widths (coverage path)"),
 }
 # module-level aliases of the default workload (tools/ and older scripts import these)
 T, N_PER_GPU, A = 200, 4096, 3
@@ -573,7 +581,7 @@ def main():
     if rank == 0:
         cols = args.cpu_cols
         if cols < 0:  # ~10-30 s of CPU work per update for every configuration
-            cols = {"mpe": 512, "cheetah6": 512, "smac3s5z": 128, "humanoid17": 16}[args.config]
+            cols = {"mpe": 512, "cheetah6": 512, "smac3s5z": 128, "humanoid17": 16, "hatrpo_gru128": 32}[args.config]
         if world == 1 and cols > 0:
             out["cpu_baseline"] = cpu_baseline(w, cols, min(args.cpu_threads, os.cpu_count() or 1), reps=max(1, args.cpu_reps))
     # the other BASELINE.json workloads at their real shapes, on the SAME JSON line (after the headline region and the CPU
@@ -582,7 +590,7 @@ def main():
     # would leave the others waiting in a collective)
     if args.other_configs and world == 1 and args.config == "mpe" and args.scaling == "weak" and not args.threads_per_gpu:
         others = {}
-        for name in ("cheetah6", "smac3s5z", "humanoid17"):
+        for name in ("cheetah6", "smac3s5z", "humanoid17", "hatrpo_gru128"):
             torch.cuda.empty_cache()
             wo = WORKLOADS[name]
             try:
@@ -601,7 +609,7 @@ def main():
                                     end_to_end=o.get("end_to_end"))
                 if args.other_cpu_cols != 0:  # the CPU path next to every reported number (BASELINE.json north_star): a bounded
                     # sample of the same workload (fewer rollout threads), one warm-up + one timed update
-                    oc = args.other_cpu_cols if args.other_cpu_cols > 0 else {"cheetah6": 128, "smac3s5z": 64, "humanoid17": 8}[name]
+                    oc = args.other_cpu_cols if args.other_cpu_cols > 0 else {"cheetah6": 128, "smac3s5z": 64, "humanoid17": 8, "hatrpo_gru128": 16}[name]
                     try:
                         others[name]["cpu_baseline"] = cpu_baseline(wo, oc, min(args.cpu_threads, os.cpu_count() or 1), reps=1)
                     except Exception as e:  # noqa: BLE001

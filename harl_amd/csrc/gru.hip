@@ -459,6 +459,252 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_gru_fwd_tp(
 }
 
 // =============================================================================================
+// forward, FOUR waves per slab (round 5): the latency variant above still spends 3.3 us per dependent step -- 72 MFMAs of 32
+// cycles and 48 gate values (6 quarter-rate transcendentals each) per wave -- and the full-length log-prob passes of a
+// recurrent policy are 160 such steps, sixteen passes per 8-agent update, eight of them in series with the updates (the next
+// agent's factor needs them).  Here a workgroup is ONE slab and its four waves split the step two ways at once:
+//   * wave (w, kh) multiplies the row tiles {g * 2 + w} (hidden features [32 w, 32 w + 32) of the three gates) by the k-steps
+//     {2 kh, 2 kh + 1} of h~ only: 36 MFMAs, PARTIAL sums;
+//   * the two waves of a feature half exchange the halves of their partial tiles through LDS (registers [8 (kh^1), +8) of each
+//     of the three accumulators go out, the partner's [8 kh, +8) come in): every wave ends up with the complete pre-activations
+//     of 8 accumulator registers = 16 features per sample, i.e. a QUARTER of the gate nonlinearities;
+//   * its 8 registers of h_l are exactly k-step 2 w + kh of the next step's B operand: split into the three bf16 terms, handed
+//     over through LDS together with the (mean, M2) of its 16 features; rnn.norm's statistics are merged four ways
+//     (mean = sum mean_k / 4, M2 = sum M2_k + 16 sum (mean_k - mean)^2).
+// Two workgroup barriers per step (partials / hand-off); both LDS areas are single-buffered: a wave writes the partials of step
+// l + 1 only after the hand-off barrier of step l, behind which nobody reads step l's partials any more, and the hand-off of
+// step l + 1 only after the partial barrier of step l + 1, which every reader of hand-off l has passed.
+// Saves the backward's operands when asked (training chunks), like k_gru_fwd_tp.
+// =============================================================================================
+template <int KH>
+__device__ __forceinline__ void quad_pack(const f32x16 &a, f32x4 (&snd)[2], float (&keep)[8]) {
+#pragma unroll
+  for (int rr = 0; rr < 8; ++rr) keep[rr] = a[8 * KH + rr];
+  snd[0] = f32x4{a[8 * (1 - KH) + 0], a[8 * (1 - KH) + 1], a[8 * (1 - KH) + 2], a[8 * (1 - KH) + 3]};
+  snd[1] = f32x4{a[8 * (1 - KH) + 4], a[8 * (1 - KH) + 5], a[8 * (1 - KH) + 6], a[8 * (1 - KH) + 7]};
+}
+
+__global__ __launch_bounds__(WG_THREADS, 1) void k_gru_fwd_q(
+    const float *__restrict__ gi_r, const float *__restrict__ gi_z, const float *__restrict__ gi_n,
+    const float *__restrict__ mrow, const float *__restrict__ h0, const float *__restrict__ Whh,
+    const float *__restrict__ bhh, int L, long m_pad, float *__restrict__ y, float *__restrict__ rstd_y,
+    float *__restrict__ h_last, float *__restrict__ hpm_s, float *__restrict__ r_s, float *__restrict__ z_s,
+    float *__restrict__ n_s, float *__restrict__ hn_s) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int MTH = 3 * GT, NJH = GH / 16, TS = MTH * NJH * 64, QR = 8;  // QR = registers per lane and wave
+  u32x4 *Whimg = reinterpret_cast<u32x4 *>(lds);                   // [3 terms][6 tiles][4 k-steps][64 lanes] x 16 B
+  u32x4 *xch = Whimg + 3 * TS;                                      // hand-off: [4 k-steps][3 terms][64 lanes]
+  f32x4 *xpp = reinterpret_cast<f32x4 *>(xch + 4 * 3 * 64);         // partials: [4 waves][3 gates][2 pieces][64 lanes]
+  float *xst = reinterpret_cast<float *>(xpp + 4 * 3 * 2 * 64);     // LayerNorm partials: [4 waves][64 lanes][2]
+  float *bhl = xst + 4 * 64 * 2;                                    // b_hn [64]
+  stage_split_matrix<3 * GH, GH, false, WG_THREADS>(Whimg, Whh);
+  for (int e = threadIdx.x; e < GH; e += WG_THREADS) bhl[e] = bhh[2 * GH + e];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = wave_id(), w = wave >> 1, kh = wave & 1;
+  const int i = lane & 31, h = lane >> 5;
+  const long groups = m_pad / SLAB;
+  const u32x4 *wl = Whimg + lane;
+  const int q0 = 4 * w + 2 * kh;  // this wave's two float4 pieces of an ATL(64) image = accumulator registers 16 w + 8 kh .. + 7
+  float bown[QR];                 // b_hn of those registers' features
+#pragma unroll
+  for (int rr = 0; rr < QR; ++rr) {
+    const int r = 8 * kh + rr;
+    bown[rr] = bhl[32 * w + (r & 3) + 8 * (r >> 2) + 4 * h];
+  }
+  for (long G = blockIdx.x; G < groups; G += gridDim.x) {  // one slab per workgroup and iteration (uniform: barriers inside)
+    float hs[QR], hm[QR];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int qq = q0 + q;
+      const f32x4 v = *reinterpret_cast<const f32x4 *>(h0 + (G * SLAB + i) * GH + 32 * (qq >> 2) + 8 * (qq & 3) + 4 * h);
+      hs[4 * q + 0] = v[0];
+      hs[4 * q + 1] = v[1];
+      hs[4 * q + 2] = v[2];
+      hs[4 * q + 3] = v[3];
+    }
+    auto own_pieces = [&](const float *base, long slab, f32x4 (&dst)[2]) {
+      const f32x4 *pp = reinterpret_cast<const f32x4 *>(base + slab * (long)(GH * SLAB)) + lane;
+      dst[0] = pp[(q0 + 0) * WAVE];
+      dst[1] = pp[(q0 + 1) * WAVE];
+    };
+    auto store_own = [&](float *base, long slab, const float (&v)[QR]) {
+      f32x4 *pp = reinterpret_cast<f32x4 *>(base + slab * (long)(GH * SLAB)) + lane;
+      pp[(q0 + 0) * WAVE] = f32x4{v[0], v[1], v[2], v[3]};
+      pp[(q0 + 1) * WAVE] = f32x4{v[4], v[5], v[6], v[7]};
+    };
+    f32x4 gr[2], gz[2], gn[2];
+    own_pieces(gi_r, G, gr);
+    own_pieces(gi_z, G, gz);
+    own_pieces(gi_n, G, gn);
+    float mk = mrow[G * SLAB + i];
+    u32x4 x1[2], x2[2], x3[2];  // B operands of this wave's k-steps 2 kh, 2 kh + 1
+    float mean_own = 0.f, m2_own = 0.f;
+    for (int l = -1; l < L; ++l) {
+      if (l >= 0) {
+        const long slab = (long)l * groups + G;
+        float pr[QR], pz[QR], pn[QR];
+#pragma unroll
+        for (int rr = 0; rr < QR; ++rr) {
+          pr[rr] = gr[rr >> 2][rr & 3];
+          pz[rr] = gz[rr >> 2][rr & 3];
+          pn[rr] = gn[rr >> 2][rr & 3];
+        }
+        if (l + 1 < L) {  // next step's input halves and mask: a whole step of latency to land
+          own_pieces(gi_r, slab + groups, gr);
+          own_pieces(gi_z, slab + groups, gz);
+          own_pieces(gi_n, slab + groups, gn);
+          mk = mrow[(slab + groups) * SLAB + i];
+        } else {
+          mk = 1.f;
+        }
+        // partial W_hh h~: 3 gates x 2 k-steps x 6 products
+        f32x16 ar, az, ah;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          ar[r] = 0.f;
+          az[r] = 0.f;
+          ah[r] = 0.f;
+        }
+        u32x4 wb[2][3];
+#pragma unroll
+        for (int term = 0; term < 3; ++term) wb[0][term] = wl[term * TS + ((0 * GT + w) * NJH + 2 * kh) * 64];
+#pragma unroll
+        for (int sidx = 0; sidx < 6; ++sidx) {
+          const int j = sidx / 3, g = sidx % 3, cur = sidx & 1, nxt = cur ^ 1;
+          if (sidx + 1 < 6) {
+            const int j1 = (sidx + 1) / 3, g1 = (sidx + 1) % 3;
+#pragma unroll
+            for (int term = 0; term < 3; ++term) wb[nxt][term] = wl[term * TS + ((g1 * GT + w) * NJH + 2 * kh + j1) * 64];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          f32x16 &a = g == 0 ? ar : (g == 1 ? az : ah);
+          a = mfma_bf16(wb[cur][2], x1[j], a);
+          a = mfma_bf16(wb[cur][0], x3[j], a);
+          a = mfma_bf16(wb[cur][1], x2[j], a);
+          a = mfma_bf16(wb[cur][1], x1[j], a);
+          a = mfma_bf16(wb[cur][0], x2[j], a);
+          a = mfma_bf16(wb[cur][0], x1[j], a);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        // exchange the partial tiles' halves with the other k-half of this feature half (wave ^ 1)
+        f32x4 snd[3][2];
+        float kr[QR], kz[QR], kn[QR];
+        if (kh == 0) {  // (wave-uniform: register indices stay compile-time constants in either branch)
+          quad_pack<0>(ar, snd[0], kr);
+          quad_pack<0>(az, snd[1], kz);
+          quad_pack<0>(ah, snd[2], kn);
+        } else {
+          quad_pack<1>(ar, snd[0], kr);
+          quad_pack<1>(az, snd[1], kz);
+          quad_pack<1>(ah, snd[2], kn);
+        }
+        f32x4 *po = xpp + (wave * 3 * 2) * 64 + lane;
+        const f32x4 *pi = xpp + ((wave ^ 1) * 3 * 2) * 64 + lane;
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+          po[(g * 2 + 0) * 64] = snd[g][0];
+          po[(g * 2 + 1) * 64] = snd[g][1];
+        }
+        __syncthreads();
+        float sum = 0.f;
+        float rgs[QR], zgs[QR], ngs[QR], hns[QR];
+        {
+          f32x4 rc[3][2];
+#pragma unroll
+          for (int g = 0; g < 3; ++g) {
+            rc[g][0] = pi[(g * 2 + 0) * 64];
+            rc[g][1] = pi[(g * 2 + 1) * 64];
+          }
+#pragma unroll
+          for (int rr = 0; rr < QR; ++rr) {
+            const float rg = sigmoidf_(pr[rr] + (kr[rr] + rc[0][rr >> 2][rr & 3]));
+            const float zg = sigmoidf_(pz[rr] + (kz[rr] + rc[1][rr >> 2][rr & 3]));
+            const float hn = bown[rr] + (kn[rr] + rc[2][rr >> 2][rr & 3]);
+            const float ng = tanhf_(pn[rr] + rg * hn);
+            rgs[rr] = rg;
+            zgs[rr] = zg;
+            ngs[rr] = ng;
+            hns[rr] = hn;
+            hs[rr] = (1.f - zg) * ng + zg * hm[rr];
+            sum += hs[rr];
+          }
+        }
+        if (r_s) {  // (kernel-uniform) the backward's operands, as k_gru_fwd<true> leaves them
+          store_own(r_s, slab, rgs);
+          store_own(z_s, slab, zgs);
+          store_own(n_s, slab, ngs);
+          store_own(hn_s, slab, hns);
+        }
+        sum = wave_sum32(sum);
+        mean_own = sum * (1.0f / 16.f);
+        float vs = 0.f;
+#pragma unroll
+        for (int rr = 0; rr < QR; ++rr) {
+          const float d = hs[rr] - mean_own;
+          vs += d * d;
+        }
+        m2_own = wave_sum32(vs);
+      }
+      // ---- hand-off: h~ (own quarter) as the split operands of k-step 2 w + kh, and the LayerNorm partials
+#pragma unroll
+      for (int rr = 0; rr < QR; ++rr) hm[rr] = hs[rr] * mk;
+      if (hpm_s && l + 1 < L) store_own(hpm_s, (long)(l + 1) * groups + G, hm);  // h~_{l+1} = h_l * mask_{l+1}
+      {
+        u32x4 o1[1], o2[1], o3[1];
+        split_acts<QR>(hm, o1, o2, o3);
+        u32x4 *xo = xch + ((2 * w + kh) * 3) * 64 + lane;
+        xo[0 * 64] = o1[0];
+        xo[1 * 64] = o2[0];
+        xo[2 * 64] = o3[0];
+        float *so = xst + (wave * 64 + lane) * 2;
+        so[0] = mean_own;
+        so[1] = m2_own;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const u32x4 *xi = xch + ((2 * kh + jj) * 3) * 64 + lane;
+        x1[jj] = xi[0 * 64];
+        x2[jj] = xi[1 * 64];
+        x3[jj] = xi[2 * 64];
+      }
+      if (l >= 0) {  // y_l = rnn.norm(h_l), own quarter
+        float mk_[4], m2_[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          mk_[k] = xst[(k * 64 + lane) * 2 + 0];
+          m2_[k] = xst[(k * 64 + lane) * 2 + 1];
+        }
+        const float mean = 0.25f * ((mk_[0] + mk_[1]) + (mk_[2] + mk_[3]));
+        float dev2 = 0.f, m2 = (m2_[0] + m2_[1]) + (m2_[2] + m2_[3]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float d = mk_[k] - mean;
+          dev2 += d * d;
+        }
+        m2 += 16.f * dev2;
+        const float rstd = 1.0f / sqrtf(m2 * (1.0f / GH) + 1e-5f);
+        const long slab = (long)l * groups + G;
+        float yo[QR];
+#pragma unroll
+        for (int rr = 0; rr < QR; ++rr) yo[rr] = (hs[rr] - mean) * rstd;
+        store_own(y, slab, yo);
+        if (wave == 0 && lane < 32) rstd_y[slab * SLAB + lane] = rstd;
+      }
+    }
+    if (h_last) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int qq = q0 + q;
+        *reinterpret_cast<f32x4 *>(h_last + (G * SLAB + i) * GH + 32 * (qq >> 2) + 8 * (qq & 3) + 4 * h) =
+            f32x4{hs[4 * q], hs[4 * q + 1], hs[4 * q + 2], hs[4 * q + 3]};
+      }
+    }
+    __syncthreads();  // the next slab's first hand-off overwrites areas the slowest wave may still be reading
+  }
+}
+
+// =============================================================================================
 // backward (BPTT over the chunk, reverse in l).  Input: dh_out = d(loss)/d(h_l) through the output path (the head
 // kernels already applied the rnn.norm backward); output: the four gate-gradient tensors (for the weight-gradient
 // kernel) and dz of the last MLP layer (LayerNorm/ReLU backward of d(loss)/d(x_hat_mlp) applied here).
@@ -786,6 +1032,17 @@ extern "C" int harl_gru_fwd(const float *xin, const float *mask_rows, const floa
                        n_slabs, gr, gz, gn);
     // few dependent chains: two waves per slab (k_gru_fwd_tp); HARL_GRU_TP_SAVE=0 keeps training forwards on the one-wave kernel (A/B)
     static const bool tp_save = [] { const char *e = getenv("HARL_GRU_TP_SAVE"); return !(e && e[0] == '0'); }();
+    // four waves per slab (k_gru_fwd_q) while a slab per CU does not queue: up to 256 chains.  HARL_GRU_QUAD=0: the two-wave kernel
+    static const bool quad = [] { const char *e = getenv("HARL_GRU_QUAD"); return !(e && e[0] == '0'); }();
+    if (quad && groups <= 256 && (!save || tp_save)) {
+      const size_t shm_q = split_image_bytes(3 * GH, GH) + (size_t)4 * 3 * 64 * 16 + (size_t)4 * 3 * 2 * 64 * 16 +
+                           ((size_t)4 * 64 * 2 + GH) * sizeof(float);
+      allow_big_lds(k_gru_fwd_q, shm_q);
+      hipLaunchKernelGGL(k_gru_fwd_q, dim3((unsigned)groups), dim3(WG_THREADS), shm_q, s, gr, gz, gn, mask_rows, h0, Whh, bhh, L,
+                         m_pad, y, rstd_y, h_last, save ? hpm : nullptr, save ? r : nullptr, save ? z : nullptr,
+                         save ? n : nullptr, save ? hn : nullptr);
+      return check_launch("harl_gru_fwd");
+    }
     if (groups <= GRU_TP_MAX_GROUPS && (!save || tp_save)) {
       const size_t shm_tp = split_image_bytes(3 * GH, GH) + (size_t)2 * 2 * 2 * 6 * 64 * 16 + ((size_t)2 * 2 * 2 * 64 * 2 + GH) * sizeof(float);
       allow_big_lds(k_gru_fwd_tp, shm_tp);

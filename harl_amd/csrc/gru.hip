@@ -798,6 +798,150 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_gru_bwd(
   }
 }
 
+// Four waves per slab (round 5), the backward twin of k_gru_fwd_q: wave q owns the accumulator registers R = 8 q .. 8 q + 7 (16
+// hidden features per sample) of EVERYTHING that is per-feature -- the carry, the saved gates, the four gate gradients it stores --
+// and therefore the k-steps {q, 4 + q, 8 + q} of the 192-wide operand [dr | dz | dhn] of W_hh^T: 36 of the step's 144 MFMAs,
+// a quarter of the gate arithmetic and of the operand split, 12 instead of 48 row loads.  Its two accumulator tiles are PARTIAL
+// sums over its k-steps: all four waves park them in LDS (8 float4 pieces each), one barrier, and every wave adds up the four
+// partials of its own two pieces, in wave order.  Two buffers: the partials of step l + 1 go where step l - 1's were, which
+// every wave has finished reading when it arrives at step l's barrier.  One workgroup = one slab: the 256 chains of a
+// chunked SMAC minibatch (8192 sequences x 10 steps) occupy 256 CUs instead of 64.
+__global__ __launch_bounds__(WG_THREADS, 1) void k_gru_bwd_q(
+    const float *__restrict__ dhout, const float *__restrict__ mrow, const float *__restrict__ Whh,
+    const float *__restrict__ hpm_s, const float *__restrict__ r_s, const float *__restrict__ z_s,
+    const float *__restrict__ n_s, const float *__restrict__ hn_s, int L, long m_pad, float *__restrict__ dr_s,
+    float *__restrict__ dz_s, float *__restrict__ dn_s, float *__restrict__ dhn_s) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int MT = GT, NJ = 3 * GH / 16, TS = MT * NJ * 64, QR = 8;
+  u32x4 *img = reinterpret_cast<u32x4 *>(lds);
+  f32x4 *xp = reinterpret_cast<f32x4 *>(img + 3 * TS);  // [2 buffers][4 waves][8 pieces][64 lanes]
+  stage_split_matrix<3 * GH, GH, true, WG_THREADS>(img, Whh);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, q = wave_id();
+  const int i = lane & 31;
+  const long groups = m_pad / SLAB;
+  const u32x4 *wl = img + lane;
+  int buf = 0;
+  for (long G = blockIdx.x; G < groups; G += gridDim.x) {  // uniform: barriers inside
+    auto own = [&](const float *base, long slab, float (&dst)[QR]) {
+      const f32x4 *pp = reinterpret_cast<const f32x4 *>(base + slab * (long)(GH * SLAB)) + lane;
+      const f32x4 a = pp[(2 * q) * WAVE], b = pp[(2 * q + 1) * WAVE];
+      dst[0] = a[0]; dst[1] = a[1]; dst[2] = a[2]; dst[3] = a[3];
+      dst[4] = b[0]; dst[5] = b[1]; dst[6] = b[2]; dst[7] = b[3];
+    };
+    auto store_own = [&](float *base, long slab, const float (&v)[QR]) {
+      f32x4 *pp = reinterpret_cast<f32x4 *>(base + slab * (long)(GH * SLAB)) + lane;
+      pp[(2 * q) * WAVE] = f32x4{v[0], v[1], v[2], v[3]};
+      pp[(2 * q + 1) * WAVE] = f32x4{v[4], v[5], v[6], v[7]};
+    };
+    float dcarry[QR];
+#pragma unroll
+    for (int rr = 0; rr < QR; ++rr) dcarry[rr] = 0.f;
+    float dh[QR], rg[QR], zg[QR], ng[QR], hn[QR], hp[QR];
+    {
+      const long slab = (long)(L - 1) * groups + G;
+      own(dhout, slab, dh);
+      own(r_s, slab, rg);
+      own(z_s, slab, zg);
+      own(n_s, slab, ng);
+      own(hn_s, slab, hn);
+      own(hpm_s, slab, hp);
+    }
+    float mk = mrow[((long)(L - 1) * groups + G) * SLAB + i];
+    for (int l = L - 1; l >= 0; --l) {
+      const long slab = (long)l * groups + G;
+      float g_r[QR], g_z[QR], g_hn[QR], dnp[QR], dhp[QR];
+#pragma unroll
+      for (int rr = 0; rr < QR; ++rr) {
+        const float d = dh[rr] + dcarry[rr];
+        const float dz_ = d * (hp[rr] - ng[rr]);
+        const float dn_ = d * (1.f - zg[rr]);
+        dhp[rr] = d * zg[rr];
+        dnp[rr] = dn_ * (1.f - ng[rr] * ng[rr]);
+        g_hn[rr] = dnp[rr] * rg[rr];
+        g_r[rr] = (dnp[rr] * hn[rr]) * rg[rr] * (1.f - rg[rr]);
+        g_z[rr] = dz_ * zg[rr] * (1.f - zg[rr]);
+      }
+      const float mk_cur = mk;
+      store_own(dr_s, slab, g_r);
+      store_own(dz_s, slab, g_z);
+      store_own(dn_s, slab, dnp);
+      store_own(dhn_s, slab, g_hn);
+      // this wave's three k-steps of [dr | dz | dhn]: q, 4 + q, 8 + q
+      u32x4 b1[3], b2[3], b3[3];
+      {
+        u32x4 t1[1], t2[1], t3[1];
+        split_acts<QR>(g_r, t1, t2, t3);
+        b1[0] = t1[0]; b2[0] = t2[0]; b3[0] = t3[0];
+        split_acts<QR>(g_z, t1, t2, t3);
+        b1[1] = t1[0]; b2[1] = t2[0]; b3[1] = t3[0];
+        split_acts<QR>(g_hn, t1, t2, t3);
+        b1[2] = t1[0]; b2[2] = t2[0]; b3[2] = t3[0];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (l > 0) {  // the previous step's operands: the GEMM's and the exchange's time to land
+        const long sp = slab - groups;
+        own(dhout, sp, dh);
+        own(r_s, sp, rg);
+        own(z_s, sp, zg);
+        own(n_s, sp, ng);
+        own(hn_s, sp, hn);
+        own(hpm_s, sp, hp);
+        mk = mrow[sp * SLAB + i];
+      }
+      f32x16 acc[MT];
+#pragma unroll
+      for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+      {
+        u32x4 wb[2][3];
+#pragma unroll
+        for (int term = 0; term < 3; ++term) wb[0][term] = wl[term * TS + (0 * NJ + q) * 64];
+#pragma unroll
+        for (int sidx = 0; sidx < 3 * MT; ++sidx) {
+          const int ty = sidx / MT, t = sidx % MT, cur = sidx & 1, nxt = cur ^ 1;
+          if (sidx + 1 < 3 * MT) {
+            const int ty1 = (sidx + 1) / MT, t1 = (sidx + 1) % MT;
+#pragma unroll
+            for (int term = 0; term < 3; ++term) wb[nxt][term] = wl[term * TS + (t1 * NJ + 4 * ty1 + q) * 64];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          acc[t] = mfma_bf16(wb[cur][2], b1[ty], acc[t]);
+          acc[t] = mfma_bf16(wb[cur][0], b3[ty], acc[t]);
+          acc[t] = mfma_bf16(wb[cur][1], b2[ty], acc[t]);
+          acc[t] = mfma_bf16(wb[cur][1], b1[ty], acc[t]);
+          acc[t] = mfma_bf16(wb[cur][0], b2[ty], acc[t]);
+          acc[t] = mfma_bf16(wb[cur][0], b1[ty], acc[t]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      f32x4 *po = xp + ((buf * 4 + q) * 8) * 64 + lane;
+#pragma unroll
+      for (int p8 = 0; p8 < 8; ++p8)
+        po[p8 * 64] = f32x4{acc[p8 >> 2][4 * (p8 & 3) + 0], acc[p8 >> 2][4 * (p8 & 3) + 1], acc[p8 >> 2][4 * (p8 & 3) + 2],
+                            acc[p8 >> 2][4 * (p8 & 3) + 3]};
+      __syncthreads();
+      {
+        f32x4 s0[4], s1[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const f32x4 *pi = xp + ((buf * 4 + k) * 8) * 64 + lane;
+          s0[k] = pi[(2 * q) * 64];
+          s1[k] = pi[(2 * q + 1) * 64];
+        }
+        const f32x4 a0 = (s0[0] + s0[1]) + (s0[2] + s0[3]), a1 = (s1[0] + s1[1]) + (s1[2] + s1[3]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          dcarry[c] = (dhp[c] + a0[c]) * mk_cur;
+          dcarry[4 + c] = (dhp[4 + c] + a1[c]) * mk_cur;
+        }
+      }
+      buf ^= 1;
+    }
+  }
+}
+
 // d x_hat_mlp = W_ih'^T [dr, dz, dn]  ->  LayerNorm/ReLU backward of the last MLP layer -> dz_mlp, every slab independent
 __global__ __launch_bounds__(WG_THREADS, 2) void k_gru_dx(const float *__restrict__ Wih, const float *__restrict__ dr_s,
                                                           const float *__restrict__ dz_s, const float *__restrict__ dn_s,
@@ -1075,9 +1219,17 @@ extern "C" int harl_gru_bwd(const float *dhout, const float *mask_rows, const fl
   const long groups = m_pad / SLAB;
   long wgs = (groups + WAVES_PER_WG - 1) / WAVES_PER_WG;
   const int grid = (int)(wgs < 256 ? wgs : 256);
-  allow_big_lds(k_gru_bwd, shm);
-  hipLaunchKernelGGL(k_gru_bwd, dim3(grid), dim3(WG_THREADS), shm, (hipStream_t)stream, dhout, mask_rows, Whh, hpm, r, z, n, hn,
-                     L, m_pad, dr, dz, dn, dhn);
+  static const bool quad = [] { const char *e = getenv("HARL_GRU_QUAD"); return !(e && e[0] == '0'); }();
+  if (quad && groups <= 256) {  // four waves per slab (k_gru_bwd_q): one chain per CU
+    const size_t shm_q = shm + (size_t)2 * 4 * 8 * 64 * 16;
+    allow_big_lds(k_gru_bwd_q, shm_q);
+    hipLaunchKernelGGL(k_gru_bwd_q, dim3((unsigned)groups), dim3(WG_THREADS), shm_q, (hipStream_t)stream, dhout, mask_rows, Whh,
+                       hpm, r, z, n, hn, L, m_pad, dr, dz, dn, dhn);
+  } else {
+    allow_big_lds(k_gru_bwd, shm);
+    hipLaunchKernelGGL(k_gru_bwd, dim3(grid), dim3(WG_THREADS), shm, (hipStream_t)stream, dhout, mask_rows, Whh, hpm, r, z, n, hn,
+                       L, m_pad, dr, dz, dn, dhn);
+  }
   const long n_slabs = (long)L * groups;
   allow_big_lds(k_gru_dx, shm);
   hipLaunchKernelGGL(k_gru_dx, dim3(persistent_grid(n_slabs, 2)), dim3(WG_THREADS), shm, (hipStream_t)stream, Wih, dr, dz, dn,

@@ -1245,13 +1245,20 @@ def _oracle_bench_run(payload: dict, tag: str, dt_name: str, pert_seed, keep_gra
         if pert_seed is not None:
             _perturb_one_ulp([a_.net for a_ in actors] + [critic.net], pert_seed)
         abufs = [O.OracleActorBuffer(d["obs"].copy(), d["actions"].copy(), d["logp"].copy(), d["masks"].copy(), d["active"].copy(),
-                                     None) for d in abuf_np]
+                                     None if d.get("avail") is None else d["avail"].copy(),
+                                     rnn_states=None if d.get("rnn") is None else d["rnn"].copy()) for d in abuf_np]
         cbuf = O.OracleCriticBufferEP(cbuf_np["share_obs"].copy(), cbuf_np["rewards"].copy(), cbuf_np["value_preds"].copy(),
                                       cbuf_np["masks"].copy(), cbuf_np["bad_masks"].copy())
+        if cbuf_np.get("rnn") is not None:
+            cbuf.rnn_states_critic = cbuf_np["rnn"].copy()
         vn = O.OracleValueNorm()
         vn.load_state(dict(running_mean=float(st0[0]), running_mean_sq=float(st0[1]), debiasing_term=float(st0[2])))
         with torch.no_grad():  # compute(): the critic's value of slot T (on_policy_base_runner.py:462-484)
-            nv = critic.get_values(cbuf_np["share_obs"][-1]).detach().double().numpy().reshape(-1, 1)
+            if cbuf_np.get("rnn") is not None:
+                nv = critic.get_values(cbuf_np["share_obs"][-1], cbuf_np["rnn"][-1], cbuf_np["masks"][-1])
+            else:
+                nv = critic.get_values(cbuf_np["share_obs"][-1])
+            nv = nv.detach().double().numpy().reshape(-1, 1)
         # identical scan inputs on both sides: the fp32 oracle's compute_returns is fed the HIP value of slot T (which is
         # compared with the oracle's own first)
         cbuf.compute_returns(payload["next_value_hip"].copy() if tag == "f32" else nv.astype(np.float64 if dt == torch.float64 else np.float32),
@@ -1308,7 +1315,7 @@ def _bench_config_runs(n_threads: int, with_f64: bool, keep_grad: bool = False, 
     bench.WORKLOADS ("mpe" = BASELINE configs[1], "cheetah6" = configs[2] at one GPU's share)."""
     import bench
     w = bench.WORKLOADS[workload]
-    assert w["algo"] == "happo" and not w.get("rnn") and not w["disc"], "feed-forward Box HAPPO workloads"
+    assert w["algo"] == "happo", "HAPPO workloads (feed-forward Box, or the recurrent Discrete one with unavailable actions)"
     T, A = w["T"], w["A"]
     torch.manual_seed(1)
     r = bench.build_gpu_runner(w, n_threads, 0, 1, DEV, logp)
@@ -1317,10 +1324,11 @@ def _bench_config_runs(n_threads: int, with_f64: bool, keep_grad: bool = False, 
     actor_sd = [{k: v.detach().cpu().clone() for k, v in a.actor.state_dict().items()} for a in r.actor]
     critic_sd = {k: v.detach().cpu().clone() for k, v in r.critic.critic.state_dict().items()}
     abuf_np = [dict(obs=npy(b.obs), actions=npy(b.actions), logp=npy(b.action_log_probs), masks=npy(b.masks),
-                    active=npy(b.active_masks)) for b in r.actor_buffer]
+                    active=npy(b.active_masks), avail=None if b.available_actions is None else npy(b.available_actions),
+                    rnn=npy(b.rnn_states) if w.get("rnn") else None) for b in r.actor_buffer]
     cb = r.critic_buffer
     cbuf_np = dict(share_obs=npy(cb.share_obs), rewards=npy(cb.rewards), value_preds=npy(cb.value_preds), masks=npy(cb.masks),
-                   bad_masks=npy(cb.bad_masks))
+                   bad_masks=npy(cb.bad_masks), rnn=npy(cb.rnn_states_critic) if w.get("rnn") else None)
     st0 = npy(r.value_normalizer.stats)
     rng0 = torch.get_rng_state()
     # ---- HIP path: one bench step (bench.one_step) with the per-update traces switched on
@@ -1410,6 +1418,8 @@ def check_bench_config_parity(logp: str = "recipe", n_threads: int = 4096, n_per
     out: Dict[str, float] = {}
     hip, runs, _shapes, meta = _bench_config_runs(n_threads, True, logp=logp, n_pert=n_pert, workload=workload)
     T, A = meta["T"], meta["A"]
+    import bench as _bench
+    recurrent = bool(_bench.WORKLOADS[workload].get("rnn"))  # GRU chains: no flat 1e-5 on anything downstream of them
     o, o64 = runs["f32"], runs["f64"]
     perts = [runs[k] for k in sorted(runs) if k.startswith("pert")]
     out["_oracle_seconds"] = float(sum(v["seconds"] for v in runs.values()))
@@ -1435,7 +1445,7 @@ def check_bench_config_parity(logp: str = "recipe", n_threads: int = 4096, n_per
     for c, nm in enumerate(names):
         get = lambda run, c=c: np.stack([t[:, c] for t in run["atr"]])  # noqa: E731  [agent, epoch]
         first = float(rel(get(hip)[0, 0], get(o)[0, 0]))
-        if logp == "recipe":
+        if logp == "recipe" and not recurrent:
             out[f"first_update_{nm}_rel"] = first  # flat 1e-5
         else:
             # on-policy buffers: the policy loss is a masked mean of advantage-normalised surrogates with ratios ~ 1, i.e. ~ 0 by
@@ -1444,7 +1454,7 @@ def check_bench_config_parity(logp: str = "recipe", n_threads: int = 4096, n_per
             ffloor = max([float(rel(get(o)[0, 0], get(o64)[0, 0]))] + [float(rel(get(pr)[0, 0], get(o)[0, 0])) for pr in perts])
             out[f"_first_update_{nm}_rel"] = first
             out[f"_first_update_{nm}_oracle_own_uncertainty"] = ffloor
-            if nm == "policy_loss":
+            if nm == "policy_loss" and not recurrent:
                 # |loss| ~ 2e-3 here (mean of 819 200 unit-scale terms that cancel): the figure with a meaning is the ABSOLUTE
                 # difference -- in units of the advantage-normalised terms' scale (~1) -- held to 1e-7 by the test
                 out["_first_update_policy_loss_value"] = float(get(o)[0, 0])

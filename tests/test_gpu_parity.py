@@ -299,6 +299,18 @@ def test_cheetah6_full_size_against_oracle():
     _assert_all(res)
 
 
+def test_smac3s5z_full_size_against_oracle():
+    """BASELINE configs[3] at FULL size -- SMAC 3s5z shape, 8 agents, T = 160, 512 rollout threads, MLP [64, 64, 64] + GRU,
+    Discrete(14) with 30 % unavailable actions, chunks of 10, 5 + 5 epochs -- against the fp32 oracle on identical buffer
+    contents: the oracle's entry to the four-waves-per-slab GRU kernels at their measured size (256 training chains per launch,
+    full-length log-prob passes of 160 dependent steps), to `harl_build_seq` and to the recurrent critic.  Returns / generator
+    state bit-exact; the critic and the first update on the recurrent fixtures' 2e-5 / measured bars (nothing downstream of a
+    160-step recurrence is held to 1e-5 flat); the rest on the pooled measured bars."""
+    res = _G().check_bench_config_parity(workload="smac3s5z", n_threads=512, n_pert=1)
+    print("smac3s5z full-size parity:", {k: (f"{v:.3e}" if isinstance(v, float) else v) for k, v in res.items()})
+    _assert_all(res, tol=2e-5)
+
+
 def test_full_size_properties_baseline_config():
     """BASELINE configs[1] sizes (819 200 transitions x 3 agents): column independence vs the oracle, linearity of the
     unscaled sums under a column split, bit-exact determinism of train()."""

@@ -40,3 +40,30 @@ def test_worker_process_matches_in_process_run(monkeypatch):
         assert np.array_equal(a[tag]["cfin"], b[tag]["cfin"])
         assert torch.equal(a[tag]["rng"], b[tag]["rng"])
     assert not np.array_equal(a["f32"]["cfin"], a["pert0"]["cfin"])  # the one-ulp twin really is another run
+
+
+def test_recurrent_payload_runs_through_the_oracle(monkeypatch):
+    """The payload format of the recurrent full-size check (SMAC shape: available actions, GRU states of actors and critic) on
+    a few rollout threads: one in-process oracle run produces per-update traces for every agent and a finite value of slot T."""
+    import bench
+    from harl_amd.synthetic import Shapes, actor_param_shapes, critic_param_shapes, make_buffers, synthetic_state_dict
+    from tests import gpu_checks as G
+    w = bench.WORKLOADS["smac3s5z"]
+    n = 4
+    sh = Shapes(T=w["T"], N=n, A=w["A"], obs_dim=w["obs"], share_obs_dim=w["sobs"], act_dim=w["act"], discrete=True,
+                hidden_sizes=w["hidden"])
+    d = make_buffers(sh, seed=6, unavailable_p=0.3, rnn=True)
+    t = lambda sd: {k: torch.from_numpy(v) for k, v in sd.items()}  # noqa: E731
+    torch.manual_seed(4)
+    pl = dict(workload="smac3s5z", n_threads=n,
+              actor_sd=[t(synthetic_state_dict(actor_param_shapes(sh, True, True), 10 + a)) for a in range(w["A"])],
+              critic_sd=t(synthetic_state_dict(critic_param_shapes(sh, True, True), 99)),
+              abuf=[dict(obs=d.obs[a], actions=d.actions[a], logp=d.action_log_probs[a], masks=d.masks[a], active=d.active_masks[a],
+                         avail=d.available_actions[a], rnn=d.rnn["actor"][a]) for a in range(w["A"])],
+              cbuf=dict(share_obs=d.share_obs, rewards=d.rewards, value_preds=d.value_preds, masks=d.critic_masks,
+                        bad_masks=d.bad_masks, rnn=d.rnn["critic"]),
+              st0=np.zeros(3, dtype=np.float32), rng0=torch.get_rng_state(), next_value_hip=d.value_preds[-1].copy())
+    monkeypatch.setenv("HARL_ORACLE_THREADS", "2")
+    run = G._oracle_bench_run(pl, "f32", "f32", None, False)
+    assert len(run["atr"]) == w["A"] and all(x.shape == (5, 4) and np.isfinite(x).all() for x in run["atr"])
+    assert run["ctr"].shape == (5, 2) and np.isfinite(run["nv"]).all() and run["nv"].shape == (n, 1)

@@ -1464,7 +1464,10 @@ def check_bench_config_parity(logp: str = "recipe", n_threads: int = 4096, n_per
                 out[f"first_update_{nm}_excess"] = first / max(1e-5, NOISE_FACTOR * ffloor)
         pooled(get, f"actor_update_{nm}")
     for c, nm in enumerate(("value_loss", "grad_norm")):
-        out[f"critic_update_{nm}_rel"] = float(rel(hip["ctr"][:, c], o["ctr"][:, c]).max())
+        if recurrent:  # the critic's GRU chunks: per-update figures on the pooled measured bar, like the actors'
+            pooled(lambda run, c=c: run["ctr"][:, c], f"critic_update_{nm}")
+        else:
+            out[f"critic_update_{nm}_rel"] = float(rel(hip["ctr"][:, c], o["ctr"][:, c]).max())
     keys = ("policy_loss", "dist_entropy", "actor_grad_norm", "ratio")
     pooled(lambda run: np.array([[float(i[k]) for k in keys] for i in run["infos"]], dtype=np.float64), "actor_infos")
     out["critic_info_rel"] = rel_err([hip["cinfo"]["value_loss"], hip["cinfo"]["critic_grad_norm"]],

@@ -309,6 +309,9 @@ def test_smac3s5z_full_size_against_oracle():
     res = _G().check_bench_config_parity(workload="smac3s5z", n_threads=512, n_pert=1)
     print("smac3s5z full-size parity:", {k: (f"{v:.3e}" if isinstance(v, float) else v) for k, v in res.items()})
     _assert_all(res, tol=2e-5)
+    # measured on MI355X (profiles/r05_parity_smac3s5z_full_size.json): every actor figure of all 40 updates within 1.3e-6 of the
+    # fp32 oracle, the critic's value loss 1e-7, its grad-norms 2.8e-5 where the oracle's own float64 twin sits 4e-5 away
+    assert res["_critic_update_grad_norm_rel"] < 1e-4 and res["_actor_update_grad_norm_rel"] < 1e-4, res
 
 
 def test_full_size_properties_baseline_config():

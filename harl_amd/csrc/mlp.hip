@@ -1223,8 +1223,10 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_dw_tr_multi(DwMulti P, long n
 //     Its A operand -- that 32-feature block of the slab's dz, transposed -- it makes itself on the matrix pipe (its four float4
 //     pieces of the block, split exactly, times the permuted identity: 6 MFMAs, no LDS, and the transposition's row sums are
 //     db'); the B operand x_hat_prev^T is shared: every wave splits a quarter of the slab's pieces and stores them into the
-//     round's buffer, the fragments come back through ds_read_b64_tr_b16.  Both are fetched again from L2 / the infinity cache
-//     (the owners touched them microseconds ago), so HBM sees dz and x_hat_prev once.
+//     round's buffer, the fragments come back through ds_read_b64_tr_b16.  Both are fetched a second time microseconds after
+//     their owners touched them -- which, measured (rocprofv3 --pmc FETCH_SIZE, profiles/r05_hbm_traffic.md), does NOT stay in the
+//     L2: 1.56 GB leave it per launch against 0.96 GB of operands (a super-round's working set per XCD, 32 workgroups x 4 slabs x
+//     32 KB, is the L2's 4 MB); the pair of layer kernels fetched 1.83 GB.
 // Version 1 of this kernel (one buffer, both operands through LDS, two barriers per round) measured no faster than the pair it
 // replaces: with one workgroup per CU nothing overlaps a barrier wait (profiles/r05_bwd_fused_ab.md).  Hence the software
 // pipeline: everything round n+1 needs is prepared DURING round n's 48 product MFMAs -- a wave has one MFMA in flight for 32

@@ -241,3 +241,21 @@ def test_update_supported_accounts_for_lds():
     assert f(40, 128, 5, 0) == 1                                    # ... its log-prob passes fit
     assert f(40, 64, 8, 1) == 1 and f(0, 128, 8, 1) == 1 and f(0, 64, 3, 2) == 1
     assert f(65, 128, 5, 1) == 0 and f(18, 96, 5, 1) == 0 and f(18, 128, 9, 1) == 0
+
+
+def test_comm_entry_points_validate_arguments_and_fail_loudly_without_a_gpu():
+    """harl_comm_* (csrc/comm.hip): bad arguments are refused before anything is allocated; without a GPU the allocation fails
+    with an error text instead of a crash (no compute call is made here)."""
+    lib = _lib.load()
+    handle = ctypes.create_string_buffer(64)
+    ctx = ctypes.c_void_p()
+    assert lib.harl_comm_create(17, 0, 1024, 8, handle, ctypes.byref(ctx)) == -2      # more ranks than slots
+    assert b"harl_comm_create" in lib.harl_last_error()
+    assert lib.harl_comm_create(2, 2, 1024, 8, handle, ctypes.byref(ctx)) == -2       # rank outside the world
+    assert lib.harl_comm_create(2, 0, 1024, 64, handle, ctypes.byref(ctx)) == -2      # more blocks than flag columns
+    assert lib.harl_comm_allreduce(None, None, 4, 0, None) == -2
+    assert lib.harl_comm_connect(None, None) == -2
+    assert lib.harl_comm_destroy(None) == 0
+    import torch
+    if not torch.cuda.is_available():
+        assert lib.harl_comm_create(2, 0, 1024, 8, handle, ctypes.byref(ctx)) < 0 and ctx.value is None

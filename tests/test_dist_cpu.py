@@ -127,3 +127,32 @@ def test_world2_gloo_packed_allreduce_and_sharded_gradient_identity():
         assert act_err == 0.0
         assert sc_err < 1e-15, sc_err            # fp64 scalars survive the single fp32 all-reduce (fixed-grid pieces, exact sums)
         assert idx_ok
+
+
+def _oneshot_cpu_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      HARL_ALLREDUCE="oneshot")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        comm = Comm()  # HARL_ALLREDUCE=oneshot without a GPU: the hipIpc exchange is not set up, the backend's all-reduce serves
+        t = torch.full((5,), float(rank + 1), dtype=torch.float32)
+        comm.all_reduce_sum(t)
+        q.put((rank, comm.oneshot is None, comm.oneshot_status(), t.tolist()))
+        comm.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_oneshot_request_without_gpu_falls_back_to_the_backend():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_oneshot_cpu_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, no_ctx, status, vals in res:
+        assert no_ctx and status == 0 and vals == [3.0] * 5, (rank, no_ctx, status, vals)

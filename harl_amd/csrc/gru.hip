@@ -130,6 +130,49 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_gru_gates_x(const float *__re
   }
 }
 
+// The same product on the bf16 pipe with the exact three-way operand split (round 5): 6 row tiles x 4 k-steps x 6 products = 144
+// MFMAs of 32 cycles per slab instead of 192 fp32 MFMAs of 64 (each behind its own ds_read_b32), the split images of W_ih'
+// (72 KiB) leave room for two workgroups per CU.  62 launches per 8-agent recurrent update over 2 560 slabs each: the kernel was
+// at twice its own matrix-pipe bound and is now bound by its 84 MB of row traffic.  HARL_GRU_GATES_F32=1 keeps the fp32 kernel.
+__global__ __launch_bounds__(WG_THREADS, 2) void k_gru_gates_xs(const float *__restrict__ xin,
+                                                                const float *__restrict__ Wih,
+                                                                const float *__restrict__ bih,
+                                                                const float *__restrict__ bhh, long n_slabs,
+                                                                float *__restrict__ gi_r, float *__restrict__ gi_z,
+                                                                float *__restrict__ gi_n) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int MTH = 3 * GT, NJH = GH / 16;
+  u32x4 *img = reinterpret_cast<u32x4 *>(lds);                      // [3 terms][6 tiles][4 k-steps][64 lanes] x 16 B
+  float *bl = reinterpret_cast<float *>(img + 3 * MTH * NJH * 64);  // [192]  b_i (+ b_h for the r and z gates)
+  stage_split_matrix<3 * GH, GH, false, WG_THREADS>(img, Wih);
+  for (int e = threadIdx.x; e < 3 * GH; e += WG_THREADS) bl[e] = bih[e] + (e < 2 * GH ? bhh[e] : 0.f);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = wave_id();
+  const int h = lane >> 5;
+  const u32x4 *wl = img + lane;
+  const long s0 = (long)blockIdx.x * WAVES_PER_WG + wave, stride = (long)gridDim.x * WAVES_PER_WG;
+  float x[GR];
+  if (s0 < n_slabs) load_act(xin, s0, lane, x);
+  for (long slab = s0; slab < n_slabs; slab += stride) {
+    u32x4 x1[NJH], x2[NJH], x3[NJH];
+    split_acts<GR>(x, x1, x2, x3);
+    if (slab + stride < n_slabs) load_act(xin, slab + stride, lane, x);  // one slab ahead
+    f32x16 a6[MTH];
+#pragma unroll
+    for (int t6 = 0; t6 < MTH; ++t6)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a6[t6][r] = bl[32 * t6 + (r & 3) + 8 * (r >> 2) + 4 * h];
+    split_gemm<MTH, NJH>(wl, x1, x2, x3, a6, [](int) {});
+    float o[GR];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+#pragma unroll
+      for (int R = 0; R < GR; ++R) o[R] = a6[g * GT + (R >> 4)][R & 15];
+      store_act(g == 0 ? gi_r : (g == 1 ? gi_z : gi_n), slab, lane, o);
+    }
+  }
+}
+
 // =============================================================================================
 // forward
 // =============================================================================================
@@ -1170,10 +1213,18 @@ extern "C" int harl_gru_fwd(const float *xin, const float *mask_rows, const floa
   if (gi_ws) {  // two phases: parallel x half over all L*groups slabs, then the recurrence with W_hh only
     const long n_slabs = (long)L * groups, M = n_slabs * SLAB;
     float *gr = gi_ws, *gz = gi_ws + M * GH, *gn = gi_ws + 2 * M * GH;
-    const size_t shm_x = ((size_t)3 * GH * (GH + 1) + 3 * GH) * sizeof(float);
-    allow_big_lds(k_gru_gates_x, shm_x);
-    hipLaunchKernelGGL(k_gru_gates_x, dim3(persistent_grid(n_slabs, 1)), dim3(WG_THREADS), shm_x, s, xin, Wih, bih, bhh,
-                       n_slabs, gr, gz, gn);
+    static const bool gates_f32 = [] { const char *e = getenv("HARL_GRU_GATES_F32"); return e && e[0] == '1'; }();
+    if (gates_f32) {
+      const size_t shm_x = ((size_t)3 * GH * (GH + 1) + 3 * GH) * sizeof(float);
+      allow_big_lds(k_gru_gates_x, shm_x);
+      hipLaunchKernelGGL(k_gru_gates_x, dim3(persistent_grid(n_slabs, 1)), dim3(WG_THREADS), shm_x, s, xin, Wih, bih, bhh,
+                         n_slabs, gr, gz, gn);
+    } else {
+      const size_t shm_x = split_image_bytes(3 * GH, GH) + (size_t)3 * GH * sizeof(float);
+      allow_big_lds(k_gru_gates_xs, shm_x);
+      hipLaunchKernelGGL(k_gru_gates_xs, dim3(persistent_grid(n_slabs, 2)), dim3(WG_THREADS), shm_x, s, xin, Wih, bih, bhh,
+                         n_slabs, gr, gz, gn);
+    }
     // few dependent chains: two waves per slab (k_gru_fwd_tp); HARL_GRU_TP_SAVE=0 keeps training forwards on the one-wave kernel (A/B)
     static const bool tp_save = [] { const char *e = getenv("HARL_GRU_TP_SAVE"); return !(e && e[0] == '0'); }();
     // four waves per slab (k_gru_fwd_q) while a slab per CU does not queue: up to 256 chains.  HARL_GRU_QUAD=0: the two-wave kernel

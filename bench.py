@@ -22,14 +22,15 @@ Gradients / loss scalars are all-reduced over RCCL each optimiser step (one mess
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P \\
         bench.py --gpus 8 --steps 5 --warmup 2
 
-The default run (mpe) appends the three other BASELINE workloads (3 steps each, fresh runners, AFTER the headline region and the
-CPU baseline) to the same line as `other_configs` (`--no-other-configs` to skip).
+The default run (mpe) appends the three other BASELINE workloads and the coverage workload `hatrpo_gru128` (3 steps each, fresh
+runners, AFTER the headline region and the CPU baseline; each with its own bounded CPU baseline) to the same line as
+`other_configs` (`--no-other-configs` to skip).
 
 Prints ONE JSON line (rank 0).  `roofline`: the streaming kernel family with the largest total time per step (decided in the
 last warm-up step, where every family is bracketed by HIP events; inside the timed region only that family is) -- achieved =
 algorithmic HBM bytes of its launches in the timed region (harl_amd/traffic.py, from each launch's own arguments) / their
 HIP-event time; `traffic` = measured HBM bytes per launch from the committed PMC pass of that kernel
-(profiles/r04_hbm_traffic.json, stamped with the commit it was taken at).  `kernels`: full per-kernel breakdown from extra
+(the newest profiles/r0N_hbm_traffic.json, stamped with the commit it was taken at).  `kernels`: full per-kernel breakdown from extra
 instrumented steps after the timed region.  `cpu_baseline`: the oracle (torch-CPU restatement of the reference, same ATen
 kernels) on this box's host cores on a bounded sample of the same workload, warm-up + best of 3.
 """

@@ -1118,6 +1118,7 @@ def check_checkpoint_compat(tmpdir: str) -> Dict[str, float]:
     v1, _ = r.critic.get_values(np.random.default_rng(1).standard_normal((8, sh.share_obs_dim)).astype(np.float32),
                                 np.zeros((8, 1, 64), np.float32), np.ones((8, 1), np.float32))
     p = {k: torch.from_numpy(v) for k, v in want.items()}
+    O.set_activation(a.get("activation_func", "relu"))  # (the oracle's functional code reads a module global: not the previous test's)
     vref = O.critic_forward(p, torch.from_numpy(np.random.default_rng(1).standard_normal((8, sh.share_obs_dim)).astype(np.float32)),
                             torch.zeros(8, 1, 64), torch.ones(8, 1))
     out["values_after_restore_vec_rel"] = vec_rel_err(v1.cpu().numpy(), vref.detach().numpy())

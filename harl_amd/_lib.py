@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
-from typing import Optional
+from typing import Dict, Optional
 
 import torch
 
@@ -27,7 +27,7 @@ _vp, _i, _l, _f, _d = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_double
 # name -> argtypes (restype is int unless noted); mirrors include/harl_hip.h line by line
 SIGNATURES = {
     "harl_gae_returns": [_vp] * 8 + [_i, _i, _f, _f, _i, _i, _i, _vp],
-    "harl_masked_moments": [_vp, _vp, _l, _vp, _vp],
+    "harl_masked_moments": [_vp, _vp, _l, _vp, _vp, _vp],
     "harl_dist_rows": [_vp, _l, _i, _i, _vp, _f, _f, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "harl_moments_mean": [_vp, _vp, _vp],
     "harl_clock_probe": [_vp, _l, _vp],
@@ -92,7 +92,7 @@ SIGNATURES = {
     "harl_update_bwd": [_vp, _vp, _l, _i, _i] + [_vp] * 5 + [_i, _vp],
     "harl_head_blocks": [_l],
     "harl_trpo_fvp_finish": [_vp, _vp, _vp, _vp, _l, _f, _f, _l, _i, _f, _f, _vp],
-    "harl_trpo_cg_step": [_vp, _vp, _vp, _vp, _l, _vp, _vp],
+    "harl_trpo_cg_step": [_vp, _vp, _vp, _vp, _l, _vp, _vp, _vp],
     "harl_mlp_panel_fwd": [_vp, _l, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp],
     "harl_mlp_panel_bwd": [_vp, _vp, _vp, _vp, _l, _i, _i, _vp, _vp, _vp],
     "harl_head_dw_rows256": [_vp, _l, _i, _vp, _vp, _i, _vp],
@@ -110,6 +110,7 @@ SIGNATURES = {
     "harl_comm_create": [_i, _i, _l, _i, _vp, _vp],
     "harl_comm_connect": [_vp, _vp],
     "harl_comm_allreduce": [_vp, _vp, _l, _i, _vp],
+    "harl_comm_set_timeout": [_vp, _d],
     "harl_comm_status": [_vp],
     "harl_comm_destroy": [_vp],
     "harl_version": [],
@@ -211,6 +212,23 @@ def call(name: str, *args, tag: Optional[str] = None) -> None:
         rc = getattr(lib, name)(*args)
     if rc != 0:
         raise RuntimeError(f"{name} failed ({rc}): {lib.harl_last_error().decode()}")
+
+
+SCRATCH_BYTES = {"mm": 24640, "cg": 1088}  # include/harl_hip.h: HARL_MM_SCRATCH_BYTES, HARL_CG_SCRATCH_BYTES
+_scratch: Dict[tuple, torch.Tensor] = {}
+
+
+def scratch(kind: str) -> int:
+    """Device pointer of the caller-owned scratch block of ``harl_masked_moments`` ("mm") / ``harl_trpo_cg_step`` ("cg") for the
+    CURRENT device and stream: the C ABI allocates nothing, so the blocks are torch tensors, one per (device, stream, kind) --
+    two streams may have such a launch in flight at the same time -- zero-filled on that stream when first asked for and kept
+    for the life of the process (a few KiB each)."""
+    st = torch.cuda.current_stream()
+    key = (st.device_index, st.cuda_stream, kind)
+    t = _scratch.get(key)
+    if t is None:
+        t = _scratch[key] = torch.zeros(SCRATCH_BYTES[kind] // 8, dtype=torch.float64, device=torch.device("cuda", st.device_index))
+    return t.data_ptr()
 
 
 def default_device() -> torch.device:

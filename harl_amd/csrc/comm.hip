@@ -34,12 +34,19 @@ namespace {
 
 typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
 constexpr int MAX_RANKS = 16, MAX_BLK = 32, CM_THREADS = 256;
-constexpr long long WAIT_TICKS = 400000000LL;  // 4 s of the constant 100 MHz counter, then give up (err word, NaN result)
+// A flag wait gives up after `wait_ticks` of the constant 100 MHz counter (err word set, NaN result) -- 0 = wait for ever, as
+// RCCL does.  The default is 10 minutes (harl_comm_set_timeout / HARL_ONESHOT_TIMEOUT_S): a rank that arrives seconds late at a
+// collective (rank-0 evaluation, a checkpoint, a first-call build) is ordinary and must not be turned into NaN gradients.  A
+// time-out is FATAL for the communicator: the late peer's flags and this rank's epochs are out of step from then on, every
+// later exchange times out as well -- the Python side checks harl_comm_status() at every host synchronisation point of
+// compute() / train() and raises (harl_amd/dist.py).
+constexpr long long DEFAULT_WAIT_TICKS = 600LL * 100000000LL;
 
 struct CommDev {
   char *peer[MAX_RANKS];  // base address of every rank's buffer in THIS process (peer[rank] = the local one)
   int world, rank, nblk;
   long cap;               // bytes per slot
+  long long wait_ticks;   // flag-wait limit in 100 MHz ticks, 0 = none
 };
 
 struct CommHost {
@@ -101,7 +108,7 @@ __global__ __launch_bounds__(CM_THREADS) void k_oneshot_allreduce(CommDev c, T *
     const long long t0 = __builtin_amdgcn_s_memrealtime();
     while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != epoch) {
       __builtin_amdgcn_s_sleep(4);
-      if (__builtin_amdgcn_s_memrealtime() - t0 > WAIT_TICKS) {
+      if (c.wait_ticks > 0 && (long long)__builtin_amdgcn_s_memrealtime() - t0 > c.wait_ticks) {
         timed_out = 1;
         __hip_atomic_store(reinterpret_cast<int *>(loc + err_off(P, c.cap)), 1 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         break;
@@ -152,6 +159,7 @@ extern "C" int harl_comm_create(int world, int rank, long cap_bytes, int n_block
   h->d.rank = rank;
   h->d.nblk = n_blocks;
   h->d.cap = (cap_bytes + 255) / 256 * 256;
+  h->d.wait_ticks = DEFAULT_WAIT_TICKS;
   const size_t bytes = (size_t)total_bytes(world, h->d.cap);
   hipIpcMemHandle_t hd;
   const unsigned flags[3] = {hipDeviceMallocUncached, hipDeviceMallocFinegrained, hipDeviceMallocDefault};
@@ -218,6 +226,15 @@ extern "C" int harl_comm_allreduce(void *ctx, void *msg, long n, int is_f64, voi
   if (is_f64) hipLaunchKernelGGL(k_oneshot_allreduce<double>, dim3(h->d.nblk), dim3(CM_THREADS), 0, s, h->d, static_cast<double *>(msg), n);
   else hipLaunchKernelGGL(k_oneshot_allreduce<float>, dim3(h->d.nblk), dim3(CM_THREADS), 0, s, h->d, static_cast<float *>(msg), n);
   return check_launch("harl_comm_allreduce");
+}
+
+// Flag-wait limit of every later harl_comm_allreduce launch of this communicator, in seconds (0 = wait for ever).  Host-side
+// state only: no device work, no synchronisation.
+extern "C" int harl_comm_set_timeout(void *ctx, double seconds) {
+  CommHost *h = static_cast<CommHost *>(ctx);
+  if (!h || !(seconds >= 0.0) || seconds > 1e6) return bad("harl_comm_set_timeout: bad arguments (0 <= seconds <= 1e6)");
+  h->d.wait_ticks = (long long)(seconds * 1e8);
+  return 0;
 }
 
 // 0 = healthy; q + 1 = a wait for rank q's flag timed out (results of that launch are NaN).  Synchronises the device.

@@ -238,32 +238,18 @@ __global__ __launch_bounds__(256) void k_masked_moments(const float *__restrict_
   }
 }
 
-// One scratch block per (device, stream), allocated on first use and kept for the life of the process (a few KiB each; never
-// released: a destroyed stream's handle may be reused by the runtime and then simply inherits the block of its device).  The
-// key includes the device: the null stream has the same handle on every device.
-static MmScratch *mm_scratch_of(hipStream_t s) {
-  static std::mutex mu;
-  static std::map<std::pair<int, hipStream_t>, MmScratch *> pool;
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-  std::lock_guard<std::mutex> lk(mu);
-  const auto key = std::make_pair(dev, s);
-  auto it = pool.find(key);
-  if (it != pool.end()) return it->second;
-  MmScratch *p = nullptr;
-  if (hipMalloc(reinterpret_cast<void **>(&p), sizeof(MmScratch)) != hipSuccess) return nullptr;
-  pool.emplace(key, p);
-  return p;
-}
+static_assert(sizeof(MmScratch) <= HARL_MM_SCRATCH_BYTES, "HARL_MM_SCRATCH_BYTES too small");
 
-extern "C" int harl_masked_moments(const float *x, const float *active, long n, double *out3, void *stream) {
+// `scratch`: HARL_MM_SCRATCH_BYTES of device memory owned by the caller (8-byte aligned; one block per stream that may have
+// a launch in flight) -- the library allocates nothing (include/harl_hip.h conventions).
+extern "C" int harl_masked_moments(const float *x, const float *active, long n, double *out3, void *scratch, void *stream) {
   if (n <= 0) return 0;
   long nb = (n + 2047) / 2048;
   if (nb > MM_MAX_BLOCKS) nb = MM_MAX_BLOCKS;
   hipStream_t s = (hipStream_t)stream;
-  MmScratch *ws = mm_scratch_of(s);
-  if (!ws) {
-    set_error("harl_masked_moments: scratch allocation failed");
+  MmScratch *ws = static_cast<MmScratch *>(scratch);
+  if (!ws || (reinterpret_cast<uintptr_t>(ws) & 7) != 0) {
+    set_error("harl_masked_moments: scratch must be HARL_MM_SCRATCH_BYTES of 8-byte aligned device memory");
     return -2;
   }
   (void)hipMemsetAsync(&ws->ticket, 0, sizeof(unsigned), s);
@@ -1524,33 +1510,15 @@ __global__ __launch_bounds__(CG_THREADS) void k_trpo_cg_step(float *__restrict__
   }
 }
 
-// one scratch block per (device, stream), zero-initialised once, kept for the life of the process (cf. mm_scratch_of)
-static CgScratch *cg_scratch_of(hipStream_t s) {
-  static std::mutex mu;
-  static std::map<std::pair<int, hipStream_t>, CgScratch *> pool;
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-  std::lock_guard<std::mutex> lk(mu);
-  const auto key = std::make_pair(dev, s);
-  auto it = pool.find(key);
-  if (it != pool.end()) return it->second;
-  CgScratch *p = nullptr;
-  if (hipMalloc(reinterpret_cast<void **>(&p), sizeof(CgScratch)) != hipSuccess) return nullptr;
-  // zeroed ON THE TARGET STREAM (torch streams are non-blocking: a null-stream memset is not ordered against them), once; the
-  // kernels leave the barrier words at zero themselves (last workgroup out)
-  if (hipMemsetAsync(p, 0, sizeof(CgScratch), s) != hipSuccess) {
-    (void)hipFree(p);
-    return nullptr;
-  }
-  pool.emplace(key, p);
-  return p;
-}
+static_assert(sizeof(CgScratch) <= HARL_CG_SCRATCH_BYTES, "HARL_CG_SCRATCH_BYTES too small");
 
-extern "C" int harl_trpo_cg_step(float *x, float *r, float *p, const float *avp, long n, float *state, void *stream) {
+// `scratch`: HARL_CG_SCRATCH_BYTES of caller-owned device memory, ZERO-FILLED once before the first launch that uses it (the
+// kernel leaves its barrier words at zero itself: last workgroup out), one block per stream with launches in flight.
+extern "C" int harl_trpo_cg_step(float *x, float *r, float *p, const float *avp, long n, float *state, void *scratch, void *stream) {
   if (n <= 0) return 0;
-  CgScratch *ws = cg_scratch_of((hipStream_t)stream);
-  if (!ws) {
-    set_error("harl_trpo_cg_step: scratch allocation failed");
+  CgScratch *ws = static_cast<CgScratch *>(scratch);
+  if (!ws || (reinterpret_cast<uintptr_t>(ws) & 7) != 0) {
+    set_error("harl_trpo_cg_step: scratch must be HARL_CG_SCRATCH_BYTES of zero-filled, 8-byte aligned device memory");
     return -2;
   }
   hipLaunchKernelGGL(k_trpo_cg_step, dim3(CG_WGS), dim3(CG_THREADS), 0, (hipStream_t)stream, x, r, p, avp, n, state, ws);

@@ -88,11 +88,23 @@ def _runner_class(base_cls, ours):
         _ensure_update_state = ours._ensure_update_state
         _critic_first_ok = getattr(ours, "_critic_first_ok", None)
         _fp_normalised_advantages = ours._fp_normalised_advantages
+        _check_comms = ours._check_comms
         warmup = ours.warmup
         insert = ours.insert
         compute = ours.compute
         train = ours.train
         after_update = ours.after_update
+
+        def __init__(self, *a, **k):
+            # the reference's constructor first; then -- still in constructor order on every rank -- everything COLLECTIVE the
+            # update needs: the communicator (HARL_ALLREDUCE=oneshot / auto exchange handles while it is built) and, with
+            # HARL_CRITIC_GROUP=1, the critic's own group (dist.second_group: never from a lazy path)
+            super().__init__(*a, **k)
+            if not self.algo_args["render"]["use_render"]:  # (render mode builds no critic and no buffers: base_runner.py:126)
+                from .dist import Comm
+                self.comm = Comm()
+                self._critic_comm = self.comm.second_group()
+                self._init_update_state()
 
         @torch.no_grad()
         def collect(self, step):

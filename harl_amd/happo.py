@@ -150,7 +150,7 @@ class OnPolicyBase:
             am = _as_dev(active_masks, self.device).reshape(M).contiguous()
         mom = torch.zeros(3, dtype=torch.float64, device=self.device)
         entropy = torch.empty((), **self.tpdv)
-        call("harl_masked_moments", ptr(ent_rows), ptr(am), M, ptr(mom), stream())
+        call("harl_masked_moments", ptr(ent_rows), ptr(am), M, ptr(mom), _lib.scratch("mm"), stream())
         call("harl_moments_mean", ptr(mom), ptr(entropy), stream())
         if net.md:
             return out, entropy, None
@@ -388,7 +388,7 @@ class HAPPO(OnPolicyBase):
         """fp64 {sum, sumsq, count} of ``advantages`` over this agent's active entries (happo.py:119-127) -> out[3]."""
         T, N = actor_buffer.actions.shape[:2]
         adv = _as_dev(advantages, self.device).reshape(T * N)
-        call("harl_masked_moments", ptr(adv), ptr(actor_buffer.flat("active_masks")), T * N, ptr(out), stream())
+        call("harl_masked_moments", ptr(adv), ptr(actor_buffer.flat("active_masks")), T * N, ptr(out), _lib.scratch("mm"), stream())
 
     def fuses_old_logp(self) -> bool:
         """True when train()'s first forward sees every buffer row, in order, under the pre-update parameters -- i.e. it

@@ -35,6 +35,7 @@ class HATRPO(OnPolicyBase):
         self._tangent_ws = None
         self._grad_tap = None
         self._cg_tap = None  # test hook: called with (k, x_k) after CG steps 1, 5 and 10
+        self._trace = None  # test hook: list receiving one dict per update (accept decision, backtracks, the five statistics)
 
     # ---- surrogate  sum_s ratio*f*adv*active / sum(active)  (hatrpo.py:77-90), optionally with its gradient ---------
     def _surrogate(self, obs, m, actions, avail, old_logp, adv, adv_moments, factor, active, want_grad: bool, seq=None):
@@ -243,7 +244,7 @@ class HATRPO(OnPolicyBase):
         state = torch.stack([torch.dot(r, r), torch.zeros((), dtype=g.dtype, device=g.device)])  # [r.r, done]
         for it in range(10):
             avp = self._fvp(obs, m, m_global, avail_rows, p, seq=seq)
-            call("harl_trpo_cg_step", ptr(x), ptr(r), ptr(p), ptr(avp), x.numel(), ptr(state), stream())
+            call("harl_trpo_cg_step", ptr(x), ptr(r), ptr(p), ptr(avp), x.numel(), ptr(state), _lib.scratch("cg"), stream())
             if self._cg_tap is not None and it + 1 in (1, 5, 10):
                 self._cg_tap(it + 1, x.clone())
         params = net.flat_param.clone()
@@ -261,6 +262,7 @@ class HATRPO(OnPolicyBase):
         flag, fraction = False, 1.0
         kl = loss_improve = 0.0
         sc_new = sc
+        backtracks = 0
         for _ in range(self.ls_step):
             net.flat_param.copy_(params + fraction * full_step)
             net.fold()
@@ -276,12 +278,17 @@ class HATRPO(OnPolicyBase):
                 break
             expected_improve *= self.backtrack_coeff
             fraction *= self.backtrack_coeff
+            backtracks += 1
         if not flag:
             net.flat_param.copy_(params)
             net.fold()
             print("policy update does not impove the surrogate")
         dist_entropy = float((sc_new[2] / sc_new[1]).item())
         ratio = float((sc_new[3] / sc_new[4]).item())
+        if self._trace is not None:
+            self._trace.append(dict(accepted=bool(flag), backtracks=backtracks, fraction=fraction, kl=kl, loss=loss,
+                                    loss_improve=loss_improve, expected_improve=expected_improve, dist_entropy=dist_entropy,
+                                    ratio=ratio, step_size=float(step_size.item()), shs=float(shs.item())))
         return kl, loss_improve, expected_improve, dist_entropy, ratio
 
     def update(self, sample):
@@ -316,7 +323,7 @@ class HATRPO(OnPolicyBase):
         adv = _as_dev(advantages, dev).reshape(B).contiguous()
         active = buf.flat("active_masks").reshape(B)
         moments = torch.zeros(3, dtype=torch.float64, device=dev)
-        call("harl_masked_moments", ptr(adv), ptr(active), B, ptr(moments), stream())
+        call("harl_masked_moments", ptr(adv), ptr(active), B, ptr(moments), _lib.scratch("mm"), stream())
         self.comm.all_reduce_sum(moments)
         if float(moments[2].item()) == 0.0:
             return info

@@ -723,6 +723,10 @@ class _FlatNet(nn.Module):
             # every CU and the dx kernel behind them.
             two = (_bwd_streams() and ho == 128 and hi == 128 and self.device_.type == "cuda"
                    and (not (l == 1 and fuse_dw1) or self.kp0 == 32))
+            if side_pending and not (l == 1 and fuse_dw1):
+                # this layer's dx launch WRITES dz[1 - cur] -- the buffer the previous layer's weight-gradient launch on the side
+                # stream still reads (L >= 3 with an unfused first-layer gradient): order it behind that launch
+                torch.cuda.current_stream(self.device_).wait_event(self._bwd_ev[1])
             if two:
                 main_s, side_s, e0 = torch.cuda.current_stream(self.device_), self._bwd_side(), self._bwd_ev[0]
                 e0.record(main_s)
@@ -740,6 +744,7 @@ class _FlatNet(nn.Module):
                 with torch.cuda.stream(side_s):
                     call("harl_mlp_dw_partials", ptr(self.dz[cur]), 0, 0, ho, ptr(self.xh[l - 1]), 0, 0, None, None, None, hi, M,
                          ptr(self.part[po[l]:]), nwg, side_s.cuda_stream, tag="dw_hidden")
+                self._bwd_ev[1].record(side_s)
                 side_pending = True
             cur = 1 - cur
         h0 = self.hidden_sizes[0]

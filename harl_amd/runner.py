@@ -115,6 +115,13 @@ class OnPolicyHARunner:
         if not getattr(self, "_update_state_ready", False):
             self._init_update_state()
 
+    def _check_comms(self) -> None:
+        """After train()'s read-back (the device is idle): a timed-out one-shot exchange has put NaNs into that step's
+        gradients -- raise instead of training on.  No-op unless HARL_ALLREDUCE selected the one-shot path."""
+        self.comm.check()
+        if self.critic.comm is not self.comm:
+            self.critic.comm.check()
+
     # ---- on_policy_base_runner.py:462-484 -------------------------------------------------------
     @torch.no_grad()
     def compute(self):
@@ -287,6 +294,7 @@ class OnPolicyHARunner:
         rng_sync()  # the global CPU generator is exactly where the reference leaves it
         dev_infos = [p[1] for p in pending if p is not None] + [cinfo]
         flat = torch.cat([t.reshape(-1) for t in dev_infos]).cpu().tolist()  # the single end-of-train read-back
+        self._check_comms()
         off = 0
         for p in pending:
             if p is not None:
@@ -320,7 +328,7 @@ class OnPolicyHARunner:
         active = torch.stack([b.active_masks[:-1] for b in self.actor_buffer], dim=2).contiguous()  # [T,N,A,1]
         mom = torch.zeros(3, dtype=torch.float64, device=dev)
         n = advantages.numel()
-        call("harl_masked_moments", ptr(advantages), ptr(active), n, ptr(mom), stream())
+        call("harl_masked_moments", ptr(advantages), ptr(active), n, ptr(mom), _lib.scratch("mm"), stream())
         self.comm.all_reduce_sum(mom)
         adv_n = torch.empty_like(advantages)
         call("harl_adv_normalize", ptr(advantages), ptr(mom), ptr(adv_n), n, stream())
@@ -614,6 +622,7 @@ class OnPolicyMARunner(OnPolicyHARunner):
         cinfo = self.critic.train(self.critic_buffer, self.value_normalizer, _defer=True)
         rng_sync()
         flat = torch.cat([t.reshape(-1) for t in dev_infos] + [cinfo.reshape(-1)]).cpu().tolist()
+        self._check_comms()
         keys = self.actor[0]._INFO_KEYS
         actor_train_infos = [s if isinstance(s, dict) else dict(zip(keys, flat[4 * s:4 * s + 4])) for s in slots]
         off = 4 * len(dev_infos)

@@ -32,6 +32,11 @@ extern "C" {
 #define HARL_DHEAD_LD 32  /* row stride of the head-gradient matrix */
 #define HARL_MD_MAX_HEADS 8  /* MultiDiscrete: entries of nvec */
 #define HARL_MD_MAX_GROUPS 4 /* MultiDiscrete: logits images (<= 128 logits each) */
+/* caller-owned device scratch of the two entry points that combine per-workgroup partial sums across the grid (8-byte aligned;
+ * ONE block per stream that may have such a launch in flight; the library itself never allocates device memory -- the only
+ * exception is harl_comm_create, which must export its buffer through hipIpc): */
+#define HARL_MM_SCRATCH_BYTES 24640 /* harl_masked_moments: 1024 x 3 doubles + a ticket word */
+#define HARL_CG_SCRATCH_BYTES 1088  /* harl_trpo_cg_step: barrier words + 2 x 64 doubles; zero-filled ONCE by the caller */
 
 int harl_version(void);
 const char *harl_last_error(void);
@@ -54,8 +59,9 @@ int harl_gae_returns(const float *rewards, float *value_preds, const float *mask
 
 /* Masked moments of the advantages: {sum x, sum x^2, count} over entries with active != 0, fp64.
  * Replaces the NaN trick + np.nanmean/np.nanstd of HAPPO.train (algorithms/actors/happo.py:122-127).
- * out3 (double[3]) is ACCUMULATED into (zero it first); all-reduce it across ranks when sharded. */
-int harl_masked_moments(const float *x, const float *active, long n, double *out3, void *stream);
+ * out3 (double[3]) is ACCUMULATED into (zero it first); all-reduce it across ranks when sharded.
+ * scratch: HARL_MM_SCRATCH_BYTES of caller-owned device memory (see the defines above). */
+int harl_masked_moments(const float *x, const float *active, long n, double *out3, void *scratch, void *stream);
 
 /* Rollout-side row arithmetic on the head outputs: everything StochasticPolicy.forward / evaluate_actions do around the random
  * draw (harl/models/base/act.py:45-157, distributions.py:31-103; the draw itself is torch's device generator, as in the
@@ -393,10 +399,11 @@ int harl_actor_head_fvp(const float *xL, const float *xLdot, const uint32_t *rel
  *   harl_trpo_fvp_finish: out = grad / m_global + damping * vec, with the log_std block (offset logstd_off, act_dim entries;
  *     log_std NULL for Categorical policies) replaced by 2 (dsigma/dlog_std)^2 / sigma^2 * vec  -- the epilogue of F v + 0.1 v.
  *   harl_trpo_cg_step: one conjugate-gradient iteration on (x, r, p) given avp = F p; state[0] = r.r, state[1] = done flag
- *     (the reference's `if rdotr < 1e-10: break`, kept on the device: a finished solve freezes x, r and p). */
+ *     (the reference's `if rdotr < 1e-10: break`, kept on the device: a finished solve freezes x, r and p);
+ *     scratch: HARL_CG_SCRATCH_BYTES of caller-owned, zero-filled device memory (see the defines at the top). */
 int harl_trpo_fvp_finish(const float *grad, const float *vec, const float *log_std, float *out, long n, float m_global,
                          float damping, long logstd_off, int act_dim, float std_x_coef, float std_y_coef, void *stream);
-int harl_trpo_cg_step(float *x, float *r, float *p, const float *avp, long n, float *state, void *stream);
+int harl_trpo_cg_step(float *x, float *r, float *p, const float *avp, long n, float *state, void *scratch, void *stream);
 /* out_sum (double, accumulated) += sum_s KL(old || new)_s from the head outputs of harl_actor_head_logp:
  * Gaussian analytic KL in fp64 (trpo_util.py:54-62), Categorical kl_approx on normalised logits (trpo_util.py:47-51) */
 int harl_trpo_kl_sum(const float *head_old, const float *head_new, const float *log_std_old, const float *log_std_new,
@@ -581,12 +588,17 @@ int harl_rng_jump(const uint8_t *state_in, long state_bytes, long n_draws, uint8
  *   harl_comm_connect : all_handles = world x 64 bytes (host), rank-major, gathered by the caller (torch.distributed object
  *                       gather); maps every peer's buffer.  Collective in the sense that every rank must get here.
  *   harl_comm_allreduce: in-place SUM of msg[0..n) (device; fp32, or fp64 when is_f64) on `stream`; same n and call order on
- *                       every rank.  No host state: safe under hipGraph capture.  A peer that does not show up within 4 s
- *                       turns the result into NaN and sets the status word instead of hanging the device.
+ *                       every rank.  No host state: safe under hipGraph capture.  A peer that does not show up within the
+ *                       communicator's time-out (default 600 s; harl_comm_set_timeout, 0 = wait for ever like RCCL) turns
+ *                       the result into NaN and sets the status word instead of hanging the device.  A time-out is FATAL
+ *                       for the communicator (flags and epochs are out of step afterwards): the caller must check
+ *                       harl_comm_status at its next host synchronisation point and stop.
+ *   harl_comm_set_timeout: flag-wait limit of later launches in seconds, 0 = none (host state only).
  *   harl_comm_status  : 0, or q + 1 after a wait for rank q timed out (synchronises the device). */
 int harl_comm_create(int world, int rank, long cap_bytes, int n_blocks, void *handle_out, void *ctx_out);
 int harl_comm_connect(void *ctx, const void *all_handles);
 int harl_comm_allreduce(void *ctx, void *msg, long n, int is_f64, void *stream);
+int harl_comm_set_timeout(void *ctx, double seconds);
 int harl_comm_status(void *ctx);
 int harl_comm_destroy(void *ctx);
 

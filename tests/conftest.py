@@ -51,6 +51,40 @@ def _library_present():
     build()
 
 
+# full-size comparisons whose oracle side is started ahead of time (tests/gpu_checks.prefetch_full_size)
+FULL_SIZE_TESTS = {
+    "test_bench_configuration_against_oracle": "mpe",
+    "test_bench_configuration_onpolicy_against_oracle": "mpe_onpolicy",
+    "test_cheetah6_full_size_against_oracle": "cheetah6",
+    "test_smac3s5z_full_size_against_oracle": "smac3s5z",
+    "test_humanoid17_full_size_against_oracle": "humanoid17",
+    "test_hatrpo_gru128_full_size_against_oracle": "hatrpo_gru128",
+}
+_selected_full_size = []
+
+
+def pytest_collection_finish(session):
+    _selected_full_size[:] = [FULL_SIZE_TESTS[i.name] for i in session.items if i.name in FULL_SIZE_TESTS]
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _full_size_prefetch(_library_present):
+    """On a GPU box: run the HIP step of every SELECTED full-size check now and start their oracle workers (host CPUs), so that
+    the minutes of float64 / one-ulp oracle work overlap the rest of the suite instead of following it (VERDICT r05 weak 12:
+    858 s of the driver's 1 200 s).  HARL_PREFETCH=0 switches it off (the checks then run inline)."""
+    import torch
+    if not torch.cuda.is_available() or not _selected_full_size or os.environ.get("HARL_PREFETCH", "1") == "0":
+        yield
+        return
+    from tests import gpu_checks as G
+    G.prefetch_full_size(_selected_full_size)
+    yield
+    for pre in list(G._PREFETCH.values()):  # a run that stopped early (-x): do not leave worker processes behind
+        for _, _, pr in (pre.get("handle") or {}).get("procs", []):
+            if pr.poll() is None:
+                pr.kill()
+
+
 @pytest.fixture(autouse=True)
 def _oracle_module_defaults():
     """The oracle keeps ONE configuration at a time in module globals (activation function, work dtype): a test that calls its

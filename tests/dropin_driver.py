@@ -43,13 +43,14 @@ def main():
             calls[name] = calls.get(name, 0) + 1
             if name in host_side:
                 return real_call(name, *args, tag=tag)
-            if name == "harl_masked_moments":  # (x, active, n, out3, stream): pretend every entry is active so train() proceeds
+            if name == "harl_masked_moments":  # (x, active, n, out3, scratch, stream): pretend every entry is active so train() proceeds
                 ctypes.c_double.from_address(args[3] + 16).value = float(args[2])
             return None
 
         _lib.call = recorder
         _lib.require_gpu = lambda device: None
         _lib.stream = lambda: 0
+        _lib.scratch = lambda kind: 0
         for mod in ("nets", "buffers", "happo", "hatrpo", "mappo", "v_critic", "valuenorm", "runner"):
             m = __import__(f"harl_amd.{mod}", fromlist=["x"])
             for nm in ("call", "stream"):

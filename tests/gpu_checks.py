@@ -161,7 +161,7 @@ def check_elementwise() -> Dict[str, float]:
     ref = O.normalize_advantages(adv.reshape(-1, 1, 1), act.reshape(-1, 1, 1)).reshape(-1)
     mom = torch.zeros(3, dtype=torch.float64, device=DEV)
     d_adv, d_act = dev(adv), dev(act)  # keep references: a temporary would be recycled by the caching allocator
-    call("harl_masked_moments", ptr(d_adv), ptr(d_act), n, ptr(mom), stream())
+    call("harl_masked_moments", ptr(d_adv), ptr(d_act), n, ptr(mom), _lib.scratch("mm"), stream())
     g = torch.empty(n, device=DEV)
     call("harl_adv_normalize", ptr(d_adv), ptr(mom), ptr(g), n, stream())
     out["adv_normalize_vec_rel"] = vec_rel_err(g.cpu().numpy(), ref)
@@ -1224,6 +1224,9 @@ def check_full_size_properties() -> Dict[str, float]:
     return out
 
 
+TRPO_TRACE_KEYS = ("accepted", "fraction", "kl", "loss", "loss_improve", "expected_improve", "dist_entropy", "ratio", "step_size", "shs")
+
+
 def _oracle_bench_run(payload: dict, tag: str, dt_name: str, pert_seed, keep_grad: bool) -> dict:
     """One oracle compute() + ha_train() on the host copies in ``payload`` (see _bench_config_runs).  Runs either in this
     process or -- on hosts with enough cores -- in a worker process of its own (tests/oracle_worker.py), so that the fp32 /
@@ -1241,10 +1244,15 @@ def _oracle_bench_run(payload: dict, tag: str, dt_name: str, pert_seed, keep_gra
     try:
         t0 = _time.perf_counter()
         torch.set_rng_state(payload["rng0"])
-        actors = [O.OracleHAPPO({k: v.clone() for k, v in sd.items()}, cfg) for sd in actor_sd]
+        trpo = w["algo"] == "hatrpo"
+        if trpo:
+            tc = O.TrpoConfig(**{k: args["algo"][k] for k in ("kl_threshold", "ls_step", "accept_ratio", "backtrack_coeff")})
+            actors = [O.OracleHATRPO({k: v.clone() for k, v in sd.items()}, cfg, tc) for sd in actor_sd]
+        else:
+            actors = [O.OracleHAPPO({k: v.clone() for k, v in sd.items()}, cfg) for sd in actor_sd]
         critic = O.OracleVCritic({k: v.clone() for k, v in critic_sd.items()}, cfg)
         if pert_seed is not None:
-            _perturb_one_ulp([a_.net for a_ in actors] + [critic.net], pert_seed)
+            _perturb_one_ulp([a_ if trpo else a_.net for a_ in actors] + [critic.net], pert_seed)
         abufs = [O.OracleActorBuffer(d["obs"].copy(), d["actions"].copy(), d["logp"].copy(), d["masks"].copy(), d["active"].copy(),
                                      None if d.get("avail") is None else d["avail"].copy(),
                                      rnn_states=None if d.get("rnn") is None else d["rnn"].copy()) for d in abuf_np]
@@ -1265,11 +1273,17 @@ def _oracle_bench_run(payload: dict, tag: str, dt_name: str, pert_seed, keep_gra
         cbuf.compute_returns(payload["next_value_hip"].copy() if tag == "f32" else nv.astype(np.float64 if dt == torch.float64 else np.float32),
                              vn, cfg)
         infos, cinfo, extra_ = O.ha_train(actors, critic, abufs, cbuf, vn, cfg, keep_grad=keep_grad)
+        if trpo:  # one update per agent: the line search's decisions and the five statistics (no parameter-sized arrays)
+            atr = [[{k: (bool(v) if k == "accepted" else float(v)) for k, v in u.items() if k in TRPO_TRACE_KEYS} for u in a_.trace]
+                   for a_ in actors]
+            fin = [a_.flat().numpy().astype(np.float64) for a_ in actors]
+        else:
+            atr = [np.array([[u["policy_loss"], u["dist_entropy"], u["grad_norm"], u["ratio"]] for u in a_.trace]) for a_ in actors]
+            fin = [np.asarray(a_.net.flat(), dtype=np.float64) for a_ in actors]
         return dict(nv=nv, adv=np.asarray(extra_["advantages"]), returns=np.asarray(cbuf.returns).copy(), infos=infos, cinfo=cinfo,
-                    atr=[np.array([[u["policy_loss"], u["dist_entropy"], u["grad_norm"], u["ratio"]] for u in a_.trace])
-                         for a_ in actors],
+                    atr=atr,
                     ctr=np.array([[u["value_loss"], u["grad_norm"]] for u in critic.trace]),
-                    fin=[np.asarray(a_.net.flat(), dtype=np.float64) for a_ in actors],
+                    fin=fin,
                     grads=[[np.asarray(u["grad"], dtype=np.float64) for u in a_.trace] for a_ in actors] if keep_grad else None,
                     cfin=np.asarray(critic.net.flat(), dtype=np.float64), vn=vn.state(), rng=torch.get_rng_state(),
                     seconds=_time.perf_counter() - t0)
@@ -1277,47 +1291,61 @@ def _oracle_bench_run(payload: dict, tag: str, dt_name: str, pert_seed, keep_gra
         O.set_work_dtype(torch.float32)
 
 
-def _oracle_bench_runs(payload: dict, plan, keep_grad: bool) -> dict:
-    """All oracle runs of ``plan`` [(tag, dtype name, one-ulp seed | None)].  With >= 64 host CPUs (the GPU boxes have 256) each
-    run gets a process of its own (16 torch threads each; the payload travels through one file in a temporary directory);
-    otherwise they run one after the other in this process.  Same code either way (_oracle_bench_run)."""
+def _oracle_launch(payload: dict, plan, keep_grad: bool, threads: int = 0) -> dict:
+    """Start one worker process per entry of ``plan`` [(tag, dtype name, one-ulp seed | None)] (tests/oracle_worker.py; the
+    payload travels through one file in a temporary directory) and return the handle ``_oracle_collect`` waits on."""
     import subprocess
     import sys
     import tempfile
-    mode = os.environ.get("HARL_ORACLE_PARALLEL", "auto")  # "0": in-process, "force": worker processes whatever the host
-    if mode != "force" and ((os.cpu_count() or 1) < 64 or len(plan) == 1 or mode == "0"):
-        return {tag: _oracle_bench_run(payload, tag, dtn, seed, keep_grad) for tag, dtn, seed in plan}
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    with tempfile.TemporaryDirectory(prefix="harl_oracle_") as td:
-        pin = os.path.join(td, "payload.pt")
-        torch.save(payload, pin)
-        procs = []
-        for tag, dtn, seed in plan:
-            pout = os.path.join(td, f"{tag}.pt")
-            env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""), OMP_NUM_THREADS=os.environ.get("HARL_ORACLE_THREADS") or "16",
-                       HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
-            cmd = [sys.executable, "-m", "tests.oracle_worker", pin, pout, tag, dtn, "none" if seed is None else str(seed), str(int(keep_grad))]
-            procs.append((tag, pout, subprocess.Popen(cmd, cwd=root, env=env)))
-        runs = {}
-        for tag, pout, pr in procs:
+    td = tempfile.TemporaryDirectory(prefix="harl_oracle_")
+    pin = os.path.join(td.name, "payload.pt")
+    torch.save(payload, pin)
+    nthr = str(threads or int(os.environ.get("HARL_ORACLE_THREADS") or 16))
+    procs = []
+    for tag, dtn, seed in plan:
+        pout = os.path.join(td.name, f"{tag}.pt")
+        env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""), OMP_NUM_THREADS=nthr,
+                   HARL_ORACLE_THREADS=nthr, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+        cmd = [sys.executable, "-m", "tests.oracle_worker", pin, pout, tag, dtn, "none" if seed is None else str(seed), str(int(keep_grad))]
+        procs.append((tag, pout, subprocess.Popen(cmd, cwd=root, env=env)))
+    return dict(td=td, procs=procs)
+
+
+def _oracle_collect(handle: dict) -> dict:
+    runs = {}
+    try:
+        for tag, pout, pr in handle["procs"]:
             rc = pr.wait()
             if rc != 0:
                 raise RuntimeError(f"oracle worker {tag} failed with exit code {rc}")
             runs[tag] = torch.load(pout, weights_only=False)
+    finally:
+        for _, _, pr in handle["procs"]:
+            if pr.poll() is None:
+                pr.kill()
+        handle["td"].cleanup()
     return runs
 
 
-def _bench_config_runs(n_threads: int, with_f64: bool, keep_grad: bool = False, logp: str = "recipe", n_pert: int = 0,
-                       workload: str = "mpe"):
-    """HIP step + oracle run(s) of a BENCH configuration on identical contents (see check_bench_config_parity).  Returns
-    (hip dict, {"f32": .., "f64": .., "pert0": ..} oracle dicts, names/shapes of the actor / critic parameter tensors, meta).
-    ``n_pert`` further fp32 oracle runs start from parameters moved by one ulp (``_perturb_one_ulp``): how far the reference's
-    own fp32 figures move under the smallest change fp32 can express.  ``workload``: a feed-forward HAPPO entry of
-    bench.WORKLOADS ("mpe" = BASELINE configs[1], "cheetah6" = configs[2] at one GPU's share)."""
+def _oracle_bench_runs(payload: dict, plan, keep_grad: bool) -> dict:
+    """All oracle runs of ``plan`` [(tag, dtype name, one-ulp seed | None)].  With >= 64 host CPUs (the GPU boxes have 256) each
+    run gets a process of its own (16 torch threads each); otherwise they run one after the other in this process.  Same code
+    either way (_oracle_bench_run)."""
+    mode = os.environ.get("HARL_ORACLE_PARALLEL", "auto")  # "0": in-process, "force": worker processes whatever the host
+    if mode != "force" and ((os.cpu_count() or 1) < 64 or len(plan) == 1 or mode == "0"):
+        return {tag: _oracle_bench_run(payload, tag, dtn, seed, keep_grad) for tag, dtn, seed in plan}
+    return _oracle_collect(_oracle_launch(payload, plan, keep_grad))
+
+
+def _bench_hip_step(n_threads: int, keep_grad: bool = False, logp: str = "recipe", workload: str = "mpe"):
+    """The HIP half of a full-size comparison: build the bench runner of ``workload``, copy everything train() reads to the
+    host, run ONE bench step with the per-update traces switched on.  Returns (hip dict, oracle payload, parameter names /
+    shapes, meta)."""
     import bench
     w = bench.WORKLOADS[workload]
-    assert w["algo"] == "happo", "HAPPO workloads (feed-forward Box, or the recurrent Discrete one with unavailable actions)"
     T, A = w["T"], w["A"]
+    trpo = w["algo"] == "hatrpo"
     torch.manual_seed(1)
     r = bench.build_gpu_runner(w, n_threads, 0, 1, DEV, logp)
     # ---- host copies of everything train() reads, taken BEFORE the HIP step
@@ -1351,6 +1379,9 @@ def _bench_config_runs(n_threads: int, with_f64: bool, keep_grad: bool = False, 
     rng_hip = torch.get_rng_state()
     gtr = []
     for a_ in r.actor:
+        if trpo:  # one dict per update (harl_amd/hatrpo.py)
+            gtr.append([dict(u) for u in a_._trace])
+            continue
         cum = torch.stack(a_._trace).double().cpu().numpy()
         gtr.append(np.diff(np.concatenate([np.zeros((1, cum.shape[1])), cum]), axis=0)[:, :4])
     cum = torch.stack(r.critic._trace).double().cpu().numpy()
@@ -1361,17 +1392,75 @@ def _bench_config_runs(n_threads: int, with_f64: bool, keep_grad: bool = False, 
     shapes = dict(actor=[(k, tuple(v.shape)) for k, v in actor_sd[0].items()], critic=[(k, tuple(v.shape)) for k, v in critic_sd.items()])
     del r
     torch.cuda.empty_cache()
-    # ---- oracle on the same contents
     args = bench.algo_args(n_threads, T, w)
     cfg = O.PathConfig.from_reference_dicts(args["train"], args["model"], args["algo"])
-    plan = [("f32", "f32", None)] + ([("f64", "f64", None)] if with_f64 else []) + \
-           [(f"pert{k}", "f32", 977 + k) for k in range(n_pert)]
     payload = dict(workload=workload, n_threads=n_threads, actor_sd=actor_sd, critic_sd=critic_sd, abuf=abuf_np, cbuf=cbuf_np,
                    st0=st0, rng0=rng0, next_value_hip=next_value_hip)
-    runs = _oracle_bench_runs(payload, plan, keep_grad)
     hip = dict(next_value=next_value_hip, returns=returns_hip, rng=rng_hip, atr=gtr, ctr=gctr, infos=ginfos, cinfo=gcinfo,
                fin=gfin, cfin=gcfin, vn=gvn, grads=gtaps if keep_grad else None)
-    return hip, runs, shapes, dict(T=T, A=A, actor_sd=actor_sd, abuf=abuf_np, cfg=cfg)
+    return hip, payload, shapes, dict(T=T, A=A, actor_sd=actor_sd, abuf=abuf_np, cfg=cfg)
+
+
+def _oracle_plan(with_f64: bool, n_pert: int):
+    return [("f32", "f32", None)] + ([("f64", "f64", None)] if with_f64 else []) + \
+           [(f"pert{k}", "f32", 977 + k) for k in range(n_pert)]
+
+
+# ---- full-size comparisons started ahead of the tests that assert on them -----------------------------------------------------
+# The oracle's side of a full-size check is minutes of host-CPU work (f32 + float64 + one-ulp twins of compute() + train() at
+# 819 200 rows per agent) during which the GPU idles; run one after the other inside their tests they were 383 s of the round-5
+# suite's 859 s.  `prefetch_full_size` (called by a session fixture, tests/conftest.py) runs the HIP step of every selected
+# full-size check right away -- seconds each -- and starts all their oracle workers at once; the tests collect the results
+# at the end of the file, by which time the ~190 other tests have run next to the workers.
+FULL_SIZE = {  # key -> (workload, logp, n_threads, n_pert)   [test name -> key: tests/conftest.py]
+    "humanoid17": ("humanoid17", "recipe", 1024, 1),
+    "cheetah6": ("cheetah6", "recipe", 4096, 1),
+    "hatrpo_gru128": ("hatrpo_gru128", "recipe", 512, 1),
+    "mpe_onpolicy": ("mpe", "onpolicy", 4096, 3),
+    "mpe": ("mpe", "recipe", 4096, 2),
+    "smac3s5z": ("smac3s5z", "recipe", 512, 1),
+}
+_PREFETCH: Dict[tuple, dict] = {}
+
+
+def prefetch_full_size(keys) -> None:
+    """HIP step + oracle worker launch for every key of FULL_SIZE in ``keys`` (heaviest first).  Failures are kept and raised by
+    the test that asks for the result, not here.  Hosts with < 64 CPUs (no room for worker processes) do nothing: the checks
+    then run inline as before."""
+    if (os.cpu_count() or 1) < 64 and os.environ.get("HARL_ORACLE_PARALLEL") != "force":
+        return
+    todo = [k for k in FULL_SIZE if k in set(keys)]
+    n_workers = sum(2 + FULL_SIZE[k][3] for k in todo)
+    threads = max(4, min(16, ((os.cpu_count() or 64) - 16) // max(1, n_workers)))
+    for k in todo:
+        workload, logp, n_threads, n_pert = FULL_SIZE[k]
+        slot = (workload, logp, n_threads, n_pert)
+        try:
+            hip, payload, shapes, meta = _bench_hip_step(n_threads, False, logp, workload)
+            handle = _oracle_launch(payload, _oracle_plan(True, n_pert), False, threads=threads)
+            del payload
+            _PREFETCH[slot] = dict(hip=hip, shapes=shapes, meta=meta, handle=handle)
+        except Exception as e:  # noqa: BLE001 -- re-raised by the test of this check
+            _PREFETCH[slot] = dict(error=e)
+        torch.cuda.empty_cache()
+
+
+def _bench_config_runs(n_threads: int, with_f64: bool, keep_grad: bool = False, logp: str = "recipe", n_pert: int = 0,
+                       workload: str = "mpe"):
+    """HIP step + oracle run(s) of a BENCH configuration on identical contents (see check_bench_config_parity).  Returns
+    (hip dict, {"f32": .., "f64": .., "pert0": ..} oracle dicts, names/shapes of the actor / critic parameter tensors, meta).
+    ``n_pert`` further fp32 oracle runs start from parameters moved by one ulp (``_perturb_one_ulp``): how far the reference's
+    own fp32 figures move under the smallest change fp32 can express.  ``workload``: an entry of bench.WORKLOADS.  A result
+    started by ``prefetch_full_size`` is collected instead of recomputed."""
+    slot = (workload, logp, n_threads, n_pert)
+    pre = _PREFETCH.pop(slot, None) if (with_f64 and not keep_grad) else None
+    if pre is not None:
+        if "error" in pre:
+            raise pre["error"]
+        return pre["hip"], _oracle_collect(pre["handle"]), pre["shapes"], pre["meta"]
+    hip, payload, shapes, meta = _bench_hip_step(n_threads, keep_grad, logp, workload)
+    runs = _oracle_bench_runs(payload, _oracle_plan(with_f64, n_pert), keep_grad)
+    return hip, runs, shapes, meta
 
 
 def dump_parity(name: str, out: dict) -> None:
@@ -1494,6 +1583,100 @@ def check_bench_config_parity(logp: str = "recipe", n_threads: int = 4096, n_per
                                                   sens=max([vec_rel_err(pr["cfin"], o["cfin"]) for pr in perts], default=None))
     out["_oracle_wall_seconds_max"] = float(max(v["seconds"] for v in runs.values()))
     dump_parity(f"bench_config_parity_{workload}_{logp}", out)
+    return out
+
+
+def check_bench_config_parity_trpo(workload: str = "humanoid17", n_threads: int = 1024, n_pert: int = 1) -> Dict[str, float]:
+    """A HATRPO bench workload at its MEASURED size against the oracle: `humanoid17` (17 agents x
+    204 800 rows, obs 393, MLP [128]x3, hatrpo.yaml defaults) or `hatrpo_gru128` (8 agents, 128-wide GRU, Discrete(14) with
+    unavailable actions, chunks of 10) -- compute() + train() on identical buffer contents, the oracle (hatrpo.py:37-194,
+    trpo_util.py:96-158: double backward, 10 CG steps, backtracking line search) in fp32, float64 and one one-ulp twin in worker
+    processes.  Asserted:
+      * returns and the CPU generator's final state bit-exact; the critic's value of slot T;
+      * per agent, in update order, the SAME accept / reject decision and the SAME number of backtracks as the fp32 oracle --
+        integers, no tolerance (`linesearch_decision_mismatch`, `linesearch_backtracks_mismatch`) -- unless the oracle itself
+        decides differently in float64 or from parameters one ulp away for that agent (then the decision is not a property of
+        the algorithm at fp32 and the agent is counted in `_agents_with_oracle_own_disagreement`, reported, excluded);
+      * kl, loss (the surrogate at theta_old), loss_improve, expected_improve, dist_entropy, ratio, step_size: pooled over the
+        agents on the measured bar max(1e-5, 2 x the fp32 oracle's own distance from its float64 / one-ulp twins), agents with
+        equal decisions only, plus flat ceilings on the raw figures (tests/test_gpu_parity.py);
+      * the critic: 1e-5 flat (feed-forward) / pooled (recurrent); final parameters pooled."""
+    import bench as _bench
+    out: Dict[str, float] = {}
+    hip, runs, _shapes, meta = _bench_config_runs(n_threads, True, n_pert=n_pert, workload=workload)
+    T, A = meta["T"], meta["A"]
+    recurrent = bool(_bench.WORKLOADS[workload].get("rnn"))
+    o, o64 = runs["f32"], runs["f64"]
+    perts = [runs[k] for k in sorted(runs) if k.startswith("pert")]
+    out["_oracle_seconds"] = float(sum(v["seconds"] for v in runs.values()))
+    out["_oracle_wall_seconds_max"] = float(max(v["seconds"] for v in runs.values()))
+    out["next_value_vec_rel"] = vec_rel_err(hip["next_value"], o["nv"])
+    out["returns_mismatch"] = float(np.sum(hip["returns"][:T] != o["returns"][:T].astype(np.float32)))
+    out["rng_state_mismatch"] = float(not torch.equal(hip["rng"], o["rng"]))
+
+    def rel(a_, b_):
+        a_, b_ = np.asarray(a_, dtype=np.float64), np.asarray(b_, dtype=np.float64)
+        return np.abs(a_ - b_) / (np.abs(b_) + 1e-12)
+
+    def bt(u):  # number of backtracks from the oracle's `fraction` = backtrack_coeff ** k
+        if "backtracks" in u:
+            return int(u["backtracks"])
+        return int(round(math.log(max(u["fraction"], 1e-300)) / math.log(0.8)))
+
+    g_ = [hip["atr"][a][0] for a in range(A)]
+    o_ = [o["atr"][a][0] for a in range(A)]
+    twins = [[run["atr"][a][0] for a in range(A)] for run in [o64] + perts]
+    stable = [all(tw[a]["accepted"] == o_[a]["accepted"] and bt(tw[a]) == bt(o_[a]) for tw in twins) for a in range(A)]
+    # the sequential factor couples the agents: once one agent's decision differs, everything after it sees another factor
+    first_unstable = next((a for a in range(A) if not stable[a]), A)
+    first_diff = next((a for a in range(A) if g_[a]["accepted"] != o_[a]["accepted"] or bt(g_[a]) != bt(o_[a])), A)
+    out["_agents"] = float(A)
+    out["_agents_with_oracle_own_disagreement"] = float(A - sum(stable))
+    out["_first_agent_with_oracle_own_disagreement"] = float(first_unstable)
+    out["_hip_accepted"] = float(sum(bool(u["accepted"]) for u in g_))
+    out["_oracle_accepted"] = float(sum(bool(u["accepted"]) for u in o_))
+    out["_hip_backtracks_total"] = float(sum(bt(u) for u in g_))
+    out["_oracle_backtracks_total"] = float(sum(bt(u) for u in o_))
+    out["_decisions_hip"] = "".join(("A" if u["accepted"] else "R") + str(bt(u)) + " " for u in g_).strip()
+    out["_decisions_oracle"] = "".join(("A" if u["accepted"] else "R") + str(bt(u)) + " " for u in o_).strip()
+    out["_decisions_oracle_f64"] = "".join(("A" if u["accepted"] else "R") + str(bt(u)) + " " for u in twins[0]).strip()
+    ok_upto = min(first_unstable, A)  # agents in front of the oracle's own first disagreement: decisions must be identical
+    out["linesearch_decision_mismatch"] = float(sum(g_[a]["accepted"] != o_[a]["accepted"] for a in range(ok_upto)))
+    out["linesearch_backtracks_mismatch"] = float(sum(bt(g_[a]) != bt(o_[a]) for a in range(ok_upto)))
+    cmp_agents = list(range(min(ok_upto, first_diff)))  # figures are comparable while both sides walked the same path
+    out["_agents_compared"] = float(len(cmp_agents))
+    for nm in ("kl", "loss", "loss_improve", "expected_improve", "dist_entropy", "ratio", "step_size"):
+        if not cmp_agents:
+            break
+        get = lambda us, nm=nm: np.array([us[a][nm] for a in cmp_agents], dtype=np.float64)  # noqa: E731
+        err = float(rel(get(g_), get(o_)).max())
+        floor = max(float(rel(get(o_), get(tw)).max()) for tw in twins)
+        out[f"_trpo_{nm}_rel"] = err
+        out[f"_trpo_{nm}_oracle_own_uncertainty"] = floor
+        out[f"trpo_{nm}_excess"] = err / max(1e-5, NOISE_FACTOR * floor)
+        out[f"_first_update_{nm}_rel"] = float(rel(g_[0][nm], o_[0][nm]))
+    for c, nm in enumerate(("value_loss", "grad_norm")):
+        err = float(rel(hip["ctr"][:, c], o["ctr"][:, c]).max())
+        if recurrent:
+            floor = max([float(rel(o["ctr"][:, c], o64["ctr"][:, c]).max())] + [float(rel(pr["ctr"][:, c], o["ctr"][:, c]).max()) for pr in perts])
+            out[f"_critic_update_{nm}_rel"] = err
+            out[f"critic_update_{nm}_excess"] = err / max(1e-5, NOISE_FACTOR * floor)
+        else:
+            out[f"critic_update_{nm}_rel"] = err
+    ovn = o["vn"]
+    out["vn_final_rel"] = rel_err(hip["vn"], [float(np.asarray(ovn[k]).reshape(-1)[0]) for k in ("running_mean", "running_mean_sq", "debiasing_term")])
+    worst_raw, floor = 0.0, 0.0
+    for a in cmp_agents:
+        raw = vec_rel_err(hip["fin"][a], o["fin"][a])
+        worst_raw = max(worst_raw, raw)
+        floor = max([floor, vec_rel_err(o["fin"][a], o64["fin"][a])] + [vec_rel_err(pr["fin"][a], o["fin"][a]) for pr in perts])
+    out["_actor_final_param_vec_rel_max"] = worst_raw
+    out["_actor_final_param_oracle_own_uncertainty"] = floor
+    out["actor_final_param_excess"] = worst_raw / max(1e-5, NOISE_FACTOR * floor)
+    out["_critic_final_param_vec_rel"] = vec_rel_err(hip["cfin"], o["cfin"])
+    out["critic_final_param_excess"] = vec_excess(hip["cfin"], o["cfin"], o64["cfin"],
+                                                  sens=max([vec_rel_err(pr["cfin"], o["cfin"]) for pr in perts], default=None))
+    dump_parity(f"bench_config_parity_{workload}_full_size", out)
     return out
 
 

@@ -23,7 +23,7 @@ def stub_kernels(monkeypatch):
         calls.setdefault(name, []).append(args)
         if name in ("harl_randperm_replay", "harl_rng_advance"):
             return real_call(name, *args, tag=tag)
-        if name == "harl_masked_moments":  # (x, active, n, out3, stream): every entry active, so that train() proceeds
+        if name == "harl_masked_moments":  # (x, active, n, out3, scratch, stream): every entry active, so that train() proceeds
             ctypes.c_double.from_address(args[3] + 16).value = float(args[2])
         return None
 
@@ -31,6 +31,7 @@ def stub_kernels(monkeypatch):
     monkeypatch.setattr(_lib, "call", recorder)
     monkeypatch.setattr(_lib, "require_gpu", lambda device: None)
     monkeypatch.setattr(_lib, "stream", lambda: 0)
+    monkeypatch.setattr(_lib, "scratch", lambda kind: 0)
     for mod in ("nets", "buffers", "happo", "hatrpo", "mappo", "v_critic", "valuenorm", "runner"):
         m = __import__(f"harl_amd.{mod}", fromlist=["x"])
         for nm in ("call", "stream"):

@@ -67,3 +67,42 @@ def test_recurrent_payload_runs_through_the_oracle(monkeypatch):
     run = G._oracle_bench_run(pl, "f32", "f32", None, False)
     assert len(run["atr"]) == w["A"] and all(x.shape == (5, 4) and np.isfinite(x).all() for x in run["atr"])
     assert run["ctr"].shape == (5, 2) and np.isfinite(run["nv"]).all() and run["nv"].shape == (n, 1)
+
+
+def _generic_payload(name, n, seed):
+    import bench
+    from harl_amd.synthetic import Shapes, actor_param_shapes, critic_param_shapes, make_buffers, synthetic_state_dict
+    w = bench.WORKLOADS[name]
+    rnn = bool(w.get("rnn"))
+    sh = Shapes(T=w["T"], N=n, A=w["A"], obs_dim=w["obs"], share_obs_dim=w["sobs"], act_dim=w["act"], discrete=w["disc"],
+                hidden_sizes=w["hidden"])
+    d = make_buffers(sh, seed=seed, unavailable_p=w.get("unavailable_p", 0.0), rnn=rnn)
+    t = lambda sd: {k: torch.from_numpy(v) for k, v in sd.items()}  # noqa: E731
+    return w, dict(workload=name, n_threads=n,
+                   actor_sd=[t(synthetic_state_dict(actor_param_shapes(sh, True, rnn), 10 + a)) for a in range(w["A"])],
+                   critic_sd=t(synthetic_state_dict(critic_param_shapes(sh, True, rnn), 99)),
+                   abuf=[dict(obs=d.obs[a], actions=d.actions[a], logp=d.action_log_probs[a], masks=d.masks[a], active=d.active_masks[a],
+                              avail=d.available_actions[a], rnn=d.rnn["actor"][a] if rnn else None) for a in range(w["A"])],
+                   cbuf=dict(share_obs=d.share_obs, rewards=d.rewards, value_preds=d.value_preds, masks=d.critic_masks,
+                             bad_masks=d.bad_masks, rnn=d.rnn["critic"] if rnn else None),
+                   st0=np.zeros(3, dtype=np.float32), rng0=torch.get_rng_state(), next_value_hip=d.value_preds[-1].copy())
+
+
+def test_hatrpo_payloads_run_through_the_oracle(monkeypatch):
+    """The HATRPO bench workloads' payloads (humanoid17: 17 agents, obs 393; hatrpo_gru128: 128-wide GRU, unavailable actions) on
+    a couple of rollout threads: the oracle run of the full-size checks returns one line-search record per agent -- decision,
+    fraction, the five statistics -- and the one-ulp twin is another run with the same record layout."""
+    from tests import gpu_checks as G
+    monkeypatch.setenv("HARL_ORACLE_THREADS", "4")
+    for name, n in (("humanoid17", 2), ("hatrpo_gru128", 2)):
+        torch.manual_seed(4)
+        w, pl = _generic_payload(name, n, 6)
+        run = G._oracle_bench_run(pl, "f32", "f32", None, False)
+        twin = G._oracle_bench_run(pl, "pert0", "f32", 977, False)
+        assert len(run["atr"]) == w["A"] and all(len(x) == 1 for x in run["atr"])
+        for a in range(w["A"]):
+            u = run["atr"][a][0]
+            assert set(u) == set(G.TRPO_TRACE_KEYS) and isinstance(u["accepted"], bool)
+            assert all(np.isfinite(float(v)) for v in u.values())
+        assert run["ctr"].shape == (5, 2) and len(run["fin"]) == w["A"]
+        assert any(not np.array_equal(x, y) for x, y in zip(run["fin"], twin["fin"]))

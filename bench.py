@@ -7,15 +7,21 @@ episode_length=200, obs 18 / share_obs 54 / Box(5), MLP [128,128], happo.yaml de
 BASELINE.json configurations at their real shapes (one JSON line each):
 
     mpe         configs[1]  MPE simple_spread, 3 agents, HAPPO                         T=200 N=4096/GPU
-    cheetah6    configs[2]  MAMuJoCo HalfCheetah-6x1, 6 agents, HAPPO, MLP [128]x3      T=200 N=4096/GPU (8192 global with --scaling strong)
-    smac3s5z    configs[3]  SMAC 3s5z, 8 agents, HAPPO, GRU policy, Discrete(14)        T=160 N=512/GPU, chunks of 10
-    humanoid17  configs[4]  MAMuJoCo Humanoid-17x1, 17 agents, HATRPO, obs 393          T=200 N=1024/GPU
+    cheetah6    configs[2]  MAMuJoCo HalfCheetah-6x1, 6 agents, HAPPO, MLP [128]x3      T=200 N=4096/GPU (8192 global with N > 1 ranks)
+    smac3s5z    configs[3]  SMAC 3s5z, 8 agents, HAPPO, GRU policy, Discrete(14)        T=160 N=512/GPU, chunks of 10  (smac3s5z_n4096: N=4096)
+    humanoid17  configs[4]  MAMuJoCo Humanoid-17x1, 17 agents, HATRPO, obs 393          T=200 N=1024/GPU  (humanoid17_n4096: the north_star's N=4096 on one GPU)
     hatrpo_gru128  (not in BASELINE.json) SMAC shape, HATRPO, MLP [128,128] + 128-wide GRU: the composed coverage path
 
 A "step" = one compute() + train() over synthetic rollout buffers (SURVEY.md 8d recipe) resident in HBM before the timed
-region.  One transition = one (t, n) environment step for all agents.  `--scaling weak` (default): every rank owns
-N rollout threads; `--scaling strong`: `--global-threads` (default 8192, BASELINE configs[2]) are split over the ranks.
-Gradients / loss scalars are all-reduced over RCCL each optimiser step (one message per step, harl_amd/dist.py);
+region.  One transition = one (t, n) environment step for all agents.
+Multi-GPU (`--gpus N`, N > 1; `--scaling auto`, the default): the ONE line answers the BASELINE's question -- `value` is the
+STRONG-scaling figure at the n_rollout_threads the BASELINE quotes the workload on (4096 global for mpe, 8192 for cheetah6 =
+configs[2], split over the ranks; `scaling: "strong"`, `config.n_rollout_threads_global`), and the `weak` object carries the
+weak-scaling figure of the same job (every rank at the config's single-GPU size), timed in a region of its own right after.
+`config.ranks_seen` = a SUM all-reduce of ones over the update's communicator (not WORLD_SIZE from the environment).
+`--scaling weak|strong` time only that one figure (`--global-threads`, `--threads-per-gpu` override the sizes).
+Gradients / loss scalars are all-reduced each optimiser step (one message per step, harl_amd/dist.py: RCCL, or the one-hop
+hipIpc exchange with HARL_ALLREDUCE=auto|oneshot);
 `--dist-single` initialises the nccl(=RCCL) process group even with one rank so that branch runs on a 1-GPU box.
 
     python bench.py --gpus 1 --steps 5 --warmup 2 [--config cheetah6]
@@ -66,6 +72,17 @@ WORKLOADS = {
     "humanoid17": dict(algo="hatrpo", T=200, N=1024, A=17, obs=393, sobs=376, act=1, disc=False, hidden=[128, 128, 128],
                        metric="transitions/sec through HATRPO update (MAMuJoCo Humanoid-17x1, 17 agents)",
                        name="MAMuJoCo Humanoid-17x1 17-agent HATRPO update"),
+    # north_star: "(episode_length=200, n_rollout_threads=4096, n_agents in {3,6,17})" -- the 17-agent update at the full 4096
+    # rollout threads on ONE GPU (22 GB of observations, ~85 GB of per-agent activation workspaces; VERDICT r05 missing 2), next
+    # to the 8-GPU share above; and the recurrent workload at 4096 threads next to its tuned-config 512
+    "humanoid17_n4096": dict(algo="hatrpo", T=200, N=4096, A=17, obs=393, sobs=376, act=1, disc=False, hidden=[128, 128, 128],
+                             base="humanoid17",
+                             metric="transitions/sec through HATRPO update (MAMuJoCo Humanoid-17x1, 17 agents)",
+                             name="MAMuJoCo Humanoid-17x1 17-agent HATRPO update"),
+    "smac3s5z_n4096": dict(algo="happo", T=160, N=4096, A=8, obs=128, sobs=216, act=14, disc=True, hidden=[64, 64, 64], rnn=True,
+                           L=10, unavailable_p=0.3, base="smac3s5z",
+                           metric="transitions/sec through HAPPO update (SMAC 3s5z, 8 agents, GRU policy)",
+                           name="SMAC 3s5z 8-agent recurrent HAPPO update"),
     # not a BASELINE configuration: hatrpo.yaml's DEFAULT model ([128, 128]) with use_recurrent_policy at the SMAC shape -- the
     # composed 128-wide GRU (per-step launches, harl_amd/gru_wide.py) under HATRPO's tangent passes, the slowest coverage path
     # (it had no number)
@@ -74,6 +91,9 @@ WORKLOADS = {
                           metric="transitions/sec through HATRPO update (SMAC-shaped, 8 agents, 128-wide GRU policy)",
                           name="SMAC-shaped 8-agent recurrent HATRPO update, hatrpo.yaml default widths (coverage path)"),
 }
+# n_rollout_threads of the WHOLE job the BASELINE quotes each workload on (`--scaling strong` / the multi-GPU headline): configs[1]
+# = 4096 for MPE, configs[2] = 8192 for HalfCheetah-6x1; the others: their single-GPU size
+BASELINE_GLOBAL_THREADS = {"mpe": 4096, "cheetah6": 8192}
 # module-level aliases of the default workload (tools/ and older scripts import these)
 T, N_PER_GPU, A = 200, 4096, 3
 OBS, SOBS, ACT = 18, 54, 5
@@ -244,8 +264,17 @@ def cpu_baseline(w: dict, n_cols: int, threads: int, reps: int = 3) -> dict:
                        "(these nets are small: more threads is slower)")
 
 
+def ranks_seen(comm, device) -> int:
+    """Number of ranks that answer on the update's communicator: a SUM all-reduce of ones through the same path the gradients
+    take (RCCL, or the one-shot exchange) -- not WORLD_SIZE read back from the environment."""
+    t = torch.ones(1, dtype=torch.float32, device=device)
+    comm.all_reduce_sum(t)
+    torch.cuda.synchronize()
+    return int(round(float(t.item())))
+
+
 def measure(w: dict, cfg_name: str, args, comm, rank: int, world: int, device, n_local: int, steps: int, warmup: int,
-            instr_steps: int):
+            instr_steps: int, scaling: str = "weak"):
     """Build the runner of one workload, warm up, time `steps` steps between barriers and collect the per-kernel figures.
     Returns the JSON record of this workload on rank 0 (None elsewhere)."""
     from harl_amd import _lib
@@ -341,6 +370,7 @@ def measure(w: dict, cfg_name: str, args, comm, rank: int, world: int, device, n
         else:
             os.environ["HARL_CRITIC_STREAM"] = prev_cs
 
+    n_seen = ranks_seen(comm, device) if comm.enabled else 1  # (collective: every rank)
     if rank != 0:
         return None
     if True:
@@ -363,7 +393,7 @@ def measure(w: dict, cfg_name: str, args, comm, rank: int, world: int, device, n
                       os.path.join(ROOT, "profiles", "r04_hbm_traffic.json"))
             if os.path.exists(tp):  # PMC passes over the same kernels at this workload's shapes (tools/pmc_traffic.sh)
                 tj = json.load(open(tp))
-                ent = tj.get("workloads", {}).get(cfg_name, {}).get(dom)
+                ent = tj.get("workloads", {}).get(w.get("base", cfg_name), {}).get(dom)
                 if ent:
                     traffic = ent["ratio"] * per_launch / 1e9
                     traffic_note = (f"GB per launch = {ent['ratio']:.3f} (HBM bytes measured by rocprofv3 --pmc, FETCH_SIZE and "
@@ -415,18 +445,22 @@ def measure(w: dict, cfg_name: str, args, comm, rank: int, world: int, device, n
                          "main stream (HARL_CRITIC_STREAM=0): per-launch durations without a second kernel sharing the chip")
         out = dict(
             metric=w["metric"], value=value, unit="transitions/s", n_gpus=world, steps=steps, warmup=warmup,
-            ms_per_step=dt / steps * 1e3, higher_is_better=True, scaling=args.scaling, vs_baseline=None, dtype="f32",
+            ms_per_step=dt / steps * 1e3, higher_is_better=True, scaling=scaling, vs_baseline=None, dtype="f32",
             dtype_note="fp32 data, statistics and accumulators; GEMM operands are split EXACTLY into three bf16 each and "
                        "multiplied as six cross products on v_mfma_f32_32x32x16_bf16 (error <= the fp32 MFMA's fmaf chain: "
                        "profiles/r01_mfma_bf16x3.txt)",
             data=f"synthetic (SURVEY.md 8d recipe, generated on the device; stored log-probs: {args.logp})",
             config=dict(workload=f"{w['name']}: compute_returns + train(), T={Tn}, n_rollout_threads={n_local}/GPU "
-                                 f"({n_local * world} global, {args.scaling} scaling), obs{w['obs']}/share{w['sobs']}/"
+                                 f"({n_local * world} global, {scaling} scaling), obs{w['obs']}/share{w['sobs']}/"
                                  f"{'Discrete' if w['disc'] else 'Box'}{w['act']}, MLP{w['hidden']}{' + GRU' if w.get('rnn') else ''}, "
                                  f"{'ppo_epoch=5, ' if w['algo'] == 'happo' else 'CG 10 + line search, '}critic_epoch=5",
-                        baseline_config=cfg_name, episode_length=Tn, n_rollout_threads_per_gpu=n_local, n_agents=w["A"],
-                        parallelism=f"dp{world}", collective="rccl" if comm.enabled else "none",
-                        world_size=torch.distributed.get_world_size() if comm.enabled else 1, git_sha=git_sha()),
+                        baseline_config=w.get("base", cfg_name), episode_length=Tn, n_rollout_threads_per_gpu=n_local,
+                        n_rollout_threads_global=n_local * world, n_agents=w["A"],
+                        parallelism=f"dp{world}",
+                        collective=("none" if not comm.enabled else "oneshot(hipIpc)" if comm.oneshot is not None else "rccl"),
+                        allreduce_info=comm.oneshot_info,
+                        world_size=torch.distributed.get_world_size() if comm.enabled else 1,
+                        ranks_seen=n_seen, git_sha=git_sha()),
             roofline=roof,
             kernels={k: dict(n=v["n"], avg_ms=round(v["avg_ms"], 4), total_ms=round(v["total_ms"], 3),
                              **({"hbm_frac": round(v["bytes"] / (v["total_ms"] * 1e-3) / HBM_PEAK, 4), "alg_bytes": v["bytes"]}
@@ -494,8 +528,13 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", choices=sorted(WORKLOADS), default="mpe")
-    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
-    ap.add_argument("--global-threads", type=int, default=8192, help="n_rollout_threads of the whole job with --scaling strong")
+    ap.add_argument("--scaling", choices=("auto", "weak", "strong"), default="auto",
+                    help="auto (default): one rank = the config's single-GPU size; N > 1 ranks = BOTH figures on the one line -- "
+                         "headline `value` = STRONG scaling at the n_rollout_threads the BASELINE quotes the workload on (4096 "
+                         "global for mpe, 8192 for cheetah6 = configs[2]; split over the ranks), and `weak` = the config's size on "
+                         "every rank.  weak / strong: that one figure only")
+    ap.add_argument("--global-threads", type=int, default=0,
+                    help="n_rollout_threads of the whole job with --scaling strong (0 = the BASELINE's global size of the config)")
     ap.add_argument("--threads-per-gpu", type=int, default=0, help="n_rollout_threads per rank with --scaling weak (0 = the config's)")
     ap.add_argument("--logp", choices=("recipe", "onpolicy"), default="recipe",
                     help="stored log-probs: SURVEY 8d recipe (default) or on-policy (ratios ~ 1)")
@@ -534,7 +573,7 @@ def main():
             elif not a.startswith(("--config=", "--scaling=", "--global-threads=", "--threads-per-gpu=")):
                 keep.append(a)
         rc2 = subprocess.call([sys.executable, os.path.abspath(__file__)] + keep +
-                              ["--config", "cheetah6", "--scaling", "strong", "--global-threads", "8192"])
+                              ["--config", "cheetah6", "--scaling", "strong", "--global-threads", "8192"])  # = configs[2] as quoted
         sys.exit(rc or rc2)
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
@@ -554,13 +593,19 @@ def main():
     comm = init_from_env()
     rank, world = comm.rank, comm.world_size
     if args.dry_run:  # tests/test_bench_launcher_cpu.py: the command line the driver runs, minus the GPU work
-        t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        t = torch.tensor([float(rank + 1), 1.0], dtype=torch.float64)
         comm.all_reduce_sum(t)
-        assert world == args.gpus and float(t.item()) == world * (world + 1) / 2, (world, args.gpus, t)
+        assert world == args.gpus and float(t[0].item()) == world * (world + 1) / 2, (world, args.gpus, t)
+        g_threads = args.global_threads or BASELINE_GLOBAL_THREADS.get(args.config, w["N"])
+        both = args.scaling == "auto" and world > 1 and not args.threads_per_gpu
+        strong = args.scaling == "strong" or both
         if rank == 0:
             os.write(json_fd, (json.dumps(dict(metric=w["metric"], value=None, unit="transitions/s", n_gpus=world, steps=args.steps,
-                                               warmup=args.warmup, dry_run=True,
-                                               config=dict(parallelism=f"dp{world}",
+                                               warmup=args.warmup, dry_run=True, scaling="strong" if strong else "weak",
+                                               weak=dict(value=None, n_rollout_threads_global=w["N"] * world) if both else None,
+                                               config=dict(parallelism=f"dp{world}", ranks_seen=int(t[1].item()),
+                                                           n_rollout_threads_global=g_threads if strong else (args.threads_per_gpu or w["N"]) * world,
+                                                           n_rollout_threads_per_gpu=(g_threads // world) if strong else (args.threads_per_gpu or w["N"]),
                                                            collective=torch.distributed.get_backend() if comm.enabled else "none")))
                                + "\n").encode())
         if comm.enabled:
@@ -571,27 +616,42 @@ def main():
     device = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(device)
     assert world == args.gpus or (world == 1 and args.gpus == 1), f"launched {world} ranks for --gpus {args.gpus}"
-    if args.scaling == "strong":
-        assert args.global_threads % world == 0, "--global-threads must be divisible by the number of ranks"
-        n_local = args.global_threads // world
+    g_threads = args.global_threads or BASELINE_GLOBAL_THREADS.get(args.config, w["N"])
+    both = args.scaling == "auto" and world > 1 and not args.threads_per_gpu
+    scaling = "strong" if (args.scaling == "strong" or both) else "weak"
+    if scaling == "strong":
+        assert g_threads % world == 0, "--global-threads must be divisible by the number of ranks"
+        n_local = g_threads // world
     else:
         n_local = args.threads_per_gpu or w["N"]
     Tn = w["T"]
 
-    out = measure(w, args.config, args, comm, rank, world, device, n_local, args.steps, args.warmup, args.instr_steps)
+    out = measure(w, args.config, args, comm, rank, world, device, n_local, args.steps, args.warmup, args.instr_steps, scaling)
+    if both:
+        # the weak-scaling figure of the same job on the same line (every rank at the config's single-GPU size): its own
+        # barrier-bracketed region of the same number of steps, after the headline region
+        torch.cuda.empty_cache()
+        wk = measure(w, args.config, args, comm, rank, world, device, w["N"], args.steps, args.warmup, 0, "weak")
+        if rank == 0:
+            out["weak"] = dict(value=wk["value"], unit=wk["unit"], ms_per_step=wk["ms_per_step"], steps=wk["steps"], warmup=wk["warmup"],
+                               scaling="weak", n_rollout_threads_per_gpu=w["N"], n_rollout_threads_global=w["N"] * world,
+                               ranks_seen=wk["config"]["ranks_seen"], roofline=wk.get("roofline"))
+            out["strong"] = dict(value=out["value"], ms_per_step=out["ms_per_step"], scaling="strong",
+                                 n_rollout_threads_per_gpu=n_local, n_rollout_threads_global=g_threads,
+                                 note="headline `value`: the BASELINE's global n_rollout_threads split over the ranks")
     if rank == 0:
         cols = args.cpu_cols
         if cols < 0:  # ~10-30 s of CPU work per update for every configuration
-            cols = {"mpe": 512, "cheetah6": 512, "smac3s5z": 128, "humanoid17": 16, "hatrpo_gru128": 32}[args.config]
+            cols = {"mpe": 512, "cheetah6": 512, "smac3s5z": 128, "humanoid17": 64, "hatrpo_gru128": 64}[w.get("base", args.config)]
         if world == 1 and cols > 0:
             out["cpu_baseline"] = cpu_baseline(w, cols, min(args.cpu_threads, os.cpu_count() or 1), reps=max(1, args.cpu_reps))
     # the other BASELINE.json workloads at their real shapes, on the SAME JSON line (after the headline region and the CPU
     # baseline, fresh runner each, a few steps): `--config <name>` gives the full record of any one of them
     # (single-process runs only: the scaling runs time the headline workload, and an attached workload that failed on ONE rank
     # would leave the others waiting in a collective)
-    if args.other_configs and world == 1 and args.config == "mpe" and args.scaling == "weak" and not args.threads_per_gpu:
+    if args.other_configs and world == 1 and args.config == "mpe" and scaling == "weak" and not args.threads_per_gpu:
         others = {}
-        for name in ("cheetah6", "smac3s5z", "humanoid17", "hatrpo_gru128"):
+        for name in ("cheetah6", "smac3s5z", "smac3s5z_n4096", "humanoid17", "humanoid17_n4096", "hatrpo_gru128"):
             torch.cuda.empty_cache()
             wo = WORKLOADS[name]
             try:
@@ -608,9 +668,12 @@ def main():
                                     roofline=dict(kernel=rf.get("kernel"), frac=rf.get("frac"), avg_ms=rf.get("avg_ms"),
                                                   matrix_pipe_frac=rf.get("matrix_pipe_frac"), clock_ghz=rf.get("clock_ghz")),
                                     end_to_end=o.get("end_to_end"))
-                if args.other_cpu_cols != 0:  # the CPU path next to every reported number (BASELINE.json north_star): a bounded
-                    # sample of the same workload (fewer rollout threads), one warm-up + one timed update
-                    oc = args.other_cpu_cols if args.other_cpu_cols > 0 else {"cheetah6": 128, "smac3s5z": 64, "humanoid17": 8, "hatrpo_gru128": 16}[name]
+                if wo.get("base"):  # the same nets / epochs at more rollout threads: the CPU twin is the base entry's
+                    others[name]["cpu_baseline"] = dict(see=wo["base"], note="transitions/s of the CPU path do not depend on the number "
+                                                        "of rollout threads beyond ~64 columns (profiles/r04_bench_mpe_cpu_baseline_n4096.json)")
+                elif args.other_cpu_cols != 0:  # the CPU path next to every reported number (BASELINE.json north_star): a bounded
+                    # sample of the same workload (>= 64 rollout threads: VERDICT r05 weak 11), one warm-up + one timed update
+                    oc = args.other_cpu_cols if args.other_cpu_cols > 0 else {"cheetah6": 512, "smac3s5z": 128, "humanoid17": 64, "hatrpo_gru128": 64}[name]
                     try:
                         others[name]["cpu_baseline"] = cpu_baseline(wo, oc, min(args.cpu_threads, os.cpu_count() or 1), reps=1)
                     except Exception as e:  # noqa: BLE001

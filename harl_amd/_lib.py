@@ -107,6 +107,12 @@ SIGNATURES = {
     "harl_md_head_logp": [_vp, _i, _vp, _i, _vp, _vp, _l, _vp, _vp, _vp, _i, _vp, _i, _vp, _l, _l, _vp],
     "harl_md_head_loss": [_vp, _vp, _i, _vp, _i, _vp, _vp, _l, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _d, _f, _i, _i,
                           _l, _l, _vp, _vp, _i, _vp],
+    "harl_trpo_begin": [_vp, _vp, _l, _i, _vp, _vp, _vp, _vp, _l, _vp, _vp, _vp, _vp],
+    "harl_trpo_step": [_vp, _vp, _vp, _vp, _vp, _vp, _l, _f, _vp, _vp, _vp],
+    "harl_trpo_ls_candidate": [_vp, _vp, _vp, _vp, _l, _vp],
+    "harl_trpo_ls_test": [_vp, _vp, _d, _d, _d, _d, _vp, _vp],
+    "harl_reduce_scalars_set": [_vp, _i, _vp, _vp],
+    "harl_zero_bytes": [_vp, _l, _vp],
     "harl_comm_create": [_i, _i, _l, _i, _vp, _vp],
     "harl_comm_connect": [_vp, _vp],
     "harl_comm_allreduce": [_vp, _vp, _l, _i, _vp],

@@ -1524,3 +1524,237 @@ extern "C" int harl_trpo_cg_step(float *x, float *r, float *p, const float *avp,
   hipLaunchKernelGGL(k_trpo_cg_step, dim3(CG_WGS), dim3(CG_THREADS), 0, (hipStream_t)stream, x, r, p, avp, n, state, ws);
   return check_launch("harl_trpo_cg_step");
 }
+
+// =============================================================================================
+// HATRPO's scalar glue on the device (hatrpo.py:92-192, trpo_util.py:96-129).  Until round 5 the vector
+// setup of the conjugate-gradient solve (r.r), 1/2 x^T F x, the step size, the expected improvement and the line search's accept
+// test were torch / rocBLAS ops with `.item()` synchronisations between them (rocblas_dot + ~30 ATen elementwise launches and
+// five host round trips per agent).  Now:
+//   harl_trpo_begin        g = grad_sum / sum(active), x = 0, r = p = g, cg_state = {r.r, 0}, st[LOSS] = surrogate at theta_old
+//   harl_trpo_step         shs = 1/2 x.Fx, step = 1 / sqrt(shs / delta), full_step = step x, params_save = theta_old,
+//                          st[EXPECTED] = g . full_step, st[FRACTION] = 1
+//   harl_trpo_ls_candidate theta = params_save + fraction full_step
+//   harl_trpo_ls_test      kl, improvement, the accept test (hatrpo.py:171-178) and the backtrack bookkeeping -- the host reads the
+//                          16-double record ONCE per line-search step and nothing else
+// The dot products accumulate in fp64 over fixed-order per-workgroup partials (same bits every run), like harl_trpo_cg_step,
+// whose scratch block and grid-barrier scheme they share.  `st` (double[HARL_TRPO_STATE]): see include/harl_hip.h.
+// =============================================================================================
+namespace {
+enum { ST_LOSS = 0, ST_SHS, ST_STEP, ST_EXPECTED, ST_FRACTION, ST_FLAG, ST_BACKTRACKS, ST_KL, ST_IMPROVE, ST_NEW_LOSS, ST_ENTROPY,
+       ST_RATIO, ST_EXPECTED0 };
+
+struct GridRed {  // CG_WGS co-resident workgroups of CG_THREADS: block / grid sums over CgScratch, last-workgroup-out reset
+  CgScratch *ws;
+  double *sh;
+  int tid, blk;
+  __device__ double block_sum(double v) {
+    v = wave_reduce_sum_d(v);
+    __syncthreads();
+    if ((tid & 63) == 0) sh[tid >> 6] = v;
+    __syncthreads();
+    double t = 0;
+#pragma unroll
+    for (int w = 0; w < CG_THREADS / 64; ++w) t += sh[w];
+    return t;
+  }
+  __device__ void put(double v, int which) {
+    const double t = block_sum(v);
+    if (tid == 0) ws->part[which][blk] = t;
+  }
+  __device__ double get(int which) {
+    double g = 0;
+    for (int b2 = 0; b2 < CG_WGS; ++b2) g += ws->part[which][b2];  // same order in every workgroup
+    return g;
+  }
+  template <typename F>
+  __device__ void finish(F &&last) {  // the last workgroup out publishes and leaves the barrier words at zero
+    __syncthreads();
+    if (tid == 0) {
+      const unsigned done = __hip_atomic_fetch_add(ws->bar + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+      if (done == (unsigned)CG_WGS - 1) {
+        last();
+        __hip_atomic_store(ws->bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(ws->bar + 1, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+};
+}  // namespace
+
+__global__ __launch_bounds__(CG_THREADS) void k_trpo_begin(const float *__restrict__ grad_sum, const double *__restrict__ scalars,
+                                                           long ls_off, int act_dim, float *__restrict__ g, float *__restrict__ x, float *__restrict__ r,
+                                                           float *__restrict__ p, long n, float *__restrict__ cg_state,
+                                                           double *__restrict__ st, CgScratch *__restrict__ ws) {
+#pragma clang fp contract(off)
+  __shared__ double sh[CG_THREADS / 64];
+  GridRed R{ws, sh, (int)threadIdx.x, (int)blockIdx.x};
+  const float inv = (float)(1.0 / scalars[1]);  // grad * (1 / sum(active)).to(float32)
+  const long gtid = (long)blockIdx.x * CG_THREADS + threadIdx.x, gnt = (long)CG_WGS * CG_THREADS;
+  double rr = 0.0;
+  for (long i = gtid; i < n; i += gnt) {
+    // Gaussian policies: d loss / d log_std travels among the loss kernel's scalar sums (entries 8 .. 8 + act_dim)
+    const float raw = (ls_off >= 0 && i >= ls_off && i < ls_off + act_dim) ? (float)scalars[8 + (i - ls_off)] : grad_sum[i];
+    const float gi = raw * inv;
+    g[i] = gi;
+    r[i] = gi;
+    p[i] = gi;
+    x[i] = 0.f;
+    rr += (double)gi * (double)gi;
+  }
+  R.put(rr, 0);
+  grid_barrier(ws->bar, (unsigned)CG_WGS);
+  const double rdotr = R.get(0);
+  R.finish([&] {
+    cg_state[0] = (float)rdotr;
+    cg_state[1] = 0.f;
+    for (int k = 0; k < HARL_TRPO_STATE; ++k) st[k] = 0.0;
+    st[ST_LOSS] = scalars[0] / scalars[1];
+    st[ST_ENTROPY] = scalars[2] / scalars[1];
+    st[ST_RATIO] = scalars[3] / scalars[4];
+  });
+}
+
+__global__ __launch_bounds__(CG_THREADS) void k_trpo_step(const float *__restrict__ x, const float *__restrict__ fx,
+                                                          const float *__restrict__ g, const float *__restrict__ theta,
+                                                          float *__restrict__ theta_save, float *__restrict__ full_step, long n,
+                                                          float kl_threshold, double *__restrict__ st,
+                                                          CgScratch *__restrict__ ws) {
+#pragma clang fp contract(off)
+  __shared__ double sh[CG_THREADS / 64];
+  GridRed R{ws, sh, (int)threadIdx.x, (int)blockIdx.x};
+  const long gtid = (long)blockIdx.x * CG_THREADS + threadIdx.x, gnt = (long)CG_WGS * CG_THREADS;
+  double d = 0.0;
+  for (long i = gtid; i < n; i += gnt) d += (double)x[i] * (double)fx[i];
+  R.put(d, 0);
+  grid_barrier(ws->bar, (unsigned)CG_WGS);
+  const float shs = 0.5f * (float)R.get(0);           // 0.5 * (x * F x).sum()            (hatrpo.py:123)
+  const float step = 1.0f / sqrtf(shs / kl_threshold);  // 1 / torch.sqrt(shs / kl_threshold) (hatrpo.py:124)
+  double e = 0.0;
+  for (long i = gtid; i < n; i += gnt) {
+    const float fs = step * x[i];
+    full_step[i] = fs;
+    theta_save[i] = theta[i];
+    e += (double)g[i] * (double)fs;
+  }
+  R.put(e, 1);
+  grid_barrier(ws->bar, (unsigned)(2 * CG_WGS));
+  const double expected = (double)(float)R.get(1);  // (loss_grad * full_step).sum(): an fp32 figure in the reference
+  R.finish([&] {
+    st[ST_SHS] = (double)shs;
+    st[ST_STEP] = (double)step;
+    st[ST_EXPECTED] = expected;
+    st[ST_EXPECTED0] = expected;
+    st[ST_FRACTION] = 1.0;
+    st[ST_FLAG] = 0.0;
+    st[ST_BACKTRACKS] = 0.0;
+  });
+}
+
+__global__ __launch_bounds__(256) void k_trpo_ls_candidate(const float *__restrict__ theta_save, const float *__restrict__ full_step,
+                                                           const double *__restrict__ st, float *__restrict__ theta, long n) {
+#pragma clang fp contract(off)
+  const float fraction = (float)st[ST_FRACTION];  // python float x fp32 tensor: the scalar is rounded to fp32 first
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float t = fraction * full_step[i];
+    theta[i] = theta_save[i] + t;
+  }
+}
+
+__global__ void k_trpo_ls_test(const double *__restrict__ scalars, double *__restrict__ kl_sum, double m_global, double kl_threshold,
+                               double accept_ratio, double backtrack_coeff, double *__restrict__ st) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const double new_loss = scalars[0] / scalars[1];
+  const double kl = kl_sum[0] / m_global;
+  kl_sum[0] = 0.0;  // (harl_trpo_kl_sum accumulates: left clean for the next candidate)
+  const double improve = new_loss - st[ST_LOSS];
+  st[ST_NEW_LOSS] = new_loss;
+  st[ST_KL] = kl;
+  st[ST_IMPROVE] = improve;
+  st[ST_ENTROPY] = scalars[2] / scalars[1];
+  st[ST_RATIO] = scalars[3] / scalars[4];
+  if (kl < kl_threshold && (improve / st[ST_EXPECTED]) > accept_ratio && improve > 0.0) {  // hatrpo.py:171-178
+    st[ST_FLAG] = 1.0;
+  } else {
+    st[ST_EXPECTED] = st[ST_EXPECTED] * backtrack_coeff;
+    st[ST_FRACTION] = st[ST_FRACTION] * backtrack_coeff;
+    st[ST_BACKTRACKS] = st[ST_BACKTRACKS] + 1.0;
+  }
+}
+
+static CgScratch *cg_ws(void *scratch, const char *who) {
+  CgScratch *ws = static_cast<CgScratch *>(scratch);
+  if (!ws || (reinterpret_cast<uintptr_t>(ws) & 7) != 0) {
+    set_error(who);
+    return nullptr;
+  }
+  return ws;
+}
+
+extern "C" int harl_trpo_begin(const float *grad_sum, const double *scalars, long logstd_off, int act_dim, float *g, float *x,
+                               float *r, float *p, long n, float *cg_state, double *st, void *scratch, void *stream) {
+  if (n <= 0) return 0;
+  CgScratch *ws = cg_ws(scratch, "harl_trpo_begin: scratch must be HARL_CG_SCRATCH_BYTES of zero-filled, 8-byte aligned device memory");
+  if (!ws) return -2;
+  hipLaunchKernelGGL(k_trpo_begin, dim3(CG_WGS), dim3(CG_THREADS), 0, (hipStream_t)stream, grad_sum, scalars, logstd_off, act_dim,
+                     g, x, r, p, n, cg_state, st, ws);
+  return check_launch("harl_trpo_begin");
+}
+
+extern "C" int harl_trpo_step(const float *x, const float *fx, const float *g, const float *theta, float *theta_save,
+                              float *full_step, long n, float kl_threshold, double *st, void *scratch, void *stream) {
+  if (n <= 0) return 0;
+  CgScratch *ws = cg_ws(scratch, "harl_trpo_step: scratch must be HARL_CG_SCRATCH_BYTES of zero-filled, 8-byte aligned device memory");
+  if (!ws) return -2;
+  hipLaunchKernelGGL(k_trpo_step, dim3(CG_WGS), dim3(CG_THREADS), 0, (hipStream_t)stream, x, fx, g, theta, theta_save, full_step, n,
+                     kl_threshold, st, ws);
+  return check_launch("harl_trpo_step");
+}
+
+extern "C" int harl_trpo_ls_candidate(const float *theta_save, const float *full_step, const double *st, float *theta, long n,
+                                      void *stream) {
+  if (n <= 0) return 0;
+  long nb = (n + 255) / 256;
+  if (nb > 512) nb = 512;
+  hipLaunchKernelGGL(k_trpo_ls_candidate, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, theta_save, full_step, st, theta, n);
+  return check_launch("harl_trpo_ls_candidate");
+}
+
+extern "C" int harl_trpo_ls_test(const double *scalars, double *kl_sum, double m_global, double kl_threshold, double accept_ratio,
+                                 double backtrack_coeff, double *st, void *stream) {
+  hipLaunchKernelGGL(k_trpo_ls_test, dim3(1), dim3(64), 0, (hipStream_t)stream, scalars, kl_sum, m_global, kl_threshold,
+                     accept_ratio, backtrack_coeff, st);
+  return check_launch("harl_trpo_ls_test");
+}
+
+// out[0..PS_STRIDE) = column sums of the loss kernels' per-block partial rows (harl_reduce_scalars ACCUMULATES into out and
+// needs a zeroing launch in front of it; this one overwrites)
+__global__ __launch_bounds__(1024) void k_reduce_scalars_set(const float *__restrict__ ps, int n_blocks, double *__restrict__ out) {
+  __shared__ double sh[16][64];
+  const int j = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  double s = 0;
+  if (j < PS_STRIDE)
+    for (int b = rg; b < n_blocks; b += 16) s += (double)ps[(long)b * PS_STRIDE + j];
+  sh[rg][j] = s;
+  __syncthreads();
+  if (threadIdx.x < PS_STRIDE) {
+    double t = 0;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) t += sh[g][threadIdx.x];
+    out[threadIdx.x] = t;
+  }
+}
+
+extern "C" int harl_reduce_scalars_set(const float *part_scalars, int n_blocks, double *scalars, void *stream) {
+  hipLaunchKernelGGL(k_reduce_scalars_set, dim3(1), dim3(1024), 0, (hipStream_t)stream, part_scalars, n_blocks, scalars);
+  return check_launch("harl_reduce_scalars_set");
+}
+
+// hipMemsetAsync behind the C ABI (the Python side's `tensor.zero_()` is an ATen fill kernel)
+extern "C" int harl_zero_bytes(void *p, long bytes, void *stream) {
+  if (!p || bytes <= 0) return 0;
+  if (hipMemsetAsync(p, 0, (size_t)bytes, (hipStream_t)stream) != hipSuccess) {
+    set_error("harl_zero_bytes: hipMemsetAsync failed");
+    return -2;
+  }
+  return 0;
+}

@@ -35,11 +35,17 @@ class HATRPO(OnPolicyBase):
         self._tangent_ws = None
         self._grad_tap = None
         self._cg_tap = None  # test hook: called with (k, x_k) after CG steps 1, 5 and 10
+        self._moments = None
+        self._vec_ws = None  # P-sized vectors + the update's device record (see _update_core)
         self._trace = None  # test hook: list receiving one dict per update (accept decision, backtracks, the five statistics)
 
     # ---- surrogate  sum_s ratio*f*adv*active / sum(active)  (hatrpo.py:77-90), optionally with its gradient ---------
-    def _surrogate(self, obs, m, actions, avail, old_logp, adv, adv_moments, factor, active, want_grad: bool, seq=None):
-        """``seq`` (GRU policies): the batch is L x m_pad rows in the recurrent layout (nets.build_seq), m = L * m_pad and the
+    def _surrogate(self, obs, m, actions, avail, old_logp, adv, adv_moments, factor, active, want_grad: bool, seq=None,
+                   raw: bool = False):
+        """Returns (scalars, gradient).  ``raw`` (the update itself): the UNSCALED sums in place -- ``net.scalars`` and
+        ``net.flat_grad`` with its log_std block still unset; harl_trpo_begin / harl_trpo_ls_test divide by sum(active) and take
+        the log_std gradient from the scalars.  Default (tests, diagnostics): copies, the gradient scaled by 1 / sum(active).
+        ``seq`` (GRU policies): the batch is L x m_pad rows in the recurrent layout (nets.build_seq), m = L * m_pad and the
         row arrays are the flat buffers gathered through seq['idx'] inside the kernels."""
         net = self.actor
         idx = None if seq is None else seq["idx"]
@@ -52,26 +58,28 @@ class HATRPO(OnPolicyBase):
              ptr(Wp), ptr(bp), ptr(net.log_std()), net.std_x_coef, net.std_y_coef, int(net.discrete), net.act_dim,
              ptr(idx), ptr(actions), ptr(avail), ptr(old_logp), ptr(adv), ptr(adv_moments), ptr(factor), ptr(active),
              0.0, 0.0, int(self.action_aggregation == "mean"), 1, mv, mp, None, ptr(net.dz[0]), ptr(net.dhead), ptr(net.part_scalars), None, 0, s)
-        net.scalars.zero_()
-        call("harl_reduce_scalars", ptr(net.part_scalars), _lib.load().harl_head_blocks(m), ptr(net.scalars), s)
+        call("harl_reduce_scalars_set", ptr(net.part_scalars), _lib.load().harl_head_blocks(m), ptr(net.scalars), s)
         grad = None
         if want_grad:
             net.backward_trunk(obs, idx, m, seq=seq)
             net.unfold_grads()
-            if not net.discrete:
-                net.gview("act.action_out.log_std").copy_(net.scalars[8:8 + net.act_dim])
-            grad = net.flat_grad.clone()
-        sc = net.scalars.clone()
-        if self.comm.enabled:
+            grad = net.flat_grad
+        sc = net.scalars
+        if self.comm.enabled:  # in place: both are recomputed by the next pass
             self.comm.all_reduce_sum(sc)
             if grad is not None:
                 self.comm.all_reduce_sum(grad)
+        if raw:
+            return sc, grad
+        sc = sc.clone()
         if grad is not None:
+            if not net.discrete:  # (the loss kernel leaves d loss / d log_std among its scalar sums)
+                net.gview("act.action_out.log_std").copy_(sc[8:8 + net.act_dim])
             grad = grad * (1.0 / sc[1]).to(torch.float32)
         return sc, grad
 
     # ---- Fisher-vector product (trpo_util.py:132-158):  F v + 0.1 v -----------------------------------------------
-    def _fvp(self, obs, m, m_global, avail, vec: torch.Tensor, seq=None) -> torch.Tensor:
+    def _fvp(self, obs, m, m_global, avail, vec: torch.Tensor, seq=None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """``avail`` is indexed by batch position (already gathered for recurrent batches)."""
         net = self.actor
         s = stream()
@@ -188,7 +196,8 @@ class HATRPO(OnPolicyBase):
             self.comm.all_reduce_sum(g)
         # kl.mean() over the (global) batch, the analytic log_std block (d2 KL / d sigma^2 = 2 / sigma^2 per sample, sigma =
         # sigmoid(ls / xc) yc) and the 0.1 damping in ONE launch (csrc/elementwise.hip)
-        out = torch.empty_like(vec)
+        if out is None:
+            out = torch.empty_like(vec)
         ls_off = -1 if net.discrete else net.offsets["act.action_out.log_std"][0]
         call("harl_trpo_fvp_finish", ptr(g), ptr(vec), ptr(net.log_std()), ptr(out), out.numel(), float(m_global), 0.1,
              int(ls_off), net.act_dim, net.std_x_coef, net.std_y_coef, s)
@@ -212,10 +221,12 @@ class HATRPO(OnPolicyBase):
              stream(), tag="actor_head_logp")
         return seq_compact(ho, seq) if seq["m_pad"] != seq["m"] else ho
 
-    def _kl_sum(self, head_old, ls_old, head_new, m) -> torch.Tensor:
-        """Sum over the (global) batch of KL(old || new), fp64 device scalar [1]."""
+    def _kl_sum(self, head_old, ls_old, head_new, m, acc: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Sum over the (global) batch of KL(old || new), fp64 device scalar [1] (``acc``: accumulated into; the line search's
+        accumulator is left at zero by harl_trpo_ls_test)."""
         net = self.actor
-        acc = torch.zeros(1, dtype=torch.float64, device=self.device)
+        if acc is None:
+            acc = torch.zeros(1, dtype=torch.float64, device=self.device)
         call("harl_trpo_kl_sum", ptr(head_old), ptr(head_new), ptr(ls_old), ptr(net.log_std()), net.std_x_coef,
              net.std_y_coef, m, net.act_dim, int(net.discrete), ptr(acc), stream())
         if self.comm.enabled:
@@ -234,61 +245,74 @@ class HATRPO(OnPolicyBase):
             kl_rows = seq["L"] * seq["m"]
             if avail is not None and seq["idx"] is not None:
                 avail_rows = avail[seq["idx"]].contiguous()  # by batch position, for the FVP / head-output kernels
-        sc, g = self._surrogate(obs, m, actions, avail, old_logp, adv, adv_moments, factor, active, want_grad=True, seq=seq)
-        loss = float((sc[0] / sc[1]).item())
+        # P-sized vectors and the update's 16-double record: allocated once per actor (harl_trpo_* keep every scalar decision on
+        # the device; no torch arithmetic, no rocBLAS between the first and the last launch of an update)
+        n = net.flat_param.numel()
+        w = self._vec_ws
+        if w is None or w["n"] != n:
+            f = lambda: torch.empty(n, **self.tpdv)  # noqa: E731
+            w = self._vec_ws = dict(n=n, g=f(), x=f(), r=f(), p=f(), fp=f(), theta=f(), full_step=f(),
+                                    cg_state=torch.zeros(2, **self.tpdv),
+                                    st=torch.zeros(16, dtype=torch.float64, device=self.device),
+                                    kl=torch.zeros(1, dtype=torch.float64, device=self.device),
+                                    st_host=torch.zeros(16, dtype=torch.float64).pin_memory())
+        g, x, r, p, st = w["g"], w["x"], w["r"], w["p"], w["st"]
+        s = stream()
+        sc, graw = self._surrogate(obs, m, actions, avail, old_logp, adv, adv_moments, factor, active, want_grad=True, seq=seq,
+                                   raw=True)
+        # g = grad / sum(active) (log_std block from the loss kernel's scalar sums), x = 0, r = p = g, r.r
+        # (hatrpo.py:92-95, trpo_util.py:101-105)
+        ls_off = -1 if net.discrete else net.offsets["act.action_out.log_std"][0]
+        call("harl_trpo_begin", ptr(graw), ptr(sc), int(ls_off), net.act_dim, ptr(g), ptr(x), ptr(r), ptr(p), n,
+             ptr(w["cg_state"]), ptr(st), _lib.scratch("cg"), s)
         # conjugate gradient, 10 steps, residual tolerance 1e-10 (trpo_util.py:96-129)
         # The reference leaves the loop once rdotr < 1e-10; here that test stays on the device (a `done` flag freezes x, r
         # and p from then on -- the same iterates, no host round trip per iteration, at the price of idle FVPs after a break).
-        x = torch.zeros_like(g)
-        r, p = g.clone(), g.clone()
-        state = torch.stack([torch.dot(r, r), torch.zeros((), dtype=g.dtype, device=g.device)])  # [r.r, done]
         for it in range(10):
-            avp = self._fvp(obs, m, m_global, avail_rows, p, seq=seq)
-            call("harl_trpo_cg_step", ptr(x), ptr(r), ptr(p), ptr(avp), x.numel(), ptr(state), _lib.scratch("cg"), stream())
+            avp = self._fvp(obs, m, m_global, avail_rows, p, seq=seq, out=w["fp"])
+            call("harl_trpo_cg_step", ptr(x), ptr(r), ptr(p), ptr(avp), n, ptr(w["cg_state"]), _lib.scratch("cg"), s)
             if self._cg_tap is not None and it + 1 in (1, 5, 10):
                 self._cg_tap(it + 1, x.clone())
-        params = net.flat_param.clone()
-        fv = self._fvp(obs, m, m_global, avail_rows, x, seq=seq)
-        shs = 0.5 * torch.dot(x, fv)
-        step_size = 1.0 / torch.sqrt(shs / self.kl_threshold)
-        full_step = step_size * x
+        fv = self._fvp(obs, m, m_global, avail_rows, x, seq=seq, out=w["fp"])
+        # shs, step size, full_step, the snapshot of theta_old, expected improvement (hatrpo.py:123-133)
+        call("harl_trpo_step", ptr(x), ptr(fv), ptr(g), ptr(net.flat_param), ptr(w["theta"]), ptr(w["full_step"]), n,
+             float(self.kl_threshold), ptr(st), _lib.scratch("cg"), s)
         # "old actor" snapshot (hatrpo.py:127-130): distribution parameters at theta_old + the RNG draws its construction costs
         head_old = self._head_outputs(obs, m, actions, avail, reuse_trunk=True, seq=seq, avail_rows=avail_rows)  # FVPs do not touch x_hat_l / y
         ls_old = None if net.discrete else net.log_std().clone()
         consume_policy_init_rng(self.args, self.obs_space, self.act_space)
-        expected_improve = float(torch.dot(g, full_step).item())
         if self._grad_tap is not None:
-            self._grad_tap(g.clone(), x.clone(), float(step_size.item()))
-        flag, fraction = False, 1.0
-        kl = loss_improve = 0.0
-        sc_new = sc
-        backtracks = 0
+            torch.cuda.synchronize()
+            self._grad_tap(g.clone(), x.clone(), float(st[2].item()))
+        rec = None
         for _ in range(self.ls_step):
-            net.flat_param.copy_(params + fraction * full_step)
+            call("harl_trpo_ls_candidate", ptr(w["theta"]), ptr(w["full_step"]), ptr(st), ptr(net.flat_param), n, s)
+            net._fold_version = None  # (the parameters changed behind torch's version counter)
             net.fold()
             sc_new, _ = self._surrogate(obs, m, actions, avail, old_logp, adv, adv_moments, factor, active, want_grad=False,
-                                        seq=seq)
+                                        seq=seq, raw=True)
             head_new = self._head_outputs(obs, m, actions, avail, reuse_trunk=True, seq=seq, avail_rows=avail_rows)
-            kl_sum = self._kl_sum(head_old, ls_old, head_new, kl_rows)
-            # ONE read-back per line-search step (the accept test needs both numbers on the host)
-            new_loss, kl = torch.stack([(sc_new[0] / sc_new[1]).to(torch.float64), kl_sum[0] / float(m_global)]).tolist()
-            loss_improve = new_loss - loss
-            if kl < self.kl_threshold and (loss_improve / expected_improve) > self.accept_ratio and loss_improve > 0:
-                flag = True
+            self._kl_sum(head_old, ls_old, head_new, kl_rows, acc=w["kl"])
+            # kl, improvement, the accept test and the backtrack bookkeeping (hatrpo.py:171-185) on the device ...
+            call("harl_trpo_ls_test", ptr(sc_new), ptr(w["kl"]), float(m_global), float(self.kl_threshold), float(self.accept_ratio),
+                 float(self.backtrack_coeff), ptr(st), s)
+            # ... and ONE read-back per line-search step: the record
+            w["st_host"].copy_(st, non_blocking=True)
+            torch.cuda.current_stream(self.device).synchronize()
+            rec = w["st_host"].tolist()
+            if rec[5] != 0.0:
                 break
-            expected_improve *= self.backtrack_coeff
-            fraction *= self.backtrack_coeff
-            backtracks += 1
+        flag = rec[5] != 0.0
         if not flag:
-            net.flat_param.copy_(params)
+            net.flat_param.copy_(w["theta"])
+            net._fold_version = None
             net.fold()
             print("policy update does not impove the surrogate")
-        dist_entropy = float((sc_new[2] / sc_new[1]).item())
-        ratio = float((sc_new[3] / sc_new[4]).item())
+        kl, loss_improve, expected_improve, dist_entropy, ratio = rec[7], rec[8], rec[3], rec[10], rec[11]
         if self._trace is not None:
-            self._trace.append(dict(accepted=bool(flag), backtracks=backtracks, fraction=fraction, kl=kl, loss=loss,
+            self._trace.append(dict(accepted=bool(flag), backtracks=int(rec[6]), fraction=rec[4], kl=kl, loss=rec[0],
                                     loss_improve=loss_improve, expected_improve=expected_improve, dist_entropy=dist_entropy,
-                                    ratio=ratio, step_size=float(step_size.item()), shs=float(shs.item())))
+                                    ratio=ratio, step_size=rec[2], shs=rec[1]))
         return kl, loss_improve, expected_improve, dist_entropy, ratio
 
     def update(self, sample):
@@ -322,7 +346,10 @@ class HATRPO(OnPolicyBase):
         self.actor.invalidate_caches()
         adv = _as_dev(advantages, dev).reshape(B).contiguous()
         active = buf.flat("active_masks").reshape(B)
-        moments = torch.zeros(3, dtype=torch.float64, device=dev)
+        if self._moments is None:
+            self._moments = torch.zeros(3, dtype=torch.float64, device=dev)
+        moments = self._moments
+        call("harl_zero_bytes", ptr(moments), 24, stream())
         call("harl_masked_moments", ptr(adv), ptr(active), B, ptr(moments), _lib.scratch("mm"), stream())
         self.comm.all_reduce_sum(moments)
         if float(moments[2].item()) == 0.0:

@@ -404,6 +404,34 @@ int harl_actor_head_fvp(const float *xL, const float *xLdot, const uint32_t *rel
 int harl_trpo_fvp_finish(const float *grad, const float *vec, const float *log_std, float *out, long n, float m_global,
                          float damping, long logstd_off, int act_dim, float std_x_coef, float std_y_coef, void *stream);
 int harl_trpo_cg_step(float *x, float *r, float *p, const float *avp, long n, float *state, void *scratch, void *stream);
+/* HATRPO's scalar glue on the device (hatrpo.py:92-192; round 6): the set-up of the conjugate-gradient solve, the step size, the
+ * expected improvement and the line search's accept test -- torch.dot / sqrt / .item() round trips in the reference and, until
+ * round 5, here.  st = double[HARL_TRPO_STATE], the update's record, read by the host ONCE per line-search step:
+ *   [0] surrogate at theta_old  [1] shs = 1/2 x.Fx  [2] step size  [3] expected improvement (x backtrack_coeff per backtrack)
+ *   [4] fraction  [5] accepted (0/1)  [6] backtracks  [7] kl  [8] loss_improve  [9] surrogate at the candidate
+ *   [10] dist_entropy  [11] ratio  [12] expected improvement at fraction 1
+ * harl_trpo_begin : g = grad_sum * (float)(1 / scalars[1]) (hatrpo.py:92-95 on the unscaled sums of harl_actor_head_loss; the
+ *                   log_std block logstd_off .. + act_dim of a Gaussian policy from scalars[8 ..], logstd_off < 0: none),
+ *                   x = 0, r = p = g, cg_state = {r.r, 0} (trpo_util.py:101-105), st cleared, st[0] = scalars[0] / scalars[1].
+ * harl_trpo_step  : st[1], st[2] (hatrpo.py:123-124), full_step = step x, theta_save = theta, st[3] = st[12] = g.full_step,
+ *                   st[4] = 1, st[5] = st[6] = 0.
+ * harl_trpo_ls_candidate : theta = theta_save + (float)st[4] * full_step (hatrpo.py:139-140).
+ * harl_trpo_ls_test : new surrogate = scalars[0] / scalars[1], kl = kl_sum[0] / m_global (kl_sum is reset to 0), the accept test
+ *                   `kl < delta and improve / expected > accept_ratio and improve > 0` (hatrpo.py:171-178); on reject st[3], st[4]
+ *                   are multiplied by backtrack_coeff and st[6] incremented (hatrpo.py:184-185).
+ * scratch (begin, step): HARL_CG_SCRATCH_BYTES, the block harl_trpo_cg_step uses.  Dot products: fp64 over fixed-order partials. */
+#define HARL_TRPO_STATE 16
+int harl_trpo_begin(const float *grad_sum, const double *scalars, long logstd_off, int act_dim, float *g, float *x, float *r,
+                    float *p, long n, float *cg_state, double *st, void *scratch, void *stream);
+int harl_trpo_step(const float *x, const float *fx, const float *g, const float *theta, float *theta_save, float *full_step,
+                   long n, float kl_threshold, double *st, void *scratch, void *stream);
+int harl_trpo_ls_candidate(const float *theta_save, const float *full_step, const double *st, float *theta, long n, void *stream);
+int harl_trpo_ls_test(const double *scalars, double *kl_sum, double m_global, double kl_threshold, double accept_ratio,
+                      double backtrack_coeff, double *st, void *stream);
+/* scalars[0..HARL_PS_STRIDE) = column sums of the loss kernels' per-block partial rows: harl_reduce_scalars ACCUMULATES (zero
+ * `scalars` first), harl_reduce_scalars_set overwrites.  harl_zero_bytes: hipMemsetAsync on `stream`. */
+int harl_reduce_scalars_set(const float *part_scalars, int n_blocks, double *scalars, void *stream);
+int harl_zero_bytes(void *p, long bytes, void *stream);
 /* out_sum (double, accumulated) += sum_s KL(old || new)_s from the head outputs of harl_actor_head_logp:
  * Gaussian analytic KL in fp64 (trpo_util.py:54-62), Categorical kl_approx on normalised logits (trpo_util.py:47-51) */
 int harl_trpo_kl_sum(const float *head_old, const float *head_new, const float *log_std_old, const float *log_std_new,

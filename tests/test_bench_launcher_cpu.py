@@ -24,6 +24,18 @@ def _run(cmd):
 def test_bench_self_spawns_ranks(n):
     out = _run([sys.executable, "bench.py", "--gpus", str(n), "--steps", "1", "--warmup", "0", "--dry-run"])
     assert out["n_gpus"] == n and out["config"]["parallelism"] == f"dp{n}" and out["config"]["collective"] == "gloo"
+    # the multi-GPU line answers the BASELINE's question: headline = strong scaling at the BASELINE's
+    # global n_rollout_threads, the weak figure on the same line, and the rank count as the communicator itself reports it
+    assert out["scaling"] == "strong" and out["config"]["n_rollout_threads_global"] == 4096
+    assert out["config"]["n_rollout_threads_per_gpu"] == 4096 // n and out["config"]["ranks_seen"] == n
+    assert out["weak"]["n_rollout_threads_global"] == 4096 * n
+
+
+def test_bench_strong_size_of_cheetah6_is_configs2():
+    out = _run([sys.executable, "bench.py", "--gpus", "2", "--config", "cheetah6", "--dry-run"])
+    assert out["scaling"] == "strong" and out["config"]["n_rollout_threads_global"] == 8192
+    out = _run([sys.executable, "bench.py", "--gpus", "2", "--scaling", "weak", "--dry-run"])
+    assert out["scaling"] == "weak" and out["config"]["n_rollout_threads_global"] == 8192 and out["weak"] is None
 
 
 def test_bench_under_explicit_torchrun():
@@ -46,3 +58,4 @@ def test_bench_second_line_flag():
 def test_bench_single_rank_dry():
     out = _run([sys.executable, "bench.py", "--dry-run"])
     assert out["n_gpus"] == 1 and out["config"]["collective"] == "none"
+    assert out["scaling"] == "weak" and out["config"]["n_rollout_threads_global"] == 4096 and out["config"]["ranks_seen"] == 1

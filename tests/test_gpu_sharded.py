@@ -37,8 +37,8 @@ def _worker(rank, world, port, name, q, env=None):
         train, model, algo = case.reference_dicts()
         space = G.act_space_of(sh)
         comm = Comm()
-        if (env or {}).get("HARL_ALLREDUCE") == "oneshot":
-            assert comm.oneshot is not None
+        if (env or {}).get("HARL_ALLREDUCE") in ("oneshot", "auto"):  # (auto: all ranks share this GPU, every kind qualifies)
+            assert comm.oneshot is not None and comm.oneshot_info["enabled"], comm.oneshot_info
         lo, hi = shard_columns(sh.N, rank, world)
         torch.manual_seed(case.seed)
         r = OnPolicyHARunner(dict(algo="happo"), dict(train=train, model=model, algo=algo), dict(state_type="EP"),
@@ -120,23 +120,29 @@ def test_two_rank_sharded_train_through_oneshot_allreduce(name):
     _run_sharded(name, {"HARL_ALLREDUCE": "oneshot"})
 
 
-def _run_sharded(name, env):
+def test_four_rank_sharded_train_matches_unsharded_golden_through_auto_exchange():
+    """FOUR ranks (a quarter of the rollout threads each) with HARL_ALLREDUCE=auto -- the collectively decided one-hop exchange --
+    against the reference's unsharded golden vectors; bit-identical replicated parameters on all four ranks."""
+    _run_sharded("mpe_box_h128", {"HARL_ALLREDUCE": "auto"}, world=4)
+
+
+def _run_sharded(name, env, world=2):
     import torch.multiprocessing as mp
 
-    world, port = 2, _free_port()
+    port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, name, q, env)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=90) for _ in range(world)]
+    res = [q.get(timeout=150) for _ in range(world)]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
     for r in res:
         assert r["ret_bad"] == 0.0 and r["rng_bad"] == 0.0 and r["oneshot_status"] == 0, r
         assert r["actor_excess"] <= 1.0 and r["critic_excess"] <= 1.0 and r["param_excess"] <= 1.0, r
-    assert res[0]["param_sum"] == res[1]["param_sum"], "replicated parameters diverged between ranks"
+    assert all(r["param_sum"] == res[0]["param_sum"] for r in res), "replicated parameters diverged between ranks"
 
 
 def _oneshot_worker(rank, world, port, q):
@@ -186,6 +192,15 @@ def _oneshot_worker(rank, world, port, q):
         us_per_call = e0.elapsed_time(e1) * 10.0
         mean0 = sum(range(1, world + 1)) / world
         chain_ok = bool(torch.all(y == mean0).item())  # after the first launch every rank holds the mean, a fixed point
+        # a tensor that is MISALIGNED on this rank only (a view one element into its storage on odd ranks) must still take the
+        # exchange -- through an aligned staging copy -- not another backend (the path is chosen from rank-invariant properties)
+        base = torch.arange(1030, dtype=torch.float32, device=dev) * (rank + 1)
+        view = base[1:1025] if rank % 2 else base[:1024]
+        want_v = sum((torch.arange(1030, dtype=torch.float32) * (q_ + 1))[1:1025] if q_ % 2 else
+                     (torch.arange(1030, dtype=torch.float32) * (q_ + 1))[:1024] for q_ in range(world))
+        comm.all_reduce_sum(view)
+        bad += int(not torch.equal(view.cpu(), want_v))
+        cases += 1
         st = comm.oneshot_status()
         kind = comm.oneshot[3]
         comm.close()
@@ -194,7 +209,7 @@ def _oneshot_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_oneshot_allreduce_is_the_rank_ordered_sum_bit_for_bit(world):
     """harl_comm_allreduce among `world` processes sharing this GPU against the rank-ordered sum of the gathered messages: every
     bit, fp32 and fp64, lengths from 1 element to the capacity, and 200 unsynchronised launches in a row."""
@@ -216,4 +231,57 @@ def test_oneshot_allreduce_is_the_rank_ordered_sum_bit_for_bit(world):
                                                         us_per_call_min=min(r["us_per_call"] for r in res),
                                                         mismatching_cases=sum(r["bad"] for r in res), cases=res[0]["cases"]))
     for r in res:
-        assert r["bad"] == 0 and r["cases"] == 24 and r["chain_ok"] and r["status"] == 0, r
+        assert r["bad"] == 0 and r["cases"] == 25 and r["chain_ok"] and r["status"] == 0, r
+
+
+def _timeout_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                      HARL_ALLREDUCE="oneshot", HARL_ONESHOT_TIMEOUT_S="1.5")
+    import time
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from harl_amd.dist import Comm
+        comm = Comm()
+        dev = torch.device("cuda:0")
+        x = torch.full((4096,), float(rank + 1), device=dev)
+        comm.all_reduce_sum(x)  # a healthy exchange first
+        torch.cuda.synchronize()
+        ok_first = bool(torch.all(x == 3.0).item()) and comm.oneshot_status() == 0
+        res = dict(rank=rank, ok_first=ok_first)
+        if rank == 0:  # rank 1 never launches the second exchange: rank 0 must give up after 1.5 s, not hang
+            y = torch.ones(4096, device=dev)
+            t0 = time.perf_counter()
+            comm.all_reduce_sum(y)
+            torch.cuda.synchronize()
+            res.update(waited_s=time.perf_counter() - t0, all_nan=bool(torch.isnan(y).all().item()), status=comm.oneshot_status())
+            try:
+                comm.check()
+                res["raised"] = False
+            except RuntimeError as e:
+                res["raised"] = "gave up waiting for rank 1" in str(e)
+        dist.barrier()
+        comm.close()
+        q.put(res)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_oneshot_timeout_is_loud_and_does_not_hang():
+    """A peer that never shows up: after HARL_ONESHOT_TIMEOUT_S the waiting rank's launch ends, its result is NaN, the
+    status word names the missing rank and Comm.check() -- what train() calls after its read-back -- raises."""
+    import torch.multiprocessing as mp
+
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_timeout_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {r["rank"]: r for r in (q.get(timeout=120) for _ in range(world))}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0]["ok_first"] and res[1]["ok_first"], res
+    r0 = res[0]
+    assert r0["all_nan"] and r0["status"] == 2 and r0["raised"] is True and 1.0 < r0["waited_s"] < 30.0, r0

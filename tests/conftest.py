@@ -23,6 +23,8 @@ def pytest_collection_modifyitems(config, items):
     import torch
 
     if torch.cuda.is_available():
+        # the full-size checks go LAST: their oracle workers, started at session start, then have the whole suite's wall time
+        items.sort(key=lambda it: it.name in FULL_SIZE_TESTS)  # (stable: everything else keeps its order)
         return
     skip = pytest.mark.skip(reason="needs an MI355X (torch.cuda.is_available() is False)")
     for item in items:

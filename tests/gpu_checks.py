@@ -1291,9 +1291,11 @@ def _oracle_bench_run(payload: dict, tag: str, dt_name: str, pert_seed, keep_gra
         O.set_work_dtype(torch.float32)
 
 
-def _oracle_launch(payload: dict, plan, keep_grad: bool, threads: int = 0) -> dict:
+def _oracle_launch(payload: dict, plan, keep_grad: bool, threads: int = 0, cores=None) -> dict:
     """Start one worker process per entry of ``plan`` [(tag, dtype name, one-ulp seed | None)] (tests/oracle_worker.py; the
-    payload travels through one file in a temporary directory) and return the handle ``_oracle_collect`` waits on."""
+    payload travels through one file in a temporary directory) and return the handle ``_oracle_collect`` waits on.
+    ``cores``: one list of logical CPUs per plan entry -- the worker pins itself to them and runs that many torch threads
+    (prefetch_full_size: disjoint sets, so that twenty oracle runs and the test process do not fight over the same cores)."""
     import subprocess
     import sys
     import tempfile
@@ -1301,12 +1303,14 @@ def _oracle_launch(payload: dict, plan, keep_grad: bool, threads: int = 0) -> di
     td = tempfile.TemporaryDirectory(prefix="harl_oracle_")
     pin = os.path.join(td.name, "payload.pt")
     torch.save(payload, pin)
-    nthr = str(threads or int(os.environ.get("HARL_ORACLE_THREADS") or 16))
     procs = []
-    for tag, dtn, seed in plan:
+    for k, (tag, dtn, seed) in enumerate(plan):
         pout = os.path.join(td.name, f"{tag}.pt")
+        mine = None if cores is None else cores[k]
+        nthr = str(len(mine) if mine else (threads or int(os.environ.get("HARL_ORACLE_THREADS") or 16)))
         env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""), OMP_NUM_THREADS=nthr,
-                   HARL_ORACLE_THREADS=nthr, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+                   HARL_ORACLE_THREADS=nthr, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="", OMP_WAIT_POLICY="PASSIVE",
+                   HARL_ORACLE_CORES=",".join(str(c) for c in mine) if mine else "")
         cmd = [sys.executable, "-m", "tests.oracle_worker", pin, pout, tag, dtn, "none" if seed is None else str(seed), str(int(keep_grad))]
         procs.append((tag, pout, subprocess.Popen(cmd, cwd=root, env=env)))
     return dict(td=td, procs=procs)
@@ -1316,7 +1320,7 @@ def _oracle_collect(handle: dict) -> dict:
     runs = {}
     try:
         for tag, pout, pr in handle["procs"]:
-            rc = pr.wait()
+            rc = pr.wait(timeout=float(os.environ.get("HARL_ORACLE_TIMEOUT_S", "1500")))
             if rc != 0:
                 raise RuntimeError(f"oracle worker {tag} failed with exit code {rc}")
             runs[tag] = torch.load(pout, weights_only=False)
@@ -1412,32 +1416,59 @@ def _oracle_plan(with_f64: bool, n_pert: int):
 # suite's 859 s.  `prefetch_full_size` (called by a session fixture, tests/conftest.py) runs the HIP step of every selected
 # full-size check right away -- seconds each -- and starts all their oracle workers at once; the tests collect the results
 # at the end of the file, by which time the ~190 other tests have run next to the workers.
-FULL_SIZE = {  # key -> (workload, logp, n_threads, n_pert)   [test name -> key: tests/conftest.py]
-    "humanoid17": ("humanoid17", "recipe", 1024, 1),
-    "cheetah6": ("cheetah6", "recipe", 4096, 1),
-    "hatrpo_gru128": ("hatrpo_gru128", "recipe", 512, 1),
-    "mpe_onpolicy": ("mpe", "onpolicy", 4096, 3),
-    "mpe": ("mpe", "recipe", 4096, 2),
-    "smac3s5z": ("smac3s5z", "recipe", 512, 1),
+FULL_SIZE = {  # key -> (workload, logp, n_threads, n_pert, float64 twin, host cores per oracle worker)   [test -> key: conftest]
+    # (humanoid17: two one-ulp twins instead of the float64 one -- 17 agents x 204 800 rows x 11 double-backward passes in
+    # float64 would be the longest job of the whole suite by a factor; the bar needs twins, not float64 specifically)
+    "humanoid17": ("humanoid17", "recipe", 1024, 2, False, 28),
+    "cheetah6": ("cheetah6", "recipe", 4096, 1, True, 12),
+    "hatrpo_gru128": ("hatrpo_gru128", "recipe", 512, 1, True, 10),
+    "mpe_onpolicy": ("mpe", "onpolicy", 4096, 3, True, 4),
+    "mpe": ("mpe", "recipe", 4096, 2, True, 4),
+    "smac3s5z": ("smac3s5z", "recipe", 512, 1, True, 4),
 }
+MAIN_PROCESS_CORES = 32  # logical CPUs the test process keeps for itself while oracle workers run
 _PREFETCH: Dict[tuple, dict] = {}
 
 
 def prefetch_full_size(keys) -> None:
     """HIP step + oracle worker launch for every key of FULL_SIZE in ``keys`` (heaviest first).  Failures are kept and raised by
     the test that asks for the result, not here.  Hosts with < 64 CPUs (no room for worker processes) do nothing: the checks
-    then run inline as before."""
+    then run inline as before.
+    The host's logical CPUs are PARTITIONED: the test process pins itself to the first MAIN_PROCESS_CORES of its affinity set
+    (and runs that many torch threads), every oracle worker gets a disjoint slice of the rest -- the first attempt let twenty
+    16-thread workers and the test process's 128 OpenMP threads share all cores, and the suite ran ~20x slower (49 tests in
+    25 minutes: every OpenMP barrier waited for descheduled threads)."""
     if (os.cpu_count() or 1) < 64 and os.environ.get("HARL_ORACLE_PARALLEL") != "force":
         return
     todo = [k for k in FULL_SIZE if k in set(keys)]
-    n_workers = sum(2 + FULL_SIZE[k][3] for k in todo)
-    threads = max(4, min(16, ((os.cpu_count() or 64) - 16) // max(1, n_workers)))
+    if not todo:
+        return
+    try:
+        avail = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = list(range(os.cpu_count() or 1))
+    n_main = min(MAIN_PROCESS_CORES, max(2, len(avail) // 4))
+    pool = avail[n_main:]
+    want = sum((1 + int(FULL_SIZE[k][4]) + FULL_SIZE[k][3]) * FULL_SIZE[k][5] for k in todo)
+    scale = min(1.0, len(pool) / max(1, want))
+    try:
+        os.sched_setaffinity(0, avail[:n_main])
+    except (AttributeError, OSError):
+        pass
+    torch.set_num_threads(n_main)
+    nxt = 0
     for k in todo:
-        workload, logp, n_threads, n_pert = FULL_SIZE[k]
+        workload, logp, n_threads, n_pert, with_f64, per = FULL_SIZE[k]
         slot = (workload, logp, n_threads, n_pert)
         try:
             hip, payload, shapes, meta = _bench_hip_step(n_threads, False, logp, workload)
-            handle = _oracle_launch(payload, _oracle_plan(True, n_pert), False, threads=threads)
+            plan = _oracle_plan(with_f64, n_pert)
+            cores = []
+            for _ in plan:
+                c = max(2, int(per * scale))
+                cores.append(pool[nxt:nxt + c] or pool[-c:])
+                nxt += c
+            handle = _oracle_launch(payload, plan, False, cores=cores)
             del payload
             _PREFETCH[slot] = dict(hip=hip, shapes=shapes, meta=meta, handle=handle)
         except Exception as e:  # noqa: BLE001 -- re-raised by the test of this check
@@ -1453,7 +1484,7 @@ def _bench_config_runs(n_threads: int, with_f64: bool, keep_grad: bool = False, 
     own fp32 figures move under the smallest change fp32 can express.  ``workload``: an entry of bench.WORKLOADS.  A result
     started by ``prefetch_full_size`` is collected instead of recomputed."""
     slot = (workload, logp, n_threads, n_pert)
-    pre = _PREFETCH.pop(slot, None) if (with_f64 and not keep_grad) else None
+    pre = _PREFETCH.pop(slot, None) if not keep_grad else None
     if pre is not None:
         if "error" in pre:
             raise pre["error"]
@@ -1586,7 +1617,8 @@ def check_bench_config_parity(logp: str = "recipe", n_threads: int = 4096, n_per
     return out
 
 
-def check_bench_config_parity_trpo(workload: str = "humanoid17", n_threads: int = 1024, n_pert: int = 1) -> Dict[str, float]:
+def check_bench_config_parity_trpo(workload: str = "humanoid17", n_threads: int = 1024, n_pert: int = 1,
+                                   with_f64: bool = True) -> Dict[str, float]:
     """A HATRPO bench workload at its MEASURED size against the oracle: `humanoid17` (17 agents x
     204 800 rows, obs 393, MLP [128]x3, hatrpo.yaml defaults) or `hatrpo_gru128` (8 agents, 128-wide GRU, Discrete(14) with
     unavailable actions, chunks of 10) -- compute() + train() on identical buffer contents, the oracle (hatrpo.py:37-194,
@@ -1603,11 +1635,14 @@ def check_bench_config_parity_trpo(workload: str = "humanoid17", n_threads: int 
       * the critic: 1e-5 flat (feed-forward) / pooled (recurrent); final parameters pooled."""
     import bench as _bench
     out: Dict[str, float] = {}
-    hip, runs, _shapes, meta = _bench_config_runs(n_threads, True, n_pert=n_pert, workload=workload)
+    hip, runs, _shapes, meta = _bench_config_runs(n_threads, with_f64, n_pert=n_pert, workload=workload)
     T, A = meta["T"], meta["A"]
     recurrent = bool(_bench.WORKLOADS[workload].get("rnn"))
-    o, o64 = runs["f32"], runs["f64"]
+    o = runs["f32"]
     perts = [runs[k] for k in sorted(runs) if k.startswith("pert")]
+    twin_runs = ([runs["f64"]] if "f64" in runs else []) + perts  # the fp32 oracle's own twins: float64 and / or one-ulp starts
+    assert twin_runs, "the measured bars need at least one twin run of the oracle"
+    out["_oracle_run_seconds"] = " ".join(f"{k}:{v['seconds']:.0f}" for k, v in sorted(runs.items()))
     out["_oracle_seconds"] = float(sum(v["seconds"] for v in runs.values()))
     out["_oracle_wall_seconds_max"] = float(max(v["seconds"] for v in runs.values()))
     out["next_value_vec_rel"] = vec_rel_err(hip["next_value"], o["nv"])
@@ -1625,7 +1660,7 @@ def check_bench_config_parity_trpo(workload: str = "humanoid17", n_threads: int 
 
     g_ = [hip["atr"][a][0] for a in range(A)]
     o_ = [o["atr"][a][0] for a in range(A)]
-    twins = [[run["atr"][a][0] for a in range(A)] for run in [o64] + perts]
+    twins = [[run["atr"][a][0] for a in range(A)] for run in twin_runs]
     stable = [all(tw[a]["accepted"] == o_[a]["accepted"] and bt(tw[a]) == bt(o_[a]) for tw in twins) for a in range(A)]
     # the sequential factor couples the agents: once one agent's decision differs, everything after it sees another factor
     first_unstable = next((a for a in range(A) if not stable[a]), A)
@@ -1639,7 +1674,7 @@ def check_bench_config_parity_trpo(workload: str = "humanoid17", n_threads: int 
     out["_oracle_backtracks_total"] = float(sum(bt(u) for u in o_))
     out["_decisions_hip"] = "".join(("A" if u["accepted"] else "R") + str(bt(u)) + " " for u in g_).strip()
     out["_decisions_oracle"] = "".join(("A" if u["accepted"] else "R") + str(bt(u)) + " " for u in o_).strip()
-    out["_decisions_oracle_f64"] = "".join(("A" if u["accepted"] else "R") + str(bt(u)) + " " for u in twins[0]).strip()
+    out["_decisions_oracle_twin0"] = "".join(("A" if u["accepted"] else "R") + str(bt(u)) + " " for u in twins[0]).strip()
     ok_upto = min(first_unstable, A)  # agents in front of the oracle's own first disagreement: decisions must be identical
     out["linesearch_decision_mismatch"] = float(sum(g_[a]["accepted"] != o_[a]["accepted"] for a in range(ok_upto)))
     out["linesearch_backtracks_mismatch"] = float(sum(bt(g_[a]) != bt(o_[a]) for a in range(ok_upto)))
@@ -1658,7 +1693,7 @@ def check_bench_config_parity_trpo(workload: str = "humanoid17", n_threads: int 
     for c, nm in enumerate(("value_loss", "grad_norm")):
         err = float(rel(hip["ctr"][:, c], o["ctr"][:, c]).max())
         if recurrent:
-            floor = max([float(rel(o["ctr"][:, c], o64["ctr"][:, c]).max())] + [float(rel(pr["ctr"][:, c], o["ctr"][:, c]).max()) for pr in perts])
+            floor = max(float(rel(tw["ctr"][:, c], o["ctr"][:, c]).max()) for tw in twin_runs)
             out[f"_critic_update_{nm}_rel"] = err
             out[f"critic_update_{nm}_excess"] = err / max(1e-5, NOISE_FACTOR * floor)
         else:
@@ -1669,13 +1704,14 @@ def check_bench_config_parity_trpo(workload: str = "humanoid17", n_threads: int 
     for a in cmp_agents:
         raw = vec_rel_err(hip["fin"][a], o["fin"][a])
         worst_raw = max(worst_raw, raw)
-        floor = max([floor, vec_rel_err(o["fin"][a], o64["fin"][a])] + [vec_rel_err(pr["fin"][a], o["fin"][a]) for pr in perts])
+        floor = max([floor] + [vec_rel_err(tw["fin"][a], o["fin"][a]) for tw in twin_runs])
     out["_actor_final_param_vec_rel_max"] = worst_raw
     out["_actor_final_param_oracle_own_uncertainty"] = floor
     out["actor_final_param_excess"] = worst_raw / max(1e-5, NOISE_FACTOR * floor)
     out["_critic_final_param_vec_rel"] = vec_rel_err(hip["cfin"], o["cfin"])
-    out["critic_final_param_excess"] = vec_excess(hip["cfin"], o["cfin"], o64["cfin"],
-                                                  sens=max([vec_rel_err(pr["cfin"], o["cfin"]) for pr in perts], default=None))
+    cfloor = max(vec_rel_err(tw["cfin"], o["cfin"]) for tw in twin_runs)
+    out["_critic_final_param_oracle_own_uncertainty"] = cfloor
+    out["critic_final_param_excess"] = out["_critic_final_param_vec_rel"] / max(1e-5, NOISE_FACTOR * cfloor)
     dump_parity(f"bench_config_parity_{workload}_full_size", out)
     return out
 

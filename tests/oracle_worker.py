@@ -10,7 +10,14 @@ import torch
 
 
 def main() -> int:
+    import os
     pin, pout, tag, dtn, seed, keep = sys.argv[1:7]
+    cores = os.environ.get("HARL_ORACLE_CORES")
+    if cores:  # this worker's slice of the host (tests/gpu_checks.prefetch_full_size)
+        try:
+            os.sched_setaffinity(0, {int(c) for c in cores.split(",")})
+        except (AttributeError, OSError, ValueError):
+            pass
     from tests import gpu_checks as G
     payload = torch.load(pin, weights_only=False)
     res = G._oracle_bench_run(payload, tag, dtn, None if seed == "none" else int(seed), bool(int(keep)))

@@ -389,7 +389,7 @@ def measure(w: dict, cfg_name: str, args, comm, rank: int, world: int, device, n
             ach = cand[dom]["bytes"] / tot_s
             per_launch = cand[dom]["bytes"] / cand[dom]["n"]
             traffic, traffic_note = None, None
-            tp = next((q for q in (os.path.join(ROOT, "profiles", f"r0{k}_hbm_traffic.json") for k in (5, 4, 3, 2)) if os.path.exists(q)),
+            tp = next((q for q in (os.path.join(ROOT, "profiles", f"r0{k}_hbm_traffic.json") for k in (6, 5, 4, 3, 2)) if os.path.exists(q)),
                       os.path.join(ROOT, "profiles", "r04_hbm_traffic.json"))
             if os.path.exists(tp):  # PMC passes over the same kernels at this workload's shapes (tools/pmc_traffic.sh)
                 tj = json.load(open(tp))

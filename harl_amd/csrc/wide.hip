@@ -377,7 +377,12 @@ __device__ __forceinline__ void wide_epilogue(f32x16 (&acc)[HO / 32], long slab,
 // pre-activations z = W' x0n + b' as an ATL(HO) image (activation functions other than ReLU: csrc/elementwise.hip applies
 // the activation and the LayerNorm in a separate element-wise launch, harl_amd/nets.py).
 // ---------------------------------------------------------------------------------------------
-template <int HO, int MODE>
+// NJL > 0 (round 6): the fragments of the first NJL k-steps are staged into LDS once per workgroup (3 terms x HO/32 tiles x NJL
+// KiB: 96 KiB at HO = 128, NJL = 8) and only the remaining k-steps stream from L2.  The streaming kernel asks the L2 for 16 KiB per
+// wave and k-step -- 32 B per clock and CU with every CU of an XCD on the same 4 MB slice -- and stalls on it (133 us per launch
+// at 204 800 rows where its issue model says 80); with half of the K = 2 H tangent GEMM's fragments (the W' half, identical
+// for every Fisher-vector product) resident, that traffic halves.  Same instruction order per accumulator: bit-identical results.
+template <int HO, int MODE, int NJL = 0>
 __global__ __launch_bounds__(WG_THREADS, 1) void k_fwd_wide(const float *__restrict__ x0n, const u32x4 *__restrict__ img,
                                                             const float *__restrict__ bp, float *__restrict__ xout,
                                                             uint32_t *__restrict__ mask_out, float *__restrict__ rstd_out,
@@ -394,6 +399,16 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_fwd_wide(const float *__restr
   const int lane = threadIdx.x & 63, wave = wave_id(), h = lane >> 5;
   const long n_pairs = (n_slabs + 1) / 2;
   const u32x4 *wl = img + lane;
+  extern __shared__ __attribute__((aligned(16))) float lds_w[];
+  const u32x4 *ll = reinterpret_cast<const u32x4 *>(lds_w) + lane;
+  if constexpr (NJL > 0) {  // [term][tile][k-step < NJL][lane]
+    u32x4 *li = reinterpret_cast<u32x4 *>(lds_w);
+    for (int e = threadIdx.x; e < 3 * MT * NJL * 64; e += WG_THREADS) {
+      const int ln = e & 63, j = (e >> 6) % NJL, t = ((e >> 6) / NJL) % MT, term = (e >> 6) / (NJL * MT);
+      li[e] = img[(long)term * TS + (t * NJ + j) * 64 + ln];
+    }
+    __syncthreads();
+  }
   for (long pair = (long)blockIdx.x * WAVES_PER_WG + wave; pair < n_pairs; pair += (long)gridDim.x * WAVES_PER_WG) {
     const long s0 = 2 * pair, s1 = s0 + 1 < n_slabs ? s0 + 1 : s0;
     const f32x4 *xp0 = reinterpret_cast<const f32x4 *>(x0n + s0 * (long)KA * SLAB) + lane;
@@ -408,10 +423,17 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_fwd_wide(const float *__restr
     u32x4 an[3][MT];
     f32x4 bn[2][2];
     auto fetch = [&](int j) {
+      if (NJL > 0 && j < NJL) {  // (wave-uniform) resident k-steps
 #pragma unroll
-      for (int term = 0; term < 3; ++term)
+        for (int term = 0; term < 3; ++term)
 #pragma unroll
-        for (int t = 0; t < MT; ++t) an[term][t] = wl[(long)term * TS + (t * NJ + j) * 64];
+          for (int t = 0; t < MT; ++t) an[term][t] = ll[((term * MT + t) * NJL + j) * 64];
+      } else {
+#pragma unroll
+        for (int term = 0; term < 3; ++term)
+#pragma unroll
+          for (int t = 0; t < MT; ++t) an[term][t] = wl[(long)term * TS + (t * NJ + j) * 64];
+      }
       const f32x4 *b0 = j < NJA ? xp0 + (2 * j) * WAVE : xq0 + (2 * (j - NJA)) * WAVE;  // (wave-uniform)
       const f32x4 *b1 = j < NJA ? xp1 + (2 * j) * WAVE : xq1 + (2 * (j - NJA)) * WAVE;
       bn[0][0] = b0[0];
@@ -733,6 +755,14 @@ bool wide_shared(long n_slabs) {
   return e && e[0] == '1' && n_slabs >= 512;
 }
 
+// Resident first-half fragments (k_fwd_wide NJL = 8): HARL_WIDE_RESIDENT=0 switches back to pure streaming (A/B, bit-for-bit test);
+// from 512 slabs on (the staging prologue is 96 KiB per workgroup)
+constexpr size_t wide_res_lds() { return (size_t)3 * 4 * 8 * 64 * 16; }
+bool wide_resident(long n_slabs) {
+  const char *e = getenv("HARL_WIDE_RESIDENT");
+  return !(e && e[0] == '0') && n_slabs >= 512;
+}
+
 template <int MODE>
 int launch_wide(const float *x0n, long M, int KP, const float *Wp, int D, const float *bp, int H, void *w_img, float *xout,
                 uint32_t *mask_out, float *rstd_out, const float *xprimal, const uint32_t *mask_in, const float *rstd_in,
@@ -758,7 +788,11 @@ int launch_wide(const float *x0n, long M, int KP, const float *Wp, int D, const 
     }
     return check_launch(what);
   }
-  if (H == 128)
+  if (H == 128 && KP >= 256 && wide_resident(n_slabs)) {
+    allow_big_lds(k_fwd_wide<128, MODE, 8>, wide_res_lds());
+    hipLaunchKernelGGL((k_fwd_wide<128, MODE, 8>), dim3(grid), dim3(WG_THREADS), wide_res_lds(), s, x0n,
+                       reinterpret_cast<const u32x4 *>(w_img), bp, xout, mask_out, rstd_out, xprimal, mask_in, rstd_in, n_slabs, KP);
+  } else if (H == 128)
     hipLaunchKernelGGL((k_fwd_wide<128, MODE>), dim3(grid), dim3(WG_THREADS), 0, s, x0n, reinterpret_cast<const u32x4 *>(w_img),
                        bp, xout, mask_out, rstd_out, xprimal, mask_in, rstd_in, n_slabs, KP);
   else
@@ -802,7 +836,12 @@ extern "C" int harl_mlp_tangent_hidden2(const float *xin_dot, const float *xin, 
     }
     return check_launch("harl_mlp_tangent_hidden2");
   }
-  if (HO == 128)
+  if (HO == 128 && HI == 128 && wide_resident(n_slabs)) {
+    allow_big_lds(k_fwd_wide<128, 1, 8>, wide_res_lds());
+    hipLaunchKernelGGL((k_fwd_wide<128, 1, 8>), dim3(grid), dim3(WG_THREADS), wide_res_lds(), s, xin_dot,
+                       reinterpret_cast<const u32x4 *>(w_img), bdp, xout_dot, nullptr, nullptr, xprimal, mask_in, rstd_in, n_slabs, KP,
+                       xin, HI);
+  } else if (HO == 128)
     hipLaunchKernelGGL((k_fwd_wide<128, 1>), dim3(grid), dim3(WG_THREADS), 0, s, xin_dot, reinterpret_cast<const u32x4 *>(w_img),
                        bdp, xout_dot, nullptr, nullptr, xprimal, mask_in, rstd_in, n_slabs, KP, xin, HI);
   else

@@ -79,12 +79,11 @@ def _full_size_prefetch(_library_present):
         yield
         return
     from tests import gpu_checks as G
+    from tests import oracle_sched
     G.prefetch_full_size(_selected_full_size)
     yield
-    for pre in list(G._PREFETCH.values()):  # a run that stopped early (-x): do not leave worker processes behind
-        for _, _, pr in (pre.get("handle") or {}).get("procs", []):
-            if pr.poll() is None:
-                pr.kill()
+    if oracle_sched.ACTIVE is not None:  # a run that stopped early (-x): do not leave worker processes behind
+        oracle_sched.ACTIVE.shutdown()
 
 
 @pytest.fixture(autouse=True)

@@ -1239,6 +1239,8 @@ def _oracle_bench_run(payload: dict, tag: str, dt_name: str, pert_seed, keep_gra
     cfg = O.PathConfig.from_reference_dicts(args["train"], args["model"], args["algo"])
     torch.set_num_threads(int(os.environ.get("HARL_ORACLE_THREADS") or min(16, os.cpu_count() or 1)))
     dt = dict(f32=torch.float32, f64=torch.float64)[dt_name]
+    if payload.get("mode") in ("agent", "critic"):  # teacher-forced single-agent / critic-only runs of the HATRPO workloads
+        return _oracle_trpo_piece(payload, w, args, cfg, dt, pert_seed)
     actor_sd, critic_sd, abuf_np, cbuf_np, st0 = (payload[k] for k in ("actor_sd", "critic_sd", "abuf", "cbuf", "st0"))
     O.set_work_dtype(dt)
     try:
@@ -1291,43 +1293,127 @@ def _oracle_bench_run(payload: dict, tag: str, dt_name: str, pert_seed, keep_gra
         O.set_work_dtype(torch.float32)
 
 
-def _oracle_launch(payload: dict, plan, keep_grad: bool, threads: int = 0, cores=None) -> dict:
-    """Start one worker process per entry of ``plan`` [(tag, dtype name, one-ulp seed | None)] (tests/oracle_worker.py; the
-    payload travels through one file in a temporary directory) and return the handle ``_oracle_collect`` waits on.
-    ``cores``: one list of logical CPUs per plan entry -- the worker pins itself to them and runs that many torch threads
-    (prefetch_full_size: disjoint sets, so that twenty oracle runs and the test process do not fight over the same cores)."""
+def _oracle_trpo_piece(payload: dict, w: dict, args: dict, cfg, dt, pert_seed) -> dict:
+    """One piece of a HATRPO workload's full-size comparison (check_bench_config_parity_trpo), so that the pieces run side by
+    side on the host's cores instead of one 17-agent chain (> 20 minutes of double backward at 204 800 rows x 393 inputs):
+      mode "agent"  : ONE agent's sequential-update step of on_policy_ha_runner.py:47-124 from the HIP path's inputs to that step
+                      (the factor the HIP path handed this agent, its pre-update parameters, the shared returns): pre-update
+                      log-probs, HATRPO.train (gradient, 10 CG steps, line search), post-update log-probs, the factor it hands
+                      on.  Teacher forcing: every link of the 17-step chain is checked from identical inputs, errors of earlier
+                      links do not pile up in later ones.
+      mode "critic" : compute() + compute_returns + VCritic.train, and the REPLAY of every draw train() takes from the global
+                      CPU generator (per agent: the single-batch sampler's randperm and the old-actor construction of
+                      hatrpo.py:127-130; then the critic's real samplers) -> the generator state the HIP path must end in."""
+    import time as _time
+    T, n_threads, A = w["T"], payload["n_threads"], w["A"]
+    rnn = bool(w.get("rnn"))
+    O.set_work_dtype(dt)
+    try:
+        t0 = _time.perf_counter()
+        cb = payload["cbuf"]
+        vn = O.OracleValueNorm()
+        st0 = payload["st0"]
+        vn.load_state(dict(running_mean=float(st0[0]), running_mean_sq=float(st0[1]), debiasing_term=float(st0[2])))
+        so = cb.get("share_obs")
+        cbuf = O.OracleCriticBufferEP(np.zeros((T + 1, n_threads, 1), dtype=np.float32) if so is None else so.copy(), cb["rewards"].copy(),
+                                      cb["value_preds"].copy(), cb["masks"].copy(), cb["bad_masks"].copy())
+        if cb.get("rnn") is not None:
+            cbuf.rnn_states_critic = cb["rnn"].copy()
+        if payload["mode"] == "critic":
+            critic = O.OracleVCritic({k: v.clone() for k, v in payload["critic_sd"].items()}, cfg)
+            if pert_seed is not None:
+                _perturb_one_ulp([critic.net], pert_seed)
+            with torch.no_grad():
+                nv = (critic.get_values(so[-1], cb["rnn"][-1], cb["masks"][-1]) if rnn else critic.get_values(so[-1]))
+                nv = nv.detach().double().numpy().reshape(-1, 1)
+            cbuf.compute_returns(payload["next_value_hip"].copy(), vn, cfg)
+            # ---- the generator: replay the actors' draws, then the critic's real ones
+            torch.set_rng_state(payload["rng0"])
+            B = T * n_threads
+            shapes = {k: tuple(v) for k, v in payload["actor_shapes"]}
+            for _ in range(A):
+                torch.randperm(B // cfg.data_chunk_length if cfg.use_recurrent_policy else (n_threads if cfg.use_naive_recurrent_policy else B))
+                O.consume_policy_init_rng(shapes)
+            cinfo = critic.train(cbuf, vn)
+            return dict(nv=nv, returns=np.asarray(cbuf.returns).copy(), cinfo=cinfo,
+                        ctr=np.array([[u["value_loss"], u["grad_norm"]] for u in critic.trace]),
+                        cfin=np.asarray(critic.net.flat(), dtype=np.float64), vn=vn.state(), rng=torch.get_rng_state(),
+                        seconds=_time.perf_counter() - t0)
+        # ---- one agent
+        a = payload["agent"]
+        tc = O.TrpoConfig(**{k: args["algo"][k] for k in ("kl_threshold", "ls_step", "accept_ratio", "backtrack_coeff")})
+        actor = O.OracleHATRPO({k: v.clone() for k, v in payload["actor_sd"].items()}, cfg, tc)
+        if pert_seed is not None:
+            _perturb_one_ulp([actor], pert_seed)
+        d = payload["abuf"]
+        buf = O.OracleActorBuffer(d["obs"].copy(), d["actions"].copy(), d["logp"].copy(), d["masks"].copy(), d["active"].copy(),
+                                  None if d.get("avail") is None else d["avail"].copy(),
+                                  rnn_states=None if d.get("rnn") is None else d["rnn"].copy())
+        cbuf.compute_returns(payload["next_value_hip"].copy(), vn, cfg)
+        advantages = O.advantages_from_returns(cbuf.returns, cbuf.value_preds, vn)
+        np_work = np.float64 if dt == torch.float64 else np.float32
+        factor_in = payload["factor_in"].astype(np_work)
+        buf.update_factor(factor_in)
+        flat = lambda v: v.reshape(T * n_threads, -1)  # noqa: E731
+        avail = None if buf.available_actions is None else flat(buf.available_actions[:-1])
+        ev = (flat(buf.obs[:-1]), flat(buf.actions), avail, flat(buf.active_masks[:-1]))
+        if cfg.recurrent:
+            ev = ev + (buf.rnn_states[0], flat(buf.masks[:-1]))
+        torch.manual_seed(4242 + a)  # (the sampler's row order only changes the order of the sums)
+        old_logp, _, _ = actor.evaluate_actions(*ev)
+        info = actor.train(buf, advantages.copy())
+        new_logp, _, _ = actor.evaluate_actions(*ev)
+        agg = getattr(torch, cfg.action_aggregation)
+        factor_out = factor_in * agg(torch.exp(new_logp - old_logp), dim=-1).reshape(T, n_threads, 1).detach().numpy()
+        u = actor.trace[-1] if actor.trace else {}
+        return dict(agent=a, info=info, trace={k: (bool(v) if k == "accepted" else float(v)) for k, v in u.items() if k in TRPO_TRACE_KEYS},
+                    fin=actor.flat().numpy().astype(np.float64), factor_out=np.asarray(factor_out, dtype=np.float64),
+                    seconds=_time.perf_counter() - t0)
+    finally:
+        O.set_work_dtype(torch.float32)
+
+
+def _oracle_launch(payload: dict, plan, keep_grad: bool, threads: int = 0) -> dict:
+    """One worker process per entry of ``plan`` [(tag, dtype name, one-ulp seed | None)] (tests/oracle_worker.py; the payload
+    travels through one file in a temporary directory); returns the handle ``_oracle_collect`` waits on.  With the core-slot
+    scheduler active (tests/oracle_sched.py, prefetch_full_size) the workers are queued on it -- 16 threads on 16 logical CPUs of
+    their own each -- otherwise they start right away."""
     import subprocess
     import sys
     import tempfile
+    from tests import oracle_sched
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     td = tempfile.TemporaryDirectory(prefix="harl_oracle_")
     pin = os.path.join(td.name, "payload.pt")
     torch.save(payload, pin)
+    nthr = str(threads or int(os.environ.get("HARL_ORACLE_THREADS") or 16))
     procs = []
-    for k, (tag, dtn, seed) in enumerate(plan):
+    for tag, dtn, seed in plan:
         pout = os.path.join(td.name, f"{tag}.pt")
-        mine = None if cores is None else cores[k]
-        nthr = str(len(mine) if mine else (threads or int(os.environ.get("HARL_ORACLE_THREADS") or 16)))
         env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""), OMP_NUM_THREADS=nthr,
-                   HARL_ORACLE_THREADS=nthr, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="", OMP_WAIT_POLICY="PASSIVE",
-                   HARL_ORACLE_CORES=",".join(str(c) for c in mine) if mine else "")
+                   HARL_ORACLE_THREADS=nthr, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="", OMP_WAIT_POLICY="PASSIVE")
         cmd = [sys.executable, "-m", "tests.oracle_worker", pin, pout, tag, dtn, "none" if seed is None else str(seed), str(int(keep_grad))]
-        procs.append((tag, pout, subprocess.Popen(cmd, cwd=root, env=env)))
+        if oracle_sched.ACTIVE is not None:
+            procs.append((tag, pout, oracle_sched.ACTIVE.submit(cmd, env, root)))
+        else:
+            procs.append((tag, pout, subprocess.Popen(cmd, cwd=root, env=env)))
     return dict(td=td, procs=procs)
 
 
 def _oracle_collect(handle: dict) -> dict:
     runs = {}
+    limit = float(os.environ.get("HARL_ORACLE_TIMEOUT_S", "1500"))
     try:
         for tag, pout, pr in handle["procs"]:
-            rc = pr.wait(timeout=float(os.environ.get("HARL_ORACLE_TIMEOUT_S", "1500")))
+            rc = pr.wait(timeout=limit)
             if rc != 0:
                 raise RuntimeError(f"oracle worker {tag} failed with exit code {rc}")
             runs[tag] = torch.load(pout, weights_only=False)
     finally:
         for _, _, pr in handle["procs"]:
-            if pr.poll() is None:
-                pr.kill()
+            p_ = getattr(pr, "proc", pr)
+            if p_ is not None and p_.poll() is None:
+                p_.kill()
         handle["td"].cleanup()
     return runs
 
@@ -1391,6 +1477,8 @@ def _bench_hip_step(n_threads: int, keep_grad: bool = False, logp: str = "recipe
     cum = torch.stack(r.critic._trace).double().cpu().numpy()
     gctr = np.diff(np.concatenate([np.zeros((1, cum.shape[1])), cum]), axis=0)[:, :2]
     gfin = [npy(a_.actor.flat_reference()) for a_ in r.actor]
+    # the factor every agent was handed (on_policy_ha_runner.py:56: actor_buffer[agent].update_factor(factor)) stays in its buffer
+    gfactor = [npy(b.factor) for b in r.actor_buffer] if trpo else None
     gcfin = npy(r.critic.critic.flat_param)
     gvn = npy(r.value_normalizer.stats)
     shapes = dict(actor=[(k, tuple(v.shape)) for k, v in actor_sd[0].items()], critic=[(k, tuple(v.shape)) for k, v in critic_sd.items()])
@@ -1401,7 +1489,7 @@ def _bench_hip_step(n_threads: int, keep_grad: bool = False, logp: str = "recipe
     payload = dict(workload=workload, n_threads=n_threads, actor_sd=actor_sd, critic_sd=critic_sd, abuf=abuf_np, cbuf=cbuf_np,
                    st0=st0, rng0=rng0, next_value_hip=next_value_hip)
     hip = dict(next_value=next_value_hip, returns=returns_hip, rng=rng_hip, atr=gtr, ctr=gctr, infos=ginfos, cinfo=gcinfo,
-               fin=gfin, cfin=gcfin, vn=gvn, grads=gtaps if keep_grad else None)
+               fin=gfin, cfin=gcfin, vn=gvn, grads=gtaps if keep_grad else None, factor=gfactor)
     return hip, payload, shapes, dict(T=T, A=A, actor_sd=actor_sd, abuf=abuf_np, cfg=cfg)
 
 
@@ -1416,64 +1504,110 @@ def _oracle_plan(with_f64: bool, n_pert: int):
 # suite's 859 s.  `prefetch_full_size` (called by a session fixture, tests/conftest.py) runs the HIP step of every selected
 # full-size check right away -- seconds each -- and starts all their oracle workers at once; the tests collect the results
 # at the end of the file, by which time the ~190 other tests have run next to the workers.
-FULL_SIZE = {  # key -> (workload, logp, n_threads, n_pert, float64 twin, host cores per oracle worker)   [test -> key: conftest]
-    # (humanoid17: two one-ulp twins instead of the float64 one -- 17 agents x 204 800 rows x 11 double-backward passes in
-    # float64 would be the longest job of the whole suite by a factor; the bar needs twins, not float64 specifically)
-    "humanoid17": ("humanoid17", "recipe", 1024, 2, False, 28),
-    "cheetah6": ("cheetah6", "recipe", 4096, 1, True, 12),
-    "hatrpo_gru128": ("hatrpo_gru128", "recipe", 512, 1, True, 10),
-    "mpe_onpolicy": ("mpe", "onpolicy", 4096, 3, True, 4),
-    "mpe": ("mpe", "recipe", 4096, 2, True, 4),
-    "smac3s5z": ("smac3s5z", "recipe", 512, 1, True, 4),
+FULL_SIZE = {  # key -> (workload, logp, n_threads, n_pert)   [test name -> key: tests/conftest.py]; heaviest first
+    "cheetah6": ("cheetah6", "recipe", 4096, 1),
+    "mpe_onpolicy": ("mpe", "onpolicy", 4096, 3),
+    "mpe": ("mpe", "recipe", 4096, 2),
+    "smac3s5z": ("smac3s5z", "recipe", 512, 1),
+    # HATRPO workloads: teacher-forced pieces (_oracle_trpo_piece) -- the agents checked at the measured size, each in fp32 and
+    # float64, and the critic; the other agents' links of the chain are the HIP path's own (their oracle counterparts would
+    # take 70 s of 16 host cores each)
+    "humanoid17": ("humanoid17", "recipe", 1024, (0, 1, 8, 16)),
+    "hatrpo_gru128": ("hatrpo_gru128", "recipe", 512, (0, 3, 7)),
 }
 MAIN_PROCESS_CORES = 32  # logical CPUs the test process keeps for itself while oracle workers run
 _PREFETCH: Dict[tuple, dict] = {}
 
 
+def _trpo_launch(hip: dict, payload: dict, shapes: dict, agents) -> dict:
+    """Queue the pieces of a HATRPO workload's comparison: per checked agent one payload (its buffers and parameters, the factor
+    the HIP path handed it, the small critic-buffer arrays) run in fp32 and float64; one critic payload (fp32 + float64)."""
+    small = {k: payload["cbuf"][k] for k in ("rewards", "value_preds", "masks", "bad_masks")}
+    small["rnn"] = payload["cbuf"].get("rnn")
+    common = dict(workload=payload["workload"], n_threads=payload["n_threads"], st0=payload["st0"], rng0=payload["rng0"],
+                  next_value_hip=payload["next_value_hip"])
+    handles = {}
+    for a in agents:
+        pl = dict(common, mode="agent", agent=a, actor_sd=payload["actor_sd"][a], abuf=payload["abuf"][a], cbuf=small,
+                  factor_in=hip["factor"][a])
+        handles[a] = _oracle_launch(pl, [("f32", "f32", None), ("f64", "f64", None)], False)
+    pl = dict(common, mode="critic", critic_sd=payload["critic_sd"], cbuf=payload["cbuf"], actor_shapes=shapes["actor"])
+    handles["critic"] = _oracle_launch(pl, [("f32", "f32", None), ("f64", "f64", None)], False)
+    return handles
+
+
 def prefetch_full_size(keys) -> None:
-    """HIP step + oracle worker launch for every key of FULL_SIZE in ``keys`` (heaviest first).  Failures are kept and raised by
-    the test that asks for the result, not here.  Hosts with < 64 CPUs (no room for worker processes) do nothing: the checks
-    then run inline as before.
+    """HIP step + oracle worker launch for every key of FULL_SIZE in ``keys``.  Failures are kept and raised by the test that asks
+    for the result, not here.  Hosts with < 64 CPUs (no room for worker processes) do nothing: the checks then run inline.
     The host's logical CPUs are PARTITIONED: the test process pins itself to the first MAIN_PROCESS_CORES of its affinity set
-    (and runs that many torch threads), every oracle worker gets a disjoint slice of the rest -- the first attempt let twenty
-    16-thread workers and the test process's 128 OpenMP threads share all cores, and the suite ran ~20x slower (49 tests in
-    25 minutes: every OpenMP barrier waited for descheduled threads)."""
+    (and runs that many torch threads); the rest are slots of 16 for the oracle workers (tests/oracle_sched.py: 16 torch
+    threads each -- the thread count the measured bars were taken at; the oracle's fp32 figures depend on it -- queued in
+    submission order).  The first attempt let twenty 16-thread workers and the test process's 128 OpenMP threads share all cores:
+    the suite ran ~20x slower, every OpenMP barrier waiting for descheduled threads."""
     if (os.cpu_count() or 1) < 64 and os.environ.get("HARL_ORACLE_PARALLEL") != "force":
         return
     todo = [k for k in FULL_SIZE if k in set(keys)]
     if not todo:
         return
+    from tests import oracle_sched
     try:
         avail = sorted(os.sched_getaffinity(0))
     except AttributeError:
         avail = list(range(os.cpu_count() or 1))
-    n_main = min(MAIN_PROCESS_CORES, max(2, len(avail) // 4))
-    pool = avail[n_main:]
-    want = sum((1 + int(FULL_SIZE[k][4]) + FULL_SIZE[k][3]) * FULL_SIZE[k][5] for k in todo)
-    scale = min(1.0, len(pool) / max(1, want))
+    main, slots = oracle_sched.partition(avail, min(MAIN_PROCESS_CORES, max(2, len(avail) // 4)))
     try:
-        os.sched_setaffinity(0, avail[:n_main])
+        os.sched_setaffinity(0, main)
     except (AttributeError, OSError):
         pass
-    torch.set_num_threads(n_main)
-    nxt = 0
+    torch.set_num_threads(max(1, len(main) // 2))  # (one thread per physical core of the test process's share)
+    oracle_sched.ACTIVE = oracle_sched.Scheduler([], slots=slots)
     for k in todo:
-        workload, logp, n_threads, n_pert, with_f64, per = FULL_SIZE[k]
-        slot = (workload, logp, n_threads, n_pert)
+        workload, logp, n_threads, spec = FULL_SIZE[k]
+        slot = (workload, logp, n_threads, spec)
         try:
             hip, payload, shapes, meta = _bench_hip_step(n_threads, False, logp, workload)
-            plan = _oracle_plan(with_f64, n_pert)
-            cores = []
-            for _ in plan:
-                c = max(2, int(per * scale))
-                cores.append(pool[nxt:nxt + c] or pool[-c:])
-                nxt += c
-            handle = _oracle_launch(payload, plan, False, cores=cores)
+            if isinstance(spec, tuple):  # HATRPO: teacher-forced pieces
+                handle = _trpo_launch(hip, payload, shapes, spec)
+            else:
+                handle = _oracle_launch(payload, _oracle_plan(True, spec), False)
             del payload
             _PREFETCH[slot] = dict(hip=hip, shapes=shapes, meta=meta, handle=handle)
         except Exception as e:  # noqa: BLE001 -- re-raised by the test of this check
             _PREFETCH[slot] = dict(error=e)
         torch.cuda.empty_cache()
+
+
+def _trpo_config_runs(workload: str, n_threads: int, agents):
+    """(hip dict, {agent: {"f32": .., "f64": ..}}, {"f32": .., "f64": ..} critic runs, meta) of a HATRPO workload: collected from
+    the session's prefetch, or computed here (worker processes on big hosts, in-process otherwise)."""
+    slot = (workload, "recipe", n_threads, tuple(agents))
+    pre = _PREFETCH.pop(slot, None)
+    if pre is not None:
+        if "error" in pre:
+            raise pre["error"]
+        hip, handles, meta = pre["hip"], pre["handle"], pre["meta"]
+    else:
+        hip, payload, shapes, meta = _bench_hip_step(n_threads, False, "recipe", workload)
+        mode = os.environ.get("HARL_ORACLE_PARALLEL", "auto")
+        if mode != "force" and ((os.cpu_count() or 1) < 64 or mode == "0"):
+            handles = None
+            small = {k: payload["cbuf"][k] for k in ("rewards", "value_preds", "masks", "bad_masks")}
+            small["rnn"] = payload["cbuf"].get("rnn")
+            common = dict(workload=workload, n_threads=n_threads, st0=payload["st0"], rng0=payload["rng0"],
+                          next_value_hip=payload["next_value_hip"])
+            runs = {}
+            for a in agents:
+                pl = dict(common, mode="agent", agent=a, actor_sd=payload["actor_sd"][a], abuf=payload["abuf"][a], cbuf=small,
+                          factor_in=hip["factor"][a])
+                runs[a] = {t: _oracle_bench_run(pl, t, t, None, False) for t in ("f32", "f64")}
+            pl = dict(common, mode="critic", critic_sd=payload["critic_sd"], cbuf=payload["cbuf"], actor_shapes=shapes["actor"])
+            crit = {t: _oracle_bench_run(pl, t, t, None, False) for t in ("f32", "f64")}
+            return hip, runs, crit, meta
+        handles = _trpo_launch(hip, payload, shapes, agents)
+        del payload
+    runs = {a: _oracle_collect(handles[a]) for a in agents}
+    crit = _oracle_collect(handles["critic"])
+    return hip, runs, crit, meta
 
 
 def _bench_config_runs(n_threads: int, with_f64: bool, keep_grad: bool = False, logp: str = "recipe", n_pert: int = 0,
@@ -1617,34 +1751,34 @@ def check_bench_config_parity(logp: str = "recipe", n_threads: int = 4096, n_per
     return out
 
 
-def check_bench_config_parity_trpo(workload: str = "humanoid17", n_threads: int = 1024, n_pert: int = 1,
-                                   with_f64: bool = True) -> Dict[str, float]:
+def check_bench_config_parity_trpo(workload: str = "humanoid17", n_threads: int = 1024, agents=(0, 1, 8, 16)) -> Dict[str, float]:
     """A HATRPO bench workload at its MEASURED size against the oracle: `humanoid17` (17 agents x
     204 800 rows, obs 393, MLP [128]x3, hatrpo.yaml defaults) or `hatrpo_gru128` (8 agents, 128-wide GRU, Discrete(14) with
-    unavailable actions, chunks of 10) -- compute() + train() on identical buffer contents, the oracle (hatrpo.py:37-194,
-    trpo_util.py:96-158: double backward, 10 CG steps, backtracking line search) in fp32, float64 and one one-ulp twin in worker
-    processes.  Asserted:
-      * returns and the CPU generator's final state bit-exact; the critic's value of slot T;
-      * per agent, in update order, the SAME accept / reject decision and the SAME number of backtracks as the fp32 oracle --
-        integers, no tolerance (`linesearch_decision_mismatch`, `linesearch_backtracks_mismatch`) -- unless the oracle itself
-        decides differently in float64 or from parameters one ulp away for that agent (then the decision is not a property of
-        the algorithm at fp32 and the agent is counted in `_agents_with_oracle_own_disagreement`, reported, excluded);
-      * kl, loss (the surrogate at theta_old), loss_improve, expected_improve, dist_entropy, ratio, step_size: pooled over the
-        agents on the measured bar max(1e-5, 2 x the fp32 oracle's own distance from its float64 / one-ulp twins), agents with
-        equal decisions only, plus flat ceilings on the raw figures (tests/test_gpu_parity.py);
-      * the critic: 1e-5 flat (feed-forward) / pooled (recurrent); final parameters pooled."""
+    unavailable actions, chunks of 10).  The HIP path runs the whole compute() + train(); the oracle (hatrpo.py:37-194,
+    trpo_util.py:96-158: double backward, 10 CG steps, backtracking line search) re-runs the sequential-update step of the
+    agents in ``agents`` -- each from the inputs the HIP path gave that step: the factor it was handed, its pre-update
+    parameters, the shared returns -- in fp32 and in float64, and the critic, as separate worker processes (the 17-agent chain
+    in one process is > 20 minutes of host time; the pieces take ~1-2 minutes side by side).  Teacher forcing: every checked link
+    of the factor chain starts from identical inputs, so nothing upstream piles up in it.  Asserted:
+      * returns bit-exact; the CPU generator's final state (the oracle side replays every draw of train()); the value of slot T;
+      * per checked agent the SAME accept / reject decision and the SAME number of backtracks as the fp32 oracle -- integers,
+        no tolerance -- unless the oracle's own float64 twin decides differently for that agent (reported, excluded);
+      * kl, loss (surrogate at theta_old), loss_improve, expected_improve, dist_entropy, ratio, step_size, the agent's final
+        parameters and the FACTOR IT HANDS ON (819 200-entry array against the HIP path's input of the next agent): pooled over
+        the checked agents on the measured bar max(1e-5, 2 x the fp32 oracle's own distance from float64), flat ceilings on the
+        raw figures in the test;
+      * the critic: 1e-5 flat (feed-forward) / measured bar (recurrent)."""
     import bench as _bench
     out: Dict[str, float] = {}
-    hip, runs, _shapes, meta = _bench_config_runs(n_threads, with_f64, n_pert=n_pert, workload=workload)
+    hip, runs, crit, meta = _trpo_config_runs(workload, n_threads, agents)
     T, A = meta["T"], meta["A"]
     recurrent = bool(_bench.WORKLOADS[workload].get("rnn"))
-    o = runs["f32"]
-    perts = [runs[k] for k in sorted(runs) if k.startswith("pert")]
-    twin_runs = ([runs["f64"]] if "f64" in runs else []) + perts  # the fp32 oracle's own twins: float64 and / or one-ulp starts
-    assert twin_runs, "the measured bars need at least one twin run of the oracle"
-    out["_oracle_run_seconds"] = " ".join(f"{k}:{v['seconds']:.0f}" for k, v in sorted(runs.items()))
-    out["_oracle_seconds"] = float(sum(v["seconds"] for v in runs.values()))
-    out["_oracle_wall_seconds_max"] = float(max(v["seconds"] for v in runs.values()))
+    o, o64 = crit["f32"], crit["f64"]
+    secs = [v["seconds"] for r_ in runs.values() for v in r_.values()] + [o["seconds"], o64["seconds"]]
+    out["_oracle_seconds"] = float(sum(secs))
+    out["_oracle_wall_seconds_max"] = float(max(secs))
+    out["_oracle_run_seconds"] = " ".join(f"a{a}:{r_['f32']['seconds']:.0f}/{r_['f64']['seconds']:.0f}" for a, r_ in runs.items()) + \
+        f" critic:{o['seconds']:.0f}/{o64['seconds']:.0f}"
     out["next_value_vec_rel"] = vec_rel_err(hip["next_value"], o["nv"])
     out["returns_mismatch"] = float(np.sum(hip["returns"][:T] != o["returns"][:T].astype(np.float32)))
     out["rng_state_mismatch"] = float(not torch.equal(hip["rng"], o["rng"]))
@@ -1658,58 +1792,60 @@ def check_bench_config_parity_trpo(workload: str = "humanoid17", n_threads: int 
             return int(u["backtracks"])
         return int(round(math.log(max(u["fraction"], 1e-300)) / math.log(0.8)))
 
-    g_ = [hip["atr"][a][0] for a in range(A)]
-    o_ = [o["atr"][a][0] for a in range(A)]
-    twins = [[run["atr"][a][0] for a in range(A)] for run in twin_runs]
-    stable = [all(tw[a]["accepted"] == o_[a]["accepted"] and bt(tw[a]) == bt(o_[a]) for tw in twins) for a in range(A)]
-    # the sequential factor couples the agents: once one agent's decision differs, everything after it sees another factor
-    first_unstable = next((a for a in range(A) if not stable[a]), A)
-    first_diff = next((a for a in range(A) if g_[a]["accepted"] != o_[a]["accepted"] or bt(g_[a]) != bt(o_[a])), A)
-    out["_agents"] = float(A)
-    out["_agents_with_oracle_own_disagreement"] = float(A - sum(stable))
-    out["_first_agent_with_oracle_own_disagreement"] = float(first_unstable)
-    out["_hip_accepted"] = float(sum(bool(u["accepted"]) for u in g_))
-    out["_oracle_accepted"] = float(sum(bool(u["accepted"]) for u in o_))
-    out["_hip_backtracks_total"] = float(sum(bt(u) for u in g_))
-    out["_oracle_backtracks_total"] = float(sum(bt(u) for u in o_))
-    out["_decisions_hip"] = "".join(("A" if u["accepted"] else "R") + str(bt(u)) + " " for u in g_).strip()
-    out["_decisions_oracle"] = "".join(("A" if u["accepted"] else "R") + str(bt(u)) + " " for u in o_).strip()
-    out["_decisions_oracle_twin0"] = "".join(("A" if u["accepted"] else "R") + str(bt(u)) + " " for u in twins[0]).strip()
-    ok_upto = min(first_unstable, A)  # agents in front of the oracle's own first disagreement: decisions must be identical
-    out["linesearch_decision_mismatch"] = float(sum(g_[a]["accepted"] != o_[a]["accepted"] for a in range(ok_upto)))
-    out["linesearch_backtracks_mismatch"] = float(sum(bt(g_[a]) != bt(o_[a]) for a in range(ok_upto)))
-    cmp_agents = list(range(min(ok_upto, first_diff)))  # figures are comparable while both sides walked the same path
+    dec = lambda u: ("A" if u["accepted"] else "R") + str(bt(u))  # noqa: E731
+    g_ = {a: hip["atr"][a][0] for a in agents}
+    o_ = {a: runs[a]["f32"]["trace"] for a in agents}
+    t_ = {a: runs[a]["f64"]["trace"] for a in agents}
+    out["_agents_checked"] = " ".join(str(a) for a in agents)
+    out["_decisions_hip_all_agents"] = " ".join(dec(hip["atr"][a][0]) for a in range(A))
+    out["_decisions_hip"] = " ".join(dec(g_[a]) for a in agents)
+    out["_decisions_oracle"] = " ".join(dec(o_[a]) for a in agents)
+    out["_decisions_oracle_f64"] = " ".join(dec(t_[a]) for a in agents)
+    stable = [a for a in agents if dec(o_[a]) == dec(t_[a])]
+    out["_agents_with_oracle_own_disagreement"] = float(len(agents) - len(stable))
+    out["linesearch_decision_mismatch"] = float(sum(g_[a]["accepted"] != o_[a]["accepted"] for a in stable))
+    out["linesearch_backtracks_mismatch"] = float(sum(bt(g_[a]) != bt(o_[a]) for a in stable))
+    cmp_agents = [a for a in stable if dec(g_[a]) == dec(o_[a])]  # figures are comparable where both sides walked the same path
     out["_agents_compared"] = float(len(cmp_agents))
     for nm in ("kl", "loss", "loss_improve", "expected_improve", "dist_entropy", "ratio", "step_size"):
         if not cmp_agents:
             break
         get = lambda us, nm=nm: np.array([us[a][nm] for a in cmp_agents], dtype=np.float64)  # noqa: E731
         err = float(rel(get(g_), get(o_)).max())
-        floor = max(float(rel(get(o_), get(tw)).max()) for tw in twins)
+        floor = float(rel(get(o_), get(t_)).max())
         out[f"_trpo_{nm}_rel"] = err
         out[f"_trpo_{nm}_oracle_own_uncertainty"] = floor
         out[f"trpo_{nm}_excess"] = err / max(1e-5, NOISE_FACTOR * floor)
-        out[f"_first_update_{nm}_rel"] = float(rel(g_[0][nm], o_[0][nm]))
+    # final parameters of the checked agents; the factor each one hands on = the HIP path's input of the next agent
+    worst, floor, fworst, ffloor, links = 0.0, 0.0, 0.0, 0.0, 0
+    for a in cmp_agents:
+        worst = max(worst, vec_rel_err(hip["fin"][a], runs[a]["f32"]["fin"]))
+        floor = max(floor, vec_rel_err(runs[a]["f32"]["fin"], runs[a]["f64"]["fin"]))
+        if a + 1 < A:
+            links += 1
+            want = runs[a]["f32"]["factor_out"].reshape(-1)
+            fworst = max(fworst, vec_rel_err(hip["factor"][a + 1].reshape(-1), want))
+            ffloor = max(ffloor, vec_rel_err(want, runs[a]["f64"]["factor_out"].reshape(-1)))
+            out[f"_factor_after_agent{a}_max_abs_rel"] = float(np.max(np.abs(hip["factor"][a + 1].reshape(-1) - want) / (np.abs(want) + 1e-30)))
+    out["_actor_final_param_vec_rel_max"] = worst
+    out["_actor_final_param_oracle_own_uncertainty"] = floor
+    out["actor_final_param_excess"] = worst / max(1e-5, NOISE_FACTOR * floor)
+    out["_factor_links_checked"] = float(links)
+    out["_factor_vec_rel_max"] = fworst
+    out["_factor_oracle_own_uncertainty"] = ffloor
+    out["factor_excess"] = fworst / max(1e-5, NOISE_FACTOR * ffloor)
     for c, nm in enumerate(("value_loss", "grad_norm")):
         err = float(rel(hip["ctr"][:, c], o["ctr"][:, c]).max())
         if recurrent:
-            floor = max(float(rel(tw["ctr"][:, c], o["ctr"][:, c]).max()) for tw in twin_runs)
+            fl = float(rel(o["ctr"][:, c], o64["ctr"][:, c]).max())
             out[f"_critic_update_{nm}_rel"] = err
-            out[f"critic_update_{nm}_excess"] = err / max(1e-5, NOISE_FACTOR * floor)
+            out[f"critic_update_{nm}_excess"] = err / max(1e-5, NOISE_FACTOR * fl)
         else:
             out[f"critic_update_{nm}_rel"] = err
     ovn = o["vn"]
     out["vn_final_rel"] = rel_err(hip["vn"], [float(np.asarray(ovn[k]).reshape(-1)[0]) for k in ("running_mean", "running_mean_sq", "debiasing_term")])
-    worst_raw, floor = 0.0, 0.0
-    for a in cmp_agents:
-        raw = vec_rel_err(hip["fin"][a], o["fin"][a])
-        worst_raw = max(worst_raw, raw)
-        floor = max([floor] + [vec_rel_err(tw["fin"][a], o["fin"][a]) for tw in twin_runs])
-    out["_actor_final_param_vec_rel_max"] = worst_raw
-    out["_actor_final_param_oracle_own_uncertainty"] = floor
-    out["actor_final_param_excess"] = worst_raw / max(1e-5, NOISE_FACTOR * floor)
     out["_critic_final_param_vec_rel"] = vec_rel_err(hip["cfin"], o["cfin"])
-    cfloor = max(vec_rel_err(tw["cfin"], o["cfin"]) for tw in twin_runs)
+    cfloor = vec_rel_err(o["cfin"], o64["cfin"])
     out["_critic_final_param_oracle_own_uncertainty"] = cfloor
     out["critic_final_param_excess"] = out["_critic_final_param_vec_rel"] / max(1e-5, NOISE_FACTOR * cfloor)
     dump_parity(f"bench_config_parity_{workload}_full_size", out)
@@ -1782,6 +1918,13 @@ def check_generator_api(name: str) -> Dict[str, float]:
     return out
 
 
+# the three ways the wide GEMMs get their weight fragments: streamed from L2, first eight k-steps resident in LDS (round 6, the
+# default from 512 slabs on), 32-column panels shared through LDS (round 5, opt-in)
+WIDE_MODES = (("stream", {"HARL_WIDE_SHARED": "0", "HARL_WIDE_RESIDENT": "0"}),
+              ("resident", {"HARL_WIDE_SHARED": "0", "HARL_WIDE_RESIDENT": "1"}),
+              ("shared", {"HARL_WIDE_SHARED": "1", "HARL_WIDE_RESIDENT": "0"}))
+
+
 def check_wide_shared(M: int = 70000) -> Dict[str, float]:
     """The wide GEMMs with their weight fragments shared through LDS (k_fwd_wide_sh, round 5) against the streaming kernel they
     replace from 512 slabs on (k_fwd_wide): same MFMA sequence per slab, so the outputs must agree BIT FOR BIT -- forward of a
@@ -1802,8 +1945,8 @@ def check_wide_shared(M: int = 70000) -> Dict[str, float]:
         mask = torch.randint(-2 ** 31, 2 ** 31 - 1, (ns * 2 * 64,), device=DEV, dtype=torch.int32, generator=g)
         rstd = torch.rand(mp, device=DEV, generator=g) + 0.5
         res = {}
-        for mode in ("0", "1"):
-            os.environ["HARL_WIDE_SHARED"] = mode
+        for mode, env in WIDE_MODES:
+            os.environ.update(env)
             xo, mo, ro = torch.zeros(mp * H, device=DEV), torch.zeros(ns * 2 * 64, dtype=torch.int32, device=DEV), torch.zeros(mp, device=DEV)
             call("harl_mlp_fwd_wide", ptr(x0n), M, KP, ptr(W), D, ptr(b), H, ptr(wimg), ptr(xo), ptr(mo), ptr(ro), stream())
             xd = torch.zeros(mp * H, device=DEV)
@@ -1813,8 +1956,9 @@ def check_wide_shared(M: int = 70000) -> Dict[str, float]:
             torch.cuda.synchronize()
             res[mode] = (xo, mo, ro, xd, zr)
         for k, nm in enumerate(("fwd_x", "fwd_mask", "fwd_rstd", "tangent", "raw")):  # (whole images: the padding rows see the same inputs)
-            out[f"D{D}_{nm}_mismatch"] = float((res["0"][k] != res["1"][k]).sum().item())
-        out[f"D{D}_fwd_all_zero_count"] = float((res["1"][0] != 0).sum().item() == 0)
+            out[f"D{D}_{nm}_mismatch"] = float((res["stream"][k] != res["shared"][k]).sum().item())
+            out[f"D{D}_{nm}_resident_mismatch"] = float((res["stream"][k] != res["resident"][k]).sum().item())
+        out[f"D{D}_fwd_all_zero_count"] = float((res["shared"][0] != 0).sum().item() == 0)
     # one-launch hidden tangent
     xin, xdot = rn(mp * H), rn(mp * H)
     Wp, Wd, bd = rn(H * H) * 0.1, rn(H * H) * 0.1, rn(H) * 0.1
@@ -1823,16 +1967,18 @@ def check_wide_shared(M: int = 70000) -> Dict[str, float]:
     mask = torch.randint(-2 ** 31, 2 ** 31 - 1, (ns * 2 * 64,), device=DEV, dtype=torch.int32, generator=g)
     rstd = torch.rand(mp, device=DEV, generator=g) + 0.5
     res = {}
-    for mode in ("0", "1"):
-        os.environ["HARL_WIDE_SHARED"] = mode
+    for mode, env in WIDE_MODES:
+        os.environ.update(env)
         o = torch.zeros(mp * H, device=DEV)
         call("harl_mlp_tangent_hidden2", ptr(xdot), ptr(xin), M, H, H, ptr(Wp), ptr(Wd), ptr(bd), ptr(wimg), ptr(xh1), ptr(mask), ptr(rstd),
              ptr(o), stream())
         torch.cuda.synchronize()
         res[mode] = o
     os.environ.pop("HARL_WIDE_SHARED", None)
-    out["tangent_hidden2_mismatch"] = float((res["0"] != res["1"]).sum().item())
-    out["tangent_hidden2_nonzero_count"] = float((res["1"] != 0).sum().item() == 0)
+    os.environ.pop("HARL_WIDE_RESIDENT", None)
+    out["tangent_hidden2_mismatch"] = float((res["stream"] != res["shared"]).sum().item())
+    out["tangent_hidden2_resident_mismatch"] = float((res["stream"] != res["resident"]).sum().item())
+    out["tangent_hidden2_nonzero_count"] = float((res["shared"] != 0).sum().item() == 0)
     return out
 
 

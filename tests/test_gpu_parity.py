@@ -316,20 +316,22 @@ def test_smac3s5z_full_size_against_oracle():
 
 def _assert_trpo_full_size(res, tol=TOL):
     _assert_all(res, tol=tol)
-    assert res["_agents_compared"] >= 1.0, res
-    # flat ceilings on the raw figures next to the pooled measured bars (what "noise" may mean)
+    assert res["_agents_compared"] >= 2.0 and res["_factor_links_checked"] >= 1.0, res
+    # flat ceilings on the raw figures next to the measured bars (what "noise" may mean)
     for k, cap in (("_trpo_kl_rel", 2e-2), ("_trpo_loss_rel", 1e-3), ("_trpo_dist_entropy_rel", 1e-4), ("_trpo_ratio_rel", 1e-3),
-                   ("_trpo_step_size_rel", 2e-2), ("_trpo_expected_improve_rel", 2e-2)):
+                   ("_trpo_step_size_rel", 2e-2), ("_trpo_expected_improve_rel", 2e-2), ("_factor_vec_rel_max", 1e-3),
+                   ("_actor_final_param_vec_rel_max", 1e-2)):
         assert res[k] < cap, (k, res[k])
 
 
 def test_humanoid17_full_size_against_oracle():
     """BASELINE configs[4] at the size `bench.py` measures it -- Humanoid-17x1, HATRPO, 17 agents x 204 800 rows (T = 200, 1024
     rollout threads), obs 393, MLP [128, 128, 128], CG 10 + line search -- against the oracle on identical buffer contents
-    (gpu_checks.check_bench_config_parity_trpo): returns / generator state bit-exact, per agent the same accept / reject decision
-    and the same number of backtracks as the fp32 oracle (integers), the five statistics and the step size on pooled measured
-    bars, the critic 1e-5 flat."""
-    res = _G().check_bench_config_parity_trpo("humanoid17", 1024, 2, with_f64=False)  # (two one-ulp twins: gpu_checks.FULL_SIZE)
+    (gpu_checks.check_bench_config_parity_trpo): returns / generator state bit-exact; for agents 0, 1, 8 and 16 of the chain --
+    each re-run by the oracle from the inputs the HIP path gave that step -- the same accept / reject decision and the same number
+    of backtracks (integers), the five statistics, the step size, the final parameters and the factor handed to the next agent
+    on measured bars; the critic 1e-5 flat."""
+    res = _G().check_bench_config_parity_trpo("humanoid17", 1024, (0, 1, 8, 16))
     print("humanoid17 full-size parity:", {k: (f"{v:.3e}" if isinstance(v, float) else v) for k, v in res.items()})
     _assert_trpo_full_size(res)
 
@@ -339,7 +341,7 @@ def test_hatrpo_gru128_full_size_against_oracle():
     (8 agents x 81 920 rows, Discrete(14) with 30 % unavailable actions, chunks of 10): the composed per-step GRU and its
     forward-mode tangent at their measured size against the oracle's double backward; same assertions as the 17-agent check,
     the recurrent critic on the pooled bar."""
-    res = _G().check_bench_config_parity_trpo("hatrpo_gru128", 512, 1)
+    res = _G().check_bench_config_parity_trpo("hatrpo_gru128", 512, (0, 3, 7))
     print("hatrpo_gru128 full-size parity:", {k: (f"{v:.3e}" if isinstance(v, float) else v) for k, v in res.items()})
     _assert_trpo_full_size(res, tol=2e-5)  # (the recurrent fixtures' bar: nothing downstream of a GRU chain is held to 1e-5 flat)
 

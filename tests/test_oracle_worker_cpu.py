@@ -106,3 +106,39 @@ def test_hatrpo_payloads_run_through_the_oracle(monkeypatch):
             assert all(np.isfinite(float(v)) for v in u.values())
         assert run["ctr"].shape == (5, 2) and len(run["fin"]) == w["A"]
         assert any(not np.array_equal(x, y) for x, y in zip(run["fin"], twin["fin"]))
+
+
+def test_hatrpo_teacher_forced_pieces_and_the_scheduler(monkeypatch):
+    """The pieces of the HATRPO full-size checks (gpu_checks._oracle_trpo_piece) on two rollout threads: one agent's step from a
+    given input factor -- fp32 in this process against the same payload through the core-slot scheduler's worker process, bit for
+    bit -- and the critic piece with its replay of the generator draws."""
+    from tests import gpu_checks as G
+    from tests import oracle_sched
+    monkeypatch.setenv("HARL_ORACLE_THREADS", "2")
+    torch.manual_seed(4)
+    w, pl = _generic_payload("hatrpo_gru128", 2, 6)
+    T, n = w["T"], 2
+    rng = np.random.default_rng(0)
+    factor_in = (1.0 + 0.1 * rng.standard_normal((T, n, 1))).astype(np.float32)
+    small = {k: pl["cbuf"][k] for k in ("rewards", "value_preds", "masks", "bad_masks")}
+    small["rnn"] = pl["cbuf"]["rnn"]
+    common = dict(workload="hatrpo_gru128", n_threads=n, st0=pl["st0"], rng0=pl["rng0"], next_value_hip=pl["next_value_hip"])
+    agent_pl = dict(common, mode="agent", agent=3, actor_sd=pl["actor_sd"][3], abuf=pl["abuf"][3], cbuf=small, factor_in=factor_in)
+    here = G._oracle_bench_run(agent_pl, "f32", "f32", None, False)
+    assert set(here["trace"]) == set(G.TRPO_TRACE_KEYS) and here["factor_out"].shape == (T, n, 1)
+    assert np.isfinite(here["factor_out"]).all() and not np.array_equal(here["factor_out"], factor_in.astype(np.float64))
+    sched = oracle_sched.Scheduler(list(range(4)), slot=2)  # two slots of two logical CPUs, three jobs: one has to queue
+    monkeypatch.setattr(oracle_sched, "ACTIVE", sched)
+    try:
+        handle = G._oracle_launch(agent_pl, [("f32", "f32", None), ("f64", "f64", None), ("pert0", "f32", 977)], False)
+        runs = G._oracle_collect(handle)
+    finally:
+        sched.shutdown()
+    assert np.array_equal(runs["f32"]["factor_out"], here["factor_out"]) and np.array_equal(runs["f32"]["fin"], here["fin"])
+    assert runs["f32"]["trace"] == here["trace"]
+    assert not np.array_equal(runs["pert0"]["fin"], here["fin"])
+    shapes = [(k, tuple(v.shape)) for k, v in pl["actor_sd"][0].items()]
+    crit = G._oracle_bench_run(dict(common, mode="critic", critic_sd=pl["critic_sd"], cbuf=pl["cbuf"], actor_shapes=shapes),
+                               "f32", "f32", None, False)
+    assert crit["ctr"].shape == (5, 2) and crit["nv"].shape == (n, 1) and np.isfinite(crit["returns"]).all()
+    assert not torch.equal(crit["rng"], pl["rng0"])

@@ -101,6 +101,26 @@ def main():
         ("gae_returns", lambda: call("harl_gae_returns", ptr(rew), ptr(vpT), ptr(mk), ptr(mk), ptr(vpT[-1].contiguous()), ptr(vn), ptr(rets), ptr(advs), T, N, 0.99, 0.9405, 1, 1, 0, s), GB(B * 24)),
         ("gradnorm_clip_adam", lambda: call("harl_gradnorm_clip_adam", ptr(pp), ptr(gg), ptr(mm), ptr(vv), P, None, 1, 10.0, 5e-4, 0.9, 0.999, 1e-5, 0.0, 0.1, 0.001, None, s), GB(P * 28)),
     ]
+    # ---- the 17-agent HATRPO shape (204 800 rows per launch, obs 393 -> KP 416): tangent / wide-input kernels of the FVP
+    B2 = 200 * 1024
+    ns2 = (B2 + 31) // 32
+    mp2 = ns2 * 32
+    x0n416 = rn(mp2 * 416)
+    W1h, W1hd = rn(H * 393) * 0.05, rn(H * 393) * 0.05
+    wimg416 = torch.empty(3 * H * 416 // 2, device=dev)
+    timg = torch.empty(3 * H * H, device=dev)
+    xa, xb, xc, xo = rn(mp2 * H), rn(mp2 * H), rn(mp2 * H), torch.empty(mp2 * H, device=dev)
+    Wd = rn(H * H) * 0.1
+    mask2_, rstd2_ = mask[:ns2 * 2 * 64], rstd[:mp2]
+    fl2 = 2.0 * B2 * H * H
+    jobs += [
+        ("h17_fwd_wide_K416", lambda: call("harl_mlp_fwd_wide", ptr(x0n416), B2, 416, ptr(W1h), 393, ptr(b), H, ptr(wimg416), ptr(xo), ptr(mask2_), ptr(rstd2_), s), GB(B2 * (1664 + 512 + 20))),
+        ("h17_tangent_wide_K416", lambda: call("harl_mlp_tangent_wide", ptr(x0n416), B2, 416, ptr(W1hd), 393, ptr(b), H, ptr(wimg416), ptr(xa), ptr(mask2_), ptr(rstd2_), ptr(xo), s), GB(B2 * (1664 + 512 + 512 + 20))),
+        ("h17_tangent_hidden2", lambda: call("harl_mlp_tangent_hidden2", ptr(xb), ptr(xa), B2, H, H, ptr(W), ptr(Wd), ptr(b), ptr(timg), ptr(xc), ptr(mask2_), ptr(rstd2_), ptr(xo), s), GB(B2 * (512 * 4 + 20))),
+        ("h17_fwd_hidden", lambda: call("harl_mlp_fwd_hidden", ptr(xa), B2, H, H, ptr(W), ptr(b), ptr(xo), ptr(mask2_), ptr(rstd2_), s), GB(B2 * (1024 + 20))),
+        ("h17_bwd_dx", lambda: call("harl_mlp_bwd_dx", ptr(xa), ptr(xb), ptr(mask2_), ptr(rstd2_), B2, H, H, ptr(W), ptr(xo), None, 0, None, 0, s), GB(B2 * (1536 + 20))),
+        ("h17_dw_hidden", lambda: call("harl_mlp_dw_partials", ptr(xa), 0, 0, H, ptr(xb), 0, 0, None, None, None, H, B2, ptr(part), n_wg, s), GB(B2 * 1024)),
+    ]
     print(f"B={B}  H={H}  reps={args.reps}  lib={_lib.LIB_PATH}")
     for name, fn, (unit, work) in jobs:
         if args.filters and not any(f in name for f in args.filters):

@@ -232,6 +232,7 @@ class HAPPO(OnPolicyBase):
         self._info = torch.zeros(4, dtype=torch.float64, device=self.device)  # fp64 sums of the per-update fp32 policy_loss, dist_entropy, grad_norm, ratio (the reference sums .item() values: happo.py:145-150)
         self._grad_tap = None
         self._trace = None  # test hook: list receiving a clone of the running statistics after every optimiser step
+        self._state_tap = None  # test hook: list receiving (parameters, exp_avg, exp_avg_sq, step) as they stand BEFORE every optimiser step
         # runner-internal: the event behind which this agent's sequential-update factor is complete (it is produced on the
         # runner's post-update stream while this agent's first forward already runs, runner.train); awaited in front of the
         # first loss launch -- the only consumer of the factor
@@ -325,6 +326,9 @@ class HAPPO(OnPolicyBase):
         net = self.actor
         net._ensure_ws(1)
         sc = net.scalars
+        if self._state_tap is not None:  # (the full-size checks re-run every update of the oracle from exactly this state)
+            o = self.actor_optimizer
+            self._state_tap.append((net.flat_param.clone(), o.exp_avg.clone(), o.exp_avg_sq.clone(), o.step_count))
         if nblk == 0:  # this rank holds no row of the (global) minibatch: contribute zeros to the all-reduce
             net.dwp.zero_()
             sc.zero_()

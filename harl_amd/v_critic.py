@@ -44,6 +44,7 @@ class VCritic:
         self._info = torch.zeros(2, dtype=torch.float64, device=self.device)  # fp64 sums of the per-update fp32 value_loss, critic_grad_norm (v_critic.py:186-187)
         self._grad_tap = None
         self._trace = None  # test hook: snapshots of the running statistics after every optimiser step
+        self._state_tap = None  # test hook: (parameters, exp_avg, exp_avg_sq, step) BEFORE every optimiser step
 
     def lr_decay(self, episode, episodes):
         lr = self.critic_lr - (self.critic_lr * ((episode - 1) / float(episodes)))
@@ -105,6 +106,9 @@ class VCritic:
             ps_kw = dict(scalars_hilo=hilo)
         # loss = mean over the (global) minibatch, times value_loss_coef before backward (v_critic.py:112,146)
         scale = float(self.value_loss_coef) / float(m_global)
+        if self._state_tap is not None:
+            o = self.critic_optimizer
+            self._state_tap.append((net.flat_param.clone(), o.exp_avg.clone(), o.exp_avg_sq.clone(), o.step_count))
         self.critic_optimizer.step(1, scale, self.use_max_grad_norm, self.max_grad_norm, self._info, **ps_kw)
         if self._trace is not None:
             self._trace.append(self._info.clone())

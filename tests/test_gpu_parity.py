@@ -278,7 +278,7 @@ def test_bench_configuration_onpolicy_against_oracle():
     What does not divide by a near-zero number is held to 1e-5 FLAT: every update's entropy, the critic throughout, the first
     update's entropy / grad-norm / ratio; the first update's policy loss (|value| ~ 2e-3) to 1e-7 absolute; the rest keeps the
     measured bar."""
-    res = _G().check_bench_config_parity(logp="onpolicy", n_pert=3)  # (worker processes: three one-ulp twins cost no wall time)
+    res = _G().check_bench_config_parity(logp="onpolicy")
     print("bench-config parity (on-policy):", {k: (f"{v:.3e}" if isinstance(v, float) else v) for k, v in res.items()})
     _assert_all(res)
     for k in ("_actor_update_dist_entropy_rel", "_first_update_dist_entropy_rel", "_first_update_grad_norm_rel", "_first_update_ratio_rel"):
@@ -294,7 +294,7 @@ def test_cheetah6_full_size_against_oracle():
     hot kernel) and to the layer-by-layer backward of a three-layer trunk at 25 slabs per wave.  Same bars as the MPE bench
     configuration: returns / generator state bit-exact, first update and critic 1e-5 flat, the rest pooled measured bars (the
     oracle in float64 and one one-ulp twin run next to the fp32 run, in worker processes on the box's host cores)."""
-    res = _G().check_bench_config_parity(workload="cheetah6", n_pert=1)
+    res = _G().check_bench_config_parity(workload="cheetah6")
     print("cheetah6 full-size parity:", {k: (f"{v:.3e}" if isinstance(v, float) else v) for k, v in res.items()})
     _assert_all(res)
 
@@ -306,7 +306,7 @@ def test_smac3s5z_full_size_against_oracle():
     full-length log-prob passes of 160 dependent steps), to `harl_build_seq` and to the recurrent critic.  Returns / generator
     state bit-exact; the critic and the first update on the recurrent fixtures' 2e-5 / measured bars (nothing downstream of a
     160-step recurrence is held to 1e-5 flat); the rest on the pooled measured bars."""
-    res = _G().check_bench_config_parity(workload="smac3s5z", n_threads=512, n_pert=1)
+    res = _G().check_bench_config_parity(workload="smac3s5z", n_threads=512)
     print("smac3s5z full-size parity:", {k: (f"{v:.3e}" if isinstance(v, float) else v) for k, v in res.items()})
     _assert_all(res, tol=2e-5)
     # measured on MI355X (profiles/r05_parity_smac3s5z_full_size.json): every actor figure of all 40 updates within 1.3e-6 of the
@@ -331,7 +331,7 @@ def test_humanoid17_full_size_against_oracle():
     each re-run by the oracle from the inputs the HIP path gave that step -- the same accept / reject decision and the same number
     of backtracks (integers), the five statistics, the step size, the final parameters and the factor handed to the next agent
     on measured bars; the critic 1e-5 flat."""
-    res = _G().check_bench_config_parity_trpo("humanoid17", 1024, (0, 1, 8, 16))
+    res = _G().check_bench_config_parity_trpo("humanoid17", 1024, (0, 8, 16))
     print("humanoid17 full-size parity:", {k: (f"{v:.3e}" if isinstance(v, float) else v) for k, v in res.items()})
     _assert_trpo_full_size(res)
 
@@ -341,7 +341,7 @@ def test_hatrpo_gru128_full_size_against_oracle():
     (8 agents x 81 920 rows, Discrete(14) with 30 % unavailable actions, chunks of 10): the composed per-step GRU and its
     forward-mode tangent at their measured size against the oracle's double backward; same assertions as the 17-agent check,
     the recurrent critic on the pooled bar."""
-    res = _G().check_bench_config_parity_trpo("hatrpo_gru128", 512, (0, 3, 7))
+    res = _G().check_bench_config_parity_trpo("hatrpo_gru128", 512, (0, 7))
     print("hatrpo_gru128 full-size parity:", {k: (f"{v:.3e}" if isinstance(v, float) else v) for k, v in res.items()})
     _assert_trpo_full_size(res, tol=2e-5)  # (the recurrent fixtures' bar: nothing downstream of a GRU chain is held to 1e-5 flat)
 

@@ -142,3 +142,55 @@ def test_hatrpo_teacher_forced_pieces_and_the_scheduler(monkeypatch):
                                "f32", "f32", None, False)
     assert crit["ctr"].shape == (5, 2) and crit["nv"].shape == (n, 1) and np.isfinite(crit["returns"]).all()
     assert not torch.equal(crit["rng"], pl["rng0"])
+
+
+def test_teacher_forcing_hook_reproduces_a_free_run_when_fed_its_own_states(monkeypatch):
+    """The forcing hook of the full-size HAPPO checks (gpu_checks._oracle_bench_run, payload['forced']): fed the states a
+    free-running oracle run went through -- parameters and Adam moments in front of every optimiser step -- the forced run must
+    reproduce that run bit for bit; fed states that are off by a factor, it must not."""
+    from oracle import harl_oracle as O
+    from tests import gpu_checks as G
+    monkeypatch.setenv("HARL_ORACLE_THREADS", "2")
+    torch.manual_seed(3)
+    pl = _payload(2)
+    taps = {}
+
+    def record(stage, obj, sample, _vn):
+        if stage != "pre":
+            return
+        flat = torch.cat([p.detach().reshape(-1) for p in obj.net.params()]).numpy().copy()
+        st = obj.net.opt.state
+        if len(st) == 0:
+            m = v = np.zeros_like(flat)
+            step = 0
+        else:
+            m = torch.cat([st[p]["exp_avg"].reshape(-1) for p in obj.net.params()]).numpy().copy()
+            v = torch.cat([st[p]["exp_avg_sq"].reshape(-1) for p in obj.net.params()]).numpy().copy()
+            step = int(st[obj.net.params()[0]]["step"])
+        taps.setdefault(id(obj), []).append((flat, m, v, step))
+
+    real_ha_train = O.ha_train
+    order = []
+
+    def spy(actors, critic, *a, **k):
+        order[:] = [id(x) for x in actors] + [id(critic)]
+        O.GRAD_HOOK = record
+        try:
+            return real_ha_train(actors, critic, *a, **k)
+        finally:
+            O.GRAD_HOOK = None
+
+    monkeypatch.setattr(O, "ha_train", spy)
+    free = G._oracle_bench_run(pl, "f32", "f32", None, False)
+    monkeypatch.setattr(O, "ha_train", real_ha_train)
+    snaps = [taps[i] for i in order]
+    assert all(len(s) == 5 for s in snaps) and snaps[0][1][3] == 1
+    pl["forced"] = dict(actor=snaps[:-1], critic=snaps[-1])
+    forced = G._oracle_bench_run(pl, "f32", "f32", None, False)
+    for x, y in zip(free["atr"], forced["atr"]):
+        assert np.array_equal(x, y)
+    assert np.array_equal(free["ctr"], forced["ctr"]) and np.array_equal(free["cfin"], forced["cfin"])
+    assert all(np.array_equal(x, y) for x, y in zip(free["fin"], forced["fin"]))
+    bad = dict(pl, forced=dict(actor=[[(f * 1.01, m, v, k) for f, m, v, k in s] for s in snaps[:-1]], critic=snaps[-1]))
+    off = G._oracle_bench_run(bad, "f32", "f32", None, False)
+    assert not np.array_equal(off["atr"][0], free["atr"][0])

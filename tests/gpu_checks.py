@@ -1227,6 +1227,37 @@ def check_full_size_properties() -> Dict[str, float]:
 TRPO_TRACE_KEYS = ("accepted", "fraction", "kl", "loss", "loss_improve", "expected_improve", "dist_entropy", "ratio", "step_size", "shs")
 
 
+def _forcing_hook(taps_of: dict):
+    """TEACHER FORCING (round 6), as an ``oracle.GRAD_HOOK``: before every optimiser step of the objects in ``taps_of`` {id(oracle
+    actor / critic): [(flat parameters, exp_avg, exp_avg_sq, step count), ...]} their parameters and Adam moments are overwritten
+    with the HIP path's state in front of the same step -- every update is compared from identical inputs, nothing a previous
+    update did differently is carried along (the free-running comparison is chaotic on the bench buffers: the same HIP step
+    against three evidence runs of the same oracle gave pooled excess ratios between 0.15 and 2.7,
+    profiles/r06_free_running_spread.md)."""
+    seen = {}
+
+    def force(stage, obj, sample, _vn):
+        if stage != "pre" or id(obj) not in taps_of:
+            return
+        n_ = seen.get(id(obj), 0)
+        seen[id(obj)] = n_ + 1
+        flat, m_, v_, step = taps_of[id(obj)][n_]
+        off = 0
+        with torch.no_grad():
+            for prm in obj.net.params():
+                n = prm.numel()
+                prm.copy_(torch.from_numpy(flat[off:off + n]).view(prm.shape).to(prm.dtype))
+                if step > 0:
+                    stt = obj.net.opt.state[prm]
+                    if "exp_avg" not in stt:
+                        stt["exp_avg"], stt["exp_avg_sq"] = torch.zeros_like(prm), torch.zeros_like(prm)
+                    stt["step"] = torch.tensor(float(step))
+                    stt["exp_avg"].copy_(torch.from_numpy(m_[off:off + n]).view(prm.shape).to(prm.dtype))
+                    stt["exp_avg_sq"].copy_(torch.from_numpy(v_[off:off + n]).view(prm.shape).to(prm.dtype))
+                off += n
+    return force
+
+
 def _oracle_bench_run(payload: dict, tag: str, dt_name: str, pert_seed, keep_grad: bool) -> dict:
     """One oracle compute() + ha_train() on the host copies in ``payload`` (see _bench_config_runs).  Runs either in this
     process or -- on hosts with enough cores -- in a worker process of its own (tests/oracle_worker.py), so that the fp32 /
@@ -1265,37 +1296,9 @@ def _oracle_bench_run(payload: dict, tag: str, dt_name: str, pert_seed, keep_gra
         vn = O.OracleValueNorm()
         vn.load_state(dict(running_mean=float(st0[0]), running_mean_sq=float(st0[1]), debiasing_term=float(st0[2])))
         if payload.get("forced") is not None and not trpo:
-            # TEACHER FORCING (round 6): before every optimiser step the oracle's parameters and Adam moments are overwritten
-            # with the HIP path's state in front of the same step -- every update is compared from identical inputs, nothing a
-            # previous update did differently is carried along (the free-running comparison is chaotic on these buffers: the
-            # same HIP step against three evidence runs of the same oracle gave pooled excess ratios between 0.15 and 2.7)
-            who = {id(a_): ("actor", k) for k, a_ in enumerate(actors)}
-            who[id(critic)] = ("critic", 0)
-            seen = {}
-
-            def force(stage, obj, sample, _vn):
-                if stage != "pre" or id(obj) not in who:
-                    return
-                kind, k = who[id(obj)]
-                n_ = seen.get(id(obj), 0)
-                seen[id(obj)] = n_ + 1
-                taps = payload["forced"]["actor"][k] if kind == "actor" else payload["forced"]["critic"]
-                flat, m_, v_, step = taps[n_]
-                off = 0
-                with torch.no_grad():
-                    for prm in obj.net.params():
-                        n = prm.numel()
-                        prm.copy_(torch.from_numpy(flat[off:off + n]).view(prm.shape).to(prm.dtype))
-                        if step > 0:
-                            stt = obj.net.opt.state[prm]
-                            if "exp_avg" not in stt:
-                                stt["step"] = torch.tensor(0.0)
-                                stt["exp_avg"], stt["exp_avg_sq"] = torch.zeros_like(prm), torch.zeros_like(prm)
-                            stt["step"] = torch.tensor(float(step))
-                            stt["exp_avg"].copy_(torch.from_numpy(m_[off:off + n]).view(prm.shape).to(prm.dtype))
-                            stt["exp_avg_sq"].copy_(torch.from_numpy(v_[off:off + n]).view(prm.shape).to(prm.dtype))
-                        off += n
-            O.GRAD_HOOK = force
+            who = {id(a_): payload["forced"]["actor"][k] for k, a_ in enumerate(actors)}
+            who[id(critic)] = payload["forced"]["critic"]
+            O.GRAD_HOOK = _forcing_hook(who)
         with torch.no_grad():  # compute(): the critic's value of slot T (on_policy_base_runner.py:462-484)
             if cbuf_np.get("rnn") is not None:
                 nv = critic.get_values(cbuf_np["share_obs"][-1], cbuf_np["rnn"][-1], cbuf_np["masks"][-1])
@@ -1367,6 +1370,8 @@ def _oracle_trpo_piece(payload: dict, w: dict, args: dict, cfg, dt, pert_seed) -
             for _ in range(A):
                 torch.randperm(B // cfg.data_chunk_length if cfg.use_recurrent_policy else (n_threads if cfg.use_naive_recurrent_policy else B))
                 O.consume_policy_init_rng(shapes)
+            if payload.get("forced_critic") is not None and pert_seed is None:  # (a one-ulp twin runs free: it IS the perturbation)
+                O.GRAD_HOOK = _forcing_hook({id(critic): payload["forced_critic"]})
             cinfo = critic.train(cbuf, vn)
             return dict(nv=nv, returns=np.asarray(cbuf.returns).copy(), cinfo=cinfo,
                         ctr=np.array([[u["value_loss"], u["grad_norm"]] for u in critic.trace]),
@@ -1403,6 +1408,7 @@ def _oracle_trpo_piece(payload: dict, w: dict, args: dict, cfg, dt, pert_seed) -
                     fin=actor.flat().numpy().astype(np.float64), factor_out=np.asarray(factor_out, dtype=np.float64),
                     seconds=_time.perf_counter() - t0)
     finally:
+        O.GRAD_HOOK = None
         O.set_work_dtype(torch.float32)
 
 
@@ -1487,11 +1493,12 @@ def _bench_hip_step(n_threads: int, keep_grad: bool = False, logp: str = "recipe
     rng0 = torch.get_rng_state()
     # ---- HIP path: one bench step (bench.one_step) with the per-update traces switched on
     gtaps = [[] for _ in r.actor]
-    forced = not trpo and not keep_grad and os.environ.get("HARL_FULLSIZE_FORCED", "1") != "0"
+    forced = not keep_grad and os.environ.get("HARL_FULLSIZE_FORCED", "1") != "0"
     if forced:  # pre-update state of every optimiser step: the oracle re-runs each update from exactly this state
-        for a_ in r.actor:
-            assert not a_.actor.md
-            a_._state_tap = []
+        if not trpo:  # (HATRPO actors take ONE step per train(): their pieces start from the initial parameters anyway)
+            for a_ in r.actor:
+                assert not a_.actor.md
+                a_._state_tap = []
         r.critic._state_tap = []
     for a_, tp in zip(r.actor, gtaps):
         a_._trace = []
@@ -1518,7 +1525,7 @@ def _bench_hip_step(n_threads: int, keep_grad: bool = False, logp: str = "recipe
     cum = torch.stack(r.critic._trace).double().cpu().numpy()
     gctr = np.diff(np.concatenate([np.zeros((1, cum.shape[1])), cum]), axis=0)[:, :2]
     forced_actor = [[(p.cpu().numpy(), m.cpu().numpy(), v.cpu().numpy(), int(k)) for p, m, v, k in a_._state_tap]
-                    for a_ in r.actor] if forced else None
+                    for a_ in r.actor] if (forced and not trpo) else None
     forced_critic = [(p.cpu().numpy(), m.cpu().numpy(), v.cpu().numpy(), int(k)) for p, m, v, k in r.critic._state_tap] if forced else None
     gfin = [npy(a_.actor.flat_reference()) for a_ in r.actor]
     # the factor every agent was handed (on_policy_ha_runner.py:56: actor_buffer[agent].update_factor(factor)) stays in its buffer
@@ -1592,7 +1599,8 @@ def _trpo_launch(hip: dict, payload: dict, shapes: dict, agents) -> dict:
         pl = dict(common, mode="agent", agent=a, actor_sd=payload["actor_sd"][a], abuf=payload["abuf"][a], cbuf=small,
                   factor_in=hip["factor"][a])
         handles[a] = _oracle_launch(pl, TRPO_AGENT_PLAN, False)
-    pl = dict(common, mode="critic", critic_sd=payload["critic_sd"], cbuf=payload["cbuf"], actor_shapes=shapes["actor"])
+    pl = dict(common, mode="critic", critic_sd=payload["critic_sd"], cbuf=payload["cbuf"], actor_shapes=shapes["actor"],
+              forced_critic=(payload.get("forced") or {}).get("critic"))
     handles["critic"] = _oracle_launch(pl, TRPO_CRITIC_PLAN, False)
     return handles
 
@@ -1662,7 +1670,8 @@ def _trpo_config_runs(workload: str, n_threads: int, agents):
                 pl = dict(common, mode="agent", agent=a, actor_sd=payload["actor_sd"][a], abuf=payload["abuf"][a], cbuf=small,
                           factor_in=hip["factor"][a])
                 runs[a] = {t: _oracle_bench_run(pl, t, dtn, sd_, False) for t, dtn, sd_ in TRPO_AGENT_PLAN}
-            pl = dict(common, mode="critic", critic_sd=payload["critic_sd"], cbuf=payload["cbuf"], actor_shapes=shapes["actor"])
+            pl = dict(common, mode="critic", critic_sd=payload["critic_sd"], cbuf=payload["cbuf"], actor_shapes=shapes["actor"],
+                      forced_critic=(payload.get("forced") or {}).get("critic"))
             crit = {t: _oracle_bench_run(pl, t, dtn, sd_, False) for t, dtn, sd_ in TRPO_CRITIC_PLAN}
             return hip, runs, crit, meta
         handles = _trpo_launch(hip, payload, shapes, agents)
@@ -1719,19 +1728,19 @@ def check_bench_config_parity(logp: str = "recipe", n_threads: int = 4096, n_per
     grad_norm / ratio (3 x 5) and value_loss / critic_grad_norm (5), the averaged infos, the final parameter vectors and the
     ValueNorm statistics.
 
-    What the bar can be.  The synthetic buffers carry no signal (advantages independent of the actions), so a gradient is a sum
-    of 819 200 random-sign terms (cancellation ~ sqrt(N)), and with the recipe's stored log-probs (-1 + 0.1 N(0,1), unrelated to
-    the policy) the importance ratios span 1e-22 .. 3e+2: a hundred samples carry 7 % of the surrogate's gradient mass.  ONE
-    ReLU decision that two fp32 implementations take differently on such a sample moves a whole row of a weight gradient by
-    1e-3 of its norm, and Adam's m / sqrt(v) carries that into every later update (tools/diag_bench_parity.py shows exactly
-    that: from the second update on, 100 % of the HIP - torch difference of dW_2 sits in one output row; the fp32 oracle moves
-    the same way against float64 and against itself when its initial parameters move by one ulp).  So:
-      * the FIRST update of the first agent -- identical parameters, factor 1 -- is held to 1e-5 flat (``first_update_*_rel``);
-      * the critic, which never sees the importance ratios, is held to 1e-5 flat throughout;
-      * every other figure gets the golden tests' measured bar, max(1e-5, 2 x the fp32 oracle's OWN uncertainty), the
-        uncertainty being pooled over the entries of one kind (all 15 grad-norms, all final parameter vectors ...): its
-        distance from the same update in float64 and how far it moves when its initial parameters move by one ulp (``n_pert``
-        further fp32 runs) -- a rare event on one heavy sample is not a property of one table entry.  Reported as ``*_excess``."""
+    Round 6: the comparison is TEACHER-FORCED (``_forcing_hook``).  The synthetic buffers carry no signal (advantages independent
+    of the actions), so a gradient is a sum of 819 200 random-sign terms, and with the recipe's stored log-probs (-1 + 0.1 N(0,1),
+    unrelated to the policy) the importance ratios span 1e-22 .. 3e+2: ONE ReLU decision that two fp32 implementations take
+    differently on a heavy sample moves a row of a weight gradient by 1e-3 of its norm, and Adam's m / sqrt(v) carries that into
+    every later update -- two free-running fp32 trajectories separate from the second update on, the oracle against its own
+    one-ulp twin as much as the HIP path against the oracle, and a bar built from a few such twins is a lottery
+    (profiles/r06_free_running_spread.md: the SAME HIP step scored pooled excess ratios between 0.15 and 2.7 against three runs
+    of the same oracle).  So the HIP path records its parameters and Adam moments in front of EVERY optimiser step and the oracle
+    -- in fp32 and in float64 -- re-runs each step from exactly that state: every update is a first update.  Asserted here:
+      * per kind of figure (all 15 grad-norms, ...) max error / max(1e-5, FULL_SIZE_NOISE x the fp32 oracle's own distance from
+        its float64 twin on the same steps) <= 1 (``*_excess``);
+    and by the tests on top: 1e-5 FLAT on every update's figures except the cancelling sums of the on-policy variant.
+    ``HARL_FULLSIZE_FORCED=0`` runs the free form (``n_pert`` one-ulp twins make sense only there)."""
     out: Dict[str, float] = {}
     hip, runs, _shapes, meta = _bench_config_runs(n_threads, True, logp=logp, n_pert=n_pert, workload=workload)
     T, A = meta["T"], meta["A"]

@@ -409,8 +409,30 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_fwd_wide(const float *__restr
     }
     __syncthreads();
   }
-  for (long pair = (long)blockIdx.x * WAVES_PER_WG + wave; pair < n_pairs; pair += (long)gridDim.x * WAVES_PER_WG) {
-    const long s0 = 2 * pair, s1 = s0 + 1 < n_slabs ? s0 + 1 : s0;
+  // Rounds: in the first `full` rounds every wave of the grid owns a whole pair of slabs; what is left (< 2 slabs per wave) is
+  // dealt as SINGLE slabs when there is at most one per wave -- a lone slab costs half a pair, and 204 800 rows (the 17-agent
+  // HATRPO share) are 3.125 pairs per wave: dealt as pairs, an eighth of the waves ran a fourth round of full length while the
+  // rest of the chip idled (round 6; same arithmetic per slab, bit-identical results)
+  const long n_waves = (long)gridDim.x * WAVES_PER_WG, wid = (long)blockIdx.x * WAVES_PER_WG + wave;
+  const long full = (n_slabs / 2) / n_waves, tail0 = 2 * full * n_waves, tail = n_slabs - tail0;
+  const bool tail_single = tail <= n_waves;
+  (void)n_pairs;
+  for (long it = 0; it <= full; ++it) {
+    long s0, s1;
+    bool single = false;
+    if (it < full) {
+      s0 = 2 * (it * n_waves + wid);
+      s1 = s0 + 1;
+    } else if (tail_single) {
+      if (wid >= tail) break;
+      s0 = s1 = tail0 + wid;
+      single = true;
+    } else {
+      s0 = tail0 + 2 * wid;
+      if (s0 >= n_slabs) break;
+      s1 = s0 + 1 < n_slabs ? s0 + 1 : s0;
+      single = s1 == s0;
+    }
     const f32x4 *xp0 = reinterpret_cast<const f32x4 *>(x0n + s0 * (long)KA * SLAB) + lane;
     const f32x4 *xp1 = reinterpret_cast<const f32x4 *>(x0n + s1 * (long)KA * SLAB) + lane;
     const f32x4 *xq0 = x0n_b ? reinterpret_cast<const f32x4 *>(x0n_b + s0 * (long)KB * SLAB) + lane : xp0;
@@ -420,9 +442,14 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_fwd_wide(const float *__restr
     for (int t = 0; t < MT; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc0[t][r] = acc1[t][r] = bp[32 * t + (r & 3) + 8 * (r >> 2) + 4 * h];
+    // Software pipeline over the k-steps (round 6): the exact split of k-step j + 1's activations (2 slabs x 4 pairs x 11 VALU)
+    // is issued BETWEEN the tile groups of k-step j's MFMAs -- two pairs behind every group of 12 (6) MFMAs, far below the ~5
+    // VALU an MFMA's shadow takes for free (profiles/r03_mfma_valu_overlap.md) -- instead of as a phase of its own in front of
+    // them (880 of ~2 400 cycles per k-step: the K = 2 H tangent GEMM ran 130 us at 204 800 rows where its MFMAs need 40).  The raw
+    // activations travel two k-steps ahead, the weight fragments one.  Same products in the same order per accumulator.
     u32x4 an[3][MT];
     f32x4 bn[2][2];
-    auto fetch = [&](int j) {
+    auto fetch_w = [&](int j) {
       if (NJL > 0 && j < NJL) {  // (wave-uniform) resident k-steps
 #pragma unroll
         for (int term = 0; term < 3; ++term)
@@ -434,6 +461,8 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_fwd_wide(const float *__restr
 #pragma unroll
           for (int t = 0; t < MT; ++t) an[term][t] = wl[(long)term * TS + (t * NJ + j) * 64];
       }
+    };
+    auto fetch_x = [&](int j) {
       const f32x4 *b0 = j < NJA ? xp0 + (2 * j) * WAVE : xq0 + (2 * (j - NJA)) * WAVE;  // (wave-uniform)
       const f32x4 *b1 = j < NJA ? xp1 + (2 * j) * WAVE : xq1 + (2 * (j - NJA)) * WAVE;
       bn[0][0] = b0[0];
@@ -441,43 +470,66 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_fwd_wide(const float *__restr
       bn[1][0] = b1[0];
       bn[1][1] = b1[WAVE];
     };
-    fetch(0);
+    u32x4 b[2][3], bx[2][3];
+    auto split_pair = [&](int q, u32x4 (&dst)[2][3]) {  // pair q = 0..7: slab q >> 2, word q & 3 of the k-step's operand
+      const int sl = q >> 2, c = q & 3;
+      const f32x4 &src = bn[sl][c >> 1];
+      unsigned p1, p2, p3;
+      split3(src[2 * (c & 1)], src[2 * (c & 1) + 1], p1, p2, p3);
+      dst[sl][0][c] = p1;
+      dst[sl][1][c] = p2;
+      dst[sl][2][c] = p3;
+    };
+    fetch_w(0);
+    fetch_x(0);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) split_pair(q, b);
+    if (NJ > 1) fetch_x(1);
     for (int j = 0; j < NJ; ++j) {
       u32x4 a[3][MT];
 #pragma unroll
       for (int term = 0; term < 3; ++term)
 #pragma unroll
         for (int t = 0; t < MT; ++t) a[term][t] = an[term][t];
-      u32x4 b[2][3];
-#pragma unroll
-      for (int sl = 0; sl < 2; ++sl)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const f32x4 &src = bn[sl][c >> 1];
-          unsigned p1, p2, p3;
-          split3(src[2 * (c & 1)], src[2 * (c & 1) + 1], p1, p2, p3);
-          b[sl][0][c] = p1;
-          b[sl][1][c] = p2;
-          b[sl][2][c] = p3;
-        }
-      if (j + 1 < NJ) fetch(j + 1);
+      const bool more = j + 1 < NJ;  // (wave-uniform)
+      if (more) fetch_w(j + 1);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int t = 0; t < MT; ++t) {
-        acc0[t] = mfma_bf16(a[2][t], b[0][0], acc0[t]);
-        acc1[t] = mfma_bf16(a[2][t], b[1][0], acc1[t]);
-        acc0[t] = mfma_bf16(a[0][t], b[0][2], acc0[t]);
-        acc1[t] = mfma_bf16(a[0][t], b[1][2], acc1[t]);
-        acc0[t] = mfma_bf16(a[1][t], b[0][1], acc0[t]);
-        acc1[t] = mfma_bf16(a[1][t], b[1][1], acc1[t]);
-        acc0[t] = mfma_bf16(a[1][t], b[0][0], acc0[t]);
-        acc1[t] = mfma_bf16(a[1][t], b[1][0], acc1[t]);
-        acc0[t] = mfma_bf16(a[0][t], b[0][1], acc0[t]);
-        acc1[t] = mfma_bf16(a[0][t], b[1][1], acc1[t]);
-        acc0[t] = mfma_bf16(a[0][t], b[0][0], acc0[t]);
-        acc1[t] = mfma_bf16(a[0][t], b[1][0], acc1[t]);
+        if (single) {  // (wave-uniform) a lone slab: its six products per tile only
+          acc0[t] = mfma_bf16(a[2][t], b[0][0], acc0[t]);
+          acc0[t] = mfma_bf16(a[0][t], b[0][2], acc0[t]);
+          acc0[t] = mfma_bf16(a[1][t], b[0][1], acc0[t]);
+          acc0[t] = mfma_bf16(a[1][t], b[0][0], acc0[t]);
+          acc0[t] = mfma_bf16(a[0][t], b[0][1], acc0[t]);
+          acc0[t] = mfma_bf16(a[0][t], b[0][0], acc0[t]);
+        } else {
+          acc0[t] = mfma_bf16(a[2][t], b[0][0], acc0[t]);
+          acc1[t] = mfma_bf16(a[2][t], b[1][0], acc1[t]);
+          acc0[t] = mfma_bf16(a[0][t], b[0][2], acc0[t]);
+          acc1[t] = mfma_bf16(a[0][t], b[1][2], acc1[t]);
+          acc0[t] = mfma_bf16(a[1][t], b[0][1], acc0[t]);
+          acc1[t] = mfma_bf16(a[1][t], b[1][1], acc1[t]);
+          acc0[t] = mfma_bf16(a[1][t], b[0][0], acc0[t]);
+          acc1[t] = mfma_bf16(a[1][t], b[1][0], acc1[t]);
+          acc0[t] = mfma_bf16(a[0][t], b[0][1], acc0[t]);
+          acc1[t] = mfma_bf16(a[0][t], b[1][1], acc1[t]);
+          acc0[t] = mfma_bf16(a[0][t], b[0][0], acc0[t]);
+          acc1[t] = mfma_bf16(a[0][t], b[1][0], acc1[t]);
+        }
+        if (more) {  // this tile group's share of the next k-step's split (8 pairs over MT groups)
+#pragma unroll
+          for (int q = t * (8 / MT); q < (t + 1) * (8 / MT); ++q) split_pair(q, bx);
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
-      __builtin_amdgcn_sched_barrier(0);
+      if (j + 2 < NJ) fetch_x(j + 2);  // (bn is free: the split above has consumed k-step j + 1's values)
+      if (more) {
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+          for (int term = 0; term < 3; ++term) b[sl][term] = bx[sl][term];
+      }
     }
     wide_epilogue<HO, MODE>(acc0, s0, lane, xout, mask_out, rstd_out, xprimal, mask_in, rstd_in);
     if (s1 != s0) wide_epilogue<HO, MODE>(acc1, s1, lane, xout, mask_out, rstd_out, xprimal, mask_in, rstd_in);

@@ -476,6 +476,10 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_fwd_wide(const float *__restr
       const f32x4 &src = bn[sl][c >> 1];
       unsigned p1, p2, p3;
       split3(src[2 * (c & 1)], src[2 * (c & 1) + 1], p1, p2, p3);
+      // (an EMPTY asm: no instruction is emitted, so the compiler's hazard handling between these VALU results and the MFMAs that
+      // read them is untouched -- but the values must exist HERE, in front of the next sched_barrier; without it LLVM's code
+      // sinking moved the whole split behind the MFMA block, to its first use, and the pipeline was a no-op)
+      asm volatile("" : "+v"(p1), "+v"(p2), "+v"(p3));
       dst[sl][0][c] = p1;
       dst[sl][1][c] = p2;
       dst[sl][2][c] = p3;
@@ -484,53 +488,53 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_fwd_wide(const float *__restr
     fetch_x(0);
 #pragma unroll
     for (int q = 0; q < 8; ++q) split_pair(q, b);
-    if (NJ > 1) fetch_x(1);
-    for (int j = 0; j < NJ; ++j) {
+    fetch_x(NJ > 1 ? 1 : 0);
+    // one k-step; SINGLE / MORE are compile-time so that the loop body has no branch (a wave-uniform `if (single)` around the
+    // MFMAs of a tile made the compiler copy the tile's accumulators at every join: 32 v_accvgpr_write per tile group, and the
+    // launch ran 1.6x SLOWER than without the pipeline)
+    auto kstep = [&](int j, auto single_c, auto more_c) {
+      constexpr bool SINGLE = decltype(single_c)::value, MORE = decltype(more_c)::value;
       u32x4 a[3][MT];
 #pragma unroll
       for (int term = 0; term < 3; ++term)
 #pragma unroll
         for (int t = 0; t < MT; ++t) a[term][t] = an[term][t];
-      const bool more = j + 1 < NJ;  // (wave-uniform)
-      if (more) fetch_w(j + 1);
+      if constexpr (MORE) fetch_w(j + 1);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int t = 0; t < MT; ++t) {
-        if (single) {  // (wave-uniform) a lone slab: its six products per tile only
-          acc0[t] = mfma_bf16(a[2][t], b[0][0], acc0[t]);
-          acc0[t] = mfma_bf16(a[0][t], b[0][2], acc0[t]);
-          acc0[t] = mfma_bf16(a[1][t], b[0][1], acc0[t]);
-          acc0[t] = mfma_bf16(a[1][t], b[0][0], acc0[t]);
-          acc0[t] = mfma_bf16(a[0][t], b[0][1], acc0[t]);
-          acc0[t] = mfma_bf16(a[0][t], b[0][0], acc0[t]);
-        } else {
-          acc0[t] = mfma_bf16(a[2][t], b[0][0], acc0[t]);
-          acc1[t] = mfma_bf16(a[2][t], b[1][0], acc1[t]);
-          acc0[t] = mfma_bf16(a[0][t], b[0][2], acc0[t]);
-          acc1[t] = mfma_bf16(a[0][t], b[1][2], acc1[t]);
-          acc0[t] = mfma_bf16(a[1][t], b[0][1], acc0[t]);
-          acc1[t] = mfma_bf16(a[1][t], b[1][1], acc1[t]);
-          acc0[t] = mfma_bf16(a[1][t], b[0][0], acc0[t]);
-          acc1[t] = mfma_bf16(a[1][t], b[1][0], acc1[t]);
-          acc0[t] = mfma_bf16(a[0][t], b[0][1], acc0[t]);
-          acc1[t] = mfma_bf16(a[0][t], b[1][1], acc1[t]);
-          acc0[t] = mfma_bf16(a[0][t], b[0][0], acc0[t]);
-          acc1[t] = mfma_bf16(a[0][t], b[1][0], acc1[t]);
-        }
-        if (more) {  // this tile group's share of the next k-step's split (8 pairs over MT groups)
+        acc0[t] = mfma_bf16(a[2][t], b[0][0], acc0[t]);
+        if constexpr (!SINGLE) acc1[t] = mfma_bf16(a[2][t], b[1][0], acc1[t]);
+        acc0[t] = mfma_bf16(a[0][t], b[0][2], acc0[t]);
+        if constexpr (!SINGLE) acc1[t] = mfma_bf16(a[0][t], b[1][2], acc1[t]);
+        acc0[t] = mfma_bf16(a[1][t], b[0][1], acc0[t]);
+        if constexpr (!SINGLE) acc1[t] = mfma_bf16(a[1][t], b[1][1], acc1[t]);
+        acc0[t] = mfma_bf16(a[1][t], b[0][0], acc0[t]);
+        if constexpr (!SINGLE) acc1[t] = mfma_bf16(a[1][t], b[1][0], acc1[t]);
+        acc0[t] = mfma_bf16(a[0][t], b[0][1], acc0[t]);
+        if constexpr (!SINGLE) acc1[t] = mfma_bf16(a[0][t], b[1][1], acc1[t]);
+        acc0[t] = mfma_bf16(a[0][t], b[0][0], acc0[t]);
+        if constexpr (!SINGLE) acc1[t] = mfma_bf16(a[0][t], b[1][0], acc1[t]);
+        if constexpr (MORE) {  // this tile group's share of the next k-step's split (8 pairs over MT groups)
 #pragma unroll
           for (int q = t * (8 / MT); q < (t + 1) * (8 / MT); ++q) split_pair(q, bx);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (j + 2 < NJ) fetch_x(j + 2);  // (bn is free: the split above has consumed k-step j + 1's values)
-      if (more) {
+      if constexpr (MORE) {
+        fetch_x(j + 2 < NJ ? j + 2 : NJ - 1);  // (bn is free: the split above has consumed k-step j + 1's values; clamped, no branch)
 #pragma unroll
         for (int sl = 0; sl < 2; ++sl)
 #pragma unroll
           for (int term = 0; term < 3; ++term) b[sl][term] = bx[sl][term];
       }
-    }
+    };
+    auto ksteps = [&](auto single_c) {
+      for (int j = 0; j + 1 < NJ; ++j) kstep(j, single_c, std::true_type{});
+      kstep(NJ - 1, single_c, std::false_type{});
+    };
+    if (single) ksteps(std::true_type{});  // (wave-uniform)
+    else ksteps(std::false_type{});
     wide_epilogue<HO, MODE>(acc0, s0, lane, xout, mask_out, rstd_out, xprimal, mask_in, rstd_in);
     if (s1 != s0) wide_epilogue<HO, MODE>(acc1, s1, lane, xout, mask_out, rstd_out, xprimal, mask_in, rstd_in);
   }

@@ -382,6 +382,7 @@ __device__ __forceinline__ void wide_epilogue(f32x16 (&acc)[HO / 32], long slab,
 // wave and k-step -- 32 B per clock and CU with every CU of an XCD on the same 4 MB slice -- and stalls on it (133 us per launch
 // at 204 800 rows where its issue model says 80); with half of the K = 2 H tangent GEMM's fragments (the W' half, identical
 // for every Fisher-vector product) resident, that traffic halves.  Same instruction order per accumulator: bit-identical results.
+// MEASURED: no gain (see wide_resident() below) -- kept opt-in for the record.
 template <int HO, int MODE, int NJL = 0>
 __global__ __launch_bounds__(WG_THREADS, 1) void k_fwd_wide(const float *__restrict__ x0n, const u32x4 *__restrict__ img,
                                                             const float *__restrict__ bp, float *__restrict__ xout,
@@ -409,30 +410,8 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_fwd_wide(const float *__restr
     }
     __syncthreads();
   }
-  // Rounds: in the first `full` rounds every wave of the grid owns a whole pair of slabs; what is left (< 2 slabs per wave) is
-  // dealt as SINGLE slabs when there is at most one per wave -- a lone slab costs half a pair, and 204 800 rows (the 17-agent
-  // HATRPO share) are 3.125 pairs per wave: dealt as pairs, an eighth of the waves ran a fourth round of full length while the
-  // rest of the chip idled (round 6; same arithmetic per slab, bit-identical results)
-  const long n_waves = (long)gridDim.x * WAVES_PER_WG, wid = (long)blockIdx.x * WAVES_PER_WG + wave;
-  const long full = (n_slabs / 2) / n_waves, tail0 = 2 * full * n_waves, tail = n_slabs - tail0;
-  const bool tail_single = tail <= n_waves;
-  (void)n_pairs;
-  for (long it = 0; it <= full; ++it) {
-    long s0, s1;
-    bool single = false;
-    if (it < full) {
-      s0 = 2 * (it * n_waves + wid);
-      s1 = s0 + 1;
-    } else if (tail_single) {
-      if (wid >= tail) break;
-      s0 = s1 = tail0 + wid;
-      single = true;
-    } else {
-      s0 = tail0 + 2 * wid;
-      if (s0 >= n_slabs) break;
-      s1 = s0 + 1 < n_slabs ? s0 + 1 : s0;
-      single = s1 == s0;
-    }
+  for (long pair = (long)blockIdx.x * WAVES_PER_WG + wave; pair < n_pairs; pair += (long)gridDim.x * WAVES_PER_WG) {
+    const long s0 = 2 * pair, s1 = s0 + 1 < n_slabs ? s0 + 1 : s0;
     const f32x4 *xp0 = reinterpret_cast<const f32x4 *>(x0n + s0 * (long)KA * SLAB) + lane;
     const f32x4 *xp1 = reinterpret_cast<const f32x4 *>(x0n + s1 * (long)KA * SLAB) + lane;
     const f32x4 *xq0 = x0n_b ? reinterpret_cast<const f32x4 *>(x0n_b + s0 * (long)KB * SLAB) + lane : xp0;
@@ -442,14 +421,9 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_fwd_wide(const float *__restr
     for (int t = 0; t < MT; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc0[t][r] = acc1[t][r] = bp[32 * t + (r & 3) + 8 * (r >> 2) + 4 * h];
-    // Software pipeline over the k-steps (round 6): the exact split of k-step j + 1's activations (2 slabs x 4 pairs x 11 VALU)
-    // is issued BETWEEN the tile groups of k-step j's MFMAs -- two pairs behind every group of 12 (6) MFMAs, far below the ~5
-    // VALU an MFMA's shadow takes for free (profiles/r03_mfma_valu_overlap.md) -- instead of as a phase of its own in front of
-    // them (880 of ~2 400 cycles per k-step: the K = 2 H tangent GEMM ran 130 us at 204 800 rows where its MFMAs need 40).  The raw
-    // activations travel two k-steps ahead, the weight fragments one.  Same products in the same order per accumulator.
     u32x4 an[3][MT];
     f32x4 bn[2][2];
-    auto fetch_w = [&](int j) {
+    auto fetch = [&](int j) {
       if (NJL > 0 && j < NJL) {  // (wave-uniform) resident k-steps
 #pragma unroll
         for (int term = 0; term < 3; ++term)
@@ -461,8 +435,6 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_fwd_wide(const float *__restr
 #pragma unroll
           for (int t = 0; t < MT; ++t) an[term][t] = wl[(long)term * TS + (t * NJ + j) * 64];
       }
-    };
-    auto fetch_x = [&](int j) {
       const f32x4 *b0 = j < NJA ? xp0 + (2 * j) * WAVE : xq0 + (2 * (j - NJA)) * WAVE;  // (wave-uniform)
       const f32x4 *b1 = j < NJA ? xp1 + (2 * j) * WAVE : xq1 + (2 * (j - NJA)) * WAVE;
       bn[0][0] = b0[0];
@@ -470,71 +442,44 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_fwd_wide(const float *__restr
       bn[1][0] = b1[0];
       bn[1][1] = b1[WAVE];
     };
-    u32x4 b[2][3], bx[2][3];
-    auto split_pair = [&](int q, u32x4 (&dst)[2][3]) {  // pair q = 0..7: slab q >> 2, word q & 3 of the k-step's operand
-      const int sl = q >> 2, c = q & 3;
-      const f32x4 &src = bn[sl][c >> 1];
-      unsigned p1, p2, p3;
-      split3(src[2 * (c & 1)], src[2 * (c & 1) + 1], p1, p2, p3);
-      // (an EMPTY asm: no instruction is emitted, so the compiler's hazard handling between these VALU results and the MFMAs that
-      // read them is untouched -- but the values must exist HERE, in front of the next sched_barrier; without it LLVM's code
-      // sinking moved the whole split behind the MFMA block, to its first use, and the pipeline was a no-op)
-      asm volatile("" : "+v"(p1), "+v"(p2), "+v"(p3));
-      dst[sl][0][c] = p1;
-      dst[sl][1][c] = p2;
-      dst[sl][2][c] = p3;
-    };
-    fetch_w(0);
-    fetch_x(0);
-#pragma unroll
-    for (int q = 0; q < 8; ++q) split_pair(q, b);
-    fetch_x(NJ > 1 ? 1 : 0);
-    // one k-step; SINGLE / MORE are compile-time so that the loop body has no branch (a wave-uniform `if (single)` around the
-    // MFMAs of a tile made the compiler copy the tile's accumulators at every join: 32 v_accvgpr_write per tile group, and the
-    // launch ran 1.6x SLOWER than without the pipeline)
-    auto kstep = [&](int j, auto single_c, auto more_c) {
-      constexpr bool SINGLE = decltype(single_c)::value, MORE = decltype(more_c)::value;
+    fetch(0);
+    for (int j = 0; j < NJ; ++j) {
       u32x4 a[3][MT];
 #pragma unroll
       for (int term = 0; term < 3; ++term)
 #pragma unroll
         for (int t = 0; t < MT; ++t) a[term][t] = an[term][t];
-      if constexpr (MORE) fetch_w(j + 1);
+      u32x4 b[2][3];
+#pragma unroll
+      for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const f32x4 &src = bn[sl][c >> 1];
+          unsigned p1, p2, p3;
+          split3(src[2 * (c & 1)], src[2 * (c & 1) + 1], p1, p2, p3);
+          b[sl][0][c] = p1;
+          b[sl][1][c] = p2;
+          b[sl][2][c] = p3;
+        }
+      if (j + 1 < NJ) fetch(j + 1);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int t = 0; t < MT; ++t) {
         acc0[t] = mfma_bf16(a[2][t], b[0][0], acc0[t]);
-        if constexpr (!SINGLE) acc1[t] = mfma_bf16(a[2][t], b[1][0], acc1[t]);
+        acc1[t] = mfma_bf16(a[2][t], b[1][0], acc1[t]);
         acc0[t] = mfma_bf16(a[0][t], b[0][2], acc0[t]);
-        if constexpr (!SINGLE) acc1[t] = mfma_bf16(a[0][t], b[1][2], acc1[t]);
+        acc1[t] = mfma_bf16(a[0][t], b[1][2], acc1[t]);
         acc0[t] = mfma_bf16(a[1][t], b[0][1], acc0[t]);
-        if constexpr (!SINGLE) acc1[t] = mfma_bf16(a[1][t], b[1][1], acc1[t]);
+        acc1[t] = mfma_bf16(a[1][t], b[1][1], acc1[t]);
         acc0[t] = mfma_bf16(a[1][t], b[0][0], acc0[t]);
-        if constexpr (!SINGLE) acc1[t] = mfma_bf16(a[1][t], b[1][0], acc1[t]);
+        acc1[t] = mfma_bf16(a[1][t], b[1][0], acc1[t]);
         acc0[t] = mfma_bf16(a[0][t], b[0][1], acc0[t]);
-        if constexpr (!SINGLE) acc1[t] = mfma_bf16(a[0][t], b[1][1], acc1[t]);
+        acc1[t] = mfma_bf16(a[0][t], b[1][1], acc1[t]);
         acc0[t] = mfma_bf16(a[0][t], b[0][0], acc0[t]);
-        if constexpr (!SINGLE) acc1[t] = mfma_bf16(a[0][t], b[1][0], acc1[t]);
-        if constexpr (MORE) {  // this tile group's share of the next k-step's split (8 pairs over MT groups)
-#pragma unroll
-          for (int q = t * (8 / MT); q < (t + 1) * (8 / MT); ++q) split_pair(q, bx);
-        }
-        __builtin_amdgcn_sched_barrier(0);
+        acc1[t] = mfma_bf16(a[0][t], b[1][0], acc1[t]);
       }
-      if constexpr (MORE) {
-        fetch_x(j + 2 < NJ ? j + 2 : NJ - 1);  // (bn is free: the split above has consumed k-step j + 1's values; clamped, no branch)
-#pragma unroll
-        for (int sl = 0; sl < 2; ++sl)
-#pragma unroll
-          for (int term = 0; term < 3; ++term) b[sl][term] = bx[sl][term];
-      }
-    };
-    auto ksteps = [&](auto single_c) {
-      for (int j = 0; j + 1 < NJ; ++j) kstep(j, single_c, std::true_type{});
-      kstep(NJ - 1, single_c, std::false_type{});
-    };
-    if (single) ksteps(std::true_type{});  // (wave-uniform)
-    else ksteps(std::false_type{});
+      __builtin_amdgcn_sched_barrier(0);
+    }
     wide_epilogue<HO, MODE>(acc0, s0, lane, xout, mask_out, rstd_out, xprimal, mask_in, rstd_in);
     if (s1 != s0) wide_epilogue<HO, MODE>(acc1, s1, lane, xout, mask_out, rstd_out, xprimal, mask_in, rstd_in);
   }
@@ -811,12 +756,18 @@ bool wide_shared(long n_slabs) {
   return e && e[0] == '1' && n_slabs >= 512;
 }
 
-// Resident first-half fragments (k_fwd_wide NJL = 8): HARL_WIDE_RESIDENT=0 switches back to pure streaming (A/B, bit-for-bit test);
-// from 512 slabs on (the staging prologue is 96 KiB per workgroup)
+// Resident first-half fragments (k_fwd_wide NJL = 8) are OPT-IN (HARL_WIDE_RESIDENT=1, from 512 slabs on; A/B and the bit-for-bit
+// test).  Measured on MI355X (round 6, 204 800 rows): the K = 2 H tangent GEMM 0.142 ms against 0.133 ms streaming, the 17-agent
+// HATRPO update 244.3 against 241.0 ms -- the launch is not waiting for its weight fragments.  Nor for its operand splits: a
+// software pipeline that issues the split of k-step j + 1 under the MFMAs of k-step j (built, bit-identical, 0.138 - 0.152 ms) and
+// dealing the ragged last round as single slabs changed nothing either.  What the launch moves is 420 MB (x_dot, x_hat_in, the
+// primal x_hat for the LayerNorm Jacobian, the output) = 3.2 TB/s at 0.133 ms against the 4.0 - 4.3 TB/s the one-image layer
+// kernels reach: it is a streaming kernel at three quarters of the achievable rate with ONE wave per SIMD and ~32 KiB of loads in
+// flight per CU, not the 2.5x-off-the-matrix-pipe kernel the issue model made of it (profiles/r06_wide_tangent_ab.md).
 constexpr size_t wide_res_lds() { return (size_t)3 * 4 * 8 * 64 * 16; }
 bool wide_resident(long n_slabs) {
   const char *e = getenv("HARL_WIDE_RESIDENT");
-  return !(e && e[0] == '0') && n_slabs >= 512;
+  return e && e[0] == '1' && n_slabs >= 512;
 }
 
 template <int MODE>

@@ -2003,8 +2003,8 @@ def check_generator_api(name: str) -> Dict[str, float]:
     return out
 
 
-# the three ways the wide GEMMs get their weight fragments: streamed from L2, first eight k-steps resident in LDS (round 6, the
-# default from 512 slabs on), 32-column panels shared through LDS (round 5, opt-in)
+# the three ways the wide GEMMs get their weight fragments: streamed from L2 (the default), first eight k-steps resident in LDS
+# (round 6, opt-in: measured neutral), 32-column panels shared through LDS (round 5, opt-in: measured slower)
 WIDE_MODES = (("stream", {"HARL_WIDE_SHARED": "0", "HARL_WIDE_RESIDENT": "0"}),
               ("resident", {"HARL_WIDE_SHARED": "0", "HARL_WIDE_RESIDENT": "1"}),
               ("shared", {"HARL_WIDE_SHARED": "1", "HARL_WIDE_RESIDENT": "0"}))

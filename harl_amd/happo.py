@@ -394,6 +394,21 @@ class HAPPO(OnPolicyBase):
         adv = _as_dev(advantages, self.device).reshape(T * N)
         call("harl_masked_moments", ptr(adv), ptr(actor_buffer.flat("active_masks")), T * N, ptr(out), _lib.scratch("mm"), stream())
 
+    def rng_footprint(self, actor_buffer: OnPolicyActorBuffer) -> list:
+        """Sizes of the ``torch.randperm`` draws ONE train() of this actor takes from the global CPU generator, in order (one
+        per epoch: on_policy_actor_buffer.py:131 / :196 / :241 over the GLOBAL buffer).  The runner fast-forwards the
+        generator over them to start the critic's update -- whose samplers draw AFTER every actor's in the reference --
+        next to the actors' (runner.train, round 6)."""
+        T, N = actor_buffer.actions.shape[:2]
+        n_g = self.shard[0] if self.shard else N
+        if self.use_recurrent_policy:
+            size = (T * n_g) // self.data_chunk_length
+        elif self.use_naive_recurrent_policy:
+            size = n_g
+        else:
+            size = T * n_g
+        return [size] * self.ppo_epoch
+
     def fuses_old_logp(self) -> bool:
         """True when train()'s first forward sees every buffer row, in order, under the pre-update parameters -- i.e. it
         computes exactly what the runner's pre-update log-prob pass computes (on_policy_ha_runner.py:66-83)."""

@@ -197,6 +197,37 @@ class OnPolicyHARunner:
                 cinfo = self.critic.train(self.critic_buffer, self.value_normalizer, _defer=True)
         ev.synchronize()
         counts = self._counts_host.tolist()
+        # Round 6: the critic's update NEXT TO the actors' also where permutations are materialised (recurrent policies, several
+        # minibatches).  In the reference the critic's samplers draw from the global CPU generator AFTER every actor's, so the
+        # generator is fast-forwarded over the actors' draws first (their sizes are known: HAPPO.rng_footprint; agents without an
+        # active entry draw nothing, happo.py:119-120), the critic's train() -- on a stream of its own -- takes its permutations
+        # from exactly the state the reference's critic finds, and the generator goes back to where the actors start; at the end
+        # it is set to the state behind the critic's draws.  Every permutation and the final state are bit-identical to the
+        # in-order run.  What it buys: with GRU policies the main stream idles ~0.4 ms per agent behind the previous agent's
+        # post-update log-prob pass (a full-length chain on 6 % of the chip: 3.9 of the SMAC update's 29.5 ms, rocprofv3 trace of
+        # round 6) and then ran the critic's 2.4 ms at the very end; now the critic's launches fill those gaps.
+        rng_after = None
+        if (cinfo is None and dev.type == "cuda" and all(hasattr(a, "rng_footprint") for a in self.actor)
+                and (not self.comm.enabled or self.critic.comm is not self.comm)
+                and os.environ.get("HARL_CRITIC_STREAM", "1") != "0" and os.environ.get("HARL_CRITIC_EARLY", "1") != "0"):
+            from .buffers import consume_randperm
+            rng_sync()
+            rng_start = torch.get_rng_state()
+            for a in agent_order:
+                if counts[a] > 0.0:
+                    for n in self.actor[a].rng_footprint(self.actor_buffer[a]):
+                        consume_randperm(n)  # (the generator advance of torch.randperm(n), no permutation materialised)
+            rng_sync()
+            if getattr(self, "_critic_stream", None) is None:
+                self._critic_stream = torch.cuda.Stream(device=dev)
+            self._critic_stream.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(self._critic_stream):
+                cinfo = self.critic.train(self.critic_buffer, self.value_normalizer, _defer=True)
+                critic_done = torch.cuda.Event()
+                critic_done.record(self._critic_stream)
+            rng_sync()
+            rng_after = torch.get_rng_state()
+            torch.set_rng_state(rng_start)
         # Pre-update log-probs that cannot come out of the first epoch's forward (recurrent policies: full-length unroll from
         # rnn_states[0]; several minibatches) depend only on the agent's OWN pre-update weights, not on the agents before it
         # (on_policy_ha_runner.py:66-83) -- so all of them are enqueued up front on a side stream, where the long, narrow
@@ -292,6 +323,8 @@ class OnPolicyHARunner:
         if critic_done is not None:
             torch.cuda.current_stream(dev).wait_event(critic_done)
         rng_sync()  # the global CPU generator is exactly where the reference leaves it
+        if rng_after is not None:  # ... i.e. behind the critic's draws, which were taken ahead of the actors' (see above)
+            torch.set_rng_state(rng_after)
         dev_infos = [p[1] for p in pending if p is not None] + [cinfo]
         flat = torch.cat([t.reshape(-1) for t in dev_infos]).cpu().tolist()  # the single end-of-train read-back
         self._check_comms()

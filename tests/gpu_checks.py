@@ -972,14 +972,17 @@ def check_train_golden(name: str) -> Dict[str, float]:
                 consume_policy_init_rng({**case.model, **case.algo}, Box((case.shapes.obs_dim,)), sp)
     out["golden_replay_mismatch"] = float(replay_bad)
     out["rng_state_mismatch"] = float(not torch.equal(state_after, torch.get_rng_state()))
-    pos, bad = 0, 0
+    # (each materialised permutation must BE one of the reference's draws, each of those used at most once.  Not "in stream
+    # order": since round 6 the critic's samplers draw -- from the generator state the reference's critic finds, the actors'
+    # draws fast-forwarded -- before the actors' do, so the critic's permutations are materialised first.  A permutation of a
+    # few thousand elements equals the reference's draw of some position only if it was drawn from that position's state.)
+    used, bad = [False] * len(gp), 0
     for pm in perms:
-        while pos < len(gp) and not (len(gp[pos]) == len(pm) and np.array_equal(gp[pos], pm)):
-            pos += 1
-        if pos == len(gp):
+        k = next((i for i in range(len(gp)) if not used[i] and len(gp[i]) == len(pm) and np.array_equal(gp[i], pm)), None)
+        if k is None:
             bad += 1
         else:
-            pos += 1
+            used[k] = True
     out["perm_mismatch"] = float(bad)
     gold = z["actor_infos"]
     nz = load_noise(name)  # the same update in float64 (oracle/gen_noise_floor.py): how exact the reference's own figures are

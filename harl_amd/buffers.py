@@ -214,7 +214,10 @@ def draw_permutation(n: int, device=None) -> torch.Tensor:
         p32 = _replay_raw(n)
         if PERM_TAP is not None:
             PERM_TAP(p32.long())
-        return p32.long() if device is None else p32.to(device).long()
+        # (NumPy for the widening copy on the host: ATen fans a 65 536-element `.long()` out to its intra-op pool, and waking
+        # 128 threads cost 30 - 70 ms per draw on the GPU box's host -- 45 draws per recurrent update at 4096 rollout threads
+        # were 250 ms of host time around 120 ms of GPU work, round 6)
+        return torch.from_numpy(p32.numpy().astype(np.int64)) if device is None else p32.to(device).long()
     p = torch.randperm(n)
     if PERM_TAP is not None:
         PERM_TAP(p.clone())
@@ -247,8 +250,8 @@ def recurrent_first_rows(T: int, N: int, num_mini_batch: int, data_chunk_length:
     L = data_chunk_length
     assert T % L == 0, "episode_length must be a multiple of data_chunk_length"
     for chunks in minibatch_indices((T * N) // L, num_mini_batch):
-        start = chunks * L
-        yield (start % T) * N + start // T, L
+        start = chunks.numpy() * L  # (host-side index arithmetic in NumPy: see draw_permutation)
+        yield torch.from_numpy((start % T) * N + start // T), L
 
 
 def _recurrent_seqs(device, T: int, n_local: int, agents: int, H: int, num_mini_batch: int, data_chunk_length: int,

@@ -998,7 +998,9 @@ def _upload_first_rows(first_rows: torch.Tensor, dev) -> torch.Tensor:
     if ring["evs"][k] is not None:
         ring["evs"][k].synchronize()
     stage = ring["bufs"][k][:n]
-    stage.copy_(first_rows.reshape(-1))
+    # (NumPy for the host-side copy: ATen's parallel copy wakes its whole intra-op pool for >= 32 768 elements -- tens of
+    # milliseconds per minibatch on a 256-thread host, buffers.draw_permutation)
+    stage.numpy()[:] = first_rows.reshape(-1).numpy()
     out = stage.to(dev, non_blocking=True)
     ev = ring["evs"][k] or torch.cuda.Event()
     ev.record(torch.cuda.current_stream(dev))

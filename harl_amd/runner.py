@@ -221,13 +221,29 @@ class OnPolicyHARunner:
             if getattr(self, "_critic_stream", None) is None:
                 self._critic_stream = torch.cuda.Stream(device=dev)
             self._critic_stream.wait_stream(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(self._critic_stream):
-                cinfo = self.critic.train(self.critic_buffer, self.value_normalizer, _defer=True)
-                critic_done = torch.cuda.Event()
-                critic_done.record(self._critic_stream)
-            rng_sync()
-            rng_after = torch.get_rng_state()
+            # ... one EPOCH at a time (VCritic._train_epochs), epoch k enqueued right behind agent k's update and ordered behind
+            # its event: that is where the main stream goes idle (agent k + 1's loss waits for agent k's post-update pass); run
+            # all at once up front the critic only competed with the first agent's kernels (27.7 against 28.3 ms, SMAC 3s5z).
+            # The generator keeps TWO positions: the actors' (restored after every critic epoch) and the critic's.
+            staggered = dict(gen=self.critic._train_epochs(self.critic_buffer, self.value_normalizer), state=torch.get_rng_state(),
+                             left=self.critic.critic_epoch)
             torch.set_rng_state(rng_start)
+
+            def critic_epoch(after_event=None, _st=staggered):
+                if _st["left"] <= 0:
+                    return
+                rng_sync()
+                actor_state = torch.get_rng_state()
+                torch.set_rng_state(_st["state"])
+                if after_event is not None:
+                    self._critic_stream.wait_event(after_event)
+                with torch.cuda.stream(self._critic_stream):
+                    next(_st["gen"])
+                _st["left"] -= 1
+                rng_sync()
+                _st["state"] = torch.get_rng_state()
+                torch.set_rng_state(actor_state)
+            rng_after = staggered
         # Pre-update log-probs that cannot come out of the first epoch's forward (recurrent policies: full-length unroll from
         # rnn_states[0]; several minibatches) depend only on the agent's OWN pre-update weights, not on the agents before it
         # (on_policy_ha_runner.py:66-83) -- so all of them are enqueued up front on a side stream, where the long, narrow
@@ -289,6 +305,10 @@ class OnPolicyHARunner:
             if factor_ev is not None and hasattr(actor, "_factor_ready"):
                 actor._factor_ready = factor_ev
             info = actor.train(buf, adv_a, self.state_type, **kw)               # :86-93
+            if rng_after is not None and rng_after["left"] > 0:  # one critic epoch behind this agent's optimiser steps
+                ev_a = torch.cuda.Event()
+                ev_a.record(torch.cuda.current_stream(dev))
+                critic_epoch(ev_a)
             if factor_ev is not None:  # (an update that never reached a loss launch has not waited yet)
                 if hasattr(actor, "_factor_ready"):
                     actor._factor_ready = None
@@ -318,13 +338,22 @@ class OnPolicyHARunner:
         if keep_alive:  # tensors of the main stream's allocator pool that the post stream has read
             torch.cuda.current_stream(dev).wait_stream(self._post_stream)
             keep_alive.clear()
+        if rng_after is not None:  # epochs not handed out yet (fewer agents than critic epochs), then the critic's statistics
+            while rng_after["left"] > 0:
+                critic_epoch(None)
+            for _ in rng_after["gen"]:  # (run the generator to its end)
+                pass
+            with torch.cuda.stream(self._critic_stream):
+                cinfo = self.critic._train_result(True)
+                critic_done = torch.cuda.Event()
+                critic_done.record(self._critic_stream)
         if cinfo is None:
             cinfo = self.critic.train(self.critic_buffer, self.value_normalizer, _defer=True)
         if critic_done is not None:
             torch.cuda.current_stream(dev).wait_event(critic_done)
         rng_sync()  # the global CPU generator is exactly where the reference leaves it
-        if rng_after is not None:  # ... i.e. behind the critic's draws, which were taken ahead of the actors' (see above)
-            torch.set_rng_state(rng_after)
+        if rng_after is not None:  # ... i.e. behind the critic's draws, which were taken from their own position (see above)
+            torch.set_rng_state(rng_after["state"])
         dev_infos = [p[1] for p in pending if p is not None] + [cinfo]
         flat = torch.cat([t.reshape(-1) for t in dev_infos]).cpu().tolist()  # the single end-of-train read-back
         self._check_comms()

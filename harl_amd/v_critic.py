@@ -168,6 +168,22 @@ class VCritic:
     def train(self, critic_buffer: OnPolicyCriticBufferEP, value_normalizer: Optional[ValueNorm] = None, _defer=False):
         """critic_epoch x critic_num_mini_batch updates (v_critic.py:159-200).  ``_defer`` (runner-internal): return the
         averaged statistics as a device tensor and leave deferred RNG advances pending."""
+        for _ in self._train_epochs(critic_buffer, value_normalizer):
+            pass
+        return self._train_result(_defer)
+
+    def _train_result(self, _defer: bool):
+        n_upd = self.critic_epoch * self.critic_num_mini_batch
+        if _defer:
+            return self._info / n_upd
+        rng_sync()
+        vals = (self._info / n_upd).cpu().tolist()
+        return {"value_loss": vals[0], "critic_grad_norm": vals[1]}
+
+    def _train_epochs(self, critic_buffer: OnPolicyCriticBufferEP, value_normalizer: Optional[ValueNorm] = None):
+        """The body of train() as a generator that yields after every epoch: the runner hands the critic's epochs out one by
+        one between the actors' updates (runner.train, round 6), each on the critic's stream behind the event of the agent it
+        follows.  Draws from the global CPU generator happen inside the epoch they belong to, exactly as in train()."""
         buf = critic_buffer
         T, N = buf.rewards.shape[:2]
         A = getattr(buf, "num_agents", None)  # FP buffers carry an agent axis: rows = (t*N + n)*A + a
@@ -190,10 +206,12 @@ class VCritic:
                         continue
                     self._update_core(share_obs, seq["idx"], seq["L"] * seq["m_pad"], seq["L"] * seq["m_global"],
                                       value_preds, returns, value_normalizer, seq=seq)
+                yield
                 continue
             if self.critic_num_mini_batch == 1:
                 consume_randperm(n_global)  # replay the generator state only (see HAPPO.train)
                 self._update_core(share_obs, None, B, n_global, value_preds, returns, value_normalizer)
+                yield
                 continue
             sampler = minibatch_indices(n_global, self.critic_num_mini_batch, dev)
             for ind in sampler:
@@ -201,12 +219,7 @@ class VCritic:
                 if self.shard:
                     ind = local_minibatch_rows(ind, self.shard[0], self.shard[1], self.shard[2], agents=A or 1)
                 self._update_core(share_obs, ind.to(dev), ind.numel(), m_global, value_preds, returns, value_normalizer)
-        n_upd = self.critic_epoch * self.critic_num_mini_batch
-        if _defer:
-            return self._info / n_upd
-        rng_sync()
-        vals = (self._info / n_upd).cpu().tolist()
-        return {"value_loss": vals[0], "critic_grad_norm": vals[1]}
+            yield
 
     def prep_training(self):
         self.critic.train()

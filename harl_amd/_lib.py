@@ -99,6 +99,7 @@ SIGNATURES = {
     "harl_mlp_panel_tangent": [_vp, _vp, _l, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "harl_reduce_scalars": [_vp, _i, _vp, _vp],
     "harl_mlp_linear": [_vp, _l, _i, _i, _vp, _vp, _vp, _vp],
+    "harl_mlp_linear3": [_vp, _vp, _vp, _l, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "harl_gru_cell_init": [_vp, _vp, _i, _l, _vp, _vp],
     "harl_gru_cell_fwd": [_vp] * 8 + [_i, _l] + [_vp] * 7 + [_vp],
     "harl_gru_cell_bwd": [_vp] * 10 + [_i, _l] + [_vp] * 5 + [_vp],

@@ -1701,6 +1701,76 @@ extern "C" int harl_mlp_tangent_hidden(const float *xin_dot, const float *xin, l
 
 // plain Linear, no epilogue: xout = Wp xin + bp as an ATL(HO) image (k_fwd_hidden MODE 1) -- the logits of the concatenated
 // MultiDiscrete heads (csrc/multihead.hip); Wp is [HO][HI] with zero rows past the last head
+// Three independent raw products  z_g = W_g x_g + b_g  (g = 0, 1, 2) in ONE launch: blockIdx.y picks the operand set, the body is
+// k_fwd_hidden's MODE 1.  The composed 128-wide GRU (harl_amd/gru_wide.py) issues the three gate products of every time step --
+// same rows, three weight blocks -- and was 16 698 launches of 9.6 us per 8-agent HATRPO update (24 147 launches in 375 ms, 18 %
+// of it with the GPU idle: rocprofv3 trace, round 6); one launch with three times the workgroups takes the time of one.
+struct Lin3 {
+  const float *x[3], *W[3], *b[3];
+  float *out[3];
+};
+template <int HI, int HO>
+__global__ __launch_bounds__(WG_THREADS, split_one_wg(HO, HI) ? 1 : 2) void k_linear3(Lin3 P, long n_slabs) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int MT = HO / 32, NJ = HI / 16, NR = HI / 2;
+  const int g = blockIdx.y;
+  const float *__restrict__ xin = P.x[g];
+  const float *__restrict__ Wp = P.W[g];
+  const float *__restrict__ bp = P.b[g];
+  float *__restrict__ xout = P.out[g];
+  u32x4 *img = reinterpret_cast<u32x4 *>(lds);
+  float *bl = reinterpret_cast<float *>(img + 3 * MT * NJ * 64);
+  stage_split_matrix<HO, HI, false, WG_THREADS>(img, Wp);
+  for (int e = threadIdx.x; e < HO; e += WG_THREADS) bl[e] = bp[e];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = wave_id(), h = lane >> 5;
+  const long slab0 = (long)blockIdx.x * WAVES_PER_WG + wave, slab_stride = (long)gridDim.x * WAVES_PER_WG;
+  const u32x4 *wl = img + lane;
+  float raw[NR];
+  atl_load<HI>(xin, slab0 < n_slabs ? slab0 : 0, lane, raw);
+  for (long slab = slab0; slab < n_slabs; slab += slab_stride) {
+    u32x4 x1[NJ], x2[NJ], x3[NJ];
+    split_acts<NR>(raw, x1, x2, x3);
+    atl_load<HI>(xin, slab + slab_stride < n_slabs ? slab + slab_stride : slab, lane, raw);
+    f32x16 acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = bl[32 * t + (r & 3) + 8 * (r >> 2) + 4 * h];
+    split_gemm<MT, NJ>(wl, x1, x2, x3, acc, [](int) {});
+    float z[HO / 2];
+#pragma unroll
+    for (int R = 0; R < HO / 2; ++R) z[R] = acc[R >> 4][R & 15];
+    atl_store<HO>(xout, slab, lane, z);
+  }
+}
+
+extern "C" int harl_mlp_linear3(const float *x0, const float *x1, const float *x2, long M, int HI, int HO, const float *W0,
+                                const float *W1, const float *W2, const float *b0, const float *b1, const float *b2, float *o0,
+                                float *o1, float *o2, void *stream) {
+  if (M <= 0) return 0;
+  if (!x0 || !x1 || !x2 || !W0 || !W1 || !W2 || !b0 || !b1 || !b2 || !o0 || !o1 || !o2) return bad("harl_mlp_linear3: NULL operand");
+  const long n_slabs = n_slabs_of(M);
+  const size_t shm = split_image_bytes(HO, HI) + (size_t)HO * sizeof(float);
+  // a third of the persistent grid per product (at least what the slabs need): the three share the chip
+  int grid = persistent_grid(n_slabs, split_one_wg(HO, HI) ? 1 : 2);
+  const long need = (n_slabs + WAVES_PER_WG - 1) / WAVES_PER_WG;
+  if (grid > need) grid = (int)need;
+  if (grid < 1) grid = 1;
+  const Lin3 P = {{x0, x1, x2}, {W0, W1, W2}, {b0, b1, b2}, {o0, o1, o2}};
+  hipStream_t s = (hipStream_t)stream;
+#define L3(a, b)                                                                                                \
+  {                                                                                                             \
+    allow_big_lds(k_linear3<a, b>, shm);                                                                        \
+    hipLaunchKernelGGL((k_linear3<a, b>), dim3(grid, 3), dim3(WG_THREADS), shm, s, P, n_slabs);                 \
+  }
+  if (HI == 128 && HO == 128) L3(128, 128)
+  else if (HI == 64 && HO == 64) L3(64, 64)
+  else return bad("harl_mlp_linear3: widths must be 64 x 64 or 128 x 128");
+#undef L3
+  return check_launch("harl_mlp_linear3");
+}
+
 extern "C" int harl_mlp_linear(const float *xin, long M, int HI, int HO, const float *Wp, const float *bp, float *xout,
                                void *stream) {
   if (M <= 0) return 0;

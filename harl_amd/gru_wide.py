@@ -19,9 +19,22 @@ the fused kernels): the default for 128-wide GRUs; ``HARL_GRU128=0`` makes ``_Fl
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from ._lib import call, ptr, stream
+
+
+def _lin3(xs, rows, H, Ws, bs, outs, s, tag):
+    """Three raw gate products  z_g = W_g x_g + b_g  over ``rows`` rows: ONE launch (harl_mlp_linear3, round 6) unless
+    HARL_GRU_LIN3=0 (three harl_mlp_linear launches: A/B and the bit-for-bit cross-check of the two)."""
+    if os.environ.get("HARL_GRU_LIN3", "1") != "0":
+        call("harl_mlp_linear3", ptr(xs[0]), ptr(xs[1]), ptr(xs[2]), rows, H, H, ptr(Ws[0]), ptr(Ws[1]), ptr(Ws[2]),
+             ptr(bs[0]), ptr(bs[1]), ptr(bs[2]), ptr(outs[0]), ptr(outs[1]), ptr(outs[2]), s, tag=tag)
+        return
+    for g in range(3):
+        call("harl_mlp_linear", ptr(xs[g]), rows, H, H, ptr(Ws[g]), ptr(bs[g]), ptr(outs[g]), s, tag=tag)
 
 
 def ensure_ws(net, mp_rows: int) -> None:
@@ -69,9 +82,10 @@ def forward(net, seq: dict, save: bool) -> None:
         Wih, bih, Whh, bhh = gp["Wih"], gp["bih"], gp["Whh"], gp["bhh"]
         xin = net.xh[-1] if layer == 0 else net.rnn_hraw_l[layer - 1]
         hraw = net.rnn_hraw_l[layer]
-        for g in range(3):  # input halves of the gates, all steps at once
-            call("harl_mlp_linear", ptr(xin), M, H, H, ptr(Wih[g * H * H:(g + 1) * H * H]), ptr(bih[g * H:(g + 1) * H]),
-                 ptr(gi[g]), s, tag="gru_gi")
+        Wi = [Wih[g * H * H:(g + 1) * H * H] for g in range(3)]
+        Wh = [Whh[g * H * H:(g + 1) * H * H] for g in range(3)]
+        bi, bh = [bih[g * H:(g + 1) * H] for g in range(3)], [bhh[g * H:(g + 1) * H] for g in range(3)]
+        _lin3([xin] * 3, M, H, Wi, bi, gi, s, "gru_gi")  # input halves of the gates, all steps at once
         hpm = sv[0]
         h0 = _layer_state(seq, "h0", layer, RN, H)
         h_last = None if h_last_all is None else (h_last_all if RN == 1 else torch.empty(mp, H, dtype=h0.dtype, device=h0.device))
@@ -79,9 +93,7 @@ def forward(net, seq: dict, save: bool) -> None:
         for l in range(L):
             lo, hi = l * n, (l + 1) * n
             last = l == L - 1
-            for g in range(3):
-                call("harl_mlp_linear", ptr(hpm[lo:hi]), mp, H, H, ptr(Whh[g * H * H:(g + 1) * H * H]), ptr(bhh[g * H:(g + 1) * H]),
-                     ptr(gh[g]), s, tag="gru_gh")
+            _lin3([hpm[lo:hi]] * 3, mp, H, Wh, bh, gh, s, "gru_gh")
             sl = (lambda t: ptr(t[lo:hi])) if save else (lambda t: None)  # noqa: E731
             call("harl_gru_cell_fwd", ptr(gi[0][lo:hi]), ptr(gi[1][lo:hi]), ptr(gi[2][lo:hi]), ptr(gh[0]), ptr(gh[1]), ptr(gh[2]),
                  ptr(hpm[lo:hi]), None if last else ptr(mask_rows[(l + 1) * mp:(l + 2) * mp]), H, mp,
@@ -114,9 +126,8 @@ def backward(net, seq: dict) -> None:
                  ptr(t[2]) if nxt else None, ptr(mask_rows[(l + 1) * mp:(l + 2) * mp]) if nxt else None,
                  ptr(sv[1][lo:hi]), ptr(sv[2][lo:hi]), ptr(sv[3][lo:hi]), ptr(sv[4][lo:hi]), ptr(sv[0][lo:hi]), H, mp, ptr(gz),
                  ptr(dg[0][lo:hi]), ptr(dg[1][lo:hi]), ptr(dg[2][lo:hi]), ptr(dg[3][lo:hi]), s, tag="gru_cell_bwd")
-            if l > 0:
-                for g, src in enumerate((dg[0], dg[1], dg[3])):  # d gh = [dr, dz, dhn]
-                    call("harl_mlp_linear", ptr(src[lo:hi]), mp, H, H, ptr(WhhT[g]), ptr(zero), ptr(t[g]), s, tag="gru_gh_bwd")
+            if l > 0:  # d gh = [dr, dz, dhn]
+                _lin3([dg[0][lo:hi], dg[1][lo:hi], dg[3][lo:hi]], mp, H, [WhhT[0], WhhT[1], WhhT[2]], [zero] * 3, t, s, "gru_gh_bwd")
         if layer > 0:
             # into the layer below: d(loss)/d(h^{layer-1}_l) = sum_g W_ig^T d gi_g for all steps (no LayerNorm in between)
             WihT = gp["Wih"].view(3, H, H).transpose(1, 2).contiguous()
@@ -167,21 +178,19 @@ def tangent(net, seq: dict, xdot: torch.Tensor, pack_d: torch.Tensor, ws: dict) 
         b0 = net._gru_pack_base + 2 * layer * (n3 + 3 * H)  # the same block of the tangent arena (nets._build_tables)
         Wihd, bihd = pack_d[b0:b0 + n3], pack_d[b0 + n3:b0 + n3 + 3 * H]
         Whhd, bhhd = pack_d[b0 + n3 + 3 * H:b0 + 2 * n3 + 3 * H], pack_d[b0 + 2 * n3 + 3 * H:b0 + 2 * n3 + 6 * H]
-        for g in range(3):
-            blk, bb = slice(g * H * H, (g + 1) * H * H), slice(g * H, (g + 1) * H)
-            call("harl_mlp_linear", ptr(xin_dot), M, H, H, ptr(gp["Wih"][blk]), ptr(zero), ptr(gia[g]), s, tag="gru_gi_tan")
-            call("harl_mlp_linear", ptr(xin), M, H, H, ptr(Wihd[blk]), ptr(bihd[bb]), ptr(gib[g]), s, tag="gru_gi_tan")
+        blk = [slice(g * H * H, (g + 1) * H * H) for g in range(3)]
+        bb = [slice(g * H, (g + 1) * H) for g in range(3)]
+        _lin3([xin_dot] * 3, M, H, [gp["Wih"][b_] for b_ in blk], [zero] * 3, gia, s, "gru_gi_tan")
+        _lin3([xin] * 3, M, H, [Wihd[b_] for b_ in blk], [bihd[b_] for b_ in bb], gib, s, "gru_gi_tan")
         hdot = ws["hdot"][layer]
         for l in range(L):
             lo, hi = l * n, (l + 1) * n
             first, last = l == 0, l == L - 1
             cur, nxt = hpmd[l & 1], hpmd[(l + 1) & 1]
             hpm_l = sv[0][lo:hi]
-            for g in range(3):
-                blk, bb = slice(g * H * H, (g + 1) * H * H), slice(g * H, (g + 1) * H)
-                call("harl_mlp_linear", ptr(hpm_l), mp, H, H, ptr(Whhd[blk]), ptr(bhhd[bb]), ptr(ghb[g]), s, tag="gru_gh_tan")
-                if not first:
-                    call("harl_mlp_linear", ptr(cur), mp, H, H, ptr(gp["Whh"][blk]), ptr(zero), ptr(gha[g]), s, tag="gru_gh_tan")
+            _lin3([hpm_l] * 3, mp, H, [Whhd[b_] for b_ in blk], [bhhd[b_] for b_ in bb], ghb, s, "gru_gh_tan")
+            if not first:
+                _lin3([cur] * 3, mp, H, [gp["Whh"][b_] for b_ in blk], [zero] * 3, gha, s, "gru_gh_tan")
             ha = [None] * 3 if first else [ptr(t) for t in gha]
             call("harl_gru_cell_tangent", ptr(gia[0][lo:hi]), ptr(gia[1][lo:hi]), ptr(gia[2][lo:hi]), ptr(gib[0][lo:hi]),
                  ptr(gib[1][lo:hi]), ptr(gib[2][lo:hi]), ha[0], ha[1], ha[2], ptr(ghb[0]), ptr(ghb[1]), ptr(ghb[2]),

@@ -306,6 +306,7 @@ ALGORITHMIC_FLOPS: Dict[str, Callable[[Sequence], float]] = {
     "harl_mlp_fwd_fused2": _f_fused2,
     "harl_mlp_fwd_hidden": lambda a: 2.0 * a[1] * a[2] * a[3],
     "harl_mlp_linear": lambda a: 2.0 * a[1] * a[2] * a[3],
+    "harl_mlp_linear3": lambda a: 3 * 2.0 * a[3] * a[4] * a[5],
     "harl_mlp_fwd_wide": lambda a: 2.0 * a[1] * a[4] * a[6],
     "harl_mlp_linear_wide": lambda a: 2.0 * a[1] * a[4] * a[6],
     "harl_mlp_fwd_input": lambda a: 2.0 * a[3] * a[4] * a[8],

@@ -459,6 +459,12 @@ int harl_trpo_kl_sum(const float *head_old, const float *head_new, const float *
  *   unscaled sums.  part_scalars[n_blocks][HARL_PS_STRIDE] as harl_actor_head_loss
  *   ({0: sum loss*active, 1: sum active, 2: ent_scale * sum ent, 3: sum ratio, 4: count}); launched with n_blocks workgroups. */
 int harl_mlp_linear(const float *xin, long M, int HI, int HO, const float *Wp, const float *bp, float *xout, void *stream);
+/* Three independent raw products z_g = W_g x_g + b_g in ONE launch (x_g ATL(HI) images of M rows, W_g [HO][HI], outputs ATL(HO)):
+ * the three gate products of one time step of the composed 128-wide / stacked GRU (harl_amd/gru_wide.py; harl/models/base/rnn.py:8-81
+ * through nn.GRU's gate blocks).  Widths 64 x 64 or 128 x 128.  Same arithmetic as three harl_mlp_linear calls: bit-identical. */
+int harl_mlp_linear3(const float *x0, const float *x1, const float *x2, long M, int HI, int HO, const float *W0, const float *W1,
+                     const float *W2, const float *b0, const float *b1, const float *b2, float *o0, float *o1, float *o2,
+                     void *stream);
 int harl_md_head_logp(const float *const *z, int n_groups, const int *sp, int n_heads, const int *nvec,
                       const int *head_group, long M, const float *actions, float *logp_out, const float *old_logp,
                       int old_w, float *factor, int agg_mean, float *head_out, long m_valid, long m_pad, void *stream);

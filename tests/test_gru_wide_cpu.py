@@ -59,9 +59,11 @@ def test_gru128_launch_sequence(stub_kernels, monkeypatch):  # noqa: F811
     assert len(calls["harl_gru_cell_bwd"]) == n_bwd_steps
     n_passes_fwd = A * (2 + n_upd) + n_upd
     assert len(calls["harl_gru_cell_init"]) == n_passes_fwd and len(calls["harl_rownorm"]) == n_passes_fwd
-    # GEMMs: 3 input-gate launches per pass + 3 per forward step + 3 per backward step except the first time step of a chunk
+    # gate GEMMs: ONE three-product launch (harl_mlp_linear3, round 6; three launches each before) per pass for the input
+    # halves, per forward step, and per backward step except the first time step of a chunk
     n_bwd_passes = (A + 1) * n_upd
-    assert len(calls["harl_mlp_linear"]) == 3 * n_passes_fwd + 3 * n_fwd_steps + 3 * (n_bwd_steps - n_bwd_passes)
+    assert len(calls["harl_mlp_linear3"]) == n_passes_fwd + n_fwd_steps + (n_bwd_steps - n_bwd_passes)
+    assert "harl_mlp_linear" not in calls
     # every cell launch works on one time step of m_pad = 32 sequences at width 128; saved gates only in training passes
     assert all(c[8] == H and c[9] == 32 for c in calls["harl_gru_cell_fwd"])
     n_saving = sum(1 for c in calls["harl_gru_cell_fwd"] if c[10] is not None)
@@ -104,6 +106,10 @@ def _emulate(arena, H):
         x = arena.view(xin, M * HI).view(M, HI)
         W = arena.view(Wp, HO * HI).view(HO, HI)
         arena.view(xout, M * HO).view(M, HO).copy_(x @ W.t() + arena.view(bp, HO))
+
+    def linear3(x0, x1, x2, M, HI, HO, W0, W1, W2, b0, b1, b2, o0, o1, o2, s):  # ONE launch for the three gate products (round 6)
+        for x_, W_, b_, o_ in ((x0, W0, b0, o0), (x1, W1, b1, o1), (x2, W2, b2, o2)):
+            linear(x_, M, HI, HO, W_, b_, o_, s)
 
     def cell_init(h0, mask_rows, H_, mp, hpm0, s):
         arena.view(hpm0, mp * H).view(mp, H).copy_(arena.view(h0, mp * H).view(mp, H) * arena.view(mask_rows, mp).view(mp, 1))
@@ -166,7 +172,7 @@ def _emulate(arena, H):
         rs = arena.view(rstd, M).view(M, 1)
         arena.view(out, M * H).view(M, H).copy_(rs * (d - d.mean(-1, keepdim=True) - x * (x * d).mean(-1, keepdim=True)))
 
-    return dict(harl_mlp_linear=linear, harl_gru_cell_init=cell_init, harl_gru_cell_fwd=cell_fwd, harl_gru_cell_bwd=cell_bwd,
+    return dict(harl_mlp_linear=linear, harl_mlp_linear3=linear3, harl_gru_cell_init=cell_init, harl_gru_cell_fwd=cell_fwd, harl_gru_cell_bwd=cell_bwd,
                 harl_rownorm=rownorm, harl_mlp_bwd_dx=bwd_dx, harl_gru_cell_tangent=cell_tangent, harl_act_ln_tangent=ln_tangent)
 
 

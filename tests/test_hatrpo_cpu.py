@@ -65,11 +65,13 @@ def test_composed_gru_tangent_launches(stub_kernels, hidden, rn):  # noqa: F811
     assert t.actor.gru_wide and t.actor.recurrent_n == rn
     L = m // 2
     assert n["harl_gru_cell_tangent"] == L * rn
-    # per layer: 6 input-side GEMMs over all steps + per step 3 (W_h_dot h~) and, except at the first step, 3 more (W_h h~_dot);
-    # the backward (gru_wide.backward) adds its own harl_mlp_linear launches: 3 per step but the first, + 3 per lower layer
-    tangent_gemms = rn * (6 + 3 * L + 3 * (L - 1))
-    backward_gemms = rn * 3 * (L - 1) + 3 * (rn - 1)
-    assert n["harl_mlp_linear"] == tangent_gemms + backward_gemms
+    # gate products travel three to a launch (harl_mlp_linear3, round 6).  Per layer: 2 input-side launches over all steps + per
+    # step 1 (W_h_dot h~) and, except at the first step, 1 more (W_h h~_dot); the backward (gru_wide.backward) adds 1 per step but
+    # the first; what a layer sends to the one below (stacked GRUs) stays three single harl_mlp_linear launches
+    tangent_launches = rn * (2 + L + (L - 1))
+    backward_launches = rn * (L - 1)
+    assert n["harl_mlp_linear3"] == tangent_launches + backward_launches
+    assert n.get("harl_mlp_linear", 0) == 3 * (rn - 1)
     assert n["harl_act_ln_tangent"] == 1                       # rnn.norm's tangent (no activation)
     ln = stub_kernels["harl_act_ln_tangent"][0]
     assert ln[1] is None and ln[3] is None and ln[7] == 0

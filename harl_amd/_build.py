@@ -9,8 +9,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libharl_hip.so")
-SOURCES = ["elementwise.hip", "mlp.hip", "wide.hip", "panel.hip", "heads.hip", "multihead.hip", "update.hip", "gru.hip", "gru_cell.hip", "host_rng.hip", "comm.hip"]
-HEADERS = ["common.h", "split_mfma.h", "mfma_transpose.h", "heads_common.h", "dw_common.h", os.path.join("..", "..", "include", "harl_hip.h")]
+SOURCES = ["elementwise.hip", "mlp.hip", "wide.hip", "trunk.hip", "panel.hip", "heads.hip", "multihead.hip", "update.hip", "gru.hip", "gru_cell.hip", "host_rng.hip", "comm.hip"]
+HEADERS = ["common.h", "split_mfma.h", "mfma_transpose.h", "heads_common.h", "dw_common.h", "fwd_epilogue.h", os.path.join("..", "..", "include", "harl_hip.h")]
 
 
 # MFMA results in VGPRs instead of AGPRs: the epilogues (LayerNorm / ReLU, operand splits, transposes) consume every
@@ -20,7 +20,7 @@ HEADERS = ["common.h", "split_mfma.h", "mfma_transpose.h", "heads_common.h", "dw
 # (gpurun_out/r3_vgpr_suite.log: 107 passed; A/B on one box 21.53 / 21.69 -> 20.93 / 21.18 ms per MPE update).
 # HARL_HIPCC_EXTRA="mlp.hip:;gru.hip:..." overrides per file for A/B builds.
 VGPR_FORM = ["-mllvm", "-amdgpu-mfma-vgpr-form"]
-DEFAULT_EXTRA: dict = {"mlp.hip": VGPR_FORM, "gru.hip": VGPR_FORM, "panel.hip": VGPR_FORM}
+DEFAULT_EXTRA: dict = {"mlp.hip": VGPR_FORM, "gru.hip": VGPR_FORM, "panel.hip": VGPR_FORM, "trunk.hip": VGPR_FORM}
 
 
 def _extra_flags() -> dict:

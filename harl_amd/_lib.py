@@ -55,6 +55,9 @@ SIGNATURES = {
     "harl_mlp_bwd_dx_dw": [_vp, _vp, _vp, _vp, _l, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _vp],
     "harl_mlp_dw_partials": [_vp, _i, _i, _i, _vp, _i, _l, _vp, _vp, _vp, _i, _l, _vp, _i, _vp],
     "harl_mlp_dw_partials_multi": [_i, _vp, _vp, _vp, _i, _i, _l, _i, _vp],
+    "harl_mlp_dw_partials_multi_v": [_i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _l, _i, _vp],
+    "harl_mlp_fwd_trunk": [_vp, _l, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "harl_mlp_bwd_trunk": [_l, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "harl_reduce_partials": [_vp, _i, _l, _vp, _vp],
     "harl_reduce_partials_multi": [_vp, _vp, _i, _i, _l, _vp, _vp],
     "harl_adam_fold": [_vp, _vp, _vp, _vp, _l, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _f, _i, _i, _vp, _i, _f, _d, _d,

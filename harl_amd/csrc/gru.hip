@@ -1210,11 +1210,17 @@ extern "C" int harl_gru_fwd(const float *xin, const float *mask_rows, const floa
   long wgs = (groups + WAVES_PER_WG - 1) / WAVES_PER_WG;
   const int grid = (int)(wgs < 256 ? wgs : 256);
   hipStream_t s = (hipStream_t)stream;
+  // bit 1 of `save`: gi_ws already holds the input half of the gates (harl_mlp_fwd_trunk wrote it from the last MLP layer's
+  // registers: the same product, bit for bit) -- the parallel gate launch is skipped, xin is not read
+  const bool gates_done = (save & 2) != 0;
+  save &= 1;
+  if (gates_done && !gi_ws) { set_error("harl_gru_fwd: save bit 1 (gates precomputed) needs gi_ws"); return -2; }
   if (gi_ws) {  // two phases: parallel x half over all L*groups slabs, then the recurrence with W_hh only
     const long n_slabs = (long)L * groups, M = n_slabs * SLAB;
     float *gr = gi_ws, *gz = gi_ws + M * GH, *gn = gi_ws + 2 * M * GH;
     static const bool gates_f32 = [] { const char *e = getenv("HARL_GRU_GATES_F32"); return e && e[0] == '1'; }();
-    if (gates_f32) {
+    if (gates_done) {
+    } else if (gates_f32) {
       const size_t shm_x = ((size_t)3 * GH * (GH + 1) + 3 * GH) * sizeof(float);
       allow_big_lds(k_gru_gates_x, shm_x);
       hipLaunchKernelGGL(k_gru_gates_x, dim3(persistent_grid(n_slabs, 1)), dim3(WG_THREADS), shm_x, s, xin, Wih, bih, bhh,
@@ -1281,6 +1287,7 @@ extern "C" int harl_gru_bwd(const float *dhout, const float *mask_rows, const fl
     hipLaunchKernelGGL(k_gru_bwd, dim3(grid), dim3(WG_THREADS), shm, (hipStream_t)stream, dhout, mask_rows, Whh, hpm, r, z, n, hn,
                        L, m_pad, dr, dz, dn, dhn);
   }
+  if (!dz_mlp) return check_launch("harl_gru_bwd");  // the input side is the caller's (harl_mlp_bwd_trunk's first stage)
   const long n_slabs = (long)L * groups;
   allow_big_lds(k_gru_dx, shm);
   hipLaunchKernelGGL(k_gru_dx, dim3(persistent_grid(n_slabs, 2)), dim3(WG_THREADS), shm, (hipStream_t)stream, Wih, dr, dz, dn,

@@ -20,6 +20,7 @@
 #include "split_mfma.h"
 #include "mfma_transpose.h"
 #include "dw_common.h"
+#include "fwd_epilogue.h"
 #include "../../include/harl_hip.h"
 #include <stdlib.h>
 #include <type_traits>
@@ -27,68 +28,6 @@
 using namespace harl;
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
-
-// ---------------------------------------------------------------------------------------------
-// epilogue shared by both forward kernels: relu, relu bit-mask, LayerNorm statistics over the
-// H features of each sample (in-lane + partner half), normalise, store ATL / mask / rstd.
-// ---------------------------------------------------------------------------------------------
-template <int HO>
-__device__ __forceinline__ void relu_norm_regs(f32x16 (&acc)[HO / 32], float (&v)[HO / 2], uint32_t (&bits)[(HO / 2 + 31) / 32],
-                                               float &rstd_out) {
-  constexpr int NR = HO / 2;
-#pragma unroll
-  for (int w = 0; w < (NR + 31) / 32; ++w) bits[w] = 0u;
-#pragma unroll
-  for (int R = 0; R < NR; ++R) v[R] = relu_push(acc[R >> 4][R & 15], bits[R >> 5]);
-  // statistics and normalisation on register pairs (v_pk_add_f32 / v_pk_fma_f32 / v_pk_mul_f32)
-  f32x2 s2v = {0.f, 0.f};
-#pragma unroll
-  for (int P = 0; P < NR / 2; ++P) s2v += f32x2{v[2 * P], v[2 * P + 1]};
-  float sum = s2v[0] + s2v[1];
-  sum = wave_sum32(sum);
-  const float mean = sum * (1.0f / HO);
-  const f32x2 mv = {mean, mean};
-  f32x2 vsv = {0.f, 0.f};
-#pragma unroll
-  for (int P = 0; P < NR / 2; ++P) {
-    const f32x2 d = f32x2{v[2 * P], v[2 * P + 1]} - mv;
-    vsv = __builtin_elementwise_fma(d, d, vsv);
-    v[2 * P] = d[0];
-    v[2 * P + 1] = d[1];
-  }
-  float vs = vsv[0] + vsv[1];
-  vs = wave_sum32(vs);
-  const float rstd = 1.0f / sqrtf(vs * (1.0f / HO) + 1e-5f);
-  const f32x2 rv = {rstd, rstd};
-#pragma unroll
-  for (int P = 0; P < NR / 2; ++P) {
-    const f32x2 o = f32x2{v[2 * P], v[2 * P + 1]} * rv;
-    v[2 * P] = o[0];
-    v[2 * P + 1] = o[1];
-  }
-  rstd_out = rstd;
-}
-
-template <int HO>
-__device__ __forceinline__ void act_store(const float (&v)[HO / 2], const uint32_t (&bits)[(HO / 2 + 31) / 32], float rstd,
-                                          int lane, long slab, float *__restrict__ xout,
-                                          uint32_t *__restrict__ mask_out, float *__restrict__ rstd_out) {
-  constexpr int NW = (HO / 2 + 31) / 32;
-  atl_store<HO>(xout, slab, lane, v);
-#pragma unroll
-  for (int w = 0; w < NW; ++w) mask_out[(slab * NW + w) * WAVE + lane] = bits[w];
-  if (lane < 32) rstd_out[slab * SLAB + lane] = rstd;
-}
-
-template <int HO>
-__device__ __forceinline__ void relu_norm_store(f32x16 (&acc)[HO / 32], int lane, long slab, float *__restrict__ xout,
-                                                uint32_t *__restrict__ mask_out, float *__restrict__ rstd_out) {
-  float v[HO / 2];
-  uint32_t bits[(HO / 2 + 31) / 32];
-  float rstd;
-  relu_norm_regs<HO>(acc, v, bits, rstd);
-  act_store<HO>(v, bits, rstd, lane, slab, xout, mask_out, rstd_out);
-}
 
 // forward-mode (tangent) epilogue: given the tangent of the pre-activation in acc and the PRIMAL x_hat / relu mask /
 // rstd of this layer,  a_dot = mask ? z_dot : 0 ;  x_hat_dot = rstd (a_dot - mean_f(a_dot) - x_hat mean_f(a_dot x_hat))
@@ -1208,6 +1147,33 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_dw_tr_multi(DwMulti P, long n
   dw_tr_body<MT, NT>(P.a[blockIdx.y], P.b[blockIdx.y], n_slabs, P.part[blockIdx.y], (long)KP * SLAB, 0, KP);
 }
 
+// ... and of DIFFERENT shapes (round 6): every weight gradient of a 64-wide recurrent network -- the three MLP layers (the first
+// one against the wide x0n image, in groups of <= 4 column tiles) and the six gate blocks -- was four launches per optimiser step;
+// blockIdx.y picks the problem, its column-tile count picks the body (all four instantiations live in the one kernel, LDS and
+// registers sized for the widest).  Each problem is computed exactly as its own k_dw_tr<MT, nt> launch would.
+constexpr int DW_MULTIV_MAX = 12;
+struct DwMultiV {
+  const float *a[DW_MULTIV_MAX];
+  const float *b[DW_MULTIV_MAX];
+  float *part[DW_MULTIV_MAX];
+  int K[DW_MULTIV_MAX];      // width of the B image (row stride of dWp in the partial)
+  int tile0[DW_MULTIV_MAX];  // first 32-column tile of this group
+  int nt[DW_MULTIV_MAX];     // column tiles of this group (1..4)
+};
+template <int MT>
+__global__ __launch_bounds__(WG_THREADS, 2) void k_dw_tr_multi_v(DwMultiV P, long n_slabs) {
+  const int y = blockIdx.y;
+  const float *a = P.a[y], *b = P.b[y];
+  float *part = P.part[y];
+  const int K = P.K[y], t0 = P.tile0[y];
+  switch (P.nt[y]) {  // (workgroup-uniform)
+    case 1: dw_tr_body<MT, 1>(a, b, n_slabs, part, (long)K * SLAB, t0, K); break;
+    case 2: dw_tr_body<MT, 2>(a, b, n_slabs, part, (long)K * SLAB, t0, K); break;
+    case 3: dw_tr_body<MT, 3>(a, b, n_slabs, part, (long)K * SLAB, t0, K); break;
+    default: dw_tr_body<MT, 4>(a, b, n_slabs, part, (long)K * SLAB, t0, K); break;
+  }
+}
+
 // =============================================================================================
 // k_bwd_dx_dw: the WHOLE backward of one hidden Linear(128 -> 128) and the relu + LayerNorm in front of it in ONE persistent
 // launch (round 5): dz_prev = LNrelu'(Wp^T dz), dW' += dz^T x_hat_prev, db' += sum dz, and -- first-layer variant, KT = 1 --
@@ -2023,4 +1989,30 @@ extern "C" int harl_mlp_dw_partials_multi(int n, const float *const *a, const fl
   else return bad("harl_mlp_dw_partials_multi: square 64 / 128 blocks only");
 #undef DWM
   return check_launch("harl_mlp_dw_partials_multi");
+}
+
+extern "C" int harl_mlp_dw_partials_multi_v(int n, const float *const *a, const float *const *b, float *const *part, int HO,
+                                            const int *K, const int *tile0, const int *nt, long M, int n_wg, void *stream) {
+  if (M <= 0 || n_wg <= 0 || n <= 0) return 0;
+  if (n > DW_MULTIV_MAX) return bad("harl_mlp_dw_partials_multi_v: at most 12 problems per launch");
+  if (HO != 64) return bad("harl_mlp_dw_partials_multi_v: 64-row operands only");
+  const long n_slabs = n_slabs_of(M);
+  DwMultiV P;
+  int ntmax = 1;
+  for (int k = 0; k < DW_MULTIV_MAX; ++k) {
+    const int j = k < n ? k : 0;
+    if (K[j] % 32 != 0 || K[j] < 32 || K[j] > 512 || nt[j] < 1 || nt[j] > 4 || tile0[j] < 0 || 32 * (tile0[j] + nt[j]) > K[j])
+      return bad("harl_mlp_dw_partials_multi_v: K must be a multiple of 32 up to 512, 1 <= nt <= 4, the group inside the image");
+    P.a[k] = a[j];
+    P.b[k] = b[j];
+    P.part[k] = part[j];
+    P.K[k] = K[j];
+    P.tile0[k] = tile0[j];
+    P.nt[k] = nt[j];
+    if (nt[j] > ntmax) ntmax = nt[j];
+  }
+  const size_t shm = (size_t)3 * 8 * ((2 * 2 * 128 + 8) + (2 * 4 * 128 + 8));  // k_dw_tr<2, 4>'s staging area
+  allow_big_lds(k_dw_tr_multi_v<2>, shm);
+  hipLaunchKernelGGL((k_dw_tr_multi_v<2>), dim3(n_wg, n), dim3(WG_THREADS), shm, (hipStream_t)stream, P, n_slabs);
+  return check_launch("harl_mlp_dw_partials_multi_v");
 }

@@ -84,6 +84,10 @@ __device__ __forceinline__ void split_acts(const float (&v)[NR], u32x4 (&x1)[NR 
 
 constexpr size_t split_image_bytes(int rows, int k) { return (size_t)3 * rows * k * 2; }
 
+// fp32 Wp[H][D] -> the three bf16 images [term][tile][k-step][64 lanes] x 16 B in GLOBAL memory, K zero-padded to KP (one small
+// launch on `stream`; wide.hip).  The operand of the kernels that stream their weight fragments from L2 (k_fwd_wide, k_fwd_trunk).
+void launch_split_image(const float *Wp, int H, int D, int KP, void *img, hipStream_t stream);
+
 // Workgroup-cooperative staging of the three weight images from the fp32 row-major matrix Wp[HO][HI].
 //   TRANSPOSED = false: GEMM rows = Wp rows (forward, M = HO, K = HI):  A[row][k] = Wp[row][k]
 //   TRANSPOSED = true : GEMM rows = Wp columns (backward dX, M = HI, K = HO):  A[row][k] = Wp[k][row]

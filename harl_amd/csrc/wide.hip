@@ -16,6 +16,7 @@
 #include <stdlib.h>
 #include "common.h"
 #include "split_mfma.h"
+#include "fwd_epilogue.h"
 #include "../../include/harl_hip.h"
 
 using namespace harl;
@@ -302,71 +303,6 @@ __global__ __launch_bounds__(256) void k_split_image(const float *__restrict__ W
     }
 #pragma unroll
     for (int term = 0; term < 3; ++term) img[(long)term * total + e] = u32x4{p[term][0], p[term][1], p[term][2], p[term][3]};
-  }
-}
-
-// epilogue of one slab of the wide GEMMs.  MODE 0: ReLU + LayerNorm + mask; MODE 1 (tangent): the LayerNorm Jacobian (forward mode,
-// the bias slot carries b'_dot):  x_dot = LNjac(mask * z_dot) with the PRIMAL x_hat / mask / rstd;  MODE 2 (raw): z as an ATL image
-template <int HO, int MODE>
-__device__ __forceinline__ void wide_epilogue(f32x16 (&acc)[HO / 32], long slab, int lane, float *__restrict__ xout,
-                                              uint32_t *__restrict__ mask_out, float *__restrict__ rstd_out,
-                                              const float *__restrict__ xprimal, const uint32_t *__restrict__ mask_in,
-                                              const float *__restrict__ rstd_in) {
-  constexpr int NR = HO / 2, NW = (NR + 31) / 32;
-  if constexpr (MODE == 2) {
-    float z[NR];
-#pragma unroll
-    for (int R = 0; R < NR; ++R) z[R] = acc[R >> 4][R & 15];
-    atl_store<HO>(xout, slab, lane, z);
-  } else if constexpr (MODE == 1) {
-    float xh[NR];
-    atl_load<HO>(xprimal, slab, lane, xh);
-    uint32_t bits[NW];
-#pragma unroll
-    for (int w = 0; w < NW; ++w) bits[w] = mask_in[(slab * NW + w) * WAVE + lane];
-    const float rstd = rstd_in[slab * SLAB + (lane & 31)];
-    float ad[NR];
-    float q1 = 0.f, q2 = 0.f;
-#pragma unroll
-    for (int R = 0; R < NR; ++R) {
-      ad[R] = mask_pop(acc[R >> 4][R & 15], bits[R >> 5]);
-      q1 += ad[R];
-      q2 += ad[R] * xh[R];
-    }
-    q1 = wave_sum32(q1);
-    q2 = wave_sum32(q2);
-    q1 *= (1.0f / HO);
-    q2 *= (1.0f / HO);
-#pragma unroll
-    for (int R = 0; R < NR; ++R) ad[R] = rstd * (ad[R] - q1 - xh[R] * q2);
-    atl_store<HO>(xout, slab, lane, ad);
-  } else {
-    uint32_t bits[NW];
-#pragma unroll
-    for (int w = 0; w < NW; ++w) bits[w] = 0u;
-    float v[NR];
-    float sum = 0.f;
-#pragma unroll
-    for (int R = 0; R < NR; ++R) {
-      v[R] = relu_push(acc[R >> 4][R & 15], bits[R >> 5]);
-      sum += v[R];
-    }
-    sum = wave_sum32(sum);
-    const float mean = sum * (1.0f / HO);
-    float vs = 0.f;
-#pragma unroll
-    for (int R = 0; R < NR; ++R) {
-      v[R] -= mean;
-      vs += v[R] * v[R];
-    }
-    vs = wave_sum32(vs);
-    const float rstd = 1.0f / sqrtf(vs * (1.0f / HO) + 1e-5f);
-#pragma unroll
-    for (int R = 0; R < NR; ++R) v[R] *= rstd;
-    atl_store<HO>(xout, slab, lane, v);
-#pragma unroll
-    for (int w = 0; w < NW; ++w) mask_out[(slab * NW + w) * WAVE + lane] = bits[w];
-    if (lane < 32) rstd_out[slab * SLAB + lane] = rstd;
   }
 }
 
@@ -809,6 +745,11 @@ int launch_wide(const float *x0n, long M, int KP, const float *Wp, int D, const 
 }
 
 }  // namespace
+
+void harl::launch_split_image(const float *Wp, int H, int D, int KP, void *img, hipStream_t stream) {
+  const int total = (H / 32) * (KP / 16) * 64;
+  hipLaunchKernelGGL(k_split_image, dim3((total + 255) / 256), dim3(256), 0, stream, Wp, H, D, KP, reinterpret_cast<u32x4 *>(img));
+}
 
 HARL_PHASE_ACCESSOR(wide)
 

@@ -372,7 +372,9 @@ class _FlatNet(nn.Module):
             self.zraw = torch.empty(mp * hmax, dtype=f32, device=dev)
             self.amean = [torch.empty(mp, dtype=f32, device=dev) for _ in self.hidden_sizes]
             self.ones_mask = torch.full((n_slabs * 64 * 2,), -1, dtype=u32, device=dev)
-        self.dz = [torch.empty(mp * hmax, dtype=f32, device=dev) for _ in range(2)]            # ping-pong, ATL
+        # ping-pong, ATL; a third one where the one-launch trunk backward keeps every layer's dz for the weight-gradient launch
+        self.dz = [torch.empty(mp * hmax, dtype=f32, device=dev) for _ in range(3 if len(self.hidden_sizes) == 3 and self.trunk_fused() else 2)]
+        self._trunk_cache = {}
         # head gradients for the separate dW pass: row-major [mp][32], or the ATL(64) image of a 33..64-way Categorical head
         self.wide_head = (not self.md) and self._layers()[-1][4] > 32
         self.dhead = torch.zeros(mp * (64 if self.wide_head else DHEAD_LD), dtype=f32, device=dev)
@@ -430,8 +432,9 @@ class _FlatNet(nn.Module):
             return self.xh[-1], self.ones_mask, self.rstd[-1], self.hidden_sizes[-1]
         return self.xh[-1], self.rmask[-1], self.rstd[-1], self.hidden_sizes[-1]
 
-    def forward_rnn(self, seq: dict, save: bool) -> None:
-        """GRU over a recurrent batch (seq: L, m_pad, h0 [m_pad, H], mask_rows [L*m_pad], optional h_last out)."""
+    def forward_rnn(self, seq: dict, save: bool, gates_done: bool = False) -> None:
+        """GRU over a recurrent batch (seq: L, m_pad, h0 [m_pad, H], mask_rows [L*m_pad], optional h_last out).
+        ``gates_done``: self.rnn_gi already holds the input half of the gates (harl_mlp_fwd_trunk, forward_trunk)."""
         if self.gru_wide:
             from . import gru_wide
             return gru_wide.forward(self, seq, save)
@@ -440,7 +443,31 @@ class _FlatNet(nn.Module):
         call("harl_gru_fwd", ptr(self.xh[-1]), ptr(seq["mask_rows"]), ptr(seq["h0"]), ptr(gp["Wih"]), ptr(gp["bih"]),
              ptr(gp["Whh"]), ptr(gp["bhh"]), self.hidden_sizes[-1], seq["L"], seq["m_pad"], ptr(self.rnn_y),
              ptr(self.rnn_rstd), ptr(sv[0]), ptr(sv[1]), ptr(sv[2]), ptr(sv[3]), ptr(sv[4]), ptr(seq.get("h_last")),
-             int(save), ptr(self.rnn_gi), stream(), tag="gru_fwd")
+             int(save) | (2 if gates_done else 0), ptr(self.rnn_gi), stream(), tag="gru_fwd")
+
+    # ---- the whole 64-wide trunk in one launch per direction (csrc/trunk.hip, round 6)
+    def trunk_fused(self) -> bool:
+        """Wide first layer + one or two more 64-wide ReLU layers (the SMAC shapes: obs 128 / 216 -> [64, 64, 64] -> GRU):
+        harl_mlp_fwd_trunk / harl_mlp_bwd_trunk / harl_mlp_dw_partials_multi_v replace the layer launches one for one,
+        bit-identically.  HARL_TRUNK_FUSED=0 keeps the layer-by-layer launches (A/B, tests/gpu_checks.check_trunk_fused)."""
+        hs = self.hidden_sizes
+        return (os.environ.get("HARL_TRUNK_FUSED", "1") != "0" and self.wide and not self.act_id and not self.panel
+                and 2 <= len(hs) <= 3 and all(h == 64 for h in hs))
+
+    def _trunk_ptrs(self, save: bool, gates: bool):
+        """ctypes pointer arrays of harl_mlp_fwd_trunk for the current workspaces (cached: they change with _ensure_ws only)."""
+        key = (save, gates, self._max_rows)
+        hit = self._trunk_cache.get(key)
+        if hit is None:
+            import ctypes as C
+            L = len(self.hidden_sizes)
+            keep = [save or (l == L - 1 and not gates) for l in range(L)]  # activation records a later kernel reads
+            vp = lambda ts: (C.c_void_p * len(ts))(*[ptr(t) for t in ts])  # noqa: E731
+            hit = self._trunk_cache[key] = (
+                vp([self._packs[l][0] for l in range(1, L)]), vp([self._packs[l][1] for l in range(1, L)]),
+                vp([self.xh[l] if keep[l] else None for l in range(L)]), vp([self.rmask[l] if keep[l] else None for l in range(L)]),
+                vp([self.rstd[l] if keep[l] else None for l in range(L)]))
+        return hit
 
     def _x0n_image(self, X: torch.Tensor, M: int, s, idx: Optional[torch.Tensor] = None) -> None:
         """Normalised inputs of rows X[idx] as the ATL(kp0) image self.x0n (csrc/wide.hip).  It depends on the rows only:
@@ -497,6 +524,20 @@ class _FlatNet(nn.Module):
                 xin, kp, d = (self.x0n, self.kp0, self.in_dim) if l == 0 else (self.xh[l - 1], 256, 256)
                 call("harl_mlp_panel_fwd", ptr(xin), M, kp, ptr(Wp), d, ptr(bp), 256, ptr(self.xh[l]), ptr(self.rmask[l]),
                      ptr(self.rstd[l]), s, tag="fwd_panel")
+            return
+        if upto is None and self.trunk_fused():
+            # every layer (+ the input half of a fused GRU's gates) in ONE launch; forward-only passes write nothing but what
+            # the next kernel reads (the three gate images, or x_hat_L)
+            gates = self.recurrent and not self.gru_wide
+            Wp, bp = self._packs[0]
+            self._x0n_image(X, M, s, idx)
+            pW, pb, pX, pM, pR = self._trunk_ptrs(bool(rnn_save), gates)
+            gp = self.gru_pack if gates else None
+            call("harl_mlp_fwd_trunk", ptr(self.x0n), M, self.kp0, ptr(Wp), self.in_dim, ptr(bp), 64, ptr(self.w1img),
+                 len(hs) - 1, pW, pb, pX, pM, pR, ptr(gp["Wih"]) if gates else None, ptr(gp["bih"]) if gates else None,
+                 ptr(gp["bhh"]) if gates else None, ptr(self.rnn_gi) if gates else None, s, tag="fwd_trunk")
+            if self.recurrent:
+                self.forward_rnn(seq, save=rnn_save, gates_done=gates)
             return
         if len(hs) >= 2 and hs[0] == hs[1] and self.in_dim <= 64 and idx is None:
             # layers 1+2 fused, from the x0n image: the rows are gathered and normalised ONCE per buffer (every epoch, log-prob
@@ -641,6 +682,8 @@ class _FlatNet(nn.Module):
             else:
                 call("harl_mlp_dw_partials", ptr(self.dhead), 1, DHEAD_LD, hdim, ptr(fx), 0, 0, None, None, None, fh, M,
                      ptr(self.part[po[-1]:]), nwg, s, tag="dw_head")
+        if self.trunk_fused() and not self.gru_wide:
+            return self._backward_trunk_fused(M, seq, s)
         cur = 0  # self.dz[cur] holds dz of the last MLP layer (non-recurrent) / d(loss)/d(h) (recurrent)
         if self.recurrent:
             gp, sv, dg = self.gru_pack, self.rnn_saved, self.rnn_dgate
@@ -763,6 +806,53 @@ class _FlatNet(nn.Module):
             e1.record(self._bwd_side())
             torch.cuda.current_stream(self.device_).wait_event(e1)
         # deterministic fixed-order combine of every entry's per-workgroup partials, one launch
+        self._combine_partials(s)
+
+    def _backward_trunk_fused(self, M: int, seq: Optional[dict], s) -> None:
+        """The 64-wide trunk's backward in three launches (csrc/trunk.hip): [the GRU's recurrence, harl_gru_bwd without its
+        input side] -> harl_mlp_bwd_trunk (W_ih'^T d gates + every hidden Linear's dx, every dz written once) ->
+        harl_mlp_dw_partials_multi_v (the weight gradients of all MLP layers and of the six gate blocks) -> the combine.
+        Each stage is the layer kernel's arithmetic; only the first-layer gradient of 33..63-wide inputs differs from the
+        layer path in summation order (that path folds it into harl_mlp_bwd_dx on the matrix-pipe transposes)."""
+        import ctypes as C
+        L, po, nwg = len(self.hidden_sizes), self._part_offs, self.n_wg
+        spare = [self.dz[2]] if L == 3 else []
+        if self.recurrent:
+            gp, sv, dg = self.gru_pack, self.rnn_saved, self.rnn_dgate
+            call("harl_gru_bwd", ptr(self.dz[0]), ptr(seq["mask_rows"]), ptr(gp["Wih"]), ptr(gp["Whh"]), ptr(sv[0]),
+                 ptr(sv[1]), ptr(sv[2]), ptr(sv[3]), ptr(sv[4]), 64, seq["L"], seq["m_pad"], ptr(self.xh[-1]),
+                 ptr(self.rmask[-1]), ptr(self.rstd[-1]), ptr(dg[0]), ptr(dg[1]), ptr(dg[2]), ptr(dg[3]), None, s, tag="gru_bwd")
+            dzs = [self.dz[1], self.dz[0]] + spare  # dz of layers L-1 .. 0 (d(loss)/d(h) in dz[0] is dead after the recurrence)
+        else:
+            dzs = [self.dz[0], self.dz[1]] + spare
+        args = self._trunk_cache.get("bwd")
+        if args is None:
+            vp = lambda ts: (C.c_void_p * len(ts))(*[ptr(t) for t in ts])  # noqa: E731
+            top_down = range(L - 1, -1, -1)
+            a, b, part, K, t0, nt = [], [], [], [], [], []
+
+            def add(aa, bb, l, k, t, n):
+                a.append(aa), b.append(bb), part.append(self.part[po[l]:]), K.append(k), t0.append(t), nt.append(n)
+            if self.recurrent:  # W_ih' blocks d gi_g^T x_hat_mlp (g = r, z, n), W_hh blocks d gh_g^T h~ (dhn for n)
+                for k, (aa, bb) in enumerate(zip((dg[0], dg[1], dg[2], dg[0], dg[1], dg[3]), [self.xh[-1]] * 3 + [sv[0]] * 3)):
+                    add(aa, bb, L + k, 64, 0, 2)
+            for j, l in enumerate(range(L - 1, 0, -1)):
+                add(dzs[j], self.xh[l - 1], l, 64, 0, 2)
+            for t in range(0, self.kp0 // 32, 4):  # the wide first layer in groups of <= 4 column tiles
+                add(dzs[L - 1], self.x0n, 0, self.kp0, t, min(4, self.kp0 // 32 - t))
+            n = len(a)
+            ci = lambda v: (C.c_int * n)(*v)  # noqa: E731
+            args = self._trunk_cache["bwd"] = (
+                vp([self._packs[l][0] for l in range(L - 1, 0, -1)]), vp([self.xh[l] for l in top_down]),
+                vp([self.rmask[l] for l in top_down]), vp([self.rstd[l] for l in top_down]),
+                vp([dzs[0] if self.recurrent else None] + dzs[1:]), (n, vp(a), vp(b), vp(part), ci(K), ci(t0), ci(nt)))
+        pW, pX, pM, pR, pD, (n, pa, pb, pp, pK, pT, pN) = args
+        if self.recurrent:
+            call("harl_mlp_bwd_trunk", M, 64, L - 1, ptr(gp["Wih"]), ptr(dg[0]), ptr(dg[1]), ptr(dg[2]), None, pW, pX, pM, pR, pD, s,
+                 tag="bwd_trunk")
+        else:
+            call("harl_mlp_bwd_trunk", M, 64, L - 1, None, None, None, None, ptr(self.dz[0]), pW, pX, pM, pR, pD, s, tag="bwd_trunk")
+        call("harl_mlp_dw_partials_multi_v", n, pa, pb, pp, 64, pK, pT, pN, M, nwg, s, tag="dw_trunk")
         self._combine_partials(s)
 
     # ---- MultiDiscrete heads (csrc/multihead.hip): logits of every group from the head input; backward of the groups

@@ -83,15 +83,44 @@ def _dw_partials_multi(a: Sequence) -> float:
 
 def _gru_fwd(a: Sequence) -> float:
     # (xin, mask_rows, h0, Wih, bih, Whh, bhh, H, L, m_pad, y, rstd_y, hpm, r, z, n, hn, h_last, save, gi_ws, stream)
+    # save bit 1: the input half of the gates was written by harl_mlp_fwd_trunk -- the three gate images are read instead of x_hat
     H, L, m_pad, save = a[7], a[8], a[9], a[18]
-    return L * m_pad * (4.0 * H + 4.0 + 4.0 * H + 4.0 + (5 * 4.0 * H if save else 0.0))
+    xin = 3 * 4.0 * H if (save & 2) else 4.0 * H
+    return L * m_pad * (xin + 4.0 + 4.0 * H + 4.0 + (5 * 4.0 * H if (save & 1) else 0.0))
 
 
 def _gru_bwd(a: Sequence) -> float:
     # reads dhout + the five saved images + the MLP output feeding the GRU (+mask, rstd); writes the four gate gradients
     # and the gradient into the MLP
     H, L, m_pad = a[9], a[10], a[11]
+    if not a[19]:  # dz_mlp = NULL: the input side is harl_mlp_bwd_trunk's first stage
+        return L * m_pad * (6 * 4.0 * H + 4.0 + 4 * 4.0 * H)
     return L * m_pad * (6 * 4.0 * H + 4.0 + _act(H) + 4 * 4.0 * H + 4.0 * H)
+
+
+def _nonnull(arr) -> int:
+    return sum(1 for p in arr if p)
+
+
+def _fwd_trunk(a: Sequence) -> float:
+    # (x0n, M, KP, W1p, D, b1p, H, w_img, n_hidden, Wp, bp, xout, relu_mask, rstd, Wih, bih, bhh, gi_ws, stream): the input image,
+    # the activation records that are written, the three gate images
+    M, KP, H = a[1], a[2], a[6]
+    return M * (4.0 * KP + _nonnull(a[11]) * _act(H) + (3 * 4.0 * H if a[17] else 0.0))
+
+
+def _bwd_trunk(a: Sequence) -> float:
+    # (M, H, n_hidden, Wih, dr, dzg, dn, dz_in, Wp, xh, relu_mask, rstd, dz_out, stream): gate gradients (or dz of the top layer) in,
+    # one activation record read and one dz written per stage
+    M, H, nh = a[0], a[1], a[2]
+    top = (3 * 4.0 * H + _act(H) + 4.0 * H) if a[3] else 4.0 * H
+    return M * (top + nh * (_act(H) + 4.0 * H))
+
+
+def _dw_partials_multi_v(a: Sequence) -> float:
+    # (n, a_ptrs, b_ptrs, part_ptrs, HO, K[], tile0[], nt[], M, n_wg, stream): every problem reads its dz rows and its column group
+    n, HO, M = a[0], a[4], a[8]
+    return M * sum(4.0 * HO + 4.0 * 32 * a[7][k] for k in range(n))
 
 
 def _head_rows(discrete: int, act_dim: int, avail) -> float:  # actions + old log-probs (+ availability mask) of one row
@@ -197,6 +226,9 @@ ALGORITHMIC_BYTES: Dict[str, Callable[[Sequence], float]] = {
     "harl_mlp_bwd_dx_dw": _bwd_dx_dw,
     "harl_mlp_dw_partials": _dw_partials,
     "harl_mlp_dw_partials_multi": _dw_partials_multi,
+    "harl_mlp_dw_partials_multi_v": _dw_partials_multi_v,
+    "harl_mlp_fwd_trunk": _fwd_trunk,
+    "harl_mlp_bwd_trunk": _bwd_trunk,
     "harl_gru_fwd": _gru_fwd,
     "harl_gru_bwd": _gru_bwd,
     "harl_actor_head_loss": _actor_head_loss,
@@ -287,14 +319,24 @@ def _f_dw_multi(a):  # (n, a_ptrs, b_ptrs, part_ptrs, HO, K, M, ...)
     return 2.0 * a[0] * a[6] * a[4] * a[5]
 
 
-def _f_gru_fwd(a):  # input + recurrent halves of the three gates
+def _f_gru_fwd(a):  # input + recurrent halves of the three gates (save bit 1: the input half ran inside harl_mlp_fwd_trunk)
     H, L, m_pad = a[7], a[8], a[9]
-    return 2.0 * L * m_pad * 6 * H * H
+    return 2.0 * L * m_pad * (3 if (a[18] & 2) else 6) * H * H
 
 
 def _f_gru_bwd(a):
     H, L, m_pad = a[9], a[10], a[11]
-    return 2.0 * L * m_pad * 6 * H * H
+    return 2.0 * L * m_pad * (6 if a[19] else 3) * H * H
+
+
+def _f_fwd_trunk(a):  # first layer + hidden layers (+ the input half of the gates)
+    M, D, H, nh = a[1], a[4], a[6], a[8]
+    return 2.0 * M * (D * H + nh * H * H + (3 * H * H if a[17] else 0))
+
+
+def _f_bwd_trunk(a):
+    M, H, nh = a[0], a[1], a[2]
+    return 2.0 * M * ((3 * H * H if a[3] else 0) + nh * H * H)
 
 
 def _f_head(a_M, a_H, ad, train):
@@ -317,6 +359,9 @@ ALGORITHMIC_FLOPS: Dict[str, Callable[[Sequence], float]] = {
     "harl_mlp_bwd_dx_dw": _f_bwd_dx_dw,
     "harl_mlp_dw_partials": _f_dw,
     "harl_mlp_dw_partials_multi": _f_dw_multi,
+    "harl_mlp_dw_partials_multi_v": lambda a: 2.0 * a[8] * a[4] * 32 * sum(a[7][k] for k in range(a[0])),
+    "harl_mlp_fwd_trunk": _f_fwd_trunk,
+    "harl_mlp_bwd_trunk": _f_bwd_trunk,
     "harl_mlp_panel_fwd": lambda a: 2.0 * a[1] * a[4] * a[6],
     "harl_mlp_panel_bwd": lambda a: 2.0 * a[4] * a[5] * a[6],
     "harl_gru_fwd": _f_gru_fwd,

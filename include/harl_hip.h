@@ -226,6 +226,32 @@ int harl_mlp_dw_partials(const float *a, int a_kind, int lda, int HO, const floa
  * (autograd of nn.GRU's weight_ih / weight_hh, harl/models/base/rnn.py:14-27). */
 int harl_mlp_dw_partials_multi(int n, const float *const *a, const float *const *b, float *const *part, int HO, int K,
                                long M, int n_wg, void *stream);
+/* ... and of DIFFERENT widths in one launch (round 6): problem k multiplies the ATL(64) image a[k] with column tiles
+ * tile0[k] .. tile0[k] + nt[k] - 1 (nt <= 4) of the ATL(K[k]) image b[k] and writes n_wg partial rows dWp[64][K[k]] | dbp[64] at
+ * part[k] (db' by the tile0 = 0 group) exactly as harl_mlp_dw_partials does for that group.  n <= 12; a / b / part and K / tile0 /
+ * nt are HOST arrays.  All weight gradients of a 64-wide recurrent network (three MLP layers, six gate blocks) in one launch:
+ * autograd through harl/models/base/mlp.py:25-38 and nn.GRU (harl/models/base/rnn.py:14-27). */
+int harl_mlp_dw_partials_multi_v(int n, const float *const *a, const float *const *b, float *const *part, int HO, const int *K,
+                                 const int *tile0, const int *nt, long M, int n_wg, void *stream);
+/* The whole 64-wide trunk in one launch per direction (csrc/trunk.hip; replaces MLPBase.forward / autograd through it,
+ * harl/models/base/mlp.py:41-70, and the input half of nn.GRU's gates, harl/models/base/rnn.py:23-81).
+ * harl_mlp_fwd_trunk: layer 1 as harl_mlp_fwd_wide (x0n ATL(KP), W1p [64][D], w_img scratch), then n_hidden (1 or 2) layers
+ *   as harl_mlp_fwd_hidden (Wp[l] [64][64], bp[l]), then -- gi_ws != NULL -- the gate product of harl_gru_fwd's first phase
+ *   (Wih [192][64] folded, b_ih + b_hh for r and z) into gi_ws (3 * M_pad * 64 floats; pass save | 2 to harl_gru_fwd).
+ *   xout / relu_mask / rstd: HOST arrays of n_hidden + 1 device pointers; a NULL xout[l] skips that layer's activation record
+ *   (forward-only passes).  Results are bit-identical to the layer-by-layer launches.
+ * harl_mlp_bwd_trunk: Wih != NULL: d x_hat_top = Wih^T [dr, dzg, dn] and the LayerNorm / ReLU backward of the top MLP layer
+ *   (the dx launch of harl_gru_bwd; call that with dz_mlp = NULL) -> dz_out[0]; else dz of the top layer is read from dz_in.
+ *   Then for k = 0 .. n_hidden - 1: dz_out[k + 1] = harl_mlp_bwd_dx(dz_out[k] (or dz_in), xh[k + 1], relu_mask[k + 1],
+ *   rstd[k + 1], Wp[k]) with Wp[k] the folded weights of the k-th hidden Linear FROM THE TOP; xh[0] .. rstd[0] describe the top
+ *   layer (used by the gate stage only).  HOST arrays of device pointers; bit-identical to the separate launches. */
+int harl_mlp_fwd_trunk(const float *x0n, long M, int KP, const float *W1p, int D, const float *b1p, int H, void *w_img,
+                       int n_hidden, const float *const *Wp, const float *const *bp, float *const *xout,
+                       uint32_t *const *relu_mask, float *const *rstd, const float *Wih, const float *bih, const float *bhh,
+                       float *gi_ws, void *stream);
+int harl_mlp_bwd_trunk(long M, int H, int n_hidden, const float *Wih, const float *dr, const float *dzg, const float *dn,
+                       const float *dz_in, const float *const *Wp, const float *const *xh, const uint32_t *const *relu_mask,
+                       const float *const *rstd, float *const *dz_out, void *stream);
 /* out[e] = sum_w part[w][e] in fixed order (deterministic), e < elems */
 int harl_reduce_partials(const float *part, int n_wg, long elems, float *out, void *stream);
 
@@ -546,6 +572,9 @@ int harl_update_bwd(const float *x0n, const float *dz2, long M, int D, int H, co
  * save != 0 stores h~ = h*mask, r, z, n, hn for the backward pass.
  * gi_ws (optional, 3*L*m_pad*H floats): when given, the input half of the gates (W_i' x + b) of ALL steps is computed
  * first by a fully parallel kernel and the recurrence only carries the W_hh products (bit-identical results).
+ * save bit 1 (value 2): gi_ws ALREADY holds that product (harl_mlp_fwd_trunk wrote it) -- the gate launch is skipped and xin is
+ * not read.  harl_gru_bwd with dz_mlp = NULL leaves the input side (W_ih'^T d gates and the MLP's LayerNorm backward) to
+ * harl_mlp_bwd_trunk.
  */
 int harl_gru_fwd(const float *xin, const float *mask_rows, const float *h0, const float *Wih, const float *bih,
                  const float *Whh, const float *bhh, int H, int L, long m_pad, float *y, float *rstd_y, float *hpm, float *r,

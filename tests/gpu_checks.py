@@ -687,6 +687,86 @@ def check_rnn_update(spec) -> Dict[str, float]:
     return out
 
 
+TRUNK_SPECS = [
+    # the SMAC 3s5z shapes (bench.py `smac3s5z`): obs 128 / state 216 -> [64, 64, 64] -> GRU 64, Discrete(14); 300 sequences = 9.4 slabs per step
+    dict(name="smac_rnn_3x64", obs_dim=128, share_obs_dim=216, act_dim=14, discrete=True, hidden_sizes=[64, 64, 64], L=10, m=300, rnn=True),
+    dict(name="rnn_2x64_box3", obs_dim=100, share_obs_dim=70, act_dim=3, discrete=False, hidden_sizes=[64, 64], L=4, m=45, rnn=True),
+    # feed-forward: a 12-way Gaussian head keeps the last layer out of the loss launch (every layer through the trunk launch) ...
+    dict(name="ff_3x64_box12", obs_dim=200, share_obs_dim=300, act_dim=12, discrete=False, hidden_sizes=[64, 64, 64], L=1, m=1500, rnn=False),
+    # ... a 5-way Categorical head takes it (harl_update_last_*): trunk launch in the log-prob passes, one-launch backward behind it
+    dict(name="ff_2x64_disc5", obs_dim=70, share_obs_dim=90, act_dim=5, discrete=True, hidden_sizes=[64, 64], L=1, m=777, rnn=False),
+]
+
+
+def check_trunk_fused(spec) -> Dict[str, float]:
+    """csrc/trunk.hip (one launch per direction for a 64-wide trunk behind a wide first layer + one launch for every weight
+    gradient, the default) against the layer-by-layer launches it replaces (HARL_TRUNK_FUSED=0) on the same data and weights:
+    log-probs, values, the flat gradients of ONE HAPPO.update / VCritic.update and the parameters after the step must be the same
+    BITS (every stage calls the device functions of the layer kernel it stands for); a second fused run repeats itself."""
+    L, m = spec["L"], spec["m"]
+    M = L * m
+    rnn = spec["rnn"]
+    over = dict(use_recurrent_policy=True) if rnn else {}
+    sh = Shapes(T=L, N=m, A=1, obs_dim=spec["obs_dim"], share_obs_dim=spec["share_obs_dim"], act_dim=spec["act_dim"],
+                discrete=spec["discrete"], hidden_sizes=spec["hidden_sizes"])
+    d = make_buffers(sh, 61, inactive_p=0.2, unavailable_p=0.25 if sh.discrete else 0.0, rnn=rnn)
+    rng = np.random.default_rng(8)
+    obs = d.obs[0][:-1].reshape(M, -1)
+    masks = d.masks[0][:-1].reshape(M, 1)
+    h0 = d.rnn["actor"][0][0] if rnn else None
+    act = d.actions[0].reshape(M, -1)
+    avail = None if not sh.discrete else d.available_actions[0][:-1].reshape(M, -1)
+    active = d.active_masks[0][:-1].reshape(M, 1)
+    so = d.share_obs[:-1].reshape(M, -1)
+    ch0 = d.rnn["critic"][0] if rnn else None
+    cmask = d.critic_masks[:-1].reshape(M, 1)
+    adv = rng.standard_normal((M, 1)).astype(np.float32)
+    factor = (1 + 0.2 * rng.standard_normal((M, 1))).astype(np.float32)
+    vp = rng.standard_normal((M, 1)).astype(np.float32)
+    ret = (3.0 * rng.standard_normal((M, 1)) + 1.0).astype(np.float32)
+    from harl_amd.valuenorm import ValueNorm
+    prev = os.environ.get("HARL_TRUNK_FUSED")
+    got = {}
+    old_logp = None
+    try:
+        for tag, mode in (("layers", "0"), ("fused", "1"), ("again", "1")):
+            os.environ["HARL_TRUNK_FUSED"] = mode
+            actor, _, _ = _mk_actor(sh, 17, **over)
+            critic, _, _ = _mk_critic(sh, 23, **over)
+            assert actor.actor.trunk_fused() == (mode == "1") and critic.critic.trunk_fused() == (mode == "1")
+            lp, _, _ = actor.evaluate_actions(obs, h0, act, masks, avail, None)
+            if old_logp is None:
+                old_logp = (lp.cpu().numpy() + 0.15 * rng.standard_normal(tuple(lp.shape))).astype(np.float32)
+            taps = []
+            actor._grad_tap = lambda gr, sc: taps.append(gr.clone())
+            res = actor.update((obs, h0, act, masks, active, old_logp, adv, avail, factor))
+            vals, hnew = critic.get_values(so, ch0, cmask)
+            gvn = ValueNorm(1, device=DEV)
+            gvn.stats.copy_(dev(np.array([0.15, 0.85, 0.5], dtype=np.float32)))
+            ctaps = []
+            critic._grad_tap = lambda gr, sc: ctaps.append(gr.clone())
+            cres = critic.update((so, ch0, vp, ret, cmask), gvn)
+            lp2, _, _ = actor.evaluate_actions(obs, h0, act, masks, avail, None)  # forward-only pass with the stepped weights
+            torch.cuda.synchronize()
+            got[tag] = dict(logp=lp.clone(), grad=taps[0], stats=torch.stack([r_.reshape(()).double() for r_ in res[:3]]),
+                            param=actor.actor.flat_param.clone(), logp_after=lp2.clone(), values=vals.clone(),
+                            cgrad=ctaps[0], cstats=torch.stack([r_.reshape(()).double() for r_ in cres[:2]]),
+                            cparam=critic.critic.flat_param.clone())
+    finally:
+        if prev is None:
+            os.environ.pop("HARL_TRUNK_FUSED", None)
+        else:
+            os.environ["HARL_TRUNK_FUSED"] = prev
+    out = {}
+    a, b, c = got["layers"], got["fused"], got["again"]
+    for k in a:
+        out[f"{k}_mismatch"] = float(not torch.equal(a[k], b[k]))
+        out[f"{k}_rerun_mismatch"] = float(not torch.equal(b[k], c[k]))
+        den = float(a[k].abs().max().clamp_min(1e-30))
+        out[f"_{k}_vec_rel"] = float((a[k].double() - b[k].double()).abs().max()) / den
+    return out
+
+
 def _perturb_one_ulp(nets, seed: int) -> None:
     """Every parameter of the oracle networks moved to a neighbouring float32, up or down at random (the perturbation of
     oracle/gen_noise_floor.py): how far the reference's fp32 figures move under the smallest change fp32 can express."""

@@ -419,6 +419,15 @@ def test_backward_variants_train_golden(name, env, monkeypatch):
     _assert_all(_G().check_train_golden(name), tol=TOL)
 
 
+@pytest.mark.parametrize("i", range(4))
+def test_trunk_in_one_launch_is_bit_identical(i):
+    """harl_mlp_fwd_trunk / harl_mlp_bwd_trunk / harl_mlp_dw_partials_multi_v (round 6: a 64-wide trunk behind a wide first layer,
+    with a fused GRU's input gates, in one launch per direction + one for every weight gradient) against the layer launches
+    they replace: log-probs, values, gradients and stepped parameters of one actor and one critic update, bit for bit."""
+    g = _G()
+    _assert_all(g.check_trunk_fused(g.TRUNK_SPECS[i]))
+
+
 @pytest.mark.parametrize("first", [True, False])
 @pytest.mark.parametrize("M", [45, 300, 32 * 4 * 7 + 1, 32 * 4 * 256 * 3 + 32 * 5 + 9])
 def test_whole_layer_backward_in_one_launch(M, first):

@@ -840,19 +840,40 @@ class _FlatNet(nn.Module):
                 add(dzs[j], self.xh[l - 1], l, 64, 0, 2)
             for t in range(0, self.kp0 // 32, 4):  # the wide first layer in groups of <= 4 column tiles
                 add(dzs[L - 1], self.x0n, 0, self.kp0, t, min(4, self.kp0 // 32 - t))
-            n = len(a)
-            ci = lambda v: (C.c_int * n)(*v)  # noqa: E731
+            def pack(lo, hi):  # problems lo .. hi - 1 as the argument arrays of one harl_mlp_dw_partials_multi_v launch
+                n = hi - lo
+                ci = lambda v: (C.c_int * n)(*v[lo:hi])  # noqa: E731
+                return (n, vp(a[lo:hi]), vp(b[lo:hi]), vp(part[lo:hi]), ci(K), ci(t0), ci(nt))
+            ng = 6 if self.recurrent else 0
             args = self._trunk_cache["bwd"] = (
                 vp([self._packs[l][0] for l in range(L - 1, 0, -1)]), vp([self.xh[l] for l in top_down]),
                 vp([self.rmask[l] for l in top_down]), vp([self.rstd[l] for l in top_down]),
-                vp([dzs[0] if self.recurrent else None] + dzs[1:]), (n, vp(a), vp(b), vp(part), ci(K), ci(t0), ci(nt)))
-        pW, pX, pM, pR, pD, (n, pa, pb, pp, pK, pT, pN) = args
+                vp([dzs[0] if self.recurrent else None] + dzs[1:]), pack(0, len(a)), pack(0, ng) if ng else None, pack(ng, len(a)))
+        pW, pX, pM, pR, pD, dw_all, dw_gates, dw_mlp = args
+        # The gate blocks' weight gradients need nothing from the trunk's backward (d gates and the saved activations are there
+        # once the recurrence is done): HARL_TRUNK_DW_STREAM=1 sends them to a SECOND stream next to harl_mlp_bwd_trunk (one
+        # workgroup of each fits a CU: 120 + 37 KiB of LDS, 272 + 64 registers per SIMD lane).  MEASURED SLOWER and therefore
+        # opt-in: 26.4 / 25.9 against 23.8 / 23.7 ms per SMAC 3s5z update, 116.1 / 116.3 against 114.0 / 114.1 ms at 4096
+        # threads (gpurun_out/r06h, call 3) -- two cross-stream dependencies per optimiser step cost more than the ~40 us of
+        # overlap return.  Default: one launch for all nine problems behind the trunk's backward.
+        two = (self.recurrent and self.device_.type == "cuda" and os.environ.get("HARL_TRUNK_DW_STREAM", "0") == "1")
+        if two:
+            main_s, side_s, (e0, e1) = torch.cuda.current_stream(self.device_), self._bwd_side(), self._bwd_ev
+            e0.record(main_s)
+            side_s.wait_event(e0)
+            with torch.cuda.stream(side_s):
+                call("harl_mlp_dw_partials_multi_v", dw_gates[0], *dw_gates[1:4], 64, *dw_gates[4:], M, nwg, side_s.cuda_stream,
+                     tag="dw_gru")
+                e1.record(side_s)
         if self.recurrent:
             call("harl_mlp_bwd_trunk", M, 64, L - 1, ptr(gp["Wih"]), ptr(dg[0]), ptr(dg[1]), ptr(dg[2]), None, pW, pX, pM, pR, pD, s,
                  tag="bwd_trunk")
         else:
             call("harl_mlp_bwd_trunk", M, 64, L - 1, None, None, None, None, ptr(self.dz[0]), pW, pX, pM, pR, pD, s, tag="bwd_trunk")
-        call("harl_mlp_dw_partials_multi_v", n, pa, pb, pp, 64, pK, pT, pN, M, nwg, s, tag="dw_trunk")
+        dw = dw_mlp if two else dw_all
+        call("harl_mlp_dw_partials_multi_v", dw[0], *dw[1:4], 64, *dw[4:], M, nwg, s, tag="dw_trunk")
+        if two:
+            main_s.wait_event(e1)
         self._combine_partials(s)
 
     # ---- MultiDiscrete heads (csrc/multihead.hip): logits of every group from the head input; backward of the groups

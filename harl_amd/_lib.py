@@ -56,6 +56,7 @@ SIGNATURES = {
     "harl_mlp_dw_partials": [_vp, _i, _i, _i, _vp, _i, _l, _vp, _vp, _vp, _i, _l, _vp, _i, _vp],
     "harl_mlp_dw_partials_multi": [_i, _vp, _vp, _vp, _i, _i, _l, _i, _vp],
     "harl_mlp_dw_partials_multi_v": [_i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _l, _i, _vp],
+    "harl_gru_dw6": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _vp],
     "harl_mlp_fwd_trunk": [_vp, _l, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "harl_mlp_bwd_trunk": [_l, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "harl_reduce_partials": [_vp, _i, _l, _vp, _vp],

@@ -1174,6 +1174,146 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_dw_tr_multi_v(DwMultiV P, lon
   }
 }
 
+// The six gate blocks of a 64-wide GRU as ONE problem (round 6): dW_ih_g = d gi_g^T x_hat (g = r, z, n), dW_hh_g = d gh_g^T h~ with
+// d gi = [dr, dz, dn], d gh = [dr, dz, dhn].  As six launches-in-one they read x_hat and h~ three times each and dr, dz twice:
+// 3 072 B per row; here every image is staged ONCE per slab -- A = [dr | dz | dn | dhn] (256 features), B = [x_hat | h~] (128) --
+// 1 536 B per row (the launch is bound by its row traffic: 4.4 TB/s at 655 360 rows).  Eight waves: all of them split and store
+// their sixth of the 48 float4 pieces (k_dw_tr's transposing image, same addresses as an ATL(256) / ATL(128) operand would
+// get), six of them own one 64 x 64 gate block each -- 2 x 2 tiles, two k-steps, the six cross products in k_dw_tr's order --
+// and write it as that problem's partial row.  Same slabs per workgroup, same order of every sum: bit-identical to six k_dw_tr<2, 2>.
+struct DwGru6 {
+  const float *a[4];  // dr, dz, dn, dhn   (ATL(64) images)
+  const float *b[2];  // x_hat of the last MLP layer, h~
+  float *part[6];     // W_ih r, z, n ; W_hh r, z, n
+};
+constexpr int G6_WAVES = 8;
+__global__ __launch_bounds__(64 * G6_WAVES, 1) void k_dw_gru6(DwGru6 P, long n_slabs) {
+  constexpr int HA = 256, HB = 128, NPA = HA / 8, NPB = HB / 8, PER = (NPA + NPB) / G6_WAVES;
+  static_assert((NPA + NPB) % G6_WAVES == 0, "pieces divide evenly over the waves");
+  constexpr int SQA = (HA / 16) * 128 + 8, SQB = (HB / 16) * 128 + 8, IMG_A = 8 * SQA, IMG_B = 8 * SQB;
+  extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
+  unsigned char *Ab = ldsb, *Bb = ldsb + 3 * IMG_A;
+  const int lane = threadIdx.x & 63, wave = wave_id();
+  const int i = lane & 31, h = lane >> 5;
+  f32x4 pr[PER];
+  float dbacc[PER][4];
+#pragma unroll
+  for (int u = 0; u < PER; ++u)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) dbacc[u][c] = 0.f;
+  auto prefetch = [&](long slab) {
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int gu = wave * PER + u;
+      const bool is_a = gu < NPA;
+      const int q = is_a ? gu : gu - NPA;
+      const float *src = (is_a ? P.a[q >> 3] : P.b[q >> 3]) + slab * (long)(64 * SLAB);
+      pr[u] = (reinterpret_cast<const f32x4 *>(src) + lane)[(q & 7) * WAVE];
+    }
+  };
+  // wave p < 6 owns problem p: A block / B image
+  const int ablk = wave == 5 ? 3 : (wave < 3 ? wave : wave - 3), bimg = wave < 3 ? 0 : 1;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  const int p16 = lane & 15, g1 = (lane >> 4) & 1;
+  const int frag_lane = g1 * 128 + (p16 >> 2) * 32 + (p16 & 3) * 8;
+  if ((long)blockIdx.x < n_slabs) prefetch(blockIdx.x);
+  for (long slab = blockIdx.x; slab < n_slabs; slab += gridDim.x) {
+    __syncthreads();  // previous round's fragments fully read
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int gu = wave * PER + u;
+      const bool is_a = gu < NPA;
+      const int q = is_a ? gu : gu - NPA;
+      const int sqb = is_a ? SQA : SQB, tstride = is_a ? IMG_A : IMG_B;
+      unsigned char *d = (is_a ? Ab : Bb) + (i >> 2) * sqb + (2 * (q >> 2) + ((q & 3) >> 1)) * 128 + (i & 3) * 32 +
+                         (8 * (q & 1) + 4 * h) * 2;
+      if (is_a) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) dbacc[u][c] += pr[u][c];
+      }
+      unsigned t1a, t2a, t3a, t1b, t2b, t3b;
+      split3<false>(pr[u][0], pr[u][1], t1a, t2a, t3a);
+      split3<false>(pr[u][2], pr[u][3], t1b, t2b, t3b);
+      *reinterpret_cast<u32x2_t *>(d) = u32x2_t{t1a, t1b};
+      *reinterpret_cast<u32x2_t *>(d + tstride) = u32x2_t{t2a, t2b};
+      *reinterpret_cast<u32x2_t *>(d + 2 * tstride) = u32x2_t{t3a, t3b};
+    }
+    __syncthreads();
+    if (slab + gridDim.x < n_slabs) prefetch(slab + gridDim.x);
+    __builtin_amdgcn_sched_barrier(0);
+    if (wave < 6) {  // (wave-uniform)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        u32x4 av[3][2], bv[3][2];
+#pragma unroll
+        for (int term = 0; term < 3; ++term) {
+#pragma unroll
+          for (int a = 0; a < 2; ++a) {
+            const unsigned char *fp = Ab + term * IMG_A + (4 * ks + 2 * h) * SQA + 2 * (2 * ablk + a) * 128 + frag_lane;
+            const u32x2_t lo = tr_read(fp), hi = tr_read(fp + SQA);
+            av[term][a] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+          }
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            const unsigned char *fp = Bb + term * IMG_B + (4 * ks + 2 * h) * SQB + 2 * (2 * bimg + b) * 128 + frag_lane;
+            const u32x2_t lo = tr_read(fp), hi = tr_read(fp + SQB);
+            bv[term][b] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+          }
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            acc[a][b] = mfma_bf16(av[2][a], bv[0][b], acc[a][b]);
+            acc[a][b] = mfma_bf16(av[0][a], bv[2][b], acc[a][b]);
+            acc[a][b] = mfma_bf16(av[1][a], bv[1][b], acc[a][b]);
+            acc[a][b] = mfma_bf16(av[1][a], bv[0][b], acc[a][b]);
+            acc[a][b] = mfma_bf16(av[0][a], bv[1][b], acc[a][b]);
+            acc[a][b] = mfma_bf16(av[0][a], bv[0][b], acc[a][b]);
+          }
+      }
+    }
+  }
+  constexpr long ROW = 64 * 64 + 64;  // dWp[64][64] | dbp[64]
+  if (wave < 6) {
+    float *mypart = P.part[wave] + (long)blockIdx.x * ROW;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int o = 32 * a + (r & 3) + 8 * (r >> 2) + 4 * h;
+          mypart[(long)o * 64 + 32 * b + i] = acc[a][b][r];
+        }
+  }
+  // db' of a gate block goes to every problem that uses it: dr -> W_ih r, W_hh r ; dz -> W_ih z, W_hh z ; dn -> W_ih n ; dhn -> W_hh n
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    const int gu = wave * PER + u;
+    if (gu < NPA) {
+      const int blk = gu >> 3, lq = gu & 7;
+      float *p0 = P.part[blk == 3 ? 5 : blk] + (long)blockIdx.x * ROW + 64 * 64;
+      float *p1 = blk < 2 ? P.part[blk + 3] + (long)blockIdx.x * ROW + 64 * 64 : nullptr;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float t = half_reduce_sum(dbacc[u][c]);
+        if (i == 0) {
+          const int f = 32 * (lq >> 2) + 8 * (lq & 3) + 4 * h + c;
+          p0[f] = t;
+          if (p1) p1[f] = t;
+        }
+      }
+    }
+  }
+}
+
 // =============================================================================================
 // k_bwd_dx_dw: the WHOLE backward of one hidden Linear(128 -> 128) and the relu + LayerNorm in front of it in ONE persistent
 // launch (round 5): dz_prev = LNrelu'(Wp^T dz), dW' += dz^T x_hat_prev, db' += sum dz, and -- first-layer variant, KT = 1 --
@@ -2015,4 +2155,21 @@ extern "C" int harl_mlp_dw_partials_multi_v(int n, const float *const *a, const 
   allow_big_lds(k_dw_tr_multi_v<2>, shm);
   hipLaunchKernelGGL((k_dw_tr_multi_v<2>), dim3(n_wg, n), dim3(WG_THREADS), shm, (hipStream_t)stream, P, n_slabs);
   return check_launch("harl_mlp_dw_partials_multi_v");
+}
+
+extern "C" int harl_gru_dw6(const float *dr, const float *dz, const float *dn, const float *dhn, const float *xhat, const float *hpm,
+                            float *const *part, long M, int n_wg, void *stream) {
+  if (M <= 0 || n_wg <= 0) return 0;
+  DwGru6 P;
+  P.a[0] = dr;
+  P.a[1] = dz;
+  P.a[2] = dn;
+  P.a[3] = dhn;
+  P.b[0] = xhat;
+  P.b[1] = hpm;
+  for (int k = 0; k < 6; ++k) P.part[k] = part[k];
+  const size_t shm = (size_t)3 * 8 * ((2 * 8 * 128 + 8) + (2 * 4 * 128 + 8));
+  allow_big_lds(k_dw_gru6, shm);
+  hipLaunchKernelGGL(k_dw_gru6, dim3(n_wg), dim3(64 * G6_WAVES), shm, (hipStream_t)stream, P, n_slabs_of(M));
+  return check_launch("harl_gru_dw6");
 }

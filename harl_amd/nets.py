@@ -870,7 +870,17 @@ class _FlatNet(nn.Module):
                  tag="bwd_trunk")
         else:
             call("harl_mlp_bwd_trunk", M, 64, L - 1, None, None, None, None, ptr(self.dz[0]), pW, pX, pM, pR, pD, s, tag="bwd_trunk")
-        dw = dw_mlp if two else dw_all
+        # the six gate blocks as ONE problem whose six operand images are each read once (harl_gru_dw6: 1 536 instead of 3 072 B
+        # per row on a launch that is bound by its row traffic), then the MLP layers.  Bit-identical to the nine problems of the
+        # generic launch; it is one launch more, which costs what it saves at 81 920 rows per minibatch (24.2 / 24.3 against
+        # 23.8 / 24.1 ms per SMAC 3s5z update) and pays at 655 360 (112.2 / 112.6 against 116.7 / 116.7 ms; gpurun_out/r06h call
+        # 6): taken from 160 000 rows.  HARL_GRU_DW6=1 / 0 force it on / off.
+        g6 = os.environ.get("HARL_GRU_DW6", "auto")
+        gru6 = self.recurrent and not two and (g6 == "1" or (g6 == "auto" and M >= 160000))
+        if gru6:
+            call("harl_gru_dw6", ptr(dg[0]), ptr(dg[1]), ptr(dg[2]), ptr(dg[3]), ptr(self.xh[-1]), ptr(sv[0]), dw_gates[3], M, nwg, s,
+                 tag="dw_gru")
+        dw = dw_mlp if (two or gru6) else dw_all
         call("harl_mlp_dw_partials_multi_v", dw[0], *dw[1:4], 64, *dw[4:], M, nwg, s, tag="dw_trunk")
         if two:
             main_s.wait_event(e1)

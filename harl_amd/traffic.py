@@ -227,6 +227,7 @@ ALGORITHMIC_BYTES: Dict[str, Callable[[Sequence], float]] = {
     "harl_mlp_dw_partials": _dw_partials,
     "harl_mlp_dw_partials_multi": _dw_partials_multi,
     "harl_mlp_dw_partials_multi_v": _dw_partials_multi_v,
+    "harl_gru_dw6": lambda a: a[7] * 6 * 4.0 * 64,  # (dr, dz, dn, dhn, xhat, hpm, part, M, n_wg, stream): six ATL(64) images, each once
     "harl_mlp_fwd_trunk": _fwd_trunk,
     "harl_mlp_bwd_trunk": _bwd_trunk,
     "harl_gru_fwd": _gru_fwd,
@@ -360,6 +361,7 @@ ALGORITHMIC_FLOPS: Dict[str, Callable[[Sequence], float]] = {
     "harl_mlp_dw_partials": _f_dw,
     "harl_mlp_dw_partials_multi": _f_dw_multi,
     "harl_mlp_dw_partials_multi_v": lambda a: 2.0 * a[8] * a[4] * 32 * sum(a[7][k] for k in range(a[0])),
+    "harl_gru_dw6": lambda a: 2.0 * a[7] * 6 * 64 * 64,
     "harl_mlp_fwd_trunk": _f_fwd_trunk,
     "harl_mlp_bwd_trunk": _f_bwd_trunk,
     "harl_mlp_panel_fwd": lambda a: 2.0 * a[1] * a[4] * a[6],

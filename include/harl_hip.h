@@ -233,6 +233,12 @@ int harl_mlp_dw_partials_multi(int n, const float *const *a, const float *const 
  * autograd through harl/models/base/mlp.py:25-38 and nn.GRU (harl/models/base/rnn.py:14-27). */
 int harl_mlp_dw_partials_multi_v(int n, const float *const *a, const float *const *b, float *const *part, int HO, const int *K,
                                  const int *tile0, const int *nt, long M, int n_wg, void *stream);
+/* The six gate blocks of a 64-wide GRU as ONE weight-gradient problem (autograd of nn.GRU's weight_ih_l0 / weight_hh_l0 and both
+ * biases, harl/models/base/rnn.py:14-27): part[0..2] = d gi_g^T xhat, part[3..5] = d gh_g^T hpm with d gi = [dr, dz, dn],
+ * d gh = [dr, dz, dhn]; all six operands ATL(64) images of M rows, each read once; part: HOST array of six device pointers, each
+ * receiving n_wg partial rows dWp[64][64] | dbp[64] exactly as harl_mlp_dw_partials_multi(HO = K = 64) writes them. */
+int harl_gru_dw6(const float *dr, const float *dz, const float *dn, const float *dhn, const float *xhat, const float *hpm,
+                 float *const *part, long M, int n_wg, void *stream);
 /* The whole 64-wide trunk in one launch per direction (csrc/trunk.hip; replaces MLPBase.forward / autograd through it,
  * harl/models/base/mlp.py:41-70, and the input half of nn.GRU's gates, harl/models/base/rnn.py:23-81).
  * harl_mlp_fwd_trunk: layer 1 as harl_mlp_fwd_wide (x0n ATL(KP), W1p [64][D], w_img scratch), then n_hidden (1 or 2) layers

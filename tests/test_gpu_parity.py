@@ -428,6 +428,15 @@ def test_trunk_in_one_launch_is_bit_identical(i):
     _assert_all(g.check_trunk_fused(g.TRUNK_SPECS[i]))
 
 
+@pytest.mark.parametrize("i", [0, 1])
+def test_gate_weight_gradients_as_one_problem_bit_identical(i, monkeypatch):
+    """harl_gru_dw6 (the six gate blocks of a GRU as one weight-gradient problem, every operand image read once; taken from
+    160 000 rows per minibatch by default, forced here) inside the one-launch trunk path against the layer launches: the same bits."""
+    monkeypatch.setenv("HARL_GRU_DW6", "1")
+    g = _G()
+    _assert_all(g.check_trunk_fused(g.TRUNK_SPECS[i]))
+
+
 @pytest.mark.parametrize("first", [True, False])
 @pytest.mark.parametrize("M", [45, 300, 32 * 4 * 7 + 1, 32 * 4 * 256 * 3 + 32 * 5 + 9])
 def test_whole_layer_backward_in_one_launch(M, first):

@@ -255,14 +255,56 @@ def recurrent_first_rows(T: int, N: int, num_mini_batch: int, data_chunk_length:
 
 
 def _recurrent_seqs(device, T: int, n_local: int, agents: int, H: int, num_mini_batch: int, data_chunk_length: int,
-                    naive: bool, shard, h0_src: torch.Tensor, masks_src: torch.Tensor):
+                    naive: bool, shard, h0_src: torch.Tensor, masks_src: torch.Tensor, cache: Optional[dict] = None):
     """Shared body of the buffers' ``recurrent_batches``: draws the reference's sequence starts over the GLOBAL column
     count (identical on every rank), keeps the sequences whose rollout thread lives on this rank and re-indexes them to
     the local buffers.  Yields nets.build_seq dicts with ``m_global`` (sequences in the global minibatch) added, or
-    ``dict(empty=True, ...)`` when none of them is local."""
+    ``dict(empty=True, ...)`` when none of them is local.
+
+    ONE minibatch (the tuned recurrent configurations: ``actor_num_mini_batch`` = ``critic_num_mini_batch`` = 1): the minibatch
+    is EVERY sequence of the buffer, and the update -- sums and means over its rows, each sequence unrolled from its own stored
+    state -- does not depend on the order the permutation puts them in.  So, as the feed-forward samplers have done since round
+    1 (``consume_randperm``), only the GENERATOR is advanced by the reference's ``torch.randperm`` draw; the sequences are taken
+    in buffer order.  That layout is the same in every epoch: the device-side tables (``harl_build_seq``) are built once per
+    update and handed out again (``cache``: keyed on the source tensors' addresses and version counters), and because the row
+    index tensor is the same OBJECT every epoch, the networks' normalised-input image (nets._x0n_image) is reused as well --
+    per optimiser step of the 8-agent SMAC update that is two launches (8 + 33 us), a host-side permutation of 8 192 starts and
+    its upload less.  ``HARL_RNN_ORDERED=0`` materialises the permutation as before (the results differ by summation order)."""
     from .nets import build_seq
     n_global, lo, hi = shard if shard else (n_local, 0, n_local)
     ncol_g, ncol_l = n_global * agents, n_local * agents
+    if num_mini_batch == 1 and os.environ.get("HARL_RNN_ORDERED", "1") != "0":
+        import numpy as np
+        L = T if naive else data_chunk_length
+        assert T % L == 0, "episode_length must be a multiple of data_chunk_length"
+        n_seq = ncol_g if naive else (T * ncol_g) // L
+        consume_randperm(n_seq)  # the generator advance of the reference's single torch.randperm(n_seq)
+        key = (str(device), T, n_local, agents, H, L, bool(naive), tuple(shard) if shard else None, h0_src.data_ptr(),
+               h0_src._version, masks_src.data_ptr(), masks_src._version)
+        if cache is not None and cache.get("key") == key:
+            yield cache["seq"]
+            return
+        start = np.arange(n_seq, dtype=np.int64) * L  # sequence c: thread-major rows [c L, (c + 1) L) (recurrent_first_rows)
+        first = start if naive else (start % T) * ncol_g + start // T
+        if naive:
+            first = np.arange(n_seq, dtype=np.int64)
+        if shard:
+            t0 = first // ncol_g
+            c = first - t0 * ncol_g
+            n = c // agents
+            keep = (n >= lo) & (n < hi)
+            first = t0[keep] * ncol_l + (n[keep] - lo) * agents + (c[keep] - n[keep] * agents)
+        if first.size == 0:
+            seq = dict(empty=True, L=L, m=0, m_global=n_seq)
+        else:
+            seq = build_seq(device, L, int(first.size), H, first_rows=torch.from_numpy(np.ascontiguousarray(first)), stride=ncol_l,
+                            h0_src=h0_src, masks_src=masks_src)
+            seq["m_global"] = n_seq
+        if cache is not None:
+            cache.clear()
+            cache.update(key=key, seq=seq, src=(h0_src, masks_src))  # (the sources stay alive: their addresses are the key)
+        yield seq
+        return
     for first, L in recurrent_first_rows(T, ncol_g, num_mini_batch, data_chunk_length, naive):
         m_global = first.numel()
         if shard:
@@ -343,7 +385,8 @@ class OnPolicyActorBuffer:
         the GLOBAL sampler is drawn and filtered to this rank's rollout threads."""
         T, N = self.actions.shape[:2]
         return _recurrent_seqs(self.device, T, N, 1, self.rnn_hidden_size * self.recurrent_n, num_mini_batch, data_chunk_length, naive, shard,
-                               self.rnn_states.reshape((T + 1) * N, -1), self.masks.reshape(-1))
+                               self.rnn_states.reshape((T + 1) * N, -1), self.masks.reshape(-1),
+                               cache=self.__dict__.setdefault("_seq_cache", {}))
 
     def feed_forward_generator_actor(self, advantages, actor_num_mini_batch=None, mini_batch_size=None):
         """API-compatible generator (actor_buffer.py:114-178): yields gathered device tensors in the reference's
@@ -462,7 +505,8 @@ class OnPolicyCriticBufferEP:
         T, N = self.rewards.shape[:2]
         agents = getattr(self, "num_agents", None) or 1
         return _recurrent_seqs(self.device, T, N, agents, self.rnn_hidden_size * self.recurrent_n, num_mini_batch, data_chunk_length, naive,
-                               shard, self.rnn_states_critic.reshape((T + 1) * N * agents, -1), self.masks.reshape(-1))
+                               shard, self.rnn_states_critic.reshape((T + 1) * N * agents, -1), self.masks.reshape(-1),
+                               cache=self.__dict__.setdefault("_seq_cache", {}))
 
     def _recurrent_api_generator(self, num_mini_batch, data_chunk_length, naive):
         T, N = self.rewards.shape[:2]

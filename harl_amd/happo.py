@@ -444,6 +444,7 @@ class HAPPO(OnPolicyBase):
         if state_type != "EP":  # FP: the runner already normalised over all agents (on_policy_ha_runner.py:36-45)
             moments = None
         self._info.zero_()
+        buf.__dict__.pop("_seq_cache", None)  # the recurrent samplers' per-update table never outlives one train() (buffers._recurrent_seqs)
         self.actor.fold()
         obs = buf.flat("obs")
         actions = buf.flat("actions")

@@ -357,6 +357,7 @@ class HATRPO(OnPolicyBase):
         if state_type != "EP":  # FP: advantages arrive normalised over all agents (on_policy_ha_runner.py:36-45)
             moments = None
         n_global = self.shard[0] * T if self.shard else B
+        buf.__dict__.pop("_seq_cache", None)  # (buffers._recurrent_seqs: one table per update)
         if self.use_recurrent_policy or self.use_naive_recurrent_policy:
             # recurrent_generator_actor(advantages, 1, L) / naive_recurrent_generator_actor(advantages, 1): ONE sample that
             # holds every chunk (hatrpo.py:222-231)

@@ -474,11 +474,15 @@ class _FlatNet(nn.Module):
         every epoch / line-search step / log-prob pass over the same (unmodified) tensor reuses it -- torch's version
         counter catches in-place writes; identity row order only; the cache keeps a reference to the source tensor, so its
         storage cannot have been recycled for different data at the same address."""
-        key = (X.data_ptr(), X._version, tuple(X.shape), M) if idx is None else None
-        if key is None or key != self._x0n_key:
+        # ... a GATHERED image is reused only when the row-index tensor is the very same object, unmodified (the recurrent
+        # samplers hand out one table per update when there is a single minibatch, buffers._recurrent_seqs): the cache keeps
+        # both tensors alive, so an equal address cannot belong to a recycled allocation with other rows in it
+        key = ((X.data_ptr(), X._version, tuple(X.shape), M) if idx is None
+               else (X.data_ptr(), X._version, tuple(X.shape), M, idx.data_ptr(), idx._version, idx.numel()))
+        if key != self._x0n_key:
             call("harl_mlp_x0n_wide", ptr(X), X.shape[1], ptr(idx), M, self.in_dim, int(self.use_feature_normalization),
                  ptr(self.x0n), ptr(self.mu0), ptr(self.rstd0), s, tag="x0n_wide")
-            self._x0n_key, self._x0n_src = key, (X if key is not None else None)
+            self._x0n_key, self._x0n_src = key, (X, idx)
 
     def invalidate_caches(self) -> None:
         """Drop the cached normalised-input image.  The cache key is (data_ptr, torch version counter, shape, rows): it

@@ -191,6 +191,7 @@ class VCritic:
         dev = self.device
         self._info.zero_()
         self.critic.invalidate_caches()
+        buf.__dict__.pop("_seq_cache", None)  # the recurrent samplers' per-update table never outlives one train() (buffers._recurrent_seqs)
         self.critic.fold()
         share_obs = buf.flat("share_obs")
         value_preds = buf.flat("value_preds").reshape(B)

@@ -77,6 +77,7 @@ SIGNATURES = {
     "harl_gru_fwd": [_vp] * 7 + [_i, _i, _l] + [_vp] * 8 + [_i, _vp, _vp],
     "harl_gru_bwd": [_vp] * 9 + [_i, _i, _l] + [_vp] * 8 + [_vp],
     "harl_fold_linear_tangent": [_vp] * 9 + [_i, _i, _vp],
+    "harl_fold_table": [_vp, _vp, _vp, _i, _i, _vp],
     "harl_unfold_table": [_vp, _vp, _vp, _vp, _i, _i, _vp],
     "harl_fold_tangent_table": [_vp, _vp, _vp, _vp, _i, _i, _vp],
     "harl_mlp_tangent_input": [_vp, _l, _vp, _l, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp],

@@ -987,6 +987,37 @@ extern "C" int harl_unfold_table(const float *param, float *grad, const float *d
   return check_launch("harl_unfold_table");
 }
 
+// every entry of the layer table in ONE launch (one block per output row, k_fold_linear's arithmetic): the fold at the head of
+// every update was one launch per Linear -- 11 per network of the 8-agent recurrent workload, 122 per update
+__global__ __launch_bounds__(64) void k_fold_table(const float *__restrict__ p, float *__restrict__ packs,
+                                                   const int *__restrict__ tab, int n_layers) {
+  int o = blockIdx.x, l = 0;
+  for (; l < n_layers; ++l) {
+    if (o < tab[l * TS + 4]) break;
+    o -= tab[l * TS + 4];
+  }
+  if (l >= n_layers) return;
+  const int *t = tab + l * TS;
+  const int in_dim = t[5];
+  const float *W = p + t[0], *b = p + t[1];
+  const float *gamma = t[2] >= 0 ? p + t[2] : nullptr, *beta = t[3] >= 0 ? p + t[3] : nullptr;
+  float *Wp = packs + t[6], *bp = packs + t[7];
+  float acc = 0.f;
+  for (int k = threadIdx.x; k < in_dim; k += 64) {
+    float w = W[(long)o * in_dim + k];
+    Wp[(long)o * in_dim + k] = gamma ? w * gamma[k] : w;
+    if (beta) acc += w * beta[k];
+  }
+  acc = wave_reduce_sum(acc);
+  if (threadIdx.x == 0) bp[o] = b[o] + acc;
+}
+
+extern "C" int harl_fold_table(const float *param, float *packs, const int *table, int n_layers, int total_rows, void *stream) {
+  if (n_layers <= 0 || total_rows <= 0) return 0;
+  hipLaunchKernelGGL(k_fold_table, dim3(total_rows), dim3(64), 0, (hipStream_t)stream, param, packs, table, n_layers);
+  return check_launch("harl_fold_table");
+}
+
 // tangent of the LayerNorm-affine fold of every entry:  Wp_dot = W_dot*g + W*g_dot ;  bp_dot = b_dot + W_dot.beta + W.beta_dot
 // (vec = the tangent direction in the flat parameter layout; one block per output row of every entry)
 __global__ __launch_bounds__(64) void k_fold_tangent_table(const float *__restrict__ p, const float *__restrict__ vec,

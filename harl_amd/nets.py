@@ -341,6 +341,10 @@ class _FlatNet(nn.Module):
             return
         s = stream()
         fp, pa = self.flat_param, self.pack_arena
+        if self.table is not None and os.environ.get("HARL_FOLD_TABLE", "1") != "0":  # every entry in one launch
+            call("harl_fold_table", ptr(fp), ptr(pa), ptr(self.table), self.n_entries, sum(r[4] for r in self._table_rows), s)
+            self._fold_version = ver
+            return
         for (wo, bo, go, beo, o, k), (pw, pb, _, _) in zip(self._entries(), self._pack_slots):
             call("harl_fold_linear", ptr(fp[wo:]), ptr(fp[bo:]), ptr(fp[go:]) if go >= 0 else None,
                  ptr(fp[beo:]) if beo >= 0 else None, ptr(pa[pw:]), ptr(pa[pb:]), o, k, s)

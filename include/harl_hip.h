@@ -271,6 +271,11 @@ int harl_reduce_partials(const float *part, int n_wg, long elems, float *out, vo
 /* dwp[dwp_off_l + e] = sum_w part[part_off_l + w*elems_l + e] for all layers in ONE launch (fixed order, deterministic) */
 int harl_reduce_partials_multi(const float *part, const int *table, int n_layers, int n_wg, long total_elems,
                                float *dwp, void *stream);
+/* harl_fold_linear for EVERY entry of the device layer table (HARL_TABLE_STRIDE ints per entry, as harl_adam_fold reads it) in
+ * one launch: packs[pack_w] = W * gamma, packs[pack_b] = b + W . beta, one block per output row, total_rows = sum of the
+ * entries' out_dim.  The same arithmetic per row as harl_fold_linear (the fold in front of every update: models/base/mlp.py:25-38
+ * evaluated with the LayerNorm affine folded into the next Linear). */
+int harl_fold_table(const float *param, float *packs, const int *table, int n_layers, int total_rows, void *stream);
 /* harl_unfold_linear_grads / harl_fold_linear_tangent for EVERY entry of the layer table in one launch each (same arithmetic
  * and summation order; Linears sharing a LayerNorm accumulate in table order): grad (reference parameter layout) from the
  * dense folded gradients `dwp`; pack_d (laid out like the folded-weight arena) = tangent of the folded weights in direction

@@ -8,7 +8,7 @@ TAG=${1:-r06}
 mkdir -p $R/gpurun_out/$TAG
 cd /tmp && export TMPDIR=/tmp
 ( time timeout 1500 python $R/bench.py --steps 20 --warmup 3 ) > $R/gpurun_out/$TAG/bench_default.json 2> $R/gpurun_out/$TAG/bench_default.err
-for c in mpe cheetah6 smac3s5z humanoid17; do
+for c in mpe cheetah6 smac3s5z smac3s5z_n4096 humanoid17; do
   rm -rf /tmp/kt
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python $R/bench.py --config $c --steps 3 --warmup 1 --cpu-cols 0 --instr-steps 0 --no-kernel-timing --no-other-configs > /dev/null 2>&1
   python $R/tools/prof_summary.py $(ls /tmp/kt/*/*kernel_trace.csv | head -1) --gaps 60 > $R/gpurun_out/$TAG/kernel_trace_$c.md 2>&1

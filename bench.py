@@ -28,7 +28,7 @@ hipIpc exchange with HARL_ALLREDUCE=auto|oneshot);
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P \\
         bench.py --gpus 8 --steps 5 --warmup 2
 
-The default run (mpe) appends the three other BASELINE workloads and the coverage workload `hatrpo_gru128` (3 steps each, fresh
+The default run (mpe) appends the three other BASELINE workloads and the coverage workload `hatrpo_gru128` (5 steps each, no events inside their timed regions, fresh
 runners, AFTER the headline region and the CPU baseline; each with its own bounded CPU baseline) to the same line as
 `other_configs` (`--no-other-configs` to skip).
 
@@ -274,9 +274,14 @@ def ranks_seen(comm, device) -> int:
 
 
 def measure(w: dict, cfg_name: str, args, comm, rank: int, world: int, device, n_local: int, steps: int, warmup: int,
-            instr_steps: int, scaling: str = "weak"):
+            instr_steps: int, scaling: str = "weak", region_events: bool = True):
     """Build the runner of one workload, warm up, time `steps` steps between barriers and collect the per-kernel figures.
-    Returns the JSON record of this workload on rank 0 (None elsewhere)."""
+    Returns the JSON record of this workload on rank 0 (None elsewhere).
+    ``region_events`` = False (the workloads ATTACHED to the default line as `other_configs`): no HIP events inside the timed
+    region -- their `roofline` comes from the instrumented step behind it.  An event pair between two launches keeps the second
+    from starting under the first one's tail; for the headline's 15 long launches per step that is noise, for the recurrent
+    workload's 62 short ones it was 1.2 ms of a 21.5 ms step (22.7 in the line against 21.5 from `--config smac3s5z
+    --no-kernel-timing` on the same box, round 6)."""
     from harl_amd import _lib
 
     Tn = w["T"]
@@ -294,7 +299,8 @@ def measure(w: dict, cfg_name: str, args, comm, rank: int, world: int, device, n
     # all ~20 families inside the region cost 2.5-3 % of the step (MPE; 10-15 % for the launch-heavy 17-agent HATRPO step).
     ROOF_TAGS = ("fwd_fused2", "fwd_fused2_k64", "fwd_hidden", "bwd_dx", "bwd_dx_dw1", "bwd_full", "bwd_full_dw1", "dw_hidden", "fwd_wide", "dw_input",
                  "tangent_wide", "tangent_hidden", "gru_fwd", "gru_bwd", "update_fwd", "update_bwd", "update_logp",
-                 "update_fwd_critic", "update_last", "update_last_critic", "fwd_panel", "bwd_panel")
+                 "update_fwd_critic", "update_last", "update_last_critic", "fwd_panel", "bwd_panel", "fwd_trunk", "bwd_trunk",
+                 "dw_trunk", "dw_gru")
     warm_kern = {}
     for k in range(warmup):
         last = k == warmup - 1 and not args.no_kernel_timing and not args.time_all_tags
@@ -334,7 +340,7 @@ def measure(w: dict, cfg_name: str, args, comm, rank: int, world: int, device, n
     cw = {k: v for k, v in warm_kern.items() if v["n"] > 0 and v.get("bytes")}
     if cw:
         region_tags = (max(cw, key=lambda k: cw[k]["total_ms"]),)
-    if not args.no_kernel_timing:
+    if not args.no_kernel_timing and region_events:
         if cw:  # two events per bracketed launch, created before the clock starts
             _lib.reserve_timing_events(2 * (cw[region_tags[0]]["n"] + 8) * steps)
         _lib.enable_kernel_timing(True, None if args.time_all_tags else region_tags)
@@ -344,7 +350,7 @@ def measure(w: dict, cfg_name: str, args, comm, rank: int, world: int, device, n
     barrier()
     dt = time.perf_counter() - t0
     roof_kern = {}
-    if not args.no_kernel_timing:
+    if not args.no_kernel_timing and region_events:
         roof_kern = _lib.collect_kernel_timing()
         _lib.enable_kernel_timing(False)
     if comm.enabled:
@@ -370,6 +376,8 @@ def measure(w: dict, cfg_name: str, args, comm, rank: int, world: int, device, n
         else:
             os.environ["HARL_CRITIC_STREAM"] = prev_cs
 
+    if not region_events:  # attached workloads: the streaming families of the instrumented step behind the region
+        roof_kern = {t: x for t, x in kern.items() if t in ROOF_TAGS}
     n_seen = ranks_seen(comm, device) if comm.enabled else 1  # (collective: every rank)
     if rank != 0:
         return None
@@ -420,8 +428,10 @@ def measure(w: dict, cfg_name: str, args, comm, rank: int, world: int, device, n
                                    "slots of the same waves (DESIGN.md 3)",
                         traffic=traffic, traffic_note=traffic_note, launches=cand[dom]["n"], avg_ms=cand[dom]["avg_ms"],
                         bytes_per_launch=per_launch,
-                        timing="HIP events around every launch of the streaming kernel families inside the timed region; bytes "
-                               "from each launch's own arguments (harl_amd/traffic.py)",
+                        timing=("HIP events around every launch of the streaming kernel families inside the timed region; bytes "
+                                "from each launch's own arguments (harl_amd/traffic.py)" if region_events else
+                                "HIP events around every tagged launch of ONE instrumented single-stream step BEHIND the timed region "
+                                "(attached workload: nothing is bracketed inside its region); bytes from each launch's own arguments"),
                         others={k: dict(hbm_frac=round(v["bytes"] / (v["total_ms"] * 1e-3) / HBM_PEAK, 4), n=v["n"],
                                         avg_ms=round(v["avg_ms"], 4))
                                 for k, v in ({t: x for t, x in kern.items() if t in ROOF_TAGS and x["n"] > 0 and x.get("bytes")}
@@ -554,7 +564,7 @@ def main():
     ap.add_argument("--no-other-configs", dest="other_configs", action="store_false",
                     help="default run (mpe): do NOT append the three other BASELINE workloads (cheetah6, smac3s5z, humanoid17; "
                          "`--other-steps` steps each after the headline region) as `other_configs` to the JSON line")
-    ap.add_argument("--other-steps", type=int, default=3)
+    ap.add_argument("--other-steps", type=int, default=5)
     ap.add_argument("--other-cpu-cols", type=int, default=-1,
                     help="rollout threads of the bounded CPU-baseline sample attached to each `other_configs` entry (0 = skip, -1 = auto)")
     ap.add_argument("--dry-run", action="store_true",
@@ -655,7 +665,7 @@ def main():
             torch.cuda.empty_cache()
             wo = WORKLOADS[name]
             try:
-                o = measure(wo, name, args, comm, rank, world, device, wo["N"], args.other_steps, 2, 1)
+                o = measure(wo, name, args, comm, rank, world, device, wo["N"], args.other_steps, 2, 1, region_events=False)
             except Exception as e:  # noqa: BLE001 -- the headline record must survive a failure of an attached one
                 o = dict(error=f"{type(e).__name__}: {e}") if rank == 0 else None
             if rank == 0:

@@ -30,6 +30,10 @@ GROUPS = [
     (r"void k_bwd_dx<\d+, \d+, 0>", ("bwd_dx",)),
     (r"void k_bwd_dx<\d+, \d+, [1-9]>", ("bwd_dx_dw1",)),
     (r"void k_dw(_tr<|_tr_multi<|<0)", ("dw_hidden", "dw_gru", "dw_input")),
+    (r"void k_dw_tr_multi_v<", ("dw_trunk",)),
+    (r"(void )?k_dw_gru6", ("dw_gru",)),
+    (r"void k_fwd_trunk<", ("fwd_trunk",)),
+    (r"void k_bwd_trunk<", ("bwd_trunk",)),
     (r"void k_dw<1", ("dw_head",)),
     (r"void k_fwd_wide<", ("fwd_wide", "tangent_wide", "tangent_hidden")),  # (the one-launch hidden tangent is a k_fwd_wide)
     (r"(void )?k_x0n_", ("x0n_wide",)),

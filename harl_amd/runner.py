@@ -252,6 +252,24 @@ class OnPolicyHARunner:
         old_all, old_ev = {}, {}
         side_agents = [a for a in agent_order
                        if not (fast[a] and self.actor[a].fuses_old_logp() and counts[a] > 0.0) and os.environ.get("HARL_SIDE_STREAM", "1") != "0"]
+        def enqueue_old_logp(a):
+            """Agent a's pre-update pass on the side stream (+ the event its update waits for)."""
+            act_a, buf_a = self.actor[a], self.actor_buffer[a]
+            with torch.cuda.stream(self._side_stream):
+                act_a.actor.fold()
+                kw_a = dict(rnn_states=buf_a.rnn_states[0], masks=buf_a.flat("masks")) if act_a.actor.recurrent else {}
+                act_a._logp_pass(buf_a.flat("obs"), buf_a.flat("actions"),
+                                 None if buf_a.available_actions is None else buf_a.flat("available_actions"), B, old_all[a], **kw_a)
+                old_ev[a] = torch.cuda.Event()
+                old_ev[a].record(self._side_stream)
+
+        # ... ONE AGENT AHEAD of the main stream (round 6, second session): enqueueing all of them up front is ~0.3 ms of host time
+        # each -- the raw rocprofv3 trace of the 8-agent recurrent update showed the main queue EMPTY for the first 2.6 of its 22.7
+        # ms while the host was still feeding the side stream.  The first agent's pass goes out here, agent k + 1's right behind
+        # the launches of agent k's update (2.5 ms of queued GPU work for a 0.47 ms pass): same kernels, same operands per agent.
+        # HARL_SIDE_AHEAD=0: all up front, as before.
+        side_lazy = os.environ.get("HARL_SIDE_AHEAD", "1") != "0"
+        side_pending = []
         if side_agents:
             if getattr(self, "_side_stream", None) is None:
                 self._side_stream = torch.cuda.Stream(device=dev)
@@ -260,15 +278,10 @@ class OnPolicyHARunner:
             for a in side_agents:
                 act_a, buf_a = self.actor[a], self.actor_buffer[a]
                 old_all[a] = torch.empty(B, act_a.actor.act_w, dtype=torch.float32, device=dev)
-            with torch.cuda.stream(self._side_stream):
-                for a in side_agents:
-                    act_a, buf_a = self.actor[a], self.actor_buffer[a]
-                    act_a.actor.fold()
-                    kw_a = dict(rnn_states=buf_a.rnn_states[0], masks=buf_a.flat("masks")) if act_a.actor.recurrent else {}
-                    act_a._logp_pass(buf_a.flat("obs"), buf_a.flat("actions"),
-                                     None if buf_a.available_actions is None else buf_a.flat("available_actions"), B, old_all[a], **kw_a)
-                    old_ev[a] = torch.cuda.Event()
-                    old_ev[a].record(self._side_stream)
+            side_pending = list(side_agents)
+            for a in (side_pending[:1] if side_lazy else list(side_pending)):
+                enqueue_old_logp(a)
+                side_pending.remove(a)
         pending = []
         # Post-update log-probs of RECURRENT policies (full-length unroll: N/32 dependent chains of T steps, ~0.5 ms on 32 waves
         # of the chip at the SMAC sizes) go to a stream of their own: the next agent's first forward -- sequence tables, input
@@ -305,6 +318,8 @@ class OnPolicyHARunner:
             if factor_ev is not None and hasattr(actor, "_factor_ready"):
                 actor._factor_ready = factor_ev
             info = actor.train(buf, adv_a, self.state_type, **kw)               # :86-93
+            if side_pending:  # the next agent's pre-update pass, behind this agent's queued launches (see enqueue_old_logp)
+                enqueue_old_logp(side_pending.pop(0))
             if rng_after is not None and rng_after["left"] > 0:  # one critic epoch behind this agent's optimiser steps
                 ev_a = torch.cuda.Event()
                 ev_a.record(torch.cuda.current_stream(dev))

@@ -164,8 +164,17 @@ def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_raw_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def stream() -> int:
-    """Raw hipStream_t of torch's current stream (PyTorch-ROCm names the HIP device 'cuda')."""
+    """Raw hipStream_t of torch's current stream (PyTorch-ROCm names the HIP device 'cuda').  Every launch asks for it:
+    ``torch.cuda.current_stream()`` builds a Stream object through three Python layers -- 8 us a call, 3.3 ms of host time per
+    8-agent recurrent update (cProfile, round 6: the host was within 3 ms of the GPU there) -- the raw query behind it is one
+    C call."""
+    if _raw_stream is not None and _raw_device is not None:
+        return _raw_stream(_raw_device())
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -210,20 +219,25 @@ def collect_kernel_timing() -> dict:
     return out
 
 
+_fn_cache: dict = {}
+
+
 def call(name: str, *args, tag: Optional[str] = None) -> None:
-    lib = load()
+    fn = _fn_cache.get(name)
+    if fn is None:  # (one attribute lookup on the CDLL per entry point and process, not per launch)
+        fn = _fn_cache[name] = getattr(load(), name)
     if _timing_on and tag is not None and (_timing_tags is None or tag in _timing_tags):
         # events come from a pool filled outside the timed region (hipEventCreate is not free on the launch path)
         a = _event_pool.pop() if _event_pool else torch.cuda.Event(enable_timing=True)
         b = _event_pool.pop() if _event_pool else torch.cuda.Event(enable_timing=True)
         a.record()
-        rc = getattr(lib, name)(*args)
+        rc = fn(*args)
         b.record()
         _timing_events.setdefault(tag, []).append((a, b, algorithmic_bytes(name, args), algorithmic_flops(name, args)))
     else:
-        rc = getattr(lib, name)(*args)
+        rc = fn(*args)
     if rc != 0:
-        raise RuntimeError(f"{name} failed ({rc}): {lib.harl_last_error().decode()}")
+        raise RuntimeError(f"{name} failed ({rc}): {load().harl_last_error().decode()}")
 
 
 SCRATCH_BYTES = {"mm": 24640, "cg": 1088}  # include/harl_hip.h: HARL_MM_SCRATCH_BYTES, HARL_CG_SCRATCH_BYTES

@@ -93,4 +93,6 @@ class ValueNorm:
 def _as_dev(x, device) -> torch.Tensor:
     if isinstance(x, np.ndarray):
         x = torch.from_numpy(x)
+    elif x.dtype == torch.float32 and x.device == device and x.is_contiguous():
+        return x  # already in place (the device-resident buffers): not worth a dispatcher round trip per argument and update
     return x.to(device=device, dtype=torch.float32).contiguous()

@@ -20,7 +20,18 @@ HEADERS = ["common.h", "split_mfma.h", "mfma_transpose.h", "heads_common.h", "dw
 # (gpurun_out/r3_vgpr_suite.log: 107 passed; A/B on one box 21.53 / 21.69 -> 20.93 / 21.18 ms per MPE update).
 # HARL_HIPCC_EXTRA="mlp.hip:;gru.hip:..." overrides per file for A/B builds.
 VGPR_FORM = ["-mllvm", "-amdgpu-mfma-vgpr-form"]
-DEFAULT_EXTRA: dict = {"mlp.hip": VGPR_FORM, "gru.hip": VGPR_FORM, "panel.hip": VGPR_FORM, "trunk.hip": VGPR_FORM}
+# No packed fp32 VALU (v_pk_add / v_pk_mul / v_pk_fma_f32) in the kernels that interleave their epilogues with MFMAs (round 6,
+# session 3): the LayerNorm / ReLU epilogues and the operand splits were written on register pairs (f32x2, common.h) to halve
+# their instruction count, but beside matrix instructions a packed fp32 op costs MORE than the two scalar ops it replaces
+# (MI355X_MICROARCH.md, "price of one filler beside MFMAs": 2 v_pk_add_f32 per gap +26 cycles against 2 v_fma_f32).  -DHARL_NO_PK
+# turns f32x2 into a pair of scalars (same arithmetic, same bits), -fno-slp-vectorize keeps hipcc from re-packing them.  A/B on
+# one box, three interleaved runs each (profiles/r06s3_packed_valu_ab.md): MPE 16.77 -> 16.36-16.51 ms, HalfCheetah-6x1
+# 50.27 -> 49.43 ms, SMAC 3s5z unchanged (20.5 ms; the GRU chain kernels of gru.hip, which have no MFMA shadow to lose, keep
+# their packed epilogues: unpacked they measured 0.1 - 0.2 ms slower).  One setting for every file whose kernels must agree bit
+# for bit with each other (trunk.hip <-> mlp.hip / wide.hip layer launches: tests/gpu_checks.check_trunk_fused).
+NO_PK = ["-DHARL_NO_PK", "-fno-slp-vectorize"]
+DEFAULT_EXTRA: dict = {"mlp.hip": VGPR_FORM + NO_PK, "gru.hip": VGPR_FORM, "panel.hip": VGPR_FORM + NO_PK, "trunk.hip": VGPR_FORM + NO_PK,
+                       "update.hip": NO_PK, "heads.hip": NO_PK, "wide.hip": NO_PK, "multihead.hip": NO_PK}
 
 
 def _extra_flags() -> dict:

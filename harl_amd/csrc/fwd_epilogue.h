@@ -30,7 +30,7 @@ __device__ __forceinline__ void relu_norm_regs(f32x16 (&acc)[HO / 32], float (&v
 #pragma unroll
   for (int P = 0; P < NR / 2; ++P) {
     const f32x2 d = f32x2{v[2 * P], v[2 * P + 1]} - mv;
-    vsv = __builtin_elementwise_fma(d, d, vsv);
+    vsv = fma2(d, d, vsv);
     v[2 * P] = d[0];
     v[2 * P + 1] = d[1];
   }

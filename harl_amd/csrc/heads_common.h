@@ -264,7 +264,7 @@ __device__ __forceinline__ void head_bwd_regs_bits(const f32x4 (&xs)[H / 8], uin
       for (int P = 0; P < 2; ++P) {
         const int e = 4 * q + 2 * P;
         const f32x2 d = {acc[e >> 4][e & 15], acc[(e + 1) >> 4][(e + 1) & 15]}, x = {xs[q][2 * P], xs[q][2 * P + 1]};
-        const f32x2 da = __builtin_elementwise_fma(x, c2v, __builtin_elementwise_fma(d, rv, c1v));
+        const f32x2 da = fma2(x, c2v, fma2(d, rv, c1v));
         o[2 * P] = mask_pop(da[0], b0);
         o[2 * P + 1] = mask_pop(da[1], b0);
       }

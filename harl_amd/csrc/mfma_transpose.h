@@ -79,7 +79,7 @@ __device__ __forceinline__ float transpose_block(const u32x4 &x1a, const u32x4 &
 }
 
 // 16 accumulator-layout registers (one 32-feature block) -> split + transposed
-template <bool SUM, bool PACKED = true>
+template <bool SUM, bool PACKED = PK_DEFAULT>
 __device__ __forceinline__ float split_transpose_block(const float *v16, const Ident &I, u32x4 (&T)[3][2]) {
   u32x4 y1[2], y2[2], y3[2];
 #pragma unroll

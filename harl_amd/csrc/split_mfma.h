@@ -30,7 +30,7 @@ __device__ __forceinline__ f32x16 mfma_bf16(const u32x4 &a, const u32x4 &b, cons
 
 // exact split of two floats into three packed bf16 pairs (low half = first value).  Truncation at every level: the three
 // pieces are the three bytes-and-a-bit of the significand, all of the sign of x (3 VALU ops per value, 1.5 per pack).
-template <bool PACKED = true>
+template <bool PACKED = PK_DEFAULT>
 __device__ __forceinline__ void split3(float f0, float f1, unsigned &p1, unsigned &p2, unsigned &p3) {
   // v_perm takes the high halves directly (no masking needed for the packed terms)
   const unsigned b0 = __float_as_uint(f0), b1 = __float_as_uint(f1);
@@ -68,7 +68,7 @@ __device__ __forceinline__ void split3_rne(float f0, float f1, unsigned &p1, uns
 }
 
 // activations: NR = H/2 accumulator-layout registers of one lane -> NR/8 k-step operands per term
-template <int NR, bool PACKED = true>
+template <int NR, bool PACKED = PK_DEFAULT>
 __device__ __forceinline__ void split_acts(const float (&v)[NR], u32x4 (&x1)[NR / 8], u32x4 (&x2)[NR / 8], u32x4 (&x3)[NR / 8]) {
 #pragma unroll
   for (int j = 0; j < NR / 8; ++j)

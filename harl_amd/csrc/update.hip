@@ -66,7 +66,7 @@ __device__ __forceinline__ void relu_ln(const f32x16 (&acc)[H / 32], float (&v)[
 #pragma unroll
   for (int P = 0; P < NR / 2; ++P) {
     const f32x2 d = f32x2{v[2 * P], v[2 * P + 1]} - mv;
-    vsv = __builtin_elementwise_fma(d, d, vsv);
+    vsv = fma2(d, d, vsv);
     v[2 * P] = d[0];
     v[2 * P + 1] = d[1];
   }
@@ -107,7 +107,7 @@ __device__ __forceinline__ void ln_bwd_relu_bits(const float (&dx)[H / 2], const
 #pragma unroll
   for (int P = 0; P < NR / 2; ++P) {
     const f32x2 d = {dx[2 * P], dx[2 * P + 1]}, x = {xh[2 * P], xh[2 * P + 1]};
-    const f32x2 da = __builtin_elementwise_fma(x, c2v, __builtin_elementwise_fma(d, rv, c1v));
+    const f32x2 da = fma2(x, c2v, fma2(d, rv, c1v));
     out[2 * P] = mask_pop(da[0], bits[(2 * P) >> 5]);
     out[2 * P + 1] = mask_pop(da[1], bits[(2 * P + 1) >> 5]);
   }

@@ -1118,10 +1118,21 @@ constexpr int ADAM_WGS = 64, ADAM_THREADS = 256, ADAM_SROWS = 64;
 __device__ __forceinline__ void grid_barrier(unsigned *bar, unsigned target) {
   __syncthreads();
   if (threadIdx.x == 0) {
+#ifdef HARL_BARRIER_V1  // A/B: two full fences, release RMW, acquire polling (rounds 3 - 6: ~10 us of fences per barrier)
     __threadfence();  // release: this workgroup's global writes precede the arrival
     __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     while (__hip_atomic_load(bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(2);
     __threadfence();  // acquire: invalidates this CU's vector L1 for the whole workgroup
+#else
+    // MI355X_MICROARCH.md, "Valid forms": ONE agent release (write back the XCD L2's dirty lines, ~1.7 us) -> explicit
+    // s_waitcnt (ROCm 7.2 may drop the one behind buffer_wbl2) -> relaxed arrival; relaxed polls (an acquire load costs a
+    // buffer_inv per iteration) -> ONE agent acquire (invalidates this CU's vector L1 for the whole workgroup)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
   }
   __syncthreads();
 }
@@ -1346,8 +1357,16 @@ __global__ __launch_bounds__(ADAM_THREADS) void k_adam_fold(
   __syncthreads();
   __shared__ unsigned last_flag;
   if (tid == 0) {
+#ifdef HARL_BARRIER_V1
     __threadfence();
     const unsigned done = __hip_atomic_fetch_add(ws + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    // a write-after-read hand-off: the last workgroup overwrites LayerNorm parameters the others have READ (their loads are
+    // complete: the values went into the stores above) and needs nothing they wrote after the grid barrier -- a relaxed
+    // ticket is enough (the full fence + acq_rel RMW were ~5 us at the tail of every optimiser step)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned done = __hip_atomic_fetch_add(ws + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
     last_flag = done == (unsigned)G - 1 ? 1u : 0u;
   }
   __syncthreads();

@@ -26,6 +26,9 @@ ALGO_REGISTRY = {"happo": HAPPO, "hatrpo": HATRPO, "haa2c": HAA2C, "mappo": MAPP
 
 
 class OnPolicyHARunner:
+    # feed-forward, one-minibatch updates: the critic's chain gets a stream of its own up to this many rows per minibatch (train())
+    CRITIC_STREAM_MAX_ROWS = 150_000
+
     def __init__(self, args: dict, algo_args: dict, env_args: Optional[dict] = None, *, obs_spaces=None,
                  share_obs_space=None, act_spaces=None, device: Optional[torch.device] = None,
                  comm: Optional[Comm] = None, envs=None, logger=None, eval_envs=None, save_dir: Optional[str] = None):
@@ -183,8 +186,15 @@ class OnPolicyHARunner:
             # kernel fills it.  HARL_CRITIC_STREAM=0 keeps one stream.
             # Under data parallelism the second stream needs the critic's own communicator (two chains issuing into ONE
             # communicator would have to interleave their collectives identically on every rank).
+            # Round 6, session 3: ... and only where the launches are short.  From ~150 000 rows per minibatch every heavy kernel
+            # of either chain fills the chip for 0.2 - 0.5 ms (one workgroup per CU, LDS-bound occupancy): the other chain's light
+            # kernels then wait for a whole heavy launch to drain, the sum of the kernel times is the update either way, and
+            # one stream measured as fast or faster (16.06 against 16.18 ms at 4096 threads, 8.90 / 9.00 at 2048, 5.45 / 5.58 at
+            # 1024 -- and 3.90 against 3.73 at 512 threads, where the second stream stays; profiles/r06s3_critic_stream_ab.md).
+            # HARL_CRITIC_STREAM=1 forces the second stream, 0 forbids it.
+            cs_mode = os.environ.get("HARL_CRITIC_STREAM", "auto")
             if (dev.type == "cuda" and (not self.comm.enabled or self.critic.comm is not self.comm)
-                    and os.environ.get("HARL_CRITIC_STREAM", "1") != "0"):
+                    and cs_mode != "0" and (cs_mode == "1" or B <= self.CRITIC_STREAM_MAX_ROWS)):
                 if getattr(self, "_critic_stream", None) is None:
                     self._critic_stream = torch.cuda.Stream(device=dev)
                 main_s = torch.cuda.current_stream(dev)

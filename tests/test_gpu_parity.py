@@ -409,6 +409,15 @@ def test_fused_update_kernels_train_golden(name, mode, monkeypatch):
     _assert_all(_G().check_train_golden(name), tol=TOL)
 
 
+@pytest.mark.parametrize("mode", ["0", "1", "auto"])
+@pytest.mark.parametrize("name", ["mpe_box_h128", "cheetah_h128x3_mb2"])
+def test_critic_stream_modes_train_golden(name, mode, monkeypatch):
+    """Whole train() vs the reference's golden vectors with the critic's chain on the main stream (0), on a stream of its own (1)
+    and under the size rule of round 6 (auto: own stream up to OnPolicyHARunner.CRITIC_STREAM_MAX_ROWS rows per minibatch)."""
+    monkeypatch.setenv("HARL_CRITIC_STREAM", mode)
+    _assert_all(_G().check_train_golden(name), tol=TOL)
+
+
 @pytest.mark.parametrize("env", ["HARL_BWD_FUSED", "HARL_BWD_STREAMS"])
 @pytest.mark.parametrize("name", ["mpe_box_h128", "cheetah_h128x3_mb2", "disc50_h128", "fp_disc_h128_mb2"])
 def test_backward_variants_train_golden(name, env, monkeypatch):

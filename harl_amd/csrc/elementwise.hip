@@ -94,7 +94,7 @@ __device__ __forceinline__ float denorm(const DenormStats &s, float v) {
 // contraction off); what is parallel is the MEMORY side: the inputs of GAE_TC time steps are fetched into registers before
 // the dependent arithmetic of those steps starts (4 * GAE_TC independent coalesced loads in flight per lane instead of one
 // load latency per step: the loop was latency-bound at ~550 ns / step).
-constexpr int GAE_TC = 8;
+constexpr int GAE_TC = 20;  // (8 until round 6 session 3; 2 x 20 steps of inputs in flight per lane: 160 registers)
 template <bool GAE, bool PTL, bool FP_ORDER>
 __global__ __launch_bounds__(64) void k_gae(const float *__restrict__ rewards, float *__restrict__ value_preds,
                                             const float *__restrict__ masks, const float *__restrict__ bad_masks,
@@ -111,8 +111,9 @@ __global__ __launch_bounds__(64) void k_gae(const float *__restrict__ rewards, f
   float dv1 = denorm(ds, nv);  // value_preds[t+1], denormalised
   if (GAE) value_preds[(long)T * N + c] = nv;  // critic_buffer_ep.py:107
   else returns[(long)T * N + c] = nv;
-  for (int t0 = T - 1; t0 >= 0; t0 -= GAE_TC) {
-    float r[GAE_TC], v0[GAE_TC], m1[GAE_TC], b1[GAE_TC];
+  // the inputs of chunk k + 1 are requested BEFORE the dependent arithmetic of chunk k (two register sets, round 6 session 3):
+  // one memory round trip per chunk used to be exposed (25 of them per 200-step scan, ~1.5 us each)
+  auto load = [&](int t0, float (&r)[GAE_TC], float (&v0)[GAE_TC], float (&m1)[GAE_TC], float (&b1)[GAE_TC]) {
 #pragma unroll
     for (int k = 0; k < GAE_TC; ++k) {
       const int t = t0 - k;
@@ -123,6 +124,9 @@ __global__ __launch_bounds__(64) void k_gae(const float *__restrict__ rewards, f
       m1[k] = masks[o + N];
       b1[k] = PTL ? bad_masks[o + N] : 1.f;
     }
+  };
+  auto scan = [&](int t0, const float (&r)[GAE_TC], const float (&v0)[GAE_TC], const float (&m1)[GAE_TC], const float (&b1)[GAE_TC]) {
+#pragma clang fp contract(off)
 #pragma unroll
     for (int k = 0; k < GAE_TC; ++k) {
       const int t = t0 - k;
@@ -145,6 +149,18 @@ __global__ __launch_bounds__(64) void k_gae(const float *__restrict__ rewards, f
       returns[(long)t * N + c] = ret;
       if (adv) adv[(long)t * N + c] = ret - dv0;
     }
+  };
+  float rA[GAE_TC], vA[GAE_TC], mA[GAE_TC], bA[GAE_TC], rB[GAE_TC], vB[GAE_TC], mB[GAE_TC], bB[GAE_TC];
+  int t0 = T - 1;
+  load(t0, rA, vA, mA, bA);
+  while (t0 >= 0) {
+    if (t0 - GAE_TC >= 0) load(t0 - GAE_TC, rB, vB, mB, bB);
+    scan(t0, rA, vA, mA, bA);
+    t0 -= GAE_TC;
+    if (t0 < 0) break;
+    if (t0 - GAE_TC >= 0) load(t0 - GAE_TC, rA, vA, mA, bA);
+    scan(t0, rB, vB, mB, bB);
+    t0 -= GAE_TC;
   }
 }
 

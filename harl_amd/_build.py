@@ -31,7 +31,12 @@ VGPR_FORM = ["-mllvm", "-amdgpu-mfma-vgpr-form"]
 # for bit with each other (trunk.hip <-> mlp.hip / wide.hip layer launches: tests/gpu_checks.check_trunk_fused).
 NO_PK = ["-DHARL_NO_PK", "-fno-slp-vectorize"]
 DEFAULT_EXTRA: dict = {"mlp.hip": VGPR_FORM + NO_PK, "gru.hip": VGPR_FORM, "panel.hip": VGPR_FORM + NO_PK, "trunk.hip": VGPR_FORM + NO_PK,
-                       "update.hip": NO_PK, "heads.hip": NO_PK, "wide.hip": NO_PK, "multihead.hip": NO_PK}
+                       "update.hip": NO_PK, "heads.hip": NO_PK, "wide.hip": NO_PK, "multihead.hip": NO_PK,
+                       # ... and the element-wise kernels (the composed GRU cell of gru_cell.hip, the activation / LayerNorm launches and
+                       # the optimiser kernels of elementwise.hip): hatrpo_gru128 256 -> 230 ms, SMAC 3s5z 20.02 -> 19.83 ms
+                       # (three interleaved runs each, profiles/r06s3_packed_valu_ab.md); gru.hip alone measured neutral and
+                       # keeps its packed epilogues
+                       "gru_cell.hip": NO_PK, "elementwise.hip": NO_PK}
 
 
 def _extra_flags() -> dict:

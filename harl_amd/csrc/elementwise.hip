@@ -1070,6 +1070,9 @@ extern "C" int harl_fold_tangent_table(const float *param, const float *vec, flo
 // A block owns 64 consecutive elements; its four waves each sum a quarter of the partial rows (w = 4 k + wave) with
 // 8 independent accumulators, and the four sums are combined in fixed order through LDS: the kernel is a chain of
 // dependent-latency-bound strided loads, so it is n_wg / 32 loads deep instead of n_wg / 8 (37 -> ~15 us at 512 rows).
+#ifndef HARL_REDUCE_DEPTH
+#define HARL_REDUCE_DEPTH 16
+#endif
 __global__ __launch_bounds__(256) void k_reduce_partials_multi(const float *__restrict__ part, const int *__restrict__ tab,
                                                                int n_layers, int n_wg, float *__restrict__ dwp) {
   // The per-workgroup partials are summed in DOUBLE (fixed order): the LayerNorm-affine gradients are later formed as
@@ -1085,14 +1088,26 @@ __global__ __launch_bounds__(256) void k_reduce_partials_multi(const float *__re
     const long elems = (long)t[10] * t[9] + t[10];
     if (e < elems) {
       const float *p = part + (long)t[11] + e;  // part_off is in floats
-      double acc[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-      int w = rg;
-      for (; w + 28 < n_wg; w += 32) {
+      // RD independent loads per lane in flight (8 until round 6 session 3: ~3 MB in flight over the chip, 2 TB/s at the ~2 us
+      // these strided reads take; HARL_REDUCE_DEPTH A/B: profiles/r06s3_reduce_depth_ab.txt)
+      constexpr int RD = HARL_REDUCE_DEPTH;
+      double acc[RD];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) acc[u] += (double)p[(long)(w + 4 * u) * elems];
+      for (int u = 0; u < RD; ++u) acc[u] = 0.0;
+      int w = rg;
+      for (; w + 4 * (RD - 1) < n_wg; w += 4 * RD) {
+        float v[RD];
+#pragma unroll
+        for (int u = 0; u < RD; ++u) v[u] = p[(long)(w + 4 * u) * elems];
+#pragma unroll
+        for (int u = 0; u < RD; ++u) acc[u] += (double)v[u];
       }
       for (; w < n_wg; w += 4) acc[0] += (double)p[(long)w * elems];
-      total = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+#pragma unroll
+      for (int st = 1; st < RD; st *= 2)
+#pragma unroll
+        for (int u = 0; u + st < RD; u += 2 * st) acc[u] += acc[u + st];
+      total = acc[0];
       out_idx = t[8] + e;
       break;
     }

@@ -1144,7 +1144,11 @@ extern "C" int harl_reduce_partials_multi(const float *part, const int *table, i
 // makes the spin barrier safe; other kernels on the chip only delay their arrival.
 // ws: [0] arrivals, [1] finished, then doubles from byte 32: [w] per-workgroup sum of squares, [G + r*48 + j] scalar row sums
 // ---------------------------------------------------------------------------------------------
-constexpr int ADAM_WGS = 64, ADAM_THREADS = 256, ADAM_SROWS = 64;
+#ifndef HARL_ADAM_WGS
+#define HARL_ADAM_WGS 64
+#endif
+constexpr int ADAM_WGS = HARL_ADAM_WGS, ADAM_THREADS = 256, ADAM_SROWS = ADAM_WGS < 64 ? ADAM_WGS : 64;  // (HARL_ADAM_WGS: A/B builds, tools/gpurun_calls_r06_s3n.sh)
+static_assert(ADAM_WGS >= ADAM_SROWS && ADAM_WGS % 4 == 0 && 64 + ADAM_WGS * 8 + ADAM_SROWS * PS_STRIDE * 8 <= 32768, "workspace layout");
 
 __device__ __forceinline__ void grid_barrier(unsigned *bar, unsigned target) {
   __syncthreads();

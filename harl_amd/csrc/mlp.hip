@@ -1373,6 +1373,10 @@ constexpr int BDW_SQ = (128 / 16) * 128 + 8, BDW_IMG = 8 * BDW_SQ;  // k_dw_tr's
 constexpr int BDW_BUF = 3 * BDW_IMG;                                // one transposition buffer: three term images
 constexpr size_t bdw_lds_bytes() { return split_image_bytes(128, 128) + (size_t)2 * BDW_BUF; }
 
+#ifndef HARL_BWD_OSPLIT_IN_GEMM
+#define HARL_BWD_OSPLIT_IN_GEMM 1
+#endif
+constexpr bool OSPLIT_IN_GEMM = HARL_BWD_OSPLIT_IN_GEMM != 0;  // (0: the owner's split in the weight-gradient rounds, rounds 5 - 6; A/B builds)
 template <int KT, bool FILL>
 __global__ __launch_bounds__(WG_THREADS, 1) void k_bwd_dx_dw(
     const float *__restrict__ dz, const float *__restrict__ xprev, const uint32_t *__restrict__ mask_prev,
@@ -1502,7 +1506,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_bwd_dx_dw(
   {
     const long s0 = base0 + wave;
     atl_load<H>(dz, s0 < n_slabs ? s0 : 0, lane, raw);
-    split_acts<NR, false>(raw, g1, g2, g3);
+    if constexpr (!OSPLIT_IN_GEMM) split_acts<NR, false>(raw, g1, g2, g3);
   }
   // O chunk k (0..63) of the NEXT slab's split: pair k>>1 (registers 2p, 2p+1 -> word p&3 of k-step p>>2), stage k&1
   // (two streams of them run side by side in a round: each keeps its own remainders between the stages of a pair)
@@ -1521,6 +1525,10 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_bwd_dx_dw(
       g3[j][c] = p3;
     }
   };
+  if constexpr (OSPLIT_IN_GEMM) {  // k-step 0 of the first slab (later slabs: the last weight-gradient round's slots 32..39)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o_chunk(k, false);
+  }
   // ---- the first round of the first super-round is prepared in the open
   if (base0 < n_slabs) {
     d_load(base0);
@@ -1565,7 +1573,17 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_bwd_dx_dw(
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
       PHASE(0);
-      split_gemm<MT, NJ>(wl, g1, g2, g3, acc, [](int) {});
+      if constexpr (OSPLIT_IN_GEMM) {
+        // the split of k-step j + 1 of THIS slab's dz (raw) behind the 24 product MFMAs of k-step j: one chunk (one stage of
+        // a pair: ~5.5 VALU) behind every third MFMA -- the 192 shadows of this GEMM were empty while the weight-gradient rounds carried
+        // 6.7 VALU per MFMA (profiles/r05_bwd_fused_ab.md), 64 of their 216 chunks being exactly these
+        split_gemm_fill<MT, NJ>(wl, g1, g2, g3, acc, [&](int s_, int k6) {
+          const int j1 = s_ / MT + 1, q = (s_ % MT) * 6 + k6;  // q = 0..23: the MFMA's position inside k-step j
+          if (j1 < NJ && q % 3 == 0) o_chunk(8 * j1 + q / 3, false);
+        });
+      } else {
+        split_gemm<MT, NJ>(wl, g1, g2, g3, acc, [](int) {});
+      }
       PHASE(1);
       float dx[NR];
 #pragma unroll
@@ -1629,9 +1647,11 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_bwd_dx_dw(
             if constexpr (s_ < 16) a_chunk(s_);
             else if constexpr (s_ < 26) b_chunk(s_ - 16 + 6);
             else if constexpr (s_ < 32) p_chunk(s_ - 26);
-            else {
+            else if constexpr (!OSPLIT_IN_GEMM) {
               o_chunk(O_FIRST + s_ - 32, false);
               if constexpr (s_ - 32 < O_EXTRA) o_chunk(O_FIRST + 16 + s_ - 32, true);
+            } else if constexpr (r == 3 && s_ < 40) {
+              o_chunk(s_ - 32, false);  // k-step 0 of the owner's next slab; the other seven ride inside its dX GEMM
             }
             if constexpr (s_ == 25 && r < 3) d_load_next(ds2, base);
           }

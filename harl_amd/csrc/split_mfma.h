@@ -152,4 +152,44 @@ __device__ __forceinline__ void split_gemm(const u32x4 *__restrict__ wl, const u
   }
 }
 
+// split_gemm with a filler hook behind EVERY product MFMA (fill(s, k6), s = step, k6 = 0..5): independent VALU work of the
+// caller issued in the matrix instructions' shadows (<= 5 plain VALU per MFMA hide for free: profiles/r03_mfma_valu_overlap.md).
+// Same fragments, same six products in the same order as split_gemm: bit-identical accumulators.
+template <int MT, int NJ, typename FILLF>
+__device__ __forceinline__ void split_gemm_fill(const u32x4 *__restrict__ wl, const u32x4 (&x1)[NJ], const u32x4 (&x2)[NJ],
+                                                const u32x4 (&x3)[NJ], f32x16 (&acc)[MT], FILLF &&fill) {
+  constexpr int TS = MT * NJ * 64;
+  u32x4 wb[2][3];
+#pragma unroll
+  for (int term = 0; term < 3; ++term) wb[0][term] = wl[term * TS];
+#pragma unroll
+  for (int s = 0; s < MT * NJ; ++s) {
+    const int j = s / MT, t = s % MT, cur = s & 1, nxt = cur ^ 1;
+    if (s + 1 < MT * NJ) {
+      const int j1 = (s + 1) / MT, t1 = (s + 1) % MT;
+#pragma unroll
+      for (int term = 0; term < 3; ++term) wb[nxt][term] = wl[term * TS + (t1 * NJ + j1) * 64];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    acc[t] = mfma_bf16(wb[cur][2], x1[j], acc[t]);
+    fill(s, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    acc[t] = mfma_bf16(wb[cur][0], x3[j], acc[t]);
+    fill(s, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    acc[t] = mfma_bf16(wb[cur][1], x2[j], acc[t]);
+    fill(s, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    acc[t] = mfma_bf16(wb[cur][1], x1[j], acc[t]);
+    fill(s, 3);
+    __builtin_amdgcn_sched_barrier(0);
+    acc[t] = mfma_bf16(wb[cur][0], x2[j], acc[t]);
+    fill(s, 4);
+    __builtin_amdgcn_sched_barrier(0);
+    acc[t] = mfma_bf16(wb[cur][0], x1[j], acc[t]);
+    fill(s, 5);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 }  // namespace harl
